@@ -1,0 +1,256 @@
+"""ctypes binding of libaadg_hip.so (include/aadg_hip.h) for torch device tensors.
+
+torch is used only as plumbing here: device memory, the current HIP stream, and dtype/shape checks.
+There is deliberately NO CPU fallback: every wrapper raises if the shared library or a GPU is
+missing, so a silent eager path can never stand in for the HIP kernels.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libaadg_hip.so")
+MAX_OPS = 4
+
+# mirror of `aadg_unit` (include/aadg_hip.h); 140 bytes, no padding
+UNIT_DTYPE = np.dtype([
+    ("src", "<i4"), ("n_ops", "<i4"),
+    ("op", "<i4", (MAX_OPS,)), ("iarg", "<i4", (MAX_OPS,)), ("farg", "<f4", (MAX_OPS,)),
+    ("rect", "<i4", (MAX_OPS, 4)),
+    ("scaled_w", "<i4"), ("scaled_h", "<i4"), ("pad", "<i4"), ("crop_x", "<i4"), ("crop_y", "<i4"),
+], align=False)
+assert UNIT_DTYPE.itemsize == 140
+
+DATASET_OPTIC, DATASET_VESSEL = 0, 1
+
+# every symbol include/aadg_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "aadg_abi_version",
+    "aadg_aug_u8_workspace_bytes", "aadg_aug_u8_forward", "aadg_op_u8",
+    "aadg_sinkhorn_workspace_bytes", "aadg_sinkhorn_divergence_f32", "aadg_sinkhorn_rewards_f32",
+    "aadg_normalize_rewards_f32",
+    "aadg_seg_loss_workspace_bytes", "aadg_seg_bce_dice_f32",
+    "aadg_fop_workspace_bytes", "aadg_fop_f32",
+]
+
+_lib = None
+_c = ctypes
+_vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
+
+
+def load():
+    """Load libaadg_hip.so; raises RuntimeError (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libaadg_hip.so is missing (%s). Build it with `python -m aadg_amd.build` or "
+            "`__graft_entry__.build()`; aadg_amd has no CPU fallback." % LIB_PATH)
+    lib = _c.CDLL(LIB_PATH)
+    lib.aadg_abi_version.restype = _i
+    lib.aadg_aug_u8_workspace_bytes.restype = _sz
+    lib.aadg_aug_u8_workspace_bytes.argtypes = [_i, _i, _i, _i]
+    lib.aadg_aug_u8_forward.restype = _i
+    lib.aadg_aug_u8_forward.argtypes = [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]
+    lib.aadg_op_u8.restype = _i
+    lib.aadg_op_u8.argtypes = [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp]
+    lib.aadg_sinkhorn_workspace_bytes.restype = _sz
+    lib.aadg_sinkhorn_workspace_bytes.argtypes = [_i, _i]
+    lib.aadg_sinkhorn_divergence_f32.restype = _i
+    lib.aadg_sinkhorn_divergence_f32.argtypes = [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _sz, _vp]
+    lib.aadg_sinkhorn_rewards_f32.restype = _i
+    lib.aadg_sinkhorn_rewards_f32.argtypes = [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _sz, _vp]
+    lib.aadg_normalize_rewards_f32.restype = _i
+    lib.aadg_normalize_rewards_f32.argtypes = [_vp, _i, _vp, _vp]
+    if hasattr(lib, "aadg_seg_bce_dice_f32"):
+        lib.aadg_seg_loss_workspace_bytes.restype = _sz
+        lib.aadg_seg_loss_workspace_bytes.argtypes = [_i, _i]
+        lib.aadg_seg_bce_dice_f32.restype = _i
+        lib.aadg_seg_bce_dice_f32.argtypes = [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]
+    if hasattr(lib, "aadg_fop_f32"):
+        lib.aadg_fop_workspace_bytes.restype = _sz
+        lib.aadg_fop_workspace_bytes.argtypes = [_i, _i]
+        lib.aadg_fop_f32.restype = _i
+        lib.aadg_fop_f32.argtypes = [_i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]
+    if lib.aadg_abi_version() != 1:
+        raise RuntimeError("libaadg_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class AadgError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc == 0:
+        return
+    if rc == -1:
+        raise AadgError("%s: bad argument" % what)
+    if rc == -2:
+        raise AadgError("%s: workspace too small" % what)
+    if rc == -3:
+        raise AadgError("%s: unsupported size for this kernel" % what)
+    raise AadgError("%s: HIP error %d" % (what, rc))
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise AadgError("aadg_amd kernels need GPU tensors (got %s); there is no CPU path" % t.device)
+        if not t.is_contiguous():
+            raise AadgError("aadg_amd kernels need contiguous tensors")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """Caller-owned scratch (the library itself never allocates). Cached per (device, tag)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+def units_to_device(units, device):
+    """numpy UNIT_DTYPE[N] -> uint8 device tensor [N,140]."""
+    units = np.ascontiguousarray(units, dtype=UNIT_DTYPE)
+    host = torch.from_numpy(units.view(np.uint8).reshape(units.shape[0], UNIT_DTYPE.itemsize))
+    return host.to(device, non_blocking=False)
+
+
+def validate_units(units, P, Hs, Ws):
+    """Host-side argument checks the kernels rely on (raises like the reference's asserts would)."""
+    units = np.asarray(units)
+    if units.dtype != UNIT_DTYPE:
+        raise AadgError("units must have UNIT_DTYPE")
+    if units.shape[0] == 0:
+        raise AadgError("empty unit list")
+    if (units["src"] < 0).any() or (units["src"] >= P).any():
+        raise AadgError("unit.src out of range")
+    if (units["n_ops"] < 0).any() or (units["n_ops"] > MAX_OPS).any():
+        raise AadgError("unit.n_ops out of range (CONTROLLER.L <= %d)" % MAX_OPS)
+    if (units["scaled_w"] * 3 < Ws).any() or (units["scaled_h"] * 3 < Hs).any() or \
+            (units["scaled_w"] < 1).any() or (units["scaled_h"] < 1).any():
+        raise AadgError("scale factor below 1/3 is not supported by the 8-tap resampler")
+    for k in range(MAX_OPS):
+        live = units["n_ops"] > k
+        ops = units["op"][:, k][live]
+        if ((ops < 0) | (ops > 9)).any():
+            raise AadgError("unknown op id")
+        r = units["rect"][:, k][live & (units["op"][:, k] == 9)]
+        if r.size and ((r[:, 0] < 0).any() or (r[:, 1] < 0).any() or (r[:, 2] >= Ws).any() or (r[:, 3] >= Hs).any()):
+            raise AadgError("cutout rectangle must be clipped to the image")
+        b = units["iarg"][:, k][live & (units["op"][:, k] == 4)]
+        if b.size and ((b < 0).any() or (b > 8).any()):
+            raise AadgError("posterize bits out of range")
+    return int(units["n_ops"].max())
+
+
+def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None):
+    """pool u8 [P,Hs,Ws,3], masks u8 [P,Hs,Ws] (device), units numpy UNIT_DTYPE[N].
+    Returns (aug_images f32 [N,3,crop,crop], aug_labels f32 [N,K,crop,crop]) on the device."""
+    lib = load()
+    _require_cuda(pool, masks)
+    if pool.dtype != torch.uint8 or masks.dtype != torch.uint8 or pool.dim() != 4 or pool.shape[3] != 3:
+        raise AadgError("pool must be uint8 [P,H,W,3] and masks uint8 [P,H,W]")
+    P, Hs, Ws, _ = pool.shape
+    if tuple(masks.shape) != (P, Hs, Ws):
+        raise AadgError("masks shape must match pool")
+    max_ops = validate_units(units, P, Hs, Ws)
+    N = units.shape[0]
+    K = 2 if dataset == DATASET_OPTIC else 1
+    dev = pool.device
+    if out_img is None:
+        out_img = torch.empty((N, 3, crop, crop), dtype=torch.float32, device=dev)
+    if out_lbl is None:
+        out_lbl = torch.empty((N, K, crop, crop), dtype=torch.float32, device=dev)
+    _require_cuda(out_img, out_lbl)
+    d_units = units_to_device(units, dev)
+    nb = lib.aadg_aug_u8_workspace_bytes(N, Hs, Ws, crop)
+    ws = workspace(nb, dev, "aug")
+    rc = lib.aadg_aug_u8_forward(pool.data_ptr(), masks.data_ptr(), P, Hs, Ws, d_units.data_ptr(), N, max_ops, crop,
+                                 dataset, out_img.data_ptr(), out_lbl.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "aadg_aug_u8_forward")
+    # d_units must stay alive until the stream has consumed it
+    d_units.record_stream(torch.cuda.current_stream())
+    return out_img, out_lbl
+
+
+def op_u8(img, op, iarg=0, farg=0.0, rect=None):
+    """One registry op on a uint8 HWC device image."""
+    lib = load()
+    _require_cuda(img)
+    if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
+        raise AadgError("img must be uint8 [H,W,3]")
+    H, W, _ = img.shape
+    out = torch.empty_like(img)
+    r = (ctypes.c_int32 * 4)(*(rect if rect is not None else (0, 0, -1, -1)))
+    nb = lib.aadg_aug_u8_workspace_bytes(1, H, W, 0)
+    ws = workspace(nb, img.device, "op")
+    rc = lib.aadg_op_u8(img.data_ptr(), out.data_ptr(), H, W, int(op), int(iarg), float(farg),
+                        ctypes.cast(r, _vp), ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "aadg_op_u8")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def sinkhorn_rewards(fe, D, B, M, blur=0.05, scaling=0.5, rewards=None):
+    """fe f32 [D*B*M, E] in collate order (row (b*D+d)*M + j). rewards[j] += sum_pairs S(x_d1, x_d2)."""
+    lib = load()
+    _require_cuda(fe, rewards)
+    if fe.dtype != torch.float32 or fe.dim() != 2 or fe.shape[0] != D * B * M:
+        raise AadgError("fe must be float32 [D*B*M, E]")
+    if rewards is None:
+        rewards = torch.zeros(M, dtype=torch.float32, device=fe.device)
+    P = D * (D - 1) // 2
+    nb = lib.aadg_sinkhorn_workspace_bytes(M * P, B)
+    ws = workspace(nb, fe.device, "sinkhorn")
+    rc = lib.aadg_sinkhorn_rewards_f32(fe.data_ptr(), D, B, M, fe.shape[1], blur, scaling, rewards.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "aadg_sinkhorn_rewards_f32")
+    return rewards
+
+
+def sinkhorn_divergence(feat, cloud_rows, cloud_off, prob_xy, max_cloud, blur=0.05, scaling=0.5):
+    """General form: index tables (int32 device tensors) into feat f32 [rows, E]; returns f32 [n_prob]."""
+    lib = load()
+    _require_cuda(feat, cloud_rows, cloud_off, prob_xy)
+    if feat.dtype != torch.float32 or feat.dim() != 2:
+        raise AadgError("feat must be float32 [rows, E]")
+    for t in (cloud_rows, cloud_off, prob_xy):
+        if t.dtype != torch.int32:
+            raise AadgError("index tables must be int32")
+    n_prob = prob_xy.numel() // 2
+    out = torch.empty(n_prob, dtype=torch.float32, device=feat.device)
+    rc = lib.aadg_sinkhorn_divergence_f32(feat.data_ptr(), feat.stride(0), feat.shape[1], cloud_rows.data_ptr(),
+                                          cloud_off.data_ptr(), prob_xy.data_ptr(), n_prob, int(max_cloud), blur,
+                                          scaling, out.data_ptr(), 0, 0, _stream())
+    _check(rc, "aadg_sinkhorn_divergence_f32")
+    return out
+
+
+def normalize_rewards(rewards):
+    lib = load()
+    _require_cuda(rewards)
+    out = torch.empty_like(rewards)
+    rc = lib.aadg_normalize_rewards_f32(rewards.data_ptr(), rewards.numel(), out.data_ptr(), _stream())
+    _check(rc, "aadg_normalize_rewards_f32")
+    return out

@@ -1,0 +1,306 @@
+"""Scale / crop / normalise / tensorise / collate -- host side; API mirror of data/transform.py.
+
+Reference classes kept by name and constructor signature: RandomCrop (data/transform.py:27-55),
+DGRandomCrop (:58-69), DGRandomScaleCrop (:97-135), Normalize_dg (:138-186), ToTensor (:208-236),
+Identity (:239-241), to_multilabel/ToMultiLabel/SoftLable (:244-274), get_dg_segtransform
+(:281-309), train_dg_collate_fn / test_dg_collate_fn (:323-362).
+
+In this implementation the transforms operate on `ImageRef`s: each one makes the reference's random
+draws in the reference's order (python `random`, as there) and records the geometry; the pixels of
+the WHOLE batch -- ops, Pillow-exact BILINEAR/NEAREST resize, pad, crop, /127.5-1, mask->multilabel,
+HWC->CHW -- are produced by one GPU call in the collate function (the kernels replace what
+Normalize_dg/ToTensor/collate spent 90 % of the reference's CPU pipeline time on).
+"""
+import numbers
+import random
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .basic import ImageRef, MaskRef
+
+
+class Compose(object):
+    """torchvision.transforms.Compose stand-in: `.transforms` is the list the search driver patches
+    (train_loader.dataset.transforms.transforms[0] = DGMultiPolicy(...), search_dg.py:341)."""
+
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, sample):
+        for t in self.transforms:
+            sample = t(sample)
+        return sample
+
+
+class Identity(object):
+    def __call__(self, sample):
+        return sample
+
+
+def _square(size):
+    if isinstance(size, numbers.Number):
+        return (int(size), int(size))
+    return tuple(size)
+
+
+class RandomCrop(object):
+    """Pads (fill 0) when the image is smaller than the target, then crops at a random offset."""
+
+    def __init__(self, size, padding=0):
+        self.size = _square(size)  # (h, w)
+        self.padding = padding
+
+    def draw(self, w, h):
+        """Returns (pad, x1, y1) for an image of PIL size (w, h); draws like data/transform.py:50-51."""
+        pad = 0
+        if self.padding > 0 or w < self.size[0] or h < self.size[1]:
+            pad = int(max(self.padding, (self.size[0] - w) // 2 + 5, (self.size[1] - h) // 2 + 5))
+            w, h = w + 2 * pad, h + 2 * pad
+        th, tw = self.size
+        if w == tw and h == th:
+            return pad, 0, 0
+        x1 = random.randint(0, w - tw)
+        y1 = random.randint(0, h - th)
+        return pad, x1, y1
+
+    def __call__(self, img, mask):
+        assert img.width == mask.width
+        assert img.height == mask.height
+        w, h = img.size
+        pad, x1, y1 = self.draw(w, h)
+        out = []
+        for ref in (img, mask):
+            r = ref.copy()
+            if r.scaled is None:
+                r.scaled = r.pool.size
+            r.pad, r.crop, r.crop_size = pad, (x1, y1), self.size
+            out.append(r)
+        return out[0], out[1]
+
+
+class DGRandomCrop(object):
+    def __init__(self, size, padding=0):
+        self.size = _square(size)
+        self.padding = padding
+        self.crop = RandomCrop(size, padding)
+
+    def __call__(self, sample):
+        sample['image'], sample['label'] = self.crop(sample['image'], sample['label'])
+        return sample
+
+
+class DGRandomScaleCrop(object):
+    """p=0.8: resize to int(U(s0,s1)*w) x int(U(s0,s1)*h) (BILINEAR image / NEAREST mask), then
+    RandomCrop.  Every augmented image gets its own scale and crop draw and is paired with a
+    re-scaled copy of the ORIGINAL mask (data/transform.py:122-131)."""
+
+    def __init__(self, size, scale_range=[1, 1.5]):
+        self.size = size
+        self.scale_range = scale_range
+        self.crop = RandomCrop(self.size)
+
+    def scale(self, img, mask):
+        if random.random() > 0.2:
+            w = int(random.uniform(self.scale_range[0], self.scale_range[1]) * img.size[0])
+            h = int(random.uniform(self.scale_range[0], self.scale_range[1]) * img.size[1])
+            img, mask = img.copy(), mask.copy()
+            img.scaled = mask.scaled = (w, h)
+        return img, mask
+
+    def __call__(self, sample):
+        img, mask = sample['image'], sample['label']
+        assert img.width == mask.width
+        assert img.height == mask.height
+        sample['image'], sample['label'] = self.crop(*self.scale(img, mask.copy()))
+        if 'aug_images' in sample:
+            done = [self.crop(*self.scale(aug, mask.copy())) for aug in sample['aug_images']]
+            sample['aug_images'] = [d[0] for d in done]
+            sample['aug_labels'] = [d[1] for d in done]
+        return sample
+
+
+class Normalize_dg(object):
+    """img -> float32 x/127.5 - 1; mask -> multilabel (optic: [cup, disc]) or binary (vessel).
+    Deferred: only tags the refs with the dataset kind; the arithmetic runs in the fused kernel."""
+
+    def __init__(self, dataset_name, mean=(0., 0., 0.), std=(1., 1., 1.)):
+        self.mean = mean
+        self.std = std
+        self.dataset_name = dataset_name
+
+    def _tag(self, ref):
+        r = ref.copy()
+        r.norm = self.dataset_name
+        return r
+
+    def __call__(self, sample):
+        if 'aug_images' in sample:
+            sample['aug_images'] = [self._tag(r) for r in sample['aug_images']]
+            sample['aug_labels'] = [self._tag(r) for r in sample['aug_labels']]
+        sample['image'] = self._tag(sample['image'])
+        sample['label'] = self._tag(sample['label'])
+        return sample
+
+
+def to_multilabel(pre_mask, classes=2):
+    mask = np.zeros((*pre_mask.shape, classes))
+    mask[pre_mask == 1] = [0, 1]
+    mask[pre_mask == 2] = [1, 1]
+    return mask
+
+
+def ToMultiLabel(dc, c):
+    new_dc = np.zeros([c])
+    new_dc[dc] = 1
+    return new_dc
+
+
+def SoftLable(label):
+    """Soft one-hot: true class U[0.8,1], the rest random, summing to 1 (data/transform.py:260-274);
+    draws from python `random` in the reference's order."""
+    hard = list(label)
+    hot = hard.index(1)
+    soft = np.array(label, dtype=np.float64)
+    soft[hot] = 0.8 + random.random() * 0.2
+    used = soft[hot]
+    last = len(hard) - 1
+    for i in range(len(hard)):
+        if i == hot:
+            continue
+        if i == last:
+            soft[i] = 1 - used
+        else:
+            soft[i] = random.random() * (1 - used)
+            used += soft[i]
+    return soft
+
+
+class ToTensor(object):
+    """Draws the soft domain code; the HWC->CHW float conversion itself happens in the fused kernel."""
+
+    def __init__(self, dataset_name) -> None:
+        super().__init__()
+        self.n = 3 if dataset_name in ['optic', 'vessel'] else 2
+
+    def __call__(self, sample):
+        domain_code = torch.from_numpy(SoftLable(ToMultiLabel(sample['dc'], self.n))).float()
+        sample['dc'] = domain_code
+        if 'aug_images' in sample:
+            sample['dc'] = torch.stack([domain_code] * len(sample['aug_images']), dim=0).contiguous()
+            sample['dc_single'] = domain_code
+        return sample
+
+
+def get_dg_segtransform(dataset, size=256):
+    """Same pipelines as data/transform.py:281-309; `size` generalises the hard-coded 256 crop
+    (BASELINE configs run 512 and 1024)."""
+    if 'optic' in dataset:
+        transform_train_imgs = Compose([
+            Identity(),  # slot 0: the search driver installs DGMultiPolicy here
+            DGRandomScaleCrop(size),
+            Normalize_dg('optic'),
+            ToTensor('optic')
+        ])
+        transform_test_imgs = Compose([
+            DGRandomCrop(size),
+            Normalize_dg('optic'),
+            ToTensor('optic')
+        ])
+    elif 'rvs' in dataset:
+        transform_train_imgs = Compose([
+            Identity(),
+            DGRandomScaleCrop(size, scale_range=[0.5, 2]),
+            Normalize_dg('vessel'),
+            ToTensor('vessel')
+        ])
+        transform_test_imgs = Compose([
+            Normalize_dg('vessel'),
+            ToTensor('vessel'),
+        ])
+    else:
+        raise NotImplementedError(dataset)
+    return transform_train_imgs, transform_test_imgs
+
+
+# ------------------------------------------------------------------------------------------------
+# ImageRef -> aadg_unit records -> one GPU launch
+# ------------------------------------------------------------------------------------------------
+def refs_to_units(refs):
+    """Pack recorded ImageRefs into the C-ABI unit array (include/aadg_hip.h: aadg_unit)."""
+    units = np.zeros(len(refs), dtype=_lib.UNIT_DTYPE)
+    units['rect'][:, :, 2:] = -1
+    for i, r in enumerate(refs):
+        u = units[i]
+        u['src'] = r.src
+        u['n_ops'] = len(r.ops)
+        for k, (op, iarg, farg, rect) in enumerate(r.ops):
+            u['op'][k], u['iarg'][k], u['farg'][k] = op, iarg, farg
+            u['rect'][k] = rect
+        w, h = r.scaled if r.scaled is not None else r.pool.size
+        u['scaled_w'], u['scaled_h'] = w, h
+        u['pad'] = r.pad
+        u['crop_x'], u['crop_y'] = r.crop
+    return units
+
+
+def materialize(refs, out_img=None, out_lbl=None):
+    """Run the fused GPU pipeline for a list of ImageRefs (same pool, same crop, same dataset kind)."""
+    first = refs[0]
+    pool = first.pool
+    if first.crop_size is None:
+        crop_hw = (pool.size[1], pool.size[0]) if first.scaled is None else (first.scaled[1], first.scaled[0])
+    else:
+        crop_hw = first.crop_size
+    if crop_hw[0] != crop_hw[1]:
+        raise NotImplementedError("non-square output crops are not supported")
+    for r in refs:
+        if r.pool is not pool or r.norm != first.norm:
+            raise ValueError("all images of a batch must come from one DevicePool / one dataset kind")
+        if r.crop_size is not None and tuple(r.crop_size) != tuple(crop_hw):
+            raise ValueError("all images of a batch must share one crop size")
+    if first.norm is None:
+        raise ValueError("Normalize_dg must run before collation")
+    kind = _lib.DATASET_OPTIC if first.norm == 'optic' else _lib.DATASET_VESSEL
+    return _lib.aug_u8_forward(pool.images, pool.masks, refs_to_units(refs), int(crop_hw[0]), kind, out_img, out_lbl)
+
+
+def collect_refs(batch, nested):
+    """Flattens a batch and lists its ImageRefs in output-row order: the S un-augmented images first,
+    then the augmented ones at row S + s*M + j (sample s, policy j)."""
+    if nested:
+        batch = [item for sublist in batch for item in sublist]
+    refs = [b['image'] for b in batch]
+    M = len(batch[0]['aug_images']) if 'aug_images' in batch[0] else 0
+    if M:
+        for b in batch:
+            refs.extend(b['aug_images'])
+    return batch, refs, M
+
+
+def _collate(batch, nested):
+    batch, refs, M = collect_refs(batch, nested)
+    S = len(batch)
+    new_batch = {'img_name': [b['img_name'] for b in batch]}
+    img, lbl = materialize(refs)
+    new_batch['image'], new_batch['label'] = img[:S], lbl[:S]
+    dev = img.device
+    if M:
+        new_batch['aug_images'], new_batch['aug_labels'] = img[S:], lbl[S:]
+        new_batch['dc'] = torch.cat([b['dc'] for b in batch], dim=0).to(dev, non_blocking=True)
+    else:
+        new_batch['dc'] = torch.stack([b['dc'] for b in batch], dim=0).to(dev, non_blocking=True)
+    if 'roi' in batch[0]:
+        new_batch['roi'] = torch.stack([b['roi'] for b in batch], dim=0)
+    return new_batch
+
+
+def train_dg_collate_fn(batch):
+    """batch = [[sample per domain] per item]; rows come out item-major, domain-minor, and the
+    augmented tensors in `sample*M + policy` order, as data/transform.py:323-340."""
+    return _collate(batch, nested=True)
+
+
+def test_dg_collate_fn(batch):
+    return _collate(batch, nested=False)

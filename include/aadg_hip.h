@@ -1,0 +1,149 @@
+/*
+ * aadg_hip.h -- C ABI of libaadg_hip.so, the MI355X (gfx950) implementation of the AADG
+ * policy-search hot path.
+ *
+ * Conventions (SURVEY.md 8b "Ownership / errors / threading"):
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - the caller owns and allocates every buffer, including the workspace (`ws`, size from the
+ *     matching *_workspace_bytes query); the library keeps no state, allocates nothing, and is
+ *     re-entrant;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*) and the call returns without
+ *     synchronising;
+ *   - return value: 0 = ok, <0 = bad argument (AADG_E_*), >0 = hipError_t of a failed launch.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference
+ * repository root).
+ */
+#ifndef AADG_HIP_H
+#define AADG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AADG_ABI_VERSION 1
+#define AADG_MAX_OPS 4
+
+#define AADG_E_BADARG (-1)
+#define AADG_E_WORKSPACE (-2)
+#define AADG_E_UNSUPPORTED (-3)
+
+/* op ids = position in augment_list(), data/basic.py:231-243 */
+enum aadg_op {
+    AADG_OP_AUTOCONTRAST = 0,
+    AADG_OP_INVERT = 1,
+    AADG_OP_EQUALIZE = 2,
+    AADG_OP_SOLARIZE = 3,
+    AADG_OP_POSTERIZE = 4,
+    AADG_OP_CONTRAST = 5,
+    AADG_OP_COLOR = 6,
+    AADG_OP_BRIGHTNESS = 7,
+    AADG_OP_SHARPNESS = 8,
+    AADG_OP_CUTOUT = 9,
+    AADG_OP_COUNT = 10
+};
+
+/* dataset kinds of Normalize_dg, data/transform.py:149-172 */
+enum aadg_dataset { AADG_DATASET_OPTIC = 0 /* K=2 multilabel */, AADG_DATASET_VESSEL = 1 /* K=1 */ };
+
+/*
+ * One (sample, policy) unit of the live augmentation path: every random draw the reference makes
+ * in Policy.__call__ (data/policy.py:15-30), Cutout (data/basic.py:146-155) and
+ * DGRandomScaleCrop / RandomCrop (data/transform.py:27-55,104-131) is made on the host and
+ * recorded here; the kernels only apply.  140 bytes, no padding.
+ */
+typedef struct aadg_unit {
+    int32_t src;                     /* index of the source image in the pool */
+    int32_t n_ops;                   /* 0..AADG_MAX_OPS (CONTROLLER.L) */
+    int32_t op[AADG_MAX_OPS];        /* enum aadg_op */
+    int32_t iarg[AADG_MAX_OPS];      /* Solarize: ceil(threshold); Posterize: int(bits) */
+    float farg[AADG_MAX_OPS];        /* Contrast/Color/Brightness/Sharpness: factor as C float */
+    int32_t rect[AADG_MAX_OPS][4];   /* Cutout: inclusive clipped (x0,y0,x1,y1); empty if x1<x0 */
+    int32_t scaled_w, scaled_h;      /* Image.resize target; == source size when not scaled */
+    int32_t pad, crop_x, crop_y;     /* RandomCrop border (fill 0) and crop offset */
+} aadg_unit;
+
+int aadg_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Live uint8 augmentation path, replaces the DataLoader-worker chain
+ *   DGMultiPolicy (data/policy.py:45-61) -> DGRandomScaleCrop (data/transform.py:97-135)
+ *   -> Normalize_dg (:138-186) -> ToTensor (:208-236) -> train_dg_collate_fn (:323-340).
+ *
+ *   pool      uint8 [P, Hs, Ws, 3]  RGB source images (HWC)
+ *   masks     uint8 [P, Hs, Ws]     label images (mode L)
+ *   units     aadg_unit[N]
+ *   out_img   float [N, 3, crop, crop]   = u8/127.5 - 1
+ *   out_lbl   float [N, K, crop, crop]   K = 2 (optic multilabel) or 1 (vessel)
+ * ------------------------------------------------------------------------------------------- */
+size_t aadg_aug_u8_workspace_bytes(int N, int Hs, int Ws, int crop);
+/* max_ops = largest n_ops over the units (number of op stages to run, <= AADG_MAX_OPS).
+ * Every unit must satisfy 3*scaled_w >= Ws and 3*scaled_h >= Hs (8 filter taps). */
+int aadg_aug_u8_forward(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,
+                        const aadg_unit* units, int N, int max_ops, int crop, int dataset,
+                        float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream);
+
+/* One registry op on one image, replaces fn(img, mask, v) of augment_list()
+ * (data/basic.py:70-120,137-167) for uint8 HWC tensors.  ws >= aadg_aug_u8_workspace_bytes(1,H,W,0);
+ * in != out. */
+int aadg_op_u8(const uint8_t* in, uint8_t* out, int H, int W, int op, int iarg, float farg,
+               const int32_t* rect_host, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sinkhorn reward, replaces geomloss.SamplesLoss("sinkhorn", cost=cosine, backend="online")
+ * (search_dg.py:116) and the reward loop (search_dg.py:150-162).
+ *
+ * Problems are described by index tables into one feature matrix `feat` [rows, E] (row stride
+ * `ld` floats): cloud c = rows cloud_rows[cloud_off[c] .. cloud_off[c+1]); problem p compares
+ * clouds prob_xy[2p] and prob_xy[2p+1].  out[p] = S_eps(x, y), debiased, p=2.
+ * ------------------------------------------------------------------------------------------- */
+size_t aadg_sinkhorn_workspace_bytes(int n_prob, int max_cloud);
+int aadg_sinkhorn_divergence_f32(const float* feat, int ld, int E, const int32_t* cloud_rows,
+                                 const int32_t* cloud_off, const int32_t* prob_xy, int n_prob,
+                                 int max_cloud, float blur, float scaling, float* out, void* ws,
+                                 size_t ws_bytes, void* stream);
+/* fe [D*B*M, E], row (b*D + d)*M + j  (train_dg_collate_fn order);  rewards[j] += sum over the
+ * D(D-1)/2 domain pairs, added in the reference's order (d1<d2 lexicographic). */
+int aadg_sinkhorn_rewards_f32(const float* fe, int D, int B, int M, int E, float blur,
+                              float scaling, float* rewards_accum, void* ws, size_t ws_bytes,
+                              void* stream);
+/* (r - mean) / (std_unbiased + 1e-5), search_dg.py:214 */
+int aadg_normalize_rewards_f32(const float* rewards, int M, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-policy BCE + samplewise Dice in one pass over logits/labels, replaces
+ *   [BCELoss(sigmoid(z)[j::M], y[j::M]) for j in range(M)]        (search_dg.py:140-142)
+ *   torchmetrics F1(num_classes=2, average=None, mdmc_average='samplewise')[1]  (:164-165)
+ * logits/labels float [N, K, HW]; out_bce[M]; out_dice[K]; optional grad_logits (d mean_j BCE_j / dz).
+ * ------------------------------------------------------------------------------------------- */
+size_t aadg_seg_loss_workspace_bytes(int N, int K);
+int aadg_seg_bce_dice_f32(const float* logits, const float* labels, int N, int K, int HW, int M,
+                          float* out_bce, float* out_dice, float* grad_logits, void* ws,
+                          size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Float tensor ops, data/functional.py (batched [B,3,H,W] float in [0,1], mag scalar or [B]).
+ * `mag` is a device pointer to mag_n (1 or B) floats, or NULL for ops without magnitude.
+ * Output is clamped to [0,1] as tensor_function does (data/functional.py:49-73).
+ * ------------------------------------------------------------------------------------------- */
+enum aadg_fop {
+    AADG_FOP_INVERT = 0, AADG_FOP_SOLARIZE, AADG_FOP_POSTERIZE, AADG_FOP_GRAY, AADG_FOP_CONTRAST,
+    AADG_FOP_AUTO_CONTRAST, AADG_FOP_SATURATE, AADG_FOP_BRIGHTNESS, AADG_FOP_HUE,
+    AADG_FOP_SAMPLE_PAIRING, AADG_FOP_EQUALIZE, AADG_FOP_SHARPNESS, AADG_FOP_GAUSSIAN_BLUR3X3,
+    AADG_FOP_SHEAR_X, AADG_FOP_SHEAR_Y, AADG_FOP_TRANSLATE_X, AADG_FOP_TRANSLATE_Y,
+    AADG_FOP_ROTATE, AADG_FOP_HFLIP, AADG_FOP_VFLIP, AADG_FOP_COUNT
+};
+size_t aadg_fop_workspace_bytes(int B, int C);
+/* kernel3x3: 9 floats (device) for SHARPNESS / GAUSSIAN_BLUR3X3, NULL = reference default;
+ * perm: B int32 (device) for SAMPLE_PAIRING. */
+int aadg_fop_f32(int fop, const float* in, float* out, const float* mag, int mag_n,
+                 const float* kernel3x3, const int32_t* perm, int B, int C, int H, int W, void* ws,
+                 size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AADG_HIP_H */

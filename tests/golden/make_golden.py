@@ -1,0 +1,207 @@
+"""Generates the golden fixtures under tests/golden/ by IMPORTING THE REFERENCE in the build container.
+
+Run (build container only; /root/reference does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+What travels is data only: inputs (seeded synthetic uint8 images, policy matrices, RNG seeds) and
+the outputs the reference's own functions produced for them.  Third-party modules the reference
+imports but this image lacks are replaced by empty stand-ins *that the exercised code paths never
+call* (cv2: only GammaCorrection; torchvision: only `transforms.Compose`, re-implemented in 6 lines;
+kornia: only the geometric/hue float ops, which are NOT fixture material; segmentation_models_pytorch:
+only the model factory).  The pixel arithmetic itself is executed by the reference's code + Pillow.
+"""
+import json
+import os
+import random
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def install_stubs():
+    cv2 = types.ModuleType("cv2")
+    sys.modules["cv2"] = cv2
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tvtt = types.ModuleType("torchvision.transforms.transforms")
+
+    class Compose(object):
+        def __init__(self, transforms):
+            self.transforms = transforms
+
+        def __call__(self, x):
+            for t in self.transforms:
+                x = t(x)
+            return x
+
+    tvtt.Compose = Compose
+    tvt.transforms = tvtt
+    tvt.Compose = Compose
+    tv.transforms = tvt
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.transforms"] = tvt
+    sys.modules["torchvision.transforms.transforms"] = tvtt
+    sys.modules["kornia"] = types.ModuleType("kornia")
+    sys.modules["segmentation_models_pytorch"] = types.ModuleType("segmentation_models_pytorch")
+    sys.path.insert(0, REF)
+
+
+def synth_image(rs, H, W, kind):
+    """Seeded synthetic RGB uint8 image (smooth field + colour cast + noise) and a 0/128/255 mask."""
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    field = 90 + 60 * np.sin(xx / (3.0 + kind)) * np.cos(yy / (4.0 + kind))
+    cast = np.array([1.0, 0.8 - 0.1 * kind, 0.5 + 0.15 * kind])
+    img = field[..., None] * cast + rs.randint(0, 40, (H, W, 3))
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    cy, cx = H * (0.4 + 0.1 * rs.rand()), W * (0.4 + 0.1 * rs.rand())
+    rr = np.sqrt((yy - cy) ** 2 + (xx - cx) ** 2)
+    mask = np.full((H, W), 255, np.uint8)
+    mask[rr < 0.35 * H] = 128
+    mask[rr < 0.18 * H] = 0
+    return img, mask
+
+
+class Cfg(object):
+    """Attribute bag with the CONTROLLER keys parse_policies reads."""
+
+    class _C(object):
+        pass
+
+    def __init__(self, L=2, NUM_MAGS=10, EXCLUDE_OPS=(), EXCLUDE_OPS_NUM=0, SEED=1023):
+        self.CONTROLLER = Cfg._C()
+        self.CONTROLLER.L = L
+        self.CONTROLLER.NUM_MAGS = NUM_MAGS
+        self.CONTROLLER.EXCLUDE_OPS = list(EXCLUDE_OPS)
+        self.CONTROLLER.EXCLUDE_OPS_NUM = EXCLUDE_OPS_NUM
+        self.SEED = SEED
+
+
+class NullLogger(object):
+    def info(self, *a):
+        pass
+
+
+def gen_ops():
+    """Each of the 10 registry ops x 10 magnitude levels, via the reference's apply_augment."""
+    from PIL import Image
+    import PIL
+    from data.basic import apply_augment, augment_list
+    rs = np.random.RandomState(1023)
+    out = {"pillow_version": np.array(PIL.__version__)}
+    names = [fn.__name__ for fn, _, _ in augment_list()]
+    out["op_names"] = np.array(names)
+    for tag, (H, W) in (("a", (32, 32)), ("b", (24, 40))):
+        img, mask = synth_image(rs, H, W, 0 if tag == "a" else 2)
+        out["img_" + tag], out["mask_" + tag] = img, mask
+        pim, pmask = Image.fromarray(img), Image.fromarray(mask)
+        res = np.zeros((10, 10, H, W, 3), np.uint8)
+        mres = np.zeros((10, 10, H, W), np.uint8)
+        for oi, name in enumerate(names):
+            for li in range(10):
+                np.random.seed(1000 * oi + li)  # Cutout draws np.random.uniform twice
+                o, m = apply_augment(pim, pmask, name, li / 9)
+                res[oi, li] = np.asarray(o)
+                mres[oi, li] = np.asarray(m)
+        out["out_" + tag], out["mout_" + tag] = res, mres
+    np.savez_compressed(os.path.join(OUT, "u8_ops.npz"), **out)
+
+
+def gen_parse():
+    from data.policy import parse_policies
+    rs = np.random.RandomState(7)
+    cases = []
+    for L, excl in ((2, []), (2, ["Cutout"]), (3, ["Invert", "Equalize"]), (1, [])):
+        n_ops = 10 - len(excl)
+        pol = np.zeros((6, 5 * L * 2), np.int64)
+        pol[:, 0::2] = rs.randint(0, n_ops, (6, 5 * L))
+        pol[:, 1::2] = rs.randint(0, 10, (6, 5 * L))
+        parsed = parse_policies(pol, Cfg(L=L, EXCLUDE_OPS=excl), NullLogger())
+        cases.append({"L": L, "exclude": excl, "policies": pol.tolist(),
+                      "parsed": [[[[n, float(v)] for n, v in sp] for sp in p] for p in parsed]})
+    with open(os.path.join(OUT, "parse_policies.json"), "w") as f:
+        json.dump(cases, f)
+
+
+def gen_pipeline():
+    """Whole live pipeline: DGMultiPolicy -> DGRandomScaleCrop -> Normalize_dg -> ToTensor -> collate."""
+    from PIL import Image
+    from data.policy import DGMultiPolicy, parse_policies
+    from data import transform as T
+    # the 256 float32 values Normalize_dg can produce, from the reference's own arithmetic
+    ramp = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    ramp3 = np.stack([ramp] * 3, -1)
+    lut, _ = T.Normalize_dg('vessel').normalize(Image.fromarray(ramp3), Image.fromarray(ramp))
+    lut = np.ascontiguousarray(lut[..., 0].reshape(256))
+    out = {"lut256": lut}
+    cfgs = [
+        # name, dataset, src HxW, crop, scale range, D, items, seed
+        ("optic_up", "optic", (40, 40), 32, [1, 1.5], 3, 2, 11),
+        ("optic_pad", "optic", (28, 28), 32, [1, 1.5], 3, 1, 12),
+        ("rvs_down", "vessel", (48, 48), 32, [0.5, 2], 3, 1, 13),
+        ("optic_rect", "optic", (36, 44), 32, [1, 1.5], 2, 1, 14),
+    ]
+    meta = []
+    for name, ds, (H, W), crop, sr, D, items, seed in cfgs:
+        rs = np.random.RandomState(seed)
+        pool_img, pool_msk = [], []
+        for d in range(D):
+            for _ in range(2):
+                im, mk = synth_image(rs, H, W, d)
+                if ds == "vessel":
+                    mk = ((mk == 128) * 255).astype(np.uint8)
+                pool_img.append(im)
+                pool_msk.append(mk)
+        pol = np.zeros((6, 20), np.int64)
+        pol[:, 0::2] = rs.randint(0, 10, (6, 10))
+        pol[:, 1::2] = rs.randint(0, 10, (6, 10))
+        parsed = parse_policies(pol, Cfg(), NullLogger())
+        tf = T.transforms.Compose([DGMultiPolicy(parsed), T.DGRandomScaleCrop(crop, scale_range=sr),
+                                   T.Normalize_dg(ds), T.ToTensor(ds)])
+        random.seed(seed)
+        np.random.seed(seed)
+        batch, picks = [], []
+        for it in range(items):
+            per_item = []
+            for d in range(D):
+                idx = int(np.random.choice(2, 1)[0])  # FundusSegmentation.__getitem__ draw (data/optic.py:84)
+                picks.append(2 * d + idx)
+                s = {'image': Image.fromarray(pool_img[2 * d + idx]), 'label': Image.fromarray(pool_msk[2 * d + idx]),
+                     'img_name': 'im%d_%d' % (d, idx), 'dc': d}
+                per_item.append(tf(s))
+            batch.append(per_item)
+        nb = T.train_dg_collate_fn(batch)
+
+        def codes(x):  # float32 image tensor -> index into lut256 (exact)
+            x = x.numpy()
+            c = np.rint((x + 1.0) * 127.5).astype(np.int64)
+            assert np.array_equal(lut[c], x)
+            return c.astype(np.uint8)
+
+        out[name + "_pool_img"] = np.stack(pool_img)
+        out[name + "_pool_msk"] = np.stack(pool_msk)
+        out[name + "_policies"] = pol
+        out[name + "_picks"] = np.array(picks)
+        out[name + "_aug_images"] = codes(nb['aug_images'])
+        out[name + "_aug_labels"] = nb['aug_labels'].numpy().astype(np.uint8)
+        out[name + "_image"] = codes(nb['image'])
+        out[name + "_label"] = nb['label'].numpy().astype(np.uint8)
+        out[name + "_dc"] = nb['dc'].numpy()
+        assert np.array_equal(out[name + "_aug_labels"].astype(np.float32), nb['aug_labels'].numpy())
+        meta.append({"name": name, "dataset": ds, "H": H, "W": W, "crop": crop, "scale_range": sr, "D": D,
+                     "items": items, "seed": seed})
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "pipeline.npz"), **out)
+
+
+if __name__ == "__main__":
+    install_stubs()
+    gen_ops()
+    gen_parse()
+    gen_pipeline()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

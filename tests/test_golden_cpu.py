@@ -1,0 +1,102 @@
+"""CPU suite, part 1: the oracle (and aadg_amd's host-side draw logic) against the golden vectors the
+reference itself produced (tests/golden/make_golden.py), and against live Pillow when importable."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, Cfg, draw_batch, load_pipeline_golden
+
+
+def test_oracle_ops_match_reference_golden(oracle):
+    """All 10 registry ops x 10 magnitude levels, bit-exact vs reference apply_augment outputs."""
+    from aadg_amd.data.basic import cutout_rect
+    z = np.load(os.path.join(GOLDEN, "u8_ops.npz"))
+    los = [0, 0, 0, 0, 4, .1, .1, .1, .1, 0]
+    his = [1, 1, 1, 256, 8, 1.9, 1.9, 1.9, 1.9, .2]
+    for tag in ("a", "b"):
+        img = z["img_" + tag]
+        H, W, _ = img.shape
+        for op in range(10):
+            for li in range(10):
+                v = li / 9 * (his[op] - los[op]) + los[op]
+                iarg, farg, rect = 0, 0.0, None
+                if op == 3:
+                    iarg = int(math.ceil(v))
+                elif op == 4:
+                    iarg = int(v)
+                elif op in (5, 6, 7, 8):
+                    farg = np.float32(v)
+                elif op == 9:
+                    if v <= 0:
+                        rect = (0, 0, -1, -1)
+                    else:
+                        np.random.seed(1000 * op + li)
+                        x0, y0 = np.random.uniform(W), np.random.uniform(H)
+                        rect = cutout_rect(W, H, v * W, x0, y0)
+                got = oracle.op_u8(img, op, iarg, farg, rect)
+                assert np.array_equal(got, z["out_" + tag][op, li]), (tag, op, li)
+
+
+def test_parse_policies_bit_exact():
+    """Policy indexing must be bit-exact (north_star): names AND float64 levels."""
+    from aadg_amd.data.policy import parse_policies
+    with open(os.path.join(GOLDEN, "parse_policies.json")) as f:
+        cases = json.load(f)
+    for c in cases:
+        got = parse_policies(np.array(c["policies"], np.int64), Cfg(L=c["L"], EXCLUDE_OPS=c["exclude"]), None)
+        want = c["parsed"]
+        assert len(got) == len(want)
+        for gp, wp in zip(got, want):
+            assert len(gp) == len(wp)
+            for gs, ws in zip(gp, wp):
+                assert [(n, float(v)) for n, v in gs] == [(n, v) for n, v in ws]
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_pipeline_seed_for_seed_vs_reference(oracle, case):
+    """Same seeds as the reference run -> aadg_amd's host code records the same draws -> the oracle
+    reproduces the reference's collated tensors exactly (images, labels, soft domain codes)."""
+    z, meta = load_pipeline_golden()
+    m = meta[case]
+    name = m["name"]
+    pool, flat, refs, M = draw_batch(z[name + "_pool_img"], z[name + "_pool_msk"], z[name + "_policies"], m)
+    from aadg_amd.data.transform import refs_to_units
+    import torch
+    units = refs_to_units(refs)
+    S = len(flat)
+    assert [int(u) for u in units["src"][:S]] == [int(p) for p in z[name + "_picks"]]
+    kind = 0 if m["dataset"] == "optic" else 1
+    img, lbl = oracle.aug_units(pool.images.numpy(), pool.masks.numpy(), units, m["crop"], kind)
+    lut = z["lut256"]
+    assert np.array_equal(img[:S], lut[z[name + "_image"]])
+    assert np.array_equal(lbl[:S], z[name + "_label"].astype(np.float32))
+    assert np.array_equal(img[S:], lut[z[name + "_aug_images"]])
+    assert np.array_equal(lbl[S:], z[name + "_aug_labels"].astype(np.float32))
+    dc = torch.cat([b['dc'] for b in flat], dim=0).numpy()
+    assert np.array_equal(dc, z[name + "_dc"])
+
+
+def test_oracle_vs_live_pillow(oracle):
+    """Stronger pin when Pillow is importable: random sizes/scales, every op, resize both filters."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image, ImageOps, ImageEnhance
+    rs = np.random.RandomState(5)
+    for (H, W) in [(32, 32), (17, 45), (64, 48)]:
+        a = rs.randint(0, 256, (H, W, 3)).astype(np.uint8)
+        a[:, : W // 2, 1] //= 3
+        pil = Image.fromarray(a)
+        assert np.array_equal(np.asarray(ImageOps.autocontrast(pil)), oracle.op_u8(a, 0))
+        assert np.array_equal(np.asarray(ImageOps.equalize(pil)), oracle.op_u8(a, 2))
+        for f in (0.1, 0.5, 0.9, 1.0, 1.3, 1.9):
+            for op, E in ((5, ImageEnhance.Contrast), (6, ImageEnhance.Color), (7, ImageEnhance.Brightness),
+                          (8, ImageEnhance.Sharpness)):
+                assert np.array_equal(np.asarray(E(pil).enhance(f)), oracle.op_u8(a, op, farg=np.float32(f))), (op, f)
+        m = (rs.randint(0, 3, (H, W)) * 127).astype(np.uint8)
+        pm = Image.fromarray(m)
+        for _ in range(25):
+            w, h = int(rs.uniform(0.5, 2) * W), int(rs.uniform(0.5, 2) * H)
+            assert np.array_equal(np.asarray(pil.resize((w, h), Image.BILINEAR)), oracle.resize_bilinear(a, w, h))
+            assert np.array_equal(np.asarray(pm.resize((w, h), Image.NEAREST)), oracle.resize_nearest(m, w, h))
