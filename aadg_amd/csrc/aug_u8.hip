@@ -520,9 +520,22 @@ extern "C" size_t aadg_aug_u8_workspace_bytes(int N, int Hs, int Ws, int crop) {
     return ws_layout(N, Hs, Ws, crop).total;
 }
 
+extern "C" int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,
+                                      const aadg_unit* units, int N, int max_ops, int crop, int dataset,
+                                      float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream,
+                                      void* ev_before_final, void* ev_after_final);
+
 extern "C" int aadg_aug_u8_forward(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,
                                    const aadg_unit* units, int N, int max_ops, int crop, int dataset,
                                    float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream) {
+    return aadg_aug_u8_forward_ex(pool, masks, P, Hs, Ws, units, N, max_ops, crop, dataset, out_img, out_lbl, ws,
+                                  ws_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,
+                                      const aadg_unit* units, int N, int max_ops, int crop, int dataset,
+                                      float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream,
+                                      void* ev_before_final, void* ev_after_final) {
     if (!pool || !masks || !units || !out_img || !out_lbl || !ws) return AADG_E_BADARG;
     if (P <= 0 || Hs <= 0 || Ws <= 0 || N <= 0 || crop <= 0) return AADG_E_BADARG;
     if (max_ops < 0 || max_ops > AADG_MAX_OPS) return AADG_E_BADARG;
@@ -545,8 +558,10 @@ extern "C" int aadg_aug_u8_forward(const uint8_t* pool, const uint8_t* masks, in
     hipLaunchKernelGGL(k_tables, dim3(N), dim3(256), 0, st, ur, Hs, Ws, crop, tab);
     AADG_LAUNCH_CHECK();
     const dim3 g((crop + 255) / 256, (crop + FIN_ROWS - 1) / FIN_ROWS, N);
+    if (ev_before_final) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_before_final), st));
     hipLaunchKernelGGL(k_final, g, dim3(256), 0, st, bufs, masks, ur, Hs, Ws, crop, dataset, tab, out_img, out_lbl);
     AADG_LAUNCH_CHECK();
+    if (ev_after_final) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_after_final), st));
     return 0;
 }
 

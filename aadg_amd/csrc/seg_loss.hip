@@ -1,0 +1,145 @@
+// Per-policy BCE + samplewise Dice (+ the BCE gradient) in ONE pass over logits/labels
+// (a21, a22; 8f item 2).
+//
+// Replaces, per inner iteration of the reference (search_dg.py:140-142,164-165):
+//   seg_soft = sigmoid(seg_output)                                   1 read + 1 write of [N,K,H,W]
+//   [BCELoss(seg_soft[j::M], mask_gt[j::M]) for j in range(M)]       2 reads (strided gathers)
+//   M x { F1(stack([1-p, p]), gt.long())[1] per class }              2*M*K full-tensor passes (redundant: the
+//                                                                    same value is recomputed for every j)
+// with one streaming read of logits + labels (float4 per lane) and an optional write of d(loss)/d(logits),
+// where loss = mean_j BCE_j, so that backward needs no further pass.
+//
+// Determinism: block partials go to the workspace and are combined in a fixed order by a second tiny
+// kernel (no float atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int SL_THREADS = 256;
+constexpr int SL_CHUNK = SL_THREADS * 4 * 8;  // elements per block: 8 float4 per thread
+
+struct Partial {
+    double bce;
+    int tp, fp, fn, pad;
+};
+
+__device__ __forceinline__ void elem(float z, float y, float gscale, float& bce, int& tp, int& fp, int& fn, float* g) {
+    const float p = 1.0f / (1.0f + expf(-z));            // torch.sigmoid
+    float lp = logf(p), lq = log1pf(-p);                 // nn.BCELoss: logs clamped at -100
+    lp = fmaxf(lp, -100.0f);
+    lq = fmaxf(lq, -100.0f);
+    bce += (y - 1.0f) * lq - y * lp;
+    const int pr = p > 0.5f, gt = ((long)y) != 0;        // argmax([1-p, p]) == 1  <=>  p > 0.5
+    tp += pr & gt; fp += pr & (gt ^ 1); fn += (pr ^ 1) & gt;
+    if (g) {
+        const float pq = p * (1.0f - p);
+        *g = gscale * (p - y) / fmaxf(pq, 1e-12f) * pq;  // BCELoss backward (eps 1e-12) x sigmoid backward
+    }
+}
+
+// grid (chunks, N*K)
+__global__ __launch_bounds__(SL_THREADS) void k_seg_partial(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                            int HW, float gscale, float* __restrict__ grad,
+                                                            Partial* __restrict__ part) {
+    const int plane = blockIdx.y;
+    const size_t base = (size_t)plane * HW;
+    const int c0 = blockIdx.x * SL_CHUNK;
+    const int c1 = min(c0 + SL_CHUNK, HW);
+    float bce = 0.f;
+    int tp = 0, fp = 0, fn = 0;
+    const bool vec = ((HW & 3) == 0) && ((((uintptr_t)logits | (uintptr_t)labels | (uintptr_t)grad) & 15) == 0);
+    if (vec) {
+        for (int i = c0 + threadIdx.x * 4; i < c1; i += SL_THREADS * 4) {
+            const float4 z = *reinterpret_cast<const float4*>(logits + base + i);
+            const float4 y = *reinterpret_cast<const float4*>(labels + base + i);
+            float4 g;
+            elem(z.x, y.x, gscale, bce, tp, fp, fn, grad ? &g.x : nullptr);
+            elem(z.y, y.y, gscale, bce, tp, fp, fn, grad ? &g.y : nullptr);
+            elem(z.z, y.z, gscale, bce, tp, fp, fn, grad ? &g.z : nullptr);
+            elem(z.w, y.w, gscale, bce, tp, fp, fn, grad ? &g.w : nullptr);
+            if (grad) *reinterpret_cast<float4*>(grad + base + i) = g;
+        }
+    } else {
+        for (int i = c0 + threadIdx.x; i < c1; i += SL_THREADS) {
+            float g;
+            elem(logits[base + i], labels[base + i], gscale, bce, tp, fp, fn, grad ? &g : nullptr);
+            if (grad) grad[base + i] = g;
+        }
+    }
+    double b = wave_sum((double)bce);
+    tp = wave_sum(tp); fp = wave_sum(fp); fn = wave_sum(fn);
+    __shared__ double sb[4];
+    __shared__ int st[4][3];
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sb[wv] = b; st[wv][0] = tp; st[wv][1] = fp; st[wv][2] = fn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Partial o;
+        o.bce = (sb[0] + sb[1]) + (sb[2] + sb[3]);
+        o.tp = st[0][0] + st[1][0] + st[2][0] + st[3][0];
+        o.fp = st[0][1] + st[1][1] + st[2][1] + st[3][1];
+        o.fn = st[0][2] + st[1][2] + st[2][2] + st[3][2];
+        o.pad = 0;
+        part[(size_t)plane * gridDim.x + blockIdx.x] = o;
+    }
+}
+
+// grid M + K blocks of one wave: block t < M -> BCE of policy t; block M + k -> Dice of class k.
+// Lanes stride over rows, partials are summed in a fixed order (deterministic).
+__global__ __launch_bounds__(64) void k_seg_final(const Partial* __restrict__ part, int N, int K, int HW, int M,
+                                                  int chunks, float* __restrict__ out_bce, float* __restrict__ out_dice) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t < M) {
+        double s = 0.0;
+        const int rows = (N - t + M - 1) / M;
+        for (int i = lane; i < rows * K; i += 64) {
+            const int r = t + (i / K) * M, k = i % K;
+            const Partial* p = part + ((size_t)r * K + k) * chunks;
+            double a = 0.0;
+            for (int c = 0; c < chunks; ++c) a += p[c].bce;
+            s += a;
+        }
+        s = wave_sum(s);
+        if (lane == 0) out_bce[t] = (float)(s / ((double)rows * K * HW));
+    } else {
+        const int k = t - M;
+        double acc = 0.0;
+        for (int r = lane; r < N; r += 64) {
+            const Partial* p = part + ((size_t)r * K + k) * chunks;
+            long tp = 0, fp = 0, fn = 0;
+            for (int c = 0; c < chunks; ++c) { tp += p[c].tp; fp += p[c].fp; fn += p[c].fn; }
+            const long den = 2 * tp + fp + fn;
+            acc += den ? (2.0 * (double)tp) / (double)den : 0.0;
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) out_dice[k] = (float)(acc / N);
+    }
+}
+
+int chunks_of(int HW) { return (HW + SL_CHUNK - 1) / SL_CHUNK; }
+
+}  // namespace
+
+extern "C" size_t aadg_seg_loss_workspace_bytes(int N, int K, int HW) {
+    if (N <= 0 || K <= 0 || HW <= 0) return 0;
+    return aadg_align_up((size_t)N * K * chunks_of(HW) * sizeof(Partial), 256);
+}
+
+extern "C" int aadg_seg_bce_dice_f32(const float* logits, const float* labels, int N, int K, int HW, int M,
+                                     float* out_bce, float* out_dice, float* grad_logits, void* ws, size_t ws_bytes,
+                                     void* stream) {
+    if (!logits || !labels || !out_bce || !out_dice || !ws) return AADG_E_BADARG;
+    if (N <= 0 || K <= 0 || HW <= 0 || M <= 0 || M > N || N % M) return AADG_E_BADARG;
+    if (ws_bytes < aadg_seg_loss_workspace_bytes(N, K, HW)) return AADG_E_WORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int chunks = chunks_of(HW);
+    Partial* part = reinterpret_cast<Partial*>(ws);
+    // d mean_j(BCE_j) / dz: every element of policy j weighs 1 / (M * (N/M) * K * HW)
+    const float gscale = (float)(1.0 / ((double)N * K * HW));
+    hipLaunchKernelGGL(k_seg_partial, dim3(chunks, N * K), dim3(SL_THREADS), 0, st, logits, labels, HW, gscale,
+                       grad_logits, part);
+    AADG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_seg_final, dim3(M + K), dim3(64), 0, st, part, N, K, HW, M, chunks, out_bce, out_dice);
+    AADG_LAUNCH_CHECK();
+    return 0;
+}

@@ -279,18 +279,43 @@ def collect_refs(batch, nested):
     return batch, refs, M
 
 
+_ROW_SHARD = (0, 1)   # (rank, world): which contiguous slice of the collate rows this process materialises
+
+
+def set_row_shard(rank, world_size):
+    """Multi-GPU: every rank draws the SAME batch plan (same seeds -> same draws, no communication) but
+    materialises only its contiguous slice of the rows (aadg_amd/distributed.py: shard_rows)."""
+    global _ROW_SHARD
+    _ROW_SHARD = (int(rank), int(world_size))
+
+
+def _slice(n):
+    rank, world = _ROW_SHARD
+    if world == 1:
+        return 0, n
+    if n % world:
+        raise ValueError("rows (%d) must divide evenly over %d ranks" % (n, world))
+    return rank * (n // world), (rank + 1) * (n // world)
+
+
 def _collate(batch, nested):
     batch, refs, M = collect_refs(batch, nested)
     S = len(batch)
     new_batch = {'img_name': [b['img_name'] for b in batch]}
-    img, lbl = materialize(refs)
-    new_batch['image'], new_batch['label'] = img[:S], lbl[:S]
+    lo_s, hi_s = _slice(S)
+    lo, hi = _slice(S * M) if M else (0, 0)
+    img, lbl = materialize(refs[lo_s:hi_s] + refs[S + lo:S + hi])
+    ns = hi_s - lo_s
+    new_batch['image'], new_batch['label'] = img[:ns], lbl[:ns]
     dev = img.device
     if M:
-        new_batch['aug_images'], new_batch['aug_labels'] = img[S:], lbl[S:]
-        new_batch['dc'] = torch.cat([b['dc'] for b in batch], dim=0).to(dev, non_blocking=True)
+        new_batch['aug_images'], new_batch['aug_labels'] = img[ns:], lbl[ns:]
+        dc = torch.cat([b['dc'] for b in batch], dim=0)
+        new_batch['dc'] = dc[lo:hi].to(dev, non_blocking=True)
+        new_batch['dc_image'] = torch.stack([b['dc_single'] for b in batch], dim=0)[lo_s:hi_s].to(dev, non_blocking=True)
+        new_batch['rows'] = (lo, hi, S * M)
     else:
-        new_batch['dc'] = torch.stack([b['dc'] for b in batch], dim=0).to(dev, non_blocking=True)
+        new_batch['dc'] = torch.stack([b['dc'] for b in batch], dim=0)[lo_s:hi_s].to(dev, non_blocking=True)
     if 'roi' in batch[0]:
         new_batch['roi'] = torch.stack([b['roi'] for b in batch], dim=0)
     return new_batch

@@ -1,0 +1,199 @@
+"""DeepLabV3+ segmentation backbone with the `(mask_logits, pooled_encoder_feature)` contract the inner
+loop relies on (reference: models/__init__.py:17-23 builds smp.DeepLabV3Plus(..., aux_params=dict(
+pooling='avg')) and models/heads.py:14-25 reduces the aux head to pool+flatten, so `model(x)` returns
+`(logits [N,K,H,W], feature [N,C_enc])`, search_dg.py:132).
+
+segmentation_models_pytorch / torchvision / timm are not in this image, so the architecture is written
+here in plain torch.nn (MIOpen convolutions; the backbone is host plumbing, not a parity target --
+SURVEY.md 8c).  Same topology as smp 0.2.0's DeepLabV3Plus: encoder at output stride 16 (last stage
+dilated), ASPP with separable atrous convs (12, 24, 36) + image pooling, 48-channel skip from the
+stride-4 feature, separable 3x3 fuse, 1x1 classifier, x4 bilinear upsampling (align_corners=True).
+Encoders: mobilenet_v2 (C_enc = 1280, the reference's only reachable choice) and resnet50
+(C_enc = 2048, BASELINE config 2).  Weights are randomly initialised (no network for ImageNet weights).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _bn_relu(c):
+    return [nn.BatchNorm2d(c), nn.ReLU(inplace=True)]
+
+
+class SeparableConv2d(nn.Sequential):
+    def __init__(self, cin, cout, k=3, dilation=1):
+        pad = dilation * (k // 2)
+        super().__init__(nn.Conv2d(cin, cin, k, padding=pad, dilation=dilation, groups=cin, bias=False),
+                         nn.Conv2d(cin, cout, 1, bias=False))
+
+
+# ---------------------------------------------------------------------------------------------- ResNet-50
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cin, planes, stride=1, dilation=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + idt)
+
+
+class ResNet50Encoder(nn.Module):
+    """Stages at strides 2, 4, 8, 16, 16 (layer4 dilated by 2 for output stride 16)."""
+    out_channels = 2048
+    skip_channels = 256
+
+    def __init__(self):
+        super().__init__()
+        self.stem = nn.Sequential(nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False), *_bn_relu(64))
+        self.pool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.cin = 64
+        self.layer1 = self._stage(64, 3, 1, 1)
+        self.layer2 = self._stage(128, 4, 2, 1)
+        self.layer3 = self._stage(256, 6, 2, 1)
+        self.layer4 = self._stage(512, 3, 1, 2)
+
+    def _stage(self, planes, blocks, stride, dilation):
+        down = None
+        if stride != 1 or self.cin != planes * 4:
+            down = nn.Sequential(nn.Conv2d(self.cin, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.cin, planes, stride, dilation, down)]
+        self.cin = planes * 4
+        layers += [Bottleneck(self.cin, planes, 1, dilation) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = self.pool(self.stem(x))
+        skip = self.layer1(x)
+        x = self.layer4(self.layer3(self.layer2(skip)))
+        return skip, x
+
+
+# ---------------------------------------------------------------------------------------------- MobileNetV2
+class InvertedResidual(nn.Module):
+    def __init__(self, cin, cout, stride, expand, dilation=1):
+        super().__init__()
+        hid = cin * expand
+        self.use_res = stride == 1 and cin == cout
+        layers = []
+        if expand != 1:
+            layers += [nn.Conv2d(cin, hid, 1, bias=False), nn.BatchNorm2d(hid), nn.ReLU6(inplace=True)]
+        layers += [nn.Conv2d(hid, hid, 3, stride, dilation, dilation=dilation, groups=hid, bias=False),
+                   nn.BatchNorm2d(hid), nn.ReLU6(inplace=True),
+                   nn.Conv2d(hid, cout, 1, bias=False), nn.BatchNorm2d(cout)]
+        self.conv = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return x + self.conv(x) if self.use_res else self.conv(x)
+
+
+class MobileNetV2Encoder(nn.Module):
+    out_channels = 1280
+    skip_channels = 24
+
+    def __init__(self):
+        super().__init__()
+        cfg = [(1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1)]
+        feats = [nn.Sequential(nn.Conv2d(3, 32, 3, 2, 1, bias=False), nn.BatchNorm2d(32), nn.ReLU6(inplace=True))]
+        cin, stride_so_far, dilation = 32, 2, 1
+        for t, c, n, s in cfg:
+            for i in range(n):
+                st = s if i == 0 else 1
+                d = dilation
+                if st == 2 and stride_so_far >= 16:      # keep output stride 16: dilate instead of striding
+                    st, dilation = 1, dilation * 2
+                if st == 2:
+                    stride_so_far *= 2
+                feats.append(InvertedResidual(cin, c, st, t, d if st == 1 else 1))
+                cin = c
+        feats.append(nn.Sequential(nn.Conv2d(cin, 1280, 1, bias=False), nn.BatchNorm2d(1280), nn.ReLU6(inplace=True)))
+        self.features = nn.Sequential(*feats)
+
+    def forward(self, x):
+        skip = None
+        for i, f in enumerate(self.features):
+            x = f(x)
+            if i == 3:
+                skip = x                                   # stride 4, 24 channels
+        return skip, x
+
+
+# ---------------------------------------------------------------------------------------------- head
+class ASPP(nn.Module):
+    def __init__(self, cin, cout=256, rates=(12, 24, 36)):
+        super().__init__()
+        self.branches = nn.ModuleList(
+            [nn.Sequential(nn.Conv2d(cin, cout, 1, bias=False), *_bn_relu(cout))] +
+            [nn.Sequential(SeparableConv2d(cin, cout, 3, r), *_bn_relu(cout)) for r in rates])
+        self.image_pool = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(cin, cout, 1, bias=False), *_bn_relu(cout))
+        self.project = nn.Sequential(nn.Conv2d(cout * 5, cout, 1, bias=False), *_bn_relu(cout), nn.Dropout(0.5))
+
+    def forward(self, x):
+        outs = [b(x) for b in self.branches]
+        outs.append(F.interpolate(self.image_pool(x), size=x.shape[-2:], mode='bilinear', align_corners=False))
+        return self.project(torch.cat(outs, dim=1))
+
+
+class DeepLabV3Plus(nn.Module):
+    def __init__(self, encoder_name='mobilenet_v2', classes=2, aux_pooling=True):
+        super().__init__()
+        if encoder_name == 'mobilenet_v2':
+            self.encoder = MobileNetV2Encoder()
+        elif encoder_name in ('resnet50', 'resnet-50'):
+            self.encoder = ResNet50Encoder()
+        else:
+            raise NotImplementedError(encoder_name + ' has not been implemented!')
+        self.feature_channels = self.encoder.out_channels
+        self.aspp = nn.Sequential(ASPP(self.encoder.out_channels), SeparableConv2d(256, 256, 3), *_bn_relu(256))
+        self.skip = nn.Sequential(nn.Conv2d(self.encoder.skip_channels, 48, 1, bias=False), *_bn_relu(48))
+        self.fuse = nn.Sequential(SeparableConv2d(256 + 48, 256, 3), *_bn_relu(256))
+        self.classifier = nn.Conv2d(256, classes, 1)
+        self.aux_pooling = aux_pooling
+
+    def forward(self, x):
+        skip, deep = self.encoder(x)
+        y = F.interpolate(self.aspp(deep), size=skip.shape[-2:], mode='bilinear', align_corners=True)
+        y = self.fuse(torch.cat([y, self.skip(skip)], dim=1))
+        mask = F.interpolate(self.classifier(y), size=x.shape[-2:], mode='bilinear', align_corners=True)
+        if not self.aux_pooling:
+            return mask
+        return mask, deep.float().mean(dim=(2, 3))          # ClassificationHead = avg-pool + flatten (models/heads.py:19-25)
+
+
+class UNetSmall(nn.Module):
+    """Small UNet returning (logits, pooled bottleneck) -- BASELINE config 0 (CPU plumbing case)."""
+
+    def __init__(self, classes=1, width=16):
+        super().__init__()
+        def block(cin, cout):
+            return nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1, bias=False), *_bn_relu(cout),
+                                 nn.Conv2d(cout, cout, 3, padding=1, bias=False), *_bn_relu(cout))
+        w = width
+        self.d1, self.d2, self.d3 = block(3, w), block(w, 2 * w), block(2 * w, 4 * w)
+        self.mid = block(4 * w, 8 * w)
+        self.u3, self.u2, self.u1 = block(12 * w, 4 * w), block(6 * w, 2 * w), block(3 * w, w)
+        self.out = nn.Conv2d(w, classes, 1)
+        self.feature_channels = 8 * w
+
+    def forward(self, x):
+        a = self.d1(x)
+        b = self.d2(F.max_pool2d(a, 2))
+        c = self.d3(F.max_pool2d(b, 2))
+        m = self.mid(F.max_pool2d(c, 2))
+        up = lambda t, ref: F.interpolate(t, size=ref.shape[-2:], mode='bilinear', align_corners=False)  # noqa: E731
+        y = self.u3(torch.cat([up(m, c), c], 1))
+        y = self.u2(torch.cat([up(y, b), b], 1))
+        y = self.u1(torch.cat([up(y, a), a], 1))
+        return self.out(y), m.float().mean(dim=(2, 3))

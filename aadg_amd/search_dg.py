@@ -1,0 +1,259 @@
+"""Search driver and inner loop -- API mirror of the reference's search_dg.py (pretrain :24-99,
+train :102-214, validate :217-286, search_seg_dg_policy :289-407; search_dg_2d.py is the same loop for
+the single-class RVS task and is served by this module too).
+
+What differs from the reference, by design:
+  * `sample['aug_images']` etc. come from the fused GPU augmentation call (no DataLoader workers, no H2D);
+  * sigmoid + M per-policy BCE + M redundant F1 passes (search_dg.py:140-144,164-165) are ONE fused kernel
+    (`_lib.policy_bce_loss`, forward and backward in a single pass over logits/labels);
+  * the 3 x M geomloss calls with ~790 launches and 18 host syncs (search_dg.py:150-162) are ONE kernel
+    (`_lib.sinkhorn_rewards`) -- no `.item()` inside the iteration; meters are read once per PRINT_FREQ;
+  * multi-GPU: rows are sharded over ranks, embeddings are all-gathered once (distributed.py), rewards are
+    computed redundantly and identically on every rank.
+"""
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import _lib, utils
+from . import distributed as adist
+from .data.dataloader import get_seg_dg_dataloader
+from .data.policy import DGMultiPolicy, parse_policies
+from .data import transform as T
+from .losses import CrossEntropy, search_loss, task_loss
+from .models import load_ddp_controller, load_ddp_discriminator, load_ddp_model
+from .scheduler import get_dis_optimizer_scheduler, get_optimizer_scheduler
+
+
+def _autocast(args):
+    dt = getattr(args, 'backbone_dtype', 'fp32')
+    if dt == 'bf16' and torch.cuda.is_available():
+        return torch.autocast('cuda', dtype=torch.bfloat16)
+    return torch.autocast('cuda', enabled=False) if torch.cuda.is_available() else torch.autocast('cpu', enabled=False)
+
+
+def _bare(module):
+    return module.module if hasattr(module, 'module') else module
+
+
+def _dice_monitor(seg_output, mask_gt):
+    """Samplewise Dice per class (the reference's torchmetrics F1[1], search_dg.py:57-58) via the fused kernel."""
+    _, dice, _ = _lib.seg_bce_dice(seg_output.float().contiguous(), mask_gt.contiguous(), 1, want_grad=False)
+    return dice
+
+
+def pretrain(config, train_loader, model, discriminator, model_criterion, dis_criterion, model_optimizer,
+             dis_optimizer, epoch, writer_dict, logger, args=None):
+    """Warm-up epoch on the un-augmented images (search_dg.py:24-99)."""
+    batch_time, seg_losses, dis_losses = utils.AverageMeter(), utils.AverageMeter(), utils.AverageMeter()
+    model.train()
+    discriminator.train()
+    end = time.time()
+    for i, sample in enumerate(train_loader):
+        input, mask_gt = sample['image'], sample['label']
+        domain_gt = sample.get('dc_image', sample['dc'])
+        with _autocast(args):
+            seg_output, feature = model(input)
+        dis_output = discriminator(feature.detach().float())
+        seg_loss = model_criterion(torch.sigmoid(seg_output.float()), mask_gt)
+        dis_loss = dis_criterion(dis_output, domain_gt)
+        model_optimizer.zero_grad(set_to_none=True)
+        seg_loss.backward()
+        model_optimizer.step()
+        dis_optimizer.zero_grad(set_to_none=True)
+        dis_loss.backward()
+        dis_optimizer.step()
+        if i % config.PRINT_FREQ == 0 and logger:
+            seg_losses.update(seg_loss.item(), input.size(0))
+            dis_losses.update(dis_loss.item(), input.size(0))
+            batch_time.update(time.time() - end)
+            logger.info('Epoch: [{0}][{1}/{2}]\tTime {3:.3f}s\tSpeed {4:.1f} samples/s\tSeg Loss {5:.5f}\tDis Loss {6:.5f}'.format(
+                epoch, i, len(train_loader), batch_time.val, input.size(0) / max(batch_time.val, 1e-9), seg_losses.val, dis_losses.val))
+        end = time.time()
+
+
+def inner_iteration(config, sample, model, discriminator, dis_criterion, model_optimizer, dis_optimizer, M, rewards,
+                    args=None, n_domains=3):
+    """One pass of search_dg.py:123-176 on one collated batch.  Accumulates into `rewards` ([M], device).
+    Returns device scalars (seg_loss, dis_loss, diversity_ot, dice[K]) -- no host sync in here."""
+    input, mask_gt, domain_gt = sample['aug_images'], sample['aug_labels'], sample['dc']
+    lo, hi, n_rows = sample.get('rows', (0, input.size(0), input.size(0)))
+    with _autocast(args):
+        seg_output, feature = model(input)
+    feature = feature.detach().float()
+    # action: EMA-branch embeddings (no grad); bp: online branch trained on the soft domain codes
+    dis_output, domain_feature = discriminator(feature, momentum=True, return_feature=True)
+    dis_loss_bp = dis_criterion(discriminator(feature, momentum=False), domain_gt)
+    # sigmoid + per-policy BCE + Dice, one fused pass (forward + gradient)
+    seg_loss, _, dice = _lib.policy_bce_loss(seg_output.float(), mask_gt, M)
+    with torch.no_grad():
+        logp = torch.log_softmax(dis_output, dim=1)
+        per_row = -(domain_gt * logp).sum(dim=1)
+        dis_loss = per_row.view(-1, M).mean(dim=0).mean()          # mean_j CE(dis_output[j::M], gt[j::M])
+    # reward: all-gather the [rows_local, 128] embeddings once, then ONE kernel for all M x P problems
+    fe_all = domain_feature.contiguous()
+    if hi - lo != n_rows:
+        fe_all = adist.all_gather([fe_all])[0]
+    before = rewards.clone()
+    B = n_rows // (M * n_domains)
+    _lib.sinkhorn_rewards(fe_all, n_domains, B, M, rewards=rewards)
+    diversity_ot = (rewards - before).sum()
+    model_optimizer.zero_grad(set_to_none=True)
+    seg_loss.backward()
+    model_optimizer.step()
+    dis_optimizer.zero_grad(set_to_none=True)
+    dis_loss_bp.backward()
+    dis_optimizer.step()
+    return seg_loss.detach(), dis_loss, diversity_ot, dice
+
+
+def train(config, train_loader, model, discriminator, model_criterion, dis_criterion, model_optimizer, dis_optimizer,
+          M, epoch, writer_dict, logger, args=None, max_iters=None):
+    """One search epoch (search_dg.py:102-214): returns the normalised rewards [M]."""
+    batch_time = utils.AverageMeter()
+    model.train()
+    discriminator.train()
+    dev = next(model.parameters()).device
+    rewards = torch.zeros(M, device=dev)
+    n_domains = len(config.DATASET.DG.TRAIN)
+    length = len(train_loader)
+    end = time.time()
+    for i, sample in enumerate(train_loader):
+        if max_iters is not None and i >= max_iters:
+            break
+        seg_loss, dis_loss, div_ot, dice = inner_iteration(config, sample, model, discriminator, dis_criterion,
+                                                           model_optimizer, dis_optimizer, M, rewards, args, n_domains)
+        if i % config.PRINT_FREQ == 0 and logger:
+            n_img = sample['rows'][2] if 'rows' in sample else sample['aug_images'].size(0)
+            vals = torch.stack([seg_loss, dis_loss, div_ot]).tolist()        # the only host sync, every PRINT_FREQ
+            batch_time.update(time.time() - end)
+            logger.info('Epoch: [{0}][{1}/{2}]\tTime {3:.3f}s\tSpeed {4:.1f} samples/s\tSeg Loss {5:.5f}\t'
+                        'Dis Loss {6:.5f}\tOT {7:.5f}'.format(epoch, i, length, batch_time.val,
+                                                              n_img / max(batch_time.val, 1e-9), *vals))
+            if writer_dict:
+                writer = writer_dict['writer']
+                steps = writer_dict['train_global_steps']
+                writer.add_scalar('train_seg_loss', vals[0], steps)
+                writer.add_scalar('train_dis_loss', vals[1], steps)
+                writer.add_scalar('diversity_ot_distance', vals[2], steps)
+                writer_dict['train_global_steps'] = steps + 1
+        end = time.time()
+    return _lib.normalize_rewards(rewards)          # (r - mean) / (std + 1e-5), search_dg.py:214
+
+
+@torch.no_grad()
+def validate(config, val_loader, model, epoch, writer_dict, logger, args=None):
+    """Thresholded (0.75) Dice on the held-out domain (search_dg.py:217-286).  hd95 (medpy) is not available
+    in this image and is reported as 0 (out of scope)."""
+    model.eval()
+    K = 2 if config.DATASET.NAME == 'optic' else 1
+    sums = torch.zeros(K, device=next(model.parameters()).device)
+    count = 0
+    shift = float(np.log(0.75 / 0.25))               # sigmoid(z) > 0.75  <=>  z - log(3) > 0
+    for sample in val_loader:
+        input, mask_gt = sample['image'], sample['label']
+        with _autocast(args):
+            seg_output, _ = model(input)
+        sums += _dice_monitor(seg_output.float() - shift, mask_gt) * input.size(0)
+        count += input.size(0)
+    dsc = (sums / max(count, 1)).tolist()
+    if logger:
+        logger.info('Test Epoch {} dsc: {}'.format(epoch, ' '.join('%.4f' % d for d in dsc)))
+    if K == 2:
+        return dsc[0], dsc[1], 0.0, 0.0
+    return dsc[0], dsc[0], 0.0, 0.0
+
+
+class SearchState(object):
+    """Everything one policy-search step needs (built once by search_seg_dg_policy / bench.py)."""
+
+    def __init__(self, gpu, ngpus_per_node, config, args):
+        self.config, self.args = config, args
+        self.model, self.batch_size, workers = load_ddp_model(ngpus_per_node, args, config)
+        self.controller, self.M, _ = load_ddp_controller(ngpus_per_node, args, config)
+        self.discriminator, _, _ = load_ddp_discriminator(ngpus_per_node, args, config)
+        rank, world = adist.world()
+        T.set_row_shard(rank, world)
+        _, self.train_loader, self.test_loader = get_seg_dg_dataloader(config, args, self.batch_size, workers)
+        self.model_optimizer, self.model_lrscheduler, self.controller_optimizer = \
+            get_optimizer_scheduler(self.controller, self.model, config)
+        self.dis_optimizer, self.dis_lrscheduler = get_dis_optimizer_scheduler(self.discriminator, config)
+        self.model_criterion = task_loss(config)
+        self.controller_criterion = search_loss(config)
+        self.dis_criterion = CrossEntropy()
+        self.controller_criterion.register_optimizer(self.controller_optimizer)
+
+    def search_step(self, epoch, writer_dict=None, logger=None, max_iters=None):
+        """The epoch body of search_dg.py:338-347: sample M policies -> inject -> train -> EMA -> PPO."""
+        self.controller.train()
+        policies, op_probs, mag_probs, log_probs, entropies = self.controller(self.M)
+        if adist.is_dist():
+            # the controller is replicated, not wrapped: make rank 0's draw authoritative and re-derive the
+            # (graph-carrying) log-probs for it -- evaluate() equals sample()'s log-prob for the same actions
+            torch.distributed.broadcast(policies, 0)
+            log_probs = self.controller.evaluate(policies, self.M)
+        parsed = parse_policies(policies.cpu().detach().numpy(), self.config, logger)
+        self.train_loader.dataset.transforms.transforms[0] = DGMultiPolicy(parsed)
+        normalized_rewards = train(self.config, self.train_loader, self.model, self.discriminator, self.model_criterion,
+                                   self.dis_criterion, self.model_optimizer, self.dis_optimizer, self.M, epoch,
+                                   writer_dict, logger, self.args, max_iters)
+        _bare(self.discriminator).momentum_update()
+        losses = self.controller_criterion(self.controller, policies, log_probs, entropies, normalized_rewards)
+        return parsed, op_probs, mag_probs, normalized_rewards, losses
+
+
+def search_seg_dg_policy(gpu, ngpus_per_node, config, args):
+    st = SearchState(gpu, ngpus_per_node, config, args)
+    rank, _ = adist.world()
+    main = rank == 0
+    logger, final_output_dir, writer_dict = None, None, None
+    if main:
+        logger, final_output_dir, tb_log_dir = utils.create_logger(config, args.cfg, 'train')
+        writer_dict = {'writer': utils.make_summary_writer(tb_log_dir), 'train_global_steps': 0, 'valid_global_steps': 0}
+    best_dsc = 0
+    best_metric = {'epoch': 0, 'avg_dsc': 0, 'cup_dsc': 0, 'disc_dsc': 0, 'avg_hd': 0, 'cup_hd': 0, 'disc_hd': 0}
+    mag_probs_trajectory, op_probs_trajectory = [], []
+    end_epoch = min(config.TRAIN.END_EPOCH, getattr(args, 'max_epochs', None) or config.TRAIN.END_EPOCH)
+    for epoch in range(config.TRAIN.BEGIN_EPOCH, end_epoch):
+        searching = config.TRAIN.WARMUP_EPOCH <= epoch
+        if not searching:
+            pretrain(config, st.train_loader, st.model, st.discriminator, st.model_criterion, st.dis_criterion,
+                     st.model_optimizer, st.dis_optimizer, epoch, writer_dict, logger, args)
+        else:
+            if config.TRAIN.WARMUP_EPOCH == epoch:
+                _bare(st.discriminator).synchronize_parameters()
+            parsed, op_probs, mag_probs, _, (controller_loss, score_loss, entropy_penalty) = \
+                st.search_step(epoch, writer_dict, logger)
+        st.model_lrscheduler.step()
+        st.dis_lrscheduler.step()
+        cup_dsc, disc_dsc, cup_hd, disc_hd = validate(config, st.test_loader, st.model, epoch, writer_dict, logger, args)
+        dsc, hd = (cup_dsc + disc_dsc) / 2, (cup_hd + disc_hd) / 2
+        is_best = dsc > best_dsc
+        if is_best:
+            best_dsc = dsc
+            best_metric = {'epoch': epoch + 1, 'avg_dsc': dsc, 'cup_dsc': cup_dsc, 'disc_dsc': disc_dsc,
+                           'avg_hd': hd, 'cup_hd': cup_hd, 'disc_hd': disc_hd}
+        if main and searching:
+            mag_probs_trajectory.append(mag_probs.detach().cpu().numpy())
+            op_probs_trajectory.append(op_probs.detach().cpu().numpy())
+            logger.info('Train Epoch {}: controller loss:{:.4f} score loss:{:.4f} entropy penalty:{:.4f}'.format(
+                epoch, controller_loss.item(), score_loss.item(), entropy_penalty.item()))
+            utils.save_checkpoint({"state_dict": _bare(st.model), "epoch": epoch + 1, "best_dsc": best_dsc,
+                                   "optimizer": st.model_optimizer.state_dict(), "policies": parsed},
+                                  is_best, final_output_dir, 'checkpoint_{}.pth'.format(epoch))
+    if main:
+        torch.save(_bare(st.model).state_dict(), os.path.join(final_output_dir, 'final_model_state.pth'))
+        torch.save(st.controller.state_dict(), os.path.join(final_output_dir, 'final_controller_state.pth'))
+        np.save(os.path.join(final_output_dir, 'mag_probs_trajectory.npy'), np.array(mag_probs_trajectory))
+        np.save(os.path.join(final_output_dir, 'op_probs_trajectory.npy'), np.array(op_probs_trajectory))
+        with open(os.path.join(final_output_dir, 'final_result.json'), 'w') as f:
+            f.write(json.dumps(best_metric))
+        if writer_dict and writer_dict['writer'] is not None:
+            writer_dict['writer'].close()
+    return best_metric
+
+
+search_seg2d_dg_policy = search_seg_dg_policy      # the RVS entry point of the reference (search_dg_2d.py:284)

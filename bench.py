@@ -1,0 +1,245 @@
+"""Benchmark of the AADG policy-search hot path on MI355X (driver contract: see the task statement).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A *step* is one policy-search step: controller(M) -> parse_policies -> policy injection ->
+ONE inner iteration over the N = D*B*M augmented images (fused uint8 augmentation kernels -> DeepLabV3+
+forward/backward + Adam -> discriminator forward/backward + Adam -> fused BCE/Dice kernel -> fused Sinkhorn
+reward kernel) -> reward normalisation -> PPO update (5 controller updates).  Workload = BASELINE.json
+configs[1]: DeepLabv3+/ResNet-50, 3 Fundus-like source domains, 512x512, B=8, M=6 (N = 144), synthetic data,
+random-init weights.  With N GPUs the SAME 144 rows are sharded over the ranks (strong scaling); the exchange
+steps are one all-gather of the [144/G,128] embeddings and the DDP gradient all-reduce.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      dominant HIP kernel (the fused resample/crop/normalise/store kernel of the augmentation path):
+                algorithmic bytes per launch / its average duration, timed with HIP events recorded on the launch
+                stream around exactly that kernel inside the timed region (aadg_aug_u8_forward_ex);
+  cpu_baseline  the CPU oracle (oracle/aadg_oracle.c, a scalar restatement of the reference's Pillow/geomloss
+                path) timed on this host on a bounded sample, for the same hot-path work;
+  hot_path      the same step with the backbone removed (features/logits = fixed random tensors), i.e. only the
+                parts this repository implements as HIP kernels -- the figure comparable with cpu_baseline.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+# MIOpen: use the fast find mode (heuristics + find-db) instead of the exhaustive per-shape search, which costs
+# ~15 minutes of warm-up for the ~60 convolution shapes of DeepLabV3+/ResNet-50 at 144x512x512.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=8, help="TRAIN.BATCH_SIZE (items; each item = one image per domain)")
+    ap.add_argument("--backbone", default="resnet50")
+    ap.add_argument("--backbone_dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_units", type=int, default=24, help="units of the CPU-baseline sample")
+    return ap.parse_args()
+
+
+class Args(object):
+    pass
+
+
+def build_state(a, local_rank, world):
+    from aadg_amd.config.defaults import get_default_config
+    from aadg_amd.search_dg import SearchState
+    cfg = get_default_config()
+    cfg.merge_from_file(os.path.join(ROOT, "experiments", "optic_sinkhorn", "diversity.yaml"))
+    cfg.MODEL.BACKBONE = a.backbone
+    cfg.TRAIN.BATCH_SIZE = a.batch
+    cfg.SEED = 1023
+    cfg.PRINT_FREQ = 10 ** 9
+    cfg.freeze()
+    args = Args()
+    args.gpu, args.workers, args.distributed = local_rank, 0, world > 1
+    args.crop_size, args.backbone_dtype, args.epoch_items = a.size, a.backbone_dtype, a.batch
+    st = SearchState(local_rank, world, cfg, args)
+    st.discriminator.synchronize_parameters()       # what the driver does at epoch == WARMUP_EPOCH
+    return cfg, st
+
+
+def algorithmic_bytes(units, Hs, Ws, crop, K):
+    """per output image read 3*Hs*Ws source bytes (x2 when the sub-policy contains a
+    histogram/mean op: AutoContrast, Equalize, Contrast) + Hs*Ws mask bytes; write (3+K)*crop^2*4 bytes."""
+    total = 0
+    for u in units:
+        ops = [int(u["op"][k]) for k in range(int(u["n_ops"]))]
+        hist = any(o in (0, 2, 5) for o in ops)
+        total += 3 * Hs * Ws * (2 if hist else 1) + Hs * Ws + (3 + K) * crop * crop * 4
+    return total
+
+
+def cpu_baseline(cfg, st, a, n_units):
+    """Oracle (CPU restatement) on a bounded sample of the same workload, rank 0 only."""
+    from oracle import oracle as O
+    from aadg_amd.data import transform as T
+    O.lib()
+    rs = np.random.RandomState(0)
+    # same kind of batch plan as the timed steps
+    batch = [st.train_loader.dataset[0] for _ in range(a.batch)]
+    flat, refs, M = T.collect_refs(batch, nested=True)
+    S = len(flat)
+    units = T.refs_to_units(refs[S:])
+    n_units = min(n_units, len(units))
+    sel = rs.choice(len(units), n_units, replace=False)
+    pool = st.train_loader.dataset.pool
+    imgs, msks = pool.images.cpu().numpy(), pool.masks.cpu().numpy()
+    t0 = time.perf_counter()
+    O.aug_units(imgs, msks, units[sel], a.size, 0)
+    t_aug = (time.perf_counter() - t0) / n_units * len(units)
+    D, B = len(cfg.DATASET.DG.TRAIN), a.batch
+    fe = rs.randn(D * B * M, 128).astype(np.float32)
+    fe = np.where(fe > 0, fe, 0.2 * fe)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        O.sinkhorn_rewards(fe, D, B, M)
+    t_sink = (time.perf_counter() - t0) / 3
+    z = rs.randn(4, 2, a.size, a.size).astype(np.float32)
+    y = (rs.rand(4, 2, a.size, a.size) > 0.5).astype(np.float32)
+    t0 = time.perf_counter()
+    O.policy_bce(z, y, 1)
+    O.dice(z, y)
+    t_loss = (time.perf_counter() - t0) / 4 * len(units)
+    total = t_aug + t_sink + t_loss
+    return {"value": 1.0 / total, "unit": "hot-path steps/s (augmentation + Sinkhorn reward + BCE/Dice of one 144-image batch; backbone excluded)",
+            "cores": 1, "kind": "port",
+            "sample": "%d of %d augmentation units at %dx%d, 3 full reward loops (18 Sinkhorn problems), BCE+Dice on 4 of %d images; "
+                      "scaled to one batch: aug %.2fs + reward %.4fs + loss %.2fs" % (n_units, len(units), a.size, a.size, len(units), t_aug, t_sink, t_loss),
+            "seconds_per_step": total}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU product path)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.backends.cudnn.benchmark = False
+    for seed_fn in (random.seed, np.random.seed, torch.manual_seed):
+        seed_fn(1023)                                # identical on every rank: identical batch plans and policies
+    from aadg_amd import _lib
+    _lib.load()
+    cfg, st = build_state(a, local_rank, world)
+    M, D = st.M, len(cfg.DATASET.DG.TRAIN)
+    n_rows = D * a.batch * M
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        st.search_step(i, max_iters=1)
+    sync()
+    # events around the dominant kernel, one pair per timed step (recorded on the launch stream)
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    for e0, e1 in pairs:
+        e0.record(); e1.record()                     # force creation of the underlying hipEvent_t
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        _lib.PROFILE_EVENTS = pairs[i]
+        st.search_step(a.warmup + i, max_iters=1)
+    _lib.PROFILE_EVENTS = None
+    sync()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed / a.steps * 1e3
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in pairs]))
+
+    # ---- the same step with the backbone removed (only what this repo implements) ------------------
+    from aadg_amd.data import transform as T
+    from aadg_amd.data.policy import DGMultiPolicy, parse_policies
+    K = 2
+    lo, hi = (rank * n_rows // world, (rank + 1) * n_rows // world)
+    z = torch.randn(hi - lo, K, a.size, a.size, device="cuda", requires_grad=True)
+    fe = torch.nn.functional.leaky_relu(torch.randn(n_rows, 128, device="cuda"), 0.2)
+    rewards = torch.zeros(M, device="cuda")
+
+    def hot_step():
+        policies, _, _, log_probs, entropies = st.controller(M)
+        parsed = parse_policies(policies.cpu().numpy(), cfg, None)
+        st.train_loader.dataset.transforms.transforms[0] = DGMultiPolicy(parsed)
+        sample = next(iter(st.train_loader))
+        loss, _, _ = _lib.policy_bce_loss(z, sample['aug_labels'], M)
+        loss.backward()
+        rewards.zero_()
+        _lib.sinkhorn_rewards(fe, D, a.batch, M, rewards=rewards)
+        st.controller_criterion(st.controller, policies, log_probs, entropies, _lib.normalize_rewards(rewards))
+        return sample
+
+    units_last = None
+    for _ in range(2):
+        hot_step()
+    sync()
+    t0 = time.perf_counter()
+    HK = max(a.steps, 10)
+    for _ in range(HK):
+        hot_step()
+    sync()
+    hot_ms = (time.perf_counter() - t0) / HK * 1e3
+
+    # algorithmic bytes of one launch of the dominant kernel (this rank's slice of one batch plan)
+    batch = [st.train_loader.dataset[0] for _ in range(a.batch)]
+    flat, refs, _ = T.collect_refs(batch, nested=True)
+    S = len(flat)
+    lo_s, hi_s = rank * S // world, (rank + 1) * S // world
+    units = T.refs_to_units(refs[lo_s:hi_s] + refs[S + lo:S + hi])
+    alg = algorithmic_bytes(units, a.size, a.size, a.size, K)
+    achieved = alg / (kern_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "policy-search steps/sec", "value": 1e3 / ms_per_step, "unit": "steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8+f32 (augmentation / Sinkhorn / loss kernels); backbone %s" % a.backbone_dtype,
+            "data": "synthetic",
+            "inner_loop_img_per_s": n_rows * 1e3 / ms_per_step,
+            "config": {"workload": "BASELINE configs[1]: DeepLabv3+/%s, 3-domain Fundus-like OD/OC Sinkhorn search, %dx%d, "
+                                   "TRAIN.BATCH_SIZE=%d, CONTROLLER.M=%d -> %d augmented images per step, PPO controller"
+                                   % (a.backbone, a.size, a.size, a.batch, M, n_rows),
+                       "images_per_step": n_rows, "parallelism": "rows sharded over %d GPU(s)" % world,
+                       "backbone_dtype": a.backbone_dtype},
+            "roofline": {"bound": "hbm", "kernel": "k_final (resample+crop+normalise+CHW store)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms},
+            "hot_path": {"ms_per_step": hot_ms, "steps_per_s": 1e3 / hot_ms, "img_per_s": n_rows * 1e3 / hot_ms,
+                         "what": "controller sample + parse + draw + augmentation kernels + BCE/Dice kernel (fwd+bwd) + "
+                                 "Sinkhorn kernel + reward normalise + PPO; backbone and discriminator removed"},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, st, a, a.cpu_units)
+            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

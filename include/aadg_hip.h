@@ -85,6 +85,12 @@ size_t aadg_aug_u8_workspace_bytes(int N, int Hs, int Ws, int crop);
 int aadg_aug_u8_forward(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,
                         const aadg_unit* units, int N, int max_ops, int crop, int dataset,
                         float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream);
+/* Same, plus two optional hipEvent_t (may be NULL) recorded on `stream` immediately before and after the
+ * dominant kernel (the fused resample/normalise/store kernel), so a caller can time exactly that kernel. */
+int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,
+                           const aadg_unit* units, int N, int max_ops, int crop, int dataset,
+                           float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream,
+                           void* ev_before_final, void* ev_after_final);
 
 /* One registry op on one image, replaces fn(img, mask, v) of augment_list()
  * (data/basic.py:70-120,137-167) for uint8 HWC tensors.  ws >= aadg_aug_u8_workspace_bytes(1,H,W,0);
@@ -119,7 +125,7 @@ int aadg_normalize_rewards_f32(const float* rewards, int M, float* out, void* st
  *   torchmetrics F1(num_classes=2, average=None, mdmc_average='samplewise')[1]  (:164-165)
  * logits/labels float [N, K, HW]; out_bce[M]; out_dice[K]; optional grad_logits (d mean_j BCE_j / dz).
  * ------------------------------------------------------------------------------------------- */
-size_t aadg_seg_loss_workspace_bytes(int N, int K);
+size_t aadg_seg_loss_workspace_bytes(int N, int K, int HW);
 int aadg_seg_bce_dice_f32(const float* logits, const float* labels, int N, int K, int HW, int M,
                           float* out_bce, float* out_dice, float* grad_logits, void* ws,
                           size_t ws_bytes, void* stream);

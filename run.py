@@ -1,0 +1,47 @@
+"""Entry point with the reference's CLI (run.py:14-67):  python run.py --cfg experiments/<...>.yaml
+[--mode search] [--gpu N] [--multiprocessing_distributed] [--dist_backend nccl] [--dist_url ...] ...
+
+Extra, optional flags (not in the reference): --crop_size (the reference hard-codes 256),
+--backbone_dtype {fp32,bf16}, --max_epochs / --epoch_items (short synthetic runs)."""
+import argparse
+import sys
+
+from aadg_amd.config.defaults import _C as config
+from aadg_amd.config.defaults import update_config
+from aadg_amd.search import lanuch_mp_worker, search_worker
+
+
+def parse_args(argv=None):
+    parser = argparse.ArgumentParser(description='Adversarial AutoAugment (MI355X-native hot path)')
+    parser.add_argument('-j', '--workers', default=4, type=int, metavar='N')
+    parser.add_argument('--world_size', default=-1, type=int)
+    parser.add_argument('--rank', default=-1, type=int)
+    parser.add_argument('--dist_url', default='tcp://localhost:10001', type=str)
+    parser.add_argument('--dist_backend', default='nccl', type=str)
+    parser.add_argument('--gpu', default=0, type=int)
+    parser.add_argument('--gpus', default=1, type=int)
+    parser.add_argument('--multiprocessing_distributed', action='store_true')
+    parser.add_argument('--smoke_test', action='store_true')
+    parser.add_argument('--mode', default='search')
+    parser.add_argument('--cfg', required=True, type=str)
+    parser.add_argument('--output_dir', default='output', type=str)
+    parser.add_argument('--vis_dir', default='vis', type=str)
+    parser.add_argument('--output_type', default='image', type=str)
+    parser.add_argument('--seed', default=1023, type=int)
+    parser.add_argument('--crop_size', default=256, type=int)
+    parser.add_argument('--backbone_dtype', default='fp32', choices=['fp32', 'bf16'])
+    parser.add_argument('--max_epochs', default=None, type=int)
+    parser.add_argument('--epoch_items', default=32, type=int)
+    return parser.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    update_config(config, args)
+    if args.mode == 'search':
+        return lanuch_mp_worker(search_worker, config, args)
+    raise NotImplementedError("Only --mode search is on the hot path (train/test are out of scope, SURVEY.md section 2).")
+
+
+if __name__ == '__main__':
+    main()

@@ -198,10 +198,72 @@ def gen_pipeline():
     np.savez_compressed(os.path.join(OUT, "pipeline.npz"), **out)
 
 
+def gen_controller():
+    """Controller sample/evaluate, PPO and REINFORCE updates, momentum discriminator (CPU; the
+    reference's hard-wired .cuda() calls are neutralised)."""
+    import torch
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    from models.controller import Controller
+    from models.discriminator import MomentumFeatureDiscriminator
+    import losses as RL
+    out = {}
+    for tag, excl in (("full", []), ("excl", ["Cutout"])):
+        cfg = Cfg(EXCLUDE_OPS=excl)
+        cfg.CONTROLLER.T, cfg.CONTROLLER.C, cfg.CONTROLLER.PENALTY, cfg.CONTROLLER.LOSS = 2, 2.5, 1e-5, 'ppo'
+        torch.manual_seed(1023)
+        c = Controller(cfg)
+        for k, v in c.state_dict().items():
+            out["%s_sd_%s" % (tag, k)] = v.numpy().copy()
+        torch.manual_seed(7)
+        policies, op_probs, mag_probs, log_probs, entropies = c(6)
+        out[tag + "_policies"] = policies.numpy()
+        out[tag + "_op_probs"] = op_probs.detach().numpy()
+        out[tag + "_mag_probs"] = mag_probs.detach().numpy()
+        out[tag + "_log_probs"] = log_probs.detach().numpy()
+        out[tag + "_entropies"] = entropies.detach().numpy()
+        out[tag + "_evaluate"] = c.evaluate(policies, 6).detach().numpy()
+        reward = torch.tensor([0.3, -1.2, 0.8, 1.1, -0.4, -0.6])
+        out[tag + "_reward"] = reward.numpy()
+        opt = torch.optim.Adam(c.parameters(), lr=0.00035)
+        crit = RL.ProximalPolicyOptimization(cfg)
+        crit.register_optimizer(opt)
+        loss, score, ent = crit(c, policies, log_probs, entropies, reward)
+        out[tag + "_ppo"] = np.array([loss.item(), score.item(), ent.item()], np.float64)
+        out[tag + "_ppo_evaluate_after"] = c.evaluate(policies, 6).detach().numpy()
+        # REINFORCE on a fresh controller
+        torch.manual_seed(1023)
+        c2 = Controller(cfg)
+        torch.manual_seed(7)
+        policies, _, _, log_probs, entropies = c2(6)
+        opt2 = torch.optim.Adam(c2.parameters(), lr=0.00035)
+        crit2 = RL.Reinforce(cfg)
+        crit2.register_optimizer(opt2)
+        loss, score, ent = crit2(c2, policies, log_probs, entropies, reward)
+        out[tag + "_reinforce"] = np.array([loss.item(), score.item(), ent.item()], np.float64)
+        out[tag + "_reinforce_evaluate_after"] = c2.evaluate(policies, 6).detach().numpy()
+    torch.manual_seed(3)
+    d = MomentumFeatureDiscriminator(3, 64)
+    x = torch.randn(12, 64)
+    out["disc_x"] = x.numpy()
+    for k, v in d.state_dict().items():
+        out["disc_sd_" + k] = v.numpy().copy()
+    logits, fe = d(x, momentum=True, return_feature=True)
+    out["disc_mom_logits"], out["disc_mom_fe"] = logits.numpy(), fe.numpy()
+    out["disc_logits"] = d(x, momentum=False).detach().numpy()
+    d.momentum_update()
+    logits, fe = d(x, momentum=True, return_feature=True)
+    out["disc_mom_fe_after_update"] = fe.numpy()
+    t = torch.softmax(torch.randn(12, 3), dim=1)
+    out["ce_target"] = t.numpy()
+    out["ce_value"] = np.array(RL.CrossEntropy()(d(x), t).item())
+    np.savez_compressed(os.path.join(OUT, "controller.npz"), **out)
+
+
 if __name__ == "__main__":
     install_stubs()
     gen_ops()
     gen_parse()
     gen_pipeline()
+    gen_controller()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,130 @@
+"""GPU parity tests for the uint8 augmentation path: HIP (through the C ABI) vs the oracle and vs
+the reference's golden vectors.  Bit-exact everywhere (integer / Pillow fixed-point work; the float32
+outputs are a pure function of a byte)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, draw_batch, load_pipeline_golden, random_units, synth_pool
+
+pytestmark = pytest.mark.gpu
+
+
+def test_eager_ops_vs_reference_golden(hip):
+    """aadg_op_u8 (the registry op entry point) against reference apply_augment outputs."""
+    from aadg_amd.data import basic
+    z = np.load(os.path.join(GOLDEN, "u8_ops.npz"))
+    names = [str(n) for n in z["op_names"]]
+    for tag in ("a", "b"):
+        img = torch.from_numpy(z["img_" + tag]).cuda()
+        msk = torch.from_numpy(z["mask_" + tag]).cuda()
+        for oi, name in enumerate(names):
+            for li in range(10):
+                np.random.seed(1000 * oi + li)
+                o, m = basic.apply_augment(img, msk, name, li / 9)
+                assert np.array_equal(o.cpu().numpy(), z["out_" + tag][oi, li]), (tag, name, li)
+                assert np.array_equal(m.cpu().numpy(), z["mout_" + tag][oi, li]), (tag, name, li)
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_pipeline_seed_for_seed_vs_reference(hip, case):
+    """Whole collate on the GPU, seeded like the reference run: identical tensors."""
+    from aadg_amd.data import transform as T
+    z, meta = load_pipeline_golden()
+    m = meta[case]
+    name = m["name"]
+    pool, flat, refs, M = draw_batch(z[name + "_pool_img"], z[name + "_pool_msk"], z[name + "_policies"], m, "cuda")
+    img, lbl = T.materialize(refs)
+    S = len(flat)
+    lut = z["lut256"]
+    img, lbl = img.cpu().numpy(), lbl.cpu().numpy()
+    assert np.array_equal(img[:S], lut[z[name + "_image"]])
+    assert np.array_equal(lbl[:S], z[name + "_label"].astype(np.float32))
+    assert np.array_equal(img[S:], lut[z[name + "_aug_images"]])
+    assert np.array_equal(lbl[S:], z[name + "_aug_labels"].astype(np.float32))
+
+
+@pytest.mark.parametrize("H,W,crop,sr,kind,N", [
+    (64, 64, 64, (1.0, 1.5), 0, 96),      # optic-like, upscale
+    (40, 52, 48, (1.0, 1.5), 0, 64),      # non-square source, pad on one axis
+    (96, 96, 64, (0.5, 2.0), 1, 96),      # rvs-like, antialiased downscale, K=1
+    (30, 30, 50, (0.5, 2.0), 1, 48),      # always padded
+    (33, 35, 31, (1.0, 1.5), 0, 40),      # odd sizes: scalar (non-vector) code paths
+    (256, 256, 256, (1.0, 1.5), 0, 36),   # the reference's own size
+])
+def test_random_units_vs_oracle(hip, oracle, H, W, crop, sr, kind, N):
+    rs = np.random.RandomState(H * 1000 + W)
+    P = 5
+    imgs, msks = synth_pool(rs, P, H, W, vessel=(kind == 1))
+    imgs[1] = rs.randint(0, 256, imgs[1].shape)   # one pure-noise image
+    imgs[2][...] = 93                              # one constant image (degenerate histograms)
+    units = random_units(rs, N, P, H, W, crop, sr)
+    want_img, want_lbl = oracle.aug_units(imgs, msks, units, crop, kind)
+    got_img, got_lbl = hip.aug_u8_forward(torch.from_numpy(imgs).cuda(), torch.from_numpy(msks).cuda(), units, crop, kind)
+    got_img, got_lbl = got_img.cpu().numpy(), got_lbl.cpu().numpy()
+    bad = [i for i in range(N) if not np.array_equal(got_img[i], want_img[i])]
+    assert not bad, "image mismatch in units %s: %s" % (bad[:5], units[bad[:1]])
+    assert np.array_equal(got_lbl, want_lbl)
+
+
+def test_three_and_four_op_chains(hip, oracle):
+    rs = np.random.RandomState(3)
+    imgs, msks = synth_pool(rs, 4, 48, 48)
+    units = random_units(rs, 64, 4, 48, 48, 48, (1.0, 1.5), L=4)
+    want_img, want_lbl = oracle.aug_units(imgs, msks, units, 48, 0)
+    got_img, got_lbl = hip.aug_u8_forward(torch.from_numpy(imgs).cuda(), torch.from_numpy(msks).cuda(), units, 48, 0)
+    assert np.array_equal(got_img.cpu().numpy(), want_img)
+    assert np.array_equal(got_lbl.cpu().numpy(), want_lbl)
+
+
+def test_full_size_properties(hip, oracle):
+    """BASELINE size (512x512, N=144): identity round trip, determinism, and an oracle spot check."""
+    rs = np.random.RandomState(1023)
+    H = W = crop = 512
+    P, N = 24, 144
+    imgs, msks = synth_pool(rs, P, H, W)
+    d_img, d_msk = torch.from_numpy(imgs).cuda(), torch.from_numpy(msks).cuda()
+    # (a) no ops, no scale, full crop == u8/127.5-1 of the source, exactly
+    ident = np.zeros(P, hip.UNIT_DTYPE)
+    ident['rect'][:, :, 2:] = -1
+    ident['src'] = np.arange(P)
+    ident['scaled_w'], ident['scaled_h'] = W, H
+    oi, ol = hip.aug_u8_forward(d_img, d_msk, ident, crop, 0)
+    lut = (np.arange(256, dtype=np.float32) / np.float32(127.5)) - np.float32(1.0)
+    assert np.array_equal(oi.cpu().numpy(), lut[imgs].transpose(0, 3, 1, 2))
+    assert np.array_equal(ol[:, 0].cpu().numpy(), (msks <= 50).astype(np.float32))
+    assert np.array_equal(ol[:, 1].cpu().numpy(), (msks <= 200).astype(np.float32))
+    # (b) Invert twice is the identity (an involution through two full op stages)
+    inv2 = ident.copy()
+    inv2['n_ops'] = 2
+    inv2['op'][:, 0] = inv2['op'][:, 1] = 1
+    oi2, _ = hip.aug_u8_forward(d_img, d_msk, inv2, crop, 0)
+    assert torch.equal(oi, oi2)
+    # (c) the real workload: deterministic, and equal to the oracle on a sample of units
+    units = random_units(rs, N, P, H, W, crop, (1.0, 1.5))
+    a_img, a_lbl = hip.aug_u8_forward(d_img, d_msk, units, crop, 0)
+    b_img, b_lbl = hip.aug_u8_forward(d_img, d_msk, units, crop, 0)
+    assert torch.equal(a_img, b_img) and torch.equal(a_lbl, b_lbl)
+    sel = np.arange(0, N, 12)
+    w_img, w_lbl = oracle.aug_units(imgs, msks, units[sel], crop, 0)
+    assert np.array_equal(a_img[torch.from_numpy(sel).cuda()].cpu().numpy(), w_img)
+    assert np.array_equal(a_lbl[torch.from_numpy(sel).cuda()].cpu().numpy(), w_lbl)
+
+
+def test_bad_arguments_raise(hip):
+    imgs = torch.zeros((2, 16, 16, 3), dtype=torch.uint8, device="cuda")
+    msks = torch.zeros((2, 16, 16), dtype=torch.uint8, device="cuda")
+    u = np.zeros(1, hip.UNIT_DTYPE)
+    u['scaled_w'] = u['scaled_h'] = 16
+    u['src'] = 5
+    with pytest.raises(hip.AadgError):
+        hip.aug_u8_forward(imgs, msks, u, 16, 0)
+    u['src'] = 0
+    u['scaled_w'] = 4  # below 1/3 scale
+    with pytest.raises(hip.AadgError):
+        hip.aug_u8_forward(imgs, msks, u, 16, 0)
+    with pytest.raises(hip.AadgError):
+        hip.aug_u8_forward(imgs.cpu(), msks.cpu(), u, 16, 0)

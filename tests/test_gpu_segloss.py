@@ -1,0 +1,40 @@
+"""GPU parity: fused per-policy BCE + Dice (+ gradient) kernel vs the oracle and vs plain torch fp32
+(tolerance 1e-4 on the losses, north_star: Dice within 1e-4 fp32; Dice itself is count-exact)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,K,H,W,M", [(12, 2, 32, 32, 6), (6, 1, 40, 36, 3), (18, 2, 17, 19, 6), (8, 2, 256, 256, 2)])
+def test_bce_dice_and_grad(hip, oracle, N, K, H, W, M):
+    rs = np.random.RandomState(N * H + W)
+    z = (rs.randn(N, K, H, W) * 3).astype(np.float32)
+    z[0, 0, 0, :4] = [60.0, -60.0, 120.0, -120.0]          # saturated logits: clamped logs / eps-guarded gradient
+    y = (rs.rand(N, K, H, W) > 0.6).astype(np.float32)
+    zt = torch.from_numpy(z).cuda().requires_grad_(True)
+    yt = torch.from_numpy(y).cuda()
+    loss, bce, dice = hip.policy_bce_loss(zt, yt, M)
+    loss.backward()
+    want_bce = oracle.policy_bce(z, y, M)
+    assert np.abs(bce.detach().cpu().numpy() - want_bce).max() < 1e-4 * max(1.0, want_bce.max())
+    assert np.abs(dice.detach().cpu().numpy() - oracle.dice(z, y)).max() < 1e-6
+    # plain torch fp32 reference of the same op (search_dg.py:140-142)
+    zr = torch.from_numpy(z).cuda().requires_grad_(True)
+    p = torch.sigmoid(zr)
+    ref = torch.stack([torch.nn.functional.binary_cross_entropy(p[j::M], yt[j::M]) for j in range(M)]).mean()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-4 * max(1.0, abs(ref.item()))
+    assert (zt.grad - zr.grad).abs().max().item() < 1e-6 + 1e-3 * zr.grad.abs().max().item()
+
+
+def test_full_size_property(hip):
+    """BASELINE size: logits == +/-20 exactly on the labels -> Dice 1, BCE ~ 2e-9; flipped -> Dice 0."""
+    N, K, S, M = 24, 2, 512, 6
+    y = (torch.rand(N, K, S, S, device="cuda") > 0.5).float()
+    z = (y * 2 - 1) * 20
+    bce, dice, _ = hip.seg_bce_dice(z, y, M)
+    assert torch.all(dice == 1.0) and bce.max().item() < 1e-7
+    bce, dice, _ = hip.seg_bce_dice(-z, y, M)
+    assert torch.all(dice == 0.0) and abs(bce.mean().item() - 20.0) < 1e-3

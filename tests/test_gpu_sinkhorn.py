@@ -1,0 +1,85 @@
+"""GPU parity tests for the fused Sinkhorn reward kernel vs the oracle (geomloss-0.2.4 semantics).
+Tolerance: |HIP - oracle| <= 1e-5 absolute (north_star: Sinkhorn within 1e-4 fp32)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def features(rs, D, B, M, E=128):
+    """LeakyReLU_0.2(randn*0.5 + domain mean), rows in collate order (b*D+d)*M+j."""
+    means = rs.randn(D, E).astype(np.float32)
+    fe = np.empty((D * B * M, E), np.float32)
+    for b in range(B):
+        for d in range(D):
+            for j in range(M):
+                v = rs.randn(E).astype(np.float32) * 0.5 + means[d] * (0.3 + 0.1 * j)
+                fe[(b * D + d) * M + j] = np.where(v > 0, v, 0.2 * v)
+    return fe
+
+
+def test_rewards_vs_oracle(hip, oracle):
+    rs = np.random.RandomState(1023)
+    for (D, B, M) in [(3, 8, 6), (2, 4, 3), (8, 8, 6), (3, 5, 1)]:
+        fe = features(rs, D, B, M)
+        want = oracle.sinkhorn_rewards(fe, D, B, M)
+        got = hip.sinkhorn_rewards(torch.from_numpy(fe).cuda(), D, B, M).cpu().numpy()
+        assert np.abs(got - want).max() <= TOL * D * (D - 1) / 2, (D, B, M, got, want)
+        # accumulation semantics: rewards[j] += ...
+        acc = torch.full((M,), 2.0, device="cuda")
+        hip.sinkhorn_rewards(torch.from_numpy(fe).cuda(), D, B, M, rewards=acc)
+        assert np.abs(acc.cpu().numpy() - 2.0 - want).max() <= 1e-4
+
+
+def _tables(sizes, pairs, dev):
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    rows = np.arange(off[-1], dtype=np.int32)
+    return (torch.from_numpy(rows).to(dev), torch.from_numpy(off).to(dev),
+            torch.from_numpy(np.asarray(pairs, np.int32).reshape(-1)).to(dev))
+
+
+def test_general_tables_uneven_clouds(hip, oracle):
+    rs = np.random.RandomState(4)
+    sizes = [8, 3, 17, 1, 40, 64]
+    E = 96
+    x = rs.randn(sum(sizes), E).astype(np.float32)
+    x = np.where(x > 0, x, 0.2 * x) + 0.1
+    pairs = [(0, 1), (1, 2), (2, 4), (3, 0), (4, 5), (5, 5), (2, 2)]
+    rows, off, pxy = _tables(sizes, pairs, "cuda")
+    got = hip.sinkhorn_divergence(torch.from_numpy(x).cuda(), rows, off, pxy, max(sizes)).cpu().numpy()
+    o = np.concatenate([[0], np.cumsum(sizes)])
+    for k, (a, b) in enumerate(pairs):
+        want = oracle.sinkhorn_divergence(x[o[a]:o[a + 1]], x[o[b]:o[b + 1]])
+        assert abs(got[k] - want) <= TOL, (k, a, b, got[k], want)
+    # S(x, x) == 0 and symmetry
+    assert abs(got[5]) <= TOL and abs(got[6]) <= TOL
+    rows, off, pxy = _tables(sizes, [(2, 4), (4, 2)], "cuda")
+    g2 = hip.sinkhorn_divergence(torch.from_numpy(x).cuda(), rows, off, pxy, max(sizes)).cpu().numpy()
+    assert abs(g2[0] - g2[1]) <= TOL
+
+
+def test_known_answers(hip):
+    """N=M=1: S = C(x,y) = 1 - cos(x,y); row permutation invariance; scale invariance of the cosine cost."""
+    rs = np.random.RandomState(9)
+    E = 128
+    x = rs.randn(2, E).astype(np.float32)
+    rows, off, pxy = _tables([1, 1], [(0, 1)], "cuda")
+    got = hip.sinkhorn_divergence(torch.from_numpy(x).cuda(), rows, off, pxy, 1).cpu().numpy()[0]
+    cos = float(x[0] @ x[1] / (np.linalg.norm(x[0]) * np.linalg.norm(x[1])))
+    assert abs(got - (1 - cos)) <= TOL
+    y = np.abs(rs.randn(16, E)).astype(np.float32)
+    rows, off, pxy = _tables([8, 8], [(0, 1)], "cuda")
+    a = hip.sinkhorn_divergence(torch.from_numpy(y).cuda(), rows, off, pxy, 8).cpu().numpy()[0]
+    perm = np.concatenate([rs.permutation(8), 8 + rs.permutation(8)])
+    b = hip.sinkhorn_divergence(torch.from_numpy(y[perm]).cuda(), rows, off, pxy, 8).cpu().numpy()[0]
+    assert abs(a - b) <= TOL
+
+
+def test_normalize_rewards(hip, oracle):
+    r = np.array([0.31, 0.27, 0.45, 0.12, 0.39, 0.30], np.float32)
+    got = hip.normalize_rewards(torch.from_numpy(r).cuda()).cpu().numpy()
+    want = oracle.normalize_rewards(r)
+    ref = (torch.from_numpy(r) - torch.from_numpy(r).mean()) / (torch.from_numpy(r).std() + 1e-5)
+    assert np.abs(got - want).max() <= 1e-6 and np.abs(got - ref.numpy()).max() <= 1e-6

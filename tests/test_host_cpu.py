@@ -1,0 +1,120 @@
+"""CPU suite, part 2: host logic (controller, PPO/REINFORCE, discriminator, config, sharding law)
+against golden vectors produced by the reference (tests/golden/make_golden.py: gen_controller)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, Cfg
+
+
+def _cfg(excl):
+    cfg = Cfg(EXCLUDE_OPS=excl)
+    cfg.CONTROLLER.T, cfg.CONTROLLER.C, cfg.CONTROLLER.PENALTY, cfg.CONTROLLER.LOSS = 2, 2.5, 1e-5, 'ppo'
+    return cfg
+
+
+def _load(tag, z, controller):
+    sd = {k[len(tag) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + "_sd_")}
+    controller.load_state_dict(sd, strict=True)  # same key names as the reference's state_dict
+
+
+@pytest.mark.parametrize("tag,excl", [("full", []), ("excl", ["Cutout"])])
+def test_controller_and_search_losses_match_reference(tag, excl):
+    from aadg_amd.models.controller import Controller
+    from aadg_amd import losses
+    z = np.load(os.path.join(GOLDEN, "controller.npz"))
+    cfg = _cfg(excl)
+    c = Controller(cfg)
+    assert sum(p.numel() for p in c.parameters()) == sum(z[k].size for k in z.files if k.startswith(tag + "_sd_"))
+    _load(tag, z, c)
+    # same torch seed -> same multinomial draws -> the very same policies (CPU generator)
+    torch.manual_seed(7)
+    policies, op_probs, mag_probs, log_probs, entropies = c(6)
+    assert policies.dtype == torch.int64 and tuple(policies.shape) == (6, 20)
+    assert np.array_equal(policies.numpy(), z[tag + "_policies"])           # bit-exact policy indexing
+    assert np.allclose(op_probs.detach().numpy(), z[tag + "_op_probs"], atol=1e-6)
+    assert np.allclose(mag_probs.detach().numpy(), z[tag + "_mag_probs"], atol=1e-6)
+    assert np.allclose(log_probs.detach().numpy(), z[tag + "_log_probs"], atol=1e-5)
+    assert np.allclose(entropies.detach().numpy(), z[tag + "_entropies"], atol=1e-5)
+    ev = c.evaluate(torch.from_numpy(z[tag + "_policies"]), 6)
+    assert np.allclose(ev.detach().numpy(), z[tag + "_evaluate"], atol=1e-5)
+    assert np.allclose(ev.detach().numpy(), log_probs.detach().numpy(), atol=1e-5)  # evaluate == sample log-prob
+    reward = torch.from_numpy(z[tag + "_reward"])
+    opt = torch.optim.Adam(c.parameters(), lr=0.00035)
+    crit = losses.search_loss(cfg)
+    assert isinstance(crit, losses.ProximalPolicyOptimization)
+    crit.register_optimizer(opt)
+    loss, score, ent = crit(c, policies, log_probs, entropies, reward)
+    assert np.allclose([loss.item(), score.item(), ent.item()], z[tag + "_ppo"], atol=1e-5)
+    assert np.allclose(c.evaluate(policies, 6).detach().numpy(), z[tag + "_ppo_evaluate_after"], atol=1e-4)
+    # REINFORCE
+    c2 = Controller(cfg)
+    _load(tag, z, c2)
+    torch.manual_seed(7)
+    policies, _, _, log_probs, entropies = c2(6)
+    cfg.CONTROLLER.LOSS = 'reinforce'
+    crit2 = losses.search_loss(cfg)
+    crit2.register_optimizer(torch.optim.Adam(c2.parameters(), lr=0.00035))
+    loss, score, ent = crit2(c2, policies, log_probs, entropies, reward)
+    assert np.allclose([loss.item(), score.item(), ent.item()], z[tag + "_reinforce"], atol=1e-5)
+    assert np.allclose(c2.evaluate(policies, 6).detach().numpy(), z[tag + "_reinforce_evaluate_after"], atol=1e-4)
+
+
+def test_momentum_discriminator_and_soft_ce_match_reference():
+    from aadg_amd.models.discriminator import MomentumFeatureDiscriminator
+    from aadg_amd.losses import CrossEntropy
+    z = np.load(os.path.join(GOLDEN, "controller.npz"))
+    d = MomentumFeatureDiscriminator(3, 64)
+    d.load_state_dict({k[8:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("disc_sd_")}, strict=True)
+    x = torch.from_numpy(z["disc_x"])
+    logits, fe = d(x, momentum=True, return_feature=True)
+    assert not fe.requires_grad
+    assert np.allclose(fe.numpy(), z["disc_mom_fe"], atol=1e-6) and np.allclose(logits.numpy(), z["disc_mom_logits"], atol=1e-6)
+    assert np.allclose(d(x).detach().numpy(), z["disc_logits"], atol=1e-6)
+    ce = CrossEntropy()(d(x), torch.from_numpy(z["ce_target"]))
+    assert abs(ce.item() - float(z["ce_value"])) < 1e-6
+    d.momentum_update()
+    _, fe2 = d(x, momentum=True, return_feature=True)
+    assert np.allclose(fe2.numpy(), z["disc_mom_fe_after_update"], atol=1e-6)
+    # synchronize_parameters aliases the EMA twin to the online weights (reference quirk, kept)
+    d.synchronize_parameters()
+    with torch.no_grad():
+        d.dis[0].weight.add_(1.0)
+    assert torch.equal(d.dis[0].weight, d.mom_dis[0].weight)
+
+
+def test_reference_style_yaml_configs_load_unchanged():
+    from aadg_amd.config.defaults import get_default_config, update_config
+
+    class Args:
+        output_dir, seed = "out", 1023
+
+    root = os.path.join(os.path.dirname(GOLDEN), "..", "experiments")
+    files = sorted(glob.glob(os.path.join(root, "*", "*.yaml")))
+    assert files, "experiments/*.yaml missing"
+    for f in files:
+        cfg = get_default_config()
+        a = Args()
+        a.cfg = f
+        update_config(cfg, a)
+        assert cfg.is_frozen() and cfg.SEED == 1023 and cfg.OUTPUT_DIR == "out"
+        assert cfg.CONTROLLER.M == 6 and cfg.DATASET.NAME in ("optic", "rvs")
+        with pytest.raises(AttributeError):
+            cfg.SEED = 1
+        cfg.CONTROLLER.EXCLUDE_OPS.append("x")  # list mutation is allowed on a frozen node, as in yacs
+    bad = get_default_config()
+    with pytest.raises(KeyError):
+        bad._merge({"NOT_A_KEY": 1}, [])
+
+
+def test_shard_rows_law():
+    from aadg_amd.distributed import shard_rows
+    for G in (1, 2, 3, 4, 6, 8):
+        spans = [shard_rows(144, r, G) for r in range(G)]
+        assert spans[0][0] == 0 and spans[-1][1] == 144
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    with pytest.raises(ValueError):
+        shard_rows(144, 0, 5)
