@@ -31,8 +31,9 @@ EXPORTS = [
     "aadg_aug_u8_workspace_bytes", "aadg_aug_u8_forward", "aadg_aug_u8_forward_ex", "aadg_op_u8",
     "aadg_sinkhorn_workspace_bytes", "aadg_sinkhorn_divergence_f32", "aadg_sinkhorn_rewards_f32",
     "aadg_normalize_rewards_f32",
+    "aadg_seg_loss_workspace_bytes", "aadg_seg_bce_dice_f32",
+    "aadg_fop_workspace_bytes", "aadg_fop_f32",
 ]
-_PENDING = ["aadg_seg_loss_workspace_bytes", "aadg_seg_bce_dice_f32", "aadg_fop_workspace_bytes", "aadg_fop_f32"]
 
 _lib = None
 _c = ctypes
@@ -55,7 +56,7 @@ def load():
     lib.aadg_aug_u8_forward.restype = _i
     lib.aadg_aug_u8_forward.argtypes = [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]
     lib.aadg_aug_u8_forward_ex.restype = _i
-    lib.aadg_aug_u8_forward_ex.argtypes = lib.aadg_aug_u8_forward.argtypes + [_vp, _vp]
+    lib.aadg_aug_u8_forward_ex.argtypes = lib.aadg_aug_u8_forward.argtypes + [_i, _i, _vp, _vp]
     lib.aadg_op_u8.restype = _i
     lib.aadg_op_u8.argtypes = [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp]
     lib.aadg_sinkhorn_workspace_bytes.restype = _sz
@@ -73,7 +74,7 @@ def load():
         lib.aadg_seg_bce_dice_f32.argtypes = [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]
     if hasattr(lib, "aadg_fop_f32"):
         lib.aadg_fop_workspace_bytes.restype = _sz
-        lib.aadg_fop_workspace_bytes.argtypes = [_i, _i]
+        lib.aadg_fop_workspace_bytes.argtypes = [_i, _i, _i]
         lib.aadg_fop_f32.restype = _i
         lib.aadg_fop_f32.argtypes = [_i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]
     if lib.aadg_abi_version() != 1:
@@ -165,6 +166,23 @@ def validate_units(units, P, Hs, Ws):
     return int(units["n_ops"].max())
 
 
+def launch_hints(units, Hs, Ws, crop):
+    """(classes, stats_mask) for aadg_aug_u8_forward_ex -- mirrors unit_fusable() in csrc/aug_u8.hip."""
+    n_ops = units["n_ops"]
+    live = np.arange(MAX_OPS)[None, :] < n_ops[:, None]
+    sharp = ((units["op"] == 8) & (units["farg"] != np.float32(1.0)) & live).sum(axis=1)
+    fusable = (units["scaled_w"] >= Ws) & (units["scaled_h"] >= Hs) & (sharp <= 2)
+    if (Ws & 3) or (crop & 3):
+        fusable[:] = False
+    classes = (1 if fusable.any() else 0) | (2 if (~fusable).any() else 0)
+    needs = np.isin(units["op"], (0, 2, 5)) & live
+    stats_mask = 0
+    for k in range(MAX_OPS):
+        if needs[:, k].any():
+            stats_mask |= 1 << k
+    return classes, stats_mask
+
+
 # optional (start, stop) torch.cuda.Event pair recorded around the dominant kernel of the next
 # aug_u8_forward call(s); used by bench.py to time that kernel live on the launch stream
 PROFILE_EVENTS = None
@@ -212,12 +230,13 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
     _pinned["units_ready"] = ready
     nb = lib.aadg_aug_u8_workspace_bytes(N, Hs, Ws, crop)
     ws = workspace(nb, dev, "aug")
+    classes, stats_mask = launch_hints(units, Hs, Ws, crop)
     ev0 = ev1 = 0
     if PROFILE_EVENTS is not None:
         ev0, ev1 = PROFILE_EVENTS[0].cuda_event, PROFILE_EVENTS[1].cuda_event
     rc = lib.aadg_aug_u8_forward_ex(pool.data_ptr(), masks.data_ptr(), P, Hs, Ws, d_units.data_ptr(), N, max_ops, crop,
                                     dataset, out_img.data_ptr(), out_lbl.data_ptr(), ws.data_ptr(), ws.numel(), _stream(),
-                                    ev0, ev1)
+                                    classes, stats_mask, ev0, ev1)
     _check(rc, "aadg_aug_u8_forward")
     d_units.record_stream(torch.cuda.current_stream())
     return out_img, out_lbl
@@ -326,3 +345,36 @@ class _PolicyBCE(torch.autograd.Function):
 def policy_bce_loss(logits, labels, M):
     """Drop-in for search_dg.py:140-142 (+ the Dice monitor of :164-165): returns (seg_loss, bce[M], dice[K])."""
     return _PolicyBCE.apply(logits, labels, M)
+
+
+# ------------------------------------------------------------------------------------------------
+FOP = {name: i for i, name in enumerate([
+    "invert", "solarize", "posterize", "gray", "contrast", "auto_contrast", "saturate", "brightness", "hue",
+    "sample_pairing", "equalize", "sharpness", "gaussian_blur3x3", "shear_x", "shear_y", "translate_x",
+    "translate_y", "rotate", "hflip", "vflip"])}
+
+
+def fop(name, img, mag=None, kernel=None, perm=None):
+    """One float tensor op of data/functional.py on a [B,3,H,W] float32 GPU tensor (output clamped to [0,1])."""
+    lib = load()
+    _require_cuda(img, mag, kernel, perm)
+    if img.dtype != torch.float32 or img.dim() != 4 or img.shape[1] != 3:
+        raise AadgError("img must be float32 [B,3,H,W]")
+    B, C, H, W = img.shape
+    out = torch.empty_like(img)
+    mag_n = 0
+    if mag is not None:
+        mag = mag.to(torch.float32).reshape(-1).contiguous()
+        mag_n = mag.numel()
+    if kernel is not None:
+        kernel = kernel.to(torch.float32).reshape(-1).contiguous()
+        if kernel.numel() != 9:
+            raise AadgError("kernel must be 3x3")
+    if perm is not None:
+        perm = perm.to(torch.int32).contiguous()
+    nb = lib.aadg_fop_workspace_bytes(B, H, W)
+    ws = workspace(nb, img.device, "fop")
+    rc = lib.aadg_fop_f32(FOP[name], img.data_ptr(), out.data_ptr(), _ptr(mag), mag_n, _ptr(kernel), _ptr(perm),
+                          B, C, H, W, ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "aadg_fop_f32(%s)" % name)
+    return out

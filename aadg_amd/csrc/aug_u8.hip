@@ -11,13 +11,21 @@
 //   * Image.blend's float32 expression, and
 //   * the final u8/127.5-1 (a correctly rounded float32 division, tabulated per block).
 //
-// Stage kernels (this file, "v1" data flow):
-//   k_hist   per-channel 256-bin histograms + sum of L   (AutoContrast / Equalize / Contrast)
-//   k_lut    builds the 3x256 byte LUT of every LUT-class op (7 of the 10 ops)
-//   k_apply  one op: LUT | Color | Sharpness (3x3 SMOOTH + blend) | Cutout, u8 -> u8
-//   k_tables Pillow BILINEAR coefficient tables + NEAREST index tables for the crop window
-//   k_final  horizontal+vertical fixed-point resample, pad, crop, normalise, HWC u8 -> CHW f32,
-//            mask -> multilabel planes
+// Two data flows share the statistics / LUT / table kernels:
+//
+//  FUSED (units that are not down-scaled, <= 2 Sharpness ops, 4-aligned sizes -- every unit of the optic
+//  configs): nothing but the final tensors is written to HBM.
+//   k_hist        stage 0: per-channel histograms + sum of L of the raw source image
+//   k_hist_fused  stage k>=1: rebuilds the image after k ops tile by tile in LDS and histograms it
+//   k_lut         the 3x256 byte LUT of every LUT-class op (7 of the 10 ops), kept per stage
+//   k_tables      Pillow BILINEAR coefficient tables + NEAREST index tables for the crop window
+//   k_fused       per 256x16 output tile: source patch (+halo) -> LDS as RGBX words (12-byte vector loads),
+//                 the whole op chain applied in LDS (LUT / Color / Cutout in place, Sharpness ping-pong),
+//                 horizontal fixed-point pass -> LDS, vertical pass from LDS (ds_read_b128), pad, /127.5-1 via
+//                 an LDS table, CHW float4 stores, mask gather -> multilabel float4 stores.
+//
+//  STAGED (everything else; also the eager single-op entry point): u8 intermediates in the workspace.
+//   k_hist / k_lut / k_apply per op stage, then k_tables and k_final (gathers from global memory).
 #include "common.h"
 
 namespace {
@@ -27,10 +35,16 @@ constexpr int HIST_STRIDE = 772;  // 768 bins + u64 L-sum + pad (u32 words)
 constexpr int TAB_STRIDE = 2 * KMAX + 4;  // ints per crop position: xmin,xk[KMAX],ymin,yk[KMAX],xnn,ynn
 constexpr int PRECISION_BITS = 22;
 
+constexpr int FT_W = 256;          // fused tile: output columns (one float4 per lane and row)
+constexpr int FT_H = 16;           // fused tile: output rows
+constexpr int PATCH_CAP = 6144;    // LDS pixels (u32) per patch buffer: 24 KiB, two buffers per block
+constexpr int MAX_SHARP = 2;       // Sharpness ops a fused unit may chain (1-pixel halo each)
+
 struct UnitRef {
     const aadg_unit* units;
     aadg_unit single;
     int use_single;
+    int allow_fused;
 };
 __device__ __forceinline__ const aadg_unit& pick(const UnitRef& r, int u) {
     return r.use_single ? r.single : r.units[u];
@@ -41,6 +55,18 @@ __device__ __forceinline__ bool op_needs_stats(int op) {
 }
 __device__ __forceinline__ bool op_is_lut(int op) {
     return op <= AADG_OP_CONTRAST || op == AADG_OP_BRIGHTNESS;  // 0..5 and 7
+}
+
+// does this unit take the fused (LDS-resident) data flow?  Must agree across all kernels of a call.
+__device__ __forceinline__ int sharp_count(const aadg_unit& un, int upto) {
+    int s = 0;
+    for (int k = 0; k < upto; ++k) s += (un.op[k] == AADG_OP_SHARPNESS && un.farg[k] != 1.0f) ? 1 : 0;
+    return s;
+}
+__device__ __forceinline__ bool unit_fusable(const UnitRef& ur, const aadg_unit& un, int Hs, int Ws, int crop) {
+    if (!ur.allow_fused || (Ws & 3) || (crop & 3)) return false;
+    if (un.scaled_w < Ws || un.scaled_h < Hs) return false;
+    return sharp_count(un, un.n_ops) <= MAX_SHARP;
 }
 
 __device__ __forceinline__ uint32_t rgb2l(uint32_t r, uint32_t g, uint32_t b) {
@@ -71,10 +97,12 @@ __device__ __forceinline__ const uint8_t* stage_input(const Bufs& b, const aadg_
 // ------------------------------------------------------------------------------------------------
 // k_hist: grid (chunks, N), 256 threads.  Thread = groups of 4 pixels (12 bytes, 3 dword loads).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_hist(Bufs bufs, UnitRef ur, int stage, int npix, uint32_t* hist) {
+__global__ __launch_bounds__(256) void k_hist(Bufs bufs, UnitRef ur, int stage, int npix, int Hs, int Ws, int crop,
+                                              uint32_t* hist) {
     const int u = blockIdx.y;
     const aadg_unit& un = pick(ur, u);
     if (un.n_ops <= stage || !op_needs_stats(un.op[stage])) return;
+    if (stage > 0 && unit_fusable(ur, un, Hs, Ws, crop)) return;   // k_hist_fused covers those
     const uint8_t* in = stage_input(bufs, un, u, stage);
     __shared__ uint32_t sh[4][768];
     const int tid = threadIdx.x, wv = tid >> 6;
@@ -123,7 +151,7 @@ __global__ __launch_bounds__(256) void k_lut(UnitRef ur, int stage, int npix, co
     const int op = un.op[stage];
     if (!op_is_lut(op)) return;
     const int i = threadIdx.x;
-    uint8_t* L = lut + (size_t)u * 768;
+    uint8_t* L = lut + ((size_t)stage * gridDim.x + u) * 768;
     const uint32_t* gh = hist + (size_t)u * HIST_STRIDE;
     __shared__ uint32_t scan[256];
     __shared__ int s_lo, s_hi, s_nnz;
@@ -193,11 +221,12 @@ __global__ __launch_bounds__(256) void k_lut(UnitRef ur, int stage, int npix, co
 // ------------------------------------------------------------------------------------------------
 // k_apply: grid (chunks, N), 256 threads; one op, u8 HWC -> u8 HWC.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_apply(Bufs bufs, UnitRef ur, int stage, int H, int W, const uint8_t* lut,
-                                               uint8_t* out_override) {
+__global__ __launch_bounds__(256) void k_apply(Bufs bufs, UnitRef ur, int stage, int H, int W, int crop,
+                                               const uint8_t* lut, uint8_t* out_override) {
     const int u = blockIdx.y;
     const aadg_unit& un = pick(ur, u);
     if (un.n_ops <= stage) return;
+    if (unit_fusable(ur, un, H, W, crop)) return;
     const int op = un.op[stage];
     const uint8_t* in = stage_input(bufs, un, u, stage);
     uint8_t* out = out_override ? out_override : ((stage & 1) ? bufs.buf1 : bufs.buf0) + (size_t)u * bufs.img_bytes;
@@ -205,7 +234,7 @@ __global__ __launch_bounds__(256) void k_apply(Bufs bufs, UnitRef ur, int stage,
     const int npix = H * W;
     __shared__ uint8_t sl[768];
     if (op_is_lut(op)) {
-        const uint8_t* L = lut + (size_t)u * 768;
+        const uint8_t* L = lut + ((size_t)stage * gridDim.y + u) * 768;
         for (int i = tid; i < 768; i += 256) sl[i] = L[i];
         __syncthreads();
     }
@@ -339,28 +368,34 @@ __global__ __launch_bounds__(256) void k_tables(UnitRef ur, int Hs, int Ws, int 
         int* kk = (isx ? xk : yk) + (size_t)o * KMAX;
         for (int t = 0; t < KMAX; ++t) kk[t] = k[t];
     }
-    // NEAREST tables: ImagingScaleAffine accumulates xo += a0 in double, sequentially
+    // NEAREST tables: ImagingScaleAffine accumulates xo += a0 in double, SEQUENTIALLY (the rounding of the
+    // running sum decides exact ties), so one lane walks each axis; results are staged in LDS and written
+    // out coalesced by the whole block.
+    extern __shared__ int nn_lds[];   // 2 * crop ints
     if (threadIdx.x == 0 || threadIdx.x == 64) {
         const bool isx = threadIdx.x == 0;
         const int outSize = isx ? w : h, inSize = isx ? Ws : Hs, off = isx ? ox : oy;
-        int* nn = isx ? xnn : ynn;
+        int* nn = nn_lds + (isx ? 0 : crop);
         const double a0 = (double)inSize / (double)outSize;
         double xo = 0.0 + a0 * 0.5;
         int lim = off + crop;
         if (lim > outSize) lim = outSize;
-        for (int o = 0; o < crop; ++o) {
-            const int s = o + off;
-            if (s < 0 || s >= outSize) nn[o] = -1;
-        }
-        for (int s = 0; s < lim; ++s) {
-            if (s >= off) {
+        for (int o = 0; o < crop; ++o) nn[o] = -1;
+        if (inSize == outSize) {       // a0 == 1: xo = s + 0.5 exactly
+            for (int sidx = off < 0 ? 0 : off; sidx < lim; ++sidx) nn[sidx - off] = sidx;
+        } else {
+            int sidx = 0;
+            for (; sidx < off && sidx < lim; ++sidx) xo += a0;
+            for (; sidx < lim; ++sidx) {
                 int xin = xo < 0.0 ? -1 : (int)xo;
                 if (xin >= inSize) xin = -1;
-                nn[s - off] = xin;
+                nn[sidx - off] = xin;
+                xo += a0;
             }
-            xo += a0;
         }
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < crop; i += 256) { xnn[i] = nn_lds[i]; ynn[i] = nn_lds[crop + i]; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -378,6 +413,7 @@ __global__ __launch_bounds__(256) void k_final(Bufs bufs, const uint8_t* masks, 
                                                int dataset, const int* tab, float* out_img, float* out_lbl) {
     const int u = blockIdx.z;
     const aadg_unit& un = pick(ur, u);
+    if (unit_fusable(ur, un, Hs, Ws, crop)) return;
     const uint8_t* img = stage_input(bufs, un, u, un.n_ops);
     const uint8_t* msk = masks + (size_t)un.src * Hs * Ws;
     const int K = dataset == AADG_DATASET_OPTIC ? 2 : 1;
@@ -473,6 +509,263 @@ __global__ __launch_bounds__(256) void k_final(Bufs bufs, const uint8_t* masks, 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fused data flow: LDS patch builder shared by k_hist_fused and k_fused.
+//
+// Loads source rows [r_lo, r_hi) x cols [c_lo, c_hi) (c_lo, c_hi multiples of 4, region already includes the
+// halo and is clipped to the image) as one RGBX word per pixel, then applies ops [0, nops) in LDS.
+// Pixels within `sharp_count` of a patch edge that is not an image edge are NOT valid afterwards.
+// Returns the buffer (A or B) that holds the result.  Ends with a __syncthreads().
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t blend3(uint32_t deg, uint32_t img, float alpha, bool interp) {
+    if (alpha == 0.0f) return deg;
+    const uint32_t r = blend_px((int)(deg & 255), (int)(img & 255), alpha, interp);
+    const uint32_t g = blend_px((int)((deg >> 8) & 255), (int)((img >> 8) & 255), alpha, interp);
+    const uint32_t b = blend_px((int)((deg >> 16) & 255), (int)((img >> 16) & 255), alpha, interp);
+    return r | (g << 8) | (b << 16);
+}
+
+__device__ uint32_t* build_patch(const aadg_unit& un, int nops, const uint8_t* __restrict__ src, int Hs, int Ws,
+                                 int r_lo, int r_hi, int c_lo, int c_hi, uint32_t* A, uint32_t* B,
+                                 const uint8_t* __restrict__ lut, size_t lut_stage_stride, int u, uint8_t* sl) {
+    const int tid = threadIdx.x;
+    const int pw = c_hi - c_lo, ph = r_hi - r_lo, q4 = pw >> 2, npx = ph * pw;
+    for (int i = tid; i < ph * q4; i += 256) {
+        const int row = i / q4, q = i - row * q4;
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(src + ((size_t)(r_lo + row) * Ws + c_lo + 4 * q) * 3);
+        const uint32_t a = p[0], b = p[1], c = p[2];
+        uint4 o;
+        o.x = a & 0xFFFFFFu;
+        o.y = (a >> 24) | ((b & 0xFFFFu) << 8);
+        o.z = (b >> 16) | ((c & 0xFFu) << 16);
+        o.w = c >> 8;
+        *reinterpret_cast<uint4*>(&A[row * pw + 4 * q]) = o;
+    }
+    uint32_t* cur = A;
+    uint32_t* oth = B;
+    __syncthreads();
+    for (int j = 0; j < nops; ++j) {
+        const int op = un.op[j];
+        const float alpha = un.farg[j];
+        const bool interp = alpha >= 0.0f && alpha <= 1.0f;
+        if (op_is_lut(op)) {
+            const uint32_t* L = reinterpret_cast<const uint32_t*>(lut + (size_t)j * lut_stage_stride + (size_t)u * 768);
+            if (tid < 192) reinterpret_cast<uint32_t*>(sl)[tid] = L[tid];
+            __syncthreads();
+            for (int i = tid; i < npx; i += 256) {
+                const uint32_t p = cur[i];
+                cur[i] = (uint32_t)sl[p & 255] | ((uint32_t)sl[256 + ((p >> 8) & 255)] << 8) |
+                         ((uint32_t)sl[512 + ((p >> 16) & 255)] << 16);
+            }
+        } else if (op == AADG_OP_COLOR) {
+            if (alpha != 1.0f)
+                for (int i = tid; i < npx; i += 256) {
+                    const uint32_t p = cur[i];
+                    const uint32_t l = rgb2l(p & 255, (p >> 8) & 255, (p >> 16) & 255);
+                    cur[i] = blend3(l * 0x010101u, p, alpha, interp);
+                }
+        } else if (op == AADG_OP_CUTOUT) {
+            const int rx0 = un.rect[j][0], ry0 = un.rect[j][1], rx1 = un.rect[j][2], ry1 = un.rect[j][3];
+            for (int i = tid; i < npx; i += 256) {
+                const int row = i / pw, col = i - row * pw;
+                const int y = r_lo + row, x = c_lo + col;
+                if (x >= rx0 && x <= rx1 && y >= ry0 && y <= ry1) cur[i] = 0x7F7F7Fu;
+            }
+        } else if (op == AADG_OP_SHARPNESS && alpha != 1.0f) {
+            for (int i = tid; i < npx; i += 256) {
+                const int row = i / pw, col = i - row * pw;
+                const int y = r_lo + row, x = c_lo + col;
+                const uint32_t p = cur[i];
+                uint32_t d = p;   // ImageFilter.SMOOTH copies the 1-pixel image border
+                if (y > 0 && x > 0 && y < Hs - 1 && x < Ws - 1 && row > 0 && col > 0 && row < ph - 1 && col < pw - 1) {
+                    uint32_t srb = 4u * (p & 0xFF00FFu), sg = 4u * ((p >> 8) & 255u);   // centre weight 5 = 4 + 1
+#pragma unroll
+                    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const uint32_t q = cur[i + dy * pw + dx];
+                            srb += q & 0xFF00FFu;
+                            sg += (q >> 8) & 255u;
+                        }
+                    const uint32_t r = ((srb & 0xFFFFu) + 6u) / 13u, b = ((srb >> 16) + 6u) / 13u, g = (sg + 6u) / 13u;
+                    d = r | (g << 8) | (b << 16);
+                }
+                oth[i] = blend3(d, p, alpha, interp);
+            }
+            uint32_t* t = cur; cur = oth; oth = t;
+        }
+        __syncthreads();
+    }
+    return cur;
+}
+
+// k_hist_fused: grid (ceil(Ws/256), ceil(Hs/16), N); histogram of the image after `stage` ops (stage >= 1)
+__global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ pool, UnitRef ur, int stage, int Hs, int Ws,
+                                                    int crop, const uint8_t* __restrict__ lut, size_t lut_stage_stride,
+                                                    uint32_t* hist) {
+    const int u = blockIdx.z;
+    const aadg_unit& un = pick(ur, u);
+    if (un.n_ops <= stage || !op_needs_stats(un.op[stage]) || !unit_fusable(ur, un, Hs, Ws, crop)) return;
+    __shared__ __attribute__((aligned(16))) uint32_t A[PATCH_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t B[PATCH_CAP];
+    __shared__ __attribute__((aligned(16))) uint8_t sl[768];
+    __shared__ uint32_t sh[768];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 768; i += 256) sh[i] = 0;
+    const int ry0 = blockIdx.y * 16, ry1 = min(ry0 + 16, Hs);
+    const int cx0 = blockIdx.x * 256, cx1 = min(cx0 + 256, Ws);
+    const int s = sharp_count(un, stage);
+    const int r_lo = max(0, ry0 - s), r_hi = min(Hs, ry1 + s);
+    const int c_lo = max(0, cx0 - s) & ~3, c_hi = min(Ws, (cx1 + s + 3) & ~3);
+    const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
+    const uint32_t* cur = build_patch(un, stage, src, Hs, Ws, r_lo, r_hi, c_lo, c_hi, A, B, lut, lut_stage_stride, u, sl);
+    const int pw = c_hi - c_lo, rw = cx1 - cx0, n = (ry1 - ry0) * rw;
+    unsigned long long lsum = 0;
+    for (int i = tid; i < n; i += 256) {
+        const int row = i / rw, col = i - row * rw;
+        const uint32_t p = cur[(ry0 + row - r_lo) * pw + (cx0 + col - c_lo)];
+        const uint32_t r = p & 255, g = (p >> 8) & 255, b = (p >> 16) & 255;
+        atomicAdd(&sh[r], 1u); atomicAdd(&sh[256 + g], 1u); atomicAdd(&sh[512 + b], 1u);
+        lsum += rgb2l(r, g, b);
+    }
+    lsum = wave_sum(lsum);
+    __syncthreads();
+    uint32_t* gh = hist + (size_t)u * HIST_STRIDE;
+    for (int i = tid; i < 768; i += 256) if (sh[i]) atomicAdd(&gh[i], sh[i]);
+    if ((tid & 63) == 0 && lsum) atomicAdd(reinterpret_cast<unsigned long long*>(gh + 768), lsum);
+}
+
+// k_fused: grid (ceil(crop/256), ceil(crop/16), N)
+__global__ __launch_bounds__(256) void k_fused(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks, UnitRef ur,
+                                               int Hs, int Ws, int crop, int dataset, const int* __restrict__ tab,
+                                               const uint8_t* __restrict__ lut, size_t lut_stage_stride,
+                                               float* __restrict__ out_img, float* __restrict__ out_lbl) {
+    const int u = blockIdx.z;
+    const aadg_unit& un = pick(ur, u);
+    if (!unit_fusable(ur, un, Hs, Ws, crop)) return;
+    __shared__ __attribute__((aligned(16))) uint32_t A[PATCH_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t B[PATCH_CAP];
+    __shared__ __attribute__((aligned(16))) uint8_t sl[768];
+    __shared__ float lutf[256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    lutf[tid] = __fsub_rn(__fdiv_rn((float)tid, 127.5f), 1.0f);   // np.float32: x /= 127.5; x -= 1.0
+
+    const int K = dataset == AADG_DATASET_OPTIC ? 2 : 1;
+    const int* base = tab + (size_t)u * crop * TAB_STRIDE;
+    const int* xmin_t = base;
+    const int* xk_t = xmin_t + crop;
+    const int* ymin_t = xk_t + (size_t)crop * KMAX;
+    const int* yk_t = ymin_t + crop;
+    const int* xnn_t = yk_t + (size_t)crop * KMAX;
+    const int* ynn_t = xnn_t + crop;
+
+    const int x0 = blockIdx.x * FT_W, x1 = min(x0 + FT_W, crop);
+    const int y0 = blockIdx.y * FT_H, y1 = min(y0 + FT_H, crop);
+    const int w = un.scaled_w, h = un.scaled_h;
+    const int ox = un.crop_x - un.pad, oy = un.crop_y - un.pad;
+    // valid (non-pad) output range of this tile: scaled coordinate s = o + off must lie in [0, size)
+    const int fx = max(x0, -ox), lx = min(x1 - 1, w - 1 - ox);
+    const int fy = max(y0, -oy), ly = min(y1 - 1, h - 1 - oy);
+    const bool any = fx <= lx && fy <= ly;
+    const int ntx = w == Ws ? 1 : 2, nty = h == Hs ? 1 : 2;   // taps of an up-scaling BILINEAR axis: <= 2
+
+    int r_lo = 0, r_hi = 0, c_lo_h = 0, r_lo_h = 0, pw = 4;
+    const uint32_t* cur = A;
+    uint32_t* Hbuf = B;
+    if (any) {
+        r_lo = ymin_t[fy];
+        r_hi = min(Hs, ymin_t[ly] + nty);
+        const int c_lo = xmin_t[fx], c_hi = min(Ws, xmin_t[lx] + ntx);
+        const int s = sharp_count(un, un.n_ops);
+        r_lo_h = max(0, r_lo - s);
+        const int r_hi_h = min(Hs, r_hi + s);
+        c_lo_h = max(0, c_lo - s) & ~3;
+        const int c_hi_h = min(Ws, (c_hi + s + 3) & ~3);
+        pw = c_hi_h - c_lo_h;
+        const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
+        cur = build_patch(un, un.n_ops, src, Hs, Ws, r_lo_h, r_hi_h, c_lo_h, c_hi_h, A, B, lut, lut_stage_stride, u, sl);
+        Hbuf = cur == A ? B : A;
+        // ---- horizontal pass: thread <-> output column, loop over the needed source rows ------------
+        const int x = x0 + tid;
+        int xm = -1, k0 = 0, k1 = 0;
+        if (x >= fx && x <= lx) {
+            xm = xmin_t[x];
+            k0 = xk_t[(size_t)x * KMAX];
+            k1 = ntx > 1 ? xk_t[(size_t)x * KMAX + 1] : 0;
+        }
+        const int nrows = r_hi - r_lo;
+        if (xm >= 0) {
+            const uint32_t* col = cur + (r_lo - r_lo_h) * pw + (xm - c_lo_h);
+            for (int rr = 0; rr < nrows; ++rr) {
+                const uint32_t p0 = col[rr * pw];
+                const uint32_t p1 = k1 ? col[rr * pw + 1] : 0u;
+                const int half = 1 << (PRECISION_BITS - 1);
+                const int s0 = half + (int)(p0 & 255) * k0 + (int)(p1 & 255) * k1;
+                const int s1 = half + (int)((p0 >> 8) & 255) * k0 + (int)((p1 >> 8) & 255) * k1;
+                const int s2 = half + (int)((p0 >> 16) & 255) * k0 + (int)((p1 >> 16) & 255) * k1;
+                Hbuf[rr * FT_W + tid] = (uint32_t)clip8(s0) | ((uint32_t)clip8(s1) << 8) | ((uint32_t)clip8(s2) << 16);
+            }
+        } else {
+            for (int rr = 0; rr < nrows; ++rr) Hbuf[rr * FT_W + tid] = 0u;
+        }
+    }
+    __syncthreads();
+
+    // ---- vertical pass + normalise + store: wave <-> output row, lane <-> 4 consecutive columns -------
+    const int xq = x0 + 4 * lane;
+    if (xq >= crop) return;
+    const int4 xm4 = *reinterpret_cast<const int4*>(xmin_t + xq);
+    const int4 xn4 = *reinterpret_cast<const int4*>(xnn_t + xq);
+    const int xm[4] = {xm4.x, xm4.y, xm4.z, xm4.w};
+    const int xn[4] = {xn4.x, xn4.y, xn4.z, xn4.w};
+    const size_t plane = (size_t)crop * crop;
+    float* oi = out_img + (size_t)u * 3 * plane;
+    float* ol = out_lbl + (size_t)u * K * plane;
+    const uint8_t* msk = masks + (size_t)un.src * Hs * Ws;
+    const float padv = lutf[0];
+    for (int y = y0 + wv; y < y1; y += 4) {
+        const int ym = ymin_t[y];
+        const int yn = ynn_t[y];
+        float o[3][4];
+        if (ym >= 0) {
+            const int ky0 = yk_t[(size_t)y * KMAX];
+            const int ky1 = nty > 1 ? yk_t[(size_t)y * KMAX + 1] : 0;
+            const uint4 h0 = *reinterpret_cast<const uint4*>(Hbuf + (ym - r_lo) * FT_W + 4 * lane);
+            uint4 h1 = make_uint4(0u, 0u, 0u, 0u);
+            if (ky1) h1 = *reinterpret_cast<const uint4*>(Hbuf + (ym + 1 - r_lo) * FT_W + 4 * lane);
+            const uint32_t a0[4] = {h0.x, h0.y, h0.z, h0.w};
+            const uint32_t a1[4] = {h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int v = (1 << (PRECISION_BITS - 1)) + (int)((a0[i] >> (8 * c)) & 255) * ky0 +
+                                  (int)((a1[i] >> (8 * c)) & 255) * ky1;
+                    o[c][i] = xm[i] >= 0 ? lutf[clip8(v)] : padv;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[0][i] = o[1][i] = o[2][i] = padv;
+        }
+        float l0[4], l1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t m = 0;
+            if (yn >= 0 && xn[i] >= 0) m = msk[(size_t)yn * Ws + xn[i]];
+            if (dataset == AADG_DATASET_OPTIC) { l0[i] = m <= 50 ? 1.0f : 0.0f; l1[i] = m <= 200 ? 1.0f : 0.0f; }
+            else { l0[i] = m != 0 ? 1.0f : 0.0f; l1[i] = 0.0f; }
+        }
+        const size_t off = (size_t)y * crop + xq;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<float4*>(oi + c * plane + off) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+        *reinterpret_cast<float4*>(ol + off) = make_float4(l0[0], l0[1], l0[2], l0[3]);
+        if (K == 2) *reinterpret_cast<float4*>(ol + plane + off) = make_float4(l1[0], l1[1], l1[2], l1[3]);
+    }
+}
+
 struct WsLayout {
     size_t hist, lut, tab, buf0, buf1, total;
 };
@@ -480,7 +773,7 @@ WsLayout ws_layout(int N, int Hs, int Ws, int crop) {
     WsLayout l;
     size_t o = 0;
     l.hist = o; o = aadg_align_up(o + (size_t)N * HIST_STRIDE * 4, 256);
-    l.lut = o;  o = aadg_align_up(o + (size_t)N * 768, 256);
+    l.lut = o;  o = aadg_align_up(o + (size_t)AADG_MAX_OPS * N * 768, 256);
     l.tab = o;  o = aadg_align_up(o + (size_t)N * crop * TAB_STRIDE * 4, 256);
     const size_t img = (size_t)Hs * Ws * 3;
     l.buf0 = o; o = aadg_align_up(o + (size_t)N * img, 256);
@@ -494,21 +787,36 @@ int chunks_for(int npix) {
     return c < 1 ? 1 : (c > 1024 ? 1024 : c);
 }
 
-// runs stages [0, max_ops) for N units
-int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int max_ops, uint8_t* ws8, const WsLayout& L,
-               uint8_t* out_override, hipStream_t st) {
+// hints from a caller that has the unit records on the host (all bits set = unknown, launch everything)
+constexpr int HINT_FUSED = 1, HINT_STAGED = 2;
+
+// statistics + LUT (+ staged apply) for stages [0, max_ops)
+int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int crop, int max_ops, uint8_t* ws8,
+               const WsLayout& L, uint8_t* out_override, int classes, int stats_mask, hipStream_t st) {
     const int npix = Hs * Ws;
     uint32_t* hist = reinterpret_cast<uint32_t*>(ws8 + L.hist);
     uint8_t* lut = ws8 + L.lut;
+    const size_t lut_stage_stride = (size_t)N * 768;
     const dim3 g(chunks_for(npix), N);
     for (int k = 0; k < max_ops; ++k) {
-        AADG_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)N * HIST_STRIDE * 4, st));
-        hipLaunchKernelGGL(k_hist, g, dim3(256), 0, st, bufs, ur, k, npix, hist);
-        AADG_LAUNCH_CHECK();
+        if (stats_mask & (1 << k)) {
+            AADG_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)N * HIST_STRIDE * 4, st));
+            if (k == 0 || (classes & HINT_STAGED)) {
+                hipLaunchKernelGGL(k_hist, g, dim3(256), 0, st, bufs, ur, k, npix, Hs, Ws, crop, hist);
+                AADG_LAUNCH_CHECK();
+            }
+            if (k > 0 && (classes & HINT_FUSED)) {
+                const dim3 gf((Ws + 255) / 256, (Hs + 15) / 16, N);
+                hipLaunchKernelGGL(k_hist_fused, gf, dim3(256), 0, st, bufs.pool, ur, k, Hs, Ws, crop, lut, lut_stage_stride, hist);
+                AADG_LAUNCH_CHECK();
+            }
+        }
         hipLaunchKernelGGL(k_lut, dim3(N), dim3(256), 0, st, ur, k, npix, hist, lut);
         AADG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_apply, g, dim3(256), 0, st, bufs, ur, k, Hs, Ws, lut, out_override);
-        AADG_LAUNCH_CHECK();
+        if (classes & HINT_STAGED) {
+            hipLaunchKernelGGL(k_apply, g, dim3(256), 0, st, bufs, ur, k, Hs, Ws, crop, lut, out_override);
+            AADG_LAUNCH_CHECK();
+        }
     }
     return 0;
 }
@@ -523,19 +831,7 @@ extern "C" size_t aadg_aug_u8_workspace_bytes(int N, int Hs, int Ws, int crop) {
 extern "C" int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,
                                       const aadg_unit* units, int N, int max_ops, int crop, int dataset,
                                       float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream,
-                                      void* ev_before_final, void* ev_after_final);
-
-extern "C" int aadg_aug_u8_forward(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,
-                                   const aadg_unit* units, int N, int max_ops, int crop, int dataset,
-                                   float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream) {
-    return aadg_aug_u8_forward_ex(pool, masks, P, Hs, Ws, units, N, max_ops, crop, dataset, out_img, out_lbl, ws,
-                                  ws_bytes, stream, nullptr, nullptr);
-}
-
-extern "C" int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,
-                                      const aadg_unit* units, int N, int max_ops, int crop, int dataset,
-                                      float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream,
-                                      void* ev_before_final, void* ev_after_final) {
+                                      int classes_hint, int stats_mask_hint, void* ev_before_final, void* ev_after_final) {
     if (!pool || !masks || !units || !out_img || !out_lbl || !ws) return AADG_E_BADARG;
     if (P <= 0 || Hs <= 0 || Ws <= 0 || N <= 0 || crop <= 0) return AADG_E_BADARG;
     if (max_ops < 0 || max_ops > AADG_MAX_OPS) return AADG_E_BADARG;
@@ -550,19 +846,38 @@ extern "C" int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks,
     UnitRef ur;
     ur.units = units;
     ur.use_single = 0;
+    ur.allow_fused = 1;
     ::memset(&ur.single, 0, sizeof(ur.single));
-    int rc = 0;
-    rc = run_stages(bufs, ur, N, Hs, Ws, max_ops, ws8, L, nullptr, st);
+    int classes = classes_hint & (HINT_FUSED | HINT_STAGED);
+    if (classes == 0) classes = HINT_FUSED | HINT_STAGED;
+    if ((Ws & 3) || (crop & 3)) classes = HINT_STAGED;        // unit_fusable() is false for every unit
+    const int stats_mask = stats_mask_hint < 0 ? 0xF : stats_mask_hint;
+    int rc = run_stages(bufs, ur, N, Hs, Ws, crop, max_ops, ws8, L, nullptr, classes, stats_mask, st);
     if (rc) return rc;
     int* tab = reinterpret_cast<int*>(ws8 + L.tab);
-    hipLaunchKernelGGL(k_tables, dim3(N), dim3(256), 0, st, ur, Hs, Ws, crop, tab);
+    hipLaunchKernelGGL(k_tables, dim3(N), dim3(256), 2 * crop * sizeof(int), st, ur, Hs, Ws, crop, tab);
     AADG_LAUNCH_CHECK();
-    const dim3 g((crop + 255) / 256, (crop + FIN_ROWS - 1) / FIN_ROWS, N);
     if (ev_before_final) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_before_final), st));
-    hipLaunchKernelGGL(k_final, g, dim3(256), 0, st, bufs, masks, ur, Hs, Ws, crop, dataset, tab, out_img, out_lbl);
-    AADG_LAUNCH_CHECK();
+    if (classes & HINT_FUSED) {
+        const dim3 g((crop + FT_W - 1) / FT_W, (crop + FT_H - 1) / FT_H, N);
+        hipLaunchKernelGGL(k_fused, g, dim3(256), 0, st, pool, masks, ur, Hs, Ws, crop, dataset, tab, ws8 + L.lut,
+                           (size_t)N * 768, out_img, out_lbl);
+        AADG_LAUNCH_CHECK();
+    }
+    if (classes & HINT_STAGED) {
+        const dim3 g((crop + 255) / 256, (crop + FIN_ROWS - 1) / FIN_ROWS, N);
+        hipLaunchKernelGGL(k_final, g, dim3(256), 0, st, bufs, masks, ur, Hs, Ws, crop, dataset, tab, out_img, out_lbl);
+        AADG_LAUNCH_CHECK();
+    }
     if (ev_after_final) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_after_final), st));
     return 0;
+}
+
+extern "C" int aadg_aug_u8_forward(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,
+                                   const aadg_unit* units, int N, int max_ops, int crop, int dataset,
+                                   float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream) {
+    return aadg_aug_u8_forward_ex(pool, masks, P, Hs, Ws, units, N, max_ops, crop, dataset, out_img, out_lbl, ws,
+                                  ws_bytes, stream, 0, -1, nullptr, nullptr);
 }
 
 extern "C" int aadg_op_u8(const uint8_t* in, uint8_t* out, int H, int W, int op, int iarg, float farg,
@@ -578,6 +893,7 @@ extern "C" int aadg_op_u8(const uint8_t* in, uint8_t* out, int H, int W, int op,
     UnitRef ur;
     ur.units = nullptr;
     ur.use_single = 1;
+    ur.allow_fused = 0;
     ::memset(&ur.single, 0, sizeof(ur.single));
     ur.single.src = 0;
     ur.single.n_ops = 1;
@@ -587,5 +903,5 @@ extern "C" int aadg_op_u8(const uint8_t* in, uint8_t* out, int H, int W, int op,
     for (int i = 0; i < 4; ++i) ur.single.rect[0][i] = rect_host ? rect_host[i] : (i < 2 ? 0 : -1);
     ur.single.scaled_w = W;
     ur.single.scaled_h = H;
-    return run_stages(bufs, ur, 1, H, W, 1, ws8, L, out, st);
+    return run_stages(bufs, ur, 1, H, W, 0, 1, ws8, L, out, HINT_STAGED, 1, st);
 }

@@ -85,12 +85,17 @@ size_t aadg_aug_u8_workspace_bytes(int N, int Hs, int Ws, int crop);
 int aadg_aug_u8_forward(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,
                         const aadg_unit* units, int N, int max_ops, int crop, int dataset,
                         float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream);
-/* Same, plus two optional hipEvent_t (may be NULL) recorded on `stream` immediately before and after the
- * dominant kernel (the fused resample/normalise/store kernel), so a caller can time exactly that kernel. */
+/* Same, with launch hints from a caller that holds the unit records on the host, and two optional
+ * hipEvent_t (may be NULL) recorded on `stream` immediately before and after the dominant kernel(s) (the fused
+ * resample/normalise/store kernel), so a caller can time exactly that part.
+ *   classes_hint    bit 0: some unit takes the fused (LDS-resident) data flow; bit 1: some unit takes the
+ *                   staged flow (down-scaled, > 2 Sharpness ops, or sizes not multiples of 4); 0 = unknown.
+ *   stats_mask_hint bit k: some unit's k-th op needs image statistics (AutoContrast/Equalize/Contrast);
+ *                   -1 = unknown. */
 int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,
                            const aadg_unit* units, int N, int max_ops, int crop, int dataset,
                            float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream,
-                           void* ev_before_final, void* ev_after_final);
+                           int classes_hint, int stats_mask_hint, void* ev_before_final, void* ev_after_final);
 
 /* One registry op on one image, replaces fn(img, mask, v) of augment_list()
  * (data/basic.py:70-120,137-167) for uint8 HWC tensors.  ws >= aadg_aug_u8_workspace_bytes(1,H,W,0);
@@ -142,7 +147,7 @@ enum aadg_fop {
     AADG_FOP_SHEAR_X, AADG_FOP_SHEAR_Y, AADG_FOP_TRANSLATE_X, AADG_FOP_TRANSLATE_Y,
     AADG_FOP_ROTATE, AADG_FOP_HFLIP, AADG_FOP_VFLIP, AADG_FOP_COUNT
 };
-size_t aadg_fop_workspace_bytes(int B, int C);
+size_t aadg_fop_workspace_bytes(int B, int H, int W);
 /* kernel3x3: 9 floats (device) for SHARPNESS / GAUSSIAN_BLUR3X3, NULL = reference default;
  * perm: B int32 (device) for SAMPLE_PAIRING. */
 int aadg_fop_f32(int fop, const float* in, float* out, const float* mag, int mag_n,

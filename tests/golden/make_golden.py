@@ -259,8 +259,53 @@ def gen_controller():
     np.savez_compressed(os.path.join(OUT, "controller.npz"), **out)
 
 
+def gen_functional():
+    """Non-kornia float ops of data/functional.py (+ data/kernels.py) on torch-CPU."""
+    import torch
+    from data import functional as RF
+    from data import kernels as RK
+    out = {}
+    torch.manual_seed(1023)
+    img = torch.rand(2, 3, 20, 24)
+    img[0, :, :4, :4] = 0.0
+    img[1, 1] *= 0.5                      # a channel with a reduced range
+    out["img"] = img.numpy().copy()
+    permag = torch.tensor([0.25, 0.8])
+    for sg in (0.5, 1.0, 2.0):
+        out["gauss3_%g" % sg] = RK.get_gaussian_3x3kernel(torch.tensor([sg])).numpy()
+    out["sharp_kernel"] = RK.get_sharpness_kernel().numpy()
+    cases = []
+    for name in ("invert", "gray", "auto_contrast", "equalize", "hflip", "vflip"):
+        cases.append((name, None))
+    for name in ("solarize", "contrast", "saturate", "brightness", "sharpness"):
+        for m in (0.0, 0.3, 1.0):
+            cases.append((name, torch.tensor([m])))
+        cases.append((name, permag))
+    cases.append(("posterize", torch.tensor([0.5])))
+    cases.append(("gaussian_blur3x3", torch.tensor([0.7])))
+    cases.append(("gaussian_blur3x3", torch.tensor([1.5])))
+    keys = []
+    for i, (name, mag) in enumerate(cases):
+        fn = getattr(RF, name)
+        res = fn(img.clone()) if mag is None else fn(img.clone(), mag.clone())
+        key = "f%02d_%s" % (i, name)
+        keys.append(key)
+        out[key] = res.detach().numpy().copy()
+        out[key + "_mag"] = np.zeros(0, np.float32) if mag is None else mag.numpy()
+    for i, m in enumerate((torch.tensor([0.4]), permag)):
+        torch.manual_seed(55 + i)
+        res = RF.sample_pairing(img.clone(), m.clone())
+        torch.manual_seed(55 + i)
+        out["sp%d_perm" % i] = torch.randperm(2).numpy()
+        out["sp%d" % i] = res.numpy().copy()
+        out["sp%d_mag" % i] = m.numpy()
+    out["keys"] = np.array(keys)
+    np.savez_compressed(os.path.join(OUT, "functional.npz"), **out)
+
+
 if __name__ == "__main__":
     install_stubs()
+    gen_functional()
     gen_ops()
     gen_parse()
     gen_pipeline()

@@ -37,4 +37,7 @@ def test_full_size_property(hip):
     bce, dice, _ = hip.seg_bce_dice(z, y, M)
     assert torch.all(dice == 1.0) and bce.max().item() < 1e-7
     bce, dice, _ = hip.seg_bce_dice(-z, y, M)
-    assert torch.all(dice == 0.0) and abs(bce.mean().item() - 20.0) < 1e-3
+    # fp32 sigmoid saturates: sigmoid(20) == 1.0f -> log(1-p) clamps at -100 (nn.BCELoss semantics), so the
+    # wrong-side loss is 20 where y=1 and 100 where y=0; compare with torch's own fp32 result
+    ref = torch.nn.functional.binary_cross_entropy(torch.sigmoid(-z), y)
+    assert torch.all(dice == 0.0) and abs(bce.mean().item() - ref.item()) < 1e-3
