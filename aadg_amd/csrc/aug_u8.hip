@@ -26,6 +26,8 @@
 //
 //  STAGED (everything else; also the eager single-op entry point): u8 intermediates in the workspace.
 //   k_hist / k_lut / k_apply per op stage, then k_tables and k_final (gathers from global memory).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -63,10 +65,13 @@ __device__ __forceinline__ int sharp_count(const aadg_unit& un, int upto) {
     for (int k = 0; k < upto; ++k) s += (un.op[k] == AADG_OP_SHARPNESS && un.farg[k] != 1.0f) ? 1 : 0;
     return s;
 }
-__device__ __forceinline__ bool unit_fusable(const UnitRef& ur, const aadg_unit& un, int Hs, int Ws, int crop) {
-    if (!ur.allow_fused || (Ws & 3) || (crop & 3)) return false;
+__device__ __forceinline__ bool unit_fusable(bool allow, const aadg_unit& un, int Hs, int Ws, int crop) {
+    if (!allow || (Ws & 3) || (crop & 3)) return false;
     if (un.scaled_w < Ws || un.scaled_h < Hs) return false;
     return sharp_count(un, un.n_ops) <= MAX_SHARP;
+}
+__device__ __forceinline__ bool unit_fusable(const UnitRef& ur, const aadg_unit& un, int Hs, int Ws, int crop) {
+    return unit_fusable(ur.allow_fused != 0, un, Hs, Ws, crop);
 }
 
 __device__ __forceinline__ uint32_t rgb2l(uint32_t r, uint32_t g, uint32_t b) {
@@ -154,8 +159,6 @@ __global__ __launch_bounds__(256) void k_lut(UnitRef ur, int stage, int npix, co
     uint8_t* L = lut + ((size_t)stage * gridDim.x + u) * 768;
     const uint32_t* gh = hist + (size_t)u * HIST_STRIDE;
     __shared__ uint32_t scan[256];
-    __shared__ int s_lo, s_hi, s_nnz;
-    __shared__ unsigned long long s_sum;
     if (op == AADG_OP_INVERT) {
         for (int c = 0; c < 3; ++c) L[256 * c + i] = (uint8_t)(255 - i);
     } else if (op == AADG_OP_SOLARIZE) {
@@ -177,13 +180,24 @@ __global__ __launch_bounds__(256) void k_lut(UnitRef ur, int stage, int npix, co
         else v = (uint8_t)blend_px(deg, i, alpha, alpha >= 0.0f && alpha <= 1.0f);
         for (int c = 0; c < 3; ++c) L[256 * c + i] = v;
     } else {  // AUTOCONTRAST / EQUALIZE
+        __shared__ int w_lo[4], w_hi[4], w_nnz[4];
+        __shared__ unsigned long long w_sum[4];
+        const int wv = i >> 6;
         for (int c = 0; c < 3; ++c) {
             const uint32_t hv = gh[256 * c + i];
             __syncthreads();
-            if (i == 0) { s_lo = 256; s_hi = -1; s_nnz = 0; s_sum = 0; }
+            // lowest / highest non-empty bin, number of non-empty bins, pixel count: wave shuffles, then 4 partials
+            int lo = hv ? i : 256, hi = hv ? i : -1, nnz = hv ? 1 : 0;
+            unsigned long long sm = hv;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                lo = min(lo, __shfl_xor(lo, o, 64));
+                hi = max(hi, __shfl_xor(hi, o, 64));
+                nnz += __shfl_xor(nnz, o, 64);
+                sm += __shfl_xor(sm, o, 64);
+            }
+            if ((i & 63) == 0) { w_lo[wv] = lo; w_hi[wv] = hi; w_nnz[wv] = nnz; w_sum[wv] = sm; }
             scan[i] = hv;
-            __syncthreads();
-            if (hv) { atomicMin(&s_lo, i); atomicMax(&s_hi, i); atomicAdd(&s_nnz, 1); atomicAdd(&s_sum, (unsigned long long)hv); }
             // inclusive Hillis-Steele scan of the 256 bins
             for (int o = 1; o < 256; o <<= 1) {
                 __syncthreads();
@@ -192,12 +206,16 @@ __global__ __launch_bounds__(256) void k_lut(UnitRef ur, int stage, int npix, co
                 scan[i] += t;
             }
             __syncthreads();
+            const int s_lo = min(min(w_lo[0], w_lo[1]), min(w_lo[2], w_lo[3]));
+            const int s_hi = max(max(w_hi[0], w_hi[1]), max(w_hi[2], w_hi[3]));
+            const int s_nnz = w_nnz[0] + w_nnz[1] + w_nnz[2] + w_nnz[3];
+            const unsigned long long s_sum = w_sum[0] + w_sum[1] + w_sum[2] + w_sum[3];
             uint8_t v = (uint8_t)i;
             if (op == AADG_OP_AUTOCONTRAST) {
-                const int lo = s_lo, hi = s_hi;
-                if (hi > lo) {
-                    const double scale = 255.0 / (double)(hi - lo);
-                    const double offset = (double)(-lo) * scale;
+                const int lo2 = s_lo, hi2 = s_hi;
+                if (hi2 > lo2) {
+                    const double scale = 255.0 / (double)(hi2 - lo2);
+                    const double offset = (double)(-lo2) * scale;
                     int ix = (int)((double)i * scale + offset);
                     ix = ix < 0 ? 0 : (ix > 255 ? 255 : ix);
                     v = (uint8_t)ix;
@@ -309,6 +327,18 @@ __device__ __forceinline__ double bilinear_filter(double x) {
     return 0.0;
 }
 
+// first source tap of output index xx (the xmin of Pillow's precompute_coeffs); same double expressions as
+// bilinear_coeffs below, so the two always agree
+__device__ __forceinline__ int bilinear_xmin(int inSize, int outSize, int xx) {
+    if (inSize == outSize) return xx;
+    const double scale = (double)inSize / (double)outSize;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 1.0 * filterscale;
+    const double center = 0.0 + ((double)xx + 0.5) * scale;
+    const int xmin = (int)(center - support + 0.5);
+    return xmin < 0 ? 0 : xmin;
+}
+
 // Pillow precompute_coeffs + normalize_coeffs_8bpc for output index `xx` (of outSize) from inSize
 __device__ void bilinear_coeffs(int inSize, int outSize, int xx, int* xmin_out, int* k /*KMAX*/) {
     if (inSize == outSize) {  // Image.resize does not resample an unchanged axis
@@ -385,11 +415,14 @@ __global__ __launch_bounds__(256) void k_tables(UnitRef ur, int Hs, int Ws, int 
             for (int sidx = off < 0 ? 0 : off; sidx < lim; ++sidx) nn[sidx - off] = sidx;
         } else {
             int sidx = 0;
-            for (; sidx < off && sidx < lim; ++sidx) xo += a0;
+            const int skip = off < lim ? off : lim;
+#pragma unroll 8
+            for (; sidx < skip; ++sidx) xo += a0;
+            // xo > 0 always (a0 > 0); values reaching inSize cannot occur for a full-image box
+#pragma unroll 8
             for (; sidx < lim; ++sidx) {
-                int xin = xo < 0.0 ? -1 : (int)xo;
-                if (xin >= inSize) xin = -1;
-                nn[sidx - off] = xin;
+                const int xin = (int)xo;
+                nn[sidx - off] = xin < inSize ? xin : -1;
                 xo += a0;
             }
         }
@@ -526,55 +559,121 @@ __device__ __forceinline__ uint32_t blend3(uint32_t deg, uint32_t img, float alp
     return r | (g << 8) | (b << 16);
 }
 
-__device__ uint32_t* build_patch(const aadg_unit& un, int nops, const uint8_t* __restrict__ src, int Hs, int Ws,
+// one pointwise op on a packed RGBX pixel at image position (y, x).  `op` is uniform per workgroup, so the
+// switch does not diverge.  Invert / Posterize / Solarize are plain integer arithmetic; the four ops whose
+// transfer function depends on float or image statistics (AutoContrast, Equalize, Contrast, Brightness) go
+// through the stage's byte LUT in LDS.  Sharpness is NOT pointwise and is handled by the caller.
+__device__ __forceinline__ uint32_t pointwise_op(const aadg_unit& un, int j, uint32_t p, int y, int x, const uint8_t* sl_all) {
+    const int op = un.op[j];
+    switch (op) {
+        case AADG_OP_INVERT:
+            return ~p & 0xFFFFFFu;
+        case AADG_OP_POSTERIZE:
+            return p & ((0xFFu & ~((1u << (8 - un.iarg[j])) - 1u)) * 0x010101u);
+        case AADG_OP_SOLARIZE: {
+            const uint32_t thr = (uint32_t)un.iarg[j];
+            uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u;
+            r = r < thr ? r : 255u - r; g = g < thr ? g : 255u - g; b = b < thr ? b : 255u - b;
+            return r | (g << 8) | (b << 16);
+        }
+        case AADG_OP_AUTOCONTRAST: case AADG_OP_EQUALIZE: case AADG_OP_CONTRAST: case AADG_OP_BRIGHTNESS: {
+            const uint8_t* sl = sl_all + j * 768;
+            return (uint32_t)sl[p & 255u] | ((uint32_t)sl[256 + ((p >> 8) & 255u)] << 8) | ((uint32_t)sl[512 + ((p >> 16) & 255u)] << 16);
+        }
+        case AADG_OP_COLOR: {
+            const float alpha = un.farg[j];
+            if (alpha == 1.0f) return p;
+            const uint32_t l = rgb2l(p & 255u, (p >> 8) & 255u, (p >> 16) & 255u);
+            return blend3(l * 0x010101u, p, alpha, alpha >= 0.0f && alpha <= 1.0f);
+        }
+        case AADG_OP_CUTOUT:
+            return (x >= un.rect[j][0] && x <= un.rect[j][2] && y >= un.rect[j][1] && y <= un.rect[j][3]) ? 0x7F7F7Fu : p;
+        default:
+            return p;
+    }
+}
+__device__ __forceinline__ bool needs_lds_lut(int op) { return op_needs_stats(op) || op == AADG_OP_BRIGHTNESS; }
+__device__ __forceinline__ bool is_stencil(const aadg_unit& un, int j) {
+    return un.op[j] == AADG_OP_SHARPNESS && un.farg[j] != 1.0f;
+}
+
+// Loads the patch (12-byte vector loads, all issued up front), applies the leading pointwise ops while the
+// pixels are still in registers, stores RGBX words to LDS; every Sharpness op then costs one LDS ping-pong
+// pass, into which the pointwise ops that follow it are folded.
+__device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, const uint8_t* __restrict__ src, int Hs, int Ws,
                                  int r_lo, int r_hi, int c_lo, int c_hi, uint32_t* A, uint32_t* B,
-                                 const uint8_t* __restrict__ lut, size_t lut_stage_stride, int u, uint8_t* sl) {
+                                 const uint8_t* __restrict__ lut, size_t lut_stage_stride, int u, uint8_t* sl_all) {
     const int tid = threadIdx.x;
-    const int pw = c_hi - c_lo, ph = r_hi - r_lo, q4 = pw >> 2, npx = ph * pw;
-    for (int i = tid; i < ph * q4; i += 256) {
-        const int row = i / q4, q = i - row * q4;
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(src + ((size_t)(r_lo + row) * Ws + c_lo + 4 * q) * 3);
-        const uint32_t a = p[0], b = p[1], c = p[2];
-        uint4 o;
-        o.x = a & 0xFFFFFFu;
-        o.y = (a >> 24) | ((b & 0xFFFFu) << 8);
-        o.z = (b >> 16) | ((c & 0xFFu) << 16);
-        o.w = c >> 8;
-        *reinterpret_cast<uint4*>(&A[row * pw + 4 * q]) = o;
+    uint32_t lreg[AADG_MAX_OPS];
+    bool any_lut = false;
+#pragma unroll
+    for (int j = 0; j < AADG_MAX_OPS; ++j) {
+        lreg[j] = 0;
+        if (j < nops && needs_lds_lut(un.op[j])) {
+            any_lut = true;
+            if (tid < 192) lreg[j] = reinterpret_cast<const uint32_t*>(lut + (size_t)j * lut_stage_stride + (size_t)u * 768)[tid];
+        }
+    }
+    const int pw = c_hi - c_lo, ph = r_hi - r_lo, q4 = pw >> 2;
+    // thread <-> (row = wave + 4k, group of 4 pixels = lane (+64)): no integer divisions.  All loads of this
+    // thread are issued before the first use.
+    const int lane = tid & 63, wv = tid >> 6;
+    constexpr int NR = 6;                       // rows per wave: ph <= 22 < 4 * NR
+    uint32_t ra[NR], rb[NR], rc[NR], rd[NR], re[NR], rf[NR];
+    const bool has2 = lane + 64 < q4;           // patches wider than 256 pixels: a second group per lane
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int row = wv + 4 * k;
+        ra[k] = rb[k] = rc[k] = rd[k] = re[k] = rf[k] = 0;
+        if (row < ph) {
+            const uint8_t* rowp = src + ((size_t)(r_lo + row) * Ws + c_lo) * 3;
+            if (lane < q4) {
+                const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + 12 * lane);
+                ra[k] = p[0]; rb[k] = p[1]; rc[k] = p[2];
+            }
+            if (has2) {
+                const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + 12 * (lane + 64));
+                rd[k] = p[0]; re[k] = p[1]; rf[k] = p[2];
+            }
+        }
+    }
+    if (any_lut) {
+#pragma unroll
+        for (int j = 0; j < AADG_MAX_OPS; ++j)
+            if (j < nops && needs_lds_lut(un.op[j]) && tid < 192)
+                reinterpret_cast<uint32_t*>(sl_all + j * 768)[tid] = lreg[j];
+        __syncthreads();
+    }
+    int j0 = 0;                                   // leading pointwise segment [0, j0)
+    while (j0 < nops && !is_stencil(un, j0)) ++j0;
+    auto commit = [&](uint32_t a, uint32_t b, uint32_t c, int row, int q) {
+        uint32_t px[4] = {a & 0xFFFFFFu, (a >> 24) | ((b & 0xFFFFu) << 8), (b >> 16) | ((c & 0xFFu) << 16), c >> 8};
+        const int y = r_lo + row, x = c_lo + 4 * q;
+        for (int j = 0; j < j0; ++j) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) px[t] = pointwise_op(un, j, px[t], y, x + t, sl_all);
+        }
+        *reinterpret_cast<uint4*>(&A[row * pw + 4 * q]) = make_uint4(px[0], px[1], px[2], px[3]);
+    };
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int row = wv + 4 * k;
+        if (row < ph) {
+            if (lane < q4) commit(ra[k], rb[k], rc[k], row, lane);
+            if (has2) commit(rd[k], re[k], rf[k], row, lane + 64);
+        }
     }
     uint32_t* cur = A;
     uint32_t* oth = B;
     __syncthreads();
-    for (int j = 0; j < nops; ++j) {
-        const int op = un.op[j];
-        const float alpha = un.farg[j];
+    while (j0 < nops) {                           // op j0 is a Sharpness stencil
+        const float alpha = un.farg[j0];
         const bool interp = alpha >= 0.0f && alpha <= 1.0f;
-        if (op_is_lut(op)) {
-            const uint32_t* L = reinterpret_cast<const uint32_t*>(lut + (size_t)j * lut_stage_stride + (size_t)u * 768);
-            if (tid < 192) reinterpret_cast<uint32_t*>(sl)[tid] = L[tid];
-            __syncthreads();
-            for (int i = tid; i < npx; i += 256) {
-                const uint32_t p = cur[i];
-                cur[i] = (uint32_t)sl[p & 255] | ((uint32_t)sl[256 + ((p >> 8) & 255)] << 8) |
-                         ((uint32_t)sl[512 + ((p >> 16) & 255)] << 16);
-            }
-        } else if (op == AADG_OP_COLOR) {
-            if (alpha != 1.0f)
-                for (int i = tid; i < npx; i += 256) {
-                    const uint32_t p = cur[i];
-                    const uint32_t l = rgb2l(p & 255, (p >> 8) & 255, (p >> 16) & 255);
-                    cur[i] = blend3(l * 0x010101u, p, alpha, interp);
-                }
-        } else if (op == AADG_OP_CUTOUT) {
-            const int rx0 = un.rect[j][0], ry0 = un.rect[j][1], rx1 = un.rect[j][2], ry1 = un.rect[j][3];
-            for (int i = tid; i < npx; i += 256) {
-                const int row = i / pw, col = i - row * pw;
-                const int y = r_lo + row, x = c_lo + col;
-                if (x >= rx0 && x <= rx1 && y >= ry0 && y <= ry1) cur[i] = 0x7F7F7Fu;
-            }
-        } else if (op == AADG_OP_SHARPNESS && alpha != 1.0f) {
-            for (int i = tid; i < npx; i += 256) {
-                const int row = i / pw, col = i - row * pw;
+        int j1 = j0 + 1;
+        while (j1 < nops && !is_stencil(un, j1)) ++j1;
+        for (int row = wv; row < ph; row += 4) {
+            for (int col = lane; col < pw; col += 64) {
+                const int i = row * pw + col;
                 const int y = r_lo + row, x = c_lo + col;
                 const uint32_t p = cur[i];
                 uint32_t d = p;   // ImageFilter.SMOOTH copies the 1-pixel image border
@@ -591,25 +690,28 @@ __device__ uint32_t* build_patch(const aadg_unit& un, int nops, const uint8_t* _
                     const uint32_t r = ((srb & 0xFFFFu) + 6u) / 13u, b = ((srb >> 16) + 6u) / 13u, g = (sg + 6u) / 13u;
                     d = r | (g << 8) | (b << 16);
                 }
-                oth[i] = blend3(d, p, alpha, interp);
+                uint32_t v = blend3(d, p, alpha, interp);
+                for (int j = j0 + 1; j < j1; ++j) v = pointwise_op(un, j, v, y, x, sl_all);
+                oth[i] = v;
             }
-            uint32_t* t = cur; cur = oth; oth = t;
         }
+        uint32_t* t = cur; cur = oth; oth = t;
         __syncthreads();
+        j0 = j1;
     }
     return cur;
 }
 
 // k_hist_fused: grid (ceil(Ws/256), ceil(Hs/16), N); histogram of the image after `stage` ops (stage >= 1)
-__global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ pool, UnitRef ur, int stage, int Hs, int Ws,
-                                                    int crop, const uint8_t* __restrict__ lut, size_t lut_stage_stride,
-                                                    uint32_t* hist) {
+__global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ pool, const aadg_unit* __restrict__ units,
+                                                    int stage, int Hs, int Ws, int crop, const uint8_t* __restrict__ lut,
+                                                    size_t lut_stage_stride, uint32_t* hist) {
     const int u = blockIdx.z;
-    const aadg_unit& un = pick(ur, u);
-    if (un.n_ops <= stage || !op_needs_stats(un.op[stage]) || !unit_fusable(ur, un, Hs, Ws, crop)) return;
-    __shared__ __attribute__((aligned(16))) uint32_t A[PATCH_CAP];
-    __shared__ __attribute__((aligned(16))) uint32_t B[PATCH_CAP];
-    __shared__ __attribute__((aligned(16))) uint8_t sl[768];
+    const aadg_unit& un = units[u];
+    if (un.n_ops <= stage || !op_needs_stats(un.op[stage]) || !unit_fusable(true, un, Hs, Ws, crop)) return;
+    __shared__ __attribute__((aligned(16))) uint32_t A[5632];
+    __shared__ __attribute__((aligned(16))) uint32_t B[5632];
+    __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
     __shared__ uint32_t sh[768];
     const int tid = threadIdx.x;
     for (int i = tid; i < 768; i += 256) sh[i] = 0;
@@ -636,20 +738,36 @@ __global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ 
     if ((tid & 63) == 0 && lsum) atomicAdd(reinterpret_cast<unsigned long long*>(gh + 768), lsum);
 }
 
-// k_fused: grid (ceil(crop/256), ceil(crop/16), N)
-__global__ __launch_bounds__(256) void k_fused(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks, UnitRef ur,
+// np.float32(v) / 127.5 - 1.0 for an integer 0 <= v <= 255, bit-exact without a division: one Newton step on
+// the reciprocal product is correctly rounded for all 256 inputs (checked exhaustively, tests + DESIGN.md).
+__device__ __forceinline__ float normalise_u8(int v) {
+    const float x = (float)v;
+    const float r = 0.00784313725490196f;                 // float32(1 / 127.5)
+    const float q0 = __fmul_rn(x, r);
+    const float e = __fmaf_rn(-q0, 127.5f, x);
+    return __fsub_rn(__fmaf_rn(e, r, q0), 1.0f);
+}
+
+// k_fused: grid (ceil(crop/256), ceil(crop/TH), N).  Memory round trips are kept to three dependent levels:
+// unit record -> all table entries / LUTs (issued together) -> source patch; the mask gather of the vertical
+// phase is issued before the arithmetic it is independent of.
+template <int TH>
+__global__ __launch_bounds__(256) void k_fused(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
+                                               const aadg_unit* __restrict__ units,
                                                int Hs, int Ws, int crop, int dataset, const int* __restrict__ tab,
                                                const uint8_t* __restrict__ lut, size_t lut_stage_stride,
                                                float* __restrict__ out_img, float* __restrict__ out_lbl) {
+    constexpr int CAP = TH == 16 ? PATCH_CAP : 3584;     // pixels per patch buffer (13 x 268 = 3484 needed at TH = 8)
+    constexpr int ROWS_PER_WAVE = TH / 4;
     const int u = blockIdx.z;
-    const aadg_unit& un = pick(ur, u);
-    if (!unit_fusable(ur, un, Hs, Ws, crop)) return;
-    __shared__ __attribute__((aligned(16))) uint32_t A[PATCH_CAP];
-    __shared__ __attribute__((aligned(16))) uint32_t B[PATCH_CAP];
-    __shared__ __attribute__((aligned(16))) uint8_t sl[768];
+    const aadg_unit& un = units[u];
+    if (!unit_fusable(true, un, Hs, Ws, crop)) return;
+    __shared__ __attribute__((aligned(16))) uint32_t A[CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t B[CAP];
+    __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
     __shared__ float lutf[256];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    lutf[tid] = __fsub_rn(__fdiv_rn((float)tid, 127.5f), 1.0f);   // np.float32: x /= 127.5; x -= 1.0
+    lutf[tid] = normalise_u8(tid);
 
     const int K = dataset == AADG_DATASET_OPTIC ? 2 : 1;
     const int* base = tab + (size_t)u * crop * TAB_STRIDE;
@@ -661,8 +779,8 @@ __global__ __launch_bounds__(256) void k_fused(const uint8_t* __restrict__ pool,
     const int* ynn_t = xnn_t + crop;
 
     const int x0 = blockIdx.x * FT_W, x1 = min(x0 + FT_W, crop);
-    const int y0 = blockIdx.y * FT_H, y1 = min(y0 + FT_H, crop);
-    const int w = un.scaled_w, h = un.scaled_h;
+    const int y0 = blockIdx.y * TH, y1 = min(y0 + TH, crop);
+    const int w = un.scaled_w, h = un.scaled_h, n_ops = un.n_ops;
     const int ox = un.crop_x - un.pad, oy = un.crop_y - un.pad;
     // valid (non-pad) output range of this tile: scaled coordinate s = o + off must lie in [0, size)
     const int fx = max(x0, -ox), lx = min(x1 - 1, w - 1 - ox);
@@ -670,67 +788,96 @@ __global__ __launch_bounds__(256) void k_fused(const uint8_t* __restrict__ pool,
     const bool any = fx <= lx && fy <= ly;
     const int ntx = w == Ws ? 1 : 2, nty = h == Hs ? 1 : 2;   // taps of an up-scaling BILINEAR axis: <= 2
 
-    int r_lo = 0, r_hi = 0, c_lo_h = 0, r_lo_h = 0, pw = 4;
-    const uint32_t* cur = A;
+    // ---- level 2 loads, all independent: tile bounds, per-thread x tables, per-wave y tables, LUTs ----------
+    // tile bounds in the source image (uniform addresses: scalar loads)
+    int t_rlo = 0, t_rhi = 0, t_clo = 0, t_chi = 0;
+    if (any) { t_rlo = ymin_t[fy]; t_rhi = ymin_t[ly]; t_clo = xmin_t[fx]; t_chi = xmin_t[lx]; }
+    const int xh = x0 + tid;                         // horizontal pass: thread <-> output column
+    int hxm = -1, hk0 = 0, hk1 = 0;
+    if (any && xh >= fx && xh <= lx) {
+        hxm = xmin_t[xh];
+        hk0 = xk_t[(size_t)xh * KMAX];
+        hk1 = ntx > 1 ? xk_t[(size_t)xh * KMAX + 1] : 0;
+    }
+    const int xq = x0 + 4 * lane;                    // vertical pass: lane <-> 4 consecutive columns
+    const bool col_ok = xq < crop;
+    int4 xm4 = make_int4(-1, -1, -1, -1), xn4 = make_int4(-1, -1, -1, -1);
+    if (col_ok) {
+        xm4 = *reinterpret_cast<const int4*>(xmin_t + xq);
+        xn4 = *reinterpret_cast<const int4*>(xnn_t + xq);
+    }
+    int vym[ROWS_PER_WAVE], vk0[ROWS_PER_WAVE], vk1[ROWS_PER_WAVE], vyn[ROWS_PER_WAVE];
+#pragma unroll
+    for (int r = 0; r < ROWS_PER_WAVE; ++r) {
+        const int y = y0 + wv + 4 * r;
+        vym[r] = -1; vk0[r] = vk1[r] = 0; vyn[r] = -1;
+        if (y < y1) {
+            vym[r] = ymin_t[y];
+            vyn[r] = ynn_t[y];
+            vk0[r] = yk_t[(size_t)y * KMAX];
+            vk1[r] = nty > 1 ? yk_t[(size_t)y * KMAX + 1] : 0;
+        }
+    }
+
+    int r_lo = 0;
     uint32_t* Hbuf = B;
     if (any) {
-        r_lo = ymin_t[fy];
-        r_hi = min(Hs, ymin_t[ly] + nty);
-        const int c_lo = xmin_t[fx], c_hi = min(Ws, xmin_t[lx] + ntx);
-        const int s = sharp_count(un, un.n_ops);
-        r_lo_h = max(0, r_lo - s);
-        const int r_hi_h = min(Hs, r_hi + s);
-        c_lo_h = max(0, c_lo - s) & ~3;
-        const int c_hi_h = min(Ws, (c_hi + s + 3) & ~3);
-        pw = c_hi_h - c_lo_h;
+        r_lo = t_rlo;
+        const int r_hi = min(Hs, t_rhi + nty);
+        const int c_hi = min(Ws, t_chi + ntx);
+        const int s = sharp_count(un, n_ops);
+        const int r_lo_h = max(0, r_lo - s), r_hi_h = min(Hs, r_hi + s);
+        const int c_lo_h = max(0, t_clo - s) & ~3, c_hi_h = min(Ws, (c_hi + s + 3) & ~3);
+        const int pw = c_hi_h - c_lo_h;
         const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
-        cur = build_patch(un, un.n_ops, src, Hs, Ws, r_lo_h, r_hi_h, c_lo_h, c_hi_h, A, B, lut, lut_stage_stride, u, sl);
+        const uint32_t* cur = build_patch(un, n_ops, src, Hs, Ws, r_lo_h, r_hi_h, c_lo_h, c_hi_h, A, B, lut, lut_stage_stride, u, sl);
         Hbuf = cur == A ? B : A;
-        // ---- horizontal pass: thread <-> output column, loop over the needed source rows ------------
-        const int x = x0 + tid;
-        int xm = -1, k0 = 0, k1 = 0;
-        if (x >= fx && x <= lx) {
-            xm = xmin_t[x];
-            k0 = xk_t[(size_t)x * KMAX];
-            k1 = ntx > 1 ? xk_t[(size_t)x * KMAX + 1] : 0;
-        }
+        // ---- horizontal pass ---------------------------------------------------------------------------
         const int nrows = r_hi - r_lo;
-        if (xm >= 0) {
-            const uint32_t* col = cur + (r_lo - r_lo_h) * pw + (xm - c_lo_h);
+        if (hxm >= 0) {
+            const uint32_t* col = cur + (r_lo - r_lo_h) * pw + (hxm - c_lo_h);
             for (int rr = 0; rr < nrows; ++rr) {
                 const uint32_t p0 = col[rr * pw];
-                const uint32_t p1 = k1 ? col[rr * pw + 1] : 0u;
+                const uint32_t p1 = hk1 ? col[rr * pw + 1] : 0u;
                 const int half = 1 << (PRECISION_BITS - 1);
-                const int s0 = half + (int)(p0 & 255) * k0 + (int)(p1 & 255) * k1;
-                const int s1 = half + (int)((p0 >> 8) & 255) * k0 + (int)((p1 >> 8) & 255) * k1;
-                const int s2 = half + (int)((p0 >> 16) & 255) * k0 + (int)((p1 >> 16) & 255) * k1;
+                // pixel (8 bit) x coefficient (<= 2^22): 24-bit multiplies are full rate, v_mul_lo_u32 is not
+                const int s0 = half + __mul24((int)(p0 & 255), hk0) + __mul24((int)(p1 & 255), hk1);
+                const int s1 = half + __mul24((int)((p0 >> 8) & 255), hk0) + __mul24((int)((p1 >> 8) & 255), hk1);
+                const int s2 = half + __mul24((int)((p0 >> 16) & 255), hk0) + __mul24((int)((p1 >> 16) & 255), hk1);
                 Hbuf[rr * FT_W + tid] = (uint32_t)clip8(s0) | ((uint32_t)clip8(s1) << 8) | ((uint32_t)clip8(s2) << 16);
             }
         } else {
             for (int rr = 0; rr < nrows; ++rr) Hbuf[rr * FT_W + tid] = 0u;
         }
     }
+    // mask bytes for this wave's rows (needs only the NEAREST tables): in flight across the barrier
+    const uint8_t* msk = masks + (size_t)un.src * Hs * Ws;
+    const int xn[4] = {xn4.x, xn4.y, xn4.z, xn4.w};
+    uint32_t mv[ROWS_PER_WAVE][4];
+#pragma unroll
+    for (int r = 0; r < ROWS_PER_WAVE; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mv[r][i] = 0;
+            if (vyn[r] >= 0 && xn[i] >= 0) mv[r][i] = msk[(size_t)vyn[r] * Ws + xn[i]];
+        }
     __syncthreads();
 
-    // ---- vertical pass + normalise + store: wave <-> output row, lane <-> 4 consecutive columns -------
-    const int xq = x0 + 4 * lane;
-    if (xq >= crop) return;
-    const int4 xm4 = *reinterpret_cast<const int4*>(xmin_t + xq);
-    const int4 xn4 = *reinterpret_cast<const int4*>(xnn_t + xq);
+    // ---- vertical pass + normalise + store: wave <-> output row, lane <-> 4 consecutive columns -----------
+    if (!col_ok) return;
     const int xm[4] = {xm4.x, xm4.y, xm4.z, xm4.w};
-    const int xn[4] = {xn4.x, xn4.y, xn4.z, xn4.w};
     const size_t plane = (size_t)crop * crop;
     float* oi = out_img + (size_t)u * 3 * plane;
     float* ol = out_lbl + (size_t)u * K * plane;
-    const uint8_t* msk = masks + (size_t)un.src * Hs * Ws;
-    const float padv = lutf[0];
-    for (int y = y0 + wv; y < y1; y += 4) {
-        const int ym = ymin_t[y];
-        const int yn = ynn_t[y];
+    const float padv = -1.0f;                    // normalise(0)
+#pragma unroll
+    for (int r = 0; r < ROWS_PER_WAVE; ++r) {
+        const int y = y0 + wv + 4 * r;
+        if (y >= y1) break;
+        const int ym = vym[r];
         float o[3][4];
         if (ym >= 0) {
-            const int ky0 = yk_t[(size_t)y * KMAX];
-            const int ky1 = nty > 1 ? yk_t[(size_t)y * KMAX + 1] : 0;
+            const int ky0 = vk0[r], ky1 = vk1[r];
             const uint4 h0 = *reinterpret_cast<const uint4*>(Hbuf + (ym - r_lo) * FT_W + 4 * lane);
             uint4 h1 = make_uint4(0u, 0u, 0u, 0u);
             if (ky1) h1 = *reinterpret_cast<const uint4*>(Hbuf + (ym + 1 - r_lo) * FT_W + 4 * lane);
@@ -740,8 +887,8 @@ __global__ __launch_bounds__(256) void k_fused(const uint8_t* __restrict__ pool,
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const int v = (1 << (PRECISION_BITS - 1)) + (int)((a0[i] >> (8 * c)) & 255) * ky0 +
-                                  (int)((a1[i] >> (8 * c)) & 255) * ky1;
+                    const int v = (1 << (PRECISION_BITS - 1)) + __mul24((int)((a0[i] >> (8 * c)) & 255), ky0) +
+                                  __mul24((int)((a1[i] >> (8 * c)) & 255), ky1);
                     o[c][i] = xm[i] >= 0 ? lutf[clip8(v)] : padv;
                 }
             }
@@ -752,8 +899,7 @@ __global__ __launch_bounds__(256) void k_fused(const uint8_t* __restrict__ pool,
         float l0[4], l1[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            uint32_t m = 0;
-            if (yn >= 0 && xn[i] >= 0) m = msk[(size_t)yn * Ws + xn[i]];
+            const uint32_t m = mv[r][i];
             if (dataset == AADG_DATASET_OPTIC) { l0[i] = m <= 50 ? 1.0f : 0.0f; l1[i] = m <= 200 ? 1.0f : 0.0f; }
             else { l0[i] = m != 0 ? 1.0f : 0.0f; l1[i] = 0.0f; }
         }
@@ -807,7 +953,7 @@ int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int c
             }
             if (k > 0 && (classes & HINT_FUSED)) {
                 const dim3 gf((Ws + 255) / 256, (Hs + 15) / 16, N);
-                hipLaunchKernelGGL(k_hist_fused, gf, dim3(256), 0, st, bufs.pool, ur, k, Hs, Ws, crop, lut, lut_stage_stride, hist);
+                hipLaunchKernelGGL(k_hist_fused, gf, dim3(256), 0, st, bufs.pool, ur.units, k, Hs, Ws, crop, lut, lut_stage_stride, hist);
                 AADG_LAUNCH_CHECK();
             }
         }
@@ -859,9 +1005,16 @@ extern "C" int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks,
     AADG_LAUNCH_CHECK();
     if (ev_before_final) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_before_final), st));
     if (classes & HINT_FUSED) {
-        const dim3 g((crop + FT_W - 1) / FT_W, (crop + FT_H - 1) / FT_H, N);
-        hipLaunchKernelGGL(k_fused, g, dim3(256), 0, st, pool, masks, ur, Hs, Ws, crop, dataset, tab, ws8 + L.lut,
-                           (size_t)N * 768, out_img, out_lbl);
+        static const int tile_h = [] { const char* e = getenv("AADG_FUSED_TILE_H"); return e ? atoi(e) : FT_H; }();
+        if (tile_h == 8) {
+            const dim3 g((crop + FT_W - 1) / FT_W, (crop + 7) / 8, N);
+            hipLaunchKernelGGL(k_fused<8>, g, dim3(256), 0, st, pool, masks, units, Hs, Ws, crop, dataset, tab, ws8 + L.lut,
+                               (size_t)N * 768, out_img, out_lbl);
+        } else {
+            const dim3 g((crop + FT_W - 1) / FT_W, (crop + 15) / 16, N);
+            hipLaunchKernelGGL(k_fused<16>, g, dim3(256), 0, st, pool, masks, units, Hs, Ws, crop, dataset, tab, ws8 + L.lut,
+                               (size_t)N * 768, out_img, out_lbl);
+        }
         AADG_LAUNCH_CHECK();
     }
     if (classes & HINT_STAGED) {

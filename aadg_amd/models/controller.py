@@ -57,7 +57,7 @@ class Controller(nn.Module):
             yield self.outop, 0
             yield self.outmag, self.NUM_OPS
 
-    def _rollout(self, batch_size, forced=None):
+    def _rollout(self, batch_size, forced=None, want_entropy=False):
         """Shared by sample (forced=None: draw actions) and evaluate (forced = policies: teacher forcing)."""
         actions, log_probs, entropies, probs_op, probs_mag = [], [], [], [], []
         col = 0
@@ -67,11 +67,12 @@ class Controller(nn.Module):
                 hx, cx = self.lstm(inp, (hx, cx))
                 logits = head(hx)
                 logp = self._log_policy(logits)
-                if forced is None:
+                if forced is None or want_entropy:
                     p = F.softmax(self.C * torch.tanh(logits) / self.T, dim=-1)
-                    act = p.multinomial(num_samples=1)[:, 0]
                     entropies.append(-(logp * p).sum(1))
                     (probs_op if offset == 0 else probs_mag).append(p)
+                if forced is None:
+                    act = p.multinomial(num_samples=1)[:, 0]
                 else:
                     act = forced[:, col].long()
                 actions.append(act)

@@ -1,0 +1,113 @@
+"""hipGraph-captured controller step.
+
+The controller is launch-bound by construction: Q*L*2 = 20 sequential LSTMCell steps on a batch of M = 6
+(models/controller.py:73-145 in the reference) is ~200 micro-kernels for one sample() and, for the PPO update
+(losses.py:132-151: 5 x {evaluate, backward, Adam}), ~5000 more -- ~35 ms of pure launch latency per
+policy-search step on an MI355X, 30x the time of all augmentation / reward kernels together.  Both halves are
+therefore captured once into two HIP graphs (torch.cuda.CUDAGraph == hipGraph on ROCm) and replayed:
+
+  graph 1  sample:  policies, mean op/mag probs, sum log-prob, sum entropy   (no autograd; multinomial draws use
+                    the graph-registered Philox generator state, so every replay draws fresh actions)
+  graph 2  update:  PPO  -> 5 x { evaluate(policies) -> clipped surrogate -> backward -> Adam(capturable) }
+                    REINFORCE -> teacher-forced rollout (same log-probs / entropies as the sample) -> loss ->
+                    backward -> Adam
+
+Same arithmetic, same parameter updates as the eager criterion objects in aadg_amd/losses.py (checked by
+tests/test_gpu_controller_graph.py); the eager path remains the reference-API entry point and the CPU path.
+"""
+import torch
+
+from ..losses import ProximalPolicyOptimization, Reinforce
+
+
+class GraphedControllerStep(object):
+    def __init__(self, controller, criterion, optimizer, M):
+        if not torch.cuda.is_available():
+            raise RuntimeError("GraphedControllerStep needs a GPU")
+        self.controller, self.criterion, self.optimizer, self.M = controller, criterion, optimizer, M
+        dev = next(controller.parameters()).device
+        n_dec = controller.Q * controller.L * 2
+        self.policies = torch.zeros(M, n_dec, dtype=torch.int64, device=dev)
+        self.old_log_probs = torch.zeros(M, device=dev)
+        self.reward = torch.zeros(M, device=dev)
+        for group in optimizer.param_groups:
+            group['capturable'] = True
+        self._g_sample = self._g_update = None
+        self._sample_out = self._update_out = None
+
+    # ---- graph 1 -------------------------------------------------------------------------------------------
+    def _sample_body(self):
+        with torch.no_grad():
+            policies, op_probs, mag_probs, log_probs, entropies = self.controller.sample(self.M)
+            self.policies.copy_(policies)
+            self.old_log_probs.copy_(log_probs)
+        return op_probs, mag_probs, log_probs, entropies
+
+    def sample(self):
+        if self._g_sample is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self._sample_body()
+            torch.cuda.current_stream().wait_stream(side)
+            self._g_sample = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_sample):
+                self._sample_out = self._sample_body()
+        self._g_sample.replay()
+        op_probs, mag_probs, log_probs, entropies = self._sample_out
+        return self.policies, op_probs, mag_probs, log_probs, entropies
+
+    # ---- graph 2 -------------------------------------------------------------------------------------------
+    def _update_body(self):
+        crit, ctrl = self.criterion, self.controller
+        if isinstance(crit, ProximalPolicyOptimization):
+            total_loss = torch.zeros((), device=self.reward.device)
+            for _ in range(crit.n_updates_per_iteration):
+                ratios = torch.exp(ctrl.evaluate(self.policies, self.M) - self.old_log_probs)
+                clipped = torch.clamp(ratios, 1 - crit.clip, 1 + crit.clip)
+                loss = (-torch.min(ratios * self.reward, clipped * self.reward)).mean()
+                self.optimizer.zero_grad(set_to_none=True)
+                loss.backward()
+                self.optimizer.step()
+                total_loss = total_loss + loss.detach()
+            mean_loss = total_loss / crit.n_updates_per_iteration
+            return mean_loss, mean_loss
+        if isinstance(crit, Reinforce):
+            _, log_probs, entropies, _, _ = ctrl._rollout(self.M, forced=self.policies, want_entropy=True)
+            log_probs = torch.stack(log_probs, dim=-1).sum(dim=-1)
+            entropy_penalty = torch.stack(entropies, dim=-1).sum(dim=-1).mean()
+            score_loss = (-log_probs * self.reward).mean()
+            loss = score_loss - crit.penalty * entropy_penalty
+            self.optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            self.optimizer.step()
+            return loss.detach(), score_loss.detach()
+        raise NotImplementedError(type(crit))
+
+    def update(self, reward, entropies):
+        """Same return contract as the criterion call: (loss, score_loss, entropy_penalty)."""
+        self.reward.copy_(reward)
+        if self._g_update is None:
+            # warm-up iterations would move the parameters: snapshot and restore around them
+            params = [p.detach().clone() for p in self.controller.parameters()]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self._update_body()
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.no_grad():
+                for p, q in zip(self.controller.parameters(), params):
+                    p.copy_(q)
+            for state in self.optimizer.state.values():          # Adam moments / step back to zero
+                for v in state.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+            self.optimizer.zero_grad(set_to_none=True)
+            self._g_update = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_update):
+                self._update_out = self._update_body()
+        self._g_update.replay()
+        loss, score_loss = self._update_out
+        return loss, score_loss, entropies.mean()

@@ -185,23 +185,38 @@ class SearchState(object):
         self.controller_criterion = search_loss(config)
         self.dis_criterion = CrossEntropy()
         self.controller_criterion.register_optimizer(self.controller_optimizer)
+        # launch-bound controller sample / PPO update replayed as two HIP graphs (models/graphed.py)
+        self.graphed = None
+        if torch.cuda.is_available() and getattr(args, 'controller_graphs', True):
+            from .models.graphed import GraphedControllerStep
+            self.graphed = GraphedControllerStep(self.controller, self.controller_criterion, self.controller_optimizer, self.M)
 
     def search_step(self, epoch, writer_dict=None, logger=None, max_iters=None):
         """The epoch body of search_dg.py:338-347: sample M policies -> inject -> train -> EMA -> PPO."""
         self.controller.train()
-        policies, op_probs, mag_probs, log_probs, entropies = self.controller(self.M)
+        if self.graphed is not None:
+            policies, op_probs, mag_probs, log_probs, entropies = self.graphed.sample()
+        else:
+            policies, op_probs, mag_probs, log_probs, entropies = self.controller(self.M)
         if adist.is_dist():
             # the controller is replicated, not wrapped: make rank 0's draw authoritative and re-derive the
-            # (graph-carrying) log-probs for it -- evaluate() equals sample()'s log-prob for the same actions
+            # log-probs for it -- evaluate() equals sample()'s log-prob for the same actions
             torch.distributed.broadcast(policies, 0)
-            log_probs = self.controller.evaluate(policies, self.M)
+            if self.graphed is not None:
+                with torch.no_grad():
+                    self.graphed.old_log_probs.copy_(self.controller.evaluate(policies, self.M))
+            else:
+                log_probs = self.controller.evaluate(policies, self.M)
         parsed = parse_policies(policies.cpu().detach().numpy(), self.config, logger)
         self.train_loader.dataset.transforms.transforms[0] = DGMultiPolicy(parsed)
         normalized_rewards = train(self.config, self.train_loader, self.model, self.discriminator, self.model_criterion,
                                    self.dis_criterion, self.model_optimizer, self.dis_optimizer, self.M, epoch,
                                    writer_dict, logger, self.args, max_iters)
         _bare(self.discriminator).momentum_update()
-        losses = self.controller_criterion(self.controller, policies, log_probs, entropies, normalized_rewards)
+        if self.graphed is not None:
+            losses = self.graphed.update(normalized_rewards, entropies)
+        else:
+            losses = self.controller_criterion(self.controller, policies, log_probs, entropies, normalized_rewards)
         return parsed, op_probs, mag_probs, normalized_rewards, losses
 
 

@@ -191,7 +191,10 @@ def main():
     rewards = torch.zeros(M, device="cuda")
 
     def hot_step():
-        policies, _, _, log_probs, entropies = st.controller(M)
+        if st.graphed is not None:
+            policies, _, _, log_probs, entropies = st.graphed.sample()
+        else:
+            policies, _, _, log_probs, entropies = st.controller(M)
         parsed = parse_policies(policies.cpu().numpy(), cfg, None)
         st.train_loader.dataset.transforms.transforms[0] = DGMultiPolicy(parsed)
         sample = next(iter(st.train_loader))
@@ -199,7 +202,10 @@ def main():
         loss.backward()
         rewards.zero_()
         _lib.sinkhorn_rewards(fe, D, a.batch, M, rewards=rewards)
-        st.controller_criterion(st.controller, policies, log_probs, entropies, _lib.normalize_rewards(rewards))
+        if st.graphed is not None:
+            st.graphed.update(_lib.normalize_rewards(rewards), entropies)
+        else:
+            st.controller_criterion(st.controller, policies, log_probs, entropies, _lib.normalize_rewards(rewards))
         return sample
 
     units_last = None

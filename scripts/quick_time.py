@@ -19,6 +19,12 @@ def main():
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     K = 20
+    pe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    pe[0].record(); pe[1].record(); torch.cuda.synchronize()
+    _lib.PROFILE_EVENTS = pe
+    _lib.aug_u8_forward(d_img, d_msk, units, H, 0, oi, ol); torch.cuda.synchronize()
+    print("dominant kernel(s): %.3f ms" % pe[0].elapsed_time(pe[1]))
+    _lib.PROFILE_EVENTS = None
     e0.record()
     for _ in range(K): _lib.aug_u8_forward(d_img, d_msk, units, H, 0, oi, ol)
     e1.record(); torch.cuda.synchronize()
