@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--backbone_dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_units", type=int, default=24, help="units of the CPU-baseline sample")
+    ap.add_argument("--shard_of", type=int, default=0,
+                    help="single process: run only rank 0's row slice of a G-rank job (no collectives); used to "
+                         "pre-build the MIOpen kernel cache for the per-rank shapes of --gpus G runs")
     return ap.parse_args()
 
 
@@ -92,6 +95,22 @@ def algorithmic_bytes(units, Hs, Ws, crop, K):
         hist = any(o in (0, 2, 5) for o in ops)
         total += 3 * Hs * Ws * (2 if hist else 1) + Hs * Ws + (3 + K) * crop * crop * 4
     return total
+
+
+def measured_traffic(n_units, size):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
+    separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot collect
+    counters itself: it scales the committed per-unit measurement (profiles/traffic_k_fused.json, same kernel and
+    image size) by the number of units of its own launch; null when no matching measurement is committed."""
+    path = os.path.join(ROOT, "profiles", "traffic_k_fused.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        if rec.get("size") == size:
+            return int(rec["hbm_bytes_per_unit"]) * n_units
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def cpu_baseline(cfg, st, a, n_units):
@@ -144,6 +163,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.backends.cudnn.benchmark = False
+    emulate = a.shard_of if (world == 1 and a.shard_of > 1) else 0
     for seed_fn in (random.seed, np.random.seed, torch.manual_seed):
         seed_fn(1023)                                # identical on every rank: identical batch plans and policies
     from aadg_amd import _lib
@@ -151,6 +171,9 @@ def main():
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):     # keep stdout for the ONE JSON line
         cfg, st = build_state(a, local_rank, world)
+    if emulate:
+        from aadg_amd.data import transform as _T
+        _T.set_row_shard(0, emulate)
     M, D = st.M, len(cfg.DATASET.DG.TRAIN)
     n_rows = D * a.batch * M
 
@@ -185,7 +208,8 @@ def main():
     from aadg_amd.data import transform as T
     from aadg_amd.data.policy import DGMultiPolicy, parse_policies
     K = 2
-    lo, hi = (rank * n_rows // world, (rank + 1) * n_rows // world)
+    shards = emulate or world
+    lo, hi = (rank * n_rows // shards, (rank + 1) * n_rows // shards)
     z = torch.randn(hi - lo, K, a.size, a.size, device="cuda", requires_grad=True)
     fe = torch.nn.functional.leaky_relu(torch.randn(n_rows, 128, device="cuda"), 0.2)
     rewards = torch.zeros(M, device="cuda")
@@ -223,7 +247,7 @@ def main():
     batch = [st.train_loader.dataset[0] for _ in range(a.batch)]
     flat, refs, _ = T.collect_refs(batch, nested=True)
     S = len(flat)
-    lo_s, hi_s = rank * S // world, (rank + 1) * S // world
+    lo_s, hi_s = rank * S // shards, (rank + 1) * S // shards
     units = T.refs_to_units(refs[lo_s:hi_s] + refs[S + lo:S + hi])
     alg = algorithmic_bytes(units, a.size, a.size, a.size, K)
     achieved = alg / (kern_ms * 1e-3) / 1e9
@@ -241,9 +265,10 @@ def main():
                                    % (a.backbone, a.size, a.size, a.batch, M, n_rows),
                        "images_per_step": n_rows, "parallelism": "rows sharded over %d GPU(s)" % world,
                        "backbone_dtype": a.backbone_dtype},
-            "roofline": {"bound": "hbm", "kernel": "k_final (resample+crop+normalise+CHW store)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms},
+            "roofline": {"bound": "hbm", "kernel": "k_fused<16> (LDS-tiled ops + resample + crop + normalise + CHW store)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(len(units), a.size),
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms, "units_per_launch": len(units)},
             "hot_path": {"ms_per_step": hot_ms, "steps_per_s": 1e3 / hot_ms, "img_per_s": n_rows * 1e3 / hot_ms,
                          "what": "controller sample + parse + draw + augmentation kernels + BCE/Dice kernel (fwd+bwd) + "
                                  "Sinkhorn kernel + reward normalise + PPO; backbone and discriminator removed"},
