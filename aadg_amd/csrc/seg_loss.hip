@@ -24,8 +24,11 @@ struct Partial {
 };
 
 __device__ __forceinline__ void elem(float z, float y, float gscale, float& bce, int& tp, int& fp, int& fn, float* g) {
-    const float p = 1.0f / (1.0f + expf(-z));            // torch.sigmoid
-    float lp = logf(p), lq = log1pf(-p);                 // nn.BCELoss: logs clamped at -100
+    // torch.sigmoid then nn.BCELoss on the ROUNDED probability (so fp32 saturation behaves as in the reference:
+    // p == 1.0f -> log(1-p) clamps at -100).  Hardware exp/log/rcp (v_exp_f32, v_log_f32, v_rcp_f32; ~1 ulp)
+    // keep the per-policy means well inside the 1e-4 parity tolerance and make the pass bandwidth bound.
+    const float p = __frcp_rn(1.0f + __expf(-z));
+    float lp = __logf(p), lq = __logf(1.0f - p);         // logs clamped at -100
     lp = fmaxf(lp, -100.0f);
     lq = fmaxf(lq, -100.0f);
     bce += (y - 1.0f) * lq - y * lp;
@@ -33,7 +36,7 @@ __device__ __forceinline__ void elem(float z, float y, float gscale, float& bce,
     tp += pr & gt; fp += pr & (gt ^ 1); fn += (pr ^ 1) & gt;
     if (g) {
         const float pq = p * (1.0f - p);
-        *g = gscale * (p - y) / fmaxf(pq, 1e-12f) * pq;  // BCELoss backward (eps 1e-12) x sigmoid backward
+        *g = gscale * (p - y) * __frcp_rn(fmaxf(pq, 1e-12f)) * pq;  // BCELoss backward (eps 1e-12) x sigmoid backward
     }
 }
 

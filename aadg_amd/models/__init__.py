@@ -79,6 +79,10 @@ def load_ddp_discriminator(ngpus_per_node, args, cfg):
         model = FeatureDiscriminator(num_classes, in_channels)
     elif name == 'momentum_feature':
         model = MomentumFeatureDiscriminator(num_classes, in_channels)
+        # the EMA twin is only ever written by momentum_update()/synchronize_parameters(); marking it
+        # non-trainable keeps DDP from waiting for gradients that never come
+        for p in list(model.mom_dis.parameters()) + list(model.mom_fc.parameters()):
+            p.requires_grad_(False)
     else:
         raise NotImplementedError(name + ' has not been implemented!')
     return model.to(dev), cfg.TRAIN.BATCH_SIZE, args.workers

@@ -52,7 +52,7 @@ class GraphedControllerStep(object):
                     self._sample_body()
             torch.cuda.current_stream().wait_stream(side)
             self._g_sample = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g_sample):
+            with torch.cuda.graph(self._g_sample, capture_error_mode="thread_local"):
                 self._sample_out = self._sample_body()
         self._g_sample.replay()
         op_probs, mag_probs, log_probs, entropies = self._sample_out
@@ -106,7 +106,7 @@ class GraphedControllerStep(object):
                         v.zero_()
             self.optimizer.zero_grad(set_to_none=True)
             self._g_update = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g_update):
+            with torch.cuda.graph(self._g_update, capture_error_mode="thread_local"):
                 self._update_out = self._update_body()
         self._g_update.replay()
         loss, score_loss = self._update_out

@@ -96,7 +96,14 @@ def inner_iteration(config, sample, model, discriminator, dis_criterion, model_o
     # reward: all-gather the [rows_local, 128] embeddings once, then ONE kernel for all M x P problems
     fe_all = domain_feature.contiguous()
     if hi - lo != n_rows:
-        fe_all = adist.all_gather([fe_all])[0]
+        if adist.is_dist():
+            fe_all = adist.all_gather([fe_all])[0]
+        elif getattr(args, 'emulate_shards', 0):
+            # single-process emulation of one rank of a sharded job (bench.py --shard_of, used to pre-build
+            # kernel caches for the per-rank shapes): stand in for the missing peers by repetition
+            fe_all = fe_all.repeat(n_rows // (hi - lo), 1)
+        else:
+            raise RuntimeError("row-sharded batch without an initialised process group")
     before = rewards.clone()
     B = n_rows // (M * n_domains)
     _lib.sinkhorn_rewards(fe_all, n_domains, B, M, rewards=rewards)
@@ -195,8 +202,13 @@ class SearchState(object):
         """The epoch body of search_dg.py:338-347: sample M policies -> inject -> train -> EMA -> PPO."""
         self.controller.train()
         if self.graphed is not None:
-            policies, op_probs, mag_probs, log_probs, entropies = self.graphed.sample()
-        else:
+            try:
+                policies, op_probs, mag_probs, log_probs, entropies = self.graphed.sample()
+            except RuntimeError as e:                      # capture refused (e.g. by another thread's HIP call)
+                import sys
+                print("aadg_amd: controller graph capture failed (%s); using the eager controller" % e, file=sys.stderr)
+                self.graphed = None
+        if self.graphed is None:
             policies, op_probs, mag_probs, log_probs, entropies = self.controller(self.M)
         if adist.is_dist():
             # the controller is replicated, not wrapped: make rank 0's draw authoritative and re-derive the
@@ -213,9 +225,18 @@ class SearchState(object):
                                    self.dis_criterion, self.model_optimizer, self.dis_optimizer, self.M, epoch,
                                    writer_dict, logger, self.args, max_iters)
         _bare(self.discriminator).momentum_update()
+        losses = None
         if self.graphed is not None:
-            losses = self.graphed.update(normalized_rewards, entropies)
-        else:
+            try:
+                losses = self.graphed.update(normalized_rewards, entropies)
+            except RuntimeError as e:
+                import sys
+                print("aadg_amd: controller update graph capture failed (%s); using the eager criterion" % e, file=sys.stderr)
+                self.graphed = None
+                policies = policies.clone()
+                _, lps, ents, _, _ = self.controller._rollout(self.M, forced=policies, want_entropy=True)
+                log_probs, entropies = torch.stack(lps, -1).sum(-1), torch.stack(ents, -1).sum(-1)
+        if losses is None:
             losses = self.controller_criterion(self.controller, policies, log_probs, entropies, normalized_rewards)
         return parsed, op_probs, mag_probs, normalized_rewards, losses
 

@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--backbone_dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_units", type=int, default=24, help="units of the CPU-baseline sample")
+    ap.add_argument("--dist_backend", default="nccl", help="nccl (= RCCL) by default; gloo for single-GPU functional tests")
+    ap.add_argument("--all_ranks_on_gpu0", action="store_true", help="functional test of the N>1 path on a 1-GPU box")
     ap.add_argument("--shard_of", type=int, default=0,
                     help="single process: run only rank 0's row slice of a G-rank job (no collectives); used to "
                          "pre-build the MIOpen kernel cache for the per-rank shapes of --gpus G runs")
@@ -158,10 +160,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU product path)"
+    if a.all_ranks_on_gpu0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.dist_backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            torch.distributed.init_process_group(a.dist_backend)
     torch.backends.cudnn.benchmark = False
     emulate = a.shard_of if (world == 1 and a.shard_of > 1) else 0
     for seed_fn in (random.seed, np.random.seed, torch.manual_seed):
@@ -174,6 +181,7 @@ def main():
     if emulate:
         from aadg_amd.data import transform as _T
         _T.set_row_shard(0, emulate)
+        st.args.emulate_shards = emulate
     M, D = st.M, len(cfg.DATASET.DG.TRAIN)
     n_rows = D * a.batch * M
 

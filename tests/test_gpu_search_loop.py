@@ -1,0 +1,61 @@
+"""GPU: the search driver end to end through the reference CLI (run.py --cfg ...), short synthetic run:
+warm-up epoch -> EMA sync -> 2 policy-search epochs (controller graphs, fused augmentation, BCE/Dice and
+Sinkhorn kernels, PPO) -> validation -> the reference's on-disk artefacts (search_dg.py:388-407)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_run_py_search_smoke(hip, tmp_path):
+    import run
+    from aadg_amd.config.defaults import _C
+    args = ["--cfg", os.path.join(ROOT, "experiments", "optic_sinkhorn", "smoke.yaml"), "--output_dir", str(tmp_path / "out"),
+            "--crop_size", "64", "--epoch_items", "4", "--backbone_dtype", "bf16"]
+    _C.defrost()
+    _C.LOG_DIR = str(tmp_path / "log")
+    best = run.main(args)
+    assert set(best) >= {"epoch", "avg_dsc", "cup_dsc", "disc_dsc"}
+    outs = glob.glob(str(tmp_path / "out" / "optic" / "smoke_*"))
+    assert len(outs) == 1
+    d = outs[0]
+    for f in ("final_model_state.pth", "final_controller_state.pth", "mag_probs_trajectory.npy",
+              "op_probs_trajectory.npy", "final_result.json", "train.log"):
+        assert os.path.exists(os.path.join(d, f)), f
+    assert np.load(os.path.join(d, "op_probs_trajectory.npy")).shape == (2, 10)
+    assert np.load(os.path.join(d, "mag_probs_trajectory.npy")).shape == (2, 10)
+    sd = torch.load(os.path.join(d, "final_controller_state.pth"), map_location="cpu")
+    assert set(k.split(".")[0] for k in sd) == {"embedding", "lstm", "outop", "outmag"}
+    json.load(open(os.path.join(d, "final_result.json")))
+    log = open(os.path.join(d, "train.log")).read()
+    assert "OT" in log and "controller loss" in log
+    assert all(np.isfinite(float(x)) for x in [best["avg_dsc"]])
+
+
+def test_baseline_config0_fixed_policy_vessel(hip, oracle):
+    """BASELINE configs[0]: single-domain vessel data, FIXED policy [Contrast .5, Sharpness .5] (no controller
+    search), 256x256, batch 2 -- the reference's CPU-runnable plumbing case, HIP vs oracle, bit-exact."""
+    import random
+    from aadg_amd.data import transform as T
+    from aadg_amd.data.basic import DevicePool
+    from aadg_amd.data.policy import DGMultiPolicy
+    from aadg_amd.data.synthetic import make_pool
+    imgs, msks = make_pool(7, 1, 4, 256, 256, 'rvs')
+    pool = DevicePool(torch.from_numpy(imgs).cuda(), torch.from_numpy(msks).cuda())
+    fixed = [[[('Contrast', 0.5), ('Sharpness', 0.5)]]]                       # M = 1 policy, Q = 1 sub-policy, L = 2
+    tf = T.Compose([DGMultiPolicy(fixed), T.DGRandomScaleCrop(256, scale_range=[0.5, 2]), T.Normalize_dg('vessel'), T.ToTensor('vessel')])
+    random.seed(3)
+    np.random.seed(3)
+    batch = [[tf({'image': pool.image(i), 'label': pool.mask(i), 'img_name': 'v%d' % i, 'dc': 0})] for i in range(2)]
+    flat, refs, M = T.collect_refs(batch, nested=True)
+    units = T.refs_to_units(refs)
+    got_img, got_lbl = T.materialize(refs)
+    want_img, want_lbl = oracle.aug_units(imgs, msks, units, 256, 1)
+    assert got_lbl.shape[1] == 1
+    assert np.array_equal(got_img.cpu().numpy(), want_img) and np.array_equal(got_lbl.cpu().numpy(), want_lbl)
