@@ -171,10 +171,13 @@ def launch_hints(units, Hs, Ws, crop):
     n_ops = units["n_ops"]
     live = np.arange(MAX_OPS)[None, :] < n_ops[:, None]
     sharp = ((units["op"] == 8) & (units["farg"] != np.float32(1.0)) & live).sum(axis=1)
-    fusable = (units["scaled_w"] >= Ws) & (units["scaled_h"] >= Hs) & (sharp <= 2)
+    ok = sharp <= 2
     if (Ws & 3) or (crop & 3):
-        fusable[:] = False
-    classes = (1 if fusable.any() else 0) | (2 if (~fusable).any() else 0)
+        ok[:] = False
+    up = ok & (units["scaled_w"] >= Ws) & (units["scaled_h"] >= Hs)
+    generic = ok & ~up & (2 * units["scaled_w"] >= Ws) & (2 * units["scaled_h"] >= Hs)
+    staged = ~(up | generic)
+    classes = (1 if up.any() else 0) | (2 if staged.any() else 0) | (4 if generic.any() else 0)
     needs = np.isin(units["op"], (0, 2, 5)) & live
     stats_mask = 0
     for k in range(MAX_OPS):

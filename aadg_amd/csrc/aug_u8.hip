@@ -65,10 +65,18 @@ __device__ __forceinline__ int sharp_count(const aadg_unit& un, int upto) {
     for (int k = 0; k < upto; ++k) s += (un.op[k] == AADG_OP_SHARPNESS && un.farg[k] != 1.0f) ? 1 : 0;
     return s;
 }
+// data flow of a unit: 0 = staged, 1 = fused "UP" tile (no down-scaling: <= 2 taps per axis), 2 = fused
+// "GENERIC" tile (down-scaling by at most 2x on either axis: <= 5 taps)
+enum { FLOW_STAGED = 0, FLOW_UP = 1, FLOW_GENERIC = 2 };
+__device__ __forceinline__ int unit_flow(bool allow, const aadg_unit& un, int Hs, int Ws, int crop) {
+    if (!allow || (Ws & 3) || (crop & 3)) return FLOW_STAGED;
+    if (sharp_count(un, un.n_ops) > MAX_SHARP) return FLOW_STAGED;
+    if (un.scaled_w >= Ws && un.scaled_h >= Hs) return FLOW_UP;
+    if (2 * un.scaled_w >= Ws && 2 * un.scaled_h >= Hs) return FLOW_GENERIC;
+    return FLOW_STAGED;
+}
 __device__ __forceinline__ bool unit_fusable(bool allow, const aadg_unit& un, int Hs, int Ws, int crop) {
-    if (!allow || (Ws & 3) || (crop & 3)) return false;
-    if (un.scaled_w < Ws || un.scaled_h < Hs) return false;
-    return sharp_count(un, un.n_ops) <= MAX_SHARP;
+    return unit_flow(allow, un, Hs, Ws, crop) != FLOW_STAGED;
 }
 __device__ __forceinline__ bool unit_fusable(const UnitRef& ur, const aadg_unit& un, int Hs, int Ws, int crop) {
     return unit_fusable(ur.allow_fused != 0, un, Hs, Ws, crop);
@@ -600,6 +608,7 @@ __device__ __forceinline__ bool is_stencil(const aadg_unit& un, int j) {
 // Loads the patch (12-byte vector loads, all issued up front), applies the leading pointwise ops while the
 // pixels are still in registers, stores RGBX words to LDS; every Sharpness op then costs one LDS ping-pong
 // pass, into which the pointwise ops that follow it are folded.
+template <int NR, bool WIDE>
 __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, const uint8_t* __restrict__ src, int Hs, int Ws,
                                  int r_lo, int r_hi, int c_lo, int c_hi, uint32_t* A, uint32_t* B,
                                  const uint8_t* __restrict__ lut, size_t lut_stage_stride, int u, uint8_t* sl_all) {
@@ -618,22 +627,24 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
     // thread <-> (row = wave + 4k, group of 4 pixels = lane (+64)): no integer divisions.  All loads of this
     // thread are issued before the first use.
     const int lane = tid & 63, wv = tid >> 6;
-    constexpr int NR = 6;                       // rows per wave: ph <= 22 < 4 * NR
-    uint32_t ra[NR], rb[NR], rc[NR], rd[NR], re[NR], rf[NR];
-    const bool has2 = lane + 64 < q4;           // patches wider than 256 pixels: a second group per lane
+    // NR = rows per wave (4 * NR >= patch rows); WIDE = patch may be wider than 256 pixels (second group per lane)
+    constexpr int NW = WIDE ? NR : 1;
+    uint32_t ra[NR], rb[NR], rc[NR], rd[NW], re[NW], rf[NW];
+    const bool has2 = WIDE && lane + 64 < q4;
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
         const int row = wv + 4 * k;
-        ra[k] = rb[k] = rc[k] = rd[k] = re[k] = rf[k] = 0;
+        ra[k] = rb[k] = rc[k] = 0;
+        if (WIDE) rd[k % NW] = re[k % NW] = rf[k % NW] = 0;
         if (row < ph) {
             const uint8_t* rowp = src + ((size_t)(r_lo + row) * Ws + c_lo) * 3;
             if (lane < q4) {
                 const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + 12 * lane);
                 ra[k] = p[0]; rb[k] = p[1]; rc[k] = p[2];
             }
-            if (has2) {
+            if (WIDE && has2) {
                 const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + 12 * (lane + 64));
-                rd[k] = p[0]; re[k] = p[1]; rf[k] = p[2];
+                rd[k % NW] = p[0]; re[k % NW] = p[1]; rf[k % NW] = p[2];
             }
         }
     }
@@ -660,7 +671,7 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
         const int row = wv + 4 * k;
         if (row < ph) {
             if (lane < q4) commit(ra[k], rb[k], rc[k], row, lane);
-            if (has2) commit(rd[k], re[k], rf[k], row, lane + 64);
+            if (WIDE && has2) commit(rd[k % NW], re[k % NW], rf[k % NW], row, lane + 64);
         }
     }
     uint32_t* cur = A;
@@ -721,7 +732,7 @@ __global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ 
     const int r_lo = max(0, ry0 - s), r_hi = min(Hs, ry1 + s);
     const int c_lo = max(0, cx0 - s) & ~3, c_hi = min(Ws, (cx1 + s + 3) & ~3);
     const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
-    const uint32_t* cur = build_patch(un, stage, src, Hs, Ws, r_lo, r_hi, c_lo, c_hi, A, B, lut, lut_stage_stride, u, sl);
+    const uint32_t* cur = build_patch<6, true>(un, stage, src, Hs, Ws, r_lo, r_hi, c_lo, c_hi, A, B, lut, lut_stage_stride, u, sl);
     const int pw = c_hi - c_lo, rw = cx1 - cx0, n = (ry1 - ry0) * rw;
     unsigned long long lsum = 0;
     for (int i = tid; i < n; i += 256) {
@@ -764,7 +775,7 @@ __device__ __forceinline__ void fused_tile(const uint8_t* __restrict__ pool, con
                                            int u, int bx, int by, uint32_t* A, uint32_t* B, uint8_t* sl, const float* lutf) {
     constexpr int ROWS_PER_WAVE = TH / 4;
     const aadg_unit& un = units[u];
-    if (!unit_fusable(true, un, Hs, Ws, crop)) return;
+    if (unit_flow(true, un, Hs, Ws, crop) != FLOW_UP) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     const int K = dataset == AADG_DATASET_OPTIC ? 2 : 1;
@@ -828,7 +839,7 @@ __device__ __forceinline__ void fused_tile(const uint8_t* __restrict__ pool, con
         const int c_lo_h = max(0, t_clo - s) & ~3, c_hi_h = min(Ws, (c_hi + s + 3) & ~3);
         const int pw = c_hi_h - c_lo_h;
         const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
-        const uint32_t* cur = build_patch(un, n_ops, src, Hs, Ws, r_lo_h, r_hi_h, c_lo_h, c_hi_h, A, B, lut, lut_stage_stride, u, sl);
+        const uint32_t* cur = build_patch<6, true>(un, n_ops, src, Hs, Ws, r_lo_h, r_hi_h, c_lo_h, c_hi_h, A, B, lut, lut_stage_stride, u, sl);
         Hbuf = cur == A ? B : A;
         // ---- horizontal pass ---------------------------------------------------------------------------
         const int nrows = r_hi - r_lo;
@@ -910,6 +921,180 @@ __device__ __forceinline__ void fused_tile(const uint8_t* __restrict__ pool, con
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// GENERIC fused tile: any axis scale in [1/2, inf) (Pillow's antialiased BILINEAR: up to 5 taps when shrinking
+// by 2).  Tile = 64 x 16 outputs: the source patch of a 2x down-scale (<= 41 x 144 pixels) fits the same two
+// 24 KiB LDS buffers as the UP tile.  Horizontal: thread <-> (column, row group); vertical: a wave covers
+// 4 rows x 64 columns (16 lanes x float4 per row).
+// ------------------------------------------------------------------------------------------------
+constexpr int GT_W = 64, GT_H = 16, GT_TAPS = 5;
+
+__device__ __forceinline__ int axis_taps(int inSize, int outSize) {
+    if (inSize == outSize) return 1;
+    if (outSize > inSize) return 2;
+    const double scale = (double)inSize / (double)outSize;      // in (1, 2]
+    return (int)ceil(scale) * 2 + 1;                            // Pillow ksize; 5 for scale <= 2
+}
+
+__global__ __launch_bounds__(256) void k_fused_generic(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
+                                                       const aadg_unit* __restrict__ units, int Hs, int Ws, int crop, int dataset,
+                                                       const int* __restrict__ tab, const uint8_t* __restrict__ lut,
+                                                       size_t lut_stage_stride, float* __restrict__ out_img,
+                                                       float* __restrict__ out_lbl) {
+    const int u = blockIdx.z;
+    const aadg_unit& un = units[u];
+    if (unit_flow(true, un, Hs, Ws, crop) != FLOW_GENERIC) return;
+    __shared__ __attribute__((aligned(16))) uint32_t A[PATCH_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t B[PATCH_CAP];
+    __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
+    __shared__ float lutf[256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    lutf[tid] = normalise_u8(tid);
+
+    const int K = dataset == AADG_DATASET_OPTIC ? 2 : 1;
+    const int* base = tab + (size_t)u * crop * TAB_STRIDE;
+    const int* xmin_t = base;
+    const int* xk_t = xmin_t + crop;
+    const int* ymin_t = xk_t + (size_t)crop * KMAX;
+    const int* yk_t = ymin_t + crop;
+    const int* xnn_t = yk_t + (size_t)crop * KMAX;
+    const int* ynn_t = xnn_t + crop;
+
+    const int x0 = blockIdx.x * GT_W, x1 = min(x0 + GT_W, crop);
+    const int y0 = blockIdx.y * GT_H, y1 = min(y0 + GT_H, crop);
+    const int w = un.scaled_w, h = un.scaled_h, n_ops = un.n_ops;
+    const int ox = un.crop_x - un.pad, oy = un.crop_y - un.pad;
+    const int fx = max(x0, -ox), lx = min(x1 - 1, w - 1 - ox);
+    const int fy = max(y0, -oy), ly = min(y1 - 1, h - 1 - oy);
+    const bool any = fx <= lx && fy <= ly;
+    const int ntx = axis_taps(Ws, w), nty = axis_taps(Hs, h);
+
+    // horizontal pass: thread <-> (output column hc, row group hg)
+    const int hc = tid & (GT_W - 1), hg = tid >> 6;
+    const int xh = x0 + hc;
+    int hxm = -1, hk[GT_TAPS];
+#pragma unroll
+    for (int t = 0; t < GT_TAPS; ++t) hk[t] = 0;
+    if (any && xh >= fx && xh <= lx) {
+        hxm = xmin_t[xh];
+#pragma unroll
+        for (int t = 0; t < GT_TAPS; ++t) if (t < ntx) hk[t] = xk_t[(size_t)xh * KMAX + t];
+    }
+    // vertical pass: lane <-> (row-in-wave vr = lane >> 4, 4 consecutive columns)
+    const int vr = lane >> 4, xq = x0 + 4 * (lane & 15);
+    const bool col_ok = xq < crop;
+    int4 xm4 = make_int4(-1, -1, -1, -1), xn4 = make_int4(-1, -1, -1, -1);
+    if (col_ok) {
+        xm4 = *reinterpret_cast<const int4*>(xmin_t + xq);
+        xn4 = *reinterpret_cast<const int4*>(xnn_t + xq);
+    }
+    const int yv = y0 + wv * 4 + vr;                 // this lane's output row (one row per lane group, one pass)
+    const bool row_ok = yv < y1;
+    int vym = -1, vyn = -1, vk[GT_TAPS];
+#pragma unroll
+    for (int t = 0; t < GT_TAPS; ++t) vk[t] = 0;
+    if (row_ok) {
+        vym = ymin_t[yv];
+        vyn = ynn_t[yv];
+#pragma unroll
+        for (int t = 0; t < GT_TAPS; ++t) if (t < nty) vk[t] = yk_t[(size_t)yv * KMAX + t];
+    }
+
+    int r_lo = 0, nrows = 0;
+    uint32_t* Hbuf = B;
+    if (any) {
+        r_lo = ymin_t[fy];
+        const int r_hi = min(Hs, ymin_t[ly] + nty);
+        const int c_lo = xmin_t[fx], c_hi = min(Ws, xmin_t[lx] + ntx);
+        const int s = sharp_count(un, n_ops);
+        const int r_lo_h = max(0, r_lo - s), r_hi_h = min(Hs, r_hi + s);
+        const int c_lo_h = max(0, c_lo - s) & ~3, c_hi_h = min(Ws, (c_hi + s + 3) & ~3);
+        const int pw = c_hi_h - c_lo_h;
+        const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
+        const uint32_t* cur = build_patch<11, false>(un, n_ops, src, Hs, Ws, r_lo_h, r_hi_h, c_lo_h, c_hi_h, A, B, lut,
+                                                     lut_stage_stride, u, sl);
+        Hbuf = cur == A ? B : A;
+        nrows = r_hi - r_lo;
+        const int pcols = c_hi_h - c_lo_h;
+        for (int rr = hg; rr < nrows; rr += 4) {
+            uint32_t packed = 0u;
+            if (hxm >= 0) {
+                const uint32_t* rowp = cur + (r_lo - r_lo_h + rr) * pw + (hxm - c_lo_h);
+                const int lim = pcols - (hxm - c_lo_h);          // taps beyond the patch have zero coefficients
+                int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+#pragma unroll
+                for (int t = 0; t < GT_TAPS; ++t) {
+                    if (t < ntx) {
+                        const uint32_t p = rowp[t < lim ? t : 0];
+                        s0 += __mul24((int)(p & 255), hk[t]);
+                        s1 += __mul24((int)((p >> 8) & 255), hk[t]);
+                        s2 += __mul24((int)((p >> 16) & 255), hk[t]);
+                    }
+                }
+                packed = (uint32_t)clip8(s0) | ((uint32_t)clip8(s1) << 8) | ((uint32_t)clip8(s2) << 16);
+            }
+            Hbuf[rr * GT_W + hc] = packed;
+        }
+    }
+    // mask bytes (NEAREST tables only)
+    const uint8_t* msk = masks + (size_t)un.src * Hs * Ws;
+    const int xn[4] = {xn4.x, xn4.y, xn4.z, xn4.w};
+    uint32_t mv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        mv[i] = 0;
+        if (row_ok && vyn >= 0 && xn[i] >= 0) mv[i] = msk[(size_t)vyn * Ws + xn[i]];
+    }
+    __syncthreads();
+    if (!col_ok || !row_ok) return;
+    const int xm[4] = {xm4.x, xm4.y, xm4.z, xm4.w};
+    const size_t plane = (size_t)crop * crop;
+    float* oi = out_img + (size_t)u * 3 * plane;
+    float* ol = out_lbl + (size_t)u * K * plane;
+    const float padv = -1.0f;
+    float o[3][4];
+    if (vym >= 0) {
+        int acc[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = 1 << (PRECISION_BITS - 1);
+#pragma unroll
+        for (int t = 0; t < GT_TAPS; ++t) {
+            if (t < nty) {
+                int hr = vym + t - r_lo;
+                hr = hr < nrows ? hr : nrows - 1;                // zero coefficient beyond the last row
+                const uint4 hv = *reinterpret_cast<const uint4*>(Hbuf + hr * GT_W + 4 * (lane & 15));
+                const uint32_t a[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][0] += __mul24((int)(a[i] & 255), vk[t]);
+                    acc[i][1] += __mul24((int)((a[i] >> 8) & 255), vk[t]);
+                    acc[i][2] += __mul24((int)((a[i] >> 16) & 255), vk[t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c][i] = xm[i] >= 0 ? lutf[clip8(acc[i][c])] : padv;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[0][i] = o[1][i] = o[2][i] = padv;
+    }
+    float l0[4], l1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t m = mv[i];
+        if (dataset == AADG_DATASET_OPTIC) { l0[i] = m <= 50 ? 1.0f : 0.0f; l1[i] = m <= 200 ? 1.0f : 0.0f; }
+        else { l0[i] = m != 0 ? 1.0f : 0.0f; l1[i] = 0.0f; }
+    }
+    const size_t off = (size_t)yv * crop + xq;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        *reinterpret_cast<float4*>(oi + c * plane + off) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+    *reinterpret_cast<float4*>(ol + off) = make_float4(l0[0], l0[1], l0[2], l0[3]);
+    if (K == 2) *reinterpret_cast<float4*>(ol + plane + off) = make_float4(l1[0], l1[1], l1[2], l1[3]);
+}
+
 // one workgroup per tile
 template <int TH>
 __global__ __launch_bounds__(256) void k_fused(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
@@ -970,7 +1155,7 @@ int chunks_for(int npix) {
 }
 
 // hints from a caller that has the unit records on the host (all bits set = unknown, launch everything)
-constexpr int HINT_FUSED = 1, HINT_STAGED = 2;
+constexpr int HINT_FUSED = 1, HINT_STAGED = 2, HINT_GENERIC = 4;
 
 // statistics + LUT (+ staged apply) for stages [0, max_ops)
 int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int crop, int max_ops, uint8_t* ws8,
@@ -987,7 +1172,7 @@ int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int c
                 hipLaunchKernelGGL(k_hist, g, dim3(256), 0, st, bufs, ur, k, npix, Hs, Ws, crop, hist);
                 AADG_LAUNCH_CHECK();
             }
-            if (k > 0 && (classes & HINT_FUSED)) {
+            if (k > 0 && (classes & (HINT_FUSED | HINT_GENERIC))) {
                 const dim3 gf((Ws + 255) / 256, (Hs + 15) / 16, N);
                 hipLaunchKernelGGL(k_hist_fused, gf, dim3(256), 0, st, bufs.pool, ur.units, k, Hs, Ws, crop, lut, lut_stage_stride, hist);
                 AADG_LAUNCH_CHECK();
@@ -1030,8 +1215,8 @@ extern "C" int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks,
     ur.use_single = 0;
     ur.allow_fused = 1;
     ::memset(&ur.single, 0, sizeof(ur.single));
-    int classes = classes_hint & (HINT_FUSED | HINT_STAGED);
-    if (classes == 0) classes = HINT_FUSED | HINT_STAGED;
+    int classes = classes_hint & (HINT_FUSED | HINT_STAGED | HINT_GENERIC);
+    if (classes == 0) classes = HINT_FUSED | HINT_STAGED | HINT_GENERIC;
     if ((Ws & 3) || (crop & 3)) classes = HINT_STAGED;        // unit_fusable() is false for every unit
     const int stats_mask = stats_mask_hint < 0 ? 0xF : stats_mask_hint;
     int rc = run_stages(bufs, ur, N, Hs, Ws, crop, max_ops, ws8, L, nullptr, classes, stats_mask, st);
@@ -1055,6 +1240,12 @@ extern "C" int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks,
             hipLaunchKernelGGL(k_fused<16>, g, dim3(256), 0, st, pool, masks, units, Hs, Ws, crop, dataset, tab, ws8 + L.lut,
                                (size_t)N * 768, out_img, out_lbl);
         }
+        AADG_LAUNCH_CHECK();
+    }
+    if (classes & HINT_GENERIC) {
+        const dim3 g((crop + GT_W - 1) / GT_W, (crop + GT_H - 1) / GT_H, N);
+        hipLaunchKernelGGL(k_fused_generic, g, dim3(256), 0, st, pool, masks, units, Hs, Ws, crop, dataset, tab, ws8 + L.lut,
+                           (size_t)N * 768, out_img, out_lbl);
         AADG_LAUNCH_CHECK();
     }
     if (classes & HINT_STAGED) {

@@ -88,8 +88,9 @@ int aadg_aug_u8_forward(const uint8_t* pool, const uint8_t* masks, int P, int Hs
 /* Same, with launch hints from a caller that holds the unit records on the host, and two optional
  * hipEvent_t (may be NULL) recorded on `stream` immediately before and after the dominant kernel(s) (the fused
  * resample/normalise/store kernel), so a caller can time exactly that part.
- *   classes_hint    bit 0: some unit takes the fused (LDS-resident) data flow; bit 1: some unit takes the
- *                   staged flow (down-scaled, > 2 Sharpness ops, or sizes not multiples of 4); 0 = unknown.
+ *   classes_hint    bit 0: some unit takes the fused up-scaling tile kernel; bit 1: some unit takes the staged
+ *                   flow (scale < 1/2, > 2 Sharpness ops, or sizes not multiples of 4); bit 2: some unit takes
+ *                   the fused generic (down-scaling by <= 2x) tile kernel; 0 = unknown.
  *   stats_mask_hint bit k: some unit's k-th op needs image statistics (AutoContrast/Equalize/Contrast);
  *                   -1 = unknown. */
 int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,

@@ -54,6 +54,8 @@ def test_pipeline_seed_for_seed_vs_reference(hip, case):
     (30, 30, 50, (0.5, 2.0), 1, 48),      # always padded
     (33, 35, 31, (1.0, 1.5), 0, 40),      # odd sizes: scalar (non-vector) code paths
     (256, 256, 256, (1.0, 1.5), 0, 36),   # the reference's own size
+    (256, 256, 256, (0.5, 2.0), 1, 36),   # RVS scale range at the reference's size: generic (down-scaling) fused tiles
+    (128, 128, 96, (0.34, 0.6), 1, 24),   # scale < 1/2: staged flow with up to 7 taps
 ])
 def test_random_units_vs_oracle(hip, oracle, H, W, crop, sr, kind, N):
     rs = np.random.RandomState(H * 1000 + W)
