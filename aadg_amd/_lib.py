@@ -33,6 +33,7 @@ EXPORTS = [
     "aadg_normalize_rewards_f32",
     "aadg_seg_loss_workspace_bytes", "aadg_seg_bce_dice_f32",
     "aadg_fop_workspace_bytes", "aadg_fop_f32",
+    "aadg_upsample_bilinear2d",
 ]
 
 _lib = None
@@ -77,6 +78,8 @@ def load():
         lib.aadg_fop_workspace_bytes.argtypes = [_i, _i, _i]
         lib.aadg_fop_f32.restype = _i
         lib.aadg_fop_f32.argtypes = [_i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]
+    lib.aadg_upsample_bilinear2d.restype = _i
+    lib.aadg_upsample_bilinear2d.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
     if lib.aadg_abi_version() != 1:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
@@ -381,3 +384,35 @@ def fop(name, img, mag=None, kernel=None, perm=None):
                           B, C, H, W, ws.data_ptr(), ws.numel(), _stream())
     _check(rc, "aadg_fop_f32(%s)" % name)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+class _UpsampleBilinearAC(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear', align_corners=True) with the HIP forward kernel; the backward is
+    ATen's upsample_bilinear2d_backward (already bandwidth-bound)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        lib = load()
+        _require_cuda(x)
+        if x.dtype not in (torch.float32, torch.bfloat16) or x.dim() != 4:
+            raise AadgError("upsample: expected a float32/bfloat16 NCHW tensor")
+        x = x.contiguous()
+        N, C, h, w = x.shape
+        H, W = int(size[0]), int(size[1])
+        out = torch.empty((N, C, H, W), dtype=x.dtype, device=x.device)
+        rc = lib.aadg_upsample_bilinear2d(x.data_ptr(), out.data_ptr(), N * C, h, w, H, W,
+                                          0 if x.dtype == torch.float32 else 1, _stream())
+        _check(rc, "aadg_upsample_bilinear2d")
+        ctx.in_shape = (N, C, h, w)
+        ctx.out_size = (H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gi = torch.ops.aten.upsample_bilinear2d_backward(g.contiguous(), list(ctx.out_size), list(ctx.in_shape), True, None, None)
+        return gi, None
+
+
+def upsample_bilinear_ac(x, size):
+    return _UpsampleBilinearAC.apply(x, tuple(size))

@@ -16,6 +16,15 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+def _upsample_ac(x, size):
+    """Bilinear, align_corners=True.  On the GPU the forward is the HIP streaming kernel (csrc/upsample.hip);
+    the CPU branch only serves shape tests of this host-plumbing module."""
+    if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
+        from .. import _lib
+        return _lib.upsample_bilinear_ac(x, size)
+    return F.interpolate(x, size=size, mode='bilinear', align_corners=True)
+
+
 def _bn_relu(c):
     return [nn.BatchNorm2d(c), nn.ReLU(inplace=True)]
 
@@ -164,9 +173,9 @@ class DeepLabV3Plus(nn.Module):
 
     def forward(self, x):
         skip, deep = self.encoder(x)
-        y = F.interpolate(self.aspp(deep), size=skip.shape[-2:], mode='bilinear', align_corners=True)
+        y = _upsample_ac(self.aspp(deep), skip.shape[-2:])
         y = self.fuse(torch.cat([y, self.skip(skip)], dim=1))
-        mask = F.interpolate(self.classifier(y), size=x.shape[-2:], mode='bilinear', align_corners=True)
+        mask = _upsample_ac(self.classifier(y), x.shape[-2:])
         if not self.aux_pooling:
             return mask
         return mask, deep.float().mean(dim=(2, 3))          # ClassificationHead = avg-pool + flatten (models/heads.py:19-25)

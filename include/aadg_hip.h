@@ -155,6 +155,13 @@ int aadg_fop_f32(int fop, const float* in, float* out, const float* mag, int mag
                  const float* kernel3x3, const int32_t* perm, int B, int C, int H, int W, void* ws,
                  size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Bilinear up-sampling, align_corners = True, NCHW planes (the x4 up-samplings between the augmentation output
+ * and the BCE/Dice kernel in DeepLabV3+; same arithmetic as torch.nn.functional.interpolate / ATen
+ * upsample_bilinear2d).  in [planes, h, w] -> out [planes, H, W]; dtype 0 = float32, 1 = bfloat16.
+ * ------------------------------------------------------------------------------------------- */
+int aadg_upsample_bilinear2d(const void* in, void* out, int planes, int h, int w, int H, int W, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,40 @@
+"""GPU: HIP bilinear (align_corners=True) up-sampling vs torch.nn.functional.interpolate, forward and backward."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape,size,dtype", [((3, 5, 8, 8), (32, 32), torch.float32), ((2, 7, 9, 13), (33, 50), torch.float32),
+                                              ((4, 16, 32, 32), (128, 128), torch.bfloat16), ((2, 2, 128, 128), (512, 512), torch.float32),
+                                              ((1, 3, 1, 1), (16, 16), torch.float32)])
+def test_upsample_matches_torch(hip, shape, size, dtype):
+    torch.manual_seed(0)
+    x = torch.randn(shape, device="cuda").to(dtype).requires_grad_(True)
+    y = hip.upsample_bilinear_ac(x, size)
+    xr = x.detach().clone().requires_grad_(True)
+    yr = F.interpolate(xr, size=size, mode="bilinear", align_corners=True)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert y.dtype == dtype and y.shape == yr.shape
+    assert (y.float() - yr.float()).abs().max().item() <= tol
+    g = torch.randn_like(yr)
+    y.backward(g)
+    yr.backward(g)
+    assert (x.grad.float() - xr.grad.float()).abs().max().item() <= tol * 50
+
+
+def test_deeplab_uses_the_kernel_and_matches_interpolate(hip):
+    from aadg_amd.models import deeplab
+    torch.manual_seed(1)
+    m = deeplab.DeepLabV3Plus("mobilenet_v2", 2).cuda().eval()
+    x = torch.randn(2, 3, 64, 64, device="cuda")
+    with torch.no_grad():
+        y1, f1 = m(x)
+        saved = deeplab._upsample_ac
+        deeplab._upsample_ac = lambda t, size: F.interpolate(t, size=size, mode="bilinear", align_corners=True)
+        try:
+            y2, f2 = m(x)
+        finally:
+            deeplab._upsample_ac = saved
+    assert torch.allclose(y1, y2, atol=1e-5) and torch.equal(f1, f2)
