@@ -59,6 +59,21 @@ class Policy(object):
     def __init__(self, policy):
         self.policy = policy
         self.queue = []
+        # (function, value) per step, resolved once: value = level * (hi - lo) + lo exactly as apply_augment
+        # computes it (data/basic.py:258-260), so a call only draws and records
+        self._compiled = None
+
+    def _compile(self):
+        out = []
+        for sub in self.policy:
+            steps = []
+            for name, level in sub:
+                if name == 'CutMix':
+                    raise KeyError(name)  # not in augment_dict in the reference either (data/basic.py:253)
+                fn, low, high = basic.get_augment(name)
+                steps.append((fn, level * (high - low) + low))
+            out.append(steps)
+        return out
 
     def _cutmix_partner(self, img, mask):
         # The reference maintains a CutMix partner queue even though CutMix is unreachable; its
@@ -71,10 +86,11 @@ class Policy(object):
 
     def __call__(self, img, mask):
         self._cutmix_partner(img, mask)
-        for name, level in random.choice(self.policy):
-            if name == 'CutMix':
-                raise KeyError(name)  # not in augment_dict in the reference either (data/basic.py:253)
-            img, mask = basic.apply_augment(img, mask, name, level)
+        if self._compiled is None:
+            self._compiled = self._compile()
+        # random.choice(self.policy) in the reference: same draw (an index below len(policy))
+        for fn, value in random.choice(self._compiled):
+            img, mask = fn(img, mask, value)
         return img, mask
 
 

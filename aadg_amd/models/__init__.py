@@ -56,7 +56,12 @@ def build_model(cfg):
 def load_ddp_model(ngpus_per_node, args, cfg):
     print("=> creating model '{}' with '{}".format(cfg.MODEL.NAME, cfg.MODEL.BACKBONE))
     dev = _device(args)
-    model = _wrap(build_model(cfg).to(dev), args, dev)
+    model = build_model(cfg).to(dev)
+    if getattr(args, 'distributed', False) and getattr(args, 'sync_bn', False):
+        # The reference's single-GPU batch mixes all domains in every BatchNorm batch; row-sharded replicas see
+        # only their slice.  --sync_bn reduces the per-channel statistics over the ranks (SURVEY.md 8e caveat 1).
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    model = _wrap(model, args, dev)
     return model, cfg.TRAIN.BATCH_SIZE, args.workers
 
 

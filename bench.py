@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--backbone_dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_units", type=int, default=24, help="units of the CPU-baseline sample")
+    ap.add_argument("--sync_bn", action="store_true", help="SyncBatchNorm over the ranks (strict single-GPU BN parity)")
     ap.add_argument("--dist_backend", default="nccl", help="nccl (= RCCL) by default; gloo for single-GPU functional tests")
     ap.add_argument("--all_ranks_on_gpu0", action="store_true", help="functional test of the N>1 path on a 1-GPU box")
     ap.add_argument("--shard_of", type=int, default=0,
@@ -83,6 +84,7 @@ def build_state(a, local_rank, world):
     args = Args()
     args.gpu, args.workers, args.distributed = local_rank, 0, world > 1
     args.crop_size, args.backbone_dtype, args.epoch_items = a.size, a.backbone_dtype, a.batch
+    args.sync_bn = a.sync_bn
     st = SearchState(local_rank, world, cfg, args)
     st.discriminator.synchronize_parameters()       # what the driver does at epoch == WARMUP_EPOCH
     return cfg, st

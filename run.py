@@ -30,6 +30,7 @@ def parse_args(argv=None):
     parser.add_argument('--seed', default=1023, type=int)
     parser.add_argument('--crop_size', default=256, type=int)
     parser.add_argument('--backbone_dtype', default='fp32', choices=['fp32', 'bf16'])
+    parser.add_argument('--sync_bn', action='store_true', help='SyncBatchNorm over the row-sharded ranks')
     parser.add_argument('--max_epochs', default=None, type=int)
     parser.add_argument('--epoch_items', default=32, type=int)
     return parser.parse_args(argv)
