@@ -898,7 +898,7 @@ __device__ __forceinline__ void fused_tile(const uint8_t* __restrict__ pool, con
                 for (int c = 0; c < 3; ++c) {
                     const int v = (1 << (PRECISION_BITS - 1)) + __mul24((int)((a0[i] >> (8 * c)) & 255), ky0) +
                                   __mul24((int)((a1[i] >> (8 * c)) & 255), ky1);
-                    o[c][i] = xm[i] >= 0 ? lutf[clip8(v)] : padv;
+                    o[c][i] = lutf[clip8(v)];    // pad columns: H == 0 -> v >> 22 == 0 -> lutf[0] == -1.0 == pad value
                 }
             }
         } else {
