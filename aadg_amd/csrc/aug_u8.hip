@@ -845,9 +845,10 @@ __device__ __forceinline__ void fused_tile(const uint8_t* __restrict__ pool, con
         const int nrows = r_hi - r_lo;
         if (hxm >= 0) {
             const uint32_t* col = cur + (r_lo - r_lo_h) * pw + (hxm - c_lo_h);
+            const int d1 = hk1 ? 1 : 0;             // no second tap (identity axis / right image edge): re-read the first
             for (int rr = 0; rr < nrows; ++rr) {
                 const uint32_t p0 = col[rr * pw];
-                const uint32_t p1 = hk1 ? col[rr * pw + 1] : 0u;
+                const uint32_t p1 = col[rr * pw + d1];
                 const int half = 1 << (PRECISION_BITS - 1);
                 // pixel (8 bit) x coefficient (<= 2^22): 24-bit multiplies are full rate, v_mul_lo_u32 is not
                 const int s0 = half + __mul24((int)(p0 & 255), hk0) + __mul24((int)(p1 & 255), hk1);
@@ -874,11 +875,12 @@ __device__ __forceinline__ void fused_tile(const uint8_t* __restrict__ pool, con
 
     // ---- vertical pass + normalise + store: wave <-> output row, lane <-> 4 consecutive columns -----------
     if (!col_ok) return;
-    const int xm[4] = {xm4.x, xm4.y, xm4.z, xm4.w};
     const size_t plane = (size_t)crop * crop;
     float* oi = out_img + (size_t)u * 3 * plane;
     float* ol = out_lbl + (size_t)u * K * plane;
     const float padv = -1.0f;                    // normalise(0)
+    const uint32_t lbl_t0 = dataset == AADG_DATASET_OPTIC ? 50u : 0u;
+    const bool lbl_flip = dataset != AADG_DATASET_OPTIC;
 #pragma unroll
     for (int r = 0; r < ROWS_PER_WAVE; ++r) {
         const int y = y0 + wv + 4 * r;
@@ -888,8 +890,7 @@ __device__ __forceinline__ void fused_tile(const uint8_t* __restrict__ pool, con
         if (ym >= 0) {
             const int ky0 = vk0[r], ky1 = vk1[r];
             const uint4 h0 = *reinterpret_cast<const uint4*>(Hbuf + (ym - r_lo) * FT_W + 4 * lane);
-            uint4 h1 = make_uint4(0u, 0u, 0u, 0u);
-            if (ky1) h1 = *reinterpret_cast<const uint4*>(Hbuf + (ym + 1 - r_lo) * FT_W + 4 * lane);
+            const uint4 h1 = *reinterpret_cast<const uint4*>(Hbuf + (ym + (ky1 ? 1 : 0) - r_lo) * FT_W + 4 * lane);
             const uint32_t a0[4] = {h0.x, h0.y, h0.z, h0.w};
             const uint32_t a1[4] = {h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
@@ -905,12 +906,14 @@ __device__ __forceinline__ void fused_tile(const uint8_t* __restrict__ pool, con
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[0][i] = o[1][i] = o[2][i] = padv;
         }
+        // multilabel planes without per-pixel branches: optic  l0 = (m <= 50), l1 = (m <= 200);
+        //                                                vessel l0 = (m >= 1) == !(m <= 0)
         float l0[4], l1[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t m = mv[r][i];
-            if (dataset == AADG_DATASET_OPTIC) { l0[i] = m <= 50 ? 1.0f : 0.0f; l1[i] = m <= 200 ? 1.0f : 0.0f; }
-            else { l0[i] = m != 0 ? 1.0f : 0.0f; l1[i] = 0.0f; }
+            l0[i] = ((m <= lbl_t0) != lbl_flip) ? 1.0f : 0.0f;
+            l1[i] = m <= 200u ? 1.0f : 0.0f;
         }
         const size_t off = (size_t)y * crop + xq;
 #pragma unroll
