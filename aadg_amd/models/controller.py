@@ -34,6 +34,9 @@ class Controller(nn.Module):
         self.lstm = nn.LSTMCell(embedding_dim, hidden_dim)
         self.outop = nn.Linear(hidden_dim, self.NUM_OPS)
         self.outmag = nn.Linear(hidden_dim, self.NUM_MAGS)
+        # token offset of each of the 2L decisions of a sub-policy (op tokens at 0, magnitude tokens at NUM_OPS);
+        # a non-persistent buffer: not in the state_dict, but resident on the device (hipGraph capture forbids H2D)
+        self.register_buffer("_tok_offsets", torch.tensor([0, self.NUM_OPS] * self.L, dtype=torch.long), persistent=False)
         self.init_parameters()
 
     def init_parameters(self):
@@ -94,5 +97,35 @@ class Controller(nn.Module):
                 torch.stack(log_probs, dim=-1).sum(dim=-1), torch.stack(entropies, dim=-1).sum(dim=-1))
 
     def evaluate(self, policies, batch_size):
+        """Teacher-forced sum of log-probabilities of `policies` [M, Q*L*2] (models/controller.py:118-145).
+
+        Same arithmetic as replaying the 2*L*Q LSTMCell steps one by one, restructured for the GPU: with the
+        actions given, the Q sub-policies are independent sequences (the reference resets the state per
+        sub-policy), so they run as ONE batch of M*Q sequences of length 2*L, the input-to-hidden product is a
+        single GEMM over all steps, and the two heads / log-softmax / gather run once over all steps.  That is
+        ~25 kernels instead of ~240 per call (the PPO update calls this 5 times, forward and backward)."""
+        M, Q, S, H = batch_size, self.Q, 2 * self.L, self.hidden_dim
+        acts = policies.reshape(M, Q, S).long()
+        tokens = acts + self._tok_offsets                                             # op tokens / NUM_OPS + mag tokens
+        emb = self.embedding(tokens[:, :, :-1])                              # inputs of steps 1..S-1
+        x = torch.cat([emb.new_zeros(M, Q, 1, self.embedding_dim), emb], dim=2).reshape(M * Q, S, self.embedding_dim)
+        gi = F.linear(x, self.lstm.weight_ih, self.lstm.bias_ih + self.lstm.bias_hh)   # [MQ, S, 4H], gate order i,f,g,o
+        h = gi.new_zeros(M * Q, H)
+        c = gi.new_zeros(M * Q, H)
+        hs = []
+        for t in range(S):
+            gates = gi[:, t] + F.linear(h, self.lstm.weight_hh)
+            i, f, g, o = gates.chunk(4, dim=1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            hs.append(h)
+        hs = torch.stack(hs, dim=1)                                          # [MQ, S, H]
+        a = acts.reshape(M * Q, S)
+        lp_op = self._log_policy(self.outop(hs[:, 0::2])).gather(2, a[:, 0::2].unsqueeze(-1))
+        lp_mag = self._log_policy(self.outmag(hs[:, 1::2])).gather(2, a[:, 1::2].unsqueeze(-1))
+        return (lp_op.sum(dim=(1, 2)) + lp_mag.sum(dim=(1, 2))).reshape(M, Q).sum(dim=1)
+
+    def evaluate_stepwise(self, policies, batch_size):
+        """The reference's step-by-step formulation (kept for tests: `evaluate` must agree with it)."""
         _, log_probs, _, _, _ = self._rollout(batch_size, forced=policies)
         return torch.stack(log_probs, dim=-1).sum(dim=-1)

@@ -83,3 +83,32 @@ def test_normalize_rewards(hip, oracle):
     want = oracle.normalize_rewards(r)
     ref = (torch.from_numpy(r) - torch.from_numpy(r).mean()) / (torch.from_numpy(r).std() + 1e-5)
     assert np.abs(got - want).max() <= 1e-6 and np.abs(got - ref.numpy()).max() <= 1e-6
+
+
+def test_samplesloss_compatible_callable(hip, oracle):
+    """The reference's own call pattern (search_dg.py:116,150-162) through the SamplesLoss-shaped object."""
+    from aadg_amd.sinkhorn import SamplesLoss
+    sinkhorn = SamplesLoss("sinkhorn", cost='( IntCst(1) - (X | Y) / ( Norm2(X) * Norm2(Y) ) )', backend='online')
+    rs = np.random.RandomState(2)
+    D, B, M = 3, 8, 6
+    fe = features(rs, D, B, M)
+    t = torch.from_numpy(fe).cuda()
+    dc = torch.zeros(D * B * M, D)
+    for r in range(D * B * M):
+        dc[r, (r // M) % D] = 1.0
+    rewards = torch.zeros(M)
+    for j in range(M):                                       # the reference's loop, verbatim in structure
+        sub, gt = t[j::M], dc[j::M]
+        idx = torch.argmax(gt, dim=1)
+        d1, d2, d3 = sub[(idx == 0).nonzero(as_tuple=True)], sub[(idx == 1).nonzero(as_tuple=True)], sub[(idx == 2).nonzero(as_tuple=True)]
+        dist_12, dist_23, dist_13 = sinkhorn(d1, d2), sinkhorn(d2, d3), sinkhorn(d1, d3)
+        assert dist_12.dim() == 0
+        rewards[j] += (dist_12 + dist_13 + dist_23).cpu()
+    want = oracle.sinkhorn_rewards(fe, D, B, M)
+    assert np.abs(rewards.numpy() - want).max() <= 3 * TOL
+    fused = hip.sinkhorn_rewards(t, D, B, M).cpu().numpy()
+    assert np.abs(fused - rewards.numpy()).max() <= 3 * TOL
+    with pytest.raises(NotImplementedError):
+        SamplesLoss("sinkhorn", cost=None)
+    with pytest.raises(NotImplementedError):
+        SamplesLoss("gaussian")
