@@ -38,6 +38,21 @@ def test_run_py_search_smoke(hip, tmp_path):
     assert all(np.isfinite(float(x)) for x in [best["avg_dsc"]])
 
 
+def test_run_py_search_smoke_rvs_reinforce(hip, tmp_path):
+    """The single-class RVS driver (the reference's search_dg_2d.py) with the REINFORCE criterion, scale range
+    [0.5, 2] (generic fused tiles) and fp32 backbone."""
+    import run
+    from aadg_amd.config.defaults import _C
+    args = ["--cfg", os.path.join(ROOT, "experiments", "rvs_sinkhorn", "smoke.yaml"), "--output_dir", str(tmp_path / "out"),
+            "--crop_size", "64", "--epoch_items", "4"]
+    _C.defrost()
+    _C.LOG_DIR = str(tmp_path / "log")
+    best = run.main(args)
+    outs = glob.glob(str(tmp_path / "out" / "rvs" / "smoke_*"))
+    assert len(outs) == 1 and os.path.exists(os.path.join(outs[0], "final_result.json"))
+    assert np.isfinite(best["avg_dsc"])
+
+
 def test_baseline_config0_fixed_policy_vessel(hip, oracle):
     """BASELINE configs[0]: single-domain vessel data, FIXED policy [Contrast .5, Sharpness .5] (no controller
     search), 256x256, batch 2 -- the reference's CPU-runnable plumbing case, HIP vs oracle, bit-exact."""
