@@ -89,55 +89,19 @@ def _to_plain(node):
 
 CN = CfgNode
 
-_C = CN()
-
-_C.OUTPUT_DIR = 'output'
-_C.LOG_DIR = 'log'
-_C.PRINT_FREQ = 100
-_C.SEED = 0
-
-_C.MODEL = CN()
-_C.MODEL.NAME = 'deeplabv3+'
-_C.MODEL.BACKBONE = 'mobilenet_v2'
-_C.MODEL.PRETRAINED_WEIGHTS = ''
-
-_C.CONTROLLER = CN()
-_C.CONTROLLER.NAME = 'controller'
-_C.CONTROLLER.LOSS = 'ppo'
-_C.CONTROLLER.PENALTY = 0.00001
-_C.CONTROLLER.L = 2
-_C.CONTROLLER.M = 6
-_C.CONTROLLER.T = 2
-_C.CONTROLLER.C = 2.5
-_C.CONTROLLER.NUM_MAGS = 10
-_C.CONTROLLER.EXCLUDE_OPS_NUM = 0
-_C.CONTROLLER.EXCLUDE_OPS = []
-
-_C.DISCRIMINATOR = CN()
-_C.DISCRIMINATOR.NAME = 'momentum_feature'
-
-_C.DATASET = CN()
-_C.DATASET.ROOT = './dataset'
-_C.DATASET.NAME = 'cifar10'
-_C.DATASET.TRAINSET = ''
-_C.DATASET.TESTSET = ''
-
-_C.DATASET.DG = CN()
-_C.DATASET.DG.TRAIN = [1, 2, 3]
-_C.DATASET.DG.TEST = [4]
-
-_C.TRAIN = CN()
-_C.TRAIN.LR = 0.1
-_C.TRAIN.WD = 0.0004
-_C.TRAIN.BEGIN_EPOCH = 0
-_C.TRAIN.WARMUP_EPOCH = 0
-_C.TRAIN.END_EPOCH = 200
-_C.TRAIN.BATCH_SIZE = 8
-_C.TRAIN.SHUFFLE = True
-
-_C.TEST = CN()
-_C.TEST.BATCH_SIZE = _C.TRAIN.BATCH_SIZE
-_C.TEST.MODEL_DIR = ''
+# Same tree, keys and default values as the reference's config/defaults.py:8-66 (written as one literal).
+_C = CN({
+    'OUTPUT_DIR': 'output', 'LOG_DIR': 'log', 'PRINT_FREQ': 100, 'SEED': 0,
+    'MODEL': {'NAME': 'deeplabv3+', 'BACKBONE': 'mobilenet_v2', 'PRETRAINED_WEIGHTS': ''},
+    'CONTROLLER': {'NAME': 'controller', 'LOSS': 'ppo', 'PENALTY': 0.00001, 'L': 2, 'M': 6, 'T': 2, 'C': 2.5,
+                   'NUM_MAGS': 10, 'EXCLUDE_OPS_NUM': 0, 'EXCLUDE_OPS': []},
+    'DISCRIMINATOR': {'NAME': 'momentum_feature'},
+    'DATASET': {'ROOT': './dataset', 'NAME': 'cifar10', 'TRAINSET': '', 'TESTSET': '',
+                'DG': {'TRAIN': [1, 2, 3], 'TEST': [4]}},
+    'TRAIN': {'LR': 0.1, 'WD': 0.0004, 'BEGIN_EPOCH': 0, 'WARMUP_EPOCH': 0, 'END_EPOCH': 200, 'BATCH_SIZE': 8,
+              'SHUFFLE': True},
+    'TEST': {'BATCH_SIZE': 8, 'MODEL_DIR': ''},
+})
 
 
 def update_config(cfg, args):

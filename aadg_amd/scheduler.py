@@ -1,25 +1,36 @@
-"""Optimisers / LR schedules of the search path, as in the reference's scheduler.py:5-34:
-controller Adam(lr 3.5e-4); model Adam(TRAIN.LR, TRAIN.WD) + MultiStepLR([WARMUP_EPOCH], 0.1);
-discriminator Adam(TRAIN.LR) + MultiStepLR([WARMUP_EPOCH], gamma 1) (cosine only for the unused image
-discriminator)."""
+"""Optimisers / LR schedules of the search path (reference: scheduler.py:5-34).
+
+controller: Adam(lr 3.5e-4), no schedule; segmentation model: Adam(TRAIN.LR, TRAIN.WD) whose LR drops x0.1 when the
+warm-up ends; discriminator: Adam(TRAIN.LR) with a constant LR (a cosine schedule only for the unused image
+discriminator).  Function names and return tuples follow the reference."""
 from torch.optim import Adam
 from torch.optim.lr_scheduler import CosineAnnealingLR, MultiStepLR
 
+CONTROLLER_LR = 0.00035
+
+
+def _step_at_warmup_end(optimizer, cfg, gamma):
+    return MultiStepLR(optimizer, milestones=[cfg.TRAIN.WARMUP_EPOCH], gamma=gamma, last_epoch=-1)
+
+
+def _model_adam(model, cfg):
+    return Adam(model.parameters(), lr=cfg.TRAIN.LR, weight_decay=cfg.TRAIN.WD)
+
 
 def get_optimizer_scheduler(controller, model, cfg):
-    controller_optimizer = Adam(controller.parameters(), lr=0.00035)
-    optimizer = Adam(model.parameters(), lr=cfg.TRAIN.LR, weight_decay=cfg.TRAIN.WD)
-    scheduler = MultiStepLR(optimizer, [cfg.TRAIN.WARMUP_EPOCH], gamma=0.1, last_epoch=-1)
-    return optimizer, scheduler, controller_optimizer
+    """-> (model optimiser, model LR scheduler, controller optimiser)"""
+    model_opt = _model_adam(model, cfg)
+    return model_opt, _step_at_warmup_end(model_opt, cfg, 0.1), Adam(controller.parameters(), lr=CONTROLLER_LR)
 
 
 def get_optimizer_scheduler2(model, cfg):
-    optimizer = Adam(model.parameters(), lr=cfg.TRAIN.LR, weight_decay=cfg.TRAIN.WD)
-    return optimizer, CosineAnnealingLR(optimizer, T_max=cfg.TRAIN.END_EPOCH)
+    model_opt = _model_adam(model, cfg)
+    return model_opt, CosineAnnealingLR(model_opt, T_max=cfg.TRAIN.END_EPOCH)
 
 
 def get_dis_optimizer_scheduler(discriminator, cfg):
-    optimizer = Adam(discriminator.parameters(), lr=cfg.TRAIN.LR)
-    if cfg.TRAIN.WARMUP_EPOCH > 0 and cfg.DISCRIMINATOR.NAME == 'image':
-        return optimizer, CosineAnnealingLR(optimizer, T_max=cfg.TRAIN.WARMUP_EPOCH)
-    return optimizer, MultiStepLR(optimizer, [cfg.TRAIN.WARMUP_EPOCH], gamma=1, last_epoch=-1)
+    """-> (discriminator optimiser, LR scheduler)"""
+    dis_opt = Adam([p for p in discriminator.parameters() if p.requires_grad], lr=cfg.TRAIN.LR)
+    cosine = cfg.TRAIN.WARMUP_EPOCH > 0 and cfg.DISCRIMINATOR.NAME == 'image'
+    sched = CosineAnnealingLR(dis_opt, T_max=cfg.TRAIN.WARMUP_EPOCH) if cosine else _step_at_warmup_end(dis_opt, cfg, 1)
+    return dis_opt, sched
