@@ -657,21 +657,64 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
     }
     int j0 = 0;                                   // leading pointwise segment [0, j0)
     while (j0 < nops && !is_stencil(un, j0)) ++j0;
-    auto commit = [&](uint32_t a, uint32_t b, uint32_t c, int row, int q) {
-        uint32_t px[4] = {a & 0xFFFFFFu, (a >> 24) | ((b & 0xFFFFu) << 8), (b >> 16) | ((c & 0xFFu) << 16), c >> 8};
-        const int y = r_lo + row, x = c_lo + 4 * q;
-        for (int j = 0; j < j0; ++j) {
+    // unpack to RGBX pixels held in registers, then apply the leading pointwise ops OP BY OP (one uniform dispatch per
+    // op for all of this thread's pixels, instead of one per pixel group), then store to LDS
+    uint32_t px[NR][4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) px[t] = pointwise_op(un, j, px[t], y, x + t, sl_all);
+    for (int k = 0; k < NR; ++k) {
+        const uint32_t a = ra[k], b = rb[k], c = rc[k];
+        px[k][0] = a & 0xFFFFFFu; px[k][1] = (a >> 24) | ((b & 0xFFFFu) << 8);
+        px[k][2] = (b >> 16) | ((c & 0xFFu) << 16); px[k][3] = c >> 8;
+    }
+    for (int j = 0; j < j0; ++j) {
+        const int op = un.op[j];
+        if (op == AADG_OP_INVERT) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) px[k][t] = ~px[k][t] & 0xFFFFFFu;
+        } else if (op == AADG_OP_POSTERIZE) {
+            const uint32_t m = (0xFFu & ~((1u << (8 - un.iarg[j])) - 1u)) * 0x010101u;
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) px[k][t] &= m;
+        } else if (needs_lds_lut(op)) {
+            const uint8_t* sl = sl_all + j * 768;
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t p = px[k][t];
+                    px[k][t] = (uint32_t)sl[p & 255u] | ((uint32_t)sl[256 + ((p >> 8) & 255u)] << 8) |
+                               ((uint32_t)sl[512 + ((p >> 16) & 255u)] << 16);
+                }
+        } else {   // Solarize, Color, Cutout (position dependent) and identities
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    px[k][t] = pointwise_op(un, j, px[k][t], r_lo + wv + 4 * k, c_lo + 4 * lane + t, sl_all);
         }
-        *reinterpret_cast<uint4*>(&A[row * pw + 4 * q]) = make_uint4(px[0], px[1], px[2], px[3]);
-    };
+    }
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
         const int row = wv + 4 * k;
-        if (row < ph) {
-            if (lane < q4) commit(ra[k], rb[k], rc[k], row, lane);
-            if (WIDE && has2) commit(rd[k % NW], re[k % NW], rf[k % NW], row, lane + 64);
+        if (row < ph && lane < q4)
+            *reinterpret_cast<uint4*>(&A[row * pw + 4 * lane]) = make_uint4(px[k][0], px[k][1], px[k][2], px[k][3]);
+    }
+    if (WIDE && has2) {            // patches wider than 256 pixels: lanes 0..2 own a second group per row (rare, small)
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int row = wv + 4 * k;
+            if (row < ph) {
+                const uint32_t a = rd[k % NW], b = re[k % NW], c = rf[k % NW];
+                uint32_t q[4] = {a & 0xFFFFFFu, (a >> 24) | ((b & 0xFFFFu) << 8), (b >> 16) | ((c & 0xFFu) << 16), c >> 8};
+                for (int j = 0; j < j0; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) q[t] = pointwise_op(un, j, q[t], r_lo + row, c_lo + 4 * (lane + 64) + t, sl_all);
+                *reinterpret_cast<uint4*>(&A[row * pw + 4 * (lane + 64)]) = make_uint4(q[0], q[1], q[2], q[3]);
+            }
         }
     }
     uint32_t* cur = A;

@@ -178,7 +178,9 @@ class DeepLabV3Plus(nn.Module):
         mask = _upsample_ac(self.classifier(y), x.shape[-2:])
         if not self.aux_pooling:
             return mask
-        return mask, deep.float().mean(dim=(2, 3))          # ClassificationHead = avg-pool + flatten (models/heads.py:19-25)
+        # ClassificationHead = avg-pool + flatten (models/heads.py:19-25); accumulate in fp32 without materialising
+        # an fp32 copy of the [N, C_enc, h/16, w/16] map
+        return mask, deep.mean(dim=(2, 3), dtype=torch.float32)
 
 
 class UNetSmall(nn.Module):
@@ -205,4 +207,4 @@ class UNetSmall(nn.Module):
         y = self.u3(torch.cat([up(m, c), c], 1))
         y = self.u2(torch.cat([up(y, b), b], 1))
         y = self.u1(torch.cat([up(y, a), a], 1))
-        return self.out(y), m.float().mean(dim=(2, 3))
+        return self.out(y), m.mean(dim=(2, 3), dtype=torch.float32)
