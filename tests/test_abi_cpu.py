@@ -48,3 +48,25 @@ def test_no_cpu_fallback():
         basic.apply_augment(img, torch.zeros((8, 8), dtype=torch.uint8), "Invert", 0.0)
     with pytest.raises(_lib.AadgError):
         _lib.sinkhorn_rewards(torch.zeros((18, 128)), 3, 2, 3)
+
+
+def test_entry_points_reject_bad_arguments_without_touching_the_gpu():
+    """Every entry validates its arguments before enqueuing anything: NULL pointers / bad sizes -> AADG_E_BADARG (-1)."""
+    import ctypes
+    from aadg_amd import _lib
+    lib = _lib.load()
+    z = ctypes.c_void_p(0)
+    assert lib.aadg_aug_u8_forward(z, z, 1, 8, 8, z, 1, 0, 8, 0, z, z, z, 0, z) == -1
+    assert lib.aadg_op_u8(z, z, 8, 8, 1, 0, 0.0, z, z, 0, z) == -1
+    assert lib.aadg_sinkhorn_rewards_f32(z, 3, 8, 6, 128, 0.05, 0.5, z, z, 0, z) == -1
+    assert lib.aadg_sinkhorn_divergence_f32(z, 128, 128, z, z, z, 1, 8, 0.05, 0.5, z, z, 0, z) == -1
+    assert lib.aadg_normalize_rewards_f32(z, 6, z, z) == -1
+    assert lib.aadg_seg_bce_dice_f32(z, z, 6, 2, 16, 6, z, z, z, z, 0, z) == -1
+    assert lib.aadg_fop_f32(0, z, z, z, 0, z, z, 1, 3, 8, 8, z, 0, z) == -1
+    assert lib.aadg_upsample_bilinear2d(z, z, 1, 8, 8, 16, 16, 0, z) == -1
+    one = ctypes.c_void_p(16)       # non-NULL dummy: size / enum checks come before any dereference
+    assert lib.aadg_fop_f32(99, one, one, z, 0, z, z, 1, 3, 8, 8, z, 0, z) == -1
+    assert lib.aadg_upsample_bilinear2d(one, one, 1, 8, 8, 16, 16, 7, z) == -1
+    assert lib.aadg_aug_u8_forward(one, one, 1, 8, 8, one, 1, 9, 8, 0, one, one, one, 1 << 30, z) == -1      # max_ops > 4
+    assert lib.aadg_aug_u8_forward(one, one, 1, 8, 8, one, 1, 2, 8, 0, one, one, one, 16, z) == -2           # workspace too small
+    assert lib.aadg_seg_bce_dice_f32(one, one, 7, 2, 16, 6, one, one, z, one, 1 << 20, z) == -1              # N % M != 0

@@ -116,6 +116,47 @@ def test_full_size_properties(hip, oracle):
     assert np.array_equal(a_lbl[torch.from_numpy(sel).cuda()].cpu().numpy(), w_lbl)
 
 
+def test_config2_rvs_1024_spot_check(hip, oracle):
+    """BASELINE configs[2] geometry: 1024x1024 sources and crops, RVS scale range [0.5, 2], K = 1.
+    Oracle comparison on a handful of units (the oracle needs ~0.2 s per 1024^2 unit)."""
+    rs = np.random.RandomState(77)
+    H = W = crop = 1024
+    imgs, msks = synth_pool(rs, 3, H, W, vessel=True)
+    units = random_units(rs, 10, 3, H, W, crop, (0.5, 2.0))
+    want_img, want_lbl = oracle.aug_units(imgs, msks, units, crop, 1)
+    got_img, got_lbl = hip.aug_u8_forward(torch.from_numpy(imgs).cuda(), torch.from_numpy(msks).cuda(), units, crop, 1)
+    assert np.array_equal(got_img.cpu().numpy(), want_img)
+    assert np.array_equal(got_lbl.cpu().numpy(), want_lbl)
+
+
+def test_excluded_ops_and_magnitude_grid_through_the_pipeline(hip, oracle):
+    """CONTROLLER.EXCLUDE_OPS shifts the op indexing (data/policy.py:72-74); NUM_MAGS changes the level grid."""
+    import random
+    from helpers import Cfg
+    from aadg_amd.data import transform as T
+    from aadg_amd.data.basic import DevicePool
+    from aadg_amd.data.policy import DGMultiPolicy, parse_policies
+    rs = np.random.RandomState(5)
+    imgs, msks = synth_pool(rs, 3, 48, 48)
+    pool = DevicePool(torch.from_numpy(imgs).cuda(), torch.from_numpy(msks).cuda())
+    cfg = Cfg(L=3, NUM_MAGS=7, EXCLUDE_OPS=["Invert", "Cutout"])
+    pol = np.zeros((4, 5 * 3 * 2), np.int64)
+    pol[:, 0::2] = rs.randint(0, 8, (4, 15))
+    pol[:, 1::2] = rs.randint(0, 7, (4, 15))
+    parsed = parse_policies(pol, cfg, None)
+    assert all(name not in ("Invert", "Cutout") for p in parsed for sp in p for name, _ in sp)
+    tf = T.Compose([DGMultiPolicy(parsed), T.DGRandomScaleCrop(48), T.Normalize_dg('optic'), T.ToTensor('optic')])
+    random.seed(9)
+    np.random.seed(9)
+    batch = [[tf({'image': pool.image(d), 'label': pool.mask(d), 'img_name': 'x', 'dc': d}) for d in range(3)]]
+    flat, refs, M = T.collect_refs(batch, nested=True)
+    units = T.refs_to_units(refs)
+    assert int(units['n_ops'][3:].max()) == 3
+    got_img, got_lbl = T.materialize(refs)
+    want_img, want_lbl = oracle.aug_units(imgs, msks, units, 48, 0)
+    assert np.array_equal(got_img.cpu().numpy(), want_img) and np.array_equal(got_lbl.cpu().numpy(), want_lbl)
+
+
 def test_bad_arguments_raise(hip):
     imgs = torch.zeros((2, 16, 16, 3), dtype=torch.uint8, device="cuda")
     msks = torch.zeros((2, 16, 16), dtype=torch.uint8, device="cuda")
