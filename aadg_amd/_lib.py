@@ -61,7 +61,7 @@ def load():
     lib.aadg_op_u8.restype = _i
     lib.aadg_op_u8.argtypes = [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp]
     lib.aadg_sinkhorn_workspace_bytes.restype = _sz
-    lib.aadg_sinkhorn_workspace_bytes.argtypes = [_i, _i]
+    lib.aadg_sinkhorn_workspace_bytes.argtypes = [_i, _i, _i]
     lib.aadg_sinkhorn_divergence_f32.restype = _i
     lib.aadg_sinkhorn_divergence_f32.argtypes = [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _sz, _vp]
     lib.aadg_sinkhorn_rewards_f32.restype = _i
@@ -275,7 +275,7 @@ def sinkhorn_rewards(fe, D, B, M, blur=0.05, scaling=0.5, rewards=None):
     if rewards is None:
         rewards = torch.zeros(M, dtype=torch.float32, device=fe.device)
     P = D * (D - 1) // 2
-    nb = lib.aadg_sinkhorn_workspace_bytes(M * P, B)
+    nb = lib.aadg_sinkhorn_workspace_bytes(M * P, B, fe.shape[1])
     ws = workspace(nb, fe.device, "sinkhorn")
     rc = lib.aadg_sinkhorn_rewards_f32(fe.data_ptr(), D, B, M, fe.shape[1], blur, scaling, rewards.data_ptr(),
                                        ws.data_ptr(), ws.numel(), _stream())
@@ -294,9 +294,11 @@ def sinkhorn_divergence(feat, cloud_rows, cloud_off, prob_xy, max_cloud, blur=0.
             raise AadgError("index tables must be int32")
     n_prob = prob_xy.numel() // 2
     out = torch.empty(n_prob, dtype=torch.float32, device=feat.device)
+    nb = lib.aadg_sinkhorn_workspace_bytes(n_prob, int(max_cloud), feat.shape[1])
+    ws = workspace(nb, feat.device, "sinkhorn")
     rc = lib.aadg_sinkhorn_divergence_f32(feat.data_ptr(), feat.stride(0), feat.shape[1], cloud_rows.data_ptr(),
                                           cloud_off.data_ptr(), prob_xy.data_ptr(), n_prob, int(max_cloud), blur,
-                                          scaling, out.data_ptr(), 0, 0, _stream())
+                                          scaling, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     _check(rc, "aadg_sinkhorn_divergence_f32")
     return out
 

@@ -232,19 +232,29 @@ int launch(const float* feat, int ld, int E, const int* cloud_rows, const int* c
 
 }  // namespace
 
-extern "C" size_t aadg_sinkhorn_workspace_bytes(int n_prob, int max_cloud) {
-    (void)max_cloud;
-    return n_prob > 0 ? aadg_align_up((size_t)n_prob * sizeof(float), 256) : 0;
+// large-cloud path (sinkhorn_big.hip)
+size_t aadg_sinkhorn_big_workspace_bytes(int n_prob, int nmax, int E);
+int aadg_sinkhorn_big_launch(const float* feat, int ld, int E, const int* cloud_rows, const int* cloud_off, const int* prob_xy,
+                             int n_prob, int nmax, float blur, float scaling, float* out, void* ws, size_t ws_bytes,
+                             hipStream_t st);
+
+extern "C" size_t aadg_sinkhorn_workspace_bytes(int n_prob, int max_cloud, int E) {
+    if (n_prob <= 0 || max_cloud <= 0 || E <= 0) return 0;
+    const size_t small = aadg_align_up((size_t)n_prob * sizeof(float), 256);
+    if (lds_bytes(max_cloud, E) <= 160 * 1024) return small;
+    return aadg_align_up(aadg_sinkhorn_big_workspace_bytes(n_prob, max_cloud, E), 256);
 }
 
 extern "C" int aadg_sinkhorn_divergence_f32(const float* feat, int ld, int E, const int32_t* cloud_rows,
                                             const int32_t* cloud_off, const int32_t* prob_xy, int n_prob, int max_cloud,
                                             float blur, float scaling, float* out, void* ws, size_t ws_bytes,
                                             void* stream) {
-    (void)ws; (void)ws_bytes;
     if (!feat || !cloud_rows || !cloud_off || !prob_xy || !out) return AADG_E_BADARG;
     if (E <= 0 || ld < E || n_prob <= 0 || max_cloud <= 0) return AADG_E_BADARG;
     if (!(blur > 0.f) || !(scaling > 0.f && scaling < 1.f)) return AADG_E_BADARG;
+    if (lds_bytes(max_cloud, E) > 160 * 1024)           // clouds too large for the LDS-resident kernel
+        return aadg_sinkhorn_big_launch(feat, ld, E, cloud_rows, cloud_off, prob_xy, n_prob, max_cloud, blur, scaling, out, ws,
+                                        ws_bytes, reinterpret_cast<hipStream_t>(stream));
     return launch<false>(feat, ld, E, cloud_rows, cloud_off, prob_xy, 0, 0, 0, n_prob, max_cloud, blur, scaling, out,
                          reinterpret_cast<hipStream_t>(stream));
 }
@@ -255,7 +265,7 @@ extern "C" int aadg_sinkhorn_rewards_f32(const float* fe, int D, int B, int M, i
     if (D < 2 || B <= 0 || M <= 0 || E <= 0) return AADG_E_BADARG;
     if (!(blur > 0.f) || !(scaling > 0.f && scaling < 1.f)) return AADG_E_BADARG;
     const int P = D * (D - 1) / 2;
-    if (ws_bytes < aadg_sinkhorn_workspace_bytes(M * P, B)) return AADG_E_WORKSPACE;
+    if (ws_bytes < aadg_align_up((size_t)M * P * sizeof(float), 256)) return AADG_E_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float* dist = reinterpret_cast<float*>(ws);
     int rc = launch<true>(fe, E, E, nullptr, nullptr, nullptr, D, B, M, M * P, B, blur, scaling, dist, st);

@@ -1,0 +1,300 @@
+// Sinkhorn divergence for point clouds that do not fit the LDS-resident kernel of sinkhorn.hip (more than ~100
+// points per cloud; the reference's own size is 8).  Same algorithm (geomloss 0.2.4 sinkhorn_loop, debiased,
+// cosine cost, p = 2); the difference is where the cost matrices live:
+//
+//   k_big_prep    rows normalised to unit length (so C = 1 - <x^, y^>), per-chunk column min / max
+//   k_big_schedule diameter of x u y, eps schedule (float64)
+//   k_big_cost    the four cost matrices C_xx, C_yy, C_xy, C_yx as dense 64x64-tiled contractions on the matrix
+//                 cores: v_mfma_f32_32x32x2_f32 -- exact f32 (an fmaf chain), operands staged in LDS with an
+//                 odd row stride; this is the one place on the path where a dense feature GEMM is the
+//                 bottleneck (N = 4096, E = 128: 4 x 4.3 GFLOP), so it is the one place MFMA is used
+//   k_big_sweep   one eps-scaling step: every row of the four matrices is an independent log-sum-exp,
+//                 one wavefront per row, float4 loads, online (max, sum) in registers, wave-shuffle merge;
+//                 potentials are double-buffered so the symmetrised update needs no second pass.
+//                 HBM-bound: 4 * N^2 * 4 bytes per step.
+//   k_big_final   <alpha, b_x - a_x> + <beta, a_y - b_y>
+//
+// The number of eps steps depends on the data (diameter), which lives on the device: the host enqueues a fixed
+// number of sweep launches (MAX_ITS + 2) and the surplus ones exit immediately -- no host synchronisation.
+#include "common.h"
+
+namespace {
+
+constexpr int BIG_EPS_CAP = 32;     // eps entries: 2 + ceil(log2(diameter / blur)) <= 32  <=>  diameter/blur < 2^30
+constexpr int BIG_PREP_CHUNKS = 32;        // row chunks of the prep pass (one workgroup each)
+constexpr int BIG_MAX_ITS = BIG_EPS_CAP;   // sweeps enqueued: init + up to BIG_EPS_CAP eps steps + final extrapolation
+
+struct BigLayout {                  // per-problem float offsets into the workspace
+    size_t xn, yn, cxx, cyy, cxy, cyx, pot, til, meta, scr, total;
+};
+__host__ __device__ inline BigLayout big_layout(int nmax, int E) {
+    BigLayout l;
+    size_t o = 0;
+    const size_t mat = (size_t)nmax * nmax;
+    l.xn = o; o += (size_t)nmax * E;
+    l.yn = o; o += (size_t)nmax * E;
+    l.cxx = o; o += mat;
+    l.cyy = o; o += mat;
+    l.cxy = o; o += mat;
+    l.cyx = o; o += mat;
+    l.pot = o; o += (size_t)2 * 4 * nmax;     // [buffer][a_x, b_y, a_y, b_x][nmax]
+    l.til = o; o += (size_t)4 * nmax;
+    l.meta = o; o += 2 * BIG_EPS_CAP + 8;      // eps_s as doubles (2 floats each) + nits
+    l.scr = o; o += (size_t)BIG_PREP_CHUNKS * 2 * 512;   // per-chunk column min / max (E <= 512)
+    l.total = (o + 63) / 64 * 64;
+    return l;
+}
+
+struct BigProb {
+    const int* rows_x; const int* rows_y; int n, m;
+};
+__device__ __forceinline__ BigProb big_problem(const int* cloud_rows, const int* cloud_off, const int* prob_xy, int p) {
+    const int cx = prob_xy[2 * p], cy = prob_xy[2 * p + 1];
+    BigProb r;
+    r.rows_x = cloud_rows + cloud_off[cx]; r.n = cloud_off[cx + 1] - cloud_off[cx];
+    r.rows_y = cloud_rows + cloud_off[cy]; r.m = cloud_off[cy + 1] - cloud_off[cy];
+    return r;
+}
+
+// ---- prep: grid (BIG_PREP_CHUNKS, n_prob), 256 threads: wave <-> rows of this chunk, lanes <-> feature columns ------
+constexpr int PREP_KPL = 8;   // E <= 64 * PREP_KPL = 512
+
+__global__ __launch_bounds__(256) void k_big_prep(const float* __restrict__ feat, int ld, int E, const int* cloud_rows,
+                                                  const int* cloud_off, const int* prob_xy, int nmax, float* ws) {
+    const int p = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const BigProb pr = big_problem(cloud_rows, cloud_off, prob_xy, p);
+    const BigLayout L = big_layout(nmax, E);
+    float* base = ws + (size_t)p * L.total;
+    // one pass over the rows: unit-length copy (so that C = 1 - <x^, y^>) and per-column min / max of the raw values
+    float lo[PREP_KPL], hi[PREP_KPL];
+#pragma unroll
+    for (int q = 0; q < PREP_KPL; ++q) { lo[q] = INFINITY; hi[q] = -INFINITY; }
+    const int total = pr.n + pr.m, per = (total + BIG_PREP_CHUNKS - 1) / BIG_PREP_CHUNKS;
+    const int r1 = min(total, (chunk + 1) * per);
+    for (int r = chunk * per + wv; r < r1; r += 4) {
+        const bool isy = r >= pr.n;
+        const int rr = isy ? r - pr.n : r;
+        const float* src = feat + (size_t)(isy ? pr.rows_y[rr] : pr.rows_x[rr]) * ld;
+        float v[PREP_KPL];
+        float ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < PREP_KPL; ++q) {
+            const int k = lane + 64 * q;
+            v[q] = k < E ? src[k] : 0.0f;
+            ss = fmaf(v[q], v[q], ss);
+            if (k < E) { lo[q] = fminf(lo[q], v[q]); hi[q] = fmaxf(hi[q], v[q]); }
+        }
+        ss = wave_sum(ss);
+        const float inv = 1.0f / sqrtf(ss);
+        float* dst = base + (isy ? L.yn : L.xn) + (size_t)rr * E;
+#pragma unroll
+        for (int q = 0; q < PREP_KPL; ++q) {
+            const int k = lane + 64 * q;
+            if (k < E) dst[k] = v[q] * inv;
+        }
+    }
+    __shared__ float s_lo[4][64 * PREP_KPL], s_hi[4][64 * PREP_KPL];
+#pragma unroll
+    for (int q = 0; q < PREP_KPL; ++q) { s_lo[wv][lane + 64 * q] = lo[q]; s_hi[wv][lane + 64 * q] = hi[q]; }
+    __syncthreads();
+    float* scr = base + L.scr + (size_t)chunk * 2 * 512;
+    for (int k = tid; k < E; k += 256) {
+        scr[k] = fminf(fminf(s_lo[0][k], s_lo[1][k]), fminf(s_lo[2][k], s_lo[3][k]));
+        scr[512 + k] = fmaxf(fmaxf(s_hi[0][k], s_hi[1][k]), fmaxf(s_hi[2][k], s_hi[3][k]));
+    }
+}
+
+// diameter of x u y and the eps schedule: grid n_prob, 256 threads
+__global__ __launch_bounds__(256) void k_big_schedule(int nmax, int E, float blur, float scaling, float* ws) {
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const BigLayout L = big_layout(nmax, E);
+    float* base = ws + (size_t)p * L.total;
+    __shared__ float red[4];
+    float part = 0.f;
+    for (int k = tid; k < E; k += 256) {
+        float a = INFINITY, b = -INFINITY;
+        for (int c = 0; c < BIG_PREP_CHUNKS; ++c) {
+            a = fminf(a, base[L.scr + (size_t)c * 1024 + k]);
+            b = fmaxf(b, base[L.scr + (size_t)c * 1024 + 512 + k]);
+        }
+        part += (b - a) * (b - a);
+    }
+    part = wave_sum(part);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) {
+        const double diameter = (double)sqrtf(red[0] + red[1] + red[2] + red[3]);
+        double* eps_s = reinterpret_cast<double*>(base + L.meta);
+        int c = 0;
+        eps_s[c++] = diameter * diameter;
+        const double start = 2.0 * log(diameter), stop = 2.0 * log((double)blur), step = 2.0 * log((double)scaling);
+        int len = (int)ceil((stop - start) / step);
+        if (len < 0) len = 0;
+        for (int i = 0; i < len && c < BIG_EPS_CAP - 1; ++i) eps_s[c++] = exp(start + (double)i * step);
+        eps_s[c++] = (double)blur * (double)blur;
+        reinterpret_cast<int*>(base + L.meta + 2 * BIG_EPS_CAP)[0] = c;
+    }
+}
+
+// ---- cost matrices on the matrix cores: grid (ceil(nmax/64), ceil(nmax/64), n_prob*4), 256 threads ---------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int CT = 64;          // block tile (4 waves, 32x32 each)
+constexpr int CK = 64;          // K chunk staged in LDS (2 x 64 x 65 floats = 33 KB)
+
+__global__ __launch_bounds__(256) void k_big_cost(const int* cloud_off, const int* prob_xy, int nmax, int E, float* ws) {
+    const int p = blockIdx.z >> 2, which = blockIdx.z & 3;            // 0 xx, 1 yy, 2 xy, 3 yx
+    const BigLayout L = big_layout(nmax, E);
+    float* base = ws + (size_t)p * L.total;
+    const int cx = prob_xy[2 * p], cy = prob_xy[2 * p + 1];
+    const int n = cloud_off[cx + 1] - cloud_off[cx], m = cloud_off[cy + 1] - cloud_off[cy];
+    const float* Am = base + ((which == 0 || which == 2) ? L.xn : L.yn);
+    const float* Bm = base + ((which == 0 || which == 3) ? L.xn : L.yn);
+    const int rows = (which == 0 || which == 2) ? n : m, cols = (which == 0 || which == 3) ? n : m;
+    float* C = base + (which == 0 ? L.cxx : which == 1 ? L.cyy : which == 2 ? L.cxy : L.cyx);
+    const int i0 = blockIdx.y * CT, j0 = blockIdx.x * CT;
+    if (i0 >= rows || j0 >= cols) return;
+    __shared__ float As[CT][CK + 1];
+    __shared__ float Bs[CT][CK + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wi = (wv >> 1) * 32, wj = (wv & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int k0 = 0; k0 < E; k0 += CK) {
+        const int kc = min(CK, E - k0);
+        for (int idx = tid; idx < CT * CK; idx += 256) {
+            const int r = idx / CK, k = idx - r * CK;
+            As[r][k] = (i0 + r < rows && k < kc) ? Am[(size_t)(i0 + r) * E + k0 + k] : 0.0f;
+            Bs[r][k] = (j0 + r < cols && k < kc) ? Bm[(size_t)(j0 + r) * E + k0 + k] : 0.0f;
+        }
+        __syncthreads();
+        const int kk = (kc + 1) & ~1;                                  // zero-padded to even
+        const float* ap = &As[wi + (lane & 31)][lane >> 5];
+        const float* bp = &Bs[wj + (lane & 31)][lane >> 5];
+        for (int k = 0; k < kk; k += 2)                               // A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = j0 + wj + (lane & 31);
+        if (row < rows && col < cols) C[(size_t)row * nmax + col] = 1.0f - acc[r];
+    }
+}
+
+// ---- one sweep: grid (4 * ceil(nmax/4), n_prob), 256 threads: wave <-> one row of one of the four softmins ---------
+// step 0: initialisation at eps_s[0] (no potentials);  1..nits: eps-scaling with symmetrised update;
+// nits+1: final extrapolation (no averaging, written to the tilde buffers);  beyond: nothing.
+__global__ __launch_bounds__(256) void k_big_sweep(const int* cloud_off, const int* prob_xy, int nmax, int E, int step, float* ws) {
+    const int p = blockIdx.y;
+    const BigLayout L = big_layout(nmax, E);
+    float* base = ws + (size_t)p * L.total;
+    const int nits = reinterpret_cast<const int*>(base + L.meta + 2 * BIG_EPS_CAP)[0];
+    if (step > nits + 1) return;
+    const int cx = prob_xy[2 * p], cy = prob_xy[2 * p + 1];
+    const int n = cloud_off[cx + 1] - cloud_off[cx], m = cloud_off[cy + 1] - cloud_off[cy];
+    const int groups = (nmax + 3) / 4;
+    const int kind = blockIdx.x / groups;                              // 0 a_x (C_xx), 1 b_y (C_yy), 2 a_y (C_yx), 3 b_x (C_xy)
+    const int row = (blockIdx.x - kind * groups) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int rows = (kind == 0 || kind == 3) ? n : m, cols = (kind == 0 || kind == 2) ? n : m;
+    if (row >= rows) return;
+    const double* eps_s = reinterpret_cast<const double*>(base + L.meta);
+    const bool init = step == 0, fin = step == nits + 1;
+    const int it = init ? 0 : (fin ? nits - 1 : step - 1);
+    const double eps = eps_s[it];
+    const float inv = (float)(1.0 / eps), feps = (float)eps;
+    // source potential of each softmin: a_x <- a_x, b_y <- b_y, a_y <- b_x, b_x <- a_y   (index into [a_x,b_y,a_y,b_x])
+    const int src_kind = kind == 2 ? 3 : (kind == 3 ? 2 : kind);
+    const int rd = init ? 0 : (fin ? (nits & 1) : ((step - 1) & 1));
+    const float* pot = base + L.pot + ((size_t)rd * 4 + src_kind) * nmax;
+    const float* own = base + L.pot + ((size_t)rd * 4 + kind) * nmax;
+    const float lw = logf(1.0f / (float)cols);
+    const float* Crow = base + (kind == 0 ? L.cxx : kind == 1 ? L.cyy : kind == 2 ? L.cyx : L.cxy) + (size_t)row * nmax;
+    float mx = -INFINITY, s = 0.f;
+    auto push = [&](float c, float pj) {
+        const float h = init ? lw : lw + pj / feps;
+        const float v = h - c * inv;
+        // online log-sum-exp; hardware exp (v_exp_f32, ~1 ulp): 4 * N^2 of these per step make the sweep VALU bound otherwise
+        if (v > mx) { s = s * __expf(mx - v) + 1.0f; mx = v; } else { s += __expf(v - mx); }
+    };
+    const bool vec = (nmax & 3) == 0;
+    if (vec) {
+        for (int j = lane * 4; j < cols; j += 256) {
+            const float4 c4 = *reinterpret_cast<const float4*>(Crow + j);
+            float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!init) p4 = *reinterpret_cast<const float4*>(pot + j);
+            push(c4.x, p4.x);
+            if (j + 1 < cols) push(c4.y, p4.y);
+            if (j + 2 < cols) push(c4.z, p4.z);
+            if (j + 3 < cols) push(c4.w, p4.w);
+        }
+    } else {
+        for (int j = lane; j < cols; j += 64) push(Crow[j], init ? 0.f : pot[j]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(mx, o, 64), s2 = __shfl_xor(s, o, 64);
+        const float mn = fmaxf(mx, m2);
+        const float e1 = mx == -INFINITY ? 0.f : __expf(mx - mn), e2 = m2 == -INFINITY ? 0.f : __expf(m2 - mn);
+        s = s * e1 + s2 * e2;
+        mx = mn;
+    }
+    if (lane == 0) {
+        const float val = -feps * (mx + logf(s));
+        if (init) base[L.pot + ((size_t)0 * 4 + kind) * nmax + row] = val;                 // buffer 0
+        else if (fin) base[L.til + (size_t)kind * nmax + row] = val;
+        else base[L.pot + ((size_t)(((step - 1) & 1) ^ 1) * 4 + kind) * nmax + row] = 0.5f * (own[row] + val);
+    }
+}
+
+// ---- cost: grid n_prob, 256 threads ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_big_final(const int* cloud_off, const int* prob_xy, int nmax, int E, const float* ws,
+                                                   float* out) {
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const BigLayout L = big_layout(nmax, E);
+    const float* base = ws + (size_t)p * L.total;
+    const int cx = prob_xy[2 * p], cy = prob_xy[2 * p + 1];
+    const int n = cloud_off[cx + 1] - cloud_off[cx], m = cloud_off[cy + 1] - cloud_off[cy];
+    const float* a_x = base + L.til, *b_y = a_x + nmax, *a_y = b_y + nmax, *b_x = a_y + nmax;
+    float s1 = 0.f, s2 = 0.f;
+    const float wa = 1.0f / (float)n, wb = 1.0f / (float)m;
+    for (int i = tid; i < n; i += 256) s1 += wa * (b_x[i] - a_x[i]);
+    for (int i = tid; i < m; i += 256) s2 += wb * (a_y[i] - b_y[i]);
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    __shared__ float r1[4], r2[4];
+    if ((tid & 63) == 0) { r1[tid >> 6] = s1; r2[tid >> 6] = s2; }
+    __syncthreads();
+    if (tid == 0) out[p] = ((r1[0] + r1[1]) + (r1[2] + r1[3])) + ((r2[0] + r2[1]) + (r2[2] + r2[3]));
+}
+
+}  // namespace
+
+size_t aadg_sinkhorn_big_workspace_bytes(int n_prob, int nmax, int E) {
+    return (size_t)n_prob * big_layout(nmax, E).total * sizeof(float);
+}
+
+int aadg_sinkhorn_big_launch(const float* feat, int ld, int E, const int* cloud_rows, const int* cloud_off, const int* prob_xy,
+                             int n_prob, int nmax, float blur, float scaling, float* out, void* ws, size_t ws_bytes,
+                             hipStream_t st) {
+    if (!ws || ws_bytes < aadg_sinkhorn_big_workspace_bytes(n_prob, nmax, E)) return AADG_E_WORKSPACE;
+    if (E > 64 * PREP_KPL) return AADG_E_UNSUPPORTED;
+    float* w = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(k_big_prep, dim3(BIG_PREP_CHUNKS, n_prob), dim3(256), 0, st, feat, ld, E, cloud_rows, cloud_off, prob_xy,
+                       nmax, w);
+    AADG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_big_schedule, dim3(n_prob), dim3(256), 0, st, nmax, E, blur, scaling, w);
+    AADG_LAUNCH_CHECK();
+    const int tiles = (nmax + CT - 1) / CT;
+    hipLaunchKernelGGL(k_big_cost, dim3(tiles, tiles, n_prob * 4), dim3(256), 0, st, cloud_off, prob_xy, nmax, E, w);
+    AADG_LAUNCH_CHECK();
+    const dim3 gs(4 * ((nmax + 3) / 4), n_prob);
+    for (int step = 0; step <= BIG_MAX_ITS + 1; ++step) {
+        hipLaunchKernelGGL(k_big_sweep, gs, dim3(256), 0, st, cloud_off, prob_xy, nmax, E, step, w);
+        AADG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_big_final, dim3(n_prob), dim3(256), 0, st, cloud_off, prob_xy, nmax, E, w, out);
+    AADG_LAUNCH_CHECK();
+    return 0;
+}

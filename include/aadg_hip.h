@@ -112,7 +112,9 @@ int aadg_op_u8(const uint8_t* in, uint8_t* out, int H, int W, int op, int iarg, 
  * `ld` floats): cloud c = rows cloud_rows[cloud_off[c] .. cloud_off[c+1]); problem p compares
  * clouds prob_xy[2p] and prob_xy[2p+1].  out[p] = S_eps(x, y), debiased, p=2.
  * ------------------------------------------------------------------------------------------- */
-size_t aadg_sinkhorn_workspace_bytes(int n_prob, int max_cloud);
+/* clouds up to ~100 points run out of LDS (no workspace beyond n_prob floats); larger clouds keep their cost
+ * matrices in the workspace (4 * max_cloud^2 floats per problem) and build them on the matrix cores. */
+size_t aadg_sinkhorn_workspace_bytes(int n_prob, int max_cloud, int E);
 int aadg_sinkhorn_divergence_f32(const float* feat, int ld, int E, const int32_t* cloud_rows,
                                  const int32_t* cloud_off, const int32_t* prob_xy, int n_prob,
                                  int max_cloud, float blur, float scaling, float* out, void* ws,

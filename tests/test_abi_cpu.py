@@ -34,7 +34,8 @@ def test_workspace_queries_are_pure_host_calls():
     lib = _lib.load()
     assert lib.aadg_aug_u8_workspace_bytes(144, 512, 512, 512) >= 2 * 144 * 512 * 512 * 3
     assert lib.aadg_aug_u8_workspace_bytes(0, 512, 512, 512) == 0
-    assert lib.aadg_sinkhorn_workspace_bytes(18, 8) >= 18 * 4
+    assert lib.aadg_sinkhorn_workspace_bytes(18, 8, 128) >= 18 * 4
+    assert lib.aadg_sinkhorn_workspace_bytes(1, 4096, 128) >= 4 * 4096 * 4096 * 4      # cost matrices in HBM
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")

@@ -112,3 +112,38 @@ def test_samplesloss_compatible_callable(hip, oracle):
         SamplesLoss("sinkhorn", cost=None)
     with pytest.raises(NotImplementedError):
         SamplesLoss("gaussian")
+
+
+def test_large_clouds_matrix_core_path(hip, oracle):
+    """Clouds beyond the LDS-resident kernel: cost matrices in HBM (built with v_mfma_f32_32x32x2_f32), one wave per
+    log-sum-exp row.  Against the oracle, and against the LDS kernel on a size both can do."""
+    rs = np.random.RandomState(11)
+    E = 128
+    sizes = [300, 257, 64, 40]
+    x = rs.randn(sum(sizes), E).astype(np.float32) * 0.6 + rs.randn(E).astype(np.float32)
+    x = np.where(x > 0, x, 0.2 * x)
+    o = np.concatenate([[0], np.cumsum(sizes)])
+    pairs = [(0, 1), (1, 0), (0, 0), (2, 3)]
+    rows, off, pxy = _tables(sizes, pairs, "cuda")
+    t = torch.from_numpy(x).cuda()
+    got = hip.sinkhorn_divergence(t, rows, off, pxy, max(sizes)).cpu().numpy()          # max_cloud 300 -> large path
+    for k, (a, b) in enumerate(pairs):
+        want = oracle.sinkhorn_divergence(x[o[a]:o[a + 1]], x[o[b]:o[b + 1]])
+        assert abs(got[k] - want) <= 2e-5, (k, got[k], want)
+    assert abs(got[0] - got[1]) <= 2e-5 and abs(got[2]) <= 2e-5                          # symmetry, S(x,x) = 0
+    rows2, off2, pxy2 = _tables(sizes, [(2, 3)], "cuda")
+    small = hip.sinkhorn_divergence(t, rows2, off2, pxy2, 64).cpu().numpy()[0]          # LDS path on the same problem
+    assert abs(small - got[3]) <= 1e-5
+
+
+def test_scaled_synthetic_4096(hip, oracle):
+    """SURVEY 8d scaled synthetic: 4096 points per cloud, E = 128 (one problem).  Oracle on a 1024-point subsample is
+    too different a problem to compare, so check invariants at full size: symmetry and S(x,x) = 0."""
+    rs = np.random.RandomState(12)
+    n, E = 4096, 128
+    x = rs.randn(2 * n, E).astype(np.float32) * 0.5 + rs.randn(E).astype(np.float32)
+    x = np.where(x > 0, x, 0.2 * x)
+    rows, off, pxy = _tables([n, n], [(0, 1), (1, 0), (0, 0)], "cuda")
+    got = hip.sinkhorn_divergence(torch.from_numpy(x).cuda(), rows, off, pxy, n).cpu().numpy()
+    assert np.isfinite(got).all() and got[0] > 0
+    assert abs(got[0] - got[1]) <= 1e-4 * max(1.0, abs(got[0])) and abs(got[2]) <= 1e-4
