@@ -34,6 +34,7 @@ EXPORTS = [
     "aadg_seg_loss_workspace_bytes", "aadg_seg_bce_dice_f32",
     "aadg_fop_workspace_bytes", "aadg_fop_f32",
     "aadg_upsample_bilinear2d",
+    "aadg_bn_workspace_bytes", "aadg_bn_forward", "aadg_bn_backward",
 ]
 
 _lib = None
@@ -80,6 +81,12 @@ def load():
         lib.aadg_fop_f32.argtypes = [_i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]
     lib.aadg_upsample_bilinear2d.restype = _i
     lib.aadg_upsample_bilinear2d.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
+    lib.aadg_bn_workspace_bytes.restype = _sz
+    lib.aadg_bn_workspace_bytes.argtypes = [_i]
+    lib.aadg_bn_forward.restype = _i
+    lib.aadg_bn_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]
+    lib.aadg_bn_backward.restype = _i
+    lib.aadg_bn_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]
     if lib.aadg_abi_version() != 1:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
@@ -418,3 +425,84 @@ class _UpsampleBilinearAC(torch.autograd.Function):
 
 def upsample_bilinear_ac(x, size):
     return _UpsampleBilinearAC.apply(x, tuple(size))
+
+
+# ------------------------------------------------------------------------------------------------
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+_BN_DTYPES = {torch.float32: 0, torch.bfloat16: 1}
+_bn_ws_cache = {}
+
+
+def _bn_ws(C, device):
+    """Per-(device, stream) scratch for the per-channel partials; reused across layers (stream-ordered)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    need = load().aadg_bn_workspace_bytes(C)
+    ws = _bn_ws_cache.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+        _bn_ws_cache[key] = ws
+    return ws
+
+
+class _BatchNormAct(torch.autograd.Function):
+    """act(batch_norm(x) [+ residual]) with the HIP streaming kernels (csrc/batchnorm.hip); training mode."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, act):
+        lib = load()
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _bn_ws(C, x.device)
+        rc = lib.aadg_bn_forward(x.data_ptr(), _ptr(residual), y.data_ptr(), _ptr(weight), _ptr(bias), _ptr(running_mean),
+                                 _ptr(running_var), momentum, eps, act, 1, N, C, H * W, _BN_DTYPES[x.dtype],
+                                 mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+        _check(rc, "aadg_bn_forward")
+        ctx.act = act
+        ctx.has_res = residual is not None
+        # the activation mask is re-derived from x (no residual) or from the stored output (residual fused)
+        ctx.save_for_backward(x, y if ctx.has_res else None, weight, bias, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load()
+        x, y, weight, bias, mean, invstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        dw = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _bn_ws(C, x.device)
+        rc = lib.aadg_bn_backward(x.data_ptr(), _ptr(y), dy.data_ptr(), _ptr(weight), _ptr(bias), mean.data_ptr(),
+                                  invstd.data_ptr(), ctx.act, dx.data_ptr(), _ptr(dres), dw.data_ptr(), db.data_ptr(),
+                                  N, C, H * W, _BN_DTYPES[x.dtype], ws.data_ptr(), ws.numel(), _stream())
+        _check(rc, "aadg_bn_backward")
+        return (dx, dres, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None)
+
+
+def bn_act_supported(x, residual=None):
+    return (x.is_cuda and x.dim() == 4 and x.dtype in _BN_DTYPES and x.is_contiguous() and
+            (residual is None or (residual.is_contiguous() and residual.dtype == x.dtype and residual.shape == x.shape)))
+
+
+def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentum, eps, act=ACT_NONE, residual=None):
+    """act(F.batch_norm(x, ...) [+ residual]) on NCHW float32 / bfloat16 GPU tensors."""
+    _require_cuda(x, residual)
+    if not bn_act_supported(x, residual):
+        raise AadgError("batch_norm_act: expected contiguous NCHW float32/bfloat16 tensors")
+    if training:
+        return _BatchNormAct.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), int(act))
+    lib = load()
+    N, C, H, W = x.shape
+    if x.requires_grad or (residual is not None and residual.requires_grad):
+        raise AadgError("batch_norm_act: inference mode is forward-only")
+    y = torch.empty_like(x)
+    ws = _bn_ws(C, x.device)
+    rc = lib.aadg_bn_forward(x.data_ptr(), _ptr(residual), y.data_ptr(), _ptr(weight), _ptr(bias), running_mean.data_ptr(),
+                             running_var.data_ptr(), 0.0, float(eps), int(act), 0, N, C, H * W, _BN_DTYPES[x.dtype],
+                             None, None, ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "aadg_bn_forward")
+    return y

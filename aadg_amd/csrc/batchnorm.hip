@@ -1,0 +1,447 @@
+// Training / inference BatchNorm2d over NCHW planes fused with the activation (ReLU / ReLU6) and the residual add
+// that follow it in the segmentation backbone -- the consumer of the augmentation batch.  At
+// N = 144 x 512 x 512 the 62 BatchNorm layers of DeepLabV3+/ResNet-50 move ~21 GB per pass over the activations;
+// the library kernels they replace launch one workgroup per channel (64 workgroups for the stem on a 256-CU part).
+// Here every phase is a streaming pass with 16-byte accesses and a (channel, split) grid:
+//
+//   k_bn_reduce<FWD>   per (c, split): sum x, sum x^2                       -> partials (float2)
+//   k_bn_finalize_fwd  per c: mean, invstd (double combine), running stats, scale = w*invstd, shift = b - mean*scale
+//   k_bn_apply         y = act(x * scale[c] + shift[c] (+ residual))
+//   k_bn_reduce<BWD>   per (c, split): sum g, sum g*xhat with g = dy * act'(.)  (optionally writes g = d residual)
+//   k_bn_finalize_bwd  dweight, dbias and the three per-channel coefficients of dx = a*g + b*x + c0
+//   k_bn_dx            dx = a[c]*g + b[c]*x + c0[c]
+//
+// Arithmetic = torch.nn.functional.batch_norm (biased variance for normalisation, unbiased for running_var),
+// float32 accumulation, partial sums combined in float64.
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int BN_MAX_SPLIT = 64;
+
+// ---- 16-byte vectors of T ---------------------------------------------------------------------------------
+template <typename T> struct Pack;
+template <> struct Pack<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float* v) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float* v) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    static __device__ __forceinline__ float load1(const float* p) { return *p; }
+    static __device__ __forceinline__ void store1(float* p, float v) { *p = v; }
+    static __device__ __forceinline__ float round(float v) { return v; }
+};
+__device__ __forceinline__ uint32_t f2bf_bits(float f) {      // round to nearest even (finite inputs; NaN kept quiet)
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+template <> struct Pack<__hip_bfloat16> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const __hip_bfloat16* p, float* v) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(__hip_bfloat16* p, const float* v) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = f2bf_bits(v[2 * i]) | (f2bf_bits(v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    static __device__ __forceinline__ float load1(const __hip_bfloat16* p) {
+        return __uint_as_float((uint32_t)(*reinterpret_cast<const uint16_t*>(p)) << 16);
+    }
+    static __device__ __forceinline__ void store1(__hip_bfloat16* p, float v) {
+        *reinterpret_cast<uint16_t*>(p) = (uint16_t)f2bf_bits(v);
+    }
+    static __device__ __forceinline__ float round(float v) { return __uint_as_float(f2bf_bits(v) << 16); }
+};
+
+// activation on the value the forward STORED (rounded to T): the backward re-derives the mask from the same value
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == AADG_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == AADG_ACT_RELU6) return fminf(fmaxf(v, 0.0f), 6.0f);
+    return v;
+}
+__device__ __forceinline__ bool act_open(float v, int act) {   // derivative is 1 (else 0)
+    if (act == AADG_ACT_RELU) return v > 0.0f;
+    if (act == AADG_ACT_RELU6) return v > 0.0f && v < 6.0f;
+    return true;
+}
+
+struct BnWs {      // float offsets into the workspace
+    size_t partial;   // [C][split] float2
+    size_t scale, shift, ca, cb, cc;   // [C] each
+    size_t total;
+};
+__host__ __device__ inline BnWs bn_ws(int C) {
+    BnWs w;
+    size_t o = 0;
+    w.partial = o; o += (size_t)C * BN_MAX_SPLIT * 2;
+    w.scale = o; o += C;
+    w.shift = o; o += C;
+    w.ca = o; o += C;
+    w.cb = o; o += C;
+    w.cc = o; o += C;
+    w.total = o;
+    return w;
+}
+
+// work split of one channel: N strips of `len` vectors (len = HW / VEC); a block owns pieces p = split, split + S, ...
+// where a piece is up to `plen` consecutive vectors of one strip.
+struct Pieces {
+    int per_strip;   // pieces per strip
+    int plen;        // vectors per piece (multiple of the block size)
+    int total;       // N * per_strip
+};
+inline Pieces make_pieces(int N, int len, int threads) {
+    Pieces p;
+    const int span = threads * 4;                          // 4 vectors in flight per thread
+    p.per_strip = (len + span - 1) / span;
+    p.plen = span;
+    p.total = N * p.per_strip;
+    return p;
+}
+inline int pick_threads(int len) { return len >= 256 ? 256 : (len > 128 ? 256 : (len > 64 ? 128 : 64)); }
+inline int pick_split(int C, int pieces) {
+    int s = (4096 + C - 1) / C;                            // aim at >= 4096 workgroups
+    if (s > pieces) s = pieces;
+    if (s > BN_MAX_SPLIT) s = BN_MAX_SPLIT;
+    return s < 1 ? 1 : s;
+}
+
+__device__ __forceinline__ float2 block_sum2(float a, float b) {
+    __shared__ float red[2][4];
+    a = wave_sum(a); b = wave_sum(b);
+    const int wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wv] = a; red[1][wv] = b; }
+    __syncthreads();
+    float2 r = make_float2(0.f, 0.f);
+    for (int i = 0; i < nw; ++i) { r.x += red[0][i]; r.y += red[1][i]; }
+    return r;
+}
+
+// ---- reductions: grid (split, C) ---------------------------------------------------------------------------
+// MODE 0: sum x, sum x^2.   MODE 1: g = dy * act'(v) with v = the forward's stored output (recomputed from x, or read
+// from y when a residual was fused); sums g and g * (x - mean) * invstd; writes g to dres when dres != nullptr.
+template <typename T, int VEC, int MODE>
+__global__ __launch_bounds__(256) void k_bn_reduce(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
+                                                   T* __restrict__ dres, const float* __restrict__ mean,
+                                                   const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                   const float* __restrict__ shift, int act, int C, int len, int per_strip,
+                                                   int plen, int total, float* __restrict__ partial) {
+    const int c = blockIdx.y, S = gridDim.x;
+    const size_t strip_elems = (size_t)len * VEC;
+    float s0 = 0.f, s1 = 0.f;
+    float mu = 0.f, is = 0.f, sc = 0.f, sh = 0.f;
+    if (MODE == 1) { mu = mean[c]; is = invstd[c]; sc = scale[c]; sh = shift[c]; }
+    for (int p = blockIdx.x; p < total; p += S) {
+        const int n = p / per_strip, part = p - n * per_strip;
+        const size_t base = ((size_t)n * C + c) * strip_elems;
+        const int j1 = min(len, (part + 1) * plen);
+#pragma unroll 4
+        for (int j = part * plen + threadIdx.x; j < j1; j += blockDim.x) {
+            const size_t off = base + (size_t)j * VEC;
+            float xv[VEC];
+            if (VEC == 1) xv[0] = Pack<T>::load1(x + off); else Pack<T>::load(x + off, xv);
+            if (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { s0 += xv[i]; s1 = fmaf(xv[i], xv[i], s1); }
+            } else {
+                float gv[VEC], yv[VEC];
+                if (VEC == 1) gv[0] = Pack<T>::load1(dy + off); else Pack<T>::load(dy + off, gv);
+                if (y != nullptr) {
+                    if (VEC == 1) yv[0] = Pack<T>::load1(y + off); else Pack<T>::load(y + off, yv);
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    // pre-activation value as the forward saw it: the stored output when we have it (for ReLU the
+                    // sign of the output decides; ReLU6 needs the interval, still decidable from the clamped value)
+                    const float v = y != nullptr ? yv[i] : Pack<T>::round(fmaf(xv[i], sc, sh));
+                    const float g = act_open(v, act) ? gv[i] : 0.0f;
+                    gv[i] = g;
+                    s0 += g;
+                    s1 = fmaf(g, (xv[i] - mu) * is, s1);
+                }
+                if (dres != nullptr) {
+                    if (VEC == 1) Pack<T>::store1(dres + off, gv[0]); else Pack<T>::store(dres + off, gv);
+                }
+            }
+        }
+    }
+    const float2 r = block_sum2(s0, s1);
+    if (threadIdx.x == 0) reinterpret_cast<float2*>(partial)[(size_t)c * BN_MAX_SPLIT + blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict__ partial, int split, int C, double count,
+                                                         const float* __restrict__ weight, const float* __restrict__ bias,
+                                                         float* running_mean, float* running_var, float momentum, float eps,
+                                                         float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                         float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < split; ++i) {
+        const float2 p = reinterpret_cast<const float2*>(partial)[(size_t)c * BN_MAX_SPLIT + i];
+        s += (double)p.x; q += (double)p.y;
+    }
+    const double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = (float)m;
+    save_invstd[c] = is;
+    if (running_mean != nullptr) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+    const float w = weight != nullptr ? weight[c] : 1.0f, b = bias != nullptr ? bias[c] : 0.0f;
+    const float sc = w * is;
+    scale[c] = sc;
+    shift[c] = fmaf(-(float)m, sc, b);
+}
+
+// scale / shift from given statistics: `from_var` = 1: second array is a variance (inference, running statistics),
+// 0: it is the saved invstd of a training forward (bit-identical to what k_bn_finalize_fwd produced)
+__global__ __launch_bounds__(256) void k_bn_scale_shift(int C, const float* __restrict__ weight, const float* __restrict__ bias,
+                                                        const float* __restrict__ mean, const float* __restrict__ second,
+                                                        float eps, int from_var, float* __restrict__ scale,
+                                                        float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = from_var ? 1.0f / sqrtf(second[c] + eps) : second[c];
+    const float w = weight != nullptr ? weight[c] : 1.0f, b = bias != nullptr ? bias[c] : 0.0f;
+    const float sc = w * is;
+    scale[c] = sc;
+    shift[c] = fmaf(-mean[c], sc, b);
+}
+
+__global__ __launch_bounds__(256) void k_bn_finalize_bwd(const float* __restrict__ partial, int split, int C, double count,
+                                                         const float* __restrict__ weight, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, float* __restrict__ dweight,
+                                                         float* __restrict__ dbias, float* __restrict__ ca,
+                                                         float* __restrict__ cb, float* __restrict__ cc) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double sg = 0.0, sgx = 0.0;
+    for (int i = 0; i < split; ++i) {
+        const float2 p = reinterpret_cast<const float2*>(partial)[(size_t)c * BN_MAX_SPLIT + i];
+        sg += (double)p.x; sgx += (double)p.y;
+    }
+    if (dweight != nullptr) dweight[c] = (float)sgx;
+    if (dbias != nullptr) dbias[c] = (float)sg;
+    const double w = weight != nullptr ? (double)weight[c] : 1.0;
+    const double is = (double)invstd[c], mu = (double)mean[c];
+    const double a = w * is;                              // dx = a*g - a*sg/n - a*is*sgx/n * (x - mu)
+    const double b = -a * is * sgx / count;
+    ca[c] = (float)a;
+    cb[c] = (float)b;
+    cc[c] = (float)(-a * sg / count - b * mu);
+}
+
+// ---- elementwise passes: grid (N*C strips, pieces per strip) ------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                  const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                  int C, int len, int plen) {
+    const int strip = blockIdx.x, c = strip % C;
+    const float sc = scale[c], sh = shift[c];
+    const size_t base = (size_t)strip * len * VEC;
+    const int j1 = min(len, ((int)blockIdx.y + 1) * plen);
+#pragma unroll 4
+    for (int j = blockIdx.y * plen + threadIdx.x; j < j1; j += blockDim.x) {
+        const size_t off = base + (size_t)j * VEC;
+        float v[VEC], r[VEC];
+        if (VEC == 1) v[0] = Pack<T>::load1(x + off); else Pack<T>::load(x + off, v);
+        if (res != nullptr) {
+            if (VEC == 1) r[0] = Pack<T>::load1(res + off); else Pack<T>::load(res + off, r);
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float t = fmaf(v[i], sc, sh);
+            if (res != nullptr) t = Pack<T>::round(t) + r[i];     // same roundings as bn (stored in T) followed by add
+            v[i] = act_fwd(t, act);
+        }
+        if (VEC == 1) Pack<T>::store1(y + off, v[0]); else Pack<T>::store(y + off, v);
+    }
+}
+
+// g = dy * act'(.) is recomputed exactly as in k_bn_reduce<BWD> unless `g_ready` (then `dy` already holds g = dres)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_bn_dx(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                               const float* __restrict__ ca, const float* __restrict__ cb,
+                                               const float* __restrict__ cc, int act, int g_ready, int C, int len, int plen) {
+    const int strip = blockIdx.x, c = strip % C;
+    const float sc = scale[c], sh = shift[c], a = ca[c], b = cb[c], c0 = cc[c];
+    const size_t base = (size_t)strip * len * VEC;
+    const int j1 = min(len, ((int)blockIdx.y + 1) * plen);
+    const bool mask = !g_ready && act != AADG_ACT_NONE;
+#pragma unroll 4
+    for (int j = blockIdx.y * plen + threadIdx.x; j < j1; j += blockDim.x) {
+        const size_t off = base + (size_t)j * VEC;
+        float xv[VEC], gv[VEC];
+        if (VEC == 1) { xv[0] = Pack<T>::load1(x + off); gv[0] = Pack<T>::load1(dy + off); }
+        else { Pack<T>::load(x + off, xv); Pack<T>::load(dy + off, gv); }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float g = gv[i];
+            if (mask && !act_open(Pack<T>::round(fmaf(xv[i], sc, sh)), act)) g = 0.0f;
+            xv[i] = fmaf(a, g, fmaf(b, xv[i], c0));
+        }
+        if (VEC == 1) Pack<T>::store1(dx + off, xv[0]); else Pack<T>::store(dx + off, xv);
+    }
+}
+
+struct Shape {
+    int N, C, HW, vec, len, threads;
+    Pieces pc;
+    int split;
+};
+template <typename T>
+inline bool make_shape(int N, int C, int HW, const void* a, const void* b, const void* c, const void* d, Shape* s) {
+    if (N <= 0 || C <= 0 || HW <= 0 || (long long)N * C > 0x7FFFFFFFLL) return false;
+    constexpr int V = Pack<T>::N;
+    const bool aligned = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15u) == 0;
+    s->N = N; s->C = C; s->HW = HW;
+    s->vec = (HW % V == 0 && aligned) ? V : 1;
+    s->len = HW / s->vec;
+    s->threads = pick_threads(s->len);
+    s->pc = make_pieces(N, s->len, s->threads);
+    s->split = pick_split(C, s->pc.total);
+    return s->pc.per_strip <= 65535;
+}
+
+template <typename T>
+int bn_forward(const T* x, const T* res, T* y, const float* weight, const float* bias, float* rmean, float* rvar, float momentum,
+               float eps, int act, int training, int N, int C, int HW, float* save_mean, float* save_invstd, float* ws,
+               hipStream_t st) {
+    Shape s;
+    if (!make_shape<T>(N, C, HW, x, res, y, nullptr, &s)) return AADG_E_BADARG;
+    const BnWs L = bn_ws(C);
+    float* scale = ws + L.scale;
+    float* shift = ws + L.shift;
+    const dim3 blk(s.threads);
+    if (training) {
+        const dim3 grid(s.split, C);
+        if (s.vec > 1)
+            hipLaunchKernelGGL((k_bn_reduce<T, Pack<T>::N, 0>), grid, blk, 0, st, x, (const T*)nullptr, (const T*)nullptr, (T*)nullptr,
+                               (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act, C,
+                               s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
+        else
+            hipLaunchKernelGGL((k_bn_reduce<T, 1, 0>), grid, blk, 0, st, x, (const T*)nullptr, (const T*)nullptr, (T*)nullptr,
+                               (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act, C,
+                               s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
+        AADG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((C + 255) / 256), dim3(256), 0, st, ws + L.partial, s.split, C,
+                           (double)N * (double)HW, weight, bias, rmean, rvar, momentum, eps, save_mean, save_invstd, scale, shift);
+        AADG_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(k_bn_scale_shift, dim3((C + 255) / 256), dim3(256), 0, st, C, weight, bias, (const float*)rmean,
+                           (const float*)rvar, eps, 1, scale, shift);
+        AADG_LAUNCH_CHECK();
+    }
+    const dim3 grid(N * C, s.pc.per_strip);
+    if (s.vec > 1)
+        hipLaunchKernelGGL((k_bn_apply<T, Pack<T>::N>), grid, blk, 0, st, x, res, y, scale, shift, act, C, s.len, s.pc.plen);
+    else
+        hipLaunchKernelGGL((k_bn_apply<T, 1>), grid, blk, 0, st, x, res, y, scale, shift, act, C, s.len, s.pc.plen);
+    AADG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+int bn_backward(const T* x, const T* y, const T* dy, const float* weight, const float* bias, const float* mean, const float* invstd,
+                int act, T* dx, T* dres, float* dweight, float* dbias, int N, int C, int HW, float* ws, hipStream_t st) {
+    Shape s;
+    if (!make_shape<T>(N, C, HW, x, y, dy, dx, &s) || (((uintptr_t)dres & 15u) && s.vec > 1)) return AADG_E_BADARG;
+    const BnWs L = bn_ws(C);
+    float* scale = ws + L.scale;
+    float* shift = ws + L.shift;
+    const dim3 blk(s.threads);
+    hipLaunchKernelGGL(k_bn_scale_shift, dim3((C + 255) / 256), dim3(256), 0, st, C, weight, bias, mean, invstd, 0.0f, 0, scale, shift);
+    AADG_LAUNCH_CHECK();
+    {
+        const dim3 grid(s.split, C);
+        if (s.vec > 1)
+            hipLaunchKernelGGL((k_bn_reduce<T, Pack<T>::N, 1>), grid, blk, 0, st, x, y, dy, dres, mean, invstd, (const float*)scale,
+                               (const float*)shift, act, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
+        else
+            hipLaunchKernelGGL((k_bn_reduce<T, 1, 1>), grid, blk, 0, st, x, y, dy, dres, mean, invstd, (const float*)scale,
+                               (const float*)shift, act, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
+        AADG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((C + 255) / 256), dim3(256), 0, st, ws + L.partial, s.split, C,
+                       (double)N * (double)HW, weight, mean, invstd, dweight, dbias, ws + L.ca, ws + L.cb, ws + L.cc);
+    AADG_LAUNCH_CHECK();
+    {
+        // when the masked gradient was materialised (dres), the last pass reads it instead of re-deriving the mask
+        const T* g = dres != nullptr ? (const T*)dres : dy;
+        const int g_ready = dres != nullptr ? 1 : 0;
+        const dim3 grid(N * C, s.pc.per_strip);
+        if (s.vec > 1)
+            hipLaunchKernelGGL((k_bn_dx<T, Pack<T>::N>), grid, blk, 0, st, x, g, dx, (const float*)scale, (const float*)shift,
+                               (const float*)(ws + L.ca), (const float*)(ws + L.cb), (const float*)(ws + L.cc), act, g_ready, C,
+                               s.len, s.pc.plen);
+        else
+            hipLaunchKernelGGL((k_bn_dx<T, 1>), grid, blk, 0, st, x, g, dx, (const float*)scale, (const float*)shift,
+                               (const float*)(ws + L.ca), (const float*)(ws + L.cb), (const float*)(ws + L.cc), act, g_ready, C,
+                               s.len, s.pc.plen);
+        AADG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t aadg_bn_workspace_bytes(int C) { return C > 0 ? bn_ws(C).total * sizeof(float) : 0; }
+
+extern "C" int aadg_bn_forward(const void* x, const void* residual, void* y, const float* weight, const float* bias,
+                               float* running_mean, float* running_var, float momentum, float eps, int act, int training, int N,
+                               int C, int HW, int dtype, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
+                               void* stream) {
+    if (x == nullptr || y == nullptr || ws == nullptr || act < 0 || act > AADG_ACT_RELU6) return AADG_E_BADARG;
+    if (training && (save_mean == nullptr || save_invstd == nullptr)) return AADG_E_BADARG;
+    if (!training && (running_mean == nullptr || running_var == nullptr)) return AADG_E_BADARG;
+    if (C <= 0 || ws_bytes < aadg_bn_workspace_bytes(C)) return AADG_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0)
+        return bn_forward<float>((const float*)x, (const float*)residual, (float*)y, weight, bias, running_mean, running_var,
+                                 momentum, eps, act, training, N, C, HW, save_mean, save_invstd, (float*)ws, st);
+    if (dtype == 1)
+        return bn_forward<__hip_bfloat16>((const __hip_bfloat16*)x, (const __hip_bfloat16*)residual, (__hip_bfloat16*)y, weight,
+                                          bias, running_mean, running_var, momentum, eps, act, training, N, C, HW, save_mean,
+                                          save_invstd, (float*)ws, st);
+    return AADG_E_BADARG;
+}
+
+extern "C" int aadg_bn_backward(const void* x, const void* y, const void* dy, const float* weight, const float* bias,
+                                const float* save_mean, const float* save_invstd, int act, void* dx, void* dres, float* dweight,
+                                float* dbias, int N, int C, int HW, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (x == nullptr || dy == nullptr || dx == nullptr || save_mean == nullptr || save_invstd == nullptr || ws == nullptr ||
+        act < 0 || act > AADG_ACT_RELU6)
+        return AADG_E_BADARG;
+    if (dres != nullptr && y == nullptr) return AADG_E_BADARG;   // a fused residual needs the stored output for the mask
+    if (C <= 0 || ws_bytes < aadg_bn_workspace_bytes(C)) return AADG_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0)
+        return bn_backward<float>((const float*)x, (const float*)y, (const float*)dy, weight, bias, save_mean, save_invstd, act,
+                                  (float*)dx, (float*)dres, dweight, dbias, N, C, HW, (float*)ws, st);
+    if (dtype == 1)
+        return bn_backward<__hip_bfloat16>((const __hip_bfloat16*)x, (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy, weight,
+                                           bias, save_mean, save_invstd, act, (__hip_bfloat16*)dx, (__hip_bfloat16*)dres, dweight,
+                                           dbias, N, C, HW, (float*)ws, st);
+    return AADG_E_BADARG;
+}

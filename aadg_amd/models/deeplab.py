@@ -25,8 +25,46 @@ def _upsample_ac(x, size):
     return F.interpolate(x, size=size, mode='bilinear', align_corners=True)
 
 
+_ACT_CODE = {None: 0, 'relu': 1, 'relu6': 2}
+
+
+def bn_act(bn, x, act=None, residual=None):
+    """act(bn(x) [+ residual]).  On the GPU a plain `nn.BatchNorm2d` runs as the fused HIP streaming kernels
+    (csrc/batchnorm.hip: statistics, normalise + activation + residual add in one pass, two-pass backward); anything
+    else (SyncBatchNorm after `--sync_bn`, CPU shape tests) takes the module's own path."""
+    if type(bn) is nn.BatchNorm2d and x.is_cuda and bn.momentum is not None and bn.track_running_stats:
+        from .. import _lib
+        xc = x.contiguous()
+        rc = residual.contiguous() if residual is not None else None
+        if _lib.bn_act_supported(xc, rc):
+            if bn.training:
+                bn.num_batches_tracked.add_(1)
+            return _lib.batch_norm_act(xc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum,
+                                       bn.eps, _ACT_CODE[act], rc)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    if act == 'relu':
+        return F.relu(y)
+    if act == 'relu6':
+        return F.relu6(y)
+    return y
+
+
+class BNAct(nn.Module):
+    """BatchNorm2d followed by ReLU / ReLU6 / nothing, fused on the GPU (see `bn_act`)."""
+
+    def __init__(self, c, act='relu'):
+        super().__init__()
+        self.bn = nn.BatchNorm2d(c)
+        self.act = act
+
+    def forward(self, x):
+        return bn_act(self.bn, x, self.act)
+
+
 def _bn_relu(c):
-    return [nn.BatchNorm2d(c), nn.ReLU(inplace=True)]
+    return [BNAct(c, 'relu')]
 
 
 class SeparableConv2d(nn.Sequential):
@@ -48,15 +86,13 @@ class Bottleneck(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
         self.bn3 = nn.BatchNorm2d(planes * 4)
-        self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        return self.relu(out + idt)
+        out = bn_act(self.bn1, self.conv1(x), 'relu')
+        out = bn_act(self.bn2, self.conv2(out), 'relu')
+        return bn_act(self.bn3, self.conv3(out), 'relu', residual=idt)
 
 
 class ResNet50Encoder(nn.Module):
@@ -77,7 +113,7 @@ class ResNet50Encoder(nn.Module):
     def _stage(self, planes, blocks, stride, dilation):
         down = None
         if stride != 1 or self.cin != planes * 4:
-            down = nn.Sequential(nn.Conv2d(self.cin, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4))
+            down = nn.Sequential(nn.Conv2d(self.cin, planes * 4, 1, stride=stride, bias=False), BNAct(planes * 4, None))
         layers = [Bottleneck(self.cin, planes, stride, dilation, down)]
         self.cin = planes * 4
         layers += [Bottleneck(self.cin, planes, 1, dilation) for _ in range(1, blocks)]
@@ -98,10 +134,9 @@ class InvertedResidual(nn.Module):
         self.use_res = stride == 1 and cin == cout
         layers = []
         if expand != 1:
-            layers += [nn.Conv2d(cin, hid, 1, bias=False), nn.BatchNorm2d(hid), nn.ReLU6(inplace=True)]
-        layers += [nn.Conv2d(hid, hid, 3, stride, dilation, dilation=dilation, groups=hid, bias=False),
-                   nn.BatchNorm2d(hid), nn.ReLU6(inplace=True),
-                   nn.Conv2d(hid, cout, 1, bias=False), nn.BatchNorm2d(cout)]
+            layers += [nn.Conv2d(cin, hid, 1, bias=False), BNAct(hid, 'relu6')]
+        layers += [nn.Conv2d(hid, hid, 3, stride, dilation, dilation=dilation, groups=hid, bias=False), BNAct(hid, 'relu6'),
+                   nn.Conv2d(hid, cout, 1, bias=False), BNAct(cout, None)]
         self.conv = nn.Sequential(*layers)
 
     def forward(self, x):
@@ -115,7 +150,7 @@ class MobileNetV2Encoder(nn.Module):
     def __init__(self):
         super().__init__()
         cfg = [(1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1)]
-        feats = [nn.Sequential(nn.Conv2d(3, 32, 3, 2, 1, bias=False), nn.BatchNorm2d(32), nn.ReLU6(inplace=True))]
+        feats = [nn.Sequential(nn.Conv2d(3, 32, 3, 2, 1, bias=False), BNAct(32, 'relu6'))]
         cin, stride_so_far, dilation = 32, 2, 1
         for t, c, n, s in cfg:
             for i in range(n):
@@ -127,7 +162,7 @@ class MobileNetV2Encoder(nn.Module):
                     stride_so_far *= 2
                 feats.append(InvertedResidual(cin, c, st, t, d if st == 1 else 1))
                 cin = c
-        feats.append(nn.Sequential(nn.Conv2d(cin, 1280, 1, bias=False), nn.BatchNorm2d(1280), nn.ReLU6(inplace=True)))
+        feats.append(nn.Sequential(nn.Conv2d(cin, 1280, 1, bias=False), BNAct(1280, 'relu6')))
         self.features = nn.Sequential(*feats)
 
     def forward(self, x):

@@ -164,6 +164,28 @@ int aadg_fop_f32(int fop, const float* in, float* out, const float* mag, int mag
  * ------------------------------------------------------------------------------------------- */
 int aadg_upsample_bilinear2d(const void* in, void* out, int planes, int h, int w, int H, int W, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm2d (+ activation, + residual add) over NCHW planes: the normalisation layers of the segmentation
+ * backbone that consumes the augmentation batch (reference: smp DeepLabV3+ built at models/__init__.py:17-23; every
+ * `nn.BatchNorm2d` followed by `ReLU`/`ReLU6`, and the `relu(bn3(conv3(x)) + identity)` tail of a bottleneck).
+ * Same arithmetic as torch.nn.functional.batch_norm: biased variance for normalisation, unbiased for running_var,
+ * running <- (1 - momentum) * running + momentum * batch.  dtype 0 = float32, 1 = bfloat16 (x, residual, y, dy, dx);
+ * weight / bias / statistics are float32 [C].  act: AADG_ACT_*.  residual (nullable): y = act(bn(x) + residual).
+ * training = 0 normalises with running_mean / running_var and writes no statistics.
+ * Backward: dx, dweight, dbias (nullable) and, if dres != NULL, dres = dy * act'(.) = gradient of the residual
+ * branch (then y, the stored forward output, must be given: the activation mask is taken from it).
+ * ------------------------------------------------------------------------------------------- */
+enum { AADG_ACT_NONE = 0, AADG_ACT_RELU = 1, AADG_ACT_RELU6 = 2 };
+size_t aadg_bn_workspace_bytes(int C);
+int aadg_bn_forward(const void* x, const void* residual, void* y, const float* weight, const float* bias,
+                    float* running_mean, float* running_var, float momentum, float eps, int act, int training,
+                    int N, int C, int HW, int dtype, float* save_mean, float* save_invstd, void* ws,
+                    size_t ws_bytes, void* stream);
+int aadg_bn_backward(const void* x, const void* y, const void* dy, const float* weight, const float* bias,
+                     const float* save_mean, const float* save_invstd, int act, void* dx, void* dres,
+                     float* dweight, float* dbias, int N, int C, int HW, int dtype, void* ws, size_t ws_bytes,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

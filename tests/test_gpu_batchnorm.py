@@ -1,0 +1,126 @@
+"""GPU: fused BatchNorm (+ ReLU / ReLU6, + residual add) kernels vs torch.nn.functional.batch_norm, forward,
+backward, running statistics, inference mode; and the backbone wired to them."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ACTS = {0: lambda t: t, 1: F.relu, 2: F.relu6}
+
+
+def _reference(x, res, w, b, rm, rv, training, momentum, eps, act):
+    y = F.batch_norm(x.float(), rm, rv, w, b, training, momentum, eps)
+    if x.dtype != torch.float32:
+        y = y.to(x.dtype).float()          # the unfused graph stores bn's output in the activation dtype
+    if res is not None:
+        y = y + res.float()
+    return ACTS[act](y)
+
+
+@pytest.mark.parametrize("shape", [(4, 8, 16, 16), (3, 5, 7, 9), (6, 16, 1, 1), (2, 64, 64, 64), (5, 3, 33, 8)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act,with_res", [(0, False), (1, False), (2, False), (1, True), (0, True)])
+def test_bn_training_matches_torch(hip, shape, dtype, act, with_res):
+    torch.manual_seed(sum(shape) + act)
+    N, C, H, W = shape
+    x = (torch.randn(shape, device="cuda") * 2 + 0.5).to(dtype).requires_grad_(True)
+    res = torch.randn(shape, device="cuda").to(dtype).requires_grad_(True) if with_res else None
+    w = (torch.rand(C, device="cuda") + 0.5).requires_grad_(True)
+    b = (torch.randn(C, device="cuda") * (2.0 if act == 2 else 0.3)).requires_grad_(True)
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    rm_r, rv_r = rm.clone(), rv.clone()
+    y = hip.batch_norm_act(x, w, b, rm, rv, True, 0.1, 1e-5, act, res)
+    xr = x.detach().clone().requires_grad_(True)
+    rr = res.detach().clone().requires_grad_(True) if with_res else None
+    wr, br = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    yr = _reference(xr, rr, wr, br, rm_r, rv_r, True, 0.1, 1e-5, act)
+    lo = dtype == torch.bfloat16
+    assert y.dtype == dtype
+    assert (y.float() - yr).abs().max().item() <= (6e-2 if lo else 2e-5)
+    assert torch.allclose(rm, rm_r, atol=1e-5) and torch.allclose(rv, rv_r, rtol=1e-4, atol=1e-5)
+    g = torch.randn(shape, device="cuda").to(dtype)
+    y.backward(g)
+    yr.backward(g.float())
+    n = N * H * W
+    scale = max(1.0, n ** 0.5)
+    tol_x = 8e-2 if lo else 2e-4
+    # elements whose pre-activation is within rounding distance of the kink may take the other branch in bf16
+    dxd = (x.grad.float() - xr.grad.float()).abs()
+    if lo:
+        assert (dxd > tol_x).float().mean().item() < 5e-3
+    else:
+        assert dxd.max().item() <= tol_x
+    assert (w.grad - wr.grad).abs().max().item() <= (0.05 * scale if lo else 2e-3)
+    assert (b.grad - br.grad).abs().max().item() <= (0.05 * scale if lo else 2e-3)
+    if with_res:
+        d = (res.grad.float() - rr.grad.float()).abs()
+        assert (d > 1e-6).float().mean().item() < (5e-3 if lo else 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_inference_uses_running_stats(hip, dtype):
+    torch.manual_seed(3)
+    x = torch.randn(3, 12, 10, 16, device="cuda").to(dtype)
+    w, b = torch.rand(12, device="cuda") + 0.5, torch.randn(12, device="cuda")
+    rm, rv = torch.randn(12, device="cuda"), torch.rand(12, device="cuda") + 0.2
+    rm0, rv0 = rm.clone(), rv.clone()
+    y = hip.batch_norm_act(x, w, b, rm, rv, False, 0.1, 1e-5, 1)
+    yr = F.relu(F.batch_norm(x.float(), rm0, rv0, w, b, False, 0.1, 1e-5))
+    assert torch.equal(rm, rm0) and torch.equal(rv, rv0)
+    assert (y.float() - yr).abs().max().item() <= (5e-2 if dtype == torch.bfloat16 else 2e-5)
+
+
+def test_bn_rejects_cpu_and_bad_layout(hip):
+    x = torch.randn(2, 4, 8, 8)
+    w = torch.ones(4)
+    with pytest.raises(hip.AadgError):
+        hip.batch_norm_act(x, w, w, w.clone(), w.clone(), True, 0.1, 1e-5)
+    xc = torch.randn(2, 4, 8, 8, device="cuda").permute(0, 1, 3, 2)
+    wc = w.cuda()
+    with pytest.raises(hip.AadgError):
+        hip.batch_norm_act(xc, wc, wc, wc.clone(), wc.clone(), True, 0.1, 1e-5)
+
+
+@pytest.mark.parametrize("encoder", ["resnet50", "mobilenet_v2"])
+def test_backbone_fused_bn_matches_module_path(hip, encoder):
+    """The same DeepLabV3+ with bn_act forced onto the nn.Module path gives the same logits / gradients (fp32)."""
+    from aadg_amd.models import deeplab
+    torch.manual_seed(5)
+    m = deeplab.DeepLabV3Plus(encoder, 2).cuda().train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    x = torch.randn(4, 3, 64, 64, device="cuda")
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def run():
+        m.load_state_dict(state)
+        m.zero_grad(set_to_none=True)
+        y, f = m(x)
+        (y.square().mean() + f.square().mean()).backward()
+        return y.detach(), f.detach(), m.classifier.weight.grad.clone(), m.encoder_first_grad()
+
+    m.encoder_first_grad = lambda: next(m.encoder.parameters()).grad.clone()
+    y1, f1, gc1, ge1 = run()
+    rm1 = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+    saved = deeplab.bn_act
+
+    def module_path(bn, t, act=None, residual=None):
+        y = bn(t)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if act == "relu" else (F.relu6(y) if act == "relu6" else y)
+
+    deeplab.bn_act = module_path
+    try:
+        y2, f2, gc2, ge2 = run()
+    finally:
+        deeplab.bn_act = saved
+    rm2 = {k: v for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+    assert (y1 - y2).abs().max().item() <= 2e-3 * max(1.0, y2.abs().max().item())
+    assert (f1 - f2).abs().max().item() <= 2e-3 * max(1.0, f2.abs().max().item())
+    assert (gc1 - gc2).abs().max().item() <= 2e-3 * max(1e-3, gc2.abs().max().item())
+    assert (ge1 - ge2).abs().max().item() <= 2e-2 * max(1e-3, ge2.abs().max().item())
+    for k in rm1:
+        assert torch.allclose(rm1[k].float(), rm2[k].float(), rtol=1e-3, atol=1e-4), k
