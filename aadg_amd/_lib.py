@@ -35,6 +35,7 @@ EXPORTS = [
     "aadg_fop_workspace_bytes", "aadg_fop_f32",
     "aadg_upsample_bilinear2d",
     "aadg_bn_workspace_bytes", "aadg_bn_forward", "aadg_bn_backward",
+    "aadg_dwconv3x3_supported", "aadg_dwconv3x3_workspace_bytes", "aadg_dwconv3x3", "aadg_dwconv3x3_wgrad",
 ]
 
 _lib = None
@@ -87,6 +88,14 @@ def load():
     lib.aadg_bn_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]
     lib.aadg_bn_backward.restype = _i
     lib.aadg_bn_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]
+    lib.aadg_dwconv3x3_supported.restype = _i
+    lib.aadg_dwconv3x3_supported.argtypes = [_i, _i, _i, _i]
+    lib.aadg_dwconv3x3_workspace_bytes.restype = _sz
+    lib.aadg_dwconv3x3_workspace_bytes.argtypes = [_i]
+    lib.aadg_dwconv3x3.restype = _i
+    lib.aadg_dwconv3x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]
+    lib.aadg_dwconv3x3_wgrad.restype = _i
+    lib.aadg_dwconv3x3_wgrad.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]
     if lib.aadg_abi_version() != 1:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
@@ -506,3 +515,57 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
                              None, None, ws.data_ptr(), ws.numel(), _stream())
     _check(rc, "aadg_bn_forward")
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+class _DepthwiseConv3x3(torch.autograd.Function):
+    """F.conv2d(x, weight, stride=1, padding=d, dilation=d, groups=C) with the HIP kernels (csrc/depthwise.hip).
+    `weight` is the float32 master copy [C,1,3,3]; activations float32 or bfloat16."""
+
+    @staticmethod
+    def forward(ctx, x, weight, dilation):
+        lib = load()
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        rc = lib.aadg_dwconv3x3(x.data_ptr(), weight.data_ptr(), y.data_ptr(), N, C, H, W, dilation, 0,
+                                _BN_DTYPES[x.dtype], _stream())
+        _check(rc, "aadg_dwconv3x3")
+        ctx.dilation = dilation
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load()
+        x, weight = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            rc = lib.aadg_dwconv3x3(dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), N, C, H, W, ctx.dilation, 1,
+                                    _BN_DTYPES[x.dtype], _stream())
+            _check(rc, "aadg_dwconv3x3(flip)")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            ws = _bn_ws(C, x.device)
+            need = lib.aadg_dwconv3x3_workspace_bytes(C)
+            if ws.numel() < need:
+                ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+            rc = lib.aadg_dwconv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, C, H, W, ctx.dilation,
+                                          _BN_DTYPES[x.dtype], ws.data_ptr(), ws.numel(), _stream())
+            _check(rc, "aadg_dwconv3x3_wgrad")
+        return dx, dw, None
+
+
+def dwconv3x3_supported(x, weight, dilation):
+    return (x.is_cuda and x.dim() == 4 and x.dtype in _BN_DTYPES and x.is_contiguous() and weight.dtype == torch.float32 and
+            weight.is_contiguous() and tuple(weight.shape) == (x.shape[1], 1, 3, 3) and
+            bool(load().aadg_dwconv3x3_supported(x.shape[2], x.shape[3], int(dilation), _BN_DTYPES[x.dtype])))
+
+
+def dwconv3x3(x, weight, dilation=1):
+    _require_cuda(x, weight)
+    if not dwconv3x3_supported(x, weight, dilation):
+        raise AadgError("dwconv3x3: unsupported shape / dtype / layout")
+    return _DepthwiseConv3x3.apply(x, weight, int(dilation))

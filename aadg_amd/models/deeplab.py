@@ -67,11 +67,26 @@ def _bn_relu(c):
     return [BNAct(c, 'relu')]
 
 
+class DepthwiseConv3x3(nn.Conv2d):
+    """groups = channels 3x3 convolution; stride 1 with 'same' padding runs as the HIP LDS-tiled kernel on the GPU
+    (csrc/depthwise.hip: float32 master weights, no cast kernel), anything else takes nn.Conv2d's path."""
+
+    def __init__(self, c, stride=1, dilation=1):
+        super().__init__(c, c, 3, stride=stride, padding=dilation, dilation=dilation, groups=c, bias=False)
+
+    def forward(self, x):
+        if x.is_cuda and self.stride == (1, 1):
+            from .. import _lib
+            xc = x.contiguous()
+            if _lib.dwconv3x3_supported(xc, self.weight, self.dilation[0]):
+                return _lib.dwconv3x3(xc, self.weight, self.dilation[0])
+        return super().forward(x)
+
+
 class SeparableConv2d(nn.Sequential):
     def __init__(self, cin, cout, k=3, dilation=1):
-        pad = dilation * (k // 2)
-        super().__init__(nn.Conv2d(cin, cin, k, padding=pad, dilation=dilation, groups=cin, bias=False),
-                         nn.Conv2d(cin, cout, 1, bias=False))
+        assert k == 3
+        super().__init__(DepthwiseConv3x3(cin, dilation=dilation), nn.Conv2d(cin, cout, 1, bias=False))
 
 
 # ---------------------------------------------------------------------------------------------- ResNet-50
@@ -135,7 +150,7 @@ class InvertedResidual(nn.Module):
         layers = []
         if expand != 1:
             layers += [nn.Conv2d(cin, hid, 1, bias=False), BNAct(hid, 'relu6')]
-        layers += [nn.Conv2d(hid, hid, 3, stride, dilation, dilation=dilation, groups=hid, bias=False), BNAct(hid, 'relu6'),
+        layers += [DepthwiseConv3x3(hid, stride, dilation), BNAct(hid, 'relu6'),
                    nn.Conv2d(hid, cout, 1, bias=False), BNAct(cout, None)]
         self.conv = nn.Sequential(*layers)
 
@@ -186,7 +201,8 @@ class ASPP(nn.Module):
 
     def forward(self, x):
         outs = [b(x) for b in self.branches]
-        outs.append(F.interpolate(self.image_pool(x), size=x.shape[-2:], mode='bilinear', align_corners=False))
+        # bilinear up-sampling of a 1x1 map is a broadcast (ATen's kernel would walk all N*C planes in one workgroup)
+        outs.append(self.image_pool(x).expand(-1, -1, x.shape[-2], x.shape[-1]))
         return self.project(torch.cat(outs, dim=1))
 
 

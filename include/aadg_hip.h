@@ -186,6 +186,21 @@ int aadg_bn_backward(const void* x, const void* y, const void* dy, const float* 
                      float* dweight, float* dbias, int N, int C, int HW, int dtype, void* ws, size_t ws_bytes,
                      void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Depthwise 3x3 convolution, stride 1, padding = dilation, no bias, NCHW planes (the atrous separable convolutions
+ * of the DeepLabV3+ head: smp's SeparableConv2d / ASPPSeparableConv built at models/__init__.py:17-23).
+ * x, y: [N, C, H, W] float32 (dtype 0) or bfloat16 (dtype 1); weight: float32 [C, 3, 3].
+ * flip = 1 applies the kernel rotated by 180 degrees: dx = aadg_dwconv3x3(dy, weight, flip = 1).
+ * aadg_dwconv3x3_wgrad: dweight[c, a, b] = sum_{n, i, j} dy[n, c, i, j] * x[n, c, i + (a-1)d, j + (b-1)d].
+ * Supported: W <= 256, W a multiple of the 16-byte vector (4 / 8 elements), (rows + halo) * W * 4 <= 64 KiB.
+ * ------------------------------------------------------------------------------------------- */
+int aadg_dwconv3x3_supported(int H, int W, int dilation, int dtype);
+size_t aadg_dwconv3x3_workspace_bytes(int C);
+int aadg_dwconv3x3(const void* x, const float* weight, void* y, int N, int C, int H, int W, int dilation, int flip,
+                   int dtype, void* stream);
+int aadg_dwconv3x3_wgrad(const void* x, const void* dy, float* dweight, int N, int C, int H, int W, int dilation,
+                         int dtype, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
