@@ -36,6 +36,7 @@ EXPORTS = [
     "aadg_upsample_bilinear2d",
     "aadg_bn_workspace_bytes", "aadg_bn_forward", "aadg_bn_backward",
     "aadg_dwconv3x3_supported", "aadg_dwconv3x3_workspace_bytes", "aadg_dwconv3x3", "aadg_dwconv3x3_wgrad",
+    "aadg_maxpool3x3s2_supported", "aadg_maxpool3x3s2_forward", "aadg_maxpool3x3s2_backward",
 ]
 
 _lib = None
@@ -96,6 +97,12 @@ def load():
     lib.aadg_dwconv3x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]
     lib.aadg_dwconv3x3_wgrad.restype = _i
     lib.aadg_dwconv3x3_wgrad.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]
+    lib.aadg_maxpool3x3s2_supported.restype = _i
+    lib.aadg_maxpool3x3s2_supported.argtypes = [_i, _i]
+    lib.aadg_maxpool3x3s2_forward.restype = _i
+    lib.aadg_maxpool3x3s2_forward.argtypes = [_vp, _vp, _i, _i, _i, _i, _vp]
+    lib.aadg_maxpool3x3s2_backward.restype = _i
+    lib.aadg_maxpool3x3s2_backward.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp]
     if lib.aadg_abi_version() != 1:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
@@ -569,3 +576,41 @@ def dwconv3x3(x, weight, dilation=1):
     if not dwconv3x3_supported(x, weight, dilation):
         raise AadgError("dwconv3x3: unsupported shape / dtype / layout")
     return _DepthwiseConv3x3.apply(x, weight, int(dilation))
+
+
+# ------------------------------------------------------------------------------------------------
+class _MaxPool3x3s2(torch.autograd.Function):
+    """F.max_pool2d(x, 3, 2, 1) with the HIP kernels (csrc/maxpool.hip); the backward re-derives the arg-max from x."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = load()
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, (H - 1) // 2 + 1, W // 2), dtype=x.dtype, device=x.device)
+        rc = lib.aadg_maxpool3x3s2_forward(x.data_ptr(), y.data_ptr(), N * C, H, W, _BN_DTYPES[x.dtype], _stream())
+        _check(rc, "aadg_maxpool3x3s2_forward")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load()
+        x, = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        rc = lib.aadg_maxpool3x3s2_backward(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), N * C, H, W, _BN_DTYPES[x.dtype], _stream())
+        _check(rc, "aadg_maxpool3x3s2_backward")
+        return dx
+
+
+def maxpool3x3s2_supported(x):
+    return (x.is_cuda and x.dim() == 4 and x.dtype in _BN_DTYPES and x.is_contiguous() and
+            bool(load().aadg_maxpool3x3s2_supported(x.shape[2], x.shape[3])))
+
+
+def maxpool3x3s2(x):
+    _require_cuda(x)
+    if not maxpool3x3s2_supported(x):
+        raise AadgError("maxpool3x3s2: unsupported shape / dtype / layout")
+    return _MaxPool3x3s2.apply(x)

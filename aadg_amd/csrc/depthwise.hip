@@ -59,32 +59,42 @@ template <> struct Elem<__hip_bfloat16> {
     }
 };
 
+constexpr int DW_MAX_PP = 16;    // planes per workgroup when a whole plane is one tile
+
 struct DwGeom {
     int H, W, d, TH, tiles;     // tile = TH rows x full width; tiles per plane
+    int PP;                     // planes per workgroup (> 1 only when tiles == 1)
     int w4, rows_per_pass;      // W / 4 lanes per row; rows covered by one pass of the workgroup
-    int lds_rows;               // rows staged (TH + 2d, clipped to H)
+    int lds_rows;               // rows staged per plane (TH + 2d, clipped to H)
 };
 inline bool dw_geom(int H, int W, int d, int elems_per_vec, DwGeom* g) {
     if (H <= 0 || W <= 0 || d <= 0 || W > 256 || (W % elems_per_vec) != 0) return false;
     g->H = H; g->W = W; g->d = d;
-    int th = 2048 / W;
-    if (th < 8) th = 8;
+    int th = 8192 / W;                                   // ~8 output quads per lane
+    while (th > 8 && (size_t)(th + 2 * d < H ? th + 2 * d : H) * W * sizeof(float) > 48 * 1024) th /= 2;
     if (th > H) th = H;
     g->TH = th;
     g->tiles = (H + th - 1) / th;
+    g->PP = 1;
+    if (g->tiles == 1) {
+        int pp = 8192 / (H * W);
+        if (pp > DW_MAX_PP) pp = DW_MAX_PP;
+        if (pp < 1) pp = 1;
+        g->PP = pp;
+    }
     g->w4 = W / 4;
     g->rows_per_pass = 256 / g->w4;
     const int need = th + 2 * d;
     g->lds_rows = need < H ? need : H;
-    return (size_t)g->lds_rows * W * sizeof(float) <= 64 * 1024;
+    return (size_t)g->PP * g->lds_rows * W * sizeof(float) <= 64 * 1024;
 }
 
-// stage rows [R0, R1) of the plane into LDS as float (full rows are contiguous in memory: flat 16-byte loads)
+// stage `count` contiguous elements (a multiple of the 16-byte vector) into LDS as float
 template <typename T>
-__device__ __forceinline__ void stage_rows(const T* __restrict__ plane, int W, int R0, int R1, float* L) {
+__device__ __forceinline__ void stage_flat(const T* __restrict__ src, int count, float* L) {
     constexpr int V = Elem<T>::V;
-    const int nvec = (R1 - R0) * W / V;
-    const T* src = plane + (size_t)R0 * W;
+    const int nvec = count / V;
+#pragma unroll 4
     for (int i = threadIdx.x; i < nvec; i += 256) {
         float v[V];
         Elem<T>::load16(src + (size_t)i * V, v);
@@ -93,51 +103,98 @@ __device__ __forceinline__ void stage_rows(const T* __restrict__ plane, int W, i
     }
 }
 
-// grid: planes * tiles.  flip = 1 applies the kernel rotated by 180 degrees (gradient w.r.t. the input).
+// the 12 inputs of one staged row that the 4 outputs at columns j0..j0+3 see: tap b of output t = in[b][t]
+// (zero outside the row).  d == 1 and d % 4 == 0 (the ASPP rates) use 16-byte LDS reads.
+__device__ __forceinline__ void dw_row_taps(const float* row, int W, int d, int j0, float in[3][4]) {
+    if (d == 1) {
+        const float4 m = *reinterpret_cast<const float4*>(row + j0);
+        const float l = j0 > 0 ? row[j0 - 1] : 0.0f, r = j0 + 4 < W ? row[j0 + 4] : 0.0f;
+        in[0][0] = l;   in[0][1] = m.x; in[0][2] = m.y; in[0][3] = m.z;
+        in[1][0] = m.x; in[1][1] = m.y; in[1][2] = m.z; in[1][3] = m.w;
+        in[2][0] = m.y; in[2][1] = m.z; in[2][2] = m.w; in[2][3] = r;
+    } else if ((d & 3) == 0) {          // a shifted quad is entirely inside or entirely outside the row
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int cj = j0 + (b - 1) * d;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cj >= 0 && cj < W) v = *reinterpret_cast<const float4*>(row + cj);
+            in[b][0] = v.x; in[b][1] = v.y; in[b][2] = v.z; in[b][3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int cj = j0 + (b - 1) * d;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) in[b][t] = (cj + t >= 0 && cj + t < W) ? row[cj + t] : 0.0f;
+        }
+    }
+}
+
+// 4 outputs of row i (columns j0..j0+3) of one plane from its staged rows (row R0 of the plane at L)
+__device__ __forceinline__ void dw_quad(const float* L, const float* k, const DwGeom& g, int R0, int i, int j0, float* acc) {
+    acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int ri = i + (a - 1) * g.d;
+        if (ri < 0 || ri >= g.H) continue;
+        float in[3][4];
+        dw_row_taps(L + (size_t)(ri - R0) * g.W, g.W, g.d, j0, in);
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = fmaf(k[a * 3 + b], in[b][t], acc[t]);
+    }
+}
+// the 3x3 products of 4 output gradients with the staged input: acc[a*3+b] += sum_t gy[t] * x[i+(a-1)d][j0+t+(b-1)d]
+__device__ __forceinline__ void dw_quad_wgrad(const float* L, const float* gy, const DwGeom& g, int R0, int i, int j0, float* acc) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int ri = i + (a - 1) * g.d;
+        if (ri < 0 || ri >= g.H) continue;
+        float in[3][4];
+        dw_row_taps(L + (size_t)(ri - R0) * g.W, g.W, g.d, j0, in);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s = fmaf(gy[t], in[b][t], s);
+            acc[a * 3 + b] += s;
+        }
+    }
+}
+
+// grid: ceil(planes / PP) * tiles.  flip = 1 applies the kernel rotated by 180 degrees (gradient w.r.t. the input).
 template <typename T>
-__global__ __launch_bounds__(256) void k_dw3x3(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, int C,
-                                               DwGeom g, int flip) {
+__global__ __launch_bounds__(256) void k_dw3x3(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, int planes,
+                                               int C, DwGeom g, int flip) {
     extern __shared__ __attribute__((aligned(16))) float L[];
-    const int plane = blockIdx.x / g.tiles, tile = blockIdx.x - plane * g.tiles;
-    const int c = plane % C;
+    __shared__ float kw[DW_MAX_PP * 9];
+    const int grp = blockIdx.x / g.tiles, tile = blockIdx.x - grp * g.tiles;
+    const int plane0 = grp * g.PP, np = min(g.PP, planes - plane0);
     const int r0 = tile * g.TH, r1 = min(g.H, r0 + g.TH);
     const int R0 = max(0, r0 - g.d), R1 = min(g.H, r1 + g.d);
-    const T* px = x + (size_t)plane * g.H * g.W;
-    stage_rows<T>(px, g.W, R0, R1, L);
-    float k[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) k[i] = w[c * 9 + (flip ? 8 - i : i)];
+    const size_t psz = (size_t)g.H * g.W;
+    // tiles == 1: the np planes are whole and adjacent in memory; else one plane, rows [R0, R1)
+    stage_flat<T>(x + (size_t)plane0 * psz + (size_t)R0 * g.W, (g.tiles == 1 ? np * g.H : R1 - R0) * g.W, L);
+    if (threadIdx.x < np * 9) {
+        const int pl = threadIdx.x / 9, i = threadIdx.x - pl * 9;
+        kw[threadIdx.x] = w[((plane0 + pl) % C) * 9 + (flip ? 8 - i : i)];
+    }
     __syncthreads();
     const int cg = threadIdx.x % g.w4, ro = threadIdx.x / g.w4;
     if (ro >= g.rows_per_pass) return;
     const int j0 = cg * 4;
-    T* py = y + (size_t)plane * g.H * g.W;
-    for (int i = r0 + ro; i < r1; i += g.rows_per_pass) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int ri = i + (a - 1) * g.d;
-            if (ri < 0 || ri >= g.H) continue;
-            const float* row = L + (size_t)(ri - R0) * g.W;
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const int cj = j0 + (b - 1) * g.d;
-                const float kv = k[a * 3 + b];
-                if (cj >= 0 && cj + 3 < g.W) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = fmaf(kv, row[cj + t], acc[t]);
-                } else if (cj + 3 >= 0 && cj < g.W) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (cj + t >= 0 && cj + t < g.W) acc[t] = fmaf(kv, row[cj + t], acc[t]);
-                }
-            }
-        }
-        Elem<T>::store4(py + (size_t)i * g.W + j0, acc);
+    const int nrows = r1 - r0, vrows = np * nrows;          // virtual rows over the planes of this workgroup
+    for (int v = ro; v < vrows; v += g.rows_per_pass) {
+        const int pl = v / nrows, i = r0 + (v - pl * nrows);
+        float acc[4];
+        dw_quad(L + (size_t)pl * psz, kw + pl * 9, g, R0, i, j0, acc);
+        Elem<T>::store4(y + (size_t)(plane0 + pl) * psz + (size_t)i * g.W + j0, acc);
     }
 }
 
-// grid (split, C): partial[c][split][9] = sum over this workgroup's (plane, tile) items of dy[i][j] * x[i+(a-1)d][j+(b-1)d]
+// grid (split, C): partial[c][split][9] = sum over this workgroup's (plane group, tile) items of
+// dy[i][j] * x[i+(a-1)d][j+(b-1)d];  with tiles == 1 an item is PP images' planes of channel c
 template <typename T>
 __global__ __launch_bounds__(256) void k_dw3x3_wgrad(const T* __restrict__ x, const T* __restrict__ dy, int N, int C, DwGeom g,
                                                      float* __restrict__ partial) {
@@ -146,42 +203,29 @@ __global__ __launch_bounds__(256) void k_dw3x3_wgrad(const T* __restrict__ x, co
     const int c = blockIdx.y, S = gridDim.x;
     const int cg = threadIdx.x % g.w4, ro = threadIdx.x / g.w4;
     const int j0 = cg * 4;
+    const size_t psz = (size_t)g.H * g.W;
     float acc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = 0.f;
-    const int items = N * g.tiles;
+    const int groups = (N + g.PP - 1) / g.PP;
+    const int items = groups * g.tiles;
     for (int q = blockIdx.x; q < items; q += S) {
-        const int n = q / g.tiles, tile = q - n * g.tiles;
-        const size_t pl = ((size_t)n * C + c) * g.H * g.W;
+        const int grp = q / g.tiles, tile = q - grp * g.tiles;
+        const int n0 = grp * g.PP, np = min(g.PP, N - n0);
         const int r0 = tile * g.TH, r1 = min(g.H, r0 + g.TH);
         const int R0 = max(0, r0 - g.d), R1 = min(g.H, r1 + g.d);
+        const int srows = R1 - R0;
         __syncthreads();                       // previous item's readers are done with L
-        stage_rows<T>(x + pl, g.W, R0, R1, L);
+        for (int pl = 0; pl < np; ++pl)        // channel c of consecutive images: planes C * psz apart
+            stage_flat<T>(x + ((size_t)(n0 + pl) * C + c) * psz + (size_t)R0 * g.W, srows * g.W, L + (size_t)pl * srows * g.W);
         __syncthreads();
         if (ro < g.rows_per_pass) {
-            for (int i = r0 + ro; i < r1; i += g.rows_per_pass) {
+            const int nrows = r1 - r0, vrows = np * nrows;
+            for (int v = ro; v < vrows; v += g.rows_per_pass) {
+                const int pl = v / nrows, i = r0 + (v - pl * nrows);
                 float gy[4];
-                Elem<T>::load4(dy + pl + (size_t)i * g.W + j0, gy);
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const int ri = i + (a - 1) * g.d;
-                    if (ri < 0 || ri >= g.H) continue;
-                    const float* row = L + (size_t)(ri - R0) * g.W;
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) {
-                        const int cj = j0 + (b - 1) * g.d;
-                        float s = 0.f;
-                        if (cj >= 0 && cj + 3 < g.W) {
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) s = fmaf(gy[t], row[cj + t], s);
-                        } else if (cj + 3 >= 0 && cj < g.W) {
-#pragma unroll
-                            for (int t = 0; t < 4; ++t)
-                                if (cj + t >= 0 && cj + t < g.W) s = fmaf(gy[t], row[cj + t], s);
-                        }
-                        acc[a * 3 + b] += s;
-                    }
-                }
+                Elem<T>::load4(dy + ((size_t)(n0 + pl) * C + c) * psz + (size_t)i * g.W + j0, gy);
+                dw_quad_wgrad(L + (size_t)pl * srows * g.W, gy, g, R0, i, j0, acc);
             }
         }
     }
@@ -209,8 +253,9 @@ template <typename T>
 int dw_forward(const T* x, const float* w, T* y, int N, int C, int H, int W, int d, int flip, hipStream_t st) {
     DwGeom g;
     if (!dw_geom(H, W, d, Elem<T>::V, &g) || (long long)N * C * g.tiles > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
-    const size_t lds = (size_t)g.lds_rows * W * sizeof(float);
-    hipLaunchKernelGGL((k_dw3x3<T>), dim3((unsigned)(N * C * g.tiles)), dim3(256), lds, st, x, w, y, C, g, flip);
+    const size_t lds = (size_t)g.PP * g.lds_rows * W * sizeof(float);
+    const int planes = N * C, groups = (planes + g.PP - 1) / g.PP;
+    hipLaunchKernelGGL((k_dw3x3<T>), dim3((unsigned)(groups * g.tiles)), dim3(256), lds, st, x, w, y, planes, C, g, flip);
     AADG_LAUNCH_CHECK();
     return 0;
 }
@@ -220,10 +265,10 @@ int dw_wgrad(const T* x, const T* dy, float* dw, int N, int C, int H, int W, int
     DwGeom g;
     if (!dw_geom(H, W, d, Elem<T>::V, &g) || C > 65535) return AADG_E_UNSUPPORTED;
     int split = (4096 + C - 1) / C;
-    const int items = N * g.tiles;
+    const int items = (N + g.PP - 1) / g.PP * g.tiles;
     if (split > items) split = items;
     if (split > DW_MAX_SPLIT) split = DW_MAX_SPLIT;
-    const size_t lds = (size_t)g.lds_rows * W * sizeof(float);
+    const size_t lds = (size_t)g.PP * g.lds_rows * W * sizeof(float);
     hipLaunchKernelGGL((k_dw3x3_wgrad<T>), dim3(split, C), dim3(256), lds, st, x, dy, N, C, g, ws);
     AADG_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_dw3x3_wgrad_final, dim3((C * 9 + 255) / 256), dim3(256), 0, st, (const float*)ws, split, C, dw);

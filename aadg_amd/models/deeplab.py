@@ -83,6 +83,21 @@ class DepthwiseConv3x3(nn.Conv2d):
         return super().forward(x)
 
 
+class MaxPool3x3s2(nn.MaxPool2d):
+    """MaxPool2d(3, 2, 1); on the GPU the HIP kernels (csrc/maxpool.hip: no index tensor, arg-max re-derived in backward)."""
+
+    def __init__(self):
+        super().__init__(3, stride=2, padding=1)
+
+    def forward(self, x):
+        if x.is_cuda:
+            from .. import _lib
+            xc = x.contiguous()
+            if _lib.maxpool3x3s2_supported(xc):
+                return _lib.maxpool3x3s2(xc)
+        return super().forward(x)
+
+
 class SeparableConv2d(nn.Sequential):
     def __init__(self, cin, cout, k=3, dilation=1):
         assert k == 3
@@ -118,7 +133,7 @@ class ResNet50Encoder(nn.Module):
     def __init__(self):
         super().__init__()
         self.stem = nn.Sequential(nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False), *_bn_relu(64))
-        self.pool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.pool = MaxPool3x3s2()
         self.cin = 64
         self.layer1 = self._stage(64, 3, 1, 1)
         self.layer2 = self._stage(128, 4, 2, 1)

@@ -201,6 +201,16 @@ int aadg_dwconv3x3(const void* x, const float* weight, void* y, int N, int C, in
 int aadg_dwconv3x3_wgrad(const void* x, const void* dy, float* dweight, int N, int C, int H, int W, int dilation,
                          int dtype, void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Max pooling 3x3, stride 2, padding 1 over NCHW planes (the ResNet stem pool of the backbone's encoder,
+ * torch.nn.MaxPool2d(3, 2, 1) semantics: padding never wins, ties -> first element in window order).
+ * x [planes, H, W] -> y [planes, (H-1)/2+1, W/2]; W a multiple of 8.  The backward takes the forward INPUT and
+ * re-derives the arg-max (no index tensor).  dtype 0 = float32, 1 = bfloat16.
+ * ------------------------------------------------------------------------------------------- */
+int aadg_maxpool3x3s2_supported(int H, int W);
+int aadg_maxpool3x3s2_forward(const void* x, void* y, int planes, int H, int W, int dtype, void* stream);
+int aadg_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int planes, int H, int W, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
