@@ -37,6 +37,7 @@ EXPORTS = [
     "aadg_bn_workspace_bytes", "aadg_bn_forward", "aadg_bn_backward",
     "aadg_dwconv3x3_supported", "aadg_dwconv3x3_workspace_bytes", "aadg_dwconv3x3", "aadg_dwconv3x3_wgrad",
     "aadg_maxpool3x3s2_supported", "aadg_maxpool3x3s2_forward", "aadg_maxpool3x3s2_backward",
+    "aadg_conv1x1_wgrad_supported", "aadg_conv1x1_wgrad_bf16",
 ]
 
 _lib = None
@@ -103,6 +104,10 @@ def load():
     lib.aadg_maxpool3x3s2_forward.argtypes = [_vp, _vp, _i, _i, _i, _i, _vp]
     lib.aadg_maxpool3x3s2_backward.restype = _i
     lib.aadg_maxpool3x3s2_backward.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp]
+    lib.aadg_conv1x1_wgrad_supported.restype = _i
+    lib.aadg_conv1x1_wgrad_supported.argtypes = [_i, _i, _i]
+    lib.aadg_conv1x1_wgrad_bf16.restype = _i
+    lib.aadg_conv1x1_wgrad_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp]
     if lib.aadg_abi_version() != 1:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
@@ -614,3 +619,55 @@ def maxpool3x3s2(x):
     if not maxpool3x3s2_supported(x):
         raise AadgError("maxpool3x3s2: unsupported shape / dtype / layout")
     return _MaxPool3x3s2.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------
+def conv1x1_wgrad(dy, x):
+    """dW [Co, Ci] float32 of a 1x1 / stride-1 convolution from NCHW bfloat16 dy [N,Co,H,W] and x [N,Ci,H,W]."""
+    lib = load()
+    _require_cuda(dy, x)
+    if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or not (dy.is_contiguous() and x.is_contiguous()):
+        raise AadgError("conv1x1_wgrad: expected contiguous NCHW bfloat16 tensors")
+    N, Co, H, W = dy.shape
+    Ci = x.shape[1]
+    if x.shape[0] != N or x.shape[2:] != dy.shape[2:]:
+        raise AadgError("conv1x1_wgrad: shape mismatch")
+    dw = torch.empty((Co, Ci), dtype=torch.float32, device=x.device)
+    rc = lib.aadg_conv1x1_wgrad_bf16(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, Co, Ci, H * W, _stream())
+    _check(rc, "aadg_conv1x1_wgrad_bf16")
+    return dw
+
+
+class _Conv1x1(torch.autograd.Function):
+    """1x1 / stride-1 convolution without bias: forward and input gradient are the library GEMMs (NCHW, no transposes),
+    the weight gradient is the MFMA kernel of csrc/conv1x1_wgrad.hip.  `weight` is the float32 master copy."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        wq = weight.to(x.dtype)
+        ctx.save_for_backward(x, wq)
+        return torch.ops.aten.convolution(x, wq, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wq = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            dw = conv1x1_wgrad(dy, x).view(wq.shape)
+        return dx, dw
+
+
+def conv1x1_supported(x, weight):
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.is_contiguous() and weight.dtype == torch.float32 and
+            bool(load().aadg_conv1x1_wgrad_supported(weight.shape[0], weight.shape[1], x.shape[2] * x.shape[3])))
+
+
+def conv1x1(x, weight):
+    _require_cuda(x, weight)
+    if not conv1x1_supported(x, weight):
+        raise AadgError("conv1x1: unsupported shape / dtype / layout")
+    return _Conv1x1.apply(x, weight)

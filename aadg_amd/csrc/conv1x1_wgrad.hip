@@ -1,0 +1,156 @@
+// Weight gradient of a 1x1 / stride-1 convolution over NCHW bfloat16 activations on the matrix cores:
+//
+//     dW[o][c] = sum_n sum_k dY[n][o][k] * X[n][c][k]          (k = pixel index, HW contiguous in both operands)
+//
+// The library path for this op transposes both activation tensors to NHWC first (two extra passes over tensors of
+// up to 1.2 GB each at N = 144 x 512 x 512) and then runs an implicit-GEMM kernel.  In NCHW both operands are already
+// K-contiguous, which is exactly the A / B fragment layout of v_mfma_f32_32x32x16_bf16 (lane = row, 8 consecutive k):
+// no transpose, no im2col.  One workgroup = one (BM x BN) tile of dW and one slice of the N*HW reduction:
+//
+//   global --16-byte loads (128 contiguous bytes per row)--> registers --> LDS (double buffered, 144-byte row pitch)
+//   LDS --ds_read_b128 fragments--> 4 x 4 MFMA 32x32x16 per wave and K-step of 64 --> float32 atomics into dW
+//
+// float32 accumulation; the split-K partials are combined with hardware float atomics (order-dependent in the last bit).
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int WG_BK = 64;                 // K elements per step (128 bytes per row)
+constexpr int WG_PITCH = WG_BK + 8;       // LDS row pitch in elements (144 bytes: conflict-free 16-byte fragment reads)
+
+// WR x WC waves, each a 64 x 64 tile of dW (2 x 2 MFMA tiles)
+template <int WR, int WC>
+__global__ __launch_bounds__(256) void k_wgrad1x1(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X,
+                                                  float* __restrict__ acc, int Co, int Ci, int HW, int tiles_n, int steps_total,
+                                                  int steps_per_block) {
+    static_assert(WR * WC == 4, "four waves per workgroup");
+    constexpr int BM = 64 * WR, BN = 64 * WC, R = BM + BN, LPT = R * 8 / 256;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];      // [2][R][WG_PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv / WC, wc = wv - wr * WC;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int s0 = blockIdx.y * steps_per_block, s1 = min(steps_total, s0 + steps_per_block);
+    if (s0 >= s1) return;
+    const int spi = HW / WG_BK;           // steps per image
+
+    // this thread's LPT (row, 16-byte chunk) slots of the staged tile; rows beyond Co / Ci read as zero
+    const uint16_t* src[LPT];
+    size_t img_stride[LPT];
+    int lds_off[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int id = tid + 256 * i, row = id >> 3, c = id & 7;
+        lds_off[i] = row * WG_PITCH + c * 8;
+        if (row < BM) {
+            const int m = m0 + row;
+            src[i] = m < Co ? dY + (size_t)m * HW + c * 8 : nullptr;
+            img_stride[i] = (size_t)Co * HW;
+        } else {
+            const int n = n0 + row - BM;
+            src[i] = n < Ci ? X + (size_t)n * HW + c * 8 : nullptr;
+            img_stride[i] = (size_t)Ci * HW;
+        }
+    }
+    uint4 stage[LPT];
+    auto fetch = [&](int step) {
+        const int n = step / spi, kk = (step - n * spi) * WG_BK;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i)
+            stage[i] = src[i] != nullptr ? *reinterpret_cast<const uint4*>(src[i] + (size_t)n * img_stride[i] + kk) : make_uint4(0, 0, 0, 0);
+    };
+
+    f32x16 d[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[mi][ni][r] = 0.0f;
+
+    const int a_row = wr * 64 + (lane & 31), b_row = BM + wc * 64 + (lane & 31), koff = (lane >> 5) * 8;
+    fetch(s0);
+    int buf = 0;
+    for (int step = s0; step < s1; ++step) {
+        uint16_t* L = lds + (size_t)buf * R * WG_PITCH;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) *reinterpret_cast<uint4*>(L + lds_off[i]) = stage[i];
+        __syncthreads();
+        if (step + 1 < s1) fetch(step + 1);              // in flight during the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < WG_BK / 16; ++ks) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                a[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(L + (a_row + 32 * mi) * WG_PITCH + ks * 16 + koff));
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                b[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(L + (b_row + 32 * ni) * WG_PITCH + ks * 16 + koff));
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], d[mi][ni], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = n0 + wc * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < Co && n < Ci) unsafeAtomicAdd(acc + (size_t)m * Ci + n, d[mi][ni][r]);
+            }
+        }
+}
+
+template <int WR, int WC>
+int launch(const uint16_t* dY, const uint16_t* X, float* acc, int N, int Co, int Ci, int HW, hipStream_t st) {
+    constexpr int BM = 64 * WR, BN = 64 * WC, R = BM + BN;
+    const int tiles_m = (Co + BM - 1) / BM, tiles_n = (Ci + BN - 1) / BN, tiles = tiles_m * tiles_n;
+    const int steps_total = N * (HW / WG_BK);
+    int split = (1024 + tiles - 1) / tiles;                  // ~4 workgroups per CU
+    if (split > steps_total / 8) split = steps_total / 8;    // >= 8 K-steps per workgroup
+    if (split < 1) split = 1;
+    if (split > 65535) split = 65535;
+    const int steps_per_block = (steps_total + split - 1) / split;
+    split = (steps_total + steps_per_block - 1) / steps_per_block;
+    const size_t lds = (size_t)2 * R * WG_PITCH * sizeof(uint16_t);
+    static bool attr_set = false;                            // per instantiation; idempotent
+    if (!attr_set) {
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad1x1<WR, WC>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    AADG_HIP_TRY(hipMemsetAsync(acc, 0, (size_t)Co * Ci * sizeof(float), st));
+    hipLaunchKernelGGL((k_wgrad1x1<WR, WC>), dim3(tiles, split), dim3(256), lds, st, dY, X, acc, Co, Ci, HW, tiles_n, steps_total,
+                       steps_per_block);
+    AADG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int aadg_conv1x1_wgrad_supported(int Co, int Ci, int HW) {
+    return Co > 0 && Ci > 0 && HW >= WG_BK && (HW % WG_BK) == 0 ? 1 : 0;
+}
+
+extern "C" int aadg_conv1x1_wgrad_bf16(const void* dy, const void* x, float* dweight, int N, int Co, int Ci, int HW, void* stream) {
+    if (dy == nullptr || x == nullptr || dweight == nullptr || N <= 0) return AADG_E_BADARG;
+    if ((((uintptr_t)dy | (uintptr_t)x) & 15u) != 0) return AADG_E_BADARG;
+    if (!aadg_conv1x1_wgrad_supported(Co, Ci, HW) || (long long)N * (HW / WG_BK) > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const uint16_t* a = (const uint16_t*)dy;
+    const uint16_t* b = (const uint16_t*)x;
+    if (Co <= 64) return launch<1, 4>(a, b, dweight, N, Co, Ci, HW, st);
+    if (Ci <= 64) return launch<4, 1>(a, b, dweight, N, Co, Ci, HW, st);
+    return launch<2, 2>(a, b, dweight, N, Co, Ci, HW, st);
+}

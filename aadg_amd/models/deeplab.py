@@ -83,6 +83,23 @@ class DepthwiseConv3x3(nn.Conv2d):
         return super().forward(x)
 
 
+class Conv1x1(nn.Conv2d):
+    """Pointwise convolution without bias.  bfloat16 activations on the GPU: forward / input gradient stay the library
+    GEMMs on NCHW, the weight gradient runs on the matrix cores straight from the NCHW tensors
+    (csrc/conv1x1_wgrad.hip) instead of transposing both activations to NHWC first."""
+
+    def __init__(self, cin, cout, stride=1):
+        super().__init__(cin, cout, 1, stride=stride, bias=False)
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.bfloat16 and self.stride == (1, 1):
+            from .. import _lib
+            xc = x.contiguous()
+            if _lib.conv1x1_supported(xc, self.weight):
+                return _lib.conv1x1(xc, self.weight)
+        return super().forward(x)
+
+
 class MaxPool3x3s2(nn.MaxPool2d):
     """MaxPool2d(3, 2, 1); on the GPU the HIP kernels (csrc/maxpool.hip: no index tensor, arg-max re-derived in backward)."""
 
@@ -101,7 +118,7 @@ class MaxPool3x3s2(nn.MaxPool2d):
 class SeparableConv2d(nn.Sequential):
     def __init__(self, cin, cout, k=3, dilation=1):
         assert k == 3
-        super().__init__(DepthwiseConv3x3(cin, dilation=dilation), nn.Conv2d(cin, cout, 1, bias=False))
+        super().__init__(DepthwiseConv3x3(cin, dilation=dilation), Conv1x1(cin, cout))
 
 
 # ---------------------------------------------------------------------------------------------- ResNet-50
@@ -110,11 +127,11 @@ class Bottleneck(nn.Module):
 
     def __init__(self, cin, planes, stride=1, dilation=1, downsample=None):
         super().__init__()
-        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.conv1 = Conv1x1(cin, planes)
         self.bn1 = nn.BatchNorm2d(planes)
         self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
         self.bn2 = nn.BatchNorm2d(planes)
-        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.conv3 = Conv1x1(planes, planes * 4)
         self.bn3 = nn.BatchNorm2d(planes * 4)
         self.downsample = downsample
 
@@ -143,7 +160,7 @@ class ResNet50Encoder(nn.Module):
     def _stage(self, planes, blocks, stride, dilation):
         down = None
         if stride != 1 or self.cin != planes * 4:
-            down = nn.Sequential(nn.Conv2d(self.cin, planes * 4, 1, stride=stride, bias=False), BNAct(planes * 4, None))
+            down = nn.Sequential(Conv1x1(self.cin, planes * 4, stride), BNAct(planes * 4, None))
         layers = [Bottleneck(self.cin, planes, stride, dilation, down)]
         self.cin = planes * 4
         layers += [Bottleneck(self.cin, planes, 1, dilation) for _ in range(1, blocks)]
@@ -164,9 +181,9 @@ class InvertedResidual(nn.Module):
         self.use_res = stride == 1 and cin == cout
         layers = []
         if expand != 1:
-            layers += [nn.Conv2d(cin, hid, 1, bias=False), BNAct(hid, 'relu6')]
+            layers += [Conv1x1(cin, hid), BNAct(hid, 'relu6')]
         layers += [DepthwiseConv3x3(hid, stride, dilation), BNAct(hid, 'relu6'),
-                   nn.Conv2d(hid, cout, 1, bias=False), BNAct(cout, None)]
+                   Conv1x1(hid, cout), BNAct(cout, None)]
         self.conv = nn.Sequential(*layers)
 
     def forward(self, x):
@@ -192,7 +209,7 @@ class MobileNetV2Encoder(nn.Module):
                     stride_so_far *= 2
                 feats.append(InvertedResidual(cin, c, st, t, d if st == 1 else 1))
                 cin = c
-        feats.append(nn.Sequential(nn.Conv2d(cin, 1280, 1, bias=False), BNAct(1280, 'relu6')))
+        feats.append(nn.Sequential(Conv1x1(cin, 1280), BNAct(1280, 'relu6')))
         self.features = nn.Sequential(*feats)
 
     def forward(self, x):
@@ -209,10 +226,10 @@ class ASPP(nn.Module):
     def __init__(self, cin, cout=256, rates=(12, 24, 36)):
         super().__init__()
         self.branches = nn.ModuleList(
-            [nn.Sequential(nn.Conv2d(cin, cout, 1, bias=False), *_bn_relu(cout))] +
+            [nn.Sequential(Conv1x1(cin, cout), *_bn_relu(cout))] +
             [nn.Sequential(SeparableConv2d(cin, cout, 3, r), *_bn_relu(cout)) for r in rates])
-        self.image_pool = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(cin, cout, 1, bias=False), *_bn_relu(cout))
-        self.project = nn.Sequential(nn.Conv2d(cout * 5, cout, 1, bias=False), *_bn_relu(cout), nn.Dropout(0.5))
+        self.image_pool = nn.Sequential(nn.AdaptiveAvgPool2d(1), Conv1x1(cin, cout), *_bn_relu(cout))
+        self.project = nn.Sequential(Conv1x1(cout * 5, cout), *_bn_relu(cout), nn.Dropout(0.5))
 
     def forward(self, x):
         outs = [b(x) for b in self.branches]
@@ -232,7 +249,7 @@ class DeepLabV3Plus(nn.Module):
             raise NotImplementedError(encoder_name + ' has not been implemented!')
         self.feature_channels = self.encoder.out_channels
         self.aspp = nn.Sequential(ASPP(self.encoder.out_channels), SeparableConv2d(256, 256, 3), *_bn_relu(256))
-        self.skip = nn.Sequential(nn.Conv2d(self.encoder.skip_channels, 48, 1, bias=False), *_bn_relu(48))
+        self.skip = nn.Sequential(Conv1x1(self.encoder.skip_channels, 48), *_bn_relu(48))
         self.fuse = nn.Sequential(SeparableConv2d(256 + 48, 256, 3), *_bn_relu(256))
         self.classifier = nn.Conv2d(256, classes, 1)
         self.aux_pooling = aux_pooling

@@ -211,6 +211,15 @@ int aadg_maxpool3x3s2_supported(int H, int W);
 int aadg_maxpool3x3s2_forward(const void* x, void* y, int planes, int H, int W, int dtype, void* stream);
 int aadg_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int planes, int H, int W, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Weight gradient of a 1x1 / stride-1 / no-padding convolution, NCHW bfloat16 activations (the pointwise
+ * convolutions of the backbone: bottleneck conv1 / conv3, ASPP, decoder):
+ *     dweight[o][c] = sum_{n, k} dy[n][o][k] * x[n][c][k],   dy [N, Co, HW], x [N, Ci, HW], dweight float32 [Co, Ci].
+ * Runs on the matrix cores straight from the NCHW tensors (both operands are K-contiguous); HW a multiple of 64.
+ * ------------------------------------------------------------------------------------------- */
+int aadg_conv1x1_wgrad_supported(int Co, int Ci, int HW);
+int aadg_conv1x1_wgrad_bf16(const void* dy, const void* x, float* dweight, int N, int Co, int Ci, int HW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,51 @@
+"""GPU: MFMA weight-gradient kernel of the 1x1 convolutions vs a float32 reference, and the module wired to it."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,Co,Ci,H,W", [(3, 64, 64, 16, 16), (2, 256, 64, 16, 8), (2, 64, 256, 8, 8), (5, 128, 192, 16, 16),
+                                          (2, 48, 256, 32, 32), (3, 256, 304, 8, 16), (1, 2048, 512, 8, 8), (7, 20, 36, 8, 8),
+                                          (4, 130, 70, 16, 4)])
+def test_wgrad_matches_float32_reference(hip, N, Co, Ci, H, W):
+    torch.manual_seed(Co + Ci)
+    dy = torch.randn(N, Co, H, W, device="cuda").bfloat16()
+    x = (torch.randn(N, Ci, H, W, device="cuda") + torch.arange(Ci, device="cuda").view(1, Ci, 1, 1) * 0.01).bfloat16()
+    dw = hip.conv1x1_wgrad(dy, x)
+    ref = torch.einsum("nok,nck->oc", dy.float().view(N, Co, -1), x.float().view(N, Ci, -1))
+    assert dw.shape == (Co, Ci) and dw.dtype == torch.float32
+    assert (dw - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())      # float32 accumulation of exact products
+
+
+def test_wgrad_rejects_unsupported(hip):
+    dy = torch.randn(1, 8, 4, 4, device="cuda").bfloat16()          # HW = 16 < 64
+    with pytest.raises(hip.AadgError):
+        hip.conv1x1_wgrad(dy, dy)
+    with pytest.raises(hip.AadgError):
+        hip.conv1x1_wgrad(dy.float(), dy.float())
+
+
+def test_module_matches_conv2d_under_autocast(hip):
+    from aadg_amd.models.deeplab import Conv1x1
+    torch.manual_seed(2)
+    m = Conv1x1(96, 160).cuda()
+    x = torch.randn(4, 96, 16, 16, device="cuda").bfloat16().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = m(x)
+    assert y.dtype == torch.bfloat16
+    g = torch.randn_like(y)
+    y.backward(g)
+    xr = x.detach().clone().requires_grad_(True)
+    wr = m.weight.detach().clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yr = F.conv2d(xr, wr)
+    yr.backward(g)
+    assert torch.equal(y, yr)
+    assert (x.grad.float() - xr.grad.float()).abs().max().item() <= 1e-6
+    assert m.weight.grad.dtype == torch.float32
+    assert (m.weight.grad - wr.grad).abs().max().item() <= 2e-2 * wr.grad.abs().max().item()   # the reference rounds dW to bf16
+    # float32 activations (no autocast) keep the library path
+    xf = torch.randn(2, 96, 16, 16, device="cuda")
+    assert torch.allclose(m(xf), F.conv2d(xf, m.weight), atol=1e-4)
