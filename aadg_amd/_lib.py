@@ -38,6 +38,8 @@ EXPORTS = [
     "aadg_dwconv3x3_supported", "aadg_dwconv3x3_workspace_bytes", "aadg_dwconv3x3", "aadg_dwconv3x3_wgrad",
     "aadg_maxpool3x3s2_supported", "aadg_maxpool3x3s2_forward", "aadg_maxpool3x3s2_backward",
     "aadg_conv1x1_wgrad_supported", "aadg_conv1x1_wgrad_bf16",
+    "aadg_controller_supported", "aadg_controller_workspace_bytes", "aadg_controller_sample_f32",
+    "aadg_controller_ppo_update_f32",
 ]
 
 _lib = None
@@ -108,6 +110,14 @@ def load():
     lib.aadg_conv1x1_wgrad_supported.argtypes = [_i, _i, _i]
     lib.aadg_conv1x1_wgrad_bf16.restype = _i
     lib.aadg_conv1x1_wgrad_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp]
+    lib.aadg_controller_supported.restype = _i
+    lib.aadg_controller_supported.argtypes = [_i] * 7
+    lib.aadg_controller_workspace_bytes.restype = _sz
+    lib.aadg_controller_workspace_bytes.argtypes = [_i] * 7
+    lib.aadg_controller_sample_f32.restype = _i
+    lib.aadg_controller_sample_f32.argtypes = [_vp] + [_i] * 7 + [_f] + [_vp] * 7 + [_sz, _vp]
+    lib.aadg_controller_ppo_update_f32.restype = _i
+    lib.aadg_controller_ppo_update_f32.argtypes = [_vp] * 3 + [_i] * 7 + [_f] + [_vp] * 3 + [_f, _i, _i, _f, _f, _f, _f, _vp, _vp, _sz, _vp]
     if lib.aadg_abi_version() != 1:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
@@ -671,3 +681,61 @@ def conv1x1(x, weight):
     if not conv1x1_supported(x, weight):
         raise AadgError("conv1x1: unsupported shape / dtype / layout")
     return _Conv1x1.apply(x, weight)
+
+
+# ------------------------------------------------------------------------------------------------
+def _ptr_array(tensors):
+    arr = (_c.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def controller_dims(controller, M):
+    """(M, Q, S, E, H, n_ops, n_mags) of a Controller module."""
+    return (int(M), int(controller.Q), 2 * int(controller.L), int(controller.embedding_dim), int(controller.hidden_dim),
+            int(controller.NUM_OPS), int(controller.NUM_MAGS))
+
+
+def controller_supported(controller, M):
+    ps = list(controller.parameters())
+    return (len(ps) == 9 and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps) and
+            bool(load().aadg_controller_supported(*controller_dims(controller, M))))
+
+
+def controller_workspace(controller, M):
+    need = load().aadg_controller_workspace_bytes(*controller_dims(controller, M))
+    return torch.zeros(need, dtype=torch.uint8, device=next(controller.parameters()).device)
+
+
+def controller_sample(controller, M, uniforms, ws):
+    """Fused controller.sample(M): returns (policies int64 [M, Q*2L], mean op probs, mean mag probs, log_probs, entropies)."""
+    lib = load()
+    dims = controller_dims(controller, M)
+    dev = uniforms.device
+    policies = torch.empty((M, dims[1] * dims[2]), dtype=torch.int64, device=dev)
+    op_probs = torch.empty(dims[5], dtype=torch.float32, device=dev)
+    mag_probs = torch.empty(dims[6], dtype=torch.float32, device=dev)
+    log_probs = torch.empty(M, dtype=torch.float32, device=dev)
+    entropies = torch.empty(M, dtype=torch.float32, device=dev)
+    params = _ptr_array(list(controller.parameters()))
+    rc = lib.aadg_controller_sample_f32(params, *dims, float(controller.C) / float(controller.T), uniforms.data_ptr(),
+                                        policies.data_ptr(), op_probs.data_ptr(), mag_probs.data_ptr(), log_probs.data_ptr(),
+                                        entropies.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "aadg_controller_sample_f32")
+    return policies, op_probs, mag_probs, log_probs, entropies
+
+
+def controller_ppo_update(controller, M, exp_avg, exp_avg_sq, policies, old_log_probs, reward, clip, n_updates, step0, lr,
+                          betas, eps, ws):
+    """n_updates PPO epochs (evaluate -> clipped surrogate -> backward -> Adam) in place; returns loss terms [n_updates, M]."""
+    lib = load()
+    dims = controller_dims(controller, M)
+    losses = torch.empty((n_updates, M), dtype=torch.float32, device=policies.device)
+    rc = lib.aadg_controller_ppo_update_f32(_ptr_array(list(controller.parameters())), _ptr_array(exp_avg), _ptr_array(exp_avg_sq),
+                                            *dims, float(controller.C) / float(controller.T), policies.data_ptr(),
+                                            old_log_probs.data_ptr(), reward.data_ptr(), float(clip), int(n_updates), int(step0),
+                                            float(lr), float(betas[0]), float(betas[1]), float(eps), losses.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "aadg_controller_ppo_update_f32")
+    return losses

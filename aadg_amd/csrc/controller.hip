@@ -1,0 +1,610 @@
+// The policy controller as three kernels: the reference's Controller (models/controller.py:
+// 9-145: embedding -> LSTMCell(32 -> 100) -> two tanh-squashed softmax heads, Q sub-policies x 2L decisions, state
+// reset per sub-policy) and its PPO update (losses.py:117-157: 5 x {teacher-forced evaluate, clipped surrogate, backward,
+// Adam}) are ~200 + ~5000 micro-launches in eager PyTorch and still ~1900 graph nodes when captured.  Here:
+//
+//   k_ctrl_transpose   W_ih^T, W_hh^T scratch copies (gate row = fastest index: coalesced forward reads)
+//   k_ctrl_rollout     grid M, one workgroup per policy row: its Q independent sequences run in lock-step; all
+//                      activations of the 2L steps stay in LDS.  SAMPLE: inverse-CDF draw from caller-supplied uniforms,
+//                      policies / sum log-prob / sum entropy / mean head probabilities.  UPDATE: teacher-forced
+//                      forward, PPO ratio + clipped surrogate, full BPTT; per-(sequence, step) gate / logit / input
+//                      gradients go to a scratch of R = M*Q*2L rows
+//   k_ctrl_adam        one thread per parameter: gradient = sum over the R scratch rows (a [P x R] x [R x K] product,
+//                      deterministic order), then the Adam update in place (torch.optim.Adam arithmetic) and the
+//                      refreshed transposed copies for the next epoch
+//
+// float32 throughout; same arithmetic as the eager module up to summation order.
+#include "common.h"
+
+namespace {
+
+constexpr int CT_THREADS = 512;
+constexpr int CT_MAX_Q = 8;        // sequences per workgroup (sub-policies)
+constexpr int CT_MAX_A = 16;       // actions per head
+constexpr int CT_HP = 5, CT_XP = 16;   // row ranges of the transposed products in the backward
+
+struct CtrlDims {
+    int M, Q, S, E, H, NOPS, NMAGS;
+    float cdiv;                    // C / T
+};
+struct CtrlParams {                // torch parameter order of the module
+    float* emb;   // [NOPS + NMAGS, E]
+    float* w_ih;  // [4H, E]
+    float* w_hh;  // [4H, H]
+    float* b_ih;  // [4H]
+    float* b_hh;  // [4H]
+    float* wop;   // [NOPS, H]
+    float* bop;   // [NOPS]
+    float* wmag;  // [NMAGS, H]
+    float* bmag;  // [NMAGS]
+};
+struct CtrlPtrs9 { float* p[9]; };
+
+// workspace layout (floats)
+struct CtrlWs {
+    size_t wt_ih, wt_hh;           // [E][4H], [H][4H]
+    size_t dg, dl, dx, xin, hprev, hcur, tok;   // R rows each: 4H, CT_MAX_A, E, E, H, H, 1(int)
+    size_t probs;                  // [M][2][CT_MAX_A] partial head-probability sums
+    size_t counter;                // 1 int
+    size_t total;
+};
+__host__ __device__ inline CtrlWs ctrl_ws(const CtrlDims& d) {
+    CtrlWs w;
+    const size_t R = (size_t)d.M * d.Q * d.S, H4 = 4 * (size_t)d.H;
+    size_t o = 0;
+    w.wt_ih = o; o += (size_t)d.E * H4;
+    w.wt_hh = o; o += (size_t)d.H * H4;
+    w.dg = o; o += R * H4;
+    w.dl = o; o += R * CT_MAX_A;
+    w.dx = o; o += R * d.E;
+    w.xin = o; o += R * d.E;
+    w.hprev = o; o += R * d.H;
+    w.hcur = o; o += R * d.H;
+    w.tok = o; o += R;
+    w.probs = o; o += (size_t)d.M * 2 * CT_MAX_A;
+    w.counter = o; o += 4;
+    w.total = o;
+    return w;
+}
+
+// LDS layout of k_ctrl_rollout (floats)
+struct CtrlLds {
+    size_t G, Cs, TC, Hs, X, P, TL, DL, DG, DH, DC, part, act, misc, Wh, Bh, Emb, total;
+};
+__host__ __device__ inline CtrlLds ctrl_lds(const CtrlDims& d) {
+    CtrlLds l;
+    const size_t Q = d.Q, S = d.S, H = d.H, E = d.E;
+    size_t o = 0;
+    l.G = o; o += Q * S * 4 * H;          // activated gates i, f, g, o
+    l.Cs = o; o += Q * S * H;             // cell states
+    l.TC = o; o += Q * S * H;             // tanh(c)
+    l.Hs = o; o += Q * (S + 1) * H;       // hidden states, slot 0 = zeros
+    l.X = o; o += Q * S * E;              // step inputs
+    l.P = o; o += Q * S * CT_MAX_A;       // head probabilities
+    l.TL = o; o += Q * S * CT_MAX_A;      // tanh(logits)
+    l.DL = o; o += Q * CT_MAX_A;          // d logits of the current step
+    l.DG = o; o += Q * 4 * H;             // d gate pre-activations of the current step
+    l.DH = o; o += Q * H;
+    l.DC = o; o += Q * H;
+    l.part = o; o += (CT_HP * Q * H > CT_XP * Q * E ? CT_HP * Q * H : CT_XP * Q * E);   // partial transposed products
+    l.act = o; o += Q * S;                // actions (int)
+    l.misc = o; o += 8 + 2 * CT_MAX_Q + 8;
+    l.Wh = o; o += (size_t)(d.NOPS + d.NMAGS) * H;      // head weights: op rows, then magnitude rows
+    l.Bh = o; o += 2 * CT_MAX_A;                        // head biases
+    l.Emb = o; o += (size_t)(d.NOPS + d.NMAGS) * E;     // embedding table
+    l.total = o;
+    return l;
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void k_ctrl_transpose(CtrlParams P, CtrlDims d, float* ws) {
+    const CtrlWs W = ctrl_ws(d);
+    const int H4 = 4 * d.H, n_ih = H4 * d.E, n_hh = H4 * d.H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_ih + n_hh; i += gridDim.x * blockDim.x) {
+        if (i < n_ih) {
+            const int k = i / H4, j = i - k * H4;
+            ws[W.wt_ih + i] = P.w_ih[(size_t)j * d.E + k];
+        } else {
+            const int i2 = i - n_ih, k = i2 / H4, j = i2 - k * H4;
+            ws[W.wt_hh + i2] = P.w_hh[(size_t)j * d.H + k];
+        }
+    }
+}
+
+// SAMPLE = true: draw actions from `uniforms`; false: teacher-forced on `policies`, then the PPO backward.
+template <bool SAMPLE>
+__global__ __launch_bounds__(CT_THREADS) void k_ctrl_rollout(CtrlParams P, CtrlDims d, float* ws, const float* __restrict__ uniforms,
+                                                             long long* __restrict__ policies, float* __restrict__ op_probs,
+                                                             float* __restrict__ mag_probs, float* __restrict__ log_probs,
+                                                             float* __restrict__ entropies, const float* __restrict__ old_log_probs,
+                                                             const float* __restrict__ reward, float clip,
+                                                             float* __restrict__ loss_terms) {
+    extern __shared__ __attribute__((aligned(16))) float L[];
+    const CtrlWs W = ctrl_ws(d);
+    const CtrlLds O = ctrl_lds(d);
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const int Q = d.Q, S = d.S, H = d.H, E = d.E, H4 = 4 * H;
+    float* G = L + O.G; float* Cs = L + O.Cs; float* TC = L + O.TC; float* Hs = L + O.Hs; float* X = L + O.X;
+    float* Pp = L + O.P; float* TL = L + O.TL; float* DL = L + O.DL; float* DG = L + O.DG; float* DH = L + O.DH;
+    float* DC = L + O.DC; float* part = L + O.part; int* act = reinterpret_cast<int*>(L + O.act); float* misc = L + O.misc;
+    float* Wh = L + O.Wh; float* Bh = L + O.Bh; float* Emb = L + O.Emb;
+    const float* wt_ih = ws + W.wt_ih;
+    const float* wt_hh = ws + W.wt_hh;
+    // the small tables live in LDS for the whole rollout
+    for (int i = tid; i < d.NOPS * H; i += CT_THREADS) Wh[i] = P.wop[i];
+    for (int i = tid; i < d.NMAGS * H; i += CT_THREADS) Wh[d.NOPS * H + i] = P.wmag[i];
+    for (int i = tid; i < (d.NOPS + d.NMAGS) * E; i += CT_THREADS) Emb[i] = P.emb[i];
+    if (tid < CT_MAX_A) { Bh[tid] = tid < d.NOPS ? P.bop[tid] : 0.0f; Bh[CT_MAX_A + tid] = tid < d.NMAGS ? P.bmag[tid] : 0.0f; }
+
+    for (int i = tid; i < Q * (S + 1) * H; i += CT_THREADS) Hs[i] = 0.0f;
+    for (int i = tid; i < Q * S * E; i += CT_THREADS) X[i] = 0.0f;
+    if (!SAMPLE)
+        for (int i = tid; i < Q * S; i += CT_THREADS) act[i] = (int)policies[(size_t)m * Q * S + i];
+    if (tid < 8 + 2 * CT_MAX_Q) misc[tid] = 0.0f;
+    __syncthreads();
+
+    // ---------------------------------------------------------------------------------------------- forward
+    float my_lp = 0.0f, my_ent = 0.0f;                     // threads 0..Q-1: their sequence's sum log-prob / entropy
+    for (int t = 0; t < S; ++t) {
+        const bool op_step = (t & 1) == 0;
+        const int NA = op_step ? d.NOPS : d.NMAGS;
+        if (tid < H4) {                                    // gate row `tid` of all Q sequences
+            float acc[CT_MAX_Q];
+            const float b = P.b_ih[tid] + P.b_hh[tid];
+#pragma unroll
+            for (int q = 0; q < CT_MAX_Q; ++q) acc[q] = b;
+            if (t > 0) {
+                constexpr int KB = 16;                     // weights in flight per lane
+                for (int k0 = 0; k0 < E; k0 += KB) {
+                    float w[KB];
+#pragma unroll
+                    for (int i = 0; i < KB; ++i) w[i] = k0 + i < E ? wt_ih[(size_t)(k0 + i) * H4 + tid] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < KB; ++i)
+#pragma unroll
+                        for (int q = 0; q < CT_MAX_Q; ++q)
+                            if (q < Q && k0 + i < E) acc[q] = fmaf(w[i], X[(q * S + t) * E + k0 + i], acc[q]);
+                }
+                for (int k0 = 0; k0 < H; k0 += KB) {
+                    float w[KB];
+#pragma unroll
+                    for (int i = 0; i < KB; ++i) w[i] = k0 + i < H ? wt_hh[(size_t)(k0 + i) * H4 + tid] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < KB; ++i)
+#pragma unroll
+                        for (int q = 0; q < CT_MAX_Q; ++q)
+                            if (q < Q && k0 + i < H) acc[q] = fmaf(w[i], Hs[(q * (S + 1) + t) * H + k0 + i], acc[q]);
+                }
+            }
+            const bool is_g = tid >= 2 * H && tid < 3 * H;
+#pragma unroll
+            for (int q = 0; q < CT_MAX_Q; ++q)
+                if (q < Q) G[(q * S + t) * H4 + tid] = is_g ? tanhf(acc[q]) : sigmoidf_(acc[q]);
+        }
+        __syncthreads();
+        for (int i = tid; i < Q * H; i += CT_THREADS) {    // cell / hidden update
+            const int q = i / H, u = i - q * H;
+            const float* g4 = G + (q * S + t) * H4;
+            const float c_prev = t > 0 ? Cs[(q * S + t - 1) * H + u] : 0.0f;
+            const float c = g4[H + u] * c_prev + g4[u] * g4[2 * H + u];
+            const float tc = tanhf(c);
+            Cs[(q * S + t) * H + u] = c;
+            TC[(q * S + t) * H + u] = tc;
+            Hs[(q * (S + 1) + t + 1) * H + u] = g4[3 * H + u] * tc;
+        }
+        __syncthreads();
+        {                                                  // head logits: 4 lanes per (sequence, action) output
+            const int o = tid >> 2, part = tid & 3;
+            const int q = o / NA, a = o - q * NA;
+            const bool live = q < Q;
+            float z = 0.0f;
+            if (live) {
+                const float* wrow = Wh + (size_t)((op_step ? 0 : d.NOPS) + a) * H;
+                const float* h = Hs + (q * (S + 1) + t + 1) * H;
+#pragma unroll 5
+                for (int k = part; k < H; k += 4) z = fmaf(wrow[k], h[k], z);
+            }
+            z += __shfl_xor(z, 1, 64); z += __shfl_xor(z, 2, 64);
+            if (live && part == 0) {
+                z += Bh[(op_step ? 0 : CT_MAX_A) + a];
+                const float tl = tanhf(z);
+                TL[(q * S + t) * CT_MAX_A + a] = tl;
+                Pp[(q * S + t) * CT_MAX_A + a] = d.cdiv * tl;      // squashed logit, turned into a probability below
+            }
+        }
+        __syncthreads();
+        if (tid < Q) {                                     // softmax, draw / gather, next input token
+            const int q = tid;
+            float* p = Pp + (q * S + t) * CT_MAX_A;
+            float mx = -INFINITY;
+            for (int a = 0; a < NA; ++a) mx = fmaxf(mx, p[a]);
+            float z[CT_MAX_A], sum = 0.0f;
+            for (int a = 0; a < NA; ++a) { z[a] = p[a] - mx; sum += expf(z[a]); }
+            const float lse = logf(sum);
+            float ent = 0.0f;
+            for (int a = 0; a < NA; ++a) {
+                const float lp = z[a] - lse, pr = expf(lp);
+                p[a] = pr;
+                ent -= lp * pr;
+                z[a] = lp;
+            }
+            int a_sel;
+            if (SAMPLE) {
+                const float u = uniforms[(size_t)m * Q * S + q * S + t];
+                float cum = 0.0f;
+                a_sel = NA - 1;
+                for (int a = 0; a < NA; ++a) {
+                    cum += p[a];
+                    if (u < cum) { a_sel = a; break; }
+                }
+                act[q * S + t] = a_sel;
+                policies[(size_t)m * Q * S + q * S + t] = a_sel;
+            } else {
+                a_sel = act[q * S + t];
+            }
+            my_lp += z[a_sel];                             // per-sequence sums, combined in fixed order after the loop
+            my_ent += ent;
+            if (t + 1 < S) {
+                const int tok = a_sel + (op_step ? 0 : d.NOPS);
+                for (int k = 0; k < E; ++k) X[(q * S + t + 1) * E + k] = Emb[(size_t)tok * E + k];
+            }
+        }
+        __syncthreads();
+    }
+
+    if (tid < Q) { misc[8 + tid] = my_lp; misc[8 + CT_MAX_Q + tid] = my_ent; }
+    __syncthreads();
+    if (tid == 0) {
+        float a = 0.0f, b = 0.0f;
+        for (int q = 0; q < Q; ++q) { a += misc[8 + q]; b += misc[8 + CT_MAX_Q + q]; }
+        misc[1] = a; misc[2] = b;
+    }
+    __syncthreads();
+    if (SAMPLE) {
+        if (tid == 0) { log_probs[m] = misc[1]; entropies[m] = misc[2]; }
+        // mean head probabilities over all M*Q*L rows: per-workgroup partial sums, last workgroup combines
+        float* partial = ws + W.probs + (size_t)m * 2 * CT_MAX_A;
+        if (tid < 2 * CT_MAX_A) {
+            const int head = tid / CT_MAX_A, a = tid - head * CT_MAX_A;
+            float s = 0.0f;
+            for (int q = 0; q < Q; ++q)
+                for (int t = head; t < S; t += 2) s += Pp[(q * S + t) * CT_MAX_A + a];
+            partial[tid] = (a < (head == 0 ? d.NOPS : d.NMAGS)) ? s : 0.0f;
+        }
+        __threadfence();
+        __syncthreads();
+        int* counter = reinterpret_cast<int*>(ws + W.counter);
+        __shared__ int last;
+        if (tid == 0) last = atomicAdd(counter, 1) == d.M - 1;
+        __syncthreads();
+        if (last) {
+            __threadfence();
+            if (tid < 2 * CT_MAX_A) {
+                const int head = tid / CT_MAX_A, a = tid - head * CT_MAX_A;
+                float s = 0.0f;
+                for (int mm = 0; mm < d.M; ++mm) s += ws[W.probs + (size_t)mm * 2 * CT_MAX_A + tid];
+                const float inv = 1.0f / (float)(d.M * Q * (S / 2));
+                if (head == 0 && a < d.NOPS) op_probs[a] = s * inv;
+                if (head == 1 && a < d.NMAGS) mag_probs[a] = s * inv;
+            }
+            if (tid == 0) *counter = 0;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------- PPO surrogate
+    if (tid == 0) {
+        const float lp = misc[1];
+        const float ratio = expf(lp - old_log_probs[m]);
+        const float clipped = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+        const float r = reward[m];
+        const float a = ratio * r, b = clipped * r;
+        loss_terms[m] = -fminf(a, b);                      // the caller averages over M
+        // d(-min(a, b))/d lp: through a when a <= b (ties: both halves reach `ratio` because clamp is then the identity)
+        const bool inside = ratio >= 1.0f - clip && ratio <= 1.0f + clip;
+        float g = 0.0f;
+        if (a < b || (a == b && inside)) g = -r * ratio;
+        else if (a == b && !inside) g = -0.5f * r * ratio;
+        misc[3] = g / (float)d.M;
+    }
+    for (int i = tid; i < Q * H; i += CT_THREADS) { DH[i] = 0.0f; DC[i] = 0.0f; }
+    __syncthreads();
+    const float gl = misc[3];
+
+    // ---------------------------------------------------------------------------------------------- backward
+    for (int t = S - 1; t >= 0; --t) {
+        const bool op_step = (t & 1) == 0;
+        const int NA = op_step ? d.NOPS : d.NMAGS;
+        if (tid < Q * CT_MAX_A) {                          // d logits
+            const int q = tid / CT_MAX_A, a = tid - q * CT_MAX_A;
+            const size_t r = ((size_t)m * Q + q) * S + t;
+            float dl = 0.0f;
+            if (a < NA) {
+                const float p = Pp[(q * S + t) * CT_MAX_A + a], tl = TL[(q * S + t) * CT_MAX_A + a];
+                const float dz = gl * ((a == act[q * S + t] ? 1.0f : 0.0f) - p);
+                dl = dz * d.cdiv * (1.0f - tl * tl);
+            }
+            DL[q * CT_MAX_A + a] = dl;
+            ws[W.dl + r * CT_MAX_A + a] = dl;
+        }
+        __syncthreads();
+        for (int i = tid; i < Q * H; i += CT_THREADS) {    // through the head and the cell
+            const int q = i / H, u = i - q * H;
+            const size_t r = ((size_t)m * Q + q) * S + t;
+            const float* wh = Wh + (size_t)(op_step ? 0 : d.NOPS) * H;
+            float dh = DH[i];
+            for (int a = 0; a < NA; ++a) dh = fmaf(wh[(size_t)a * H + u], DL[q * CT_MAX_A + a], dh);
+            const float* g4 = G + (q * S + t) * H4;
+            const float ig = g4[u], fg = g4[H + u], gg = g4[2 * H + u], og = g4[3 * H + u];
+            const float tc = TC[(q * S + t) * H + u];
+            const float c_prev = t > 0 ? Cs[(q * S + t - 1) * H + u] : 0.0f;
+            const float d_o = dh * tc;
+            const float dc = dh * og * (1.0f - tc * tc) + DC[i];
+            DC[i] = dc * fg;
+            const float dgi = dc * gg * ig * (1.0f - ig);
+            const float dgf = dc * c_prev * fg * (1.0f - fg);
+            const float dgg = dc * ig * (1.0f - gg * gg);
+            const float dgo = d_o * og * (1.0f - og);
+            DG[q * H4 + u] = dgi; DG[q * H4 + H + u] = dgf; DG[q * H4 + 2 * H + u] = dgg; DG[q * H4 + 3 * H + u] = dgo;
+            float* dgr = ws + W.dg + r * H4;
+            dgr[u] = dgi; dgr[H + u] = dgf; dgr[2 * H + u] = dgg; dgr[3 * H + u] = dgo;
+            ws[W.hprev + r * H + u] = Hs[(q * (S + 1) + t) * H + u];
+            ws[W.hcur + r * H + u] = Hs[(q * (S + 1) + t + 1) * H + u];
+        }
+        for (int i = tid; i < Q * E; i += CT_THREADS) {    // the step input (for dW_ih)
+            const int q = i / E, k = i - q * E;
+            const size_t r = ((size_t)m * Q + q) * S + t;
+            ws[W.xin + r * E + k] = X[(q * S + t) * E + k];
+        }
+        if (tid < Q) {
+            const size_t r = ((size_t)m * Q + tid) * S + t;
+            // token whose embedding was this step's input (-1: the zero input of the first step)
+            reinterpret_cast<int*>(ws + W.tok)[r] = t > 0 ? act[tid * S + t - 1] + (((t - 1) & 1) == 0 ? 0 : d.NOPS) : -1;
+        }
+        __syncthreads();
+        if (t > 0) {
+            // dh_{t-1} = W_hh^T dgates: CT_HP row ranges x H columns (reads of W_hh are contiguous over the column index)
+            for (int i = tid; i < CT_HP * H; i += CT_THREADS) {
+                const int pr = i / H, k = i - pr * H;
+                const int j0 = pr * H4 / CT_HP, j1 = (pr + 1) * H4 / CT_HP;
+                float acc[CT_MAX_Q];
+#pragma unroll
+                for (int q = 0; q < CT_MAX_Q; ++q) acc[q] = 0.0f;
+                constexpr int JB = 16;
+                for (int jb = j0; jb < j1; jb += JB) {
+                    float w[JB];
+#pragma unroll
+                    for (int i = 0; i < JB; ++i) w[i] = jb + i < j1 ? P.w_hh[(size_t)(jb + i) * H + k] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < JB; ++i)
+#pragma unroll
+                        for (int q = 0; q < CT_MAX_Q; ++q)
+                            if (q < Q && jb + i < j1) acc[q] = fmaf(w[i], DG[q * H4 + jb + i], acc[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < CT_MAX_Q; ++q)
+                    if (q < Q) part[(pr * Q + q) * H + k] = acc[q];
+            }
+            __syncthreads();
+            for (int i = tid; i < Q * H; i += CT_THREADS) {
+                const int q = i / H, k = i - q * H;
+                float s = 0.0f;
+                for (int pr = 0; pr < CT_HP; ++pr) s += part[(pr * Q + q) * H + k];
+                DH[i] = s;
+            }
+            __syncthreads();
+            // dx_t = W_ih^T dgates -> gradient of the embedding row that fed this step: CT_XP row ranges x E columns
+            for (int i = tid; i < CT_XP * E; i += CT_THREADS) {
+                const int pr = i / E, k = i - pr * E;
+                const int j0 = pr * H4 / CT_XP, j1 = (pr + 1) * H4 / CT_XP;
+                float acc[CT_MAX_Q];
+#pragma unroll
+                for (int q = 0; q < CT_MAX_Q; ++q) acc[q] = 0.0f;
+                constexpr int JB = 25;
+                for (int jb = j0; jb < j1; jb += JB) {
+                    float w[JB];
+#pragma unroll
+                    for (int i = 0; i < JB; ++i) w[i] = jb + i < j1 ? P.w_ih[(size_t)(jb + i) * E + k] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < JB; ++i)
+#pragma unroll
+                        for (int q = 0; q < CT_MAX_Q; ++q)
+                            if (q < Q && jb + i < j1) acc[q] = fmaf(w[i], DG[q * H4 + jb + i], acc[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < CT_MAX_Q; ++q)
+                    if (q < Q) part[(pr * Q + q) * E + k] = acc[q];
+            }
+            __syncthreads();
+            for (int i = tid; i < Q * E; i += CT_THREADS) {
+                const int q = i / E, k = i - q * E;
+                const size_t r = ((size_t)m * Q + q) * S + t;
+                float s = 0.0f;
+                for (int pr = 0; pr < CT_XP; ++pr) s += part[(pr * Q + q) * E + k];
+                ws[W.dx + r * E + k] = s;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// sum_r a[r * sa] * b[r * sb] with 12 row pairs in flight
+__device__ __forceinline__ float dot_rows(const float* __restrict__ a, int sa, const float* __restrict__ b, int sb, int R) {
+    constexpr int RB = 12;
+    float g = 0.0f;
+    for (int r0 = 0; r0 < R; r0 += RB) {
+        float x[RB], y[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const bool in = r0 + i < R;
+            x[i] = in ? a[(size_t)(r0 + i) * sa] : 0.0f;
+            y[i] = in ? b[(size_t)(r0 + i) * sb] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) g = fmaf(x[i], y[i], g);
+    }
+    return g;
+}
+
+// one thread per parameter element: gradient from the R scratch rows, then Adam in place
+__global__ __launch_bounds__(256) void k_ctrl_adam(CtrlParams P, CtrlPtrs9 exp_avg, CtrlPtrs9 exp_avg_sq, CtrlDims d, float* ws,
+                                                   float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
+    const CtrlWs W = ctrl_ws(d);
+    const int H4 = 4 * d.H, NT = d.NOPS + d.NMAGS, R = d.M * d.Q * d.S;
+    const int sizes[9] = {NT * d.E, H4 * d.E, H4 * d.H, H4, H4, d.NOPS * d.H, d.NOPS, d.NMAGS * d.H, d.NMAGS};
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int which = 0;
+    while (which < 9 && idx >= sizes[which]) { idx -= sizes[which]; ++which; }
+    if (which >= 9) return;
+    const float* dg = ws + W.dg;
+    const float* dl = ws + W.dl;
+    float g = 0.0f;
+    float* param;
+    switch (which) {
+        case 0: {                                          // embedding[row][k]
+            const int row = idx / d.E, k = idx - row * d.E;
+            const int* tok = reinterpret_cast<const int*>(ws + W.tok);
+            for (int r = 0; r < R; ++r)
+                if (tok[r] == row) g += ws[W.dx + (size_t)r * d.E + k];
+            param = P.emb;
+            break;
+        }
+        case 1: {                                          // W_ih[j][k]
+            const int j = idx / d.E, k = idx - j * d.E;
+            g = dot_rows(dg + j, H4, ws + W.xin + k, d.E, R);
+            param = P.w_ih;
+            break;
+        }
+        case 2: {                                          // W_hh[j][k]
+            const int j = idx / d.H, k = idx - j * d.H;
+            g = dot_rows(dg + j, H4, ws + W.hprev + k, d.H, R);
+            param = P.w_hh;
+            break;
+        }
+        case 3: case 4: {                                  // b_ih[j], b_hh[j]
+            _Pragma("unroll 8") for (int r = 0; r < R; ++r) g += dg[(size_t)r * H4 + idx];
+            param = which == 3 ? P.b_ih : P.b_hh;
+            break;
+        }
+        case 5: case 7: {                                  // head weight[a][k]: steps of that head only
+            const int a = idx / d.H, k = idx - a * d.H, par = which == 5 ? 0 : 1;
+            for (int r = 0; r < R; ++r)
+                if (((r % d.S) & 1) == par) g = fmaf(dl[(size_t)r * CT_MAX_A + a], ws[W.hcur + (size_t)r * d.H + k], g);
+            param = which == 5 ? P.wop : P.wmag;
+            break;
+        }
+        default: {                                         // head bias[a]
+            const int par = which == 6 ? 0 : 1;
+            for (int r = 0; r < R; ++r)
+                if (((r % d.S) & 1) == par) g += dl[(size_t)r * CT_MAX_A + idx];
+            param = which == 6 ? P.bop : P.bmag;
+            break;
+        }
+    }
+    // torch.optim.Adam (no weight decay, no amsgrad): m, v EMAs, step = lr / bc1, denom = sqrt(v) / sqrt(bc2) + eps
+    float* mp = exp_avg.p[which] + idx;
+    float* vp = exp_avg_sq.p[which] + idx;
+    const float mnew = *mp + (g - *mp) * (1.0f - beta1);   // lerp, as torch does
+    const float vnew = beta2 * *vp + (1.0f - beta2) * g * g;
+    *mp = mnew;
+    *vp = vnew;
+    const float denom = sqrtf(vnew) / bc2_sqrt + eps;
+    const float pnew = param[idx] - (lr / bc1) * (mnew / denom);
+    param[idx] = pnew;
+    if (which == 1) { const int j = idx / d.E, k = idx - j * d.E; ws[W.wt_ih + (size_t)k * H4 + j] = pnew; }
+    if (which == 2) { const int j = idx / d.H, k = idx - j * d.H; ws[W.wt_hh + (size_t)k * H4 + j] = pnew; }
+}
+
+inline bool ctrl_ok(const CtrlDims& d) {
+    return d.M > 0 && d.Q > 0 && d.Q <= CT_MAX_Q && d.S > 0 && (d.S % 2) == 0 && d.E > 0 && d.H > 0 && 4 * d.H <= CT_THREADS &&
+           d.NOPS > 0 && d.NOPS <= CT_MAX_A && d.NMAGS > 0 && d.NMAGS <= CT_MAX_A && d.Q * CT_MAX_A * 4 <= CT_THREADS &&
+           ctrl_lds(d).total * sizeof(float) <= 160 * 1024 - 256;
+}
+inline CtrlParams as_params(void* const* p) {
+    CtrlParams P;
+    P.emb = (float*)p[0]; P.w_ih = (float*)p[1]; P.w_hh = (float*)p[2]; P.b_ih = (float*)p[3]; P.b_hh = (float*)p[4];
+    P.wop = (float*)p[5]; P.bop = (float*)p[6]; P.wmag = (float*)p[7]; P.bmag = (float*)p[8];
+    return P;
+}
+template <bool SAMPLE>
+int set_lds(size_t bytes) {
+    static size_t current = 0;
+    if (bytes > current) {
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ctrl_rollout<SAMPLE>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        current = bytes;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int aadg_controller_supported(int M, int Q, int S, int E, int H, int n_ops, int n_mags) {
+    CtrlDims d = {M, Q, S, E, H, n_ops, n_mags, 1.0f};
+    return ctrl_ok(d) ? 1 : 0;
+}
+
+extern "C" size_t aadg_controller_workspace_bytes(int M, int Q, int S, int E, int H, int n_ops, int n_mags) {
+    CtrlDims d = {M, Q, S, E, H, n_ops, n_mags, 1.0f};
+    return ctrl_ok(d) ? ctrl_ws(d).total * sizeof(float) : 0;
+}
+
+extern "C" int aadg_controller_sample_f32(void* const* params, int M, int Q, int S, int E, int H, int n_ops, int n_mags, float c_over_t,
+                                          const float* uniforms, long long* policies, float* op_probs, float* mag_probs,
+                                          float* log_probs, float* entropies, void* ws, size_t ws_bytes, void* stream) {
+    CtrlDims d = {M, Q, S, E, H, n_ops, n_mags, c_over_t};
+    if (params == nullptr || uniforms == nullptr || policies == nullptr || op_probs == nullptr || mag_probs == nullptr ||
+        log_probs == nullptr || entropies == nullptr || ws == nullptr)
+        return AADG_E_BADARG;
+    if (!ctrl_ok(d)) return AADG_E_UNSUPPORTED;
+    if (ws_bytes < ctrl_ws(d).total * sizeof(float)) return AADG_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const CtrlParams P = as_params(params);
+    const size_t lds = ctrl_lds(d).total * sizeof(float);
+    const int rc = set_lds<true>(lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ctrl_transpose, dim3(64), dim3(256), 0, st, P, d, (float*)ws);
+    AADG_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_ctrl_rollout<true>), dim3(M), dim3(CT_THREADS), lds, st, P, d, (float*)ws, uniforms, policies, op_probs,
+                       mag_probs, log_probs, entropies, (const float*)nullptr, (const float*)nullptr, 0.0f, (float*)nullptr);
+    AADG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int aadg_controller_ppo_update_f32(void* const* params, void* const* exp_avg, void* const* exp_avg_sq, int M, int Q, int S,
+                                              int E, int H, int n_ops, int n_mags, float c_over_t, const long long* policies,
+                                              const float* old_log_probs, const float* reward, float clip, int n_updates,
+                                              int step0, float lr, float beta1, float beta2, float eps, float* loss_terms,
+                                              void* ws, size_t ws_bytes, void* stream) {
+    CtrlDims d = {M, Q, S, E, H, n_ops, n_mags, c_over_t};
+    if (params == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr || policies == nullptr || old_log_probs == nullptr ||
+        reward == nullptr || loss_terms == nullptr || ws == nullptr || n_updates <= 0 || step0 < 0)
+        return AADG_E_BADARG;
+    if (!ctrl_ok(d)) return AADG_E_UNSUPPORTED;
+    if (ws_bytes < ctrl_ws(d).total * sizeof(float)) return AADG_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const CtrlParams P = as_params(params);
+    CtrlPtrs9 m1, m2;
+    for (int i = 0; i < 9; ++i) { m1.p[i] = (float*)exp_avg[i]; m2.p[i] = (float*)exp_avg_sq[i]; }
+    const size_t lds = ctrl_lds(d).total * sizeof(float);
+    const int rc = set_lds<false>(lds);
+    if (rc) return rc;
+    const int H4 = 4 * H;
+    const int n_params = (n_ops + n_mags) * E + H4 * E + H4 * H + 2 * H4 + n_ops * H + n_ops + n_mags * H + n_mags;
+    hipLaunchKernelGGL(k_ctrl_transpose, dim3(64), dim3(256), 0, st, P, d, (float*)ws);
+    AADG_LAUNCH_CHECK();
+    for (int it = 0; it < n_updates; ++it) {
+        hipLaunchKernelGGL((k_ctrl_rollout<false>), dim3(M), dim3(CT_THREADS), lds, st, P, d, (float*)ws, (const float*)nullptr,
+                           const_cast<long long*>(policies), (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                           old_log_probs, reward, clip, loss_terms + (size_t)it * M);
+        AADG_LAUNCH_CHECK();
+        const double step = (double)(step0 + it + 1);
+        const float bc1 = (float)(1.0 - pow((double)beta1, step));
+        const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
+        hipLaunchKernelGGL(k_ctrl_adam, dim3((n_params + 255) / 256), dim3(256), 0, st, P, m1, m2, d, (float*)ws, lr, beta1, beta2, eps,
+                           bc1, bc2_sqrt);
+        AADG_LAUNCH_CHECK();
+    }
+    return 0;
+}

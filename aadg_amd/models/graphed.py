@@ -111,3 +111,74 @@ class GraphedControllerStep(object):
         self._g_update.replay()
         loss, score_loss = self._update_out
         return loss, score_loss, entropies.mean()
+
+
+class FusedControllerStep(object):
+    """Same interface as GraphedControllerStep, PPO only: the sample rollout and the 5 PPO epochs
+    (evaluate -> clipped surrogate -> backward -> Adam) run as the fused HIP kernels of csrc/controller.hip
+    (3 + 11 launches instead of ~1900 graph nodes).  Parameters and the optimizer's Adam state are updated in
+    place, so `controller.state_dict()` / `optimizer.state_dict()` checkpoints stay the reference's."""
+
+    def __init__(self, controller, criterion, optimizer, M):
+        from .. import _lib
+        if not self.supported(controller, criterion, optimizer, M):
+            raise RuntimeError("FusedControllerStep: unsupported controller / criterion / optimizer")
+        self._lib = _lib
+        self.controller, self.criterion, self.optimizer, self.M = controller, criterion, optimizer, M
+        self.params = list(controller.parameters())
+        self.ws = _lib.controller_workspace(controller, M)
+        self.n_dec = controller.Q * controller.L * 2
+        self.policies = self.old_log_probs = None
+        group = optimizer.param_groups[0]
+        self.lr, self.betas, self.eps = group['lr'], group['betas'], group['eps']
+        for p in self.params:                                   # Adam state exactly as torch.optim.Adam lays it out
+            state = optimizer.state[p]
+            if len(state) == 0:
+                state['step'] = torch.tensor(0.0, dtype=torch.float32)
+                state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        self.exp_avg = [optimizer.state[p]['exp_avg'] for p in self.params]
+        self.exp_avg_sq = [optimizer.state[p]['exp_avg_sq'] for p in self.params]
+
+    @staticmethod
+    def supported(controller, criterion, optimizer, M):
+        from .. import _lib
+        if not (torch.cuda.is_available() and isinstance(criterion, ProximalPolicyOptimization)):
+            return False
+        if type(optimizer) is not torch.optim.Adam or len(optimizer.param_groups) != 1:
+            return False
+        g = optimizer.param_groups[0]
+        plain = (not g.get('amsgrad', False) and g.get('weight_decay', 0) == 0 and not g.get('maximize', False) and
+                 not g.get('capturable', False) and not g.get('fused', False) and not torch.is_tensor(g['lr']))
+        same = len(g['params']) == 9 and all(a is b for a, b in zip(g['params'], controller.parameters()))
+        on_host = all(not optimizer.state[p] or not optimizer.state[p]['step'].is_cuda for p in g['params'])
+        return plain and same and on_host and _lib.controller_supported(controller, M)
+
+    def sample(self):
+        dev = self.params[0].device
+        uniforms = torch.rand(self.M, self.n_dec, device=dev)
+        policies, op_probs, mag_probs, log_probs, entropies = self._lib.controller_sample(self.controller, self.M, uniforms, self.ws)
+        self.policies, self.old_log_probs = policies, log_probs
+        return policies, op_probs, mag_probs, log_probs, entropies
+
+    def update(self, reward, entropies):
+        """Same return contract as the criterion call: (loss, score_loss, entropy_penalty)."""
+        crit = self.criterion
+        group = self.optimizer.param_groups[0]                 # a scheduler may have moved the learning rate
+        steps = self.optimizer.state[self.params[0]]['step']
+        step0 = int(steps.item())
+        n = crit.n_updates_per_iteration
+        terms = self._lib.controller_ppo_update(self.controller, self.M, self.exp_avg, self.exp_avg_sq, self.policies,
+                                                self.old_log_probs, reward.contiguous().float(), crit.clip, n, step0,
+                                                group['lr'], group['betas'], group['eps'], self.ws)
+        for p in self.params:
+            self.optimizer.state[p]['step'] += n
+        mean_loss = terms.mean()
+        return mean_loss, mean_loss, entropies.mean()
+
+
+def make_controller_step(controller, criterion, optimizer, M, fused=True):
+    """Fastest available implementation of the controller's sample / update pair on the GPU."""
+    if fused and FusedControllerStep.supported(controller, criterion, optimizer, M):
+        return FusedControllerStep(controller, criterion, optimizer, M)
+    return GraphedControllerStep(controller, criterion, optimizer, M)

@@ -192,11 +192,13 @@ class SearchState(object):
         self.controller_criterion = search_loss(config)
         self.dis_criterion = CrossEntropy()
         self.controller_criterion.register_optimizer(self.controller_optimizer)
-        # launch-bound controller sample / PPO update replayed as two HIP graphs (models/graphed.py)
+        # launch-bound controller sample / PPO update: fused HIP kernels (csrc/controller.hip) for PPO, else replayed as
+        # two HIP graphs (models/graphed.py)
         self.graphed = None
         if torch.cuda.is_available() and getattr(args, 'controller_graphs', True):
-            from .models.graphed import GraphedControllerStep
-            self.graphed = GraphedControllerStep(self.controller, self.controller_criterion, self.controller_optimizer, self.M)
+            from .models.graphed import make_controller_step
+            self.graphed = make_controller_step(self.controller, self.controller_criterion, self.controller_optimizer, self.M,
+                                                fused=getattr(args, 'controller_fused', True))
 
     def search_step(self, epoch, writer_dict=None, logger=None, max_iters=None):
         """The epoch body of search_dg.py:338-347: sample M policies -> inject -> train -> EMA -> PPO."""

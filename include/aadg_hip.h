@@ -220,6 +220,30 @@ int aadg_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int plan
 int aadg_conv1x1_wgrad_supported(int Co, int Ci, int HW);
 int aadg_conv1x1_wgrad_bf16(const void* dy, const void* x, float* dweight, int N, int Co, int Ci, int HW, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Policy controller (reference: models/controller.py:9-145) and its PPO update (losses.py:117-157) as fused kernels.
+ * `params`: 9 device pointers in the module's parameter order -- embedding.weight [n_ops + n_mags, E],
+ * lstm.weight_ih [4H, E], lstm.weight_hh [4H, H], lstm.bias_ih [4H], lstm.bias_hh [4H], outop.weight [n_ops, H],
+ * outop.bias, outmag.weight [n_mags, H], outmag.bias (float32).  Q sub-policies x S = 2L decisions (op, magnitude,
+ * op, ...), LSTM state reset per sub-policy, logits squashed as (C/T) * tanh(z).
+ * sample: `uniforms` [M, Q*S] in [0, 1) drive an inverse-CDF draw per decision; writes policies [M, Q*S] int64, mean
+ *   op / magnitude probabilities, sum log-prob [M], sum entropy [M]  (controller.sample / forward).
+ * ppo_update: n_updates x { evaluate(policies) -> ratio = exp(lp - old) -> -min(ratio R, clip(ratio, 1 -+ clip) R).mean()
+ *   -> backward -> Adam(lr, beta1, beta2, eps; step = step0 + 1 ...) } in place on params / exp_avg / exp_avg_sq;
+ *   loss_terms [n_updates, M] receives the per-row surrogate terms (their mean over M is the update's loss).
+ * ------------------------------------------------------------------------------------------- */
+int aadg_controller_supported(int M, int Q, int S, int E, int H, int n_ops, int n_mags);
+size_t aadg_controller_workspace_bytes(int M, int Q, int S, int E, int H, int n_ops, int n_mags);
+int aadg_controller_sample_f32(void* const* params, int M, int Q, int S, int E, int H, int n_ops, int n_mags,
+                               float c_over_t, const float* uniforms, long long* policies, float* op_probs,
+                               float* mag_probs, float* log_probs, float* entropies, void* ws, size_t ws_bytes,
+                               void* stream);
+int aadg_controller_ppo_update_f32(void* const* params, void* const* exp_avg, void* const* exp_avg_sq, int M, int Q,
+                                   int S, int E, int H, int n_ops, int n_mags, float c_over_t,
+                                   const long long* policies, const float* old_log_probs, const float* reward,
+                                   float clip, int n_updates, int step0, float lr, float beta1, float beta2, float eps,
+                                   float* loss_terms, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
