@@ -118,7 +118,10 @@ def measured_traffic(n_units, size):
 
 
 def cpu_baseline(cfg, st, a, n_units):
-    """Oracle (CPU restatement) on a bounded sample of the same workload, rank 0 only."""
+    """Oracle (CPU restatement) on a bounded sample of the same workload, rank 0 only.  Three legs, as SURVEY 8(d) asks:
+    W = all host cores (the headline `value`), W = 4 (the reference's default `-j`, run.py:17) and W = 1.  The oracle is
+    scalar C called through ctypes (which releases the GIL), so W worker threads = W busy cores."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     from aadg_amd.data import transform as T
     O.lib()
@@ -128,32 +131,62 @@ def cpu_baseline(cfg, st, a, n_units):
     flat, refs, M = T.collect_refs(batch, nested=True)
     S = len(flat)
     units = T.refs_to_units(refs[S:])
-    n_units = min(n_units, len(units))
-    sel = rs.choice(len(units), n_units, replace=False)
+    n_all = len(units)
     pool = st.train_loader.dataset.pool
     imgs, msks = pool.images.cpu().numpy(), pool.masks.cpu().numpy()
-    t0 = time.perf_counter()
-    O.aug_units(imgs, msks, units[sel], a.size, 0)
-    t_aug = (time.perf_counter() - t0) / n_units * len(units)
     D, B = len(cfg.DATASET.DG.TRAIN), a.batch
     fe = rs.randn(D * B * M, 128).astype(np.float32)
     fe = np.where(fe > 0, fe, 0.2 * fe)
+    z = rs.randn(8, 2, a.size, a.size).astype(np.float32)
+    y = (rs.rand(8, 2, a.size, a.size) > 0.5).astype(np.float32)
+
+    def aug_one(i):
+        O.aug_units(imgs, msks, units[i:i + 1], a.size, 0)
+
+    def loss_one(i):
+        O.policy_bce(z[i % 8:i % 8 + 1], y[i % 8:i % 8 + 1], 1)
+        O.dice(z[i % 8:i % 8 + 1], y[i % 8:i % 8 + 1])
+
     t0 = time.perf_counter()
     for _ in range(3):
         O.sinkhorn_rewards(fe, D, B, M)
     t_sink = (time.perf_counter() - t0) / 3
-    z = rs.randn(4, 2, a.size, a.size).astype(np.float32)
-    y = (rs.rand(4, 2, a.size, a.size) > 0.5).astype(np.float32)
-    t0 = time.perf_counter()
-    O.policy_bce(z, y, 1)
-    O.dice(z, y)
-    t_loss = (time.perf_counter() - t0) / 4 * len(units)
-    total = t_aug + t_sink + t_loss
+
+    def leg(workers, n_aug, n_loss):
+        """seconds for one full batch with `workers` threads, measured on n_aug units / n_loss images and scaled"""
+        sel = rs.choice(n_all, n_aug, replace=False)
+        if workers == 1:
+            t0 = time.perf_counter()
+            for i in sel:
+                aug_one(int(i))
+            t_aug = (time.perf_counter() - t0) / n_aug * n_all
+            t0 = time.perf_counter()
+            for i in range(n_loss):
+                loss_one(i)
+            t_loss = (time.perf_counter() - t0) / n_loss * n_all
+        else:
+            with ThreadPoolExecutor(workers) as ex:
+                t0 = time.perf_counter()
+                list(ex.map(aug_one, [int(i) for i in sel]))
+                t_aug = (time.perf_counter() - t0) / n_aug * n_all
+                t0 = time.perf_counter()
+                list(ex.map(loss_one, range(n_loss)))
+                t_loss = (time.perf_counter() - t0) / n_loss * n_all
+        return t_aug, t_loss
+
+    cores = os.cpu_count() or 1
+    W = max(1, min(cores, n_all))
+    a1, l1 = leg(1, min(n_units, n_all), 4)
+    a4, l4 = leg(4, min(2 * n_units, n_all), 16)
+    aw, lw = leg(W, n_all, n_all)
+    total = aw + t_sink + lw
     return {"value": 1.0 / total, "unit": "hot-path steps/s (augmentation + Sinkhorn reward + BCE/Dice of one 144-image batch; backbone excluded)",
-            "cores": 1, "kind": "port",
-            "sample": "%d of %d augmentation units at %dx%d, 3 full reward loops (18 Sinkhorn problems), BCE+Dice on 4 of %d images; "
-                      "scaled to one batch: aug %.2fs + reward %.4fs + loss %.2fs" % (n_units, len(units), a.size, a.size, len(units), t_aug, t_sink, t_loss),
-            "seconds_per_step": total}
+            "cores": W, "kind": "port",
+            "sample": "all %d augmentation units at %dx%d + BCE/Dice on %d images on %d worker threads, 3 full reward loops (18 Sinkhorn "
+                      "problems, 1 thread): aug %.3fs + reward %.4fs + loss %.3fs per batch" % (n_all, a.size, a.size, n_all, W, aw, t_sink, lw),
+            "seconds_per_step": total,
+            "value_1core": 1.0 / (a1 + t_sink + l1), "value_4cores": 1.0 / (a4 + t_sink + l4),
+            "sample_1core": "%d of %d units, BCE/Dice on 4 images, scaled: aug %.2fs + reward %.4fs + loss %.2fs" % (min(n_units, n_all), n_all, a1, t_sink, l1)}
 
 
 def main():
