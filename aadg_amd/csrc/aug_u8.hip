@@ -87,12 +87,11 @@ __device__ __forceinline__ uint32_t rgb2l(uint32_t r, uint32_t g, uint32_t b) {
 }
 
 // Image.blend(degenerate, image, alpha) for one byte; float32, unfused (Blend.c)
-__device__ __forceinline__ uint32_t blend_px(int deg, int img, float alpha, bool interp) {
-    float t = __fadd_rn((float)deg, __fmul_rn(alpha, (float)(img - deg)));
-    if (interp) return (uint32_t)(int)t;
-    if (t <= 0.0f) return 0u;
-    if (t >= 255.0f) return 255u;
-    return (uint32_t)(int)t;
+__device__ __forceinline__ uint32_t blend_px(int deg, int img, float alpha, bool /*interp*/) {
+    // Pillow: 0 <= alpha <= 1 truncates t, otherwise t <= 0 -> 0, t >= 255 -> 255, else truncate.  One clamp serves both:
+    // for alpha in [0, 1] the float32 t already lies between deg and img (rounding is monotonic), so it is a no-op there.
+    const float t = __fadd_rn((float)deg, __fmul_rn(alpha, (float)(img - deg)));
+    return (uint32_t)(int)fminf(fmaxf(t, 0.0f), 255.0f);
 }
 
 struct Bufs {
@@ -560,54 +559,72 @@ __global__ __launch_bounds__(256) void k_final(Bufs bufs, const uint8_t* masks, 
 // Returns the buffer (A or B) that holds the result.  Ends with a __syncthreads().
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t blend3(uint32_t deg, uint32_t img, float alpha, bool interp) {
-    if (alpha == 0.0f) return deg;
     const uint32_t r = blend_px((int)(deg & 255), (int)(img & 255), alpha, interp);
     const uint32_t g = blend_px((int)((deg >> 8) & 255), (int)((img >> 8) & 255), alpha, interp);
     const uint32_t b = blend_px((int)((deg >> 16) & 255), (int)((img >> 16) & 255), alpha, interp);
     return r | (g << 8) | (b << 16);
 }
 
-// one pointwise op on a packed RGBX pixel at image position (y, x).  `op` is uniform per workgroup, so the
-// switch does not diverge.  Invert / Posterize / Solarize are plain integer arithmetic; the four ops whose
-// transfer function depends on float or image statistics (AutoContrast, Equalize, Contrast, Brightness) go
-// through the stage's byte LUT in LDS.  Sharpness is NOT pointwise and is handled by the caller.
-__device__ __forceinline__ uint32_t pointwise_op(const aadg_unit& un, int j, uint32_t p, int y, int x, const uint8_t* sl_all) {
-    const int op = un.op[j];
-    switch (op) {
-        case AADG_OP_INVERT:
-            return ~p & 0xFFFFFFu;
-        case AADG_OP_POSTERIZE:
-            return p & ((0xFFu & ~((1u << (8 - un.iarg[j])) - 1u)) * 0x010101u);
-        case AADG_OP_SOLARIZE: {
-            const uint32_t thr = (uint32_t)un.iarg[j];
-            uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u;
-            r = r < thr ? r : 255u - r; g = g < thr ? g : 255u - g; b = b < thr ? b : 255u - b;
-            return r | (g << 8) | (b << 16);
-        }
-        case AADG_OP_AUTOCONTRAST: case AADG_OP_EQUALIZE: case AADG_OP_CONTRAST: case AADG_OP_BRIGHTNESS: {
-            const uint8_t* sl = sl_all + j * 768;
-            return (uint32_t)sl[p & 255u] | ((uint32_t)sl[256 + ((p >> 8) & 255u)] << 8) | ((uint32_t)sl[512 + ((p >> 16) & 255u)] << 16);
-        }
-        case AADG_OP_COLOR: {
-            const float alpha = un.farg[j];
-            if (alpha == 1.0f) return p;
-            const uint32_t l = rgb2l(p & 255u, (p >> 8) & 255u, (p >> 16) & 255u);
-            return blend3(l * 0x010101u, p, alpha, alpha >= 0.0f && alpha <= 1.0f);
-        }
-        case AADG_OP_CUTOUT:
-            return (x >= un.rect[j][0] && x <= un.rect[j][2] && y >= un.rect[j][1] && y <= un.rect[j][3]) ? 0x7F7F7Fu : p;
-        default:
-            return p;
-    }
+// ops whose per-channel byte map is staged in LDS (768 bytes per stage, built by k_lut): the three statistics ops,
+// Brightness and Solarize.  Invert / Posterize are one integer instruction per pixel; Color mixes channels and
+// Cutout depends on the position; Sharpness is not pointwise and is handled by the caller.
+__device__ __forceinline__ bool needs_lds_lut(int op) {
+    return op_needs_stats(op) || op == AADG_OP_BRIGHTNESS || op == AADG_OP_SOLARIZE;
 }
-__device__ __forceinline__ bool needs_lds_lut(int op) { return op_needs_stats(op) || op == AADG_OP_BRIGHTNESS; }
 __device__ __forceinline__ bool is_stencil(const aadg_unit& un, int j) {
     return un.op[j] == AADG_OP_SHARPNESS && un.farg[j] != 1.0f;
 }
 
+// One pointwise op applied to a set of pixels.  The op is uniform per workgroup: the dispatch happens ONCE here and
+// `each(f)` then runs the branch-free per-pixel function f(p, y, x) over the caller's pixels (registers, unrolled, or an
+// LDS region) -- no per-pixel switch, no per-pixel checks of uniform parameters.
+template <typename Each>
+__device__ __forceinline__ void dispatch_op(const aadg_unit& un, int j, const uint8_t* sl_all, Each each) {
+    const int op = un.op[j];
+    switch (op) {
+        case AADG_OP_INVERT:
+            each([](uint32_t p, int, int) { return ~p & 0xFFFFFFu; });
+            break;
+        case AADG_OP_POSTERIZE: {
+            const uint32_t m = (0xFFu & ~((1u << (8 - un.iarg[j])) - 1u)) * 0x010101u;
+            each([m](uint32_t p, int, int) { return p & m; });
+            break;
+        }
+        case AADG_OP_SOLARIZE: case AADG_OP_AUTOCONTRAST: case AADG_OP_EQUALIZE: case AADG_OP_CONTRAST: case AADG_OP_BRIGHTNESS: {
+            const uint8_t* sl = sl_all + j * 768;
+            each([sl](uint32_t p, int, int) {
+                return (uint32_t)sl[p & 255u] | ((uint32_t)sl[256 + ((p >> 8) & 255u)] << 8) | ((uint32_t)sl[512 + ((p >> 16) & 255u)] << 16);
+            });
+            break;
+        }
+        case AADG_OP_COLOR: {
+            const float alpha = un.farg[j];
+            each([alpha](uint32_t p, int, int) {
+                const uint32_t l = rgb2l(p & 255u, (p >> 8) & 255u, (p >> 16) & 255u);
+                return blend3(l * 0x010101u, p, alpha, true);
+            });
+            break;
+        }
+        case AADG_OP_CUTOUT: {
+            const int x0 = un.rect[j][0], y0 = un.rect[j][1], x1 = un.rect[j][2], y1 = un.rect[j][3];
+            each([=](uint32_t p, int y, int x) { return (x >= x0 && x <= x1 && y >= y0 && y <= y1) ? 0x7F7F7Fu : p; });
+            break;
+        }
+        default:
+            break;      // Sharpness with factor 1 and unknown ids: identity
+    }
+}
+
+// one pointwise op on a single pixel (staged / histogram helpers; the tile kernels use dispatch_op over many pixels)
+__device__ __forceinline__ uint32_t pointwise_op(const aadg_unit& un, int j, uint32_t p, int y, int x, const uint8_t* sl_all) {
+    uint32_t r = p;
+    dispatch_op(un, j, sl_all, [&](auto f) { r = f(p, y, x); });
+    return r;
+}
+
 // Loads the patch (12-byte vector loads, all issued up front), applies the leading pointwise ops while the
 // pixels are still in registers, stores RGBX words to LDS; every Sharpness op then costs one LDS ping-pong
-// pass, into which the pointwise ops that follow it are folded.
+// pass, after which the pointwise ops that follow it run in place on the lane's own pixels.
 template <int NR, bool WIDE>
 __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, const uint8_t* __restrict__ src, int Hs, int Ws,
                                  int r_lo, int r_hi, int c_lo, int c_hi, uint32_t* A, uint32_t* B,
@@ -657,8 +674,8 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
     }
     int j0 = 0;                                   // leading pointwise segment [0, j0)
     while (j0 < nops && !is_stencil(un, j0)) ++j0;
-    // unpack to RGBX pixels held in registers, then apply the leading pointwise ops OP BY OP (one uniform dispatch per
-    // op for all of this thread's pixels, instead of one per pixel group), then store to LDS
+    // unpack to RGBX pixels held in registers, apply the leading pointwise ops OP BY OP (one uniform dispatch per op for
+    // all of this thread's pixels), store to LDS
     uint32_t px[NR][4];
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
@@ -666,72 +683,61 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
         px[k][0] = a & 0xFFFFFFu; px[k][1] = (a >> 24) | ((b & 0xFFFFu) << 8);
         px[k][2] = (b >> 16) | ((c & 0xFFu) << 16); px[k][3] = c >> 8;
     }
-    for (int j = 0; j < j0; ++j) {
-        const int op = un.op[j];
-        if (op == AADG_OP_INVERT) {
+    for (int j = 0; j < j0; ++j)
+        dispatch_op(un, j, sl_all, [&](auto f) {
 #pragma unroll
             for (int k = 0; k < NR; ++k)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) px[k][t] = ~px[k][t] & 0xFFFFFFu;
-        } else if (op == AADG_OP_POSTERIZE) {
-            const uint32_t m = (0xFFu & ~((1u << (8 - un.iarg[j])) - 1u)) * 0x010101u;
-#pragma unroll
-            for (int k = 0; k < NR; ++k)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) px[k][t] &= m;
-        } else if (needs_lds_lut(op)) {
-            const uint8_t* sl = sl_all + j * 768;
-#pragma unroll
-            for (int k = 0; k < NR; ++k)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const uint32_t p = px[k][t];
-                    px[k][t] = (uint32_t)sl[p & 255u] | ((uint32_t)sl[256 + ((p >> 8) & 255u)] << 8) |
-                               ((uint32_t)sl[512 + ((p >> 16) & 255u)] << 16);
-                }
-        } else {   // Solarize, Color, Cutout (position dependent) and identities
-#pragma unroll
-            for (int k = 0; k < NR; ++k)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    px[k][t] = pointwise_op(un, j, px[k][t], r_lo + wv + 4 * k, c_lo + 4 * lane + t, sl_all);
-        }
-    }
+                for (int t = 0; t < 4; ++t) px[k][t] = f(px[k][t], r_lo + wv + 4 * k, c_lo + 4 * lane + t);
+        });
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
         const int row = wv + 4 * k;
         if (row < ph && lane < q4)
             *reinterpret_cast<uint4*>(&A[row * pw + 4 * lane]) = make_uint4(px[k][0], px[k][1], px[k][2], px[k][3]);
     }
-    if (WIDE && has2) {            // patches wider than 256 pixels: lanes 0..2 own a second group per row (rare, small)
-#pragma unroll
+    if (WIDE && has2) {            // patches wider than 256 pixels: lanes 0..2 own a second group per row (rare, small);
+#pragma unroll                     // stored raw, the leading ops run on them in LDS below
         for (int k = 0; k < NR; ++k) {
             const int row = wv + 4 * k;
             if (row < ph) {
                 const uint32_t a = rd[k % NW], b = re[k % NW], c = rf[k % NW];
-                uint32_t q[4] = {a & 0xFFFFFFu, (a >> 24) | ((b & 0xFFFFu) << 8), (b >> 16) | ((c & 0xFFu) << 16), c >> 8};
-                for (int j = 0; j < j0; ++j)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) q[t] = pointwise_op(un, j, q[t], r_lo + row, c_lo + 4 * (lane + 64) + t, sl_all);
-                *reinterpret_cast<uint4*>(&A[row * pw + 4 * (lane + 64)]) = make_uint4(q[0], q[1], q[2], q[3]);
+                *reinterpret_cast<uint4*>(&A[row * pw + 4 * (lane + 64)]) =
+                    make_uint4(a & 0xFFFFFFu, (a >> 24) | ((b & 0xFFFFu) << 8), (b >> 16) | ((c & 0xFFu) << 16), c >> 8);
             }
         }
     }
     uint32_t* cur = A;
     uint32_t* oth = B;
     __syncthreads();
+    // in-place pointwise ops [ja, jb) on the lane's own pixels (row = wave + 4k, column = c0 + lane + 64c) of an LDS buffer
+    auto lds_ops = [&](uint32_t* buf, int ja, int jb, int c0) {
+        for (int j = ja; j < jb; ++j)
+            dispatch_op(un, j, sl_all, [&](auto f) {
+                for (int row = wv; row < ph; row += 4)
+                    for (int col = c0 + lane; col < pw; col += 64) {
+                        const int i = row * pw + col;
+                        buf[i] = f(buf[i], r_lo + row, c_lo + col);
+                    }
+            });
+    };
+    if (WIDE && pw > 256 && j0 > 0) {             // uniform per workgroup
+        lds_ops(cur, 0, j0, 256);
+        __syncthreads();
+    }
     while (j0 < nops) {                           // op j0 is a Sharpness stencil
         const float alpha = un.farg[j0];
-        const bool interp = alpha >= 0.0f && alpha <= 1.0f;
         int j1 = j0 + 1;
         while (j1 < nops && !is_stencil(un, j1)) ++j1;
         for (int row = wv; row < ph; row += 4) {
+            const int y = r_lo + row;
+            const bool row_in = y > 0 && y < Hs - 1 && row > 0 && row < ph - 1;
             for (int col = lane; col < pw; col += 64) {
                 const int i = row * pw + col;
-                const int y = r_lo + row, x = c_lo + col;
+                const int x = c_lo + col;
                 const uint32_t p = cur[i];
                 uint32_t d = p;   // ImageFilter.SMOOTH copies the 1-pixel image border
-                if (y > 0 && x > 0 && y < Hs - 1 && x < Ws - 1 && row > 0 && col > 0 && row < ph - 1 && col < pw - 1) {
+                if (row_in && x > 0 && x < Ws - 1 && col > 0 && col < pw - 1) {
                     uint32_t srb = 4u * (p & 0xFF00FFu), sg = 4u * ((p >> 8) & 255u);   // centre weight 5 = 4 + 1
 #pragma unroll
                     for (int dy = -1; dy <= 1; ++dy)
@@ -744,11 +750,10 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
                     const uint32_t r = ((srb & 0xFFFFu) + 6u) / 13u, b = ((srb >> 16) + 6u) / 13u, g = (sg + 6u) / 13u;
                     d = r | (g << 8) | (b << 16);
                 }
-                uint32_t v = blend3(d, p, alpha, interp);
-                for (int j = j0 + 1; j < j1; ++j) v = pointwise_op(un, j, v, y, x, sl_all);
-                oth[i] = v;
+                oth[i] = blend3(d, p, alpha, true);
             }
         }
+        lds_ops(oth, j0 + 1, j1, 0);              // same lane <-> pixel mapping as the pass above: no barrier needed
         uint32_t* t = cur; cur = oth; oth = t;
         __syncthreads();
         j0 = j1;
