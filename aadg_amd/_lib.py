@@ -40,6 +40,7 @@ EXPORTS = [
     "aadg_conv1x1_wgrad_supported", "aadg_conv1x1_wgrad_bf16",
     "aadg_controller_supported", "aadg_controller_workspace_bytes", "aadg_controller_sample_f32",
     "aadg_controller_ppo_update_f32",
+    "aadg_embed_prologue_f32",
 ]
 
 _lib = None
@@ -118,6 +119,8 @@ def load():
     lib.aadg_controller_sample_f32.argtypes = [_vp] + [_i] * 7 + [_f] + [_vp] * 7 + [_sz, _vp]
     lib.aadg_controller_ppo_update_f32.restype = _i
     lib.aadg_controller_ppo_update_f32.argtypes = [_vp] * 3 + [_i] * 7 + [_f] + [_vp] * 3 + [_f, _i, _i, _f, _f, _f, _f, _vp, _vp, _sz, _vp]
+    lib.aadg_embed_prologue_f32.restype = _i
+    lib.aadg_embed_prologue_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp]
     if lib.aadg_abi_version() != 1:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
@@ -739,3 +742,29 @@ def controller_ppo_update(controller, M, exp_avg, exp_avg_sq, policies, old_log_
                                             ws.data_ptr(), ws.numel(), _stream())
     _check(rc, "aadg_controller_ppo_update_f32")
     return losses
+
+
+# ------------------------------------------------------------------------------------------------
+def embed_prologue(x, w1, b1, w2=None, b2=None, slope=0.2):
+    """(out [N, D] or None, fe [N, E]): fe = LeakyReLU(x W1^T + b1), out = fe W2^T + b2 -- the no-grad EMA branch of the
+    domain discriminator, one launch."""
+    lib = load()
+    _require_cuda(w1, b1, w2, b2)
+    if not x.is_cuda:
+        raise AadgError("aadg_amd kernels need GPU tensors (got %s); there is no CPU path" % x.device)
+    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise AadgError("embed_prologue: expected a float32 [N, C] matrix with unit column stride")
+    w1, b1 = w1.detach().contiguous(), b1.detach().contiguous()
+    N, C = x.shape
+    E = w1.shape[0]
+    fe = torch.empty((N, E), dtype=torch.float32, device=x.device)
+    out = None
+    D = 0
+    if w2 is not None:
+        w2, b2 = w2.detach().contiguous(), b2.detach().contiguous()
+        D = w2.shape[0]
+        out = torch.empty((N, D), dtype=torch.float32, device=x.device)
+    rc = lib.aadg_embed_prologue_f32(x.data_ptr(), x.stride(0), N, C, w1.data_ptr(), b1.data_ptr(), E, _ptr(w2), _ptr(b2), D,
+                                     float(slope), fe.data_ptr(), _ptr(out), _stream())
+    _check(rc, "aadg_embed_prologue_f32")
+    return out, fe

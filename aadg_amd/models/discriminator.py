@@ -53,8 +53,15 @@ class MomentumFeatureDiscriminator(nn.Module):
     def forward(self, x, momentum=False, return_feature=False):
         if momentum:
             with torch.no_grad():
-                fe = self.mom_dis(x)
-                out = self.mom_fc(fe)
+                if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] <= 4096:
+                    # the reward's embedding prologue as one HIP launch (csrc/embed.hip)
+                    from .. import _lib
+                    lin = self.mom_dis[0]
+                    out, fe = _lib.embed_prologue(x, lin.weight, lin.bias, self.mom_fc.weight, self.mom_fc.bias,
+                                                  self.mom_dis[1].negative_slope)
+                else:
+                    fe = self.mom_dis(x)
+                    out = self.mom_fc(fe)
         else:
             fe = self.dis(x)
             out = self.fc(fe)

@@ -244,6 +244,18 @@ int aadg_controller_ppo_update_f32(void* const* params, void* const* exp_avg, vo
                                    float clip, int n_updates, int step0, float lr, float beta1, float beta2, float eps,
                                    float* loss_terms, void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Embedding prologue of the Sinkhorn reward: the EMA branch of MomentumFeatureDiscriminator under no_grad
+ * (reference: models/discriminator.py:48-51, called at search_dg.py:133-135).
+ *   fe[n]  = LeakyReLU_slope(W1 x[n] + b1)   x [N, C] (row stride ldx), W1 [E, C], fe [N, E] -> feeds
+ *                                            aadg_sinkhorn_rewards_f32 directly
+ *   out[n] = W2 fe[n] + b2                   W2 [D, E], out [N, D]; out == NULL skips it
+ * C <= 4096, E <= 256.
+ * ------------------------------------------------------------------------------------------- */
+int aadg_embed_prologue_f32(const float* x, int ldx, int N, int C, const float* W1, const float* b1, int E,
+                            const float* W2, const float* b2, int D, float slope, float* fe, float* out,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif
