@@ -81,6 +81,127 @@ __global__ __launch_bounds__(256) void k_upsample(const T* __restrict__ in, T* _
     }
 }
 
+// ---- backward: dx[i][j] = sum_Y sum_X wy(Y, i) * wx(X, j) * dy[Y][X], separable, gathered (no atomics) ---------------
+// The taps of an input row / column (which outputs touch it, with which weight) depend on the geometry only, so a tiny
+// kernel tabulates them once per call (forward arithmetic re-derived exactly); the streaming kernel then stages the
+// rectangle of dy that feeds an 8 x 32 input tile in LDS, reduces it along y with 16-byte LDS reads and along x.
+constexpr int BT_I = 8, BT_J = 32, BT_MAXTAP = 16, BT_CAP = 12288;   // BT_CAP: staged floats per workgroup (48 KiB)
+constexpr int TAP_STRIDE = BT_MAXTAP + 2;                            // floats per table row: first, count, weights
+
+__device__ __forceinline__ int first_out_reaching(float s, int i, int OUT) {   // smallest X with (int)(s * X) >= i
+    if (i <= 0) return 0;
+    int X = s > 0.0f ? (int)((float)i / s) - 1 : OUT;
+    if (X < 0) X = 0;
+    if (X > OUT) X = OUT;
+    while (X < OUT && (int)(s * (float)X) < i) ++X;
+    return X;
+}
+
+// table[idx] = {first output, tap count, weights[BT_MAXTAP]} for idx < in_size; grid 2 (y axis, x axis)
+__global__ __launch_bounds__(256) void k_upsample_bwd_taps(int h, int w, int H, int W, float sy, float sx, float* tab) {
+    const bool isx = blockIdx.x == 1;
+    const int in_size = isx ? w : h, OUT = isx ? W : H;
+    const float s = isx ? sx : sy;
+    float* t = tab + (isx ? (size_t)h * TAP_STRIDE : 0);
+    for (int idx = threadIdx.x; idx < in_size; idx += 256) {
+        const int a = first_out_reaching(s, idx - 1, OUT), b = first_out_reaching(s, idx + 1, OUT);
+        int cnt = b - a;
+        if (cnt > BT_MAXTAP) cnt = BT_MAXTAP;        // excluded by _supported()
+        float* row = t + (size_t)idx * TAP_STRIDE;
+        reinterpret_cast<int*>(row)[0] = a;
+        reinterpret_cast<int*>(row)[1] = cnt;
+        for (int k = 0; k < BT_MAXTAP; ++k) {
+            const int X = a + k;
+            const float src = s * (float)X;
+            const int x0 = (int)src, x1 = x0 + (x0 < in_size - 1 ? 1 : 0);
+            const float l1 = src - (float)x0;
+            row[2 + k] = k < cnt ? (x0 == idx ? 1.0f - l1 : 0.0f) + (x1 == idx ? l1 : 0.0f) : 0.0f;
+        }
+    }
+}
+
+// grid (ceil(w / BT_J) * ceil(h / BT_I), planes); ldc = LDS pitch of the staged rectangle (multiple of 4)
+template <typename T>
+__global__ __launch_bounds__(256) void k_upsample_bwd(const T* __restrict__ dy, T* __restrict__ dx, int h, int w, int H, int W,
+                                                      const float* __restrict__ tab, int ld_rows, int ldc) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float taps_y[BT_I * TAP_STRIDE];
+    __shared__ float taps_x[BT_J * TAP_STRIDE];
+    const size_t plane = blockIdx.y;
+    const int tj = (w + BT_J - 1) / BT_J;
+    const int i0 = (blockIdx.x / tj) * BT_I, j0 = (blockIdx.x % tj) * BT_J;
+    const int i1 = min(h, i0 + BT_I), j1 = min(w, j0 + BT_J);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* ty = tab + (size_t)i0 * TAP_STRIDE;
+    const float* tx = tab + (size_t)h * TAP_STRIDE + (size_t)j0 * TAP_STRIDE;
+    for (int t = tid; t < (i1 - i0) * TAP_STRIDE; t += 256) taps_y[t] = ty[t];
+    for (int t = tid; t < (j1 - j0) * TAP_STRIDE; t += 256) taps_x[t] = tx[t];
+    // rectangle of dy feeding this tile (uniform: scalar loads)
+    const int Ylo = reinterpret_cast<const int*>(ty)[0];
+    const int* ly = reinterpret_cast<const int*>(ty + (size_t)(i1 - 1 - i0) * TAP_STRIDE);
+    const int Yhi = ly[0] + ly[1];
+    const int Xlo = reinterpret_cast<const int*>(tx)[0] & ~3;          // 4-aligned start: float4 LDS reads line up
+    const int* lx = reinterpret_cast<const int*>(tx + (size_t)(j1 - 1 - j0) * TAP_STRIDE);
+    const int Xhi = lx[0] + lx[1];
+    const int nr = Yhi - Ylo, nc = Xhi - Xlo;
+    float* D = lds;                                   // [nr][ldc]
+    float* V = lds + (size_t)ld_rows * ldc;           // [BT_I][ldc]: reduced along y
+    const T* pdy = dy + plane * (size_t)H * W;
+    for (int rb = wv; rb < nr; rb += 16) {            // 4 rows x 3 column groups in flight per lane
+        float v[4][3];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int r = rb + 4 * a, c = lane + 64 * b;
+                v[a][b] = (r < nr && c < nc) ? Vec4<T>::ld(pdy + (size_t)(Ylo + r) * W + Xlo + c) : 0.0f;
+            }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int r = rb + 4 * a, c = lane + 64 * b;
+                if (r < nr && c < ldc) D[r * ldc + c] = v[a][b];      // columns in [nc, ldc) are zero padding
+            }
+    }
+    __syncthreads();
+    // along y: thread <-> (input row ii, 4 consecutive staged columns)
+    for (int t = tid; t < BT_I * (ldc >> 2); t += 256) {
+        const int ii = t / (ldc >> 2), c4 = (t - ii * (ldc >> 2)) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i0 + ii < i1) {
+            const float* tp = taps_y + ii * TAP_STRIDE;
+            const int yf = reinterpret_cast<const int*>(tp)[0] - Ylo, yn = reinterpret_cast<const int*>(tp)[1];
+            for (int k = 0; k < yn; ++k) {
+                const float wgt = tp[2 + k];
+                const float4 d = *reinterpret_cast<const float4*>(D + (yf + k) * ldc + c4);
+                acc.x = fmaf(wgt, d.x, acc.x); acc.y = fmaf(wgt, d.y, acc.y); acc.z = fmaf(wgt, d.z, acc.z); acc.w = fmaf(wgt, d.w, acc.w);
+            }
+        }
+        *reinterpret_cast<float4*>(V + ii * ldc + c4) = acc;
+    }
+    __syncthreads();
+    {                                                  // along x: one output per thread (256 / BT_J == BT_I)
+        const int jj = tid % BT_J, ii = tid / BT_J, i = i0 + ii, j = j0 + jj;
+        if (i < i1 && j < j1) {
+            const float* tp = taps_x + jj * TAP_STRIDE;
+            const int xf = reinterpret_cast<const int*>(tp)[0] - Xlo, xn = reinterpret_cast<const int*>(tp)[1];
+            const float* vrow = V + ii * ldc + xf;
+            float acc = 0.0f;
+            for (int k = 0; k < xn; ++k) acc = fmaf(tp[2 + k], vrow[k], acc);
+            Vec4<T>::st1(dx + plane * (size_t)h * w + (size_t)i * w + j, acc);
+        }
+    }
+}
+
+// rows / columns of dy a tile may need (upper bound used to size the LDS image)
+inline int span_bound(int tile, float s, int OUT) {
+    if (s <= 0.0f) return OUT;
+    const int n = (int)((float)(tile + 1) / s) + 3;
+    return n < OUT ? n : OUT;
+}
+inline int staged_pitch(int nc) { return ((nc + 3 + 3) & ~3) + 4; }   // + up to 3 alignment columns, multiple of 4, + pad
+
 }  // namespace
 
 extern "C" int aadg_upsample_bilinear2d(const void* in, void* out, int planes, int h, int w, int H, int W, int dtype,
@@ -100,5 +221,52 @@ extern "C" int aadg_upsample_bilinear2d(const void* in, void* out, int planes, i
         hipLaunchKernelGGL(k_upsample<__hip_bfloat16>, g, dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(in),
                            reinterpret_cast<__hip_bfloat16*>(out), h, w, H, W, sy, sx, rows_per_block);
     AADG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int aadg_upsample_bilinear2d_backward_supported(int h, int w, int H, int W) {
+    if (h <= 0 || w <= 0 || H <= 0 || W <= 0) return 0;
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
+    const int nr = span_bound(BT_I, sy, H), nc = span_bound(BT_J, sx, W);
+    if (span_bound(1, sy, H) > BT_MAXTAP || span_bound(1, sx, W) > BT_MAXTAP) return 0;   // taps per input row / column
+    const int ldc = staged_pitch(nc);
+    if (ldc > 192) return 0;                                                             // 3 column groups of 64 lanes
+    return (size_t)(nr + BT_I) * ldc <= (size_t)BT_CAP ? 1 : 0;
+}
+
+extern "C" size_t aadg_upsample_bilinear2d_backward_workspace_bytes(int h, int w) {
+    return h > 0 && w > 0 ? (size_t)(h + w) * TAP_STRIDE * sizeof(float) : 0;
+}
+
+/* dx [planes, h, w] = gradient of aadg_upsample_bilinear2d w.r.t. its input, from dy [planes, H, W] */
+extern "C" int aadg_upsample_bilinear2d_backward(const void* dy, void* dx, int planes, int h, int w, int H, int W, int dtype,
+                                                 void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !dx || !ws || planes <= 0 || planes > 65535 * 64) return AADG_E_BADARG;
+    if (dtype != 0 && dtype != 1) return AADG_E_BADARG;
+    if (!aadg_upsample_bilinear2d_backward_supported(h, w, H, W)) return AADG_E_UNSUPPORTED;
+    if (ws_bytes < aadg_upsample_bilinear2d_backward_workspace_bytes(h, w)) return AADG_E_WORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
+    float* tab = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(k_upsample_bwd_taps, dim3(2), dim3(256), 0, st, h, w, H, W, sy, sx, tab);
+    AADG_LAUNCH_CHECK();
+    const int nr = span_bound(BT_I, sy, H), nc = span_bound(BT_J, sx, W);
+    const int ldc = staged_pitch(nc);
+    const size_t lds = (size_t)(nr + BT_I) * ldc * sizeof(float);
+    const int tiles = ((w + BT_J - 1) / BT_J) * ((h + BT_I - 1) / BT_I);
+    for (int p0 = 0; p0 < planes; p0 += 65535) {
+        const int np = planes - p0 < 65535 ? planes - p0 : 65535;
+        const dim3 g(tiles, np);
+        if (dtype == 0)
+            hipLaunchKernelGGL(k_upsample_bwd<float>, g, dim3(256), lds, st, reinterpret_cast<const float*>(dy) + (size_t)p0 * H * W,
+                               reinterpret_cast<float*>(dx) + (size_t)p0 * h * w, h, w, H, W, (const float*)tab, nr, ldc);
+        else
+            hipLaunchKernelGGL(k_upsample_bwd<__hip_bfloat16>, g, dim3(256), lds, st,
+                               reinterpret_cast<const __hip_bfloat16*>(dy) + (size_t)p0 * H * W,
+                               reinterpret_cast<__hip_bfloat16*>(dx) + (size_t)p0 * h * w, h, w, H, W, (const float*)tab, nr, ldc);
+        AADG_LAUNCH_CHECK();
+    }
     return 0;
 }
