@@ -21,7 +21,7 @@ namespace {
 constexpr int CT_THREADS = 512;
 constexpr int CT_MAX_Q = 8;        // sequences per workgroup (sub-policies)
 constexpr int CT_MAX_A = 16;       // actions per head
-constexpr int CT_HP = 5, CT_XP = 16;   // row ranges of the transposed products in the backward
+constexpr int CT_HP = 5, CT_XP = 10;   // row ranges of the transposed products in the backward (4H / CT_* % 4 == 0)
 
 struct CtrlDims {
     int M, Q, S, E, H, NOPS, NMAGS;
@@ -155,26 +155,53 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_rollout(CtrlParams P, CtrlD
 #pragma unroll
             for (int q = 0; q < CT_MAX_Q; ++q) acc[q] = b;
             if (t > 0) {
-                constexpr int KB = 16;                     // weights in flight per lane
+                // 16 weights in flight per lane; activations are read as 16-byte LDS broadcasts (4 inputs per read):
+                // the scalar version spent ~40 us per step here (wall_clock64), mostly waiting on 660 dependent ds_reads
+                constexpr int KB = 16;
+                const bool vec4 = ((E | H) & 3) == 0;
                 for (int k0 = 0; k0 < E; k0 += KB) {
                     float w[KB];
 #pragma unroll
                     for (int i = 0; i < KB; ++i) w[i] = k0 + i < E ? wt_ih[(size_t)(k0 + i) * H4 + tid] : 0.0f;
+                    if (vec4) {
 #pragma unroll
-                    for (int i = 0; i < KB; ++i)
+                        for (int i = 0; i < KB; i += 4)
 #pragma unroll
-                        for (int q = 0; q < CT_MAX_Q; ++q)
-                            if (q < Q && k0 + i < E) acc[q] = fmaf(w[i], X[(q * S + t) * E + k0 + i], acc[q]);
+                            for (int q = 0; q < CT_MAX_Q; ++q)
+                                if (q < Q && k0 + i < E) {
+                                    const float4 a = *reinterpret_cast<const float4*>(X + (q * S + t) * E + k0 + i);
+                                    acc[q] = fmaf(w[i], a.x, acc[q]); acc[q] = fmaf(w[i + 1], a.y, acc[q]);
+                                    acc[q] = fmaf(w[i + 2], a.z, acc[q]); acc[q] = fmaf(w[i + 3], a.w, acc[q]);
+                                }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < KB; ++i)
+#pragma unroll
+                            for (int q = 0; q < CT_MAX_Q; ++q)
+                                if (q < Q && k0 + i < E) acc[q] = fmaf(w[i], X[(q * S + t) * E + k0 + i], acc[q]);
+                    }
                 }
                 for (int k0 = 0; k0 < H; k0 += KB) {
                     float w[KB];
 #pragma unroll
                     for (int i = 0; i < KB; ++i) w[i] = k0 + i < H ? wt_hh[(size_t)(k0 + i) * H4 + tid] : 0.0f;
+                    if (vec4) {
 #pragma unroll
-                    for (int i = 0; i < KB; ++i)
+                        for (int i = 0; i < KB; i += 4)
 #pragma unroll
-                        for (int q = 0; q < CT_MAX_Q; ++q)
-                            if (q < Q && k0 + i < H) acc[q] = fmaf(w[i], Hs[(q * (S + 1) + t) * H + k0 + i], acc[q]);
+                            for (int q = 0; q < CT_MAX_Q; ++q)
+                                if (q < Q && k0 + i < H) {
+                                    const float4 a = *reinterpret_cast<const float4*>(Hs + (q * (S + 1) + t) * H + k0 + i);
+                                    acc[q] = fmaf(w[i], a.x, acc[q]); acc[q] = fmaf(w[i + 1], a.y, acc[q]);
+                                    acc[q] = fmaf(w[i + 2], a.z, acc[q]); acc[q] = fmaf(w[i + 3], a.w, acc[q]);
+                                }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < KB; ++i)
+#pragma unroll
+                            for (int q = 0; q < CT_MAX_Q; ++q)
+                                if (q < Q && k0 + i < H) acc[q] = fmaf(w[i], Hs[(q * (S + 1) + t) * H + k0 + i], acc[q]);
+                    }
                 }
             }
             const bool is_g = tid >= 2 * H && tid < 3 * H;
@@ -377,10 +404,14 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_rollout(CtrlParams P, CtrlD
 #pragma unroll
                     for (int i = 0; i < JB; ++i) w[i] = jb + i < j1 ? P.w_hh[(size_t)(jb + i) * H + k] : 0.0f;
 #pragma unroll
-                    for (int i = 0; i < JB; ++i)
+                    for (int i = 0; i < JB; i += 4)           // ranges start at multiples of 4: 16-byte LDS broadcasts
 #pragma unroll
                         for (int q = 0; q < CT_MAX_Q; ++q)
-                            if (q < Q && jb + i < j1) acc[q] = fmaf(w[i], DG[q * H4 + jb + i], acc[q]);
+                            if (q < Q && jb + i < j1) {
+                                const float4 a = *reinterpret_cast<const float4*>(DG + q * H4 + jb + i);
+                                acc[q] = fmaf(w[i], a.x, acc[q]); acc[q] = fmaf(w[i + 1], a.y, acc[q]);
+                                acc[q] = fmaf(w[i + 2], a.z, acc[q]); acc[q] = fmaf(w[i + 3], a.w, acc[q]);
+                            }
                 }
 #pragma unroll
                 for (int q = 0; q < CT_MAX_Q; ++q)
@@ -401,16 +432,20 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_rollout(CtrlParams P, CtrlD
                 float acc[CT_MAX_Q];
 #pragma unroll
                 for (int q = 0; q < CT_MAX_Q; ++q) acc[q] = 0.0f;
-                constexpr int JB = 25;
+                constexpr int JB = 20;
                 for (int jb = j0; jb < j1; jb += JB) {
                     float w[JB];
 #pragma unroll
                     for (int i = 0; i < JB; ++i) w[i] = jb + i < j1 ? P.w_ih[(size_t)(jb + i) * E + k] : 0.0f;
 #pragma unroll
-                    for (int i = 0; i < JB; ++i)
+                    for (int i = 0; i < JB; i += 4)           // ranges start at multiples of 4: 16-byte LDS broadcasts
 #pragma unroll
                         for (int q = 0; q < CT_MAX_Q; ++q)
-                            if (q < Q && jb + i < j1) acc[q] = fmaf(w[i], DG[q * H4 + jb + i], acc[q]);
+                            if (q < Q && jb + i < j1) {
+                                const float4 a = *reinterpret_cast<const float4*>(DG + q * H4 + jb + i);
+                                acc[q] = fmaf(w[i], a.x, acc[q]); acc[q] = fmaf(w[i + 1], a.y, acc[q]);
+                                acc[q] = fmaf(w[i + 2], a.z, acc[q]); acc[q] = fmaf(w[i + 3], a.w, acc[q]);
+                            }
                 }
 #pragma unroll
                 for (int q = 0; q < CT_MAX_Q; ++q)
@@ -519,6 +554,7 @@ __global__ __launch_bounds__(256) void k_ctrl_adam(CtrlParams P, CtrlPtrs9 exp_a
 inline bool ctrl_ok(const CtrlDims& d) {
     return d.M > 0 && d.Q > 0 && d.Q <= CT_MAX_Q && d.S > 0 && (d.S % 2) == 0 && d.E > 0 && d.H > 0 && 4 * d.H <= CT_THREADS &&
            d.NOPS > 0 && d.NOPS <= CT_MAX_A && d.NMAGS > 0 && d.NMAGS <= CT_MAX_A && d.Q * CT_MAX_A * 4 <= CT_THREADS &&
+           (4 * d.H / CT_HP) % 4 == 0 && (4 * d.H) % CT_HP == 0 && (4 * d.H / CT_XP) % 4 == 0 && (4 * d.H) % CT_XP == 0 &&
            ctrl_lds(d).total * sizeof(float) <= 160 * 1024 - 256;
 }
 inline CtrlParams as_params(void* const* p) {
