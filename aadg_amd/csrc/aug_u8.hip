@@ -715,6 +715,7 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
         for (int j = ja; j < jb; ++j)
             dispatch_op(un, j, sl_all, [&](auto f) {
                 for (int row = wv; row < ph; row += 4)
+#pragma unroll 2
                     for (int col = c0 + lane; col < pw; col += 64) {
                         const int i = row * pw + col;
                         buf[i] = f(buf[i], r_lo + row, c_lo + col);
@@ -732,6 +733,7 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
         for (int row = wv; row < ph; row += 4) {
             const int y = r_lo + row;
             const bool row_in = y > 0 && y < Hs - 1 && row > 0 && row < ph - 1;
+#pragma unroll 2
             for (int col = lane; col < pw; col += 64) {
                 const int i = row * pw + col;
                 const int x = c_lo + col;
@@ -894,6 +896,7 @@ __device__ __forceinline__ void fused_tile(const uint8_t* __restrict__ pool, con
         if (hxm >= 0) {
             const uint32_t* col = cur + (r_lo - r_lo_h) * pw + (hxm - c_lo_h);
             const int d1 = hk1 ? 1 : 0;             // no second tap (identity axis / right image edge): re-read the first
+#pragma unroll 4                                    // LDS latency of 4 rows in flight (0.219 -> 0.201 ms per batch)
             for (int rr = 0; rr < nrows; ++rr) {
                 const uint32_t p0 = col[rr * pw];
                 const uint32_t p1 = col[rr * pw + d1];
@@ -1067,6 +1070,7 @@ __global__ __launch_bounds__(256) void k_fused_generic(const uint8_t* __restrict
         Hbuf = cur == A ? B : A;
         nrows = r_hi - r_lo;
         const int pcols = c_hi_h - c_lo_h;
+#pragma unroll 2
         for (int rr = hg; rr < nrows; rr += 4) {
             uint32_t packed = 0u;
             if (hxm >= 0) {

@@ -172,11 +172,13 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const T* __restrict__ dy, 
         if (i0 + ii < i1) {
             const float* tp = taps_y + ii * TAP_STRIDE;
             const int yf = reinterpret_cast<const int*>(tp)[0] - Ylo, yn = reinterpret_cast<const int*>(tp)[1];
-            for (int k = 0; k < yn; ++k) {
-                const float wgt = tp[2 + k];
-                const float4 d = *reinterpret_cast<const float4*>(D + (yf + k) * ldc + c4);
-                acc.x = fmaf(wgt, d.x, acc.x); acc.y = fmaf(wgt, d.y, acc.y); acc.z = fmaf(wgt, d.z, acc.z); acc.w = fmaf(wgt, d.w, acc.w);
-            }
+#pragma unroll
+            for (int k = 0; k < BT_MAXTAP; ++k)        // fixed trip count: all LDS reads issue before the first wait
+                if (k < yn) {
+                    const float wgt = tp[2 + k];
+                    const float4 d = *reinterpret_cast<const float4*>(D + (yf + k) * ldc + c4);
+                    acc.x = fmaf(wgt, d.x, acc.x); acc.y = fmaf(wgt, d.y, acc.y); acc.z = fmaf(wgt, d.z, acc.z); acc.w = fmaf(wgt, d.w, acc.w);
+                }
         }
         *reinterpret_cast<float4*>(V + ii * ldc + c4) = acc;
     }
@@ -188,7 +190,9 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const T* __restrict__ dy, 
             const int xf = reinterpret_cast<const int*>(tp)[0] - Xlo, xn = reinterpret_cast<const int*>(tp)[1];
             const float* vrow = V + ii * ldc + xf;
             float acc = 0.0f;
-            for (int k = 0; k < xn; ++k) acc = fmaf(tp[2 + k], vrow[k], acc);
+#pragma unroll
+            for (int k = 0; k < BT_MAXTAP; ++k)
+                if (k < xn) acc = fmaf(tp[2 + k], vrow[k], acc);
             Vec4<T>::st1(dx + plane * (size_t)h * w + (size_t)i * w + j, acc);
         }
     }
