@@ -71,3 +71,50 @@ def test_entry_points_reject_bad_arguments_without_touching_the_gpu():
     assert lib.aadg_aug_u8_forward(one, one, 1, 8, 8, one, 1, 9, 8, 0, one, one, one, 1 << 30, z) == -1      # max_ops > 4
     assert lib.aadg_aug_u8_forward(one, one, 1, 8, 8, one, 1, 2, 8, 0, one, one, one, 16, z) == -2           # workspace too small
     assert lib.aadg_seg_bce_dice_f32(one, one, 7, 2, 16, 6, one, one, z, one, 1 << 20, z) == -1              # N % M != 0
+
+
+def test_backbone_and_controller_entry_points_validate_arguments():
+    """The layer / controller entries added around the hot path: NULL -> -1, too-small workspace -> -2, shapes outside a
+    kernel's tiling -> -3 (AADG_E_UNSUPPORTED); nothing is enqueued in any of these cases."""
+    import ctypes
+    from aadg_amd import _lib
+    lib = _lib.load()
+    z, one = ctypes.c_void_p(0), ctypes.c_void_p(16)
+    f = ctypes.c_float
+    # BatchNorm
+    assert lib.aadg_bn_workspace_bytes(64) > 0 and lib.aadg_bn_workspace_bytes(0) == 0
+    assert lib.aadg_bn_forward(z, z, z, z, z, z, z, f(0.1), f(1e-5), 1, 1, 2, 4, 16, 0, z, z, z, 0, z) == -1
+    assert lib.aadg_bn_forward(one, z, one, z, z, z, z, f(0.1), f(1e-5), 7, 1, 2, 4, 16, 0, one, one, one, 1 << 20, z) == -1   # act
+    assert lib.aadg_bn_forward(one, z, one, z, z, z, z, f(0.1), f(1e-5), 1, 1, 2, 4, 16, 0, one, one, one, 8, z) == -2        # workspace
+    assert lib.aadg_bn_backward(one, z, one, z, z, one, one, 1, one, one, z, z, 2, 4, 16, 0, one, 1 << 20, z) == -1            # dres without y
+    # depthwise 3x3
+    assert lib.aadg_dwconv3x3_supported(32, 32, 12, 1) == 1 and lib.aadg_dwconv3x3_supported(32, 12, 1, 1) == 0
+    assert lib.aadg_dwconv3x3_supported(8, 512, 1, 0) == 0
+    assert lib.aadg_dwconv3x3(z, z, z, 1, 1, 8, 8, 1, 0, 0, z) == -1
+    assert lib.aadg_dwconv3x3(one, one, one, 1, 1, 8, 12, 1, 0, 1, z) == -3
+    assert lib.aadg_dwconv3x3_wgrad(one, one, one, 1, 4, 8, 8, 1, 1, one, 4, z) == -2
+    # 1x1 weight gradient
+    assert lib.aadg_conv1x1_wgrad_supported(256, 64, 1024) == 1 and lib.aadg_conv1x1_wgrad_supported(256, 64, 100) == 0
+    assert lib.aadg_conv1x1_wgrad_bf16(z, z, z, 1, 8, 8, 64, z) == -1
+    assert lib.aadg_conv1x1_wgrad_bf16(one, one, one, 1, 8, 8, 48, z) == -3
+    # max pooling
+    assert lib.aadg_maxpool3x3s2_supported(16, 16) == 1 and lib.aadg_maxpool3x3s2_supported(16, 12) == 0
+    assert lib.aadg_maxpool3x3s2_forward(z, z, 1, 16, 16, 0, z) == -1
+    assert lib.aadg_maxpool3x3s2_backward(one, one, one, 1, 16, 12, 0, z) == -3
+    # up-sampling backward
+    assert lib.aadg_upsample_bilinear2d_backward_supported(32, 32, 128, 128) == 1
+    assert lib.aadg_upsample_bilinear2d_backward_supported(4, 4, 256, 256) == 0          # factor 64: rectangle exceeds the LDS tile
+    assert lib.aadg_upsample_bilinear2d_backward(one, one, 1, 32, 32, 128, 128, 0, one, 8, z) == -2
+    assert lib.aadg_upsample_bilinear2d_backward(z, z, 1, 32, 32, 128, 128, 0, z, 0, z) == -1
+    # controller
+    dims = (6, 5, 4, 32, 100, 10, 10)
+    assert lib.aadg_controller_supported(*dims) == 1 and lib.aadg_controller_workspace_bytes(*dims) > 0
+    assert lib.aadg_controller_supported(6, 9, 4, 32, 100, 10, 10) == 0                  # more sub-policies than a workgroup runs
+    assert lib.aadg_controller_supported(6, 5, 4, 32, 200, 10, 10) == 0                  # 4H gate rows > 512 lanes
+    assert lib.aadg_controller_sample_f32(z, *dims, f(1.25), z, z, z, z, z, z, z, 0, z) == -1
+    assert lib.aadg_controller_sample_f32(one, 6, 9, 4, 32, 100, 10, 10, f(1.25), one, one, one, one, one, one, one, 1 << 30, z) == -3
+    assert lib.aadg_controller_ppo_update_f32(one, one, one, *dims, f(1.25), one, one, one, f(0.2), 5, 0, f(3.5e-4), f(0.9), f(0.999),
+                                              f(1e-8), one, one, 16, z) == -2
+    # embedding prologue
+    assert lib.aadg_embed_prologue_f32(z, 8, 1, 8, z, z, 128, z, z, 0, f(0.2), z, z, z) == -1
+    assert lib.aadg_embed_prologue_f32(one, 5000, 1, 5000, one, one, 128, z, z, 0, f(0.2), one, z, z) == -3
