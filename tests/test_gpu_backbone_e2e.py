@@ -1,0 +1,71 @@
+"""GPU: the whole DeepLabV3+ with every HIP layer kernel in place vs the same network with all of them switched off
+(plain torch.nn / ATen / MIOpen paths).
+
+float32: logits, pooled features and all parameter gradients agree tightly.
+bfloat16 autocast: a randomly initialised 50-layer BatchNorm network on a tiny batch is chaotic in bf16 (the library path
+differs from a float32 run by tens of percent, and from ITSELF by ~10 % run to run), so the check there is accuracy against
+the float32 run: the HIP layers must not be further from it than the library layers are."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SWITCHES = ["bn_act_supported", "dwconv3x3_supported", "conv1x1_supported", "maxpool3x3s2_supported"]
+
+
+def _run(model, state, x, y, autocast):
+    model.load_state_dict(state)
+    model.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        logits, feat = model(x)
+    (F.binary_cross_entropy_with_logits(logits.float(), y) + feat.float().square().mean()).backward()
+    grads = torch.cat([p.grad.float().flatten() for p in model.parameters()])
+    return logits.detach().float(), feat.detach().float(), grads
+
+
+def _rel(a, b):
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.mark.parametrize("encoder", ["resnet50", "mobilenet_v2"])
+def test_hip_layers_match_library_layers_in_situ(hip, encoder, monkeypatch):
+    from aadg_amd.models import deeplab
+    torch.manual_seed(7)
+    m = deeplab.DeepLabV3Plus(encoder, 2).cuda().train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    x = torch.randn(8, 3, 128, 128, device="cuda")
+    y = (torch.rand(8, 2, 128, 128, device="cuda") > 0.5).float()
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+
+    used = {"bn": 0, "dw": 0, "c1": 0, "mp": 0}
+    real = {"bn": hip.batch_norm_act, "dw": hip.dwconv3x3, "c1": hip.conv1x1, "mp": hip.maxpool3x3s2}
+
+    def counted(key):
+        def f(*a, **k):
+            used[key] += 1
+            return real[key](*a, **k)
+        return f
+    for key, name in (("bn", "batch_norm_act"), ("dw", "dwconv3x3"), ("c1", "conv1x1"), ("mp", "maxpool3x3s2")):
+        monkeypatch.setattr(hip, name, counted(key))
+    ours32 = _run(m, state, x, y, False)
+    ours16 = _run(m, state, x, y, True)
+    assert used["bn"] > 60 and used["dw"] >= 8 and used["c1"] > 5              # both runs went through the kernels
+    if encoder == "resnet50":
+        assert used["mp"] == 2
+    # every HIP layer refused -> module fallbacks
+    for name in SWITCHES:
+        monkeypatch.setattr(hip, name, lambda *a, **k: False)
+    monkeypatch.setattr(deeplab, "_upsample_ac", lambda t, size: F.interpolate(t, size=size, mode="bilinear", align_corners=True))
+    before = dict(used)
+    lib32 = _run(m, state, x, y, False)
+    lib16 = _run(m, state, x, y, True)
+    assert used == before                                                       # nothing of ours ran this time
+    # float32: same network
+    assert _rel(ours32[0], lib32[0]) < 2e-3 and _rel(ours32[1], lib32[1]) < 2e-3 and _rel(ours32[2], lib32[2]) < 6e-2
+    # bfloat16: no further from the float32 run than the library layers are
+    for k in range(3):
+        e_ours, e_lib = _rel(ours16[k], lib32[k]), _rel(lib16[k], lib32[k])
+        assert e_ours <= 1.3 * e_lib + 0.02, (k, e_ours, e_lib)
