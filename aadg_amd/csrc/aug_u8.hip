@@ -902,10 +902,11 @@ __device__ __forceinline__ void fused_tile(const uint8_t* __restrict__ pool, con
                 const uint32_t p1 = col[rr * pw + d1];
                 const int half = 1 << (PRECISION_BITS - 1);
                 // pixel (8 bit) x coefficient (<= 2^22): 24-bit multiplies are full rate, v_mul_lo_u32 is not
-                const int s0 = half + __mul24((int)(p0 & 255), hk0) + __mul24((int)(p1 & 255), hk1);
-                const int s1 = half + __mul24((int)((p0 >> 8) & 255), hk0) + __mul24((int)((p1 >> 8) & 255), hk1);
-                const int s2 = half + __mul24((int)((p0 >> 16) & 255), hk0) + __mul24((int)((p1 >> 16) & 255), hk1);
-                Hbuf[rr * FT_W + tid] = (uint32_t)clip8(s0) | ((uint32_t)clip8(s1) << 8) | ((uint32_t)clip8(s2) << 16);
+                const uint32_t s0 = half + __mul24((int)(p0 & 255), hk0) + __mul24((int)(p1 & 255), hk1);
+                const uint32_t s1 = half + __mul24((int)((p0 >> 8) & 255), hk0) + __mul24((int)((p1 >> 8) & 255), hk1);
+                const uint32_t s2 = half + __mul24((int)((p0 >> 16) & 255), hk0) + __mul24((int)((p1 >> 16) & 255), hk1);
+                // <= 2 non-negative taps with k0 + k1 <= 2^22 + 1: 0 < s < 256 * 2^22, so Pillow's clip8 is the identity here
+                Hbuf[rr * FT_W + tid] = (s0 >> 22) | ((s1 >> 14) & 0xFF00u) | ((s2 >> 6) & 0xFF0000u);
             }
         } else {
             for (int rr = 0; rr < nrows; ++rr) Hbuf[rr * FT_W + tid] = 0u;
@@ -948,9 +949,9 @@ __device__ __forceinline__ void fused_tile(const uint8_t* __restrict__ pool, con
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const int v = (1 << (PRECISION_BITS - 1)) + __mul24((int)((a0[i] >> (8 * c)) & 255), ky0) +
-                                  __mul24((int)((a1[i] >> (8 * c)) & 255), ky1);
-                    o[c][i] = lutf[clip8(v)];    // pad columns: H == 0 -> v >> 22 == 0 -> lutf[0] == -1.0 == pad value
+                    const uint32_t v = (1u << (PRECISION_BITS - 1)) + __mul24((int)((a0[i] >> (8 * c)) & 255), ky0) +
+                                       __mul24((int)((a1[i] >> (8 * c)) & 255), ky1);
+                    o[c][i] = lutf[v >> 22];     // no clip needed (see the horizontal pass); pad columns: H == 0 -> lutf[0] == -1.0
                 }
             }
         } else {
