@@ -46,6 +46,10 @@ class DevicePool(object):
         return MaskRef(self, int(index))
 
 
+_NO_RECT = (0, 0, -1, -1)
+_F32 = {}
+
+
 class ImageRef(object):
     """A not-yet-materialised RGB image: pool index + recorded ops + recorded geometry."""
     __slots__ = ("pool", "src", "ops", "scaled", "pad", "crop", "crop_size", "norm")
@@ -68,13 +72,20 @@ class ImageRef(object):
     width = property(lambda self: self.size[0])
     height = property(lambda self: self.size[1])
 
-    def with_op(self, op, iarg=0, farg=0.0, rect=(0, 0, -1, -1)):
+    def with_op(self, op, iarg=0, farg=0.0, rect=_NO_RECT):
         if self.scaled is not None or self.crop_size is not None:
             raise RuntimeError("policy ops must precede scale/crop (Compose slot 0, data/transform.py:284)")
         if len(self.ops) >= _lib.MAX_OPS:
             raise RuntimeError("more than %d ops per sub-policy are not supported" % _lib.MAX_OPS)
+        f32 = _F32.get(farg)
+        if f32 is None:                       # magnitudes come from a small discrete set: round to float32 once each
+            f32 = float(np.float32(farg))
+            if len(_F32) < 4096:
+                _F32[farg] = f32
+        if rect is not _NO_RECT:
+            rect = tuple(int(v) for v in rect)
         r = self.copy()
-        r.ops = self.ops + ((int(op), int(iarg), float(np.float32(farg)), tuple(int(v) for v in rect)),)
+        r.ops = self.ops + ((int(op), int(iarg), f32, rect),)
         return r
 
 
@@ -97,7 +108,7 @@ def _size(img):
     return (img.shape[1], img.shape[0])
 
 
-def _run(img, op, iarg=0, farg=0.0, rect=(0, 0, -1, -1)):
+def _run(img, op, iarg=0, farg=0.0, rect=_NO_RECT):
     if _is_ref(img):
         return img.with_op(op, iarg, farg, rect)
     if torch.is_tensor(img):
