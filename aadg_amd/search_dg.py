@@ -217,8 +217,9 @@ class SearchState(object):
             # log-probs for it -- evaluate() equals sample()'s log-prob for the same actions
             torch.distributed.broadcast(policies, 0)
             if self.graphed is not None:
-                with torch.no_grad():
-                    self.graphed.old_log_probs.copy_(self.controller.evaluate(policies, self.M))
+                # the replicas' parameters are identical, so rank 0's log-probs of rank 0's draw are THE log-probs:
+                # ship the [M] vector instead of re-evaluating the controller on every rank
+                torch.distributed.broadcast(self.graphed.old_log_probs, 0)
             else:
                 log_probs = self.controller.evaluate(policies, self.M)
         parsed = parse_policies(policies.cpu().detach().numpy(), self.config, logger)
