@@ -36,12 +36,6 @@ template <> struct Pack<float> {
     static __device__ __forceinline__ void store1(float* p, float v) { *p = v; }
     static __device__ __forceinline__ float round(float v) { return v; }
 };
-__device__ __forceinline__ uint32_t f2bf_bits(float f) {      // round to nearest even (finite inputs; NaN kept quiet)
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return u >> 16;
-}
 template <> struct Pack<__hip_bfloat16> {
     static constexpr int N = 8;
     static __device__ __forceinline__ void load(const __hip_bfloat16* p, float* v) {
@@ -56,16 +50,16 @@ template <> struct Pack<__hip_bfloat16> {
     static __device__ __forceinline__ void store(__hip_bfloat16* p, const float* v) {
         uint32_t w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = f2bf_bits(v[2 * i]) | (f2bf_bits(v[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = aadg_f2bf_bits(v[2 * i]) | (aadg_f2bf_bits(v[2 * i + 1]) << 16);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
     static __device__ __forceinline__ float load1(const __hip_bfloat16* p) {
         return __uint_as_float((uint32_t)(*reinterpret_cast<const uint16_t*>(p)) << 16);
     }
     static __device__ __forceinline__ void store1(__hip_bfloat16* p, float v) {
-        *reinterpret_cast<uint16_t*>(p) = (uint16_t)f2bf_bits(v);
+        *reinterpret_cast<uint16_t*>(p) = (uint16_t)aadg_f2bf_bits(v);
     }
-    static __device__ __forceinline__ float round(float v) { return __uint_as_float(f2bf_bits(v) << 16); }
+    static __device__ __forceinline__ float round(float v) { return __uint_as_float(aadg_f2bf_bits(v) << 16); }
 };
 
 // activation on the value the forward STORED (rounded to T): the backward re-derives the mask from the same value

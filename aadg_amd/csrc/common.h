@@ -50,3 +50,11 @@ __device__ __forceinline__ int wave_sum(int v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// float32 -> bfloat16 bits, round to nearest even (NaN kept quiet); bfloat16 bits -> float32 is a 16-bit shift
+__device__ __forceinline__ uint32_t aadg_f2bf_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}

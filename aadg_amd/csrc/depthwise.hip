@@ -29,12 +29,6 @@ template <> struct Elem<float> {
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     }
 };
-__device__ __forceinline__ uint32_t dw_f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return u >> 16;
-}
 template <> struct Elem<__hip_bfloat16> {
     static constexpr int V = 8;
     static __device__ __forceinline__ void load16(const __hip_bfloat16* p, float* v) {
@@ -53,8 +47,8 @@ template <> struct Elem<__hip_bfloat16> {
     }
     static __device__ __forceinline__ void store4(__hip_bfloat16* p, const float* v) {
         uint2 t;
-        t.x = dw_f2bf(v[0]) | (dw_f2bf(v[1]) << 16);
-        t.y = dw_f2bf(v[2]) | (dw_f2bf(v[3]) << 16);
+        t.x = aadg_f2bf_bits(v[0]) | (aadg_f2bf_bits(v[1]) << 16);
+        t.y = aadg_f2bf_bits(v[2]) | (aadg_f2bf_bits(v[3]) << 16);
         *reinterpret_cast<uint2*>(p) = t;
     }
 };

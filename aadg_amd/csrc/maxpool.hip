@@ -23,12 +23,6 @@ template <> struct Px<float> {
     }
     static __device__ __forceinline__ void store8(float* p, const float* v) { store4(p, v); store4(p + 4, v + 4); }
 };
-__device__ __forceinline__ uint32_t mp_f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return u >> 16;
-}
 template <> struct Px<__hip_bfloat16> {
     static __device__ __forceinline__ void load8(const __hip_bfloat16* p, float* v) {
         const uint4 t = *reinterpret_cast<const uint4*>(p);
@@ -44,16 +38,16 @@ template <> struct Px<__hip_bfloat16> {
     }
     static __device__ __forceinline__ void store4(__hip_bfloat16* p, const float* v) {
         uint2 t;
-        t.x = mp_f2bf(v[0]) | (mp_f2bf(v[1]) << 16);
-        t.y = mp_f2bf(v[2]) | (mp_f2bf(v[3]) << 16);
+        t.x = aadg_f2bf_bits(v[0]) | (aadg_f2bf_bits(v[1]) << 16);
+        t.y = aadg_f2bf_bits(v[2]) | (aadg_f2bf_bits(v[3]) << 16);
         *reinterpret_cast<uint2*>(p) = t;
     }
     static __device__ __forceinline__ void store8(__hip_bfloat16* p, const float* v) {
         uint4 t;
-        t.x = mp_f2bf(v[0]) | (mp_f2bf(v[1]) << 16);
-        t.y = mp_f2bf(v[2]) | (mp_f2bf(v[3]) << 16);
-        t.z = mp_f2bf(v[4]) | (mp_f2bf(v[5]) << 16);
-        t.w = mp_f2bf(v[6]) | (mp_f2bf(v[7]) << 16);
+        t.x = aadg_f2bf_bits(v[0]) | (aadg_f2bf_bits(v[1]) << 16);
+        t.y = aadg_f2bf_bits(v[2]) | (aadg_f2bf_bits(v[3]) << 16);
+        t.z = aadg_f2bf_bits(v[4]) | (aadg_f2bf_bits(v[5]) << 16);
+        t.w = aadg_f2bf_bits(v[6]) | (aadg_f2bf_bits(v[7]) << 16);
         *reinterpret_cast<uint4*>(p) = t;
     }
 };
