@@ -179,6 +179,46 @@ __global__ __launch_bounds__(256) void k_dw3x3(const T* __restrict__ x, const fl
     if (ro >= g.rows_per_pass) return;
     const int j0 = cg * 4;
     const int nrows = r1 - r0, vrows = np * nrows;          // virtual rows over the planes of this workgroup
+    const int strip = (vrows + g.rows_per_pass - 1) / g.rows_per_pass;
+    if (g.d == 1 && strip > 1 && nrows % strip == 0) {
+        // d = 1: a lane walks `strip` CONSECUTIVE rows of one plane with a 3-row window of taps in registers: one new row of
+        // LDS reads per output row instead of three (the strided mapping below spent ~70 % of its time on those reads)
+        const int v0 = ro * strip;
+        if (v0 >= vrows) return;
+        const int pl = v0 / nrows, i0 = r0 + (v0 - pl * nrows);
+        const float* Lp = L + (size_t)pl * psz;
+        const float* k = kw + pl * 9;
+        float w0[3][4], w1[3][4], w2[3][4];
+        auto fetch = [&](int ri, float in[3][4]) {
+            if (ri >= 0 && ri < g.H) dw_row_taps(Lp + (size_t)(ri - R0) * g.W, g.W, 1, j0, in);
+            else
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) in[b][t] = 0.0f;
+        };
+        fetch(i0 - 1, w0);
+        fetch(i0, w1);
+        T* py = y + (size_t)(plane0 + pl) * psz;
+        for (int r = 0; r < strip; ++r) {
+            fetch(i0 + r + 1, w2);
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc[t] = fmaf(k[b], w0[b][t], acc[t]);
+                    acc[t] = fmaf(k[3 + b], w1[b][t], acc[t]);
+                    acc[t] = fmaf(k[6 + b], w2[b][t], acc[t]);
+                }
+            Elem<T>::store4(py + (size_t)(i0 + r) * g.W + j0, acc);
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { w0[b][t] = w1[b][t]; w1[b][t] = w2[b][t]; }
+        }
+        return;
+    }
     for (int v = ro; v < vrows; v += g.rows_per_pass) {
         const int pl = v / nrows, i = r0 + (v - pl * nrows);
         float acc[4];
@@ -215,6 +255,46 @@ __global__ __launch_bounds__(256) void k_dw3x3_wgrad(const T* __restrict__ x, co
         __syncthreads();
         if (ro < g.rows_per_pass) {
             const int nrows = r1 - r0, vrows = np * nrows;
+            const int strip = (vrows + g.rows_per_pass - 1) / g.rows_per_pass;
+            if (g.d == 1 && strip > 1 && nrows % strip == 0) {      // consecutive rows, 3-row window of input taps (see k_dw3x3)
+                const int v0 = ro * strip;
+                if (v0 < vrows) {
+                    const int pl = v0 / nrows, i0 = r0 + (v0 - pl * nrows);
+                    const float* Lp = L + (size_t)pl * srows * g.W;
+                    const T* pdy = dy + ((size_t)(n0 + pl) * C + c) * psz;
+                    float w0[3][4], w1[3][4], w2[3][4];
+                    auto fetch = [&](int ri, float in[3][4]) {
+                        if (ri >= 0 && ri < g.H) dw_row_taps(Lp + (size_t)(ri - R0) * g.W, g.W, 1, j0, in);
+                        else
+#pragma unroll
+                            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) in[b][t] = 0.0f;
+                    };
+                    fetch(i0 - 1, w0);
+                    fetch(i0, w1);
+                    for (int r = 0; r < strip; ++r) {
+                        fetch(i0 + r + 1, w2);
+                        float gy[4];
+                        Elem<T>::load4(pdy + (size_t)(i0 + r) * g.W + j0, gy);
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) {
+                            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                s0 = fmaf(gy[t], w0[b][t], s0);
+                                s1 = fmaf(gy[t], w1[b][t], s1);
+                                s2 = fmaf(gy[t], w2[b][t], s2);
+                            }
+                            acc[b] += s0; acc[3 + b] += s1; acc[6 + b] += s2;
+                        }
+#pragma unroll
+                        for (int b = 0; b < 3; ++b)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) { w0[b][t] = w1[b][t]; w1[b][t] = w2[b][t]; }
+                    }
+                }
+            } else
             for (int v = ro; v < vrows; v += g.rows_per_pass) {
                 const int pl = v / nrows, i = r0 + (v - pl * nrows);
                 float gy[4];
