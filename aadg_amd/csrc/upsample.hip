@@ -81,6 +81,58 @@ __global__ __launch_bounds__(256) void k_upsample(const T* __restrict__ in, T* _
     }
 }
 
+// Small input planes (h * w <= UP_LDS_MAX, e.g. the 32 x 32 ASPP map): the plane is staged once in LDS as float, so the
+// 16 taps of a lane's 4 outputs are LDS reads instead of 2-byte global gathers.  grid (ceil(H / UP_ROWS), planes).
+constexpr int UP_LDS_MAX = 4096, UP_ROWS = 32;
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_upsample_lds(const T* __restrict__ in, T* __restrict__ out, int h, int w, int H, int W,
+                                                      float sy, float sx) {
+    __shared__ float P[UP_LDS_MAX];
+    const size_t plane = blockIdx.y;
+    const T* pin = in + plane * (size_t)h * w;
+    for (int i = threadIdx.x; i < h * w; i += 256) P[i] = Vec4<T>::ld(pin + i);
+    __syncthreads();
+    T* po = out + plane * (size_t)H * W;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int Y0 = blockIdx.x * UP_ROWS, Y1 = min(H, Y0 + UP_ROWS);
+    const bool vec = (W & 3) == 0;
+    for (int xg = 0; xg * 256 < W; ++xg) {
+        const int x0 = xg * 256 + lane * 4;
+        if (x0 >= W) continue;
+        int xi0[4], xi1[4];
+        float lx1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int X = min(x0 + k, W - 1);
+            const float src = sx * (float)X;
+            const int i0 = (int)src;
+            xi0[k] = i0;
+            xi1[k] = i0 + (i0 < w - 1 ? 1 : 0);
+            lx1[k] = src - (float)i0;
+        }
+#pragma unroll 2
+        for (int Y = Y0 + wv; Y < Y1; Y += 4) {
+            const float srcy = sy * (float)Y;
+            const int y0 = (int)srcy;
+            const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+            const float ly1 = srcy - (float)y0, ly0 = 1.0f - ly1;
+            const float* r0 = P + y0 * w;
+            const float* r1 = P + y1 * w;
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lx0 = 1.0f - lx1[k];
+                v[k] = ly0 * (lx0 * r0[xi0[k]] + lx1[k] * r0[xi1[k]]) + ly1 * (lx0 * r1[xi0[k]] + lx1[k] * r1[xi1[k]]);
+            }
+            T* dst = po + (size_t)Y * W + x0;
+            if (vec) Vec4<T>::st4(dst, v[0], v[1], v[2], v[3]);
+            else
+                for (int k = 0; k < 4 && x0 + k < W; ++k) Vec4<T>::st1(dst + k, v[k]);
+        }
+    }
+}
+
 // ---- backward: dx[i][j] = sum_Y sum_X wy(Y, i) * wx(X, j) * dy[Y][X], separable, gathered (no atomics) ---------------
 // The taps of an input row / column (which outputs touch it, with which weight) depend on the geometry only, so a tiny
 // kernel tabulates them once per call (forward arithmetic re-derived exactly); the streaming kernel then stages the
@@ -215,6 +267,22 @@ extern "C" int aadg_upsample_bilinear2d(const void* in, void* out, int planes, i
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;
     const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
+    if (h * w <= UP_LDS_MAX) {
+        for (int p0 = 0; p0 < planes; p0 += 65535) {          // gridDim.y limit
+            const int np = planes - p0 < 65535 ? planes - p0 : 65535;
+            const dim3 gl((H + UP_ROWS - 1) / UP_ROWS, np);
+            if (dtype == 0)
+                hipLaunchKernelGGL(k_upsample_lds<float>, gl, dim3(256), 0, st, reinterpret_cast<const float*>(in) + (size_t)p0 * h * w,
+                                   reinterpret_cast<float*>(out) + (size_t)p0 * H * W, h, w, H, W, sy, sx);
+            else
+                hipLaunchKernelGGL(k_upsample_lds<__hip_bfloat16>, gl, dim3(256), 0, st,
+                                   reinterpret_cast<const __hip_bfloat16*>(in) + (size_t)p0 * h * w,
+                                   reinterpret_cast<__hip_bfloat16*>(out) + (size_t)p0 * H * W, h, w, H, W, sy, sx);
+            AADG_LAUNCH_CHECK();
+        }
+        return 0;
+    }
+    if (planes > 65535) return AADG_E_UNSUPPORTED;
     const int rows_per_block = 16;
     const int xgroups = (W + 255) / 256;
     const dim3 g(xgroups * ((H + rows_per_block - 1) / rows_per_block), planes);
