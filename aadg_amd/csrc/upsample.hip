@@ -15,6 +15,10 @@ template <typename T> struct Vec4;
 template <> struct Vec4<float> {
     using type = float4;
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void ld4(const float* p, float* v) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
     static __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
         *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
     }
@@ -22,6 +26,11 @@ template <> struct Vec4<float> {
 };
 template <> struct Vec4<__hip_bfloat16> {
     static __device__ __forceinline__ float ld(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+    static __device__ __forceinline__ void ld4(const __hip_bfloat16* p, float* v) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
+        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
+    }
     static __device__ __forceinline__ void st4(__hip_bfloat16* p, float a, float b, float c, float d) {
         const __hip_bfloat16 e[4] = {__float2bfloat16(a), __float2bfloat16(b), __float2bfloat16(c), __float2bfloat16(d)};
         uint2 v;
@@ -250,6 +259,58 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const T* __restrict__ dy, 
     }
 }
 
+// Whole-plane variant for small outputs (H * W <= UPB_MAX_OUT, e.g. 128 x 128 -> 32 x 32): one workgroup per plane stages
+// the plane of dy once (contiguous 16-byte loads, no halo re-reads), reduces along y into V[h][W], then along x.
+constexpr int UPB_MAX_OUT = 16384, UPB_MAX_IN_ROWS = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_upsample_bwd_plane(const T* __restrict__ dy, T* __restrict__ dx, int h, int w, int H, int W,
+                                                            const float* __restrict__ tab) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* D = lds;                         // [H][W] staged dy (float)
+    float* V = lds + (size_t)H * W;         // [h][W]
+    const size_t plane = blockIdx.x;
+    const T* pdy = dy + plane * (size_t)H * W;
+    const int tid = threadIdx.x;
+    const int n4 = H * W / 4;
+    for (int i = tid; i < n4; i += 256) {
+        float v[4];
+        Vec4<T>::ld4(pdy + (size_t)i * 4, v);
+        *reinterpret_cast<float4*>(D + (size_t)i * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+    const float* ty = tab;
+    const float* tx = tab + (size_t)h * TAP_STRIDE;
+    const int w4 = W / 4;
+    for (int t = tid; t < h * w4; t += 256) {          // along y: (input row i, 4 consecutive output columns)
+        const int i = t / w4, c4 = (t - i * w4) * 4;
+        const float* tp = ty + (size_t)i * TAP_STRIDE;
+        const int yf = reinterpret_cast<const int*>(tp)[0], yn = reinterpret_cast<const int*>(tp)[1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < BT_MAXTAP; ++k)
+            if (k < yn) {
+                const float wgt = tp[2 + k];
+                const float4 d = *reinterpret_cast<const float4*>(D + (size_t)(yf + k) * W + c4);
+                acc.x = fmaf(wgt, d.x, acc.x); acc.y = fmaf(wgt, d.y, acc.y); acc.z = fmaf(wgt, d.z, acc.z); acc.w = fmaf(wgt, d.w, acc.w);
+            }
+        *reinterpret_cast<float4*>(V + (size_t)i * W + c4) = acc;
+    }
+    __syncthreads();
+    T* pdx = dx + plane * (size_t)h * w;
+    for (int t = tid; t < h * w; t += 256) {           // along x
+        const int i = t / w, j = t - i * w;
+        const float* tp = tx + (size_t)j * TAP_STRIDE;
+        const int xf = reinterpret_cast<const int*>(tp)[0], xn = reinterpret_cast<const int*>(tp)[1];
+        const float* vrow = V + (size_t)i * W + xf;
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < BT_MAXTAP; ++k)
+            if (k < xn) acc = fmaf(tp[2 + k], vrow[k], acc);
+        Vec4<T>::st1(pdx + t, acc);
+    }
+}
+
 // rows / columns of dy a tile may need (upper bound used to size the LDS image)
 inline int span_bound(int tile, float s, int OUT) {
     if (s <= 0.0f) return OUT;
@@ -324,6 +385,28 @@ extern "C" int aadg_upsample_bilinear2d_backward(const void* dy, void* dx, int p
     float* tab = reinterpret_cast<float*>(ws);
     hipLaunchKernelGGL(k_upsample_bwd_taps, dim3(2), dim3(256), 0, st, h, w, H, W, sy, sx, tab);
     AADG_LAUNCH_CHECK();
+    if (H * W <= UPB_MAX_OUT && (W & 3) == 0 && h <= UPB_MAX_IN_ROWS && (((uintptr_t)dy) & 15u) == 0 && (((size_t)H * W) % 8) == 0) {
+        static bool attr[2] = {false, false};
+        const size_t lds_p = ((size_t)H * W + (size_t)h * W) * sizeof(float);      // <= 64 KiB + 16 KiB
+        if (!attr[dtype]) {
+            if (dtype == 0)
+                AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_upsample_bwd_plane<float>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            else
+                AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_upsample_bwd_plane<__hip_bfloat16>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            attr[dtype] = true;
+        }
+        if (dtype == 0)
+            hipLaunchKernelGGL(k_upsample_bwd_plane<float>, dim3(planes), dim3(256), lds_p, st, reinterpret_cast<const float*>(dy),
+                               reinterpret_cast<float*>(dx), h, w, H, W, (const float*)tab);
+        else
+            hipLaunchKernelGGL(k_upsample_bwd_plane<__hip_bfloat16>, dim3(planes), dim3(256), lds_p, st,
+                               reinterpret_cast<const __hip_bfloat16*>(dy), reinterpret_cast<__hip_bfloat16*>(dx), h, w, H, W,
+                               (const float*)tab);
+        AADG_LAUNCH_CHECK();
+        return 0;
+    }
     const int nr = span_bound(BT_I, sy, H), nc = span_bound(BT_J, sx, W);
     const int ldc = staged_pitch(nc);
     const size_t lds = (size_t)(nr + BT_I) * ldc * sizeof(float);
