@@ -95,6 +95,19 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const T* __restrict__ x, co
     const T* px = x + plane * (size_t)H * W;
     const int row0 = blockIdx.y * BT_IH - 1, col0 = blockIdx.x * BT_IW - 1;     // image coordinates of patch (0, 0)
     const int tid = threadIdx.x;
+    // this lane's output gradients (up to 3 of the 9 x 65 outputs of the tile + halo): issued first, so that their
+    // latency overlaps the staging of the input patch instead of following the barrier
+    const int oi0 = blockIdx.y * BT_OH, oj0 = blockIdx.x * BT_OW;
+    const T* pdy = dy + plane * (size_t)Ho * Wo;
+    constexpr int NOUT = (BT_OH + 1) * (BT_OW + 1), PER = (NOUT + 255) / 256;
+    float gq[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int o = tid + 256 * q;
+        const int oi = o / (BT_OW + 1), oj = o - oi * (BT_OW + 1);
+        const int i = oi0 + oi, j = oj0 + oj;
+        gq[q] = (o < NOUT && i < Ho && j < Wo) ? Px<T>::load1(pdy + (size_t)i * Wo + j) : 0.0f;
+    }
     for (int i = tid; i < BT_PH * BT_LD; i += 256) dL[i] = 0.0f;
     // aligned middle of every patch row: 16 vectors of 8 elements; then the 3 edge columns
     for (int i = tid; i < BT_PH * 16; i += 256) {
@@ -116,9 +129,10 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const T* __restrict__ x, co
         xL[rr * BT_LD + cc] = (r >= 0 && r < H && c >= 0 && c < W) ? Px<T>::load1(px + (size_t)r * W + c) : -INFINITY;
     }
     __syncthreads();
-    const int oi0 = blockIdx.y * BT_OH, oj0 = blockIdx.x * BT_OW;
-    const T* pdy = dy + plane * (size_t)Ho * Wo;
-    for (int o = tid; o < (BT_OH + 1) * (BT_OW + 1); o += 256) {
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int o = tid + 256 * q;
+        if (o >= NOUT) continue;
         const int oi = o / (BT_OW + 1), oj = o - oi * (BT_OW + 1);
         const int i = oi0 + oi, j = oj0 + oj;
         if (i >= Ho || j >= Wo) continue;
@@ -132,8 +146,7 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const T* __restrict__ x, co
                 const float v = w[a * BT_LD + b];
                 if (v > best) { best = v; at = a * BT_LD + b; }
             }
-        const float g = Px<T>::load1(pdy + (size_t)i * Wo + j);
-        __hip_atomic_fetch_add(&dL[(2 * oi) * BT_LD + 2 * oj + at], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&dL[(2 * oi) * BT_LD + 2 * oj + at], gq[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
     {
