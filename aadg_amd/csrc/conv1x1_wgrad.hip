@@ -26,16 +26,21 @@ constexpr int WG_PITCH = WG_BK + 8;       // LDS row pitch in elements (144 byte
 // WR x WC waves, each a 64 x 64 tile of dW (2 x 2 MFMA tiles)
 template <int WR, int WC>
 __global__ __launch_bounds__(256) void k_wgrad1x1(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X,
-                                                  float* __restrict__ acc, int Co, int Ci, int HW, int tiles_n, int steps_total,
-                                                  int steps_per_block) {
+                                                  float* __restrict__ acc, int Co, int Ci, int HW, int tiles, int tiles_n,
+                                                  int steps_total, int steps_per_block) {
     static_assert(WR * WC == 4, "four waves per workgroup");
     constexpr int BM = 64 * WR, BN = 64 * WC, R = BM + BN, LPT = R * 8 / 256;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];      // [2][R][WG_PITCH]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv / WC, wc = wv - wr * WC;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    // 1-D grid, XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the id is
+    // decoded as (K-slice group, tile, xcd): all tiles that stream the SAME K-slice of dY / X run on the same XCD and share
+    // those tiles of the operands through its L2 instead of re-reading them from HBM once per tile.
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int tile = q % tiles, slice = (q / tiles) * 8 + xcd;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int s0 = blockIdx.y * steps_per_block, s1 = min(steps_total, s0 + steps_per_block);
+    const int s0 = slice * steps_per_block, s1 = min(steps_total, s0 + steps_per_block);
     if (s0 >= s1) return;
     const int spi = HW / WG_BK;           // steps per image
 
@@ -131,8 +136,9 @@ int launch(const uint16_t* dY, const uint16_t* X, float* acc, int N, int Co, int
         attr_set = true;
     }
     AADG_HIP_TRY(hipMemsetAsync(acc, 0, (size_t)Co * Ci * sizeof(float), st));
-    hipLaunchKernelGGL((k_wgrad1x1<WR, WC>), dim3(tiles, split), dim3(256), lds, st, dY, X, acc, Co, Ci, HW, tiles_n, steps_total,
-                       steps_per_block);
+    const int slice_groups = (split + 7) / 8;                 // slices are padded to a multiple of 8 (empty ones exit at once)
+    hipLaunchKernelGGL((k_wgrad1x1<WR, WC>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(256), lds, st, dY, X, acc, Co, Ci, HW,
+                       tiles, tiles_n, steps_total, steps_per_block);
     AADG_LAUNCH_CHECK();
     return 0;
 }
