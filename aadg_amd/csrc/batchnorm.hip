@@ -131,7 +131,7 @@ __device__ __forceinline__ float2 block_sum2(float a, float b) {
 // from y when a residual was fused); sums g and g * (x - mean) * invstd; writes g to dres when dres != nullptr.
 template <typename T, int VEC, int MODE>
 __global__ __launch_bounds__(256) void k_bn_reduce(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
-                                                   T* __restrict__ dres, const float* __restrict__ mean,
+                                                   const T* __restrict__ dy2, T* __restrict__ dres, const float* __restrict__ mean,
                                                    const float* __restrict__ invstd, const float* __restrict__ scale,
                                                    const float* __restrict__ shift, int act, int C, int len, int per_strip,
                                                    int plen, int total, float* __restrict__ partial) {
@@ -155,6 +155,12 @@ __global__ __launch_bounds__(256) void k_bn_reduce(const T* __restrict__ x, cons
             } else {
                 float gv[VEC], yv[VEC];
                 if (VEC == 1) gv[0] = Pack<T>::load1(dy + off); else Pack<T>::load(dy + off, gv);
+                if (dy2 != nullptr) {            // the output had two consumers: their gradients are summed here, not in a separate pass
+                    float g2[VEC];
+                    if (VEC == 1) g2[0] = Pack<T>::load1(dy2 + off); else Pack<T>::load(dy2 + off, g2);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) gv[i] += g2[i];
+                }
                 if (y != nullptr) {
                     if (VEC == 1) yv[0] = Pack<T>::load1(y + off); else Pack<T>::load(y + off, yv);
                 }
@@ -331,11 +337,11 @@ int bn_forward(const T* x, const T* res, T* y, const float* weight, const float*
     if (training) {
         const dim3 grid(s.split, C);
         if (s.vec > 1)
-            hipLaunchKernelGGL((k_bn_reduce<T, Pack<T>::N, 0>), grid, blk, 0, st, x, (const T*)nullptr, (const T*)nullptr, (T*)nullptr,
+            hipLaunchKernelGGL((k_bn_reduce<T, Pack<T>::N, 0>), grid, blk, 0, st, x, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, (T*)nullptr,
                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act, C,
                                s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         else
-            hipLaunchKernelGGL((k_bn_reduce<T, 1, 0>), grid, blk, 0, st, x, (const T*)nullptr, (const T*)nullptr, (T*)nullptr,
+            hipLaunchKernelGGL((k_bn_reduce<T, 1, 0>), grid, blk, 0, st, x, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, (T*)nullptr,
                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act, C,
                                s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         AADG_LAUNCH_CHECK();
@@ -357,7 +363,7 @@ int bn_forward(const T* x, const T* res, T* y, const float* weight, const float*
 }
 
 template <typename T>
-int bn_backward(const T* x, const T* y, const T* dy, const float* weight, const float* bias, const float* mean, const float* invstd,
+int bn_backward(const T* x, const T* y, const T* dy, const T* dy2, const float* weight, const float* bias, const float* mean, const float* invstd,
                 int act, T* dx, T* dres, float* dweight, float* dbias, int N, int C, int HW, float* ws, hipStream_t st) {
     Shape s;
     if (!make_shape<T>(N, C, HW, x, y, dy, dx, &s) || (((uintptr_t)dres & 15u) && s.vec > 1)) return AADG_E_BADARG;
@@ -370,10 +376,10 @@ int bn_backward(const T* x, const T* y, const T* dy, const float* weight, const 
     {
         const dim3 grid(s.split, C);
         if (s.vec > 1)
-            hipLaunchKernelGGL((k_bn_reduce<T, Pack<T>::N, 1>), grid, blk, 0, st, x, y, dy, dres, mean, invstd, (const float*)scale,
+            hipLaunchKernelGGL((k_bn_reduce<T, Pack<T>::N, 1>), grid, blk, 0, st, x, y, dy, dy2, dres, mean, invstd, (const float*)scale,
                                (const float*)shift, act, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         else
-            hipLaunchKernelGGL((k_bn_reduce<T, 1, 1>), grid, blk, 0, st, x, y, dy, dres, mean, invstd, (const float*)scale,
+            hipLaunchKernelGGL((k_bn_reduce<T, 1, 1>), grid, blk, 0, st, x, y, dy, dy2, dres, mean, invstd, (const float*)scale,
                                (const float*)shift, act, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         AADG_LAUNCH_CHECK();
     }
@@ -421,20 +427,22 @@ extern "C" int aadg_bn_forward(const void* x, const void* residual, void* y, con
     return AADG_E_BADARG;
 }
 
-extern "C" int aadg_bn_backward(const void* x, const void* y, const void* dy, const float* weight, const float* bias,
+extern "C" int aadg_bn_backward(const void* x, const void* y, const void* dy, const void* dy2, const float* weight, const float* bias,
                                 const float* save_mean, const float* save_invstd, int act, void* dx, void* dres, float* dweight,
                                 float* dbias, int N, int C, int HW, int dtype, void* ws, size_t ws_bytes, void* stream) {
     if (x == nullptr || dy == nullptr || dx == nullptr || save_mean == nullptr || save_invstd == nullptr || ws == nullptr ||
         act < 0 || act > AADG_ACT_RELU6)
         return AADG_E_BADARG;
     if (dres != nullptr && y == nullptr) return AADG_E_BADARG;   // a fused residual needs the stored output for the mask
+    if (dy2 != nullptr && (dres == nullptr || (((uintptr_t)dy2) & 15u))) return AADG_E_BADARG;   // summed gradients are materialised as dres
     if (C <= 0 || ws_bytes < aadg_bn_workspace_bytes(C)) return AADG_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
-        return bn_backward<float>((const float*)x, (const float*)y, (const float*)dy, weight, bias, save_mean, save_invstd, act,
+        return bn_backward<float>((const float*)x, (const float*)y, (const float*)dy, (const float*)dy2, weight, bias, save_mean, save_invstd, act,
                                   (float*)dx, (float*)dres, dweight, dbias, N, C, HW, (float*)ws, st);
     if (dtype == 1)
-        return bn_backward<__hip_bfloat16>((const __hip_bfloat16*)x, (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy, weight,
+        return bn_backward<__hip_bfloat16>((const __hip_bfloat16*)x, (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy,
+                                           (const __hip_bfloat16*)dy2, weight,
                                            bias, save_mean, save_invstd, act, (__hip_bfloat16*)dx, (__hip_bfloat16*)dres, dweight,
                                            dbias, N, C, HW, (float*)ws, st);
     return AADG_E_BADARG;

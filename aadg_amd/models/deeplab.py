@@ -28,7 +28,7 @@ def _upsample_ac(x, size):
 _ACT_CODE = {None: 0, 'relu': 1, 'relu6': 2}
 
 
-def bn_act(bn, x, act=None, residual=None):
+def bn_act(bn, x, act=None, residual=None, dual=False):
     """act(bn(x) [+ residual]).  On the GPU a plain `nn.BatchNorm2d` runs as the fused HIP streaming kernels
     (csrc/batchnorm.hip: statistics, normalise + activation + residual add in one pass, two-pass backward); anything
     else (SyncBatchNorm after `--sync_bn`, CPU shape tests) takes the module's own path."""
@@ -40,7 +40,7 @@ def bn_act(bn, x, act=None, residual=None):
             if bn.training:
                 bn.num_batches_tracked.add_(1)
             return _lib.batch_norm_act(xc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum,
-                                       bn.eps, _ACT_CODE[act], rc)
+                                       bn.eps, _ACT_CODE[act], rc, dual=dual and bn.training and torch.is_grad_enabled())
     y = bn(x)
     if residual is not None:
         y = y + residual
@@ -135,11 +135,25 @@ class Bottleneck(nn.Module):
         self.bn3 = nn.BatchNorm2d(planes * 4)
         self.downsample = downsample
 
-    def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        out = bn_act(self.bn1, self.conv1(x), 'relu')
+    def forward(self, x, dual_out=False):
+        """`x` may be a pair (main, alias) produced by the previous block with dual_out=True: two tensors on one storage,
+        one per consumer (conv1 / residual branch), so that their gradients reach the producing BatchNorm kernel separately
+        and are summed there instead of by an autograd add over the whole activation."""
+        x_main, x_res = x if isinstance(x, tuple) else (x, x)
+        idt = x_res if self.downsample is None else self.downsample(x_res)
+        out = bn_act(self.bn1, self.conv1(x_main), 'relu')
         out = bn_act(self.bn2, self.conv2(out), 'relu')
-        return bn_act(self.bn3, self.conv3(out), 'relu', residual=idt)
+        return bn_act(self.bn3, self.conv3(out), 'relu', residual=idt, dual=dual_out)
+
+
+class _Stage(nn.Sequential):
+    """Bottlenecks in sequence; a block followed by another block of the stage hands its output over as a (main, alias) pair."""
+
+    def forward(self, x):
+        last = len(self) - 1
+        for i, blk in enumerate(self):
+            x = blk(x, dual_out=i < last)
+        return x
 
 
 class ResNet50Encoder(nn.Module):
@@ -164,7 +178,7 @@ class ResNet50Encoder(nn.Module):
         layers = [Bottleneck(self.cin, planes, stride, dilation, down)]
         self.cin = planes * 4
         layers += [Bottleneck(self.cin, planes, 1, dilation) for _ in range(1, blocks)]
-        return nn.Sequential(*layers)
+        return _Stage(*layers)
 
     def forward(self, x):
         x = self.pool(self.stem(x))

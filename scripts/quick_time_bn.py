@@ -25,7 +25,7 @@ for C, S in shapes:
         y = F.relu(F.batch_norm(x, rm, rv, w, b, True, 0.1, 1e-5))
         y.backward(g)
     def ours_f():
-        with torch.no_grad(): _lib._BatchNormAct.apply(x, None, w, b, rm, rv, 0.1, 1e-5, 1)
+        with torch.no_grad(): _lib._BatchNormAct.apply(x, None, w, b, rm, rv, 0.1, 1e-5, 1, False)
     def ref_f():
         with torch.no_grad(): F.relu(F.batch_norm(x, rm, rv, w, b, True, 0.1, 1e-5))
     to, tr, tof, trf = bench(ours), bench(ref), bench(ours_f), bench(ref_f)

@@ -106,7 +106,7 @@ def test_backbone_fused_bn_matches_module_path(hip, encoder):
     rm1 = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
     saved = deeplab.bn_act
 
-    def module_path(bn, t, act=None, residual=None):
+    def module_path(bn, t, act=None, residual=None, dual=False):
         y = bn(t)
         if residual is not None:
             y = y + residual
@@ -124,3 +124,46 @@ def test_backbone_fused_bn_matches_module_path(hip, encoder):
     assert (ge1 - ge2).abs().max().item() <= 2e-2 * max(1e-3, ge2.abs().max().item())
     for k in rm1:
         assert torch.allclose(rm1[k].float(), rm2[k].float(), rtol=1e-3, atol=1e-4), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_bn_dual_output_sums_both_gradients(hip, dtype, with_res):
+    """dual=True hands the output out twice (same storage); gradients arriving through the two handles are summed inside
+    the backward kernel -- same result as using one output tensor twice."""
+    torch.manual_seed(9)
+    shape = (3, 16, 8, 16)
+    C = shape[1]
+    x0 = torch.randn(shape, device="cuda").to(dtype)
+    r0 = torch.randn(shape, device="cuda").to(dtype) if with_res else None
+    w0, b0 = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.2
+    ga, gb = torch.randn(shape, device="cuda").to(dtype), torch.randn(shape, device="cuda").to(dtype)
+
+    def run(dual):
+        x = x0.clone().requires_grad_(True)
+        r = r0.clone().requires_grad_(True) if with_res else None
+        w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        out = hip.batch_norm_act(x, w, b, torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), True, 0.1, 1e-5, 1, r, dual=dual)
+        if dual:
+            ya, yb = out
+            assert ya.data_ptr() == yb.data_ptr()
+        else:
+            ya = yb = out
+        torch.autograd.backward([ya, yb], [ga, gb])
+        return ya.detach().float(), x.grad.float(), w.grad, b.grad, (r.grad.float() if with_res else None)
+
+    a, b = run(True), run(False)
+    lo = dtype == torch.bfloat16
+    assert torch.equal(a[0], b[0])
+    assert (a[1] - b[1]).abs().max().item() <= (6e-2 if lo else 1e-5)
+    assert (a[2] - b[2]).abs().max().item() <= (0.5 if lo else 1e-4) and (a[3] - b[3]).abs().max().item() <= (0.5 if lo else 1e-4)
+    if with_res:
+        assert (a[4] - b[4]).abs().max().item() <= (6e-2 if lo else 1e-6)
+    # only one of the two handles used: the other gradient is absent
+    x = x0.clone().requires_grad_(True)
+    ya, yb = hip.batch_norm_act(x, w0, b0, torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), True, 0.1, 1e-5, 1, r0, dual=True)
+    yb.backward(gb)
+    x2 = x0.clone().requires_grad_(True)
+    y2 = hip.batch_norm_act(x2, w0, b0, torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), True, 0.1, 1e-5, 1, r0)
+    y2.backward(gb)
+    assert (x.grad.float() - x2.grad.float()).abs().max().item() <= (6e-2 if lo else 1e-6)
