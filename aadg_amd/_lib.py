@@ -99,7 +99,7 @@ def load():
     lib.aadg_bn_forward.restype = _i
     lib.aadg_bn_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]
     lib.aadg_bn_backward.restype = _i
-    lib.aadg_bn_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]
+    lib.aadg_bn_backward.argtypes = [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]
     lib.aadg_dwconv3x3_supported.restype = _i
     lib.aadg_dwconv3x3_supported.argtypes = [_i, _i, _i, _i]
     lib.aadg_dwconv3x3_workspace_bytes.restype = _sz
@@ -497,12 +497,12 @@ def _bn_ws(C, device):
 
 class _BatchNormAct(torch.autograd.Function):
     """act(batch_norm(x) [+ residual]) with the HIP streaming kernels (csrc/batchnorm.hip); training mode.
-    dual = True returns the output twice (two tensors on one storage): a consumer pair such as the next bottleneck's
-    first convolution and its residual branch then delivers two separate gradients, which the backward kernel sums while
-    reading them instead of autograd running an elementwise add over the full activation first."""
+    handles = k > 1 returns the output k times (k tensors on one storage), one per consumer -- e.g. the next bottleneck's
+    first convolution and its residual branch, or the five ASPP branches: the consumers then deliver separate gradients,
+    which the backward kernel sums while reading them instead of autograd running elementwise adds over the full activation."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, act, dual):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, act, handles):
         lib = load()
         N, C, H, W = x.shape
         y = torch.empty_like(x)
@@ -515,35 +515,41 @@ class _BatchNormAct(torch.autograd.Function):
         _check(rc, "aadg_bn_forward")
         ctx.act = act
         ctx.has_res = residual is not None
-        ctx.dual = bool(dual)
         # the activation mask is re-derived from x (no residual) or from the stored output (residual fused)
         ctx.save_for_backward(x, y if ctx.has_res else None, weight, bias, mean, invstd)
-        if ctx.dual:
-            return y, y.view_as(y)
+        if handles > 1:
+            return (y,) + tuple(y.view_as(y) for _ in range(handles - 1))
         return y
 
     @staticmethod
-    def backward(ctx, dy, dy_b=None):
+    def backward(ctx, *grads):
         lib = load()
         x, y, weight, bias, mean, invstd = ctx.saved_tensors
         N, C, H, W = x.shape
-        if dy is None:                       # only the alias was used
-            dy, dy_b = dy_b, None
-        dy = dy.contiguous()
-        if dy_b is not None:
-            dy_b = dy_b.contiguous()
-            if not ctx.has_res:              # the fused sum rides on the materialised masked gradient of the residual case
-                dy, dy_b = dy + dy_b, None
+        grads = [g.contiguous() for g in grads if g is not None]      # unused handles deliver no gradient
+        if not grads:
+            grads = [torch.zeros_like(x)]
+        if len(grads) > 1 and (not ctx.has_res or len(grads) > 1 + BN_MAX_EXTRA):
+            # the fused sum rides on the materialised masked gradient of the residual case
+            total = grads[0]
+            for g in grads[1:]:
+                total = total + g
+            grads = [total]
+        dy, extra = grads[0], grads[1:]
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         dw = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _bn_ws(C, x.device)
-        rc = lib.aadg_bn_backward(x.data_ptr(), _ptr(y), dy.data_ptr(), _ptr(dy_b), _ptr(weight), _ptr(bias), mean.data_ptr(),
-                                  invstd.data_ptr(), ctx.act, dx.data_ptr(), _ptr(dres), dw.data_ptr(), db.data_ptr(),
-                                  N, C, H * W, _BN_DTYPES[x.dtype], ws.data_ptr(), ws.numel(), _stream())
+        rc = lib.aadg_bn_backward(x.data_ptr(), _ptr(y), dy.data_ptr(), _ptr_array(extra) if extra else None, len(extra),
+                                  _ptr(weight), _ptr(bias), mean.data_ptr(), invstd.data_ptr(), ctx.act, dx.data_ptr(),
+                                  _ptr(dres), dw.data_ptr(), db.data_ptr(), N, C, H * W, _BN_DTYPES[x.dtype], ws.data_ptr(),
+                                  ws.numel(), _stream())
         _check(rc, "aadg_bn_backward")
         return (dx, dres, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None)
+
+
+BN_MAX_EXTRA = 6
 
 
 def bn_act_supported(x, residual=None):
@@ -551,14 +557,16 @@ def bn_act_supported(x, residual=None):
             (residual is None or (residual.is_contiguous() and residual.dtype == x.dtype and residual.shape == x.shape)))
 
 
-def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentum, eps, act=ACT_NONE, residual=None, dual=False):
-    """act(F.batch_norm(x, ...) [+ residual]) on NCHW float32 / bfloat16 GPU tensors.  dual = True (training only) returns the
-    output as a pair of tensors on one storage, see _BatchNormAct."""
+def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentum, eps, act=ACT_NONE, residual=None, dual=False,
+                   handles=None):
+    """act(F.batch_norm(x, ...) [+ residual]) on NCHW float32 / bfloat16 GPU tensors.  handles = k > 1 (training only; dual =
+    True means k = 2) returns the output as a tuple of k tensors on one storage, one per consumer, see _BatchNormAct."""
+    handles = int(handles) if handles else (2 if dual else 1)
     _require_cuda(x, residual)
     if not bn_act_supported(x, residual):
         raise AadgError("batch_norm_act: expected contiguous NCHW float32/bfloat16 tensors")
     if training:
-        return _BatchNormAct.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), int(act), bool(dual))
+        return _BatchNormAct.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), int(act), handles)
     lib = load()
     N, C, H, W = x.shape
     if x.requires_grad or (residual is not None and residual.requires_grad):

@@ -126,12 +126,18 @@ __device__ __forceinline__ float2 block_sum2(float a, float b) {
     return r;
 }
 
+constexpr int BN_MAX_EXTRA = 6;
+template <typename T> struct BnExtra {      // further gradients of the same output (one per additional consumer)
+    const T* p[BN_MAX_EXTRA];
+    int n;
+};
+
 // ---- reductions: grid (split, C) ---------------------------------------------------------------------------
 // MODE 0: sum x, sum x^2.   MODE 1: g = dy * act'(v) with v = the forward's stored output (recomputed from x, or read
 // from y when a residual was fused); sums g and g * (x - mean) * invstd; writes g to dres when dres != nullptr.
 template <typename T, int VEC, int MODE>
 __global__ __launch_bounds__(256) void k_bn_reduce(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
-                                                   const T* __restrict__ dy2, T* __restrict__ dres, const float* __restrict__ mean,
+                                                   BnExtra<T> more, T* __restrict__ dres, const float* __restrict__ mean,
                                                    const float* __restrict__ invstd, const float* __restrict__ scale,
                                                    const float* __restrict__ shift, int act, int C, int len, int per_strip,
                                                    int plen, int total, float* __restrict__ partial) {
@@ -155,9 +161,10 @@ __global__ __launch_bounds__(256) void k_bn_reduce(const T* __restrict__ x, cons
             } else {
                 float gv[VEC], yv[VEC];
                 if (VEC == 1) gv[0] = Pack<T>::load1(dy + off); else Pack<T>::load(dy + off, gv);
-                if (dy2 != nullptr) {            // the output had two consumers: their gradients are summed here, not in a separate pass
+                // the output had several consumers: their gradients are summed here, not by separate elementwise passes
+                for (int e = 0; e < more.n; ++e) {
                     float g2[VEC];
-                    if (VEC == 1) g2[0] = Pack<T>::load1(dy2 + off); else Pack<T>::load(dy2 + off, g2);
+                    if (VEC == 1) g2[0] = Pack<T>::load1(more.p[e] + off); else Pack<T>::load(more.p[e] + off, g2);
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) gv[i] += g2[i];
                 }
@@ -337,11 +344,11 @@ int bn_forward(const T* x, const T* res, T* y, const float* weight, const float*
     if (training) {
         const dim3 grid(s.split, C);
         if (s.vec > 1)
-            hipLaunchKernelGGL((k_bn_reduce<T, Pack<T>::N, 0>), grid, blk, 0, st, x, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, (T*)nullptr,
+            hipLaunchKernelGGL((k_bn_reduce<T, Pack<T>::N, 0>), grid, blk, 0, st, x, (const T*)nullptr, (const T*)nullptr, BnExtra<T>{}, (T*)nullptr,
                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act, C,
                                s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         else
-            hipLaunchKernelGGL((k_bn_reduce<T, 1, 0>), grid, blk, 0, st, x, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, (T*)nullptr,
+            hipLaunchKernelGGL((k_bn_reduce<T, 1, 0>), grid, blk, 0, st, x, (const T*)nullptr, (const T*)nullptr, BnExtra<T>{}, (T*)nullptr,
                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act, C,
                                s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         AADG_LAUNCH_CHECK();
@@ -363,7 +370,7 @@ int bn_forward(const T* x, const T* res, T* y, const float* weight, const float*
 }
 
 template <typename T>
-int bn_backward(const T* x, const T* y, const T* dy, const T* dy2, const float* weight, const float* bias, const float* mean, const float* invstd,
+int bn_backward(const T* x, const T* y, const T* dy, const void* const* dy_extra, int n_extra, const float* weight, const float* bias, const float* mean, const float* invstd,
                 int act, T* dx, T* dres, float* dweight, float* dbias, int N, int C, int HW, float* ws, hipStream_t st) {
     Shape s;
     if (!make_shape<T>(N, C, HW, x, y, dy, dx, &s) || (((uintptr_t)dres & 15u) && s.vec > 1)) return AADG_E_BADARG;
@@ -371,15 +378,21 @@ int bn_backward(const T* x, const T* y, const T* dy, const T* dy2, const float* 
     float* scale = ws + L.scale;
     float* shift = ws + L.shift;
     const dim3 blk(s.threads);
+    BnExtra<T> more = {};
+    for (int e = 0; e < n_extra; ++e) {
+        if (dy_extra[e] == nullptr || (((uintptr_t)dy_extra[e]) & 15u)) return AADG_E_BADARG;
+        more.p[e] = (const T*)dy_extra[e];
+    }
+    more.n = n_extra;
     hipLaunchKernelGGL(k_bn_scale_shift, dim3((C + 255) / 256), dim3(256), 0, st, C, weight, bias, mean, invstd, 0.0f, 0, scale, shift);
     AADG_LAUNCH_CHECK();
     {
         const dim3 grid(s.split, C);
         if (s.vec > 1)
-            hipLaunchKernelGGL((k_bn_reduce<T, Pack<T>::N, 1>), grid, blk, 0, st, x, y, dy, dy2, dres, mean, invstd, (const float*)scale,
+            hipLaunchKernelGGL((k_bn_reduce<T, Pack<T>::N, 1>), grid, blk, 0, st, x, y, dy, more, dres, mean, invstd, (const float*)scale,
                                (const float*)shift, act, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         else
-            hipLaunchKernelGGL((k_bn_reduce<T, 1, 1>), grid, blk, 0, st, x, y, dy, dy2, dres, mean, invstd, (const float*)scale,
+            hipLaunchKernelGGL((k_bn_reduce<T, 1, 1>), grid, blk, 0, st, x, y, dy, more, dres, mean, invstd, (const float*)scale,
                                (const float*)shift, act, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         AADG_LAUNCH_CHECK();
     }
@@ -427,22 +440,24 @@ extern "C" int aadg_bn_forward(const void* x, const void* residual, void* y, con
     return AADG_E_BADARG;
 }
 
-extern "C" int aadg_bn_backward(const void* x, const void* y, const void* dy, const void* dy2, const float* weight, const float* bias,
+extern "C" int aadg_bn_backward(const void* x, const void* y, const void* dy, const void* const* dy_extra, int n_extra,
+                                const float* weight, const float* bias,
                                 const float* save_mean, const float* save_invstd, int act, void* dx, void* dres, float* dweight,
                                 float* dbias, int N, int C, int HW, int dtype, void* ws, size_t ws_bytes, void* stream) {
     if (x == nullptr || dy == nullptr || dx == nullptr || save_mean == nullptr || save_invstd == nullptr || ws == nullptr ||
         act < 0 || act > AADG_ACT_RELU6)
         return AADG_E_BADARG;
     if (dres != nullptr && y == nullptr) return AADG_E_BADARG;   // a fused residual needs the stored output for the mask
-    if (dy2 != nullptr && (dres == nullptr || (((uintptr_t)dy2) & 15u))) return AADG_E_BADARG;   // summed gradients are materialised as dres
+    if (n_extra < 0 || n_extra > BN_MAX_EXTRA || (n_extra > 0 && (dy_extra == nullptr || dres == nullptr)))
+        return AADG_E_BADARG;                                     // summed gradients are materialised as dres
     if (C <= 0 || ws_bytes < aadg_bn_workspace_bytes(C)) return AADG_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
-        return bn_backward<float>((const float*)x, (const float*)y, (const float*)dy, (const float*)dy2, weight, bias, save_mean, save_invstd, act,
+        return bn_backward<float>((const float*)x, (const float*)y, (const float*)dy, dy_extra, n_extra, weight, bias, save_mean, save_invstd, act,
                                   (float*)dx, (float*)dres, dweight, dbias, N, C, HW, (float*)ws, st);
     if (dtype == 1)
-        return bn_backward<__hip_bfloat16>((const __hip_bfloat16*)x, (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy,
-                                           (const __hip_bfloat16*)dy2, weight,
+        return bn_backward<__hip_bfloat16>((const __hip_bfloat16*)x, (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy, dy_extra,
+                                           n_extra, weight,
                                            bias, save_mean, save_invstd, act, (__hip_bfloat16*)dx, (__hip_bfloat16*)dres, dweight,
                                            dbias, N, C, HW, (float*)ws, st);
     return AADG_E_BADARG;

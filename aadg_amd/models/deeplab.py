@@ -28,7 +28,7 @@ def _upsample_ac(x, size):
 _ACT_CODE = {None: 0, 'relu': 1, 'relu6': 2}
 
 
-def bn_act(bn, x, act=None, residual=None, dual=False):
+def bn_act(bn, x, act=None, residual=None, handles=1):
     """act(bn(x) [+ residual]).  On the GPU a plain `nn.BatchNorm2d` runs as the fused HIP streaming kernels
     (csrc/batchnorm.hip: statistics, normalise + activation + residual add in one pass, two-pass backward); anything
     else (SyncBatchNorm after `--sync_bn`, CPU shape tests) takes the module's own path."""
@@ -40,7 +40,8 @@ def bn_act(bn, x, act=None, residual=None, dual=False):
             if bn.training:
                 bn.num_batches_tracked.add_(1)
             return _lib.batch_norm_act(xc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum,
-                                       bn.eps, _ACT_CODE[act], rc, dual=dual and bn.training and torch.is_grad_enabled())
+                                       bn.eps, _ACT_CODE[act], rc,
+                                       handles=handles if (bn.training and torch.is_grad_enabled() and rc is not None) else 1)
     y = bn(x)
     if residual is not None:
         y = y + residual
@@ -135,25 +136,34 @@ class Bottleneck(nn.Module):
         self.bn3 = nn.BatchNorm2d(planes * 4)
         self.downsample = downsample
 
-    def forward(self, x, dual_out=False):
-        """`x` may be a pair (main, alias) produced by the previous block with dual_out=True: two tensors on one storage,
-        one per consumer (conv1 / residual branch), so that their gradients reach the producing BatchNorm kernel separately
-        and are summed there instead of by an autograd add over the whole activation."""
-        x_main, x_res = x if isinstance(x, tuple) else (x, x)
+    def forward(self, x, handles=1):
+        """`x` may be a tuple (main, alias, ...) produced by the previous block with handles > 1: tensors on one storage,
+        one per consumer (conv1 / residual branch or downsample), so that their gradients reach the producing BatchNorm
+        kernel separately and are summed there instead of by autograd adds over the whole activation."""
+        x_main, x_res = (x[0], x[1]) if isinstance(x, tuple) else (x, x)
         idt = x_res if self.downsample is None else self.downsample(x_res)
         out = bn_act(self.bn1, self.conv1(x_main), 'relu')
         out = bn_act(self.bn2, self.conv2(out), 'relu')
-        return bn_act(self.bn3, self.conv3(out), 'relu', residual=idt, dual=dual_out)
+        return bn_act(self.bn3, self.conv3(out), 'relu', residual=idt, handles=handles)
 
 
 class _Stage(nn.Sequential):
-    """Bottlenecks in sequence; a block followed by another block of the stage hands its output over as a (main, alias) pair."""
+    """Bottlenecks in sequence.  A block output consumed by the next block is handed over as a (main, alias) pair; the
+    stage output gets `out_handles` handles (one per consumer outside the stage)."""
 
-    def forward(self, x):
+    def forward(self, x, out_handles=1):
         last = len(self) - 1
         for i, blk in enumerate(self):
-            x = blk(x, dual_out=i < last)
+            x = blk(x, handles=2 if i < last else out_handles)
         return x
+
+
+def _handles(x, k):
+    """k per-consumer handles of a stage output (the tensor itself k times when it came as a plain tensor)."""
+    if isinstance(x, tuple):
+        assert len(x) >= k
+        return list(x[:k])
+    return [x] * k
 
 
 class ResNet50Encoder(nn.Module):
@@ -180,11 +190,15 @@ class ResNet50Encoder(nn.Module):
         layers += [Bottleneck(self.cin, planes, 1, dilation) for _ in range(1, blocks)]
         return _Stage(*layers)
 
+    deep_handles = 6     # consumers of the encoder output: four ASPP convolutions, the image pool, the pooled feature
+
     def forward(self, x):
         x = self.pool(self.stem(x))
-        skip = self.layer1(x)
-        x = self.layer4(self.layer3(self.layer2(skip)))
-        return skip, x
+        s = _handles(self.layer1(x, out_handles=3), 3)            # layer2's conv1, layer2's downsample, the decoder skip
+        x = self.layer2((s[0], s[1]), out_handles=2)
+        x = self.layer3(x, out_handles=2)
+        x = self.layer4(x, out_handles=self.deep_handles)
+        return s[2], x
 
 
 # ---------------------------------------------------------------------------------------------- MobileNetV2
@@ -246,9 +260,10 @@ class ASPP(nn.Module):
         self.project = nn.Sequential(Conv1x1(cout * 5, cout), *_bn_relu(cout), nn.Dropout(0.5))
 
     def forward(self, x):
-        outs = [b(x) for b in self.branches]
+        h = _handles(x, len(self.branches) + 1)                    # one handle of the encoder output per branch
+        outs = [b(hx) for b, hx in zip(self.branches, h)]
         # bilinear up-sampling of a 1x1 map is a broadcast (ATen's kernel would walk all N*C planes in one workgroup)
-        outs.append(self.image_pool(x).expand(-1, -1, x.shape[-2], x.shape[-1]))
+        outs.append(self.image_pool(h[-1]).expand(-1, -1, h[-1].shape[-2], h[-1].shape[-1]))
         return self.project(torch.cat(outs, dim=1))
 
 
@@ -270,7 +285,12 @@ class DeepLabV3Plus(nn.Module):
 
     def forward(self, x):
         skip, deep = self.encoder(x)
-        y = _upsample_ac(self.aspp(deep), skip.shape[-2:])
+        hd = _handles(deep, 6)
+        deep = hd[5]
+        a = self.aspp[0](tuple(hd[:5]))                  # ASPP takes one handle of the encoder output per branch
+        for mod in list(self.aspp)[1:]:
+            a = mod(a)
+        y = _upsample_ac(a, skip.shape[-2:])
         y = self.fuse(torch.cat([y, self.skip(skip)], dim=1))
         mask = _upsample_ac(self.classifier(y), x.shape[-2:])
         if not self.aux_pooling:

@@ -179,9 +179,10 @@ int aadg_upsample_bilinear2d_backward(const void* dy, void* dx, int planes, int 
  * weight / bias / statistics are float32 [C].  act: AADG_ACT_*.  residual (nullable): y = act(bn(x) + residual).
  * training = 0 normalises with running_mean / running_var and writes no statistics.
  * Backward: dx, dweight, dbias (nullable) and, if dres != NULL, dres = dy * act'(.) = gradient of the residual
- * branch (then y, the stored forward output, must be given: the activation mask is taken from it).  dy2 (nullable, only
- * with dres): a second gradient of the same output -- a block output feeds the next block's first convolution AND its
- * residual branch -- summed on the fly instead of by a separate elementwise pass.
+ * branch (then y, the stored forward output, must be given: the activation mask is taken from it).  dy_extra (host array of
+ * n_extra <= 6 device pointers, only with dres): further gradients of the same output -- a block output feeds the next
+ * block's first convolution AND its residual branch, the encoder output feeds five ASPP branches -- summed on the fly
+ * instead of by separate elementwise passes.
  * ------------------------------------------------------------------------------------------- */
 enum { AADG_ACT_NONE = 0, AADG_ACT_RELU = 1, AADG_ACT_RELU6 = 2 };
 size_t aadg_bn_workspace_bytes(int C);
@@ -189,7 +190,8 @@ int aadg_bn_forward(const void* x, const void* residual, void* y, const float* w
                     float* running_mean, float* running_var, float momentum, float eps, int act, int training,
                     int N, int C, int HW, int dtype, float* save_mean, float* save_invstd, void* ws,
                     size_t ws_bytes, void* stream);
-int aadg_bn_backward(const void* x, const void* y, const void* dy, const void* dy2, const float* weight, const float* bias,
+int aadg_bn_backward(const void* x, const void* y, const void* dy, const void* const* dy_extra, int n_extra,
+                     const float* weight, const float* bias,
                      const float* save_mean, const float* save_invstd, int act, void* dx, void* dres,
                      float* dweight, float* dbias, int N, int C, int HW, int dtype, void* ws, size_t ws_bytes,
                      void* stream);

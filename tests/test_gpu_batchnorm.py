@@ -106,7 +106,7 @@ def test_backbone_fused_bn_matches_module_path(hip, encoder):
     rm1 = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
     saved = deeplab.bn_act
 
-    def module_path(bn, t, act=None, residual=None, dual=False):
+    def module_path(bn, t, act=None, residual=None, handles=1):
         y = bn(t)
         if residual is not None:
             y = y + residual
@@ -124,6 +124,27 @@ def test_backbone_fused_bn_matches_module_path(hip, encoder):
     assert (ge1 - ge2).abs().max().item() <= 2e-2 * max(1e-3, ge2.abs().max().item())
     for k in rm1:
         assert torch.allclose(rm1[k].float(), rm2[k].float(), rtol=1e-3, atol=1e-4), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_many_handles_sum_all_gradients(hip, dtype):
+    """handles = 6 (the encoder output: five ASPP branches + the pooled feature): six gradients summed in the kernel."""
+    torch.manual_seed(4)
+    shape = (2, 8, 8, 16)
+    x0 = torch.randn(shape, device="cuda").to(dtype)
+    r0 = torch.randn(shape, device="cuda").to(dtype)
+    w0, b0 = torch.rand(8, device="cuda") + 0.5, torch.randn(8, device="cuda") * 0.2
+    gs = [torch.randn(shape, device="cuda").to(dtype) for _ in range(6)]
+    res = []
+    for k in (6, 1):
+        x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        out = hip.batch_norm_act(x, w0, b0, torch.zeros(8, device="cuda"), torch.ones(8, device="cuda"), True, 0.1, 1e-5, 1, r, handles=k)
+        outs = list(out) if k > 1 else [out] * 6
+        assert len(outs) == 6
+        torch.autograd.backward(outs, gs)
+        res.append((x.grad.float(), r.grad.float()))
+    tol = 0.15 if dtype == torch.bfloat16 else 1e-5          # bf16: the reference rounds every partial sum
+    assert (res[0][0] - res[1][0]).abs().max().item() <= tol and (res[0][1] - res[1][1]).abs().max().item() <= tol
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
