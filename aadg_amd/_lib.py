@@ -35,7 +35,7 @@ EXPORTS = [
     "aadg_fop_workspace_bytes", "aadg_fop_f32",
     "aadg_upsample_bilinear2d", "aadg_upsample_bilinear2d_backward_supported", "aadg_upsample_bilinear2d_backward",
     "aadg_upsample_bilinear2d_backward_workspace_bytes",
-    "aadg_bn_workspace_bytes", "aadg_bn_forward", "aadg_bn_backward",
+    "aadg_bn_workspace_bytes", "aadg_bn_mask_bytes", "aadg_bn_forward", "aadg_bn_backward",
     "aadg_dwconv3x3_supported", "aadg_dwconv3x3_workspace_bytes", "aadg_dwconv3x3", "aadg_dwconv3x3_wgrad",
     "aadg_maxpool3x3s2_supported", "aadg_maxpool3x3s2_forward", "aadg_maxpool3x3s2_backward",
     "aadg_conv1x1_wgrad_supported", "aadg_conv1x1_wgrad_bf16",
@@ -97,9 +97,11 @@ def load():
     lib.aadg_bn_workspace_bytes.restype = _sz
     lib.aadg_bn_workspace_bytes.argtypes = [_i]
     lib.aadg_bn_forward.restype = _i
-    lib.aadg_bn_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]
+    lib.aadg_bn_mask_bytes.restype = _sz
+    lib.aadg_bn_mask_bytes.argtypes = [_i, _i, _i, _i]
+    lib.aadg_bn_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]
     lib.aadg_bn_backward.restype = _i
-    lib.aadg_bn_backward.argtypes = [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]
+    lib.aadg_bn_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]
     lib.aadg_dwconv3x3_supported.restype = _i
     lib.aadg_dwconv3x3_supported.argtypes = [_i, _i, _i, _i]
     lib.aadg_dwconv3x3_workspace_bytes.restype = _sz
@@ -509,14 +511,20 @@ class _BatchNormAct(torch.autograd.Function):
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _bn_ws(C, x.device)
-        rc = lib.aadg_bn_forward(x.data_ptr(), _ptr(residual), y.data_ptr(), _ptr(weight), _ptr(bias), _ptr(running_mean),
-                                 _ptr(running_var), momentum, eps, act, 1, N, C, H * W, _BN_DTYPES[x.dtype],
+        mask = None
+        if residual is not None and act != ACT_NONE:
+            nb = lib.aadg_bn_mask_bytes(N, C, H * W, _BN_DTYPES[x.dtype])
+            if nb and (x.data_ptr() | residual.data_ptr() | y.data_ptr()) % 16 == 0:
+                mask = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        rc = lib.aadg_bn_forward(x.data_ptr(), _ptr(residual), y.data_ptr(), _ptr(mask), _ptr(weight), _ptr(bias),
+                                 _ptr(running_mean), _ptr(running_var), momentum, eps, act, 1, N, C, H * W, _BN_DTYPES[x.dtype],
                                  mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
         _check(rc, "aadg_bn_forward")
         ctx.act = act
         ctx.has_res = residual is not None
-        # the activation mask is re-derived from x (no residual) or from the stored output (residual fused)
-        ctx.save_for_backward(x, y if ctx.has_res else None, weight, bias, mean, invstd)
+        # the activation mask is re-derived from x (no residual), or taken from the bit mask the forward wrote (fused residual;
+        # 1/16 of the output's bytes) or, where that is not available, from the stored output
+        ctx.save_for_backward(x, y if (ctx.has_res and mask is None) else None, mask, weight, bias, mean, invstd)
         if handles > 1:
             return (y,) + tuple(y.view_as(y) for _ in range(handles - 1))
         return y
@@ -524,7 +532,7 @@ class _BatchNormAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         lib = load()
-        x, y, weight, bias, mean, invstd = ctx.saved_tensors
+        x, y, mask, weight, bias, mean, invstd = ctx.saved_tensors
         N, C, H, W = x.shape
         grads = [g.contiguous() for g in grads if g is not None]      # unused handles deliver no gradient
         if not grads:
@@ -541,7 +549,7 @@ class _BatchNormAct(torch.autograd.Function):
         dw = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _bn_ws(C, x.device)
-        rc = lib.aadg_bn_backward(x.data_ptr(), _ptr(y), dy.data_ptr(), _ptr_array(extra) if extra else None, len(extra),
+        rc = lib.aadg_bn_backward(x.data_ptr(), _ptr(y), _ptr(mask), dy.data_ptr(), _ptr_array(extra) if extra else None, len(extra),
                                   _ptr(weight), _ptr(bias), mean.data_ptr(), invstd.data_ptr(), ctx.act, dx.data_ptr(),
                                   _ptr(dres), dw.data_ptr(), db.data_ptr(), N, C, H * W, _BN_DTYPES[x.dtype], ws.data_ptr(),
                                   ws.numel(), _stream())
@@ -573,7 +581,7 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
         raise AadgError("batch_norm_act: inference mode is forward-only")
     y = torch.empty_like(x)
     ws = _bn_ws(C, x.device)
-    rc = lib.aadg_bn_forward(x.data_ptr(), _ptr(residual), y.data_ptr(), _ptr(weight), _ptr(bias), running_mean.data_ptr(),
+    rc = lib.aadg_bn_forward(x.data_ptr(), _ptr(residual), y.data_ptr(), None, _ptr(weight), _ptr(bias), running_mean.data_ptr(),
                              running_var.data_ptr(), 0.0, float(eps), int(act), 0, N, C, H * W, _BN_DTYPES[x.dtype],
                              None, None, ws.data_ptr(), ws.numel(), _stream())
     _check(rc, "aadg_bn_forward")

@@ -137,7 +137,7 @@ template <typename T> struct BnExtra {      // further gradients of the same out
 // from y when a residual was fused); sums g and g * (x - mean) * invstd; writes g to dres when dres != nullptr.
 template <typename T, int VEC, int MODE>
 __global__ __launch_bounds__(256) void k_bn_reduce(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
-                                                   BnExtra<T> more, T* __restrict__ dres, const float* __restrict__ mean,
+                                                   BnExtra<T> more, const uint8_t* __restrict__ mask, T* __restrict__ dres, const float* __restrict__ mean,
                                                    const float* __restrict__ invstd, const float* __restrict__ scale,
                                                    const float* __restrict__ shift, int act, int C, int len, int per_strip,
                                                    int plen, int total, float* __restrict__ partial) {
@@ -168,15 +168,19 @@ __global__ __launch_bounds__(256) void k_bn_reduce(const T* __restrict__ x, cons
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) gv[i] += g2[i];
                 }
-                if (y != nullptr) {
+                uint32_t mbits = 0;
+                if (VEC > 1 && mask != nullptr) mbits = mask[(size_t)((size_t)n * C + c) * len + j];   // 1 byte instead of a 16-byte vector of y
+                else if (y != nullptr) {
                     if (VEC == 1) yv[0] = Pack<T>::load1(y + off); else Pack<T>::load(y + off, yv);
                 }
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     // pre-activation value as the forward saw it: the stored output when we have it (for ReLU the
                     // sign of the output decides; ReLU6 needs the interval, still decidable from the clamped value)
-                    const float v = y != nullptr ? yv[i] : Pack<T>::round(fmaf(xv[i], sc, sh));
-                    const float g = act_open(v, act) ? gv[i] : 0.0f;
+                    bool open;
+                    if (VEC > 1 && mask != nullptr) open = (mbits >> i) & 1u;
+                    else open = act_open(y != nullptr ? yv[i] : Pack<T>::round(fmaf(xv[i], sc, sh)), act);
+                    const float g = open ? gv[i] : 0.0f;
                     gv[i] = g;
                     s0 += g;
                     s1 = fmaf(g, (xv[i] - mu) * is, s1);
@@ -261,8 +265,8 @@ __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const float* __restrict
 // ---- elementwise passes: grid (N*C strips, pieces per strip) ------------------------------------------------
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
-                                                  const float* __restrict__ scale, const float* __restrict__ shift, int act,
-                                                  int C, int len, int plen) {
+                                                  uint8_t* __restrict__ mask, const float* __restrict__ scale,
+                                                  const float* __restrict__ shift, int act, int C, int len, int plen) {
     const int strip = blockIdx.x, c = strip % C;
     const float sc = scale[c], sh = shift[c];
     const size_t base = (size_t)strip * len * VEC;
@@ -280,6 +284,12 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const
             float t = fmaf(v[i], sc, sh);
             if (res != nullptr) t = Pack<T>::round(t) + r[i];     // same roundings as bn (stored in T) followed by add
             v[i] = act_fwd(t, act);
+        }
+        if (VEC > 1 && mask != nullptr) {       // one byte per vector: bit i = act'(stored output i) != 0, read back by the backward
+            uint32_t bits = 0;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) bits |= act_open(Pack<T>::round(v[i]), act) ? (1u << i) : 0u;
+            mask[(size_t)strip * len + j] = (uint8_t)bits;
         }
         if (VEC == 1) Pack<T>::store1(y + off, v[0]); else Pack<T>::store(y + off, v);
     }
@@ -332,11 +342,12 @@ inline bool make_shape(int N, int C, int HW, const void* a, const void* b, const
 }
 
 template <typename T>
-int bn_forward(const T* x, const T* res, T* y, const float* weight, const float* bias, float* rmean, float* rvar, float momentum,
+int bn_forward(const T* x, const T* res, T* y, uint8_t* mask, const float* weight, const float* bias, float* rmean, float* rvar, float momentum,
                float eps, int act, int training, int N, int C, int HW, float* save_mean, float* save_invstd, float* ws,
                hipStream_t st) {
     Shape s;
     if (!make_shape<T>(N, C, HW, x, res, y, nullptr, &s)) return AADG_E_BADARG;
+    if (mask != nullptr && s.vec == 1) return AADG_E_BADARG;        // the bit mask exists for the vector path only (aadg_bn_mask_bytes)
     const BnWs L = bn_ws(C);
     float* scale = ws + L.scale;
     float* shift = ws + L.shift;
@@ -344,11 +355,13 @@ int bn_forward(const T* x, const T* res, T* y, const float* weight, const float*
     if (training) {
         const dim3 grid(s.split, C);
         if (s.vec > 1)
-            hipLaunchKernelGGL((k_bn_reduce<T, Pack<T>::N, 0>), grid, blk, 0, st, x, (const T*)nullptr, (const T*)nullptr, BnExtra<T>{}, (T*)nullptr,
+            hipLaunchKernelGGL((k_bn_reduce<T, Pack<T>::N, 0>), grid, blk, 0, st, x, (const T*)nullptr, (const T*)nullptr, BnExtra<T>{},
+                               (const uint8_t*)nullptr, (T*)nullptr,
                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act, C,
                                s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         else
-            hipLaunchKernelGGL((k_bn_reduce<T, 1, 0>), grid, blk, 0, st, x, (const T*)nullptr, (const T*)nullptr, BnExtra<T>{}, (T*)nullptr,
+            hipLaunchKernelGGL((k_bn_reduce<T, 1, 0>), grid, blk, 0, st, x, (const T*)nullptr, (const T*)nullptr, BnExtra<T>{},
+                               (const uint8_t*)nullptr, (T*)nullptr,
                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act, C,
                                s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         AADG_LAUNCH_CHECK();
@@ -362,18 +375,19 @@ int bn_forward(const T* x, const T* res, T* y, const float* weight, const float*
     }
     const dim3 grid(N * C, s.pc.per_strip);
     if (s.vec > 1)
-        hipLaunchKernelGGL((k_bn_apply<T, Pack<T>::N>), grid, blk, 0, st, x, res, y, scale, shift, act, C, s.len, s.pc.plen);
+        hipLaunchKernelGGL((k_bn_apply<T, Pack<T>::N>), grid, blk, 0, st, x, res, y, mask, scale, shift, act, C, s.len, s.pc.plen);
     else
-        hipLaunchKernelGGL((k_bn_apply<T, 1>), grid, blk, 0, st, x, res, y, scale, shift, act, C, s.len, s.pc.plen);
+        hipLaunchKernelGGL((k_bn_apply<T, 1>), grid, blk, 0, st, x, res, y, mask, scale, shift, act, C, s.len, s.pc.plen);
     AADG_LAUNCH_CHECK();
     return 0;
 }
 
 template <typename T>
-int bn_backward(const T* x, const T* y, const T* dy, const void* const* dy_extra, int n_extra, const float* weight, const float* bias, const float* mean, const float* invstd,
+int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const void* const* dy_extra, int n_extra, const float* weight, const float* bias, const float* mean, const float* invstd,
                 int act, T* dx, T* dres, float* dweight, float* dbias, int N, int C, int HW, float* ws, hipStream_t st) {
     Shape s;
     if (!make_shape<T>(N, C, HW, x, y, dy, dx, &s) || (((uintptr_t)dres & 15u) && s.vec > 1)) return AADG_E_BADARG;
+    if (mask != nullptr && s.vec == 1) return AADG_E_BADARG;
     const BnWs L = bn_ws(C);
     float* scale = ws + L.scale;
     float* shift = ws + L.shift;
@@ -389,10 +403,10 @@ int bn_backward(const T* x, const T* y, const T* dy, const void* const* dy_extra
     {
         const dim3 grid(s.split, C);
         if (s.vec > 1)
-            hipLaunchKernelGGL((k_bn_reduce<T, Pack<T>::N, 1>), grid, blk, 0, st, x, y, dy, more, dres, mean, invstd, (const float*)scale,
+            hipLaunchKernelGGL((k_bn_reduce<T, Pack<T>::N, 1>), grid, blk, 0, st, x, y, dy, more, mask, dres, mean, invstd, (const float*)scale,
                                (const float*)shift, act, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         else
-            hipLaunchKernelGGL((k_bn_reduce<T, 1, 1>), grid, blk, 0, st, x, y, dy, more, dres, mean, invstd, (const float*)scale,
+            hipLaunchKernelGGL((k_bn_reduce<T, 1, 1>), grid, blk, 0, st, x, y, dy, more, mask, dres, mean, invstd, (const float*)scale,
                                (const float*)shift, act, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         AADG_LAUNCH_CHECK();
     }
@@ -421,7 +435,15 @@ int bn_backward(const T* x, const T* y, const T* dy, const void* const* dy_extra
 
 extern "C" size_t aadg_bn_workspace_bytes(int C) { return C > 0 ? bn_ws(C).total * sizeof(float) : 0; }
 
-extern "C" int aadg_bn_forward(const void* x, const void* residual, void* y, const float* weight, const float* bias,
+// bytes of the activation bit mask of an [N, C, HW] tensor (one byte per 16-byte vector), 0 when the vector path does not
+// apply (HW not a multiple of the vector length): the backward of a fused residual then reads the stored output instead
+extern "C" size_t aadg_bn_mask_bytes(int N, int C, int HW, int dtype) {
+    const int V = dtype == 0 ? 4 : 8;
+    if (N <= 0 || C <= 0 || HW <= 0 || (dtype != 0 && dtype != 1) || (HW % V) != 0) return 0;
+    return (size_t)N * C * (HW / V);
+}
+
+extern "C" int aadg_bn_forward(const void* x, const void* residual, void* y, void* act_mask, const float* weight, const float* bias,
                                float* running_mean, float* running_var, float momentum, float eps, int act, int training, int N,
                                int C, int HW, int dtype, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
                                void* stream) {
@@ -431,34 +453,35 @@ extern "C" int aadg_bn_forward(const void* x, const void* residual, void* y, con
     if (C <= 0 || ws_bytes < aadg_bn_workspace_bytes(C)) return AADG_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
-        return bn_forward<float>((const float*)x, (const float*)residual, (float*)y, weight, bias, running_mean, running_var,
-                                 momentum, eps, act, training, N, C, HW, save_mean, save_invstd, (float*)ws, st);
+        return bn_forward<float>((const float*)x, (const float*)residual, (float*)y, (uint8_t*)act_mask, weight, bias, running_mean,
+                                 running_var, momentum, eps, act, training, N, C, HW, save_mean, save_invstd, (float*)ws, st);
     if (dtype == 1)
-        return bn_forward<__hip_bfloat16>((const __hip_bfloat16*)x, (const __hip_bfloat16*)residual, (__hip_bfloat16*)y, weight,
-                                          bias, running_mean, running_var, momentum, eps, act, training, N, C, HW, save_mean,
-                                          save_invstd, (float*)ws, st);
+        return bn_forward<__hip_bfloat16>((const __hip_bfloat16*)x, (const __hip_bfloat16*)residual, (__hip_bfloat16*)y,
+                                          (uint8_t*)act_mask, weight, bias, running_mean, running_var, momentum, eps, act, training,
+                                          N, C, HW, save_mean, save_invstd, (float*)ws, st);
     return AADG_E_BADARG;
 }
 
-extern "C" int aadg_bn_backward(const void* x, const void* y, const void* dy, const void* const* dy_extra, int n_extra,
-                                const float* weight, const float* bias,
-                                const float* save_mean, const float* save_invstd, int act, void* dx, void* dres, float* dweight,
-                                float* dbias, int N, int C, int HW, int dtype, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int aadg_bn_backward(const void* x, const void* y, const void* act_mask, const void* dy, const void* const* dy_extra,
+                                int n_extra, const float* weight, const float* bias, const float* save_mean,
+                                const float* save_invstd, int act, void* dx, void* dres, float* dweight, float* dbias, int N, int C,
+                                int HW, int dtype, void* ws, size_t ws_bytes, void* stream) {
     if (x == nullptr || dy == nullptr || dx == nullptr || save_mean == nullptr || save_invstd == nullptr || ws == nullptr ||
         act < 0 || act > AADG_ACT_RELU6)
         return AADG_E_BADARG;
-    if (dres != nullptr && y == nullptr) return AADG_E_BADARG;   // a fused residual needs the stored output for the mask
+    // a fused residual needs the forward's activation mask: the bit mask it wrote, or the stored output
+    if (dres != nullptr && y == nullptr && act_mask == nullptr) return AADG_E_BADARG;
     if (n_extra < 0 || n_extra > BN_MAX_EXTRA || (n_extra > 0 && (dy_extra == nullptr || dres == nullptr)))
         return AADG_E_BADARG;                                     // summed gradients are materialised as dres
     if (C <= 0 || ws_bytes < aadg_bn_workspace_bytes(C)) return AADG_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
-        return bn_backward<float>((const float*)x, (const float*)y, (const float*)dy, dy_extra, n_extra, weight, bias, save_mean, save_invstd, act,
-                                  (float*)dx, (float*)dres, dweight, dbias, N, C, HW, (float*)ws, st);
+        return bn_backward<float>((const float*)x, (const float*)y, (const uint8_t*)act_mask, (const float*)dy, dy_extra, n_extra,
+                                  weight, bias, save_mean, save_invstd, act, (float*)dx, (float*)dres, dweight, dbias, N, C, HW,
+                                  (float*)ws, st);
     if (dtype == 1)
-        return bn_backward<__hip_bfloat16>((const __hip_bfloat16*)x, (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy, dy_extra,
-                                           n_extra, weight,
-                                           bias, save_mean, save_invstd, act, (__hip_bfloat16*)dx, (__hip_bfloat16*)dres, dweight,
-                                           dbias, N, C, HW, (float*)ws, st);
+        return bn_backward<__hip_bfloat16>((const __hip_bfloat16*)x, (const __hip_bfloat16*)y, (const uint8_t*)act_mask,
+                                           (const __hip_bfloat16*)dy, dy_extra, n_extra, weight, bias, save_mean, save_invstd, act,
+                                           (__hip_bfloat16*)dx, (__hip_bfloat16*)dres, dweight, dbias, N, C, HW, (float*)ws, st);
     return AADG_E_BADARG;
 }

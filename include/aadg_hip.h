@@ -179,22 +179,24 @@ int aadg_upsample_bilinear2d_backward(const void* dy, void* dx, int planes, int 
  * weight / bias / statistics are float32 [C].  act: AADG_ACT_*.  residual (nullable): y = act(bn(x) + residual).
  * training = 0 normalises with running_mean / running_var and writes no statistics.
  * Backward: dx, dweight, dbias (nullable) and, if dres != NULL, dres = dy * act'(.) = gradient of the residual
- * branch (then y, the stored forward output, must be given: the activation mask is taken from it).  dy_extra (host array of
+ * branch (then y, the stored forward output, or the forward's act_mask must be given: the activation mask is taken from it).  dy_extra (host array of
  * n_extra <= 6 device pointers, only with dres): further gradients of the same output -- a block output feeds the next
  * block's first convolution AND its residual branch, the encoder output feeds five ASPP branches -- summed on the fly
  * instead of by separate elementwise passes.
  * ------------------------------------------------------------------------------------------- */
 enum { AADG_ACT_NONE = 0, AADG_ACT_RELU = 1, AADG_ACT_RELU6 = 2 };
 size_t aadg_bn_workspace_bytes(int C);
-int aadg_bn_forward(const void* x, const void* residual, void* y, const float* weight, const float* bias,
+/* bytes of the optional activation bit mask (one byte per 16-byte vector; 0 = not available for this shape): a forward with
+ * a fused residual may write it (act_mask != NULL) so that the backward reads 1 byte instead of a 16-byte vector of y */
+size_t aadg_bn_mask_bytes(int N, int C, int HW, int dtype);
+int aadg_bn_forward(const void* x, const void* residual, void* y, void* act_mask, const float* weight, const float* bias,
                     float* running_mean, float* running_var, float momentum, float eps, int act, int training,
                     int N, int C, int HW, int dtype, float* save_mean, float* save_invstd, void* ws,
                     size_t ws_bytes, void* stream);
-int aadg_bn_backward(const void* x, const void* y, const void* dy, const void* const* dy_extra, int n_extra,
-                     const float* weight, const float* bias,
-                     const float* save_mean, const float* save_invstd, int act, void* dx, void* dres,
-                     float* dweight, float* dbias, int N, int C, int HW, int dtype, void* ws, size_t ws_bytes,
-                     void* stream);
+int aadg_bn_backward(const void* x, const void* y, const void* act_mask, const void* dy, const void* const* dy_extra,
+                     int n_extra, const float* weight, const float* bias, const float* save_mean,
+                     const float* save_invstd, int act, void* dx, void* dres, float* dweight, float* dbias, int N,
+                     int C, int HW, int dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Depthwise 3x3 convolution, stride 1, padding = dilation, no bias, NCHW planes (the atrous separable convolutions
