@@ -34,7 +34,7 @@ EXPORTS = [
     "aadg_seg_loss_workspace_bytes", "aadg_seg_bce_dice_f32",
     "aadg_fop_workspace_bytes", "aadg_fop_f32",
     "aadg_upsample_bilinear2d", "aadg_upsample_bilinear2d_backward_supported", "aadg_upsample_bilinear2d_backward",
-    "aadg_upsample_bilinear2d_backward_workspace_bytes",
+    "aadg_upsample_bilinear2d_backward_workspace_bytes", "aadg_upsample_bilinear2d_backward_strided",
     "aadg_bn_workspace_bytes", "aadg_bn_mask_bytes", "aadg_bn_forward", "aadg_bn_backward",
     "aadg_dwconv3x3_supported", "aadg_dwconv3x3_workspace_bytes", "aadg_dwconv3x3", "aadg_dwconv3x3_wgrad",
     "aadg_maxpool3x3s2_supported", "aadg_maxpool3x3s2_forward", "aadg_maxpool3x3s2_backward",
@@ -92,6 +92,8 @@ def load():
     lib.aadg_upsample_bilinear2d_backward_supported.argtypes = [_i, _i, _i, _i]
     lib.aadg_upsample_bilinear2d_backward.restype = _i
     lib.aadg_upsample_bilinear2d_backward.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]
+    lib.aadg_upsample_bilinear2d_backward_strided.restype = _i
+    lib.aadg_upsample_bilinear2d_backward_strided.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _i, _c.c_longlong, _i, _vp, _sz, _vp]
     lib.aadg_upsample_bilinear2d_backward_workspace_bytes.restype = _sz
     lib.aadg_upsample_bilinear2d_backward_workspace_bytes.argtypes = [_i, _i]
     lib.aadg_bn_workspace_bytes.restype = _sz
@@ -464,15 +466,19 @@ class _UpsampleBilinearAC(torch.autograd.Function):
         lib = load()
         N, C, h, w = ctx.in_shape
         H, W = ctx.out_size
-        g = g.contiguous()
+        # a channel slice of a wider tensor (the gradient of the decoder's concatenation) is read in place
+        sliced = g.dim() == 4 and g.stride()[1:] == (H * W, W, 1) and g.stride(0) >= C * H * W
+        if not sliced:
+            g = g.contiguous()
         if lib.aadg_upsample_bilinear2d_backward_supported(h, w, H, W):
             gi = torch.empty(ctx.in_shape, dtype=g.dtype, device=g.device)
             ws = torch.empty(lib.aadg_upsample_bilinear2d_backward_workspace_bytes(h, w), dtype=torch.uint8, device=g.device)
-            rc = lib.aadg_upsample_bilinear2d_backward(g.data_ptr(), gi.data_ptr(), N * C, h, w, H, W,
-                                                       0 if g.dtype == torch.float32 else 1, ws.data_ptr(), ws.numel(), _stream())
-            _check(rc, "aadg_upsample_bilinear2d_backward")
+            rc = lib.aadg_upsample_bilinear2d_backward_strided(g.data_ptr(), gi.data_ptr(), N, C, h, w, H, W, g.stride(0),
+                                                               0 if g.dtype == torch.float32 else 1, ws.data_ptr(), ws.numel(),
+                                                               _stream())
+            _check(rc, "aadg_upsample_bilinear2d_backward_strided")
         else:       # very large factors: the LDS tile does not hold the contributing rectangle
-            gi = torch.ops.aten.upsample_bilinear2d_backward(g, list(ctx.out_size), list(ctx.in_shape), True, None, None)
+            gi = torch.ops.aten.upsample_bilinear2d_backward(g.contiguous(), list(ctx.out_size), list(ctx.in_shape), True, None, None)
         return gi, None
 
 

@@ -184,11 +184,12 @@ __global__ __launch_bounds__(256) void k_upsample_bwd_taps(int h, int w, int H, 
 // grid (ceil(w / BT_J) * ceil(h / BT_I), planes); ldc = LDS pitch of the staged rectangle (multiple of 4)
 template <typename T>
 __global__ __launch_bounds__(256) void k_upsample_bwd(const T* __restrict__ dy, T* __restrict__ dx, int h, int w, int H, int W,
-                                                      const float* __restrict__ tab, int ld_rows, int ldc) {
+                                                      const float* __restrict__ tab, int ld_rows, int ldc, int C,
+                                                      long long dy_img_stride, int plane0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float taps_y[BT_I * TAP_STRIDE];
     __shared__ float taps_x[BT_J * TAP_STRIDE];
-    const size_t plane = blockIdx.y;
+    const size_t plane = (size_t)plane0 + blockIdx.y;
     const int tj = (w + BT_J - 1) / BT_J;
     const int i0 = (blockIdx.x / tj) * BT_I, j0 = (blockIdx.x % tj) * BT_J;
     const int i1 = min(h, i0 + BT_I), j1 = min(w, j0 + BT_J);
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const T* __restrict__ dy, 
     const int nr = Yhi - Ylo, nc = Xhi - Xlo;
     float* D = lds;                                   // [nr][ldc]
     float* V = lds + (size_t)ld_rows * ldc;           // [BT_I][ldc]: reduced along y
-    const T* pdy = dy + plane * (size_t)H * W;
+    // dy may be a channel slice of a wider tensor (the gradient of a concatenation): image stride given by the caller
+    const T* pdy = dy + (plane / C) * (size_t)dy_img_stride + (plane % C) * (size_t)H * W;
     for (int rb = wv; rb < nr; rb += 16) {            // 4 rows x 3 column groups in flight per lane
         float v[4][3];
 #pragma unroll
@@ -265,12 +267,13 @@ constexpr int UPB_MAX_OUT = 16384, UPB_MAX_IN_ROWS = 64;
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_upsample_bwd_plane(const T* __restrict__ dy, T* __restrict__ dx, int h, int w, int H, int W,
-                                                            const float* __restrict__ tab) {
+                                                            const float* __restrict__ tab, int C, long long dy_img_stride) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* D = lds;                         // [H][W] staged dy (float)
     float* V = lds + (size_t)H * W;         // [h][W]
     const size_t plane = blockIdx.x;
-    const T* pdy = dy + plane * (size_t)H * W;
+    // dy may be a channel slice of a wider tensor (the gradient of a concatenation): image stride given by the caller
+    const T* pdy = dy + (plane / C) * (size_t)dy_img_stride + (plane % C) * (size_t)H * W;
     const int tid = threadIdx.x;
     const int n4 = H * W / 4;
     for (int i = tid; i < n4; i += 256) {
@@ -372,20 +375,27 @@ extern "C" size_t aadg_upsample_bilinear2d_backward_workspace_bytes(int h, int w
     return h > 0 && w > 0 ? (size_t)(h + w) * TAP_STRIDE * sizeof(float) : 0;
 }
 
-/* dx [planes, h, w] = gradient of aadg_upsample_bilinear2d w.r.t. its input, from dy [planes, H, W] */
-extern "C" int aadg_upsample_bilinear2d_backward(const void* dy, void* dx, int planes, int h, int w, int H, int W, int dtype,
-                                                 void* ws, size_t ws_bytes, void* stream) {
-    if (!dy || !dx || !ws || planes <= 0 || planes > 65535 * 64) return AADG_E_BADARG;
+/* dx [N*C, h, w] (contiguous) = gradient of aadg_upsample_bilinear2d w.r.t. its input, from dy: plane (n, c) of dy starts at
+ * n * dy_image_stride + c * H * W elements -- dy may be a channel slice of a wider tensor (the gradient of a concatenation). */
+extern "C" int aadg_upsample_bilinear2d_backward_strided(const void* dy, void* dx, int N, int C, int h, int w, int H, int W,
+                                                         long long dy_image_stride, int dtype, void* ws, size_t ws_bytes,
+                                                         void* stream) {
+    if (!dy || !dx || !ws || N <= 0 || C <= 0 || (long long)N * C > 65535LL * 64 || dy_image_stride < (long long)C * H * W)
+        return AADG_E_BADARG;
     if (dtype != 0 && dtype != 1) return AADG_E_BADARG;
     if (!aadg_upsample_bilinear2d_backward_supported(h, w, H, W)) return AADG_E_UNSUPPORTED;
     if (ws_bytes < aadg_upsample_bilinear2d_backward_workspace_bytes(h, w)) return AADG_E_WORKSPACE;
+    const int planes = N * C;
+    const long long img_stride = dy_image_stride;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;
     const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
     float* tab = reinterpret_cast<float*>(ws);
     hipLaunchKernelGGL(k_upsample_bwd_taps, dim3(2), dim3(256), 0, st, h, w, H, W, sy, sx, tab);
     AADG_LAUNCH_CHECK();
-    if (H * W <= UPB_MAX_OUT && (W & 3) == 0 && h <= UPB_MAX_IN_ROWS && (((uintptr_t)dy) & 15u) == 0 && (((size_t)H * W) % 8) == 0) {
+    const size_t esz = dtype == 0 ? 4 : 2;
+    if (H * W <= UPB_MAX_OUT && (W & 3) == 0 && h <= UPB_MAX_IN_ROWS && (((uintptr_t)dy) & 15u) == 0 && (((size_t)H * W) % 8) == 0 &&
+        ((size_t)img_stride * esz) % 16 == 0) {
         static bool attr[2] = {false, false};
         const size_t lds_p = ((size_t)H * W + (size_t)h * W) * sizeof(float);      // <= 64 KiB + 16 KiB
         if (!attr[dtype]) {
@@ -399,11 +409,11 @@ extern "C" int aadg_upsample_bilinear2d_backward(const void* dy, void* dx, int p
         }
         if (dtype == 0)
             hipLaunchKernelGGL(k_upsample_bwd_plane<float>, dim3(planes), dim3(256), lds_p, st, reinterpret_cast<const float*>(dy),
-                               reinterpret_cast<float*>(dx), h, w, H, W, (const float*)tab);
+                               reinterpret_cast<float*>(dx), h, w, H, W, (const float*)tab, C, img_stride);
         else
             hipLaunchKernelGGL(k_upsample_bwd_plane<__hip_bfloat16>, dim3(planes), dim3(256), lds_p, st,
                                reinterpret_cast<const __hip_bfloat16*>(dy), reinterpret_cast<__hip_bfloat16*>(dx), h, w, H, W,
-                               (const float*)tab);
+                               (const float*)tab, C, img_stride);
         AADG_LAUNCH_CHECK();
         return 0;
     }
@@ -415,13 +425,20 @@ extern "C" int aadg_upsample_bilinear2d_backward(const void* dy, void* dx, int p
         const int np = planes - p0 < 65535 ? planes - p0 : 65535;
         const dim3 g(tiles, np);
         if (dtype == 0)
-            hipLaunchKernelGGL(k_upsample_bwd<float>, g, dim3(256), lds, st, reinterpret_cast<const float*>(dy) + (size_t)p0 * H * W,
-                               reinterpret_cast<float*>(dx) + (size_t)p0 * h * w, h, w, H, W, (const float*)tab, nr, ldc);
+            hipLaunchKernelGGL(k_upsample_bwd<float>, g, dim3(256), lds, st, reinterpret_cast<const float*>(dy),
+                               reinterpret_cast<float*>(dx), h, w, H, W, (const float*)tab, nr, ldc, C, img_stride, p0);
         else
-            hipLaunchKernelGGL(k_upsample_bwd<__hip_bfloat16>, g, dim3(256), lds, st,
-                               reinterpret_cast<const __hip_bfloat16*>(dy) + (size_t)p0 * H * W,
-                               reinterpret_cast<__hip_bfloat16*>(dx) + (size_t)p0 * h * w, h, w, H, W, (const float*)tab, nr, ldc);
+            hipLaunchKernelGGL(k_upsample_bwd<__hip_bfloat16>, g, dim3(256), lds, st, reinterpret_cast<const __hip_bfloat16*>(dy),
+                               reinterpret_cast<__hip_bfloat16*>(dx), h, w, H, W, (const float*)tab, nr, ldc, C, img_stride, p0);
         AADG_LAUNCH_CHECK();
     }
     return 0;
+}
+
+/* contiguous dy [planes, H, W] */
+extern "C" int aadg_upsample_bilinear2d_backward(const void* dy, void* dx, int planes, int h, int w, int H, int W, int dtype,
+                                                 void* ws, size_t ws_bytes, void* stream) {
+    if (planes <= 0) return AADG_E_BADARG;
+    return aadg_upsample_bilinear2d_backward_strided(dy, dx, 1, planes, h, w, H, W, (long long)planes * H * W, dtype, ws, ws_bytes,
+                                                     stream);
 }

@@ -167,6 +167,10 @@ int aadg_upsample_bilinear2d(const void* in, void* out, int planes, int h, int w
  * rectangle feeding an 8 x 32 input tile must fit 48 KiB of LDS, i.e. up-sampling factors up to ~6) */
 int aadg_upsample_bilinear2d_backward_supported(int h, int w, int H, int W);
 size_t aadg_upsample_bilinear2d_backward_workspace_bytes(int h, int w);
+/* dy as a channel slice of a wider tensor: plane (n, c) starts at n * dy_image_stride + c * H * W elements */
+int aadg_upsample_bilinear2d_backward_strided(const void* dy, void* dx, int N, int C, int h, int w, int H, int W,
+                                              long long dy_image_stride, int dtype, void* ws, size_t ws_bytes,
+                                              void* stream);
 int aadg_upsample_bilinear2d_backward(const void* dy, void* dx, int planes, int h, int w, int H, int W, int dtype,
                                       void* ws, size_t ws_bytes, void* stream);
 

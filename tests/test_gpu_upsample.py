@@ -38,3 +38,19 @@ def test_deeplab_uses_the_kernel_and_matches_interpolate(hip):
         finally:
             deeplab._upsample_ac = saved
     assert torch.allclose(y1, y2, atol=1e-5) and torch.equal(f1, f2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upsample_backward_reads_a_channel_slice_in_place(hip, dtype):
+    """The decoder concatenates the up-sampled map with the skip branch: the gradient reaching the up-sampling is a channel
+    slice of the concatenation's gradient and is consumed without a contiguous copy."""
+    torch.manual_seed(2)
+    x = torch.randn(3, 6, 8, 8, device="cuda").to(dtype).requires_grad_(True)
+    other = torch.randn(3, 5, 32, 32, device="cuda").to(dtype).requires_grad_(True)
+    g = torch.randn(3, 11, 32, 32, device="cuda").to(dtype)
+    torch.cat([hip.upsample_bilinear_ac(x, (32, 32)), other], dim=1).backward(g)
+    xr = x.detach().clone().requires_grad_(True)
+    torch.cat([F.interpolate(xr, size=(32, 32), mode="bilinear", align_corners=True), other.detach()], dim=1).backward(g)
+    tol = 1e-4 if dtype == torch.float32 else 0.15
+    assert (x.grad.float() - xr.grad.float()).abs().max().item() <= tol
+    assert torch.equal(other.grad, g[:, 6:])
