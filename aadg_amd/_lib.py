@@ -33,7 +33,7 @@ EXPORTS = [
     "aadg_normalize_rewards_f32",
     "aadg_seg_loss_workspace_bytes", "aadg_seg_bce_dice_f32",
     "aadg_fop_workspace_bytes", "aadg_fop_f32",
-    "aadg_upsample_bilinear2d", "aadg_upsample_bilinear2d_backward_supported", "aadg_upsample_bilinear2d_backward",
+    "aadg_upsample_bilinear2d", "aadg_upsample_bilinear2d_strided", "aadg_upsample_bilinear2d_backward_supported", "aadg_upsample_bilinear2d_backward",
     "aadg_upsample_bilinear2d_backward_workspace_bytes", "aadg_upsample_bilinear2d_backward_strided",
     "aadg_bn_workspace_bytes", "aadg_bn_mask_bytes", "aadg_bn_forward", "aadg_bn_backward",
     "aadg_dwconv3x3_supported", "aadg_dwconv3x3_workspace_bytes", "aadg_dwconv3x3", "aadg_dwconv3x3_wgrad",
@@ -88,6 +88,8 @@ def load():
         lib.aadg_fop_f32.argtypes = [_i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]
     lib.aadg_upsample_bilinear2d.restype = _i
     lib.aadg_upsample_bilinear2d.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
+    lib.aadg_upsample_bilinear2d_strided.restype = _i
+    lib.aadg_upsample_bilinear2d_strided.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _i, _c.c_longlong, _i, _vp]
     lib.aadg_upsample_bilinear2d_backward_supported.restype = _i
     lib.aadg_upsample_bilinear2d_backward_supported.argtypes = [_i, _i, _i, _i]
     lib.aadg_upsample_bilinear2d_backward.restype = _i
@@ -820,3 +822,52 @@ def embed_prologue(x, w1, b1, w2=None, b2=None, slope=0.2):
                                      float(slope), fe.data_ptr(), _ptr(out), _stream())
     _check(rc, "aadg_embed_prologue_f32")
     return out, fe
+
+
+# ------------------------------------------------------------------------------------------------
+class _UpsampleCat(torch.autograd.Function):
+    """torch.cat([upsample_bilinear_ac(a, size), b], dim=1): the up-sampling writes straight into the concatenation buffer
+    (no separate copy of its output) and its backward reads the corresponding channel slice of the gradient in place."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = load()
+        N, Ca, h, w = a.shape
+        _, Cb, H, W = b.shape
+        out = torch.empty((N, Ca + Cb, H, W), dtype=a.dtype, device=a.device)
+        rc = lib.aadg_upsample_bilinear2d_strided(a.data_ptr(), out.data_ptr(), N, Ca, h, w, H, W, (Ca + Cb) * H * W,
+                                                  0 if a.dtype == torch.float32 else 1, _stream())
+        _check(rc, "aadg_upsample_bilinear2d_strided")
+        out[:, Ca:].copy_(b)
+        ctx.shape_a = (N, Ca, h, w)
+        ctx.Cb = Cb
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load()
+        N, Ca, h, w = ctx.shape_a
+        H, W = g.shape[2], g.shape[3]
+        g = g.contiguous()
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            if lib.aadg_upsample_bilinear2d_backward_supported(h, w, H, W):
+                ga = torch.empty(ctx.shape_a, dtype=g.dtype, device=g.device)
+                ws = torch.empty(lib.aadg_upsample_bilinear2d_backward_workspace_bytes(h, w), dtype=torch.uint8, device=g.device)
+                rc = lib.aadg_upsample_bilinear2d_backward_strided(g.data_ptr(), ga.data_ptr(), N, Ca, h, w, H, W, g.stride(0),
+                                                                   0 if g.dtype == torch.float32 else 1, ws.data_ptr(), ws.numel(),
+                                                                   _stream())
+                _check(rc, "aadg_upsample_bilinear2d_backward_strided")
+            else:
+                ga = torch.ops.aten.upsample_bilinear2d_backward(g[:, :Ca].contiguous(), [H, W], list(ctx.shape_a), True, None, None)
+        if ctx.needs_input_grad[1]:
+            gb = g[:, Ca:]
+        return ga, gb
+
+
+def upsample_cat(a, b):
+    """cat([bilinear up-sampling of a (align_corners=True) to b's spatial size, b], dim=1) on NCHW float32 / bfloat16 tensors."""
+    _require_cuda(a, b)
+    if a.dtype != b.dtype or a.dtype not in (torch.float32, torch.bfloat16) or a.dim() != 4 or b.dim() != 4 or a.shape[0] != b.shape[0]:
+        raise AadgError("upsample_cat: expected two NCHW float32/bfloat16 tensors with one batch size")
+    return _UpsampleCat.apply(a.contiguous(), b.contiguous())

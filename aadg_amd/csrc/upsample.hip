@@ -44,10 +44,12 @@ template <> struct Vec4<__hip_bfloat16> {
 // grid (ceil(W/4/64) * rows-chunks, planes): a wave writes 256 consecutive output pixels of one row
 template <typename T>
 __global__ __launch_bounds__(256) void k_upsample(const T* __restrict__ in, T* __restrict__ out, int h, int w, int H, int W,
-                                                  float sy, float sx, int rows_per_block) {
-    const size_t plane = blockIdx.y;
+                                                  float sy, float sx, int rows_per_block, int C, long long out_img_stride,
+                                                  int plane0) {
+    const size_t plane = (size_t)plane0 + blockIdx.y;
     const T* pin = in + plane * (size_t)h * w;
-    T* po = out + plane * (size_t)H * W;
+    // the output may be a channel slice of a wider tensor (written straight into a concatenation buffer)
+    T* po = out + (plane / C) * (size_t)out_img_stride + (plane % C) * (size_t)H * W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int xgroups = (W + 255) / 256;
     const int xg = blockIdx.x % xgroups, yb = (blockIdx.x / xgroups) * rows_per_block;
@@ -96,13 +98,14 @@ constexpr int UP_LDS_MAX = 4096, UP_ROWS = 32;
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_upsample_lds(const T* __restrict__ in, T* __restrict__ out, int h, int w, int H, int W,
-                                                      float sy, float sx) {
+                                                      float sy, float sx, int C, long long out_img_stride, int plane0) {
     __shared__ float P[UP_LDS_MAX];
-    const size_t plane = blockIdx.y;
+    const size_t plane = (size_t)plane0 + blockIdx.y;
     const T* pin = in + plane * (size_t)h * w;
     for (int i = threadIdx.x; i < h * w; i += 256) P[i] = Vec4<T>::ld(pin + i);
     __syncthreads();
-    T* po = out + plane * (size_t)H * W;
+    // the output may be a channel slice of a wider tensor (written straight into a concatenation buffer)
+    T* po = out + (plane / C) * (size_t)out_img_stride + (plane % C) * (size_t)H * W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int Y0 = blockIdx.x * UP_ROWS, Y1 = min(H, Y0 + UP_ROWS);
     const bool vec = (W & 3) == 0;
@@ -324,40 +327,49 @@ inline int staged_pitch(int nc) { return ((nc + 3 + 3) & ~3) + 4; }   // + up to
 
 }  // namespace
 
-extern "C" int aadg_upsample_bilinear2d(const void* in, void* out, int planes, int h, int w, int H, int W, int dtype,
-                                        void* stream) {
-    if (!in || !out || planes <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return AADG_E_BADARG;
+/* in [N*C, h, w] contiguous -> out plane (n, c) at n * out_image_stride + c * H * W elements (out_image_stride = C * H * W for
+ * a contiguous output; larger when `out` is a channel slice of a concatenation buffer) */
+extern "C" int aadg_upsample_bilinear2d_strided(const void* in, void* out, int N, int C, int h, int w, int H, int W,
+                                                long long out_image_stride, int dtype, void* stream) {
+    if (!in || !out || N <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || out_image_stride < (long long)C * H * W)
+        return AADG_E_BADARG;
     if (dtype != 0 && dtype != 1) return AADG_E_BADARG;
+    if ((long long)N * C > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
+    const int planes = N * C;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;
     const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
-    if (h * w <= UP_LDS_MAX) {
-        for (int p0 = 0; p0 < planes; p0 += 65535) {          // gridDim.y limit
-            const int np = planes - p0 < 65535 ? planes - p0 : 65535;
-            const dim3 gl((H + UP_ROWS - 1) / UP_ROWS, np);
-            if (dtype == 0)
-                hipLaunchKernelGGL(k_upsample_lds<float>, gl, dim3(256), 0, st, reinterpret_cast<const float*>(in) + (size_t)p0 * h * w,
-                                   reinterpret_cast<float*>(out) + (size_t)p0 * H * W, h, w, H, W, sy, sx);
-            else
-                hipLaunchKernelGGL(k_upsample_lds<__hip_bfloat16>, gl, dim3(256), 0, st,
-                                   reinterpret_cast<const __hip_bfloat16*>(in) + (size_t)p0 * h * w,
-                                   reinterpret_cast<__hip_bfloat16*>(out) + (size_t)p0 * H * W, h, w, H, W, sy, sx);
-            AADG_LAUNCH_CHECK();
-        }
-        return 0;
-    }
-    if (planes > 65535) return AADG_E_UNSUPPORTED;
+    const bool lds_path = h * w <= UP_LDS_MAX;
     const int rows_per_block = 16;
     const int xgroups = (W + 255) / 256;
-    const dim3 g(xgroups * ((H + rows_per_block - 1) / rows_per_block), planes);
-    if (dtype == 0)
-        hipLaunchKernelGGL(k_upsample<float>, g, dim3(256), 0, st, reinterpret_cast<const float*>(in),
-                           reinterpret_cast<float*>(out), h, w, H, W, sy, sx, rows_per_block);
-    else
-        hipLaunchKernelGGL(k_upsample<__hip_bfloat16>, g, dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(in),
-                           reinterpret_cast<__hip_bfloat16*>(out), h, w, H, W, sy, sx, rows_per_block);
-    AADG_LAUNCH_CHECK();
+    for (int p0 = 0; p0 < planes; p0 += 65535) {          // gridDim.y limit
+        const int np = planes - p0 < 65535 ? planes - p0 : 65535;
+        if (lds_path) {
+            const dim3 gl((H + UP_ROWS - 1) / UP_ROWS, np);
+            if (dtype == 0)
+                hipLaunchKernelGGL(k_upsample_lds<float>, gl, dim3(256), 0, st, reinterpret_cast<const float*>(in),
+                                   reinterpret_cast<float*>(out), h, w, H, W, sy, sx, C, out_image_stride, p0);
+            else
+                hipLaunchKernelGGL(k_upsample_lds<__hip_bfloat16>, gl, dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(in),
+                                   reinterpret_cast<__hip_bfloat16*>(out), h, w, H, W, sy, sx, C, out_image_stride, p0);
+        } else {
+            const dim3 g(xgroups * ((H + rows_per_block - 1) / rows_per_block), np);
+            if (dtype == 0)
+                hipLaunchKernelGGL(k_upsample<float>, g, dim3(256), 0, st, reinterpret_cast<const float*>(in),
+                                   reinterpret_cast<float*>(out), h, w, H, W, sy, sx, rows_per_block, C, out_image_stride, p0);
+            else
+                hipLaunchKernelGGL(k_upsample<__hip_bfloat16>, g, dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(in),
+                                   reinterpret_cast<__hip_bfloat16*>(out), h, w, H, W, sy, sx, rows_per_block, C, out_image_stride, p0);
+        }
+        AADG_LAUNCH_CHECK();
+    }
     return 0;
+}
+
+extern "C" int aadg_upsample_bilinear2d(const void* in, void* out, int planes, int h, int w, int H, int W, int dtype,
+                                        void* stream) {
+    if (planes <= 0 || H <= 0 || W <= 0) return AADG_E_BADARG;
+    return aadg_upsample_bilinear2d_strided(in, out, 1, planes, h, w, H, W, (long long)planes * H * W, dtype, stream);
 }
 
 extern "C" int aadg_upsample_bilinear2d_backward_supported(int h, int w, int H, int W) {

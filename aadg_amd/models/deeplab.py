@@ -290,8 +290,13 @@ class DeepLabV3Plus(nn.Module):
         a = self.aspp[0](tuple(hd[:5]))                  # ASPP takes one handle of the encoder output per branch
         for mod in list(self.aspp)[1:]:
             a = mod(a)
-        y = _upsample_ac(a, skip.shape[-2:])
-        y = self.fuse(torch.cat([y, self.skip(skip)], dim=1))
+        s = self.skip(skip)
+        if a.is_cuda and a.dtype == s.dtype and a.dtype in (torch.float32, torch.bfloat16):
+            from .. import _lib
+            y = _lib.upsample_cat(a, s)                     # up-sampling written straight into the concatenation
+        else:
+            y = torch.cat([_upsample_ac(a, skip.shape[-2:]), s], dim=1)
+        y = self.fuse(y)
         mask = _upsample_ac(self.classifier(y), x.shape[-2:])
         if not self.aux_pooling:
             return mask

@@ -163,6 +163,9 @@ int aadg_fop_f32(int fop, const float* in, float* out, const float* mag, int mag
  * upsample_bilinear2d).  in [planes, h, w] -> out [planes, H, W]; dtype 0 = float32, 1 = bfloat16.
  * ------------------------------------------------------------------------------------------- */
 int aadg_upsample_bilinear2d(const void* in, void* out, int planes, int h, int w, int H, int W, int dtype, void* stream);
+/* out as a channel slice of a wider tensor (e.g. a concatenation buffer): plane (n, c) at n * out_image_stride + c * H * W */
+int aadg_upsample_bilinear2d_strided(const void* in, void* out, int N, int C, int h, int w, int H, int W,
+                                     long long out_image_stride, int dtype, void* stream);
 /* gradient w.r.t. the input: dy [planes, H, W] -> dx [planes, h, w] (gathered, deterministic; _supported: the dy
  * rectangle feeding an 8 x 32 input tile must fit 48 KiB of LDS, i.e. up-sampling factors up to ~6) */
 int aadg_upsample_bilinear2d_backward_supported(int h, int w, int H, int W);

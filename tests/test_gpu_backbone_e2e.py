@@ -59,6 +59,8 @@ def test_hip_layers_match_library_layers_in_situ(hip, encoder, monkeypatch):
     for name in SWITCHES:
         monkeypatch.setattr(hip, name, lambda *a, **k: False)
     monkeypatch.setattr(deeplab, "_upsample_ac", lambda t, size: F.interpolate(t, size=size, mode="bilinear", align_corners=True))
+    monkeypatch.setattr(hip, "upsample_cat", lambda a, b: torch.cat(
+        [F.interpolate(a, size=b.shape[-2:], mode="bilinear", align_corners=True), b], dim=1))
     before = dict(used)
     lib32 = _run(m, state, x, y, False)
     lib16 = _run(m, state, x, y, True)

@@ -54,3 +54,21 @@ def test_upsample_backward_reads_a_channel_slice_in_place(hip, dtype):
     tol = 1e-4 if dtype == torch.float32 else 0.15
     assert (x.grad.float() - xr.grad.float()).abs().max().item() <= tol
     assert torch.equal(other.grad, g[:, 6:])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape_a,shape_b", [((3, 6, 8, 8), (3, 5, 32, 32)), ((2, 16, 32, 32), (2, 48, 128, 128)), ((1, 3, 5, 7), (1, 2, 9, 20))])
+def test_upsample_cat_matches_cat_of_interpolate(hip, dtype, shape_a, shape_b):
+    torch.manual_seed(6)
+    a = torch.randn(shape_a, device="cuda").to(dtype).requires_grad_(True)
+    b = torch.randn(shape_b, device="cuda").to(dtype).requires_grad_(True)
+    y = hip.upsample_cat(a, b)
+    ar, br = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    yr = torch.cat([F.interpolate(ar, size=shape_b[2:], mode="bilinear", align_corners=True), br], dim=1)
+    lo = dtype == torch.bfloat16
+    assert y.shape == yr.shape and (y.float() - yr.float()).abs().max().item() <= (2e-2 if lo else 1e-5)
+    g = torch.randn_like(yr)
+    y.backward(g)
+    yr.backward(g)
+    assert (a.grad.float() - ar.grad.float()).abs().max().item() <= (0.2 if lo else 5e-4)
+    assert torch.equal(b.grad, br.grad)
