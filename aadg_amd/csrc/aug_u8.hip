@@ -813,11 +813,6 @@ __device__ __forceinline__ float normalise_u8(int v) {
 // unit record -> all table entries / LUTs (issued together) -> source patch; the mask gather of the vertical
 // phase is issued before the arithmetic it is independent of.
 template <int TH>
-struct FusedCfg {
-    static constexpr int CAP = TH == 16 ? PATCH_CAP : 3584;   // pixels per patch buffer (13 x 268 = 3484 needed at TH = 8)
-};
-
-template <int TH>
 __device__ __forceinline__ void fused_tile(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
                                            const aadg_unit* __restrict__ units, int Hs, int Ws, int crop, int dataset,
                                            const int* __restrict__ tab, const uint8_t* __restrict__ lut,
@@ -1157,36 +1152,13 @@ __global__ __launch_bounds__(256) void k_fused(const uint8_t* __restrict__ pool,
                                                const aadg_unit* __restrict__ units, int Hs, int Ws, int crop, int dataset,
                                                const int* __restrict__ tab, const uint8_t* __restrict__ lut,
                                                size_t lut_stage_stride, float* __restrict__ out_img, float* __restrict__ out_lbl) {
-    __shared__ __attribute__((aligned(16))) uint32_t A[FusedCfg<TH>::CAP];
-    __shared__ __attribute__((aligned(16))) uint32_t B[FusedCfg<TH>::CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t A[PATCH_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t B[PATCH_CAP];
     __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
     __shared__ float lutf[256];
     lutf[threadIdx.x] = normalise_u8(threadIdx.x);
     fused_tile<TH>(pool, masks, units, Hs, Ws, crop, dataset, tab, lut, lut_stage_stride, out_img, out_lbl, blockIdx.z,
                    blockIdx.x, blockIdx.y, A, B, sl, lutf);
-}
-
-// persistent variant: gridDim.x resident workgroups walk the tile list (unit-major) with a grid stride
-template <int TH>
-__global__ __launch_bounds__(256) void k_fused_persistent(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
-                                                          const aadg_unit* __restrict__ units, int N, int Hs, int Ws, int crop,
-                                                          int dataset, const int* __restrict__ tab,
-                                                          const uint8_t* __restrict__ lut, size_t lut_stage_stride,
-                                                          float* __restrict__ out_img, float* __restrict__ out_lbl) {
-    __shared__ __attribute__((aligned(16))) uint32_t A[FusedCfg<TH>::CAP];
-    __shared__ __attribute__((aligned(16))) uint32_t B[FusedCfg<TH>::CAP];
-    __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
-    __shared__ float lutf[256];
-    lutf[threadIdx.x] = normalise_u8(threadIdx.x);
-    const int ntx = (crop + FT_W - 1) / FT_W, nty = (crop + TH - 1) / TH;
-    const int per_unit = ntx * nty, total = N * per_unit;
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
-        const int u = t / per_unit, rem = t - u * per_unit;
-        const int by = rem / ntx, bx = rem - by * ntx;
-        fused_tile<TH>(pool, masks, units, Hs, Ws, crop, dataset, tab, lut, lut_stage_stride, out_img, out_lbl, u, bx, by,
-                       A, B, sl, lutf);
-        __syncthreads();
-    }
 }
 
 struct WsLayout {
@@ -1282,20 +1254,9 @@ extern "C" int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks,
     AADG_LAUNCH_CHECK();
     if (ev_before_final) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_before_final), st));
     if (classes & HINT_FUSED) {
-        static const int tile_h = [] { const char* e = getenv("AADG_FUSED_TILE_H"); return e ? atoi(e) : FT_H; }();
-        static const int persistent = [] { const char* e = getenv("AADG_FUSED_PERSISTENT"); return e ? atoi(e) : 0; }();
-        if (persistent > 0) {
-            hipLaunchKernelGGL(k_fused_persistent<16>, dim3(persistent), dim3(256), 0, st, pool, masks, units, N, Hs, Ws, crop,
-                               dataset, tab, ws8 + L.lut, (size_t)N * 768, out_img, out_lbl);
-        } else if (tile_h == 8) {
-            const dim3 g((crop + FT_W - 1) / FT_W, (crop + 7) / 8, N);
-            hipLaunchKernelGGL(k_fused<8>, g, dim3(256), 0, st, pool, masks, units, Hs, Ws, crop, dataset, tab, ws8 + L.lut,
-                               (size_t)N * 768, out_img, out_lbl);
-        } else {
-            const dim3 g((crop + FT_W - 1) / FT_W, (crop + 15) / 16, N);
-            hipLaunchKernelGGL(k_fused<16>, g, dim3(256), 0, st, pool, masks, units, Hs, Ws, crop, dataset, tab, ws8 + L.lut,
-                               (size_t)N * 768, out_img, out_lbl);
-        }
+        const dim3 g((crop + FT_W - 1) / FT_W, (crop + FT_H - 1) / FT_H, N);
+        hipLaunchKernelGGL(k_fused<FT_H>, g, dim3(256), 0, st, pool, masks, units, Hs, Ws, crop, dataset, tab, ws8 + L.lut,
+                           (size_t)N * 768, out_img, out_lbl);
         AADG_LAUNCH_CHECK();
     }
     if (classes & HINT_GENERIC) {

@@ -50,7 +50,7 @@ template <> struct Pack<__hip_bfloat16> {
     static __device__ __forceinline__ void store(__hip_bfloat16* p, const float* v) {
         uint32_t w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = aadg_f2bf_bits(v[2 * i]) | (aadg_f2bf_bits(v[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = aadg_f2bf_pk(v[2 * i], v[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
     static __device__ __forceinline__ float load1(const __hip_bfloat16* p) {
@@ -59,7 +59,7 @@ template <> struct Pack<__hip_bfloat16> {
     static __device__ __forceinline__ void store1(__hip_bfloat16* p, float v) {
         *reinterpret_cast<uint16_t*>(p) = (uint16_t)aadg_f2bf_bits(v);
     }
-    static __device__ __forceinline__ float round(float v) { return __uint_as_float(aadg_f2bf_bits(v) << 16); }
+    static __device__ __forceinline__ float round(float v) { return __uint_as_float(aadg_f2bf_pk(v, v) & 0xFFFF0000u); }
 };
 
 // activation on the value the forward STORED (rounded to T): the backward re-derives the mask from the same value
@@ -133,61 +133,98 @@ template <typename T> struct BnExtra {      // further gradients of the same out
 };
 
 // ---- reductions: grid (split, C) ---------------------------------------------------------------------------
-// MODE 0: sum x, sum x^2.   MODE 1: g = dy * act'(v) with v = the forward's stored output (recomputed from x, or read
-// from y when a residual was fused); sums g and g * (x - mean) * invstd; writes g to dres when dres != nullptr.
-template <typename T, int VEC, int MODE>
-__global__ __launch_bounds__(256) void k_bn_reduce(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
-                                                   BnExtra<T> more, const uint8_t* __restrict__ mask, T* __restrict__ dres, const float* __restrict__ mean,
-                                                   const float* __restrict__ invstd, const float* __restrict__ scale,
-                                                   const float* __restrict__ shift, int act, int C, int len, int per_strip,
-                                                   int plen, int total, float* __restrict__ partial) {
+// Everything that does not change inside a launch (activation kind, where the activation mask comes from, the number of
+// summed gradients, whether g is written back) is a template parameter: the loop bodies are then straight-line code, the
+// `#pragma unroll 4` really puts four vectors per operand in flight, and there is no per-element branch.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_bn_reduce_fwd(const T* __restrict__ x, int C, int len, int per_strip, int plen, int total,
+                                                       float* __restrict__ partial) {
     const int c = blockIdx.y, S = gridDim.x;
     const size_t strip_elems = (size_t)len * VEC;
     float s0 = 0.f, s1 = 0.f;
-    float mu = 0.f, is = 0.f, sc = 0.f, sh = 0.f;
-    if (MODE == 1) { mu = mean[c]; is = invstd[c]; sc = scale[c]; sh = shift[c]; }
     for (int p = blockIdx.x; p < total; p += S) {
         const int n = p / per_strip, part = p - n * per_strip;
         const size_t base = ((size_t)n * C + c) * strip_elems;
         const int j1 = min(len, (part + 1) * plen);
 #pragma unroll 4
         for (int j = part * plen + threadIdx.x; j < j1; j += blockDim.x) {
-            const size_t off = base + (size_t)j * VEC;
             float xv[VEC];
-            if (VEC == 1) xv[0] = Pack<T>::load1(x + off); else Pack<T>::load(x + off, xv);
-            if (MODE == 0) {
+            if (VEC == 1) xv[0] = Pack<T>::load1(x + base + j); else Pack<T>::load(x + base + (size_t)j * VEC, xv);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) { s0 += xv[i]; s1 = fmaf(xv[i], xv[i], s1); }
+            for (int i = 0; i < VEC; ++i) { s0 += xv[i]; s1 = fmaf(xv[i], xv[i], s1); }
+        }
+    }
+    const float2 r = block_sum2(s0, s1);
+    if (threadIdx.x == 0) reinterpret_cast<float2*>(partial)[(size_t)c * BN_MAX_SPLIT + blockIdx.x] = r;
+}
+
+// backward: g = (dy + extra gradients) * act'(v), v = the value the forward stored; sums g and g * (x - mean) * invstd;
+// writes g to dres when asked to.
+//   MK 0: no activation (every element open)     MK 1: the forward's bit mask (one byte per 16-byte vector)
+//   MK 2: generic -- v read from y when given, else recomputed from x; `act` is a run-time value (scalar / odd shapes)
+//   MK 3 / 4: ReLU / ReLU6 with v recomputed from x exactly as the forward computed it (BatchNorm without a fused residual)
+//   NE  : number of extra gradients (-1 = more.n at run time);  DRES: 0 / 1 (-1 = dres may or may not be null)
+template <typename T, int VEC, int MK, int NE, int DRES>
+__global__ __launch_bounds__(256) void k_bn_reduce_bwd(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
+                                                       BnExtra<T> more, const uint8_t* __restrict__ mask, T* __restrict__ dres,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                       int C, int len, int per_strip, int plen, int total, float* __restrict__ partial) {
+    static_assert(MK == 2 || VEC > 1, "the specialised variants are vector-only");
+    const int c = blockIdx.y, S = gridDim.x;
+    const size_t strip_elems = (size_t)len * VEC;
+    float s0 = 0.f, s1 = 0.f;
+    const float mu = mean[c], is = invstd[c];
+    float sc = 0.f, sh = 0.f;
+    if (MK >= 2) { sc = scale[c]; sh = shift[c]; }
+    const bool write_g = DRES < 0 ? dres != nullptr : DRES != 0;
+    for (int p = blockIdx.x; p < total; p += S) {
+        const int n = p / per_strip, part = p - n * per_strip;
+        const size_t strip = (size_t)n * C + c;
+        const size_t base = strip * strip_elems;
+        const int j1 = min(len, (part + 1) * plen);
+#pragma unroll 4
+        for (int j = part * plen + threadIdx.x; j < j1; j += blockDim.x) {
+            const size_t off = base + (size_t)j * VEC;
+            float xv[VEC], gv[VEC], yv[VEC];
+            if (VEC == 1) { xv[0] = Pack<T>::load1(x + off); gv[0] = Pack<T>::load1(dy + off); }
+            else { Pack<T>::load(x + off, xv); Pack<T>::load(dy + off, gv); }
+            uint32_t mbits = 0;
+            if (MK == 1) mbits = mask[strip * len + j];
+            if (MK == 2 && y != nullptr) {
+                if (VEC == 1) yv[0] = Pack<T>::load1(y + off); else Pack<T>::load(y + off, yv);
+            }
+            // the output had several consumers: their gradients are summed here, not by separate elementwise passes
+            if (NE >= 0) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    float g2[VEC];
+                    Pack<T>::load(more.p[e] + off, g2);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) gv[i] += g2[i];
+                }
             } else {
-                float gv[VEC], yv[VEC];
-                if (VEC == 1) gv[0] = Pack<T>::load1(dy + off); else Pack<T>::load(dy + off, gv);
-                // the output had several consumers: their gradients are summed here, not by separate elementwise passes
                 for (int e = 0; e < more.n; ++e) {
                     float g2[VEC];
                     if (VEC == 1) g2[0] = Pack<T>::load1(more.p[e] + off); else Pack<T>::load(more.p[e] + off, g2);
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) gv[i] += g2[i];
                 }
-                uint32_t mbits = 0;
-                if (VEC > 1 && mask != nullptr) mbits = mask[(size_t)((size_t)n * C + c) * len + j];   // 1 byte instead of a 16-byte vector of y
-                else if (y != nullptr) {
-                    if (VEC == 1) yv[0] = Pack<T>::load1(y + off); else Pack<T>::load(y + off, yv);
-                }
+            }
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    // pre-activation value as the forward saw it: the stored output when we have it (for ReLU the
-                    // sign of the output decides; ReLU6 needs the interval, still decidable from the clamped value)
-                    bool open;
-                    if (VEC > 1 && mask != nullptr) open = (mbits >> i) & 1u;
-                    else open = act_open(y != nullptr ? yv[i] : Pack<T>::round(fmaf(xv[i], sc, sh)), act);
-                    const float g = open ? gv[i] : 0.0f;
-                    gv[i] = g;
-                    s0 += g;
-                    s1 = fmaf(g, (xv[i] - mu) * is, s1);
-                }
-                if (dres != nullptr) {
-                    if (VEC == 1) Pack<T>::store1(dres + off, gv[0]); else Pack<T>::store(dres + off, gv);
-                }
+            for (int i = 0; i < VEC; ++i) {
+                bool open = true;
+                if (MK == 1) open = (mbits >> i) & 1u;
+                if (MK == 2) open = act_open(y != nullptr ? yv[i] : Pack<T>::round(fmaf(xv[i], sc, sh)), act);
+                if (MK == 3) open = act_open(Pack<T>::round(fmaf(xv[i], sc, sh)), AADG_ACT_RELU);
+                if (MK == 4) open = act_open(Pack<T>::round(fmaf(xv[i], sc, sh)), AADG_ACT_RELU6);
+                const float g = open ? gv[i] : 0.0f;
+                gv[i] = g;
+                s0 += g;
+                s1 = fmaf(g, (xv[i] - mu) * is, s1);
+            }
+            if (write_g) {
+                if (VEC == 1) Pack<T>::store1(dres + off, gv[0]); else Pack<T>::store(dres + off, gv);
             }
         }
     }
@@ -263,10 +300,13 @@ __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const float* __restrict
 }
 
 // ---- elementwise passes: grid (N*C strips, pieces per strip) ------------------------------------------------
-template <typename T, int VEC>
+// ACT >= 0: the activation is a compile-time constant (vector path); ACT < 0: the run-time `act` (scalar path).
+template <typename T, int VEC, int ACT, bool RES, bool MASK>
 __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                   uint8_t* __restrict__ mask, const float* __restrict__ scale,
-                                                  const float* __restrict__ shift, int act, int C, int len, int plen) {
+                                                  const float* __restrict__ shift, int act_rt, int C, int len, int plen) {
+    static_assert(!MASK || VEC > 1, "one mask byte per 16-byte vector");
+    const int act = ACT >= 0 ? ACT : act_rt;
     const int strip = blockIdx.x, c = strip % C;
     const float sc = scale[c], sh = shift[c];
     const size_t base = (size_t)strip * len * VEC;
@@ -276,16 +316,16 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const
         const size_t off = base + (size_t)j * VEC;
         float v[VEC], r[VEC];
         if (VEC == 1) v[0] = Pack<T>::load1(x + off); else Pack<T>::load(x + off, v);
-        if (res != nullptr) {
+        if (RES) {
             if (VEC == 1) r[0] = Pack<T>::load1(res + off); else Pack<T>::load(res + off, r);
         }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float t = fmaf(v[i], sc, sh);
-            if (res != nullptr) t = Pack<T>::round(t) + r[i];     // same roundings as bn (stored in T) followed by add
+            if (RES) t = Pack<T>::round(t) + r[i];                // same roundings as bn (stored in T) followed by add
             v[i] = act_fwd(t, act);
         }
-        if (VEC > 1 && mask != nullptr) {       // one byte per vector: bit i = act'(stored output i) != 0, read back by the backward
+        if (MASK) {       // one byte per vector: bit i = act'(stored output i) != 0, read back by the backward
             uint32_t bits = 0;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) bits |= act_open(Pack<T>::round(v[i]), act) ? (1u << i) : 0u;
@@ -295,17 +335,18 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const
     }
 }
 
-// g = dy * act'(.) is recomputed exactly as in k_bn_reduce<BWD> unless `g_ready` (then `dy` already holds g = dres)
-template <typename T, int VEC>
+// ACT = activation whose mask is re-derived from x exactly as the forward did (0: none, or `dy` already holds the masked
+// gradient g = dres); ACT < 0: run-time `act_rt`
+template <typename T, int VEC, int ACT>
 __global__ __launch_bounds__(256) void k_bn_dx(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                const float* __restrict__ ca, const float* __restrict__ cb,
-                                               const float* __restrict__ cc, int act, int g_ready, int C, int len, int plen) {
+                                               const float* __restrict__ cc, int act_rt, int C, int len, int plen) {
+    const int act = ACT >= 0 ? ACT : act_rt;
     const int strip = blockIdx.x, c = strip % C;
     const float sc = scale[c], sh = shift[c], a = ca[c], b = cb[c], c0 = cc[c];
     const size_t base = (size_t)strip * len * VEC;
     const int j1 = min(len, ((int)blockIdx.y + 1) * plen);
-    const bool mask = !g_ready && act != AADG_ACT_NONE;
 #pragma unroll 4
     for (int j = blockIdx.y * plen + threadIdx.x; j < j1; j += blockDim.x) {
         const size_t off = base + (size_t)j * VEC;
@@ -315,7 +356,7 @@ __global__ __launch_bounds__(256) void k_bn_dx(const T* __restrict__ x, const T*
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float g = gv[i];
-            if (mask && !act_open(Pack<T>::round(fmaf(xv[i], sc, sh)), act)) g = 0.0f;
+            if (act != AADG_ACT_NONE && !act_open(Pack<T>::round(fmaf(xv[i], sc, sh)), act)) g = 0.0f;
             xv[i] = fmaf(a, g, fmaf(b, xv[i], c0));
         }
         if (VEC == 1) Pack<T>::store1(dx + off, xv[0]); else Pack<T>::store(dx + off, xv);
@@ -355,15 +396,9 @@ int bn_forward(const T* x, const T* res, T* y, uint8_t* mask, const float* weigh
     if (training) {
         const dim3 grid(s.split, C);
         if (s.vec > 1)
-            hipLaunchKernelGGL((k_bn_reduce<T, Pack<T>::N, 0>), grid, blk, 0, st, x, (const T*)nullptr, (const T*)nullptr, BnExtra<T>{},
-                               (const uint8_t*)nullptr, (T*)nullptr,
-                               (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act, C,
-                               s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
+            hipLaunchKernelGGL((k_bn_reduce_fwd<T, Pack<T>::N>), grid, blk, 0, st, x, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         else
-            hipLaunchKernelGGL((k_bn_reduce<T, 1, 0>), grid, blk, 0, st, x, (const T*)nullptr, (const T*)nullptr, BnExtra<T>{},
-                               (const uint8_t*)nullptr, (T*)nullptr,
-                               (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act, C,
-                               s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
+            hipLaunchKernelGGL((k_bn_reduce_fwd<T, 1>), grid, blk, 0, st, x, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         AADG_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((C + 255) / 256), dim3(256), 0, st, ws + L.partial, s.split, C,
                            (double)N * (double)HW, weight, bias, rmean, rvar, momentum, eps, save_mean, save_invstd, scale, shift);
@@ -374,10 +409,20 @@ int bn_forward(const T* x, const T* res, T* y, uint8_t* mask, const float* weigh
         AADG_LAUNCH_CHECK();
     }
     const dim3 grid(N * C, s.pc.per_strip);
-    if (s.vec > 1)
-        hipLaunchKernelGGL((k_bn_apply<T, Pack<T>::N>), grid, blk, 0, st, x, res, y, mask, scale, shift, act, C, s.len, s.pc.plen);
-    else
-        hipLaunchKernelGGL((k_bn_apply<T, 1>), grid, blk, 0, st, x, res, y, mask, scale, shift, act, C, s.len, s.pc.plen);
+#define AADG_BN_APPLY(VEC_, ACT_, RES_, MASK_) \
+    hipLaunchKernelGGL((k_bn_apply<T, VEC_, ACT_, RES_, MASK_>), grid, blk, 0, st, x, res, y, mask, scale, shift, act, C, s.len, s.pc.plen)
+#define AADG_BN_APPLY_ACT(ACT_)                                                          \
+    do {                                                                                 \
+        if (res != nullptr) { if (mask != nullptr) AADG_BN_APPLY(Pack<T>::N, ACT_, true, true); else AADG_BN_APPLY(Pack<T>::N, ACT_, true, false); } \
+        else { if (mask != nullptr) AADG_BN_APPLY(Pack<T>::N, ACT_, false, true); else AADG_BN_APPLY(Pack<T>::N, ACT_, false, false); }              \
+    } while (0)
+    if (s.vec == 1) {
+        if (res != nullptr) AADG_BN_APPLY(1, -1, true, false); else AADG_BN_APPLY(1, -1, false, false);
+    } else if (act == AADG_ACT_RELU) AADG_BN_APPLY_ACT(AADG_ACT_RELU);
+    else if (act == AADG_ACT_RELU6) AADG_BN_APPLY_ACT(AADG_ACT_RELU6);
+    else AADG_BN_APPLY_ACT(AADG_ACT_NONE);
+#undef AADG_BN_APPLY_ACT
+#undef AADG_BN_APPLY
     AADG_LAUNCH_CHECK();
     return 0;
 }
@@ -402,12 +447,23 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
     AADG_LAUNCH_CHECK();
     {
         const dim3 grid(s.split, C);
-        if (s.vec > 1)
-            hipLaunchKernelGGL((k_bn_reduce<T, Pack<T>::N, 1>), grid, blk, 0, st, x, y, dy, more, mask, dres, mean, invstd, (const float*)scale,
-                               (const float*)shift, act, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
-        else
-            hipLaunchKernelGGL((k_bn_reduce<T, 1, 1>), grid, blk, 0, st, x, y, dy, more, mask, dres, mean, invstd, (const float*)scale,
-                               (const float*)shift, act, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
+#define AADG_BN_REDUCE_BWD(VEC_, MK_, NE_, DRES_)                                                                                        \
+    hipLaunchKernelGGL((k_bn_reduce_bwd<T, VEC_, MK_, NE_, DRES_>), grid, blk, 0, st, x, y, dy, more, mask, dres, mean, invstd,          \
+                       (const float*)scale, (const float*)shift, act, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial)
+#define AADG_BN_REDUCE_BWD_MK(MK_)                                                                     \
+    do {                                                                                               \
+        if (n_extra == 0) { if (dres != nullptr) AADG_BN_REDUCE_BWD(Pack<T>::N, MK_, 0, 1); else AADG_BN_REDUCE_BWD(Pack<T>::N, MK_, 0, 0); } \
+        else if (n_extra == 1) AADG_BN_REDUCE_BWD(Pack<T>::N, MK_, 1, 1);   /* a residual block's output: trunk + identity branch */          \
+        else AADG_BN_REDUCE_BWD(Pack<T>::N, MK_, -1, 1);                                                \
+    } while (0)
+        if (s.vec == 1) AADG_BN_REDUCE_BWD(1, 2, -1, -1);
+        else if (act == AADG_ACT_NONE) AADG_BN_REDUCE_BWD_MK(0);
+        else if (mask != nullptr) AADG_BN_REDUCE_BWD_MK(1);
+        else if (y == nullptr && n_extra == 0 && dres == nullptr && act == AADG_ACT_RELU) AADG_BN_REDUCE_BWD(Pack<T>::N, 3, 0, 0);
+        else if (y == nullptr && n_extra == 0 && dres == nullptr && act == AADG_ACT_RELU6) AADG_BN_REDUCE_BWD(Pack<T>::N, 4, 0, 0);
+        else AADG_BN_REDUCE_BWD(Pack<T>::N, 2, -1, -1);
+#undef AADG_BN_REDUCE_BWD_MK
+#undef AADG_BN_REDUCE_BWD
         AADG_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((C + 255) / 256), dim3(256), 0, st, ws + L.partial, s.split, C,
@@ -418,14 +474,15 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
         const T* g = dres != nullptr ? (const T*)dres : dy;
         const int g_ready = dres != nullptr ? 1 : 0;
         const dim3 grid(N * C, s.pc.per_strip);
-        if (s.vec > 1)
-            hipLaunchKernelGGL((k_bn_dx<T, Pack<T>::N>), grid, blk, 0, st, x, g, dx, (const float*)scale, (const float*)shift,
-                               (const float*)(ws + L.ca), (const float*)(ws + L.cb), (const float*)(ws + L.cc), act, g_ready, C,
-                               s.len, s.pc.plen);
-        else
-            hipLaunchKernelGGL((k_bn_dx<T, 1>), grid, blk, 0, st, x, g, dx, (const float*)scale, (const float*)shift,
-                               (const float*)(ws + L.ca), (const float*)(ws + L.cb), (const float*)(ws + L.cc), act, g_ready, C,
-                               s.len, s.pc.plen);
+        const int act_dx = g_ready ? AADG_ACT_NONE : act;
+#define AADG_BN_DX(VEC_, ACT_)                                                                                                \
+    hipLaunchKernelGGL((k_bn_dx<T, VEC_, ACT_>), grid, blk, 0, st, x, g, dx, (const float*)scale, (const float*)shift,         \
+                       (const float*)(ws + L.ca), (const float*)(ws + L.cb), (const float*)(ws + L.cc), act_dx, C, s.len, s.pc.plen)
+        if (s.vec == 1) AADG_BN_DX(1, -1);
+        else if (act_dx == AADG_ACT_RELU) AADG_BN_DX(Pack<T>::N, AADG_ACT_RELU);
+        else if (act_dx == AADG_ACT_RELU6) AADG_BN_DX(Pack<T>::N, AADG_ACT_RELU6);
+        else AADG_BN_DX(Pack<T>::N, AADG_ACT_NONE);
+#undef AADG_BN_DX
         AADG_LAUNCH_CHECK();
     }
     return 0;

@@ -47,8 +47,8 @@ template <> struct Elem<__hip_bfloat16> {
     }
     static __device__ __forceinline__ void store4(__hip_bfloat16* p, const float* v) {
         uint2 t;
-        t.x = aadg_f2bf_bits(v[0]) | (aadg_f2bf_bits(v[1]) << 16);
-        t.y = aadg_f2bf_bits(v[2]) | (aadg_f2bf_bits(v[3]) << 16);
+        t.x = aadg_f2bf_pk(v[0], v[1]);
+        t.y = aadg_f2bf_pk(v[2], v[3]);
         *reinterpret_cast<uint2*>(p) = t;
     }
 };

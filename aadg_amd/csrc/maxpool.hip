@@ -38,16 +38,16 @@ template <> struct Px<__hip_bfloat16> {
     }
     static __device__ __forceinline__ void store4(__hip_bfloat16* p, const float* v) {
         uint2 t;
-        t.x = aadg_f2bf_bits(v[0]) | (aadg_f2bf_bits(v[1]) << 16);
-        t.y = aadg_f2bf_bits(v[2]) | (aadg_f2bf_bits(v[3]) << 16);
+        t.x = aadg_f2bf_pk(v[0], v[1]);
+        t.y = aadg_f2bf_pk(v[2], v[3]);
         *reinterpret_cast<uint2*>(p) = t;
     }
     static __device__ __forceinline__ void store8(__hip_bfloat16* p, const float* v) {
         uint4 t;
-        t.x = aadg_f2bf_bits(v[0]) | (aadg_f2bf_bits(v[1]) << 16);
-        t.y = aadg_f2bf_bits(v[2]) | (aadg_f2bf_bits(v[3]) << 16);
-        t.z = aadg_f2bf_bits(v[4]) | (aadg_f2bf_bits(v[5]) << 16);
-        t.w = aadg_f2bf_bits(v[6]) | (aadg_f2bf_bits(v[7]) << 16);
+        t.x = aadg_f2bf_pk(v[0], v[1]);
+        t.y = aadg_f2bf_pk(v[2], v[3]);
+        t.z = aadg_f2bf_pk(v[4], v[5]);
+        t.w = aadg_f2bf_pk(v[6], v[7]);
         *reinterpret_cast<uint4*>(p) = t;
     }
 };

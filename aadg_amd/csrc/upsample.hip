@@ -32,10 +32,9 @@ template <> struct Vec4<__hip_bfloat16> {
         v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
     }
     static __device__ __forceinline__ void st4(__hip_bfloat16* p, float a, float b, float c, float d) {
-        const __hip_bfloat16 e[4] = {__float2bfloat16(a), __float2bfloat16(b), __float2bfloat16(c), __float2bfloat16(d)};
         uint2 v;
-        v.x = (uint32_t)(*reinterpret_cast<const uint16_t*>(&e[0])) | ((uint32_t)(*reinterpret_cast<const uint16_t*>(&e[1])) << 16);
-        v.y = (uint32_t)(*reinterpret_cast<const uint16_t*>(&e[2])) | ((uint32_t)(*reinterpret_cast<const uint16_t*>(&e[3])) << 16);
+        v.x = aadg_f2bf_pk(a, b);
+        v.y = aadg_f2bf_pk(c, d);
         *reinterpret_cast<uint2*>(p) = v;
     }
     static __device__ __forceinline__ void st1(__hip_bfloat16* p, float a) { *p = __float2bfloat16(a); }

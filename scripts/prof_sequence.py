@@ -1,5 +1,5 @@
 """rocprofv3 rocpd database -> time-ordered, run-length compressed kernel sequence of the last full step
-(longest window between two consecutive launches of the marker kernel, default k_fused)."""
+(a steady-state window between two consecutive launches of the marker kernel, default k_fused)."""
 import sqlite3
 import sys
 
@@ -9,9 +9,16 @@ def main(db, marker="k_fused"):
     rows = list(c.execute("select name, start, end, grid_x, grid_y, grid_z from kernels order by start"))
     idx = [i for i, r in enumerate(rows) if marker in r[0]]
     lo, hi = 0, len(rows)
-    if len(idx) >= 2:        # the longest marker-to-marker window = one full step (the hot-path loop launches the marker too)
-        k = max(range(len(idx) - 1), key=lambda i: rows[idx[i + 1]][1] - rows[idx[i]][1])
-        lo, hi = idx[k], idx[k + 1]
+    if len(idx) >= 2:
+        # marker-to-marker windows; a full step is much longer (in kernels) than a hot-path iteration, and the first full step
+        # also carries lazy initialisations: take the LAST window among those whose kernel count is within 2 % of the median
+        # count of the long windows
+        spans = [(idx[i], idx[i + 1]) for i in range(len(idx) - 1)]
+        longest = max(b - a for a, b in spans)
+        full = sorted(b - a for a, b in spans if (b - a) * 2 > longest)
+        med = full[len(full) // 2]
+        steady = [(a, b) for a, b in spans if abs((b - a) - med) <= 0.02 * med]
+        lo, hi = steady[-1] if steady else max(spans, key=lambda ab: ab[1] - ab[0])
     out, prev, cnt, dur = [], None, 0, 0.0
     for r in rows[lo:hi]:
         name = r[0].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:90]
