@@ -37,7 +37,7 @@ EXPORTS = [
     "aadg_upsample_bilinear2d_backward_workspace_bytes", "aadg_upsample_bilinear2d_backward_strided",
     "aadg_bn_workspace_bytes", "aadg_bn_mask_bytes", "aadg_bn_forward", "aadg_bn_backward",
     "aadg_dwconv3x3_supported", "aadg_dwconv3x3_workspace_bytes", "aadg_dwconv3x3", "aadg_dwconv3x3_wgrad",
-    "aadg_maxpool3x3s2_supported", "aadg_maxpool3x3s2_forward", "aadg_maxpool3x3s2_backward",
+    "aadg_maxpool3x3s2_supported", "aadg_maxpool3x3s2_index_bytes", "aadg_maxpool3x3s2_forward", "aadg_maxpool3x3s2_backward",
     "aadg_conv1x1_wgrad_supported", "aadg_conv1x1_wgrad_bf16",
     "aadg_controller_supported", "aadg_controller_workspace_bytes", "aadg_controller_sample_f32",
     "aadg_controller_ppo_update_f32",
@@ -117,7 +117,9 @@ def load():
     lib.aadg_maxpool3x3s2_supported.restype = _i
     lib.aadg_maxpool3x3s2_supported.argtypes = [_i, _i]
     lib.aadg_maxpool3x3s2_forward.restype = _i
-    lib.aadg_maxpool3x3s2_forward.argtypes = [_vp, _vp, _i, _i, _i, _i, _vp]
+    lib.aadg_maxpool3x3s2_index_bytes.restype = ctypes.c_size_t
+    lib.aadg_maxpool3x3s2_index_bytes.argtypes = [_i, _i, _i]
+    lib.aadg_maxpool3x3s2_forward.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp]
     lib.aadg_maxpool3x3s2_backward.restype = _i
     lib.aadg_maxpool3x3s2_backward.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp]
     lib.aadg_conv1x1_wgrad_supported.restype = _i
@@ -652,26 +654,31 @@ def dwconv3x3(x, weight, dilation=1):
 
 # ------------------------------------------------------------------------------------------------
 class _MaxPool3x3s2(torch.autograd.Function):
-    """F.max_pool2d(x, 3, 2, 1) with the HIP kernels (csrc/maxpool.hip); the backward re-derives the arg-max from x."""
+    """F.max_pool2d(x, 3, 2, 1) with the HIP kernels (csrc/maxpool.hip).  The forward stores the arg-max as one byte per
+    output (its position in the 3x3 window); the backward gathers from that and dy alone, so x is not kept alive."""
 
     @staticmethod
     def forward(ctx, x):
         lib = load()
         N, C, H, W = x.shape
         y = torch.empty((N, C, (H - 1) // 2 + 1, W // 2), dtype=x.dtype, device=x.device)
-        rc = lib.aadg_maxpool3x3s2_forward(x.data_ptr(), y.data_ptr(), N * C, H, W, _BN_DTYPES[x.dtype], _stream())
+        idx = None
+        if x.requires_grad:
+            idx = torch.empty(lib.aadg_maxpool3x3s2_index_bytes(N * C, H, W), dtype=torch.uint8, device=x.device)
+        rc = lib.aadg_maxpool3x3s2_forward(x.data_ptr(), y.data_ptr(), _ptr(idx), N * C, H, W, _BN_DTYPES[x.dtype], _stream())
         _check(rc, "aadg_maxpool3x3s2_forward")
-        ctx.save_for_backward(x)
+        ctx.save_for_backward(idx)
+        ctx.in_shape = tuple(x.shape)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = load()
-        x, = ctx.saved_tensors
-        N, C, H, W = x.shape
+        idx, = ctx.saved_tensors
+        N, C, H, W = ctx.in_shape
         dy = dy.contiguous()
-        dx = torch.empty_like(x)
-        rc = lib.aadg_maxpool3x3s2_backward(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), N * C, H, W, _BN_DTYPES[x.dtype], _stream())
+        dx = torch.empty(ctx.in_shape, dtype=dy.dtype, device=dy.device)
+        rc = lib.aadg_maxpool3x3s2_backward(idx.data_ptr(), dy.data_ptr(), dx.data_ptr(), N * C, H, W, _BN_DTYPES[dy.dtype], _stream())
         _check(rc, "aadg_maxpool3x3s2_backward")
         return dx
 

@@ -223,12 +223,15 @@ int aadg_dwconv3x3_wgrad(const void* x, const void* dy, float* dweight, int N, i
 /* ---------------------------------------------------------------------------------------------
  * Max pooling 3x3, stride 2, padding 1 over NCHW planes (the ResNet stem pool of the backbone's encoder,
  * torch.nn.MaxPool2d(3, 2, 1) semantics: padding never wins, ties -> first element in window order).
- * x [planes, H, W] -> y [planes, (H-1)/2+1, W/2]; W a multiple of 8.  The backward takes the forward INPUT and
- * re-derives the arg-max (no index tensor).  dtype 0 = float32, 1 = bfloat16.
+ * x [planes, H, W] -> y [planes, (H-1)/2+1, W/2]; W a multiple of 8.  `index` (optional in the forward: inference) receives
+ * one byte per output, the arg-max as its position 3*a + b inside the 3x3 window (the library keeps an int64 element index:
+ * 8 bytes); the backward needs only `index` and dy -- the pooled input is neither saved nor read.  aadg_maxpool3x3s2_index_bytes
+ * = planes * Ho * Wo.  dtype 0 = float32, 1 = bfloat16.
  * ------------------------------------------------------------------------------------------- */
 int aadg_maxpool3x3s2_supported(int H, int W);
-int aadg_maxpool3x3s2_forward(const void* x, void* y, int planes, int H, int W, int dtype, void* stream);
-int aadg_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int planes, int H, int W, int dtype, void* stream);
+size_t aadg_maxpool3x3s2_index_bytes(int planes, int H, int W);
+int aadg_maxpool3x3s2_forward(const void* x, void* y, void* index, int planes, int H, int W, int dtype, void* stream);
+int aadg_maxpool3x3s2_backward(const void* index, const void* dy, void* dx, int planes, int H, int W, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight gradient of a 1x1 / stride-1 / no-padding convolution, NCHW bfloat16 activations (the pointwise

@@ -102,7 +102,8 @@ def test_backbone_and_controller_entry_points_validate_arguments():
     assert lib.aadg_conv1x1_wgrad_bf16(one, one, one, 1, 8, 8, 48, z) == -3
     # max pooling
     assert lib.aadg_maxpool3x3s2_supported(16, 16) == 1 and lib.aadg_maxpool3x3s2_supported(16, 12) == 0
-    assert lib.aadg_maxpool3x3s2_forward(z, z, 1, 16, 16, 0, z) == -1
+    assert lib.aadg_maxpool3x3s2_forward(z, z, z, 1, 16, 16, 0, z) == -1
+    assert lib.aadg_maxpool3x3s2_index_bytes(3, 16, 16) == 3 * 8 * 8 and lib.aadg_maxpool3x3s2_index_bytes(3, 16, 12) == 0
     assert lib.aadg_maxpool3x3s2_backward(one, one, one, 1, 16, 12, 0, z) == -3
     # up-sampling backward
     assert lib.aadg_upsample_bilinear2d_backward_supported(32, 32, 128, 128) == 1

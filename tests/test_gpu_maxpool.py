@@ -27,6 +27,13 @@ def test_maxpool_matches_torch(hip, shape, dtype, ties):
     assert (x.grad.float() - xr.grad.float()).abs().max().item() <= tol
 
 
+def test_maxpool_without_gradient_skips_the_index(hip):
+    x = torch.randn(2, 3, 20, 32, device="cuda", dtype=torch.bfloat16)
+    with torch.no_grad():
+        y = hip.maxpool3x3s2(x)
+    assert torch.equal(y, F.max_pool2d(x, 3, 2, 1))
+
+
 def test_maxpool_unsupported_width(hip):
     x = torch.randn(1, 1, 8, 12, device="cuda")
     assert not hip.maxpool3x3s2_supported(x)
