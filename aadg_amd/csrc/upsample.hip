@@ -19,9 +19,12 @@ template <> struct Vec4<float> {
         const float4 t = *reinterpret_cast<const float4*>(p);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
+    static constexpr int V16 = 4;                       // elements per 16-byte load
+    static __device__ __forceinline__ void ld16(const float* p, float* v) { ld4(p, v); }
     static __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
         *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
     }
+    static __device__ __forceinline__ void st8(float* p, const float* v) { st4(p, v[0], v[1], v[2], v[3]); st4(p + 4, v[4], v[5], v[6], v[7]); }
     static __device__ __forceinline__ void st1(float* p, float a) { *p = a; }
 };
 template <> struct Vec4<__hip_bfloat16> {
@@ -31,11 +34,21 @@ template <> struct Vec4<__hip_bfloat16> {
         v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
         v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
     }
+    static constexpr int V16 = 8;
+    static __device__ __forceinline__ void ld16(const __hip_bfloat16* p, float* v) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(u[i] << 16); v[2 * i + 1] = __uint_as_float(u[i] & 0xFFFF0000u); }
+    }
     static __device__ __forceinline__ void st4(__hip_bfloat16* p, float a, float b, float c, float d) {
         uint2 v;
         v.x = aadg_f2bf_pk(a, b);
         v.y = aadg_f2bf_pk(c, d);
         *reinterpret_cast<uint2*>(p) = v;
+    }
+    static __device__ __forceinline__ void st8(__hip_bfloat16* p, const float* v) {      // one 16-byte store
+        *reinterpret_cast<uint4*>(p) = make_uint4(aadg_f2bf_pk(v[0], v[1]), aadg_f2bf_pk(v[2], v[3]), aadg_f2bf_pk(v[4], v[5]), aadg_f2bf_pk(v[6], v[7]));
     }
     static __device__ __forceinline__ void st1(__hip_bfloat16* p, float a) { *p = __float2bfloat16(a); }
 };
@@ -92,54 +105,59 @@ __global__ __launch_bounds__(256) void k_upsample(const T* __restrict__ in, T* _
 }
 
 // Small input planes (h * w <= UP_LDS_MAX, e.g. the 32 x 32 ASPP map): the plane is staged once in LDS as float, so the
-// 16 taps of a lane's 4 outputs are LDS reads instead of 2-byte global gathers.  grid (ceil(H / UP_ROWS), planes).
-constexpr int UP_LDS_MAX = 4096, UP_ROWS = 32;
+// taps of a lane's outputs are LDS reads instead of 2-byte global gathers.  An item = OPI consecutive outputs of one row
+// (16 bytes of T when the width allows); the items of `rows` output rows are dealt round-robin to the 256 lanes, so every
+// lane is busy whatever the width.  grid (ceil(H / rows), planes); rows = H (one staging per plane) for outputs <= 128 x 128.
+constexpr int UP_LDS_MAX = 4096, UP_ROWS = 32, UP_WHOLE_PLANE = 16384;
 
-template <typename T>
+template <typename T, int OPI>
 __global__ __launch_bounds__(256) void k_upsample_lds(const T* __restrict__ in, T* __restrict__ out, int h, int w, int H, int W,
-                                                      float sy, float sx, int C, long long out_img_stride, int plane0) {
-    __shared__ float P[UP_LDS_MAX];
+                                                      float sy, float sx, int C, long long out_img_stride, int plane0, int rows) {
+    __shared__ __attribute__((aligned(16))) float P[UP_LDS_MAX];
     const size_t plane = (size_t)plane0 + blockIdx.y;
     const T* pin = in + plane * (size_t)h * w;
-    for (int i = threadIdx.x; i < h * w; i += 256) P[i] = Vec4<T>::ld(pin + i);
+    constexpr int V = Vec4<T>::V16;
+    const int hw = h * w;
+    if ((hw % V) == 0 && (((uintptr_t)pin) & 15u) == 0) {
+        for (int i = threadIdx.x; i < hw / V; i += 256) {
+            float v[V];
+            Vec4<T>::ld16(pin + (size_t)i * V, v);
+#pragma unroll
+            for (int e = 0; e < V; e += 4) *reinterpret_cast<float4*>(P + (size_t)i * V + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < hw; i += 256) P[i] = Vec4<T>::ld(pin + i);
+    }
     __syncthreads();
     // the output may be a channel slice of a wider tensor (written straight into a concatenation buffer)
     T* po = out + (plane / C) * (size_t)out_img_stride + (plane % C) * (size_t)H * W;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int Y0 = blockIdx.x * UP_ROWS, Y1 = min(H, Y0 + UP_ROWS);
-    const bool vec = (W & 3) == 0;
-    for (int xg = 0; xg * 256 < W; ++xg) {
-        const int x0 = xg * 256 + lane * 4;
-        if (x0 >= W) continue;
-        int xi0[4], xi1[4];
-        float lx1[4];
+    const int Y0 = blockIdx.x * rows, nrows = min(H, Y0 + rows) - Y0;
+    const int per_row = (W + OPI - 1) / OPI;
+    const bool vec = (W % OPI) == 0;
+    for (int item = threadIdx.x; item < nrows * per_row; item += 256) {
+        const int yy = item / per_row, x0 = (item - yy * per_row) * OPI;
+        const int Y = Y0 + yy;
+        const float srcy = sy * (float)Y;
+        const int y0 = (int)srcy;
+        const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+        const float ly1 = srcy - (float)y0, ly0 = 1.0f - ly1;
+        const float* r0 = P + y0 * w;
+        const float* r1 = P + y1 * w;
+        float v[OPI];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < OPI; ++k) {
             const int X = min(x0 + k, W - 1);
             const float src = sx * (float)X;
             const int i0 = (int)src;
-            xi0[k] = i0;
-            xi1[k] = i0 + (i0 < w - 1 ? 1 : 0);
-            lx1[k] = src - (float)i0;
+            const int i1 = i0 + (i0 < w - 1 ? 1 : 0);
+            const float lx1 = src - (float)i0, lx0 = 1.0f - lx1;
+            v[k] = ly0 * (lx0 * r0[i0] + lx1 * r0[i1]) + ly1 * (lx0 * r1[i0] + lx1 * r1[i1]);
         }
-#pragma unroll 2
-        for (int Y = Y0 + wv; Y < Y1; Y += 4) {
-            const float srcy = sy * (float)Y;
-            const int y0 = (int)srcy;
-            const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
-            const float ly1 = srcy - (float)y0, ly0 = 1.0f - ly1;
-            const float* r0 = P + y0 * w;
-            const float* r1 = P + y1 * w;
-            float v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float lx0 = 1.0f - lx1[k];
-                v[k] = ly0 * (lx0 * r0[xi0[k]] + lx1[k] * r0[xi1[k]]) + ly1 * (lx0 * r1[xi0[k]] + lx1[k] * r1[xi1[k]]);
-            }
-            T* dst = po + (size_t)Y * W + x0;
-            if (vec) Vec4<T>::st4(dst, v[0], v[1], v[2], v[3]);
-            else
-                for (int k = 0; k < 4 && x0 + k < W; ++k) Vec4<T>::st1(dst + k, v[k]);
+        T* dst = po + (size_t)Y * W + x0;
+        if (vec) {
+            if constexpr (OPI == 8) Vec4<T>::st8(dst, v); else Vec4<T>::st4(dst, v[0], v[1], v[2], v[3]);
+        } else {
+            for (int k = 0; k < OPI && x0 + k < W; ++k) Vec4<T>::st1(dst + k, v[k]);
         }
     }
 }
@@ -263,43 +281,43 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const T* __restrict__ dy, 
     }
 }
 
-// Whole-plane variant for small outputs (H * W <= UPB_MAX_OUT, e.g. 128 x 128 -> 32 x 32): one workgroup per plane stages
-// the plane of dy once (contiguous 16-byte loads, no halo re-reads), reduces along y into V[h][W], then along x.
+// Whole-plane variant for small outputs (H * W <= UPB_MAX_OUT, e.g. 128 x 128 -> 32 x 32): one workgroup per plane.  The
+// reduction along y reads dy straight from global memory with 16-byte loads -- every tap of an item is an independent load
+// (<= BT_MAXTAP in flight per lane), an output row feeds at most two input rows, so the second read hits L1 / L2 -- into
+// V[h][W] in LDS (16 KiB at 32 x 128: eight workgroups per CU instead of the two a staged copy of dy allowed); then along x.
 constexpr int UPB_MAX_OUT = 16384, UPB_MAX_IN_ROWS = 64;
 
-template <typename T>
+template <typename T, int CPI>          // CPI = columns per item of the first pass (16 bytes of T, or 4)
 __global__ __launch_bounds__(256) void k_upsample_bwd_plane(const T* __restrict__ dy, T* __restrict__ dx, int h, int w, int H, int W,
                                                             const float* __restrict__ tab, int C, long long dy_img_stride) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* D = lds;                         // [H][W] staged dy (float)
-    float* V = lds + (size_t)H * W;         // [h][W]
+    extern __shared__ __attribute__((aligned(16))) float V[];      // [h][W]
     const size_t plane = blockIdx.x;
     // dy may be a channel slice of a wider tensor (the gradient of a concatenation): image stride given by the caller
     const T* pdy = dy + (plane / C) * (size_t)dy_img_stride + (plane % C) * (size_t)H * W;
     const int tid = threadIdx.x;
-    const int n4 = H * W / 4;
-    for (int i = tid; i < n4; i += 256) {
-        float v[4];
-        Vec4<T>::ld4(pdy + (size_t)i * 4, v);
-        *reinterpret_cast<float4*>(D + (size_t)i * 4) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    __syncthreads();
     const float* ty = tab;
     const float* tx = tab + (size_t)h * TAP_STRIDE;
-    const int w4 = W / 4;
-    for (int t = tid; t < h * w4; t += 256) {          // along y: (input row i, 4 consecutive output columns)
-        const int i = t / w4, c4 = (t - i * w4) * 4;
+    const int wc = W / CPI;
+    for (int t = tid; t < h * wc; t += 256) {          // along y: (input row i, CPI consecutive output columns)
+        const int i = t / wc, c0 = (t - i * wc) * CPI;
         const float* tp = ty + (size_t)i * TAP_STRIDE;
         const int yf = reinterpret_cast<const int*>(tp)[0], yn = reinterpret_cast<const int*>(tp)[1];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float acc[CPI];
+#pragma unroll
+        for (int e = 0; e < CPI; ++e) acc[e] = 0.f;
+        const T* col = pdy + (size_t)yf * W + c0;
 #pragma unroll
         for (int k = 0; k < BT_MAXTAP; ++k)
             if (k < yn) {
                 const float wgt = tp[2 + k];
-                const float4 d = *reinterpret_cast<const float4*>(D + (size_t)(yf + k) * W + c4);
-                acc.x = fmaf(wgt, d.x, acc.x); acc.y = fmaf(wgt, d.y, acc.y); acc.z = fmaf(wgt, d.z, acc.z); acc.w = fmaf(wgt, d.w, acc.w);
+                float d[CPI];
+                if (CPI == 4) Vec4<T>::ld4(col + (size_t)k * W, d); else Vec4<T>::ld16(col + (size_t)k * W, d);
+#pragma unroll
+                for (int e = 0; e < CPI; ++e) acc[e] = fmaf(wgt, d[e], acc[e]);
             }
-        *reinterpret_cast<float4*>(V + (size_t)i * W + c4) = acc;
+#pragma unroll
+        for (int e = 0; e < CPI; e += 4)
+            *reinterpret_cast<float4*>(V + (size_t)i * W + c0 + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
     }
     __syncthreads();
     T* pdx = dx + plane * (size_t)h * w;
@@ -344,13 +362,19 @@ extern "C" int aadg_upsample_bilinear2d_strided(const void* in, void* out, int N
     for (int p0 = 0; p0 < planes; p0 += 65535) {          // gridDim.y limit
         const int np = planes - p0 < 65535 ? planes - p0 : 65535;
         if (lds_path) {
-            const dim3 gl((H + UP_ROWS - 1) / UP_ROWS, np);
+            const int rows = (long long)H * W <= UP_WHOLE_PLANE ? H : UP_ROWS;
+            const dim3 gl((H + rows - 1) / rows, np);
+            // 16-byte stores need the whole destination aligned: base pointer, image stride and plane size
+            const bool wide = dtype == 1 && (W & 7) == 0 && (((uintptr_t)out) & 15u) == 0 && (out_image_stride & 7) == 0 && (((long long)H * W) & 7) == 0;
             if (dtype == 0)
-                hipLaunchKernelGGL(k_upsample_lds<float>, gl, dim3(256), 0, st, reinterpret_cast<const float*>(in),
-                                   reinterpret_cast<float*>(out), h, w, H, W, sy, sx, C, out_image_stride, p0);
+                hipLaunchKernelGGL((k_upsample_lds<float, 4>), gl, dim3(256), 0, st, reinterpret_cast<const float*>(in),
+                                   reinterpret_cast<float*>(out), h, w, H, W, sy, sx, C, out_image_stride, p0, rows);
+            else if (wide)
+                hipLaunchKernelGGL((k_upsample_lds<__hip_bfloat16, 8>), gl, dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(in),
+                                   reinterpret_cast<__hip_bfloat16*>(out), h, w, H, W, sy, sx, C, out_image_stride, p0, rows);
             else
-                hipLaunchKernelGGL(k_upsample_lds<__hip_bfloat16>, gl, dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(in),
-                                   reinterpret_cast<__hip_bfloat16*>(out), h, w, H, W, sy, sx, C, out_image_stride, p0);
+                hipLaunchKernelGGL((k_upsample_lds<__hip_bfloat16, 4>), gl, dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(in),
+                                   reinterpret_cast<__hip_bfloat16*>(out), h, w, H, W, sy, sx, C, out_image_stride, p0, rows);
         } else {
             const dim3 g(xgroups * ((H + rows_per_block - 1) / rows_per_block), np);
             if (dtype == 0)
@@ -405,24 +429,18 @@ extern "C" int aadg_upsample_bilinear2d_backward_strided(const void* dy, void* d
     hipLaunchKernelGGL(k_upsample_bwd_taps, dim3(2), dim3(256), 0, st, h, w, H, W, sy, sx, tab);
     AADG_LAUNCH_CHECK();
     const size_t esz = dtype == 0 ? 4 : 2;
-    if (H * W <= UPB_MAX_OUT && (W & 3) == 0 && h <= UPB_MAX_IN_ROWS && (((uintptr_t)dy) & 15u) == 0 && (((size_t)H * W) % 8) == 0 &&
+    if (H * W <= UPB_MAX_OUT && (size_t)h * W <= (size_t)UPB_MAX_OUT && (W & 3) == 0 && h <= UPB_MAX_IN_ROWS && (((uintptr_t)dy) & 15u) == 0 && (((size_t)H * W) % 8) == 0 &&
         ((size_t)img_stride * esz) % 16 == 0) {
-        static bool attr[2] = {false, false};
-        const size_t lds_p = ((size_t)H * W + (size_t)h * W) * sizeof(float);      // <= 64 KiB + 16 KiB
-        if (!attr[dtype]) {
-            if (dtype == 0)
-                AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_upsample_bwd_plane<float>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            else
-                AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_upsample_bwd_plane<__hip_bfloat16>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            attr[dtype] = true;
-        }
+        const size_t lds_p = (size_t)h * W * sizeof(float);                         // <= 64 KiB
         if (dtype == 0)
-            hipLaunchKernelGGL(k_upsample_bwd_plane<float>, dim3(planes), dim3(256), lds_p, st, reinterpret_cast<const float*>(dy),
+            hipLaunchKernelGGL((k_upsample_bwd_plane<float, 4>), dim3(planes), dim3(256), lds_p, st, reinterpret_cast<const float*>(dy),
                                reinterpret_cast<float*>(dx), h, w, H, W, (const float*)tab, C, img_stride);
+        else if ((W & 7) == 0)
+            hipLaunchKernelGGL((k_upsample_bwd_plane<__hip_bfloat16, 8>), dim3(planes), dim3(256), lds_p, st,
+                               reinterpret_cast<const __hip_bfloat16*>(dy), reinterpret_cast<__hip_bfloat16*>(dx), h, w, H, W,
+                               (const float*)tab, C, img_stride);
         else
-            hipLaunchKernelGGL(k_upsample_bwd_plane<__hip_bfloat16>, dim3(planes), dim3(256), lds_p, st,
+            hipLaunchKernelGGL((k_upsample_bwd_plane<__hip_bfloat16, 4>), dim3(planes), dim3(256), lds_p, st,
                                reinterpret_cast<const __hip_bfloat16*>(dy), reinterpret_cast<__hip_bfloat16*>(dx), h, w, H, W,
                                (const float*)tab, C, img_stride);
         AADG_LAUNCH_CHECK();
