@@ -23,13 +23,17 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int WG_BK = 64;                 // K elements per step (128 bytes per row)
 constexpr int WG_PITCH = WG_BK + 8;       // LDS row pitch in elements (144 bytes: conflict-free 16-byte fragment reads)
 
-// WR x WC waves, each a 64 x 64 tile of dW (2 x 2 MFMA tiles)
-template <int WR, int WC>
-__global__ __launch_bounds__(256) void k_wgrad1x1(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X,
-                                                  float* __restrict__ acc, int Co, int Ci, int HW, int tiles, int tiles_n,
-                                                  int steps_total, int steps_per_block) {
-    static_assert(WR * WC == 4, "four waves per workgroup");
-    constexpr int BM = 64 * WR, BN = 64 * WC, R = BM + BN, LPT = R * 8 / 256;
+// WR x WC waves, each an (MI x NI) block of 32 x 32 MFMA tiles of dW: workgroup tile BM x BN = (32 MI WR) x (32 NI WC).
+// Per 16-wide K sub-step a wave reads MI + NI fragments from LDS for MI * NI MFMAs, and a workgroup pulls (BM + BN) * 128
+// bytes per 64-wide K step through L2 for BM * BN * 128 flops: the 256 x 256 tile (8 waves of 128 x 64) halves both ratios
+// relative to 128 x 128 (4 waves of 64 x 64), which is what the channel-rich late layers (>= 256 x 256 weights) are bound by.
+template <int WR, int WC, int MI, int NI>
+__global__ __launch_bounds__(64 * WR * WC) void k_wgrad1x1(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X,
+                                                           float* __restrict__ acc, int Co, int Ci, int HW, int tiles, int tiles_n,
+                                                           int steps_total, int steps_per_block) {
+    constexpr int NT = 64 * WR * WC;
+    constexpr int BM = 32 * MI * WR, BN = 32 * NI * WC, R = BM + BN, LPT = R * 8 / NT, LPT_A = BM * 8 / NT;
+    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "a staging slot is entirely dY or entirely X");
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];      // [2][R][WG_PITCH]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv / WC, wc = wv - wr * WC;
@@ -46,83 +50,83 @@ __global__ __launch_bounds__(256) void k_wgrad1x1(const uint16_t* __restrict__ d
 
     // this thread's LPT (row, 16-byte chunk) slots of the staged tile; rows beyond Co / Ci read as zero
     const uint16_t* src[LPT];
-    size_t img_stride[LPT];
-    int lds_off[LPT];
+    const int row0 = tid >> 3, c8 = (tid & 7) * 8;
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
-        const int id = tid + 256 * i, row = id >> 3, c = id & 7;
-        lds_off[i] = row * WG_PITCH + c * 8;
-        if (row < BM) {
+        const int row = row0 + (NT / 8) * i;
+        if (i < LPT_A) {
             const int m = m0 + row;
-            src[i] = m < Co ? dY + (size_t)m * HW + c * 8 : nullptr;
-            img_stride[i] = (size_t)Co * HW;
+            src[i] = m < Co ? dY + (size_t)m * HW + c8 : nullptr;
         } else {
             const int n = n0 + row - BM;
-            src[i] = n < Ci ? X + (size_t)n * HW + c * 8 : nullptr;
-            img_stride[i] = (size_t)Ci * HW;
+            src[i] = n < Ci ? X + (size_t)n * HW + c8 : nullptr;
         }
     }
+    const size_t stride_a = (size_t)Co * HW, stride_b = (size_t)Ci * HW;
     uint4 stage[LPT];
     auto fetch = [&](int step) {
         const int n = step / spi, kk = (step - n * spi) * WG_BK;
 #pragma unroll
         for (int i = 0; i < LPT; ++i)
-            stage[i] = src[i] != nullptr ? *reinterpret_cast<const uint4*>(src[i] + (size_t)n * img_stride[i] + kk) : make_uint4(0, 0, 0, 0);
+            stage[i] = src[i] != nullptr ? *reinterpret_cast<const uint4*>(src[i] + (size_t)n * (i < LPT_A ? stride_a : stride_b) + kk)
+                                         : make_uint4(0, 0, 0, 0);
     };
 
-    f32x16 d[2][2];
+    f32x16 d[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) d[mi][ni][r] = 0.0f;
 
-    const int a_row = wr * 64 + (lane & 31), b_row = BM + wc * 64 + (lane & 31), koff = (lane >> 5) * 8;
+    const int a_row = wr * 32 * MI + (lane & 31), b_row = BM + wc * 32 * NI + (lane & 31), koff = (lane >> 5) * 8;
+    const int st_off = row0 * WG_PITCH + c8;
     fetch(s0);
     int buf = 0;
     for (int step = s0; step < s1; ++step) {
         uint16_t* L = lds + (size_t)buf * R * WG_PITCH;
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) *reinterpret_cast<uint4*>(L + lds_off[i]) = stage[i];
+        for (int i = 0; i < LPT; ++i) *reinterpret_cast<uint4*>(L + st_off + (NT / 8) * i * WG_PITCH) = stage[i];
         __syncthreads();
         if (step + 1 < s1) fetch(step + 1);              // in flight during the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < WG_BK / 16; ++ks) {
-            bf16x8 a[2], b[2];
+            bf16x8 a[MI], b[NI];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
                 a[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(L + (a_row + 32 * mi) * WG_PITCH + ks * 16 + koff));
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
                 b[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(L + (b_row + 32 * ni) * WG_PITCH + ks * 16 + koff));
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], d[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < NI; ++ni) d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], d[mi][ni], 0, 0, 0);
         }
         buf ^= 1;
     }
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int n = n0 + wc * 64 + ni * 32 + (lane & 31);
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + wc * 32 * NI + ni * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = m0 + wr * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < Co && n < Ci) unsafeAtomicAdd(acc + (size_t)m * Ci + n, d[mi][ni][r]);
             }
         }
 }
 
-template <int WR, int WC>
-int launch(const uint16_t* dY, const uint16_t* X, float* acc, int N, int Co, int Ci, int HW, hipStream_t st) {
-    constexpr int BM = 64 * WR, BN = 64 * WC, R = BM + BN;
+// target_wgs: workgroups aimed at (every one of them ends with BM * BN float atomics: the big tile runs one per CU)
+template <int WR, int WC, int MI, int NI>
+int launch(const uint16_t* dY, const uint16_t* X, float* acc, int N, int Co, int Ci, int HW, int target_wgs, hipStream_t st) {
+    constexpr int BM = 32 * MI * WR, BN = 32 * NI * WC, R = BM + BN, NT = 64 * WR * WC;
     const int tiles_m = (Co + BM - 1) / BM, tiles_n = (Ci + BN - 1) / BN, tiles = tiles_m * tiles_n;
     const int steps_total = N * (HW / WG_BK);
-    int split = (1024 + tiles - 1) / tiles;                  // ~4 workgroups per CU
+    int split = (target_wgs + tiles - 1) / tiles;
     if (split > steps_total / 8) split = steps_total / 8;    // >= 8 K-steps per workgroup
     if (split < 1) split = 1;
     if (split > 65535) split = 65535;
@@ -131,14 +135,14 @@ int launch(const uint16_t* dY, const uint16_t* X, float* acc, int N, int Co, int
     const size_t lds = (size_t)2 * R * WG_PITCH * sizeof(uint16_t);
     static bool attr_set = false;                            // per instantiation; idempotent
     if (!attr_set) {
-        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad1x1<WR, WC>),
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad1x1<WR, WC, MI, NI>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     AADG_HIP_TRY(hipMemsetAsync(acc, 0, (size_t)Co * Ci * sizeof(float), st));
     const int slice_groups = (split + 7) / 8;                 // slices are padded to a multiple of 8 (empty ones exit at once)
-    hipLaunchKernelGGL((k_wgrad1x1<WR, WC>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(256), lds, st, dY, X, acc, Co, Ci, HW,
-                       tiles, tiles_n, steps_total, steps_per_block);
+    hipLaunchKernelGGL((k_wgrad1x1<WR, WC, MI, NI>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(NT), lds, st, dY, X, acc, Co, Ci,
+                       HW, tiles, tiles_n, steps_total, steps_per_block);
     AADG_LAUNCH_CHECK();
     return 0;
 }
@@ -156,7 +160,9 @@ extern "C" int aadg_conv1x1_wgrad_bf16(const void* dy, const void* x, float* dwe
     hipStream_t st = (hipStream_t)stream;
     const uint16_t* a = (const uint16_t*)dy;
     const uint16_t* b = (const uint16_t*)x;
-    if (Co <= 64) return launch<1, 4>(a, b, dweight, N, Co, Ci, HW, st);
-    if (Ci <= 64) return launch<4, 1>(a, b, dweight, N, Co, Ci, HW, st);
-    return launch<2, 2>(a, b, dweight, N, Co, Ci, HW, st);
+    if (Co <= 64) return launch<1, 4, 2, 2>(a, b, dweight, N, Co, Ci, HW, 1024, st);
+    if (Ci <= 64) return launch<4, 1, 2, 2>(a, b, dweight, N, Co, Ci, HW, 1024, st);
+    if (Co >= 256 && Ci >= 256 && (Co % 256) == 0 && (Ci % 256) == 0 && (long long)Co * Ci >= 512 * 512)
+        return launch<2, 4, 4, 2>(a, b, dweight, N, Co, Ci, HW, 256, st);
+    return launch<2, 2, 2, 2>(a, b, dweight, N, Co, Ci, HW, 1024, st);
 }

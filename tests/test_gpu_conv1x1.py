@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("N,Co,Ci,H,W", [(3, 64, 64, 16, 16), (2, 256, 64, 16, 8), (2, 64, 256, 8, 8), (5, 128, 192, 16, 16),
                                           (2, 48, 256, 32, 32), (3, 256, 304, 8, 16), (1, 2048, 512, 8, 8), (7, 20, 36, 8, 8),
-                                          (4, 130, 70, 16, 4)])
+                                          (4, 130, 70, 16, 4), (3, 512, 1024, 16, 8), (2, 768, 512, 8, 8)])
 def test_wgrad_matches_float32_reference(hip, N, Co, Ci, H, W):
     torch.manual_seed(Co + Ci)
     dy = torch.randn(N, Co, H, W, device="cuda").bfloat16()
