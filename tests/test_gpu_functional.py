@@ -116,7 +116,7 @@ def test_operation_modules(hip):
     for name in Op.__all__:
         mod = getattr(Op, name)().cuda()
         mod.train()
-        y = mod(x.clone())
+        y = mod(x.clone()).detach()
         assert y.shape == x.shape and float(y.min()) >= 0 and float(y.max()) <= 1, name
         mod.eval()
         y = mod(x.clone())
