@@ -102,7 +102,7 @@ class Conv1x1(nn.Conv2d):
 
 
 class MaxPool3x3s2(nn.MaxPool2d):
-    """MaxPool2d(3, 2, 1); on the GPU the HIP kernels (csrc/maxpool.hip: no index tensor, arg-max re-derived in backward)."""
+    """MaxPool2d(3, 2, 1); on the GPU the HIP kernels (csrc/maxpool.hip: one index byte per output, gather backward)."""
 
     def __init__(self):
         super().__init__(3, stride=2, padding=1)
@@ -117,9 +117,28 @@ class MaxPool3x3s2(nn.MaxPool2d):
 
 
 class SeparableConv2d(nn.Sequential):
+    """Depthwise 3x3 (dilated) followed by a pointwise convolution, no normalisation in between."""
+
     def __init__(self, cin, cout, k=3, dilation=1):
         assert k == 3
         super().__init__(DepthwiseConv3x3(cin, dilation=dilation), Conv1x1(cin, cout))
+
+    def forward(self, x):
+        dw, pw = self[0], self[1]
+        d = dw.dilation[0]
+        if d >= x.shape[2] and d >= x.shape[3] and dw.stride == (1, 1) and dw.padding == (d, d):
+            # The dilation reaches past the map (ASPP rate 36 on the 32 x 32 map of a 512 x 512 input): every tap but the centre
+            # reads padding only, so the depthwise pass is a per-channel scale -- folded into the pointwise weights (a [cout, cin]
+            # product) instead of streaming the whole activation through a convolution, forward and backward.  The gradient of
+            # the eight unused taps is exactly zero either way.
+            w = pw.weight * dw.weight[:, 0, 1, 1].view(1, -1, 1, 1)
+            if x.is_cuda and x.dtype == torch.bfloat16:
+                from .. import _lib
+                xc = x.contiguous()
+                if _lib.conv1x1_supported(xc, w):
+                    return _lib.conv1x1(xc, w)
+            return F.conv2d(x, w.to(x.dtype))
+        return pw(dw(x))
 
 
 # ---------------------------------------------------------------------------------------------- ResNet-50

@@ -52,7 +52,9 @@ def test_hip_layers_match_library_layers_in_situ(hip, encoder, monkeypatch):
         monkeypatch.setattr(hip, name, counted(key))
     ours32 = _run(m, state, x, y, False)
     ours16 = _run(m, state, x, y, True)
-    assert used["bn"] > 60 and used["dw"] >= 8 and used["c1"] > 5              # both runs went through the kernels
+    # both runs went through the kernels (on this 8 x 8 encoder map every ASPP rate reaches past the map, so the ResNet
+    # variant folds its three dilated depthwise passes into the pointwise weights: only the decoder's remain)
+    assert used["bn"] > 60 and used["dw"] >= (8 if encoder == "mobilenet_v2" else 2) and used["c1"] > 5
     if encoder == "resnet50":
         assert used["mp"] == 2
     # every HIP layer refused -> module fallbacks

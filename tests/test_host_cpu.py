@@ -118,3 +118,29 @@ def test_shard_rows_law():
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     with pytest.raises(ValueError):
         shard_rows(144, 0, 5)
+
+
+def test_separable_conv_folds_a_dilation_that_reaches_past_the_map():
+    """ASPP rate 36 on a 32 x 32 map: only the centre tap of the depthwise kernel sees data, so SeparableConv2d folds it into
+    the pointwise weights -- same output and gradients as the two convolutions, zero gradient on the eight unused taps."""
+    from aadg_amd.models.deeplab import SeparableConv2d
+    torch.manual_seed(0)
+    m = SeparableConv2d(6, 4, dilation=36).double()
+    x = torch.randn(2, 6, 32, 32, dtype=torch.float64, requires_grad=True)
+    y = m(x)
+    y.square().sum().backward()
+    got = (y.detach(), x.grad.clone(), m[0].weight.grad.clone(), m[1].weight.grad.clone())
+    x.grad = None
+    m.zero_grad()
+    y2 = m[1](m[0](x))                                         # the two convolutions, unfolded
+    y2.square().sum().backward()
+    want = (y2.detach(), x.grad, m[0].weight.grad, m[1].weight.grad)
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b, rtol=1e-10, atol=1e-10)
+    g = got[2].clone()
+    g[:, 0, 1, 1] = 0
+    assert g.abs().max().item() == 0.0
+    # a map larger than the dilation takes the ordinary path
+    m2 = SeparableConv2d(6, 4, dilation=12).double()
+    x2 = torch.randn(1, 6, 32, 32, dtype=torch.float64)
+    assert torch.allclose(m2(x2), m2[1](m2[0](x2)))
