@@ -37,6 +37,7 @@ EXPORTS = [
     "aadg_upsample_bilinear2d_backward_workspace_bytes", "aadg_upsample_bilinear2d_backward_strided",
     "aadg_bn_workspace_bytes", "aadg_bn_mask_bytes", "aadg_bn_forward", "aadg_bn_backward",
     "aadg_dwconv3x3_supported", "aadg_dwconv3x3_workspace_bytes", "aadg_dwconv3x3", "aadg_dwconv3x3_wgrad",
+    "aadg_subsample2x2_supported", "aadg_subsample2x2", "aadg_subsample2x2_backward",
     "aadg_maxpool3x3s2_supported", "aadg_maxpool3x3s2_index_bytes", "aadg_maxpool3x3s2_forward", "aadg_maxpool3x3s2_backward",
     "aadg_conv1x1_wgrad_supported", "aadg_conv1x1_wgrad_bf16",
     "aadg_controller_supported", "aadg_controller_workspace_bytes", "aadg_controller_sample_f32",
@@ -114,6 +115,12 @@ def load():
     lib.aadg_dwconv3x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]
     lib.aadg_dwconv3x3_wgrad.restype = _i
     lib.aadg_dwconv3x3_wgrad.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]
+    lib.aadg_subsample2x2_supported.restype = _i
+    lib.aadg_subsample2x2_supported.argtypes = [_i, _i, _i]
+    lib.aadg_subsample2x2.restype = _i
+    lib.aadg_subsample2x2.argtypes = [_vp, _vp, _i, _i, _i, _i, _vp]
+    lib.aadg_subsample2x2_backward.restype = _i
+    lib.aadg_subsample2x2_backward.argtypes = [_vp, _vp, _i, _i, _i, _i, _vp]
     lib.aadg_maxpool3x3s2_supported.restype = _i
     lib.aadg_maxpool3x3s2_supported.argtypes = [_i, _i]
     lib.aadg_maxpool3x3s2_forward.restype = _i
@@ -693,6 +700,42 @@ def maxpool3x3s2(x):
     if not maxpool3x3s2_supported(x):
         raise AadgError("maxpool3x3s2: unsupported shape / dtype / layout")
     return _MaxPool3x3s2.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------
+class _Subsample2x2(torch.autograd.Function):
+    """x[:, :, ::2, ::2] as a contiguous tensor (csrc/subsample.hip); the backward writes the whole input gradient in one pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = load()
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
+        _check(lib.aadg_subsample2x2(x.data_ptr(), y.data_ptr(), N * C, H, W, _BN_DTYPES[x.dtype], _stream()), "aadg_subsample2x2")
+        ctx.in_shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load()
+        N, C, H, W = ctx.in_shape
+        dy = dy.contiguous()
+        dx = torch.empty(ctx.in_shape, dtype=dy.dtype, device=dy.device)
+        _check(lib.aadg_subsample2x2_backward(dy.data_ptr(), dx.data_ptr(), N * C, H, W, _BN_DTYPES[dy.dtype], _stream()),
+               "aadg_subsample2x2_backward")
+        return dx
+
+
+def subsample2x2_supported(x):
+    return (x.is_cuda and x.dim() == 4 and x.dtype in _BN_DTYPES and x.is_contiguous() and
+            bool(load().aadg_subsample2x2_supported(x.shape[2], x.shape[3], _BN_DTYPES[x.dtype])))
+
+
+def subsample2x2(x):
+    _require_cuda(x)
+    if not subsample2x2_supported(x):
+        raise AadgError("subsample2x2: unsupported shape / dtype / layout")
+    return _Subsample2x2.apply(x)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -93,11 +93,19 @@ class Conv1x1(nn.Conv2d):
         super().__init__(cin, cout, 1, stride=stride, bias=False)
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.bfloat16 and self.stride == (1, 1):
+        if x.is_cuda and x.dtype == torch.bfloat16 and self.stride in ((1, 1), (2, 2)):
             from .. import _lib
             xc = x.contiguous()
+            if self.stride == (2, 2):
+                # stride 2 (a stage's down-sampling shortcut) = pick the even pixels, then the stride-1 path: one streaming
+                # pass each way instead of the library's NCHW <-> CNHW transposes of the whole activation around its GEMM
+                if not _lib.subsample2x2_supported(xc):
+                    return super().forward(x)
+                xc = _lib.subsample2x2(xc)
             if _lib.conv1x1_supported(xc, self.weight):
                 return _lib.conv1x1(xc, self.weight)
+            if self.stride == (2, 2):
+                return F.conv2d(xc, self.weight.to(xc.dtype))
         return super().forward(x)
 
 

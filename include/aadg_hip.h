@@ -221,6 +221,16 @@ int aadg_dwconv3x3_wgrad(const void* x, const void* dy, float* dweight, int N, i
                          int dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Stride-2 pixel sub-sampling of NCHW planes: y[p][i][j] = x[p][2i][2j], x [planes, H, W] -> y [planes, H/2, W/2], and its
+ * gradient dx (dy at the even positions, zeros elsewhere; every element of dx is written).  With a stride-1 1x1 convolution
+ * behind it this is torch.nn.Conv2d(cin, cout, 1, stride=2) -- the down-sampling shortcut of a ResNet stage -- without the
+ * library's NCHW <-> CNHW transposes of the full activation.  H even, W a multiple of 8 (float32) / 16 (bfloat16).
+ * ------------------------------------------------------------------------------------------- */
+int aadg_subsample2x2_supported(int H, int W, int dtype);
+int aadg_subsample2x2(const void* x, void* y, int planes, int H, int W, int dtype, void* stream);
+int aadg_subsample2x2_backward(const void* dy, void* dx, int planes, int H, int W, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Max pooling 3x3, stride 2, padding 1 over NCHW planes (the ResNet stem pool of the backbone's encoder,
  * torch.nn.MaxPool2d(3, 2, 1) semantics: padding never wins, ties -> first element in window order).
  * x [planes, H, W] -> y [planes, (H-1)/2+1, W/2]; W a multiple of 8.  `index` (optional in the forward: inference) receives
