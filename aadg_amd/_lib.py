@@ -37,6 +37,7 @@ EXPORTS = [
     "aadg_upsample_bilinear2d_backward_workspace_bytes", "aadg_upsample_bilinear2d_backward_strided",
     "aadg_bn_workspace_bytes", "aadg_bn_mask_bytes", "aadg_bn_forward", "aadg_bn_backward",
     "aadg_dwconv3x3_supported", "aadg_dwconv3x3_workspace_bytes", "aadg_dwconv3x3", "aadg_dwconv3x3_wgrad",
+    "aadg_stem_conv7x7_supported", "aadg_stem_conv7x7_workspace_bytes", "aadg_stem_conv7x7_bf16",
     "aadg_subsample2x2_supported", "aadg_subsample2x2", "aadg_subsample2x2_backward",
     "aadg_maxpool3x3s2_supported", "aadg_maxpool3x3s2_index_bytes", "aadg_maxpool3x3s2_forward", "aadg_maxpool3x3s2_backward",
     "aadg_conv1x1_wgrad_supported", "aadg_conv1x1_wgrad_bf16",
@@ -115,6 +116,12 @@ def load():
     lib.aadg_dwconv3x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]
     lib.aadg_dwconv3x3_wgrad.restype = _i
     lib.aadg_dwconv3x3_wgrad.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]
+    lib.aadg_stem_conv7x7_supported.restype = _i
+    lib.aadg_stem_conv7x7_supported.argtypes = [_i, _i]
+    lib.aadg_stem_conv7x7_workspace_bytes.restype = ctypes.c_size_t
+    lib.aadg_stem_conv7x7_workspace_bytes.argtypes = []
+    lib.aadg_stem_conv7x7_bf16.restype = _i
+    lib.aadg_stem_conv7x7_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp, ctypes.c_size_t, _vp]
     lib.aadg_subsample2x2_supported.restype = _i
     lib.aadg_subsample2x2_supported.argtypes = [_i, _i, _i]
     lib.aadg_subsample2x2.restype = _i
@@ -700,6 +707,44 @@ def maxpool3x3s2(x):
     if not maxpool3x3s2_supported(x):
         raise AadgError("maxpool3x3s2: unsupported shape / dtype / layout")
     return _MaxPool3x3s2.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------
+class _StemConv7x7(torch.autograd.Function):
+    """conv2d(x [N,3,H,W] bf16, weight [64,3,7,7] float32 master, stride 2, padding 3) with the MFMA kernel of csrc/stem_conv.hip;
+    the weight gradient (the image needs none) stays the library's."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        lib = load()
+        N, C, H, W = x.shape
+        y = torch.empty((N, 64, H // 2, W // 2), dtype=x.dtype, device=x.device)
+        ws = workspace(lib.aadg_stem_conv7x7_workspace_bytes(), x.device, "stem")
+        _check(lib.aadg_stem_conv7x7_bf16(x.data_ptr(), weight.data_ptr(), y.data_ptr(), N, H, W, ws.data_ptr(), ws.numel(), _stream()),
+               "aadg_stem_conv7x7_bf16")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        need_x = ctx.needs_input_grad[0]
+        dx, dw, _ = torch.ops.aten.convolution_backward(dy.contiguous(), x, weight.to(x.dtype), None, [2, 2], [3, 3], [1, 1], False,
+                                                        [0, 0], 1, [need_x, True, False])
+        return (dx if need_x else None), dw.to(weight.dtype)
+
+
+def stem_conv7x7_supported(x, weight):
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[1] == 3 and
+            tuple(weight.shape) == (64, 3, 7, 7) and weight.dtype == torch.float32 and weight.is_contiguous() and
+            bool(load().aadg_stem_conv7x7_supported(x.shape[2], x.shape[3])))
+
+
+def stem_conv7x7(x, weight):
+    _require_cuda(x, weight)
+    if not stem_conv7x7_supported(x, weight):
+        raise AadgError("stem_conv7x7: unsupported shape / dtype / layout")
+    return _StemConv7x7.apply(x, weight)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -109,6 +109,25 @@ class Conv1x1(nn.Conv2d):
         return super().forward(x)
 
 
+class StemConv7x7(nn.Conv2d):
+    """The ResNet stem Conv2d(3, 64, 7, stride 2, padding 3).  Under bfloat16 autocast on the GPU the forward is the MFMA
+    kernel of csrc/stem_conv.hip (straight from NCHW: the library surrounds its NHWC implicit GEMM with three layout
+    transposes and a zero-fill); the weight gradient stays the library's."""
+
+    def __init__(self):
+        super().__init__(3, 64, 7, stride=2, padding=3, bias=False)
+
+    def forward(self, x):
+        lowp = x.dtype == torch.bfloat16 or (x.is_cuda and torch.is_autocast_enabled('cuda') and
+                                             torch.get_autocast_dtype('cuda') == torch.bfloat16)
+        if x.is_cuda and lowp:
+            from .. import _lib
+            xb = x.to(torch.bfloat16).contiguous()
+            if _lib.stem_conv7x7_supported(xb, self.weight):
+                return _lib.stem_conv7x7(xb, self.weight)
+        return super().forward(x)
+
+
 class MaxPool3x3s2(nn.MaxPool2d):
     """MaxPool2d(3, 2, 1); on the GPU the HIP kernels (csrc/maxpool.hip: one index byte per output, gather backward)."""
 
@@ -200,7 +219,7 @@ class ResNet50Encoder(nn.Module):
 
     def __init__(self):
         super().__init__()
-        self.stem = nn.Sequential(nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False), *_bn_relu(64))
+        self.stem = nn.Sequential(StemConv7x7(), *_bn_relu(64))
         self.pool = MaxPool3x3s2()
         self.cin = 64
         self.layer1 = self._stage(64, 3, 1, 1)

@@ -221,6 +221,16 @@ int aadg_dwconv3x3_wgrad(const void* x, const void* dy, float* dweight, int N, i
                          int dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The ResNet stem convolution, forward: y [N, 64, H/2, W/2] = conv2d(x [N, 3, H, W], weight [64, 3, 7, 7], stride 2, padding 3),
+ * bfloat16 activations, float32 master weights (rounded to bfloat16 in the kernel, float32 accumulation) -- what
+ * torch.nn.Conv2d(3, 64, 7, 2, 3, bias=False) computes under bfloat16 autocast (smp's ResNet encoder `conv1`).  MFMA implicit
+ * GEMM straight from NCHW (csrc/stem_conv.hip).  H even, W a multiple of 16.  `ws`: aadg_stem_conv7x7_workspace_bytes().
+ * ------------------------------------------------------------------------------------------- */
+int aadg_stem_conv7x7_supported(int H, int W);
+size_t aadg_stem_conv7x7_workspace_bytes(void);
+int aadg_stem_conv7x7_bf16(const void* x, const float* weight, void* y, int N, int H, int W, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Stride-2 pixel sub-sampling of NCHW planes: y[p][i][j] = x[p][2i][2j], x [planes, H, W] -> y [planes, H/2, W/2], and its
  * gradient dx (dy at the even positions, zeros elsewhere; every element of dx is written).  With a stride-1 1x1 convolution
  * behind it this is torch.nn.Conv2d(cin, cout, 1, stride=2) -- the down-sampling shortcut of a ResNet stage -- without the

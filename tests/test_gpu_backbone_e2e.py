@@ -11,7 +11,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-SWITCHES = ["bn_act_supported", "dwconv3x3_supported", "conv1x1_supported", "maxpool3x3s2_supported", "subsample2x2_supported"]
+SWITCHES = ["bn_act_supported", "dwconv3x3_supported", "conv1x1_supported", "maxpool3x3s2_supported", "subsample2x2_supported",
+            "stem_conv7x7_supported"]
 
 
 def _run(model, state, x, y, autocast):
