@@ -37,7 +37,7 @@ EXPORTS = [
     "aadg_upsample_bilinear2d_backward_workspace_bytes", "aadg_upsample_bilinear2d_backward_strided",
     "aadg_bn_workspace_bytes", "aadg_bn_mask_bytes", "aadg_bn_forward", "aadg_bn_backward",
     "aadg_dwconv3x3_supported", "aadg_dwconv3x3_workspace_bytes", "aadg_dwconv3x3", "aadg_dwconv3x3_wgrad",
-    "aadg_stem_conv7x7_supported", "aadg_stem_conv7x7_workspace_bytes", "aadg_stem_conv7x7_bf16",
+    "aadg_stem_conv7x7_supported", "aadg_stem_conv7x7_workspace_bytes", "aadg_stem_conv7x7_bf16", "aadg_stem_conv7x7_wgrad_bf16",
     "aadg_subsample2x2_supported", "aadg_subsample2x2", "aadg_subsample2x2_backward",
     "aadg_maxpool3x3s2_supported", "aadg_maxpool3x3s2_index_bytes", "aadg_maxpool3x3s2_forward", "aadg_maxpool3x3s2_backward",
     "aadg_conv1x1_wgrad_supported", "aadg_conv1x1_wgrad_bf16",
@@ -122,6 +122,8 @@ def load():
     lib.aadg_stem_conv7x7_workspace_bytes.argtypes = []
     lib.aadg_stem_conv7x7_bf16.restype = _i
     lib.aadg_stem_conv7x7_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp, ctypes.c_size_t, _vp]
+    lib.aadg_stem_conv7x7_wgrad_bf16.restype = _i
+    lib.aadg_stem_conv7x7_wgrad_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp]
     lib.aadg_subsample2x2_supported.restype = _i
     lib.aadg_subsample2x2_supported.argtypes = [_i, _i, _i]
     lib.aadg_subsample2x2.restype = _i
@@ -712,7 +714,7 @@ def maxpool3x3s2(x):
 # ------------------------------------------------------------------------------------------------
 class _StemConv7x7(torch.autograd.Function):
     """conv2d(x [N,3,H,W] bf16, weight [64,3,7,7] float32 master, stride 2, padding 3) with the MFMA kernel of csrc/stem_conv.hip;
-    the weight gradient (the image needs none) stays the library's."""
+    the weight gradient runs on the matrix cores too (k_stem7x7_wgrad); an input gradient, if ever asked for, is the library's."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -728,10 +730,16 @@ class _StemConv7x7(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        need_x = ctx.needs_input_grad[0]
-        dx, dw, _ = torch.ops.aten.convolution_backward(dy.contiguous(), x, weight.to(x.dtype), None, [2, 2], [3, 3], [1, 1], False,
-                                                        [0, 0], 1, [need_x, True, False])
-        return (dx if need_x else None), dw.to(weight.dtype)
+        dy = dy.contiguous()
+        if not ctx.needs_input_grad[0]:                      # the image itself needs no gradient: weight gradient on the matrix cores
+            N, C, H, W = x.shape
+            dw = torch.empty_like(weight)
+            _check(load().aadg_stem_conv7x7_wgrad_bf16(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, H, W, _stream()),
+                   "aadg_stem_conv7x7_wgrad_bf16")
+            return None, dw
+        dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight.to(x.dtype), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                                        [True, True, False])
+        return dx, dw.to(weight.dtype)
 
 
 def stem_conv7x7_supported(x, weight):

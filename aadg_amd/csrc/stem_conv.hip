@@ -122,6 +122,138 @@ __global__ __launch_bounds__(256) void k_stem7x7(const uint16_t* __restrict__ x,
     }
 }
 
+// ---- weight gradient ------------------------------------------------------------------------------------------------
+//     dW[o][t] = sum over images and output pixels of dY[o][pixel] * X[c][2i + kh - 3][2j + kw - 3],   t = (c, kh, kw)
+// as an MFMA GEMM with M = 64 channels, N = 147 taps (5 tiles of 32) and K = output pixels.  The 8 K-values of a lane are
+// 8 consecutive output columns j: contiguous in dY, but every second input column of X -- so the input patch is staged as
+// two planes (even / odd input columns), in which the taps of consecutive j ARE consecutive; their start is only 2-byte
+// aligned (it depends on the lane's kw), hence five 4-byte LDS reads + a per-lane byte funnel (v_alignbyte) per fragment.
+// A workgroup owns 4 output rows x 64 columns x 32 output channels per tile (one row per wave; the two channel halves are
+// separate tiles so that the 32 x 160 accumulator + fragments stay under 256 registers: two waves per SIMD), walks tiles
+// persistently with the next tile's global loads in flight during the MFMAs, and ends with one LDS reduction over its waves
+// + 32 x 147 float atomics.
+constexpr int SW_ROWS = 4, SW_PX = 64, SW_CH = 32, SW_DPITCH = 72, SW_XROWS = 2 * SW_ROWS + 5, SW_XPITCH = 72, SW_NT = 5;
+constexpr int SW_DY_ELEMS = SW_ROWS * SW_CH * SW_DPITCH, SW_X_ELEMS = 2 * 3 * SW_XROWS * SW_XPITCH;
+constexpr int SW_RED_FLOATS = SW_CH * 32 * SW_NT;
+constexpr int SW_DY_ITEMS = SW_ROWS * SW_CH * (SW_PX / 8) / 256, SW_X_CHUNKS = 3 * SW_XROWS * 18, SW_X_ITEMS = (SW_X_CHUNKS + 255) / 256;
+
+__global__ __launch_bounds__(256, 2) void k_stem7x7_wgrad(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                       float* __restrict__ dw, int H, int W, int tiles_x, int tiles_y, int total_tiles) {
+    constexpr int LDS_BYTES = (SW_DY_ELEMS + SW_X_ELEMS) * 2 > SW_RED_FLOATS * 4 ? (SW_DY_ELEMS + SW_X_ELEMS) * 2 : SW_RED_FLOATS * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    uint16_t* dyL = reinterpret_cast<uint16_t*>(lds_raw);                 // [row][channel][SW_DPITCH]
+    uint16_t* xL = dyL + SW_DY_ELEMS;                                     // [parity][c][patch row][SW_XPITCH], index = m + 2
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = lane >> 5;
+    const int Ho = H / 2, Wo = W / 2;
+    // this lane's tap per N tile: patch offset (elements) of K-value 0 of K-step 0 for output row 0
+    int toff[SW_NT];
+#pragma unroll
+    for (int nt = 0; nt < SW_NT; ++nt) {
+        const int t = min(32 * nt + (lane & 31), 146);                    // taps >= 147 are never stored: any finite data
+        const int c = t / 49, rem = t - c * 49, kh = rem / 7, kw = rem - kh * 7;
+        const int par = (kw & 1) ? 0 : 1;                                 // odd kw <-> even input column
+        toff[nt] = ((par * 3 + c) * SW_XROWS + kh + 2 * wv) * SW_XPITCH + ((kw + 1) >> 1) + 2 + 8 * g;
+    }
+    f32x16 d[SW_NT];
+#pragma unroll
+    for (int nt = 0; nt < SW_NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[nt][r] = 0.0f;
+
+    // tile = (image, row block, column block, channel half); the staged chunks of a tile live in registers until the LDS is free
+    uint4 rdy[SW_DY_ITEMS], rx[SW_X_ITEMS];
+#define AADG_SW_ISSUE(tile_)                                                                                               \
+    do {                                                                                                                   \
+        const int half_ = (tile_) & 1, t1_ = (tile_) >> 1;                                                                 \
+        const int tx_ = t1_ % tiles_x, t2_ = t1_ / tiles_x;                                                                \
+        const int ty_ = t2_ % tiles_y, n_ = t2_ / tiles_y;                                                                 \
+        const int i0_ = ty_ * SW_ROWS, j0_ = tx_ * SW_PX;                                                                  \
+        const uint16_t* xn_ = x + (size_t)n_ * 3 * H * W;                                                                  \
+        const uint16_t* dyn_ = dy + ((size_t)n_ * ST_CO + half_ * SW_CH) * Ho * Wo;                                       \
+        _Pragma("unroll") for (int k_ = 0; k_ < SW_DY_ITEMS; ++k_) {                                                       \
+            const int it_ = tid + 256 * k_, q_ = it_ & 7, o_ = (it_ >> 3) & (SW_CH - 1), r_ = it_ >> 8;                    \
+            const int i_ = i0_ + r_, j_ = j0_ + 8 * q_;                                                                    \
+            rdy[k_] = make_uint4(0u, 0u, 0u, 0u);                                                                          \
+            if (i_ < Ho && j_ < Wo) rdy[k_] = *reinterpret_cast<const uint4*>(dyn_ + ((size_t)o_ * Ho + i_) * Wo + j_);    \
+        }                                                                                                                  \
+        _Pragma("unroll") for (int k_ = 0; k_ < SW_X_ITEMS; ++k_) {                                                        \
+            const int it_ = tid + 256 * k_, q_ = it_ % 18, rc_ = it_ / 18;                                                 \
+            const int pr_ = rc_ % SW_XROWS, c_ = rc_ / SW_XROWS;                                                           \
+            const int row_ = 2 * i0_ - 3 + pr_, col_ = 2 * j0_ - 8 + 8 * q_;                                               \
+            rx[k_] = make_uint4(0u, 0u, 0u, 0u);                                                                           \
+            if (it_ < SW_X_CHUNKS && row_ >= 0 && row_ < H && col_ >= 0 && col_ < W)                                       \
+                rx[k_] = *reinterpret_cast<const uint4*>(xn_ + ((size_t)c_ * H + row_) * W + col_);                        \
+        }                                                                                                                  \
+    } while (0)
+
+    int tile = blockIdx.x;
+    if (tile < total_tiles) AADG_SW_ISSUE(tile);
+    for (; tile < total_tiles; tile += gridDim.x) {
+        const int i0 = (((tile >> 1) / tiles_x) % tiles_y) * SW_ROWS;
+        __syncthreads();                                                  // the previous tile's readers are done with the LDS
+#pragma unroll
+        for (int k = 0; k < SW_DY_ITEMS; ++k) {
+            const int it = tid + 256 * k, q = it & 7, o = (it >> 3) & (SW_CH - 1), r = it >> 8;
+            *reinterpret_cast<uint4*>(dyL + (r * SW_CH + o) * SW_DPITCH + 8 * q) = rdy[k];
+        }
+        // input patch rows 2*i0 - 3 .. 2*i0 + 9, columns 2*j0 - 8 .. 2*j0 + 135, split into even / odd column planes:
+        // chunk q (8 columns) -> plane indices 4q .. 4q + 3 of both planes
+#pragma unroll
+        for (int k = 0; k < SW_X_ITEMS; ++k) {
+            const int it = tid + 256 * k;
+            if (it < SW_X_CHUNKS) {
+                const int q = it % 18, rc = it / 18;
+                const int pr = rc % SW_XROWS, c = rc / SW_XROWS;
+                const uint4 v = rx[k];
+                const uint2 ev = make_uint2((v.x & 0xFFFFu) | (v.y << 16), (v.z & 0xFFFFu) | (v.w << 16));
+                const uint2 od = make_uint2((v.x >> 16) | (v.y & 0xFFFF0000u), (v.z >> 16) | (v.w & 0xFFFF0000u));
+                *reinterpret_cast<uint2*>(xL + ((0 * 3 + c) * SW_XROWS + pr) * SW_XPITCH + 4 * q) = ev;
+                *reinterpret_cast<uint2*>(xL + ((1 * 3 + c) * SW_XROWS + pr) * SW_XPITCH + 4 * q) = od;
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < total_tiles) AADG_SW_ISSUE(tile + (int)gridDim.x);     // in flight during the MFMAs below
+        if (i0 + wv < Ho) {
+            const uint16_t* A = dyL + (wv * SW_CH + (lane & 31)) * SW_DPITCH + 8 * g;
+#pragma unroll
+            for (int ks = 0; ks < SW_PX / 16; ++ks) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(A + 16 * ks));
+#pragma unroll
+                for (int nt = 0; nt < SW_NT; ++nt) {
+                    const int s = toff[nt] + 16 * ks;                                // first element of this lane's 8 K-values
+                    const uint32_t* p = reinterpret_cast<const uint32_t*>(xL) + (s >> 1);
+                    const uint32_t sh = (uint32_t)(s & 1) * 2u;                      // byte shift inside the first dword
+                    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4];
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
+                                                                            __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh)));
+                    d[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, d[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+#undef AADG_SW_ISSUE
+    // reduce the four waves in LDS, then one float atomic per weight and workgroup.  The channel half is the same for every
+    // tile of a workgroup (the grid is even, tiles alternate halves)
+    const int half = blockIdx.x & 1;
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds_raw);                       // [32][160]
+    for (int i = tid; i < SW_RED_FLOATS; i += 256) red[i] = 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < SW_NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = (r & 3) + 8 * (r >> 2) + 4 * g, t = 32 * nt + (lane & 31);
+            __hip_atomic_fetch_add(&red[o * (32 * SW_NT) + t], d[nt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    __syncthreads();
+    for (int i = tid; i < SW_CH * 147; i += 256) {
+        const int o = i / 147, t = i - o * 147;
+        unsafeAtomicAdd(dw + (size_t)(half * SW_CH + o) * 147 + t, red[o * (32 * SW_NT) + t]);
+    }
+}
+
 }  // namespace
 
 extern "C" int aadg_stem_conv7x7_supported(int H, int W) {
@@ -146,6 +278,25 @@ extern "C" int aadg_stem_conv7x7_bf16(const void* x, const float* weight, void* 
     AADG_LAUNCH_CHECK();
     const int grid = (int)(total < 512 ? total : 512);              // persistent: the 2 workgroups a CU holds (241 registers per lane), weight fragments loaded once each
     hipLaunchKernelGGL(k_stem7x7, dim3(grid), dim3(256), 0, st, (const uint16_t*)x, (const uint4*)ws, (uint16_t*)y, H, W, tiles_x,
+                       tiles_y, (int)total);
+    AADG_LAUNCH_CHECK();
+    return 0;
+}
+
+/* dweight [64, 3, 7, 7] (float32, overwritten) = gradient of aadg_stem_conv7x7_bf16 w.r.t. its weight, from x [N, 3, H, W] and
+ * dy [N, 64, H/2, W/2] (bfloat16); float32 accumulation, partial sums combined with float atomics. */
+extern "C" int aadg_stem_conv7x7_wgrad_bf16(const void* x, const void* dy, float* dweight, int N, int H, int W, void* stream) {
+    if (x == nullptr || dy == nullptr || dweight == nullptr || N <= 0) return AADG_E_BADARG;
+    if ((((uintptr_t)x | (uintptr_t)dy) & 15u) != 0) return AADG_E_BADARG;
+    if (!aadg_stem_conv7x7_supported(H, W)) return AADG_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int Ho = H / 2, Wo = W / 2;
+    const int tiles_x = (Wo + SW_PX - 1) / SW_PX, tiles_y = (Ho + SW_ROWS - 1) / SW_ROWS;
+    const long long total = (long long)N * tiles_x * tiles_y * 2;          // x 2 channel halves (tile parity)
+    if (total > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
+    AADG_HIP_TRY(hipMemsetAsync(dweight, 0, (size_t)ST_CO * 147 * sizeof(float), st));
+    const int grid = (int)(total < 1024 ? total : 1024);                   // even: a workgroup keeps one channel half
+    hipLaunchKernelGGL(k_stem7x7_wgrad, dim3(grid), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)dy, dweight, H, W, tiles_x,
                        tiles_y, (int)total);
     AADG_LAUNCH_CHECK();
     return 0;

@@ -112,7 +112,7 @@ class Conv1x1(nn.Conv2d):
 class StemConv7x7(nn.Conv2d):
     """The ResNet stem Conv2d(3, 64, 7, stride 2, padding 3).  Under bfloat16 autocast on the GPU the forward is the MFMA
     kernel of csrc/stem_conv.hip (straight from NCHW: the library surrounds its NHWC implicit GEMM with three layout
-    transposes and a zero-fill); the weight gradient stays the library's."""
+    transposes and a zero-fill), and so is the weight gradient."""
 
     def __init__(self):
         super().__init__(3, 64, 7, stride=2, padding=3, bias=False)

@@ -63,3 +63,17 @@ def test_stem_rejects_unsupported(hip):
     assert not hip.stem_conv7x7_supported(torch.zeros(1, 3, 32, 32, device="cuda"), w)
     with pytest.raises(hip.AadgError):
         hip.stem_conv7x7(torch.zeros(1, 3, 32, 24, device="cuda", dtype=torch.bfloat16), w)
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 32, 32), (3, 18, 48), (2, 128, 256), (1, 2, 16)])
+def test_stem_weight_gradient_matches_conv2d(hip, N, H, W):
+    torch.manual_seed(H * 3 + W)
+    x = torch.randn(N, 3, H, W, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(64, 3, 7, 7, device="cuda") * 0.1).requires_grad_(True)
+    y = hip.stem_conv7x7(x, w)
+    g = torch.randn_like(y)
+    y.backward(g)
+    wr = w.detach().clone().requires_grad_(True)
+    F.conv2d(x.float(), wr, stride=2, padding=3).backward(g.float())          # exact products of the same bf16 operands, float32 sums
+    scale = max(1.0, wr.grad.abs().max().item())
+    assert (w.grad - wr.grad).abs().max().item() <= 2e-3 * scale
