@@ -236,7 +236,7 @@ class ResNet50Encoder(nn.Module):
         layers += [Bottleneck(self.cin, planes, 1, dilation) for _ in range(1, blocks)]
         return _Stage(*layers)
 
-    deep_handles = 6     # consumers of the encoder output: four ASPP convolutions, the image pool, the pooled feature
+    deep_handles = 5     # consumers of the encoder output: four ASPP convolutions + the global average (image pool & pooled feature)
 
     def forward(self, x):
         x = self.pool(self.stem(x))
@@ -305,11 +305,21 @@ class ASPP(nn.Module):
         self.image_pool = nn.Sequential(nn.AdaptiveAvgPool2d(1), Conv1x1(cin, cout), *_bn_relu(cout))
         self.project = nn.Sequential(Conv1x1(cout * 5, cout), *_bn_relu(cout), nn.Dropout(0.5))
 
-    def forward(self, x):
-        h = _handles(x, len(self.branches) + 1)                    # one handle of the encoder output per branch
+    def forward(self, x, pooled=None):
+        """`pooled` = the float32 global average of x when the caller has it anyway (the classification feature of the
+        discriminator): the image-pool branch then starts from it instead of reducing the encoder output a second time."""
+        nb = len(self.branches)
+        h = _handles(x, nb if pooled is not None else nb + 1)      # one handle of the encoder output per consumer
         outs = [b(hx) for b, hx in zip(self.branches, h)]
+        ref = h[0]
+        if pooled is None:
+            ip = self.image_pool(h[-1])
+        else:
+            ip = pooled.to(ref.dtype)[:, :, None, None]
+            for mod in list(self.image_pool)[1:]:                  # [0] is the pooling itself
+                ip = mod(ip)
         # bilinear up-sampling of a 1x1 map is a broadcast (ATen's kernel would walk all N*C planes in one workgroup)
-        outs.append(self.image_pool(h[-1]).expand(-1, -1, h[-1].shape[-2], h[-1].shape[-1]))
+        outs.append(ip.expand(-1, -1, ref.shape[-2], ref.shape[-1]))
         return self.project(torch.cat(outs, dim=1))
 
 
@@ -331,9 +341,12 @@ class DeepLabV3Plus(nn.Module):
 
     def forward(self, x):
         skip, deep = self.encoder(x)
-        hd = _handles(deep, 6)
-        deep = hd[5]
-        a = self.aspp[0](tuple(hd[:5]))                  # ASPP takes one handle of the encoder output per branch
+        hd = _handles(deep, 5)
+        # ClassificationHead = avg-pool + flatten (models/heads.py:19-25): accumulated in fp32 without materialising an fp32
+        # copy of the [N, C_enc, h/16, w/16] map; the same average feeds the ASPP image-pool branch (one reduction, one
+        # broadcast gradient instead of two)
+        pooled = hd[4].mean(dim=(2, 3), dtype=torch.float32)
+        a = self.aspp[0](tuple(hd[:4]), pooled)          # ASPP takes one handle of the encoder output per convolution branch
         for mod in list(self.aspp)[1:]:
             a = mod(a)
         s = self.skip(skip)
@@ -346,9 +359,7 @@ class DeepLabV3Plus(nn.Module):
         mask = _upsample_ac(self.classifier(y), x.shape[-2:])
         if not self.aux_pooling:
             return mask
-        # ClassificationHead = avg-pool + flatten (models/heads.py:19-25); accumulate in fp32 without materialising
-        # an fp32 copy of the [N, C_enc, h/16, w/16] map
-        return mask, deep.mean(dim=(2, 3), dtype=torch.float32)
+        return mask, pooled
 
 
 class UNetSmall(nn.Module):
