@@ -107,7 +107,7 @@ def load():
     lib.aadg_bn_mask_bytes.argtypes = [_i, _i, _i, _i]
     lib.aadg_bn_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]
     lib.aadg_bn_backward.restype = _i
-    lib.aadg_bn_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]
+    lib.aadg_bn_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]
     lib.aadg_dwconv3x3_supported.restype = _i
     lib.aadg_dwconv3x3_supported.argtypes = [_i, _i, _i, _i]
     lib.aadg_dwconv3x3_workspace_bytes.restype = _sz
@@ -560,7 +560,19 @@ class _BatchNormAct(torch.autograd.Function):
         lib = load()
         x, y, mask, weight, bias, mean, invstd = ctx.saved_tensors
         N, C, H, W = x.shape
-        grads = [g.contiguous() for g in grads if g is not None]      # unused handles deliver no gradient
+        grads = [g for g in grads if g is not None]                   # unused handles deliver no gradient
+        # a gradient that is a broadcast over each plane (the backward of a global average pool of this output) travels as one
+        # float per plane instead of a materialised activation-sized tensor
+        pconst = None
+        if ctx.has_res and len(grads) > 1:
+            flat = [g for g in grads if g.dim() == 4 and g.stride(2) == 0 and g.stride(3) == 0 and g.shape[2] * g.shape[3] > 1]
+            if flat:
+                grads = [g for g in grads if not any(g is f for f in flat)]
+                pconst = flat[0][:, :, 0, 0].float()
+                for f in flat[1:]:
+                    pconst = pconst + f[:, :, 0, 0].float()
+                pconst = pconst.contiguous()
+        grads = [g.contiguous() for g in grads]
         if not grads:
             grads = [torch.zeros_like(x)]
         if len(grads) > 1 and (not ctx.has_res or len(grads) > 1 + BN_MAX_EXTRA):
@@ -576,7 +588,7 @@ class _BatchNormAct(torch.autograd.Function):
         db = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _bn_ws(C, x.device)
         rc = lib.aadg_bn_backward(x.data_ptr(), _ptr(y), _ptr(mask), dy.data_ptr(), _ptr_array(extra) if extra else None, len(extra),
-                                  _ptr(weight), _ptr(bias), mean.data_ptr(), invstd.data_ptr(), ctx.act, dx.data_ptr(),
+                                  _ptr(pconst), _ptr(weight), _ptr(bias), mean.data_ptr(), invstd.data_ptr(), ctx.act, dx.data_ptr(),
                                   _ptr(dres), dw.data_ptr(), db.data_ptr(), N, C, H * W, _BN_DTYPES[x.dtype], ws.data_ptr(),
                                   ws.numel(), _stream())
         _check(rc, "aadg_bn_backward")

@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256) void k_bn_reduce_fwd(const T* __restrict__ x, 
 //   NE  : number of extra gradients (-1 = more.n at run time);  DRES: 0 / 1 (-1 = dres may or may not be null)
 template <typename T, int VEC, int MK, int NE, int DRES>
 __global__ __launch_bounds__(256) void k_bn_reduce_bwd(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
-                                                       BnExtra<T> more, const uint8_t* __restrict__ mask, T* __restrict__ dres,
-                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       BnExtra<T> more, const float* __restrict__ pconst, const uint8_t* __restrict__ mask,
+                                                       T* __restrict__ dres, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ scale, const float* __restrict__ shift, int act,
                                                        int C, int len, int per_strip, int plen, int total, float* __restrict__ partial) {
     static_assert(MK == 2 || VEC > 1, "the specialised variants are vector-only");
@@ -183,6 +183,8 @@ __global__ __launch_bounds__(256) void k_bn_reduce_bwd(const T* __restrict__ x, 
         const size_t strip = (size_t)n * C + c;
         const size_t base = strip * strip_elems;
         const int j1 = min(len, (part + 1) * plen);
+        // a consumer whose gradient is constant over each plane (a global average pool) hands in one value per plane
+        const float pc = pconst != nullptr ? pconst[strip] : 0.0f;
 #pragma unroll 4
         for (int j = part * plen + threadIdx.x; j < j1; j += blockDim.x) {
             const size_t off = base + (size_t)j * VEC;
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(256) void k_bn_reduce_bwd(const T* __restrict__ x, 
             }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
+                gv[i] += pc;
                 bool open = true;
                 if (MK == 1) open = (mbits >> i) & 1u;
                 if (MK == 2) open = act_open(y != nullptr ? yv[i] : Pack<T>::round(fmaf(xv[i], sc, sh)), act);
@@ -428,7 +431,7 @@ int bn_forward(const T* x, const T* res, T* y, uint8_t* mask, const float* weigh
 }
 
 template <typename T>
-int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const void* const* dy_extra, int n_extra, const float* weight, const float* bias, const float* mean, const float* invstd,
+int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const void* const* dy_extra, int n_extra, const float* pconst, const float* weight, const float* bias, const float* mean, const float* invstd,
                 int act, T* dx, T* dres, float* dweight, float* dbias, int N, int C, int HW, float* ws, hipStream_t st) {
     Shape s;
     if (!make_shape<T>(N, C, HW, x, y, dy, dx, &s) || (((uintptr_t)dres & 15u) && s.vec > 1)) return AADG_E_BADARG;
@@ -448,7 +451,7 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
     {
         const dim3 grid(s.split, C);
 #define AADG_BN_REDUCE_BWD(VEC_, MK_, NE_, DRES_)                                                                                        \
-    hipLaunchKernelGGL((k_bn_reduce_bwd<T, VEC_, MK_, NE_, DRES_>), grid, blk, 0, st, x, y, dy, more, mask, dres, mean, invstd,          \
+    hipLaunchKernelGGL((k_bn_reduce_bwd<T, VEC_, MK_, NE_, DRES_>), grid, blk, 0, st, x, y, dy, more, pconst, mask, dres, mean, invstd,  \
                        (const float*)scale, (const float*)shift, act, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial)
 #define AADG_BN_REDUCE_BWD_MK(MK_)                                                                     \
     do {                                                                                               \
@@ -520,7 +523,7 @@ extern "C" int aadg_bn_forward(const void* x, const void* residual, void* y, voi
 }
 
 extern "C" int aadg_bn_backward(const void* x, const void* y, const void* act_mask, const void* dy, const void* const* dy_extra,
-                                int n_extra, const float* weight, const float* bias, const float* save_mean,
+                                int n_extra, const float* dy_plane_const, const float* weight, const float* bias, const float* save_mean,
                                 const float* save_invstd, int act, void* dx, void* dres, float* dweight, float* dbias, int N, int C,
                                 int HW, int dtype, void* ws, size_t ws_bytes, void* stream) {
     if (x == nullptr || dy == nullptr || dx == nullptr || save_mean == nullptr || save_invstd == nullptr || ws == nullptr ||
@@ -530,15 +533,16 @@ extern "C" int aadg_bn_backward(const void* x, const void* y, const void* act_ma
     if (dres != nullptr && y == nullptr && act_mask == nullptr) return AADG_E_BADARG;
     if (n_extra < 0 || n_extra > BN_MAX_EXTRA || (n_extra > 0 && (dy_extra == nullptr || dres == nullptr)))
         return AADG_E_BADARG;                                     // summed gradients are materialised as dres
+    if (dy_plane_const != nullptr && dres == nullptr) return AADG_E_BADARG;
     if (C <= 0 || ws_bytes < aadg_bn_workspace_bytes(C)) return AADG_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
         return bn_backward<float>((const float*)x, (const float*)y, (const uint8_t*)act_mask, (const float*)dy, dy_extra, n_extra,
-                                  weight, bias, save_mean, save_invstd, act, (float*)dx, (float*)dres, dweight, dbias, N, C, HW,
+                                  dy_plane_const, weight, bias, save_mean, save_invstd, act, (float*)dx, (float*)dres, dweight, dbias, N, C, HW,
                                   (float*)ws, st);
     if (dtype == 1)
         return bn_backward<__hip_bfloat16>((const __hip_bfloat16*)x, (const __hip_bfloat16*)y, (const uint8_t*)act_mask,
-                                           (const __hip_bfloat16*)dy, dy_extra, n_extra, weight, bias, save_mean, save_invstd, act,
+                                           (const __hip_bfloat16*)dy, dy_extra, n_extra, dy_plane_const, weight, bias, save_mean, save_invstd, act,
                                            (__hip_bfloat16*)dx, (__hip_bfloat16*)dres, dweight, dbias, N, C, HW, (float*)ws, st);
     return AADG_E_BADARG;
 }

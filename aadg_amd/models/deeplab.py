@@ -296,6 +296,25 @@ class MobileNetV2Encoder(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------------- head
+class _GlobalAvgPoolF32(torch.autograd.Function):
+    """x.mean(dim=(2, 3), dtype=float32).  autograd's own backward builds the full-size gradient in float32 and casts it
+    afterwards (1.2 GB written + read again for the encoder output at N = 144); here it is a broadcast view in x's dtype."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape, ctx.dtype = tuple(x.shape), x.dtype
+        return x.mean(dim=(2, 3), dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, H, W = ctx.shape
+        return (g * (1.0 / (H * W))).to(ctx.dtype)[:, :, None, None].expand(N, C, H, W)
+
+
+def global_avg_pool_f32(x):
+    return _GlobalAvgPoolF32.apply(x)
+
+
 class ASPP(nn.Module):
     def __init__(self, cin, cout=256, rates=(12, 24, 36)):
         super().__init__()
@@ -345,7 +364,7 @@ class DeepLabV3Plus(nn.Module):
         # ClassificationHead = avg-pool + flatten (models/heads.py:19-25): accumulated in fp32 without materialising an fp32
         # copy of the [N, C_enc, h/16, w/16] map; the same average feeds the ASPP image-pool branch (one reduction, one
         # broadcast gradient instead of two)
-        pooled = hd[4].mean(dim=(2, 3), dtype=torch.float32)
+        pooled = global_avg_pool_f32(hd[4])
         a = self.aspp[0](tuple(hd[:4]), pooled)          # ASPP takes one handle of the encoder output per convolution branch
         for mod in list(self.aspp)[1:]:
             a = mod(a)

@@ -200,8 +200,10 @@ int aadg_bn_forward(const void* x, const void* residual, void* y, void* act_mask
                     float* running_mean, float* running_var, float momentum, float eps, int act, int training,
                     int N, int C, int HW, int dtype, float* save_mean, float* save_invstd, void* ws,
                     size_t ws_bytes, void* stream);
+/* dy_plane_const (optional, needs dres): [N*C] float32, a further gradient that is constant over each plane -- what a global
+ * average pool of the output sends back -- added to dy without materialising it */
 int aadg_bn_backward(const void* x, const void* y, const void* act_mask, const void* dy, const void* const* dy_extra,
-                     int n_extra, const float* weight, const float* bias, const float* save_mean,
+                     int n_extra, const float* dy_plane_const, const float* weight, const float* bias, const float* save_mean,
                      const float* save_invstd, int act, void* dx, void* dres, float* dweight, float* dbias, int N,
                      int C, int HW, int dtype, void* ws, size_t ws_bytes, void* stream);
 

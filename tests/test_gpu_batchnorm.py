@@ -188,3 +188,26 @@ def test_bn_dual_output_sums_both_gradients(hip, dtype, with_res):
     y2 = hip.batch_norm_act(x2, w0, b0, torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), True, 0.1, 1e-5, 1, r0)
     y2.backward(gb)
     assert (x.grad.float() - x2.grad.float()).abs().max().item() <= (6e-2 if lo else 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_plane_constant_gradient_travels_as_one_value_per_plane(hip, dtype):
+    """The output also feeds a global average pool: its gradient (a broadcast over each plane) is handed to the kernel as
+    [N*C] floats -- same result as the materialised tensor."""
+    from aadg_amd.models.deeplab import global_avg_pool_f32
+    torch.manual_seed(11)
+    shape = (3, 8, 8, 16)
+    x0 = torch.randn(shape, device="cuda").to(dtype)
+    r0 = torch.randn(shape, device="cuda").to(dtype)
+    w0, b0 = torch.rand(8, device="cuda") + 0.5, torch.randn(8, device="cuda") * 0.2
+    g = torch.randn(shape, device="cuda").to(dtype)
+    gp = torch.randn(3, 8, device="cuda")
+    res = []
+    for custom in (True, False):
+        x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        ya, yb = hip.batch_norm_act(x, w0, b0, torch.zeros(8, device="cuda"), torch.ones(8, device="cuda"), True, 0.1, 1e-5, 1, r, handles=2)
+        pooled = global_avg_pool_f32(yb) if custom else yb.float().mean(dim=(2, 3))
+        torch.autograd.backward([ya, pooled], [g, gp])
+        res.append((x.grad.float(), r.grad.float()))
+    tol = 0.1 if dtype == torch.bfloat16 else 1e-5
+    assert (res[0][0] - res[1][0]).abs().max().item() <= tol and (res[0][1] - res[1][1]).abs().max().item() <= tol

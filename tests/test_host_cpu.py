@@ -144,3 +144,16 @@ def test_separable_conv_folds_a_dilation_that_reaches_past_the_map():
     m2 = SeparableConv2d(6, 4, dilation=12).double()
     x2 = torch.randn(1, 6, 32, 32, dtype=torch.float64)
     assert torch.allclose(m2(x2), m2[1](m2[0](x2)))
+
+
+def test_global_avg_pool_f32_matches_mean():
+    from aadg_amd.models.deeplab import global_avg_pool_f32
+    torch.manual_seed(1)
+    x = torch.randn(3, 5, 4, 6, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(3, 5)
+    y = global_avg_pool_f32(x)
+    (y * w).sum().backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = x2.mean(dim=(2, 3), dtype=torch.float32)
+    (y2 * w).sum().backward()
+    assert y.dtype == torch.float32 and torch.equal(y, y2) and torch.allclose(x.grad, x2.grad, rtol=1e-6, atol=1e-8)
