@@ -121,9 +121,9 @@ def load():
     lib.aadg_stem_conv7x7_workspace_bytes.restype = ctypes.c_size_t
     lib.aadg_stem_conv7x7_workspace_bytes.argtypes = []
     lib.aadg_stem_conv7x7_bf16.restype = _i
-    lib.aadg_stem_conv7x7_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp, ctypes.c_size_t, _vp]
+    lib.aadg_stem_conv7x7_bf16.argtypes = [_vp, _i, _vp, _vp, _i, _i, _i, _vp, ctypes.c_size_t, _vp]
     lib.aadg_stem_conv7x7_wgrad_bf16.restype = _i
-    lib.aadg_stem_conv7x7_wgrad_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp]
+    lib.aadg_stem_conv7x7_wgrad_bf16.argtypes = [_vp, _i, _vp, _vp, _i, _i, _i, _vp]
     lib.aadg_subsample2x2_supported.restype = _i
     lib.aadg_subsample2x2_supported.argtypes = [_i, _i, _i]
     lib.aadg_subsample2x2.restype = _i
@@ -725,17 +725,18 @@ def maxpool3x3s2(x):
 
 # ------------------------------------------------------------------------------------------------
 class _StemConv7x7(torch.autograd.Function):
-    """conv2d(x [N,3,H,W] bf16, weight [64,3,7,7] float32 master, stride 2, padding 3) with the MFMA kernel of csrc/stem_conv.hip;
-    the weight gradient runs on the matrix cores too (k_stem7x7_wgrad); an input gradient, if ever asked for, is the library's."""
+    """conv2d(bfloat16(x [N,3,H,W]), weight [64,3,7,7] float32 master, stride 2, padding 3) -> bfloat16 with the MFMA kernels of
+    csrc/stem_conv.hip, forward and weight gradient.  x may still be float32 (the augmentation kernel's output): it is rounded
+    while it is loaded.  An input gradient, if ever asked for, is the library's."""
 
     @staticmethod
     def forward(ctx, x, weight):
         lib = load()
         N, C, H, W = x.shape
-        y = torch.empty((N, 64, H // 2, W // 2), dtype=x.dtype, device=x.device)
+        y = torch.empty((N, 64, H // 2, W // 2), dtype=torch.bfloat16, device=x.device)
         ws = workspace(lib.aadg_stem_conv7x7_workspace_bytes(), x.device, "stem")
-        _check(lib.aadg_stem_conv7x7_bf16(x.data_ptr(), weight.data_ptr(), y.data_ptr(), N, H, W, ws.data_ptr(), ws.numel(), _stream()),
-               "aadg_stem_conv7x7_bf16")
+        _check(lib.aadg_stem_conv7x7_bf16(x.data_ptr(), _BN_DTYPES[x.dtype], weight.data_ptr(), y.data_ptr(), N, H, W, ws.data_ptr(),
+                                          ws.numel(), _stream()), "aadg_stem_conv7x7_bf16")
         ctx.save_for_backward(x, weight)
         return y
 
@@ -746,16 +747,17 @@ class _StemConv7x7(torch.autograd.Function):
         if not ctx.needs_input_grad[0]:                      # the image itself needs no gradient: weight gradient on the matrix cores
             N, C, H, W = x.shape
             dw = torch.empty_like(weight)
-            _check(load().aadg_stem_conv7x7_wgrad_bf16(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, H, W, _stream()),
+            _check(load().aadg_stem_conv7x7_wgrad_bf16(x.data_ptr(), _BN_DTYPES[x.dtype], dy.data_ptr(), dw.data_ptr(), N, H, W, _stream()),
                    "aadg_stem_conv7x7_wgrad_bf16")
             return None, dw
-        dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight.to(x.dtype), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+        xb = x.to(torch.bfloat16)
+        dx, dw, _ = torch.ops.aten.convolution_backward(dy, xb, weight.to(torch.bfloat16), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
                                                         [True, True, False])
-        return dx, dw.to(weight.dtype)
+        return dx.to(x.dtype), dw.to(weight.dtype)
 
 
 def stem_conv7x7_supported(x, weight):
-    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[1] == 3 and
+    return (x.is_cuda and x.dim() == 4 and x.dtype in _BN_DTYPES and x.is_contiguous() and x.shape[1] == 3 and
             tuple(weight.shape) == (64, 3, 7, 7) and weight.dtype == torch.float32 and weight.is_contiguous() and
             bool(load().aadg_stem_conv7x7_supported(x.shape[2], x.shape[3])))
 

@@ -24,6 +24,15 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int ST_CO = 64, ST_KS = 11, ST_TR = 8, ST_TC = 64;       // out channels, K-steps, tile rows / columns (outputs)
 constexpr int ST_PR = 2 * ST_TR + 5, ST_PC = 144;                 // patch rows per channel, patch row pitch (elements)
 
+// 8 consecutive image elements as bfloat16: the image may still be float32 (the augmentation kernel's output) -- rounding
+// it here (round to nearest even, what Tensor.to(bfloat16) does) saves the separate cast pass over the batch
+template <typename TIN> __device__ __forceinline__ uint4 load8_bf16(const TIN* p);
+template <> __device__ __forceinline__ uint4 load8_bf16<uint16_t>(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+template <> __device__ __forceinline__ uint4 load8_bf16<float>(const float* p) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    return make_uint4(aadg_f2bf_pk(a.x, a.y), aadg_f2bf_pk(a.z, a.w), aadg_f2bf_pk(b.x, b.y), aadg_f2bf_pk(b.z, b.w));
+}
+
 // wfrag[(ks * 2 + mt) * 64 + lane] = the A fragment (8 bfloat16) of lane for K-step ks and channel tile mt
 __global__ __launch_bounds__(256) void k_stem_pack(const float* __restrict__ w, uint4* __restrict__ wfrag) {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -39,7 +48,8 @@ __global__ __launch_bounds__(256) void k_stem_pack(const float* __restrict__ w, 
     wfrag[t] = make_uint4(aadg_f2bf_pk(v[0], v[1]), aadg_f2bf_pk(v[2], v[3]), aadg_f2bf_pk(v[4], v[5]), aadg_f2bf_pk(v[6], v[7]));
 }
 
-__global__ __launch_bounds__(256) void k_stem7x7(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
+template <typename TIN>
+__global__ __launch_bounds__(256) void k_stem7x7(const TIN* __restrict__ x, const uint4* __restrict__ wfrag,
                                                  uint16_t* __restrict__ y, int H, int W, int tiles_x, int tiles_y, int total_tiles) {
     __shared__ __attribute__((aligned(16))) uint16_t P[3 * ST_PR * ST_PC];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -58,7 +68,7 @@ __global__ __launch_bounds__(256) void k_stem7x7(const uint16_t* __restrict__ x,
         const int tx = tile % tiles_x, t2 = tile / tiles_x;
         const int ty = t2 % tiles_y, n = t2 / tiles_y;
         const int i0 = ty * ST_TR, j0 = tx * ST_TC;
-        const uint16_t* xn = x + (size_t)n * 3 * H * W;
+        const TIN* xn = x + (size_t)n * 3 * H * W;
         __syncthreads();                                           // the previous tile's readers are done with P
         // patch: input rows 2*i0 - 3 .. 2*i0 + 17, columns 2*j0 - 8 .. 2*j0 + 135 (18 chunks of 8), zero outside the image
         for (int it = tid; it < 3 * ST_PR * (ST_PC / 8); it += 256) {
@@ -66,7 +76,7 @@ __global__ __launch_bounds__(256) void k_stem7x7(const uint16_t* __restrict__ x,
             const int pr = rc % ST_PR, c = rc / ST_PR;
             const int row = 2 * i0 - 3 + pr, col = 2 * j0 - 8 + 8 * q;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (row >= 0 && row < H && col >= 0 && col < W) v = *reinterpret_cast<const uint4*>(xn + ((size_t)c * H + row) * W + col);
+            if (row >= 0 && row < H && col >= 0 && col < W) v = load8_bf16<TIN>(xn + ((size_t)c * H + row) * W + col);
             *reinterpret_cast<uint4*>(P + (c * ST_PR + pr) * ST_PC + 8 * q) = v;
         }
         __syncthreads();
@@ -137,7 +147,8 @@ constexpr int SW_DY_ELEMS = SW_ROWS * SW_CH * SW_DPITCH, SW_X_ELEMS = 2 * 3 * SW
 constexpr int SW_RED_FLOATS = SW_CH * 32 * SW_NT;
 constexpr int SW_DY_ITEMS = SW_ROWS * SW_CH * (SW_PX / 8) / 256, SW_X_CHUNKS = 3 * SW_XROWS * 18, SW_X_ITEMS = (SW_X_CHUNKS + 255) / 256;
 
-__global__ __launch_bounds__(256, 2) void k_stem7x7_wgrad(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+template <typename TIN>
+__global__ __launch_bounds__(256, 2) void k_stem7x7_wgrad(const TIN* __restrict__ x, const uint16_t* __restrict__ dy,
                                                        float* __restrict__ dw, int H, int W, int tiles_x, int tiles_y, int total_tiles) {
     constexpr int LDS_BYTES = (SW_DY_ELEMS + SW_X_ELEMS) * 2 > SW_RED_FLOATS * 4 ? (SW_DY_ELEMS + SW_X_ELEMS) * 2 : SW_RED_FLOATS * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7_wgrad(const uint16_t* __rest
         const int tx_ = t1_ % tiles_x, t2_ = t1_ / tiles_x;                                                                \
         const int ty_ = t2_ % tiles_y, n_ = t2_ / tiles_y;                                                                 \
         const int i0_ = ty_ * SW_ROWS, j0_ = tx_ * SW_PX;                                                                  \
-        const uint16_t* xn_ = x + (size_t)n_ * 3 * H * W;                                                                  \
+        const TIN* xn_ = x + (size_t)n_ * 3 * H * W;                                                                  \
         const uint16_t* dyn_ = dy + ((size_t)n_ * ST_CO + half_ * SW_CH) * Ho * Wo;                                       \
         _Pragma("unroll") for (int k_ = 0; k_ < SW_DY_ITEMS; ++k_) {                                                       \
             const int it_ = tid + 256 * k_, q_ = it_ & 7, o_ = (it_ >> 3) & (SW_CH - 1), r_ = it_ >> 8;                    \
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7_wgrad(const uint16_t* __rest
             const int row_ = 2 * i0_ - 3 + pr_, col_ = 2 * j0_ - 8 + 8 * q_;                                               \
             rx[k_] = make_uint4(0u, 0u, 0u, 0u);                                                                           \
             if (it_ < SW_X_CHUNKS && row_ >= 0 && row_ < H && col_ >= 0 && col_ < W)                                       \
-                rx[k_] = *reinterpret_cast<const uint4*>(xn_ + ((size_t)c_ * H + row_) * W + col_);                        \
+                rx[k_] = load8_bf16<TIN>(xn_ + ((size_t)c_ * H + row_) * W + col_);                        \
         }                                                                                                                  \
     } while (0)
 
@@ -262,10 +273,11 @@ extern "C" int aadg_stem_conv7x7_supported(int H, int W) {
 
 extern "C" size_t aadg_stem_conv7x7_workspace_bytes(void) { return (size_t)ST_KS * 2 * 64 * sizeof(uint4); }
 
-/* y [N, 64, H/2, W/2] (bfloat16) = conv2d(x [N, 3, H, W] (bfloat16), weight [64, 3, 7, 7] (float32), stride 2, padding 3) */
-extern "C" int aadg_stem_conv7x7_bf16(const void* x, const float* weight, void* y, int N, int H, int W, void* ws, size_t ws_bytes,
-                                      void* stream) {
-    if (x == nullptr || weight == nullptr || y == nullptr || ws == nullptr || N <= 0) return AADG_E_BADARG;
+/* y [N, 64, H/2, W/2] (bfloat16) = conv2d(bfloat16(x [N, 3, H, W]), weight [64, 3, 7, 7] (float32), stride 2, padding 3);
+ * x_dtype 0: x is float32 and is rounded to bfloat16 on load, 1: x is bfloat16 */
+extern "C" int aadg_stem_conv7x7_bf16(const void* x, int x_dtype, const float* weight, void* y, int N, int H, int W, void* ws,
+                                      size_t ws_bytes, void* stream) {
+    if (x == nullptr || weight == nullptr || y == nullptr || ws == nullptr || N <= 0 || (x_dtype != 0 && x_dtype != 1)) return AADG_E_BADARG;
     if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)ws) & 15u) != 0) return AADG_E_BADARG;
     if (!aadg_stem_conv7x7_supported(H, W)) return AADG_E_UNSUPPORTED;
     if (ws_bytes < aadg_stem_conv7x7_workspace_bytes()) return AADG_E_WORKSPACE;
@@ -277,16 +289,20 @@ extern "C" int aadg_stem_conv7x7_bf16(const void* x, const float* weight, void* 
     hipLaunchKernelGGL(k_stem_pack, dim3((ST_KS * 2 * 64 + 255) / 256), dim3(256), 0, st, weight, reinterpret_cast<uint4*>(ws));
     AADG_LAUNCH_CHECK();
     const int grid = (int)(total < 512 ? total : 512);              // persistent: the 2 workgroups a CU holds (241 registers per lane), weight fragments loaded once each
-    hipLaunchKernelGGL(k_stem7x7, dim3(grid), dim3(256), 0, st, (const uint16_t*)x, (const uint4*)ws, (uint16_t*)y, H, W, tiles_x,
-                       tiles_y, (int)total);
+    if (x_dtype == 0)
+        hipLaunchKernelGGL(k_stem7x7<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (const uint4*)ws, (uint16_t*)y, H, W, tiles_x,
+                           tiles_y, (int)total);
+    else
+        hipLaunchKernelGGL(k_stem7x7<uint16_t>, dim3(grid), dim3(256), 0, st, (const uint16_t*)x, (const uint4*)ws, (uint16_t*)y, H, W,
+                           tiles_x, tiles_y, (int)total);
     AADG_LAUNCH_CHECK();
     return 0;
 }
 
-/* dweight [64, 3, 7, 7] (float32, overwritten) = gradient of aadg_stem_conv7x7_bf16 w.r.t. its weight, from x [N, 3, H, W] and
- * dy [N, 64, H/2, W/2] (bfloat16); float32 accumulation, partial sums combined with float atomics. */
-extern "C" int aadg_stem_conv7x7_wgrad_bf16(const void* x, const void* dy, float* dweight, int N, int H, int W, void* stream) {
-    if (x == nullptr || dy == nullptr || dweight == nullptr || N <= 0) return AADG_E_BADARG;
+/* dweight [64, 3, 7, 7] (float32, overwritten) = gradient of aadg_stem_conv7x7_bf16 w.r.t. its weight, from x [N, 3, H, W]
+ * (x_dtype as in the forward) and dy [N, 64, H/2, W/2] (bfloat16); float32 accumulation, partial sums combined with float atomics. */
+extern "C" int aadg_stem_conv7x7_wgrad_bf16(const void* x, int x_dtype, const void* dy, float* dweight, int N, int H, int W, void* stream) {
+    if (x == nullptr || dy == nullptr || dweight == nullptr || N <= 0 || (x_dtype != 0 && x_dtype != 1)) return AADG_E_BADARG;
     if ((((uintptr_t)x | (uintptr_t)dy) & 15u) != 0) return AADG_E_BADARG;
     if (!aadg_stem_conv7x7_supported(H, W)) return AADG_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -296,8 +312,12 @@ extern "C" int aadg_stem_conv7x7_wgrad_bf16(const void* x, const void* dy, float
     if (total > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
     AADG_HIP_TRY(hipMemsetAsync(dweight, 0, (size_t)ST_CO * 147 * sizeof(float), st));
     const int grid = (int)(total < 1024 ? total : 1024);                   // even: a workgroup keeps one channel half
-    hipLaunchKernelGGL(k_stem7x7_wgrad, dim3(grid), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)dy, dweight, H, W, tiles_x,
-                       tiles_y, (int)total);
+    if (x_dtype == 0)
+        hipLaunchKernelGGL(k_stem7x7_wgrad<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (const uint16_t*)dy, dweight, H, W,
+                           tiles_x, tiles_y, (int)total);
+    else
+        hipLaunchKernelGGL(k_stem7x7_wgrad<uint16_t>, dim3(grid), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)dy, dweight, H, W,
+                           tiles_x, tiles_y, (int)total);
     AADG_LAUNCH_CHECK();
     return 0;
 }

@@ -122,9 +122,9 @@ class StemConv7x7(nn.Conv2d):
                                              torch.get_autocast_dtype('cuda') == torch.bfloat16)
         if x.is_cuda and lowp:
             from .. import _lib
-            xb = x.to(torch.bfloat16).contiguous()
-            if _lib.stem_conv7x7_supported(xb, self.weight):
-                return _lib.stem_conv7x7(xb, self.weight)
+            xc = x.contiguous()                              # float32 images are rounded to bfloat16 inside the kernel
+            if _lib.stem_conv7x7_supported(xc, self.weight):
+                return _lib.stem_conv7x7(xc, self.weight)
         return super().forward(x)
 
 

@@ -230,9 +230,11 @@ int aadg_dwconv3x3_wgrad(const void* x, const void* dy, float* dweight, int N, i
  * ------------------------------------------------------------------------------------------- */
 int aadg_stem_conv7x7_supported(int H, int W);
 size_t aadg_stem_conv7x7_workspace_bytes(void);
-int aadg_stem_conv7x7_bf16(const void* x, const float* weight, void* y, int N, int H, int W, void* ws, size_t ws_bytes, void* stream);
+/* x_dtype: 0 = x is float32 (rounded to bfloat16 on load: no separate cast of the batch), 1 = bfloat16 */
+int aadg_stem_conv7x7_bf16(const void* x, int x_dtype, const float* weight, void* y, int N, int H, int W, void* ws, size_t ws_bytes,
+                           void* stream);
 /* dweight [64,3,7,7] (float32, overwritten) from x [N,3,H,W] and dy [N,64,H/2,W/2] (bfloat16): MFMA GEMM over the output pixels */
-int aadg_stem_conv7x7_wgrad_bf16(const void* x, const void* dy, float* dweight, int N, int H, int W, void* stream);
+int aadg_stem_conv7x7_wgrad_bf16(const void* x, int x_dtype, const void* dy, float* dweight, int N, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stride-2 pixel sub-sampling of NCHW planes: y[p][i][j] = x[p][2i][2j], x [planes, H, W] -> y [planes, H/2, W/2], and its

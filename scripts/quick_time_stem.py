@@ -22,7 +22,7 @@ dy = torch.randn_like(a)
 ref = lambda: torch.ops.aten.convolution_backward(dy, x, wq, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
 def ours():
     dw = torch.empty_like(w)
-    _lib._check(_lib.load().aadg_stem_conv7x7_wgrad_bf16(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, 512, 512, _lib._stream()), "wgrad")
+    _lib._check(_lib.load().aadg_stem_conv7x7_wgrad_bf16(x.data_ptr(), 1, dy.data_ptr(), dw.data_ptr(), N, 512, 512, _lib._stream()), "wgrad")
     return dw
 ga, gb_ = ours(), ref().float()
 print("wgrad max diff %.3e of %.3e" % ((ga - gb_).abs().max().item(), gb_.abs().max().item()))

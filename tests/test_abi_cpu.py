@@ -104,8 +104,8 @@ def test_backbone_and_controller_entry_points_validate_arguments():
     # stem convolution
     assert lib.aadg_stem_conv7x7_supported(512, 512) == 1 and lib.aadg_stem_conv7x7_supported(512, 520) == 0
     assert lib.aadg_stem_conv7x7_workspace_bytes() == 11 * 2 * 64 * 16
-    assert lib.aadg_stem_conv7x7_bf16(z, z, z, 1, 32, 32, z, 0, z) == -1
-    assert lib.aadg_stem_conv7x7_wgrad_bf16(z, z, z, 1, 32, 32, z) == -1
+    assert lib.aadg_stem_conv7x7_bf16(z, 1, z, z, 1, 32, 32, z, 0, z) == -1
+    assert lib.aadg_stem_conv7x7_wgrad_bf16(z, 1, z, z, 1, 32, 32, z) == -1
     # stride-2 sub-sampling
     assert lib.aadg_subsample2x2_supported(16, 32, 1) == 1 and lib.aadg_subsample2x2_supported(16, 24, 1) == 0
     assert lib.aadg_subsample2x2_supported(16, 24, 0) == 1 and lib.aadg_subsample2x2_supported(15, 32, 0) == 0

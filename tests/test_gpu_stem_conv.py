@@ -60,7 +60,8 @@ def test_stem_module_trains_like_conv2d(hip):
 def test_stem_rejects_unsupported(hip):
     w = torch.randn(64, 3, 7, 7, device="cuda")
     assert not hip.stem_conv7x7_supported(torch.zeros(1, 3, 32, 24, device="cuda", dtype=torch.bfloat16), w)
-    assert not hip.stem_conv7x7_supported(torch.zeros(1, 3, 32, 32, device="cuda"), w)
+    assert hip.stem_conv7x7_supported(torch.zeros(1, 3, 32, 32, device="cuda"), w)              # float32 images are rounded on load
+    assert not hip.stem_conv7x7_supported(torch.zeros(1, 3, 32, 32, device="cuda", dtype=torch.float16), w)
     with pytest.raises(hip.AadgError):
         hip.stem_conv7x7(torch.zeros(1, 3, 32, 24, device="cuda", dtype=torch.bfloat16), w)
 
@@ -77,3 +78,18 @@ def test_stem_weight_gradient_matches_conv2d(hip, N, H, W):
     F.conv2d(x.float(), wr, stride=2, padding=3).backward(g.float())          # exact products of the same bf16 operands, float32 sums
     scale = max(1.0, wr.grad.abs().max().item())
     assert (w.grad - wr.grad).abs().max().item() <= 2e-3 * scale
+
+
+def test_stem_float32_image_is_rounded_on_load(hip):
+    torch.manual_seed(2)
+    x = torch.randn(2, 3, 64, 96, device="cuda")
+    w = (torch.randn(64, 3, 7, 7, device="cuda") * 0.1).requires_grad_(True)
+    y32 = hip.stem_conv7x7(x, w)
+    g = torch.randn_like(y32)
+    y32.backward(g)
+    g32 = w.grad.clone()
+    w.grad = None
+    y16 = hip.stem_conv7x7(x.to(torch.bfloat16), w)
+    y16.backward(g)
+    assert y32.dtype == torch.bfloat16 and torch.equal(y32, y16)
+    assert (g32 - w.grad).abs().max().item() <= 1e-4 * max(1.0, w.grad.abs().max().item())     # same products, atomics reorder the sums
