@@ -4,13 +4,13 @@
 // the library kernels they replace launch one workgroup per channel (64 workgroups for the stem on a 256-CU part).
 // Here every phase is a streaming pass with 16-byte accesses and a (channel, split) grid:
 //
-//   k_bn_reduce<FWD>   per (c, split): sum x, sum x^2                       -> partials (float2)
-//   k_bn_finalize_fwd  per c: mean, invstd (double combine), running stats, scale = w*invstd, shift = b - mean*scale
-//   k_bn_apply         y = act(x * scale[c] + shift[c] (+ residual))
-//   k_bn_reduce<BWD>   per (c, split): sum g, sum g*xhat with g = dy * act'(.)  (optionally writes g = d residual)
-//   k_bn_finalize_bwd  dweight, dbias and the three per-channel coefficients of dx = a*g + b*x + c0
-//   k_bn_dx            dx = a[c]*g + b[c]*x + c0[c]
+//   k_bn_reduce_fwd    per (c, split): sum x, sum x^2                       -> partials (float2)
+//   k_bn_apply         every wave combines its channel's partials (float64): mean, invstd, scale = w*invstd, shift = b - mean*scale;
+//                      y = act(x * scale + shift (+ residual)); the workgroup of image 0 stores saved / running statistics
+//   k_bn_reduce_bwd    per (c, split): sum g, sum g*xhat with g = (dy + further gradients) * act'(.)  (optionally writes g)
+//   k_bn_dx            every wave combines the partials into the coefficients of dx = a*g + b*x + c0; image 0 stores dweight, dbias
 //
+// Two launches per layer and direction: the per-channel finalisation lives inside the elementwise passes (see bn_combine).
 // Arithmetic = torch.nn.functional.batch_norm (biased variance for normalisation, unbiased for running_var),
 // float32 accumulation, partial sums combined in float64.
 #include <hip/hip_bf16.h>
@@ -126,6 +126,31 @@ __device__ __forceinline__ float2 block_sum2(float a, float b) {
     return r;
 }
 
+// The per-channel finalisation (combine the <= 64 partial sums in float64, derive the coefficients) used to be two tiny
+// kernels per BatchNorm layer and direction: ~190 launches of ~5 us per step, a fixed cost that does not shrink with the
+// per-rank batch.  Every wave of the elementwise kernels now redoes it for its own channel: 64 lanes load one partial each,
+// a float64 butterfly leaves the same totals in every lane (same order in every workgroup of the channel: identical
+// coefficients), and the workgroup of image 0 writes what has to be stored (saved / running statistics, dweight, dbias).
+__device__ __forceinline__ void bn_combine(const float* __restrict__ partial, int c, int split, double* s, double* q) {
+    const int lane = threadIdx.x & 63;
+    double a = 0.0, b = 0.0;
+    if (lane < split) {
+        const float2 p = reinterpret_cast<const float2*>(partial)[(size_t)c * BN_MAX_SPLIT + lane];
+        a = (double)p.x; b = (double)p.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    *s = a; *q = b;
+}
+// scale / shift of channel c from the SAVED float32 statistics: the forward derives them the same way, so the backward
+// recomputes bit-identical pre-activations
+__device__ __forceinline__ void bn_scale_shift_of(const float* __restrict__ weight, const float* __restrict__ bias, float mean, float invstd,
+                                                  int c, float* sc, float* sh) {
+    const float w = weight != nullptr ? weight[c] : 1.0f, b = bias != nullptr ? bias[c] : 0.0f;
+    *sc = w * invstd;
+    *sh = fmaf(-mean, *sc, b);
+}
+
 constexpr int BN_MAX_EXTRA = 6;
 template <typename T> struct BnExtra {      // further gradients of the same output (one per additional consumer)
     const T* p[BN_MAX_EXTRA];
@@ -168,7 +193,7 @@ template <typename T, int VEC, int MK, int NE, int DRES>
 __global__ __launch_bounds__(256) void k_bn_reduce_bwd(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
                                                        BnExtra<T> more, const float* __restrict__ pconst, const uint8_t* __restrict__ mask,
                                                        T* __restrict__ dres, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                       const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                       const float* __restrict__ weight, const float* __restrict__ bias, int act,
                                                        int C, int len, int per_strip, int plen, int total, float* __restrict__ partial) {
     static_assert(MK == 2 || VEC > 1, "the specialised variants are vector-only");
     const int c = blockIdx.y, S = gridDim.x;
@@ -176,7 +201,7 @@ __global__ __launch_bounds__(256) void k_bn_reduce_bwd(const T* __restrict__ x, 
     float s0 = 0.f, s1 = 0.f;
     const float mu = mean[c], is = invstd[c];
     float sc = 0.f, sh = 0.f;
-    if (MK >= 2) { sc = scale[c]; sh = shift[c]; }
+    if (MK >= 2) bn_scale_shift_of(weight, bias, mu, is, c, &sc, &sh);
     const bool write_g = DRES < 0 ? dres != nullptr : DRES != 0;
     for (int p = blockIdx.x; p < total; p += S) {
         const int n = p / per_strip, part = p - n * per_strip;
@@ -235,83 +260,53 @@ __global__ __launch_bounds__(256) void k_bn_reduce_bwd(const T* __restrict__ x, 
     if (threadIdx.x == 0) reinterpret_cast<float2*>(partial)[(size_t)c * BN_MAX_SPLIT + blockIdx.x] = r;
 }
 
-__global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict__ partial, int split, int C, double count,
-                                                         const float* __restrict__ weight, const float* __restrict__ bias,
-                                                         float* running_mean, float* running_var, float momentum, float eps,
-                                                         float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                         float* __restrict__ scale, float* __restrict__ shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int i = 0; i < split; ++i) {
-        const float2 p = reinterpret_cast<const float2*>(partial)[(size_t)c * BN_MAX_SPLIT + i];
-        s += (double)p.x; q += (double)p.y;
-    }
-    const double m = s / count;
-    double var = q / count - m * m;
-    if (var < 0.0) var = 0.0;
-    const float is = (float)(1.0 / sqrt(var + (double)eps));
-    save_mean[c] = (float)m;
-    save_invstd[c] = is;
-    if (running_mean != nullptr) {
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)m;
-        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
-    }
-    const float w = weight != nullptr ? weight[c] : 1.0f, b = bias != nullptr ? bias[c] : 0.0f;
-    const float sc = w * is;
-    scale[c] = sc;
-    shift[c] = fmaf(-(float)m, sc, b);
-}
-
-// scale / shift from given statistics: `from_var` = 1: second array is a variance (inference, running statistics),
-// 0: it is the saved invstd of a training forward (bit-identical to what k_bn_finalize_fwd produced)
+// inference: scale / shift from the running statistics
 __global__ __launch_bounds__(256) void k_bn_scale_shift(int C, const float* __restrict__ weight, const float* __restrict__ bias,
-                                                        const float* __restrict__ mean, const float* __restrict__ second,
-                                                        float eps, int from_var, float* __restrict__ scale,
-                                                        float* __restrict__ shift) {
+                                                        const float* __restrict__ mean, const float* __restrict__ var,
+                                                        float eps, float* __restrict__ scale, float* __restrict__ shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float is = from_var ? 1.0f / sqrtf(second[c] + eps) : second[c];
-    const float w = weight != nullptr ? weight[c] : 1.0f, b = bias != nullptr ? bias[c] : 0.0f;
-    const float sc = w * is;
-    scale[c] = sc;
-    shift[c] = fmaf(-mean[c], sc, b);
-}
-
-__global__ __launch_bounds__(256) void k_bn_finalize_bwd(const float* __restrict__ partial, int split, int C, double count,
-                                                         const float* __restrict__ weight, const float* __restrict__ mean,
-                                                         const float* __restrict__ invstd, float* __restrict__ dweight,
-                                                         float* __restrict__ dbias, float* __restrict__ ca,
-                                                         float* __restrict__ cb, float* __restrict__ cc) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double sg = 0.0, sgx = 0.0;
-    for (int i = 0; i < split; ++i) {
-        const float2 p = reinterpret_cast<const float2*>(partial)[(size_t)c * BN_MAX_SPLIT + i];
-        sg += (double)p.x; sgx += (double)p.y;
-    }
-    if (dweight != nullptr) dweight[c] = (float)sgx;
-    if (dbias != nullptr) dbias[c] = (float)sg;
-    const double w = weight != nullptr ? (double)weight[c] : 1.0;
-    const double is = (double)invstd[c], mu = (double)mean[c];
-    const double a = w * is;                              // dx = a*g - a*sg/n - a*is*sgx/n * (x - mu)
-    const double b = -a * is * sgx / count;
-    ca[c] = (float)a;
-    cb[c] = (float)b;
-    cc[c] = (float)(-a * sg / count - b * mu);
+    bn_scale_shift_of(weight, bias, mean[c], 1.0f / sqrtf(var[c] + eps), c, scale + c, shift + c);
 }
 
 // ---- elementwise passes: grid (N*C strips, pieces per strip) ------------------------------------------------
 // ACT >= 0: the activation is a compile-time constant (vector path); ACT < 0: the run-time `act` (scalar path).
-template <typename T, int VEC, int ACT, bool RES, bool MASK>
+// FIN: training -- the statistics of this channel are finalised here from the reduction's partial sums (BnFin); else
+// scale / shift come from the arrays k_bn_scale_shift filled (inference).
+struct BnFin {
+    const float* partial; int split; double count;
+    const float* weight; const float* bias;
+    float* running_mean; float* running_var; float momentum, eps;
+    float* save_mean; float* save_invstd;
+};
+template <typename T, int VEC, int ACT, bool RES, bool MASK, bool FIN>
 __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                   uint8_t* __restrict__ mask, const float* __restrict__ scale,
-                                                  const float* __restrict__ shift, int act_rt, int C, int len, int plen) {
+                                                  const float* __restrict__ shift, BnFin fin, int act_rt, int C, int len, int plen) {
     static_assert(!MASK || VEC > 1, "one mask byte per 16-byte vector");
     const int act = ACT >= 0 ? ACT : act_rt;
     const int strip = blockIdx.x, c = strip % C;
-    const float sc = scale[c], sh = shift[c];
+    float sc, sh;
+    if (FIN) {
+        double s, q;
+        bn_combine(fin.partial, c, fin.split, &s, &q);
+        const double m = s / fin.count;
+        double var = q / fin.count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)fin.eps));
+        bn_scale_shift_of(fin.weight, fin.bias, (float)m, is, c, &sc, &sh);
+        if (strip == c && blockIdx.y == 0 && threadIdx.x == 0) {      // image 0, first piece: the one writer of this channel
+            fin.save_mean[c] = (float)m;
+            fin.save_invstd[c] = is;
+            if (fin.running_mean != nullptr) {
+                const double unbiased = fin.count > 1.0 ? var * fin.count / (fin.count - 1.0) : var;
+                fin.running_mean[c] = (1.0f - fin.momentum) * fin.running_mean[c] + fin.momentum * (float)m;
+                fin.running_var[c] = (1.0f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unbiased;
+            }
+        }
+    } else {
+        sc = scale[c]; sh = shift[c];
+    }
     const size_t base = (size_t)strip * len * VEC;
     const int j1 = min(len, ((int)blockIdx.y + 1) * plen);
 #pragma unroll 4
@@ -339,15 +334,31 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const
 }
 
 // ACT = activation whose mask is re-derived from x exactly as the forward did (0: none, or `dy` already holds the masked
-// gradient g = dres); ACT < 0: run-time `act_rt`
+// gradient g = dres); ACT < 0: run-time `act_rt`.  The channel's coefficients of dx = a*g + b*x + c0 are finalised here from
+// the backward reduction's partial sums; the workgroup of image 0 stores dweight / dbias.
 template <typename T, int VEC, int ACT>
 __global__ __launch_bounds__(256) void k_bn_dx(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
-                                               const float* __restrict__ scale, const float* __restrict__ shift,
-                                               const float* __restrict__ ca, const float* __restrict__ cb,
-                                               const float* __restrict__ cc, int act_rt, int C, int len, int plen) {
+                                               const float* __restrict__ partial, int split, double count,
+                                               const float* __restrict__ weight, const float* __restrict__ bias,
+                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                               float* __restrict__ dweight, float* __restrict__ dbias, int act_rt, int C, int len,
+                                               int plen) {
     const int act = ACT >= 0 ? ACT : act_rt;
     const int strip = blockIdx.x, c = strip % C;
-    const float sc = scale[c], sh = shift[c], a = ca[c], b = cb[c], c0 = cc[c];
+    double sg, sgx;
+    bn_combine(partial, c, split, &sg, &sgx);
+    const float mu_f = mean[c], is_f = invstd[c];
+    const double w = weight != nullptr ? (double)weight[c] : 1.0;
+    const double is = (double)is_f, mu = (double)mu_f;
+    const double ad = w * is;                             // dx = a*g - a*sg/n - a*is*sgx/n * (x - mu)
+    const double bd = -ad * is * sgx / count;
+    const float a = (float)ad, b = (float)bd, c0 = (float)(-ad * sg / count - bd * mu);
+    if (strip == c && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (dweight != nullptr) dweight[c] = (float)sgx;
+        if (dbias != nullptr) dbias[c] = (float)sg;
+    }
+    float sc = 0.f, sh = 0.f;
+    if (ACT != 0) bn_scale_shift_of(weight, bias, mu_f, is_f, c, &sc, &sh);
     const size_t base = (size_t)strip * len * VEC;
     const int j1 = min(len, ((int)blockIdx.y + 1) * plen);
 #pragma unroll 4
@@ -403,24 +414,24 @@ int bn_forward(const T* x, const T* res, T* y, uint8_t* mask, const float* weigh
         else
             hipLaunchKernelGGL((k_bn_reduce_fwd<T, 1>), grid, blk, 0, st, x, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         AADG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((C + 255) / 256), dim3(256), 0, st, ws + L.partial, s.split, C,
-                           (double)N * (double)HW, weight, bias, rmean, rvar, momentum, eps, save_mean, save_invstd, scale, shift);
-        AADG_LAUNCH_CHECK();
     } else {
         hipLaunchKernelGGL(k_bn_scale_shift, dim3((C + 255) / 256), dim3(256), 0, st, C, weight, bias, (const float*)rmean,
-                           (const float*)rvar, eps, 1, scale, shift);
+                           (const float*)rvar, eps, scale, shift);
         AADG_LAUNCH_CHECK();
     }
     const dim3 grid(N * C, s.pc.per_strip);
-#define AADG_BN_APPLY(VEC_, ACT_, RES_, MASK_) \
-    hipLaunchKernelGGL((k_bn_apply<T, VEC_, ACT_, RES_, MASK_>), grid, blk, 0, st, x, res, y, mask, scale, shift, act, C, s.len, s.pc.plen)
+    const BnFin fin = {ws + L.partial, s.split, (double)N * (double)HW, weight, bias, rmean, rvar, momentum, eps, save_mean, save_invstd};
+#define AADG_BN_APPLY(VEC_, ACT_, RES_, MASK_, FIN_) \
+    hipLaunchKernelGGL((k_bn_apply<T, VEC_, ACT_, RES_, MASK_, FIN_>), grid, blk, 0, st, x, res, y, mask, (const float*)scale, (const float*)shift, fin, act, C, s.len, s.pc.plen)
 #define AADG_BN_APPLY_ACT(ACT_)                                                          \
     do {                                                                                 \
-        if (res != nullptr) { if (mask != nullptr) AADG_BN_APPLY(Pack<T>::N, ACT_, true, true); else AADG_BN_APPLY(Pack<T>::N, ACT_, true, false); } \
-        else { if (mask != nullptr) AADG_BN_APPLY(Pack<T>::N, ACT_, false, true); else AADG_BN_APPLY(Pack<T>::N, ACT_, false, false); }              \
+        if (!training) { if (res != nullptr) AADG_BN_APPLY(Pack<T>::N, ACT_, true, false, false); else AADG_BN_APPLY(Pack<T>::N, ACT_, false, false, false); } \
+        else if (res != nullptr) { if (mask != nullptr) AADG_BN_APPLY(Pack<T>::N, ACT_, true, true, true); else AADG_BN_APPLY(Pack<T>::N, ACT_, true, false, true); } \
+        else { if (mask != nullptr) AADG_BN_APPLY(Pack<T>::N, ACT_, false, true, true); else AADG_BN_APPLY(Pack<T>::N, ACT_, false, false, true); }              \
     } while (0)
     if (s.vec == 1) {
-        if (res != nullptr) AADG_BN_APPLY(1, -1, true, false); else AADG_BN_APPLY(1, -1, false, false);
+        if (training) { if (res != nullptr) AADG_BN_APPLY(1, -1, true, false, true); else AADG_BN_APPLY(1, -1, false, false, true); }
+        else { if (res != nullptr) AADG_BN_APPLY(1, -1, true, false, false); else AADG_BN_APPLY(1, -1, false, false, false); }
     } else if (act == AADG_ACT_RELU) AADG_BN_APPLY_ACT(AADG_ACT_RELU);
     else if (act == AADG_ACT_RELU6) AADG_BN_APPLY_ACT(AADG_ACT_RELU6);
     else AADG_BN_APPLY_ACT(AADG_ACT_NONE);
@@ -437,8 +448,6 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
     if (!make_shape<T>(N, C, HW, x, y, dy, dx, &s) || (((uintptr_t)dres & 15u) && s.vec > 1)) return AADG_E_BADARG;
     if (mask != nullptr && s.vec == 1) return AADG_E_BADARG;
     const BnWs L = bn_ws(C);
-    float* scale = ws + L.scale;
-    float* shift = ws + L.shift;
     const dim3 blk(s.threads);
     BnExtra<T> more = {};
     for (int e = 0; e < n_extra; ++e) {
@@ -446,13 +455,11 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
         more.p[e] = (const T*)dy_extra[e];
     }
     more.n = n_extra;
-    hipLaunchKernelGGL(k_bn_scale_shift, dim3((C + 255) / 256), dim3(256), 0, st, C, weight, bias, mean, invstd, 0.0f, 0, scale, shift);
-    AADG_LAUNCH_CHECK();
     {
         const dim3 grid(s.split, C);
 #define AADG_BN_REDUCE_BWD(VEC_, MK_, NE_, DRES_)                                                                                        \
     hipLaunchKernelGGL((k_bn_reduce_bwd<T, VEC_, MK_, NE_, DRES_>), grid, blk, 0, st, x, y, dy, more, pconst, mask, dres, mean, invstd,  \
-                       (const float*)scale, (const float*)shift, act, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial)
+                       weight, bias, act, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial)
 #define AADG_BN_REDUCE_BWD_MK(MK_)                                                                     \
     do {                                                                                               \
         if (n_extra == 0) { if (dres != nullptr) AADG_BN_REDUCE_BWD(Pack<T>::N, MK_, 0, 1); else AADG_BN_REDUCE_BWD(Pack<T>::N, MK_, 0, 0); } \
@@ -469,18 +476,15 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
 #undef AADG_BN_REDUCE_BWD
         AADG_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((C + 255) / 256), dim3(256), 0, st, ws + L.partial, s.split, C,
-                       (double)N * (double)HW, weight, mean, invstd, dweight, dbias, ws + L.ca, ws + L.cb, ws + L.cc);
-    AADG_LAUNCH_CHECK();
     {
         // when the masked gradient was materialised (dres), the last pass reads it instead of re-deriving the mask
         const T* g = dres != nullptr ? (const T*)dres : dy;
         const int g_ready = dres != nullptr ? 1 : 0;
         const dim3 grid(N * C, s.pc.per_strip);
         const int act_dx = g_ready ? AADG_ACT_NONE : act;
-#define AADG_BN_DX(VEC_, ACT_)                                                                                                \
-    hipLaunchKernelGGL((k_bn_dx<T, VEC_, ACT_>), grid, blk, 0, st, x, g, dx, (const float*)scale, (const float*)shift,         \
-                       (const float*)(ws + L.ca), (const float*)(ws + L.cb), (const float*)(ws + L.cc), act_dx, C, s.len, s.pc.plen)
+#define AADG_BN_DX(VEC_, ACT_)                                                                                                  \
+    hipLaunchKernelGGL((k_bn_dx<T, VEC_, ACT_>), grid, blk, 0, st, x, g, dx, (const float*)(ws + L.partial), s.split,              \
+                       (double)N * (double)HW, weight, bias, mean, invstd, dweight, dbias, act_dx, C, s.len, s.pc.plen)
         if (s.vec == 1) AADG_BN_DX(1, -1);
         else if (act_dx == AADG_ACT_RELU) AADG_BN_DX(Pack<T>::N, AADG_ACT_RELU);
         else if (act_dx == AADG_ACT_RELU6) AADG_BN_DX(Pack<T>::N, AADG_ACT_RELU6);
