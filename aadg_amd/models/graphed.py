@@ -119,6 +119,8 @@ class FusedControllerStep(object):
     (3 + 11 launches instead of ~1900 graph nodes).  Parameters and the optimizer's Adam state are updated in
     place, so `controller.state_dict()` / `optimizer.state_dict()` checkpoints stay the reference's."""
 
+    fused = True                 # plain kernel launches (no graph capture): safe to call in the middle of a training step
+
     def __init__(self, controller, criterion, optimizer, M):
         from .. import _lib
         if not self.supported(controller, criterion, optimizer, M):

@@ -76,9 +76,10 @@ def pretrain(config, train_loader, model, discriminator, model_criterion, dis_cr
 
 
 def inner_iteration(config, sample, model, discriminator, dis_criterion, model_optimizer, dis_optimizer, M, rewards,
-                    args=None, n_domains=3):
+                    args=None, n_domains=3, after_rewards=None):
     """One pass of search_dg.py:123-176 on one collated batch.  Accumulates into `rewards` ([M], device).
-    Returns device scalars (seg_loss, dis_loss, diversity_ot, dice[K]) -- no host sync in here."""
+    Returns device scalars (seg_loss, dis_loss, diversity_ot, dice[K]) -- no host sync in here.
+    `after_rewards()` (optional) runs once this batch's rewards are accumulated, before the backward passes."""
     input, mask_gt, domain_gt = sample['aug_images'], sample['aug_labels'], sample['dc']
     lo, hi, n_rows = sample.get('rows', (0, input.size(0), input.size(0)))
     with _autocast(args):
@@ -108,6 +109,8 @@ def inner_iteration(config, sample, model, discriminator, dis_criterion, model_o
     B = n_rows // (M * n_domains)
     _lib.sinkhorn_rewards(fe_all, n_domains, B, M, rewards=rewards)
     diversity_ot = (rewards - before).sum()
+    if after_rewards is not None:
+        after_rewards()
     model_optimizer.zero_grad(set_to_none=True)
     seg_loss.backward()
     model_optimizer.step()
@@ -118,8 +121,10 @@ def inner_iteration(config, sample, model, discriminator, dis_criterion, model_o
 
 
 def train(config, train_loader, model, discriminator, model_criterion, dis_criterion, model_optimizer, dis_optimizer,
-          M, epoch, writer_dict, logger, args=None, max_iters=None):
-    """One search epoch (search_dg.py:102-214): returns the normalised rewards [M]."""
+          M, epoch, writer_dict, logger, args=None, max_iters=None, on_last_rewards=None):
+    """One search epoch (search_dg.py:102-214): returns the normalised rewards [M].
+    `on_last_rewards(normalised rewards)` (optional) is called as soon as the epoch's rewards are complete -- after the forward
+    pass of the LAST batch, before its backward passes: nothing after that point changes them."""
     batch_time = utils.AverageMeter()
     model.train()
     discriminator.train()
@@ -127,12 +132,16 @@ def train(config, train_loader, model, discriminator, model_criterion, dis_crite
     rewards = torch.zeros(M, device=dev)
     n_domains = len(config.DATASET.DG.TRAIN)
     length = len(train_loader)
+    last = (length if max_iters is None else min(length, max_iters)) - 1
     end = time.time()
     for i, sample in enumerate(train_loader):
         if max_iters is not None and i >= max_iters:
             break
+        hook = None
+        if on_last_rewards is not None and i == last:
+            hook = lambda: on_last_rewards(_lib.normalize_rewards(rewards))
         seg_loss, dis_loss, div_ot, dice = inner_iteration(config, sample, model, discriminator, dis_criterion,
-                                                           model_optimizer, dis_optimizer, M, rewards, args, n_domains)
+                                                           model_optimizer, dis_optimizer, M, rewards, args, n_domains, hook)
         if i % config.PRINT_FREQ == 0 and logger:
             n_img = sample['rows'][2] if 'rows' in sample else sample['aug_images'].size(0)
             vals = torch.stack([seg_loss, dis_loss, div_ot]).tolist()        # the only host sync, every PRINT_FREQ
@@ -200,9 +209,9 @@ class SearchState(object):
             self.graphed = make_controller_step(self.controller, self.controller_criterion, self.controller_optimizer, self.M,
                                                 fused=getattr(args, 'controller_fused', True))
 
-    def search_step(self, epoch, writer_dict=None, logger=None, max_iters=None):
-        """The epoch body of search_dg.py:338-347: sample M policies -> inject -> train -> EMA -> PPO."""
-        self.controller.train()
+    def _sample_policies(self):
+        """Sample M policies from the controller (rank 0's draw is authoritative in a distributed run) and fetch them to the
+        host: (policies, op_probs, mag_probs, log_probs, entropies, policies as a numpy array)."""
         if self.graphed is not None:
             try:
                 policies, op_probs, mag_probs, log_probs, entropies = self.graphed.sample()
@@ -222,14 +231,33 @@ class SearchState(object):
                 torch.distributed.broadcast(self.graphed.old_log_probs, 0)
             else:
                 log_probs = self.controller.evaluate(policies, self.M)
-        parsed = parse_policies(policies.cpu().detach().numpy(), self.config, logger)
+        return policies, op_probs, mag_probs, log_probs, entropies, policies.cpu().detach().numpy()
+
+    def search_step(self, epoch, writer_dict=None, logger=None, max_iters=None):
+        """The epoch body of search_dg.py:338-347: sample M policies -> inject -> train -> EMA -> PPO.
+
+        With the fused controller kernels the PPO update and the NEXT epoch's sampling are issued as soon as this epoch's
+        rewards are complete, i.e. before the backward passes of its last batch: the device-to-host copy of the sampled
+        policies (a full pipeline drain when it sat between two epochs) then waits only for the forward pass, and the host
+        parses / draws the next batch plan while the GPU is still busy with the backward.  Same arithmetic, same random
+        streams (the backward consumes no random numbers)."""
+        self.controller.train()
+        nxt, self._prefetched = getattr(self, '_prefetched', None), None
+        policies, op_probs, mag_probs, log_probs, entropies, host_policies = nxt if nxt is not None else self._sample_policies()
+        parsed = parse_policies(host_policies, self.config, logger)
         self.train_loader.dataset.transforms.transforms[0] = DGMultiPolicy(parsed)
+        early = {}
+        hook = None
+        if getattr(self.graphed, 'fused', False) and getattr(self.args, 'early_controller_update', True):
+            def hook(normalized):
+                early['losses'] = self.graphed.update(normalized, entropies)
+                self._prefetched = self._sample_policies()
         normalized_rewards = train(self.config, self.train_loader, self.model, self.discriminator, self.model_criterion,
                                    self.dis_criterion, self.model_optimizer, self.dis_optimizer, self.M, epoch,
-                                   writer_dict, logger, self.args, max_iters)
+                                   writer_dict, logger, self.args, max_iters, hook)
         _bare(self.discriminator).momentum_update()
-        losses = None
-        if self.graphed is not None:
+        losses = early.get('losses')
+        if losses is None and self.graphed is not None:
             try:
                 losses = self.graphed.update(normalized_rewards, entropies)
             except RuntimeError as e:

@@ -74,3 +74,45 @@ def test_baseline_config0_fixed_policy_vessel(hip, oracle):
     want_img, want_lbl = oracle.aug_units(imgs, msks, units, 256, 1)
     assert got_lbl.shape[1] == 1
     assert np.array_equal(got_img.cpu().numpy(), want_img) and np.array_equal(got_lbl.cpu().numpy(), want_lbl)
+
+
+def test_early_controller_update_is_the_same_search(hip, tmp_path, monkeypatch):
+    """Issuing the PPO update and the next epoch's sampling before the last backward pass (search_step) changes the schedule,
+    not the search.  With the training epoch replaced by a deterministic reward source (the real one carries run-to-run
+    last-bit noise from split-K atomics, which Adam amplifies) both orders give bit-identical controllers and trajectories."""
+    import random
+    import run
+    from aadg_amd import search_dg
+    from aadg_amd.config.defaults import _C
+
+    def fake_train(config, loader, model, disc, mc, dc, mo, do, M, epoch, wd, logger, args=None, max_iters=None, on_last_rewards=None):
+        g = torch.Generator(device="cpu").manual_seed(100 + epoch)
+        nr = hip.normalize_rewards(torch.randn(M, generator=g).cuda())
+        if on_last_rewards is not None:
+            on_last_rewards(nr)
+        return nr
+    monkeypatch.setattr(search_dg, "train", fake_train)
+    results = []
+    for early in (True, False):
+        orig = search_dg.SearchState.__init__
+
+        def init(self, *a, _orig=orig, _early=early, **k):
+            _orig(self, *a, **k)
+            self.args.early_controller_update = _early
+        monkeypatch.setattr(search_dg.SearchState, "__init__", init)
+        out = tmp_path / ("out_%d" % early)
+        args = ["--cfg", os.path.join(ROOT, "experiments", "optic_sinkhorn", "smoke.yaml"), "--output_dir", str(out),
+                "--crop_size", "64", "--epoch_items", "4", "--backbone_dtype", "fp32"]
+        _C.defrost()
+        _C.LOG_DIR = str(tmp_path / ("log_%d" % early))
+        for seed_fn in (random.seed, np.random.seed, torch.manual_seed):      # the driver itself seeds nothing (as the reference)
+            seed_fn(77)
+        run.main(args)
+        monkeypatch.setattr(search_dg.SearchState, "__init__", orig)
+        d = glob.glob(str(out / "optic" / "smoke_*"))[0]
+        results.append((torch.load(os.path.join(d, "final_controller_state.pth"), map_location="cpu"),
+                        np.load(os.path.join(d, "op_probs_trajectory.npy")), np.load(os.path.join(d, "mag_probs_trajectory.npy"))))
+    a, b = results
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    for k in a[0]:
+        assert torch.equal(a[0][k], b[0][k]), k
