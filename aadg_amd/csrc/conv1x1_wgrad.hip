@@ -127,10 +127,12 @@ int launch(const uint16_t* dY, const uint16_t* X, float* acc, int N, int Co, int
     const int tiles_m = (Co + BM - 1) / BM, tiles_n = (Ci + BN - 1) / BN, tiles = tiles_m * tiles_n;
     const int steps_total = N * (HW / WG_BK);
     int split = (target_wgs + tiles - 1) / tiles;
-    // >= 32 K-steps per workgroup: each one ends with BM x BN float atomics (the cost of several K-steps), which must not
-    // dominate when the reduction is short (small per-rank batches): 8 -> 32 is 1.15 -> 1.06 ms over the 16 backbone shapes at
-    // N = 18 and 4.66 -> 4.46 ms at N = 144
-    if (split > steps_total / 32) split = steps_total / 32;
+    // K-steps per workgroup: each workgroup ends with BM x BN float atomics (the cost of several K-steps), so 32 steps when the
+    // reduction is long enough to still fill the chip (N = 144: 4.66 -> 4.46 ms over the 16 backbone shapes against 8), fewer --
+    // down to 8 -- when that would leave CUs idle (the 32 x 32 layers at 18 images per rank have 288 steps in all)
+    int min_steps = 32;
+    while (min_steps > 8 && (long long)(steps_total / min_steps) * tiles < 256) min_steps /= 2;
+    if (split > steps_total / min_steps) split = steps_total / min_steps;
     if (split < 1) split = 1;
     if (split > 65535) split = 65535;
     const int steps_per_block = (steps_total + split - 1) / split;
@@ -165,7 +167,9 @@ extern "C" int aadg_conv1x1_wgrad_bf16(const void* dy, const void* x, float* dwe
     const uint16_t* b = (const uint16_t*)x;
     if (Co <= 64) return launch<1, 4, 2, 2>(a, b, dweight, N, Co, Ci, HW, 1024, st);
     if (Ci <= 64) return launch<4, 1, 2, 2>(a, b, dweight, N, Co, Ci, HW, 1024, st);
-    if (Co >= 256 && Ci >= 256 && (Co % 256) == 0 && (Ci % 256) == 0 && (long long)Co * Ci >= 512 * 512)
+    // the 256 x 256 tile needs a reduction long enough for ~one workgroup per CU at >= 32 steps each
+    const long long big_wgs = (long long)(Co / 256) * (Ci / 256) * ((long long)N * (HW / WG_BK) / 32);
+    if (Co >= 256 && Ci >= 256 && (Co % 256) == 0 && (Ci % 256) == 0 && (long long)Co * Ci >= 512 * 512 && big_wgs >= 192)
         return launch<2, 4, 4, 2>(a, b, dweight, N, Co, Ci, HW, 256, st);
     return launch<2, 2, 2, 2>(a, b, dweight, N, Co, Ci, HW, 1024, st);
 }
