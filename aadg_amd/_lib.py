@@ -152,7 +152,7 @@ def load():
     lib.aadg_controller_ppo_update_f32.argtypes = [_vp] * 3 + [_i] * 7 + [_f] + [_vp] * 3 + [_f, _i, _i, _f, _f, _f, _f, _vp, _vp, _sz, _vp]
     lib.aadg_embed_prologue_f32.restype = _i
     lib.aadg_embed_prologue_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp]
-    if lib.aadg_abi_version() != 1:
+    if lib.aadg_abi_version() != 2:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
     return lib
