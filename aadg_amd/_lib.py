@@ -37,6 +37,7 @@ EXPORTS = [
     "aadg_upsample_bilinear2d_backward_workspace_bytes", "aadg_upsample_bilinear2d_backward_strided",
     "aadg_bn_workspace_bytes", "aadg_bn_mask_bytes", "aadg_bn_forward", "aadg_bn_backward",
     "aadg_dwconv3x3_supported", "aadg_dwconv3x3_workspace_bytes", "aadg_dwconv3x3", "aadg_dwconv3x3_wgrad",
+    "aadg_conv1x1_nchw_supported", "aadg_conv1x1_nchw_bf16",
     "aadg_stem_conv7x7_supported", "aadg_stem_conv7x7_workspace_bytes", "aadg_stem_conv7x7_bf16", "aadg_stem_conv7x7_wgrad_bf16",
     "aadg_subsample2x2_supported", "aadg_subsample2x2", "aadg_subsample2x2_backward",
     "aadg_maxpool3x3s2_supported", "aadg_maxpool3x3s2_index_bytes", "aadg_maxpool3x3s2_forward", "aadg_maxpool3x3s2_backward",
@@ -116,6 +117,10 @@ def load():
     lib.aadg_dwconv3x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]
     lib.aadg_dwconv3x3_wgrad.restype = _i
     lib.aadg_dwconv3x3_wgrad.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]
+    lib.aadg_conv1x1_nchw_supported.restype = _i
+    lib.aadg_conv1x1_nchw_supported.argtypes = [_i, _i, _i]
+    lib.aadg_conv1x1_nchw_bf16.restype = _i
+    lib.aadg_conv1x1_nchw_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp]
     lib.aadg_stem_conv7x7_supported.restype = _i
     lib.aadg_stem_conv7x7_supported.argtypes = [_i, _i]
     lib.aadg_stem_conv7x7_workspace_bytes.restype = ctypes.c_size_t
@@ -724,6 +729,21 @@ def maxpool3x3s2(x):
 
 
 # ------------------------------------------------------------------------------------------------
+def conv1x1_nchw(a, x):
+    """out [N, M, H, W] = a [M, K] (bfloat16) applied to the channels of x [N, K, H, W] (bfloat16): the matrix-core kernel of
+    csrc/conv1x1_fwd.hip (LDS transpose reads: no layout change of the NCHW activations)."""
+    _require_cuda(a, x)
+    N, K, H, W = x.shape
+    M = a.shape[0]
+    if (a.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or a.dim() != 2 or a.shape[1] != K or
+            not load().aadg_conv1x1_nchw_supported(M, K, H * W)):
+        raise AadgError("conv1x1_nchw: unsupported shape / dtype / layout")
+    out = torch.empty((N, M, H, W), dtype=x.dtype, device=x.device)
+    _check(load().aadg_conv1x1_nchw_bf16(a.data_ptr(), x.data_ptr(), out.data_ptr(), N, M, K, H * W, _stream()), "aadg_conv1x1_nchw_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 class _StemConv7x7(torch.autograd.Function):
     """conv2d(bfloat16(x [N,3,H,W]), weight [64,3,7,7] float32 master, stride 2, padding 3) -> bfloat16 with the MFMA kernels of
     csrc/stem_conv.hip, forward and weight gradient.  x may still be float32 (the augmentation kernel's output): it is rounded
@@ -822,14 +842,27 @@ def conv1x1_wgrad(dy, x):
     return dw
 
 
+def _own_gemm_1x1(M, K, HW):
+    """Shapes (out channels M, reduction K) on which the matrix-core kernel of csrc/conv1x1_fwd.hip beats the library GEMM on
+    an MI355X (scripts/quick_time_conv1x1_own.py, N = 144): the bandwidth-bound ones -- few output channels, or a short
+    reduction -- plus the 1024 -> 256 / 304 -> 256 layers; the compute-bound late layers stay with hipBLASLt."""
+    if not load().aadg_conv1x1_nchw_supported(M, K, HW):
+        return False
+    return M <= 128 or (M <= 320 and (K <= 128 or K in (304, 1024)))
+
+
 class _Conv1x1(torch.autograd.Function):
-    """1x1 / stride-1 convolution without bias: forward and input gradient are the library GEMMs (NCHW, no transposes),
-    the weight gradient is the MFMA kernel of csrc/conv1x1_wgrad.hip.  `weight` is the float32 master copy."""
+    """1x1 / stride-1 convolution without bias on NCHW bfloat16 activations.  Forward and input gradient: the matrix-core
+    kernel of csrc/conv1x1_fwd.hip where it is the faster one (_own_gemm_1x1), else the library GEMMs; weight gradient: the
+    MFMA kernel of csrc/conv1x1_wgrad.hip.  `weight` is the float32 master copy."""
 
     @staticmethod
     def forward(ctx, x, weight):
         wq = weight.to(x.dtype)
         ctx.save_for_backward(x, wq)
+        Co, Ci = wq.shape[0], wq.shape[1]
+        if _own_gemm_1x1(Co, Ci, x.shape[2] * x.shape[3]):
+            return conv1x1_nchw(wq.view(Co, Ci), x)
         return torch.ops.aten.convolution(x, wq, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
 
     @staticmethod
@@ -838,8 +871,12 @@ class _Conv1x1(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
-                                                     [True, False, False])[0]
+            Co, Ci = wq.shape[0], wq.shape[1]
+            if _own_gemm_1x1(Ci, Co, dy.shape[2] * dy.shape[3]):
+                dx = conv1x1_nchw(wq.view(Co, Ci).t().contiguous(), dy)
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
         if ctx.needs_input_grad[1]:
             dw = conv1x1_wgrad(dy, x).view(wq.shape)
         return dx, dw

@@ -1,0 +1,168 @@
+// 1x1 / stride-1 convolution over NCHW bfloat16 activations as a per-image GEMM on the matrix cores:
+//
+//     OUT[n][m][p] = sum_k A[m][k] * IN[n][k][p]        (m: output channel, k: input channel, p: pixel, contiguous)
+//
+// forward: A = weight [Co][Ci];  input gradient: A = weight^T [Ci][Co] (a contiguous transposed copy made by the caller), IN = dY.
+// A is K-contiguous: plain 16-byte LDS fragments.  IN is K-STRIDED (NCHW: pixels are contiguous, channels are H*W apart) --
+// the layout a matrix-core B operand cannot take from row-major memory with ordinary reads.  gfx950's LDS transpose read
+// solves it without touching the data: rows of IN go to LDS exactly as they lie in memory ([k][p], 16-byte copies), and
+// ds_read_b64_tr_b16 hands every lane the 4 consecutive k of ITS pixel column (16 lanes read one 4 x 16 block; lane i passes
+// the address of row i / 4, columns 4 (i % 4) .. + 3 and receives column i) -- two of them make the 8-k B fragment of
+// v_mfma_f32_32x32x16_bf16.  No NHWC copy of the activations, no im2col, no transposing pass.
+//
+// Workgroup = 4 waves, tile BM x 256 pixels of one image, K-step 64 through a single LDS buffer with the next step's global
+// loads in flight (registers) during the MFMAs.  Epilogue: neighbouring lanes trade one register (DPP) and store pixel pairs.
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int CF_BK = 64, CF_BP = 256;
+constexpr int CF_APITCH = CF_BK + 8;            // A rows: 144 bytes (conflict-free 16-byte fragment reads)
+constexpr int CF_BPITCH = CF_BP + 16;           // B rows: 544 bytes = 32 (mod 256): the 4 rows of a transpose read hit distinct banks
+
+__device__ __forceinline__ u32x2 lds_read_tr16(const uint16_t* p) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
+    return v;
+}
+
+// WR x WC waves; wave tile (32 MI) x (32 NI); BM = 32 MI WR, BP = 32 NI WC = 256
+template <int WR, int WC, int MI, int NI>
+__global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restrict__ A, const uint16_t* __restrict__ IN,
+                                                      uint16_t* __restrict__ OUT, int M, int K, int HW, int tiles_p, int tiles_m) {
+    static_assert(WR * WC == 4 && 32 * NI * WC == CF_BP, "4 waves, 256 pixels");
+    constexpr int BM = 32 * MI * WR;
+    constexpr int LA = BM * 8 / 256, LB = CF_BK * (CF_BP / 8) / 256;       // 16-byte chunks per thread and K-step
+    __shared__ __attribute__((aligned(16))) uint16_t As[BM * CF_APITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[CF_BK * CF_BPITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv / WC, wc = wv - wr * WC;
+    // grid: pixel tile fastest, then output-channel tile, then image: the workgroups that share an IN tile are neighbours
+    const int tp = blockIdx.x % tiles_p, t2 = blockIdx.x / tiles_p;
+    const int tm = t2 % tiles_m, n = t2 / tiles_m;
+    const int m0 = tm * BM, p0 = tp * CF_BP;
+    const uint16_t* inn = IN + (size_t)n * K * HW;
+    uint16_t* outn = OUT + (size_t)n * M * HW;
+
+    uint4 ra[LA], rb[LB];
+#define CF_FETCH(k0_)                                                                                              \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                           \
+            const int id = tid + 256 * i, row = id >> 3, c = (id & 7) * 8;                                         \
+            const int m = m0 + row, k = (k0_) + c;                                                                 \
+            ra[i] = (m < M && k < K) ? *reinterpret_cast<const uint4*>(A + (size_t)m * K + k) : make_uint4(0, 0, 0, 0); \
+        }                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < LB; ++i) {                                                           \
+            const int id = tid + 256 * i, row = id >> 5, c = (id & 31) * 8;                                        \
+            const int k = (k0_) + row, p = p0 + c;                                                                 \
+            rb[i] = (k < K && p < HW) ? *reinterpret_cast<const uint4*>(inn + (size_t)k * HW + p) : make_uint4(0, 0, 0, 0); \
+        }                                                                                                          \
+    } while (0)
+
+    f32x16 d[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[mi][ni][r] = 0.0f;
+
+    const int g = lane >> 5, i16 = lane & 15, gi = (lane >> 4) & 1;
+    const uint16_t* a_base = As + (wr * 32 * MI + (lane & 31)) * CF_APITCH + 8 * g;
+    // transpose-read address of this lane: row (8 g + i16 / 4) of the K-sub-step, columns 16 gi + 4 (i16 % 4) of the N tile
+    const uint16_t* b_base = Bs + (8 * g + (i16 >> 2)) * CF_BPITCH + wc * 32 * NI + 16 * gi + 4 * (i16 & 3);
+
+    CF_FETCH(0);
+    for (int k0 = 0; k0 < K; k0 += CF_BK) {
+        __syncthreads();                                  // the previous step's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int id = tid + 256 * i;
+            *reinterpret_cast<uint4*>(As + (id >> 3) * CF_APITCH + (id & 7) * 8) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int id = tid + 256 * i;
+            *reinterpret_cast<uint4*>(Bs + (id >> 5) * CF_BPITCH + (id & 31) * 8) = rb[i];
+        }
+        __syncthreads();
+        if (k0 + CF_BK < K) CF_FETCH(k0 + CF_BK);         // in flight during the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < CF_BK / 16; ++ks) {
+            bf16x8 a[MI], b[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                a[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a_base + 32 * mi * CF_APITCH + 16 * ks));
+            u32x2 lo[NI], hi[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                lo[ni] = lds_read_tr16(b_base + (16 * ks) * CF_BPITCH + 32 * ni);
+                hi[ni] = lds_read_tr16(b_base + (16 * ks + 4) * CF_BPITCH + 32 * ni);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b[ni] = __builtin_bit_cast(bf16x8, make_uint4(lo[ni].x, lo[ni].y, hi[ni].x, hi[ni].y));
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], d[mi][ni], 0, 0, 0);
+        }
+    }
+#undef CF_FETCH
+    // C/D layout: column (pixel) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); lanes p / p + 1 trade
+    // registers r / r + 1 so that each stores two adjacent pixels of one channel row (4-byte stores)
+    const int jj = lane & 31;
+    const bool odd = jj & 1;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float mine0 = d[mi][ni][r], mine1 = d[mi][ni][r + 1];
+                const float give = odd ? mine0 : mine1;
+                const float got = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give), 0xB1, 0xF, 0xF, true));
+                const float lo = odd ? got : mine0, hi = odd ? mine1 : got;
+                const int rsel = r + (odd ? 1 : 0);
+                const int m = m0 + wr * 32 * MI + 32 * mi + (rsel & 3) + 8 * (rsel >> 2) + 4 * g;
+                const int p = p0 + wc * 32 * NI + 32 * ni + (jj & ~1);
+                if (m < M && p < HW) *reinterpret_cast<uint32_t*>(outn + (size_t)m * HW + p) = aadg_f2bf_pk(lo, hi);
+            }
+}
+
+template <int WR, int WC, int MI, int NI>
+int launch(const uint16_t* A, const uint16_t* IN, uint16_t* OUT, int N, int M, int K, int HW, hipStream_t st) {
+    constexpr int BM = 32 * MI * WR;
+    const int tiles_p = (HW + CF_BP - 1) / CF_BP, tiles_m = (M + BM - 1) / BM;
+    const long long wgs = (long long)N * tiles_p * tiles_m;
+    if (wgs > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
+    hipLaunchKernelGGL((k_conv1x1_nchw<WR, WC, MI, NI>), dim3((unsigned)wgs), dim3(256), 0, st, A, IN, OUT, M, K, HW, tiles_p, tiles_m);
+    AADG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int aadg_conv1x1_nchw_supported(int M, int K, int HW) {
+    return M > 0 && K > 0 && (K % 8) == 0 && HW >= 8 && (HW % 8) == 0 ? 1 : 0;      // 16-byte rows of A and IN
+}
+
+/* out [N, M, HW] = a [M, K] x in [N, K, HW] per image (all bfloat16, float32 accumulation): the forward of a 1x1 convolution
+ * (a = weight) or its input gradient (a = weight^T, in = dY) on NCHW tensors */
+extern "C" int aadg_conv1x1_nchw_bf16(const void* a, const void* in, void* out, int N, int M, int K, int HW, void* stream) {
+    if (a == nullptr || in == nullptr || out == nullptr || N <= 0) return AADG_E_BADARG;
+    if ((((uintptr_t)a | (uintptr_t)in | (uintptr_t)out) & 15u) != 0) return AADG_E_BADARG;
+    if (!aadg_conv1x1_nchw_supported(M, K, HW)) return AADG_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const uint16_t* pa = (const uint16_t*)a;
+    const uint16_t* pi = (const uint16_t*)in;
+    uint16_t* po = (uint16_t*)out;
+    if (M <= 64) return launch<1, 4, 2, 2>(pa, pi, po, N, M, K, HW, st);             // 64 x 256 tile
+    return launch<2, 2, 2, 4>(pa, pi, po, N, M, K, HW, st);                         // 128 x 256 tile
+}

@@ -223,6 +223,14 @@ int aadg_dwconv3x3_wgrad(const void* x, const void* dy, float* dweight, int N, i
                          int dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * 1x1 / stride-1 convolution on NCHW bfloat16 tensors as a per-image matrix-core GEMM (csrc/conv1x1_fwd.hip):
+ * out [N, M, HW] = a [M, K] x in [N, K, HW], float32 accumulation.  Forward of torch.nn.Conv2d(K, M, 1, bias=False): a = weight;
+ * its input gradient: a = weight^T (contiguous [Ci, Co]), in = dY.  K and HW multiples of 8.
+ * ------------------------------------------------------------------------------------------- */
+int aadg_conv1x1_nchw_supported(int M, int K, int HW);
+int aadg_conv1x1_nchw_bf16(const void* a, const void* in, void* out, int N, int M, int K, int HW, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The ResNet stem convolution, forward: y [N, 64, H/2, W/2] = conv2d(x [N, 3, H, W], weight [64, 3, 7, 7], stride 2, padding 3),
  * bfloat16 activations, float32 master weights (rounded to bfloat16 in the kernel, float32 accumulation) -- what
  * torch.nn.Conv2d(3, 64, 7, 2, 3, bias=False) computes under bfloat16 autocast (smp's ResNet encoder `conv1`).  MFMA implicit

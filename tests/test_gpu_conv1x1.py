@@ -42,8 +42,10 @@ def test_module_matches_conv2d_under_autocast(hip):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         yr = F.conv2d(xr, wr)
     yr.backward(g)
-    assert torch.equal(y, yr)
-    assert (x.grad.float() - xr.grad.float()).abs().max().item() <= 1e-6
+    # forward / input gradient may run on the matrix-core kernel (csrc/conv1x1_fwd.hip) instead of the library GEMM: same
+    # bfloat16 operands, float32 accumulation in a different order, one bfloat16 rounding of the result
+    assert (y.float() - yr.float()).abs().max().item() <= 2e-2 * max(1.0, yr.float().abs().max().item())
+    assert (x.grad.float() - xr.grad.float()).abs().max().item() <= 2e-2 * max(1.0, xr.grad.float().abs().max().item())
     assert m.weight.grad.dtype == torch.float32
     assert (m.weight.grad - wr.grad).abs().max().item() <= 2e-2 * wr.grad.abs().max().item()   # the reference rounds dW to bf16
     # float32 activations (no autocast) keep the library path
