@@ -37,6 +37,7 @@ EXPORTS = [
     "aadg_upsample_bilinear2d_backward_workspace_bytes", "aadg_upsample_bilinear2d_backward_strided",
     "aadg_bn_workspace_bytes", "aadg_bn_mask_bytes", "aadg_bn_forward", "aadg_bn_backward",
     "aadg_dwconv3x3_supported", "aadg_dwconv3x3_workspace_bytes", "aadg_dwconv3x3", "aadg_dwconv3x3_wgrad",
+    "aadg_bn_relu_maxpool_supported", "aadg_bn_relu_maxpool_forward",
     "aadg_conv1x1_nchw_supported", "aadg_conv1x1_nchw_bf16",
     "aadg_stem_conv7x7_supported", "aadg_stem_conv7x7_workspace_bytes", "aadg_stem_conv7x7_bf16", "aadg_stem_conv7x7_wgrad_bf16",
     "aadg_subsample2x2_supported", "aadg_subsample2x2", "aadg_subsample2x2_backward",
@@ -117,6 +118,10 @@ def load():
     lib.aadg_dwconv3x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]
     lib.aadg_dwconv3x3_wgrad.restype = _i
     lib.aadg_dwconv3x3_wgrad.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]
+    lib.aadg_bn_relu_maxpool_supported.restype = _i
+    lib.aadg_bn_relu_maxpool_supported.argtypes = [_i, _i, _i]
+    lib.aadg_bn_relu_maxpool_forward.restype = _i
+    lib.aadg_bn_relu_maxpool_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]
     lib.aadg_conv1x1_nchw_supported.restype = _i
     lib.aadg_conv1x1_nchw_supported.argtypes = [_i, _i, _i]
     lib.aadg_conv1x1_nchw_bf16.restype = _i
@@ -629,6 +634,60 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
                              None, None, ws.data_ptr(), ws.numel(), _stream())
     _check(rc, "aadg_bn_forward")
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+class _BNReluMaxPool(torch.autograd.Function):
+    """max_pool2d(relu(batch_norm(x)), 3, 2, 1), training mode, in one pass over x (csrc/batchnorm.hip k_bn_relu_maxpool): the
+    normalised map is never materialised.  Backward: the pooling gather (index + dy) then the ordinary BatchNorm backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        lib = load()
+        N, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, W // 2
+        y = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device)
+        idx = torch.empty(N * C * Ho * Wo, dtype=torch.uint8, device=x.device)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _bn_ws(C, x.device)
+        _check(lib.aadg_bn_relu_maxpool_forward(x.data_ptr(), y.data_ptr(), idx.data_ptr(), _ptr(weight), _ptr(bias), _ptr(running_mean),
+                                                _ptr(running_var), momentum, eps, N, C, H, W, _BN_DTYPES[x.dtype], mean.data_ptr(),
+                                                invstd.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "aadg_bn_relu_maxpool_forward")
+        ctx.save_for_backward(x, idx, weight, bias, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dyp):
+        lib = load()
+        x, idx, weight, bias, mean, invstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dyp = dyp.contiguous()
+        dy = torch.empty_like(x)
+        _check(lib.aadg_maxpool3x3s2_backward(idx.data_ptr(), dyp.data_ptr(), dy.data_ptr(), N * C, H, W, _BN_DTYPES[x.dtype], _stream()),
+               "aadg_maxpool3x3s2_backward")
+        dx = torch.empty_like(x)
+        dw = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _bn_ws(C, x.device)
+        _check(lib.aadg_bn_backward(x.data_ptr(), None, None, dy.data_ptr(), None, 0, None, _ptr(weight), _ptr(bias), mean.data_ptr(),
+                                    invstd.data_ptr(), ACT_RELU, dx.data_ptr(), None, dw.data_ptr(), db.data_ptr(), N, C, H * W,
+                                    _BN_DTYPES[x.dtype], ws.data_ptr(), ws.numel(), _stream()), "aadg_bn_backward")
+        return dx, dw if weight is not None else None, db if bias is not None else None, None, None, None, None
+
+
+def bn_relu_maxpool_supported(x):
+    return (x.is_cuda and x.dim() == 4 and x.dtype in _BN_DTYPES and x.is_contiguous() and x.data_ptr() % 16 == 0 and
+            (x.shape[2] * x.shape[3]) % (8 if x.dtype == torch.bfloat16 else 4) == 0 and
+            bool(load().aadg_bn_relu_maxpool_supported(x.shape[2], x.shape[3], _BN_DTYPES[x.dtype])))
+
+
+def bn_relu_maxpool(x, weight, bias, running_mean, running_var, momentum, eps):
+    """Training-mode max_pool2d(relu(batch_norm(x)), 3, 2, 1) on a contiguous NCHW float32 / bfloat16 GPU tensor."""
+    _require_cuda(x)
+    if not bn_relu_maxpool_supported(x):
+        raise AadgError("bn_relu_maxpool: unsupported shape / dtype / layout")
+    return _BNReluMaxPool.apply(x, weight, bias, running_mean, running_var, float(momentum), float(eps))
 
 
 # ------------------------------------------------------------------------------------------------

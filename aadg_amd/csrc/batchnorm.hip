@@ -495,6 +495,69 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
     return 0;
 }
 
+// ---- training BatchNorm + ReLU + MaxPool2d(3, 2, 1) in one pass (the ResNet stem) --------------------------------------
+// The normalised map (the largest activation of the network: 64 channels at half resolution) is never written: one lane =
+// 4 pooled outputs of one row, computed from 3 rows x 9 inputs that are normalised and rectified on the fly; the arg-max is
+// stored as its window position (one byte per output), exactly as aadg_maxpool3x3s2_forward does, so the pooling backward is
+// that kernel's.  A wave (256 outputs) lies inside one plane (Ho * Wo a multiple of 256), so bn_combine serves it.
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_relu_maxpool(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx,
+                                                         BnFin fin, int C, int H, int W, int Ho, int Wo) {
+    const int w4 = Wo / 4, per_plane = Ho * w4;
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;      // grid sized exactly: planes * per_plane is a multiple of 256
+    const long long plane = q / per_plane;
+    const int rem = (int)(q - plane * per_plane);
+    const int i = rem / w4, cg = rem - i * w4;
+    const int c = (int)(plane % C);
+    double s, sq;
+    bn_combine(fin.partial, c, fin.split, &s, &sq);
+    const double m = s / fin.count;
+    double var = sq / fin.count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)fin.eps));
+    float sc, sh;
+    bn_scale_shift_of(fin.weight, fin.bias, (float)m, is, c, &sc, &sh);
+    if (plane == c && rem == 0) {                            // image 0, first lane of the plane: the one writer of this channel
+        fin.save_mean[c] = (float)m;
+        fin.save_invstd[c] = is;
+        if (fin.running_mean != nullptr) {
+            const double unbiased = fin.count > 1.0 ? var * fin.count / (fin.count - 1.0) : var;
+            fin.running_mean[c] = (1.0f - fin.momentum) * fin.running_mean[c] + fin.momentum * (float)m;
+            fin.running_var[c] = (1.0f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unbiased;
+        }
+    }
+    const T* px = x + (size_t)plane * H * W;
+    float out[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    uint32_t at[4] = {4u, 4u, 4u, 4u};                       // the centre is always inside the image
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int r = 2 * i - 1 + a;
+        if (r < 0 || r >= H) continue;
+        const T* row = px + (size_t)r * W + 8 * cg;
+        float v[9];
+        Pack<T>::load(row, v + 1);                           // VEC = 8 for bfloat16; float32 takes the two-load path below
+        if (Pack<T>::N == 4) Pack<T>::load(row + 4, v + 5);
+        v[0] = cg > 0 ? Pack<T>::load1(row - 1) : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = fmaxf(Pack<T>::round(fmaf(v[k], sc, sh)), 0.0f);   // what BatchNorm + ReLU would have stored
+        if (cg == 0) v[0] = -INFINITY;                       // left padding never wins
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float e = v[2 * k + b];
+                if (e > out[k]) { out[k] = e; at[k] = 3 * a + b; }
+            }
+    }
+    const size_t o = (size_t)plane * Ho * Wo + (size_t)i * Wo + 4 * cg;
+    if (Pack<T>::N == 8) {
+        *reinterpret_cast<uint2*>(y + o) = make_uint2(aadg_f2bf_pk(out[0], out[1]), aadg_f2bf_pk(out[2], out[3]));
+    } else {
+        *reinterpret_cast<float4*>(y + o) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+    *reinterpret_cast<uint32_t*>(idx + o) = at[0] | (at[1] << 8) | (at[2] << 16) | (at[3] << 24);
+}
+
 }  // namespace
 
 extern "C" size_t aadg_bn_workspace_bytes(int C) { return C > 0 ? bn_ws(C).total * sizeof(float) : 0; }
@@ -549,4 +612,48 @@ extern "C" int aadg_bn_backward(const void* x, const void* y, const void* act_ma
                                            (const __hip_bfloat16*)dy, dy_extra, n_extra, dy_plane_const, weight, bias, save_mean, save_invstd, act,
                                            (__hip_bfloat16*)dx, (__hip_bfloat16*)dres, dweight, dbias, N, C, HW, (float*)ws, st);
     return AADG_E_BADARG;
+}
+
+extern "C" int aadg_bn_relu_maxpool_supported(int H, int W, int dtype) {
+    const int Ho = (H - 1) / 2 + 1, Wo = W / 2;
+    return (dtype == 0 || dtype == 1) && H >= 2 && W >= 8 && (W % 8) == 0 && ((long long)Ho * Wo) % 1024 == 0 ? 1 : 0;
+}
+
+/* y [N, C, Ho, Wo] = max_pool2d(relu(batch_norm(x [N, C, H, W], training)), 3, 2, 1) and the pooling index (one byte per output,
+ * as aadg_maxpool3x3s2_forward); save_mean / save_invstd / running statistics as aadg_bn_forward(training = 1).  Backward:
+ * aadg_maxpool3x3s2_backward(index, dy) followed by aadg_bn_backward(x, ..., act = AADG_ACT_RELU). */
+extern "C" int aadg_bn_relu_maxpool_forward(const void* x, void* y, void* index, const float* weight, const float* bias, float* running_mean,
+                                            float* running_var, float momentum, float eps, int N, int C, int H, int W, int dtype,
+                                            float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
+    if (x == nullptr || y == nullptr || index == nullptr || save_mean == nullptr || save_invstd == nullptr || ws == nullptr) return AADG_E_BADARG;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0 || (((uintptr_t)index) & 3u) != 0) return AADG_E_BADARG;
+    if (N <= 0 || C <= 0 || ws_bytes < aadg_bn_workspace_bytes(C)) return AADG_E_WORKSPACE;
+    if (!aadg_bn_relu_maxpool_supported(H, W, dtype)) return AADG_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    float* wsf = (float*)ws;
+    const BnWs L = bn_ws(C);
+    const int Ho = (H - 1) / 2 + 1, Wo = W / 2, HW = H * W;
+    const long long quads = (long long)N * C * Ho * (Wo / 4);
+    if (quads / 256 > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
+    Shape s;
+    if (dtype == 0) {
+        if (!make_shape<float>(N, C, HW, x, nullptr, nullptr, nullptr, &s) || s.vec == 1) return AADG_E_UNSUPPORTED;
+        hipLaunchKernelGGL((k_bn_reduce_fwd<float, 4>), dim3(s.split, C), dim3(s.threads), 0, st, (const float*)x, C, s.len, s.pc.per_strip,
+                           s.pc.plen, s.pc.total, wsf + L.partial);
+    } else {
+        if (!make_shape<__hip_bfloat16>(N, C, HW, x, nullptr, nullptr, nullptr, &s) || s.vec == 1) return AADG_E_UNSUPPORTED;
+        hipLaunchKernelGGL((k_bn_reduce_fwd<__hip_bfloat16, 8>), dim3(s.split, C), dim3(s.threads), 0, st, (const __hip_bfloat16*)x, C, s.len,
+                           s.pc.per_strip, s.pc.plen, s.pc.total, wsf + L.partial);
+    }
+    AADG_LAUNCH_CHECK();
+    const BnFin fin = {wsf + L.partial, s.split, (double)N * (double)HW, weight, bias, running_mean, running_var, momentum, eps, save_mean,
+                       save_invstd};
+    const dim3 grid((unsigned)(quads / 256));
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_bn_relu_maxpool<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, (uint8_t*)index, fin, C, H, W, Ho, Wo);
+    else
+        hipLaunchKernelGGL(k_bn_relu_maxpool<__hip_bfloat16>, grid, dim3(256), 0, st, (const __hip_bfloat16*)x, (__hip_bfloat16*)y,
+                           (uint8_t*)index, fin, C, H, W, Ho, Wo);
+    AADG_LAUNCH_CHECK();
+    return 0;
 }

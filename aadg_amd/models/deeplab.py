@@ -238,8 +238,23 @@ class ResNet50Encoder(nn.Module):
 
     deep_handles = 5     # consumers of the encoder output: four ASPP convolutions + the global average (image pool & pooled feature)
 
+    def _stem_pool(self, x):
+        """pool(relu(bn(conv(x)))); in training on the GPU BatchNorm + ReLU + pooling are one pass over the convolution's output
+        (the normalised 64-channel half-resolution map, the largest activation of the network, is never written)."""
+        conv, bna = self.stem[0], self.stem[1]
+        bn = bna.bn
+        y = conv(x)
+        if (y.is_cuda and bn.training and torch.is_grad_enabled() and type(bn) is nn.BatchNorm2d and bna.act == 'relu' and
+                bn.momentum is not None and bn.track_running_stats and type(self.pool) is MaxPool3x3s2):
+            from .. import _lib
+            yc = y.contiguous()
+            if _lib.bn_relu_maxpool_supported(yc):
+                bn.num_batches_tracked.add_(1)
+                return _lib.bn_relu_maxpool(yc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+        return self.pool(bna(y))
+
     def forward(self, x):
-        x = self.pool(self.stem(x))
+        x = self._stem_pool(x)
         s = _handles(self.layer1(x, out_handles=3), 3)            # layer2's conv1, layer2's downsample, the decoder skip
         x = self.layer2((s[0], s[1]), out_handles=2)
         x = self.layer3(x, out_handles=2)

@@ -207,6 +207,15 @@ int aadg_bn_backward(const void* x, const void* y, const void* act_mask, const v
                      const float* save_invstd, int act, void* dx, void* dres, float* dweight, float* dbias, int N,
                      int C, int HW, int dtype, void* ws, size_t ws_bytes, void* stream);
 
+/* Training BatchNorm + ReLU + MaxPool2d(3, 2, 1) in one pass (the ResNet stem after its convolution): the normalised map is
+ * never written.  y [N, C, Ho, Wo] and the pooling index (one byte per output, as aadg_maxpool3x3s2_forward); statistics as
+ * aadg_bn_forward(training = 1).  Backward = aadg_maxpool3x3s2_backward(index, dy) then aadg_bn_backward(x, ..., AADG_ACT_RELU).
+ * W a multiple of 8, Ho * Wo a multiple of 1024. */
+int aadg_bn_relu_maxpool_supported(int H, int W, int dtype);
+int aadg_bn_relu_maxpool_forward(const void* x, void* y, void* index, const float* weight, const float* bias, float* running_mean,
+                                 float* running_var, float momentum, float eps, int N, int C, int H, int W, int dtype,
+                                 float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Depthwise 3x3 convolution, stride 1, padding = dilation, no bias, NCHW planes (the atrous separable convolutions
  * of the DeepLabV3+ head: smp's SeparableConv2d / ASPPSeparableConv built at models/__init__.py:17-23).

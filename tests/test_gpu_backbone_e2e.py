@@ -12,7 +12,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 SWITCHES = ["bn_act_supported", "dwconv3x3_supported", "conv1x1_supported", "maxpool3x3s2_supported", "subsample2x2_supported",
-            "stem_conv7x7_supported"]
+            "stem_conv7x7_supported", "bn_relu_maxpool_supported"]
 
 
 def _run(model, state, x, y, autocast):
@@ -41,15 +41,15 @@ def test_hip_layers_match_library_layers_in_situ(hip, encoder, monkeypatch):
     y = (torch.rand(8, 2, 128, 128, device="cuda") > 0.5).float()
     state = {k: v.clone() for k, v in m.state_dict().items()}
 
-    used = {"bn": 0, "dw": 0, "c1": 0, "mp": 0}
-    real = {"bn": hip.batch_norm_act, "dw": hip.dwconv3x3, "c1": hip.conv1x1, "mp": hip.maxpool3x3s2}
+    used = {"bn": 0, "dw": 0, "c1": 0, "mp": 0, "bp": 0}
+    real = {"bn": hip.batch_norm_act, "dw": hip.dwconv3x3, "c1": hip.conv1x1, "mp": hip.maxpool3x3s2, "bp": hip.bn_relu_maxpool}
 
     def counted(key):
         def f(*a, **k):
             used[key] += 1
             return real[key](*a, **k)
         return f
-    for key, name in (("bn", "batch_norm_act"), ("dw", "dwconv3x3"), ("c1", "conv1x1"), ("mp", "maxpool3x3s2")):
+    for key, name in (("bn", "batch_norm_act"), ("dw", "dwconv3x3"), ("c1", "conv1x1"), ("mp", "maxpool3x3s2"), ("bp", "bn_relu_maxpool")):
         monkeypatch.setattr(hip, name, counted(key))
     ours32 = _run(m, state, x, y, False)
     ours16 = _run(m, state, x, y, True)
@@ -57,7 +57,7 @@ def test_hip_layers_match_library_layers_in_situ(hip, encoder, monkeypatch):
     # variant folds its three dilated depthwise passes into the pointwise weights: only the decoder's remain)
     assert used["bn"] > 60 and used["dw"] >= (8 if encoder == "mobilenet_v2" else 2) and used["c1"] > 5
     if encoder == "resnet50":
-        assert used["mp"] == 2
+        assert used["mp"] + used["bp"] == 2                  # the stem pool, on its own or fused with BatchNorm + ReLU
     # every HIP layer refused -> module fallbacks
     for name in SWITCHES:
         monkeypatch.setattr(hip, name, lambda *a, **k: False)

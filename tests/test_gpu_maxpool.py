@@ -39,3 +39,34 @@ def test_maxpool_unsupported_width(hip):
     assert not hip.maxpool3x3s2_supported(x)
     with pytest.raises(hip.AadgError):
         hip.maxpool3x3s2(x)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 4, 64, 64), (3, 2, 128, 32), (1, 3, 66, 64)])
+def test_bn_relu_maxpool_matches_the_three_layers(hip, dtype, shape):
+    """One pass (BatchNorm statistics -> normalise + ReLU + 3x3/2 pooling) vs batch_norm -> relu -> max_pool2d: same pooled map,
+    running statistics and gradients."""
+    torch.manual_seed(sum(shape))
+    N, C, H, W = shape
+    x = (torch.randn(shape, device="cuda") * 1.5 + 0.3).to(dtype)
+    if not hip.bn_relu_maxpool_supported(x):
+        pytest.skip("shape outside the fused kernel's domain")
+    w = (torch.rand(C, device="cuda") + 0.5).requires_grad_(True)
+    b = (torch.randn(C, device="cuda") * 0.3).requires_grad_(True)
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    x1 = x.clone().requires_grad_(True)
+    y = hip.bn_relu_maxpool(x1, w, b, rm, rv, 0.1, 1e-5)
+    g = torch.randn_like(y)
+    y.backward(g)
+    x2 = x.clone().requires_grad_(True)
+    w2, b2 = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    rm2, rv2 = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    t = hip.batch_norm_act(x2, w2, b2, rm2, rv2, True, 0.1, 1e-5, 1)           # the unfused kernels: same arithmetic
+    y2 = hip.maxpool3x3s2(t)
+    y2.backward(g)
+    assert torch.equal(y, y2)
+    assert torch.allclose(rm, rm2) and torch.allclose(rv, rv2)
+    lo = dtype == torch.bfloat16
+    assert (x1.grad.float() - x2.grad.float()).abs().max().item() <= (2e-2 if lo else 1e-5)
+    assert (w.grad - w2.grad).abs().max().item() <= (2e-2 if lo else 1e-4) * max(1.0, w2.grad.abs().max().item())
+    assert (b.grad - b2.grad).abs().max().item() <= (2e-2 if lo else 1e-4) * max(1.0, b2.grad.abs().max().item())
