@@ -37,7 +37,7 @@ EXPORTS = [
     "aadg_upsample_bilinear2d_backward_workspace_bytes", "aadg_upsample_bilinear2d_backward_strided",
     "aadg_bn_workspace_bytes", "aadg_bn_mask_bytes", "aadg_bn_forward", "aadg_bn_backward",
     "aadg_dwconv3x3_supported", "aadg_dwconv3x3_workspace_bytes", "aadg_dwconv3x3", "aadg_dwconv3x3_wgrad",
-    "aadg_bn_relu_maxpool_supported", "aadg_bn_relu_maxpool_forward",
+    "aadg_bn_relu_maxpool_supported", "aadg_bn_relu_maxpool_forward", "aadg_bn_relu_maxpool_backward",
     "aadg_conv1x1_nchw_supported", "aadg_conv1x1_nchw_bf16",
     "aadg_stem_conv7x7_supported", "aadg_stem_conv7x7_workspace_bytes", "aadg_stem_conv7x7_bf16", "aadg_stem_conv7x7_wgrad_bf16",
     "aadg_subsample2x2_supported", "aadg_subsample2x2", "aadg_subsample2x2_backward",
@@ -122,6 +122,8 @@ def load():
     lib.aadg_bn_relu_maxpool_supported.argtypes = [_i, _i, _i]
     lib.aadg_bn_relu_maxpool_forward.restype = _i
     lib.aadg_bn_relu_maxpool_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]
+    lib.aadg_bn_relu_maxpool_backward.restype = _i
+    lib.aadg_bn_relu_maxpool_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]
     lib.aadg_conv1x1_nchw_supported.restype = _i
     lib.aadg_conv1x1_nchw_supported.argtypes = [_i, _i, _i]
     lib.aadg_conv1x1_nchw_bf16.restype = _i
@@ -639,7 +641,8 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
 # ------------------------------------------------------------------------------------------------
 class _BNReluMaxPool(torch.autograd.Function):
     """max_pool2d(relu(batch_norm(x)), 3, 2, 1), training mode, in one pass over x (csrc/batchnorm.hip k_bn_relu_maxpool): the
-    normalised map is never materialised.  Backward: the pooling gather (index + dy) then the ordinary BatchNorm backward."""
+    normalised map is never materialised.  Backward (bfloat16): two passes over x that rebuild the pooling gradient from
+    (index, dy) on the fly; float32: the pooling gather followed by the ordinary BatchNorm backward."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
@@ -663,6 +666,16 @@ class _BNReluMaxPool(torch.autograd.Function):
         x, idx, weight, bias, mean, invstd = ctx.saved_tensors
         N, C, H, W = x.shape
         dyp = dyp.contiguous()
+        if x.dtype == torch.bfloat16:
+            # both BatchNorm backward passes rebuild the pooling gradient from (index, dyp): nothing activation-sized in between
+            dx = torch.empty_like(x)
+            dw = torch.empty(C, dtype=torch.float32, device=x.device)
+            db = torch.empty(C, dtype=torch.float32, device=x.device)
+            ws = _bn_ws(C, x.device)
+            _check(lib.aadg_bn_relu_maxpool_backward(x.data_ptr(), idx.data_ptr(), dyp.data_ptr(), _ptr(weight), _ptr(bias), mean.data_ptr(),
+                                                     invstd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), N, C, H, W, 1,
+                                                     ws.data_ptr(), ws.numel(), _stream()), "aadg_bn_relu_maxpool_backward")
+            return dx, dw if weight is not None else None, db if bias is not None else None, None, None, None, None
         dy = torch.empty_like(x)
         _check(lib.aadg_maxpool3x3s2_backward(idx.data_ptr(), dyp.data_ptr(), dy.data_ptr(), N * C, H, W, _BN_DTYPES[x.dtype], _stream()),
                "aadg_maxpool3x3s2_backward")

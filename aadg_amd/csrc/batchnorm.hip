@@ -558,6 +558,122 @@ __global__ __launch_bounds__(256) void k_bn_relu_maxpool(const T* __restrict__ x
     *reinterpret_cast<uint32_t*>(idx + o) = at[0] | (at[1] << 8) | (at[2] << 16) | (at[3] << 24);
 }
 
+// ---- backward of BatchNorm + ReLU + MaxPool2d(3, 2, 1) --------------------------------------------------------------------
+// The gradient of the normalised map is the pooling gather: input (r, c) receives dy of the <= 4 pooled outputs whose 3x3
+// window covers it and whose stored arg-max is its window position.  Instead of materialising that map (the size of the
+// stem activation) and reading it back twice, both BatchNorm backward passes rebuild their 8-column vector of it from the
+// pooled gradient and the one-byte index.  bfloat16, W a multiple of 8 (one vector = 8 columns of one row).
+__device__ __forceinline__ void pool_gather8(const uint8_t* __restrict__ idx, const __hip_bfloat16* __restrict__ dyp, int r, int cg,
+                                             int Ho, int Wo, float* acc) {
+    const int j0 = 4 * cg;
+    const bool has5 = j0 + 4 < Wo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int sft = 0; sft < 2; ++sft) {
+        const int i = (r + sft) >> 1;
+        const int a = r - 2 * i + 1;                         // window row of input row r in output row i
+        if ((sft == 1 && !(r & 1)) || i >= Ho) continue;
+        const size_t o = (size_t)i * Wo + j0;
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(idx + o);
+        const uint2 t = *reinterpret_cast<const uint2*>(dyp + o);
+        float gq[5] = {__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xFFFF0000u), __uint_as_float(t.y << 16),
+                       __uint_as_float(t.y & 0xFFFF0000u), 0.0f};
+        uint32_t p[5] = {w & 255u, (w >> 8) & 255u, (w >> 16) & 255u, w >> 24, 255u};
+        if (has5) { p[4] = idx[o + 4]; gq[4] = Pack<__hip_bfloat16>::load1(dyp + o + 4); }
+        const uint32_t base = 3u * (uint32_t)a;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = k >> 1;
+            if (p[j] == base + 1u + (uint32_t)(k & 1)) acc[k] += gq[j];
+            if ((k & 1) && p[j + 1] == base) acc[k] += gq[j + 1];
+        }
+    }
+    // the unfused path stores this sum as bfloat16 before BatchNorm reads it: same rounding
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = Pack<__hip_bfloat16>::round(acc[k]);
+}
+
+// grid (split, C), as k_bn_reduce_bwd with MK = 3 (ReLU mask recomputed from x)
+__global__ __launch_bounds__(256) void k_bn_pool_reduce_bwd(const __hip_bfloat16* __restrict__ x, const uint8_t* __restrict__ idx,
+                                                            const __hip_bfloat16* __restrict__ dyp, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ weight,
+                                                            const float* __restrict__ bias, int C, int H, int W, int Ho, int Wo, int len,
+                                                            int per_strip, int plen, int total, float* __restrict__ partial) {
+    const int c = blockIdx.y, S = gridDim.x, w8 = W / 8;
+    float s0 = 0.f, s1 = 0.f;
+    const float mu = mean[c], is = invstd[c];
+    float sc, sh;
+    bn_scale_shift_of(weight, bias, mu, is, c, &sc, &sh);
+    for (int p = blockIdx.x; p < total; p += S) {
+        const int n = p / per_strip, part = p - n * per_strip;
+        const size_t strip = (size_t)n * C + c;
+        const __hip_bfloat16* px = x + strip * (size_t)len * 8;
+        const uint8_t* pi = idx + strip * (size_t)Ho * Wo;
+        const __hip_bfloat16* pg = dyp + strip * (size_t)Ho * Wo;
+        const int j1 = min(len, (part + 1) * plen);
+#pragma unroll 2
+        for (int j = part * plen + threadIdx.x; j < j1; j += blockDim.x) {
+            float xv[8], gv[8];
+            Pack<__hip_bfloat16>::load(px + (size_t)j * 8, xv);
+            const int r = j / w8, cg = j - r * w8;
+            pool_gather8(pi, pg, r, cg, Ho, Wo, gv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool open = Pack<__hip_bfloat16>::round(fmaf(xv[i], sc, sh)) > 0.0f;
+                const float g = open ? gv[i] : 0.0f;
+                s0 += g;
+                s1 = fmaf(g, (xv[i] - mu) * is, s1);
+            }
+        }
+    }
+    const float2 rr = block_sum2(s0, s1);
+    if (threadIdx.x == 0) reinterpret_cast<float2*>(partial)[(size_t)c * BN_MAX_SPLIT + blockIdx.x] = rr;
+}
+
+// grid (N * C strips, pieces), as k_bn_dx with ACT = ReLU
+__global__ __launch_bounds__(256) void k_bn_pool_dx(const __hip_bfloat16* __restrict__ x, const uint8_t* __restrict__ idx,
+                                                    const __hip_bfloat16* __restrict__ dyp, __hip_bfloat16* __restrict__ dx,
+                                                    const float* __restrict__ partial, int split, double count,
+                                                    const float* __restrict__ weight, const float* __restrict__ bias,
+                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                    float* __restrict__ dweight, float* __restrict__ dbias, int C, int H, int W, int Ho,
+                                                    int Wo, int len, int plen) {
+    const int strip = blockIdx.x, c = strip % C, w8 = W / 8;
+    double sg, sgx;
+    bn_combine(partial, c, split, &sg, &sgx);
+    const float mu_f = mean[c], is_f = invstd[c];
+    const double wd = weight != nullptr ? (double)weight[c] : 1.0;
+    const double is = (double)is_f, mu = (double)mu_f;
+    const double ad = wd * is;
+    const double bd = -ad * is * sgx / count;
+    const float a = (float)ad, b = (float)bd, c0 = (float)(-ad * sg / count - bd * mu);
+    if (strip == c && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (dweight != nullptr) dweight[c] = (float)sgx;
+        if (dbias != nullptr) dbias[c] = (float)sg;
+    }
+    float sc, sh;
+    bn_scale_shift_of(weight, bias, mu_f, is_f, c, &sc, &sh);
+    const __hip_bfloat16* px = x + (size_t)strip * len * 8;
+    __hip_bfloat16* pdx = dx + (size_t)strip * len * 8;
+    const uint8_t* pi = idx + (size_t)strip * Ho * Wo;
+    const __hip_bfloat16* pg = dyp + (size_t)strip * Ho * Wo;
+    const int j1 = min(len, ((int)blockIdx.y + 1) * plen);
+#pragma unroll 2
+    for (int j = blockIdx.y * plen + threadIdx.x; j < j1; j += blockDim.x) {
+        float xv[8], gv[8];
+        Pack<__hip_bfloat16>::load(px + (size_t)j * 8, xv);
+        const int r = j / w8, cg = j - r * w8;
+        pool_gather8(pi, pg, r, cg, Ho, Wo, gv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float g = Pack<__hip_bfloat16>::round(fmaf(xv[i], sc, sh)) > 0.0f ? gv[i] : 0.0f;
+            xv[i] = fmaf(a, g, fmaf(b, xv[i], c0));
+        }
+        Pack<__hip_bfloat16>::store(pdx + (size_t)j * 8, xv);
+    }
+}
+
 }  // namespace
 
 extern "C" size_t aadg_bn_workspace_bytes(int C) { return C > 0 ? bn_ws(C).total * sizeof(float) : 0; }
@@ -654,6 +770,34 @@ extern "C" int aadg_bn_relu_maxpool_forward(const void* x, void* y, void* index,
     else
         hipLaunchKernelGGL(k_bn_relu_maxpool<__hip_bfloat16>, grid, dim3(256), 0, st, (const __hip_bfloat16*)x, (__hip_bfloat16*)y,
                            (uint8_t*)index, fin, C, H, W, Ho, Wo);
+    AADG_LAUNCH_CHECK();
+    return 0;
+}
+
+/* Backward of aadg_bn_relu_maxpool_forward (bfloat16 only): dx [N, C, H, W], dweight, dbias from x, the pooling index and the
+ * pooled gradient dy [N, C, Ho, Wo] -- the gradient of the normalised map is rebuilt on the fly in both passes, never stored. */
+extern "C" int aadg_bn_relu_maxpool_backward(const void* x, const void* index, const void* dy, const float* weight, const float* bias,
+                                             const float* save_mean, const float* save_invstd, void* dx, float* dweight, float* dbias,
+                                             int N, int C, int H, int W, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (x == nullptr || index == nullptr || dy == nullptr || save_mean == nullptr || save_invstd == nullptr || dx == nullptr || ws == nullptr)
+        return AADG_E_BADARG;
+    if ((((uintptr_t)x | (uintptr_t)dx) & 15u) != 0 || (((uintptr_t)index) & 3u) != 0 || (((uintptr_t)dy) & 7u) != 0) return AADG_E_BADARG;
+    if (N <= 0 || C <= 0 || ws_bytes < aadg_bn_workspace_bytes(C)) return AADG_E_WORKSPACE;
+    if (dtype != 1 || !aadg_bn_relu_maxpool_supported(H, W, dtype)) return AADG_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    float* wsf = (float*)ws;
+    const BnWs L = bn_ws(C);
+    const int Ho = (H - 1) / 2 + 1, Wo = W / 2, HW = H * W;
+    Shape s;
+    if (!make_shape<__hip_bfloat16>(N, C, HW, x, dx, nullptr, nullptr, &s) || s.vec == 1) return AADG_E_UNSUPPORTED;
+    const __hip_bfloat16* px = (const __hip_bfloat16*)x;
+    const __hip_bfloat16* pg = (const __hip_bfloat16*)dy;
+    hipLaunchKernelGGL(k_bn_pool_reduce_bwd, dim3(s.split, C), dim3(s.threads), 0, st, px, (const uint8_t*)index, pg, save_mean, save_invstd,
+                       weight, bias, C, H, W, Ho, Wo, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, wsf + L.partial);
+    AADG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_pool_dx, dim3(N * C, s.pc.per_strip), dim3(s.threads), 0, st, px, (const uint8_t*)index, pg, (__hip_bfloat16*)dx,
+                       (const float*)(wsf + L.partial), s.split, (double)N * (double)HW, weight, bias, save_mean, save_invstd, dweight,
+                       dbias, C, H, W, Ho, Wo, s.len, s.pc.plen);
     AADG_LAUNCH_CHECK();
     return 0;
 }

@@ -215,6 +215,11 @@ int aadg_bn_relu_maxpool_supported(int H, int W, int dtype);
 int aadg_bn_relu_maxpool_forward(const void* x, void* y, void* index, const float* weight, const float* bias, float* running_mean,
                                  float* running_var, float momentum, float eps, int N, int C, int H, int W, int dtype,
                                  float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, void* stream);
+/* its backward in two passes over x (bfloat16 only): the gradient of the normalised map is rebuilt from the pooled gradient dy
+ * [N, C, Ho, Wo] and the index inside both BatchNorm backward passes instead of being stored and read back */
+int aadg_bn_relu_maxpool_backward(const void* x, const void* index, const void* dy, const float* weight, const float* bias,
+                                  const float* save_mean, const float* save_invstd, void* dx, float* dweight, float* dbias, int N,
+                                  int C, int H, int W, int dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Depthwise 3x3 convolution, stride 1, padding = dilation, no bias, NCHW planes (the atrous separable convolutions

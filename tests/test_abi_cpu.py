@@ -104,6 +104,7 @@ def test_backbone_and_controller_entry_points_validate_arguments():
     # BatchNorm + ReLU + max-pool
     assert lib.aadg_bn_relu_maxpool_supported(256, 256, 1) == 1 and lib.aadg_bn_relu_maxpool_supported(16, 16, 1) == 0
     assert lib.aadg_bn_relu_maxpool_forward(z, z, z, z, z, z, z, 0.1, 1e-5, 1, 4, 64, 64, 1, z, z, z, 0, z) == -1
+    assert lib.aadg_bn_relu_maxpool_backward(z, z, z, z, z, z, z, z, z, z, 1, 4, 64, 64, 1, z, 0, z) == -1
     # 1x1 convolution forward / input gradient
     assert lib.aadg_conv1x1_nchw_supported(64, 256, 1024) == 1 and lib.aadg_conv1x1_nchw_supported(64, 12, 1024) == 0
     assert lib.aadg_conv1x1_nchw_bf16(z, z, z, 1, 8, 8, 64, z) == -1
