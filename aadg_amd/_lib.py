@@ -107,9 +107,9 @@ def load():
     lib.aadg_bn_forward.restype = _i
     lib.aadg_bn_mask_bytes.restype = _sz
     lib.aadg_bn_mask_bytes.argtypes = [_i, _i, _i, _i]
-    lib.aadg_bn_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]
+    lib.aadg_bn_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _c.c_longlong, _vp]
     lib.aadg_bn_backward.restype = _i
-    lib.aadg_bn_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]
+    lib.aadg_bn_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _c.c_longlong, _vp]
     lib.aadg_dwconv3x3_supported.restype = _i
     lib.aadg_dwconv3x3_supported.argtypes = [_i, _i, _i, _i]
     lib.aadg_dwconv3x3_workspace_bytes.restype = _sz
@@ -542,10 +542,12 @@ class _BatchNormAct(torch.autograd.Function):
     which the backward kernel sums while reading them instead of autograd running elementwise adds over the full activation."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, act, handles):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, act, handles, out=None):
         lib = load()
         N, C, H, W = x.shape
-        y = torch.empty_like(x)
+        # out: a channel slice of a concatenation buffer (concat_slices): the result is written there, image stride = the buffer's
+        y = torch.empty_like(x) if out is None else out
+        y_stride = 0 if out is None else out.stride(0)
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _bn_ws(C, x.device)
@@ -556,8 +558,10 @@ class _BatchNormAct(torch.autograd.Function):
                 mask = torch.empty(nb, dtype=torch.uint8, device=x.device)
         rc = lib.aadg_bn_forward(x.data_ptr(), _ptr(residual), y.data_ptr(), _ptr(mask), _ptr(weight), _ptr(bias),
                                  _ptr(running_mean), _ptr(running_var), momentum, eps, act, 1, N, C, H * W, _BN_DTYPES[x.dtype],
-                                 mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+                                 mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), y_stride, _stream())
         _check(rc, "aadg_bn_forward")
+        if out is not None:
+            ctx.mark_dirty(out)
         ctx.act = act
         ctx.has_res = residual is not None
         # the activation mask is re-derived from x (no residual), or taken from the bit mask the forward wrote (fused residual;
@@ -584,7 +588,13 @@ class _BatchNormAct(torch.autograd.Function):
                 for f in flat[1:]:
                     pconst = pconst + f[:, :, 0, 0].float()
                 pconst = pconst.contiguous()
-        grads = [g.contiguous() for g in grads]
+        # a single gradient that is a channel slice of a wider one (the backward of a concatenation) is read in place
+        dy_stride = 0
+        if len(grads) == 1 and not grads[0].is_contiguous() and tuple(grads[0].stride()[1:]) == (H * W, W, 1) and \
+                grads[0].stride(0) >= C * H * W and grads[0].stride(0) % 8 == 0 and grads[0].data_ptr() % 16 == 0:
+            dy_stride = grads[0].stride(0)
+        else:
+            grads = [g.contiguous() for g in grads]
         if not grads:
             grads = [torch.zeros_like(x)]
         if len(grads) > 1 and (not ctx.has_res or len(grads) > 1 + BN_MAX_EXTRA):
@@ -602,12 +612,47 @@ class _BatchNormAct(torch.autograd.Function):
         rc = lib.aadg_bn_backward(x.data_ptr(), _ptr(y), _ptr(mask), dy.data_ptr(), _ptr_array(extra) if extra else None, len(extra),
                                   _ptr(pconst), _ptr(weight), _ptr(bias), mean.data_ptr(), invstd.data_ptr(), ctx.act, dx.data_ptr(),
                                   _ptr(dres), dw.data_ptr(), db.data_ptr(), N, C, H * W, _BN_DTYPES[x.dtype], ws.data_ptr(),
-                                  ws.numel(), _stream())
+                                  ws.numel(), dy_stride, _stream())
         _check(rc, "aadg_bn_backward")
-        return (dx, dres, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None)
+        return (dx, dres, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None, None)
 
 
 BN_MAX_EXTRA = 6
+
+
+def concat_slices(N, channels, H, W, dtype, device):
+    """A contiguous [N, sum(channels), H, W] buffer and one tensor per part aliasing its channel slice.  The parts are plain
+    aliases of the buffer's storage (not autograd views of it): producers write into them (batch_norm_act(..., out=part)) and
+    concat_from_slices(buffer, parts) is then the concatenation without a copy."""
+    buf = torch.empty((N, sum(channels), H, W), dtype=dtype, device=device)
+    parts, off = [], 0
+    for c in channels:
+        parts.append(torch.empty(0, dtype=dtype, device=device).set_(buf.untyped_storage(), buf.storage_offset() + off * H * W,
+                                                                    (N, c, H, W), buf.stride()))
+        off += c
+    return buf, parts
+
+
+class _ConcatFromSlices(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        ctx.sizes = [p.shape[1] for p in parts]
+        return buf.detach().view(buf.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, o = [], 0
+        for c in ctx.sizes:
+            outs.append(g[:, o:o + c])
+            o += c
+        return (None,) + tuple(outs)
+
+
+def concat_from_slices(buf, parts):
+    """torch.cat(parts, 1) where every part already lives in its slice of `buf` (concat_slices): no copy forward, channel-slice
+    views of the gradient backward (the BatchNorm backward kernels read them in place)."""
+    return _ConcatFromSlices.apply(buf, *parts)
+
 
 
 def bn_act_supported(x, residual=None):
@@ -616,7 +661,7 @@ def bn_act_supported(x, residual=None):
 
 
 def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentum, eps, act=ACT_NONE, residual=None, dual=False,
-                   handles=None):
+                   handles=None, out=None):
     """act(F.batch_norm(x, ...) [+ residual]) on NCHW float32 / bfloat16 GPU tensors.  handles = k > 1 (training only; dual =
     True means k = 2) returns the output as a tuple of k tensors on one storage, one per consumer, see _BatchNormAct."""
     handles = int(handles) if handles else (2 if dual else 1)
@@ -624,7 +669,10 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
     if not bn_act_supported(x, residual):
         raise AadgError("batch_norm_act: expected contiguous NCHW float32/bfloat16 tensors")
     if training:
-        return _BatchNormAct.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), int(act), handles)
+        if out is not None and (handles != 1 or out.shape != x.shape or out.dtype != x.dtype or tuple(out.stride()[1:]) != tuple(x.stride()[1:]) or
+                                out.data_ptr() % 16 or out.stride(0) % 8):
+            raise AadgError("batch_norm_act: `out` must be a channel slice of a contiguous NCHW buffer of the same dtype")
+        return _BatchNormAct.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), int(act), handles, out)
     lib = load()
     N, C, H, W = x.shape
     if x.requires_grad or (residual is not None and residual.requires_grad):
@@ -633,7 +681,7 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
     ws = _bn_ws(C, x.device)
     rc = lib.aadg_bn_forward(x.data_ptr(), _ptr(residual), y.data_ptr(), None, _ptr(weight), _ptr(bias), running_mean.data_ptr(),
                              running_var.data_ptr(), 0.0, float(eps), int(act), 0, N, C, H * W, _BN_DTYPES[x.dtype],
-                             None, None, ws.data_ptr(), ws.numel(), _stream())
+                             None, None, ws.data_ptr(), ws.numel(), 0, _stream())
     _check(rc, "aadg_bn_forward")
     return y
 
@@ -685,7 +733,7 @@ class _BNReluMaxPool(torch.autograd.Function):
         ws = _bn_ws(C, x.device)
         _check(lib.aadg_bn_backward(x.data_ptr(), None, None, dy.data_ptr(), None, 0, None, _ptr(weight), _ptr(bias), mean.data_ptr(),
                                     invstd.data_ptr(), ACT_RELU, dx.data_ptr(), None, dw.data_ptr(), db.data_ptr(), N, C, H * W,
-                                    _BN_DTYPES[x.dtype], ws.data_ptr(), ws.numel(), _stream()), "aadg_bn_backward")
+                                    _BN_DTYPES[x.dtype], ws.data_ptr(), ws.numel(), 0, _stream()), "aadg_bn_backward")
         return dx, dw if weight is not None else None, db if bias is not None else None, None, None, None, None
 
 

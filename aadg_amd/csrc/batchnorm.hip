@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void k_bn_reduce_bwd(const T* __restrict__ x, 
                                                        BnExtra<T> more, const float* __restrict__ pconst, const uint8_t* __restrict__ mask,
                                                        T* __restrict__ dres, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ weight, const float* __restrict__ bias, int act,
-                                                       int C, int len, int per_strip, int plen, int total, float* __restrict__ partial) {
+                                                       int C, int len, int per_strip, int plen, int total, float* __restrict__ partial,
+                                                       long long dy_img_stride) {
     static_assert(MK == 2 || VEC > 1, "the specialised variants are vector-only");
     const int c = blockIdx.y, S = gridDim.x;
     const size_t strip_elems = (size_t)len * VEC;
@@ -208,14 +209,16 @@ __global__ __launch_bounds__(256) void k_bn_reduce_bwd(const T* __restrict__ x, 
         const size_t strip = (size_t)n * C + c;
         const size_t base = strip * strip_elems;
         const int j1 = min(len, (part + 1) * plen);
+        // dy may be a channel slice of a wider gradient (the backward of a concatenation): image stride given by the caller
+        const T* dyp = dy + (dy_img_stride > 0 ? (size_t)n * (size_t)dy_img_stride + (size_t)c * strip_elems : base);
         // a consumer whose gradient is constant over each plane (a global average pool) hands in one value per plane
         const float pc = pconst != nullptr ? pconst[strip] : 0.0f;
 #pragma unroll 4
         for (int j = part * plen + threadIdx.x; j < j1; j += blockDim.x) {
             const size_t off = base + (size_t)j * VEC;
             float xv[VEC], gv[VEC], yv[VEC];
-            if (VEC == 1) { xv[0] = Pack<T>::load1(x + off); gv[0] = Pack<T>::load1(dy + off); }
-            else { Pack<T>::load(x + off, xv); Pack<T>::load(dy + off, gv); }
+            if (VEC == 1) { xv[0] = Pack<T>::load1(x + off); gv[0] = Pack<T>::load1(dyp + j); }
+            else { Pack<T>::load(x + off, xv); Pack<T>::load(dyp + (size_t)j * VEC, gv); }
             uint32_t mbits = 0;
             if (MK == 1) mbits = mask[strip * len + j];
             if (MK == 2 && y != nullptr) {
@@ -282,7 +285,8 @@ struct BnFin {
 template <typename T, int VEC, int ACT, bool RES, bool MASK, bool FIN>
 __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                   uint8_t* __restrict__ mask, const float* __restrict__ scale,
-                                                  const float* __restrict__ shift, BnFin fin, int act_rt, int C, int len, int plen) {
+                                                  const float* __restrict__ shift, BnFin fin, int act_rt, int C, int len, int plen,
+                                                  long long y_img_stride) {
     static_assert(!MASK || VEC > 1, "one mask byte per 16-byte vector");
     const int act = ACT >= 0 ? ACT : act_rt;
     const int strip = blockIdx.x, c = strip % C;
@@ -308,6 +312,8 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const
         sc = scale[c]; sh = shift[c];
     }
     const size_t base = (size_t)strip * len * VEC;
+    // y may be a channel slice of a wider tensor (written straight into a concatenation buffer): image stride given by the caller
+    T* yp = y + (y_img_stride > 0 ? (size_t)(strip / C) * (size_t)y_img_stride + (size_t)c * len * VEC : base);
     const int j1 = min(len, ((int)blockIdx.y + 1) * plen);
 #pragma unroll 4
     for (int j = blockIdx.y * plen + threadIdx.x; j < j1; j += blockDim.x) {
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const
             for (int i = 0; i < VEC; ++i) bits |= act_open(Pack<T>::round(v[i]), act) ? (1u << i) : 0u;
             mask[(size_t)strip * len + j] = (uint8_t)bits;
         }
-        if (VEC == 1) Pack<T>::store1(y + off, v[0]); else Pack<T>::store(y + off, v);
+        if (VEC == 1) Pack<T>::store1(yp + j, v[0]); else Pack<T>::store(yp + (size_t)j * VEC, v);
     }
 }
 
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(256) void k_bn_dx(const T* __restrict__ x, const T*
                                                const float* __restrict__ weight, const float* __restrict__ bias,
                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                float* __restrict__ dweight, float* __restrict__ dbias, int act_rt, int C, int len,
-                                               int plen) {
+                                               int plen, long long dy_img_stride) {
     const int act = ACT >= 0 ? ACT : act_rt;
     const int strip = blockIdx.x, c = strip % C;
     double sg, sgx;
@@ -360,13 +366,14 @@ __global__ __launch_bounds__(256) void k_bn_dx(const T* __restrict__ x, const T*
     float sc = 0.f, sh = 0.f;
     if (ACT != 0) bn_scale_shift_of(weight, bias, mu_f, is_f, c, &sc, &sh);
     const size_t base = (size_t)strip * len * VEC;
+    const T* dyp = dy + (dy_img_stride > 0 ? (size_t)(strip / C) * (size_t)dy_img_stride + (size_t)c * len * VEC : base);
     const int j1 = min(len, ((int)blockIdx.y + 1) * plen);
 #pragma unroll 4
     for (int j = blockIdx.y * plen + threadIdx.x; j < j1; j += blockDim.x) {
         const size_t off = base + (size_t)j * VEC;
         float xv[VEC], gv[VEC];
-        if (VEC == 1) { xv[0] = Pack<T>::load1(x + off); gv[0] = Pack<T>::load1(dy + off); }
-        else { Pack<T>::load(x + off, xv); Pack<T>::load(dy + off, gv); }
+        if (VEC == 1) { xv[0] = Pack<T>::load1(x + off); gv[0] = Pack<T>::load1(dyp + j); }
+        else { Pack<T>::load(x + off, xv); Pack<T>::load(dyp + (size_t)j * VEC, gv); }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float g = gv[i];
@@ -399,9 +406,10 @@ inline bool make_shape(int N, int C, int HW, const void* a, const void* b, const
 template <typename T>
 int bn_forward(const T* x, const T* res, T* y, uint8_t* mask, const float* weight, const float* bias, float* rmean, float* rvar, float momentum,
                float eps, int act, int training, int N, int C, int HW, float* save_mean, float* save_invstd, float* ws,
-               hipStream_t st) {
+               long long y_img_stride, hipStream_t st) {
     Shape s;
     if (!make_shape<T>(N, C, HW, x, res, y, nullptr, &s)) return AADG_E_BADARG;
+    if (y_img_stride != 0 && (y_img_stride < (long long)C * HW || (s.vec > 1 && (y_img_stride % s.vec) != 0))) return AADG_E_BADARG;
     if (mask != nullptr && s.vec == 1) return AADG_E_BADARG;        // the bit mask exists for the vector path only (aadg_bn_mask_bytes)
     const BnWs L = bn_ws(C);
     float* scale = ws + L.scale;
@@ -422,7 +430,7 @@ int bn_forward(const T* x, const T* res, T* y, uint8_t* mask, const float* weigh
     const dim3 grid(N * C, s.pc.per_strip);
     const BnFin fin = {ws + L.partial, s.split, (double)N * (double)HW, weight, bias, rmean, rvar, momentum, eps, save_mean, save_invstd};
 #define AADG_BN_APPLY(VEC_, ACT_, RES_, MASK_, FIN_) \
-    hipLaunchKernelGGL((k_bn_apply<T, VEC_, ACT_, RES_, MASK_, FIN_>), grid, blk, 0, st, x, res, y, mask, (const float*)scale, (const float*)shift, fin, act, C, s.len, s.pc.plen)
+    hipLaunchKernelGGL((k_bn_apply<T, VEC_, ACT_, RES_, MASK_, FIN_>), grid, blk, 0, st, x, res, y, mask, (const float*)scale, (const float*)shift, fin, act, C, s.len, s.pc.plen, y_img_stride)
 #define AADG_BN_APPLY_ACT(ACT_)                                                          \
     do {                                                                                 \
         if (!training) { if (res != nullptr) AADG_BN_APPLY(Pack<T>::N, ACT_, true, false, false); else AADG_BN_APPLY(Pack<T>::N, ACT_, false, false, false); } \
@@ -443,9 +451,11 @@ int bn_forward(const T* x, const T* res, T* y, uint8_t* mask, const float* weigh
 
 template <typename T>
 int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const void* const* dy_extra, int n_extra, const float* pconst, const float* weight, const float* bias, const float* mean, const float* invstd,
-                int act, T* dx, T* dres, float* dweight, float* dbias, int N, int C, int HW, float* ws, hipStream_t st) {
+                int act, T* dx, T* dres, float* dweight, float* dbias, int N, int C, int HW, float* ws, long long dy_img_stride,
+                hipStream_t st) {
     Shape s;
     if (!make_shape<T>(N, C, HW, x, y, dy, dx, &s) || (((uintptr_t)dres & 15u) && s.vec > 1)) return AADG_E_BADARG;
+    if (dy_img_stride != 0 && (dy_img_stride < (long long)C * HW || (s.vec > 1 && (dy_img_stride % s.vec) != 0))) return AADG_E_BADARG;
     if (mask != nullptr && s.vec == 1) return AADG_E_BADARG;
     const BnWs L = bn_ws(C);
     const dim3 blk(s.threads);
@@ -459,7 +469,7 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
         const dim3 grid(s.split, C);
 #define AADG_BN_REDUCE_BWD(VEC_, MK_, NE_, DRES_)                                                                                        \
     hipLaunchKernelGGL((k_bn_reduce_bwd<T, VEC_, MK_, NE_, DRES_>), grid, blk, 0, st, x, y, dy, more, pconst, mask, dres, mean, invstd,  \
-                       weight, bias, act, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial)
+                       weight, bias, act, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial, dy_img_stride)
 #define AADG_BN_REDUCE_BWD_MK(MK_)                                                                     \
     do {                                                                                               \
         if (n_extra == 0) { if (dres != nullptr) AADG_BN_REDUCE_BWD(Pack<T>::N, MK_, 0, 1); else AADG_BN_REDUCE_BWD(Pack<T>::N, MK_, 0, 0); } \
@@ -484,7 +494,7 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
         const int act_dx = g_ready ? AADG_ACT_NONE : act;
 #define AADG_BN_DX(VEC_, ACT_)                                                                                                  \
     hipLaunchKernelGGL((k_bn_dx<T, VEC_, ACT_>), grid, blk, 0, st, x, g, dx, (const float*)(ws + L.partial), s.split,              \
-                       (double)N * (double)HW, weight, bias, mean, invstd, dweight, dbias, act_dx, C, s.len, s.pc.plen)
+                       (double)N * (double)HW, weight, bias, mean, invstd, dweight, dbias, act_dx, C, s.len, s.pc.plen, g_ready ? 0LL : dy_img_stride)
         if (s.vec == 1) AADG_BN_DX(1, -1);
         else if (act_dx == AADG_ACT_RELU) AADG_BN_DX(Pack<T>::N, AADG_ACT_RELU);
         else if (act_dx == AADG_ACT_RELU6) AADG_BN_DX(Pack<T>::N, AADG_ACT_RELU6);
@@ -689,28 +699,28 @@ extern "C" size_t aadg_bn_mask_bytes(int N, int C, int HW, int dtype) {
 extern "C" int aadg_bn_forward(const void* x, const void* residual, void* y, void* act_mask, const float* weight, const float* bias,
                                float* running_mean, float* running_var, float momentum, float eps, int act, int training, int N,
                                int C, int HW, int dtype, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
-                               void* stream) {
-    if (x == nullptr || y == nullptr || ws == nullptr || act < 0 || act > AADG_ACT_RELU6) return AADG_E_BADARG;
+                               long long y_image_stride, void* stream) {
+    if (x == nullptr || y == nullptr || ws == nullptr || act < 0 || act > AADG_ACT_RELU6 || y_image_stride < 0) return AADG_E_BADARG;
     if (training && (save_mean == nullptr || save_invstd == nullptr)) return AADG_E_BADARG;
     if (!training && (running_mean == nullptr || running_var == nullptr)) return AADG_E_BADARG;
     if (C <= 0 || ws_bytes < aadg_bn_workspace_bytes(C)) return AADG_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
         return bn_forward<float>((const float*)x, (const float*)residual, (float*)y, (uint8_t*)act_mask, weight, bias, running_mean,
-                                 running_var, momentum, eps, act, training, N, C, HW, save_mean, save_invstd, (float*)ws, st);
+                                 running_var, momentum, eps, act, training, N, C, HW, save_mean, save_invstd, (float*)ws, y_image_stride, st);
     if (dtype == 1)
         return bn_forward<__hip_bfloat16>((const __hip_bfloat16*)x, (const __hip_bfloat16*)residual, (__hip_bfloat16*)y,
                                           (uint8_t*)act_mask, weight, bias, running_mean, running_var, momentum, eps, act, training,
-                                          N, C, HW, save_mean, save_invstd, (float*)ws, st);
+                                          N, C, HW, save_mean, save_invstd, (float*)ws, y_image_stride, st);
     return AADG_E_BADARG;
 }
 
 extern "C" int aadg_bn_backward(const void* x, const void* y, const void* act_mask, const void* dy, const void* const* dy_extra,
                                 int n_extra, const float* dy_plane_const, const float* weight, const float* bias, const float* save_mean,
                                 const float* save_invstd, int act, void* dx, void* dres, float* dweight, float* dbias, int N, int C,
-                                int HW, int dtype, void* ws, size_t ws_bytes, void* stream) {
+                                int HW, int dtype, void* ws, size_t ws_bytes, long long dy_image_stride, void* stream) {
     if (x == nullptr || dy == nullptr || dx == nullptr || save_mean == nullptr || save_invstd == nullptr || ws == nullptr ||
-        act < 0 || act > AADG_ACT_RELU6)
+        act < 0 || act > AADG_ACT_RELU6 || dy_image_stride < 0)
         return AADG_E_BADARG;
     // a fused residual needs the forward's activation mask: the bit mask it wrote, or the stored output
     if (dres != nullptr && y == nullptr && act_mask == nullptr) return AADG_E_BADARG;
@@ -722,11 +732,11 @@ extern "C" int aadg_bn_backward(const void* x, const void* y, const void* act_ma
     if (dtype == 0)
         return bn_backward<float>((const float*)x, (const float*)y, (const uint8_t*)act_mask, (const float*)dy, dy_extra, n_extra,
                                   dy_plane_const, weight, bias, save_mean, save_invstd, act, (float*)dx, (float*)dres, dweight, dbias, N, C, HW,
-                                  (float*)ws, st);
+                                  (float*)ws, dy_image_stride, st);
     if (dtype == 1)
         return bn_backward<__hip_bfloat16>((const __hip_bfloat16*)x, (const __hip_bfloat16*)y, (const uint8_t*)act_mask,
                                            (const __hip_bfloat16*)dy, dy_extra, n_extra, dy_plane_const, weight, bias, save_mean, save_invstd, act,
-                                           (__hip_bfloat16*)dx, (__hip_bfloat16*)dres, dweight, dbias, N, C, HW, (float*)ws, st);
+                                           (__hip_bfloat16*)dx, (__hip_bfloat16*)dres, dweight, dbias, N, C, HW, (float*)ws, dy_image_stride, st);
     return AADG_E_BADARG;
 }
 

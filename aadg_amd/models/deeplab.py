@@ -28,7 +28,7 @@ def _upsample_ac(x, size):
 _ACT_CODE = {None: 0, 'relu': 1, 'relu6': 2}
 
 
-def bn_act(bn, x, act=None, residual=None, handles=1):
+def bn_act(bn, x, act=None, residual=None, handles=1, out=None):
     """act(bn(x) [+ residual]).  On the GPU a plain `nn.BatchNorm2d` runs as the fused HIP streaming kernels
     (csrc/batchnorm.hip: statistics, normalise + activation + residual add in one pass, two-pass backward); anything
     else (SyncBatchNorm after `--sync_bn`, CPU shape tests) takes the module's own path."""
@@ -39,16 +39,18 @@ def bn_act(bn, x, act=None, residual=None, handles=1):
         if _lib.bn_act_supported(xc, rc):
             if bn.training:
                 bn.num_batches_tracked.add_(1)
+            # out (training only): a slice of a concatenation buffer (_lib.concat_slices) that receives the result
             return _lib.batch_norm_act(xc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum,
                                        bn.eps, _ACT_CODE[act], rc,
-                                       handles=handles if (bn.training and torch.is_grad_enabled() and rc is not None) else 1)
+                                       handles=handles if (bn.training and torch.is_grad_enabled() and rc is not None) else 1,
+                                       out=out if bn.training else None)
     y = bn(x)
     if residual is not None:
         y = y + residual
     if act == 'relu':
-        return F.relu(y)
-    if act == 'relu6':
-        return F.relu6(y)
+        y = F.relu(y)
+    elif act == 'relu6':
+        y = F.relu6(y)
     return y
 
 
@@ -344,8 +346,12 @@ class ASPP(nn.Module):
         discriminator): the image-pool branch then starts from it instead of reducing the encoder output a second time."""
         nb = len(self.branches)
         h = _handles(x, nb if pooled is not None else nb + 1)      # one handle of the encoder output per consumer
-        outs = [b(hx) for b, hx in zip(self.branches, h)]
         ref = h[0]
+        fused = self._forward_into_concat(h, pooled) if (pooled is not None and self.training and torch.is_grad_enabled() and
+                                                         ref.is_cuda and ref.dtype == torch.bfloat16) else None
+        if fused is not None:
+            return self.project(fused)
+        outs = [b(hx) for b, hx in zip(self.branches, h)]
         if pooled is None:
             ip = self.image_pool(h[-1])
         else:
@@ -355,6 +361,33 @@ class ASPP(nn.Module):
         # bilinear up-sampling of a 1x1 map is a broadcast (ATen's kernel would walk all N*C planes in one workgroup)
         outs.append(ip.expand(-1, -1, ref.shape[-2], ref.shape[-1]))
         return self.project(torch.cat(outs, dim=1))
+
+
+    def _forward_into_concat(self, h, pooled):
+        """The five branch outputs written straight into their channel slices of the concatenation buffer by the BatchNorm
+        kernels (no torch.cat copy; the gradient slices are read in place by the BatchNorm backward).  None when a branch is
+        not the plain (convolution, BNAct) pair on a supported layout."""
+        from .. import _lib
+        ref = h[0]
+        N, _, H, W = ref.shape
+        cout = self.project[0].in_channels // (len(self.branches) + 1)
+        for b in self.branches:
+            if len(b) != 2 or type(b[1]) is not BNAct or type(b[1].bn) is not nn.BatchNorm2d or b[1].bn.num_features != cout:
+                return None
+        if (H * W) % 8 != 0:
+            return None
+        buf, parts = _lib.concat_slices(N, [cout] * (len(self.branches) + 1), H, W, ref.dtype, ref.device)
+        outs = []
+        for b, hx, part in zip(self.branches, h, parts):
+            y = b[0](hx)
+            if not (y.is_cuda and y.dtype == ref.dtype and _lib.bn_act_supported(y.contiguous())):
+                return None
+            outs.append(bn_act(b[1].bn, y, b[1].act, out=part))
+        ip = pooled.to(ref.dtype)[:, :, None, None]
+        for mod in list(self.image_pool)[1:]:                      # [0] is the pooling itself
+            ip = mod(ip)
+        outs.append(parts[-1].copy_(ip.expand(-1, -1, H, W)))      # bilinear up-sampling of a 1x1 map = broadcast
+        return _lib.concat_from_slices(buf, outs)
 
 
 class DeepLabV3Plus(nn.Module):

@@ -196,16 +196,18 @@ size_t aadg_bn_workspace_bytes(int C);
 /* bytes of the optional activation bit mask (one byte per 16-byte vector; 0 = not available for this shape): a forward with
  * a fused residual may write it (act_mask != NULL) so that the backward reads 1 byte instead of a 16-byte vector of y */
 size_t aadg_bn_mask_bytes(int N, int C, int HW, int dtype);
+/* y_image_stride / dy_image_stride (elements, 0 = dense): plane (n, c) of y / dy starts at n * stride + c * HW -- the output may be
+ * written straight into a channel slice of a concatenation buffer, and the gradient read from a slice of that buffer's gradient */
 int aadg_bn_forward(const void* x, const void* residual, void* y, void* act_mask, const float* weight, const float* bias,
                     float* running_mean, float* running_var, float momentum, float eps, int act, int training,
                     int N, int C, int HW, int dtype, float* save_mean, float* save_invstd, void* ws,
-                    size_t ws_bytes, void* stream);
+                    size_t ws_bytes, long long y_image_stride, void* stream);
 /* dy_plane_const (optional, needs dres): [N*C] float32, a further gradient that is constant over each plane -- what a global
  * average pool of the output sends back -- added to dy without materialising it */
 int aadg_bn_backward(const void* x, const void* y, const void* act_mask, const void* dy, const void* const* dy_extra,
                      int n_extra, const float* dy_plane_const, const float* weight, const float* bias, const float* save_mean,
                      const float* save_invstd, int act, void* dx, void* dres, float* dweight, float* dbias, int N,
-                     int C, int HW, int dtype, void* ws, size_t ws_bytes, void* stream);
+                     int C, int HW, int dtype, void* ws, size_t ws_bytes, long long dy_image_stride, void* stream);
 
 /* Training BatchNorm + ReLU + MaxPool2d(3, 2, 1) in one pass (the ResNet stem after its convolution): the normalised map is
  * never written.  y [N, C, Ho, Wo] and the pooling index (one byte per output, as aadg_maxpool3x3s2_forward); statistics as

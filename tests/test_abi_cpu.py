@@ -83,14 +83,14 @@ def test_backbone_and_controller_entry_points_validate_arguments():
     f = ctypes.c_float
     # BatchNorm
     assert lib.aadg_bn_workspace_bytes(64) > 0 and lib.aadg_bn_workspace_bytes(0) == 0
-    assert lib.aadg_bn_forward(z, z, z, z, z, z, z, z, f(0.1), f(1e-5), 1, 1, 2, 4, 16, 0, z, z, z, 0, z) == -1
-    assert lib.aadg_bn_forward(one, z, one, z, z, z, z, z, f(0.1), f(1e-5), 7, 1, 2, 4, 16, 0, one, one, one, 1 << 20, z) == -1   # act
-    assert lib.aadg_bn_forward(one, z, one, z, z, z, z, z, f(0.1), f(1e-5), 1, 1, 2, 4, 16, 0, one, one, one, 8, z) == -2        # workspace
+    assert lib.aadg_bn_forward(z, z, z, z, z, z, z, z, f(0.1), f(1e-5), 1, 1, 2, 4, 16, 0, z, z, z, 0, 0, z) == -1
+    assert lib.aadg_bn_forward(one, z, one, z, z, z, z, z, f(0.1), f(1e-5), 7, 1, 2, 4, 16, 0, one, one, one, 1 << 20, 0, z) == -1   # act
+    assert lib.aadg_bn_forward(one, z, one, z, z, z, z, z, f(0.1), f(1e-5), 1, 1, 2, 4, 16, 0, one, one, one, 8, 0, z) == -2        # workspace
     assert lib.aadg_bn_mask_bytes(2, 4, 16, 1) == 2 * 4 * 2 and lib.aadg_bn_mask_bytes(2, 4, 12, 1) == 0
-    assert lib.aadg_bn_backward(one, z, z, one, z, 0, z, z, z, one, one, 1, one, one, z, z, 2, 4, 16, 0, one, 1 << 20, z) == -1   # dres without y / mask
-    assert lib.aadg_bn_backward(one, one, z, one, z, 2, z, z, z, one, one, 1, one, one, z, z, 2, 4, 16, 0, one, 1 << 20, z) == -1  # n_extra without pointers
-    assert lib.aadg_bn_backward(one, one, z, one, one, 9, z, z, z, one, one, 1, one, one, z, z, 2, 4, 16, 0, one, 1 << 20, z) == -1  # more than 6 extra gradients
-    assert lib.aadg_bn_backward(one, z, z, one, z, 0, one, z, z, one, one, 1, one, z, z, z, 2, 4, 16, 0, one, 1 << 20, z) == -1   # plane constants without dres
+    assert lib.aadg_bn_backward(one, z, z, one, z, 0, z, z, z, one, one, 1, one, one, z, z, 2, 4, 16, 0, one, 1 << 20, 0, z) == -1   # dres without y / mask
+    assert lib.aadg_bn_backward(one, one, z, one, z, 2, z, z, z, one, one, 1, one, one, z, z, 2, 4, 16, 0, one, 1 << 20, 0, z) == -1  # n_extra without pointers
+    assert lib.aadg_bn_backward(one, one, z, one, one, 9, z, z, z, one, one, 1, one, one, z, z, 2, 4, 16, 0, one, 1 << 20, 0, z) == -1  # more than 6 extra gradients
+    assert lib.aadg_bn_backward(one, z, z, one, z, 0, one, z, z, one, one, 1, one, z, z, z, 2, 4, 16, 0, one, 1 << 20, 0, z) == -1   # plane constants without dres
     # depthwise 3x3
     assert lib.aadg_dwconv3x3_supported(32, 32, 12, 1) == 1 and lib.aadg_dwconv3x3_supported(32, 12, 1, 1) == 0
     assert lib.aadg_dwconv3x3_supported(8, 512, 1, 0) == 0

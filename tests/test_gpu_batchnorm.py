@@ -211,3 +211,37 @@ def test_bn_plane_constant_gradient_travels_as_one_value_per_plane(hip, dtype):
         res.append((x.grad.float(), r.grad.float()))
     tol = 0.1 if dtype == torch.bfloat16 else 1e-5
     assert (res[0][0] - res[1][0]).abs().max().item() <= tol and (res[0][1] - res[1][1]).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_writes_into_concat_slices_and_reads_gradient_slices(hip, dtype):
+    """batch_norm_act(out=slice of a concatenation buffer) + concat_from_slices == torch.cat of the separate outputs, forward and
+    backward (the gradient slices are read in place: image stride of the wide tensor)."""
+    torch.manual_seed(21)
+    N, H, W = 3, 8, 16
+    chans = [8, 16, 8]
+    xs = [torch.randn(N, c, H, W, device="cuda").to(dtype) for c in chans]
+    ws = [torch.rand(c, device="cuda") + 0.5 for c in chans]
+    bs = [torch.randn(c, device="cuda") * 0.2 for c in chans]
+    g = torch.randn(N, sum(chans), H, W, device="cuda").to(dtype)
+    res = []
+    for fused in (True, False):
+        xin = [x.clone().requires_grad_(True) for x in xs]
+        win = [w.clone().requires_grad_(True) for w in ws]
+        if fused:
+            buf, parts = hip.concat_slices(N, chans, H, W, dtype, xs[0].device)
+            outs = [hip.batch_norm_act(x, w, b, torch.zeros(c, device="cuda"), torch.ones(c, device="cuda"), True, 0.1, 1e-5, 1, out=p)
+                    for x, w, b, c, p in zip(xin, win, bs, chans, parts)]
+            assert all(o.data_ptr() == p.data_ptr() for o, p in zip(outs, parts))
+            y = hip.concat_from_slices(buf, outs)
+        else:
+            y = torch.cat([hip.batch_norm_act(x, w, b, torch.zeros(c, device="cuda"), torch.ones(c, device="cuda"), True, 0.1, 1e-5, 1)
+                           for x, w, b, c in zip(xin, win, bs, chans)], dim=1)
+        y.backward(g)
+        res.append((y.detach().clone(), [x.grad.clone() for x in xin], [w.grad.clone() for w in win]))
+    a, b = res
+    assert torch.equal(a[0], b[0])
+    for ga, gb in zip(a[1], b[1]):
+        assert torch.equal(ga, gb)
+    for ga, gb in zip(a[2], b[2]):
+        assert torch.allclose(ga, gb, rtol=1e-5, atol=1e-5)
