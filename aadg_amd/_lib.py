@@ -1104,15 +1104,19 @@ class _UpsampleCat(torch.autograd.Function):
     (no separate copy of its output) and its backward reads the corresponding channel slice of the gradient in place."""
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, buf):
         lib = load()
         N, Ca, h, w = a.shape
         _, Cb, H, W = b.shape
-        out = torch.empty((N, Ca + Cb, H, W), dtype=a.dtype, device=a.device)
+        # buf: the concatenation buffer whose channels [Ca:] ARE b already (b = its alias part, concat_slices): nothing to copy
+        out = torch.empty((N, Ca + Cb, H, W), dtype=a.dtype, device=a.device) if buf is None else buf
         rc = lib.aadg_upsample_bilinear2d_strided(a.data_ptr(), out.data_ptr(), N, Ca, h, w, H, W, (Ca + Cb) * H * W,
                                                   0 if a.dtype == torch.float32 else 1, _stream())
         _check(rc, "aadg_upsample_bilinear2d_strided")
-        out[:, Ca:].copy_(b)
+        if buf is None:
+            out[:, Ca:].copy_(b)
+        else:
+            out = buf.detach().view(buf.shape)
         ctx.shape_a = (N, Ca, h, w)
         ctx.Cb = Cb
         return out
@@ -1136,12 +1140,20 @@ class _UpsampleCat(torch.autograd.Function):
                 ga = torch.ops.aten.upsample_bilinear2d_backward(g[:, :Ca].contiguous(), [H, W], list(ctx.shape_a), True, None, None)
         if ctx.needs_input_grad[1]:
             gb = g[:, Ca:]
-        return ga, gb
+        return ga, gb, None
 
 
-def upsample_cat(a, b):
-    """cat([bilinear up-sampling of a (align_corners=True) to b's spatial size, b], dim=1) on NCHW float32 / bfloat16 tensors."""
-    _require_cuda(a, b)
+def upsample_cat(a, b, buf=None):
+    """cat([bilinear up-sampling of a (align_corners=True) to b's spatial size, b], dim=1) on NCHW float32 / bfloat16 tensors.
+    buf: the [N, Ca + Cb, H, W] buffer of concat_slices whose second part b already is (written there by its producer)."""
+    _require_cuda(a)
     if a.dtype != b.dtype or a.dtype not in (torch.float32, torch.bfloat16) or a.dim() != 4 or b.dim() != 4 or a.shape[0] != b.shape[0]:
         raise AadgError("upsample_cat: expected two NCHW float32/bfloat16 tensors with one batch size")
-    return _UpsampleCat.apply(a.contiguous(), b.contiguous())
+    if buf is not None:
+        Ca = a.shape[1]
+        if (tuple(buf.shape) != (a.shape[0], Ca + b.shape[1], b.shape[2], b.shape[3]) or not buf.is_contiguous() or
+                b.data_ptr() != buf.data_ptr() + Ca * b.shape[2] * b.shape[3] * buf.element_size() or b.stride() != buf.stride()):
+            raise AadgError("upsample_cat: b is not the second part of buf")
+        return _UpsampleCat.apply(a.contiguous(), b, buf)
+    _require_cuda(b)
+    return _UpsampleCat.apply(a.contiguous(), b.contiguous(), None)

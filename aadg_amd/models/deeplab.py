@@ -416,8 +416,24 @@ class DeepLabV3Plus(nn.Module):
         a = self.aspp[0](tuple(hd[:4]), pooled)          # ASPP takes one handle of the encoder output per convolution branch
         for mod in list(self.aspp)[1:]:
             a = mod(a)
-        s = self.skip(skip)
-        if a.is_cuda and a.dtype == s.dtype and a.dtype in (torch.float32, torch.bfloat16):
+        y = None
+        if (a.is_cuda and self.training and torch.is_grad_enabled() and a.dtype == torch.bfloat16 and len(self.skip) == 2 and
+                type(self.skip[1]) is BNAct and type(self.skip[1].bn) is nn.BatchNorm2d):
+            # both halves of the decoder concatenation are produced in place: the skip branch's BatchNorm writes its slice of
+            # the buffer, the up-sampling kernel the other
+            from .. import _lib
+            t = self.skip[0](skip)
+            if t.dtype == a.dtype and _lib.bn_act_supported(t.contiguous()) and (t.shape[2] * t.shape[3]) % 8 == 0:
+                buf, parts = _lib.concat_slices(a.shape[0], [a.shape[1], t.shape[1]], t.shape[2], t.shape[3], a.dtype, a.device)
+                s = bn_act(self.skip[1].bn, t, self.skip[1].act, out=parts[1])
+                y = _lib.upsample_cat(a, s, buf)
+            else:
+                s = self.skip[1](t)
+        else:
+            s = self.skip(skip)
+        if y is not None:
+            pass
+        elif a.is_cuda and a.dtype == s.dtype and a.dtype in (torch.float32, torch.bfloat16):
             from .. import _lib
             y = _lib.upsample_cat(a, s)                     # up-sampling written straight into the concatenation
         else:

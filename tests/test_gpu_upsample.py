@@ -72,3 +72,31 @@ def test_upsample_cat_matches_cat_of_interpolate(hip, dtype, shape_a, shape_b):
     yr.backward(g)
     assert (a.grad.float() - ar.grad.float()).abs().max().item() <= (0.2 if lo else 5e-4)
     assert torch.equal(b.grad, br.grad)
+
+
+def test_upsample_cat_with_second_half_already_in_place(hip):
+    """The decoder concatenation with both halves produced in place: b is written into its slice of the buffer by its producer
+    (here a BatchNorm with out=), the up-sampling kernel fills the other slice -- same result and gradients as the copying path."""
+    torch.manual_seed(8)
+    dtype = torch.bfloat16
+    a0 = torch.randn(2, 16, 8, 8, device="cuda").to(dtype)
+    t0 = torch.randn(2, 8, 32, 32, device="cuda").to(dtype)
+    w0, b0 = torch.rand(8, device="cuda") + 0.5, torch.randn(8, device="cuda") * 0.2
+    g = torch.randn(2, 24, 32, 32, device="cuda").to(dtype)
+    res = []
+    for inplace in (True, False):
+        a, t = a0.clone().requires_grad_(True), t0.clone().requires_grad_(True)
+        rm, rv = torch.zeros(8, device="cuda"), torch.ones(8, device="cuda")
+        if inplace:
+            buf, parts = hip.concat_slices(2, [16, 8], 32, 32, dtype, a.device)
+            s = hip.batch_norm_act(t, w0, b0, rm, rv, True, 0.1, 1e-5, 1, out=parts[1])
+            y = hip.upsample_cat(a, s, buf)
+        else:
+            s = hip.batch_norm_act(t, w0, b0, rm, rv, True, 0.1, 1e-5, 1)
+            y = hip.upsample_cat(a, s)
+        y.backward(g)
+        res.append((y.detach().clone(), a.grad.clone(), t.grad.clone()))
+    for u, v in zip(*res):
+        assert torch.equal(u, v)
+    with pytest.raises(hip.AadgError):
+        hip.upsample_cat(a0, t0, torch.empty(2, 24, 32, 32, device="cuda", dtype=dtype))       # t0 is not part of that buffer
