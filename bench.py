@@ -228,6 +228,11 @@ def main():
     for i in range(a.warmup):
         st.search_step(i, max_iters=1)
     sync()
+    # everything allocated so far (model, dataset pool, kernel caches) is long-lived: keep the cyclic garbage collector from
+    # re-scanning it in the middle of a step (a full collection is a ~30 ms host pause -- longer than a whole step at 18 rows per rank)
+    import gc
+    gc.collect()
+    gc.freeze()
     # events around the dominant kernel, one pair per timed step (recorded on the launch stream)
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     for e0, e1 in pairs:
