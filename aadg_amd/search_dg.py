@@ -274,6 +274,11 @@ class SearchState(object):
 
 def search_seg_dg_policy(gpu, ngpus_per_node, config, args):
     st = SearchState(gpu, ngpus_per_node, config, args)
+    # models, data pool and kernel handles live for the whole run: take them out of the cyclic garbage collector's scans
+    # (a full collection is a host pause of tens of milliseconds in the middle of a step)
+    import gc
+    gc.collect()
+    gc.freeze()
     rank, _ = adist.world()
     main = rank == 0
     logger, final_output_dir, writer_dict = None, None, None
