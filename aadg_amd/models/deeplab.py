@@ -382,7 +382,8 @@ class ASPP(nn.Module):
             y = b[0](hx)
             if not (y.is_cuda and y.dtype == ref.dtype and _lib.bn_act_supported(y.contiguous())):
                 return None
-            outs.append(bn_act(b[1].bn, y, b[1].act, out=part))
+            o = bn_act(b[1].bn, y, b[1].act, out=part)
+            outs.append(o if o.data_ptr() == part.data_ptr() else part.copy_(o))     # (a BatchNorm variant without the kernels)
         ip = pooled.to(ref.dtype)[:, :, None, None]
         for mod in list(self.image_pool)[1:]:                      # [0] is the pooling itself
             ip = mod(ip)
@@ -426,6 +427,8 @@ class DeepLabV3Plus(nn.Module):
             if t.dtype == a.dtype and _lib.bn_act_supported(t.contiguous()) and (t.shape[2] * t.shape[3]) % 8 == 0:
                 buf, parts = _lib.concat_slices(a.shape[0], [a.shape[1], t.shape[1]], t.shape[2], t.shape[3], a.dtype, a.device)
                 s = bn_act(self.skip[1].bn, t, self.skip[1].act, out=parts[1])
+                if s.data_ptr() != parts[1].data_ptr():
+                    s = parts[1].copy_(s)
                 y = _lib.upsample_cat(a, s, buf)
             else:
                 s = self.skip[1](t)
