@@ -36,6 +36,7 @@ EXPORTS = [
     "aadg_upsample_bilinear2d", "aadg_upsample_bilinear2d_strided", "aadg_upsample_bilinear2d_backward_supported", "aadg_upsample_bilinear2d_backward",
     "aadg_upsample_bilinear2d_backward_workspace_bytes", "aadg_upsample_bilinear2d_backward_strided",
     "aadg_bn_workspace_bytes", "aadg_bn_mask_bytes", "aadg_bn_forward", "aadg_bn_backward",
+    "aadg_bn_sync_forward", "aadg_bn_sync_backward",
     "aadg_dwconv3x3_supported", "aadg_dwconv3x3_workspace_bytes", "aadg_dwconv3x3", "aadg_dwconv3x3_wgrad",
     "aadg_bn_relu_maxpool_supported", "aadg_bn_relu_maxpool_forward", "aadg_bn_relu_maxpool_backward",
     "aadg_conv1x1_nchw_supported", "aadg_conv1x1_nchw_bf16",
@@ -110,6 +111,12 @@ def load():
     lib.aadg_bn_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _c.c_longlong, _vp]
     lib.aadg_bn_backward.restype = _i
     lib.aadg_bn_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _c.c_longlong, _vp]
+    lib.aadg_bn_sync_forward.restype = _i
+    lib.aadg_bn_sync_forward.argtypes = [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz,
+                                         _c.c_longlong, _vp]
+    lib.aadg_bn_sync_backward.restype = _i
+    lib.aadg_bn_sync_backward.argtypes = [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
+                                          _vp, _vp, _vp, _sz, _c.c_longlong, _vp]
     lib.aadg_dwconv3x3_supported.restype = _i
     lib.aadg_dwconv3x3_supported.argtypes = [_i, _i, _i, _i]
     lib.aadg_dwconv3x3_workspace_bytes.restype = _sz
@@ -576,34 +583,7 @@ class _BatchNormAct(torch.autograd.Function):
         lib = load()
         x, y, mask, weight, bias, mean, invstd = ctx.saved_tensors
         N, C, H, W = x.shape
-        grads = [g for g in grads if g is not None]                   # unused handles deliver no gradient
-        # a gradient that is a broadcast over each plane (the backward of a global average pool of this output) travels as one
-        # float per plane instead of a materialised activation-sized tensor
-        pconst = None
-        if ctx.has_res and len(grads) > 1:
-            flat = [g for g in grads if g.dim() == 4 and g.stride(2) == 0 and g.stride(3) == 0 and g.shape[2] * g.shape[3] > 1]
-            if flat:
-                grads = [g for g in grads if not any(g is f for f in flat)]
-                pconst = flat[0][:, :, 0, 0].float()
-                for f in flat[1:]:
-                    pconst = pconst + f[:, :, 0, 0].float()
-                pconst = pconst.contiguous()
-        # a single gradient that is a channel slice of a wider one (the backward of a concatenation) is read in place
-        dy_stride = 0
-        if len(grads) == 1 and not grads[0].is_contiguous() and tuple(grads[0].stride()[1:]) == (H * W, W, 1) and \
-                grads[0].stride(0) >= C * H * W and grads[0].stride(0) % 8 == 0 and grads[0].data_ptr() % 16 == 0:
-            dy_stride = grads[0].stride(0)
-        else:
-            grads = [g.contiguous() for g in grads]
-        if not grads:
-            grads = [torch.zeros_like(x)]
-        if len(grads) > 1 and (not ctx.has_res or len(grads) > 1 + BN_MAX_EXTRA):
-            # the fused sum rides on the materialised masked gradient of the residual case
-            total = grads[0]
-            for g in grads[1:]:
-                total = total + g
-            grads = [total]
-        dy, extra = grads[0], grads[1:]
+        dy, extra, pconst, dy_stride = _bn_prepare_grads(grads, x, ctx.has_res)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         dw = torch.empty(C, dtype=torch.float32, device=x.device)
@@ -614,6 +594,108 @@ class _BatchNormAct(torch.autograd.Function):
                                   _ptr(dres), dw.data_ptr(), db.data_ptr(), N, C, H * W, _BN_DTYPES[x.dtype], ws.data_ptr(),
                                   ws.numel(), dy_stride, _stream())
         _check(rc, "aadg_bn_backward")
+        return (dx, dres, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None, None)
+
+
+def _bn_prepare_grads(grads, x, has_res):
+    """The gradients of a BatchNorm output's handles as the backward kernels take them: (dy, extra gradients to be summed while
+    reading, per-plane constant gradient or None, image stride of dy when it is a channel slice of a wider tensor else 0)."""
+    N, C, H, W = x.shape
+    grads = [g for g in grads if g is not None]                   # unused handles deliver no gradient
+    # a gradient that is a broadcast over each plane (the backward of a global average pool of this output) travels as one
+    # float per plane instead of a materialised activation-sized tensor
+    pconst = None
+    if has_res and len(grads) > 1:
+        flat = [g for g in grads if g.dim() == 4 and g.stride(2) == 0 and g.stride(3) == 0 and g.shape[2] * g.shape[3] > 1]
+        if flat:
+            grads = [g for g in grads if not any(g is f for f in flat)]
+            pconst = flat[0][:, :, 0, 0].float()
+            for f in flat[1:]:
+                pconst = pconst + f[:, :, 0, 0].float()
+            pconst = pconst.contiguous()
+    # a single gradient that is a channel slice of a wider one (the backward of a concatenation) is read in place
+    dy_stride = 0
+    if len(grads) == 1 and not grads[0].is_contiguous() and tuple(grads[0].stride()[1:]) == (H * W, W, 1) and \
+            grads[0].stride(0) >= C * H * W and grads[0].stride(0) % 8 == 0 and grads[0].data_ptr() % 16 == 0:
+        dy_stride = grads[0].stride(0)
+    else:
+        grads = [g.contiguous() for g in grads]
+    if not grads:
+        grads = [torch.zeros_like(x)]
+    if len(grads) > 1 and (not has_res or len(grads) > 1 + BN_MAX_EXTRA):
+        # the fused sum rides on the materialised masked gradient of the residual case
+        total = grads[0]
+        for g in grads[1:]:
+            total = total + g
+        grads = [total]
+    return grads[0], grads[1:], pconst, dy_stride
+
+
+# ---- synchronised statistics (data-parallel ranks): the all-reduce sits between the statistics and the elementwise kernels ----
+BN_SYNC_REDUCE = None      # callable(float64 device tensor) -> None: in-place SUM over the ranks; None = torch.distributed.all_reduce
+
+
+def _bn_sync_reduce(t):
+    if BN_SYNC_REDUCE is not None:
+        return BN_SYNC_REDUCE(t)
+    import torch.distributed as dist
+    dist.all_reduce(t)
+
+
+class _SyncBatchNormAct(torch.autograd.Function):
+    """_BatchNormAct with the per-channel sums all-reduced over the ranks (aadg_bn_sync_forward / _backward): every rank
+    normalises with the statistics of the GLOBAL batch, as the reference's single-GPU batch does.  Two small
+    all-reduces per layer and step ([2C + 1] and [2C] float64)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, act, handles, out=None):
+        lib = load()
+        N, C, H, W = x.shape
+        y = torch.empty_like(x) if out is None else out
+        y_stride = 0 if out is None else out.stride(0)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
+        ws = _bn_ws(C, x.device)
+        mask = None
+        if residual is not None and act != ACT_NONE:
+            nb = lib.aadg_bn_mask_bytes(N, C, H * W, _BN_DTYPES[x.dtype])
+            if nb and (x.data_ptr() | residual.data_ptr() | y.data_ptr()) % 16 == 0:
+                mask = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        args = (x.data_ptr(), _ptr(residual), y.data_ptr(), _ptr(mask), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                momentum, eps, act, N, C, H * W, _BN_DTYPES[x.dtype], mean.data_ptr(), invstd.data_ptr(), sums.data_ptr(), ws.data_ptr(),
+                ws.numel(), y_stride, _stream())
+        _check(lib.aadg_bn_sync_forward(1, *args), "aadg_bn_sync_forward(1)")
+        _bn_sync_reduce(sums)
+        _check(lib.aadg_bn_sync_forward(2, *args), "aadg_bn_sync_forward(2)")
+        if out is not None:
+            ctx.mark_dirty(out)
+        ctx.act = act
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, y if (ctx.has_res and mask is None) else None, mask, weight, bias, mean, invstd, sums)
+        if handles > 1:
+            return (y,) + tuple(y.view_as(y) for _ in range(handles - 1))
+        return y
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = load()
+        x, y, mask, weight, bias, mean, invstd, fsums = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dy, extra, pconst, dy_stride = _bn_prepare_grads(grads, x, ctx.has_res)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        dw = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        ws = _bn_ws(C, x.device)
+        extra_arr = _ptr_array(extra) if extra else None
+        args = (x.data_ptr(), _ptr(y), _ptr(mask), dy.data_ptr(), extra_arr, len(extra), _ptr(pconst), _ptr(weight), _ptr(bias),
+                mean.data_ptr(), invstd.data_ptr(), ctx.act, dx.data_ptr(), _ptr(dres), dw.data_ptr(), db.data_ptr(), N, C, H * W,
+                _BN_DTYPES[x.dtype], sums.data_ptr(), fsums.data_ptr() + 16 * C, ws.data_ptr(), ws.numel(), dy_stride, _stream())
+        _check(lib.aadg_bn_sync_backward(1, *args), "aadg_bn_sync_backward(1)")
+        _bn_sync_reduce(sums)
+        _check(lib.aadg_bn_sync_backward(2, *args), "aadg_bn_sync_backward(2)")
         return (dx, dres, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None, None)
 
 
@@ -661,7 +743,7 @@ def bn_act_supported(x, residual=None):
 
 
 def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentum, eps, act=ACT_NONE, residual=None, dual=False,
-                   handles=None, out=None):
+                   handles=None, out=None, sync=False):
     """act(F.batch_norm(x, ...) [+ residual]) on NCHW float32 / bfloat16 GPU tensors.  handles = k > 1 (training only; dual =
     True means k = 2) returns the output as a tuple of k tensors on one storage, one per consumer, see _BatchNormAct."""
     handles = int(handles) if handles else (2 if dual else 1)
@@ -672,7 +754,8 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
         if out is not None and (handles != 1 or out.shape != x.shape or out.dtype != x.dtype or tuple(out.stride()[1:]) != tuple(x.stride()[1:]) or
                                 out.data_ptr() % 16 or out.stride(0) % 8):
             raise AadgError("batch_norm_act: `out` must be a channel slice of a contiguous NCHW buffer of the same dtype")
-        return _BatchNormAct.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), int(act), handles, out)
+        fn = _SyncBatchNormAct if sync else _BatchNormAct
+        return fn.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), int(act), handles, out)
     lib = load()
     N, C, H, W = x.shape
     if x.requires_grad or (residual is not None and residual.requires_grad):

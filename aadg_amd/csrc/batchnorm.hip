@@ -272,6 +272,35 @@ __global__ __launch_bounds__(256) void k_bn_scale_shift(int C, const float* __re
     bn_scale_shift_of(weight, bias, mean[c], 1.0f / sqrtf(var[c] + eps), c, scale + c, shift + c);
 }
 
+// ---- synchronised statistics (data-parallel ranks): the reduction's partial sums leave the device-local
+// workspace as float64 totals, are summed over the ranks by the caller (one all-reduce of 2C + 1 doubles), and come back as TWO
+// float partials per channel (head + tail of the double), which bn_combine adds in float64 again: the elementwise kernels run
+// unchanged with split = 2 and the element count read from the device.
+__global__ __launch_bounds__(64) void k_bn_pack(const float* __restrict__ partial, int split, int C, double count_local,
+                                                double* __restrict__ sums, double* __restrict__ count_out,
+                                                float* __restrict__ dweight, float* __restrict__ dbias) {
+    const int c = blockIdx.x;
+    double a, b;
+    bn_combine(partial, c, split, &a, &b);
+    if (threadIdx.x == 0) {
+        sums[2 * c] = a;
+        sums[2 * c + 1] = b;
+        // backward: the parameter gradients are the LOCAL sums (DDP averages them over the ranks like every other gradient)
+        if (dweight != nullptr) dweight[c] = (float)b;
+        if (dbias != nullptr) dbias[c] = (float)a;
+        if (c == 0 && count_out != nullptr) *count_out = count_local;
+    }
+}
+__global__ __launch_bounds__(256) void k_bn_unpack(const double* __restrict__ sums, int C, float* __restrict__ partial) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double a = sums[2 * c], b = sums[2 * c + 1];
+    const float ah = (float)a, bh = (float)b;
+    float2* p = reinterpret_cast<float2*>(partial) + (size_t)c * BN_MAX_SPLIT;
+    p[0] = make_float2(ah, bh);
+    p[1] = make_float2((float)(a - (double)ah), (float)(b - (double)bh));
+}
+
 // ---- elementwise passes: grid (N*C strips, pieces per strip) ------------------------------------------------
 // ACT >= 0: the activation is a compile-time constant (vector path); ACT < 0: the run-time `act` (scalar path).
 // FIN: training -- the statistics of this channel are finalised here from the reduction's partial sums (BnFin); else
@@ -281,6 +310,7 @@ struct BnFin {
     const float* weight; const float* bias;
     float* running_mean; float* running_var; float momentum, eps;
     float* save_mean; float* save_invstd;
+    const double* count_dev;      // synchronised statistics: the all-reduced element count lives on the device (else null)
 };
 template <typename T, int VEC, int ACT, bool RES, bool MASK, bool FIN>
 __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
@@ -294,8 +324,9 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const
     if (FIN) {
         double s, q;
         bn_combine(fin.partial, c, fin.split, &s, &q);
-        const double m = s / fin.count;
-        double var = q / fin.count - m * m;
+        const double count = fin.count_dev != nullptr ? *fin.count_dev : fin.count;
+        const double m = s / count;
+        double var = q / count - m * m;
         if (var < 0.0) var = 0.0;
         const float is = (float)(1.0 / sqrt(var + (double)fin.eps));
         bn_scale_shift_of(fin.weight, fin.bias, (float)m, is, c, &sc, &sh);
@@ -303,7 +334,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const
             fin.save_mean[c] = (float)m;
             fin.save_invstd[c] = is;
             if (fin.running_mean != nullptr) {
-                const double unbiased = fin.count > 1.0 ? var * fin.count / (fin.count - 1.0) : var;
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
                 fin.running_mean[c] = (1.0f - fin.momentum) * fin.running_mean[c] + fin.momentum * (float)m;
                 fin.running_var[c] = (1.0f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unbiased;
             }
@@ -344,7 +375,8 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const
 // the backward reduction's partial sums; the workgroup of image 0 stores dweight / dbias.
 template <typename T, int VEC, int ACT>
 __global__ __launch_bounds__(256) void k_bn_dx(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
-                                               const float* __restrict__ partial, int split, double count,
+                                               const float* __restrict__ partial, int split, double count_host,
+                                               const double* __restrict__ count_dev,
                                                const float* __restrict__ weight, const float* __restrict__ bias,
                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                float* __restrict__ dweight, float* __restrict__ dbias, int act_rt, int C, int len,
@@ -353,6 +385,7 @@ __global__ __launch_bounds__(256) void k_bn_dx(const T* __restrict__ x, const T*
     const int strip = blockIdx.x, c = strip % C;
     double sg, sgx;
     bn_combine(partial, c, split, &sg, &sgx);
+    const double count = count_dev != nullptr ? *count_dev : count_host;
     const float mu_f = mean[c], is_f = invstd[c];
     const double w = weight != nullptr ? (double)weight[c] : 1.0;
     const double is = (double)is_f, mu = (double)mu_f;
@@ -406,7 +439,9 @@ inline bool make_shape(int N, int C, int HW, const void* a, const void* b, const
 template <typename T>
 int bn_forward(const T* x, const T* res, T* y, uint8_t* mask, const float* weight, const float* bias, float* rmean, float* rvar, float momentum,
                float eps, int act, int training, int N, int C, int HW, float* save_mean, float* save_invstd, float* ws,
-               long long y_img_stride, hipStream_t st) {
+               long long y_img_stride, hipStream_t st, int phase = 0, double* sums = nullptr) {
+    // phase 0: everything on this device.  Synchronised statistics (training): phase 1 = local sums -> `sums` [2C + 1] doubles
+    // (the last one is this rank's element count); the caller all-reduces `sums`; phase 2 = normalise with the totals.
     Shape s;
     if (!make_shape<T>(N, C, HW, x, res, y, nullptr, &s)) return AADG_E_BADARG;
     if (y_img_stride != 0 && (y_img_stride < (long long)C * HW || (s.vec > 1 && (y_img_stride % s.vec) != 0))) return AADG_E_BADARG;
@@ -415,20 +450,33 @@ int bn_forward(const T* x, const T* res, T* y, uint8_t* mask, const float* weigh
     float* scale = ws + L.scale;
     float* shift = ws + L.shift;
     const dim3 blk(s.threads);
-    if (training) {
+    int split = s.split;
+    const double* count_dev = nullptr;
+    if (training && phase != 2) {
         const dim3 grid(s.split, C);
         if (s.vec > 1)
             hipLaunchKernelGGL((k_bn_reduce_fwd<T, Pack<T>::N>), grid, blk, 0, st, x, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         else
             hipLaunchKernelGGL((k_bn_reduce_fwd<T, 1>), grid, blk, 0, st, x, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         AADG_LAUNCH_CHECK();
+        if (phase == 1) {
+            hipLaunchKernelGGL(k_bn_pack, dim3(C), dim3(64), 0, st, (const float*)(ws + L.partial), s.split, C, (double)N * (double)HW,
+                               sums, sums + 2 * (size_t)C, (float*)nullptr, (float*)nullptr);
+            AADG_LAUNCH_CHECK();
+            return 0;
+        }
+    } else if (training) {
+        hipLaunchKernelGGL(k_bn_unpack, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)sums, C, ws + L.partial);
+        AADG_LAUNCH_CHECK();
+        split = 2;
+        count_dev = sums + 2 * (size_t)C;
     } else {
         hipLaunchKernelGGL(k_bn_scale_shift, dim3((C + 255) / 256), dim3(256), 0, st, C, weight, bias, (const float*)rmean,
                            (const float*)rvar, eps, scale, shift);
         AADG_LAUNCH_CHECK();
     }
     const dim3 grid(N * C, s.pc.per_strip);
-    const BnFin fin = {ws + L.partial, s.split, (double)N * (double)HW, weight, bias, rmean, rvar, momentum, eps, save_mean, save_invstd};
+    const BnFin fin = {ws + L.partial, split, (double)N * (double)HW, weight, bias, rmean, rvar, momentum, eps, save_mean, save_invstd, count_dev};
 #define AADG_BN_APPLY(VEC_, ACT_, RES_, MASK_, FIN_) \
     hipLaunchKernelGGL((k_bn_apply<T, VEC_, ACT_, RES_, MASK_, FIN_>), grid, blk, 0, st, x, res, y, mask, (const float*)scale, (const float*)shift, fin, act, C, s.len, s.pc.plen, y_img_stride)
 #define AADG_BN_APPLY_ACT(ACT_)                                                          \
@@ -452,7 +500,10 @@ int bn_forward(const T* x, const T* res, T* y, uint8_t* mask, const float* weigh
 template <typename T>
 int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const void* const* dy_extra, int n_extra, const float* pconst, const float* weight, const float* bias, const float* mean, const float* invstd,
                 int act, T* dx, T* dres, float* dweight, float* dbias, int N, int C, int HW, float* ws, long long dy_img_stride,
-                hipStream_t st) {
+                hipStream_t st, int phase = 0, double* sums = nullptr, const double* count_dev = nullptr) {
+    // phase 0: everything on this device.  Synchronised statistics: phase 1 = masked gradient (dres) + local sums -> `sums`
+    // [2C] doubles and the LOCAL dweight / dbias; the caller all-reduces `sums`; phase 2 = dx from the totals and the forward's
+    // all-reduced element count (`count_dev`).
     Shape s;
     if (!make_shape<T>(N, C, HW, x, y, dy, dx, &s) || (((uintptr_t)dres & 15u) && s.vec > 1)) return AADG_E_BADARG;
     if (dy_img_stride != 0 && (dy_img_stride < (long long)C * HW || (s.vec > 1 && (dy_img_stride % s.vec) != 0))) return AADG_E_BADARG;
@@ -465,7 +516,13 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
         more.p[e] = (const T*)dy_extra[e];
     }
     more.n = n_extra;
-    {
+    int split = s.split;
+    if (phase == 2) {
+        hipLaunchKernelGGL(k_bn_unpack, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)sums, C, ws + L.partial);
+        AADG_LAUNCH_CHECK();
+        split = 2;
+        dweight = nullptr; dbias = nullptr;                     // written by phase 1 (local sums)
+    } else {
         const dim3 grid(s.split, C);
 #define AADG_BN_REDUCE_BWD(VEC_, MK_, NE_, DRES_)                                                                                        \
     hipLaunchKernelGGL((k_bn_reduce_bwd<T, VEC_, MK_, NE_, DRES_>), grid, blk, 0, st, x, y, dy, more, pconst, mask, dres, mean, invstd,  \
@@ -485,6 +542,12 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
 #undef AADG_BN_REDUCE_BWD_MK
 #undef AADG_BN_REDUCE_BWD
         AADG_LAUNCH_CHECK();
+        if (phase == 1) {
+            hipLaunchKernelGGL(k_bn_pack, dim3(C), dim3(64), 0, st, (const float*)(ws + L.partial), s.split, C, 0.0, sums,
+                               (double*)nullptr, dweight, dbias);
+            AADG_LAUNCH_CHECK();
+            return 0;
+        }
     }
     {
         // when the masked gradient was materialised (dres), the last pass reads it instead of re-deriving the mask
@@ -493,8 +556,8 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
         const dim3 grid(N * C, s.pc.per_strip);
         const int act_dx = g_ready ? AADG_ACT_NONE : act;
 #define AADG_BN_DX(VEC_, ACT_)                                                                                                  \
-    hipLaunchKernelGGL((k_bn_dx<T, VEC_, ACT_>), grid, blk, 0, st, x, g, dx, (const float*)(ws + L.partial), s.split,              \
-                       (double)N * (double)HW, weight, bias, mean, invstd, dweight, dbias, act_dx, C, s.len, s.pc.plen, g_ready ? 0LL : dy_img_stride)
+    hipLaunchKernelGGL((k_bn_dx<T, VEC_, ACT_>), grid, blk, 0, st, x, g, dx, (const float*)(ws + L.partial), split,                \
+                       (double)N * (double)HW, count_dev, weight, bias, mean, invstd, dweight, dbias, act_dx, C, s.len, s.pc.plen, g_ready ? 0LL : dy_img_stride)
         if (s.vec == 1) AADG_BN_DX(1, -1);
         else if (act_dx == AADG_ACT_RELU) AADG_BN_DX(Pack<T>::N, AADG_ACT_RELU);
         else if (act_dx == AADG_ACT_RELU6) AADG_BN_DX(Pack<T>::N, AADG_ACT_RELU6);
@@ -737,6 +800,60 @@ extern "C" int aadg_bn_backward(const void* x, const void* y, const void* act_ma
         return bn_backward<__hip_bfloat16>((const __hip_bfloat16*)x, (const __hip_bfloat16*)y, (const uint8_t*)act_mask,
                                            (const __hip_bfloat16*)dy, dy_extra, n_extra, dy_plane_const, weight, bias, save_mean, save_invstd, act,
                                            (__hip_bfloat16*)dx, (__hip_bfloat16*)dres, dweight, dbias, N, C, HW, (float*)ws, dy_image_stride, st);
+    return AADG_E_BADARG;
+}
+
+// ---- synchronised statistics over data-parallel ranks (the reference's single-GPU batch mixes all domains in every
+// BatchNorm batch; sharded replicas reproduce that by summing the per-channel statistics over the ranks).  The library stays
+// free of any communication: phase 1 leaves this rank's float64 sums in `sums`, the CALLER all-reduces them (RCCL through
+// torch.distributed), phase 2 consumes the totals.  training mode only.
+//   forward : sums [2C + 1] doubles = (sum x, sum x^2) per channel + this rank's element count N * HW
+//   backward: sums [2C] doubles = (sum g, sum g * xhat) per channel; `count` = the forward's all-reduced element count
+//             (device pointer, sums_fwd + 2C); phase 1 also writes the LOCAL dweight / dbias and the masked gradient dres
+extern "C" int aadg_bn_sync_forward(int phase, const void* x, const void* residual, void* y, void* act_mask, const float* weight,
+                                    const float* bias, float* running_mean, float* running_var, float momentum, float eps, int act,
+                                    int N, int C, int HW, int dtype, float* save_mean, float* save_invstd, double* sums, void* ws,
+                                    size_t ws_bytes, long long y_image_stride, void* stream) {
+    if ((phase != 1 && phase != 2) || x == nullptr || sums == nullptr || ws == nullptr || act < 0 || act > AADG_ACT_RELU6 ||
+        y_image_stride < 0 || (((uintptr_t)sums) & 7u) != 0)
+        return AADG_E_BADARG;
+    if (phase == 2 && (y == nullptr || save_mean == nullptr || save_invstd == nullptr)) return AADG_E_BADARG;
+    if (C <= 0 || ws_bytes < aadg_bn_workspace_bytes(C)) return AADG_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0)
+        return bn_forward<float>((const float*)x, (const float*)residual, (float*)y, (uint8_t*)act_mask, weight, bias, running_mean,
+                                 running_var, momentum, eps, act, 1, N, C, HW, save_mean, save_invstd, (float*)ws, y_image_stride, st,
+                                 phase, sums);
+    if (dtype == 1)
+        return bn_forward<__hip_bfloat16>((const __hip_bfloat16*)x, (const __hip_bfloat16*)residual, (__hip_bfloat16*)y,
+                                          (uint8_t*)act_mask, weight, bias, running_mean, running_var, momentum, eps, act, 1, N, C, HW,
+                                          save_mean, save_invstd, (float*)ws, y_image_stride, st, phase, sums);
+    return AADG_E_BADARG;
+}
+
+extern "C" int aadg_bn_sync_backward(int phase, const void* x, const void* y, const void* act_mask, const void* dy,
+                                     const void* const* dy_extra, int n_extra, const float* dy_plane_const, const float* weight,
+                                     const float* bias, const float* save_mean, const float* save_invstd, int act, void* dx, void* dres,
+                                     float* dweight, float* dbias, int N, int C, int HW, int dtype, double* sums, const double* count,
+                                     void* ws, size_t ws_bytes, long long dy_image_stride, void* stream) {
+    if ((phase != 1 && phase != 2) || x == nullptr || dy == nullptr || save_mean == nullptr || save_invstd == nullptr ||
+        ws == nullptr || sums == nullptr || act < 0 || act > AADG_ACT_RELU6 || dy_image_stride < 0 || (((uintptr_t)sums) & 7u) != 0)
+        return AADG_E_BADARG;
+    if (phase == 2 && (dx == nullptr || count == nullptr)) return AADG_E_BADARG;
+    if (dres != nullptr && y == nullptr && act_mask == nullptr) return AADG_E_BADARG;
+    if (n_extra < 0 || n_extra > BN_MAX_EXTRA || (n_extra > 0 && (dy_extra == nullptr || dres == nullptr))) return AADG_E_BADARG;
+    if (dy_plane_const != nullptr && dres == nullptr) return AADG_E_BADARG;
+    if (C <= 0 || ws_bytes < aadg_bn_workspace_bytes(C)) return AADG_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0)
+        return bn_backward<float>((const float*)x, (const float*)y, (const uint8_t*)act_mask, (const float*)dy, dy_extra, n_extra,
+                                  dy_plane_const, weight, bias, save_mean, save_invstd, act, (float*)dx, (float*)dres, dweight, dbias, N, C, HW,
+                                  (float*)ws, dy_image_stride, st, phase, sums, count);
+    if (dtype == 1)
+        return bn_backward<__hip_bfloat16>((const __hip_bfloat16*)x, (const __hip_bfloat16*)y, (const uint8_t*)act_mask,
+                                           (const __hip_bfloat16*)dy, dy_extra, n_extra, dy_plane_const, weight, bias, save_mean,
+                                           save_invstd, act, (__hip_bfloat16*)dx, (__hip_bfloat16*)dres, dweight, dbias, N, C, HW,
+                                           (float*)ws, dy_image_stride, st, phase, sums, count);
     return AADG_E_BADARG;
 }
 

@@ -32,9 +32,9 @@ class DeviceBatchLoader(object):
 def get_seg_dg_dataloader(cfg, args, batch_size, workers, size=None, per_domain=32, device=None):
     name = cfg.DATASET.NAME
     size = size if size is not None else getattr(args, 'crop_size', 256)
-    transform_train, transform_test = get_dg_segtransform(name, size)
     kind = 'optic' if name == 'optic' else 'rvs'
     n_domains = len(cfg.DATASET.DG.TRAIN)
+    transform_train, transform_test = get_dg_segtransform(name, size, n_domains)
     src = size if kind == 'optic' else 2 * size if size <= 512 else size
     trainset = SyntheticDGSegmentation(n_domains, per_domain, src if kind == 'rvs' else size, kind, 'train', transform_train,
                                        seed=cfg.SEED or 1023, device=device, length=getattr(args, 'epoch_items', per_domain))

@@ -188,9 +188,13 @@ def SoftLable(label):
 class ToTensor(object):
     """Draws the soft domain code; the HWC->CHW float conversion itself happens in the fused kernel."""
 
-    def __init__(self, dataset_name) -> None:
+    def __init__(self, dataset_name, n_domains=None) -> None:
         super().__init__()
+        # the reference hard-codes 3 source domains (data/transform.py:212-215); n_domains widens the code for configs with
+        # more sources (BASELINE configs[4]: 8)
         self.n = 3 if dataset_name in ['optic', 'vessel'] else 2
+        if n_domains is not None:
+            self.n = max(self.n, int(n_domains))
 
     def __call__(self, sample):
         soft = SoftLable(ToMultiLabel(sample['dc'], self.n)).astype(np.float32)      # same rounding as .float()
@@ -202,31 +206,31 @@ class ToTensor(object):
         return sample
 
 
-def get_dg_segtransform(dataset, size=256):
+def get_dg_segtransform(dataset, size=256, n_domains=None):
     """Same pipelines as data/transform.py:281-309; `size` generalises the hard-coded 256 crop
-    (BASELINE configs run 512 and 1024)."""
+    (BASELINE configs run 512 and 1024), `n_domains` the hard-coded 3-wide domain code."""
     if 'optic' in dataset:
         transform_train_imgs = Compose([
             Identity(),  # slot 0: the search driver installs DGMultiPolicy here
             DGRandomScaleCrop(size),
             Normalize_dg('optic'),
-            ToTensor('optic')
+            ToTensor('optic', n_domains)
         ])
         transform_test_imgs = Compose([
             DGRandomCrop(size),
             Normalize_dg('optic'),
-            ToTensor('optic')
+            ToTensor('optic', n_domains)
         ])
     elif 'rvs' in dataset:
         transform_train_imgs = Compose([
             Identity(),
             DGRandomScaleCrop(size, scale_range=[0.5, 2]),
             Normalize_dg('vessel'),
-            ToTensor('vessel')
+            ToTensor('vessel', n_domains)
         ])
         transform_test_imgs = Compose([
             Normalize_dg('vessel'),
-            ToTensor('vessel'),
+            ToTensor('vessel', n_domains),
         ])
     else:
         raise NotImplementedError(dataset)
@@ -304,43 +308,60 @@ def collect_refs(batch, nested):
     return batch, refs, M
 
 
-_ROW_SHARD = (0, 1)   # (rank, world): which contiguous slice of the collate rows this process materialises
+_ROW_SHARD = (0, 1, 'unit')   # (rank, world, placement law): which collate rows this process materialises
+_PLANS = {}
 
 
-def set_row_shard(rank, world_size):
+def set_row_shard(rank, world_size, law='unit'):
     """Multi-GPU: every rank draws the SAME batch plan (same seeds -> same draws, no communication) but
-    materialises only its contiguous slice of the rows (aadg_amd/distributed.py: shard_rows)."""
+    materialises only the rows of its (domain, policy) units (aadg_amd/distributed.py: RowPlan)."""
     global _ROW_SHARD
-    _ROW_SHARD = (int(rank), int(world_size))
+    _ROW_SHARD = (int(rank), int(world_size), law)
 
 
-def _slice(n):
-    rank, world = _ROW_SHARD
-    if world == 1:
-        return 0, n
-    if n % world:
-        raise ValueError("rows (%d) must divide evenly over %d ranks" % (n, world))
-    return rank * (n // world), (rank + 1) * (n // world)
+def row_plan(D, B, M):
+    from ..distributed import RowPlan
+    key = (D, B, M) + _ROW_SHARD
+    plan = _PLANS.get(key)
+    if plan is None:
+        plan = _PLANS[key] = RowPlan(D, B, M, *_ROW_SHARD)
+    return plan
 
 
 def _collate(batch, nested):
+    D = len(batch[0]) if nested else 1
+    B = len(batch)
     batch, refs, M = collect_refs(batch, nested)
     S = len(batch)
     new_batch = {'img_name': [b['img_name'] for b in batch]}
-    lo_s, hi_s = _slice(S)
-    lo, hi = _slice(S * M) if M else (0, 0)
-    img, lbl = materialize(refs[lo_s:hi_s] + refs[S + lo:S + hi])
+    rank, world, _ = _ROW_SHARD
+    if M and world > 1:
+        # training batch of a sharded job: this rank's slice of the un-augmented rows (warm-up epochs) and the rows of its
+        # (domain, policy) units, in the plan's local order
+        from ..distributed import shard_rows
+        plan = row_plan(D, B, M)
+        lo_s, hi_s = shard_rows(S, rank, world)
+        local = [refs[S + int(r)] for r in plan.rows]
+    else:
+        # single process -- or a test batch, which every rank scores in full (validate() then agrees on all ranks)
+        plan = row_plan(D, B, M) if M else None
+        lo_s, hi_s = 0, S
+        local = refs[S:]
+    img, lbl = materialize(refs[lo_s:hi_s] + local)
     ns = hi_s - lo_s
     new_batch['image'], new_batch['label'] = img[:ns], lbl[:ns]
     dev = img.device
     if M:
         new_batch['aug_images'], new_batch['aug_labels'] = img[ns:], lbl[ns:]
         dc = torch.cat([b['dc'] for b in batch], dim=0)
-        new_batch['dc'] = dc[lo:hi].to(dev, non_blocking=True)
+        if plan.sharded:
+            dc = dc[torch.from_numpy(plan.rows)]
+        new_batch['dc'] = dc.to(dev, non_blocking=True)
         new_batch['dc_image'] = torch.stack([b['dc_single'] for b in batch], dim=0)[lo_s:hi_s].to(dev, non_blocking=True)
-        new_batch['rows'] = (lo, hi, S * M)
+        new_batch['plan'] = plan
+        new_batch['image_rows'] = (lo_s, hi_s, S)
     else:
-        new_batch['dc'] = torch.stack([b['dc'] for b in batch], dim=0)[lo_s:hi_s].to(dev, non_blocking=True)
+        new_batch['dc'] = torch.stack([b['dc'] for b in batch], dim=0).to(dev, non_blocking=True)
     if 'roi' in batch[0]:
         new_batch['roi'] = torch.stack([b['roi'] for b in batch], dim=0)
     return new_batch

@@ -1,15 +1,37 @@
 """Collective helpers -- API mirror of the reference's distributed.py:34-74 over torch.distributed
-(backend "nccl" is RCCL on ROCm; "gloo" on CPU for tests), plus the row-sharding law the MI355X design
+(backend "nccl" is RCCL on ROCm; "gloo" on CPU for tests), plus the placement law the MI355X design
 uses instead of DDP batch splitting.
 
+Placement.  The unit of work is the (domain d, policy j) slice of a batch = B images
+(collate rows (b*D + d)*M + j, b < B; search_dg.py:150-157 splits the embeddings exactly that way).
+Units are numbered DOMAIN-MAJOR, u = d*M + j, and the unit sequence is cut into G contiguous pieces:
+
+  law 'unit'  whole units per rank, sizes differ by at most one unit (D*M = 18 units: G = 3 -> 6/6/6 = one
+              domain per GPU, G = 4 -> 5/5/4/4, G = 8 -> 3/3/2/2/2/2/2/2);
+  law 'row'   the same domain-major ROW sequence (u*B + b) cut into G pieces that differ by at most one row
+              (G = 3 -> still one domain per GPU; G = 4 -> 36 rows each; G = 8 -> 18 rows each): units may
+              be split between two neighbouring ranks, the step time is set by 18 instead of 24 rows at G = 8.
+
+(SURVEY 8e also writes the owner as "(d*M + j) mod G"; taken literally that law puts policies j, j+G, ... of
+EVERY domain on one GPU and contradicts "G = 3 => one domain per GPU" in the same sentence, so the contiguous
+domain-major cut is what is implemented)
+
 Exchange pattern of one inner iteration on G GPUs:
-  1. every rank augments + runs the backbone on its own contiguous slice of the N = D*B*M rows,
-  2. ONE all-gather of the [N/G, 128] momentum embeddings (<= 25 KB per rank: latency-bound, one hop on
-     the fully connected xGMI mesh) -- then every rank runs the Sinkhorn kernel redundantly on the full
+  1. every rank augments + runs the backbone on its own rows only (every rank draws the SAME batch plan from
+     the same seeds, so no plan is communicated),
+  2. ONE all-gather of the local momentum embeddings, padded to the largest per-rank row count
+     (<= 25 KB per rank: latency-bound, one hop on the fully connected xGMI mesh); `RowPlan.take` puts the
+     gathered rows back into collate order, then every rank runs the Sinkhorn kernel redundantly on the full
      [N, 128] matrix, so rewards (and hence the replicated controller) stay bit-identical on all ranks
      without a second collective,
   3. gradient all-reduce of the segmentation model / discriminator (DDP buckets, overlapped with backward).
+     DDP averages over ranks; with n_r rows on rank r the local loss is the local mean times n_r*G/N
+     (`RowPlan.loss_weight`), so the averaged gradient is the gradient of the mean over all N rows whatever
+     the split (count-weighted mean),
+  4. with --sync_bn the per-channel BatchNorm sums are all-reduced between the statistics and the
+     normalisation kernels (aadg_bn_sync_*), forward and backward.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -53,12 +75,105 @@ def all_reduce(tensors, average=True):
     return tensors
 
 
+def balanced_cuts(n, parts):
+    """parts + 1 cut points of range(n) into contiguous pieces whose sizes differ by at most one (larger first)."""
+    base, extra = divmod(n, parts)
+    cuts = [0]
+    for r in range(parts):
+        cuts.append(cuts[-1] + base + (1 if r < extra else 0))
+    return cuts
+
+
 def shard_rows(n_rows, rank=None, world_size=None):
-    """Contiguous [lo, hi) slice of the N collate rows owned by `rank`.  N must divide evenly (N = D*B*M
-    = 144 divides by 1, 2, 3, 4, 6, 8); with G == D and domain-major row order this is one domain per GPU."""
+    """Contiguous balanced [lo, hi) slice of `n_rows` rows for `rank` (used for the un-augmented images of a batch,
+    which only feed the warm-up epochs)."""
     if rank is None or world_size is None:
         rank, world_size = world()
-    if n_rows % world_size:
-        raise ValueError("rows (%d) must divide evenly over %d ranks" % (n_rows, world_size))
-    per = n_rows // world_size
-    return rank * per, (rank + 1) * per
+    cuts = balanced_cuts(n_rows, world_size)
+    return cuts[rank], cuts[rank + 1]
+
+
+class RowPlan(object):
+    """Which collate rows of the N = D*B*M augmented images this rank materialises, and how the all-gathered
+    per-rank results go back into collate order.
+
+    rows        int64 [n_local]  collate-row indices owned by this rank, in local (materialisation) order
+    counts      per-rank row counts (every rank knows all of them: the plan needs no communication)
+    take        int64 [N]        index into the flattened padded gather buffer [G * max(counts)]: gathered[take] is in
+                                 collate order (row (b*D + d)*M + j)
+    loss_weight n_local * G / N  factor on the local-mean loss so that DDP's average over ranks is the global mean
+    """
+
+    def __init__(self, D, B, M, rank=0, world_size=1, law='unit'):
+        if law not in ('unit', 'row'):
+            raise ValueError("placement law must be 'unit' or 'row'")
+        self.D, self.B, self.M, self.rank, self.world, self.law = D, B, M, int(rank), int(world_size), law
+        N = D * B * M
+        self.n_rows = N
+        if self.world == 1:
+            # single GPU: collate order itself (the reference's row law), nothing to gather
+            self.order = np.arange(N, dtype=np.int64)
+            self.cuts = [0, N]
+        else:
+            d, j, b = np.meshgrid(np.arange(D), np.arange(M), np.arange(B), indexing='ij')
+            self.order = ((b * D + d) * M + j).reshape(-1).astype(np.int64)      # domain-major: position u*B + b
+            if law == 'unit':
+                if self.world > D * M:
+                    raise ValueError("%d ranks for %d (domain, policy) units: use the 'row' law" % (self.world, D * M))
+                self.cuts = [c * B for c in balanced_cuts(D * M, self.world)]
+            else:
+                if self.world > N:
+                    raise ValueError("%d ranks for %d rows" % (self.world, N))
+                self.cuts = balanced_cuts(N, self.world)
+        self.counts = [self.cuts[r + 1] - self.cuts[r] for r in range(self.world)]
+        self.max_count = max(self.counts)
+        self.rows = self.order[self.cuts[self.rank]:self.cuts[self.rank + 1]]
+        self.n_local = int(self.rows.shape[0])
+        self.loss_weight = self.n_local * self.world / float(N)
+        # gathered buffer position of domain-major position p = (owner r, offset p - cuts[r]) -> r * max_count + offset
+        pos = np.empty(N, dtype=np.int64)
+        for r in range(self.world):
+            pos[self.cuts[r]:self.cuts[r + 1]] = r * self.max_count + np.arange(self.counts[r])
+        take = np.empty(N, dtype=np.int64)
+        take[self.order] = pos
+        self.take = take
+        self._dev = {}
+
+    @property
+    def sharded(self):
+        return self.world > 1
+
+    def units(self, rank=None):
+        """(domain, policy) units touched by `rank` (whole units under the 'unit' law)."""
+        r = self.rank if rank is None else rank
+        lo, hi = self.cuts[r], self.cuts[r + 1]
+        if self.world == 1:
+            return [(d, j) for d in range(self.D) for j in range(self.M)]
+        return sorted({(int(p // self.B) // self.M, int(p // self.B) % self.M) for p in range(lo, hi)})
+
+    def on(self, device):
+        """(rows, take) as device tensors (cached per device)."""
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (torch.from_numpy(self.rows).to(device), torch.from_numpy(self.take).to(device))
+        return self._dev[key]
+
+    def gather(self, local, emulate=False):
+        """local [n_local, E] -> [N, E] in collate order on every rank: pad to the largest per-rank count, ONE all-gather,
+        one index_select.  `emulate` (single process standing in for one rank of a G-rank job, bench.py --shard_of):
+        the missing peers' rows are stood in by repetition of the local ones -- shapes and kernels as in the real job."""
+        if not self.sharded:
+            return local
+        local = local.contiguous()
+        _, take = self.on(local.device)
+        if self.n_local < self.max_count:
+            pad = local.new_zeros((self.max_count - self.n_local,) + tuple(local.shape[1:]))
+            local = torch.cat([local, pad], dim=0)
+        if emulate:
+            flat = local.repeat((self.world,) + (1,) * (local.dim() - 1))
+            if self.n_local < self.max_count:        # never read a padding row: fold the index into the valid range
+                r, o = take // self.max_count, take % self.max_count
+                take = r * self.max_count + o % self.n_local
+        else:
+            flat = all_gather([local])[0]
+        return flat.index_select(0, take)

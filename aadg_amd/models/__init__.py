@@ -20,7 +20,12 @@ def class_parser(dataset):
     return {'rvs': 1, 'optic': 2}[dataset]
 
 
-def domain_parser(dataset):
+def domain_parser(dataset, cfg=None):
+    """Number of source domains = width of the discriminator head and of the soft domain codes.  The reference hard-codes 3
+    for both datasets (models/__init__.py:211-216); with a config it follows len(DATASET.DG.TRAIN) (BASELINE configs[4] merges
+    Fundus + RVS into 8 synthetic source domains)."""
+    if cfg is not None and len(cfg.DATASET.DG.TRAIN) > 0:
+        return max(len(cfg.DATASET.DG.TRAIN), 3 if dataset in ('optic', 'rvs') else 2)
     return {'optic': 3, 'rvs': 3}[dataset]
 
 
@@ -35,10 +40,11 @@ def _device(args):
     return torch.device('cpu')
 
 
-def _wrap(module, args, dev):
+def _wrap(module, args, dev, broadcast_buffers=True):
     if getattr(args, 'distributed', False) and any(p.requires_grad for p in module.parameters()):
         ids = [dev.index] if dev.type == 'cuda' else None
-        return torch.nn.parallel.DistributedDataParallel(module, device_ids=ids, gradient_as_bucket_view=True)
+        return torch.nn.parallel.DistributedDataParallel(module, device_ids=ids, gradient_as_bucket_view=True,
+                                                         broadcast_buffers=broadcast_buffers)
     return module
 
 
@@ -57,11 +63,19 @@ def load_ddp_model(ngpus_per_node, args, cfg):
     print("=> creating model '{}' with '{}".format(cfg.MODEL.NAME, cfg.MODEL.BACKBONE))
     dev = _device(args)
     model = build_model(cfg).to(dev)
-    if getattr(args, 'distributed', False) and getattr(args, 'sync_bn', False):
-        # The reference's single-GPU batch mixes all domains in every BatchNorm batch; row-sharded replicas see
-        # only their slice.  --sync_bn reduces the per-channel statistics over the ranks (SURVEY.md 8e caveat 1).
-        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
-    model = _wrap(model, args, dev)
+    sync = bool(getattr(args, 'distributed', False) and getattr(args, 'sync_bn', False))
+    if sync:
+        # The reference's single-GPU batch mixes all domains in every BatchNorm batch; sharded replicas see only their rows.
+        # --sync_bn all-reduces the per-channel sums over the ranks (SURVEY.md 8e caveat 1).  On the GPU the modules stay
+        # nn.BatchNorm2d and keep the HIP kernels: the all-reduce sits between the statistics and the normalisation
+        # kernels (aadg_bn_sync_*, models/deeplab.py: bn_act); elsewhere (CPU, unsupported layouts) torch's SyncBatchNorm.
+        from . import deeplab
+        if dev.type == 'cuda':
+            deeplab.set_bn_sync(True)
+        else:
+            model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    # with synchronised statistics the running buffers are identical on every rank: no per-forward buffer broadcast
+    model = _wrap(model, args, dev, broadcast_buffers=not sync)
     return model, cfg.TRAIN.BATCH_SIZE, args.workers
 
 
@@ -78,7 +92,7 @@ def load_ddp_discriminator(ngpus_per_node, args, cfg):
     name = cfg.DISCRIMINATOR.NAME
     print("=> creating discriminator '{}'".format(name))
     dev = _device(args)
-    num_classes = domain_parser(cfg.DATASET.NAME)
+    num_classes = domain_parser(cfg.DATASET.NAME, cfg)
     in_channels = channel_parser('unet' if cfg.MODEL.NAME == 'unet' else cfg.MODEL.BACKBONE)
     if name == 'feature':
         model = FeatureDiscriminator(num_classes, in_channels)
@@ -90,4 +104,7 @@ def load_ddp_discriminator(ngpus_per_node, args, cfg):
             p.requires_grad_(False)
     else:
         raise NotImplementedError(name + ' has not been implemented!')
-    return model.to(dev), cfg.TRAIN.BATCH_SIZE, args.workers
+    # DDP as in the reference (models/__init__.py:165): the online branch's gradients are averaged over the ranks, so the
+    # online and (through momentum_update) the EMA weights stay identical everywhere -- the all-gathered embeddings come
+    # from ONE network.  The search loop reaches the EMA branch / momentum_update through `.module` (search_dg._bare).
+    return _wrap(model.to(dev), args, dev), cfg.TRAIN.BATCH_SIZE, args.workers

@@ -26,6 +26,14 @@ def _upsample_ac(x, size):
 
 
 _ACT_CODE = {None: 0, 'relu': 1, 'relu6': 2}
+_BN_SYNC = False
+
+
+def set_bn_sync(flag):
+    """Data-parallel ranks: training-mode BatchNorm statistics are all-reduced over the process group between the HIP
+    statistics and normalisation kernels (_lib._SyncBatchNormAct) -- the modules stay nn.BatchNorm2d."""
+    global _BN_SYNC
+    _BN_SYNC = bool(flag)
 
 
 def bn_act(bn, x, act=None, residual=None, handles=1, out=None):
@@ -43,7 +51,7 @@ def bn_act(bn, x, act=None, residual=None, handles=1, out=None):
             return _lib.batch_norm_act(xc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum,
                                        bn.eps, _ACT_CODE[act], rc,
                                        handles=handles if (bn.training and torch.is_grad_enabled() and rc is not None) else 1,
-                                       out=out if bn.training else None)
+                                       out=out if bn.training else None, sync=_BN_SYNC and bn.training)
     y = bn(x)
     if residual is not None:
         y = y + residual
@@ -246,7 +254,7 @@ class ResNet50Encoder(nn.Module):
         conv, bna = self.stem[0], self.stem[1]
         bn = bna.bn
         y = conv(x)
-        if (y.is_cuda and bn.training and torch.is_grad_enabled() and type(bn) is nn.BatchNorm2d and bna.act == 'relu' and
+        if (y.is_cuda and bn.training and torch.is_grad_enabled() and type(bn) is nn.BatchNorm2d and bna.act == 'relu' and not _BN_SYNC and
                 bn.momentum is not None and bn.track_running_stats and type(self.pool) is MaxPool3x3s2):
             from .. import _lib
             yc = y.contiguous()
@@ -347,11 +355,16 @@ class ASPP(nn.Module):
         nb = len(self.branches)
         h = _handles(x, nb if pooled is not None else nb + 1)      # one handle of the encoder output per consumer
         ref = h[0]
-        fused = self._forward_into_concat(h, pooled) if (pooled is not None and self.training and torch.is_grad_enabled() and
-                                                         ref.is_cuda and ref.dtype == torch.bfloat16) else None
+        fused, convs = self._forward_into_concat(h, pooled) if (pooled is not None and self.training and torch.is_grad_enabled() and
+                                                                ref.is_cuda and ref.dtype == torch.bfloat16) else (None, None)
         if fused is not None:
             return self.project(fused)
-        outs = [b(hx) for b, hx in zip(self.branches, h)]
+        if convs is not None:
+            # the in-place path ran the branch convolutions, found an unsupported layout and touched no BatchNorm: go on from
+            # the convolution outputs (running statistics are updated exactly once per step either way)
+            outs = [b[1](y) for b, y in zip(self.branches, convs)]
+        else:
+            outs = [b(hx) for b, hx in zip(self.branches, h)]
         if pooled is None:
             ip = self.image_pool(h[-1])
         else:
@@ -373,22 +386,24 @@ class ASPP(nn.Module):
         cout = self.project[0].in_channels // (len(self.branches) + 1)
         for b in self.branches:
             if len(b) != 2 or type(b[1]) is not BNAct or type(b[1].bn) is not nn.BatchNorm2d or b[1].bn.num_features != cout:
-                return None
+                return None, None
         if (H * W) % 8 != 0:
-            return None
+            return None, None
+        # every precondition is checked BEFORE the first BatchNorm runs (a BatchNorm call updates running statistics): first all
+        # the convolutions (stateless), then the checks on their outputs, then the BatchNorm kernels
+        convs = [b[0](hx) for b, hx in zip(self.branches, h)]
+        if not all(y.is_cuda and y.dtype == ref.dtype and _lib.bn_act_supported(y.contiguous()) for y in convs):
+            return None, convs
         buf, parts = _lib.concat_slices(N, [cout] * (len(self.branches) + 1), H, W, ref.dtype, ref.device)
         outs = []
-        for b, hx, part in zip(self.branches, h, parts):
-            y = b[0](hx)
-            if not (y.is_cuda and y.dtype == ref.dtype and _lib.bn_act_supported(y.contiguous())):
-                return None
+        for b, y, part in zip(self.branches, convs, parts):
             o = bn_act(b[1].bn, y, b[1].act, out=part)
             outs.append(o if o.data_ptr() == part.data_ptr() else part.copy_(o))     # (a BatchNorm variant without the kernels)
         ip = pooled.to(ref.dtype)[:, :, None, None]
         for mod in list(self.image_pool)[1:]:                      # [0] is the pooling itself
             ip = mod(ip)
         outs.append(parts[-1].copy_(ip.expand(-1, -1, H, W)))      # bilinear up-sampling of a 1x1 map = broadcast
-        return _lib.concat_from_slices(buf, outs)
+        return _lib.concat_from_slices(buf, outs), convs
 
 
 class DeepLabV3Plus(nn.Module):

@@ -35,6 +35,18 @@ def _autocast(args):
     return torch.autocast('cuda', enabled=False) if torch.cuda.is_available() else torch.autocast('cpu', enabled=False)
 
 
+LAST_RAW_REWARDS = None
+
+
+def seed_everything(seed):
+    import random
+    random.seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
 def _bare(module):
     return module.module if hasattr(module, 'module') else module
 
@@ -60,6 +72,11 @@ def pretrain(config, train_loader, model, discriminator, model_criterion, dis_cr
         dis_output = discriminator(feature.detach().float())
         seg_loss = model_criterion(torch.sigmoid(seg_output.float()), mask_gt)
         dis_loss = dis_criterion(dis_output, domain_gt)
+        if 'image_rows' in sample and adist.is_dist():
+            # local means -> global mean under DDP's average over ranks (count-weighted: slices may differ by a row)
+            lo_s, hi_s, S = sample['image_rows']
+            w = (hi_s - lo_s) * adist.world()[1] / float(S)
+            seg_loss, dis_loss = seg_loss * w, dis_loss * w
         model_optimizer.zero_grad(set_to_none=True)
         seg_loss.backward()
         model_optimizer.step()
@@ -81,30 +98,33 @@ def inner_iteration(config, sample, model, discriminator, dis_criterion, model_o
     Returns device scalars (seg_loss, dis_loss, diversity_ot, dice[K]) -- no host sync in here.
     `after_rewards()` (optional) runs once this batch's rewards are accumulated, before the backward passes."""
     input, mask_gt, domain_gt = sample['aug_images'], sample['aug_labels'], sample['dc']
-    lo, hi, n_rows = sample.get('rows', (0, input.size(0), input.size(0)))
+    plan = sample.get('plan')
+    sharded = plan is not None and plan.sharded
+    n_rows = plan.n_rows if plan is not None else input.size(0)
     with _autocast(args):
         seg_output, feature = model(input)
     feature = feature.detach().float()
-    # action: EMA-branch embeddings (no grad); bp: online branch trained on the soft domain codes
-    dis_output, domain_feature = discriminator(feature, momentum=True, return_feature=True)
+    # action: EMA-branch embeddings (no grad, outside the DDP wrapper: nothing to reduce); bp: online branch trained on the
+    # soft domain codes
+    dis_output, domain_feature = _bare(discriminator)(feature, momentum=True, return_feature=True)
     dis_loss_bp = dis_criterion(discriminator(feature, momentum=False), domain_gt)
-    # sigmoid + per-policy BCE + Dice, one fused pass (forward + gradient)
-    seg_loss, _, dice = _lib.policy_bce_loss(seg_output.float(), mask_gt, M)
+    # sigmoid + per-policy BCE + Dice, one fused pass (forward + gradient).  mean_j BCE_j == mean over all rows (every policy
+    # owns N/M rows), so a rank whose local rows are not policy-interleaved takes the plain mean of its rows.
+    seg_loss, _, dice = _lib.policy_bce_loss(seg_output.float(), mask_gt, 1 if sharded else M)
     with torch.no_grad():
         logp = torch.log_softmax(dis_output, dim=1)
-        per_row = -(domain_gt * logp).sum(dim=1)
-        dis_loss = per_row.view(-1, M).mean(dim=0).mean()          # mean_j CE(dis_output[j::M], gt[j::M])
-    # reward: all-gather the [rows_local, 128] embeddings once, then ONE kernel for all M x P problems
+        dis_loss = -(domain_gt * logp).sum(dim=1).mean()            # mean_j CE(dis_output[j::M], gt[j::M]) = mean over rows
+    if sharded:
+        # DDP averages the ranks' gradients: weight the local means by n_local * G / N (count-weighted mean, RowPlan)
+        seg_loss = seg_loss * plan.loss_weight
+        dis_loss_bp = dis_loss_bp * plan.loss_weight
+    # reward: all-gather the local [n_local, 128] embeddings once (back into collate order), then ONE kernel for all M x P problems
     fe_all = domain_feature.contiguous()
-    if hi - lo != n_rows:
-        if adist.is_dist():
-            fe_all = adist.all_gather([fe_all])[0]
-        elif getattr(args, 'emulate_shards', 0):
-            # single-process emulation of one rank of a sharded job (bench.py --shard_of, used to pre-build
-            # kernel caches for the per-rank shapes): stand in for the missing peers by repetition
-            fe_all = fe_all.repeat(n_rows // (hi - lo), 1)
-        else:
+    if sharded:
+        emulate = bool(getattr(args, 'emulate_shards', 0))
+        if not emulate and not adist.is_dist():
             raise RuntimeError("row-sharded batch without an initialised process group")
+        fe_all = plan.gather(fe_all, emulate=emulate)
     before = rewards.clone()
     B = n_rows // (M * n_domains)
     _lib.sinkhorn_rewards(fe_all, n_domains, B, M, rewards=rewards)
@@ -143,7 +163,7 @@ def train(config, train_loader, model, discriminator, model_criterion, dis_crite
         seg_loss, dis_loss, div_ot, dice = inner_iteration(config, sample, model, discriminator, dis_criterion,
                                                            model_optimizer, dis_optimizer, M, rewards, args, n_domains, hook)
         if i % config.PRINT_FREQ == 0 and logger:
-            n_img = sample['rows'][2] if 'rows' in sample else sample['aug_images'].size(0)
+            n_img = sample['plan'].n_rows if 'plan' in sample else sample['aug_images'].size(0)
             vals = torch.stack([seg_loss, dis_loss, div_ot]).tolist()        # the only host sync, every PRINT_FREQ
             batch_time.update(time.time() - end)
             logger.info('Epoch: [{0}][{1}/{2}]\tTime {3:.3f}s\tSpeed {4:.1f} samples/s\tSeg Loss {5:.5f}\t'
@@ -157,18 +177,23 @@ def train(config, train_loader, model, discriminator, model_criterion, dis_crite
                 writer.add_scalar('diversity_ot_distance', vals[2], steps)
                 writer_dict['train_global_steps'] = steps + 1
         end = time.time()
+    global LAST_RAW_REWARDS
+    LAST_RAW_REWARDS = rewards                      # diagnostics / tests: the epoch's accumulated Sinkhorn sums before normalisation
     return _lib.normalize_rewards(rewards)          # (r - mean) / (std + 1e-5), search_dg.py:214
 
 
 @torch.no_grad()
 def validate(config, val_loader, model, epoch, writer_dict, logger, args=None):
-    """Thresholded (0.75) Dice on the held-out domain (search_dg.py:217-286).  hd95 (medpy) is not available
-    in this image and is reported as 0 (out of scope)."""
+    """Thresholded Dice on the held-out domain (search_dg.py:217-286 / search_dg_2d.py:216-281).  hd95 (medpy) is not
+    available in this image and is reported as 0 (out of scope).  Every rank scores the WHOLE test set
+    (test batches are not sharded), so best_dsc / is_best agree on all ranks without a collective."""
     model.eval()
     K = 2 if config.DATASET.NAME == 'optic' else 1
     sums = torch.zeros(K, device=next(model.parameters()).device)
     count = 0
-    shift = float(np.log(0.75 / 0.25))               # sigmoid(z) > 0.75  <=>  z - log(3) > 0
+    # optic: sigmoid(z) > 0.75 <=> z - log(3) > 0 (search_dg.py:243); rvs: the F1 argmax over [1 - p, p], i.e. p > 0.5
+    # (search_dg_2d.py:252)
+    shift = float(np.log(0.75 / 0.25)) if config.DATASET.NAME == 'optic' else 0.0
     for sample in val_loader:
         input, mask_gt = sample['image'], sample['label']
         with _autocast(args):
@@ -188,11 +213,19 @@ class SearchState(object):
 
     def __init__(self, gpu, ngpus_per_node, config, args):
         self.config, self.args = config, args
+        # Row sharding relies on every rank drawing the SAME batch plan and holding the SAME controller / discriminator:
+        # seed python / numpy / torch identically on all ranks (the reference never seeds, SURVEY fact 8, and is single-GPU)
+        seed_everything(config.SEED if config.SEED is not None else 1023)
         self.model, self.batch_size, workers = load_ddp_model(ngpus_per_node, args, config)
         self.controller, self.M, _ = load_ddp_controller(ngpus_per_node, args, config)
         self.discriminator, _, _ = load_ddp_discriminator(ngpus_per_node, args, config)
         rank, world = adist.world()
-        T.set_row_shard(rank, world)
+        T.set_row_shard(rank, world, getattr(args, 'placement', 'unit'))
+        if adist.is_dist():
+            # the controller is replicated, not wrapped (identical rewards -> identical updates); DDP broadcast the wrapped
+            # modules' state at construction, do the same for it
+            for t in list(self.controller.parameters()) + list(self.controller.buffers()):
+                torch.distributed.broadcast(t.data, 0)
         _, self.train_loader, self.test_loader = get_seg_dg_dataloader(config, args, self.batch_size, workers)
         self.model_optimizer, self.model_lrscheduler, self.controller_optimizer = \
             get_optimizer_scheduler(self.controller, self.model, config)

@@ -71,8 +71,9 @@ def save_checkpoint(states, is_best, output_dir, filename='checkpoint.pth'):
         torch.save(states['state_dict'], os.path.join(output_dir, 'model_best.pth'))
 
 
-def load_checkpoint(model, path):
-    state = torch.load(path, map_location='cpu')
+def load_checkpoint(model_path, model):
+    """Argument order of the reference (utils.py:225): load_checkpoint(model_path, model)."""
+    state = torch.load(model_path, map_location='cpu')
     if hasattr(state, 'state_dict'):
         state = state.state_dict()
     clean = OrderedDict((k[7:] if k.startswith('module.') else k, v) for k, v in state.items())

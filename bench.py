@@ -58,9 +58,17 @@ def parse():
     ap.add_argument("--backbone_dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_units", type=int, default=24, help="units of the CPU-baseline sample")
-    ap.add_argument("--sync_bn", action="store_true", help="SyncBatchNorm over the ranks (strict single-GPU BN parity)")
+    ap.add_argument("--no_sync_bn", action="store_true",
+                    help="N > 1: keep BatchNorm statistics per rank (default: all-reduced per-channel sums between the HIP statistics "
+                         "and normalisation kernels, i.e. the single-GPU batch statistics of the reference)")
+    ap.add_argument("--placement", default="row", choices=["unit", "row"],
+                    help="N > 1: cut of the domain-major (domain, policy) unit sequence over the ranks -- whole units (SURVEY 8e as "
+                         "written: 18 units over 8 GPUs = 3/3/2/2/2/2/2/2, i.e. 24 rows on the slowest rank) or balanced to the row "
+                         "(18 rows per rank at 8 GPUs); both give one source domain per GPU at N = 3")
     ap.add_argument("--dist_backend", default="nccl", help="nccl (= RCCL) by default; gloo for single-GPU functional tests")
     ap.add_argument("--all_ranks_on_gpu0", action="store_true", help="functional test of the N>1 path on a 1-GPU box")
+    ap.add_argument("--dump_rewards", default=None, help="write the normalised rewards of every timed step to this JSON file (tests)")
+    ap.add_argument("--no_dropout", action="store_true", help="tests: make the step a deterministic function of the seed")
     ap.add_argument("--shard_of", type=int, default=0,
                     help="single process: run only rank 0's row slice of a G-rank job (no collectives); used to "
                          "pre-build the MIOpen kernel cache for the per-rank shapes of --gpus G runs")
@@ -84,9 +92,15 @@ def build_state(a, local_rank, world):
     args = Args()
     args.gpu, args.workers, args.distributed = local_rank, 0, world > 1
     args.crop_size, args.backbone_dtype, args.epoch_items = a.size, a.backbone_dtype, a.batch
-    args.sync_bn = a.sync_bn
+    args.sync_bn = world > 1 and not a.no_sync_bn
+    args.placement = a.placement
     st = SearchState(local_rank, world, cfg, args)
-    st.discriminator.synchronize_parameters()       # what the driver does at epoch == WARMUP_EPOCH
+    if a.no_dropout:
+        for m in st.model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+    bare = st.discriminator.module if hasattr(st.discriminator, "module") else st.discriminator
+    bare.synchronize_parameters()                   # what the driver does at epoch == WARMUP_EPOCH
     return cfg, st
 
 
@@ -189,14 +203,44 @@ def cpu_baseline(cfg, st, a, n_units):
             "sample_1core": "%d of %d units, BCE/Dice on 4 images, scaled: aug %.2fs + reward %.4fs + loss %.2fs" % (min(n_units, n_all), n_all, a1, t_sink, l1)}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def relaunch_under_torchrun(a):
+    """`python bench.py --gpus N` (no launcher): start the N ranks ourselves, exactly as the driver's documented command does
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...)."""
+    import subprocess
+    if not a.all_ranks_on_gpu0 and torch.cuda.device_count() < a.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (use --all_ranks_on_gpu0 for a functional run on one GPU)"
+                         % (a.gpus, torch.cuda.device_count()))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1 and not a.shard_of:
+        relaunch_under_torchrun(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and not a.shard_of:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (a.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU product path)"
     if a.all_ranks_on_gpu0:
         local_rank = 0
+        if world > 1 and a.dist_backend == "nccl":
+            a.dist_backend = "gloo"                 # RCCL refuses two ranks on one device; gloo moves the same tensors
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -215,7 +259,7 @@ def main():
         cfg, st = build_state(a, local_rank, world)
     if emulate:
         from aadg_amd.data import transform as _T
-        _T.set_row_shard(0, emulate)
+        _T.set_row_shard(0, emulate, a.placement)
         st.args.emulate_shards = emulate
     M, D = st.M, len(cfg.DATASET.DG.TRAIN)
     n_rows = D * a.batch * M
@@ -239,9 +283,13 @@ def main():
         e0.record(); e1.record()                     # force creation of the underlying hipEvent_t
     sync()
     t0 = time.perf_counter()
+    step_rewards = []
     for i in range(a.steps):
         _lib.PROFILE_EVENTS = pairs[i]
-        st.search_step(a.warmup + i, max_iters=1)
+        nr = st.search_step(a.warmup + i, max_iters=1)[3]
+        if a.dump_rewards:
+            from aadg_amd import search_dg as _sd
+            step_rewards.append((nr, _sd.LAST_RAW_REWARDS.clone()))
     _lib.PROFILE_EVENTS = None
     sync()
     elapsed = time.perf_counter() - t0
@@ -256,9 +304,8 @@ def main():
     from aadg_amd.data import transform as T
     from aadg_amd.data.policy import DGMultiPolicy, parse_policies
     K = 2
-    shards = emulate or world
-    lo, hi = (rank * n_rows // shards, (rank + 1) * n_rows // shards)
-    z = torch.randn(hi - lo, K, a.size, a.size, device="cuda", requires_grad=True)
+    plan = T.row_plan(D, a.batch, M)                      # this rank's rows of the batch (aadg_amd/distributed.py: RowPlan)
+    z = torch.randn(plan.n_local, K, a.size, a.size, device="cuda", requires_grad=True)
     fe = torch.nn.functional.leaky_relu(torch.randn(n_rows, 128, device="cuda"), 0.2)
     rewards = torch.zeros(M, device="cuda")
 
@@ -270,7 +317,7 @@ def main():
         parsed = parse_policies(policies.cpu().numpy(), cfg, None)
         st.train_loader.dataset.transforms.transforms[0] = DGMultiPolicy(parsed)
         sample = next(iter(st.train_loader))
-        loss, _, _ = _lib.policy_bce_loss(z, sample['aug_labels'], M)
+        loss, _, _ = _lib.policy_bce_loss(z, sample['aug_labels'], 1 if plan.sharded else M)
         loss.backward()
         rewards.zero_()
         _lib.sinkhorn_rewards(fe, D, a.batch, M, rewards=rewards)
@@ -295,11 +342,15 @@ def main():
     batch = [st.train_loader.dataset[0] for _ in range(a.batch)]
     flat, refs, _ = T.collect_refs(batch, nested=True)
     S = len(flat)
-    lo_s, hi_s = rank * S // shards, (rank + 1) * S // shards
-    units = T.refs_to_units(refs[lo_s:hi_s] + refs[S + lo:S + hi])
+    from aadg_amd.distributed import shard_rows
+    lo_s, hi_s = shard_rows(S, plan.rank, plan.world)
+    units = T.refs_to_units(refs[lo_s:hi_s] + [refs[S + int(r)] for r in plan.rows])
     alg = algorithmic_bytes(units, a.size, a.size, a.size, K)
     achieved = alg / (kern_ms * 1e-3) / 1e9
 
+    if rank == 0 and a.dump_rewards:
+        with open(a.dump_rewards, "w") as f:
+            json.dump({"normalized": [n.tolist() for n, _ in step_rewards], "raw": [r.tolist() for _, r in step_rewards]}, f)
     if rank == 0:
         out = {
             "metric": "policy-search steps/sec", "value": 1e3 / ms_per_step, "unit": "steps/s",
@@ -311,7 +362,11 @@ def main():
             "config": {"workload": "BASELINE configs[1]: DeepLabv3+/%s, 3-domain Fundus-like OD/OC Sinkhorn search, %dx%d, "
                                    "TRAIN.BATCH_SIZE=%d, CONTROLLER.M=%d -> %d augmented images per step, PPO controller"
                                    % (a.backbone, a.size, a.size, a.batch, M, n_rows),
-                       "images_per_step": n_rows, "parallelism": "rows sharded over %d GPU(s)" % world,
+                       "images_per_step": n_rows,
+                       "parallelism": "1 GPU" if world == 1 else
+                                      "%d GPUs: domain-major (domain, policy) units cut by %s (rows per rank %s), one embedding all-gather + DDP "
+                                      "gradient all-reduce%s" % (world, a.placement, "/".join(str(c) for c in plan.counts),
+                                                                   "" if a.no_sync_bn else " + BatchNorm statistics all-reduce"),
                        "backbone_dtype": a.backbone_dtype},
             "roofline": {"bound": "hbm", "kernel": "k_fused<16> (LDS-tiled ops + resample + crop + normalise + CHW store)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -209,6 +209,26 @@ int aadg_bn_backward(const void* x, const void* y, const void* act_mask, const v
                      const float* save_invstd, int act, void* dx, void* dres, float* dweight, float* dbias, int N,
                      int C, int HW, int dtype, void* ws, size_t ws_bytes, long long dy_image_stride, void* stream);
 
+/* Synchronised statistics over data-parallel ranks (replaces torch.nn.SyncBatchNorm around the same kernels; the reference wraps
+ * its model in DDP at models/__init__.py:39 and its single-GPU batch mixes all source domains in every BatchNorm batch, which
+ * domain-sharded replicas only reproduce with all-reduced statistics -- SURVEY.md 8e).  The library does no communication:
+ *   phase 1  local float64 sums -> `sums`; the CALLER all-reduces `sums` over the ranks (SUM);   phase 2  consumes the totals.
+ * forward : sums = [2C + 1] doubles: (sum x, sum x^2) per channel, then this rank's element count N * HW.  Phase 2 writes y, the
+ *           saved / running statistics (from the global totals, identical on every rank).
+ * backward: sums = [2C] doubles: (sum g, sum g * xhat); count = device pointer to the forward's all-reduced element count
+ *           (its sums + 2C).  Phase 1 writes the masked gradient `dres` (when given) and the LOCAL dweight / dbias (the
+ *           parameter gradients are averaged over the ranks like every other gradient); phase 2 writes dx.  Pass the same
+ *           tensors in both phases.  Training mode only; other arguments as aadg_bn_forward / aadg_bn_backward. */
+int aadg_bn_sync_forward(int phase, const void* x, const void* residual, void* y, void* act_mask, const float* weight,
+                         const float* bias, float* running_mean, float* running_var, float momentum, float eps, int act,
+                         int N, int C, int HW, int dtype, float* save_mean, float* save_invstd, double* sums, void* ws,
+                         size_t ws_bytes, long long y_image_stride, void* stream);
+int aadg_bn_sync_backward(int phase, const void* x, const void* y, const void* act_mask, const void* dy,
+                          const void* const* dy_extra, int n_extra, const float* dy_plane_const, const float* weight,
+                          const float* bias, const float* save_mean, const float* save_invstd, int act, void* dx, void* dres,
+                          float* dweight, float* dbias, int N, int C, int HW, int dtype, double* sums, const double* count,
+                          void* ws, size_t ws_bytes, long long dy_image_stride, void* stream);
+
 /* Training BatchNorm + ReLU + MaxPool2d(3, 2, 1) in one pass (the ResNet stem after its convolution): the normalised map is
  * never written.  y [N, C, Ho, Wo] and the pooling index (one byte per output, as aadg_maxpool3x3s2_forward); statistics as
  * aadg_bn_forward(training = 1).  Backward = aadg_maxpool3x3s2_backward(index, dy) then aadg_bn_backward(x, ..., AADG_ACT_RELU).

@@ -56,6 +56,110 @@ def embed(images):
     return torch.nn.functional.leaky_relu(pooled @ w, 0.2).contiguous()
 
 
+def check_plan(rank, world, law, D, B, M, size, crop, full, O, adist, T):
+    """One placement law: local rows, the single all-gather back into collate order, rewards identical on all ranks."""
+    N = D * B * M
+    T.set_row_shard(rank, world, law)
+    part = T.train_dg_collate_fn(build_batch(11, D, B, M, size, crop))
+    plan = part['plan']
+    assert plan.n_rows == N and plan.world == world and plan.law == law and sum(plan.counts) == N
+    rows = torch.from_numpy(plan.rows)
+    assert part['aug_images'].shape[0] == plan.n_local == plan.counts[rank]
+    assert torch.equal(part['aug_images'], full['aug_images'][rows])
+    assert torch.equal(part['aug_labels'], full['aug_labels'][rows])
+    assert torch.equal(part['dc'], full['dc'][rows])
+    # every row has exactly one owner
+    owners = adist.all_gather([torch.nn.functional.pad(rows, (0, plan.max_count - plan.n_local), value=-1)])[0]
+    owned = owners[owners >= 0]
+    assert owned.numel() == N and torch.equal(torch.sort(owned)[0], torch.arange(N))
+    units = plan.units()
+    if law == 'unit':
+        U = D * M
+        assert plan.n_local == len(units) * B                      # whole (domain, policy) units
+        want = [U // world + (1 if r < U % world else 0) for r in range(world)]
+        assert [c // B for c in plan.counts] == want               # 18 units over 4 ranks: 5/5/4/4
+        for (d, j) in units:                                       # the rows of a unit: all B items of (domain d, policy j)
+            assert all(((b * D + d) * M + j) in set(plan.rows.tolist()) for b in range(B))
+    else:
+        assert max(plan.counts) - min(plan.counts) <= 1            # balanced to the row
+    if world == D:
+        assert {d for d, _ in units} == {rank}                     # G == D: one source domain per GPU (north_star)
+    lo_s, hi_s, S = part['image_rows']
+    assert (lo_s, hi_s) == adist.shard_rows(S) and torch.equal(part['image'], full['image'][lo_s:hi_s])
+    # the one exchange step: padded all-gather of the local embeddings, back into collate order, reward on the full matrix
+    fe_local = embed(part['aug_images'])
+    fe_all = plan.gather(fe_local)
+    assert torch.equal(fe_all, embed(full['aug_images']))
+    rewards = O.sinkhorn_rewards(fe_all.numpy(), D, B, M)
+    truth = O.sinkhorn_rewards(embed(full['aug_images']).numpy(), D, B, M)
+    assert np.array_equal(rewards, truth)
+    gathered = adist.all_gather([torch.from_numpy(rewards)])[0].view(world, M)
+    assert all(torch.equal(gathered[0], gathered[r]) for r in range(world))     # identical on every rank
+    # gradient all-reduce: DDP over gloo averages; local mean x n_local * G / N  ==  the global mean, uneven splits included
+    torch.manual_seed(5)
+    lin = torch.nn.Linear(8, 1)
+    ddp = torch.nn.parallel.DistributedDataParallel(lin)
+    x = torch.arange(N * 8, dtype=torch.float32).view(N, 8) / 100.0
+    (ddp(x[rows]).mean() * plan.loss_weight).backward()
+    ref = torch.nn.Linear(8, 1)
+    ref.load_state_dict(lin.state_dict())
+    ref(x).mean().backward()
+    assert torch.allclose(lin.weight.grad, ref.weight.grad, atol=1e-6) and torch.allclose(lin.bias.grad, ref.bias.grad, atol=1e-6)
+    return part
+
+
+def check_discriminator(rank, world, D, plan):
+    """load_ddp_discriminator wraps the online branch in DDP: after an optimiser step on DIFFERENT local rows the parameters
+    (online and, through momentum_update, EMA) are still identical on every rank."""
+    from helpers import Cfg
+    from aadg_amd.losses import CrossEntropy
+    from aadg_amd.models import load_ddp_discriminator
+    from aadg_amd import distributed as adist
+
+    class A(object):
+        gpu, workers, distributed = None, 0, True
+    cfg = Cfg()
+    cfg.DISCRIMINATOR = Cfg._C(); cfg.DISCRIMINATOR.NAME = 'momentum_feature'
+    cfg.DATASET = Cfg._C(); cfg.DATASET.NAME = 'optic'; cfg.DATASET.DG = Cfg._C(); cfg.DATASET.DG.TRAIN = list(range(D))
+    cfg.MODEL = Cfg._C(); cfg.MODEL.NAME = 'unet'; cfg.MODEL.BACKBONE = 'unet'
+    cfg.TRAIN = Cfg._C(); cfg.TRAIN.BATCH_SIZE = 2
+    torch.manual_seed(77 + rank)                       # deliberately different initial weights: DDP broadcasts rank 0's
+    disc, _, _ = load_ddp_discriminator(1, A(), cfg)
+    assert isinstance(disc, torch.nn.parallel.DistributedDataParallel)
+    bare = disc.module
+    bare.synchronize_parameters()
+    opt = torch.optim.Adam([p for p in disc.parameters() if p.requires_grad], lr=1e-2)
+    g = torch.Generator().manual_seed(9)
+    feats = torch.randn(plan.n_rows, 128, generator=g)
+    soft = torch.softmax(torch.randn(plan.n_rows, D, generator=g), dim=1)
+    rows = torch.from_numpy(plan.rows)
+    for _ in range(2):
+        loss = CrossEntropy()(disc(feats[rows], momentum=False), soft[rows]) * plan.loss_weight
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        bare.momentum_update()
+    flat = torch.cat([p.detach().reshape(-1) for p in bare.parameters()])
+    every = adist.all_gather([flat[None]])[0]
+    assert all(torch.equal(every[0], every[r]) for r in range(world)), "discriminator replicas diverged"
+    # and they equal single-process training on ALL rows
+    torch.manual_seed(77)
+    from aadg_amd.models.discriminator import MomentumFeatureDiscriminator
+    ref = MomentumFeatureDiscriminator(D, 128)
+    for p in list(ref.mom_dis.parameters()) + list(ref.mom_fc.parameters()):
+        p.requires_grad_(False)
+    ref.synchronize_parameters()
+    ropt = torch.optim.Adam([p for p in ref.parameters() if p.requires_grad], lr=1e-2)
+    for _ in range(2):
+        loss = CrossEntropy()(ref(feats, momentum=False), soft)
+        ropt.zero_grad()
+        loss.backward()
+        ropt.step()
+        ref.momentum_update()
+    rflat = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
+    assert torch.allclose(flat, rflat, atol=2e-5), (flat - rflat).abs().max()
+
+
 def worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -65,28 +169,22 @@ def worker(rank, world, port, out_dir):
     from aadg_amd.data import transform as T
     from oracle import oracle as O
     _lib.aug_u8_forward = oracle_materialize          # test-only: CPU checker stands in for the HIP launch
-    D, B, M, size, crop = 3, 2, 4, 24, 24
-    N = D * B * M
+    D, B, M, size, crop = 3, 2, 6, 24, 24             # 18 (domain, policy) units: uneven over 4 ranks (5/5/4/4)
     # single-process truth (every rank computes it: shard = whole)
     T.set_row_shard(0, 1)
     full = T.train_dg_collate_fn(build_batch(11, D, B, M, size, crop))
-    # sharded run: same seeds -> same plan, local slice only
-    T.set_row_shard(rank, world)
-    part = T.train_dg_collate_fn(build_batch(11, D, B, M, size, crop))
-    lo, hi, n_rows = part['rows']
-    assert (lo, hi) == adist.shard_rows(N) and n_rows == N and part['aug_images'].shape[0] == N // world
-    assert torch.equal(part['aug_images'], full['aug_images'][lo:hi])
-    assert torch.equal(part['aug_labels'], full['aug_labels'][lo:hi])
-    assert torch.equal(part['dc'], full['dc'][lo:hi])
-    # the one exchange step: all-gather of the local embeddings, then the reward on the full matrix
-    fe_local = embed(part['aug_images'])
-    fe_all = adist.all_gather([fe_local])[0]
-    assert torch.equal(fe_all, embed(full['aug_images']))
-    rewards = O.sinkhorn_rewards(fe_all.numpy(), D, B, M)
-    truth = O.sinkhorn_rewards(embed(full['aug_images']).numpy(), D, B, M)
-    assert np.array_equal(rewards, truth)
-    gathered = adist.all_gather([torch.from_numpy(rewards)])[0].view(world, M)
-    assert all(torch.equal(gathered[0], gathered[r]) for r in range(world))     # identical on every rank
+    assert not full['plan'].sharded and full['aug_images'].shape[0] == D * B * M
+    for law in ('unit', 'row'):
+        part = check_plan(rank, world, law, D, B, M, size, crop, full, O, adist, T)
+    check_discriminator(rank, world, D, part['plan'])
+    # test batches are NOT sharded: every rank scores the whole test set (validate() then agrees everywhere)
+    T.set_row_shard(rank, world, 'unit')
+    tb = build_batch(11, D, B, M, size, crop)
+    items = [{k: v for k, v in item[0].items() if k not in ('aug_images', 'aug_labels', 'dc_single')} for item in tb]
+    for it in items:
+        it['dc'] = it['dc'][0]
+    test = T.test_dg_collate_fn(items)
+    assert test['image'].shape[0] == B and 'plan' not in test
     # list helpers
     t = [torch.full((3,), float(rank + 1)), torch.full((2, 2), float(rank))]
     adist.all_reduce(t, average=True)
@@ -94,26 +192,17 @@ def worker(rank, world, port, out_dir):
     # replicated controller: rank 0's policies are authoritative
     from helpers import Cfg
     from aadg_amd.models.controller import Controller
-    cfg = Cfg(M=M)
+    cfg = Cfg(M=4)
     cfg.CONTROLLER.T, cfg.CONTROLLER.C = 2, 2.5
     torch.manual_seed(1023)
     ctrl = Controller(cfg)
     torch.manual_seed(100 + rank)                      # deliberately different draws per rank
+    M = 4
     policies, _, _, log_probs, _ = ctrl(M)
     dist.broadcast(policies, 0)
     lp = ctrl.evaluate(policies, M)
     all_lp = adist.all_gather([lp.detach()])[0].view(world, M)
     assert all(torch.allclose(all_lp[0], all_lp[r], atol=1e-6) for r in range(world))
-    # gradient all-reduce: DDP over gloo averages the row-sharded losses to the global mean
-    torch.manual_seed(5)
-    lin = torch.nn.Linear(8, 1)
-    ddp = torch.nn.parallel.DistributedDataParallel(lin)
-    x = torch.arange(N * 8, dtype=torch.float32).view(N, 8) / 100.0
-    ddp(x[lo:hi]).mean().backward()
-    ref = torch.nn.Linear(8, 1)
-    ref.load_state_dict(lin.state_dict())
-    ref(x).mean().backward()
-    assert torch.allclose(lin.weight.grad, ref.weight.grad, atol=1e-6)
     open(os.path.join(out_dir, "ok_%d" % rank), "w").write("ok")
     dist.destroy_process_group()
 

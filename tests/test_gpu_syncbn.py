@@ -1,0 +1,127 @@
+"""GPU: synchronised BatchNorm statistics (aadg_bn_sync_forward / aadg_bn_sync_backward) -- the all-reduce sits
+between the HIP statistics and elementwise kernels.  Two data-parallel "ranks" are played in ONE process: the all-reduce
+hook (_lib.BN_SYNC_REDUCE) first records each rank's local sums, then replays the other rank's record as the reduction.
+The truth is the ordinary (single-device) kernel on the concatenated batch: same y, same dx, same running statistics;
+parameter gradients are LOCAL sums (DDP averages them), so they must add up to the full-batch ones."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class TwoRanks(object):
+    """Plays the collective for `n` ranks visited one after the other: pass 'record' leaves the local sums in place and
+    remembers them; pass 'reduce' adds the other ranks' remembered sums of the same call."""
+
+    def __init__(self, hip, n):
+        self.hip, self.n = hip, n
+        self.book = {}
+        self.mode, self.rank, self.call = 'record', 0, 0
+
+    def start(self, mode, rank):
+        self.mode, self.rank, self.call = mode, rank, 0
+
+    def __call__(self, t):
+        key = self.call
+        self.call += 1
+        if self.mode == 'record':
+            self.book[(self.rank, key)] = t.clone()
+        else:
+            for r in range(self.n):
+                if r != self.rank:
+                    t += self.book[(r, key)]
+
+
+def _run(hip, fake, phase_fwd, phase_bwd, xs, ress, w, b, act, g_parts, momentum=0.1, eps=1e-5):
+    outs = []
+    for r, x in enumerate(xs):
+        rm, rv = torch.zeros_like(w), torch.ones_like(w)
+        xr = x.detach().clone().requires_grad_(True)
+        rr = ress[r].detach().clone().requires_grad_(True) if ress is not None else None
+        wr, br = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+        fake.start(phase_fwd, r)
+        y = hip.batch_norm_act(xr, wr, br, rm, rv, True, momentum, eps, act, rr, sync=True)
+        outs.append((xr, rr, wr, br, rm, rv, y))
+    if phase_bwd is None:
+        return outs
+    for r, (xr, rr, wr, br, rm, rv, y) in enumerate(outs):
+        fake.start(phase_bwd, r)
+        fake.call = 1000                        # backward calls get their own keys
+        y.backward(g_parts[r])
+    return outs
+
+
+@pytest.mark.parametrize("shape,cut", [((8, 16, 16, 16), 3), ((6, 5, 7, 9), 2), ((4, 64, 32, 32), 2)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act,with_res", [(0, False), (1, False), (2, False), (1, True)])
+def test_sync_bn_equals_full_batch(hip, shape, cut, dtype, act, with_res):
+    torch.manual_seed(sum(shape) + act)
+    N, C, H, W = shape
+    x = (torch.randn(shape, device="cuda") * 2 + 0.5).to(dtype)
+    res = torch.randn(shape, device="cuda").to(dtype) if with_res else None
+    w = torch.rand(C, device="cuda") + 0.5
+    b = torch.randn(C, device="cuda") * (2.0 if act == 2 else 0.3)
+    g = torch.randn(shape, device="cuda").to(dtype)
+    # truth: one device, whole batch
+    xf = x.clone().requires_grad_(True)
+    rf = res.clone().requires_grad_(True) if with_res else None
+    wf, bf = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rm_f, rv_f = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    yf = hip.batch_norm_act(xf, wf, bf, rm_f, rv_f, True, 0.1, 1e-5, act, rf)
+    yf.backward(g)
+    # two uneven ranks
+    xs = [x[:cut].contiguous(), x[cut:].contiguous()]
+    ress = [res[:cut].contiguous(), res[cut:].contiguous()] if with_res else None
+    gs = [g[:cut].contiguous(), g[cut:].contiguous()]
+    fake = TwoRanks(hip, 2)
+    saved = hip.BN_SYNC_REDUCE
+    hip.BN_SYNC_REDUCE = fake
+    try:
+        _run(hip, fake, 'record', None, xs, ress, w, b, act, gs)                  # forward sums of both ranks
+        _run(hip, fake, 'reduce', 'record', xs, ress, w, b, act, gs)              # true forward; backward sums of both ranks
+        outs = _run(hip, fake, 'reduce', 'reduce', xs, ress, w, b, act, gs)       # true forward and backward
+    finally:
+        hip.BN_SYNC_REDUCE = saved
+    lo = dtype == torch.bfloat16
+    y = torch.cat([o[6] for o in outs]).float()
+    dx = torch.cat([o[0].grad for o in outs]).float()
+    # identical statistics -> identical elementwise arithmetic; the sums differ only in float64 summation order
+    assert (y - yf.float()).abs().max().item() <= (2e-2 if lo else 2e-5)
+    assert ((y - yf.float()).abs() > 1e-6).float().mean().item() <= (2e-3 if lo else 1.0)
+    d = (dx - xf.grad.float()).abs()
+    assert d.max().item() <= (5e-2 if lo else 2e-4)
+    for o in outs:                                                                  # every rank holds the GLOBAL running statistics
+        assert torch.allclose(o[4], rm_f, atol=1e-6) and torch.allclose(o[5], rv_f, rtol=1e-5, atol=1e-6)
+    dw = outs[0][2].grad + outs[1][2].grad
+    db = outs[0][3].grad + outs[1][3].grad
+    scale = max(1.0, (N * H * W) ** 0.5)
+    assert (dw - wf.grad).abs().max().item() <= (0.02 * scale if lo else 2e-3)
+    assert (db - bf.grad).abs().max().item() <= (0.02 * scale if lo else 2e-3)
+    if with_res:
+        dr = torch.cat([o[1].grad for o in outs]).float()
+        assert ((dr - rf.grad.float()).abs() > 1e-6).float().mean().item() <= (2e-3 if lo else 1e-6)
+
+
+def test_sync_bn_single_rank_is_the_plain_kernel(hip):
+    """World size 1: the 'all-reduce' is the identity and the synchronised path must reproduce the plain one."""
+    torch.manual_seed(0)
+    x = torch.randn(5, 12, 24, 24, device="cuda").to(torch.bfloat16)
+    w, b = torch.rand(12, device="cuda") + 0.5, torch.randn(12, device="cuda")
+    g = torch.randn_like(x)
+    outs = []
+    saved = hip.BN_SYNC_REDUCE
+    hip.BN_SYNC_REDUCE = lambda t: None
+    try:
+        for sync in (False, True):
+            xr = x.clone().requires_grad_(True)
+            wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            rm, rv = torch.zeros(12, device="cuda"), torch.ones(12, device="cuda")
+            y = hip.batch_norm_act(xr, wr, br, rm, rv, True, 0.1, 1e-5, 1, None, sync=sync)
+            y.backward(g)
+            outs.append((y, xr.grad, wr.grad, br.grad, rm, rv))
+    finally:
+        hip.BN_SYNC_REDUCE = saved
+    a, s = outs
+    assert torch.equal(a[0], s[0]) and torch.equal(a[1], s[1])
+    assert torch.allclose(a[2], s[2], rtol=1e-6, atol=1e-6) and torch.allclose(a[3], s[3], rtol=1e-6, atol=1e-6)
+    assert torch.equal(a[4], s[4]) and torch.equal(a[5], s[5])

@@ -112,12 +112,43 @@ def test_reference_style_yaml_configs_load_unchanged():
 
 def test_shard_rows_law():
     from aadg_amd.distributed import shard_rows
-    for G in (1, 2, 3, 4, 6, 8):
+    for G in (1, 2, 3, 4, 5, 6, 8):
         spans = [shard_rows(144, r, G) for r in range(G)]
         assert spans[0][0] == 0 and spans[-1][1] == 144
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_row_plan_placement_laws():
+    """SURVEY 8e: domain-major (domain, policy) units cut contiguously -- G = 3: one domain per GPU; G = 4: 5/5/4/4 units;
+    G = 8: 3/3/2/2/2/2/2/2 units ('unit') or 18 rows each ('row'); `take` restores collate order; weights sum to G."""
+    import numpy as np
+    from aadg_amd.distributed import RowPlan
+    D, B, M = 3, 8, 6
+    N = D * B * M
+    one = RowPlan(D, B, M)
+    assert not one.sharded and np.array_equal(one.rows, np.arange(N)) and one.loss_weight == 1.0
+    for law in ('unit', 'row'):
+        for G in (2, 3, 4, 8):
+            plans = [RowPlan(D, B, M, r, G, law) for r in range(G)]
+            rows = np.concatenate([p.rows for p in plans])
+            assert np.array_equal(np.sort(rows), np.arange(N))
+            assert abs(sum(p.loss_weight for p in plans) - G) < 1e-12
+            # emulate the padded all-gather: rank r's rows land at r * max_count + i
+            flat = np.full(G * plans[0].max_count, -1, np.int64)
+            for r, p in enumerate(plans):
+                flat[r * p.max_count:r * p.max_count + p.n_local] = p.rows
+            assert np.array_equal(flat[plans[0].take], np.arange(N))
+            if G == 3:
+                for r, p in enumerate(plans):
+                    assert {d for d, _ in p.units()} == {r}            # one source domain per GPU
+                    assert np.array_equal(np.sort(p.rows) // M % D, np.full(p.n_local, r))
+    assert [c // B for c in RowPlan(D, B, M, 0, 4, 'unit').counts] == [5, 5, 4, 4]
+    assert [c // B for c in RowPlan(D, B, M, 0, 8, 'unit').counts] == [3, 3, 2, 2, 2, 2, 2, 2]
+    assert RowPlan(D, B, M, 0, 8, 'row').counts == [18] * 8 and RowPlan(D, B, M, 0, 4, 'row').counts == [36] * 4
     with pytest.raises(ValueError):
-        shard_rows(144, 0, 5)
+        RowPlan(D, B, M, 0, 19, 'unit')
 
 
 def test_separable_conv_folds_a_dilation_that_reaches_past_the_map():
