@@ -3,7 +3,8 @@ load_ddp_controller :73-118, load_ddp_discriminator :134-179, class/domain/chann
 
 Differences that are design, not omission:
   * the backbone is our own torch.nn DeepLabV3+ (deeplab.py) -- smp is not in this image;
-    `MODEL.BACKBONE: resnet50` is accepted in addition to `mobilenet_v2`, `MODEL.NAME: unet` for config 0;
+    `MODEL.BACKBONE: resnet50` is accepted in addition to `mobilenet_v2`, `MODEL.NAME: unet` for config 0,
+    `MODEL.NAME: segformer` / `MODEL.BACKBONE: mit_b2` (models/segformer.py) for config 4;
   * data parallelism is NOT "split TRAIN.BATCH_SIZE across DDP replicas" but row sharding of the N =
     D*B*M augmented images (aadg_amd/distributed.py); the model is still wrapped in DDP (RCCL bucketed
     all-reduce overlapped with backward), the controller is replicated deterministically (identical
@@ -14,6 +15,7 @@ import torch
 from .controller import Controller
 from .deeplab import DeepLabV3Plus, UNetSmall
 from .discriminator import FeatureDiscriminator, MomentumFeatureDiscriminator
+from .segformer import SegFormer
 
 
 def class_parser(dataset):
@@ -30,7 +32,7 @@ def domain_parser(dataset, cfg=None):
 
 
 def channel_parser(backbone):
-    return {'mobilenet_v2': 1280, 'resnet50': 2048, 'unet': 128}[backbone]
+    return {'mobilenet_v2': 1280, 'resnet50': 2048, 'unet': 128, 'mit_b2': 512}[backbone]
 
 
 def _device(args):
@@ -56,6 +58,10 @@ def build_model(cfg):
         return DeepLabV3Plus(backbone, classes, aux_pooling='feature' in cfg.DISCRIMINATOR.NAME)
     if name == 'unet':
         return UNetSmall(classes)
+    if name == 'segformer':
+        # BASELINE configs[4]; the reference's wrapper picks the variant from MODEL.PRETRAINED_WEIGHTS (models/segformer.py:12-55)
+        assert backbone in ['mit_b2'] or 'mit_b2' in cfg.MODEL.PRETRAINED_WEIGHTS
+        return SegFormer(classes, aux_pooling='feature' in cfg.DISCRIMINATOR.NAME)
     raise NotImplementedError(name + ' has not been implemented!')
 
 
@@ -93,7 +99,7 @@ def load_ddp_discriminator(ngpus_per_node, args, cfg):
     print("=> creating discriminator '{}'".format(name))
     dev = _device(args)
     num_classes = domain_parser(cfg.DATASET.NAME, cfg)
-    in_channels = channel_parser('unet' if cfg.MODEL.NAME == 'unet' else cfg.MODEL.BACKBONE)
+    in_channels = channel_parser({'unet': 'unet', 'segformer': 'mit_b2'}.get(cfg.MODEL.NAME, cfg.MODEL.BACKBONE))
     if name == 'feature':
         model = FeatureDiscriminator(num_classes, in_channels)
     elif name == 'momentum_feature':

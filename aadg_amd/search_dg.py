@@ -127,7 +127,8 @@ def inner_iteration(config, sample, model, discriminator, dis_criterion, model_o
         fe_all = plan.gather(fe_all, emulate=emulate)
     before = rewards.clone()
     B = n_rows // (M * n_domains)
-    _lib.sinkhorn_rewards(fe_all, n_domains, B, M, rewards=rewards)
+    if n_domains >= 2:                                   # a single source domain has no domain pair to compare (BASELINE configs[0])
+        _lib.sinkhorn_rewards(fe_all, n_domains, B, M, rewards=rewards)
     diversity_ot = (rewards - before).sum()
     if after_rewards is not None:
         after_rewards()
@@ -179,6 +180,8 @@ def train(config, train_loader, model, discriminator, model_criterion, dis_crite
         end = time.time()
     global LAST_RAW_REWARDS
     LAST_RAW_REWARDS = rewards                      # diagnostics / tests: the epoch's accumulated Sinkhorn sums before normalisation
+    if M < 2:
+        return torch.zeros_like(rewards)            # one policy (fixed-policy plumbing case): the unbiased std of one value is undefined
     return _lib.normalize_rewards(rewards)          # (r - mean) / (std + 1e-5), search_dg.py:214
 
 
@@ -237,7 +240,7 @@ class SearchState(object):
         # launch-bound controller sample / PPO update: fused HIP kernels (csrc/controller.hip) for PPO, else replayed as
         # two HIP graphs (models/graphed.py)
         self.graphed = None
-        if torch.cuda.is_available() and getattr(args, 'controller_graphs', True):
+        if torch.cuda.is_available() and getattr(args, 'controller_graphs', True) and not getattr(args, 'fixed_policy', False):
             from .models.graphed import make_controller_step
             self.graphed = make_controller_step(self.controller, self.controller_criterion, self.controller_optimizer, self.M,
                                                 fused=getattr(args, 'controller_fused', True))
@@ -274,6 +277,8 @@ class SearchState(object):
         policies (a full pipeline drain when it sat between two epochs) then waits only for the forward pass, and the host
         parses / draws the next batch plan while the GPU is still busy with the backward.  Same arithmetic, same random
         streams (the backward consumes no random numbers)."""
+        if getattr(self.args, 'fixed_policy', False):
+            return self._fixed_policy_step(epoch, writer_dict, logger, max_iters)
         self.controller.train()
         nxt, self._prefetched = getattr(self, '_prefetched', None), None
         policies, op_probs, mag_probs, log_probs, entropies, host_policies = nxt if nxt is not None else self._sample_policies()
@@ -303,6 +308,25 @@ class SearchState(object):
         if losses is None:
             losses = self.controller_criterion(self.controller, policies, log_probs, entropies, normalized_rewards)
         return parsed, op_probs, mag_probs, normalized_rewards, losses
+
+
+FIXED_POLICY = [('Contrast', 0.5), ('Sharpness', 0.5)]      # the fixed sub-policy of the no-search plumbing case
+
+
+def _fixed_policy_step(self, epoch, writer_dict=None, logger=None, max_iters=None):
+    """BASELINE configs[0] ("fixed policy, no controller search"): the epoch body without the controller -- every one of the M
+    policies is the single sub-policy FIXED_POLICY, no sampling, no PPO update; the inner loop itself is unchanged."""
+    parsed = [[list(FIXED_POLICY)] for _ in range(self.M)]
+    self.train_loader.dataset.transforms.transforms[0] = DGMultiPolicy(parsed)
+    normalized_rewards = train(self.config, self.train_loader, self.model, self.discriminator, self.model_criterion,
+                               self.dis_criterion, self.model_optimizer, self.dis_optimizer, self.M, epoch, writer_dict, logger,
+                               self.args, max_iters)
+    _bare(self.discriminator).momentum_update()
+    zero = torch.zeros((), device=normalized_rewards.device)
+    return parsed, None, None, normalized_rewards, (zero, zero, zero)
+
+
+SearchState._fixed_policy_step = _fixed_policy_step
 
 
 def search_seg_dg_policy(gpu, ngpus_per_node, config, args):
@@ -342,8 +366,9 @@ def search_seg_dg_policy(gpu, ngpus_per_node, config, args):
             best_metric = {'epoch': epoch + 1, 'avg_dsc': dsc, 'cup_dsc': cup_dsc, 'disc_dsc': disc_dsc,
                            'avg_hd': hd, 'cup_hd': cup_hd, 'disc_hd': disc_hd}
         if main and searching:
-            mag_probs_trajectory.append(mag_probs.detach().cpu().numpy())
-            op_probs_trajectory.append(op_probs.detach().cpu().numpy())
+            if op_probs is not None:                                    # None: fixed policy, no controller statistics
+                mag_probs_trajectory.append(mag_probs.detach().cpu().numpy())
+                op_probs_trajectory.append(op_probs.detach().cpu().numpy())
             logger.info('Train Epoch {}: controller loss:{:.4f} score loss:{:.4f} entropy penalty:{:.4f}'.format(
                 epoch, controller_loss.item(), score_loss.item(), entropy_penalty.item()))
             utils.save_checkpoint({"state_dict": _bare(st.model), "epoch": epoch + 1, "best_dsc": best_dsc,

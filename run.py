@@ -2,7 +2,8 @@
 [--mode search] [--gpu N] [--multiprocessing_distributed] [--dist_backend nccl] [--dist_url ...] ...
 
 Extra, optional flags (not in the reference): --crop_size (the reference hard-codes 256),
---backbone_dtype {fp32,bf16}, --max_epochs / --epoch_items (short synthetic runs)."""
+--backbone_dtype {fp32,bf16}, --max_epochs / --epoch_items (short synthetic runs), --sync_bn / --placement (multi-GPU),
+--fixed_policy (BASELINE configs[0])."""
 import argparse
 import sys
 
@@ -31,6 +32,10 @@ def parse_args(argv=None):
     parser.add_argument('--crop_size', default=256, type=int)
     parser.add_argument('--backbone_dtype', default='fp32', choices=['fp32', 'bf16'])
     parser.add_argument('--sync_bn', action='store_true', help='SyncBatchNorm over the row-sharded ranks')
+    parser.add_argument('--placement', default='unit', choices=['unit', 'row'],
+                        help='multi-GPU: whole (domain, policy) units per rank (SURVEY 8e) or the same sequence balanced to the row')
+    parser.add_argument('--fixed_policy', action='store_true',
+                        help='no controller search: every policy is [Contrast .5, Sharpness .5] (BASELINE configs[0])')
     parser.add_argument('--max_epochs', default=None, type=int)
     parser.add_argument('--epoch_items', default=32, type=int)
     return parser.parse_args(argv)

@@ -303,8 +303,84 @@ def gen_functional():
     np.savez_compressed(os.path.join(OUT, "functional.npz"), **out)
 
 
+def gen_operations():
+    """`_Operation.forward` (data/operations.py:73-100) of every module whose arithmetic lives in the reference itself (the kornia
+    geometric ops and Hue are not fixture material), in training mode (RelaxedBernoulli mask blend) and eval mode (Bernoulli
+    mask, in-place on the selected samples).  The random draws are FIXED and recorded -- the mask returned by get_mask(), the
+    0/1 draw behind the magnitude sign flip (torch.randint) and SamplePairing's permutation (torch.randperm := next sample,
+    cyclic) -- because the
+    CPU and GPU generators produce different streams; the test injects the same values."""
+    import torch
+    from data import operations as RO
+    out = {}
+    torch.manual_seed(4242)
+    B = 4
+    img = torch.rand(B, 3, 16, 16)
+    img[0, :, :5, :5] = 0.0
+    img[2, 2] *= 0.4
+    out["img"] = img.numpy().copy()
+    names = ["Invert", "Solarize", "Posterize", "Gray", "Contrast", "AutoContrast", "Saturate", "Brightness", "SamplePairing",
+             "Equalize", "Sharpness", "HorizontalFlip", "VerticalFlip"]
+    soft_mask = torch.tensor([0.02, 0.97, 0.5, 0.8]).view(B, 1, 1, 1)           # what RelaxedBernoulli(T=0.1) typically returns
+    hard_masks = [torch.tensor([1., 0., 1., 1.]), torch.tensor([0., 0., 0., 0.]), torch.tensor([1., 1., 1., 1.])]
+    signs01 = torch.tensor([1., 0., 0., 1.])
+    real_randint, real_randperm = torch.randint, torch.randperm
+    keys = []
+    try:
+        torch.randint = lambda *a, **k: signs01.clone()
+        torch.randperm = lambda n, **k: (torch.arange(n) + 1) % n          # SamplePairing's partner: the next sample (cyclic)
+        for name in names:
+            cls = getattr(RO, name)
+            for ci, (mag0, prob0) in enumerate(((0.3, 0.5), (0.8, 0.9), (1.3, 0.1))):
+                try:
+                    op = cls(initial_magnitude=mag0, initial_probability=prob0)
+                    has_mag = True
+                except TypeError:
+                    op = cls(initial_probability=prob0)
+                    has_mag = False
+                if not has_mag and ci > 0:
+                    continue
+                for mode in (("train", "eval0", "eval1", "eval2"), ("train", "eval0"), ("train",))[ci]:
+                    if mode == "train":
+                        op.train()
+                        mask = soft_mask.clone()
+                    else:
+                        op.eval()
+                        mask = hard_masks[int(mode[-1])].view(B, 1, 1, 1).clone()
+                    op.get_mask = lambda batch_size=None, m=mask: m.clone()
+                    with torch.no_grad():
+                        res = op(img.clone())
+                    key = "%s_%d_%s" % (name, ci, mode)
+                    keys.append(key)
+                    out[key] = res.numpy().copy()
+                    out[key + "_mask"] = mask.numpy().copy()
+                    out[key + "_cfg"] = np.array([mag0 if has_mag else np.nan, prob0], np.float64)
+    finally:
+        torch.randint, torch.randperm = real_randint, real_randperm
+    out["signs01"] = signs01.numpy()
+    out["perm_rule"] = np.array("randperm(n) := (arange(n) + 1) % n")
+    out["keys"] = np.array(keys)
+    # the straight-through estimator (data/functional.py:21-46): forward value, gradient routing and sum_to_size
+    from data import functional as RF
+    a = torch.rand(3, 2, 4, 5)
+    bparam = torch.rand(3, 1, 1, 1, requires_grad=True)
+    y = RF.ste(a, bparam)
+    g = torch.rand_like(y)
+    y.backward(g)
+    out["ste_a"], out["ste_b"], out["ste_y"], out["ste_g"], out["ste_grad_b"] = (a.numpy(), bparam.detach().numpy(), y.detach().numpy(),
+                                                                              g.numpy(), bparam.grad.numpy())
+    # solarize / posterize route the gradient to the magnitude through ste (data/functional.py:163,181)
+    m = torch.tensor([0.4, 0.7, 0.2, 0.9], requires_grad=True)
+    r = RF.solarize(img.clone(), m)
+    gg = torch.rand_like(r)
+    r.backward(gg)
+    out["sol_mag"], out["sol_out"], out["sol_g"], out["sol_grad_mag"] = m.detach().numpy(), r.detach().numpy(), gg.numpy(), m.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "operations.npz"), **out)
+
+
 if __name__ == "__main__":
     install_stubs()
+    gen_operations()
     gen_functional()
     gen_ops()
     gen_parse()

@@ -100,3 +100,23 @@ def test_oracle_vs_live_pillow(oracle):
             w, h = int(rs.uniform(0.5, 2) * W), int(rs.uniform(0.5, 2) * H)
             assert np.array_equal(np.asarray(pil.resize((w, h), Image.BILINEAR)), oracle.resize_bilinear(a, w, h))
             assert np.array_equal(np.asarray(pm.resize((w, h), Image.NEAREST)), oracle.resize_nearest(m, w, h))
+
+
+def test_ste_and_operation_parameters_vs_reference_golden():
+    """`ste` (data/functional.py:21-46) is pure torch: forward value, gradient routed to the second argument and summed to its
+    shape -- against the reference's own outputs; `_Operation` magnitude = clamp(_magnitude, range) * scale
+    (data/operations.py:110-119) and the registered parameters / buffers."""
+    import torch
+    from aadg_amd.data import functional as Fn
+    from aadg_amd.data import operations as Ops
+    z = np.load(os.path.join(GOLDEN, "operations.npz"))
+    a = torch.from_numpy(z["ste_a"])
+    b = torch.from_numpy(z["ste_b"]).requires_grad_(True)
+    y = Fn.ste(a, b)
+    assert np.array_equal(y.detach().numpy(), z["ste_y"])
+    y.backward(torch.from_numpy(z["ste_g"]))
+    assert np.abs(b.grad.numpy() - z["ste_grad_b"]).max() <= 1e-5
+    op = Ops.Contrast(initial_magnitude=1.3, initial_probability=0.1)
+    assert float(op.magnitude) == 1.0 and float(op.probability) == pytest.approx(0.1)
+    assert set(dict(op.named_parameters())) == {"_magnitude", "_probability"} and "temperature" in dict(op.named_buffers())
+    assert Ops.Sharpness().kernel.shape == (3, 3) and Ops.Invert()._magnitude is None

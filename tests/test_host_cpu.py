@@ -101,7 +101,7 @@ def test_reference_style_yaml_configs_load_unchanged():
         a.cfg = f
         update_config(cfg, a)
         assert cfg.is_frozen() and cfg.SEED == 1023 and cfg.OUTPUT_DIR == "out"
-        assert cfg.CONTROLLER.M == 6 and cfg.DATASET.NAME in ("optic", "rvs")
+        assert cfg.CONTROLLER.M == (1 if "fixed" in f else 6) and cfg.DATASET.NAME in ("optic", "rvs")
         with pytest.raises(AttributeError):
             cfg.SEED = 1
         cfg.CONTROLLER.EXCLUDE_OPS.append("x")  # list mutation is allowed on a frozen node, as in yacs
