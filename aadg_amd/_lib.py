@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libaadg_hip.so")
+LIB_PATH = os.environ.get("AADG_LIB_PATH") or os.path.join(_HERE, "lib", "libaadg_hip.so")     # (override: kernel experiments)
 MAX_OPS = 4
 
 # mirror of `aadg_unit` (include/aadg_hip.h); 140 bytes, no padding
@@ -28,7 +28,7 @@ DATASET_OPTIC, DATASET_VESSEL = 0, 1
 # every symbol include/aadg_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "aadg_abi_version",
-    "aadg_aug_u8_workspace_bytes", "aadg_aug_u8_forward", "aadg_aug_u8_forward_ex", "aadg_op_u8",
+    "aadg_aug_u8_workspace_bytes", "aadg_aug_u8_forward", "aadg_aug_u8_forward_ex", "aadg_aug_u8_forward_ex2", "aadg_op_u8",
     "aadg_sinkhorn_workspace_bytes", "aadg_sinkhorn_divergence_f32", "aadg_sinkhorn_rewards_f32",
     "aadg_normalize_rewards_f32",
     "aadg_seg_loss_workspace_bytes", "aadg_seg_bce_dice_f32",
@@ -71,6 +71,8 @@ def load():
     lib.aadg_aug_u8_forward.argtypes = [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]
     lib.aadg_aug_u8_forward_ex.restype = _i
     lib.aadg_aug_u8_forward_ex.argtypes = lib.aadg_aug_u8_forward.argtypes + [_i, _i, _vp, _vp]
+    lib.aadg_aug_u8_forward_ex2.restype = _i
+    lib.aadg_aug_u8_forward_ex2.argtypes = lib.aadg_aug_u8_forward_ex.argtypes + [_vp, _i, _i, _i]
     lib.aadg_op_u8.restype = _i
     lib.aadg_op_u8.argtypes = [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp]
     lib.aadg_sinkhorn_workspace_bytes.restype = _sz
@@ -261,7 +263,9 @@ def validate_units(units, P, Hs, Ws):
 
 
 def launch_hints(units, Hs, Ws, crop):
-    """(classes, stats_mask) for aadg_aug_u8_forward_ex -- mirrors unit_fusable() in csrc/aug_u8.hip."""
+    """(classes, stats_mask, order, counts) for aadg_aug_u8_forward_ex2 -- mirrors unit_flow() in csrc/aug_u8.hip.
+    order: unit indices grouped by tile class (plain up-scaling, up-scaling with a Sharpness stencil, generic, staged);
+    counts = (n_plain, n_sharp, n_generic)."""
     n_ops = units["n_ops"]
     live = np.arange(MAX_OPS)[None, :] < n_ops[:, None]
     sharp = ((units["op"] == 8) & (units["farg"] != np.float32(1.0)) & live).sum(axis=1)
@@ -277,7 +281,10 @@ def launch_hints(units, Hs, Ws, crop):
     for k in range(MAX_OPS):
         if needs[:, k].any():
             stats_mask |= 1 << k
-    return classes, stats_mask
+    cls = np.where(up & (sharp == 0), 0, np.where(up, 1, np.where(generic, 2, 3)))
+    order = np.argsort(cls, kind="stable").astype(np.int32)
+    counts = (int((cls == 0).sum()), int((cls == 1).sum()), int((cls == 2).sum()))
+    return classes, stats_mask, order, counts
 
 
 # optional (start, stop) torch.cuda.Event pair recorded around the dominant kernel of the next
@@ -286,10 +293,13 @@ PROFILE_EVENTS = None
 _pinned = {}
 
 
+_REC = UNIT_DTYPE.itemsize + 4          # staging bytes per unit: the record + its slot in the class-order list
+
+
 def _pinned_units(n):
     buf = _pinned.get("units")
-    if buf is None or buf.shape[0] < n:
-        buf = torch.empty((max(n, 256), UNIT_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
+    if buf is None or buf.numel() < n * _REC:
+        buf = torch.empty(max(n, 256) * _REC, dtype=torch.uint8).pin_memory()
         _pinned["units"] = buf
     return buf
 
@@ -319,21 +329,24 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
     ready = _pinned.get("units_ready")
     if ready is not None:
         ready.synchronize()          # previous copy out of the staging buffer has completed
-    stage[:N].numpy()[...] = units.view(np.uint8).reshape(N, UNIT_DTYPE.itemsize)
-    d_units = torch.empty((N, UNIT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-    d_units.copy_(stage[:N], non_blocking=True)
+    classes, stats_mask, order, (n_plain, n_sharp, n_generic) = launch_hints(units, Hs, Ws, crop)
+    nb_units = N * UNIT_DTYPE.itemsize                       # a multiple of 4: the int32 list behind it is aligned
+    host = stage[:N * _REC].numpy()
+    host[:nb_units] = units.view(np.uint8).reshape(-1)
+    host[nb_units:] = order.view(np.uint8)
+    d_units = torch.empty(N * _REC, dtype=torch.uint8, device=dev)
+    d_units.copy_(stage[:N * _REC], non_blocking=True)          # records + class lists: one H2D copy
     ready = torch.cuda.Event()
     ready.record()
     _pinned["units_ready"] = ready
     nb = lib.aadg_aug_u8_workspace_bytes(N, Hs, Ws, crop)
     ws = workspace(nb, dev, "aug")
-    classes, stats_mask = launch_hints(units, Hs, Ws, crop)
     ev0 = ev1 = 0
     if PROFILE_EVENTS is not None:
         ev0, ev1 = PROFILE_EVENTS[0].cuda_event, PROFILE_EVENTS[1].cuda_event
-    rc = lib.aadg_aug_u8_forward_ex(pool.data_ptr(), masks.data_ptr(), P, Hs, Ws, d_units.data_ptr(), N, max_ops, crop,
-                                    dataset, out_img.data_ptr(), out_lbl.data_ptr(), ws.data_ptr(), ws.numel(), _stream(),
-                                    classes, stats_mask, ev0, ev1)
+    rc = lib.aadg_aug_u8_forward_ex2(pool.data_ptr(), masks.data_ptr(), P, Hs, Ws, d_units.data_ptr(), N, max_ops, crop,
+                                     dataset, out_img.data_ptr(), out_lbl.data_ptr(), ws.data_ptr(), ws.numel(), _stream(),
+                                     classes, stats_mask, ev0, ev1, d_units.data_ptr() + nb_units, n_plain, n_sharp, n_generic)
     _check(rc, "aadg_aug_u8_forward")
     d_units.record_stream(torch.cuda.current_stream())
     return out_img, out_lbl

@@ -625,7 +625,9 @@ __device__ __forceinline__ uint32_t pointwise_op(const aadg_unit& un, int j, uin
 // Loads the patch (12-byte vector loads, all issued up front), applies the leading pointwise ops while the
 // pixels are still in registers, stores RGBX words to LDS; every Sharpness op then costs one LDS ping-pong
 // pass, after which the pointwise ops that follow it run in place on the lane's own pixels.
-template <int NR, bool WIDE>
+// WMODE: how columns >= 256 of a patch wider than 256 pixels are fetched: 0 = never wider; 1 = a second group of registers per lane
+// (lanes 0..2 use it); 2 = a small trailing pass by the first 4 * rows threads (3 registers instead of 3 * NR)
+template <int NR, int WMODE>
 __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, const uint8_t* __restrict__ src, int Hs, int Ws,
                                  int r_lo, int r_hi, int c_lo, int c_hi, uint32_t* A, uint32_t* B,
                                  const uint8_t* __restrict__ lut, size_t lut_stage_stride, int u, uint8_t* sl_all) {
@@ -644,26 +646,35 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
     // thread <-> (row = wave + 4k, group of 4 pixels = lane (+64)): no integer divisions.  All loads of this
     // thread are issued before the first use.
     const int lane = tid & 63, wv = tid >> 6;
-    // NR = rows per wave (4 * NR >= patch rows); WIDE = patch may be wider than 256 pixels (second group per lane)
-    constexpr int NW = WIDE ? NR : 1;
+    // NR = rows per wave (4 * NR >= patch rows); WIDE = patch may be wider than 256 pixels
+    constexpr bool WIDE = WMODE != 0;
+    constexpr int NW = WMODE == 1 ? NR : 1;
     uint32_t ra[NR], rb[NR], rc[NR], rd[NW], re[NW], rf[NW];
-    const bool has2 = WIDE && lane + 64 < q4;
+    const bool has2 = WMODE == 1 && lane + 64 < q4;
+    // WMODE 2: thread t < 4 * rows fetches group 64 + (t & 3) of row t >> 2
+    const int trow = tid >> 2, tgrp = 64 + (tid & 3);
+    const bool tail = WMODE == 2 && trow < ph && tgrp < q4;
+    uint32_t wa = 0, wb = 0, wc = 0;
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
         const int row = wv + 4 * k;
         ra[k] = rb[k] = rc[k] = 0;
-        if (WIDE) rd[k % NW] = re[k % NW] = rf[k % NW] = 0;
+        if (WMODE == 1) rd[k % NW] = re[k % NW] = rf[k % NW] = 0;
         if (row < ph) {
             const uint8_t* rowp = src + ((size_t)(r_lo + row) * Ws + c_lo) * 3;
             if (lane < q4) {
                 const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + 12 * lane);
                 ra[k] = p[0]; rb[k] = p[1]; rc[k] = p[2];
             }
-            if (WIDE && has2) {
+            if (WMODE == 1 && has2) {
                 const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + 12 * (lane + 64));
                 rd[k % NW] = p[0]; re[k % NW] = p[1]; rf[k % NW] = p[2];
             }
         }
+    }
+    if (tail) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(src + ((size_t)(r_lo + trow) * Ws + c_lo) * 3 + 12 * tgrp);
+        wa = p[0]; wb = p[1]; wc = p[2];
     }
     if (any_lut) {
 #pragma unroll
@@ -696,7 +707,10 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
         if (row < ph && lane < q4)
             *reinterpret_cast<uint4*>(&A[row * pw + 4 * lane]) = make_uint4(px[k][0], px[k][1], px[k][2], px[k][3]);
     }
-    if (WIDE && has2) {            // patches wider than 256 pixels: lanes 0..2 own a second group per row (rare, small);
+    if (tail)                      // stored raw, the leading ops run on them in LDS below
+        *reinterpret_cast<uint4*>(&A[trow * pw + 4 * tgrp]) =
+            make_uint4(wa & 0xFFFFFFu, (wa >> 24) | ((wb & 0xFFFFu) << 8), (wb >> 16) | ((wc & 0xFFu) << 16), wc >> 8);
+    if (WMODE == 1 && has2) {      // patches wider than 256 pixels: lanes 0..2 own a second group per row (rare, small);
 #pragma unroll                     // stored raw, the leading ops run on them in LDS below
         for (int k = 0; k < NR; ++k) {
             const int row = wv + 4 * k;
@@ -782,7 +796,7 @@ __global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ 
     const int r_lo = max(0, ry0 - s), r_hi = min(Hs, ry1 + s);
     const int c_lo = max(0, cx0 - s) & ~3, c_hi = min(Ws, (cx1 + s + 3) & ~3);
     const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
-    const uint32_t* cur = build_patch<6, true>(un, stage, src, Hs, Ws, r_lo, r_hi, c_lo, c_hi, A, B, lut, lut_stage_stride, u, sl);
+    const uint32_t* cur = build_patch<6, 1>(un, stage, src, Hs, Ws, r_lo, r_hi, c_lo, c_hi, A, B, lut, lut_stage_stride, u, sl);
     const int pw = c_hi - c_lo, rw = cx1 - cx0, n = (ry1 - ry0) * rw;
     unsigned long long lsum = 0;
     for (int i = tid; i < n; i += 256) {
@@ -884,7 +898,7 @@ __device__ __forceinline__ void fused_tile(const uint8_t* __restrict__ pool, con
         const int c_lo_h = max(0, t_clo - s) & ~3, c_hi_h = min(Ws, (c_hi + s + 3) & ~3);
         const int pw = c_hi_h - c_lo_h;
         const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
-        const uint32_t* cur = build_patch<6, true>(un, n_ops, src, Hs, Ws, r_lo_h, r_hi_h, c_lo_h, c_hi_h, A, B, lut, lut_stage_stride, u, sl);
+        const uint32_t* cur = build_patch<6, 1>(un, n_ops, src, Hs, Ws, r_lo_h, r_hi_h, c_lo_h, c_hi_h, A, B, lut, lut_stage_stride, u, sl);
         Hbuf = cur == A ? B : A;
         // ---- horizontal pass ---------------------------------------------------------------------------
         const int nrows = r_hi - r_lo;
@@ -987,11 +1001,12 @@ __device__ __forceinline__ int axis_taps(int inSize, int outSize) {
 }
 
 __global__ __launch_bounds__(256) void k_fused_generic(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
-                                                       const aadg_unit* __restrict__ units, int Hs, int Ws, int crop, int dataset,
+                                                       const aadg_unit* __restrict__ units, const int* __restrict__ order,
+                                                       int Hs, int Ws, int crop, int dataset,
                                                        const int* __restrict__ tab, const uint8_t* __restrict__ lut,
                                                        size_t lut_stage_stride, float* __restrict__ out_img,
                                                        float* __restrict__ out_lbl) {
-    const int u = blockIdx.z;
+    const int u = order != nullptr ? order[blockIdx.z] : blockIdx.z;      // order: the units of this class (caller's list)
     const aadg_unit& un = units[u];
     if (unit_flow(true, un, Hs, Ws, crop) != FLOW_GENERIC) return;
     __shared__ __attribute__((aligned(16))) uint32_t A[PATCH_CAP];
@@ -1061,7 +1076,7 @@ __global__ __launch_bounds__(256) void k_fused_generic(const uint8_t* __restrict
         const int c_lo_h = max(0, c_lo - s) & ~3, c_hi_h = min(Ws, (c_hi + s + 3) & ~3);
         const int pw = c_hi_h - c_lo_h;
         const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
-        const uint32_t* cur = build_patch<11, false>(un, n_ops, src, Hs, Ws, r_lo_h, r_hi_h, c_lo_h, c_hi_h, A, B, lut,
+        const uint32_t* cur = build_patch<11, 0>(un, n_ops, src, Hs, Ws, r_lo_h, r_hi_h, c_lo_h, c_hi_h, A, B, lut,
                                                      lut_stage_stride, u, sl);
         Hbuf = cur == A ? B : A;
         nrows = r_hi - r_lo;
@@ -1161,6 +1176,257 @@ __global__ __launch_bounds__(256) void k_fused(const uint8_t* __restrict__ pool,
                    blockIdx.x, blockIdx.y, A, B, sl, lutf);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_fused3 (round 2): the UP tile of k_fused with a leaner instruction stream and a smaller footprint.
+//   * 39 KiB of LDS (an 18 KiB patch + a 17 KiB buffer for the horizontally resampled rows) and <= 128 VGPRs: 4 workgroups per
+//     CU instead of 3.  Units that chain Sharpness stencils (19 %) need a halo and a ping-pong buffer: their tile is processed
+//     as two 8-row halves that fit the same two buffers;
+//   * the prologue has no conditional load: indices are clamped into the tables, the loads are issued back to back and
+//     validity is applied to the values (conditional loads became branches with a wait at every join: +6 us per tile);
+//   * both fixed-point passes multiply by coefficients scaled by 4 (clamped to 2^24 - 1, which leaves every result unchanged,
+//     see prescale4): the rounded 8-bit result then IS byte 3 of the 32-bit sum, so the horizontal pass packs its three
+//     channels with two v_perm_b32 and the vertical pass turns the sum into an LDS table address with one SDWA shift;
+//   * the mask bytes of a lane's 4 columns lie within 4 consecutive source bytes (scale >= 1): one dword load per row
+//     instead of four byte loads;
+//   * 32-bit offsets from uniform base pointers for the stores.
+// Arithmetic and results are those of k_fused (bit-exact with Pillow), which stays selectable (AADG_FUSED_V1=1).
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((packed)) UnalignedU32 { uint32_t v; };
+constexpr int PATCH_CAP_PLAIN = 4608;     // 17 rows x 264 columns: a 256 x 16 tile's patch without a stencil halo
+constexpr int HBUF_ROWS = FT_H + 1;       // source rows a 16-row tile touches when no axis shrinks
+
+// coefficient k (<= 2^22) -> 4k as an unsigned 24-bit multiplier.  4k = 2^24 only for a single tap of weight one (k1 <= 1):
+// with 2^24 - 1 the sum is c0 * 2^24 + (2^23 + 4 c1 k1 - c0), whose byte 3 is still c0 because 0 < 2^23 + 4 c1 k1 - c0 < 2^24.
+__device__ __forceinline__ uint32_t prescale4(int k) {
+    const uint32_t q = (uint32_t)k << 2;
+    return q > 0xFFFFFFu ? 0xFFFFFFu : q;
+}
+
+// number of Sharpness stencils of a unit, all four op slots read unconditionally (independent scalar loads, one wait)
+__device__ __forceinline__ int sharp_count4(const aadg_unit& un, int n_ops) {
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < AADG_MAX_OPS; ++k) s += (k < n_ops && un.op[k] == AADG_OP_SHARPNESS && un.farg[k] != 1.0f) ? 1 : 0;
+    return s;
+}
+
+template <bool SHARP>
+__device__ __forceinline__ void fused3_body(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
+                                            const aadg_unit* __restrict__ units, int Hs, int Ws, int crop, int dataset,
+                                            const int* __restrict__ tab, const uint8_t* __restrict__ lut, size_t lut_stage_stride,
+                                            float* __restrict__ out_img, float* __restrict__ out_lbl, int u, int half,
+                                            uint32_t* A, uint32_t* B, uint8_t* sl, float* lutf) {
+    const aadg_unit& un = units[u];
+    const int n_ops = un.n_ops;
+    const int w = un.scaled_w, h = un.scaled_h;
+    const int sc_all = sharp_count4(un, n_ops);
+    if ((Ws & 3) || (crop & 3) || sc_all > MAX_SHARP || w < Ws || h < Hs) return;   // unit_flow(...) != FLOW_UP
+    if ((sc_all > 0) != SHARP) return;                      // the other part of the grid owns this unit
+    const int sc = SHARP ? sc_all : 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    lutf[tid] = normalise_u8(tid);
+
+    const int K = dataset == AADG_DATASET_OPTIC ? 2 : 1;
+    const uint32_t plane = (uint32_t)crop * (uint32_t)crop;
+    float* oi = out_img + (size_t)u * 3 * plane;            // uniform bases, 32-bit lane offsets
+    float* ol = out_lbl + (size_t)u * K * plane;
+    const int x0 = blockIdx.x * FT_W, x1 = min(x0 + FT_W, crop);
+    // A unit that chains Sharpness stencils needs a halo and a ping-pong buffer: its tiles are 8 rows high (two workgroups per
+    // 16-row tile), which fits the same two buffers (13 x 268 patch words) instead of a second, larger LDS layout.
+    constexpr int TROWS = SHARP ? FT_H / 2 : FT_H;
+    const int y0 = blockIdx.y * FT_H + half * TROWS, y1 = min(y0 + TROWS, crop);
+    if (y0 >= crop) return;
+    const int ox = un.crop_x - un.pad, oy = un.crop_y - un.pad;
+    const int fx = max(x0, -ox), lx = min(x1 - 1, w - 1 - ox);
+    const int xq = x0 + 4 * lane;                           // vertical pass: lane <-> 4 consecutive columns
+    const bool col_ok = xq < crop;
+    constexpr int RPW = TROWS / 4;                          // rows per wave
+    // rows [ya, yb) of the tile that lie entirely in the zero padding: image = normalise(0), mask = 0
+    auto pad_rows = [&](int ya, int yb) {
+        if (!col_ok) return;
+        const float lab0 = dataset == AADG_DATASET_OPTIC ? 1.0f : 0.0f;      // optic: 0 <= 50 -> cup & disc; vessel: 0 -> background
+        const float4 m1 = make_float4(-1.0f, -1.0f, -1.0f, -1.0f), lb = make_float4(lab0, lab0, lab0, lab0);
+        for (int y = ya + wv; y < yb; y += 4) {
+            const uint32_t off = (uint32_t)y * (uint32_t)crop + (uint32_t)xq;
+            *reinterpret_cast<float4*>(oi + off) = m1;
+            *reinterpret_cast<float4*>(oi + plane + off) = m1;
+            *reinterpret_cast<float4*>(oi + 2 * (size_t)plane + off) = m1;
+            *reinterpret_cast<float4*>(ol + off) = lb;
+            if (K == 2) *reinterpret_cast<float4*>(ol + plane + off) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        }
+    };
+    if (fx > lx) { pad_rows(y0, y1); return; }              // no valid column in this tile
+    const int* base = tab + (size_t)u * crop * TAB_STRIDE;
+    const int* xmin_t = base;
+    const int* xk_t = xmin_t + crop;
+    const int* ymin_t = xk_t + (size_t)crop * KMAX;
+    const int* yk_t = ymin_t + crop;
+    const int* xnn_t = yk_t + (size_t)crop * KMAX;
+    const int* ynn_t = xnn_t + crop;
+    const bool resx = w != Ws, resy = h != Hs;              // an unchanged axis is not resampled (one tap of weight one)
+
+    // ---- column tables.  Every index is clamped into the table, so no load here is conditional (no control flow, no wait
+    //      between the loads); validity is applied to the values afterwards ----
+    const int t_clo = xmin_t[fx], t_chi = xmin_t[lx];       // scalar loads
+    const int xh = x0 + tid;                                // horizontal pass: thread <-> output column
+    const int xhc = min(max(xh, fx), lx);
+    int hxm = xmin_t[xhc];
+    const int2 kk = *reinterpret_cast<const int2*>(xk_t + (size_t)xhc * KMAX);
+    const uint32_t hk0 = prescale4(kk.x), hk1 = prescale4(kk.y);
+    if (xh != xhc) hxm = -1;                                // pad column
+    const int4 xn4 = *reinterpret_cast<const int4*>(xnn_t + min(xq, crop - 4));
+    const int xn[4] = {xn4.x, xn4.y, xn4.z, xn4.w};
+    const uint8_t* msk = masks + (size_t)un.src * Hs * Ws;
+    const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
+    const uint32_t lbl_t0 = dataset == AADG_DATASET_OPTIC ? 50u : 0u;
+    const bool lbl_flip = dataset != AADG_DATASET_OPTIC;
+    const char* lutb = reinterpret_cast<const char*>(lutf);
+
+    {
+        const int ya = y0, yb = y1;
+        const int fy = max(ya, -oy), ly = min(yb - 1, h - 1 - oy);
+        if (fy > ly) { pad_rows(ya, yb); return; }
+        // ---- row tables (uniform per wave: scalar loads) ----
+        const int t_rlo = ymin_t[fy], t_rhi = ymin_t[ly];
+        int vym[RPW], vyn[RPW];
+        uint32_t vk0[RPW], vk1[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int yc = min(ya + wv + 4 * r, yb - 1);
+            vym[r] = ymin_t[yc];
+            vyn[r] = ynn_t[yc];
+            const int2 ky = *reinterpret_cast<const int2*>(yk_t + (size_t)yc * KMAX);
+            vk0[r] = prescale4(ky.x); vk1[r] = prescale4(ky.y);
+        }
+        // ---- patch -> LDS with the op chain applied, then the horizontal pass into the other buffer ----
+        const int r_lo = t_rlo;
+        const int nty = resy ? 2 : 1, ntx = resx ? 2 : 1;
+        const int r_hi = min(Hs, t_rhi + nty);
+        const int c_hi = min(Ws, t_chi + ntx);
+        const int r_lo_h = max(0, r_lo - sc), r_hi_h = min(Hs, r_hi + sc);
+        const int c_lo_h = max(0, t_clo - sc) & ~3, c_hi_h = min(Ws, (c_hi + sc + 3) & ~3);
+        const int pw = c_hi_h - c_lo_h;
+        const uint32_t* cur = build_patch<5, 2>(un, n_ops, src, Hs, Ws, r_lo_h, r_hi_h, c_lo_h, c_hi_h, A, B, lut, lut_stage_stride, u, sl);
+        uint32_t* Hbuf = cur == A ? B : A;
+        // mask: one (unaligned) dword per row holds the bytes of this lane's 4 columns (they lie within 4 consecutive source
+        // bytes because no axis shrinks); issued after the patch loads, consumed after the horizontal pass
+        uint32_t mw[RPW], msh[4], mkeep[4];
+        {
+            int mbase = -1;
+#pragma unroll
+            for (int i = 3; i >= 0; --i) mbase = xn[i] >= 0 ? xn[i] : mbase;      // first valid column of the lane
+            const bool lane_has = mbase >= 0;
+            mbase = min(max(mbase, 0), Ws - 4);                                    // keep the 4-byte window inside the row
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                msh[i] = xn[i] >= 0 ? 8u * (uint32_t)(xn[i] - mbase) : 0u;
+                mkeep[i] = (xn[i] >= 0 && lane_has) ? 255u : 0u;
+            }
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)                                          // unconditional: pad rows read row 0, result unused
+                mw[r] = reinterpret_cast<const UnalignedU32*>(msk + (size_t)max(vyn[r], 0) * Ws + mbase)->v;
+        }
+        const int nrows = r_hi - r_lo;
+        uint32_t* hout = Hbuf + tid;
+        if (hxm >= 0) {
+            const uint32_t* col = cur + (r_lo - r_lo_h) * pw + (hxm - c_lo_h);
+            if (resx) {
+                const int d1 = hk1 ? 1 : 0;                 // no second tap (right image edge): re-read the first
+#pragma unroll 4
+                for (int rr = 0; rr < nrows; ++rr) {
+                    const uint32_t p0 = col[rr * pw], p1 = col[rr * pw + d1];
+                    // byte 3 of each sum = the rounded channel value ((2^21 + c0 k0 + c1 k1) >> 22 with k scaled by 4)
+                    const uint32_t s0 = (1u << 23) + __umul24(p0 & 255u, hk0) + __umul24(p1 & 255u, hk1);
+                    const uint32_t s1 = (1u << 23) + __umul24((p0 >> 8) & 255u, hk0) + __umul24((p1 >> 8) & 255u, hk1);
+                    const uint32_t s2 = (1u << 23) + __umul24((p0 >> 16) & 255u, hk0) + __umul24((p1 >> 16) & 255u, hk1);
+                    const uint32_t rg = __builtin_amdgcn_perm(s1, s0, 0x0c0c0703u);      // [s0.b3, s1.b3, 0, 0]
+                    hout[rr * FT_W] = __builtin_amdgcn_perm(s2, rg, 0x0c070100u);          // [rg.b0, rg.b1, s2.b3, 0]
+                }
+            } else {
+#pragma unroll 4
+                for (int rr = 0; rr < nrows; ++rr) hout[rr * FT_W] = col[rr * pw];
+            }
+        } else {
+            for (int rr = 0; rr < nrows; ++rr) hout[rr * FT_W] = 0u;
+        }
+        __syncthreads();
+
+        // ---- vertical pass + normalise + store: wave <-> output rows ya + wv, + 4, ...; lane <-> 4 consecutive columns ----
+        if (col_ok) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int y = ya + wv + 4 * r;
+                if (y >= yb) break;
+                const int ym = vym[r];
+                float o[3][4];
+                if (ym >= 0) {
+                    const uint32_t ky0 = vk0[r], ky1 = vk1[r];
+                    const uint4 h0 = *reinterpret_cast<const uint4*>(Hbuf + (ym - r_lo) * FT_W + 4 * lane);
+                    const uint32_t a0[4] = {h0.x, h0.y, h0.z, h0.w};
+                    if (resy) {
+                        const uint4 h1 = *reinterpret_cast<const uint4*>(Hbuf + (ym + (ky1 ? 1 : 0) - r_lo) * FT_W + 4 * lane);
+                        const uint32_t a1[4] = {h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                const uint32_t v = (1u << 23) + __umul24((a0[i] >> (8 * c)) & 255u, ky0) + __umul24((a1[i] >> (8 * c)) & 255u, ky1);
+                                o[c][i] = *reinterpret_cast<const float*>(lutb + ((v >> 24) << 2));
+                            }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) o[c][i] = *reinterpret_cast<const float*>(lutb + (((a0[i] >> (8 * c)) & 255u) << 2));
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[0][i] = o[1][i] = o[2][i] = -1.0f;      // pad rows: normalise(0)
+                }
+                float l0[4], l1[4];
+                const uint32_t mrow = vyn[r] >= 0 ? mw[r] : 0u;      // pad rows: mask 0
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t m = (mrow >> msh[i]) & mkeep[i];
+                    l0[i] = ((m <= lbl_t0) != lbl_flip) ? 1.0f : 0.0f;
+                    l1[i] = m <= 200u ? 1.0f : 0.0f;
+                }
+                const uint32_t off = (uint32_t)y * (uint32_t)crop + (uint32_t)xq;
+                *reinterpret_cast<float4*>(oi + off) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
+                *reinterpret_cast<float4*>(oi + plane + off) = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
+                *reinterpret_cast<float4*>(oi + 2 * (size_t)plane + off) = make_float4(o[2][0], o[2][1], o[2][2], o[2][3]);
+                *reinterpret_cast<float4*>(ol + off) = make_float4(l0[0], l0[1], l0[2], l0[3]);
+                if (K == 2) *reinterpret_cast<float4*>(ol + plane + off) = make_float4(l1[0], l1[1], l1[2], l1[3]);
+            }
+        }
+    }
+}
+
+// grid (ceil(crop/256), ceil(crop/16), n_plain + 2 n_sharp): the first n_plain z-slices run the plain body on unit order[z],
+// the rest the Sharpness body, two 8-row workgroups per unit and 16-row tile.  `order` lists the unit indices grouped by
+// class (the caller classifies on the host); without it every unit gets a slice of each kind and the wrong kind returns after
+// reading the unit record (a returning workgroup still occupies a slot with its 39 KiB of LDS for about a microsecond).
+__global__ __launch_bounds__(256) void k_fused3(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
+                                                const aadg_unit* __restrict__ units, const int* __restrict__ order, int n_plain,
+                                                int Hs, int Ws, int crop, int dataset,
+                                                const int* __restrict__ tab, const uint8_t* __restrict__ lut,
+                                                size_t lut_stage_stride, float* __restrict__ out_img, float* __restrict__ out_lbl) {
+    __shared__ __attribute__((aligned(16))) uint32_t A[PATCH_CAP_PLAIN];
+    __shared__ __attribute__((aligned(16))) uint32_t B[HBUF_ROWS * FT_W];
+    __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
+    __shared__ float lutf[256];
+    const int z = blockIdx.z;
+    if (z < n_plain) {
+        const int u = order != nullptr ? order[z] : z;
+        fused3_body<false>(pool, masks, units, Hs, Ws, crop, dataset, tab, lut, lut_stage_stride, out_img, out_lbl, u, 0, A, B, sl, lutf);
+    } else {
+        const int zz = z - n_plain;
+        const int u = order != nullptr ? order[n_plain + (zz >> 1)] : (zz >> 1);
+        fused3_body<true>(pool, masks, units, Hs, Ws, crop, dataset, tab, lut, lut_stage_stride, out_img, out_lbl, u, zz & 1, A, B, sl, lutf);
+    }
+}
+
 struct WsLayout {
     size_t hist, lut, tab, buf0, buf1, total;
 };
@@ -1184,6 +1450,11 @@ int chunks_for(int npix) {
 
 // hints from a caller that has the unit records on the host (all bits set = unknown, launch everything)
 constexpr int HINT_FUSED = 1, HINT_STAGED = 2, HINT_GENERIC = 4;
+
+bool getenv_flag(const char* name) {
+    const char* v = getenv(name);
+    return v != nullptr && v[0] != '\0' && v[0] != '0';
+}
 
 // statistics + LUT (+ staged apply) for stages [0, max_ops)
 int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int crop, int max_ops, uint8_t* ws8,
@@ -1223,15 +1494,17 @@ extern "C" size_t aadg_aug_u8_workspace_bytes(int N, int Hs, int Ws, int crop) {
     return ws_layout(N, Hs, Ws, crop).total;
 }
 
-extern "C" int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,
-                                      const aadg_unit* units, int N, int max_ops, int crop, int dataset,
-                                      float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream,
-                                      int classes_hint, int stats_mask_hint, void* ev_before_final, void* ev_after_final) {
+extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,
+                                       const aadg_unit* units, int N, int max_ops, int crop, int dataset,
+                                       float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream,
+                                       int classes_hint, int stats_mask_hint, void* ev_before_final, void* ev_after_final,
+                                       const int32_t* order, int n_plain, int n_sharp, int n_generic) {
     if (!pool || !masks || !units || !out_img || !out_lbl || !ws) return AADG_E_BADARG;
     if (P <= 0 || Hs <= 0 || Ws <= 0 || N <= 0 || crop <= 0) return AADG_E_BADARG;
     if (max_ops < 0 || max_ops > AADG_MAX_OPS) return AADG_E_BADARG;
     if (dataset != AADG_DATASET_OPTIC && dataset != AADG_DATASET_VESSEL) return AADG_E_BADARG;
     if ((size_t)N * (size_t)crop > (size_t)1 << 28) return AADG_E_BADARG;
+    if (order != nullptr && (n_plain < 0 || n_sharp < 0 || n_generic < 0 || (long long)n_plain + n_sharp + n_generic > N)) return AADG_E_BADARG;
     const WsLayout L = ws_layout(N, Hs, Ws, crop);
     if (ws_bytes < L.total) return AADG_E_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1255,15 +1528,29 @@ extern "C" int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks,
     if (ev_before_final) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_before_final), st));
     if (classes & HINT_FUSED) {
         const dim3 g((crop + FT_W - 1) / FT_W, (crop + FT_H - 1) / FT_H, N);
-        hipLaunchKernelGGL(k_fused<FT_H>, g, dim3(256), 0, st, pool, masks, units, Hs, Ws, crop, dataset, tab, ws8 + L.lut,
-                           (size_t)N * 768, out_img, out_lbl);
-        AADG_LAUNCH_CHECK();
+        if (getenv_flag("AADG_FUSED_V1")) {
+            hipLaunchKernelGGL(k_fused<FT_H>, g, dim3(256), 0, st, pool, masks, units, Hs, Ws, crop, dataset, tab, ws8 + L.lut,
+                               (size_t)N * 768, out_img, out_lbl);
+            AADG_LAUNCH_CHECK();
+        } else {
+            // with the caller's class lists: one z-slice per plain unit, two per Sharpness unit; without: every unit gets all three
+            const int np = order ? n_plain : N, ns = order ? n_sharp : N;
+            if (np + 2 * ns > 0) {
+                const dim3 g2(g.x, g.y, np + 2 * ns);
+                hipLaunchKernelGGL(k_fused3, g2, dim3(256), 0, st, pool, masks, units, order, np, Hs, Ws, crop, dataset, tab, ws8 + L.lut,
+                                   (size_t)N * 768, out_img, out_lbl);
+            }
+            AADG_LAUNCH_CHECK();
+        }
     }
     if (classes & HINT_GENERIC) {
-        const dim3 g((crop + GT_W - 1) / GT_W, (crop + GT_H - 1) / GT_H, N);
-        hipLaunchKernelGGL(k_fused_generic, g, dim3(256), 0, st, pool, masks, units, Hs, Ws, crop, dataset, tab, ws8 + L.lut,
-                           (size_t)N * 768, out_img, out_lbl);
-        AADG_LAUNCH_CHECK();
+        const int ng = order ? n_generic : N;
+        if (ng > 0) {
+            const dim3 g((crop + GT_W - 1) / GT_W, (crop + GT_H - 1) / GT_H, ng);
+            hipLaunchKernelGGL(k_fused_generic, g, dim3(256), 0, st, pool, masks, units, order ? order + n_plain + n_sharp : nullptr, Hs, Ws,
+                               crop, dataset, tab, ws8 + L.lut, (size_t)N * 768, out_img, out_lbl);
+            AADG_LAUNCH_CHECK();
+        }
     }
     if (classes & HINT_STAGED) {
         const dim3 g((crop + 255) / 256, (crop + FIN_ROWS - 1) / FIN_ROWS, N);
@@ -1272,6 +1559,14 @@ extern "C" int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks,
     }
     if (ev_after_final) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_after_final), st));
     return 0;
+}
+
+extern "C" int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,
+                                      const aadg_unit* units, int N, int max_ops, int crop, int dataset,
+                                      float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream,
+                                      int classes_hint, int stats_mask_hint, void* ev_before_final, void* ev_after_final) {
+    return aadg_aug_u8_forward_ex2(pool, masks, P, Hs, Ws, units, N, max_ops, crop, dataset, out_img, out_lbl, ws, ws_bytes, stream,
+                                   classes_hint, stats_mask_hint, ev_before_final, ev_after_final, nullptr, 0, 0, 0);
 }
 
 extern "C" int aadg_aug_u8_forward(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,

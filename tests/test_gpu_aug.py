@@ -171,3 +171,33 @@ def test_bad_arguments_raise(hip):
         hip.aug_u8_forward(imgs, msks, u, 16, 0)
     with pytest.raises(hip.AadgError):
         hip.aug_u8_forward(imgs.cpu(), msks.cpu(), u, 16, 0)
+
+
+def test_class_lists_and_fallback_agree(hip, oracle):
+    """aadg_aug_u8_forward_ex2 with the caller's class lists (one workgroup per tile of a unit of the kernel's class) and the
+    list-free entry (every unit offered to every kernel, the wrong class returns) produce the same tensors, and both are the
+    oracle's -- on a batch that mixes plain, Sharpness (8-row half tiles), generic and staged units, at a crop that is not a
+    multiple of the 16-row tile."""
+    import ctypes
+    from helpers import random_units, synth_pool
+    rs = np.random.RandomState(77)
+    P, H, crop, N = 6, 72, 72, 40
+    imgs, msks = synth_pool(rs, P, H, H)
+    units = random_units(rs, N, P, H, H, crop, (0.36, 1.6))
+    units['op'][:10, 0] = 8; units['farg'][:10, 0] = np.float32(1.4); units['n_ops'][:10] = np.maximum(units['n_ops'][:10], 1)
+    want_img, want_lbl = oracle.aug_units(imgs, msks, units, crop, 0)
+    d_img, d_msk = torch.from_numpy(imgs).cuda(), torch.from_numpy(msks).cuda()
+    got_img, got_lbl = hip.aug_u8_forward(d_img, d_msk, units, crop, 0)                     # ex2 with lists
+    classes, stats, order, counts = hip.launch_hints(units, H, H, crop)
+    assert sum(counts) <= N and counts[0] > 0 and counts[1] > 0 and counts[2] > 0 and sum(counts) < N     # all four classes present
+    assert np.array_equal(got_img.cpu().numpy(), want_img) and np.array_equal(got_lbl.cpu().numpy(), want_lbl)
+    lib = hip.load()
+    d_units = hip.units_to_device(units, d_img.device)
+    o_img = torch.empty_like(got_img); o_lbl = torch.empty_like(got_lbl)
+    nb = lib.aadg_aug_u8_workspace_bytes(N, H, H, crop)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    rc = lib.aadg_aug_u8_forward(d_img.data_ptr(), d_msk.data_ptr(), P, H, H, d_units.data_ptr(), N, 4, crop, 0, o_img.data_ptr(),
+                                 o_lbl.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o_img, got_img) and torch.equal(o_lbl, got_lbl)

@@ -70,6 +70,7 @@ def test_search_step_segformer_8_domains(hip):
     from aadg_amd.config.defaults import get_default_config
     from aadg_amd.models.segformer import SegFormer
     cfg = get_default_config()
+    cfg.defrost()                                      # (an earlier run.py test in the same process leaves the template frozen)
     cfg.merge_from_file(os.path.join(ROOT, "experiments", "merged_sinkhorn", "segformer_b2_d8.yaml"))
     cfg.TRAIN.BATCH_SIZE = 2
     cfg.SEED = 1023
