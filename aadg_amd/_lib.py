@@ -290,6 +290,8 @@ def launch_hints(units, Hs, Ws, crop):
 # optional (start, stop) torch.cuda.Event pair recorded around the dominant kernel of the next
 # aug_u8_forward call(s); used by bench.py to time that kernel live on the launch stream
 PROFILE_EVENTS = None
+# optional (start, stop) torch.cuda.Event pair recorded on the current stream around the WHOLE library call (all its kernels)
+PROFILE_CALL_EVENTS = None
 _pinned = {}
 
 
@@ -344,9 +346,13 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
     ev0 = ev1 = 0
     if PROFILE_EVENTS is not None:
         ev0, ev1 = PROFILE_EVENTS[0].cuda_event, PROFILE_EVENTS[1].cuda_event
+    if PROFILE_CALL_EVENTS is not None:
+        PROFILE_CALL_EVENTS[0].record()
     rc = lib.aadg_aug_u8_forward_ex2(pool.data_ptr(), masks.data_ptr(), P, Hs, Ws, d_units.data_ptr(), N, max_ops, crop,
                                      dataset, out_img.data_ptr(), out_lbl.data_ptr(), ws.data_ptr(), ws.numel(), _stream(),
                                      classes, stats_mask, ev0, ev1, d_units.data_ptr() + nb_units, n_plain, n_sharp, n_generic)
+    if PROFILE_CALL_EVENTS is not None:
+        PROFILE_CALL_EVENTS[1].record()
     _check(rc, "aadg_aug_u8_forward")
     d_units.record_stream(torch.cuda.current_stream())
     return out_img, out_lbl

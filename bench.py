@@ -3,22 +3,35 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A *step* is one policy-search step: controller(M) -> parse_policies -> policy injection ->
-ONE inner iteration over the N = D*B*M augmented images (fused uint8 augmentation kernels -> DeepLabV3+
-forward/backward + Adam -> discriminator forward/backward + Adam -> fused BCE/Dice kernel -> fused Sinkhorn
-reward kernel) -> reward normalisation -> PPO update (5 controller updates).  Workload = BASELINE.json
-configs[1]: DeepLabv3+/ResNet-50, 3 Fundus-like source domains, 512x512, B=8, M=6 (N = 144), synthetic data,
-random-init weights.  With N GPUs the SAME 144 rows are sharded over the ranks (strong scaling); the exchange
-steps are one all-gather of the [144/G,128] embeddings and the DDP gradient all-reduce.
+`python bench.py --gpus N` without a launcher starts its N ranks itself (torch.distributed.run, one rank per GPU over RCCL).
+
+A *step* is one policy-search step: controller(M) -> parse_policies -> policy injection -> ONE inner iteration
+over the N = D*B*M augmented images (fused uint8 augmentation kernels -> backbone forward/backward + Adam -> discriminator
+forward/backward + Adam -> fused BCE/Dice kernel -> fused Sinkhorn reward kernel) -> reward normalisation -> PPO update (5
+controller updates).  Default workload = BASELINE.json configs[1]: DeepLabv3+/ResNet-50, 3 Fundus-like source domains,
+512x512, B = 8, M = 6 (N = 144), synthetic data, random-init weights; --cfg / --size / --batch select the other configs
+(configs[4]: --cfg experiments/merged_sinkhorn/segformer_b2_d8.yaml).  With N GPUs the SAME images are sharded over the ranks
+(strong scaling) by (domain, policy) units; the exchange steps are one all-gather of the embeddings, the DDP gradient
+all-reduce and the BatchNorm statistics all-reduce.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      dominant HIP kernel (the fused resample/crop/normalise/store kernel of the augmentation path):
-                algorithmic bytes per launch / its average duration, timed with HIP events recorded on the launch
-                stream around exactly that kernel inside the timed region (aadg_aug_u8_forward_ex);
-  cpu_baseline  the CPU oracle (oracle/aadg_oracle.c, a scalar restatement of the reference's Pillow/geomloss
-                path) timed on this host on a bounded sample, for the same hot-path work;
-  hot_path      the same step with the backbone removed (features/logits = fixed random tensors), i.e. only the
-                parts this repository implements as HIP kernels -- the figure comparable with cpu_baseline.
+  roofline       dominant HIP kernel = the fused ops + resample + crop + normalise + CHW-store tile kernel (k_fused3): the bytes
+                 THAT kernel moves per launch (source pixels and mask once, float32 image + label planes once) / its average
+                 duration, timed with HIP events recorded on the launch stream around exactly that kernel in every timed step;
+                 `stage` = SURVEY 8(d)'s algorithmic bytes of the whole augmentation call (the source is counted twice for
+                 units whose sub-policy holds a statistics op) / the duration of ALL its kernels (tables, histograms, LUTs,
+                 tile kernels), events around the whole call; `rocprof` = the committed rocprofv3 summary of this command;
+  step_ms        median / p10 / p90 of the timed steps (device-side: one event per step);
+  hot_path       the same step with the backbone removed (features / logits = fixed random tensors): the part this repository
+                 implements as HIP kernels, comparable with cpu_baseline;
+  fp32_backbone  (N = 1) the headline step with the backbone at the reference's precision (float32; the headline runs the
+                 convolutions under bf16 autocast), a few steps;
+  rvs_1024       (N = 1) BASELINE configs[2] on the hot path: RVS pipeline (scale range [0.5, 2], K = 1) at 1024x1024 crops,
+                 144 units: duration of the augmentation call and the roofline of its dominant kernels;
+  cpu_baseline   (N = 1) the CPU oracle (oracle/aadg_oracle.c, scalar restatement of the reference's Pillow / geomloss path) +
+                 the eager controller on torch-CPU, timed on this host as BASELINE.md section 3 asks: augment, loss, reward and
+                 controller stages, W = all usable cores (the container's cgroup CPU quota: 16 on this pool's GPU boxes) / 4 / 1
+                 worker PROCESSES, >= 20 timed repeats, median and p10 / p90.
 """
 import argparse
 import json
@@ -39,7 +52,6 @@ os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(_MIOPEN_DIR, "db"))
 os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(_MIOPEN_DIR, "cache"))
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -50,14 +62,18 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICR
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cfg", default=os.path.join("experiments", "optic_sinkhorn", "diversity.yaml"),
+                    help="reference-style yaml (relative to the repository); default = BASELINE configs[1]")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--batch", type=int, default=8, help="TRAIN.BATCH_SIZE (items; each item = one image per domain)")
-    ap.add_argument("--backbone", default="resnet50")
+    ap.add_argument("--backbone", default="resnet50", help="MODEL.BACKBONE for deeplabv3+ configs (the yaml's mobilenet_v2 is the "
+                                                           "reference's only reachable encoder; BASELINE configs[1] names ResNet-50)")
     ap.add_argument("--backbone_dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--cpu_units", type=int, default=24, help="units of the CPU-baseline sample")
+    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N = 1: fp32,rvs1024,cpu  (auto = all; none = skip)")
+    ap.add_argument("--no_cpu_baseline", action="store_true", help="same as removing `cpu` from --legs")
+    ap.add_argument("--cpu_repeats", type=int, default=20)
     ap.add_argument("--no_sync_bn", action="store_true",
                     help="N > 1: keep BatchNorm statistics per rank (default: all-reduced per-channel sums between the HIP statistics "
                          "and normalisation kernels, i.e. the single-GPU batch statistics of the reference)")
@@ -67,7 +83,7 @@ def parse():
                          "(18 rows per rank at 8 GPUs); both give one source domain per GPU at N = 3")
     ap.add_argument("--dist_backend", default="nccl", help="nccl (= RCCL) by default; gloo for single-GPU functional tests")
     ap.add_argument("--all_ranks_on_gpu0", action="store_true", help="functional test of the N>1 path on a 1-GPU box")
-    ap.add_argument("--dump_rewards", default=None, help="write the normalised rewards of every timed step to this JSON file (tests)")
+    ap.add_argument("--dump_rewards", default=None, help="write the rewards of every timed step to this JSON file (tests)")
     ap.add_argument("--no_dropout", action="store_true", help="tests: make the step a deterministic function of the seed")
     ap.add_argument("--shard_of", type=int, default=0,
                     help="single process: run only rank 0's row slice of a G-rank job (no collectives); used to "
@@ -79,19 +95,221 @@ class Args(object):
     pass
 
 
-def build_state(a, local_rank, world):
+# ---------------------------------------------------------------------------------------------------------------------------
+# CPU baseline: worker processes are forked BEFORE the HIP runtime is initialised in this process and never touch the GPU
+# ---------------------------------------------------------------------------------------------------------------------------
+_W = {}
+
+
+def _worker_arrays(paths, names):
+    """memory-map the published arrays once per worker process and publication"""
+    if _W.get("stamp") != paths["stamp"]:
+        _W.clear()
+        _W["stamp"] = paths["stamp"]
+    for n in names:
+        if n not in _W:
+            _W[n] = np.load(paths[n], mmap_mode="r")
+    return [_W[n] for n in names]
+
+
+def _worker_loop(r, w, go_fd, done_fd, task_path):
+    """Persistent worker r of a pool of w: block on its `go` pipe, read the task, do every w-th item, write one byte to the
+    shared `done` pipe.  (A multiprocessing.Pool dispatches its tasks one by one from a single thread -- ~0.7 ms per task,
+    100 ms for a 144-unit batch, 20 times the work itself -- and multiprocessing.Barrier wakes its parties one by one too.)"""
+    from oracle import oracle as O
+    O.lib()
+    while True:
+        if not os.read(go_fd, 1):
+            return
+        with open(task_path) as f:
+            t = json.load(f)
+        if t["kind"] == "exit":
+            return
+        idx = t["idx"][r::w]
+        if t["kind"] == "aug":
+            imgs, msks, units = _worker_arrays(t["paths"], ("imgs", "msks", "units"))
+            for i in idx:
+                O.aug_units(imgs, msks, np.array(units[i:i + 1]), t["size"], t["dataset"])
+        elif t["kind"] == "loss":
+            z, y = _worker_arrays(t["paths"], ("z", "y"))
+            for i in idx:
+                k = i % z.shape[0]
+                O.policy_bce(np.array(z[k:k + 1]), np.array(y[k:k + 1]), 1)
+                O.dice(np.array(z[k:k + 1]), np.array(y[k:k + 1]))
+        os.write(done_fd, b"d")
+
+
+class CpuPools(object):
+    """Persistent worker processes: W = all cores (capped at the number of augmentation units), 4 (the reference's default -j,
+    run.py:17) and 1.  Forked before the HIP runtime is initialised in this process; they never touch the GPU."""
+
+    def __init__(self, n_units):
+        import multiprocessing as mp
+        import tempfile
+        self.dir = tempfile.mkdtemp(prefix="aadg_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        self.paths = {k: os.path.join(self.dir, k + ".npy") for k in ("imgs", "msks", "units", "z", "y")}
+        self.cores = os.cpu_count() or 1
+        # the container's CPU bandwidth quota (cgroup v2 cpu.max = "<quota us> <period us>"): on the GPU boxes of this pool 256
+        # hardware threads are visible but the quota is 16 CPUs -- more busy workers than that are throttled every 100 ms period
+        self.quota = self.cores
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                self.quota = max(1, int(int(q) / int(per)))
+        except (OSError, ValueError):
+            pass
+        self.usable = min(self.cores, self.quota)
+        self.sizes = sorted({max(1, min(self.usable, n_units)), min(4, self.usable), 1}, reverse=True)
+        self.ctx = mp.get_context("fork")
+        self.pools = {}
+
+    def start(self):
+        for w in self.sizes:
+            done_r, done_w = os.pipe()
+            task = os.path.join(self.dir, "task_%d.json" % w)
+            gos, procs = [], []
+            for r in range(w):
+                go_r, go_w = os.pipe()
+                p = self.ctx.Process(target=_worker_loop, args=(r, w, go_r, done_w, task), daemon=True)
+                p.start()
+                os.close(go_r)
+                gos.append(go_w)
+                procs.append(p)
+            self.pools[w] = (gos, done_r, task, procs)
+
+    def publish(self, **arrays):
+        for k, a in arrays.items():
+            np.save(self.paths[k], a)
+        self.paths["stamp"] = time.time()
+
+    def run(self, w, kind, idx, size, dataset):
+        """one batch of `kind` items on the pool of w workers; returns the seconds between the two barriers"""
+        gos, done_r, task, _ = self.pools[w]
+        with open(task, "w") as f:
+            json.dump({"kind": kind, "idx": [int(i) for i in idx], "size": size, "dataset": dataset, "paths": self.paths}, f)
+        t0 = time.perf_counter()
+        for fd in gos:
+            os.write(fd, b"g")
+        n = 0
+        while n < w:
+            n += len(os.read(done_r, 4096))
+        return time.perf_counter() - t0
+
+    def close(self):
+        import shutil
+        for w, (gos, done_r, task, procs) in self.pools.items():
+            for fd in gos:
+                try:
+                    os.close(fd)                            # EOF on the go pipe: the worker returns
+                except OSError:
+                    pass
+            for p in procs:
+                p.join(timeout=1)
+                if p.is_alive():
+                    p.terminate()
+        self.pools = {}
+        shutil.rmtree(self.dir, ignore_errors=True)
+
+
+def _stats(ts):
+    a = np.asarray(ts, dtype=np.float64)
+    return {"median": float(np.median(a)), "p10": float(np.percentile(a, 10)), "p90": float(np.percentile(a, 90)), "n": int(a.size)}
+
+
+def cpu_baseline(pools, cfg, st, a):
+    """CPU restatement of the reference's live path on this host's cores -- augment, loss, reward and
+    controller stages; W worker processes; >= 20 timed repeats, median and p10 / p90; bounded samples scaled to one batch."""
+    import torch
+    from oracle import oracle as O
+    from aadg_amd.data import transform as T
+    from aadg_amd.losses import search_loss
+    from aadg_amd.models.controller import Controller
+    O.lib()
+    rs = np.random.RandomState(0)
+    batch = [st.train_loader.dataset[0] for _ in range(a.batch)]
+    flat, refs, M = T.collect_refs(batch, nested=True)
+    S = len(flat)
+    units = T.refs_to_units(refs[S:])
+    n_all = len(units)
+    pool = st.train_loader.dataset.pool
+    D, B = len(cfg.DATASET.DG.TRAIN), a.batch
+    z = rs.randn(8, 2, a.size, a.size).astype(np.float32)
+    y = (rs.rand(8, 2, a.size, a.size) > 0.5).astype(np.float32)
+    pools.publish(imgs=pool.images.cpu().numpy(), msks=pool.masks.cpu().numpy(), units=units, z=z, y=y)
+    fe = rs.randn(D * B * M, 128).astype(np.float32)
+    fe = np.where(fe > 0, fe, 0.2 * fe)
+    R = max(20, a.cpu_repeats)
+
+    dataset = 0 if cfg.DATASET.NAME == "optic" else 1
+
+    def timed(w, kind, n_items):
+        """R repeats of `n_items` items of `kind` spread over the w workers; seconds per repeat, scaled to the whole batch."""
+        idx = rs.choice(n_all, n_items, replace=False) if n_items < n_all else np.arange(n_all)
+        pools.run(w, kind, idx, a.size, dataset)           # warm-up (maps the arrays in the workers)
+        return [pools.run(w, kind, idx, a.size, dataset) * n_all / n_items for _ in range(R)]
+
+    # reward stage: the M x D(D-1)/2 Sinkhorn problems, one process (tiny)
+    O.sinkhorn_rewards(fe, D, B, M)
+    t_rew = []
+    for _ in range(R):
+        t0 = time.perf_counter()
+        O.sinkhorn_rewards(fe, D, B, M)
+        t_rew.append(time.perf_counter() - t0)
+    # controller stage: eager Controller.sample + PPO (5 x evaluate / backward / Adam) on torch-CPU (models/controller.py:73-145,
+    # losses.py:117-157)
+    torch.manual_seed(0)
+    torch.set_num_threads(1)          # 56 k parameters, batch of 6: more threads only add fork / join overhead
+    ctrl = Controller(cfg)
+    crit = search_loss(cfg)
+    from aadg_amd.scheduler import CONTROLLER_LR
+    crit.register_optimizer(torch.optim.Adam(ctrl.parameters(), lr=CONTROLLER_LR))
+    t_ctl = []
+    for i in range(R + 2):
+        t0 = time.perf_counter()
+        policies, _, _, log_probs, entropies = ctrl(M)
+        reward = torch.randn(M)
+        crit(ctrl, policies, log_probs.detach(), entropies, (reward - reward.mean()) / (reward.std() + 1e-5))
+        if i >= 2:
+            t_ctl.append(time.perf_counter() - t0)
+    legs = {}
+    for w in pools.sizes:
+        # bounded samples: everything at W = all cores; a quarter of the batch on one core
+        n_aug = n_all if w > 1 else max(8, n_all // 4)
+        n_loss = n_all if w > 4 else (n_all // 2 if w > 1 else max(8, n_all // 8))
+        ta = timed(w, "aug", n_aug)
+        tl = timed(w, "loss", n_loss)
+        total = [x + yv + r + c for x, yv, r, c in zip(ta, tl, t_rew, t_ctl)]
+        legs[w] = {"workers": w, "steps_per_s": 1.0 / float(np.median(total)),
+                   "seconds_per_step": _stats(total), "augment_s": _stats(ta), "loss_s": _stats(tl),
+                   "sample": "%d of %d augmentation units, BCE/Dice on %d of %d images, scaled to the batch" % (n_aug, n_all, n_loss, n_all)}
+    top = legs[pools.sizes[0]]
+    return {"value": top["steps_per_s"], "unit": "hot-path steps/s (controller sample + PPO, augmentation, Sinkhorn reward, BCE/Dice of one "
+                                                 "%d-image batch; backbone excluded)" % n_all,
+            "cores": pools.sizes[0], "host_cores_available": pools.cores, "host_cpu_quota": pools.quota, "kind": "port", "repeats": R,
+            "sample": "W = %d worker processes: %s; reward: %d Sinkhorn problems in one process; controller: eager torch-CPU"
+                      % (pools.sizes[0], top["sample"], M * D * (D - 1) // 2),
+            "seconds_per_step": top["seconds_per_step"], "augment_s": top["augment_s"], "loss_s": top["loss_s"],
+            "reward_s": _stats(t_rew), "controller_s": _stats(t_ctl),
+            "by_workers": {str(w): {k: v for k, v in leg.items() if k != "workers"} for w, leg in legs.items()}}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def build_state(a, local_rank, world, backbone_dtype=None):
+    import torch
     from aadg_amd.config.defaults import get_default_config
     from aadg_amd.search_dg import SearchState
     cfg = get_default_config()
-    cfg.merge_from_file(os.path.join(ROOT, "experiments", "optic_sinkhorn", "diversity.yaml"))
-    cfg.MODEL.BACKBONE = a.backbone
+    cfg.defrost()
+    cfg.merge_from_file(a.cfg if os.path.isabs(a.cfg) else os.path.join(ROOT, a.cfg))
+    if cfg.MODEL.NAME == "deeplabv3+":
+        cfg.MODEL.BACKBONE = a.backbone
     cfg.TRAIN.BATCH_SIZE = a.batch
     cfg.SEED = 1023
     cfg.PRINT_FREQ = 10 ** 9
     cfg.freeze()
     args = Args()
     args.gpu, args.workers, args.distributed = local_rank, 0, world > 1
-    args.crop_size, args.backbone_dtype, args.epoch_items = a.size, a.backbone_dtype, a.batch
+    args.crop_size, args.backbone_dtype, args.epoch_items = a.size, backbone_dtype or a.backbone_dtype, a.batch
     args.sync_bn = world > 1 and not a.no_sync_bn
     args.placement = a.placement
     st = SearchState(local_rank, world, cfg, args)
@@ -104,103 +322,24 @@ def build_state(a, local_rank, world):
     return cfg, st
 
 
-def algorithmic_bytes(units, Hs, Ws, crop, K):
-    """per output image read 3*Hs*Ws source bytes (x2 when the sub-policy contains a
-    histogram/mean op: AutoContrast, Equalize, Contrast) + Hs*Ws mask bytes; write (3+K)*crop^2*4 bytes."""
+def unit_bytes(units, Hs, Ws, crop, K, stats_twice):
+    """Bytes per launch.  stats_twice = False: what the tile kernel itself moves (source pixels + mask once, (3 + K) float32 planes
+    once).  True: SURVEY.md 8(d)'s algorithmic bytes of the whole augmentation call -- the source counted a second time for units
+    whose sub-policy holds a histogram / mean op (AutoContrast, Equalize, Contrast), read by the statistics kernels."""
     total = 0
     for u in units:
         ops = [int(u["op"][k]) for k in range(int(u["n_ops"]))]
-        hist = any(o in (0, 2, 5) for o in ops)
-        total += 3 * Hs * Ws * (2 if hist else 1) + Hs * Ws + (3 + K) * crop * crop * 4
+        twice = stats_twice and any(o in (0, 2, 5) for o in ops)
+        total += 3 * Hs * Ws * (2 if twice else 1) + Hs * Ws + (3 + K) * crop * crop * 4
     return total
 
 
-def measured_traffic(n_units, size):
-    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
-    separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot collect
-    counters itself: it scales the committed per-unit measurement (profiles/traffic_k_fused.json, same kernel and
-    image size) by the number of units of its own launch; null when no matching measurement is committed."""
-    path = os.path.join(ROOT, "profiles", "traffic_k_fused.json")
+def committed(name):
     try:
-        with open(path) as f:
-            rec = json.load(f)
-        if rec.get("size") == size:
-            return int(rec["hbm_bytes_per_unit"]) * n_units
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
-
-
-def cpu_baseline(cfg, st, a, n_units):
-    """Oracle (CPU restatement) on a bounded sample of the same workload, rank 0 only.  Three legs, as SURVEY 8(d) asks:
-    W = all host cores (the headline `value`), W = 4 (the reference's default `-j`, run.py:17) and W = 1.  The oracle is
-    scalar C called through ctypes (which releases the GIL), so W worker threads = W busy cores."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import oracle as O
-    from aadg_amd.data import transform as T
-    O.lib()
-    rs = np.random.RandomState(0)
-    # same kind of batch plan as the timed steps
-    batch = [st.train_loader.dataset[0] for _ in range(a.batch)]
-    flat, refs, M = T.collect_refs(batch, nested=True)
-    S = len(flat)
-    units = T.refs_to_units(refs[S:])
-    n_all = len(units)
-    pool = st.train_loader.dataset.pool
-    imgs, msks = pool.images.cpu().numpy(), pool.masks.cpu().numpy()
-    D, B = len(cfg.DATASET.DG.TRAIN), a.batch
-    fe = rs.randn(D * B * M, 128).astype(np.float32)
-    fe = np.where(fe > 0, fe, 0.2 * fe)
-    z = rs.randn(8, 2, a.size, a.size).astype(np.float32)
-    y = (rs.rand(8, 2, a.size, a.size) > 0.5).astype(np.float32)
-
-    def aug_one(i):
-        O.aug_units(imgs, msks, units[i:i + 1], a.size, 0)
-
-    def loss_one(i):
-        O.policy_bce(z[i % 8:i % 8 + 1], y[i % 8:i % 8 + 1], 1)
-        O.dice(z[i % 8:i % 8 + 1], y[i % 8:i % 8 + 1])
-
-    t0 = time.perf_counter()
-    for _ in range(3):
-        O.sinkhorn_rewards(fe, D, B, M)
-    t_sink = (time.perf_counter() - t0) / 3
-
-    def leg(workers, n_aug, n_loss):
-        """seconds for one full batch with `workers` threads, measured on n_aug units / n_loss images and scaled"""
-        sel = rs.choice(n_all, n_aug, replace=False)
-        if workers == 1:
-            t0 = time.perf_counter()
-            for i in sel:
-                aug_one(int(i))
-            t_aug = (time.perf_counter() - t0) / n_aug * n_all
-            t0 = time.perf_counter()
-            for i in range(n_loss):
-                loss_one(i)
-            t_loss = (time.perf_counter() - t0) / n_loss * n_all
-        else:
-            with ThreadPoolExecutor(workers) as ex:
-                t0 = time.perf_counter()
-                list(ex.map(aug_one, [int(i) for i in sel]))
-                t_aug = (time.perf_counter() - t0) / n_aug * n_all
-                t0 = time.perf_counter()
-                list(ex.map(loss_one, range(n_loss)))
-                t_loss = (time.perf_counter() - t0) / n_loss * n_all
-        return t_aug, t_loss
-
-    cores = os.cpu_count() or 1
-    W = max(1, min(cores, n_all))
-    a1, l1 = leg(1, min(n_units, n_all), 4)
-    a4, l4 = leg(4, min(2 * n_units, n_all), 16)
-    aw, lw = leg(W, n_all, n_all)
-    total = aw + t_sink + lw
-    return {"value": 1.0 / total, "unit": "hot-path steps/s (augmentation + Sinkhorn reward + BCE/Dice of one 144-image batch; backbone excluded)",
-            "cores": W, "kind": "port",
-            "sample": "all %d augmentation units at %dx%d + BCE/Dice on %d images on %d worker threads, 3 full reward loops (18 Sinkhorn "
-                      "problems, 1 thread): aug %.3fs + reward %.4fs + loss %.3fs per batch" % (n_all, a.size, a.size, n_all, W, aw, t_sink, lw),
-            "seconds_per_step": total,
-            "value_1core": 1.0 / (a1 + t_sink + l1), "value_4cores": 1.0 / (a4 + t_sink + l4),
-            "sample_1core": "%d of %d units, BCE/Dice on 4 images, scaled: aug %.2fs + reward %.4fs + loss %.2fs" % (min(n_units, n_all), n_all, a1, t_sink, l1)}
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def _free_port():
@@ -216,6 +355,7 @@ def relaunch_under_torchrun(a):
     """`python bench.py --gpus N` (no launcher): start the N ranks ourselves, exactly as the driver's documented command does
     (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...)."""
     import subprocess
+    import torch
     if not a.all_ranks_on_gpu0 and torch.cuda.device_count() < a.gpus:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (use --all_ranks_on_gpu0 for a functional run on one GPU)"
                          % (a.gpus, torch.cuda.device_count()))
@@ -227,6 +367,110 @@ def relaunch_under_torchrun(a):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def time_steps(st, a, world, steps, warmup, first_epoch=0, want_kernel_events=True, dump=None):
+    """warmup untimed steps, then `steps` timed ones between barrier + synchronize pairs.  Returns (elapsed seconds (max over
+    ranks), per-step device times ms, tile-kernel times ms, whole-augmentation-call times ms)."""
+    import torch
+    from aadg_amd import _lib
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(warmup):
+        st.search_step(first_epoch + i, max_iters=1)
+    sync()
+    import gc
+    gc.collect()
+    gc.freeze()
+    ev = lambda: torch.cuda.Event(enable_timing=True)      # noqa: E731
+    kpairs = [(ev(), ev()) for _ in range(steps)]
+    cpairs = [(ev(), ev()) for _ in range(steps)]
+    marks = [ev() for _ in range(steps + 1)]
+    for p in kpairs + cpairs:
+        p[0].record(); p[1].record()                       # force creation of the underlying hipEvent_t
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        marks[i].record()
+        if want_kernel_events:
+            _lib.PROFILE_EVENTS, _lib.PROFILE_CALL_EVENTS = kpairs[i], cpairs[i]
+        nr = st.search_step(first_epoch + warmup + i, max_iters=1)[3]
+        if dump is not None:
+            from aadg_amd import search_dg as _sd
+            dump.append((nr, _sd.LAST_RAW_REWARDS.clone()))
+    _lib.PROFILE_EVENTS = _lib.PROFILE_CALL_EVENTS = None
+    marks[steps].record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    kern_ms = [p[0].elapsed_time(p[1]) for p in kpairs] if want_kernel_events else []
+    call_ms = [p[0].elapsed_time(p[1]) for p in cpairs] if want_kernel_events else []
+    return float(t.item()), step_ms, kern_ms, call_ms
+
+
+def rvs_1024_leg(n_units=144, size=1024):
+    """BASELINE configs[2] on the hot path: the RVS pipeline of experiments/rvs_sinkhorn/diversity_ex.yaml (DGRandomScaleCrop
+    scale range [0.5, 2], vessel masks, K = 1) with 1024 x 1024 crops from 1024 x 1024 sources, D3 B8 M6 = 144 units."""
+    import torch
+    from aadg_amd import _lib
+    from aadg_amd.config.defaults import get_default_config
+    from aadg_amd.data import transform as T
+    from aadg_amd.data.dataloader import get_seg_dg_dataloader
+    from aadg_amd.data.policy import DGMultiPolicy, parse_policies
+    cfg = get_default_config()
+    cfg.defrost()
+    cfg.merge_from_file(os.path.join(ROOT, "experiments", "rvs_sinkhorn", "diversity_ex.yaml"))
+    cfg.SEED = 1023
+    cfg.freeze()
+    args = Args()
+    args.crop_size, args.epoch_items = size, 8
+    _, loader, _ = get_seg_dg_dataloader(cfg, args, 8, 0, per_domain=8)
+    pol = np.random.RandomState(1023).randint(0, 10, (6, 20))
+    loader.dataset.transforms.transforms[0] = DGMultiPolicy(parse_policies(pol, cfg, None))
+    ev = lambda: torch.cuda.Event(enable_timing=True)      # noqa: E731
+    R = 8
+    kp, cp = [(ev(), ev()) for _ in range(R)], [(ev(), ev()) for _ in range(R)]
+    for p in kp + cp:
+        p[0].record(); p[1].record()
+    it = iter(loader)
+    next(it)                                                # warm-up batch
+    torch.cuda.synchronize()
+    n_flow = None
+    for i in range(R):
+        _lib.PROFILE_EVENTS, _lib.PROFILE_CALL_EVENTS = kp[i], cp[i]
+        try:
+            next(it)
+        except StopIteration:
+            it = iter(loader)
+            next(it)
+    _lib.PROFILE_EVENTS = _lib.PROFILE_CALL_EVENTS = None
+    torch.cuda.synchronize()
+    # bytes of one batch plan (same law as the optic leg; the source here is 1024 x 1024)
+    batch = [loader.dataset[0] for _ in range(8)]
+    flat, refs, M = T.collect_refs(batch, nested=True)
+    units = T.refs_to_units(refs)
+    Hs = loader.dataset.pool.images.shape[1]
+    n_flow = _lib.launch_hints(units, Hs, Hs, size)[3]
+    kb = unit_bytes(units, Hs, Hs, size, 1, False)
+    sb = unit_bytes(units, Hs, Hs, size, 1, True)
+    k_ms, c_ms = float(np.mean([p[0].elapsed_time(p[1]) for p in kp])), float(np.mean([p[0].elapsed_time(p[1]) for p in cp]))
+    return {"workload": "BASELINE configs[2]: experiments/rvs_sinkhorn/diversity_ex.yaml pipeline, %dx%d crops from %dx%d sources, "
+                        "%d units per batch (hot path only: augmentation call)" % (size, size, Hs, Hs, len(units)),
+            "units": len(units), "units_by_tile_kernel": {"up_plain": n_flow[0], "up_sharpness": n_flow[1], "generic_downscale": n_flow[2],
+                                                          "staged": len(units) - sum(n_flow)},
+            "img_per_s": len(units) / (c_ms * 1e-3),
+            "roofline": {"bound": "hbm", "kernel": "k_fused3 + k_fused_generic (tile kernels of the batch; a 2x shrink reads 4x the source "
+                                                   "pixels per output pixel, so those tiles are LDS / issue bound)",
+                         "achieved": kb / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": None, "bytes_per_launch": kb, "kernel_ms": k_ms,
+                         "stage": {"bytes": sb, "ms": c_ms, "achieved": sb / (c_ms * 1e-3) / 1e9, "frac": sb / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}}
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1 and not a.shard_of:
@@ -236,6 +480,20 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (a.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    legs = set() if a.legs == "none" else set(("fp32,rvs1024,cpu" if a.legs == "auto" else a.legs).split(","))
+    if a.no_cpu_baseline:
+        legs.discard("cpu")
+    if world > 1 or a.shard_of or a.dump_rewards:
+        legs = set()
+    # worker processes of the CPU leg: forked before this process touches the GPU
+    pools = None
+    if "cpu" in legs:
+        from oracle import oracle as _O
+        _O.build()
+        pools = CpuPools(3 * a.batch * 6)
+        pools.start()
+
+    import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU product path)"
     if a.all_ranks_on_gpu0:
         local_rank = 0
@@ -263,47 +521,21 @@ def main():
         st.args.emulate_shards = emulate
     M, D = st.M, len(cfg.DATASET.DG.TRAIN)
     n_rows = D * a.batch * M
+    K = 2 if cfg.DATASET.NAME == "optic" else 1
+
+    dump = [] if a.dump_rewards else None
+    elapsed, step_ms, kern_ms_l, call_ms_l = time_steps(st, a, world, a.steps, a.warmup, dump=dump)
+    ms_per_step = elapsed / a.steps * 1e3
+    kern_ms, call_ms = float(np.mean(kern_ms_l)), float(np.mean(call_ms_l))
 
     def sync():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        st.search_step(i, max_iters=1)
-    sync()
-    # everything allocated so far (model, dataset pool, kernel caches) is long-lived: keep the cyclic garbage collector from
-    # re-scanning it in the middle of a step (a full collection is a ~30 ms host pause -- longer than a whole step at 18 rows per rank)
-    import gc
-    gc.collect()
-    gc.freeze()
-    # events around the dominant kernel, one pair per timed step (recorded on the launch stream)
-    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    for e0, e1 in pairs:
-        e0.record(); e1.record()                     # force creation of the underlying hipEvent_t
-    sync()
-    t0 = time.perf_counter()
-    step_rewards = []
-    for i in range(a.steps):
-        _lib.PROFILE_EVENTS = pairs[i]
-        nr = st.search_step(a.warmup + i, max_iters=1)[3]
-        if a.dump_rewards:
-            from aadg_amd import search_dg as _sd
-            step_rewards.append((nr, _sd.LAST_RAW_REWARDS.clone()))
-    _lib.PROFILE_EVENTS = None
-    sync()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(t.item())
-    ms_per_step = elapsed / a.steps * 1e3
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in pairs]))
-
     # ---- the same step with the backbone removed (only what this repo implements) ------------------
     from aadg_amd.data import transform as T
     from aadg_amd.data.policy import DGMultiPolicy, parse_policies
-    K = 2
     plan = T.row_plan(D, a.batch, M)                      # this rank's rows of the batch (aadg_amd/distributed.py: RowPlan)
     z = torch.randn(plan.n_local, K, a.size, a.size, device="cuda", requires_grad=True)
     fe = torch.nn.functional.leaky_relu(torch.randn(n_rows, 128, device="cuda"), 0.2)
@@ -320,14 +552,14 @@ def main():
         loss, _, _ = _lib.policy_bce_loss(z, sample['aug_labels'], 1 if plan.sharded else M)
         loss.backward()
         rewards.zero_()
-        _lib.sinkhorn_rewards(fe, D, a.batch, M, rewards=rewards)
+        if D >= 2:
+            _lib.sinkhorn_rewards(fe, D, a.batch, M, rewards=rewards)
         if st.graphed is not None:
             st.graphed.update(_lib.normalize_rewards(rewards), entropies)
         else:
             st.controller_criterion(st.controller, policies, log_probs, entropies, _lib.normalize_rewards(rewards))
         return sample
 
-    units_last = None
     for _ in range(2):
         hot_step()
     sync()
@@ -338,20 +570,42 @@ def main():
     sync()
     hot_ms = (time.perf_counter() - t0) / HK * 1e3
 
-    # algorithmic bytes of one launch of the dominant kernel (this rank's slice of one batch plan)
+    # bytes of one launch (this rank's slice of one batch plan): the tile kernel's own, and SURVEY 8(d)'s for the whole call
     batch = [st.train_loader.dataset[0] for _ in range(a.batch)]
     flat, refs, _ = T.collect_refs(batch, nested=True)
     S = len(flat)
     from aadg_amd.distributed import shard_rows
     lo_s, hi_s = shard_rows(S, plan.rank, plan.world)
     units = T.refs_to_units(refs[lo_s:hi_s] + [refs[S + int(r)] for r in plan.rows])
-    alg = algorithmic_bytes(units, a.size, a.size, a.size, K)
-    achieved = alg / (kern_ms * 1e-3) / 1e9
+    Hs = st.train_loader.dataset.pool.images.shape[1]
+    kbytes = unit_bytes(units, Hs, Hs, a.size, K, False)
+    sbytes = unit_bytes(units, Hs, Hs, a.size, K, True)
+    achieved = kbytes / (kern_ms * 1e-3) / 1e9
 
+    out = None
     if rank == 0 and a.dump_rewards:
         with open(a.dump_rewards, "w") as f:
-            json.dump({"normalized": [n.tolist() for n, _ in step_rewards], "raw": [r.tolist() for _, r in step_rewards]}, f)
+            json.dump({"normalized": [n.tolist() for n, _ in dump], "raw": [r.tolist() for _, r in dump]}, f)
     if rank == 0:
+        traffic = committed("r02_traffic_k_fused3.json")
+        prof = committed("r02_bench_kernel_stats.json")
+        roof = {"bound": "hbm", "kernel": "k_fused3 (LDS-tiled op chain + Pillow-exact resample + crop + normalise + CHW float32 store)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": int(traffic["hbm_bytes_per_unit"] * len(units)) if traffic and traffic.get("size") == a.size else None,
+                "bytes_per_launch": kbytes, "kernel_ms": kern_ms, "units_per_launch": len(units),
+                "what": "bytes the bracketed kernel moves (source + mask read once, %d float32 planes written once) / mean of %d "
+                        "per-step HIP-event durations around exactly that kernel" % (3 + K, a.steps),
+                "stage": {"what": "SURVEY 8(d) algorithmic bytes of the whole augmentation call (source counted twice for units with a "
+                                  "statistics op) / events around ALL its kernels: k_tables, k_hist, k_hist_fused, k_lut, tile kernels",
+                          "bytes": sbytes, "ms": call_ms, "achieved": sbytes / (call_ms * 1e-3) / 1e9,
+                          "frac": sbytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        if traffic:
+            roof["traffic_source"] = "profiles/r02_traffic_k_fused3.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes), per unit x units"
+        if prof and prof.get("k_fused3_avg_ms"):
+            roof["rocprof"] = {"kernel_avg_ms": prof["k_fused3_avg_ms"], "frac": kbytes / (prof["k_fused3_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "file": "profiles/" + prof.get("file", "r02_bench_rocprofv3_kernel_stats.txt"),
+                               "note": "average duration of the same kernel in the committed rocprofv3 --kernel-trace --stats run of this "
+                                       "command (another box of the pool)"}
         out = {
             "metric": "policy-search steps/sec", "value": 1e3 / ms_per_step, "unit": "steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
@@ -359,26 +613,54 @@ def main():
             "dtype": "u8+f32 (augmentation / Sinkhorn / loss kernels); backbone %s" % a.backbone_dtype,
             "data": "synthetic",
             "inner_loop_img_per_s": n_rows * 1e3 / ms_per_step,
-            "config": {"workload": "BASELINE configs[1]: DeepLabv3+/%s, 3-domain Fundus-like OD/OC Sinkhorn search, %dx%d, "
-                                   "TRAIN.BATCH_SIZE=%d, CONTROLLER.M=%d -> %d augmented images per step, PPO controller"
-                                   % (a.backbone, a.size, a.size, a.batch, M, n_rows),
+            "step_ms": _stats(step_ms),
+            "config": {"workload": "%s: %s/%s, %d-domain %s Sinkhorn search, %dx%d, TRAIN.BATCH_SIZE=%d, CONTROLLER.M=%d -> %d augmented "
+                                   "images per step, %s controller"
+                                   % ("BASELINE configs[1]" if "optic_sinkhorn/diversity.yaml" in a.cfg.replace(os.sep, "/") and a.size == 512
+                                      else os.path.basename(a.cfg), cfg.MODEL.NAME, cfg.MODEL.BACKBONE, D, cfg.DATASET.NAME, a.size, a.size,
+                                      a.batch, M, n_rows, cfg.CONTROLLER.LOSS.upper()),
                        "images_per_step": n_rows,
                        "parallelism": "1 GPU" if world == 1 else
                                       "%d GPUs: domain-major (domain, policy) units cut by %s (rows per rank %s), one embedding all-gather + DDP "
                                       "gradient all-reduce%s" % (world, a.placement, "/".join(str(c) for c in plan.counts),
                                                                    "" if a.no_sync_bn else " + BatchNorm statistics all-reduce"),
                        "backbone_dtype": a.backbone_dtype},
-            "roofline": {"bound": "hbm", "kernel": "k_fused<16> (LDS-tiled ops + resample + crop + normalise + CHW store)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(len(units), a.size),
-                         "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms, "units_per_launch": len(units)},
+            "roofline": roof,
             "hot_path": {"ms_per_step": hot_ms, "steps_per_s": 1e3 / hot_ms, "img_per_s": n_rows * 1e3 / hot_ms,
                          "what": "controller sample + parse + draw + augmentation kernels + BCE/Dice kernel (fwd+bwd) + "
                                  "Sinkhorn kernel + reward normalise + PPO; backbone and discriminator removed"},
         }
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, st, a, a.cpu_units)
-            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+    # ---- extra legs (one GPU only) -------------------------------------------------------------------------------------
+    if rank == 0 and "rvs1024" in legs:
+        try:
+            out["rvs_1024"] = rvs_1024_leg()
+        except Exception as e:  # noqa: BLE001  -- an extra leg must not take the headline line down with it
+            out["rvs_1024"] = {"error": repr(e)}
+    if rank == 0 and "cpu" in legs:
+        try:
+            out["cpu_baseline"] = cpu_baseline(pools, cfg, st, a)
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(e)}
+        finally:
+            pools.close()
+    if rank == 0 and "fp32" in legs and a.backbone_dtype != "fp32":
+        try:
+            del st, z
+            torch.cuda.empty_cache()
+            import gc
+            gc.unfreeze()
+            gc.collect()
+            with contextlib.redirect_stdout(sys.stderr):
+                _, st32 = build_state(a, local_rank, world, backbone_dtype="fp32")
+            n32 = max(3, min(5, a.steps))
+            el32, sm32, _, _ = time_steps(st32, a, world, n32, 2, want_kernel_events=False)
+            out["fp32_backbone"] = {"ms_per_step": el32 / n32 * 1e3, "steps_per_s": n32 / el32, "steps": n32, "warmup": 2,
+                                    "step_ms": _stats(sm32),
+                                    "what": "the same step with the backbone convolutions in float32 (the reference's precision for this "
+                                            "config); everything else unchanged"}
+        except Exception as e:  # noqa: BLE001
+            out["fp32_backbone"] = {"error": repr(e)}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
