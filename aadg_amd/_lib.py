@@ -72,7 +72,7 @@ def load():
     lib.aadg_aug_u8_forward_ex.restype = _i
     lib.aadg_aug_u8_forward_ex.argtypes = lib.aadg_aug_u8_forward.argtypes + [_i, _i, _vp, _vp]
     lib.aadg_aug_u8_forward_ex2.restype = _i
-    lib.aadg_aug_u8_forward_ex2.argtypes = lib.aadg_aug_u8_forward_ex.argtypes + [_vp, _i, _i, _i]
+    lib.aadg_aug_u8_forward_ex2.argtypes = lib.aadg_aug_u8_forward_ex.argtypes + [_vp]
     lib.aadg_op_u8.restype = _i
     lib.aadg_op_u8.argtypes = [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp]
     lib.aadg_sinkhorn_workspace_bytes.restype = _sz
@@ -263,9 +263,9 @@ def validate_units(units, P, Hs, Ws):
 
 
 def launch_hints(units, Hs, Ws, crop):
-    """(classes, stats_mask, order, counts) for aadg_aug_u8_forward_ex2 -- mirrors unit_flow() in csrc/aug_u8.hip.
+    """(classes, stats_mask, order, counts, stat_lists) for aadg_aug_u8_forward_ex2 -- mirrors unit_flow() in csrc/aug_u8.hip.
     order: unit indices grouped by tile class (plain up-scaling, up-scaling with a Sharpness stencil, generic, staged);
-    counts = (n_plain, n_sharp, n_generic)."""
+    counts = (n_plain, n_sharp, n_generic); stat_lists[k]: the units whose k-th op needs image statistics."""
     n_ops = units["n_ops"]
     live = np.arange(MAX_OPS)[None, :] < n_ops[:, None]
     sharp = ((units["op"] == 8) & (units["farg"] != np.float32(1.0)) & live).sum(axis=1)
@@ -284,7 +284,14 @@ def launch_hints(units, Hs, Ws, crop):
     cls = np.where(up & (sharp == 0), 0, np.where(up, 1, np.where(generic, 2, 3)))
     order = np.argsort(cls, kind="stable").astype(np.int32)
     counts = (int((cls == 0).sum()), int((cls == 1).sum()), int((cls == 2).sum()))
-    return classes, stats_mask, order, counts
+    stat_lists = [np.nonzero(needs[:, k])[0].astype(np.int32) for k in range(MAX_OPS)]     # work lists of the histogram kernels
+    return classes, stats_mask, order, counts, stat_lists
+
+
+class AugLists(ctypes.Structure):
+    """mirror of `aadg_aug_lists` (include/aadg_hip.h): host struct of device index arrays"""
+    _fields_ = [("order", ctypes.c_void_p), ("n_plain", ctypes.c_int32), ("n_sharp", ctypes.c_int32), ("n_generic", ctypes.c_int32),
+                ("stat_units", ctypes.c_void_p * MAX_OPS), ("n_stat", ctypes.c_int32 * MAX_OPS)]
 
 
 # optional (start, stop) torch.cuda.Event pair recorded around the dominant kernel of the next
@@ -295,7 +302,8 @@ PROFILE_CALL_EVENTS = None
 _pinned = {}
 
 
-_REC = UNIT_DTYPE.itemsize + 4          # staging bytes per unit: the record + its slot in the class-order list
+_REC = UNIT_DTYPE.itemsize + 4 * (1 + MAX_OPS)   # staging bytes per unit: the record + its slot in the class-order list and in each
+                                                 # stage's statistics work list
 
 
 def _pinned_units(n):
@@ -331,13 +339,21 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
     ready = _pinned.get("units_ready")
     if ready is not None:
         ready.synchronize()          # previous copy out of the staging buffer has completed
-    classes, stats_mask, order, (n_plain, n_sharp, n_generic) = launch_hints(units, Hs, Ws, crop)
+    classes, stats_mask, order, (n_plain, n_sharp, n_generic), stat_lists = launch_hints(units, Hs, Ws, crop)
     nb_units = N * UNIT_DTYPE.itemsize                       # a multiple of 4: the int32 list behind it is aligned
     host = stage[:N * _REC].numpy()
     host[:nb_units] = units.view(np.uint8).reshape(-1)
-    host[nb_units:] = order.view(np.uint8)
+    host[nb_units:nb_units + 4 * N] = order.view(np.uint8)
     d_units = torch.empty(N * _REC, dtype=torch.uint8, device=dev)
-    d_units.copy_(stage[:N * _REC], non_blocking=True)          # records + class lists: one H2D copy
+    lists = AugLists()
+    lists.order = d_units.data_ptr() + nb_units
+    lists.n_plain, lists.n_sharp, lists.n_generic = n_plain, n_sharp, n_generic
+    for k, lst in enumerate(stat_lists):
+        off = nb_units + 4 * N * (1 + k)
+        host[off:off + 4 * lst.size] = lst.view(np.uint8)
+        lists.stat_units[k] = d_units.data_ptr() + off
+        lists.n_stat[k] = int(lst.size)
+    d_units.copy_(stage[:N * _REC], non_blocking=True)          # records + work lists: one H2D copy
     ready = torch.cuda.Event()
     ready.record()
     _pinned["units_ready"] = ready
@@ -350,7 +366,7 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
         PROFILE_CALL_EVENTS[0].record()
     rc = lib.aadg_aug_u8_forward_ex2(pool.data_ptr(), masks.data_ptr(), P, Hs, Ws, d_units.data_ptr(), N, max_ops, crop,
                                      dataset, out_img.data_ptr(), out_lbl.data_ptr(), ws.data_ptr(), ws.numel(), _stream(),
-                                     classes, stats_mask, ev0, ev1, d_units.data_ptr() + nb_units, n_plain, n_sharp, n_generic)
+                                     classes, stats_mask, ev0, ev1, ctypes.byref(lists))
     if PROFILE_CALL_EVENTS is not None:
         PROFILE_CALL_EVENTS[1].record()
     _check(rc, "aadg_aug_u8_forward")

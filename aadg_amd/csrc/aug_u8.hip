@@ -109,14 +109,13 @@ __device__ __forceinline__ const uint8_t* stage_input(const Bufs& b, const aadg_
 // ------------------------------------------------------------------------------------------------
 // k_hist: grid (chunks, N), 256 threads.  Thread = groups of 4 pixels (12 bytes, 3 dword loads).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_hist(Bufs bufs, UnitRef ur, int stage, int npix, int Hs, int Ws, int crop,
-                                              uint32_t* hist) {
-    const int u = blockIdx.y;
+__device__ __forceinline__ void hist_body(const Bufs& bufs, const UnitRef& ur, const int* __restrict__ ulist, int stage, int npix, int Hs,
+                                          int Ws, int crop, uint32_t* hist, int bx, int by, int nbx, uint32_t (*sh)[768]) {
+    const int u = ulist != nullptr ? ulist[by] : by;      // ulist: the units whose op `stage` needs statistics
     const aadg_unit& un = pick(ur, u);
     if (un.n_ops <= stage || !op_needs_stats(un.op[stage])) return;
     if (stage > 0 && unit_fusable(ur, un, Hs, Ws, crop)) return;   // k_hist_fused covers those
     const uint8_t* in = stage_input(bufs, un, u, stage);
-    __shared__ uint32_t sh[4][768];
     const int tid = threadIdx.x, wv = tid >> 6;
     for (int i = tid; i < 4 * 768; i += 256) (&sh[0][0])[i] = 0;
     __syncthreads();
@@ -126,7 +125,7 @@ __global__ __launch_bounds__(256) void k_hist(Bufs bufs, UnitRef ur, int stage, 
     if (vec) {
         const int ngroups = npix >> 2;
         const uint32_t* p32 = reinterpret_cast<const uint32_t*>(in);
-        for (int g = blockIdx.x * 256 + tid; g < ngroups; g += gridDim.x * 256) {
+        for (int g = bx * 256 + tid; g < ngroups; g += nbx * 256) {
             uint32_t a = p32[3 * g], b = p32[3 * g + 1], c = p32[3 * g + 2];
             uint32_t r0 = a & 255, g0 = (a >> 8) & 255, b0 = (a >> 16) & 255, r1 = a >> 24;
             uint32_t g1 = b & 255, b1 = (b >> 8) & 255, r2 = (b >> 16) & 255, g2 = b >> 24;
@@ -137,7 +136,7 @@ __global__ __launch_bounds__(256) void k_hist(Bufs bufs, UnitRef ur, int stage, 
             lsum += rgb2l(r0, g0, b0) + rgb2l(r1, g1, b1) + rgb2l(r2, g2, b2) + rgb2l(r3, g3, b3);
         }
     } else {
-        for (int p = blockIdx.x * 256 + tid; p < npix; p += gridDim.x * 256) {
+        for (int p = bx * 256 + tid; p < npix; p += nbx * 256) {
             uint32_t r = in[3 * (size_t)p], g = in[3 * (size_t)p + 1], b = in[3 * (size_t)p + 2];
             atomicAdd(&h[r], 1u); atomicAdd(&h[256 + g], 1u); atomicAdd(&h[512 + b], 1u);
             lsum += rgb2l(r, g, b);
@@ -151,6 +150,11 @@ __global__ __launch_bounds__(256) void k_hist(Bufs bufs, UnitRef ur, int stage, 
         if (v) atomicAdd(&gh[i], v);
     }
     if ((tid & 63) == 0 && lsum) atomicAdd(reinterpret_cast<unsigned long long*>(gh + 768), lsum);
+}
+__global__ __launch_bounds__(256) void k_hist(Bufs bufs, UnitRef ur, const int* __restrict__ ulist, int stage, int npix, int Hs, int Ws,
+                                              int crop, uint32_t* hist) {
+    __shared__ uint32_t sh[4][768];
+    hist_body(bufs, ur, ulist, stage, npix, Hs, Ws, crop, hist, blockIdx.x, blockIdx.y, gridDim.x, sh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -380,8 +384,7 @@ __device__ void bilinear_coeffs(int inSize, int outSize, int xx, int* xmin_out, 
     *xmin_out = xmin;
 }
 
-__global__ __launch_bounds__(256) void k_tables(UnitRef ur, int Hs, int Ws, int crop, int* tab) {
-    const int u = blockIdx.x;
+__device__ __forceinline__ void tables_body(const UnitRef& ur, int Hs, int Ws, int crop, int* tab, int u, int* nn_lds /* 2 * crop ints */) {
     const aadg_unit& un = pick(ur, u);
     int* base = tab + (size_t)u * crop * TAB_STRIDE;
     int* xmin = base;
@@ -408,7 +411,6 @@ __global__ __launch_bounds__(256) void k_tables(UnitRef ur, int Hs, int Ws, int 
     // NEAREST tables: ImagingScaleAffine accumulates xo += a0 in double, SEQUENTIALLY (the rounding of the
     // running sum decides exact ties), so one lane walks each axis; results are staged in LDS and written
     // out coalesced by the whole block.
-    extern __shared__ int nn_lds[];   // 2 * crop ints
     if (threadIdx.x == 0 || threadIdx.x == 64) {
         const bool isx = threadIdx.x == 0;
         const int outSize = isx ? w : h, inSize = isx ? Ws : Hs, off = isx ? ox : oy;
@@ -436,6 +438,20 @@ __global__ __launch_bounds__(256) void k_tables(UnitRef ur, int Hs, int Ws, int 
     }
     __syncthreads();
     for (int i = threadIdx.x; i < crop; i += 256) { xnn[i] = nn_lds[i]; ynn[i] = nn_lds[crop + i]; }
+}
+__global__ __launch_bounds__(256) void k_tables(UnitRef ur, int Hs, int Ws, int crop, int* tab) {
+    extern __shared__ int nn_dyn[];   // 2 * crop ints
+    tables_body(ur, Hs, Ws, crop, tab, blockIdx.x, nn_dyn);
+}
+// The coefficient / index tables depend on the unit records only, the stage-0 histograms on the records and the source images:
+// one launch for both (blocks [0, chunks * nstat): histogram chunks; the next N blocks: one unit's tables each) instead of two
+// latency-bound kernels back to back.  2 * crop ints of table scratch fit the histogram's 12 KiB for crop <= 1536.
+__global__ __launch_bounds__(256) void k_hist_tables(Bufs bufs, UnitRef ur, const int* __restrict__ ulist, int nstat, int chunks, int npix,
+                                                     int Hs, int Ws, int crop, uint32_t* hist, int* tab) {
+    __shared__ uint32_t sh[4][768];
+    const int b = blockIdx.x, nh = chunks * nstat;
+    if (b < nh) hist_body(bufs, ur, ulist, 0, npix, Hs, Ws, crop, hist, b % chunks, b / chunks, chunks, sh);
+    else tables_body(ur, Hs, Ws, crop, tab, b - nh, reinterpret_cast<int*>(&sh[0][0]));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -779,9 +795,9 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
 
 // k_hist_fused: grid (ceil(Ws/256), ceil(Hs/16), N); histogram of the image after `stage` ops (stage >= 1)
 __global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ pool, const aadg_unit* __restrict__ units,
-                                                    int stage, int Hs, int Ws, int crop, const uint8_t* __restrict__ lut,
-                                                    size_t lut_stage_stride, uint32_t* hist) {
-    const int u = blockIdx.z;
+                                                    const int* __restrict__ ulist, int stage, int Hs, int Ws, int crop,
+                                                    const uint8_t* __restrict__ lut, size_t lut_stage_stride, uint32_t* hist) {
+    const int u = ulist != nullptr ? ulist[blockIdx.z] : blockIdx.z;      // ulist: the units whose op `stage` needs statistics
     const aadg_unit& un = units[u];
     if (un.n_ops <= stage || !op_needs_stats(un.op[stage]) || !unit_fusable(true, un, Hs, Ws, crop)) return;
     __shared__ __attribute__((aligned(16))) uint32_t A[5632];
@@ -1458,22 +1474,32 @@ bool getenv_flag(const char* name) {
 
 // statistics + LUT (+ staged apply) for stages [0, max_ops)
 int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int crop, int max_ops, uint8_t* ws8,
-               const WsLayout& L, uint8_t* out_override, int classes, int stats_mask, hipStream_t st) {
+               const WsLayout& L, uint8_t* out_override, int classes, int stats_mask, hipStream_t st,
+               const aadg_aug_lists* lists = nullptr, int* tab = nullptr, bool* tables_done = nullptr) {
     const int npix = Hs * Ws;
     uint32_t* hist = reinterpret_cast<uint32_t*>(ws8 + L.hist);
     uint8_t* lut = ws8 + L.lut;
     const size_t lut_stage_stride = (size_t)N * 768;
     const dim3 g(chunks_for(npix), N);
     for (int k = 0; k < max_ops; ++k) {
-        if (stats_mask & (1 << k)) {
+        // work list of the statistics kernels of this stage (caller's, else every unit is offered and the others return)
+        const int* ulist = lists != nullptr ? lists->stat_units[k] : nullptr;
+        const int nstat = ulist != nullptr ? lists->n_stat[k] : N;
+        if ((stats_mask & (1 << k)) && nstat > 0) {
             AADG_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)N * HIST_STRIDE * 4, st));
-            if (k == 0 || (classes & HINT_STAGED)) {
-                hipLaunchKernelGGL(k_hist, g, dim3(256), 0, st, bufs, ur, k, npix, Hs, Ws, crop, hist);
+            if (k == 0 && tab != nullptr && 2 * crop <= 4 * 768) {
+                // stage-0 histograms and the resampling tables in one launch
+                hipLaunchKernelGGL(k_hist_tables, dim3(g.x * nstat + N), dim3(256), 0, st, bufs, ur, ulist, nstat, (int)g.x, npix, Hs, Ws,
+                                   crop, hist, tab);
+                AADG_LAUNCH_CHECK();
+                *tables_done = true;
+            } else if (k == 0 || (classes & HINT_STAGED)) {
+                hipLaunchKernelGGL(k_hist, dim3(g.x, nstat), dim3(256), 0, st, bufs, ur, ulist, k, npix, Hs, Ws, crop, hist);
                 AADG_LAUNCH_CHECK();
             }
             if (k > 0 && (classes & (HINT_FUSED | HINT_GENERIC))) {
-                const dim3 gf((Ws + 255) / 256, (Hs + 15) / 16, N);
-                hipLaunchKernelGGL(k_hist_fused, gf, dim3(256), 0, st, bufs.pool, ur.units, k, Hs, Ws, crop, lut, lut_stage_stride, hist);
+                const dim3 gf((Ws + 255) / 256, (Hs + 15) / 16, nstat);
+                hipLaunchKernelGGL(k_hist_fused, gf, dim3(256), 0, st, bufs.pool, ur.units, ulist, k, Hs, Ws, crop, lut, lut_stage_stride, hist);
                 AADG_LAUNCH_CHECK();
             }
         }
@@ -1498,7 +1524,12 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
                                        const aadg_unit* units, int N, int max_ops, int crop, int dataset,
                                        float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream,
                                        int classes_hint, int stats_mask_hint, void* ev_before_final, void* ev_after_final,
-                                       const int32_t* order, int n_plain, int n_sharp, int n_generic) {
+                                       const aadg_aug_lists* lists) {
+    const int32_t* order = lists ? lists->order : nullptr;
+    const int n_plain = lists ? lists->n_plain : 0, n_sharp = lists ? lists->n_sharp : 0, n_generic = lists ? lists->n_generic : 0;
+    if (lists != nullptr)
+        for (int k = 0; k < AADG_MAX_OPS; ++k)
+            if (lists->n_stat[k] < 0 || lists->n_stat[k] > N || (lists->n_stat[k] > 0 && lists->stat_units[k] == nullptr)) return AADG_E_BADARG;
     if (!pool || !masks || !units || !out_img || !out_lbl || !ws) return AADG_E_BADARG;
     if (P <= 0 || Hs <= 0 || Ws <= 0 || N <= 0 || crop <= 0) return AADG_E_BADARG;
     if (max_ops < 0 || max_ops > AADG_MAX_OPS) return AADG_E_BADARG;
@@ -1520,11 +1551,15 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
     if (classes == 0) classes = HINT_FUSED | HINT_STAGED | HINT_GENERIC;
     if ((Ws & 3) || (crop & 3)) classes = HINT_STAGED;        // unit_fusable() is false for every unit
     const int stats_mask = stats_mask_hint < 0 ? 0xF : stats_mask_hint;
-    int rc = run_stages(bufs, ur, N, Hs, Ws, crop, max_ops, ws8, L, nullptr, classes, stats_mask, st);
-    if (rc) return rc;
     int* tab = reinterpret_cast<int*>(ws8 + L.tab);
-    hipLaunchKernelGGL(k_tables, dim3(N), dim3(256), 2 * crop * sizeof(int), st, ur, Hs, Ws, crop, tab);
-    AADG_LAUNCH_CHECK();
+    bool tables_done = false;
+    int rc = run_stages(bufs, ur, N, Hs, Ws, crop, max_ops, ws8, L, nullptr, classes, stats_mask, st,
+                        (lists != nullptr && lists->stat_units[0] != nullptr) ? lists : nullptr, tab, &tables_done);
+    if (rc) return rc;
+    if (!tables_done) {
+        hipLaunchKernelGGL(k_tables, dim3(N), dim3(256), 2 * crop * sizeof(int), st, ur, Hs, Ws, crop, tab);
+        AADG_LAUNCH_CHECK();
+    }
     if (ev_before_final) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_before_final), st));
     if (classes & HINT_FUSED) {
         const dim3 g((crop + FT_W - 1) / FT_W, (crop + FT_H - 1) / FT_H, N);
@@ -1566,7 +1601,7 @@ extern "C" int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks,
                                       float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream,
                                       int classes_hint, int stats_mask_hint, void* ev_before_final, void* ev_after_final) {
     return aadg_aug_u8_forward_ex2(pool, masks, P, Hs, Ws, units, N, max_ops, crop, dataset, out_img, out_lbl, ws, ws_bytes, stream,
-                                   classes_hint, stats_mask_hint, ev_before_final, ev_after_final, nullptr, 0, 0, 0);
+                                   classes_hint, stats_mask_hint, ev_before_final, ev_after_final, nullptr);
 }
 
 extern "C" int aadg_aug_u8_forward(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,

@@ -98,18 +98,27 @@ int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks, int P, int
                            float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream,
                            int classes_hint, int stats_mask_hint, void* ev_before_final, void* ev_after_final);
 
-/* Same, with the caller's classification of the units: `order` (device, int32 [N]) lists the unit indices grouped by tile class --
- * first the n_plain up-scaling units (both scaled sizes >= the source's) that chain no Sharpness stencil, then the n_sharp
- * up-scaling units that do, then the n_generic units that shrink an axis by at most 2x; the remaining (staged) units may follow in
- * any order.  The tile kernels then launch exactly one workgroup per tile of a unit of their class instead of one per tile
- * of EVERY unit (a workgroup of the wrong class returns at once but still occupies a slot with its LDS for about a
- * microsecond).  order = NULL: as aadg_aug_u8_forward_ex.  A unit listed under the wrong class is skipped (its outputs are not
- * written): the lists must follow unit_flow() (see aadg_amd/_lib.py: launch_hints). */
+/* Same, with the caller's work lists (a HOST struct of DEVICE index arrays; NULL = aadg_aug_u8_forward_ex).  The kernels of the call
+ * then launch one workgroup per tile of a unit THEY process instead of one per tile of EVERY unit (a workgroup that finds the wrong
+ * class returns at once but still occupies a slot with its LDS for about a microsecond).
+ *   order       int32 [N]: unit indices grouped by tile class -- first the n_plain up-scaling units (both scaled sizes >= the
+ *               source's) that chain no Sharpness stencil, then the n_sharp up-scaling units that do, then the n_generic units that
+ *               shrink an axis by at most 2x; the remaining (staged) units follow in any order.
+ *   stat_units  per op slot k: the n_stat[k] units whose k-th op needs image statistics (AutoContrast / Equalize / Contrast) --
+ *               the work list of the histogram kernels of that stage.  stat_units[0] == NULL: no statistics lists.
+ * A unit listed under the wrong class is skipped (its outputs are not written): the lists must follow unit_flow() of
+ * csrc/aug_u8.hip (aadg_amd/_lib.py: launch_hints builds them from the host copy of the unit records). */
+typedef struct aadg_aug_lists {
+    const int32_t* order;
+    int32_t n_plain, n_sharp, n_generic;
+    const int32_t* stat_units[AADG_MAX_OPS];
+    int32_t n_stat[AADG_MAX_OPS];
+} aadg_aug_lists;
 int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,
                             const aadg_unit* units, int N, int max_ops, int crop, int dataset,
                             float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream,
                             int classes_hint, int stats_mask_hint, void* ev_before_final, void* ev_after_final,
-                            const int32_t* order, int n_plain, int n_sharp, int n_generic);
+                            const aadg_aug_lists* lists);
 
 /* One registry op on one image, replaces fn(img, mask, v) of augment_list()
  * (data/basic.py:70-120,137-167) for uint8 HWC tensors.  ws >= aadg_aug_u8_workspace_bytes(1,H,W,0);

@@ -12,7 +12,7 @@ rs = np.random.RandomState(1023)
 P, N = 24, 144
 imgs, msks = synth_pool(rs, P, H, H, vessel=True)
 units = random_units(rs, N, P, H, H, crop, (0.5, 2.0))
-cls, sm = _lib.launch_hints(units, H, H, crop)
+cls, sm = _lib.launch_hints(units, H, H, crop)[:2]
 n_f = int(((units["scaled_w"] >= H) & (units["scaled_h"] >= H)).sum())
 d_img, d_msk = torch.from_numpy(imgs).cuda(), torch.from_numpy(msks).cuda()
 oi = torch.empty((N, 3, crop, crop), device="cuda"); ol = torch.empty((N, 1, crop, crop), device="cuda")
