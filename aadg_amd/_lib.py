@@ -29,7 +29,7 @@ DATASET_OPTIC, DATASET_VESSEL = 0, 1
 EXPORTS = [
     "aadg_abi_version",
     "aadg_aug_u8_workspace_bytes", "aadg_aug_u8_forward", "aadg_aug_u8_forward_ex", "aadg_aug_u8_forward_ex2", "aadg_op_u8",
-    "aadg_sinkhorn_workspace_bytes", "aadg_sinkhorn_divergence_f32", "aadg_sinkhorn_rewards_f32",
+    "aadg_sinkhorn_workspace_bytes", "aadg_sinkhorn_divergence_f32", "aadg_sinkhorn_rewards_f32", "aadg_sinkhorn_rewards_norm_f32",
     "aadg_normalize_rewards_f32",
     "aadg_seg_loss_workspace_bytes", "aadg_seg_bce_dice_f32",
     "aadg_fop_workspace_bytes", "aadg_fop_f32",
@@ -46,7 +46,7 @@ EXPORTS = [
     "aadg_conv1x1_wgrad_supported", "aadg_conv1x1_wgrad_bf16",
     "aadg_controller_supported", "aadg_controller_workspace_bytes", "aadg_controller_sample_f32",
     "aadg_controller_ppo_update_f32",
-    "aadg_embed_prologue_f32",
+    "aadg_embed_prologue_f32", "aadg_embed_prologue_norm_f32",
 ]
 
 _lib = None
@@ -81,6 +81,8 @@ def load():
     lib.aadg_sinkhorn_divergence_f32.argtypes = [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _sz, _vp]
     lib.aadg_sinkhorn_rewards_f32.restype = _i
     lib.aadg_sinkhorn_rewards_f32.argtypes = [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _sz, _vp]
+    lib.aadg_sinkhorn_rewards_norm_f32.restype = _i
+    lib.aadg_sinkhorn_rewards_norm_f32.argtypes = [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _sz, _vp]
     lib.aadg_normalize_rewards_f32.restype = _i
     lib.aadg_normalize_rewards_f32.argtypes = [_vp, _i, _vp, _vp]
     if hasattr(lib, "aadg_seg_bce_dice_f32"):
@@ -173,6 +175,8 @@ def load():
     lib.aadg_controller_ppo_update_f32.argtypes = [_vp] * 3 + [_i] * 7 + [_f] + [_vp] * 3 + [_f, _i, _i, _f, _f, _f, _f, _vp, _vp, _sz, _vp]
     lib.aadg_embed_prologue_f32.restype = _i
     lib.aadg_embed_prologue_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp]
+    lib.aadg_embed_prologue_norm_f32.restype = _i
+    lib.aadg_embed_prologue_norm_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]
     if lib.aadg_abi_version() != 2:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
@@ -392,10 +396,11 @@ def op_u8(img, op, iarg=0, farg=0.0, rect=None):
 
 
 # ------------------------------------------------------------------------------------------------
-def sinkhorn_rewards(fe, D, B, M, blur=0.05, scaling=0.5, rewards=None):
-    """fe f32 [D*B*M, E] in collate order (row (b*D+d)*M + j). rewards[j] += sum_pairs S(x_d1, x_d2)."""
+def sinkhorn_rewards(fe, D, B, M, blur=0.05, scaling=0.5, rewards=None, row_norm=None):
+    """fe f32 [D*B*M, E] in collate order (row (b*D+d)*M + j). rewards[j] += sum_pairs S(x_d1, x_d2).
+    row_norm (optional, f32 [D*B*M]): |fe[n]| from embed_prologue(..., want_norm=True); the kernel then skips its norm pass."""
     lib = load()
-    _require_cuda(fe, rewards)
+    _require_cuda(fe, rewards, row_norm)
     if fe.dtype != torch.float32 or fe.dim() != 2 or fe.shape[0] != D * B * M:
         raise AadgError("fe must be float32 [D*B*M, E]")
     if rewards is None:
@@ -403,8 +408,14 @@ def sinkhorn_rewards(fe, D, B, M, blur=0.05, scaling=0.5, rewards=None):
     P = D * (D - 1) // 2
     nb = lib.aadg_sinkhorn_workspace_bytes(M * P, B, fe.shape[1])
     ws = workspace(nb, fe.device, "sinkhorn")
-    rc = lib.aadg_sinkhorn_rewards_f32(fe.data_ptr(), D, B, M, fe.shape[1], blur, scaling, rewards.data_ptr(),
-                                       ws.data_ptr(), ws.numel(), _stream())
+    if row_norm is not None:
+        if row_norm.dtype != torch.float32 or row_norm.numel() != fe.shape[0]:
+            raise AadgError("row_norm must be float32 [D*B*M]")
+        rc = lib.aadg_sinkhorn_rewards_norm_f32(fe.data_ptr(), row_norm.data_ptr(), D, B, M, fe.shape[1], blur, scaling,
+                                                rewards.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    else:
+        rc = lib.aadg_sinkhorn_rewards_f32(fe.data_ptr(), D, B, M, fe.shape[1], blur, scaling, rewards.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), _stream())
     _check(rc, "aadg_sinkhorn_rewards_f32")
     return rewards
 
@@ -1191,9 +1202,9 @@ def controller_ppo_update(controller, M, exp_avg, exp_avg_sq, policies, old_log_
 
 
 # ------------------------------------------------------------------------------------------------
-def embed_prologue(x, w1, b1, w2=None, b2=None, slope=0.2):
+def embed_prologue(x, w1, b1, w2=None, b2=None, slope=0.2, want_norm=False):
     """(out [N, D] or None, fe [N, E]): fe = LeakyReLU(x W1^T + b1), out = fe W2^T + b2 -- the no-grad EMA branch of the
-    domain discriminator, one launch."""
+    domain discriminator, one launch.  want_norm: returns (out, fe, |fe[n]|_2 [N]) for sinkhorn_rewards(row_norm=...)."""
     lib = load()
     _require_cuda(w1, b1, w2, b2)
     if not x.is_cuda:
@@ -1210,6 +1221,12 @@ def embed_prologue(x, w1, b1, w2=None, b2=None, slope=0.2):
         w2, b2 = w2.detach().contiguous(), b2.detach().contiguous()
         D = w2.shape[0]
         out = torch.empty((N, D), dtype=torch.float32, device=x.device)
+    if want_norm:
+        nrm = torch.empty(N, dtype=torch.float32, device=x.device)
+        rc = lib.aadg_embed_prologue_norm_f32(x.data_ptr(), x.stride(0), N, C, w1.data_ptr(), b1.data_ptr(), E, _ptr(w2), _ptr(b2), D,
+                                              float(slope), fe.data_ptr(), _ptr(out), nrm.data_ptr(), _stream())
+        _check(rc, "aadg_embed_prologue_norm_f32")
+        return out, fe, nrm
     rc = lib.aadg_embed_prologue_f32(x.data_ptr(), x.stride(0), N, C, w1.data_ptr(), b1.data_ptr(), E, _ptr(w2), _ptr(b2), D,
                                      float(slope), fe.data_ptr(), _ptr(out), _stream())
     _check(rc, "aadg_embed_prologue_f32")

@@ -22,7 +22,7 @@ struct Problem {
 };
 
 template <bool LAW>
-__global__ __launch_bounds__(256) void k_sinkhorn(const float* __restrict__ feat, int ld, int E,
+__global__ __launch_bounds__(256) void k_sinkhorn(const float* __restrict__ feat, const float* __restrict__ row_norm, int ld, int E,
                                                   const int* __restrict__ cloud_rows,
                                                   const int* __restrict__ cloud_off,
                                                   const int* __restrict__ prob_xy, int D, int B, int M,
@@ -73,12 +73,18 @@ __global__ __launch_bounds__(256) void k_sinkhorn(const float* __restrict__ feat
     for (int r = tid >> 6; r < n + m; r += 4) {
         const bool is_y = r >= n;
         const int rr = is_y ? r - n : r;
-        const float* src = feat + (size_t)row_of(is_y, rr) * ld;
+        const int grow = row_of(is_y, rr);
+        const float* src = feat + (size_t)grow * ld;
         float* dst = (is_y ? ys : xs) + (size_t)rr * ldx;
-        float ss = 0.f;
-        for (int k = tid & 63; k < E; k += 64) { const float v = src[k]; dst[k] = v; ss = fmaf(v, v, ss); }
-        ss = wave_sum(ss);
-        if ((tid & 63) == 0) (is_y ? nrm_y : nrm_x)[rr] = sqrtf(ss);
+        if (row_norm != nullptr) {                           // norms from the producer (aadg_embed_prologue_norm_f32)
+            for (int k = tid & 63; k < E; k += 64) dst[k] = src[k];
+            if ((tid & 63) == 0) (is_y ? nrm_y : nrm_x)[rr] = row_norm[grow];
+        } else {
+            float ss = 0.f;
+            for (int k = tid & 63; k < E; k += 64) { const float v = src[k]; dst[k] = v; ss = fmaf(v, v, ss); }
+            ss = wave_sum(ss);
+            if ((tid & 63) == 0) (is_y ? nrm_y : nrm_x)[rr] = sqrtf(ss);
+        }
     }
     __syncthreads();
 
@@ -218,13 +224,14 @@ size_t lds_bytes(int nmax, int E) {
 
 template <bool LAW>
 int launch(const float* feat, int ld, int E, const int* cloud_rows, const int* cloud_off, const int* prob_xy, int D,
-           int B, int M, int n_prob, int nmax, float blur, float scaling, float* out, hipStream_t st) {
+           int B, int M, int n_prob, int nmax, float blur, float scaling, float* out, hipStream_t st,
+           const float* row_norm = nullptr) {
     const size_t lds = lds_bytes(nmax, E);
     if (lds > 160 * 1024) return AADG_E_UNSUPPORTED;
     if (lds > 48 * 1024)
         AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sinkhorn<LAW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_sinkhorn<LAW>, dim3(n_prob), dim3(256), lds, st, feat, ld, E, cloud_rows, cloud_off, prob_xy, D,
+    hipLaunchKernelGGL(k_sinkhorn<LAW>, dim3(n_prob), dim3(256), lds, st, feat, row_norm, ld, E, cloud_rows, cloud_off, prob_xy, D,
                        B, M, nmax, blur, scaling, out);
     AADG_LAUNCH_CHECK();
     return 0;
@@ -259,8 +266,8 @@ extern "C" int aadg_sinkhorn_divergence_f32(const float* feat, int ld, int E, co
                          reinterpret_cast<hipStream_t>(stream));
 }
 
-extern "C" int aadg_sinkhorn_rewards_f32(const float* fe, int D, int B, int M, int E, float blur, float scaling,
-                                         float* rewards_accum, void* ws, size_t ws_bytes, void* stream) {
+static int sinkhorn_rewards(const float* fe, const float* row_norm, int D, int B, int M, int E, float blur, float scaling,
+                            float* rewards_accum, void* ws, size_t ws_bytes, void* stream) {
     if (!fe || !rewards_accum || !ws) return AADG_E_BADARG;
     if (D < 2 || B <= 0 || M <= 0 || E <= 0) return AADG_E_BADARG;
     if (!(blur > 0.f) || !(scaling > 0.f && scaling < 1.f)) return AADG_E_BADARG;
@@ -268,11 +275,23 @@ extern "C" int aadg_sinkhorn_rewards_f32(const float* fe, int D, int B, int M, i
     if (ws_bytes < aadg_align_up((size_t)M * P * sizeof(float), 256)) return AADG_E_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float* dist = reinterpret_cast<float*>(ws);
-    int rc = launch<true>(fe, E, E, nullptr, nullptr, nullptr, D, B, M, M * P, B, blur, scaling, dist, st);
+    int rc = launch<true>(fe, E, E, nullptr, nullptr, nullptr, D, B, M, M * P, B, blur, scaling, dist, st, row_norm);
     if (rc) return rc;
     hipLaunchKernelGGL(k_rewards_accum, dim3((M + 63) / 64), dim3(64), 0, st, dist, M, P, rewards_accum);
     AADG_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int aadg_sinkhorn_rewards_f32(const float* fe, int D, int B, int M, int E, float blur, float scaling,
+                                         float* rewards_accum, void* ws, size_t ws_bytes, void* stream) {
+    return sinkhorn_rewards(fe, nullptr, D, B, M, E, blur, scaling, rewards_accum, ws, ws_bytes, stream);
+}
+
+extern "C" int aadg_sinkhorn_rewards_norm_f32(const float* fe, const float* row_norm, int D, int B, int M, int E, float blur,
+                                              float scaling, float* rewards_accum, void* ws, size_t ws_bytes, void* stream) {
+    if (!row_norm) return AADG_E_BADARG;
+    if ((long long)B > 0 && lds_bytes(B, E) > 160 * 1024) return AADG_E_UNSUPPORTED;      // the large-cloud path computes its own norms
+    return sinkhorn_rewards(fe, row_norm, D, B, M, E, blur, scaling, rewards_accum, ws, ws_bytes, stream);
 }
 
 extern "C" int aadg_normalize_rewards_f32(const float* rewards, int M, float* out, void* stream) {

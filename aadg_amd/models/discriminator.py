@@ -50,19 +50,26 @@ class MomentumFeatureDiscriminator(nn.Module):
         for q, k in self._pairs():
             k.data = q.data
 
-    def forward(self, x, momentum=False, return_feature=False):
+    def forward(self, x, momentum=False, return_feature=False, return_norm=False):
+        """return_norm (momentum branch on the GPU only): also |fe[n]|_2, a by-product of the fused prologue that the Sinkhorn
+        kernel takes as the denominators of its cosine cost (None when the fused kernel did not run)."""
+        nrm = None
         if momentum:
             with torch.no_grad():
                 if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] <= 4096:
                     # the reward's embedding prologue as one HIP launch (csrc/embed.hip)
                     from .. import _lib
                     lin = self.mom_dis[0]
-                    out, fe = _lib.embed_prologue(x, lin.weight, lin.bias, self.mom_fc.weight, self.mom_fc.bias,
-                                                  self.mom_dis[1].negative_slope)
+                    res = _lib.embed_prologue(x, lin.weight, lin.bias, self.mom_fc.weight, self.mom_fc.bias,
+                                              self.mom_dis[1].negative_slope, want_norm=return_norm)
+                    out, fe = res[0], res[1]
+                    nrm = res[2] if return_norm else None
                 else:
                     fe = self.mom_dis(x)
                     out = self.mom_fc(fe)
         else:
             fe = self.dis(x)
             out = self.fc(fe)
+        if return_norm:
+            return out, fe, nrm
         return (out, fe) if return_feature else out

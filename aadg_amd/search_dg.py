@@ -106,7 +106,7 @@ def inner_iteration(config, sample, model, discriminator, dis_criterion, model_o
     feature = feature.detach().float()
     # action: EMA-branch embeddings (no grad, outside the DDP wrapper: nothing to reduce); bp: online branch trained on the
     # soft domain codes
-    dis_output, domain_feature = _bare(discriminator)(feature, momentum=True, return_feature=True)
+    dis_output, domain_feature, fe_norm = _bare(discriminator)(feature, momentum=True, return_feature=True, return_norm=True)
     dis_loss_bp = dis_criterion(discriminator(feature, momentum=False), domain_gt)
     # sigmoid + per-policy BCE + Dice, one fused pass (forward + gradient).  mean_j BCE_j == mean over all rows (every policy
     # owns N/M rows), so a rank whose local rows are not policy-interleaved takes the plain mean of its rows.
@@ -125,10 +125,11 @@ def inner_iteration(config, sample, model, discriminator, dis_criterion, model_o
         if not emulate and not adist.is_dist():
             raise RuntimeError("row-sharded batch without an initialised process group")
         fe_all = plan.gather(fe_all, emulate=emulate)
+        fe_norm = None                                       # the gathered rows' norms are recomputed by the reward kernel
     before = rewards.clone()
     B = n_rows // (M * n_domains)
     if n_domains >= 2:                                   # a single source domain has no domain pair to compare (BASELINE configs[0])
-        _lib.sinkhorn_rewards(fe_all, n_domains, B, M, rewards=rewards)
+        _lib.sinkhorn_rewards(fe_all, n_domains, B, M, rewards=rewards, row_norm=fe_norm)
     diversity_ot = (rewards - before).sum()
     if after_rewards is not None:
         after_rewards()

@@ -146,6 +146,10 @@ int aadg_sinkhorn_divergence_f32(const float* feat, int ld, int E, const int32_t
 int aadg_sinkhorn_rewards_f32(const float* fe, int D, int B, int M, int E, float blur,
                               float scaling, float* rewards_accum, void* ws, size_t ws_bytes,
                               void* stream);
+/* the same with the Euclidean norm of every row supplied by the producer of fe (aadg_embed_prologue_norm_f32): the kernel skips
+ * its own norm reduction; row_norm [D*B*M].  LDS-resident clouds only (AADG_E_UNSUPPORTED otherwise). */
+int aadg_sinkhorn_rewards_norm_f32(const float* fe, const float* row_norm, int D, int B, int M, int E, float blur,
+                                   float scaling, float* rewards_accum, void* ws, size_t ws_bytes, void* stream);
 /* (r - mean) / (std_unbiased + 1e-5), search_dg.py:214 */
 int aadg_normalize_rewards_f32(const float* rewards, int M, float* out, void* stream);
 
@@ -369,6 +373,12 @@ int aadg_controller_ppo_update_f32(void* const* params, void* const* exp_avg, vo
 int aadg_embed_prologue_f32(const float* x, int ldx, int N, int C, const float* W1, const float* b1, int E,
                             const float* W2, const float* b2, int D, float slope, float* fe, float* out,
                             void* stream);
+/* the same, also writing row_norm[n] = |fe[n]|_2 for aadg_sinkhorn_rewards_norm_f32 (SURVEY (f)1: the producer hands the cosine
+ * cost its denominators).  The rows themselves stay un-normalised: geomloss derives the epsilon schedule from the diameter of
+ * the RAW clouds. */
+int aadg_embed_prologue_norm_f32(const float* x, int ldx, int N, int C, const float* W1, const float* b1, int E,
+                                 const float* W2, const float* b2, int D, float slope, float* fe, float* out,
+                                 float* row_norm, void* stream);
 
 #ifdef __cplusplus
 }
