@@ -47,6 +47,7 @@ EXPORTS = [
     "aadg_controller_supported", "aadg_controller_workspace_bytes", "aadg_controller_sample_f32",
     "aadg_controller_ppo_update_f32",
     "aadg_embed_prologue_f32", "aadg_embed_prologue_norm_f32",
+    "aadg_upsample_sum", "aadg_upsample_sum_backward",
 ]
 
 _lib = None
@@ -175,6 +176,10 @@ def load():
     lib.aadg_controller_ppo_update_f32.argtypes = [_vp] * 3 + [_i] * 7 + [_f] + [_vp] * 3 + [_f, _i, _i, _f, _f, _f, _f, _vp, _vp, _sz, _vp]
     lib.aadg_embed_prologue_f32.restype = _i
     lib.aadg_embed_prologue_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp]
+    lib.aadg_upsample_sum.restype = _i
+    lib.aadg_upsample_sum.argtypes = [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]
+    lib.aadg_upsample_sum_backward.restype = _i
+    lib.aadg_upsample_sum_backward.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
     lib.aadg_embed_prologue_norm_f32.restype = _i
     lib.aadg_embed_prologue_norm_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]
     if lib.aadg_abi_version() != 2:
@@ -569,6 +574,47 @@ class _UpsampleBilinearAC(torch.autograd.Function):
 
 def upsample_bilinear_ac(x, size):
     return _UpsampleBilinearAC.apply(x, tuple(size))
+
+
+class _UpsampleSum(torch.autograd.Function):
+    """full + sum_i F.interpolate(low_i, full.shape[-2:], mode='bilinear', align_corners=False) in one pass (csrc/upsample_sum.hip)."""
+
+    @staticmethod
+    def forward(ctx, full, *lows):
+        lib = load()
+        N, C, H, W = full.shape
+        out = torch.empty_like(full)
+        ptrs = (ctypes.c_void_p * len(lows))(*[t.data_ptr() for t in lows])
+        hs = (ctypes.c_int * len(lows))(*[t.shape[2] for t in lows])
+        ws_ = (ctypes.c_int * len(lows))(*[t.shape[3] for t in lows])
+        _check(lib.aadg_upsample_sum(full.data_ptr(), ptrs, hs, ws_, len(lows), out.data_ptr(), N * C, H, W, _BN_DTYPES[full.dtype], _stream()),
+               "aadg_upsample_sum")
+        ctx.low_shapes = [tuple(t.shape) for t in lows]
+        ctx.out_hw = (H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load()
+        g = g.contiguous()
+        H, W = ctx.out_hw
+        grads = []
+        for shp in ctx.low_shapes:
+            d = torch.empty(shp, dtype=g.dtype, device=g.device)
+            _check(lib.aadg_upsample_sum_backward(g.data_ptr(), d.data_ptr(), shp[0] * shp[1], shp[2], shp[3], H, W, _BN_DTYPES[g.dtype],
+                                                  _stream()), "aadg_upsample_sum_backward")
+            grads.append(d)
+        return (g,) + tuple(grads)
+
+
+def upsample_sum(full, lows):
+    """full [N,C,H,W] + the bilinear (align_corners=False) resizes of `lows` ([N,C,h_i,w_i], at most 3) to H x W; float32 / bfloat16."""
+    tensors = [full] + list(lows)
+    _require_cuda(*tensors)
+    if full.dim() != 4 or full.dtype not in _BN_DTYPES or len(lows) > 3 or any(t.dtype != full.dtype or t.dim() != 4 or
+                                                                              t.shape[:2] != full.shape[:2] for t in lows):
+        raise AadgError("upsample_sum: expected NCHW float32/bfloat16 tensors of one dtype with equal N and C (at most 3 low maps)")
+    return _UpsampleSum.apply(full, *lows)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -77,7 +77,17 @@ class DWConv(nn.Module):
         self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
 
     def forward(self, x, H, W):
-        y = self.dwconv(_tokens_as_map(x, H, W))                     # channels-last in, channels-last out
+        m = _tokens_as_map(x, H, W)
+        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
+            # the library's channels-last depthwise paths are pathological here (naive double-precision kernels forward, a
+            # 30 ms grouped-convolution weight gradient per block): go through NCHW and the LDS-tiled kernels of
+            # csrc/depthwise.hip (float32 master weights, own weight gradient) -- two transposing copies around them
+            from .. import _lib
+            mc = m.contiguous()
+            if _lib.dwconv3x3_supported(mc, self.dwconv.weight, 1):
+                y = _lib.dwconv3x3(mc, self.dwconv.weight, 1) + self.dwconv.bias.to(mc.dtype)[None, :, None, None]
+                return y.flatten(2).transpose(1, 2)
+        y = self.dwconv(m)                                            # channels-last in, channels-last out
         return y.permute(0, 2, 3, 1).reshape(x.shape)
 
 
@@ -212,16 +222,21 @@ class SegFormerHead(nn.Module):
         c1 = feats[0]
         size = c1.shape[-2:]
         wf = self.linear_fuse.conv.weight.flatten(1)                   # [dim, 4 * dim], concat order c4, c3, c2, c1
-        acc = None
+        ys = []
         for k, (lin, f) in enumerate(zip((self.linear_c4, self.linear_c3, self.linear_c2, self.linear_c1),
                                          (feats[3], feats[2], feats[1], feats[0]))):
             wk = wf[:, k * self.dim:(k + 1) * self.dim]
             w = (wk @ lin.proj.weight).to(f.dtype)                     # fuse slice folded into the stage's Linear: [dim, C_k]
             b = (wk @ lin.proj.bias).to(f.dtype)
-            y = F.conv2d(f, w[:, :, None, None], b)                    # at the stage's own resolution
-            if y.shape[-2:] != size:
-                y = F.interpolate(y, size=size, mode='bilinear', align_corners=False)
-            acc = y if acc is None else acc + y
+            ys.append(F.conv2d(f, w[:, :, None, None], b))             # at the stage's own resolution
+        full, lows = ys[3], ys[:3]
+        if full.is_cuda and full.dtype in (torch.float32, torch.bfloat16) and all(y.dtype == full.dtype for y in lows):
+            from .. import _lib
+            acc = _lib.upsample_sum(full.contiguous(), [y.contiguous() for y in lows])      # one pass: resize x3 + add (HIP)
+        else:
+            acc = full
+            for y in lows:
+                acc = acc + F.interpolate(y, size=size, mode='bilinear', align_corners=False)
         x = bn_act(self.linear_fuse.bn, acc.contiguous(), 'relu')
         return self.linear_pred(self.dropout(x))
 

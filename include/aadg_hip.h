@@ -380,6 +380,19 @@ int aadg_embed_prologue_norm_f32(const float* x, int ldx, int N, int C, const fl
                                  const float* W2, const float* b2, int D, float slope, float* fe, float* out,
                                  float* row_norm, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * "Resize to the stride-4 grid and add" of the all-MLP segmentation head (BASELINE configs[4]; the reference head resizes each
+ * stage's projection with bilinear, align_corners = False and concatenates them:
+ * models/mmseg/models/decode_heads/segformer_head.py:66-80 -- aadg_amd/models/segformer.py folds the fuse convolution into the
+ * projections, which turns the concatenation into this sum).
+ *   out [planes, H, W] = full [planes, H, W] (NULL = 0) + sum_i bilinear(lows[i] [planes, low_h[i], low_w[i]]),  n_low <= 3
+ * dtype 0 float32 / 1 bfloat16 for all tensors; low_h / low_w are host arrays.  Backward: d full = d out;
+ * aadg_upsample_sum_backward gives d lows[i] [planes, h, w] from d out (gathered, no atomics).
+ * ------------------------------------------------------------------------------------------- */
+int aadg_upsample_sum(const void* full, const void* const* lows, const int* low_h, const int* low_w, int n_low, void* out,
+                      int planes, int H, int W, int dtype, void* stream);
+int aadg_upsample_sum_backward(const void* dout, void* dlow, int planes, int h, int w, int H, int W, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,3 +106,30 @@ def test_search_step_segformer_8_domains(hip):
     got = hip.sinkhorn_rewards(torch.from_numpy(fe).cuda(), 8, 2, 6).cpu().numpy()
     want = O.sinkhorn_rewards(fe, 8, 2, 6)
     assert np.abs(got - want).max() < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 5, 32, 32), (1, 3, 24, 40), (2, 4, 16, 8)])
+def test_upsample_sum_matches_interpolate(hip, dtype, shape):
+    """aadg_upsample_sum / aadg_upsample_sum_backward vs full + sum F.interpolate(low_i, bilinear, align_corners=False),
+    forward and all four gradients (factors 2, 4, 8 and a non-integer one)."""
+    torch.manual_seed(sum(shape))
+    N, C, H, W = shape
+    full = torch.randn(shape, device="cuda").to(dtype).requires_grad_(True)
+    lows = [torch.randn(N, C, max(1, H // f), max(1, W // f), device="cuda").to(dtype).requires_grad_(True) for f in (8, 4, 2)]
+    if H == 24:
+        lows[0] = torch.randn(N, C, 5, 7, device="cuda").to(dtype).requires_grad_(True)       # 4.8x / 5.7x
+    got = hip.upsample_sum(full, lows)
+    fr = full.detach().float().requires_grad_(True)
+    lr = [t.detach().float().requires_grad_(True) for t in lows]
+    want = fr
+    for t in lr:
+        want = want + F.interpolate(t, size=(H, W), mode="bilinear", align_corners=False)
+    tol = 3e-2 if dtype == torch.bfloat16 else 1e-5
+    assert got.dtype == dtype and (got.float() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+    g = torch.randn(shape, device="cuda").to(dtype)
+    got.backward(g)
+    want.backward(g.float())
+    assert torch.equal(full.grad, g)
+    for a, b in zip(lows, lr):
+        assert (a.grad.float() - b.grad).abs().max().item() <= (5e-2 if dtype == torch.bfloat16 else 1e-4) * max(1.0, b.grad.abs().max().item())
