@@ -41,13 +41,15 @@ __device__ __forceinline__ void tap(float scale, int dst, int in_size, int* i0, 
     *l1 = src - (float)*i0;
 }
 
-// grid (ceil(W / 8 / 64) * H, planes): a wave writes 512 consecutive output pixels of one row, 8 per lane
+// grid (ceil(H * ceil(W / 8) / 256), planes): thread <-> 8 consecutive output pixels of one row; consecutive threads walk the
+// plane row by row, so every lane is busy whatever the width
 template <typename T>
 __global__ __launch_bounds__(256) void k_upsample_sum(const T* __restrict__ full, LowPlanes lows, T* __restrict__ out, int H, int W) {
     const size_t plane = blockIdx.y;
-    const int per_row = (W + 2047) / 2048;                 // workgroups per output row (256 threads x 8 pixels)
-    const int y = blockIdx.x / per_row, x0 = ((blockIdx.x % per_row) * 256 + threadIdx.x) * 8;
-    if (x0 >= W) return;
+    const int w8 = (W + 7) >> 3;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const int y = v / w8, x0 = (v - y * w8) * 8;
+    if (y >= H) return;
     float acc[8];
     const size_t o = plane * (size_t)H * W + (size_t)y * W + x0;
     const bool whole = x0 + 8 <= W && (W & 7) == 0;
@@ -169,7 +171,7 @@ extern "C" int aadg_upsample_sum(const void* full, const void* const* lows, cons
         L.sy[k] = (float)low_h[k] / (float)H; L.sx[k] = (float)low_w[k] / (float)W;
     }
     hipStream_t st = (hipStream_t)stream;
-    const int per_row = (W + 2047) / 2048;
+    const int w8 = (W + 7) / 8;
     const size_t esz = dtype == 0 ? 4 : 2;
     for (int p0 = 0; p0 < planes; p0 += 65535) {
         const int np = planes - p0 < 65535 ? planes - p0 : 65535;
@@ -177,7 +179,7 @@ extern "C" int aadg_upsample_sum(const void* full, const void* const* lows, cons
         for (int k = 0; k < n_low; ++k) Lp.p[k] = (const char*)L.p[k] + (size_t)p0 * L.h[k] * L.w[k] * esz;
         const char* f = full ? (const char*)full + (size_t)p0 * H * W * esz : nullptr;
         char* o = (char*)out + (size_t)p0 * H * W * esz;
-        const dim3 g(per_row * H, np);
+        const dim3 g((H * w8 + 255) / 256, np);
         if (dtype == 0) hipLaunchKernelGGL(k_upsample_sum<float>, g, dim3(256), 0, st, (const float*)f, Lp, (float*)o, H, W);
         else hipLaunchKernelGGL(k_upsample_sum<__hip_bfloat16>, g, dim3(256), 0, st, (const __hip_bfloat16*)f, Lp, (__hip_bfloat16*)o, H, W);
         AADG_LAUNCH_CHECK();
