@@ -1233,8 +1233,11 @@ __device__ __forceinline__ void fused3_body(const uint8_t* __restrict__ pool, co
                                             float* __restrict__ out_img, float* __restrict__ out_lbl, int u, int half,
                                             uint32_t* A, uint32_t* B, uint8_t* sl, float* lutf) {
     const aadg_unit& un = units[u];
+    // every field of the record the tile geometry needs, read in ONE batch of scalar loads before the first branch (loads left
+    // behind an early return come back one by one, each with its own wait)
     const int n_ops = un.n_ops;
     const int w = un.scaled_w, h = un.scaled_h;
+    const int u_pad = un.pad, u_cx = un.crop_x, u_cy = un.crop_y, u_src = un.src;
     const int sc_all = sharp_count4(un, n_ops);
     if ((Ws & 3) || (crop & 3) || sc_all > MAX_SHARP || w < Ws || h < Hs) return;   // unit_flow(...) != FLOW_UP
     if ((sc_all > 0) != SHARP) return;                      // the other part of the grid owns this unit
@@ -1253,7 +1256,7 @@ __device__ __forceinline__ void fused3_body(const uint8_t* __restrict__ pool, co
     constexpr int TROWS = SHARP ? FT_H / 2 : FT_H;
     const int y0 = blockIdx.y * FT_H + half * TROWS, y1 = min(y0 + TROWS, crop);
     if (y0 >= crop) return;
-    const int ox = un.crop_x - un.pad, oy = un.crop_y - un.pad;
+    const int ox = u_cx - u_pad, oy = u_cy - u_pad;
     const int fx = max(x0, -ox), lx = min(x1 - 1, w - 1 - ox);
     const int xq = x0 + 4 * lane;                           // vertical pass: lane <-> 4 consecutive columns
     const bool col_ok = xq < crop;
@@ -1293,8 +1296,8 @@ __device__ __forceinline__ void fused3_body(const uint8_t* __restrict__ pool, co
     if (xh != xhc) hxm = -1;                                // pad column
     const int4 xn4 = *reinterpret_cast<const int4*>(xnn_t + min(xq, crop - 4));
     const int xn[4] = {xn4.x, xn4.y, xn4.z, xn4.w};
-    const uint8_t* msk = masks + (size_t)un.src * Hs * Ws;
-    const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
+    const uint8_t* msk = masks + (size_t)u_src * Hs * Ws;
+    const uint8_t* src = pool + (size_t)u_src * Hs * Ws * 3;
     const uint32_t lbl_t0 = dataset == AADG_DATASET_OPTIC ? 50u : 0u;
     const bool lbl_flip = dataset != AADG_DATASET_OPTIC;
     const char* lutb = reinterpret_cast<const char*>(lutf);

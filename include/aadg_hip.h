@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AADG_ABI_VERSION 2
+#define AADG_ABI_VERSION 3
 #define AADG_MAX_OPS 4
 
 #define AADG_E_BADARG (-1)

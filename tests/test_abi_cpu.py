@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libaadg_hip.so does not export %s" % name
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.aadg_abi_version() == 2
+    assert lib.aadg_abi_version() == 3
 
 
 def test_unit_struct_layout_matches_header():
@@ -140,3 +140,25 @@ def test_backbone_and_controller_entry_points_validate_arguments():
     # embedding prologue
     assert lib.aadg_embed_prologue_f32(z, 8, 1, 8, z, z, 128, z, z, 0, f(0.2), z, z, z) == -1
     assert lib.aadg_embed_prologue_f32(one, 5000, 1, 5000, one, one, 128, z, z, 0, f(0.2), one, z, z) == -3
+
+
+def test_round2_entry_points_validate_arguments():
+    """aadg_aug_u8_forward_ex2 (work lists), aadg_bn_sync_* (phase split), the norm-passing embed / Sinkhorn pair and
+    aadg_upsample_sum reject bad arguments on the host, without a GPU."""
+    import ctypes
+    from aadg_amd import _lib
+    lib = _lib.load()
+    z, one = ctypes.c_void_p(0), ctypes.c_void_p(16)
+    lists = _lib.AugLists()
+    lists.n_stat[0] = 5                                  # a non-empty statistics list without its array
+    assert lib.aadg_aug_u8_forward_ex2(one, one, 1, 8, 8, one, 4, 2, 8, 0, one, one, one, 1 << 30, z, 0, -1, z, z, ctypes.byref(lists)) == -1
+    lists = _lib.AugLists()
+    lists.order, lists.n_plain, lists.n_sharp = 16, 3, 3  # more listed units than N
+    assert lib.aadg_aug_u8_forward_ex2(one, one, 1, 8, 8, one, 4, 2, 8, 0, one, one, one, 1 << 30, z, 0, -1, z, z, ctypes.byref(lists)) == -1
+    args = (one, z, one, z, z, z, z, z, 0.1, 1e-5, 0, 2, 4, 16, 0, one, one, one, one, 1 << 20, 0, z)
+    assert lib.aadg_bn_sync_forward(0, *args) == -1 and lib.aadg_bn_sync_forward(3, *args) == -1          # phase must be 1 or 2
+    assert lib.aadg_bn_sync_forward(1, *(args[:17] + (z,) + args[18:])) == -1                            # no sums buffer
+    assert lib.aadg_embed_prologue_norm_f32(one, 8, 2, 8, one, one, 4, z, z, 0, 0.2, one, z, z, z) == -1   # norm output missing
+    assert lib.aadg_sinkhorn_rewards_norm_f32(one, z, 3, 2, 2, 8, 0.05, 0.5, one, one, 1024, z) == -1
+    assert lib.aadg_upsample_sum(one, z, z, z, 4, one, 4, 8, 8, 0, z) == -1                                # n_low > 3
+    assert lib.aadg_upsample_sum_backward(z, one, 4, 2, 2, 8, 8, 1, z) == -1
