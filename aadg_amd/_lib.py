@@ -286,14 +286,24 @@ def launch_hints(units, Hs, Ws, crop):
     staged = ~(up | generic)
     classes = (1 if up.any() else 0) | (2 if staged.any() else 0) | (4 if generic.any() else 0)
     needs = np.isin(units["op"], (0, 2, 5)) & live
+    # statistics by push-forward (csrc/aug_u8.hip: stats_by_pushforward): AutoContrast / Equalize in slot k >= 1 behind per-channel
+    # byte maps only, fused-flow units -- k_lut derives that stage's histogram from the RAW image's, no pixel pass
+    lut_class = np.isin(units["op"], (0, 1, 2, 3, 4, 5, 7))
+    prefix_lut = np.ones_like(live)
+    for k in range(1, MAX_OPS):
+        prefix_lut[:, k] = prefix_lut[:, k - 1] & lut_class[:, k - 1]
+    push = live & np.isin(units["op"], (0, 2)) & prefix_lut & (up | generic)[:, None]
+    push[:, 0] = False
+    pixel_pass = needs & ~push
+    pixel_pass[:, 0] |= push.any(axis=1)                   # the raw histogram is the source of every push-forward
     stats_mask = 0
     for k in range(MAX_OPS):
-        if needs[:, k].any():
+        if pixel_pass[:, k].any():
             stats_mask |= 1 << k
     cls = np.where(up & (sharp == 0), 0, np.where(up, 1, np.where(generic, 2, 3)))
     order = np.argsort(cls, kind="stable").astype(np.int32)
     counts = (int((cls == 0).sum()), int((cls == 1).sum()), int((cls == 2).sum()))
-    stat_lists = [np.nonzero(needs[:, k])[0].astype(np.int32) for k in range(MAX_OPS)]     # work lists of the histogram kernels
+    stat_lists = [np.nonzero(pixel_pass[:, k])[0].astype(np.int32) for k in range(MAX_OPS)]     # work lists of the histogram kernels
     return classes, stats_mask, order, counts, stat_lists
 
 

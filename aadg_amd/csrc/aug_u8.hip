@@ -59,6 +59,24 @@ __device__ __forceinline__ bool op_is_lut(int op) {
     return op <= AADG_OP_CONTRAST || op == AADG_OP_BRIGHTNESS;  // 0..5 and 7
 }
 
+// Statistics by push-forward (round 2): when every op before op k is a per-channel byte map (op_is_lut) and op k needs only the
+// per-channel histograms (AutoContrast, Equalize -- Contrast needs the mean of L, which mixes the channels), the histogram of the image
+// after k ops is the push-forward of the RAW image's histogram through the composed maps: hist_k[c][L_{k-1}(...L_0(v))] += hist_0[c][v].
+// k_lut does that from the stage-0 histogram and the earlier stages' LUTs -- no pixel pass (k_hist_fused) for such a stage.  Fused-flow
+// units only (the staged flow materialises its intermediate images and histograms them directly).  Mirrored by launch_hints() on the host.
+__device__ __forceinline__ bool stats_by_pushforward(const aadg_unit& un, int k, bool fused_flow) {
+    if (!fused_flow || k < 1 || k >= un.n_ops) return false;
+    if (un.op[k] != AADG_OP_AUTOCONTRAST && un.op[k] != AADG_OP_EQUALIZE) return false;
+    for (int j = 0; j < k; ++j)
+        if (!op_is_lut(un.op[j])) return false;
+    return true;
+}
+__device__ __forceinline__ bool any_pushforward(const aadg_unit& un, bool fused_flow) {
+    for (int k = 1; k < un.n_ops && k < AADG_MAX_OPS; ++k)
+        if (stats_by_pushforward(un, k, fused_flow)) return true;
+    return false;
+}
+
 // does this unit take the fused (LDS-resident) data flow?  Must agree across all kernels of a call.
 __device__ __forceinline__ int sharp_count(const aadg_unit& un, int upto) {
     int s = 0;
@@ -113,8 +131,14 @@ __device__ __forceinline__ void hist_body(const Bufs& bufs, const UnitRef& ur, c
                                           int Ws, int crop, uint32_t* hist, int bx, int by, int nbx, uint32_t (*sh)[768]) {
     const int u = ulist != nullptr ? ulist[by] : by;      // ulist: the units whose op `stage` needs statistics
     const aadg_unit& un = pick(ur, u);
-    if (un.n_ops <= stage || !op_needs_stats(un.op[stage])) return;
-    if (stage > 0 && unit_fusable(ur, un, Hs, Ws, crop)) return;   // k_hist_fused covers those
+    const bool fused_flow = unit_fusable(ur, un, Hs, Ws, crop);
+    if (stage == 0) {
+        // the raw image's histogram: for a statistics op in slot 0, and as the source of later stages' push-forward
+        if (!(un.n_ops > 0 && op_needs_stats(un.op[0])) && !any_pushforward(un, fused_flow)) return;
+    } else {
+        if (un.n_ops <= stage || !op_needs_stats(un.op[stage])) return;
+        if (fused_flow) return;                                   // k_hist_fused / push-forward cover those
+    }
     const uint8_t* in = stage_input(bufs, un, u, stage);
     const int tid = threadIdx.x, wv = tid >> 6;
     for (int i = tid; i < 4 * 768; i += 256) (&sh[0][0])[i] = 0;
@@ -160,7 +184,8 @@ __global__ __launch_bounds__(256) void k_hist(Bufs bufs, UnitRef ur, const int* 
 // ------------------------------------------------------------------------------------------------
 // k_lut: grid N, 256 threads; thread i owns LUT entry i of each channel.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lut(UnitRef ur, int stage, int npix, const uint32_t* hist, uint8_t* lut) {
+__global__ __launch_bounds__(256) void k_lut(UnitRef ur, int stage, int npix, int Hs, int Ws, int crop, const uint32_t* hist0,
+                                             const uint32_t* hist, uint8_t* lut) {
     const int u = blockIdx.x;
     const aadg_unit& un = pick(ur, u);
     if (un.n_ops <= stage) return;
@@ -168,8 +193,23 @@ __global__ __launch_bounds__(256) void k_lut(UnitRef ur, int stage, int npix, co
     if (!op_is_lut(op)) return;
     const int i = threadIdx.x;
     uint8_t* L = lut + ((size_t)stage * gridDim.x + u) * 768;
-    const uint32_t* gh = hist + (size_t)u * HIST_STRIDE;
+    const uint32_t* gh = hist + (size_t)u * HIST_STRIDE;          // this stage's pixel-pass histogram
     __shared__ uint32_t scan[256];
+    __shared__ uint32_t pushed[768];
+    if (stats_by_pushforward(un, stage, unit_fusable(ur, un, Hs, Ws, crop))) {
+        // histogram after `stage` per-channel maps = the raw histogram pushed through them
+        for (int t = i; t < 768; t += 256) pushed[t] = 0u;
+        __syncthreads();
+        const uint32_t* g0 = hist0 + (size_t)u * HIST_STRIDE;
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t cnt = g0[256 * c + i];
+            int v = i;
+            for (int j = 0; j < stage; ++j) v = lut[((size_t)j * gridDim.x + u) * 768 + 256 * c + v];
+            if (cnt) atomicAdd(&pushed[256 * c + v], cnt);
+        }
+        __syncthreads();
+        gh = pushed;
+    }
     if (op == AADG_OP_INVERT) {
         for (int c = 0; c < 3; ++c) L[256 * c + i] = (uint8_t)(255 - i);
     } else if (op == AADG_OP_SOLARIZE) {
@@ -800,6 +840,7 @@ __global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ 
     const int u = ulist != nullptr ? ulist[blockIdx.z] : blockIdx.z;      // ulist: the units whose op `stage` needs statistics
     const aadg_unit& un = units[u];
     if (un.n_ops <= stage || !op_needs_stats(un.op[stage]) || !unit_fusable(true, un, Hs, Ws, crop)) return;
+    if (stats_by_pushforward(un, stage, true)) return;            // k_lut derives this stage's histogram from the raw one
     __shared__ __attribute__((aligned(16))) uint32_t A[5632];
     __shared__ __attribute__((aligned(16))) uint32_t B[5632];
     __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
@@ -815,7 +856,11 @@ __global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ 
     const uint32_t* cur = build_patch<6, 1>(un, stage, src, Hs, Ws, r_lo, r_hi, c_lo, c_hi, A, B, lut, lut_stage_stride, u, sl);
     const int pw = c_hi - c_lo, rw = cx1 - cx0, n = (ry1 - ry0) * rw;
     unsigned long long lsum = 0;
-    for (int i = tid; i < n; i += 256) {
+    // Neighbouring pixels of a smooth image fall into the same bins, and LDS atomics of one wave on one address serialise: the
+    // lanes of a wave therefore take pixels 97 positions apart (97 is prime: a bijection of [0, n) unless 97 divides n)
+    const int stride = (n % 97) ? 97 : 1;
+    for (int i0 = tid; i0 < n; i0 += 256) {
+        const int i = (int)(((long long)i0 * stride) % n);
         const int row = i / rw, col = i - row * rw;
         const uint32_t p = cur[(ry0 + row - r_lo) * pw + (cx0 + col - c_lo)];
         const uint32_t r = p & 255, g = (p >> 8) & 255, b = (p >> 16) & 255;
@@ -1452,7 +1497,7 @@ struct WsLayout {
 WsLayout ws_layout(int N, int Hs, int Ws, int crop) {
     WsLayout l;
     size_t o = 0;
-    l.hist = o; o = aadg_align_up(o + (size_t)N * HIST_STRIDE * 4, 256);
+    l.hist = o; o = aadg_align_up(o + (size_t)AADG_MAX_OPS * N * HIST_STRIDE * 4, 256);     // one histogram set per op stage
     l.lut = o;  o = aadg_align_up(o + (size_t)AADG_MAX_OPS * N * 768, 256);
     l.tab = o;  o = aadg_align_up(o + (size_t)N * crop * TAB_STRIDE * 4, 256);
     const size_t img = (size_t)Hs * Ws * 3;
@@ -1480,7 +1525,9 @@ int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int c
                const WsLayout& L, uint8_t* out_override, int classes, int stats_mask, hipStream_t st,
                const aadg_aug_lists* lists = nullptr, int* tab = nullptr, bool* tables_done = nullptr) {
     const int npix = Hs * Ws;
-    uint32_t* hist = reinterpret_cast<uint32_t*>(ws8 + L.hist);
+    uint32_t* hist0 = reinterpret_cast<uint32_t*>(ws8 + L.hist);          // stage k's histograms: hist0 + k * N * HIST_STRIDE
+    const size_t hist_stage = (size_t)N * HIST_STRIDE;
+    if (stats_mask != 0) AADG_HIP_TRY(hipMemsetAsync(hist0, 0, (size_t)max_ops * hist_stage * 4, st));
     uint8_t* lut = ws8 + L.lut;
     const size_t lut_stage_stride = (size_t)N * 768;
     const dim3 g(chunks_for(npix), N);
@@ -1488,8 +1535,8 @@ int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int c
         // work list of the statistics kernels of this stage (caller's, else every unit is offered and the others return)
         const int* ulist = lists != nullptr ? lists->stat_units[k] : nullptr;
         const int nstat = ulist != nullptr ? lists->n_stat[k] : N;
+        uint32_t* hist = hist0 + (size_t)k * hist_stage;
         if ((stats_mask & (1 << k)) && nstat > 0) {
-            AADG_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)N * HIST_STRIDE * 4, st));
             if (k == 0 && tab != nullptr && 2 * crop <= 4 * 768) {
                 // stage-0 histograms and the resampling tables in one launch
                 hipLaunchKernelGGL(k_hist_tables, dim3(g.x * nstat + N), dim3(256), 0, st, bufs, ur, ulist, nstat, (int)g.x, npix, Hs, Ws,
@@ -1506,7 +1553,8 @@ int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int c
                 AADG_LAUNCH_CHECK();
             }
         }
-        hipLaunchKernelGGL(k_lut, dim3(N), dim3(256), 0, st, ur, k, npix, hist, lut);
+        hipLaunchKernelGGL(k_lut, dim3(N), dim3(256), 0, st, ur, k, npix, Hs, Ws, crop, (const uint32_t*)hist0,
+                           (const uint32_t*)(hist0 + (size_t)k * hist_stage), lut);
         AADG_LAUNCH_CHECK();
         if (classes & HINT_STAGED) {
             hipLaunchKernelGGL(k_apply, g, dim3(256), 0, st, bufs, ur, k, Hs, Ws, crop, lut, out_override);
@@ -1553,7 +1601,8 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
     int classes = classes_hint & (HINT_FUSED | HINT_STAGED | HINT_GENERIC);
     if (classes == 0) classes = HINT_FUSED | HINT_STAGED | HINT_GENERIC;
     if ((Ws & 3) || (crop & 3)) classes = HINT_STAGED;        // unit_fusable() is false for every unit
-    const int stats_mask = stats_mask_hint < 0 ? 0xF : stats_mask_hint;
+    int stats_mask = stats_mask_hint < 0 ? 0xF : stats_mask_hint;
+    if (stats_mask & ~1) stats_mask |= 1;      // a later stage's statistics may be pushed forward from the raw image's histogram
     int* tab = reinterpret_cast<int*>(ws8 + L.tab);
     bool tables_done = false;
     int rc = run_stages(bufs, ur, N, Hs, Ws, crop, max_ops, ws8, L, nullptr, classes, stats_mask, st,

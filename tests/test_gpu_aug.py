@@ -202,3 +202,49 @@ def test_class_lists_and_fallback_agree(hip, oracle):
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.equal(o_img, got_img) and torch.equal(o_lbl, got_lbl)
+
+
+def test_statistics_by_pushforward_long_chains(hip, oracle):
+    """AutoContrast / Equalize behind per-channel byte maps take their histogram from the RAW image's, pushed through the earlier
+    stages' LUTs (no pixel pass).  Chains of up to 4 ops: push-forward at slots 1, 2 and 3, chains broken by Color / Cutout / Sharpness
+    (pixel pass again), Contrast (needs the mean of L: always a pixel pass), with and without the caller's work lists -- bit-exact vs the oracle."""
+    from helpers import synth_pool
+    from aadg_amd.data.basic import cutout_rect
+    rs = np.random.RandomState(5)
+    P, H, crop = 4, 64, 64
+    imgs, msks = synth_pool(rs, P, H, H)
+    chains = [[(7, 1.4), (0, 0)], [(1, 0), (3, 100), (2, 0)], [(4, 5), (7, 0.6), (5, 1.3), (0, 0)], [(2, 0), (0, 0), (2, 0), (0, 0)],
+              [(6, 1.5), (2, 0)], [(7, 1.2), (8, 1.6), (0, 0)], [(9, 0.2), (0, 0)], [(3, 64), (5, 0.7)], [(5, 1.5), (2, 0)], [(0, 0), (1, 0), (4, 4), (2, 0)]]
+    N = 2 * len(chains)
+    units = np.zeros(N, hip.UNIT_DTYPE)
+    units['rect'][:, :, 2:] = -1
+    for i in range(N):
+        ch = chains[i % len(chains)]
+        u = units[i]
+        u['src'] = rs.randint(P)
+        u['n_ops'] = len(ch)
+        for k, (op, v) in enumerate(ch):
+            u['op'][k] = op
+            if op in (3, 4):
+                u['iarg'][k] = int(v)
+            elif op in (5, 6, 7, 8):
+                u['farg'][k] = np.float32(v)
+            elif op == 9:
+                u['rect'][k] = cutout_rect(H, H, v * H, 20.0, 30.0)
+        w = h = H if i < len(chains) else int(H * 1.3)          # identity scale and up-scaling (fused flow)
+        u['scaled_w'], u['scaled_h'] = w, h
+        u['crop_x'], u['crop_y'] = (w - crop) // 2, (h - crop) // 2
+    classes, stats_mask, order, counts, stat_lists = hip.launch_hints(units, H, H, crop)
+    assert len(stat_lists[0]) == 12 and len(stat_lists[3]) == 0           # raw histograms: statistics op in slot 0 or a push-forward source; slot 3 never needs pixels here
+    want_img, want_lbl = oracle.aug_units(imgs, msks, units, crop, 0)
+    d_img, d_msk = torch.from_numpy(imgs).cuda(), torch.from_numpy(msks).cuda()
+    got_img, got_lbl = hip.aug_u8_forward(d_img, d_msk, units, crop, 0)
+    assert np.array_equal(got_img.cpu().numpy(), want_img) and np.array_equal(got_lbl.cpu().numpy(), want_lbl)
+    lib = hip.load()
+    d_units = hip.units_to_device(units, d_img.device)
+    o_img = torch.empty_like(got_img); o_lbl = torch.empty_like(got_lbl)
+    ws = torch.empty(lib.aadg_aug_u8_workspace_bytes(N, H, H, crop), dtype=torch.uint8, device="cuda")
+    assert lib.aadg_aug_u8_forward(d_img.data_ptr(), d_msk.data_ptr(), P, H, H, d_units.data_ptr(), N, 4, crop, 0, o_img.data_ptr(),
+                                   o_lbl.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o_img, got_img) and torch.equal(o_lbl, got_lbl)
