@@ -24,9 +24,15 @@ class DeviceBatchLoader(object):
     def __iter__(self):
         n = len(self.dataset)
         order = np.random.permutation(n) if self.shuffle else np.arange(n)
+        fast = None
+        if self.collate_fn is train_dg_collate_fn and getattr(self.dataset, 'phase', None) == 'train':
+            from .transform import fast_train_collate as fast       # standard pipeline: same draws, no per-image objects
         for b in range(len(self)):
             idx = order[b * self.batch_size:(b + 1) * self.batch_size]
-            yield self.collate_fn([self.dataset[int(i)] for i in idx])
+            batch = fast(self.dataset, len(idx)) if fast is not None else None
+            if batch is None:
+                batch = self.collate_fn([self.dataset[int(i)] for i in idx])
+            yield batch
 
 
 def get_seg_dg_dataloader(cfg, args, batch_size, workers, size=None, per_domain=32, device=None):

@@ -367,6 +367,164 @@ def _collate(batch, nested):
     return new_batch
 
 
+# ------------------------------------------------------------------------------------------------
+# Fast draw path: the standard training pipeline without per-image objects
+# ------------------------------------------------------------------------------------------------
+def _fast_policy_steps(policy, pool):
+    """Per sub-policy: the op records Policy.__call__ would leave on an ImageRef, captured by running every op function ONCE on a
+    probe ref (same argument conversions and asserts as the object path); Cutout is position dependent and stays symbolic:
+    ('cutout', v_abs) with v_abs = v * width, or nothing when v <= 0 (data/basic.py:137-146)."""
+    from . import basic
+    if policy._compiled is None:
+        policy._compiled = policy._compile()
+    out = []
+    for steps in policy._compiled:
+        rec = []
+        for fn, value in steps:
+            if fn is basic.Cutout:
+                assert 0.0 <= value <= 0.2
+                if value > 0.:
+                    rec.append(('cutout', value * pool.size[0]))
+            else:
+                key = (fn, value)
+                st = _STEP_CACHE.get(key)
+                if st is None:                 # (op, magnitude) pairs come from a small discrete set: probe each once
+                    probe, _ = fn(ImageRef(pool, 0), MaskRef(pool, 0), value)
+                    st = probe.ops[-1]
+                    if len(_STEP_CACHE) < 4096:
+                        _STEP_CACHE[key] = st
+                rec.append(st)
+        out.append(rec)
+    return out
+
+
+_STEP_CACHE = {}
+
+
+def fast_train_units(dataset, n_items):
+    """Draws `n_items` training items (one image per source domain each) of the STANDARD pipeline
+    [DGMultiPolicy, DGRandomScaleCrop, Normalize_dg, ToTensor] and returns the packed unit records directly:
+
+        (units UNIT_DTYPE [S + S*M] in output-row order, dc float32 [S*M, n], dc_single float32 [S, n], names, M, kind)
+
+    with S = n_items * n_domains.  Every random draw is made by the same function, with the same arguments and in the same
+    order as the object path (synthetic.py:__getitem__ -> Policy.__call__ -> DGRandomScaleCrop -> ToTensor), so a seeded run
+    produces identical records (tests/test_host_cpu.py::test_fast_draw_equals_object_path); what is skipped is the ~70 ImageRef
+    objects, copies and property calls per item.  Returns None when the dataset's pipeline is not the standard one."""
+    from .basic import cutout_rect
+    from .policy import DGMultiPolicy
+    tfs = getattr(getattr(dataset, 'transforms', None), 'transforms', None)
+    if (tfs is None or len(tfs) != 4 or type(tfs[0]) is not DGMultiPolicy or type(tfs[1]) is not DGRandomScaleCrop or
+            type(tfs[2]) is not Normalize_dg or type(tfs[3]) is not ToTensor or getattr(dataset, 'phase', 'train') == 'test'):
+        return None
+    mp, sc, nz, tt = tfs
+    pool = dataset.pool
+    W0, H0 = pool.size
+    D, per = dataset.n_domains, dataset.per_domain
+    policies = mp.policies
+    M = len(policies)
+    fast = [getattr(p, '_fast', None) or _fast_policy_steps(p, pool) for p in policies]
+    for p, f in zip(policies, fast):
+        p._fast = f
+    s0, s1 = sc.scale_range[0], sc.scale_range[1]
+    draw_crop = sc.crop.draw
+    K = _lib.MAX_OPS
+    rnd, uni, choice = random.random, random.uniform, random.choice
+    np_choice, np_uniform = np.random.choice, np.random.uniform
+    S = n_items * D
+    n = S + S * M
+    src, n_ops, geo = [0] * n, [0] * n, [None] * n
+    op = [[0] * K for _ in range(n)]
+    iarg = [[0] * K for _ in range(n)]
+    farg = [[0.0] * K for _ in range(n)]
+    rect = [[(0, 0, -1, -1)] * K for _ in range(n)]
+    names, dcs = [], []
+    s = 0
+    for _ in range(n_items):
+        for d in range(D):
+            index = int(np_choice(per, 1)[0])                       # synthetic.py: one random image per source domain
+            pidx = d * per + index
+            names.append('synth_d%d_%04d' % (d, index))
+            # -- DGMultiPolicy: per policy the CutMix-queue draw, the sub-policy draw, Cutout's two numpy draws
+            base = S + s * M
+            for j in range(M):
+                pol = policies[j]
+                q = pol.queue
+                q.append(None)
+                if len(q) > 10:
+                    q.pop(0)
+                else:
+                    choice(q)
+                steps = choice(fast[j])
+                row = base + j
+                src[row] = pidx
+                k = 0
+                oi, ii, fi, ri = op[row], iarg[row], farg[row], rect[row]
+                for st in steps:
+                    if st[0] == 'cutout':
+                        x0 = np_uniform(W0)
+                        y0 = np_uniform(H0)
+                        st = (9, 0, 0.0, cutout_rect(W0, H0, st[1], x0, y0))
+                    if k >= K:
+                        raise RuntimeError("more than %d ops per sub-policy are not supported" % K)
+                    oi[k], ii[k], fi[k], ri[k] = st
+                    k += 1
+                n_ops[row] = k
+            # -- DGRandomScaleCrop: the original first, then every augmented image (scale draw, then crop draw)
+            src[s] = pidx
+            for row in [s] + list(range(base, base + M)):
+                w, h = W0, H0
+                if rnd() > 0.2:
+                    w = int(uni(s0, s1) * W0)
+                    h = int(uni(s0, s1) * H0)
+                pad, x1, y1 = draw_crop(w, h)
+                geo[row] = (w, h, pad, x1, y1)
+            # -- ToTensor: the soft domain code
+            dcs.append(SoftLable(ToMultiLabel(d, tt.n)).astype(np.float32))
+            s += 1
+    units = np.zeros(n, dtype=_lib.UNIT_DTYPE)
+    units['src'] = src
+    units['n_ops'] = n_ops
+    units['op'] = op
+    units['iarg'] = iarg
+    units['farg'] = farg
+    units['rect'] = rect
+    g = np.asarray(geo, dtype=np.int64)
+    units['scaled_w'], units['scaled_h'], units['pad'], units['crop_x'], units['crop_y'] = g[:, 0], g[:, 1], g[:, 2], g[:, 3], g[:, 4]
+    dc_single = np.stack(dcs)
+    return units, np.repeat(dc_single, M, axis=0), dc_single, names, M, nz.dataset_name
+
+
+def fast_train_collate(dataset, n_items):
+    """train_dg_collate_fn([dataset[i] for i in ...]) through fast_train_units: same dictionary, same tensors (None when the
+    pipeline is not the standard one: the caller then takes the object path)."""
+    drawn = fast_train_units(dataset, n_items)
+    if drawn is None:
+        return None
+    units, dc, dc_single, names, M, kind_name = drawn
+    D = dataset.n_domains
+    S = n_items * D
+    pool = dataset.pool
+    crop = int(dataset.transforms.transforms[1].crop.size[0])
+    rank, world, _ = _ROW_SHARD
+    plan = row_plan(D, n_items, M)
+    if world > 1:
+        from ..distributed import shard_rows
+        lo_s, hi_s = shard_rows(S, rank, world)
+        sel = np.concatenate([np.arange(lo_s, hi_s), S + plan.rows])
+        units = units[sel]
+        dc = dc[plan.rows]
+    else:
+        lo_s, hi_s = 0, S
+    kind = _lib.DATASET_OPTIC if kind_name == 'optic' else _lib.DATASET_VESSEL
+    img, lbl = _lib.aug_u8_forward(pool.images, pool.masks, units, crop, kind)
+    ns = hi_s - lo_s
+    dev = img.device
+    return {'img_name': names, 'image': img[:ns], 'label': lbl[:ns], 'aug_images': img[ns:], 'aug_labels': lbl[ns:],
+            'dc': torch.from_numpy(dc).to(dev, non_blocking=True),
+            'dc_image': torch.from_numpy(dc_single[lo_s:hi_s]).to(dev, non_blocking=True), 'plan': plan, 'image_rows': (lo_s, hi_s, S)}
+
+
 def train_dg_collate_fn(batch):
     """batch = [[sample per domain] per item]; rows come out item-major, domain-minor, and the
     augmented tensors in `sample*M + policy` order, as data/transform.py:323-340."""

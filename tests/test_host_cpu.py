@@ -188,3 +188,45 @@ def test_global_avg_pool_f32_matches_mean():
     y2 = x2.mean(dim=(2, 3), dtype=torch.float32)
     (y2 * w).sum().backward()
     assert y.dtype == torch.float32 and torch.equal(y, y2) and torch.allclose(x.grad, x2.grad, rtol=1e-6, atol=1e-8)
+
+
+def test_fast_draw_equals_object_path():
+    """transform.fast_train_units (the standard pipeline without per-image objects) makes the same random draws, in the same order,
+    as synthetic.__getitem__ -> Policy.__call__ -> DGRandomScaleCrop -> ToTensor: identical unit records, domain codes and names over
+    several batches (the CutMix queues fill up after 10 calls), and identical python / numpy generator states afterwards."""
+    import random
+    import numpy as np
+    import torch
+    from helpers import Cfg
+    from aadg_amd.data import transform as T
+    from aadg_amd.data.policy import DGMultiPolicy, parse_policies
+    from aadg_amd.data.synthetic import SyntheticDGSegmentation
+    for name, D in (('optic', 3), ('rvs', 3), ('optic', 8)):
+        tr, _ = T.get_dg_segtransform(name, 48, D)
+        ds = SyntheticDGSegmentation(D, 3, 48 if name == 'optic' else 96, name, 'train', tr, device='cpu')
+        for seed in range(4):
+            pol = np.random.RandomState(seed).randint(0, 10, (6, 20))
+            runs = []
+            for fast in (False, True):
+                random.seed(seed)
+                np.random.seed(seed)
+                ds.transforms.transforms[0] = DGMultiPolicy(parse_policies(pol, Cfg(), None))
+                res = []
+                for _ in range(3):
+                    if fast:
+                        units, dc, dcs, names, M, kind = T.fast_train_units(ds, 3)
+                    else:
+                        flat, refs, M = T.collect_refs([ds[0] for _ in range(3)], True)
+                        units = T.refs_to_units(refs)
+                        dc = torch.cat([b['dc'] for b in flat], 0).numpy()
+                        dcs = torch.stack([b['dc_single'] for b in flat], 0).numpy()
+                        names = [b['img_name'] for b in flat]
+                    res.append((units, dc, dcs, names))
+                runs.append((res, random.random(), np.random.rand()))
+            (a, ra, na), (b, rb, nb) = runs
+            assert ra == rb and na == nb
+            for (u1, d1, s1, n1), (u2, d2, s2, n2) in zip(a, b):
+                assert u1.tobytes() == u2.tobytes() and np.array_equal(d1, d2) and np.array_equal(s1, s2) and n1 == n2
+    # a non-standard pipeline is refused (the loader then takes the object path)
+    ds.transforms.transforms[0] = T.Identity()
+    assert T.fast_train_units(ds, 2) is None
