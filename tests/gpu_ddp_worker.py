@@ -62,10 +62,14 @@ def main():
     lo, hi = cuts[rank], cuts[rank + 1]
     with cast:
         o2, f2 = ddp(x[lo:hi])
-    # bfloat16: 50 BatchNorm layers re-round every activation, a run differs from ITSELF by ~10 % (tests/test_gpu_backbone_e2e.py)
-    tol = 0.3 if dtype == 'bf16' else 1e-4
-    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()      # noqa: E731
-    assert rel(o2, o[lo:hi]) < tol and rel(f2, f[lo:hi]) < tol, (rel(o2, o[lo:hi]), rel(f2, f[lo:hi]))
+    rel = lambda a, b: ((a.float().cpu() - b.float().cpu()).norm() / b.float().cpu().norm()).item()      # noqa: E731
+    if dtype == 'fp32':
+        assert rel(o2, o[lo:hi]) < 1e-4 and rel(f2, f[lo:hi]) < 1e-4, (rel(o2, o[lo:hi]), rel(f2, f[lo:hi]))
+    else:
+        # bfloat16: 50 BatchNorm layers re-round every activation and a run differs from ITSELF by 10-40 % on this tiny batch
+        # (tests/test_gpu_backbone_e2e.py), so the yardstick is again the float64 run: no further from it than one process is
+        e1, e2 = rel(o, o64), rel(o2, o64[lo:hi])
+        assert e2 <= max(1.5 * e1, 0.5), (e1, e2)
     (loss_of(o2, f2, y[lo:hi], w[lo:hi]) * ((hi - lo) * world / float(N))).backward()
     # running statistics: the global batch's, on every rank
     checked = 0
