@@ -131,7 +131,13 @@ __device__ __forceinline__ float2 block_sum2(float a, float b) {
 // per-rank batch.  Every wave of the elementwise kernels now redoes it for its own channel: 64 lanes load one partial each,
 // a float64 butterfly leaves the same totals in every lane (same order in every workgroup of the channel: identical
 // coefficients), and the workgroup of image 0 writes what has to be stored (saved / running statistics, dweight, dbias).
+// split < 0: synchronised statistics -- `partial` holds the all-reduced float64 totals [C][2] (no partials to combine)
 __device__ __forceinline__ void bn_combine(const float* __restrict__ partial, int c, int split, double* s, double* q) {
+    if (split < 0) {
+        const double* t = reinterpret_cast<const double*>(partial);
+        *s = t[2 * c]; *q = t[2 * c + 1];
+        return;
+    }
     const int lane = threadIdx.x & 63;
     double a = 0.0, b = 0.0;
     if (lane < split) {
@@ -273,9 +279,8 @@ __global__ __launch_bounds__(256) void k_bn_scale_shift(int C, const float* __re
 }
 
 // ---- synchronised statistics (data-parallel ranks): the reduction's partial sums leave the device-local
-// workspace as float64 totals, are summed over the ranks by the caller (one all-reduce of 2C + 1 doubles), and come back as TWO
-// float partials per channel (head + tail of the double), which bn_combine adds in float64 again: the elementwise kernels run
-// unchanged with split = 2 and the element count read from the device.
+// workspace as float64 totals, are summed over the ranks by the caller (one all-reduce of 2C + 1 doubles), and the elementwise
+// kernels read the totals (bn_combine with split < 0) and the element count straight from that buffer.
 __global__ __launch_bounds__(64) void k_bn_pack(const float* __restrict__ partial, int split, int C, double count_local,
                                                 double* __restrict__ sums, double* __restrict__ count_out,
                                                 float* __restrict__ dweight, float* __restrict__ dbias) {
@@ -290,15 +295,6 @@ __global__ __launch_bounds__(64) void k_bn_pack(const float* __restrict__ partia
         if (dbias != nullptr) dbias[c] = (float)a;
         if (c == 0 && count_out != nullptr) *count_out = count_local;
     }
-}
-__global__ __launch_bounds__(256) void k_bn_unpack(const double* __restrict__ sums, int C, float* __restrict__ partial) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double a = sums[2 * c], b = sums[2 * c + 1];
-    const float ah = (float)a, bh = (float)b;
-    float2* p = reinterpret_cast<float2*>(partial) + (size_t)c * BN_MAX_SPLIT;
-    p[0] = make_float2(ah, bh);
-    p[1] = make_float2((float)(a - (double)ah), (float)(b - (double)bh));
 }
 
 // ---- elementwise passes: grid (N*C strips, pieces per strip) ------------------------------------------------
@@ -466,9 +462,7 @@ int bn_forward(const T* x, const T* res, T* y, uint8_t* mask, const float* weigh
             return 0;
         }
     } else if (training) {
-        hipLaunchKernelGGL(k_bn_unpack, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)sums, C, ws + L.partial);
-        AADG_LAUNCH_CHECK();
-        split = 2;
+        split = -1;                                             // the elementwise kernel reads the float64 totals directly
         count_dev = sums + 2 * (size_t)C;
     } else {
         hipLaunchKernelGGL(k_bn_scale_shift, dim3((C + 255) / 256), dim3(256), 0, st, C, weight, bias, (const float*)rmean,
@@ -476,7 +470,8 @@ int bn_forward(const T* x, const T* res, T* y, uint8_t* mask, const float* weigh
         AADG_LAUNCH_CHECK();
     }
     const dim3 grid(N * C, s.pc.per_strip);
-    const BnFin fin = {ws + L.partial, split, (double)N * (double)HW, weight, bias, rmean, rvar, momentum, eps, save_mean, save_invstd, count_dev};
+    const BnFin fin = {split < 0 ? reinterpret_cast<const float*>(sums) : ws + L.partial, split, (double)N * (double)HW, weight, bias, rmean,
+                       rvar, momentum, eps, save_mean, save_invstd, count_dev};
 #define AADG_BN_APPLY(VEC_, ACT_, RES_, MASK_, FIN_) \
     hipLaunchKernelGGL((k_bn_apply<T, VEC_, ACT_, RES_, MASK_, FIN_>), grid, blk, 0, st, x, res, y, mask, (const float*)scale, (const float*)shift, fin, act, C, s.len, s.pc.plen, y_img_stride)
 #define AADG_BN_APPLY_ACT(ACT_)                                                          \
@@ -518,9 +513,7 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
     more.n = n_extra;
     int split = s.split;
     if (phase == 2) {
-        hipLaunchKernelGGL(k_bn_unpack, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)sums, C, ws + L.partial);
-        AADG_LAUNCH_CHECK();
-        split = 2;
+        split = -1;                                             // k_bn_dx reads the float64 totals directly
         dweight = nullptr; dbias = nullptr;                     // written by phase 1 (local sums)
     } else {
         const dim3 grid(s.split, C);
@@ -556,7 +549,8 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
         const dim3 grid(N * C, s.pc.per_strip);
         const int act_dx = g_ready ? AADG_ACT_NONE : act;
 #define AADG_BN_DX(VEC_, ACT_)                                                                                                  \
-    hipLaunchKernelGGL((k_bn_dx<T, VEC_, ACT_>), grid, blk, 0, st, x, g, dx, (const float*)(ws + L.partial), split,                \
+    hipLaunchKernelGGL((k_bn_dx<T, VEC_, ACT_>), grid, blk, 0, st, x, g, dx,                                                       \
+                       split < 0 ? reinterpret_cast<const float*>(sums) : (const float*)(ws + L.partial), split,                     \
                        (double)N * (double)HW, count_dev, weight, bias, mean, invstd, dweight, dbias, act_dx, C, s.len, s.pc.plen, g_ready ? 0LL : dy_img_stride)
         if (s.vec == 1) AADG_BN_DX(1, -1);
         else if (act_dx == AADG_ACT_RELU) AADG_BN_DX(Pack<T>::N, AADG_ACT_RELU);
