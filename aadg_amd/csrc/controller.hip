@@ -3,7 +3,8 @@
 // reset per sub-policy) and its PPO update (losses.py:117-157: 5 x {teacher-forced evaluate, clipped surrogate, backward,
 // Adam}) are ~200 + ~5000 micro-launches in eager PyTorch and still ~1900 graph nodes when captured.  Here:
 //
-//   k_ctrl_transpose   W_ih^T, W_hh^T scratch copies (gate row = fastest index: coalesced forward reads)
+//   k_ctrl_transpose   W_ih^T, W_hh^T scratch copies (gate row = fastest index: coalesced forward reads) -- only for widths
+//                      other than the module's 32 / 100
 //   k_ctrl_rollout     grid M, one workgroup per policy row: its Q independent sequences run in lock-step; all
 //                      activations of the 2L steps stay in LDS.  SAMPLE: inverse-CDF draw from caller-supplied uniforms,
 //                      policies / sum log-prob / sum entropy / mean head probabilities.  UPDATE: teacher-forced
@@ -14,6 +15,15 @@
 //                      refreshed transposed copies for the next epoch
 //
 // float32 throughout; same arithmetic as the eager module up to summation order.
+//
+// Round 2 (wall_clock64 stamps after every barrier, scripts/ubench/ctrl_phase_times.py): with one gate row per lane the gate
+// phase took 10.5 us per step -- not load latency (weights in registers changed nothing) but 165 broadcast ds_read_b128 per wave
+// and step through ONE LDS pipe shared by 8 waves.  For the module's widths (32 / 100, compile-time instantiation) a lane now
+// owns 4 rows x one k-slice (forward) or 4 columns x one row slice (transposed products of the backward): 4x fewer LDS reads
+// per FMA, weights register-resident for the whole rollout, the slices of a quad summed with two DPP adds.  Gate phase 10.5 ->
+// 4.3 us, dh 4.9 -> 2.0, dx 2.5 -> 1.9; softmax on 16 lanes per sequence instead of one thread; k_ctrl_adam's conditional
+// per-row loops (the head weights waited on 48 dependent L2 round trips) as unconditional batched loads: 49 -> 11.5 us.
+// sample 80 -> 39 us, PPO update (5 epochs) 840 -> 320 us.
 #include "common.h"
 
 namespace {
@@ -113,7 +123,11 @@ __global__ __launch_bounds__(256) void k_ctrl_transpose(CtrlParams P, CtrlDims d
 }
 
 // SAMPLE = true: draw actions from `uniforms`; false: teacher-forced on `policies`, then the PPO backward.
-template <bool SAMPLE>
+// EC / HC > 0: embedding / hidden width known at compile time (the module's 32 / 100): every lane then keeps its weight column
+// (EC + HC floats forward, 4 HC / CT_HP and 4 HC / CT_XP floats backward) in REGISTERS for the whole rollout -- the weights
+// are read from L2 once per launch, all loads in flight together, instead of once per step in nine dependent chunks (the
+// forward step was ~15 us of load latency for ~1 us of arithmetic).  EC = HC = 0: run-time widths, weights re-read per step.
+template <bool SAMPLE, int EC, int HC>
 __global__ __launch_bounds__(CT_THREADS) void k_ctrl_rollout(CtrlParams P, CtrlDims d, float* ws, const float* __restrict__ uniforms,
                                                              long long* __restrict__ policies, float* __restrict__ op_probs,
                                                              float* __restrict__ mag_probs, float* __restrict__ log_probs,
@@ -124,7 +138,11 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_rollout(CtrlParams P, CtrlD
     const CtrlWs W = ctrl_ws(d);
     const CtrlLds O = ctrl_lds(d);
     const int m = blockIdx.x, tid = threadIdx.x;
-    const int Q = d.Q, S = d.S, H = d.H, E = d.E, H4 = 4 * H;
+    constexpr bool FAST = EC > 0 && HC > 0;
+    static_assert(!FAST || (EC % 4 == 0 && HC % 4 == 0 && 4 * HC <= CT_THREADS && CT_HP * HC <= CT_THREADS && CT_XP * EC <= CT_THREADS &&
+                            (4 * HC) % CT_HP == 0 && (4 * HC / CT_HP) % 4 == 0 && (4 * HC) % CT_XP == 0 && (4 * HC / CT_XP) % 4 == 0),
+                  "compile-time widths must fit the lane <-> weight-column mapping");
+    const int Q = d.Q, S = d.S, H = FAST ? HC : d.H, E = FAST ? EC : d.E, H4 = 4 * H;
     float* G = L + O.G; float* Cs = L + O.Cs; float* TC = L + O.TC; float* Hs = L + O.Hs; float* X = L + O.X;
     float* Pp = L + O.P; float* TL = L + O.TL; float* DL = L + O.DL; float* DG = L + O.DG; float* DH = L + O.DH;
     float* DC = L + O.DC; float* part = L + O.part; int* act = reinterpret_cast<int*>(L + O.act); float* misc = L + O.misc;
@@ -145,11 +163,93 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_rollout(CtrlParams P, CtrlD
     __syncthreads();
 
     // ---------------------------------------------------------------------------------------------- forward
-    float my_lp = 0.0f, my_ent = 0.0f;                     // threads 0..Q-1: their sequence's sum log-prob / entropy
+    float my_lp = 0.0f, my_ent = 0.0f;                     // lane 0 of each 16-lane group: its sequence's sum log-prob / entropy
+    // FAST: lane (u = tid / 4, sl = tid % 4) keeps the weights of the FOUR gate rows of hidden unit u for k-slice sl of the inputs
+    // (EC / 4 embedding inputs + HSL or HL hidden inputs).  One 16-byte LDS read of activations then feeds 16 FMAs instead of 4 (the
+    // row-per-lane mapping was bound by the LDS broadcasts: 165 reads per wave and step, 10.5 us); the four k-slices of a quad are
+    // summed with two DPP adds.
+    constexpr int XSL = FAST ? EC / 4 : 4;                 // embedding inputs per slice
+    constexpr int HSL = FAST ? (HC / 16) * 4 : 4;          // hidden inputs of slices 0..2
+    constexpr int HL = FAST ? HC - 3 * HSL : 4;            // ... of slice 3 (the remainder); slices 0..2 carry zeros beyond HSL
+    static_assert(!FAST || (EC % 16 == 0 && HL % 4 == 0 && HL >= HSL && HL - HSL <= HSL), "k-slices must be multiples of 4");
+    float wxr[4][XSL], whr[4][HL];
+    const int gu = tid >> 2, gsl = tid & 3;
+    if constexpr (FAST) {
+        if (tid < H4) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float* rx = P.w_ih + (size_t)(g * HC + gu) * EC + XSL * gsl;
+                const float* rh = P.w_hh + (size_t)(g * HC + gu) * HC + HSL * gsl;
+#pragma unroll
+                for (int i = 0; i < XSL; i += 4) {
+                    const float4 w = *reinterpret_cast<const float4*>(rx + i);
+                    wxr[g][i] = w.x; wxr[g][i + 1] = w.y; wxr[g][i + 2] = w.z; wxr[g][i + 3] = w.w;
+                }
+#pragma unroll
+                for (int i = 0; i < HL; i += 4) {
+                    float4 w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (i < HSL || gsl == 3) w = *reinterpret_cast<const float4*>(rh + i);
+                    whr[g][i] = w.x; whr[g][i + 1] = w.y; whr[g][i + 2] = w.z; whr[g][i + 3] = w.w;
+                }
+            }
+        }
+    }
     for (int t = 0; t < S; ++t) {
         const bool op_step = (t & 1) == 0;
         const int NA = op_step ? d.NOPS : d.NMAGS;
-        if (tid < H4) {                                    // gate row `tid` of all Q sequences
+        if constexpr (FAST) {
+            if (tid < H4) {
+                float acc[4][CT_MAX_Q];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int q = 0; q < CT_MAX_Q; ++q) acc[g][q] = 0.0f;
+                if (t > 0) {
+#pragma unroll
+                    for (int i = 0; i < XSL; i += 4)
+#pragma unroll
+                        for (int q = 0; q < CT_MAX_Q; ++q)
+                            if (q < Q) {
+                                const float4 a = *reinterpret_cast<const float4*>(X + (q * S + t) * EC + XSL * gsl + i);
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    acc[g][q] = fmaf(wxr[g][i], a.x, acc[g][q]); acc[g][q] = fmaf(wxr[g][i + 1], a.y, acc[g][q]);
+                                    acc[g][q] = fmaf(wxr[g][i + 2], a.z, acc[g][q]); acc[g][q] = fmaf(wxr[g][i + 3], a.w, acc[g][q]);
+                                }
+                            }
+#pragma unroll
+                    for (int i = 0; i < HL; i += 4)
+#pragma unroll
+                        for (int q = 0; q < CT_MAX_Q; ++q)
+                            if (q < Q) {
+                                // slices 0..2 read 4 inputs of the next slice in their last round: weights zero there
+                                const float4 a = *reinterpret_cast<const float4*>(Hs + (q * (S + 1) + t) * HC + HSL * gsl + i);
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    acc[g][q] = fmaf(whr[g][i], a.x, acc[g][q]); acc[g][q] = fmaf(whr[g][i + 1], a.y, acc[g][q]);
+                                    acc[g][q] = fmaf(whr[g][i + 2], a.z, acc[g][q]); acc[g][q] = fmaf(whr[g][i + 3], a.w, acc[g][q]);
+                                }
+                            }
+                }
+                // sum of the four k-slices (every lane of the quad ends with the total), then lane sl finishes gate sl:
+                // bias, sigmoid / tanh, store
+                const float b = P.b_ih[gsl * HC + gu] + P.b_hh[gsl * HC + gu];
+#pragma unroll
+                for (int q = 0; q < CT_MAX_Q; ++q)
+                    if (q < Q) {
+                        float mine = 0.0f;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float v = acc[g][q];
+                            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+                            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // lane ^ 2
+                            mine = gsl == g ? v : mine;
+                        }
+                        mine += b;
+                        G[(q * S + t) * H4 + gsl * HC + gu] = gsl == 2 ? tanhf(mine) : sigmoidf_(mine);
+                    }
+            }
+        } else if (tid < H4) {                             // gate row `tid` of all Q sequences
             float acc[CT_MAX_Q];
             const float b = P.b_ih[tid] + P.b_hh[tid];
 #pragma unroll
@@ -241,46 +341,54 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_rollout(CtrlParams P, CtrlD
             }
         }
         __syncthreads();
-        if (tid < Q) {                                     // softmax, draw / gather, next input token
-            const int q = tid;
+        if (tid < Q * CT_MAX_A) {                          // softmax, draw / gather, next input token: 16 lanes per sequence
+            const int q = tid / CT_MAX_A, a = tid % CT_MAX_A;
             float* p = Pp + (q * S + t) * CT_MAX_A;
-            float mx = -INFINITY;
-            for (int a = 0; a < NA; ++a) mx = fmaxf(mx, p[a]);
-            float z[CT_MAX_A], sum = 0.0f;
-            for (int a = 0; a < NA; ++a) { z[a] = p[a] - mx; sum += expf(z[a]); }
-            const float lse = logf(sum);
-            float ent = 0.0f;
-            for (int a = 0; a < NA; ++a) {
-                const float lp = z[a] - lse, pr = expf(lp);
-                p[a] = pr;
-                ent -= lp * pr;
-                z[a] = lp;
-            }
-            int a_sel;
+            const bool live = a < NA;
+            const float v = live ? p[a] : -INFINITY;
+            float mx = v;
+#pragma unroll
+            for (int o = CT_MAX_A / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, CT_MAX_A));
+            const float z = v - mx;
+            float sum = live ? expf(z) : 0.0f;
+#pragma unroll
+            for (int o = CT_MAX_A / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, CT_MAX_A);
+            const float lp = z - logf(sum), pr = live ? expf(lp) : 0.0f;
+            float ent = live ? -lp * pr : 0.0f;
+#pragma unroll
+            for (int o = CT_MAX_A / 2; o > 0; o >>= 1) ent += __shfl_xor(ent, o, CT_MAX_A);
+            if (live) p[a] = pr;
+            int a_sel = 0;
             if (SAMPLE) {
+                // inverse CDF in action order (a sequential sum, as a host-side scan of the same probabilities would do it)
                 const float u = uniforms[(size_t)m * Q * S + q * S + t];
                 float cum = 0.0f;
                 a_sel = NA - 1;
-                for (int a = 0; a < NA; ++a) {
-                    cum += p[a];
-                    if (u < cum) { a_sel = a; break; }
+                bool found = false;
+#pragma unroll
+                for (int b = 0; b < CT_MAX_A; ++b) {
+                    cum += __shfl(pr, b, CT_MAX_A);
+                    if (!found && b < NA && u < cum) { a_sel = b; found = true; }
                 }
-                act[q * S + t] = a_sel;
-                policies[(size_t)m * Q * S + q * S + t] = a_sel;
+                if (a == 0) {
+                    act[q * S + t] = a_sel;
+                    policies[(size_t)m * Q * S + q * S + t] = a_sel;
+                }
             } else {
                 a_sel = act[q * S + t];
             }
-            my_lp += z[a_sel];                             // per-sequence sums, combined in fixed order after the loop
+            const float lp_sel = __shfl(lp, a_sel, CT_MAX_A);
+            my_lp += lp_sel;                               // per-sequence sums, combined in fixed order after the loop
             my_ent += ent;
             if (t + 1 < S) {
                 const int tok = a_sel + (op_step ? 0 : d.NOPS);
-                for (int k = 0; k < E; ++k) X[(q * S + t + 1) * E + k] = Emb[(size_t)tok * E + k];
+                for (int k = a; k < E; k += CT_MAX_A) X[(q * S + t + 1) * E + k] = Emb[(size_t)tok * E + k];
             }
         }
         __syncthreads();
     }
 
-    if (tid < Q) { misc[8 + tid] = my_lp; misc[8 + CT_MAX_Q + tid] = my_ent; }
+    if (tid < Q * CT_MAX_A && tid % CT_MAX_A == 0) { misc[8 + tid / CT_MAX_A] = my_lp; misc[8 + CT_MAX_Q + tid / CT_MAX_A] = my_ent; }
     __syncthreads();
     if (tid == 0) {
         float a = 0.0f, b = 0.0f;
@@ -340,6 +448,32 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_rollout(CtrlParams P, CtrlD
     const float gl = misc[3];
 
     // ---------------------------------------------------------------------------------------------- backward
+    // FAST: the transposed products dh = W_hh^T dg and dx = W_ih^T dg with 4 output columns x JS gate rows per lane: lane
+    // (jg, kg, jl) owns columns 4 kg .. 4 kg + 3 and gate rows [(4 jg + jl) JS, +JS); its JS x 4 weights stay in registers for all
+    // steps, one 16-byte LDS read of dg feeds 16 FMAs, the four row slices of a quad are summed with DPP and lane jl stores column
+    // 4 kg + jl of partial sum jg (CT_HP of them, combined below in fixed order)
+    constexpr int JS = FAST ? 4 * HC / (4 * CT_HP) : 4;
+    static_assert(!FAST || (JS % 4 == 0 && JS * 4 * CT_HP == 4 * HC && CT_HP * HC <= CT_THREADS && CT_HP <= CT_XP), "row slices of the transposed products");
+    float wbh[JS][4], wbx[JS][4];
+    const int bjl = tid & 3;
+    const int hkg = (tid >> 2) % (FAST ? HC / 4 : 1), hjg = (tid >> 2) / (FAST ? HC / 4 : 1);      // dh lanes: tid < CT_HP * HC
+    const int xkg = (tid >> 2) % (FAST ? EC / 4 : 1), xjg = (tid >> 2) / (FAST ? EC / 4 : 1);      // dx lanes: tid < CT_HP * EC
+    if constexpr (FAST) {
+        if (tid < CT_HP * HC) {
+#pragma unroll
+            for (int i = 0; i < JS; ++i) {
+                const float4 w = *reinterpret_cast<const float4*>(P.w_hh + (size_t)((4 * hjg + bjl) * JS + i) * HC + 4 * hkg);
+                wbh[i][0] = w.x; wbh[i][1] = w.y; wbh[i][2] = w.z; wbh[i][3] = w.w;
+            }
+        }
+        if (tid < CT_HP * EC) {
+#pragma unroll
+            for (int i = 0; i < JS; ++i) {
+                const float4 w = *reinterpret_cast<const float4*>(P.w_ih + (size_t)((4 * xjg + bjl) * JS + i) * EC + 4 * xkg);
+                wbx[i][0] = w.x; wbx[i][1] = w.y; wbx[i][2] = w.z; wbx[i][3] = w.w;
+            }
+        }
+    }
     for (int t = S - 1; t >= 0; --t) {
         const bool op_step = (t & 1) == 0;
         const int NA = op_step ? d.NOPS : d.NMAGS;
@@ -392,6 +526,40 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_rollout(CtrlParams P, CtrlD
         __syncthreads();
         if (t > 0) {
             // dh_{t-1} = W_hh^T dgates: CT_HP row ranges x H columns (reads of W_hh are contiguous over the column index)
+            if constexpr (FAST) {
+                if (tid < CT_HP * HC) {
+                    float acc[4][CT_MAX_Q];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int q = 0; q < CT_MAX_Q; ++q) acc[c][q] = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < JS; i += 4)
+#pragma unroll
+                        for (int q = 0; q < CT_MAX_Q; ++q)
+                            if (q < Q) {
+                                const float4 a = *reinterpret_cast<const float4*>(DG + q * H4 + (4 * hjg + bjl) * JS + i);
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    acc[c][q] = fmaf(wbh[i][c], a.x, acc[c][q]); acc[c][q] = fmaf(wbh[i + 1][c], a.y, acc[c][q]);
+                                    acc[c][q] = fmaf(wbh[i + 2][c], a.z, acc[c][q]); acc[c][q] = fmaf(wbh[i + 3][c], a.w, acc[c][q]);
+                                }
+                            }
+#pragma unroll
+                    for (int q = 0; q < CT_MAX_Q; ++q)
+                        if (q < Q) {
+                            float mine = 0.0f;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                float v = acc[c][q];
+                                v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+                                v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // lane ^ 2
+                                mine = bjl == c ? v : mine;
+                            }
+                            part[(hjg * Q + q) * H + 4 * hkg + bjl] = mine;
+                        }
+                }
+            } else
             for (int i = tid; i < CT_HP * H; i += CT_THREADS) {
                 const int pr = i / H, k = i - pr * H;
                 const int j0 = pr * H4 / CT_HP, j1 = (pr + 1) * H4 / CT_HP;
@@ -426,6 +594,40 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_rollout(CtrlParams P, CtrlD
             }
             __syncthreads();
             // dx_t = W_ih^T dgates -> gradient of the embedding row that fed this step: CT_XP row ranges x E columns
+            if constexpr (FAST) {
+                if (tid < CT_HP * EC) {
+                    float acc[4][CT_MAX_Q];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int q = 0; q < CT_MAX_Q; ++q) acc[c][q] = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < JS; i += 4)
+#pragma unroll
+                        for (int q = 0; q < CT_MAX_Q; ++q)
+                            if (q < Q) {
+                                const float4 a = *reinterpret_cast<const float4*>(DG + q * H4 + (4 * xjg + bjl) * JS + i);
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    acc[c][q] = fmaf(wbx[i][c], a.x, acc[c][q]); acc[c][q] = fmaf(wbx[i + 1][c], a.y, acc[c][q]);
+                                    acc[c][q] = fmaf(wbx[i + 2][c], a.z, acc[c][q]); acc[c][q] = fmaf(wbx[i + 3][c], a.w, acc[c][q]);
+                                }
+                            }
+#pragma unroll
+                    for (int q = 0; q < CT_MAX_Q; ++q)
+                        if (q < Q) {
+                            float mine = 0.0f;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                float v = acc[c][q];
+                                v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+                                v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // lane ^ 2
+                                mine = bjl == c ? v : mine;
+                            }
+                            part[(xjg * Q + q) * E + 4 * xkg + bjl] = mine;
+                        }
+                }
+            } else
             for (int i = tid; i < CT_XP * E; i += CT_THREADS) {
                 const int pr = i / E, k = i - pr * E;
                 const int j0 = pr * H4 / CT_XP, j1 = (pr + 1) * H4 / CT_XP;
@@ -456,7 +658,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_rollout(CtrlParams P, CtrlD
                 const int q = i / E, k = i - q * E;
                 const size_t r = ((size_t)m * Q + q) * S + t;
                 float s = 0.0f;
-                for (int pr = 0; pr < CT_XP; ++pr) s += part[(pr * Q + q) * E + k];
+                for (int pr = 0; pr < (FAST ? CT_HP : CT_XP); ++pr) s += part[(pr * Q + q) * E + k];
                 ws[W.dx + r * E + k] = s;
             }
             __syncthreads();
@@ -464,9 +666,9 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_rollout(CtrlParams P, CtrlD
     }
 }
 
-// sum_r a[r * sa] * b[r * sb] with 12 row pairs in flight
+// sum_r a[r * sa] * b[r * sb] (b == nullptr: sum_r a[r * sa]) with RB row pairs in flight; ascending r, one fma per row
 __device__ __forceinline__ float dot_rows(const float* __restrict__ a, int sa, const float* __restrict__ b, int sb, int R) {
-    constexpr int RB = 12;
+    constexpr int RB = 16;
     float g = 0.0f;
     for (int r0 = 0; r0 < R; r0 += RB) {
         float x[RB], y[RB];
@@ -474,10 +676,10 @@ __device__ __forceinline__ float dot_rows(const float* __restrict__ a, int sa, c
         for (int i = 0; i < RB; ++i) {
             const bool in = r0 + i < R;
             x[i] = in ? a[(size_t)(r0 + i) * sa] : 0.0f;
-            y[i] = in ? b[(size_t)(r0 + i) * sb] : 0.0f;
+            y[i] = b == nullptr ? 1.0f : (in ? b[(size_t)(r0 + i) * sb] : 0.0f);
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) g = fmaf(x[i], y[i], g);
+        for (int i = 0; i < RB; ++i) g = b == nullptr ? g + x[i] : fmaf(x[i], y[i], g);
     }
     return g;
 }
@@ -497,11 +699,22 @@ __global__ __launch_bounds__(256) void k_ctrl_adam(CtrlParams P, CtrlPtrs9 exp_a
     float g = 0.0f;
     float* param;
     switch (which) {
-        case 0: {                                          // embedding[row][k]
+        case 0: {                                          // embedding[row][k]: rows whose input token was `row`
             const int row = idx / d.E, k = idx - row * d.E;
             const int* tok = reinterpret_cast<const int*>(ws + W.tok);
-            for (int r = 0; r < R; ++r)
-                if (tok[r] == row) g += ws[W.dx + (size_t)r * d.E + k];
+            constexpr int RB = 16;
+            for (int r0 = 0; r0 < R; r0 += RB) {           // unconditional loads, the token test selects afterwards
+                int tk[RB];
+                float x[RB];
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int r = min(r0 + i, R - 1);
+                    tk[i] = r0 + i < R ? tok[r] : -2;
+                    x[i] = ws[W.dx + (size_t)r * d.E + k];
+                }
+#pragma unroll
+                for (int i = 0; i < RB; ++i) g = tk[i] == row ? g + x[i] : g;
+            }
             param = P.emb;
             break;
         }
@@ -518,21 +731,19 @@ __global__ __launch_bounds__(256) void k_ctrl_adam(CtrlParams P, CtrlPtrs9 exp_a
             break;
         }
         case 3: case 4: {                                  // b_ih[j], b_hh[j]
-            _Pragma("unroll 8") for (int r = 0; r < R; ++r) g += dg[(size_t)r * H4 + idx];
+            g = dot_rows(dg + idx, H4, nullptr, 0, R);
             param = which == 3 ? P.b_ih : P.b_hh;
             break;
         }
-        case 5: case 7: {                                  // head weight[a][k]: steps of that head only
+        case 5: case 7: {                                  // head weight[a][k]: steps of that head only (S is even: row parity = step parity)
             const int a = idx / d.H, k = idx - a * d.H, par = which == 5 ? 0 : 1;
-            for (int r = 0; r < R; ++r)
-                if (((r % d.S) & 1) == par) g = fmaf(dl[(size_t)r * CT_MAX_A + a], ws[W.hcur + (size_t)r * d.H + k], g);
+            g = dot_rows(dl + (size_t)par * CT_MAX_A + a, 2 * CT_MAX_A, ws + W.hcur + (size_t)par * d.H + k, 2 * d.H, R / 2);
             param = which == 5 ? P.wop : P.wmag;
             break;
         }
         default: {                                         // head bias[a]
             const int par = which == 6 ? 0 : 1;
-            for (int r = 0; r < R; ++r)
-                if (((r % d.S) & 1) == par) g += dl[(size_t)r * CT_MAX_A + idx];
+            g = dot_rows(dl + (size_t)par * CT_MAX_A + idx, 2 * CT_MAX_A, nullptr, 0, R / 2);
             param = which == 6 ? P.bop : P.bmag;
             break;
         }
@@ -557,17 +768,20 @@ inline bool ctrl_ok(const CtrlDims& d) {
            (4 * d.H / CT_HP) % 4 == 0 && (4 * d.H) % CT_HP == 0 && (4 * d.H / CT_XP) % 4 == 0 && (4 * d.H) % CT_XP == 0 &&
            ctrl_lds(d).total * sizeof(float) <= 160 * 1024 - 256;
 }
+// the widths of the reference's Controller (models/controller.py:10): the register-resident-weights instantiation
+constexpr int CT_E = 32, CT_H = 100;
+inline bool ctrl_fast(const CtrlDims& d) { return d.E == CT_E && d.H == CT_H && !aadg_env_flag("AADG_CTRL_GENERIC"); }
 inline CtrlParams as_params(void* const* p) {
     CtrlParams P;
     P.emb = (float*)p[0]; P.w_ih = (float*)p[1]; P.w_hh = (float*)p[2]; P.b_ih = (float*)p[3]; P.b_hh = (float*)p[4];
     P.wop = (float*)p[5]; P.bop = (float*)p[6]; P.wmag = (float*)p[7]; P.bmag = (float*)p[8];
     return P;
 }
-template <bool SAMPLE>
+template <bool SAMPLE, int EC, int HC>
 int set_lds(size_t bytes) {
     static size_t current = 0;
     if (bytes > current) {
-        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ctrl_rollout<SAMPLE>),
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ctrl_rollout<SAMPLE, EC, HC>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         current = bytes;
     }
@@ -598,11 +812,15 @@ extern "C" int aadg_controller_sample_f32(void* const* params, int M, int Q, int
     hipStream_t st = (hipStream_t)stream;
     const CtrlParams P = as_params(params);
     const size_t lds = ctrl_lds(d).total * sizeof(float);
-    const int rc = set_lds<true>(lds);
+    const bool fast = ctrl_fast(d);
+    const int rc = fast ? set_lds<true, CT_E, CT_H>(lds) : set_lds<true, 0, 0>(lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ctrl_transpose, dim3(64), dim3(256), 0, st, P, d, (float*)ws);
-    AADG_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_ctrl_rollout<true>), dim3(M), dim3(CT_THREADS), lds, st, P, d, (float*)ws, uniforms, policies, op_probs,
+    if (!fast) {                                           // the compile-time-width kernel reads the parameters as they lie
+        hipLaunchKernelGGL(k_ctrl_transpose, dim3(64), dim3(256), 0, st, P, d, (float*)ws);
+        AADG_LAUNCH_CHECK();
+    }
+    auto* kern = fast ? &k_ctrl_rollout<true, CT_E, CT_H> : &k_ctrl_rollout<true, 0, 0>;
+    hipLaunchKernelGGL(kern, dim3(M), dim3(CT_THREADS), lds, st, P, d, (float*)ws, uniforms, policies, op_probs,
                        mag_probs, log_probs, entropies, (const float*)nullptr, (const float*)nullptr, 0.0f, (float*)nullptr);
     AADG_LAUNCH_CHECK();
     return 0;
@@ -624,14 +842,18 @@ extern "C" int aadg_controller_ppo_update_f32(void* const* params, void* const* 
     CtrlPtrs9 m1, m2;
     for (int i = 0; i < 9; ++i) { m1.p[i] = (float*)exp_avg[i]; m2.p[i] = (float*)exp_avg_sq[i]; }
     const size_t lds = ctrl_lds(d).total * sizeof(float);
-    const int rc = set_lds<false>(lds);
+    const bool fast = ctrl_fast(d);
+    const int rc = fast ? set_lds<false, CT_E, CT_H>(lds) : set_lds<false, 0, 0>(lds);
     if (rc) return rc;
+    auto* kern = fast ? &k_ctrl_rollout<false, CT_E, CT_H> : &k_ctrl_rollout<false, 0, 0>;
     const int H4 = 4 * H;
     const int n_params = (n_ops + n_mags) * E + H4 * E + H4 * H + 2 * H4 + n_ops * H + n_ops + n_mags * H + n_mags;
-    hipLaunchKernelGGL(k_ctrl_transpose, dim3(64), dim3(256), 0, st, P, d, (float*)ws);
-    AADG_LAUNCH_CHECK();
+    if (!fast) {
+        hipLaunchKernelGGL(k_ctrl_transpose, dim3(64), dim3(256), 0, st, P, d, (float*)ws);
+        AADG_LAUNCH_CHECK();
+    }
     for (int it = 0; it < n_updates; ++it) {
-        hipLaunchKernelGGL((k_ctrl_rollout<false>), dim3(M), dim3(CT_THREADS), lds, st, P, d, (float*)ws, (const float*)nullptr,
+        hipLaunchKernelGGL(kern, dim3(M), dim3(CT_THREADS), lds, st, P, d, (float*)ws, (const float*)nullptr,
                            const_cast<long long*>(policies), (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                            old_log_probs, reward, clip, loss_terms + (size_t)it * M);
         AADG_LAUNCH_CHECK();

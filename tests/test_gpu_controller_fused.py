@@ -17,12 +17,15 @@ def _cfg(L=2, num_mags=10, exclude=0):
     return cfg
 
 
-@pytest.mark.parametrize("L,num_mags,exclude,M", [(2, 10, 0, 6), (1, 5, 2, 3), (3, 12, 0, 8)])
-def test_fused_sample_is_consistent_with_the_module(hip, L, num_mags, exclude, M):
+# widths (32, 100) are the module's defaults = the register-resident-weights instantiation of k_ctrl_rollout; any other
+# width runs the run-time-width instantiation
+@pytest.mark.parametrize("L,num_mags,exclude,M,widths", [(2, 10, 0, 6, (32, 100)), (1, 5, 2, 3, (32, 100)), (3, 12, 0, 8, (32, 100)),
+                                                       (2, 10, 0, 6, (16, 60))])
+def test_fused_sample_is_consistent_with_the_module(hip, L, num_mags, exclude, M, widths):
     from aadg_amd.models.controller import Controller
     cfg = _cfg(L, num_mags, exclude)
     torch.manual_seed(11)
-    c = Controller(cfg).cuda()
+    c = Controller(cfg, embedding_dim=widths[0], hidden_dim=widths[1]).cuda()
     with torch.no_grad():
         for p in c.parameters():
             p.mul_(3.0)                       # move away from the near-uniform initial policy
@@ -68,14 +71,15 @@ def test_fused_sampling_follows_the_head_distribution(hip):
     assert (freq - p).abs().max().item() < 0.04
 
 
-@pytest.mark.parametrize("L,num_mags,exclude,M", [(2, 10, 0, 6), (1, 5, 2, 3), (3, 12, 0, 8)])
-def test_fused_ppo_update_equals_eager(hip, L, num_mags, exclude, M):
+@pytest.mark.parametrize("L,num_mags,exclude,M,widths", [(2, 10, 0, 6, (32, 100)), (1, 5, 2, 3, (32, 100)), (3, 12, 0, 8, (32, 100)),
+                                                       (2, 10, 0, 6, (16, 60))])
+def test_fused_ppo_update_equals_eager(hip, L, num_mags, exclude, M, widths):
     from aadg_amd.models.controller import Controller
     from aadg_amd.models.graphed import FusedControllerStep, make_controller_step
     from aadg_amd import losses
     cfg = _cfg(L, num_mags, exclude)
     torch.manual_seed(5)
-    eager = Controller(cfg).cuda()
+    eager = Controller(cfg, embedding_dim=widths[0], hidden_dim=widths[1]).cuda()
     fused_c = copy.deepcopy(eager)
     reward = torch.randn(M, device="cuda")
     opt_f = torch.optim.Adam(fused_c.parameters(), lr=0.00035)
