@@ -29,6 +29,7 @@ DATASET_OPTIC, DATASET_VESSEL = 0, 1
 EXPORTS = [
     "aadg_abi_version",
     "aadg_aug_u8_workspace_bytes", "aadg_aug_u8_forward", "aadg_aug_u8_forward_ex", "aadg_aug_u8_forward_ex2", "aadg_op_u8",
+    "aadg_pool_histograms_u8",
     "aadg_sinkhorn_workspace_bytes", "aadg_sinkhorn_divergence_f32", "aadg_sinkhorn_rewards_f32", "aadg_sinkhorn_rewards_norm_f32",
     "aadg_normalize_rewards_f32",
     "aadg_seg_loss_workspace_bytes", "aadg_seg_bce_dice_f32",
@@ -74,6 +75,8 @@ def load():
     lib.aadg_aug_u8_forward_ex.argtypes = lib.aadg_aug_u8_forward.argtypes + [_i, _i, _vp, _vp]
     lib.aadg_aug_u8_forward_ex2.restype = _i
     lib.aadg_aug_u8_forward_ex2.argtypes = lib.aadg_aug_u8_forward_ex.argtypes + [_vp]
+    lib.aadg_pool_histograms_u8.restype = _i
+    lib.aadg_pool_histograms_u8.argtypes = [_vp, _i, _i, _i, _vp, _vp]
     lib.aadg_op_u8.restype = _i
     lib.aadg_op_u8.argtypes = [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp]
     lib.aadg_sinkhorn_workspace_bytes.restype = _sz
@@ -182,7 +185,7 @@ def load():
     lib.aadg_upsample_sum_backward.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
     lib.aadg_embed_prologue_norm_f32.restype = _i
     lib.aadg_embed_prologue_norm_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]
-    if lib.aadg_abi_version() != 3:
+    if lib.aadg_abi_version() != 4:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -271,10 +274,11 @@ def validate_units(units, P, Hs, Ws):
     return int(units["n_ops"].max())
 
 
-def launch_hints(units, Hs, Ws, crop):
-    """(classes, stats_mask, order, counts, stat_lists) for aadg_aug_u8_forward_ex2 -- mirrors unit_flow() in csrc/aug_u8.hip.
+def launch_plan(units, Hs, Ws, crop):
+    """(classes, stats_mask, order, counts, stat_lists, late_plan) for aadg_aug_u8_forward_ex2 -- mirrors unit_flow() in csrc/aug_u8.hip.
     order: unit indices grouped by tile class (plain up-scaling, up-scaling with a Sharpness stencil, generic, staged);
-    counts = (n_plain, n_sharp, n_generic); stat_lists[k]: the units whose k-th op needs image statistics."""
+    counts = (n_plain, n_sharp, n_generic); stat_lists[k]: the units whose k-th op needs a pixel pass for its image statistics;
+    late: the units with such an op in a slot k >= 1."""
     n_ops = units["n_ops"]
     live = np.arange(MAX_OPS)[None, :] < n_ops[:, None]
     sharp = ((units["op"] == 8) & (units["farg"] != np.float32(1.0)) & live).sum(axis=1)
@@ -304,13 +308,38 @@ def launch_hints(units, Hs, Ws, crop):
     order = np.argsort(cls, kind="stable").astype(np.int32)
     counts = (int((cls == 0).sum()), int((cls == 1).sum()), int((cls == 2).sum()))
     stat_lists = [np.nonzero(pixel_pass[:, k])[0].astype(np.int32) for k in range(MAX_OPS)]     # work lists of the histogram kernels
-    return classes, stats_mask, order, counts, stat_lists
+    # "late" units: a slot k >= 1 needs a pixel pass (include/aadg_hip.h: aadg_aug_lists.late_units)
+    late = np.nonzero(pixel_pass[:, 1:].any(axis=1))[0].astype(np.int32)
+    return classes, stats_mask, order, counts, stat_lists, late
+
+
+def launch_hints(units, Hs, Ws, crop):
+    """launch_plan without the late list: (classes, stats_mask, order, counts, stat_lists)."""
+    return launch_plan(units, Hs, Ws, crop)[:5]
 
 
 class AugLists(ctypes.Structure):
     """mirror of `aadg_aug_lists` (include/aadg_hip.h): host struct of device index arrays"""
     _fields_ = [("order", ctypes.c_void_p), ("n_plain", ctypes.c_int32), ("n_sharp", ctypes.c_int32), ("n_generic", ctypes.c_int32),
-                ("stat_units", ctypes.c_void_p * MAX_OPS), ("n_stat", ctypes.c_int32 * MAX_OPS)]
+                ("stat_units", ctypes.c_void_p * MAX_OPS), ("n_stat", ctypes.c_int32 * MAX_OPS), ("pool_hist", ctypes.c_void_p),
+                ("late_units", ctypes.c_void_p), ("n_late", ctypes.c_int32)]
+
+
+HIST_STRIDE = 772      # AADG_HIST_STRIDE
+
+
+def pool_histograms(pool):
+    """uint32 [P, HIST_STRIDE] statistics of the source pool (uint8 [P,H,W,3], device): per channel histogram + sum of L.
+    The policy ops run on the raw source image, so these serve every unit / batch that draws the image: compute once per
+    resident pool and pass as `pool_hist` to aug_u8_forward (recompute after writing to the pool)."""
+    lib = load()
+    _require_cuda(pool)
+    if pool.dtype != torch.uint8 or pool.dim() != 4 or pool.shape[3] != 3 or not pool.is_contiguous():
+        raise AadgError("pool must be contiguous uint8 [P,H,W,3]")
+    P, Hs, Ws, _ = pool.shape
+    hist = torch.empty((P, HIST_STRIDE), dtype=torch.int32, device=pool.device)
+    _check(lib.aadg_pool_histograms_u8(pool.data_ptr(), P, Hs, Ws, hist.data_ptr(), _stream()), "aadg_pool_histograms_u8")
+    return hist
 
 
 # optional (start, stop) torch.cuda.Event pair recorded around the dominant kernel of the next
@@ -321,7 +350,7 @@ PROFILE_CALL_EVENTS = None
 _pinned = {}
 
 
-_REC = UNIT_DTYPE.itemsize + 4 * (1 + MAX_OPS)   # staging bytes per unit: the record + its slot in the class-order list and in each
+_REC = UNIT_DTYPE.itemsize + 4 * (2 + MAX_OPS)   # staging bytes per unit: the record + its slot in the class-order list and in each
                                                  # stage's statistics work list
 
 
@@ -333,8 +362,9 @@ def _pinned_units(n):
     return buf
 
 
-def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None):
-    """pool u8 [P,Hs,Ws,3], masks u8 [P,Hs,Ws] (device), units numpy UNIT_DTYPE[N].
+def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None, pool_hist=None):
+    """pool u8 [P,Hs,Ws,3], masks u8 [P,Hs,Ws] (device), units numpy UNIT_DTYPE[N]; pool_hist: pool_histograms(pool) or None
+    (None: the statistics passes of the call read the source images themselves).
     Returns (aug_images f32 [N,3,crop,crop], aug_labels f32 [N,K,crop,crop]) on the device."""
     lib = load()
     _require_cuda(pool, masks)
@@ -358,7 +388,7 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
     ready = _pinned.get("units_ready")
     if ready is not None:
         ready.synchronize()          # previous copy out of the staging buffer has completed
-    classes, stats_mask, order, (n_plain, n_sharp, n_generic), stat_lists = launch_hints(units, Hs, Ws, crop)
+    classes, stats_mask, order, (n_plain, n_sharp, n_generic), stat_lists, late = launch_plan(units, Hs, Ws, crop)
     nb_units = N * UNIT_DTYPE.itemsize                       # a multiple of 4: the int32 list behind it is aligned
     host = stage[:N * _REC].numpy()
     host[:nb_units] = units.view(np.uint8).reshape(-1)
@@ -372,6 +402,14 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
         host[off:off + 4 * lst.size] = lst.view(np.uint8)
         lists.stat_units[k] = d_units.data_ptr() + off
         lists.n_stat[k] = int(lst.size)
+    if pool_hist is not None:
+        if pool_hist.dtype != torch.int32 or tuple(pool_hist.shape) != (P, HIST_STRIDE) or not pool_hist.is_cuda:
+            raise AadgError("pool_hist must be pool_histograms(pool): int32 [P, %d] on the device" % HIST_STRIDE)
+        lists.pool_hist = pool_hist.data_ptr()
+        off = nb_units + 4 * N * (1 + MAX_OPS)
+        host[off:off + 4 * late.size] = late.view(np.uint8)
+        lists.late_units = d_units.data_ptr() + off
+        lists.n_late = int(late.size)
     d_units.copy_(stage[:N * _REC], non_blocking=True)          # records + work lists: one H2D copy
     ready = torch.cuda.Event()
     ready.record()

@@ -33,7 +33,7 @@
 namespace {
 
 constexpr int KMAX = 8;           // max taps per output pixel (scale factor >= 1/3)
-constexpr int HIST_STRIDE = 772;  // 768 bins + u64 L-sum + pad (u32 words)
+constexpr int HIST_STRIDE = AADG_HIST_STRIDE;  // 768 bins + u64 L-sum + pad (u32 words)
 constexpr int TAB_STRIDE = 2 * KMAX + 4;  // ints per crop position: xmin,xk[KMAX],ymin,yk[KMAX],xnn,ynn
 constexpr int PRECISION_BITS = 22;
 
@@ -127,6 +127,7 @@ __device__ __forceinline__ const uint8_t* stage_input(const Bufs& b, const aadg_
 // ------------------------------------------------------------------------------------------------
 // k_hist: grid (chunks, N), 256 threads.  Thread = groups of 4 pixels (12 bytes, 3 dword loads).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void hist_pixels(const uint8_t* __restrict__ in, int npix, int bx, int nbx, uint32_t* gh, uint32_t (*sh)[768]);
 __device__ __forceinline__ void hist_body(const Bufs& bufs, const UnitRef& ur, const int* __restrict__ ulist, int stage, int npix, int Hs,
                                           int Ws, int crop, uint32_t* hist, int bx, int by, int nbx, uint32_t (*sh)[768]) {
     const int u = ulist != nullptr ? ulist[by] : by;      // ulist: the units whose op `stage` needs statistics
@@ -139,7 +140,10 @@ __device__ __forceinline__ void hist_body(const Bufs& bufs, const UnitRef& ur, c
         if (un.n_ops <= stage || !op_needs_stats(un.op[stage])) return;
         if (fused_flow) return;                                   // k_hist_fused / push-forward cover those
     }
-    const uint8_t* in = stage_input(bufs, un, u, stage);
+    hist_pixels(stage_input(bufs, un, u, stage), npix, bx, nbx, hist + (size_t)u * HIST_STRIDE, sh);
+}
+// histogram + L-sum of chunk bx of nbx of one HWC image, added to gh[HIST_STRIDE]
+__device__ __forceinline__ void hist_pixels(const uint8_t* __restrict__ in, int npix, int bx, int nbx, uint32_t* gh, uint32_t (*sh)[768]) {
     const int tid = threadIdx.x, wv = tid >> 6;
     for (int i = tid; i < 4 * 768; i += 256) (&sh[0][0])[i] = 0;
     __syncthreads();
@@ -168,7 +172,6 @@ __device__ __forceinline__ void hist_body(const Bufs& bufs, const UnitRef& ur, c
     }
     lsum = wave_sum(lsum);
     __syncthreads();
-    uint32_t* gh = hist + (size_t)u * HIST_STRIDE;
     for (int i = tid; i < 768; i += 256) {
         uint32_t v = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i];
         if (v) atomicAdd(&gh[i], v);
@@ -181,30 +184,36 @@ __global__ __launch_bounds__(256) void k_hist(Bufs bufs, UnitRef ur, const int* 
     hist_body(bufs, ur, ulist, stage, npix, Hs, Ws, crop, hist, blockIdx.x, blockIdx.y, gridDim.x, sh);
 }
 
+// grid (chunks, P): histograms of the pool images themselves (aadg_pool_histograms_u8)
+__global__ __launch_bounds__(256) void k_pool_hist(const uint8_t* __restrict__ pool, size_t img_bytes, int npix, uint32_t* hist) {
+    __shared__ uint32_t sh[4][768];
+    hist_pixels(pool + (size_t)blockIdx.y * img_bytes, npix, blockIdx.x, gridDim.x, hist + (size_t)blockIdx.y * HIST_STRIDE, sh);
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_lut: grid N, 256 threads; thread i owns LUT entry i of each channel.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lut(UnitRef ur, int stage, int npix, int Hs, int Ws, int crop, const uint32_t* hist0,
-                                             const uint32_t* hist, uint8_t* lut) {
-    const int u = blockIdx.x;
+// pool_hist != nullptr: the raw image's statistics come from the caller's per-pool-image cache (row un.src) instead of this call's
+// stage-0 pixel pass (row u of hist0)
+__device__ __forceinline__ void lut_body(const UnitRef& ur, int stage, int N, int u, int npix, int Hs, int Ws, int crop,
+                                         const uint32_t* hist0, const uint32_t* hist, const uint32_t* pool_hist, uint8_t* lut) {
     const aadg_unit& un = pick(ur, u);
     if (un.n_ops <= stage) return;
     const int op = un.op[stage];
     if (!op_is_lut(op)) return;
     const int i = threadIdx.x;
-    uint8_t* L = lut + ((size_t)stage * gridDim.x + u) * 768;
-    const uint32_t* gh = hist + (size_t)u * HIST_STRIDE;          // this stage's pixel-pass histogram
-    __shared__ uint32_t scan[256];
-    __shared__ uint32_t pushed[768];
+    uint8_t* L = lut + ((size_t)stage * N + u) * 768;
+    const uint32_t* raw = pool_hist != nullptr ? pool_hist + (size_t)un.src * HIST_STRIDE : hist0 + (size_t)u * HIST_STRIDE;
+    const uint32_t* gh = stage == 0 ? raw : hist + (size_t)u * HIST_STRIDE;      // this stage's pixel-pass histogram
+    __shared__ __attribute__((aligned(16))) uint32_t pushed[768];
     if (stats_by_pushforward(un, stage, unit_fusable(ur, un, Hs, Ws, crop))) {
         // histogram after `stage` per-channel maps = the raw histogram pushed through them
         for (int t = i; t < 768; t += 256) pushed[t] = 0u;
         __syncthreads();
-        const uint32_t* g0 = hist0 + (size_t)u * HIST_STRIDE;
         for (int c = 0; c < 3; ++c) {
-            const uint32_t cnt = g0[256 * c + i];
+            const uint32_t cnt = raw[256 * c + i];
             int v = i;
-            for (int j = 0; j < stage; ++j) v = lut[((size_t)j * gridDim.x + u) * 768 + 256 * c + v];
+            for (int j = 0; j < stage; ++j) v = lut[((size_t)j * N + u) * 768 + 256 * c + v];
             if (cnt) atomicAdd(&pushed[256 * c + v], cnt);
         }
         __syncthreads();
@@ -230,61 +239,72 @@ __global__ __launch_bounds__(256) void k_lut(UnitRef ur, int stage, int npix, in
         else if (alpha == 0.0f) v = (uint8_t)deg;
         else v = (uint8_t)blend_px(deg, i, alpha, alpha >= 0.0f && alpha <= 1.0f);
         for (int c = 0; c < 3; ++c) L[256 * c + i] = v;
-    } else {  // AUTOCONTRAST / EQUALIZE
-        __shared__ int w_lo[4], w_hi[4], w_nnz[4];
-        __shared__ unsigned long long w_sum[4];
-        const int wv = i >> 6;
-        for (int c = 0; c < 3; ++c) {
-            const uint32_t hv = gh[256 * c + i];
-            __syncthreads();
-            // lowest / highest non-empty bin, number of non-empty bins, pixel count: wave shuffles, then 4 partials
-            int lo = hv ? i : 256, hi = hv ? i : -1, nnz = hv ? 1 : 0;
-            unsigned long long sm = hv;
+    } else {  // AUTOCONTRAST / EQUALIZE: wave c owns channel c, lane l its bins 4l .. 4l + 3 -- no barriers (the 256-thread scan
+              // needed 48 of them per map: 8 us per launch, most of k_luts_tables)
+        const int c = i >> 6, lane = i & 63;
+        if (c < 3) {
+            const uint4 h4 = *reinterpret_cast<const uint4*>(gh + 256 * c + 4 * lane);
+            const uint32_t h[4] = {h4.x, h4.y, h4.z, h4.w};
+            int lo = 256, hi = -1, nnz = 0;
+            uint32_t tot = 0;
+#pragma unroll
+            for (int t = 3; t >= 0; --t) if (h[t]) lo = 4 * lane + t;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) if (h[t]) { hi = 4 * lane + t; ++nnz; tot += h[t]; }
+            uint32_t incl = tot;                           // inclusive scan of the lane totals
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+            unsigned long long s_sum = tot;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 lo = min(lo, __shfl_xor(lo, o, 64));
                 hi = max(hi, __shfl_xor(hi, o, 64));
                 nnz += __shfl_xor(nnz, o, 64);
-                sm += __shfl_xor(sm, o, 64);
+                s_sum += __shfl_xor(s_sum, o, 64);
             }
-            if ((i & 63) == 0) { w_lo[wv] = lo; w_hi[wv] = hi; w_nnz[wv] = nnz; w_sum[wv] = sm; }
-            scan[i] = hv;
-            // inclusive Hillis-Steele scan of the 256 bins
-            for (int o = 1; o < 256; o <<= 1) {
-                __syncthreads();
-                uint32_t t = i >= o ? scan[i - o] : 0u;
-                __syncthreads();
-                scan[i] += t;
-            }
-            __syncthreads();
-            const int s_lo = min(min(w_lo[0], w_lo[1]), min(w_lo[2], w_lo[3]));
-            const int s_hi = max(max(w_hi[0], w_hi[1]), max(w_hi[2], w_hi[3]));
-            const int s_nnz = w_nnz[0] + w_nnz[1] + w_nnz[2] + w_nnz[3];
-            const unsigned long long s_sum = w_sum[0] + w_sum[1] + w_sum[2] + w_sum[3];
-            uint8_t v = (uint8_t)i;
+            const int s_lo = lo, s_hi = hi, s_nnz = nnz;
+            uint32_t v4 = 0;
             if (op == AADG_OP_AUTOCONTRAST) {
-                const int lo2 = s_lo, hi2 = s_hi;
-                if (hi2 > lo2) {
-                    const double scale = 255.0 / (double)(hi2 - lo2);
-                    const double offset = (double)(-lo2) * scale;
-                    int ix = (int)((double)i * scale + offset);
-                    ix = ix < 0 ? 0 : (ix > 255 ? 255 : ix);
-                    v = (uint8_t)ix;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int bin = 4 * lane + t;
+                    int ix = bin;
+                    if (s_hi > s_lo) {
+                        const double scale = 255.0 / (double)(s_hi - s_lo);
+                        const double offset = (double)(-s_lo) * scale;
+                        ix = (int)((double)bin * scale + offset);
+                        ix = ix < 0 ? 0 : (ix > 255 ? 255 : ix);
+                    }
+                    v4 |= (uint32_t)ix << (8 * t);
                 }
             } else {
-                if (s_nnz > 1) {
-                    const unsigned long long last = gh[256 * c + s_hi];
-                    const unsigned long long step = (s_sum - last) / 255ull;
+                const int hl = s_hi < 0 ? 0 : s_hi;
+                const uint32_t mine = (hl & 3) == 0 ? h[0] : ((hl & 3) == 1 ? h[1] : ((hl & 3) == 2 ? h[2] : h[3]));
+                const unsigned long long last = __shfl(mine, hl >> 2, 64);
+                const unsigned long long step = s_nnz > 1 ? (s_sum - last) / 255ull : 0ull;
+                uint32_t excl = incl - tot;                // exclusive prefix of bin 4 * lane
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    uint32_t v = (uint32_t)(4 * lane + t);
                     if (step) {
-                        const unsigned long long n = step / 2 + (unsigned long long)(scan[i] - hv);  // exclusive prefix
-                        const unsigned long long q = n / step;
-                        v = (uint8_t)(q > 255ull ? 255ull : q);
+                        const unsigned long long q = (step / 2 + (unsigned long long)excl) / step;
+                        v = (uint32_t)(q > 255ull ? 255ull : q);
                     }
+                    v4 |= v << (8 * t);
+                    excl += h[t];
                 }
             }
-            L[256 * c + i] = v;
+            *reinterpret_cast<uint32_t*>(L + 256 * c + 4 * lane) = v4;
         }
     }
+}
+// grid N (ulist == nullptr) or the length of ulist: one unit's stage-`stage` byte map per workgroup
+__global__ __launch_bounds__(256) void k_lut(UnitRef ur, int stage, int N, const int* __restrict__ ulist, int npix, int Hs, int Ws, int crop,
+                                             const uint32_t* hist0, const uint32_t* hist, const uint32_t* pool_hist, uint8_t* lut) {
+    lut_body(ur, stage, N, ulist != nullptr ? ulist[blockIdx.x] : (int)blockIdx.x, npix, Hs, Ws, crop, hist0, hist, pool_hist, lut);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -424,15 +444,14 @@ __device__ void bilinear_coeffs(int inSize, int outSize, int xx, int* xmin_out, 
     *xmin_out = xmin;
 }
 
-__device__ __forceinline__ void tables_body(const UnitRef& ur, int Hs, int Ws, int crop, int* tab, int u, int* nn_lds /* 2 * crop ints */) {
+// the BILINEAR tap tables of unit u (first tap + KMAX fixed-point coefficients per output column / row of the crop window)
+__device__ __forceinline__ void tables_coeff_body(const UnitRef& ur, int Hs, int Ws, int crop, int* tab, int u) {
     const aadg_unit& un = pick(ur, u);
     int* base = tab + (size_t)u * crop * TAB_STRIDE;
     int* xmin = base;
     int* xk = xmin + crop;
     int* ymin = xk + (size_t)crop * KMAX;
     int* yk = ymin + crop;
-    int* xnn = yk + (size_t)crop * KMAX;
-    int* ynn = xnn + crop;
     const int w = un.scaled_w, h = un.scaled_h;
     const int ox = un.crop_x - un.pad, oy = un.crop_y - un.pad;
     for (int i = threadIdx.x; i < 2 * crop; i += 256) {
@@ -448,9 +467,19 @@ __device__ __forceinline__ void tables_body(const UnitRef& ur, int Hs, int Ws, i
         int* kk = (isx ? xk : yk) + (size_t)o * KMAX;
         for (int t = 0; t < KMAX; ++t) kk[t] = k[t];
     }
-    // NEAREST tables: ImagingScaleAffine accumulates xo += a0 in double, SEQUENTIALLY (the rounding of the
-    // running sum decides exact ties), so one lane walks each axis; results are staged in LDS and written
-    // out coalesced by the whole block.
+}
+// the NEAREST index tables of unit u (labels).  ImagingScaleAffine accumulates xo += a0 in double, SEQUENTIALLY (the rounding of the
+// running sum decides exact ties), so one lane walks each axis (~770 dependent additions: the long pole of the tables, which is why
+// k_luts_tables gives it a workgroup of its own); results are staged in LDS and written out coalesced by the whole block.
+__device__ __forceinline__ void tables_nn_body(const UnitRef& ur, int Hs, int Ws, int crop, int* tab, int u, int* nn_lds /* 2 * crop ints */) {
+    const aadg_unit& un = pick(ur, u);
+    int* base = tab + (size_t)u * crop * TAB_STRIDE;
+    int* xnn = base + 2 * (crop + (size_t)crop * KMAX);
+    int* ynn = xnn + crop;
+    const int w = un.scaled_w, h = un.scaled_h;
+    const int ox = un.crop_x - un.pad, oy = un.crop_y - un.pad;
+    for (int i = threadIdx.x; i < 2 * crop; i += 256) nn_lds[i] = -1;
+    __syncthreads();
     if (threadIdx.x == 0 || threadIdx.x == 64) {
         const bool isx = threadIdx.x == 0;
         const int outSize = isx ? w : h, inSize = isx ? Ws : Hs, off = isx ? ox : oy;
@@ -459,7 +488,6 @@ __device__ __forceinline__ void tables_body(const UnitRef& ur, int Hs, int Ws, i
         double xo = 0.0 + a0 * 0.5;
         int lim = off + crop;
         if (lim > outSize) lim = outSize;
-        for (int o = 0; o < crop; ++o) nn[o] = -1;
         if (inSize == outSize) {       // a0 == 1: xo = s + 0.5 exactly
             for (int sidx = off < 0 ? 0 : off; sidx < lim; ++sidx) nn[sidx - off] = sidx;
         } else {
@@ -479,6 +507,57 @@ __device__ __forceinline__ void tables_body(const UnitRef& ur, int Hs, int Ws, i
     __syncthreads();
     for (int i = threadIdx.x; i < crop; i += 256) { xnn[i] = nn_lds[i]; ynn[i] = nn_lds[crop + i]; }
 }
+// The same with the walking lane doing nothing but the additions: it stores the running sums (doubles) and the whole workgroup
+// converts them afterwards.  The walk is one wave with one live lane, so its time is instructions x ~5 cycles, not arithmetic:
+// add + convert + compare + select + store per step took 20 us for a 512-wide crop at offset ~250, add + store takes ~8.
+__device__ __forceinline__ void tables_nn_body_wide(const UnitRef& ur, int Hs, int Ws, int crop, int* tab, int u, double* xs /* 2 * crop */) {
+    const aadg_unit& un = pick(ur, u);
+    int* base = tab + (size_t)u * crop * TAB_STRIDE;
+    int* xnn = base + 2 * (crop + (size_t)crop * KMAX);
+    int* ynn = xnn + crop;
+    const int w = un.scaled_w, h = un.scaled_h;
+    const int ox = un.crop_x - un.pad, oy = un.crop_y - un.pad;
+    if (threadIdx.x == 0 || threadIdx.x == 64) {
+        const bool isx = threadIdx.x == 0;
+        const int outSize = isx ? w : h, inSize = isx ? Ws : Hs, off = isx ? ox : oy;
+        if (inSize != outSize) {
+            double* x = xs + (isx ? 0 : crop);
+            const double a0 = (double)inSize / (double)outSize;
+            double xo = 0.0 + a0 * 0.5;
+            int lim = off + crop;
+            if (lim > outSize) lim = outSize;
+            int sidx = 0;
+            const int skip = off < lim ? off : lim;
+#pragma unroll 8
+            for (; sidx < skip; ++sidx) xo += a0;
+#pragma unroll 8
+            for (; sidx < lim; ++sidx) {
+                x[sidx - off] = xo;
+                xo += a0;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * crop; i += 256) {
+        const bool isx = i < crop;
+        const int o = isx ? i : i - crop;
+        const int outSize = isx ? w : h, inSize = isx ? Ws : Hs, off = isx ? ox : oy;
+        const int lim = min(off + crop, outSize), sidx = o + off;
+        int v = -1;
+        if (sidx >= 0 && sidx >= min(off, lim) && sidx < lim) {
+            if (inSize == outSize) v = sidx;               // a0 == 1: xo = s + 0.5 exactly
+            else {
+                const int xin = (int)xs[i];
+                v = xin < inSize ? xin : -1;
+            }
+        }
+        (isx ? xnn : ynn)[o] = v;
+    }
+}
+__device__ __forceinline__ void tables_body(const UnitRef& ur, int Hs, int Ws, int crop, int* tab, int u, int* nn_lds /* 2 * crop ints */) {
+    tables_coeff_body(ur, Hs, Ws, crop, tab, u);
+    tables_nn_body(ur, Hs, Ws, crop, tab, u, nn_lds);
+}
 __global__ __launch_bounds__(256) void k_tables(UnitRef ur, int Hs, int Ws, int crop, int* tab) {
     extern __shared__ int nn_dyn[];   // 2 * crop ints
     tables_body(ur, Hs, Ws, crop, tab, blockIdx.x, nn_dyn);
@@ -492,6 +571,45 @@ __global__ __launch_bounds__(256) void k_hist_tables(Bufs bufs, UnitRef ur, cons
     const int b = blockIdx.x, nh = chunks * nstat;
     if (b < nh) hist_body(bufs, ur, ulist, 0, npix, Hs, Ws, crop, hist, b % chunks, b / chunks, chunks, sh);
     else tables_body(ur, Hs, Ws, crop, tab, b - nh, reinterpret_cast<int*>(&sh[0][0]));
+}
+
+// With the pool's histograms cached by the caller, the stage-0 byte maps depend on the unit records and the cache only -- like the
+// tables: one launch for both (blocks [0, N): one unit's stage-0 map each; the next N: its tables).  crop <= 1536.
+__global__ __launch_bounds__(256) void k_lut_tables(UnitRef ur, int N, int npix, int Hs, int Ws, int crop, const uint32_t* pool_hist,
+                                                    uint8_t* lut, int* tab) {
+    __shared__ int nn[2 * 1536];
+    const int b = blockIdx.x;
+    if (b < N) lut_body(ur, 0, N, b, npix, Hs, Ws, crop, pool_hist, pool_hist, pool_hist, lut);
+    else tables_body(ur, Hs, Ws, crop, tab, b - N, nn);
+}
+
+// The same with EVERY stage's map that does not wait for a pixel pass (blocks [0, N): unit u, stages in order -- a later stage's
+// push-forward reads the earlier maps this workgroup has just written).  A stage >= 1 whose statistics need a pixel pass is left
+// to the late chain of aadg_aug_u8_forward_ex2 (and so is everything behind it: those units are re-done there).  Blocks [N, 2N):
+// unit b - N's tap tables; [2N, 3N): its NEAREST tables (a serial walk: own workgroup so that the taps do not wait behind it).
+__global__ __launch_bounds__(256) void k_luts_tables(UnitRef ur, int N, int max_ops, int npix, int Hs, int Ws, int crop,
+                                                     const uint32_t* pool_hist, uint8_t* lut, int* tab, uint32_t* hist_zero) {
+    __shared__ double nn[2 * 1536];
+    const int b = blockIdx.x;
+    if (b >= 2 * N) {
+        tables_nn_body_wide(ur, Hs, Ws, crop, tab, b - 2 * N, nn);
+        return;
+    }
+    if (b >= N) {
+        tables_coeff_body(ur, Hs, Ws, crop, tab, b - N);
+        return;
+    }
+    if (hist_zero != nullptr)                  // the pixel-pass histograms of slots 1 .. max_ops - 1 accumulate with atomics: clear this unit's rows
+        for (int k = 1; k < max_ops; ++k)
+            for (int t = threadIdx.x; t < HIST_STRIDE; t += 256) hist_zero[((size_t)k * N + b) * HIST_STRIDE + t] = 0u;
+    const aadg_unit& un = pick(ur, b);
+    const bool fused_flow = unit_fusable(ur, un, Hs, Ws, crop);
+    for (int k = 0; k < max_ops && k < un.n_ops; ++k) {
+        if (k > 0 && op_needs_stats(un.op[k]) && !stats_by_pushforward(un, k, fused_flow)) continue;
+        lut_body(ur, k, N, b, npix, Hs, Ws, crop, pool_hist, pool_hist, pool_hist, lut);
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1469,11 +1587,12 @@ __device__ __forceinline__ void fused3_body(const uint8_t* __restrict__ pool, co
 
 // grid (ceil(crop/256), ceil(crop/16), n_plain + 2 n_sharp): the first n_plain z-slices run the plain body on unit order[z],
 // the rest the Sharpness body, two 8-row workgroups per unit and 16-row tile.  `order` lists the unit indices grouped by
-// class (the caller classifies on the host); without it every unit gets a slice of each kind and the wrong kind returns after
+// class (the caller classifies on the host: `order` = the plain units, `order_sharp` = the Sharpness units); without it every
+// unit gets a slice of each kind and the wrong kind returns after
 // reading the unit record (a returning workgroup still occupies a slot with its 39 KiB of LDS for about a microsecond).
 __global__ __launch_bounds__(256) void k_fused3(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
-                                                const aadg_unit* __restrict__ units, const int* __restrict__ order, int n_plain,
-                                                int Hs, int Ws, int crop, int dataset,
+                                                const aadg_unit* __restrict__ units, const int* __restrict__ order,
+                                                const int* __restrict__ order_sharp, int n_plain, int Hs, int Ws, int crop, int dataset,
                                                 const int* __restrict__ tab, const uint8_t* __restrict__ lut,
                                                 size_t lut_stage_stride, float* __restrict__ out_img, float* __restrict__ out_lbl) {
     __shared__ __attribute__((aligned(16))) uint32_t A[PATCH_CAP_PLAIN];
@@ -1486,7 +1605,7 @@ __global__ __launch_bounds__(256) void k_fused3(const uint8_t* __restrict__ pool
         fused3_body<false>(pool, masks, units, Hs, Ws, crop, dataset, tab, lut, lut_stage_stride, out_img, out_lbl, u, 0, A, B, sl, lutf);
     } else {
         const int zz = z - n_plain;
-        const int u = order != nullptr ? order[n_plain + (zz >> 1)] : (zz >> 1);
+        const int u = order_sharp != nullptr ? order_sharp[zz >> 1] : (zz >> 1);
         fused3_body<true>(pool, masks, units, Hs, Ws, crop, dataset, tab, lut, lut_stage_stride, out_img, out_lbl, u, zz & 1, A, B, sl, lutf);
     }
 }
@@ -1523,11 +1642,19 @@ bool getenv_flag(const char* name) {
 // statistics + LUT (+ staged apply) for stages [0, max_ops)
 int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int crop, int max_ops, uint8_t* ws8,
                const WsLayout& L, uint8_t* out_override, int classes, int stats_mask, hipStream_t st,
-               const aadg_aug_lists* lists = nullptr, int* tab = nullptr, bool* tables_done = nullptr) {
+               const aadg_aug_lists* lists = nullptr, int* tab = nullptr, bool* tables_done = nullptr,
+               const aadg_aug_lists* all_lists = nullptr) {
     const int npix = Hs * Ws;
     uint32_t* hist0 = reinterpret_cast<uint32_t*>(ws8 + L.hist);          // stage k's histograms: hist0 + k * N * HIST_STRIDE
     const size_t hist_stage = (size_t)N * HIST_STRIDE;
-    if (stats_mask != 0) AADG_HIP_TRY(hipMemsetAsync(hist0, 0, (size_t)max_ops * hist_stage * 4, st));
+    // the raw images' statistics from the caller's cache: no stage-0 pixel pass
+    const uint32_t* pool_hist = all_lists != nullptr ? all_lists->pool_hist : nullptr;
+    bool zero = false;                                   // some pixel-pass histogram kernel of this call accumulates into hist
+    for (int k = 0; k < max_ops; ++k) {
+        const int nstat = lists != nullptr ? lists->n_stat[k] : N;
+        if ((stats_mask & (1 << k)) && nstat > 0 && !(k == 0 && pool_hist != nullptr)) zero = true;
+    }
+    if (zero) AADG_HIP_TRY(hipMemsetAsync(hist0, 0, (size_t)max_ops * hist_stage * 4, st));
     uint8_t* lut = ws8 + L.lut;
     const size_t lut_stage_stride = (size_t)N * 768;
     const dim3 g(chunks_for(npix), N);
@@ -1536,7 +1663,18 @@ int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int c
         const int* ulist = lists != nullptr ? lists->stat_units[k] : nullptr;
         const int nstat = ulist != nullptr ? lists->n_stat[k] : N;
         uint32_t* hist = hist0 + (size_t)k * hist_stage;
-        if ((stats_mask & (1 << k)) && nstat > 0) {
+        if (k == 0 && pool_hist != nullptr) {
+            if (tab != nullptr && crop <= 1536) {
+                hipLaunchKernelGGL(k_lut_tables, dim3(2 * N), dim3(256), 0, st, ur, N, npix, Hs, Ws, crop, pool_hist, lut, tab);
+                AADG_LAUNCH_CHECK();
+                *tables_done = true;
+                if (classes & HINT_STAGED) {
+                    hipLaunchKernelGGL(k_apply, g, dim3(256), 0, st, bufs, ur, k, Hs, Ws, crop, lut, out_override);
+                    AADG_LAUNCH_CHECK();
+                }
+                continue;
+            }
+        } else if ((stats_mask & (1 << k)) && nstat > 0) {
             if (k == 0 && tab != nullptr && 2 * crop <= 4 * 768) {
                 // stage-0 histograms and the resampling tables in one launch
                 hipLaunchKernelGGL(k_hist_tables, dim3(g.x * nstat + N), dim3(256), 0, st, bufs, ur, ulist, nstat, (int)g.x, npix, Hs, Ws,
@@ -1553,8 +1691,8 @@ int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int c
                 AADG_LAUNCH_CHECK();
             }
         }
-        hipLaunchKernelGGL(k_lut, dim3(N), dim3(256), 0, st, ur, k, npix, Hs, Ws, crop, (const uint32_t*)hist0,
-                           (const uint32_t*)(hist0 + (size_t)k * hist_stage), lut);
+        hipLaunchKernelGGL(k_lut, dim3(N), dim3(256), 0, st, ur, k, N, (const int*)nullptr, npix, Hs, Ws, crop, (const uint32_t*)hist0,
+                           (const uint32_t*)(hist0 + (size_t)k * hist_stage), pool_hist, lut);
         AADG_LAUNCH_CHECK();
         if (classes & HINT_STAGED) {
             hipLaunchKernelGGL(k_apply, g, dim3(256), 0, st, bufs, ur, k, Hs, Ws, crop, lut, out_override);
@@ -1565,6 +1703,69 @@ int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int c
 }
 
 }  // namespace
+
+// The call with the pool's statistics cached and the caller's late list (no staged units).  The first launch builds the tables and every
+// byte map that waits for no pixel pass (all of them for most units).  What is left is the late units' chain -- per slot k >= 1: histogram
+// pass over the image after k ops, then the maps of the late units -- and the tiles:
+//     k_luts_tables | k_hist_fused(1) k_lut(1, late) ... | k_fused3(all units) | k_fused_generic
+// (Measured and dropped: the chain and the late units' tiles on a second, highest-priority stream beside the tile kernel of the other
+// units -- 268 instead of 278 us per 168-unit call once k_hist_fused fitted the LDS slot a retiring tile workgroup leaves (35 KiB; with
+// 51 KiB it starved until the tile kernel had drained).  3.5 % of the call for a fork / join, a second kernel name and a tile-kernel
+// duration that no longer says how fast the tile kernel is.)
+int forward_cached(const uint8_t* pool, const uint8_t* masks, const UnitRef& ur, int N, int Hs, int Ws, int max_ops, int crop, int dataset,
+                   float* out_img, float* out_lbl, uint8_t* ws8, const WsLayout& L, hipStream_t st, int classes, int stats_mask,
+                   void* ev_before, void* ev_after, const aadg_aug_lists& ls) {
+    const int n_plain = ls.n_plain, n_sharp = ls.n_sharp, n_generic = ls.n_generic, n_late = ls.n_late;
+    if (n_late < 0 || n_late > N) return AADG_E_BADARG;
+    const int npix = Hs * Ws;
+    uint32_t* hist0 = reinterpret_cast<uint32_t*>(ws8 + L.hist);
+    const size_t hist_stage = (size_t)N * HIST_STRIDE;
+    uint8_t* lut = ws8 + L.lut;
+    const size_t lut_stage_stride = (size_t)N * 768;
+    int* tab = reinterpret_cast<int*>(ws8 + L.tab);
+    bool pixel_pass = false;
+    for (int k = 1; k < max_ops; ++k) pixel_pass |= ((stats_mask >> k) & 1) && ls.n_stat[k] > 0;
+    const bool chain = n_late > 0 && max_ops > 1;
+    hipLaunchKernelGGL(k_luts_tables, dim3(3 * N), dim3(256), 0, st, ur, N, max_ops, npix, Hs, Ws, crop, ls.pool_hist, lut, tab,
+                       (pixel_pass && chain) ? hist0 : (uint32_t*)nullptr);
+    AADG_LAUNCH_CHECK();
+    if (chain)
+        for (int k = 1; k < max_ops; ++k) {
+            uint32_t* hist = hist0 + (size_t)k * hist_stage;
+            if (((stats_mask >> k) & 1) && ls.n_stat[k] > 0) {
+                const dim3 gf((Ws + 255) / 256, (Hs + 15) / 16, ls.n_stat[k]);
+                hipLaunchKernelGGL(k_hist_fused, gf, dim3(256), 0, st, pool, ur.units, ls.stat_units[k], k, Hs, Ws, crop, lut, lut_stage_stride, hist);
+                AADG_LAUNCH_CHECK();
+            }
+            hipLaunchKernelGGL(k_lut, dim3(n_late), dim3(256), 0, st, ur, k, N, ls.late_units, npix, Hs, Ws, crop, (const uint32_t*)hist0,
+                               (const uint32_t*)hist, ls.pool_hist, lut);
+            AADG_LAUNCH_CHECK();
+        }
+    if (ev_before) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_before), st));
+    if (n_plain + 2 * n_sharp > 0) {
+        const dim3 g((crop + FT_W - 1) / FT_W, (crop + FT_H - 1) / FT_H, n_plain + 2 * n_sharp);
+        hipLaunchKernelGGL(k_fused3, g, dim3(256), 0, st, pool, masks, ur.units, ls.order, ls.order + n_plain, n_plain, Hs, Ws, crop, dataset,
+                           tab, lut, lut_stage_stride, out_img, out_lbl);
+        AADG_LAUNCH_CHECK();
+    }
+    if (n_generic > 0) {
+        const dim3 gg((crop + GT_W - 1) / GT_W, (crop + GT_H - 1) / GT_H, n_generic);
+        hipLaunchKernelGGL(k_fused_generic, gg, dim3(256), 0, st, pool, masks, ur.units, ls.order + n_plain + n_sharp, Hs, Ws, crop, dataset,
+                           tab, lut, lut_stage_stride, out_img, out_lbl);
+        AADG_LAUNCH_CHECK();
+    }
+    if (ev_after) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_after), st));
+    return 0;
+}
+
+extern "C" int aadg_pool_histograms_u8(const uint8_t* pool, int P, int Hs, int Ws, uint32_t* hist, void* stream) {
+    if (pool == nullptr || hist == nullptr || P <= 0 || Hs <= 0 || Ws <= 0) return AADG_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    AADG_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)P * HIST_STRIDE * 4, st));
+    hipLaunchKernelGGL(k_pool_hist, dim3(chunks_for(Hs * Ws), P), dim3(256), 0, st, pool, (size_t)Hs * Ws * 3, Hs * Ws, hist);
+    AADG_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" size_t aadg_aug_u8_workspace_bytes(int N, int Hs, int Ws, int crop) {
     if (N <= 0 || Hs <= 0 || Ws <= 0 || crop < 0) return 0;
@@ -1604,9 +1805,13 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
     int stats_mask = stats_mask_hint < 0 ? 0xF : stats_mask_hint;
     if (stats_mask & ~1) stats_mask |= 1;      // a later stage's statistics may be pushed forward from the raw image's histogram
     int* tab = reinterpret_cast<int*>(ws8 + L.tab);
+    if (lists != nullptr && lists->pool_hist != nullptr && lists->late_units != nullptr && order != nullptr &&
+        lists->stat_units[0] != nullptr && !(classes & HINT_STAGED) && crop <= 1536)
+        return forward_cached(pool, masks, ur, N, Hs, Ws, max_ops, crop, dataset, out_img, out_lbl, ws8, L, st, classes, stats_mask,
+                              ev_before_final, ev_after_final, *lists);
     bool tables_done = false;
     int rc = run_stages(bufs, ur, N, Hs, Ws, crop, max_ops, ws8, L, nullptr, classes, stats_mask, st,
-                        (lists != nullptr && lists->stat_units[0] != nullptr) ? lists : nullptr, tab, &tables_done);
+                        (lists != nullptr && lists->stat_units[0] != nullptr) ? lists : nullptr, tab, &tables_done, lists);
     if (rc) return rc;
     if (!tables_done) {
         hipLaunchKernelGGL(k_tables, dim3(N), dim3(256), 2 * crop * sizeof(int), st, ur, Hs, Ws, crop, tab);
@@ -1624,8 +1829,8 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
             const int np = order ? n_plain : N, ns = order ? n_sharp : N;
             if (np + 2 * ns > 0) {
                 const dim3 g2(g.x, g.y, np + 2 * ns);
-                hipLaunchKernelGGL(k_fused3, g2, dim3(256), 0, st, pool, masks, units, order, np, Hs, Ws, crop, dataset, tab, ws8 + L.lut,
-                                   (size_t)N * 768, out_img, out_lbl);
+                hipLaunchKernelGGL(k_fused3, g2, dim3(256), 0, st, pool, masks, units, order, order ? order + np : nullptr, np, Hs, Ws, crop,
+                                   dataset, tab, ws8 + L.lut, (size_t)N * 768, out_img, out_lbl);
             }
             AADG_LAUNCH_CHECK();
         }

@@ -28,12 +28,28 @@ OP_AUTOCONTRAST, OP_INVERT, OP_EQUALIZE, OP_SOLARIZE, OP_POSTERIZE, OP_CONTRAST,
 
 class DevicePool(object):
     """Source images resident in HBM: images uint8 [P,H,W,3], masks uint8 [P,H,W]."""
+    cache_statistics = True      # A/B switch (bench.py --no_pool_stats)
 
     def __init__(self, images, masks):
         assert images.dtype == torch.uint8 and masks.dtype == torch.uint8
         assert images.dim() == 4 and images.shape[3] == 3 and tuple(masks.shape) == tuple(images.shape[:3])
         self.images = images.contiguous()
         self.masks = masks.contiguous()
+        self._hist = None
+
+    def histograms(self):
+        """Per-image statistics of the resident pool (_lib.pool_histograms), computed on first use: the policy ops see the raw
+        source image, so AutoContrast / Equalize / Contrast statistics are a property of the pool image, not of the batch.
+        The pool is treated as immutable; call invalidate() after writing to `images`."""
+        if not DevicePool.cache_statistics:
+            return None
+        if self._hist is None and self.images.is_cuda:
+            from .. import _lib
+            self._hist = _lib.pool_histograms(self.images)
+        return self._hist
+
+    def invalidate(self):
+        self._hist = None
 
     @property
     def size(self):  # PIL convention (w, h)

@@ -292,7 +292,9 @@ def materialize(refs, out_img=None, out_lbl=None):
     if first.norm is None:
         raise ValueError("Normalize_dg must run before collation")
     kind = _lib.DATASET_OPTIC if first.norm == 'optic' else _lib.DATASET_VESSEL
-    return _lib.aug_u8_forward(pool.images, pool.masks, refs_to_units(refs), int(crop_hw[0]), kind, out_img, out_lbl)
+    hist = pool.histograms()
+    extra = {} if hist is None else {'pool_hist': hist}
+    return _lib.aug_u8_forward(pool.images, pool.masks, refs_to_units(refs), int(crop_hw[0]), kind, out_img, out_lbl, **extra)
 
 
 def collect_refs(batch, nested):
@@ -517,7 +519,8 @@ def fast_train_collate(dataset, n_items):
     else:
         lo_s, hi_s = 0, S
     kind = _lib.DATASET_OPTIC if kind_name == 'optic' else _lib.DATASET_VESSEL
-    img, lbl = _lib.aug_u8_forward(pool.images, pool.masks, units, crop, kind)
+    hist = pool.histograms()
+    img, lbl = _lib.aug_u8_forward(pool.images, pool.masks, units, crop, kind, **({} if hist is None else {'pool_hist': hist}))
     ns = hi_s - lo_s
     dev = img.device
     return {'img_name': names, 'image': img[:ns], 'label': lbl[:ns], 'aug_images': img[ns:], 'aug_labels': lbl[ns:],

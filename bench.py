@@ -85,6 +85,8 @@ def parse():
     ap.add_argument("--all_ranks_on_gpu0", action="store_true", help="functional test of the N>1 path on a 1-GPU box")
     ap.add_argument("--dump_rewards", default=None, help="write the rewards of every timed step to this JSON file (tests)")
     ap.add_argument("--no_dropout", action="store_true", help="tests: make the step a deterministic function of the seed")
+    ap.add_argument("--no_pool_stats", action="store_true",
+                    help="do not use the per-pool-image statistics cache (DevicePool.histograms): every call histograms the raw images again")
     ap.add_argument("--shard_of", type=int, default=0,
                     help="single process: run only rank 0's row slice of a G-rank job (no collectives); used to "
                          "pre-build the MIOpen kernel cache for the per-rank shapes of --gpus G runs")
@@ -495,6 +497,9 @@ def main():
 
     import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU product path)"
+    if a.no_pool_stats:
+        from aadg_amd.data.basic import DevicePool
+        DevicePool.cache_statistics = False
     if a.all_ranks_on_gpu0:
         local_rank = 0
         if world > 1 and a.dist_backend == "nccl":
@@ -596,9 +601,15 @@ def main():
                 "what": "bytes the bracketed kernel moves (source + mask read once, %d float32 planes written once) / mean of %d "
                         "per-step HIP-event durations around exactly that kernel" % (3 + K, a.steps),
                 "stage": {"what": "SURVEY 8(d) algorithmic bytes of the whole augmentation call (source counted twice for units with a "
-                                  "statistics op) / events around ALL its kernels: k_tables, k_hist, k_hist_fused, k_lut, tile kernels",
+                                  "statistics op) / events around ALL its kernels: k_lut_tables (or k_hist_tables + k_lut), k_hist_fused, "
+                                  "k_lut, tile kernels",
                           "bytes": sbytes, "ms": call_ms, "achieved": sbytes / (call_ms * 1e-3) / 1e9,
-                          "frac": sbytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                          "frac": sbytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "frac_source_once": kbytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "pool_statistics": ("cached" if not a.no_pool_stats else "per call") +
+                                             ": the policy ops see the raw pool image, so its histogram / mean is computed once per resident "
+                                             "pool image (aadg_pool_histograms_u8, outside the timed call) instead of once per unit and call; "
+                                             "--no_pool_stats times the call with the per-unit statistics pass"}}
         if traffic:
             roof["traffic_source"] = "profiles/r02_traffic_k_fused3.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes), per unit x units"
         if prof and prof.get("k_fused3_avg_ms"):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AADG_ABI_VERSION 3
+#define AADG_ABI_VERSION 4
 #define AADG_MAX_OPS 4
 
 #define AADG_E_BADARG (-1)
@@ -106,14 +106,30 @@ int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks, int P, int
  *               shrink an axis by at most 2x; the remaining (staged) units follow in any order.
  *   stat_units  per op slot k: the n_stat[k] units whose k-th op needs image statistics (AutoContrast / Equalize / Contrast) --
  *               the work list of the histogram kernels of that stage.  stat_units[0] == NULL: no statistics lists.
+ *   pool_hist   uint32 [P][AADG_HIST_STRIDE] from aadg_pool_histograms_u8 (or NULL): the policy ops run on the RAW source image
+ *               (data/policy.py:17-23 precedes DGRandomScaleCrop), so the statistics of an op in slot 0 -- and, pushed through
+ *               the earlier byte maps, of a later slot -- are those of the POOL image, the same for every unit and every batch
+ *               that draws it.  With the pool resident for the whole run they are computed once instead of per unit and call.
+ *               The caller owns the cache: recompute after writing to the pool.
  * A unit listed under the wrong class is skipped (its outputs are not written): the lists must follow unit_flow() of
  * csrc/aug_u8.hip (aadg_amd/_lib.py: launch_hints builds them from the host copy of the unit records). */
+#define AADG_HIST_STRIDE 772    /* uint32 words per image: 3 x 256 bins, uint64 sum of L (ImageStat mean of convert('L')), pad */
 typedef struct aadg_aug_lists {
     const int32_t* order;
     int32_t n_plain, n_sharp, n_generic;
     const int32_t* stat_units[AADG_MAX_OPS];
     int32_t n_stat[AADG_MAX_OPS];
+    const uint32_t* pool_hist;
+    /* With pool_hist: the n_late units whose op in a slot k >= 1 needs a pixel pass for its statistics ("late" units: Contrast behind
+     * anything, AutoContrast / Equalize behind Color / Cutout / Sharpness).  The call then builds every other byte map, together with
+     * the tables, in its first launch and re-does only the late units' maps behind the histogram passes.
+     * late_units == NULL: stage by stage for all units. */
+    const int32_t* late_units;
+    int32_t n_late;
 } aadg_aug_lists;
+/* per-image histograms of a source pool [P, Hs, Ws, 3] (what PIL's Image.histogram() / ImageStat.Stat(convert('L')).mean read:
+ * data/basic.py AutoContrast / Equalize / Contrast via ImageOps / ImageEnhance) */
+int aadg_pool_histograms_u8(const uint8_t* pool, int P, int Hs, int Ws, uint32_t* hist, void* stream);
 int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks, int P, int Hs, int Ws,
                             const aadg_unit* units, int N, int max_ops, int crop, int dataset,
                             float* out_img, float* out_lbl, void* ws, size_t ws_bytes, void* stream,

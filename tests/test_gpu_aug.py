@@ -248,3 +248,55 @@ def test_statistics_by_pushforward_long_chains(hip, oracle):
                                    o_lbl.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream) == 0
     torch.cuda.synchronize()
     assert torch.equal(o_img, got_img) and torch.equal(o_lbl, got_lbl)
+
+
+def test_pool_histograms_are_pil_statistics(hip):
+    """aadg_pool_histograms_u8: per channel Image.histogram() and the sum behind ImageStat.Stat(convert('L')).mean, per pool image
+    (vector and scalar code paths, noise / constant images)."""
+    from helpers import synth_pool
+    for (P, H, W) in [(5, 64, 64), (3, 33, 35)]:
+        rs = np.random.RandomState(H)
+        imgs, _ = synth_pool(rs, P, H, W)
+        imgs[1] = rs.randint(0, 256, imgs[1].shape)
+        imgs[2][...] = 93
+        hist = hip.pool_histograms(torch.from_numpy(imgs).cuda()).cpu().numpy().view(np.uint32)
+        assert hist.shape == (P, hip.HIST_STRIDE)
+        for p in range(P):
+            for c in range(3):
+                assert np.array_equal(hist[p, 256 * c:256 * (c + 1)], np.bincount(imgs[p, :, :, c].reshape(-1), minlength=256))
+            r, g, b = (imgs[p, :, :, c].astype(np.int64) for c in range(3))
+            lsum = int(((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).sum())      # ImagingConvert rgb2l
+            assert int(hist[p, 768]) + (int(hist[p, 769]) << 32) == lsum
+
+
+@pytest.mark.parametrize("H,crop,sr,L", [(64, 64, (1.0, 1.5), 2), (64, 64, (1.0, 1.5), 4), (96, 64, (0.5, 2.0), 3), (72, 72, (0.36, 1.6), 4),
+                                         (33, 31, (1.0, 1.5), 3)])
+def test_pool_statistics_cache_changes_nothing(hip, oracle, H, crop, sr, L):
+    """With pool_hist (statistics of the raw pool images, computed once) the call skips its stage-0 histogram pass, builds every byte
+    map that waits for no pixel pass together with the tables and -- when the batch holds no staged unit (the first three cases) --
+    re-does only the late units' maps behind the histogram passes; results are the oracle's and bit-identical to the uncached call -- fused, generic and staged units, statistics ops in every slot, push-forward chains, noise and constant
+    images."""
+    from helpers import random_units, synth_pool
+    rs = np.random.RandomState(100 + H)
+    P, N = 6, 96
+    imgs, msks = synth_pool(rs, P, H, H)
+    imgs[1] = rs.randint(0, 256, imgs[1].shape)
+    imgs[2][...] = 93
+    units = random_units(rs, N, P, H, H, crop, sr, L=L)
+    # make sure statistics ops sit in slot 0 and behind byte maps
+    units['op'][:12, 0] = np.tile([0, 2, 5], 4); units['farg'][:12, 0] = np.float32(1.3); units['n_ops'][:12] = np.maximum(units['n_ops'][:12], 1)
+    units['op'][12:20, 0] = 1; units['op'][12:20, 1] = np.tile([0, 2], 4); units['n_ops'][12:20] = np.maximum(units['n_ops'][12:20], 2)
+    want_img, want_lbl = oracle.aug_units(imgs, msks, units, crop, 0)
+    d_img, d_msk = torch.from_numpy(imgs).cuda(), torch.from_numpy(msks).cuda()
+    plain = hip.aug_u8_forward(d_img, d_msk, units, crop, 0)
+    ph = hip.pool_histograms(d_img)
+    late = hip.launch_plan(units, H, H, crop)[5]
+    assert late.size > 0
+    cached = hip.aug_u8_forward(d_img, d_msk, units, crop, 0, pool_hist=ph)
+    assert np.array_equal(cached[0].cpu().numpy(), want_img) and np.array_equal(cached[1].cpu().numpy(), want_lbl)
+    assert torch.equal(plain[0], cached[0]) and torch.equal(plain[1], cached[1])
+    for _ in range(3):                                   # back to back on one workspace
+        again = hip.aug_u8_forward(d_img, d_msk, units[::-1].copy(), crop, 0, pool_hist=ph)
+    assert torch.equal(again[0], cached[0].flip(0)) and torch.equal(again[1], cached[1].flip(0))
+    with pytest.raises(hip.AadgError):
+        hip.aug_u8_forward(d_img, d_msk, units, crop, 0, pool_hist=ph[:2])
