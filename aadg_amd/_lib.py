@@ -44,7 +44,7 @@ EXPORTS = [
     "aadg_stem_conv7x7_supported", "aadg_stem_conv7x7_workspace_bytes", "aadg_stem_conv7x7_bf16", "aadg_stem_conv7x7_wgrad_bf16",
     "aadg_subsample2x2_supported", "aadg_subsample2x2", "aadg_subsample2x2_backward",
     "aadg_maxpool3x3s2_supported", "aadg_maxpool3x3s2_index_bytes", "aadg_maxpool3x3s2_forward", "aadg_maxpool3x3s2_backward",
-    "aadg_conv1x1_wgrad_supported", "aadg_conv1x1_wgrad_bf16",
+    "aadg_conv1x1_wgrad_supported", "aadg_conv1x1_wgrad_bf16", "aadg_conv3x3_wgrad_supported", "aadg_conv3x3_wgrad_bf16",
     "aadg_controller_supported", "aadg_controller_workspace_bytes", "aadg_controller_sample_f32",
     "aadg_controller_ppo_update_f32",
     "aadg_embed_prologue_f32", "aadg_embed_prologue_norm_f32",
@@ -169,6 +169,10 @@ def load():
     lib.aadg_conv1x1_wgrad_supported.argtypes = [_i, _i, _i]
     lib.aadg_conv1x1_wgrad_bf16.restype = _i
     lib.aadg_conv1x1_wgrad_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp]
+    lib.aadg_conv3x3_wgrad_supported.restype = _i
+    lib.aadg_conv3x3_wgrad_supported.argtypes = [_i, _i, _i, _i, _i]
+    lib.aadg_conv3x3_wgrad_bf16.restype = _i
+    lib.aadg_conv3x3_wgrad_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
     lib.aadg_controller_supported.restype = _i
     lib.aadg_controller_supported.argtypes = [_i] * 7
     lib.aadg_controller_workspace_bytes.restype = _sz
@@ -1235,6 +1239,59 @@ def conv1x1(x, weight):
     if not conv1x1_supported(x, weight):
         raise AadgError("conv1x1: unsupported shape / dtype / layout")
     return _Conv1x1.apply(x, weight)
+
+
+def conv3x3_wgrad(dy, x, dilation=1):
+    """dW [Co, Ci, 3, 3] float32 of a 3x3 / stride-1 / padding = dilation convolution from NCHW bfloat16 dy [N,Co,H,W], x [N,Ci,H,W]."""
+    lib = load()
+    _require_cuda(dy, x)
+    if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or not (dy.is_contiguous() and x.is_contiguous()):
+        raise AadgError("conv3x3_wgrad: expected contiguous NCHW bfloat16 tensors")
+    N, Co, H, W = dy.shape
+    Ci = x.shape[1]
+    if x.shape[0] != N or x.shape[2:] != dy.shape[2:]:
+        raise AadgError("conv3x3_wgrad: shape mismatch")
+    dw9 = torch.empty((9, Co, Ci), dtype=torch.float32, device=x.device)
+    rc = lib.aadg_conv3x3_wgrad_bf16(dy.data_ptr(), x.data_ptr(), dw9.data_ptr(), N, Co, Ci, H, W, int(dilation), _stream())
+    _check(rc, "aadg_conv3x3_wgrad_bf16")
+    return dw9.permute(1, 2, 0).reshape(Co, Ci, 3, 3)
+
+
+class _Conv3x3(torch.autograd.Function):
+    """3x3 / stride-1 / padding = dilation convolution without bias on NCHW bfloat16 activations: forward and input gradient are
+    the library's, the weight gradient is the MFMA kernel of csrc/conv3x3_wgrad.hip.  `weight` is the float32 master copy."""
+
+    @staticmethod
+    def forward(ctx, x, weight, dilation):
+        wq = weight.to(x.dtype)
+        ctx.save_for_backward(x, wq)
+        ctx.dilation = dilation
+        return torch.ops.aten.convolution(x, wq, None, [1, 1], [dilation, dilation], [dilation, dilation], False, [0, 0], 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wq = ctx.saved_tensors
+        d = ctx.dilation
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [1, 1], [d, d], [d, d], False, [0, 0], 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            dw = conv3x3_wgrad(dy, x, d)
+        return dx, dw, None
+
+
+def conv3x3_supported(x, weight, dilation):
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.is_contiguous() and weight.dtype == torch.float32 and
+            tuple(weight.shape[2:]) == (3, 3) and
+            bool(load().aadg_conv3x3_wgrad_supported(weight.shape[0], weight.shape[1], x.shape[2], x.shape[3], int(dilation))))
+
+
+def conv3x3(x, weight, dilation=1):
+    _require_cuda(x, weight)
+    if not conv3x3_supported(x, weight, dilation):
+        raise AadgError("conv3x3: unsupported shape / dtype / layout")
+    return _Conv3x3.apply(x, weight, int(dilation))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,229 @@
+// Weight gradient of a 3x3 / stride-1 / "same" (padding = dilation) convolution over NCHW bfloat16 activations on the matrix cores:
+//
+//     dW[o][c][kh][kw] = sum_n sum_{y,x} dY[n][o][y][x] * X[n][c][y + (kh - 1) D][x + (kw - 1) D]        (zero outside the image)
+//
+// The library path (MIOpen igemm_wrw_*_nhwc) transposes both activations to NHWC, zero-fills a float32 workspace, runs the implicit
+// GEMM with a global K split and casts the result: at 18 images per rank that is ~110-210 us per convolution for 20-45 us of
+// arithmetic.  In NCHW both operands are K-contiguous (K = the pixels of an image row) -- the fragment layout of
+// v_mfma_f32_32x32x16_bf16 -- exactly as for the 1x1 case (conv1x1_wgrad.hip); the nine taps only SHIFT the X operand:
+//
+//   vertical taps   (kh): another image row -> another slot of a ring of 2 D + 2 rows in LDS (one new row per K-step; rows outside the
+//                         image are staged as zeros)
+//   horizontal taps (kw): a shift by D elements inside the row.  One aligned 16-byte fragment read + the 4-byte words before and
+//                         behind it give all three: D = 1 funnel-shifts by one bfloat16 (4 x v_alignbit_b32), D = 2 is a shift by one
+//                         32-bit word (register renaming only).  The words beyond the row ends are zeros (the padding columns).
+//
+// One workgroup (4 waves, 2 x 2) = a 64 x 64 tile of (out, in) channels x all nine taps (9 x 16 accumulator registers per lane) and a
+// run of consecutive image rows; K-step = one image row (W = 32 / 64 / 128 pixels).  dY rows are double buffered; the next step's rows
+// are in flight (registers) during the MFMAs.  Per 16-pixel sub-step a wave issues 1 + 3 x 3 LDS reads for 9 MFMAs.
+// float32 accumulation, split-K partials combined with hardware float atomics into acc[9][Co][Ci] (tap-major: the atomics of a wave
+// are contiguous over the in-channel index).
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int W3_BM = 64, W3_BN = 64;
+
+template <int W, int D>
+struct W3Cfg {
+    static constexpr int R = 2 * D + 2;             // ring slots: rows y - D .. y + D in use, one being replaced
+    static constexpr int PA = W + 8;                // dY row pitch (elements): 2 W + 16 bytes = 4 (mod 8) words -> conflict-free b128
+    static constexpr int PX = W + 24;               // X row pitch: 8 pad | W data | 2 halo | pad; data 16-byte aligned, pitch = 4 (mod 8) words
+    static constexpr int LPT = W / 32;              // 16-byte chunks per thread and staged row set (64 rows x W / 8 chunks / 256 threads)
+    static constexpr size_t lds_bytes = ((size_t)2 * W3_BM * PA + (size_t)R * W3_BN * PX) * sizeof(uint16_t);
+};
+
+__device__ __forceinline__ bf16x8 frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    return __builtin_bit_cast(bf16x8, make_uint4(a, b, c, d));
+}
+
+template <int W, int D>
+__global__ __launch_bounds__(256, 2) void k_wgrad3x3(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, float* __restrict__ acc,
+                                                  int Co, int Ci, int H, int tiles, int tiles_n, int rows_total, int rows_per_block) {
+    using C = W3Cfg<W, D>;
+    constexpr int R = C::R, PA = C::PA, PX = C::PX, LPT = C::LPT, CPR = W / 8;       // CPR: chunks per row
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t* dYs = lds;                                  // [2][64][PA]
+    uint16_t* Xs = lds + 2 * W3_BM * PA;                  // [R][64][PX]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 1, wc = wv & 1;
+    // XCD-aware decode (as conv1x1_wgrad.hip): the tiles that stream the same rows of dY / X share an XCD's L2
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int tile = q % tiles, slice = (q / tiles) * 8 + xcd;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * W3_BM, n0 = tn * W3_BN;
+    const int g0 = slice * rows_per_block, g1 = min(rows_total, g0 + rows_per_block);
+    if (g0 >= g1) return;
+
+    // zero the pad / halo words of every X row once (data stores never touch them)
+    for (int i = tid; i < R * W3_BN; i += 256) {
+        uint16_t* row = Xs + (size_t)i * PX;
+        *reinterpret_cast<uint4*>(row) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(row + 8 + W) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(row + 16 + W) = make_uint4(0, 0, 0, 0);
+    }
+
+    // this thread's chunks of a staged 64-row set: (row, 8 pixels)
+    int srow[LPT], sc8[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int id = tid + 256 * i;
+        srow[i] = id / CPR;
+        sc8[i] = (id - srow[i] * CPR) * 8;
+    }
+    const size_t HW = (size_t)H * W;
+    auto load_dy = [&](int n, int y, uint4* st) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int m = m0 + srow[i];
+            st[i] = m < Co ? *reinterpret_cast<const uint4*>(dY + ((size_t)n * Co + m) * HW + (size_t)y * W + sc8[i]) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto load_x = [&](int n, int y, uint4* st) {             // rows outside the image: zeros
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int c = n0 + srow[i];
+            st[i] = (c < Ci && y >= 0 && y < H) ? *reinterpret_cast<const uint4*>(X + ((size_t)n * Ci + c) * HW + (size_t)y * W + sc8[i])
+                                                : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto slot_of = [&](int y) { return (y + 2 * R) % R; };
+    auto store_x = [&](int y, const uint4* st) {
+        uint16_t* base = Xs + (size_t)slot_of(y) * W3_BN * PX;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) *reinterpret_cast<uint4*>(base + srow[i] * PX + 8 + sc8[i]) = st[i];
+    };
+    auto store_dy = [&](int buf, const uint4* st) {
+        uint16_t* base = dYs + (size_t)buf * W3_BM * PA;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) *reinterpret_cast<uint4*>(base + srow[i] * PA + sc8[i]) = st[i];
+    };
+
+    f32x16 d[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[t][r] = 0.0f;
+
+    const int a_row = wr * 32 + (lane & 31), b_row = wc * 32 + (lane & 31), koff = (lane >> 5) * 8;
+    uint4 sdy[LPT], sx[LPT];
+    int buf = 0;
+    for (int g = g0; g < g1; ++g) {
+        const int n = g / H, y = g - n * H;
+        if (g == g0 || y == 0) {
+            // (re)fill the ring for this image: rows y - D .. y + D, and dY row y
+            __syncthreads();                                 // every wave is done with the previous image's rows
+            for (int r = y - D; r <= y + D; ++r) {
+                load_x(n, r, sx);
+                store_x(r, sx);
+            }
+            load_dy(n, y, sdy);
+        } else {
+            store_x(y + D, sx);                              // fetched during the previous step
+        }
+        store_dy(buf, sdy);
+        __syncthreads();
+        if (g + 1 < g1 && y + 1 < H) {                       // next step's rows: in flight during the MFMAs below
+            load_dy(n, y + 1, sdy);
+            load_x(n, y + 1 + D, sx);
+        }
+        const uint16_t* ab = dYs + (size_t)buf * W3_BM * PA + a_row * PA + koff;
+        const uint16_t* xb[3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) xb[kh] = Xs + ((size_t)slot_of(y + (kh - 1) * D) * W3_BN + b_row) * PX + 8 + koff;
+#pragma unroll
+        for (int ks = 0; ks < W / 16; ++ks) {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ab + ks * 16));
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const uint16_t* xr = xb[kh] + ks * 16;
+                const uint4 cur = *reinterpret_cast<const uint4*>(xr);
+                const uint32_t prv = *reinterpret_cast<const uint32_t*>(xr - 2), nxt = *reinterpret_cast<const uint32_t*>(xr + 8);
+                bf16x8 f0, f2;
+                if (D == 1) {
+                    const uint32_t s1 = __builtin_amdgcn_alignbit(cur.y, cur.x, 16), s2 = __builtin_amdgcn_alignbit(cur.z, cur.y, 16),
+                                   s3 = __builtin_amdgcn_alignbit(cur.w, cur.z, 16);
+                    f0 = frag(__builtin_amdgcn_alignbit(cur.x, prv, 16), s1, s2, s3);          // X[p - 1]
+                    f2 = frag(s1, s2, s3, __builtin_amdgcn_alignbit(nxt, cur.w, 16));          // X[p + 1]
+                } else {
+                    f0 = frag(prv, cur.x, cur.y, cur.z);                                       // X[p - 2]
+                    f2 = frag(cur.y, cur.z, cur.w, nxt);                                       // X[p + 2]
+                }
+                d[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, f0, d[kh * 3 + 0], 0, 0, 0);
+                d[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, cur), d[kh * 3 + 1], 0, 0, 0);
+                d[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, f2, d[kh * 3 + 2], 0, 0, 0);
+            }
+        }
+        buf ^= 1;
+    }
+    // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int nn = n0 + wc * 32 + (lane & 31);
+    if (nn < Ci) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float* at = acc + (size_t)t * Co * Ci;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < Co) unsafeAtomicAdd(at + (size_t)m * Ci + nn, d[t][r]);
+            }
+        }
+    }
+}
+
+template <int W, int D>
+int launch(const uint16_t* dY, const uint16_t* X, float* acc, int N, int Co, int Ci, int H, hipStream_t st) {
+    using C = W3Cfg<W, D>;
+    const int tiles_m = (Co + W3_BM - 1) / W3_BM, tiles_n = (Ci + W3_BN - 1) / W3_BN, tiles = tiles_m * tiles_n;
+    const long long rows_total = (long long)N * H;
+    // Every workgroup ends with 9 x 64 x 64 float atomics (the cost of ~1000 MFMAs), so: ~512 workgroups (two per CU), and never fewer
+    // than 1152 MFMAs per wave (18 images per rank: 1.93 -> 1.20 ms over the backbone's 14 convolutions; 144 images: 5.5 -> 5.1)
+    const long long target = 512, min_mfma = 1152;
+    long long slices = (target + tiles - 1) / tiles;
+    long long rpb = (rows_total + slices - 1) / slices;
+    const long long min_rows = (min_mfma + (W / 16) * 9 - 1) / ((W / 16) * 9);
+    if (rpb < min_rows) rpb = min_rows;
+    slices = (rows_total + rpb - 1) / rpb;
+    static bool attr_set = false;                            // per instantiation; idempotent
+    if (!attr_set) {
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3<W, D>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)C::lds_bytes));
+        attr_set = true;
+    }
+    AADG_HIP_TRY(hipMemsetAsync(acc, 0, (size_t)9 * Co * Ci * sizeof(float), st));
+    const long long slice_groups = (slices + 7) / 8;          // slices are padded to a multiple of 8 (empty ones exit at once)
+    hipLaunchKernelGGL((k_wgrad3x3<W, D>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(256), C::lds_bytes, st, dY, X, acc, Co, Ci, H,
+                       tiles, tiles_n, (int)rows_total, (int)rpb);
+    AADG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int aadg_conv3x3_wgrad_supported(int Co, int Ci, int H, int W, int dilation) {
+    return Co > 0 && Ci > 0 && H > 0 && (W == 32 || W == 64 || W == 128) && (dilation == 1 || dilation == 2) ? 1 : 0;
+}
+
+// dweight9: float32 [9][Co][Ci] (tap kh * 3 + kw major); the caller permutes it into [Co][Ci][3][3]
+extern "C" int aadg_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dweight9, int N, int Co, int Ci, int H, int W, int dilation,
+                                       void* stream) {
+    if (dy == nullptr || x == nullptr || dweight9 == nullptr || N <= 0) return AADG_E_BADARG;
+    if ((((uintptr_t)dy | (uintptr_t)x) & 15u) != 0) return AADG_E_BADARG;
+    if (!aadg_conv3x3_wgrad_supported(Co, Ci, H, W, dilation) || (long long)N * H > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const uint16_t* a = (const uint16_t*)dy;
+    const uint16_t* b = (const uint16_t*)x;
+    if (dilation == 1) {
+        if (W == 32) return launch<32, 1>(a, b, dweight9, N, Co, Ci, H, st);
+        if (W == 64) return launch<64, 1>(a, b, dweight9, N, Co, Ci, H, st);
+        return launch<128, 1>(a, b, dweight9, N, Co, Ci, H, st);
+    }
+    if (W == 32) return launch<32, 2>(a, b, dweight9, N, Co, Ci, H, st);
+    if (W == 64) return launch<64, 2>(a, b, dweight9, N, Co, Ci, H, st);
+    return launch<128, 2>(a, b, dweight9, N, Co, Ci, H, st);
+}

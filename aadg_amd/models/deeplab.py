@@ -27,6 +27,8 @@ def _upsample_ac(x, size):
 
 _ACT_CODE = {None: 0, 'relu': 1, 'relu6': 2}
 _BN_SYNC = False
+# A/B switch: AADG_LIB_CONV3X3=1 keeps the library's weight gradient for the bottleneck 3x3 convolutions
+_OWN_CONV3X3_OFF = __import__('os').environ.get('AADG_LIB_CONV3X3') == '1'
 
 
 def set_bn_sync(flag):
@@ -119,6 +121,23 @@ class Conv1x1(nn.Conv2d):
         return super().forward(x)
 
 
+class Conv3x3(nn.Conv2d):
+    """The bottleneck's dense 3x3 convolution (padding = dilation, no bias).  bfloat16 activations on the GPU at stride 1: forward /
+    input gradient stay the library's implicit GEMM, the weight gradient runs on the matrix cores straight from the NCHW tensors
+    (csrc/conv3x3_wgrad.hip: no NHWC transposes of both activations, no zero-fill / cast of a float32 workspace)."""
+
+    def __init__(self, cin, cout, stride=1, dilation=1):
+        super().__init__(cin, cout, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.bfloat16 and self.stride == (1, 1) and not _OWN_CONV3X3_OFF:
+            from .. import _lib
+            xc = x.contiguous()
+            if _lib.conv3x3_supported(xc, self.weight, self.dilation[0]):
+                return _lib.conv3x3(xc, self.weight, self.dilation[0])
+        return super().forward(x)
+
+
 class StemConv7x7(nn.Conv2d):
     """The ResNet stem Conv2d(3, 64, 7, stride 2, padding 3).  Under bfloat16 autocast on the GPU the forward is the MFMA
     kernel of csrc/stem_conv.hip (straight from NCHW: the library surrounds its NHWC implicit GEMM with three layout
@@ -186,7 +205,7 @@ class Bottleneck(nn.Module):
         super().__init__()
         self.conv1 = Conv1x1(cin, planes)
         self.bn1 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.conv2 = Conv3x3(planes, planes, stride, dilation)
         self.bn2 = nn.BatchNorm2d(planes)
         self.conv3 = Conv1x1(planes, planes * 4)
         self.bn3 = nn.BatchNorm2d(planes * 4)

@@ -354,6 +354,14 @@ int aadg_maxpool3x3s2_backward(const void* index, const void* dy, void* dx, int 
 int aadg_conv1x1_wgrad_supported(int Co, int Ci, int HW);
 int aadg_conv1x1_wgrad_bf16(const void* dy, const void* x, float* dweight, int N, int Co, int Ci, int HW, void* stream);
 
+/* Weight gradient of a 3x3 / stride-1 convolution with padding = dilation (the bottleneck conv2 of the ResNet stages), NCHW bfloat16:
+ *     dweight9[kh * 3 + kw][o][c] = sum_{n, y, x} dy[n][o][y][x] * x[n][c][y + (kh - 1) d][x + (kw - 1) d]     (zero outside the image)
+ * dy [N, Co, H, W], x [N, Ci, H, W], dweight9 float32 [9, Co, Ci] (tap-major; permute(1, 2, 0) gives torch's [Co, Ci, 3, 3]).
+ * W in {32, 64, 128}, d in {1, 2}.  Replaces MIOpen's NHWC igemm_wrw + its transposes, zero-fill and cast (csrc/conv3x3_wgrad.hip). */
+int aadg_conv3x3_wgrad_supported(int Co, int Ci, int H, int W, int dilation);
+int aadg_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dweight9, int N, int Co, int Ci, int H, int W, int dilation,
+                            void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Policy controller (reference: models/controller.py:9-145) and its PPO update (losses.py:117-157) as fused kernels.
  * `params`: 9 device pointers in the module's parameter order -- embedding.weight [n_ops + n_mags, E],

@@ -20,9 +20,12 @@ for Ci, Co, S in cases:
         return torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
     def ours():
         return _lib.conv1x1_wgrad(dy, x)
-    a = miopen().float().view(Co, Ci); b = ours()
-    err = (a - b).abs().max().item() / max(1e-6, a.abs().max().item())
-    t0, t1 = bench(miopen), bench(ours)
+    if os.environ.get("SKIP_LIB"):
+        err, t0, t1 = 0.0, 0.0, bench(ours, 20)
+    else:
+        a = miopen().float().view(Co, Ci); b = ours()
+        err = (a - b).abs().max().item() / max(1e-6, a.abs().max().item())
+        t0, t1 = bench(miopen), bench(ours)
     tot[0] += t0; tot[1] += t1
     gb = (x.numel() + dy.numel()) * 2 / 1e9
     print("Ci=%4d Co=%4d %3dx%-3d miopen %.3f ms | mfma %.3f ms (%.0f GB/s, %.0f TFLOP/s) | rel diff %.1e" %

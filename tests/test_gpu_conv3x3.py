@@ -1,0 +1,63 @@
+"""GPU: the MFMA weight gradient of the bottleneck 3x3 convolutions (csrc/conv3x3_wgrad.hip) against the float32 convolution
+backward of the same bfloat16 tensors, and the Conv3x3 module against nn.Conv2d."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_wgrad(dy, x, w_shape, d):
+    w = torch.zeros(w_shape, device=x.device, dtype=torch.float32)
+    return torch.ops.aten.convolution_backward(dy.float(), x.float(), w, None, [1, 1], [d, d], [d, d], False, [0, 0], 1,
+                                               [False, True, False])[1]
+
+
+@pytest.mark.parametrize("N,Co,Ci,H,W,d", [
+    (2, 64, 64, 32, 32, 1), (3, 64, 64, 32, 32, 2),        # layer3 / layer4 row width, both dilations
+    (2, 128, 64, 64, 64, 1), (1, 64, 128, 64, 64, 2),      # several tiles along either channel axis
+    (2, 64, 64, 128, 128, 1),                              # layer1 row width
+    (5, 96, 40, 20, 32, 1), (4, 40, 96, 7, 64, 2),         # channel counts that are not multiples of the tile, odd heights, H < 2 D + 2
+    (37, 64, 64, 32, 32, 1),                               # long reduction: several images per workgroup, slices that start mid-image
+])
+def test_wgrad_matches_float32_backward(hip, N, Co, Ci, H, W, d):
+    torch.manual_seed(N * 1000 + Co + H)
+    x = torch.randn(N, Ci, H, W, device="cuda").to(torch.bfloat16)
+    dy = torch.randn(N, Co, H, W, device="cuda").to(torch.bfloat16)
+    assert hip.load().aadg_conv3x3_wgrad_supported(Co, Ci, H, W, d) == 1
+    got = hip.conv3x3_wgrad(dy, x, d)
+    want = _ref_wgrad(dy, x, (Co, Ci, 3, 3), d)
+    assert got.shape == want.shape and got.dtype == torch.float32
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 2e-4 * scale, ((got - want).abs().max().item(), scale)
+
+
+def test_wgrad_rejects_what_it_does_not_cover(hip):
+    lib = hip.load()
+    assert lib.aadg_conv3x3_wgrad_supported(64, 64, 32, 48, 1) == 0 and lib.aadg_conv3x3_wgrad_supported(64, 64, 32, 32, 3) == 0
+    x = torch.randn(1, 8, 16, 48, device="cuda").to(torch.bfloat16)
+    with pytest.raises(hip.AadgError):
+        hip.conv3x3_wgrad(x, x, 1)
+
+
+@pytest.mark.parametrize("d", [1, 2])
+def test_module_equals_conv2d(hip, d):
+    """Conv3x3 (forward / input gradient: library; weight gradient: own kernel) against nn.Conv2d under bfloat16 autocast."""
+    from aadg_amd.models.deeplab import Conv3x3
+    torch.manual_seed(3)
+    ours = Conv3x3(64, 64, 1, d).cuda()
+    ref = torch.nn.Conv2d(64, 64, 3, padding=d, dilation=d, bias=False).cuda()
+    ref.load_state_dict(ours.state_dict())
+    x1 = torch.randn(4, 64, 32, 32, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    g = torch.randn(4, 64, 32, 32, device="cuda").to(torch.bfloat16)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y1, y2 = ours(x1), ref(x2)
+    assert torch.equal(y1, y2)
+    y1.backward(g); y2.backward(g)
+    assert torch.equal(x1.grad, x2.grad)
+    gw, rw = ours.weight.grad, ref.weight.grad
+    assert gw.dtype == torch.float32 and gw.shape == rw.shape
+    # the library rounds its weight gradient to bfloat16 before the float32 master copy sees it; ours stays float32
+    assert (gw - rw).abs().max().item() <= 1e-2 * rw.abs().max().item()
+    want = _ref_wgrad(g, x1.detach(), tuple(gw.shape), d)
+    assert (gw - want).abs().max().item() <= 2e-4 * want.abs().max().item()
