@@ -45,6 +45,7 @@ EXPORTS = [
     "aadg_subsample2x2_supported", "aadg_subsample2x2", "aadg_subsample2x2_backward",
     "aadg_maxpool3x3s2_supported", "aadg_maxpool3x3s2_index_bytes", "aadg_maxpool3x3s2_forward", "aadg_maxpool3x3s2_backward",
     "aadg_conv1x1_wgrad_supported", "aadg_conv1x1_wgrad_bf16", "aadg_conv3x3_wgrad_supported", "aadg_conv3x3_wgrad_bf16",
+    "aadg_conv3x3_nchw_supported", "aadg_conv3x3_nchw_bf16",
     "aadg_controller_supported", "aadg_controller_workspace_bytes", "aadg_controller_sample_f32",
     "aadg_controller_ppo_update_f32",
     "aadg_embed_prologue_f32", "aadg_embed_prologue_norm_f32",
@@ -173,6 +174,10 @@ def load():
     lib.aadg_conv3x3_wgrad_supported.argtypes = [_i, _i, _i, _i, _i]
     lib.aadg_conv3x3_wgrad_bf16.restype = _i
     lib.aadg_conv3x3_wgrad_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
+    lib.aadg_conv3x3_nchw_supported.restype = _i
+    lib.aadg_conv3x3_nchw_supported.argtypes = [_i, _i, _i, _i, _i]
+    lib.aadg_conv3x3_nchw_bf16.restype = _i
+    lib.aadg_conv3x3_nchw_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
     lib.aadg_controller_supported.restype = _i
     lib.aadg_controller_supported.argtypes = [_i] * 7
     lib.aadg_controller_workspace_bytes.restype = _sz
@@ -1257,6 +1262,33 @@ def conv3x3_wgrad(dy, x, dilation=1):
     return dw9.permute(1, 2, 0).reshape(Co, Ci, 3, 3)
 
 
+def conv3x3_nchw(a9, x, dilation=1):
+    """out [N, M, H, W] bfloat16 = 3x3 convolution (stride 1, padding = dilation) of x [N, K, H, W] with tap-major weights a9 [9, M, K]."""
+    lib = load()
+    _require_cuda(a9, x)
+    if a9.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or not (a9.is_contiguous() and x.is_contiguous()) or a9.dim() != 3:
+        raise AadgError("conv3x3_nchw: expected contiguous bfloat16 a9 [9,M,K] and NCHW x")
+    N, K, H, W = x.shape
+    M = a9.shape[1]
+    if a9.shape[0] != 9 or a9.shape[2] != K:
+        raise AadgError("conv3x3_nchw: shape mismatch")
+    out = torch.empty((N, M, H, W), dtype=torch.bfloat16, device=x.device)
+    rc = lib.aadg_conv3x3_nchw_bf16(a9.data_ptr(), x.data_ptr(), out.data_ptr(), N, M, K, H, W, int(dilation), _stream())
+    _check(rc, "aadg_conv3x3_nchw_bf16")
+    return out
+
+
+# images per call up to which the own forward / input-gradient kernel replaces the library's (None: always); the weight gradient
+# kernel is used at every batch size
+CONV3X3_OWN_FWD_MAX_N = None
+
+
+def _own_conv3x3_fwd(x, M, K, dilation):
+    if CONV3X3_OWN_FWD_MAX_N is not None and x.shape[0] > CONV3X3_OWN_FWD_MAX_N:
+        return False
+    return bool(load().aadg_conv3x3_nchw_supported(M, K, x.shape[2], x.shape[3], int(dilation)))
+
+
 class _Conv3x3(torch.autograd.Function):
     """3x3 / stride-1 / padding = dilation convolution without bias on NCHW bfloat16 activations: forward and input gradient are
     the library's, the weight gradient is the MFMA kernel of csrc/conv3x3_wgrad.hip.  `weight` is the float32 master copy."""
@@ -1266,6 +1298,9 @@ class _Conv3x3(torch.autograd.Function):
         wq = weight.to(x.dtype)
         ctx.save_for_backward(x, wq)
         ctx.dilation = dilation
+        Co, Ci = wq.shape[0], wq.shape[1]
+        if _own_conv3x3_fwd(x, Co, Ci, dilation):
+            return conv3x3_nchw(wq.permute(2, 3, 0, 1).reshape(9, Co, Ci).contiguous(), x, dilation)
         return torch.ops.aten.convolution(x, wq, None, [1, 1], [dilation, dilation], [dilation, dilation], False, [0, 0], 1)
 
     @staticmethod
@@ -1275,7 +1310,13 @@ class _Conv3x3(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [1, 1], [d, d], [d, d], False, [0, 0], 1, [True, False, False])[0]
+            Co, Ci = wq.shape[0], wq.shape[1]
+            if _own_conv3x3_fwd(dy, Ci, Co, d):
+                # the same kernel on dy with the taps mirrored and the channel roles swapped
+                dx = conv3x3_nchw(wq.flip(2, 3).permute(2, 3, 1, 0).reshape(9, Ci, Co).contiguous(), dy, d)
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [1, 1], [d, d], [d, d], False, [0, 0], 1,
+                                                         [True, False, False])[0]
         if ctx.needs_input_grad[1]:
             dw = conv3x3_wgrad(dy, x, d)
         return dx, dw, None

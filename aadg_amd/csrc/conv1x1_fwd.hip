@@ -106,6 +106,10 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
                 hi[ni] = lds_read_tr16(b_base + (16 * ks + 4) * CF_BPITCH + 32 * ni);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // the transpose reads are opaque to the compiler's wait-count bookkeeping: pin their results behind the wait (volatile asm
+            // statements keep their order), or the scheduler may move an MFMA that uses them above it
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(lo[ni]), "+v"(hi[ni]));
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) b[ni] = __builtin_bit_cast(bf16x8, make_uint4(lo[ni].x, lo[ni].y, hi[ni].x, hi[ni].y));
 #pragma unroll

@@ -1,0 +1,237 @@
+// 3x3 / stride-1 / padding = dilation convolution over NCHW bfloat16 activations as an implicit GEMM on the matrix cores, without a
+// layout change of the activations:
+//
+//     OUT[n][m][y][x] = sum_k sum_{kh,kw} A9[kh * 3 + kw][m][k] * IN[n][k][y + (kh - 1) D][x + (kw - 1) D]      (zero outside the image)
+//
+// forward: A9 = the weight, tap-major ([9][Co][Ci], a 9 x Co x Ci copy made by the caller); input gradient: the same kernel on dY
+// with A9[t][c][m] = W[m][c][2 - kh][2 - kw].  The library path (MIOpen igemm_*_nhwc) transposes IN to NHWC and OUT back, and at
+// small batches runs a K-split variant behind a zero-fill and in front of a cast: 125-240 us per convolution and direction at 18
+// images per rank for 20-45 us of arithmetic.
+//
+// As in conv1x1_fwd.hip the K-strided operand (NCHW: channels are H*W apart) is read with gfx950's LDS transpose read: rows of IN go
+// to LDS as they lie in memory ([k][pixel]) and ds_read_b64_tr_b16 hands every lane 4 consecutive k of ITS pixel.  The nine taps:
+//   vertical   (kh): the staged region of a channel is (ROWS + 2 D) whole image rows, contiguous -- a tap row is an offset of D * W
+//                    pixels in it (a multiple of 8 bytes: aligned);
+//   horizontal (kw): a shift by D pixels = 2 or 4 bytes, which a transpose read (8-byte aligned blocks) cannot address.  The staging
+//                    step therefore writes THREE copies of every 8-pixel chunk: as loaded, and shifted by -D / +D pixels with the
+//                    pixels of the neighbouring chunks funnelled in through lane shuffles and zeros at the row ends (the padding
+//                    columns).  All fragment reads are then aligned and branch-free.
+// Workgroup = 4 waves = 64 x 256 tile (BM out channels x 256 pixels = 4 or 8 whole image rows of one image, 64 pixels per wave);
+// K-step = 16 input channels = one MFMA K; the next step's global loads are in flight (registers) during the 36 MFMAs per wave.
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int C3_BK = 16;                 // input channels per K-step
+constexpr int C3_APITCH = C3_BK + 8;      // A rows: 48 bytes (conflict-free 16-byte fragment reads)
+constexpr int C3_PIX = 256;               // pixels per workgroup tile
+
+__device__ __forceinline__ u32x2 lds_tr16(const uint16_t* p) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
+    return v;
+}
+
+template <int W, int D, int MI>
+struct C3Cfg {
+    static constexpr int BM = 32 * MI;                              // MI 32-row tiles per wave; the four waves share the m range
+    static constexpr int ROWS = C3_PIX / W;                         // image rows per tile
+    static constexpr int SPX = (ROWS + 2 * D) * W;                  // staged pixels per channel
+    static constexpr int BP = ((SPX + 127) / 128) * 128 + 16;       // pitch: 32 bytes (mod 256): the 4 rows of a transpose read hit distinct banks
+    static constexpr int A_EL = 9 * 32 * MI * C3_APITCH, B_EL = 3 * C3_BK * BP;
+    static constexpr size_t lds_bytes = (size_t)(A_EL + B_EL) * sizeof(uint16_t);
+};
+
+template <int W, int D, int MI>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_nchw(const uint16_t* __restrict__ A9, const uint16_t* __restrict__ IN,
+                                                         uint16_t* __restrict__ OUT, int M, int K, int H, int tiles_m, int tiles_r, int pts) {
+    using C = C3Cfg<W, D, MI>;
+    constexpr int BM = 32 * MI, ROWS = C::ROWS, BP = C::BP, NI = 2, CPR = W / 8, SR = ROWS + 2 * D;
+    constexpr int NA = 9 * BM * 2, LA = (NA + 255) / 256;            // 16-byte chunks of the A tile (9 taps x BM rows x 2) per K-step
+    constexpr int NB = C3_BK * SR * CPR, LB = (NB + 255) / 256;      // ... of the IN tile
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t* As = lds;                    // [9][BM][C3_APITCH]
+    uint16_t* Bs = lds + C::A_EL;          // [3 copies][16][BP]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // XCD-aware decode: the out-channel tiles of one pixel tile run on one XCD and share the IN tile through its L2
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int tm = q % tiles_m, pt = (q / tiles_m) * 8 + xcd;
+    if (pt >= pts) return;                                // the pixel tiles are padded to a multiple of 8
+    const int n = pt / tiles_r, tr = pt - n * tiles_r;
+    const int m0 = tm * BM, y0 = tr * ROWS;
+    const size_t HW = (size_t)H * W;
+    const uint16_t* inn = IN + (size_t)n * K * HW;
+    uint16_t* outn = OUT + (size_t)n * M * HW;
+
+    uint4 ra[LA], rb[LB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int id = tid + 256 * i;
+            ra[i] = make_uint4(0, 0, 0, 0);
+            if (id < NA) {
+                const int t = id / (BM * 2), r = id - t * (BM * 2), m = m0 + (r >> 1), k = k0 + (r & 1) * 8;
+                if (m < M && k < K) ra[i] = *reinterpret_cast<const uint4*>(A9 + ((size_t)t * M + m) * K + k);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int id = tid + 256 * i;
+            rb[i] = make_uint4(0, 0, 0, 0);
+            if (id < NB) {
+                const int cc = id / (SR * CPR), r2 = id - cc * (SR * CPR), rr = r2 / CPR, ch = r2 - rr * CPR;
+                const int k = k0 + cc, yy = y0 - D + rr;
+                if (k < K && yy >= 0 && yy < H) rb[i] = *reinterpret_cast<const uint4*>(inn + ((size_t)k * H + yy) * W + ch * 8);
+            }
+        }
+    };
+
+    f32x16 d[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[mi][ni][r] = 0.0f;
+
+    const int g = lane >> 5, i16 = lane & 15, gi = (lane >> 4) & 1;
+    const uint16_t* a_base = As + (lane & 31) * C3_APITCH + 8 * g;
+    // transpose-read address of this lane: row (8 g + i16 / 4) of the K-step, pixel 64 wv + 16 gi + 4 (i16 % 4) of the tile (+ 32 ni)
+    const uint16_t* b_base = Bs + (8 * g + (i16 >> 2)) * BP + wv * 64 + 16 * gi + 4 * (i16 & 3);
+
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += C3_BK) {
+        __syncthreads();                                  // the previous step's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int id = tid + 256 * i;
+            if (id < NA) *reinterpret_cast<uint4*>(As + (id >> 1) * C3_APITCH + (id & 1) * 8) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int id = tid + 256 * i;
+            // neighbouring chunks of the image row sit in the neighbouring lanes (CPR divides 64): the pixel(s) shifted in
+            const uint4 v = rb[i];
+            uint32_t left = __shfl_up(v.w, 1, 64), right = __shfl_down(v.x, 1, 64);
+            if (id < NB) {
+                const int cc = id / (SR * CPR), r2 = id - cc * (SR * CPR), ch = r2 % CPR;
+                if (ch == 0) left = 0u;                    // the padding columns
+                if (ch == CPR - 1) right = 0u;
+                uint16_t* dst = Bs + cc * BP + r2 * 8;
+                uint4 vm, vp;                              // vm[p] = IN[p - D], vp[p] = IN[p + D]
+                if (D == 1) {
+                    const uint32_t s1 = __builtin_amdgcn_alignbit(v.y, v.x, 16), s2 = __builtin_amdgcn_alignbit(v.z, v.y, 16),
+                                   s3 = __builtin_amdgcn_alignbit(v.w, v.z, 16);
+                    vm = make_uint4(__builtin_amdgcn_alignbit(v.x, left, 16), s1, s2, s3);
+                    vp = make_uint4(s1, s2, s3, __builtin_amdgcn_alignbit(right, v.w, 16));
+                } else {
+                    vm = make_uint4(left, v.x, v.y, v.z);
+                    vp = make_uint4(v.y, v.z, v.w, right);
+                }
+                *reinterpret_cast<uint4*>(dst) = vm;                               // copy 0: tap kw = 0
+                *reinterpret_cast<uint4*>(dst + C3_BK * BP) = v;                   // copy 1: kw = 1
+                *reinterpret_cast<uint4*>(dst + 2 * C3_BK * BP) = vp;              // copy 2: kw = 2
+            }
+        }
+        __syncthreads();
+        if (k0 + C3_BK < K) fetch(k0 + C3_BK);            // in flight during the MFMAs below
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            bf16x8 a[3][MI];
+            u32x2 lo[3][NI], hi[3][NI];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    a[kw][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a_base + ((kh * 3 + kw) * BM + 32 * mi) * C3_APITCH));
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const uint16_t* p = b_base + kw * C3_BK * BP + kh * D * W + 32 * ni;
+                    lo[kw][ni] = lds_tr16(p);
+                    hi[kw][ni] = lds_tr16(p + 4 * BP);
+                }
+            }
+            // the transpose reads are opaque to the compiler's wait-count bookkeeping; tying their results to the wait keeps the
+            // scheduler from moving an MFMA that uses them above it (it did: the second pixel tile of every wave came out wrong)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(lo[0][0]), "+v"(lo[0][1]), "+v"(lo[1][0]), "+v"(lo[1][1]), "+v"(lo[2][0]), "+v"(lo[2][1]), "+v"(hi[0][0]),
+                           "+v"(hi[0][1]), "+v"(hi[1][0]), "+v"(hi[1][1]), "+v"(hi[2][0]), "+v"(hi[2][1])
+                         :
+                         : "memory");
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, make_uint4(lo[kw][ni].x, lo[kw][ni].y, hi[kw][ni].x, hi[kw][ni].y));
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kw][mi], b, d[mi][ni], 0, 0, 0);
+                }
+        }
+    }
+    // C/D layout: column (pixel) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); lanes p / p + 1 trade
+    // registers r / r + 1 so that each stores two adjacent pixels of one channel row (4-byte stores)
+    const int jj = lane & 31;
+    const bool odd = jj & 1;
+    const size_t p_tile = (size_t)y0 * W + wv * 64;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float mine0 = d[mi][ni][r], mine1 = d[mi][ni][r + 1];
+                const float give = odd ? mine0 : mine1;
+                const float got = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give), 0xB1, 0xF, 0xF, true));
+                const float lo2 = odd ? got : mine0, hi2 = odd ? mine1 : got;
+                const int rsel = r + (odd ? 1 : 0);
+                const int m = m0 + 32 * mi + (rsel & 3) + 8 * (rsel >> 2) + 4 * g;
+                const size_t p = p_tile + 32 * ni + (jj & ~1);
+                if (m < M && p < HW) *reinterpret_cast<uint32_t*>(outn + (size_t)m * HW + p) = aadg_f2bf_pk(lo2, hi2);
+            }
+}
+
+template <int W, int D, int MI>
+int launch(const uint16_t* A9, const uint16_t* IN, uint16_t* OUT, int N, int M, int K, int H, hipStream_t st) {
+    using C = C3Cfg<W, D, MI>;
+    constexpr int BM = 32 * MI;
+    const int tiles_m = (M + BM - 1) / BM, tiles_r = (H + C::ROWS - 1) / C::ROWS;
+    const long long pts = (long long)N * tiles_r, groups = (pts + 7) / 8;
+    const long long wgs = groups * 8 * tiles_m;
+    if (wgs > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
+    static bool attr_set = false;                            // per instantiation; idempotent
+    if (!attr_set) {
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_nchw<W, D, MI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)C::lds_bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_conv3x3_nchw<W, D, MI>), dim3((unsigned)wgs), dim3(256), C::lds_bytes, st, A9, IN, OUT, M, K, H, tiles_m, tiles_r, (int)pts);
+    AADG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int aadg_conv3x3_nchw_supported(int M, int K, int H, int W, int dilation) {
+    return M > 0 && K > 0 && (K % 8) == 0 && H > 0 && (W == 32 || W == 64) && (dilation == 1 || dilation == 2) ? 1 : 0;
+}
+
+/* out [N, M, H, W] = conv3x3(in [N, K, H, W]; a9 [9, M, K] tap-major), stride 1, padding = dilation; all bfloat16, float32
+ * accumulation */
+extern "C" int aadg_conv3x3_nchw_bf16(const void* a9, const void* in, void* out, int N, int M, int K, int H, int W, int dilation,
+                                      void* stream) {
+    if (a9 == nullptr || in == nullptr || out == nullptr || N <= 0) return AADG_E_BADARG;
+    if ((((uintptr_t)a9 | (uintptr_t)in | (uintptr_t)out) & 15u) != 0) return AADG_E_BADARG;
+    if (!aadg_conv3x3_nchw_supported(M, K, H, W, dilation)) return AADG_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const uint16_t* pa = (const uint16_t*)a9;
+    const uint16_t* pi = (const uint16_t*)in;
+    uint16_t* po = (uint16_t*)out;
+    if (dilation == 1) return W == 32 ? launch<32, 1, 2>(pa, pi, po, N, M, K, H, st) : launch<64, 1, 2>(pa, pi, po, N, M, K, H, st);
+    return W == 32 ? launch<32, 2, 2>(pa, pi, po, N, M, K, H, st) : launch<64, 2, 2>(pa, pi, po, N, M, K, H, st);
+}

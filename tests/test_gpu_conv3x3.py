@@ -41,7 +41,7 @@ def test_wgrad_rejects_what_it_does_not_cover(hip):
 
 @pytest.mark.parametrize("d", [1, 2])
 def test_module_equals_conv2d(hip, d):
-    """Conv3x3 (forward / input gradient: library; weight gradient: own kernel) against nn.Conv2d under bfloat16 autocast."""
+    """Conv3x3 (own forward, input gradient and weight gradient kernels) against nn.Conv2d (the library) under bfloat16 autocast."""
     from aadg_amd.models.deeplab import Conv3x3
     torch.manual_seed(3)
     ours = Conv3x3(64, 64, 1, d).cuda()
@@ -52,12 +52,56 @@ def test_module_equals_conv2d(hip, d):
     g = torch.randn(4, 64, 32, 32, device="cuda").to(torch.bfloat16)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y1, y2 = ours(x1), ref(x2)
-    assert torch.equal(y1, y2)
+    # yardstick: float32 convolution of the same bfloat16 tensors (the library may run a Winograd variant here: looser)
+    wb = ours.weight.detach().to(torch.bfloat16).float()
+    xr = x1.detach().float().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wb, padding=d, dilation=d)
+    yr.backward(g.float())
+    tol, loose = 2.0 ** -8, 2.0 ** -5
+    assert (y1.float() - yr).abs().max().item() <= tol * yr.abs().max().item()
+    assert (y2.float() - yr).abs().max().item() <= loose * yr.abs().max().item()
     y1.backward(g); y2.backward(g)
-    assert torch.equal(x1.grad, x2.grad)
+    assert (x1.grad.float() - xr.grad).abs().max().item() <= tol * xr.grad.abs().max().item()
+    assert (x2.grad.float() - xr.grad).abs().max().item() <= loose * xr.grad.abs().max().item()
     gw, rw = ours.weight.grad, ref.weight.grad
     assert gw.dtype == torch.float32 and gw.shape == rw.shape
     # the library rounds its weight gradient to bfloat16 before the float32 master copy sees it; ours stays float32
     assert (gw - rw).abs().max().item() <= 1e-2 * rw.abs().max().item()
     want = _ref_wgrad(g, x1.detach(), tuple(gw.shape), d)
     assert (gw - want).abs().max().item() <= 2e-4 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("N,M,K,H,W,d", [
+    (2, 64, 64, 32, 32, 1), (2, 64, 64, 32, 32, 2), (1, 128, 64, 64, 64, 1), (1, 64, 128, 64, 64, 2),
+    (3, 96, 40, 20, 32, 1), (2, 40, 24, 7, 64, 2), (9, 64, 16, 32, 32, 1),       # ragged channels / heights, more pixel tiles than a multiple of 8
+])
+def test_forward_kernel_matches_float32_convolution(hip, N, M, K, H, W, d):
+    torch.manual_seed(M + K + H)
+    x = torch.randn(N, K, H, W, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(M, K, 3, 3, device="cuda") / (3.0 * K ** 0.5)).to(torch.bfloat16)
+    assert hip.load().aadg_conv3x3_nchw_supported(M, K, H, W, d) == 1
+    got = hip.conv3x3_nchw(w.permute(2, 3, 0, 1).reshape(9, M, K).contiguous(), x, d)
+    want = torch.nn.functional.conv2d(x.float(), w.float(), padding=d, dilation=d)
+    assert got.dtype == torch.bfloat16 and got.shape == want.shape
+    # float32 accumulation, one rounding to bfloat16 at the end
+    assert (got.float() - want).abs().max().item() <= 2.0 ** -8 * want.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("d,W", [(1, 32), (2, 32), (1, 64)])
+def test_autograd_function_all_three_kernels(hip, d, W):
+    """_Conv3x3 with the own forward, input gradient (the same kernel on dy with mirrored taps) and weight gradient against float32
+    autograd of the same bfloat16 tensors."""
+    torch.manual_seed(7)
+    Co, Ci, N, H = 64, 128, 3, 32
+    x = torch.randn(N, Ci, H, W, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(Co, Ci, 3, 3, device="cuda") / (3.0 * Ci ** 0.5)).requires_grad_(True)
+    g = torch.randn(N, Co, H, W, device="cuda").to(torch.bfloat16)
+    y = hip.conv3x3(x, w, d)
+    y.backward(g)
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, padding=d, dilation=d)
+    yr.backward(g.float())
+    assert (y.float() - yr).abs().max().item() <= 2.0 ** -8 * yr.abs().max().item()
+    assert (x.grad.float() - xr.grad).abs().max().item() <= 2.0 ** -8 * xr.grad.abs().max().item()
+    assert (w.grad - wr.grad).abs().max().item() <= 2e-4 * wr.grad.abs().max().item()
