@@ -218,7 +218,7 @@ int launch(const uint16_t* A9, const uint16_t* IN, uint16_t* OUT, int N, int M, 
 }  // namespace
 
 extern "C" int aadg_conv3x3_nchw_supported(int M, int K, int H, int W, int dilation) {
-    return M > 0 && K > 0 && (K % 8) == 0 && H > 0 && (W == 32 || W == 64) && (dilation == 1 || dilation == 2) ? 1 : 0;
+    return M > 0 && K > 0 && (K % 8) == 0 && H > 0 && (W == 32 || W == 64 || W == 128) && (dilation == 1 || dilation == 2) ? 1 : 0;
 }
 
 /* out [N, M, H, W] = conv3x3(in [N, K, H, W]; a9 [9, M, K] tap-major), stride 1, padding = dilation; all bfloat16, float32
@@ -232,6 +232,13 @@ extern "C" int aadg_conv3x3_nchw_bf16(const void* a9, const void* in, void* out,
     const uint16_t* pa = (const uint16_t*)a9;
     const uint16_t* pi = (const uint16_t*)in;
     uint16_t* po = (uint16_t*)out;
-    if (dilation == 1) return W == 32 ? launch<32, 1, 2>(pa, pi, po, N, M, K, H, st) : launch<64, 1, 2>(pa, pi, po, N, M, K, H, st);
-    return W == 32 ? launch<32, 2, 2>(pa, pi, po, N, M, K, H, st) : launch<64, 2, 2>(pa, pi, po, N, M, K, H, st);
+    // (a 128-channel tile, MI = 4, halves the weight-fragment reads per MFMA but needs 94 KB of LDS = one workgroup per CU: 10-25 % slower)
+    if (dilation == 1) {
+        if (W == 32) return launch<32, 1, 2>(pa, pi, po, N, M, K, H, st);
+        if (W == 64) return launch<64, 1, 2>(pa, pi, po, N, M, K, H, st);
+        return launch<128, 1, 2>(pa, pi, po, N, M, K, H, st);
+    }
+    if (W == 32) return launch<32, 2, 2>(pa, pi, po, N, M, K, H, st);
+    if (W == 64) return launch<64, 2, 2>(pa, pi, po, N, M, K, H, st);
+    return launch<128, 2, 2>(pa, pi, po, N, M, K, H, st);
 }

@@ -125,7 +125,7 @@ class Conv3x3(nn.Conv2d):
     """The bottleneck's dense 3x3 convolution (padding = dilation, no bias).  bfloat16 activations on the GPU at stride 1: forward,
     input gradient (csrc/conv3x3_fwd.hip: LDS transpose reads, three column-shifted copies of the staged rows) and weight gradient
     (csrc/conv3x3_wgrad.hip) run on the matrix cores straight from the NCHW tensors -- no NHWC transposes around an implicit GEMM, no
-    zero-fill / cast of a float32 workspace.  Stride 2 (the first block of stages 2 and 3) and 128-pixel rows stay the library's."""
+    zero-fill / cast of a float32 workspace.  Stride 2 (the first block of stages 2 and 3) stays the library's."""
 
     def __init__(self, cin, cout, stride=1, dilation=1):
         super().__init__(cin, cout, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)

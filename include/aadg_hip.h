@@ -362,7 +362,7 @@ int aadg_conv3x3_wgrad_supported(int Co, int Ci, int H, int W, int dilation);
 /* The convolution itself and its input gradient, NCHW bfloat16 in and out, float32 accumulation (csrc/conv3x3_fwd.hip):
  *     out[n][m][y][x] = sum_{k, kh, kw} a9[kh * 3 + kw][m][k] * in[n][k][y + (kh - 1) d][x + (kw - 1) d]
  * forward: a9[t][o][c] = weight[o][c][kh][kw]; input gradient: in = dy, a9[t][c][o] = weight[o][c][2 - kh][2 - kw].
- * a9 [9, M, K] bfloat16; K a multiple of 8; W in {32, 64}, d in {1, 2}. */
+ * a9 [9, M, K] bfloat16; K a multiple of 8; W in {32, 64, 128}, d in {1, 2}. */
 int aadg_conv3x3_nchw_supported(int M, int K, int H, int W, int dilation);
 int aadg_conv3x3_nchw_bf16(const void* a9, const void* in, void* out, int N, int M, int K, int H, int W, int dilation, void* stream);
 int aadg_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dweight9, int N, int Co, int Ci, int H, int W, int dilation,

@@ -11,7 +11,7 @@ def bench(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-cases = [(128, 64, 1, 3), (256, 32, 1, 5), (512, 32, 2, 3)]       # (channels, size, dilation, count in the backbone)
+cases = [(64, 128, 1, 3), (128, 64, 1, 3), (256, 32, 1, 5), (512, 32, 2, 3)]       # (channels, size, dilation, count in the backbone)
 tot = [0.0, 0.0, 0.0]
 for C, S, d, cnt in cases:
     x = torch.randn(N, C, S, S, device="cuda", dtype=torch.bfloat16)

@@ -73,6 +73,7 @@ def test_module_equals_conv2d(hip, d):
 
 @pytest.mark.parametrize("N,M,K,H,W,d", [
     (2, 64, 64, 32, 32, 1), (2, 64, 64, 32, 32, 2), (1, 128, 64, 64, 64, 1), (1, 64, 128, 64, 64, 2),
+    (2, 64, 64, 128, 128, 1), (1, 32, 64, 10, 128, 2),                             # layer1 row width
     (3, 96, 40, 20, 32, 1), (2, 40, 24, 7, 64, 2), (9, 64, 16, 32, 32, 1),       # ragged channels / heights, more pixel tiles than a multiple of 8
 ])
 def test_forward_kernel_matches_float32_convolution(hip, N, M, K, H, W, d):
