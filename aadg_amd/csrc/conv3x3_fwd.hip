@@ -232,7 +232,10 @@ extern "C" int aadg_conv3x3_nchw_bf16(const void* a9, const void* in, void* out,
     const uint16_t* pa = (const uint16_t*)a9;
     const uint16_t* pi = (const uint16_t*)in;
     uint16_t* po = (uint16_t*)out;
-    // (a 128-channel tile, MI = 4, halves the weight-fragment reads per MFMA but needs 94 KB of LDS = one workgroup per CU: 10-25 % slower)
+    // Measured, not kept: a 128-channel tile (MI = 4) halves the weight-fragment reads per MFMA but needs 94 KB of LDS = one workgroup per CU:
+    // 10-25 % slower.  Ablations (results wrong, timing only): a third of the weight-fragment reads, or a third of the transpose reads: no
+    // change -- LDS read bandwidth is not the limit; skipping the per-step staging of the weight tile (stores): 15-18 % faster -- the serial
+    // load -> store -> barrier section between two 36-MFMA bursts is.
     if (dilation == 1) {
         if (W == 32) return launch<32, 1, 2>(pa, pi, po, N, M, K, H, st);
         if (W == 64) return launch<64, 1, 2>(pa, pi, po, N, M, K, H, st);
