@@ -230,3 +230,43 @@ def test_fast_draw_equals_object_path():
     # a non-standard pipeline is refused (the loader then takes the object path)
     ds.transforms.transforms[0] = T.Identity()
     assert T.fast_train_units(ds, 2) is None
+
+
+def test_launch_plan_classes_statistics_and_late_units():
+    """aadg_amd._lib.launch_plan mirrors unit_flow() / stats_by_pushforward() of csrc/aug_u8.hip on the host: hand-built unit records,
+    one per rule (class by scale and Sharpness count; which slots need a pixel pass; which units are 'late')."""
+    from aadg_amd import _lib
+    H = W = crop = 64
+    def unit(ops, sw=64, sh=64):
+        u = np.zeros(1, _lib.UNIT_DTYPE)
+        u['rect'][:, :, 2:] = -1
+        u['n_ops'] = len(ops)
+        for k, (op, f) in enumerate(ops):
+            u['op'][0, k] = op
+            u['farg'][0, k] = np.float32(f)
+        u['scaled_w'], u['scaled_h'] = sw, sh
+        return u
+    AC, INV, EQ, SOL, POS, CON, COL, BRI, SHA, CUT = range(10)
+    units = np.concatenate([
+        unit([]),                                   # 0 plain, no statistics
+        unit([(AC, 0)]),                            # 1 slot-0 statistics only: raw histogram, not late
+        unit([(INV, 0), (EQ, 0)]),                  # 2 push-forward at slot 1: raw histogram, not late
+        unit([(COL, 1.3), (AC, 0)]),                # 3 Color breaks the byte-map chain: pixel pass at slot 1 -> late
+        unit([(INV, 0), (CON, 1.2)]),               # 4 Contrast needs the mean of L of the image after Invert: pixel pass -> late
+        unit([(SHA, 1.5), (BRI, 1.2)]),             # 5 Sharpness stencil: the 'sharp' tile class, no statistics
+        unit([(SHA, 1.0)]),                         # 6 Sharpness with factor 1 is the identity: plain class
+        unit([(BRI, 1.1)], sw=40, sh=70),           # 7 shrinks x by < 2: generic class
+        unit([(AC, 0), (SHA, 1.2), (EQ, 0)], 20, 64),   # 8 shrinks by > 2: staged; staged units never push forward
+        unit([(SHA, 1.2), (SHA, 1.3), (SHA, 1.4)]),     # 9 three stencils: staged
+    ])
+    classes, stats_mask, order, counts, stat_lists, late = _lib.launch_plan(units, H, W, crop)
+    assert classes == 1 | 2 | 4
+    assert counts == (6, 1, 1)
+    assert sorted(order[:6].tolist()) == [0, 1, 2, 3, 4, 6] and order[6] == 5 and order[7] == 7 and sorted(order[8:].tolist()) == [8, 9]
+    assert stat_lists[0].tolist() == [1, 2, 8]                 # raw histograms: slot-0 statistics and push-forward sources
+    assert stat_lists[1].tolist() == [3, 4] and stat_lists[2].tolist() == [8] and stat_lists[3].size == 0
+    assert stats_mask == 0b111
+    assert late.tolist() == [3, 4, 8]
+    assert _lib.launch_hints(units, H, W, crop)[3] == counts
+    # sizes that are not multiples of 4: everything is staged
+    assert _lib.launch_plan(units, 63, 63, 61)[0] == 2
