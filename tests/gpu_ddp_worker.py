@@ -64,7 +64,11 @@ def main():
         o2, f2 = ddp(x[lo:hi])
     rel = lambda a, b: ((a.float().cpu() - b.float().cpu()).norm() / b.float().cpu().norm()).item()      # noqa: E731
     if dtype == 'fp32':
-        assert rel(o2, o[lo:hi]) < 1e-4 and rel(f2, f[lo:hi]) < 1e-4, (rel(o2, o[lo:hi]), rel(f2, f[lo:hi]))
+        # the library may pick other float32 solvers for the smaller per-rank batch (atomics, Winograd): 1e-3, and no further from
+        # the float64 run than the single process is
+        assert rel(o2, o[lo:hi]) < 1e-3 and rel(f2, f[lo:hi]) < 1e-3, (rel(o2, o[lo:hi]), rel(f2, f[lo:hi]))
+        e1, e2 = rel(o, o64), rel(o2, o64[lo:hi])
+        assert e2 <= max(1.5 * e1, 1e-3), (e1, e2)
     else:
         # bfloat16: 50 BatchNorm layers re-round every activation and a run differs from ITSELF by 10-40 % on this tiny batch
         # (tests/test_gpu_backbone_e2e.py), so the yardstick is again the float64 run: no further from it than one process is
@@ -75,7 +79,7 @@ def main():
     checked = 0
     for (n, b), (_, br) in zip(model.named_buffers(), ref.named_buffers()):
         if b.dtype.is_floating_point and (dtype == 'fp32' or checked < 2):      # bfloat16: only the first layer sees equal inputs
-            assert torch.allclose(b, br, rtol=1e-2 if dtype == 'bf16' else 1e-4, atol=1e-3 if dtype == 'bf16' else 1e-4), n
+            assert torch.allclose(b, br, rtol=1e-2 if dtype == 'bf16' else 1e-3, atol=1e-3 if dtype == 'bf16' else 3e-4), n
             checked += 1
     e_ddp = ((flat_grads(model) - g64).norm() / g64.norm()).item()
     every = [None] * world
@@ -87,7 +91,7 @@ def main():
               % (" / ".join("%.3e" % e for e in single_errs), world, e_ddp), flush=True)
     # the single-process error itself varies from process to process (atomics order, 7e-4 ... 6e-3 measured in float32): the bound
     # is the worst of them with a floor; a wrong weighting or missing synchronisation is an O(0.1 - 1) error
-    floor = 0.3 if dtype == 'bf16' else 2e-2
+    floor = 0.3 if dtype == 'bf16' else 5e-2
     assert e_ddp <= max(1.5 * max(single_errs), floor), (e_ddp, single_errs)
     dist.destroy_process_group()
 
