@@ -236,7 +236,8 @@ extern "C" int aadg_conv3x3_nchw_bf16(const void* a9, const void* in, void* out,
     // 10-25 % slower.  Ablations (results wrong, timing only): a third of the weight-fragment reads, or a third of the transpose reads: no
     // change -- LDS read bandwidth is not the limit; skipping the per-step staging of the weight tile (stores): 15-18 % faster -- the serial
     // load -> store -> barrier section between two 36-MFMA bursts is.  A 32-channel tile (MI = 1, 52 KB, three workgroups per CU) to
-    // interleave more of those sections: 10-40 % slower (half the MFMAs per staged IN chunk).
+    // interleave more of those sections: 10-40 % slower (half the MFMAs per staged IN chunk).  A 512-pixel tile (8 waves, one workgroup per
+    // CU, weight tile amortised over twice the pixels, less halo): +-5 %.
     if (dilation == 1) {
         if (W == 32) return launch<32, 1, 2>(pa, pi, po, N, M, K, H, st);
         if (W == 64) return launch<64, 1, 2>(pa, pi, po, N, M, K, H, st);
