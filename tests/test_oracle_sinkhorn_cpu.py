@@ -2,6 +2,7 @@
 and the reference ships no test for them ("parity unpinned"), so the restatement is pinned
 by analytic known answers and by its float64 master."""
 import numpy as np
+import pytest
 
 
 def _feat(rs, n, E=128):
@@ -77,3 +78,21 @@ def test_bce_and_dice_oracle_vs_torch(oracle):
     assert oracle.dice(ones, np.ones_like(ones))[0] == 1.0
     assert oracle.dice(ones, np.zeros_like(ones))[0] == 0.0
     assert oracle.dice(-ones, np.zeros_like(ones))[0] == 0.0
+
+
+def test_dice_oracle_vs_scikit_learn_f1(oracle):
+    """torchmetrics 0.4.1 (`F1(num_classes=2, average=None, mdmc_average='samplewise')[1]`, search_dg.py:112) is not in the image;
+    scikit-learn is: the oracle's Dice is the mean over samples of the F1 score of the foreground class, with torchmetrics'
+    zero-division convention (0 when a sample has neither predicted nor true foreground)."""
+    f1_score = pytest.importorskip("sklearn.metrics").f1_score
+    rs = np.random.RandomState(11)
+    N, K, H = 10, 2, 12
+    z = rs.randn(N, K, H, H).astype(np.float32) * 2
+    y = (rs.rand(N, K, H, H) > 0.7).astype(np.float32)
+    z[3] = -5.0; y[3] = 0.0                                 # a sample without any foreground, predicted or true
+    y[4] = 0.0                                              # predicted foreground, no true foreground
+    dice = oracle.dice(z, y)
+    for k in range(K):
+        per = [f1_score((y[n, k] > 0).reshape(-1).astype(int), (z[n, k] > 0).reshape(-1).astype(int), pos_label=1, zero_division=0)
+               for n in range(N)]
+        assert abs(dice[k] - float(np.mean(per))) < 1e-9
