@@ -96,3 +96,33 @@ def test_dice_oracle_vs_scikit_learn_f1(oracle):
         per = [f1_score((y[n, k] > 0).reshape(-1).astype(int), (z[n, k] > 0).reshape(-1).astype(int), pos_label=1, zero_division=0)
                for n in range(N)]
         assert abs(dice[k] - float(np.mean(per))) < 1e-9
+
+
+def test_sinkhorn_oracle_approximates_the_converged_entropic_divergence(oracle):
+    """geomloss is not in the image, so the oracle restates its epsilon-scaling loop.  Independent yardstick: the debiased Sinkhorn
+    divergence S_eps = OT_eps(x, y) - OT_eps(x, x) / 2 - OT_eps(y, y) / 2 at eps = blur^2 with the SAME cost (1 - cosine) and uniform
+    weights, from a plain log-domain Sinkhorn iteration run to convergence (float64 numpy + scipy.logsumexp).  geomloss reaches
+    eps = blur^2 through ~8 annealing steps (scaling 0.5) and stops, so it approximates that fixed point: within 1 %."""
+    logsumexp = pytest.importorskip("scipy.special").logsumexp
+
+    def cost(x, y):
+        xn, yn = x / np.linalg.norm(x, axis=1, keepdims=True), y / np.linalg.norm(y, axis=1, keepdims=True)
+        return 1.0 - xn @ yn.T
+
+    def ot_eps(C, eps, iters=4000):
+        n, m = C.shape
+        f, g = np.zeros(n), np.zeros(m)
+        for _ in range(iters):
+            f = -eps * logsumexp(-np.log(m) + (g[None, :] - C) / eps, axis=1)
+            g = -eps * logsumexp(-np.log(n) + (f[:, None] - C) / eps, axis=0)
+        return f.mean() + g.mean()
+
+    rs = np.random.RandomState(0)
+    eps = 0.05 ** 2
+    for n, m in ((8, 8), (5, 13), (24, 24)):
+        x = (np.maximum(rs.randn(n, 128), 0.2 * rs.randn(n, 128)) + 0.3).astype(np.float32)       # LeakyReLU-like embeddings
+        y = np.maximum(rs.randn(m, 128) + 0.5, 0.2 * rs.randn(m, 128)).astype(np.float32)
+        got = oracle.sinkhorn_divergence(x, y, f64=True)
+        xd, yd = x.astype(np.float64), y.astype(np.float64)
+        want = ot_eps(cost(xd, yd), eps) - 0.5 * ot_eps(cost(xd, xd), eps) - 0.5 * ot_eps(cost(yd, yd), eps)
+        assert abs(got - want) < 1e-2 * abs(want), (n, m, got, want)
