@@ -1210,7 +1210,7 @@ class _Conv1x1(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight):
-        wq = weight.to(x.dtype)
+        wq = cast_weight(weight, x.dtype)
         ctx.save_for_backward(x, wq)
         Co, Ci = wq.shape[0], wq.shape[1]
         if _own_gemm_1x1(Co, Ci, x.shape[2] * x.shape[3]):
@@ -1244,6 +1244,45 @@ def conv1x1(x, weight):
     if not conv1x1_supported(x, weight):
         raise AadgError("conv1x1: unsupported shape / dtype / layout")
     return _Conv1x1.apply(x, weight)
+
+
+# ------------------------------------------------------------------------------------------------
+# bfloat16 shadows of the float32 master weights of the own convolution modules.  Every `weight.to(bfloat16)` is a 5 us launch
+# (66 of them per step); a model registered with `track_bf16_weights` refreshes all shadows that changed since the last forward
+# in ONE multi-tensor copy (a forward pre-hook), and the autograd functions below pick the shadow up through `cast_weight`.
+_SHADOWS = {}          # id(weight) -> [weakref(weight), bfloat16 copy, version of the weight the copy was made from]
+
+
+def cast_weight(weight, dtype):
+    e = _SHADOWS.get(id(weight))
+    if e is not None and dtype == torch.bfloat16 and e[2] == weight._version and e[0]() is weight:
+        return e[1]
+    return weight.to(dtype)
+
+
+def refresh_bf16_weights(weights):
+    import weakref
+    src, dst = [], []
+    for w in weights:
+        e = _SHADOWS.get(id(w))
+        if e is None or e[0]() is not w or e[1].device != w.device or e[1].shape != w.shape:
+            e = [weakref.ref(w), torch.empty_like(w, dtype=torch.bfloat16), -1]
+            _SHADOWS[id(w)] = e
+        if e[2] != w._version:
+            src.append(w.detach())
+            dst.append(e[1])
+            e[2] = w._version
+    if src:
+        with torch.no_grad():
+            torch._foreach_copy_(dst, src)
+
+
+def track_bf16_weights(model, module_types):
+    """Registers the float32 weights of `model`'s modules of the given types for batched bfloat16 casts (CUDA models only)."""
+    weights = [m.weight for m in model.modules() if isinstance(m, module_types) and m.weight.dtype == torch.float32 and m.weight.is_cuda]
+    if weights:
+        model.register_forward_pre_hook(lambda mod, args: refresh_bf16_weights(weights))
+    return len(weights)
 
 
 def conv3x3_wgrad(dy, x, dilation=1):
@@ -1295,7 +1334,7 @@ class _Conv3x3(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, dilation):
-        wq = weight.to(x.dtype)
+        wq = cast_weight(weight, x.dtype)
         ctx.save_for_backward(x, wq)
         ctx.dilation = dilation
         Co, Ci = wq.shape[0], wq.shape[1]

@@ -69,6 +69,9 @@ def load_ddp_model(ngpus_per_node, args, cfg):
     print("=> creating model '{}' with '{}".format(cfg.MODEL.NAME, cfg.MODEL.BACKBONE))
     dev = _device(args)
     model = build_model(cfg).to(dev)
+    if dev.type == 'cuda':
+        from . import deeplab
+        deeplab.batch_step_bookkeeping(model)            # weight casts and BatchNorm counters: two launches per forward
     sync = bool(getattr(args, 'distributed', False) and getattr(args, 'sync_bn', False))
     if sync:
         # The reference's single-GPU batch mixes all domains in every BatchNorm batch; sharded replicas see only their rows.

@@ -31,6 +31,39 @@ _BN_SYNC = False
 _OWN_CONV3X3_OFF = __import__('os').environ.get('AADG_LIB_CONV3X3') == '1'
 
 
+# BatchNorm's `num_batches_tracked += 1` is one 5 us launch per layer and forward (62 of them); the layers of a model registered
+# with `batch_step_bookkeeping` hand their counters to a list during the forward and one multi-tensor add bumps them afterwards.
+_PENDING_BN_COUNTERS = []
+
+
+def _bump(bn):
+    if getattr(bn, '_aadg_deferred_counter', False):
+        _PENDING_BN_COUNTERS.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked.add_(1)
+
+
+def batch_step_bookkeeping(model):
+    """Per-forward bookkeeping of a CUDA model in two launches instead of ~130: the bfloat16 casts of the own convolutions' master
+    weights (a pre-hook: _lib.track_bf16_weights) and the BatchNorm counters of its layers (a post-hook)."""
+    from .. import _lib
+    _lib.track_bf16_weights(model, (Conv1x1, Conv3x3))
+    for m in model.modules():
+        if type(m) is nn.BatchNorm2d:
+            m._aadg_deferred_counter = True
+
+    def before(mod, args):
+        del _PENDING_BN_COUNTERS[:]
+
+    def after(mod, args, out):
+        if _PENDING_BN_COUNTERS:
+            torch._foreach_add_(_PENDING_BN_COUNTERS, 1)
+            del _PENDING_BN_COUNTERS[:]
+
+    model.register_forward_pre_hook(before)
+    model.register_forward_hook(after)
+
+
 def set_bn_sync(flag):
     """Data-parallel ranks: training-mode BatchNorm statistics are all-reduced over the process group between the HIP
     statistics and normalisation kernels (_lib._SyncBatchNormAct) -- the modules stay nn.BatchNorm2d."""
@@ -48,7 +81,7 @@ def bn_act(bn, x, act=None, residual=None, handles=1, out=None):
         rc = residual.contiguous() if residual is not None else None
         if _lib.bn_act_supported(xc, rc):
             if bn.training:
-                bn.num_batches_tracked.add_(1)
+                _bump(bn)
             # out (training only): a slice of a concatenation buffer (_lib.concat_slices) that receives the result
             return _lib.batch_norm_act(xc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum,
                                        bn.eps, _ACT_CODE[act], rc,
@@ -279,7 +312,7 @@ class ResNet50Encoder(nn.Module):
             from .. import _lib
             yc = y.contiguous()
             if _lib.bn_relu_maxpool_supported(yc):
-                bn.num_batches_tracked.add_(1)
+                _bump(bn)
                 return _lib.bn_relu_maxpool(yc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
         return self.pool(bna(y))
 

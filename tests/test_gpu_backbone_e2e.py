@@ -11,8 +11,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-SWITCHES = ["bn_act_supported", "dwconv3x3_supported", "conv1x1_supported", "maxpool3x3s2_supported", "subsample2x2_supported",
-            "stem_conv7x7_supported", "bn_relu_maxpool_supported"]
+SWITCHES = ["bn_act_supported", "dwconv3x3_supported", "conv1x1_supported", "conv3x3_supported", "maxpool3x3s2_supported",
+            "subsample2x2_supported", "stem_conv7x7_supported", "bn_relu_maxpool_supported"]
 
 
 def _run(model, state, x, y, autocast):
@@ -74,3 +74,35 @@ def test_hip_layers_match_library_layers_in_situ(hip, encoder, monkeypatch):
     for k in range(3):
         e_ours, e_lib = _rel(ours16[k], lib32[k]), _rel(lib16[k], lib32[k])
         assert e_ours <= 1.3 * e_lib + 0.02, (k, e_ours, e_lib)
+
+
+def test_batched_step_bookkeeping(hip):
+    """deeplab.batch_step_bookkeeping: the BatchNorm counters of a registered model advance by one per training forward (one
+    multi-tensor add after the forward instead of one launch per layer), and the bfloat16 shadows of the convolution weights follow
+    the float32 masters (one multi-tensor copy before the forward).  (Outputs are not compared: this random bfloat16 network on a
+    tiny batch differs from ITSELF from run to run, see the module docstring.)"""
+    from aadg_amd.models import deeplab
+    torch.manual_seed(3)
+    b = deeplab.DeepLabV3Plus("resnet50", 2).cuda().train()
+    deeplab.batch_step_bookkeeping(b)
+    convs = [m for m in b.modules() if isinstance(m, (deeplab.Conv1x1, deeplab.Conv3x3))]
+    bns = [m for m in b.modules() if type(m) is torch.nn.BatchNorm2d]
+    assert len(convs) > 40 and len(bns) > 40
+    x = torch.randn(4, 3, 64, 64, device="cuda")
+    for step in range(2):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out, feat = b(x)
+        assert torch.isfinite(out.float()).all()
+        for m in convs:                                    # the shadow IS what the forward used, and it is the rounded master
+            sh = hip.cast_weight(m.weight, torch.bfloat16)
+            assert sh.data_ptr() != m.weight.data_ptr() and torch.equal(sh, m.weight.detach().to(torch.bfloat16))
+        with torch.no_grad():                              # an "optimizer step": stale until the next forward refreshes them
+            for p in b.parameters():
+                p.mul_(0.9)
+        w = convs[0].weight
+        assert torch.equal(hip.cast_weight(w, torch.bfloat16), w.detach().to(torch.bfloat16))      # version changed: falls back to a cast
+    assert all(m.num_batches_tracked.item() == 2 for m in bns)
+    b.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        b(x)
+    assert all(m.num_batches_tracked.item() == 2 for m in bns)                                      # eval: no bump
