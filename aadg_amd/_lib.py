@@ -49,6 +49,7 @@ EXPORTS = [
     "aadg_controller_supported", "aadg_controller_workspace_bytes", "aadg_controller_sample_f32",
     "aadg_controller_ppo_update_f32",
     "aadg_embed_prologue_f32", "aadg_embed_prologue_norm_f32",
+    "aadg_upsample_sum_backward_all_supported", "aadg_upsample_sum_backward_all",
     "aadg_upsample_sum", "aadg_upsample_sum_backward",
 ]
 
@@ -192,6 +193,10 @@ def load():
     lib.aadg_upsample_sum.argtypes = [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]
     lib.aadg_upsample_sum_backward.restype = _i
     lib.aadg_upsample_sum_backward.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
+    lib.aadg_upsample_sum_backward_all_supported.restype = _i
+    lib.aadg_upsample_sum_backward_all_supported.argtypes = [_i, _i, _vp, _vp, _i]
+    lib.aadg_upsample_sum_backward_all.restype = _i
+    lib.aadg_upsample_sum_backward_all.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.aadg_embed_prologue_norm_f32.restype = _i
     lib.aadg_embed_prologue_norm_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]
     if lib.aadg_abi_version() != 4:
@@ -655,6 +660,16 @@ class _UpsampleSum(torch.autograd.Function):
         lib = load()
         g = g.contiguous()
         H, W = ctx.out_hw
+        grads = [torch.empty(shp, dtype=g.dtype, device=g.device) for shp in ctx.low_shapes]
+        n = len(grads)
+        hs = (ctypes.c_int * max(n, 1))(*[shp[2] for shp in ctx.low_shapes])
+        ws_ = (ctypes.c_int * max(n, 1))(*[shp[3] for shp in ctx.low_shapes])
+        if n and lib.aadg_upsample_sum_backward_all_supported(H, W, hs, ws_, n):
+            # all levels in one pass over g (the per-level kernel reads the whole gradient once per level)
+            ptrs = (ctypes.c_void_p * n)(*[d.data_ptr() for d in grads])
+            _check(lib.aadg_upsample_sum_backward_all(g.data_ptr(), ptrs, hs, ws_, n, g.shape[0] * g.shape[1], H, W, _BN_DTYPES[g.dtype],
+                                                      _stream()), "aadg_upsample_sum_backward_all")
+            return (g,) + tuple(grads)
         grads = []
         for shp in ctx.low_shapes:
             d = torch.empty(shp, dtype=g.dtype, device=g.device)

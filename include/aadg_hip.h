@@ -422,6 +422,11 @@ int aadg_embed_prologue_norm_f32(const float* x, int ldx, int N, int C, const fl
 int aadg_upsample_sum(const void* full, const void* const* lows, const int* low_h, const int* low_w, int n_low, void* out,
                       int planes, int H, int W, int dtype, void* stream);
 int aadg_upsample_sum_backward(const void* dout, void* dlow, int planes, int h, int w, int H, int W, int dtype, void* stream);
+/* every dlow_i in ONE pass over dout (one workgroup per plane, the plane resident in LDS, separable transposed interpolation):
+ * H * W <= 128 * 128, H, W <= 256 */
+int aadg_upsample_sum_backward_all_supported(int H, int W, const int* low_h, const int* low_w, int n_low);
+int aadg_upsample_sum_backward_all(const void* dout, void* const* dlows, const int* low_h, const int* low_w, int n_low, int planes,
+                                   int H, int W, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -109,10 +109,11 @@ def test_search_step_segformer_8_domains(hip):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 5, 32, 32), (1, 3, 24, 40), (2, 4, 16, 8)])
+@pytest.mark.parametrize("shape", [(2, 5, 32, 32), (1, 3, 24, 40), (2, 4, 16, 8), (1, 3, 128, 128), (1, 2, 160, 136)])
 def test_upsample_sum_matches_interpolate(hip, dtype, shape):
     """aadg_upsample_sum / aadg_upsample_sum_backward vs full + sum F.interpolate(low_i, bilinear, align_corners=False),
-    forward and all four gradients (factors 2, 4, 8 and a non-integer one)."""
+    forward and all four gradients (factors 2, 4, 8 and a non-integer one).  Planes of up to 128 x 128 take the one-pass backward
+    (aadg_upsample_sum_backward_all: plane resident in LDS, all levels), the last shape the per-level kernel."""
     torch.manual_seed(sum(shape))
     N, C, H, W = shape
     full = torch.randn(shape, device="cuda").to(dtype).requires_grad_(True)
