@@ -36,16 +36,20 @@ class DevicePool(object):
         self.images = images.contiguous()
         self.masks = masks.contiguous()
         self._hist = None
+        self._hist_version = -1
 
     def histograms(self):
         """Per-image statistics of the resident pool (_lib.pool_histograms), computed on first use: the policy ops see the raw
         source image, so AutoContrast / Equalize / Contrast statistics are a property of the pool image, not of the batch.
-        The pool is treated as immutable; call invalidate() after writing to `images`."""
+        Recomputed when `images` was written to in place (tensor version counter); invalidate() forces it."""
         if not DevicePool.cache_statistics:
             return None
-        if self._hist is None and self.images.is_cuda:
+        if not self.images.is_cuda:
+            return None
+        if self._hist is None or self._hist_version != self.images._version:      # in-place writes to the pool bump its version
             from .. import _lib
             self._hist = _lib.pool_histograms(self.images)
+            self._hist_version = self.images._version
         return self._hist
 
     def invalidate(self):

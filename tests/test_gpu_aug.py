@@ -300,3 +300,19 @@ def test_pool_statistics_cache_changes_nothing(hip, oracle, H, crop, sr, L):
     assert torch.equal(again[0], cached[0].flip(0)) and torch.equal(again[1], cached[1].flip(0))
     with pytest.raises(hip.AadgError):
         hip.aug_u8_forward(d_img, d_msk, units, crop, 0, pool_hist=ph[:2])
+
+
+def test_device_pool_statistics_follow_in_place_writes(hip):
+    """DevicePool.histograms() is computed once per resident pool and recomputed after an in-place write to the images."""
+    from helpers import synth_pool
+    from aadg_amd.data.basic import DevicePool
+    rs = np.random.RandomState(9)
+    imgs, msks = synth_pool(rs, 3, 32, 32)
+    pool = DevicePool(torch.from_numpy(imgs).cuda(), torch.from_numpy(msks).cuda())
+    h0 = pool.histograms()
+    assert pool.histograms() is h0                                        # cached
+    pool.images[1].fill_(7)
+    h1 = pool.histograms()
+    assert h1 is not h0 and int(h1[1, 7]) == 32 * 32 and int(h1[1, 256 + 7]) == 32 * 32 and torch.equal(h1[0], h0[0])
+    cpu = DevicePool(torch.from_numpy(imgs), torch.from_numpy(msks))
+    assert cpu.histograms() is None                                       # CPU pools (tests): the statistics passes run per call
