@@ -45,7 +45,7 @@ EXPORTS = [
     "aadg_subsample2x2_supported", "aadg_subsample2x2", "aadg_subsample2x2_backward",
     "aadg_maxpool3x3s2_supported", "aadg_maxpool3x3s2_index_bytes", "aadg_maxpool3x3s2_forward", "aadg_maxpool3x3s2_backward",
     "aadg_conv1x1_wgrad_supported", "aadg_conv1x1_wgrad_bf16", "aadg_conv3x3_wgrad_supported", "aadg_conv3x3_wgrad_bf16",
-    "aadg_conv3x3_nchw_supported", "aadg_conv3x3_nchw_bf16",
+    "aadg_conv3x3_nchw_supported", "aadg_conv3x3_nchw_bf16", "aadg_conv3x3s2_wgrad_supported", "aadg_conv3x3s2_wgrad_bf16",
     "aadg_controller_supported", "aadg_controller_workspace_bytes", "aadg_controller_sample_f32",
     "aadg_controller_ppo_update_f32",
     "aadg_embed_prologue_f32", "aadg_embed_prologue_norm_f32",
@@ -175,6 +175,10 @@ def load():
     lib.aadg_conv3x3_wgrad_supported.argtypes = [_i, _i, _i, _i, _i]
     lib.aadg_conv3x3_wgrad_bf16.restype = _i
     lib.aadg_conv3x3_wgrad_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
+    lib.aadg_conv3x3s2_wgrad_supported.restype = _i
+    lib.aadg_conv3x3s2_wgrad_supported.argtypes = [_i, _i, _i, _i]
+    lib.aadg_conv3x3s2_wgrad_bf16.restype = _i
+    lib.aadg_conv3x3s2_wgrad_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.aadg_conv3x3_nchw_supported.restype = _i
     lib.aadg_conv3x3_nchw_supported.argtypes = [_i, _i, _i, _i, _i]
     lib.aadg_conv3x3_nchw_bf16.restype = _i
@@ -1314,6 +1318,56 @@ def conv3x3_wgrad(dy, x, dilation=1):
     rc = lib.aadg_conv3x3_wgrad_bf16(dy.data_ptr(), x.data_ptr(), dw9.data_ptr(), N, Co, Ci, H, W, int(dilation), _stream())
     _check(rc, "aadg_conv3x3_wgrad_bf16")
     return dw9.permute(1, 2, 0).reshape(Co, Ci, 3, 3)
+
+
+def conv3x3s2_wgrad(dy, x):
+    """dW [Co, Ci, 3, 3] float32 of a 3x3 / stride-2 / padding-1 convolution from NCHW bfloat16 dy [N,Co,Ho,Wo], x [N,Ci,2Ho,2Wo]."""
+    lib = load()
+    _require_cuda(dy, x)
+    if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or not (dy.is_contiguous() and x.is_contiguous()):
+        raise AadgError("conv3x3s2_wgrad: expected contiguous NCHW bfloat16 tensors")
+    N, Co, Ho, Wo = dy.shape
+    Ci = x.shape[1]
+    if x.shape[0] != N or x.shape[2] != 2 * Ho or x.shape[3] != 2 * Wo:
+        raise AadgError("conv3x3s2_wgrad: shape mismatch")
+    dw9 = torch.empty((9, Co, Ci), dtype=torch.float32, device=x.device)
+    _check(lib.aadg_conv3x3s2_wgrad_bf16(dy.data_ptr(), x.data_ptr(), dw9.data_ptr(), N, Co, Ci, Ho, Wo, _stream()), "aadg_conv3x3s2_wgrad_bf16")
+    return dw9.permute(1, 2, 0).reshape(Co, Ci, 3, 3)
+
+
+class _Conv3x3S2(torch.autograd.Function):
+    """3x3 / stride-2 / padding-1 convolution without bias: forward and input gradient are the library's, the weight gradient is
+    k_wgrad3x3_s2 (csrc/conv3x3_wgrad.hip).  `weight` is the float32 master copy."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        wq = cast_weight(weight, x.dtype)
+        ctx.save_for_backward(x, wq)
+        return torch.ops.aten.convolution(x, wq, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wq = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            dw = conv3x3s2_wgrad(dy, x)
+        return dx, dw
+
+
+def conv3x3s2_supported(x, weight):
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.is_contiguous() and weight.dtype == torch.float32 and
+            tuple(weight.shape[2:]) == (3, 3) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and
+            bool(load().aadg_conv3x3s2_wgrad_supported(weight.shape[0], weight.shape[1], x.shape[2] // 2, x.shape[3] // 2)))
+
+
+def conv3x3s2(x, weight):
+    _require_cuda(x, weight)
+    if not conv3x3s2_supported(x, weight):
+        raise AadgError("conv3x3s2: unsupported shape / dtype / layout")
+    return _Conv3x3S2.apply(x, weight)
 
 
 def conv3x3_nchw(a9, x, dilation=1):

@@ -176,6 +176,172 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3(const uint16_t* __restrict_
     }
 }
 
+// ---- stride 2 (padding 1, dilation 1): dW[o][c][kh][kw] = sum dY[n][o][y][x] * X[n][c][2 y + kh - 1][2 x + kw - 1] ------------------
+// K-step = one OUTPUT row (WO pixels); it reads the input rows 2 y - 1, 2 y, 2 y + 1 (two new rows per step: a ring of five).  The
+// staging step splits every input row into its even and odd columns (E[x] = X[2 x], O[x] = X[2 x + 1]; two v_perm per chunk), so
+// the three horizontal taps are again K-contiguous: kw = 1 -> E[x], kw = 2 -> O[x], kw = 0 -> O[x - 1] (funnel with the word before,
+// zero at the row start).
+template <int WO>
+struct W3S2Cfg {
+    static constexpr int R = 5;
+    static constexpr int PA = WO + 8;
+    static constexpr int PX = 2 * WO + 24;          // 8 pad | E (WO) | 8 pad = O's left halo | O (WO) | 8 pad; pitch = 4 (mod 8) words
+    static constexpr int EO = 8, OO = 16 + WO;
+    static constexpr int LPA = WO / 32;             // dY chunks per thread
+    static constexpr int LPX = WO / 16;             // chunks per thread of ONE input row (64 channels x 2 WO / 8 chunks / 256 threads)
+    static constexpr size_t lds_bytes = ((size_t)2 * W3_BM * PA + (size_t)R * W3_BN * PX) * sizeof(uint16_t);
+};
+
+template <int WO>
+__global__ __launch_bounds__(256, WO == 64 ? 1 : 2) void k_wgrad3x3_s2(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, float* __restrict__ acc,
+                                                        int Co, int Ci, int Ho, int tiles, int tiles_n, int rows_total, int rows_per_block) {
+    using C = W3S2Cfg<WO>;
+    constexpr int R = C::R, PA = C::PA, PX = C::PX, LPA = C::LPA, LPX = C::LPX, WI = 2 * WO, CPA = WO / 8, CPX = WI / 8;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t* dYs = lds;                                  // [2][64][PA]
+    uint16_t* Xs = lds + 2 * W3_BM * PA;                  // [R][64][PX]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 1, wc = wv & 1;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int tile = q % tiles, slice = (q / tiles) * 8 + xcd;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * W3_BM, n0 = tn * W3_BN;
+    const int g0 = slice * rows_per_block, g1 = min(rows_total, g0 + rows_per_block);
+    if (g0 >= g1) return;
+    const int Hi = 2 * Ho;
+    for (int i = tid; i < R * W3_BN; i += 256) {          // pads / halos: zero once
+        uint16_t* row = Xs + (size_t)i * PX;
+        *reinterpret_cast<uint4*>(row) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(row + 8 + WO) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(row + 16 + 2 * WO) = make_uint4(0, 0, 0, 0);
+    }
+    const size_t HWo = (size_t)Ho * WO, HWi = (size_t)Hi * WI;
+    auto load_dy = [&](int n, int y, uint4* st) {
+#pragma unroll
+        for (int i = 0; i < LPA; ++i) {
+            const int id = tid + 256 * i, row = id / CPA, c8 = (id - row * CPA) * 8, m = m0 + row;
+            st[i] = m < Co ? *reinterpret_cast<const uint4*>(dY + ((size_t)n * Co + m) * HWo + (size_t)y * WO + c8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_dy = [&](int buf, const uint4* st) {
+        uint16_t* base = dYs + (size_t)buf * W3_BM * PA;
+#pragma unroll
+        for (int i = 0; i < LPA; ++i) {
+            const int id = tid + 256 * i, row = id / CPA, c8 = (id - row * CPA) * 8;
+            *reinterpret_cast<uint4*>(base + row * PA + c8) = st[i];
+        }
+    };
+    auto load_x = [&](int n, int r, uint4* st) {             // input row r; rows outside the image: zeros
+#pragma unroll
+        for (int i = 0; i < LPX; ++i) {
+            const int id = tid + 256 * i, row = id / CPX, ch = id - row * CPX, c = n0 + row;
+            st[i] = (c < Ci && r >= 0 && r < Hi) ? *reinterpret_cast<const uint4*>(X + ((size_t)n * Ci + c) * HWi + (size_t)r * WI + ch * 8)
+                                                 : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto slot_of = [&](int r) { return (r + 2 * R) % R; };
+    auto store_x = [&](int r, const uint4* st) {             // split the 8 pixels of a chunk into 4 even + 4 odd columns
+        uint16_t* base = Xs + (size_t)slot_of(r) * W3_BN * PX;
+#pragma unroll
+        for (int i = 0; i < LPX; ++i) {
+            const int id = tid + 256 * i, row = id / CPX, ch = id - row * CPX;
+            const uint4 v = st[i];
+            const uint2 e = make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x05040100u), __builtin_amdgcn_perm(v.w, v.z, 0x05040100u));
+            const uint2 o = make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x07060302u), __builtin_amdgcn_perm(v.w, v.z, 0x07060302u));
+            *reinterpret_cast<uint2*>(base + row * PX + C::EO + 4 * ch) = e;
+            *reinterpret_cast<uint2*>(base + row * PX + C::OO + 4 * ch) = o;
+        }
+    };
+
+    f32x16 d[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[t][r] = 0.0f;
+    const int a_row = wr * 32 + (lane & 31), b_row = wc * 32 + (lane & 31), koff = (lane >> 5) * 8;
+    uint4 sdy[LPA], sx0[LPX], sx1[LPX];
+    int buf = 0;
+    for (int g = g0; g < g1; ++g) {
+        const int n = g / Ho, y = g - n * Ho;
+        if (g == g0 || y == 0) {
+            __syncthreads();                                 // every wave is done with the previous rows
+            for (int r = 2 * y - 1; r <= 2 * y + 1; ++r) {
+                load_x(n, r, sx0);
+                store_x(r, sx0);
+            }
+            load_dy(n, y, sdy);
+        } else {
+            store_x(2 * y, sx0);                             // fetched during the previous step
+            store_x(2 * y + 1, sx1);
+        }
+        store_dy(buf, sdy);
+        __syncthreads();
+        if (g + 1 < g1 && y + 1 < Ho) {
+            load_dy(n, y + 1, sdy);
+            load_x(n, 2 * y + 2, sx0);
+            load_x(n, 2 * y + 3, sx1);
+        }
+        const uint16_t* ab = dYs + (size_t)buf * W3_BM * PA + a_row * PA + koff;
+        const uint16_t* xb[3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) xb[kh] = Xs + ((size_t)slot_of(2 * y + kh - 1) * W3_BN + b_row) * PX + koff;
+#pragma unroll
+        for (int ks = 0; ks < WO / 16; ++ks) {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ab + ks * 16));
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const uint16_t* xr = xb[kh] + ks * 16;
+                const uint4 e = *reinterpret_cast<const uint4*>(xr + C::EO);
+                const uint4 o = *reinterpret_cast<const uint4*>(xr + C::OO);
+                const uint32_t prv = *reinterpret_cast<const uint32_t*>(xr + C::OO - 2);
+                const bf16x8 f0 = frag(__builtin_amdgcn_alignbit(o.x, prv, 16), __builtin_amdgcn_alignbit(o.y, o.x, 16),
+                                       __builtin_amdgcn_alignbit(o.z, o.y, 16), __builtin_amdgcn_alignbit(o.w, o.z, 16));       // O[x - 1]
+                d[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, f0, d[kh * 3 + 0], 0, 0, 0);
+                d[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, e), d[kh * 3 + 1], 0, 0, 0);
+                d[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, o), d[kh * 3 + 2], 0, 0, 0);
+            }
+        }
+        buf ^= 1;
+    }
+    const int nn = n0 + wc * 32 + (lane & 31);
+    if (nn < Ci) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float* at = acc + (size_t)t * Co * Ci;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < Co) unsafeAtomicAdd(at + (size_t)m * Ci + nn, d[t][r]);
+            }
+        }
+    }
+}
+
+template <int WO>
+int launch_s2(const uint16_t* dY, const uint16_t* X, float* acc, int N, int Co, int Ci, int Ho, hipStream_t st) {
+    using C = W3S2Cfg<WO>;
+    const int tiles_m = (Co + W3_BM - 1) / W3_BM, tiles_n = (Ci + W3_BN - 1) / W3_BN, tiles = tiles_m * tiles_n;
+    const long long rows_total = (long long)N * Ho;
+    const long long target = 512, min_mfma = 1152;
+    long long slices = (target + tiles - 1) / tiles;
+    long long rpb = (rows_total + slices - 1) / slices;
+    const long long min_rows = (min_mfma + (WO / 16) * 9 - 1) / ((WO / 16) * 9);
+    if (rpb < min_rows) rpb = min_rows;
+    slices = (rows_total + rpb - 1) / rpb;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3_s2<WO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)C::lds_bytes));
+        attr_set = true;
+    }
+    AADG_HIP_TRY(hipMemsetAsync(acc, 0, (size_t)9 * Co * Ci * sizeof(float), st));
+    const long long slice_groups = (slices + 7) / 8;
+    hipLaunchKernelGGL((k_wgrad3x3_s2<WO>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(256), C::lds_bytes, st, dY, X, acc, Co, Ci, Ho,
+                       tiles, tiles_n, (int)rows_total, (int)rpb);
+    AADG_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int W, int D>
 int launch(const uint16_t* dY, const uint16_t* X, float* acc, int N, int Co, int Ci, int H, hipStream_t st) {
     using C = W3Cfg<W, D>;
@@ -226,4 +392,17 @@ extern "C" int aadg_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dwe
     if (W == 32) return launch<32, 2>(a, b, dweight9, N, Co, Ci, H, st);
     if (W == 64) return launch<64, 2>(a, b, dweight9, N, Co, Ci, H, st);
     return launch<128, 2>(a, b, dweight9, N, Co, Ci, H, st);
+}
+
+/* stride 2, padding 1, dilation 1: dy [N, Co, Ho, Wo], x [N, Ci, 2 Ho, 2 Wo]; Wo in {32, 64} */
+extern "C" int aadg_conv3x3s2_wgrad_supported(int Co, int Ci, int Ho, int Wo) {
+    return Co > 0 && Ci > 0 && Ho > 0 && (Wo == 32 || Wo == 64) ? 1 : 0;
+}
+extern "C" int aadg_conv3x3s2_wgrad_bf16(const void* dy, const void* x, float* dweight9, int N, int Co, int Ci, int Ho, int Wo, void* stream) {
+    if (dy == nullptr || x == nullptr || dweight9 == nullptr || N <= 0) return AADG_E_BADARG;
+    if ((((uintptr_t)dy | (uintptr_t)x) & 15u) != 0) return AADG_E_BADARG;
+    if (!aadg_conv3x3s2_wgrad_supported(Co, Ci, Ho, Wo) || (long long)N * Ho > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (Wo == 32) return launch_s2<32>((const uint16_t*)dy, (const uint16_t*)x, dweight9, N, Co, Ci, Ho, st);
+    return launch_s2<64>((const uint16_t*)dy, (const uint16_t*)x, dweight9, N, Co, Ci, Ho, st);
 }

@@ -158,7 +158,8 @@ class Conv3x3(nn.Conv2d):
     """The bottleneck's dense 3x3 convolution (padding = dilation, no bias).  bfloat16 activations on the GPU at stride 1: forward,
     input gradient (csrc/conv3x3_fwd.hip: LDS transpose reads, three column-shifted copies of the staged rows) and weight gradient
     (csrc/conv3x3_wgrad.hip) run on the matrix cores straight from the NCHW tensors -- no NHWC transposes around an implicit GEMM, no
-    zero-fill / cast of a float32 workspace.  Stride 2 (the first block of stages 2 and 3) stays the library's."""
+    zero-fill / cast of a float32 workspace.  Stride 2 (the first block of stages 2 and 3): the weight gradient only (even / odd column
+    planes in LDS); forward and input gradient stay the library's."""
 
     def __init__(self, cin, cout, stride=1, dilation=1):
         super().__init__(cin, cout, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
@@ -169,6 +170,12 @@ class Conv3x3(nn.Conv2d):
             xc = x.contiguous()
             if _lib.conv3x3_supported(xc, self.weight, self.dilation[0]):
                 return _lib.conv3x3(xc, self.weight, self.dilation[0])
+        elif (x.is_cuda and x.dtype == torch.bfloat16 and self.stride == (2, 2) and self.dilation == (1, 1) and self.padding == (1, 1)
+              and not _OWN_CONV3X3_OFF):
+            from .. import _lib
+            xc = x.contiguous()
+            if _lib.conv3x3s2_supported(xc, self.weight):
+                return _lib.conv3x3s2(xc, self.weight)
         return super().forward(x)
 
 

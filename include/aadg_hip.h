@@ -359,6 +359,10 @@ int aadg_conv1x1_wgrad_bf16(const void* dy, const void* x, float* dweight, int N
  * dy [N, Co, H, W], x [N, Ci, H, W], dweight9 float32 [9, Co, Ci] (tap-major; permute(1, 2, 0) gives torch's [Co, Ci, 3, 3]).
  * W in {32, 64, 128}, d in {1, 2}.  Replaces MIOpen's NHWC igemm_wrw + its transposes, zero-fill and cast (csrc/conv3x3_wgrad.hip). */
 int aadg_conv3x3_wgrad_supported(int Co, int Ci, int H, int W, int dilation);
+/* the same for stride 2 (padding 1, dilation 1; the first block of ResNet stages 2 and 3): dy [N, Co, Ho, Wo], x [N, Ci, 2 Ho, 2 Wo],
+ * Wo in {32, 64} */
+int aadg_conv3x3s2_wgrad_supported(int Co, int Ci, int Ho, int Wo);
+int aadg_conv3x3s2_wgrad_bf16(const void* dy, const void* x, float* dweight9, int N, int Co, int Ci, int Ho, int Wo, void* stream);
 /* The convolution itself and its input gradient, NCHW bfloat16 in and out, float32 accumulation (csrc/conv3x3_fwd.hip):
  *     out[n][m][y][x] = sum_{k, kh, kw} a9[kh * 3 + kw][m][k] * in[n][k][y + (kh - 1) d][x + (kw - 1) d]
  * forward: a9[t][o][c] = weight[o][c][kh][kw]; input gradient: in = dy, a9[t][c][o] = weight[o][c][2 - kh][2 - kw].

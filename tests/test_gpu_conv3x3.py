@@ -106,3 +106,32 @@ def test_autograd_function_all_three_kernels(hip, d, W):
     assert (y.float() - yr).abs().max().item() <= 2.0 ** -8 * yr.abs().max().item()
     assert (x.grad.float() - xr.grad).abs().max().item() <= 2.0 ** -8 * xr.grad.abs().max().item()
     assert (w.grad - wr.grad).abs().max().item() <= 2e-4 * wr.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("N,Co,Ci,Ho,Wo", [(2, 64, 64, 32, 32), (2, 128, 64, 64, 64), (3, 96, 40, 9, 32), (19, 64, 64, 16, 32)])
+def test_stride2_wgrad_matches_float32_backward(hip, N, Co, Ci, Ho, Wo):
+    torch.manual_seed(Co + Ho)
+    x = torch.randn(N, Ci, 2 * Ho, 2 * Wo, device="cuda").to(torch.bfloat16)
+    dy = torch.randn(N, Co, Ho, Wo, device="cuda").to(torch.bfloat16)
+    got = hip.conv3x3s2_wgrad(dy, x)
+    w = torch.zeros(Co, Ci, 3, 3, device="cuda")
+    want = torch.ops.aten.convolution_backward(dy.float(), x.float(), w, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    assert got.shape == want.shape and (got - want).abs().max().item() <= 2e-4 * want.abs().max().item()
+
+
+def test_stride2_module(hip):
+    from aadg_amd.models.deeplab import Conv3x3
+    torch.manual_seed(5)
+    ours = Conv3x3(64, 64, 2, 1).cuda()
+    x = torch.randn(3, 64, 64, 64, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    g = torch.randn(3, 64, 32, 32, device="cuda").to(torch.bfloat16)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = ours(x)
+    assert y.shape == (3, 64, 32, 32) and type(y.grad_fn).__name__ == "_Conv3x3S2Backward"
+    y.backward(g)
+    xr = x.detach().float().requires_grad_(True)
+    wr = ours.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, stride=2, padding=1)
+    yr.backward(g.float())
+    assert (y.float() - yr).abs().max().item() <= 2.0 ** -5 * yr.abs().max().item()
+    assert (ours.weight.grad - wr.grad).abs().max().item() <= 2e-4 * wr.grad.abs().max().item()
