@@ -43,7 +43,7 @@ __device__ __forceinline__ bf16x8 frag(uint32_t a, uint32_t b, uint32_t c, uint3
 }
 
 template <int W, int D>
-__global__ __launch_bounds__(256, 2) void k_wgrad3x3(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, float* __restrict__ acc,
+__global__ __launch_bounds__(256, W == 128 ? 1 : 2) void k_wgrad3x3(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, float* __restrict__ acc,
                                                   int Co, int Ci, int H, int tiles, int tiles_n, int rows_total, int rows_per_block) {
     using C = W3Cfg<W, D>;
     constexpr int R = C::R, PA = C::PA, PX = C::PX, LPT = C::LPT, CPR = W / 8;       // CPR: chunks per row
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3(const uint16_t* __restrict_
         for (int r = 0; r < 16; ++r) d[t][r] = 0.0f;
 
     const int a_row = wr * 32 + (lane & 31), b_row = wc * 32 + (lane & 31), koff = (lane >> 5) * 8;
+    const bool hi_half = lane >= 32;
     uint4 sdy[LPT], sx[LPT];
     int buf = 0;
     for (int g = g0; g < g1; ++g) {
@@ -136,27 +137,45 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3(const uint16_t* __restrict_
         const uint16_t* xb[3];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) xb[kh] = Xs + ((size_t)slot_of(y + (kh - 1) * D) * W3_BN + b_row) * PX + 8 + koff;
+        // The 8 pixels of a lane's fragment are followed (lanes < 32) / preceded (lanes >= 32) by the fragment of lane ^ 32 of the same
+        // sub-step, and preceded / followed by that lane's fragment of the previous / next sub-step: the two neighbour words of the
+        // shifted taps come from v_permlane32_swap instead of two 4-byte LDS reads per fragment (64 lanes on 16 banks: 4-way
+        // conflicts -- SQ_LDS_BANK_CONFLICT was 4x the forward kernel's).  The row ends are the zero padding columns.
+        constexpr int KS = W / 16;
+        bf16x8 a[KS];
 #pragma unroll
-        for (int ks = 0; ks < W / 16; ++ks) {
-            const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ab + ks * 16));
+        for (int ks = 0; ks < KS; ++ks) a[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ab + ks * 16));
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const uint16_t* xr = xb[kh] + ks * 16;
-                const uint4 cur = *reinterpret_cast<const uint4*>(xr);
-                const uint32_t prv = *reinterpret_cast<const uint32_t*>(xr - 2), nxt = *reinterpret_cast<const uint32_t*>(xr + 8);
+        for (int kh = 0; kh < 3; ++kh) {
+            uint4 cur[KS];
+            uint32_t w_up[KS], w_lo[KS], x_up[KS], x_lo[KS];     // partner's last / first word, as seen by the upper / lower half
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) cur[ks] = *reinterpret_cast<const uint4*>(xb[kh] + ks * 16);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const auto rw = __builtin_amdgcn_permlane32_swap(cur[ks].w, cur[ks].w, false, false);
+                const auto rx = __builtin_amdgcn_permlane32_swap(cur[ks].x, cur[ks].x, false, false);
+                w_up[ks] = rw[0]; w_lo[ks] = rw[1];              // [0]: lanes >= 32 hold the lower half's value; [1]: lanes < 32 the upper half's
+                x_up[ks] = rx[0]; x_lo[ks] = rx[1];
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint32_t prv = hi_half ? w_up[ks] : (ks > 0 ? w_lo[ks - 1] : 0u);
+                const uint32_t nxt = hi_half ? (ks + 1 < KS ? x_up[ks + 1] : 0u) : x_lo[ks];
+                const uint4 c = cur[ks];
                 bf16x8 f0, f2;
                 if (D == 1) {
-                    const uint32_t s1 = __builtin_amdgcn_alignbit(cur.y, cur.x, 16), s2 = __builtin_amdgcn_alignbit(cur.z, cur.y, 16),
-                                   s3 = __builtin_amdgcn_alignbit(cur.w, cur.z, 16);
-                    f0 = frag(__builtin_amdgcn_alignbit(cur.x, prv, 16), s1, s2, s3);          // X[p - 1]
-                    f2 = frag(s1, s2, s3, __builtin_amdgcn_alignbit(nxt, cur.w, 16));          // X[p + 1]
+                    const uint32_t s1 = __builtin_amdgcn_alignbit(c.y, c.x, 16), s2 = __builtin_amdgcn_alignbit(c.z, c.y, 16),
+                                   s3 = __builtin_amdgcn_alignbit(c.w, c.z, 16);
+                    f0 = frag(__builtin_amdgcn_alignbit(c.x, prv, 16), s1, s2, s3);            // X[p - 1]
+                    f2 = frag(s1, s2, s3, __builtin_amdgcn_alignbit(nxt, c.w, 16));            // X[p + 1]
                 } else {
-                    f0 = frag(prv, cur.x, cur.y, cur.z);                                       // X[p - 2]
-                    f2 = frag(cur.y, cur.z, cur.w, nxt);                                       // X[p + 2]
+                    f0 = frag(prv, c.x, c.y, c.z);                                             // X[p - 2]
+                    f2 = frag(c.y, c.z, c.w, nxt);                                             // X[p + 2]
                 }
-                d[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, f0, d[kh * 3 + 0], 0, 0, 0);
-                d[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, cur), d[kh * 3 + 1], 0, 0, 0);
-                d[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, f2, d[kh * 3 + 2], 0, 0, 0);
+                d[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], f0, d[kh * 3 + 0], 0, 0, 0);
+                d[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], __builtin_bit_cast(bf16x8, c), d[kh * 3 + 1], 0, 0, 0);
+                d[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], f2, d[kh * 3 + 2], 0, 0, 0);
             }
         }
         buf ^= 1;
