@@ -46,6 +46,7 @@ EXPORTS = [
     "aadg_maxpool3x3s2_supported", "aadg_maxpool3x3s2_index_bytes", "aadg_maxpool3x3s2_forward", "aadg_maxpool3x3s2_backward",
     "aadg_conv1x1_wgrad_supported", "aadg_conv1x1_wgrad_bf16", "aadg_conv3x3_wgrad_supported", "aadg_conv3x3_wgrad_bf16",
     "aadg_conv3x3_nchw_supported", "aadg_conv3x3_nchw_bf16", "aadg_conv3x3s2_wgrad_supported", "aadg_conv3x3s2_wgrad_bf16",
+    "aadg_conv3x3s2_dgrad_supported", "aadg_conv3x3s2_dgrad_bf16",
     "aadg_controller_supported", "aadg_controller_workspace_bytes", "aadg_controller_sample_f32",
     "aadg_controller_ppo_update_f32",
     "aadg_embed_prologue_f32", "aadg_embed_prologue_norm_f32",
@@ -179,6 +180,10 @@ def load():
     lib.aadg_conv3x3s2_wgrad_supported.argtypes = [_i, _i, _i, _i]
     lib.aadg_conv3x3s2_wgrad_bf16.restype = _i
     lib.aadg_conv3x3s2_wgrad_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
+    lib.aadg_conv3x3s2_dgrad_supported.restype = _i
+    lib.aadg_conv3x3s2_dgrad_supported.argtypes = [_i, _i, _i, _i]
+    lib.aadg_conv3x3s2_dgrad_bf16.restype = _i
+    lib.aadg_conv3x3s2_dgrad_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.aadg_conv3x3_nchw_supported.restype = _i
     lib.aadg_conv3x3_nchw_supported.argtypes = [_i, _i, _i, _i, _i]
     lib.aadg_conv3x3_nchw_bf16.restype = _i
@@ -1335,9 +1340,25 @@ def conv3x3s2_wgrad(dy, x):
     return dw9.permute(1, 2, 0).reshape(Co, Ci, 3, 3)
 
 
+def conv3x3s2_dgrad(a9t, dy):
+    """dx [N, C, 2Ho, 2Wo] bfloat16 of a 3x3 / stride-2 / padding-1 convolution from dy [N, M, Ho, Wo] and the tap-major weights
+    a9t [9, C, M] (a9t[kh*3+kw][c][m] = weight[m][c][kh][kw])."""
+    lib = load()
+    _require_cuda(a9t, dy)
+    if a9t.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16 or not (a9t.is_contiguous() and dy.is_contiguous()) or a9t.dim() != 3:
+        raise AadgError("conv3x3s2_dgrad: expected contiguous bfloat16 a9t [9,C,M] and NCHW dy")
+    N, M, Ho, Wo = dy.shape
+    C = a9t.shape[1]
+    if a9t.shape[0] != 9 or a9t.shape[2] != M:
+        raise AadgError("conv3x3s2_dgrad: shape mismatch")
+    dx = torch.empty((N, C, 2 * Ho, 2 * Wo), dtype=torch.bfloat16, device=dy.device)
+    _check(lib.aadg_conv3x3s2_dgrad_bf16(a9t.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, C, M, Ho, Wo, _stream()), "aadg_conv3x3s2_dgrad_bf16")
+    return dx
+
+
 class _Conv3x3S2(torch.autograd.Function):
-    """3x3 / stride-2 / padding-1 convolution without bias: forward and input gradient are the library's, the weight gradient is
-    k_wgrad3x3_s2 (csrc/conv3x3_wgrad.hip).  `weight` is the float32 master copy."""
+    """3x3 / stride-2 / padding-1 convolution without bias: the forward is the library's, the input gradient is k_dgrad3x3_s2
+    (csrc/conv3x3_s2_dgrad.hip), the weight gradient k_wgrad3x3_s2 (csrc/conv3x3_wgrad.hip).  `weight` is the float32 master copy."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -1351,7 +1372,12 @@ class _Conv3x3S2(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+            M, C = wq.shape[0], wq.shape[1]
+            if load().aadg_conv3x3s2_dgrad_supported(C, M, dy.shape[2], dy.shape[3]):
+                dx = conv3x3s2_dgrad(wq.permute(2, 3, 1, 0).reshape(9, C, M).contiguous(), dy)
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
         if ctx.needs_input_grad[1]:
             dw = conv3x3s2_wgrad(dy, x)
         return dx, dw

@@ -363,6 +363,11 @@ int aadg_conv3x3_wgrad_supported(int Co, int Ci, int H, int W, int dilation);
  * Wo in {32, 64} */
 int aadg_conv3x3s2_wgrad_supported(int Co, int Ci, int Ho, int Wo);
 int aadg_conv3x3s2_wgrad_bf16(const void* dy, const void* x, float* dweight9, int N, int Co, int Ci, int Ho, int Wo, void* stream);
+/* Input gradient of the same stride-2 convolution: dx [N, C, 2 Ho, 2 Wo] from dy [N, M, Ho, Wo] and a9t [9, C, M] bfloat16 with
+ * a9t[kh * 3 + kw][c][m] = weight[m][c][kh][kw]; M % 8 == 0, Wo in {32, 64}.  Four parity classes of output pixels = four small
+ * stride-1 convolutions over dy (1 + 2 + 2 + 4 taps) in one kernel, no zero-stuffed intermediate (csrc/conv3x3_s2_dgrad.hip). */
+int aadg_conv3x3s2_dgrad_supported(int C, int M, int Ho, int Wo);
+int aadg_conv3x3s2_dgrad_bf16(const void* a9t, const void* dy, void* dx, int N, int C, int M, int Ho, int Wo, void* stream);
 /* The convolution itself and its input gradient, NCHW bfloat16 in and out, float32 accumulation (csrc/conv3x3_fwd.hip):
  *     out[n][m][y][x] = sum_{k, kh, kw} a9[kh * 3 + kw][m][k] * in[n][k][y + (kh - 1) d][x + (kw - 1) d]
  * forward: a9[t][o][c] = weight[o][c][kh][kw]; input gradient: in = dy, a9[t][c][o] = weight[o][c][2 - kh][2 - kw].

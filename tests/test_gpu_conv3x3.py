@@ -135,3 +135,22 @@ def test_stride2_module(hip):
     yr.backward(g.float())
     assert (y.float() - yr).abs().max().item() <= 2.0 ** -5 * yr.abs().max().item()
     assert (ours.weight.grad - wr.grad).abs().max().item() <= 2e-4 * wr.grad.abs().max().item()
+    assert (x.grad.float() - xr.grad).abs().max().item() <= 2.0 ** -8 * xr.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("N,C,M,Ho,Wo", [(2, 64, 64, 32, 32), (2, 128, 128, 64, 64), (3, 40, 96, 9, 32), (19, 100, 24, 7, 64),
+                                         (1, 256, 256, 32, 32)])
+def test_stride2_dgrad_matches_float32_backward(hip, N, C, M, Ho, Wo):
+    """k_dgrad3x3_s2: the four parity classes (1 + 2 + 2 + 4 taps), ragged channel / row counts, the zero column at j + 1 = Wo and
+    the zero row at i + 1 = Ho"""
+    torch.manual_seed(C + Ho)
+    dy = torch.randn(N, M, Ho, Wo, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(M, C, 3, 3, device="cuda") / 8).to(torch.bfloat16)
+    assert hip.load().aadg_conv3x3s2_dgrad_supported(C, M, Ho, Wo) == 1
+    got = hip.conv3x3s2_dgrad(w.permute(2, 3, 1, 0).reshape(9, C, M).contiguous(), dy)
+    x = torch.zeros(N, C, 2 * Ho, 2 * Wo, device="cuda")
+    want = torch.ops.aten.convolution_backward(dy.float(), x, w.float(), None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+    assert got.shape == want.shape and got.dtype == torch.bfloat16
+    assert (got.float() - want).abs().max().item() <= 2.0 ** -8 * want.abs().max().item()
+    lib = hip.load()
+    assert lib.aadg_conv3x3s2_dgrad_supported(64, 60, 32, 32) == 0 and lib.aadg_conv3x3s2_dgrad_supported(64, 64, 32, 48) == 0
