@@ -1218,12 +1218,21 @@ def conv1x1_wgrad(dy, x):
     return dw
 
 
-def _own_gemm_1x1(M, K, HW):
-    """Shapes (out channels M, reduction K) on which the matrix-core kernel of csrc/conv1x1_fwd.hip beats the library GEMM on
-    an MI355X (scripts/quick_time_conv1x1_own.py, N = 144): the bandwidth-bound ones -- few output channels, or a short
-    reduction -- plus the 1024 -> 256 / 304 -> 256 layers; the compute-bound late layers stay with hipBLASLt."""
+# images per call up to which the own 1x1 kernel also takes the mid-sized GEMMs (a per-rank batch of an 8- or 4-GPU run)
+CONV1X1_SMALL_BATCH = int(os.environ.get("AADG_CONV1X1_SMALL_BATCH", "40"))
+
+
+def _own_gemm_1x1(M, K, HW, N=None):
+    """Shapes (out channels M, reduction K, N images) on which the matrix-core kernel of csrc/conv1x1_fwd.hip beats the library
+    GEMM on an MI355X (scripts/quick_time_conv1x1_own.py at NB = 144 / 72 / 36 / 18).  At the full batch: the bandwidth-bound
+    ones -- few output channels, or a short reduction -- plus the 1024 -> 256 / 304 -> 256 layers; the compute-bound late layers
+    stay with hipBLASLt.  At a per-rank batch (N <= 40 images: one GEMM per image, hipBLASLt's 256 x 256 tiles leave the chip
+    half empty) everything but the largest weights (M K >= 2^20: 512 <-> 2048, 1024 <-> 2048): 2.37 + 2.69 -> 2.0 + 2.0 ms of
+    forward + input gradient per step at 18 images."""
     if not load().aadg_conv1x1_nchw_supported(M, K, HW):
         return False
+    if N is not None and N <= CONV1X1_SMALL_BATCH and M * K < (1 << 20):
+        return True
     return M <= 128 or (M <= 320 and (K <= 128 or K in (304, 1024)))
 
 
@@ -1237,7 +1246,7 @@ class _Conv1x1(torch.autograd.Function):
         wq = cast_weight(weight, x.dtype)
         ctx.save_for_backward(x, wq)
         Co, Ci = wq.shape[0], wq.shape[1]
-        if _own_gemm_1x1(Co, Ci, x.shape[2] * x.shape[3]):
+        if _own_gemm_1x1(Co, Ci, x.shape[2] * x.shape[3], x.shape[0]):
             return conv1x1_nchw(wq.view(Co, Ci), x)
         return torch.ops.aten.convolution(x, wq, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
 
@@ -1248,7 +1257,7 @@ class _Conv1x1(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             Co, Ci = wq.shape[0], wq.shape[1]
-            if _own_gemm_1x1(Ci, Co, dy.shape[2] * dy.shape[3]):
+            if _own_gemm_1x1(Ci, Co, dy.shape[2] * dy.shape[3], dy.shape[0]):
                 dx = conv1x1_nchw(wq.view(Co, Ci).t().contiguous(), dy)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
