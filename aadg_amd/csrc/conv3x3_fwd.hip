@@ -237,7 +237,12 @@ extern "C" int aadg_conv3x3_nchw_bf16(const void* a9, const void* in, void* out,
     // change -- LDS read bandwidth is not the limit; skipping the per-step staging of the weight tile (stores): 15-18 % faster -- the serial
     // load -> store -> barrier section between two 36-MFMA bursts is.  A 32-channel tile (MI = 1, 52 KB, three workgroups per CU) to
     // interleave more of those sections: 10-40 % slower (half the MFMAs per staged IN chunk).  A 512-pixel tile (8 waves, one workgroup per
-    // CU, weight tile amortised over twice the pixels, less halo): +-5 %.
+    // CU, weight tile amortised over twice the pixels, less halo): +-5 %.  Round 2: issuing the fragment reads of tap row kh + 1 before the
+    // MFMAs of row kh (second register set, 120 -> 220-240 VGPRs): no change -- the two waves per SIMD already overlap LDS latency.
+    // Dropping the per-step global loads (timing only): 6.5 -> 4.7 ms per step and direction (670 -> 980 TFLOP/s on 512 x 512 at 32 x 32):
+    // every workgroup re-reads its 9 x 64 x K weight slab (590 KB against 390 KB of activations at K = 512) -- 4.3 TB/s out of L2 -- and
+    // one K-step of MFMAs does not cover the load latency; loads two steps ahead need a second register set (> 256 VGPRs at two waves
+    // per SIMD with this tile).  Next: a 128 x 256 tile on 8 waves (weights amortised over twice the MFMAs at the same LDS reads per MFMA).
     if (dilation == 1) {
         if (W == 32) return launch<32, 1, 2>(pa, pi, po, N, M, K, H, st);
         if (W == 64) return launch<64, 1, 2>(pa, pi, po, N, M, K, H, st);
