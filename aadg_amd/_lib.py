@@ -46,7 +46,7 @@ EXPORTS = [
     "aadg_maxpool3x3s2_supported", "aadg_maxpool3x3s2_index_bytes", "aadg_maxpool3x3s2_forward", "aadg_maxpool3x3s2_backward",
     "aadg_conv1x1_wgrad_supported", "aadg_conv1x1_wgrad_bf16", "aadg_conv3x3_wgrad_supported", "aadg_conv3x3_wgrad_bf16",
     "aadg_conv3x3_nchw_supported", "aadg_conv3x3_nchw_bf16", "aadg_conv3x3s2_wgrad_supported", "aadg_conv3x3s2_wgrad_bf16",
-    "aadg_conv3x3s2_dgrad_supported", "aadg_conv3x3s2_dgrad_bf16",
+    "aadg_conv3x3s2_dgrad_supported", "aadg_conv3x3s2_dgrad_bf16", "aadg_conv3x3s2_nchw_supported", "aadg_conv3x3s2_nchw_bf16",
     "aadg_controller_supported", "aadg_controller_workspace_bytes", "aadg_controller_sample_f32",
     "aadg_controller_ppo_update_f32",
     "aadg_embed_prologue_f32", "aadg_embed_prologue_norm_f32",
@@ -184,6 +184,10 @@ def load():
     lib.aadg_conv3x3s2_dgrad_supported.argtypes = [_i, _i, _i, _i]
     lib.aadg_conv3x3s2_dgrad_bf16.restype = _i
     lib.aadg_conv3x3s2_dgrad_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
+    lib.aadg_conv3x3s2_nchw_supported.restype = _i
+    lib.aadg_conv3x3s2_nchw_supported.argtypes = [_i, _i, _i, _i]
+    lib.aadg_conv3x3s2_nchw_bf16.restype = _i
+    lib.aadg_conv3x3s2_nchw_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.aadg_conv3x3_nchw_supported.restype = _i
     lib.aadg_conv3x3_nchw_supported.argtypes = [_i, _i, _i, _i, _i]
     lib.aadg_conv3x3_nchw_bf16.restype = _i
@@ -1365,14 +1369,33 @@ def conv3x3s2_dgrad(a9t, dy):
     return dx
 
 
+def conv3x3s2_nchw(a9, x):
+    """out [N, M, H/2, W/2] bfloat16 = 3x3 / stride-2 / padding-1 convolution of x [N, K, H, W] with tap-major weights a9 [9, M, K]."""
+    lib = load()
+    _require_cuda(a9, x)
+    if a9.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or not (a9.is_contiguous() and x.is_contiguous()) or a9.dim() != 3:
+        raise AadgError("conv3x3s2_nchw: expected contiguous bfloat16 a9 [9,M,K] and NCHW x")
+    N, K, H, W = x.shape
+    M = a9.shape[1]
+    if a9.shape[0] != 9 or a9.shape[2] != K or H % 2 or W % 2:
+        raise AadgError("conv3x3s2_nchw: shape mismatch")
+    out = torch.empty((N, M, H // 2, W // 2), dtype=torch.bfloat16, device=x.device)
+    _check(lib.aadg_conv3x3s2_nchw_bf16(a9.data_ptr(), x.data_ptr(), out.data_ptr(), N, M, K, H // 2, W // 2, _stream()), "aadg_conv3x3s2_nchw_bf16")
+    return out
+
+
 class _Conv3x3S2(torch.autograd.Function):
-    """3x3 / stride-2 / padding-1 convolution without bias: the forward is the library's, the input gradient is k_dgrad3x3_s2
-    (csrc/conv3x3_s2_dgrad.hip), the weight gradient k_wgrad3x3_s2 (csrc/conv3x3_wgrad.hip).  `weight` is the float32 master copy."""
+    """3x3 / stride-2 / padding-1 convolution without bias on NCHW bfloat16 activations: forward k_conv3x3_s2 (csrc/conv3x3_s2_fwd.hip),
+    input gradient k_dgrad3x3_s2 (csrc/conv3x3_s2_dgrad.hip), weight gradient k_wgrad3x3_s2 (csrc/conv3x3_wgrad.hip).  `weight` is
+    the float32 master copy."""
 
     @staticmethod
     def forward(ctx, x, weight):
         wq = cast_weight(weight, x.dtype)
         ctx.save_for_backward(x, wq)
+        Co, Ci = wq.shape[0], wq.shape[1]
+        if load().aadg_conv3x3s2_nchw_supported(Co, Ci, x.shape[2] // 2, x.shape[3] // 2):
+            return conv3x3s2_nchw(wq.permute(2, 3, 0, 1).reshape(9, Co, Ci).contiguous(), x)
         return torch.ops.aten.convolution(x, wq, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1)
 
     @staticmethod

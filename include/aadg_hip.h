@@ -367,6 +367,11 @@ int aadg_conv3x3s2_wgrad_bf16(const void* dy, const void* x, float* dweight9, in
  * a9t[kh * 3 + kw][c][m] = weight[m][c][kh][kw]; M % 8 == 0, Wo in {32, 64}.  Four parity classes of output pixels = four small
  * stride-1 convolutions over dy (1 + 2 + 2 + 4 taps) in one kernel, no zero-stuffed intermediate (csrc/conv3x3_s2_dgrad.hip). */
 int aadg_conv3x3s2_dgrad_supported(int C, int M, int Ho, int Wo);
+/* ... and its forward: out [N, M, Ho, Wo] from in [N, K, 2 Ho, 2 Wo] and a9 [9, M, K] bfloat16 (a9[kh * 3 + kw][m][k] = weight[m][k][kh][kw]);
+ * K % 8 == 0, Wo in {32, 64}.  The stride is folded into the LDS staging (even / odd column planes); replaces MIOpen's NHWC igemm_fwd and
+ * the two layout transposes around it (csrc/conv3x3_s2_fwd.hip). */
+int aadg_conv3x3s2_nchw_supported(int M, int K, int Ho, int Wo);
+int aadg_conv3x3s2_nchw_bf16(const void* a9, const void* in, void* out, int N, int M, int K, int Ho, int Wo, void* stream);
 int aadg_conv3x3s2_dgrad_bf16(const void* a9t, const void* dy, void* dx, int N, int C, int M, int Ho, int Wo, void* stream);
 /* The convolution itself and its input gradient, NCHW bfloat16 in and out, float32 accumulation (csrc/conv3x3_fwd.hip):
  *     out[n][m][y][x] = sum_{k, kh, kw} a9[kh * 3 + kw][m][k] * in[n][k][y + (kh - 1) d][x + (kw - 1) d]

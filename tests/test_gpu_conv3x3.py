@@ -154,3 +154,20 @@ def test_stride2_dgrad_matches_float32_backward(hip, N, C, M, Ho, Wo):
     assert (got.float() - want).abs().max().item() <= 2.0 ** -8 * want.abs().max().item()
     lib = hip.load()
     assert lib.aadg_conv3x3s2_dgrad_supported(64, 60, 32, 32) == 0 and lib.aadg_conv3x3s2_dgrad_supported(64, 64, 32, 48) == 0
+
+
+@pytest.mark.parametrize("N,M,K,Ho,Wo", [(2, 64, 64, 32, 32), (2, 128, 128, 64, 64), (3, 96, 40, 9, 32), (19, 24, 104, 7, 64),
+                                         (1, 256, 256, 32, 32)])
+def test_stride2_forward_matches_float32_convolution(hip, N, M, K, Ho, Wo):
+    """k_conv3x3_s2: even / odd column planes, the padding column at 2x - 1 = -1 and the padding row at 2y - 1 = -1, ragged channel
+    and row counts"""
+    torch.manual_seed(M + Ho)
+    x = torch.randn(N, K, 2 * Ho, 2 * Wo, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(M, K, 3, 3, device="cuda") / 8).to(torch.bfloat16)
+    assert hip.load().aadg_conv3x3s2_nchw_supported(M, K, Ho, Wo) == 1
+    got = hip.conv3x3s2_nchw(w.permute(2, 3, 0, 1).reshape(9, M, K).contiguous(), x)
+    want = torch.nn.functional.conv2d(x.float(), w.float(), stride=2, padding=1)
+    assert got.shape == want.shape and got.dtype == torch.bfloat16
+    assert (got.float() - want).abs().max().item() <= 2.0 ** -8 * want.abs().max().item()
+    lib = hip.load()
+    assert lib.aadg_conv3x3s2_nchw_supported(64, 60, 32, 32) == 0 and lib.aadg_conv3x3s2_nchw_supported(64, 64, 32, 48) == 0
