@@ -52,6 +52,7 @@ EXPORTS = [
     "aadg_embed_prologue_f32", "aadg_embed_prologue_norm_f32",
     "aadg_upsample_sum_backward_all_supported", "aadg_upsample_sum_backward_all",
     "aadg_upsample_sum", "aadg_upsample_sum_backward",
+    "aadg_weight_layouts_bf16",
 ]
 
 _lib = None
@@ -184,6 +185,8 @@ def load():
     lib.aadg_conv3x3s2_dgrad_supported.argtypes = [_i, _i, _i, _i]
     lib.aadg_conv3x3s2_dgrad_bf16.restype = _i
     lib.aadg_conv3x3s2_dgrad_bf16.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
+    lib.aadg_weight_layouts_bf16.restype = _i
+    lib.aadg_weight_layouts_bf16.argtypes = [_vp, _vp, _i, _vp]
     lib.aadg_conv3x3s2_nchw_supported.restype = _i
     lib.aadg_conv3x3s2_nchw_supported.argtypes = [_i, _i, _i, _i]
     lib.aadg_conv3x3s2_nchw_bf16.restype = _i
@@ -1249,6 +1252,7 @@ class _Conv1x1(torch.autograd.Function):
     def forward(ctx, x, weight):
         wq = cast_weight(weight, x.dtype)
         ctx.save_for_backward(x, wq)
+        ctx.wt = weight_layout(weight, "bwd")            # [1, Ci, Co] of the tracked shadow (this step's weights), or None
         Co, Ci = wq.shape[0], wq.shape[1]
         if _own_gemm_1x1(Co, Ci, x.shape[2] * x.shape[3], x.shape[0]):
             return conv1x1_nchw(wq.view(Co, Ci), x)
@@ -1262,7 +1266,7 @@ class _Conv1x1(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             Co, Ci = wq.shape[0], wq.shape[1]
             if _own_gemm_1x1(Ci, Co, dy.shape[2] * dy.shape[3], dy.shape[0]):
-                dx = conv1x1_nchw(wq.view(Co, Ci).t().contiguous(), dy)
+                dx = conv1x1_nchw(ctx.wt[0] if ctx.wt is not None else wq.view(Co, Ci).t().contiguous(), dy)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
@@ -1284,42 +1288,114 @@ def conv1x1(x, weight):
 
 
 # ------------------------------------------------------------------------------------------------
-# bfloat16 shadows of the float32 master weights of the own convolution modules.  Every `weight.to(bfloat16)` is a 5 us launch
-# (66 of them per step); a model registered with `track_bf16_weights` refreshes all shadows that changed since the last forward
-# in ONE multi-tensor copy (a forward pre-hook), and the autograd functions below pick the shadow up through `cast_weight`.
-_SHADOWS = {}          # id(weight) -> [weakref(weight), bfloat16 copy, version of the weight the copy was made from]
+# bfloat16 shadows of the float32 master weights of the own convolution modules, in the layouts their kernels read.  Every
+# `weight.to(bfloat16)` is a 5 us launch (66 per step) and every tap-major / transposed copy (`permute(...).contiguous()`, one per
+# convolution and direction) another 5-7 us (~70 per step) -- a cost that does not shrink with the per-rank batch.  A model registered
+# with `track_bf16_weights` refreshes ALL of them in ONE launch (csrc/weight_layouts.hip) from a forward pre-hook whenever a master
+# weight changed since the last forward; the autograd functions pick them up through `cast_weight` / `weight_layout` and fall back
+# to the per-call copies for a weight that is not tracked (or whose shadow is stale).
+class WlItem(ctypes.Structure):
+    """mirror of `aadg_wl_item` (include/aadg_hip.h)"""
+    _fields_ = [("w", ctypes.c_void_p), ("plain", ctypes.c_void_p), ("fwd", ctypes.c_void_p), ("bwd", ctypes.c_void_p),
+                ("Co", ctypes.c_int32), ("Ci", ctypes.c_int32), ("taps", ctypes.c_int32), ("flip", ctypes.c_int32)]
+
+
+_SHADOWS = {}          # id(weight) -> _Shadow
+
+
+class _Shadow(object):
+    __slots__ = ("ref", "plain", "fwd", "bwd", "version", "ptr", "flip")
+
+    def valid_for(self, weight):
+        return self.version == weight._version and self.ref() is weight
 
 
 def cast_weight(weight, dtype):
     e = _SHADOWS.get(id(weight))
-    if e is not None and dtype == torch.bfloat16 and e[2] == weight._version and e[0]() is weight:
-        return e[1]
+    if e is not None and dtype == torch.bfloat16 and e.valid_for(weight):
+        return e.plain
     return weight.to(dtype)
 
 
-def refresh_bf16_weights(weights):
-    import weakref
-    src, dst = [], []
-    for w in weights:
-        e = _SHADOWS.get(id(w))
-        if e is None or e[0]() is not w or e[1].device != w.device or e[1].shape != w.shape:
-            e = [weakref.ref(w), torch.empty_like(w, dtype=torch.bfloat16), -1]
+def weight_layout(weight, which):
+    """The tracked bfloat16 copy of `weight` [Co, Ci, kh, kw] in layout 'fwd' ([taps, Co, Ci]) or 'bwd' ([taps, Ci, Co]; taps mirrored
+    for a stride-1 3x3 convolution), or None when the weight is not tracked / its shadow is stale."""
+    e = _SHADOWS.get(id(weight))
+    if e is None or not e.valid_for(weight):
+        return None
+    return e.fwd if which == "fwd" else e.bwd
+
+
+class _WeightLayouts(object):
+    """All tracked weights of one model: shadows, the device item / tile tables of aadg_weight_layouts_bf16, one launch per refresh."""
+
+    def __init__(self, entries):
+        self.entries = entries              # [(weight, flip)]
+        self.items = self.tiles = None
+        self.n_tiles = 0
+
+    def _build(self):
+        import weakref
+        dev = self.entries[0][0].device
+        items = (WlItem * len(self.entries))()
+        tiles = []
+        for i, (w, flip) in enumerate(self.entries):
+            Co, Ci, taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+            e = _Shadow()
+            e.ref, e.version, e.ptr, e.flip = weakref.ref(w), -1, w.data_ptr(), flip
+            e.plain = torch.empty(w.shape, dtype=torch.bfloat16, device=dev)
+            e.fwd = torch.empty((taps, Co, Ci), dtype=torch.bfloat16, device=dev) if taps > 1 else e.plain.view(1, Co, Ci)
+            e.bwd = torch.empty((taps, Ci, Co), dtype=torch.bfloat16, device=dev)
             _SHADOWS[id(w)] = e
-        if e[2] != w._version:
-            src.append(w.detach())
-            dst.append(e[1])
-            e[2] = w._version
-    if src:
-        with torch.no_grad():
-            torch._foreach_copy_(dst, src)
+            items[i] = WlItem(w.data_ptr(), e.plain.data_ptr(), e.fwd.data_ptr() if taps > 1 else None, e.bwd.data_ptr(), Co, Ci, taps, flip)
+            tiles += [(i, o0, c0) for o0 in range(0, Co, 32) for c0 in range(0, Ci, 32)]
+        raw = np.frombuffer(bytes(items), dtype=np.uint8).copy()
+        self.items = torch.from_numpy(raw).to(dev)
+        self.tiles = torch.tensor(tiles, dtype=torch.int32).to(dev)
+        self.n_tiles = len(tiles)
+
+    def refresh(self):
+        stale = self.items is None
+        changed = False
+        for w, _ in self.entries:
+            e = _SHADOWS.get(id(w))
+            if e is None or e.ref() is not w or e.ptr != w.data_ptr() or e.plain.device != w.device:
+                stale = True
+                break
+            changed = changed or e.version != w._version
+        if stale:
+            self._build()
+            changed = True
+        if not changed:
+            return
+        _check(load().aadg_weight_layouts_bf16(self.items.data_ptr(), self.tiles.data_ptr(), self.n_tiles, _stream()),
+               "aadg_weight_layouts_bf16")
+        for w, _ in self.entries:
+            _SHADOWS[id(w)].version = w._version
 
 
 def track_bf16_weights(model, module_types):
-    """Registers the float32 weights of `model`'s modules of the given types for batched bfloat16 casts (CUDA models only)."""
-    weights = [m.weight for m in model.modules() if isinstance(m, module_types) and m.weight.dtype == torch.float32 and m.weight.is_cuda]
-    if weights:
-        model.register_forward_pre_hook(lambda mod, args: refresh_bf16_weights(weights))
-    return len(weights)
+    """Registers the float32 weights of `model`'s modules of the given types (1x1 / 3x3 convolutions: weight [Co, Ci, k, k], k*k <= 9)
+    for the batched bfloat16 casts / re-layouts (CUDA models only).  A 3x3 module with stride 1 gets the mirrored-tap 'bwd' layout
+    (its input gradient is the forward kernel on dY), any other the plain transposed one."""
+    entries = []
+    for m in model.modules():
+        if isinstance(m, module_types) and m.weight.dtype == torch.float32 and m.weight.is_cuda and m.weight.dim() == 4 and \
+                m.weight.shape[2] * m.weight.shape[3] <= 9:
+            stride = m.stride[0] if isinstance(m.stride, (tuple, list)) else m.stride
+            entries.append((m.weight, 1 if (m.weight.shape[2] == 3 and stride == 1) else 0))
+    if entries:
+        wl = _WeightLayouts(entries)
+        model.register_forward_pre_hook(lambda mod, args: wl.refresh())
+        model._aadg_weight_layouts = wl
+    return len(entries)
+
+
+def refresh_bf16_weights(model):
+    """The pre-hook's work, callable directly (tests / callers that run sub-modules of a tracked model on their own)."""
+    wl = getattr(model, "_aadg_weight_layouts", None)
+    if wl is not None:
+        wl.refresh()
 
 
 def conv3x3_wgrad(dy, x, dilation=1):
@@ -1393,9 +1469,11 @@ class _Conv3x3S2(torch.autograd.Function):
     def forward(ctx, x, weight):
         wq = cast_weight(weight, x.dtype)
         ctx.save_for_backward(x, wq)
+        ctx.a9t = weight_layout(weight, "bwd")           # tap-major transposed shadow (this step's weights), or None
         Co, Ci = wq.shape[0], wq.shape[1]
         if load().aadg_conv3x3s2_nchw_supported(Co, Ci, x.shape[2] // 2, x.shape[3] // 2):
-            return conv3x3s2_nchw(wq.permute(2, 3, 0, 1).reshape(9, Co, Ci).contiguous(), x)
+            a9 = weight_layout(weight, "fwd")
+            return conv3x3s2_nchw(a9 if a9 is not None else wq.permute(2, 3, 0, 1).reshape(9, Co, Ci).contiguous(), x)
         return torch.ops.aten.convolution(x, wq, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1)
 
     @staticmethod
@@ -1406,7 +1484,7 @@ class _Conv3x3S2(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             M, C = wq.shape[0], wq.shape[1]
             if load().aadg_conv3x3s2_dgrad_supported(C, M, dy.shape[2], dy.shape[3]):
-                dx = conv3x3s2_dgrad(wq.permute(2, 3, 1, 0).reshape(9, C, M).contiguous(), dy)
+                dx = conv3x3s2_dgrad(ctx.a9t if ctx.a9t is not None else wq.permute(2, 3, 1, 0).reshape(9, C, M).contiguous(), dy)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
@@ -1463,10 +1541,12 @@ class _Conv3x3(torch.autograd.Function):
     def forward(ctx, x, weight, dilation):
         wq = cast_weight(weight, x.dtype)
         ctx.save_for_backward(x, wq)
+        ctx.a9t = weight_layout(weight, "bwd")           # tap-major transposed shadow (this step's weights), or None
         ctx.dilation = dilation
         Co, Ci = wq.shape[0], wq.shape[1]
         if _own_conv3x3_fwd(x, Co, Ci, dilation):
-            return conv3x3_nchw(wq.permute(2, 3, 0, 1).reshape(9, Co, Ci).contiguous(), x, dilation)
+            a9 = weight_layout(weight, "fwd")
+            return conv3x3_nchw(a9 if a9 is not None else wq.permute(2, 3, 0, 1).reshape(9, Co, Ci).contiguous(), x, dilation)
         return torch.ops.aten.convolution(x, wq, None, [1, 1], [dilation, dilation], [dilation, dilation], False, [0, 0], 1)
 
     @staticmethod
@@ -1479,7 +1559,8 @@ class _Conv3x3(torch.autograd.Function):
             Co, Ci = wq.shape[0], wq.shape[1]
             if _own_conv3x3_fwd(dy, Ci, Co, d):
                 # the same kernel on dy with the taps mirrored and the channel roles swapped
-                dx = conv3x3_nchw(wq.flip(2, 3).permute(2, 3, 1, 0).reshape(9, Ci, Co).contiguous(), dy, d)
+                a9t = ctx.a9t if ctx.a9t is not None else wq.flip(2, 3).permute(2, 3, 1, 0).reshape(9, Ci, Co).contiguous()
+                dx = conv3x3_nchw(a9t, dy, d)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [1, 1], [d, d], [d, d], False, [0, 0], 1,
                                                          [True, False, False])[0]

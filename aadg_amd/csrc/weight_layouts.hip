@@ -1,0 +1,58 @@
+// Per-step re-layout of the float32 master weights of the own convolutions, all layers in ONE launch:
+//     plain [Co][Ci][T]   bfloat16 cast (library fallbacks, shape reference)
+//     fwd   [T][Co][Ci]   tap-major: the A operand of k_conv3x3_nchw / k_conv3x3_s2 (and, T = 1, of k_conv1x1_nchw = plain)
+//     bwd   [T'][Ci][Co]  tap-major and transposed: the A operand of the same kernels run on dY (input gradient); T' = T - 1 - t
+//                         (mirrored taps) for the stride-1 3x3 convolution, T' = t for k_dgrad3x3_s2 and for 1x1
+// Before: one `weight.to(bfloat16)` multi-tensor copy plus ~70 `permute(...).contiguous()` launches of 5-7 us per step (one per
+// own convolution and direction), a cost that does not shrink with the per-rank batch.
+// Workgroup = one 32 x 32 (Co x Ci) tile of one layer with all its taps, through LDS so that all three outputs are written in
+// 64-byte runs.
+#include "common.h"
+
+namespace {
+
+constexpr int WL_T = 32, WL_MAXT = 9;
+
+__global__ __launch_bounds__(256) void k_weight_layouts(const aadg_wl_item* __restrict__ items, const int32_t* __restrict__ tiles) {
+    __shared__ uint16_t L[WL_T][WL_T * WL_MAXT + 2];
+    const int item = tiles[3 * blockIdx.x], o0 = tiles[3 * blockIdx.x + 1], c0 = tiles[3 * blockIdx.x + 2];
+    const aadg_wl_item it = items[item];
+    const int Co = it.Co, Ci = it.Ci, T = it.taps;
+    const int no = min(WL_T, Co - o0), nc = min(WL_T, Ci - c0);
+    const int run = nc * T;                                    // contiguous source elements per out channel of the tile
+    const float* w = (const float*)it.w;
+    uint16_t* plain = (uint16_t*)it.plain;
+    for (int e = threadIdx.x; e < no * run; e += 256) {
+        const int o = e / run, r = e - o * run;
+        const size_t g = ((size_t)(o0 + o) * Ci + c0) * T + r;
+        const uint16_t v = (uint16_t)aadg_f2bf_bits(w[g]);
+        L[o][r] = v;
+        if (plain != nullptr) plain[g] = v;
+    }
+    __syncthreads();
+    uint16_t* fwd = (uint16_t*)it.fwd;
+    uint16_t* bwd = (uint16_t*)it.bwd;
+    if (fwd != nullptr)
+        for (int e = threadIdx.x; e < T * no * nc; e += 256) {
+            const int t = e / (no * nc), r = e - t * (no * nc), o = r / nc, c = r - o * nc;
+            fwd[((size_t)t * Co + o0 + o) * Ci + c0 + c] = L[o][c * T + t];
+        }
+    if (bwd != nullptr)
+        for (int e = threadIdx.x; e < T * no * nc; e += 256) {
+            const int t = e / (no * nc), r = e - t * (no * nc), c = r / no, o = r - c * no;
+            const int tt = it.flip ? T - 1 - t : t;
+            bwd[((size_t)tt * Ci + c0 + c) * Co + o0 + o] = L[o][c * T + t];
+        }
+}
+
+}  // namespace
+
+/* items: DEVICE array of aadg_wl_item; tiles: DEVICE int32 [n_tiles][3] = (item, first out channel, first in channel) of every
+ * 32 x 32 tile of every item (the caller enumerates them once).  taps <= 9. */
+extern "C" int aadg_weight_layouts_bf16(const aadg_wl_item* items, const int32_t* tiles, int n_tiles, void* stream) {
+    if (items == nullptr || tiles == nullptr || n_tiles < 0) return AADG_E_BADARG;
+    if (n_tiles == 0) return 0;
+    hipLaunchKernelGGL(k_weight_layouts, dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, items, tiles);
+    AADG_LAUNCH_CHECK();
+    return 0;
+}

@@ -354,6 +354,20 @@ int aadg_maxpool3x3s2_backward(const void* index, const void* dy, void* dx, int 
 int aadg_conv1x1_wgrad_supported(int Co, int Ci, int HW);
 int aadg_conv1x1_wgrad_bf16(const void* dy, const void* x, float* dweight, int N, int Co, int Ci, int HW, void* stream);
 
+/* Per-step re-layout of the float32 master weights of the convolutions above, every layer in one launch (csrc/weight_layouts.hip):
+ * w [Co][Ci][taps] float32 -> plain [Co][Ci][taps], fwd [taps][Co][Ci], bwd [taps'][Ci][Co] bfloat16 (taps' = taps - 1 - t when flip,
+ * the mirrored taps of a stride-1 input gradient; each output may be NULL).  Replaces the reference-side `weight.to(bfloat16)` under
+ * autocast plus one permute + contiguous per convolution and direction.  `items` is a DEVICE array, `tiles` a DEVICE int32
+ * [n_tiles][3] = (item, first out channel, first in channel) of every 32 x 32 tile of every item; taps <= 9. */
+typedef struct aadg_wl_item {
+    const void* w;
+    void* plain;
+    void* fwd;
+    void* bwd;
+    int32_t Co, Ci, taps, flip;
+} aadg_wl_item;
+int aadg_weight_layouts_bf16(const aadg_wl_item* items, const int32_t* tiles, int n_tiles, void* stream);
+
 /* Weight gradient of a 3x3 / stride-1 convolution with padding = dilation (the bottleneck conv2 of the ResNet stages), NCHW bfloat16:
  *     dweight9[kh * 3 + kw][o][c] = sum_{n, y, x} dy[n][o][y][x] * x[n][c][y + (kh - 1) d][x + (kw - 1) d]     (zero outside the image)
  * dy [N, Co, H, W], x [N, Ci, H, W], dweight9 float32 [9, Co, Ci] (tap-major; permute(1, 2, 0) gives torch's [Co, Ci, 3, 3]).

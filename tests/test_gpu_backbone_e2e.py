@@ -79,8 +79,8 @@ def test_hip_layers_match_library_layers_in_situ(hip, encoder, monkeypatch):
 def test_batched_step_bookkeeping(hip):
     """deeplab.batch_step_bookkeeping: the BatchNorm counters of a registered model advance by one per training forward (one
     multi-tensor add after the forward instead of one launch per layer), and the bfloat16 shadows of the convolution weights follow
-    the float32 masters (one multi-tensor copy before the forward).  (Outputs are not compared: this random bfloat16 network on a
-    tiny batch differs from ITSELF from run to run, see the module docstring.)"""
+    the float32 masters in every layout the kernels read (one launch before the forward: csrc/weight_layouts.hip).  (Outputs are
+    not compared: this random bfloat16 network on a tiny batch differs from ITSELF from run to run, see the module docstring.)"""
     from aadg_amd.models import deeplab
     torch.manual_seed(3)
     b = deeplab.DeepLabV3Plus("resnet50", 2).cuda().train()
@@ -96,11 +96,17 @@ def test_batched_step_bookkeeping(hip):
         for m in convs:                                    # the shadow IS what the forward used, and it is the rounded master
             sh = hip.cast_weight(m.weight, torch.bfloat16)
             assert sh.data_ptr() != m.weight.data_ptr() and torch.equal(sh, m.weight.detach().to(torch.bfloat16))
+            Co, Ci, k = m.weight.shape[0], m.weight.shape[1], m.weight.shape[2]
+            fwd, bwd = hip.weight_layout(m.weight, "fwd"), hip.weight_layout(m.weight, "bwd")   # the layouts the kernels read
+            assert torch.equal(fwd, sh.permute(2, 3, 0, 1).reshape(k * k, Co, Ci))
+            mirrored = k == 3 and m.stride[0] == 1                # stride-1 input gradient = the forward kernel with mirrored taps
+            assert torch.equal(bwd, (sh.flip(2, 3) if mirrored else sh).permute(2, 3, 1, 0).reshape(k * k, Ci, Co))
         with torch.no_grad():                              # an "optimizer step": stale until the next forward refreshes them
             for p in b.parameters():
                 p.mul_(0.9)
         w = convs[0].weight
         assert torch.equal(hip.cast_weight(w, torch.bfloat16), w.detach().to(torch.bfloat16))      # version changed: falls back to a cast
+        assert hip.weight_layout(w, "fwd") is None and hip.weight_layout(w, "bwd") is None          # ... and to per-call copies
     assert all(m.num_batches_tracked.item() == 2 for m in bns)
     b.eval()
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
