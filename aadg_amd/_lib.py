@@ -375,6 +375,8 @@ def pool_histograms(pool):
 # optional (start, stop) torch.cuda.Event pair recorded around the dominant kernel of the next
 # aug_u8_forward call(s); used by bench.py to time that kernel live on the launch stream
 PROFILE_EVENTS = None
+# optional list: every aug_u8_forward call appends the op mix of its units (bench.py: the tile kernel's duration follows it)
+PROFILE_MIX = None
 # optional (start, stop) torch.cuda.Event pair recorded on the current stream around the WHOLE library call (all its kernels)
 PROFILE_CALL_EVENTS = None
 _pinned = {}
@@ -447,6 +449,11 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
     nb = lib.aadg_aug_u8_workspace_bytes(N, Hs, Ws, crop)
     ws = workspace(nb, dev, "aug")
     ev0 = ev1 = 0
+    if PROFILE_MIX is not None:
+        live = np.arange(MAX_OPS)[None, :] < units["n_ops"][:, None]
+        PROFILE_MIX.append({"units": int(N), "ops": int(live.sum()), "sharpness_ops": int(((units["op"] == 8) & live).sum()),
+                            "sharpness_units": int(n_sharp), "stat_ops": int(sum(l.size for l in stat_lists)), "late_units": int(late.size),
+                            "upscaled": int(((units["scaled_w"] != Ws) | (units["scaled_h"] != Hs)).sum())})
     if PROFILE_EVENTS is not None:
         ev0, ev1 = PROFILE_EVENTS[0].cuda_event, PROFILE_EVENTS[1].cuda_event
     if PROFILE_CALL_EVENTS is not None:

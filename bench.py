@@ -369,6 +369,9 @@ def relaunch_under_torchrun(a):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+LAST_MIXES = []
+
+
 def time_steps(st, a, world, steps, warmup, first_epoch=0, want_kernel_events=True, dump=None):
     """warmup untimed steps, then `steps` timed ones between barrier + synchronize pairs.  Returns (elapsed seconds (max over
     ranks), per-step device times ms, tile-kernel times ms, whole-augmentation-call times ms)."""
@@ -394,11 +397,25 @@ def time_steps(st, a, world, steps, warmup, first_epoch=0, want_kernel_events=Tr
         p[0].record(); p[1].record()                       # force creation of the underlying hipEvent_t
     sync()
     t0 = time.perf_counter()
+    mixes = []
+    idle_ms = float(os.environ.get("AADG_BENCH_IDLE_MS", "0"))     # experiment only: drain and idle the GPU before every step
+    pre_mb = int(os.environ.get("AADG_BENCH_PREREAD_MB", "0"))    # experiment only: stream a clean buffer through the caches before every step
+    scratch = torch.zeros(pre_mb << 18, dtype=torch.float32, device="cuda") if pre_mb > 0 else None
     for i in range(steps):
+        if idle_ms > 0:
+            torch.cuda.synchronize()
+            time.sleep(idle_ms * 1e-3)
+        if scratch is not None:
+            scratch.sum()
         marks[i].record()
         if want_kernel_events:
             _lib.PROFILE_EVENTS, _lib.PROFILE_CALL_EVENTS = kpairs[i], cpairs[i]
+        if want_kernel_events:
+            _lib.PROFILE_MIX = []
         nr = st.search_step(first_epoch + warmup + i, max_iters=1)[3]
+        if want_kernel_events:
+            mixes.append(_lib.PROFILE_MIX[0] if _lib.PROFILE_MIX else {})
+            _lib.PROFILE_MIX = None
         if dump is not None:
             from aadg_amd import search_dg as _sd
             dump.append((nr, _sd.LAST_RAW_REWARDS.clone()))
@@ -412,6 +429,8 @@ def time_steps(st, a, world, steps, warmup, first_epoch=0, want_kernel_events=Tr
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     kern_ms = [p[0].elapsed_time(p[1]) for p in kpairs] if want_kernel_events else []
     call_ms = [p[0].elapsed_time(p[1]) for p in cpairs] if want_kernel_events else []
+    global LAST_MIXES
+    LAST_MIXES = mixes
     return float(t.item()), step_ms, kern_ms, call_ms
 
 
@@ -532,6 +551,7 @@ def main():
     elapsed, step_ms, kern_ms_l, call_ms_l = time_steps(st, a, world, a.steps, a.warmup, dump=dump)
     ms_per_step = elapsed / a.steps * 1e3
     kern_ms, call_ms = float(np.mean(kern_ms_l)), float(np.mean(call_ms_l))
+    main_mixes = list(LAST_MIXES)
 
     def sync():
         if world > 1:
@@ -568,12 +588,22 @@ def main():
     for _ in range(2):
         hot_step()
     sync()
-    t0 = time.perf_counter()
     HK = max(a.steps, 10)
-    for _ in range(HK):
+    ev = lambda: torch.cuda.Event(enable_timing=True)      # noqa: E731
+    hk_pairs = [(ev(), ev(), ev(), ev()) for _ in range(HK)]
+    for p in hk_pairs:
+        for e in p:
+            e.record()                                     # force creation of the underlying hipEvent_t
+    sync()
+    t0 = time.perf_counter()
+    for i in range(HK):
+        _lib.PROFILE_EVENTS, _lib.PROFILE_CALL_EVENTS = hk_pairs[i][:2], hk_pairs[i][2:]
         hot_step()
+    _lib.PROFILE_EVENTS = _lib.PROFILE_CALL_EVENTS = None
     sync()
     hot_ms = (time.perf_counter() - t0) / HK * 1e3
+    hot_kern_ms = sum(p[0].elapsed_time(p[1]) for p in hk_pairs) / HK
+    hot_call_ms = sum(p[2].elapsed_time(p[3]) for p in hk_pairs) / HK
 
     # bytes of one launch (this rank's slice of one batch plan): the tile kernel's own, and SURVEY 8(d)'s for the whole call
     batch = [st.train_loader.dataset[0] for _ in range(a.batch)]
@@ -610,6 +640,15 @@ def main():
                                              ": the policy ops see the raw pool image, so its histogram / mean is computed once per resident "
                                              "pool image (aadg_pool_histograms_u8, outside the timed call) instead of once per unit and call; "
                                              "--no_pool_stats times the call with the per-unit statistics pass"}}
+        # the same launches in the hot-path leg below (backbone removed): the duration of this instruction-issue-bound kernel follows the
+        # core clock the power management leaves it, i.e. what ran before it -- after a step of MFMA-dense backbone kernels it runs
+        # ~10 % slower than after the library's slower convolutions or in the hot-path loop
+        # the kernel's duration follows the op mix the controller sampled for the step (every Sharpness op is a 3x3 stencil over the LDS
+        # patch + a barrier; bytes per launch are the same for every mix): per timed step, duration next to the mix
+        roof["per_step"] = [dict(m, kernel_us=round(k * 1e3, 1), call_us=round(c * 1e3, 1)) for m, k, c in zip(main_mixes, kern_ms_l, call_ms_l)]
+        roof["hot_path_leg"] = {"kernel_ms": hot_kern_ms, "frac": kbytes / (hot_kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "stage_ms": hot_call_ms, "stage_frac": sbytes / (hot_call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "what": "the same kernel / call timed the same way in the hot_path loop (no backbone kernels between two calls)"}
         if traffic:
             roof["traffic_source"] = "profiles/r02_traffic_k_fused3.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes), per unit x units"
         if prof and prof.get("k_fused3_avg_ms"):
