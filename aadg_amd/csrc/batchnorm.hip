@@ -30,7 +30,7 @@ template <> struct Pack<float> {
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
     static __device__ __forceinline__ void store(float* p, const float* v) {
-        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        aadg_store_stream(p, make_float4(v[0], v[1], v[2], v[3]));
     }
     static __device__ __forceinline__ float load1(const float* p) { return *p; }
     static __device__ __forceinline__ void store1(float* p, float v) { *p = v; }
@@ -51,7 +51,7 @@ template <> struct Pack<__hip_bfloat16> {
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = aadg_f2bf_pk(v[2 * i], v[2 * i + 1]);
-        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+        aadg_store_stream(p, make_uint4(w[0], w[1], w[2], w[3]));
     }
     static __device__ __forceinline__ float load1(const __hip_bfloat16* p) {
         return __uint_as_float((uint32_t)(*reinterpret_cast<const uint16_t*>(p)) << 16);

@@ -59,6 +59,18 @@ __device__ __forceinline__ int wave_sum(int v) {
 
 // float32 -> bfloat16 bits, round to nearest even (NaN kept quiet); bfloat16 bits -> float32 is a 16-bit shift
 // two float32 -> packed bfloat16 pair (lo in bits 0..15) with the gfx950 conversion instruction: round to nearest even,
+// 16-byte streaming (non-temporal) stores for outputs that are written once and read again only after far more than a cache of
+// other traffic: they do not displace the lines the kernel is about to (re-)read
+typedef float aadg_f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t aadg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void aadg_store_stream(float* p, float4 v) {
+    const aadg_f32x4 q = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(q, reinterpret_cast<aadg_f32x4*>(p));
+}
+__device__ __forceinline__ void aadg_store_stream(void* p, uint4 v) {
+    const aadg_u32x4 q = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(q, reinterpret_cast<aadg_u32x4*>(p));
+}
 // NaN kept quiet -- the same result as aadg_f2bf_bits() on each half, in one VALU instruction instead of ten
 __device__ __forceinline__ uint32_t aadg_f2bf_pk(float lo, float hi) {
     typedef float aadg_f32x2 __attribute__((ext_vector_type(2)));

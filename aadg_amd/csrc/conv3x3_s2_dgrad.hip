@@ -173,8 +173,8 @@ __global__ __launch_bounds__(256, 2) void k_dgrad3x3_s2(const uint16_t* __restri
             const int c = c0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
             if (c >= C) continue;
             uint16_t* row = dxn + (size_t)c * HWi + (size_t)(2 * i) * WI + 2 * j;
-            *reinterpret_cast<uint32_t*>(row) = aadg_f2bf_pk(d[0][ni][r], d[1][ni][r]);
-            *reinterpret_cast<uint32_t*>(row + WI) = aadg_f2bf_pk(d[2][ni][r], d[3][ni][r]);
+            __builtin_nontemporal_store(aadg_f2bf_pk(d[0][ni][r], d[1][ni][r]), reinterpret_cast<uint32_t*>(row));
+            __builtin_nontemporal_store(aadg_f2bf_pk(d[2][ni][r], d[3][ni][r]), reinterpret_cast<uint32_t*>(row + WI));
         }
     }
 }

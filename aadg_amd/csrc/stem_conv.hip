@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_stem7x7(const TIN* __restrict__ x, cons
                         const int o = 32 * mt + (rsel & 3) + 8 * (rsel >> 2) + 4 * g;
                         const int j = 32 * nt + (jj & ~1);
                         if (j0 + j < Wo)
-                            *reinterpret_cast<uint32_t*>(yn + (size_t)o * Ho * Wo + j) = aadg_f2bf_pk(lo, hi);
+                            __builtin_nontemporal_store(aadg_f2bf_pk(lo, hi), reinterpret_cast<uint32_t*>(yn + (size_t)o * Ho * Wo + j));
                     }
         }
     }
