@@ -49,7 +49,9 @@ template <> struct Elem<__hip_bfloat16> {
         uint2 t;
         t.x = aadg_f2bf_pk(v[0], v[1]);
         t.y = aadg_f2bf_pk(v[2], v[3]);
-        *reinterpret_cast<uint2*>(p) = t;
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t q = {t.x, t.y};
+        __builtin_nontemporal_store(q, reinterpret_cast<u32x2_t*>(p));      // written once, re-read after more than a cache of traffic
     }
 };
 

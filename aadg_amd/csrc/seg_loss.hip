@@ -60,7 +60,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_seg_partial(const float* __restr
             elem(z.y, y.y, gscale, bce, tp, fp, fn, grad ? &g.y : nullptr);
             elem(z.z, y.z, gscale, bce, tp, fp, fn, grad ? &g.z : nullptr);
             elem(z.w, y.w, gscale, bce, tp, fp, fn, grad ? &g.w : nullptr);
-            if (grad) *reinterpret_cast<float4*>(grad + base + i) = g;
+            if (grad) aadg_store_stream(grad + base + i, g);          // written once, read by the backward ~1 GB of traffic later
         }
     } else {
         for (int i = c0 + threadIdx.x; i < c1; i += SL_THREADS) {

@@ -22,7 +22,7 @@ template <> struct Vec4<float> {
     static constexpr int V16 = 4;                       // elements per 16-byte load
     static __device__ __forceinline__ void ld16(const float* p, float* v) { ld4(p, v); }
     static __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
-        *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+        aadg_store_stream(p, make_float4(a, b, c, d));
     }
     static __device__ __forceinline__ void st8(float* p, const float* v) { st4(p, v[0], v[1], v[2], v[3]); st4(p + 4, v[4], v[5], v[6], v[7]); }
     static __device__ __forceinline__ void st1(float* p, float a) { *p = a; }
@@ -48,7 +48,7 @@ template <> struct Vec4<__hip_bfloat16> {
         *reinterpret_cast<uint2*>(p) = v;
     }
     static __device__ __forceinline__ void st8(__hip_bfloat16* p, const float* v) {      // one 16-byte store
-        *reinterpret_cast<uint4*>(p) = make_uint4(aadg_f2bf_pk(v[0], v[1]), aadg_f2bf_pk(v[2], v[3]), aadg_f2bf_pk(v[4], v[5]), aadg_f2bf_pk(v[6], v[7]));
+        aadg_store_stream(p, make_uint4(aadg_f2bf_pk(v[0], v[1]), aadg_f2bf_pk(v[2], v[3]), aadg_f2bf_pk(v[4], v[5]), aadg_f2bf_pk(v[6], v[7])));
     }
     static __device__ __forceinline__ void st1(__hip_bfloat16* p, float a) { *p = __float2bfloat16(a); }
 };
