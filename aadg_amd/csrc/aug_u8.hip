@@ -35,7 +35,11 @@ namespace {
 // the 5 float32 output planes of a unit are written once and read next by the backbone, 0.9 GB later: streaming (non-temporal)
 // stores keep them from displacing the source patches other tiles of the unit are about to read (k_fused3: 228 -> 186 us per
 // 168-unit launch, the whole call 292 -> 250 us)
-__device__ __forceinline__ void store_stream4(float* p, float4 v) { aadg_store_stream(p, v); }
+// ... when the batch's output is larger than a cache can hold until the backbone reads it (a per-rank batch of 21 units, 110 MB,
+// is not: streaming it cost the tile kernel and the stem convolution behind it ~3 %).  The flag rides in the `dataset` argument.
+constexpr int AUG_STREAM_OUT = 0x100;
+constexpr size_t AUG_STREAM_BYTES = (size_t)128 << 20;
+__device__ __forceinline__ void store_out4(float* p, float4 v, bool stream) { aadg_store_out(p, v, stream); }
 
 
 constexpr int KMAX = 8;           // max taps per output pixel (scale factor >= 1/3)
@@ -630,7 +634,9 @@ __device__ __forceinline__ int clip8(int v) {
 }
 
 __global__ __launch_bounds__(256) void k_final(Bufs bufs, const uint8_t* masks, UnitRef ur, int Hs, int Ws, int crop,
-                                               int dataset, const int* tab, float* out_img, float* out_lbl) {
+                                               int dataset_in, const int* tab, float* out_img, float* out_lbl) {
+    const int dataset = dataset_in & 0xFF;
+    const bool stream_out = (dataset_in & AUG_STREAM_OUT) != 0;
     const int u = blockIdx.z;
     const aadg_unit& un = pick(ur, u);
     if (unit_fusable(ur, un, Hs, Ws, crop)) return;
@@ -716,9 +722,9 @@ __global__ __launch_bounds__(256) void k_final(Bufs bufs, const uint8_t* masks, 
         if (vec) {
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                store_stream4(oi + c * plane + off, make_float4(o[c][0], o[c][1], o[c][2], o[c][3]));
-            store_stream4(ol + off, make_float4(l0[0], l0[1], l0[2], l0[3]));
-            if (K == 2) store_stream4(ol + plane + off, make_float4(l1[0], l1[1], l1[2], l1[3]));
+                store_out4(oi + c * plane + off, make_float4(o[c][0], o[c][1], o[c][2], o[c][3]), stream_out);
+            store_out4(ol + off, make_float4(l0[0], l0[1], l0[2], l0[3]), stream_out);
+            if (K == 2) store_out4(ol + plane + off, make_float4(l1[0], l1[1], l1[2], l1[3]), stream_out);
         } else {
             for (int i = 0; i < nvalid; ++i) {
                 for (int c = 0; c < 3; ++c) oi[c * plane + off + i] = o[c][i];
@@ -1013,10 +1019,12 @@ __device__ __forceinline__ float normalise_u8(int v) {
 // phase is issued before the arithmetic it is independent of.
 template <int TH>
 __device__ __forceinline__ void fused_tile(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
-                                           const aadg_unit* __restrict__ units, int Hs, int Ws, int crop, int dataset,
+                                           const aadg_unit* __restrict__ units, int Hs, int Ws, int crop, int dataset_in,
                                            const int* __restrict__ tab, const uint8_t* __restrict__ lut,
                                            size_t lut_stage_stride, float* __restrict__ out_img, float* __restrict__ out_lbl,
                                            int u, int bx, int by, uint32_t* A, uint32_t* B, uint8_t* sl, const float* lutf) {
+    const int dataset = dataset_in & 0xFF;
+    const bool stream_out = (dataset_in & AUG_STREAM_OUT) != 0;
     constexpr int ROWS_PER_WAVE = TH / 4;
     const aadg_unit& un = units[u];
     if (unit_flow(true, un, Hs, Ws, crop) != FLOW_UP) return;
@@ -1164,9 +1172,9 @@ __device__ __forceinline__ void fused_tile(const uint8_t* __restrict__ pool, con
         const size_t off = (size_t)y * crop + xq;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            store_stream4(oi + c * plane + off, make_float4(o[c][0], o[c][1], o[c][2], o[c][3]));
-        store_stream4(ol + off, make_float4(l0[0], l0[1], l0[2], l0[3]));
-        if (K == 2) store_stream4(ol + plane + off, make_float4(l1[0], l1[1], l1[2], l1[3]));
+            store_out4(oi + c * plane + off, make_float4(o[c][0], o[c][1], o[c][2], o[c][3]), stream_out);
+        store_out4(ol + off, make_float4(l0[0], l0[1], l0[2], l0[3]), stream_out);
+        if (K == 2) store_out4(ol + plane + off, make_float4(l1[0], l1[1], l1[2], l1[3]), stream_out);
     }
 }
 
@@ -1187,10 +1195,12 @@ __device__ __forceinline__ int axis_taps(int inSize, int outSize) {
 
 __global__ __launch_bounds__(256) void k_fused_generic(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
                                                        const aadg_unit* __restrict__ units, const int* __restrict__ order,
-                                                       int Hs, int Ws, int crop, int dataset,
+                                                       int Hs, int Ws, int crop, int dataset_in,
                                                        const int* __restrict__ tab, const uint8_t* __restrict__ lut,
                                                        size_t lut_stage_stride, float* __restrict__ out_img,
                                                        float* __restrict__ out_lbl) {
+    const int dataset = dataset_in & 0xFF;
+    const bool stream_out = (dataset_in & AUG_STREAM_OUT) != 0;
     const int u = order != nullptr ? order[blockIdx.z] : blockIdx.z;      // order: the units of this class (caller's list)
     const aadg_unit& un = units[u];
     if (unit_flow(true, un, Hs, Ws, crop) != FLOW_GENERIC) return;
@@ -1341,9 +1351,9 @@ __global__ __launch_bounds__(256) void k_fused_generic(const uint8_t* __restrict
     const size_t off = (size_t)yv * crop + xq;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-        store_stream4(oi + c * plane + off, make_float4(o[c][0], o[c][1], o[c][2], o[c][3]));
-    store_stream4(ol + off, make_float4(l0[0], l0[1], l0[2], l0[3]));
-    if (K == 2) store_stream4(ol + plane + off, make_float4(l1[0], l1[1], l1[2], l1[3]));
+        store_out4(oi + c * plane + off, make_float4(o[c][0], o[c][1], o[c][2], o[c][3]), stream_out);
+    store_out4(ol + off, make_float4(l0[0], l0[1], l0[2], l0[3]), stream_out);
+    if (K == 2) store_out4(ol + plane + off, make_float4(l1[0], l1[1], l1[2], l1[3]), stream_out);
 }
 
 // one workgroup per tile
@@ -1397,10 +1407,12 @@ __device__ __forceinline__ int sharp_count4(const aadg_unit& un, int n_ops) {
 
 template <bool SHARP>
 __device__ __forceinline__ void fused3_body(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
-                                            const aadg_unit* __restrict__ units, int Hs, int Ws, int crop, int dataset,
+                                            const aadg_unit* __restrict__ units, int Hs, int Ws, int crop, int dataset_in,
                                             const int* __restrict__ tab, const uint8_t* __restrict__ lut, size_t lut_stage_stride,
                                             float* __restrict__ out_img, float* __restrict__ out_lbl, int u, int half,
                                             uint32_t* A, uint32_t* B, uint8_t* sl, float* lutf) {
+    const int dataset = dataset_in & 0xFF;
+    const bool stream_out = (dataset_in & AUG_STREAM_OUT) != 0;
     const aadg_unit& un = units[u];
     // every field of the record the tile geometry needs, read in ONE batch of scalar loads before the first branch (loads left
     // behind an early return come back one by one, each with its own wait)
@@ -1437,11 +1449,11 @@ __device__ __forceinline__ void fused3_body(const uint8_t* __restrict__ pool, co
         const float4 m1 = make_float4(-1.0f, -1.0f, -1.0f, -1.0f), lb = make_float4(lab0, lab0, lab0, lab0);
         for (int y = ya + wv; y < yb; y += 4) {
             const uint32_t off = (uint32_t)y * (uint32_t)crop + (uint32_t)xq;
-            store_stream4(oi + off, m1);
-            store_stream4(oi + plane + off, m1);
-            store_stream4(oi + 2 * (size_t)plane + off, m1);
-            store_stream4(ol + off, lb);
-            if (K == 2) store_stream4(ol + plane + off, make_float4(1.0f, 1.0f, 1.0f, 1.0f));
+            store_out4(oi + off, m1, stream_out);
+            store_out4(oi + plane + off, m1, stream_out);
+            store_out4(oi + 2 * (size_t)plane + off, m1, stream_out);
+            store_out4(ol + off, lb, stream_out);
+            if (K == 2) store_out4(ol + plane + off, make_float4(1.0f, 1.0f, 1.0f, 1.0f), stream_out);
         }
     };
     if (fx > lx) { pad_rows(y0, y1); return; }              // no valid column in this tile
@@ -1581,11 +1593,11 @@ __device__ __forceinline__ void fused3_body(const uint8_t* __restrict__ pool, co
                     l1[i] = m <= 200u ? 1.0f : 0.0f;
                 }
                 const uint32_t off = (uint32_t)y * (uint32_t)crop + (uint32_t)xq;
-                store_stream4(oi + off, make_float4(o[0][0], o[0][1], o[0][2], o[0][3]));
-                store_stream4(oi + plane + off, make_float4(o[1][0], o[1][1], o[1][2], o[1][3]));
-                store_stream4(oi + 2 * (size_t)plane + off, make_float4(o[2][0], o[2][1], o[2][2], o[2][3]));
-                store_stream4(ol + off, make_float4(l0[0], l0[1], l0[2], l0[3]));
-                if (K == 2) store_stream4(ol + plane + off, make_float4(l1[0], l1[1], l1[2], l1[3]));
+                store_out4(oi + off, make_float4(o[0][0], o[0][1], o[0][2], o[0][3]), stream_out);
+                store_out4(oi + plane + off, make_float4(o[1][0], o[1][1], o[1][2], o[1][3]), stream_out);
+                store_out4(oi + 2 * (size_t)plane + off, make_float4(o[2][0], o[2][1], o[2][2], o[2][3]), stream_out);
+                store_out4(ol + off, make_float4(l0[0], l0[1], l0[2], l0[3]), stream_out);
+                if (K == 2) store_out4(ol + plane + off, make_float4(l1[0], l1[1], l1[2], l1[3]), stream_out);
             }
         }
     }
@@ -1718,11 +1730,18 @@ int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int c
 // units -- 268 instead of 278 us per 168-unit call once k_hist_fused fitted the LDS slot a retiring tile workgroup leaves (35 KiB; with
 // 51 KiB it starved until the tile kernel had drained).  3.5 % of the call for a fork / join, a second kernel name and a tile-kernel
 // duration that no longer says how fast the tile kernel is.)
+// the `dataset` argument of the kernels that write the outputs: + AUG_STREAM_OUT when the batch's outputs exceed AUG_STREAM_BYTES
+static inline int aug_dataset_arg(int dataset, int N, int crop) {
+    const size_t K = dataset == AADG_DATASET_OPTIC ? 2 : 1;
+    return dataset | ((size_t)N * (3 + K) * crop * crop * sizeof(float) > AUG_STREAM_BYTES ? AUG_STREAM_OUT : 0);
+}
+
 int forward_cached(const uint8_t* pool, const uint8_t* masks, const UnitRef& ur, int N, int Hs, int Ws, int max_ops, int crop, int dataset,
                    float* out_img, float* out_lbl, uint8_t* ws8, const WsLayout& L, hipStream_t st, int classes, int stats_mask,
                    void* ev_before, void* ev_after, const aadg_aug_lists& ls) {
     const int n_plain = ls.n_plain, n_sharp = ls.n_sharp, n_generic = ls.n_generic, n_late = ls.n_late;
     if (n_late < 0 || n_late > N) return AADG_E_BADARG;
+    const int dsk = aug_dataset_arg(dataset, N, crop);
     const int npix = Hs * Ws;
     uint32_t* hist0 = reinterpret_cast<uint32_t*>(ws8 + L.hist);
     const size_t hist_stage = (size_t)N * HIST_STRIDE;
@@ -1750,13 +1769,13 @@ int forward_cached(const uint8_t* pool, const uint8_t* masks, const UnitRef& ur,
     if (ev_before) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_before), st));
     if (n_plain + 2 * n_sharp > 0) {
         const dim3 g((crop + FT_W - 1) / FT_W, (crop + FT_H - 1) / FT_H, n_plain + 2 * n_sharp);
-        hipLaunchKernelGGL(k_fused3, g, dim3(256), 0, st, pool, masks, ur.units, ls.order, ls.order + n_plain, n_plain, Hs, Ws, crop, dataset,
+        hipLaunchKernelGGL(k_fused3, g, dim3(256), 0, st, pool, masks, ur.units, ls.order, ls.order + n_plain, n_plain, Hs, Ws, crop, dsk,
                            tab, lut, lut_stage_stride, out_img, out_lbl);
         AADG_LAUNCH_CHECK();
     }
     if (n_generic > 0) {
         const dim3 gg((crop + GT_W - 1) / GT_W, (crop + GT_H - 1) / GT_H, n_generic);
-        hipLaunchKernelGGL(k_fused_generic, gg, dim3(256), 0, st, pool, masks, ur.units, ls.order + n_plain + n_sharp, Hs, Ws, crop, dataset,
+        hipLaunchKernelGGL(k_fused_generic, gg, dim3(256), 0, st, pool, masks, ur.units, ls.order + n_plain + n_sharp, Hs, Ws, crop, dsk,
                            tab, lut, lut_stage_stride, out_img, out_lbl);
         AADG_LAUNCH_CHECK();
     }
@@ -1795,6 +1814,7 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
     if ((size_t)N * (size_t)crop > (size_t)1 << 28) return AADG_E_BADARG;
     if (order != nullptr && (n_plain < 0 || n_sharp < 0 || n_generic < 0 || (long long)n_plain + n_sharp + n_generic > N)) return AADG_E_BADARG;
     const WsLayout L = ws_layout(N, Hs, Ws, crop);
+    const int dsk = aug_dataset_arg(dataset, N, crop);
     if (ws_bytes < L.total) return AADG_E_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     uint8_t* ws8 = reinterpret_cast<uint8_t*>(ws);
@@ -1827,7 +1847,7 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
     if (classes & HINT_FUSED) {
         const dim3 g((crop + FT_W - 1) / FT_W, (crop + FT_H - 1) / FT_H, N);
         if (getenv_flag("AADG_FUSED_V1")) {
-            hipLaunchKernelGGL(k_fused<FT_H>, g, dim3(256), 0, st, pool, masks, units, Hs, Ws, crop, dataset, tab, ws8 + L.lut,
+            hipLaunchKernelGGL(k_fused<FT_H>, g, dim3(256), 0, st, pool, masks, units, Hs, Ws, crop, dsk, tab, ws8 + L.lut,
                                (size_t)N * 768, out_img, out_lbl);
             AADG_LAUNCH_CHECK();
         } else {
@@ -1836,7 +1856,7 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
             if (np + 2 * ns > 0) {
                 const dim3 g2(g.x, g.y, np + 2 * ns);
                 hipLaunchKernelGGL(k_fused3, g2, dim3(256), 0, st, pool, masks, units, order, order ? order + np : nullptr, np, Hs, Ws, crop,
-                                   dataset, tab, ws8 + L.lut, (size_t)N * 768, out_img, out_lbl);
+                                   dsk, tab, ws8 + L.lut, (size_t)N * 768, out_img, out_lbl);
             }
             AADG_LAUNCH_CHECK();
         }
@@ -1846,13 +1866,13 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
         if (ng > 0) {
             const dim3 g((crop + GT_W - 1) / GT_W, (crop + GT_H - 1) / GT_H, ng);
             hipLaunchKernelGGL(k_fused_generic, g, dim3(256), 0, st, pool, masks, units, order ? order + n_plain + n_sharp : nullptr, Hs, Ws,
-                               crop, dataset, tab, ws8 + L.lut, (size_t)N * 768, out_img, out_lbl);
+                               crop, dsk, tab, ws8 + L.lut, (size_t)N * 768, out_img, out_lbl);
             AADG_LAUNCH_CHECK();
         }
     }
     if (classes & HINT_STAGED) {
         const dim3 g((crop + 255) / 256, (crop + FIN_ROWS - 1) / FIN_ROWS, N);
-        hipLaunchKernelGGL(k_final, g, dim3(256), 0, st, bufs, masks, ur, Hs, Ws, crop, dataset, tab, out_img, out_lbl);
+        hipLaunchKernelGGL(k_final, g, dim3(256), 0, st, bufs, masks, ur, Hs, Ws, crop, dsk, tab, out_img, out_lbl);
         AADG_LAUNCH_CHECK();
     }
     if (ev_after_final) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_after_final), st));

@@ -71,6 +71,12 @@ __device__ __forceinline__ void aadg_store_stream(void* p, uint4 v) {
     const aadg_u32x4 q = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(q, reinterpret_cast<aadg_u32x4*>(p));
 }
+__device__ __forceinline__ void aadg_store_out(float* p, float4 v, bool stream) {
+    if (stream) aadg_store_stream(p, v); else *reinterpret_cast<float4*>(p) = v;
+}
+__device__ __forceinline__ void aadg_store_out(void* p, uint4 v, bool stream) {
+    if (stream) aadg_store_stream(p, v); else *reinterpret_cast<uint4*>(p) = v;
+}
 // NaN kept quiet -- the same result as aadg_f2bf_bits() on each half, in one VALU instruction instead of ten
 __device__ __forceinline__ uint32_t aadg_f2bf_pk(float lo, float hi) {
     typedef float aadg_f32x2 __attribute__((ext_vector_type(2)));

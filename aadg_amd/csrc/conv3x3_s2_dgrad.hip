@@ -42,7 +42,7 @@ struct DgCfg {
 
 template <int WO>
 __global__ __launch_bounds__(256, 2) void k_dgrad3x3_s2(const uint16_t* __restrict__ A9, const uint16_t* __restrict__ DY,
-                                                        uint16_t* __restrict__ DX, int C, int M, int Ho, int tiles_c, int tiles_r, int pts) {
+                                                        uint16_t* __restrict__ DX, int C, int M, int Ho, int tiles_c, int tiles_r, int pts, int stream) {
     using Cfg = DgCfg<WO>;
     constexpr int ROWS = Cfg::ROWS, BP = Cfg::BP, CPR = WO / 8, SR = ROWS + 1;
     constexpr int NA = 9 * DG_BM * 2, LA = (NA + 255) / 256;
@@ -173,8 +173,14 @@ __global__ __launch_bounds__(256, 2) void k_dgrad3x3_s2(const uint16_t* __restri
             const int c = c0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
             if (c >= C) continue;
             uint16_t* row = dxn + (size_t)c * HWi + (size_t)(2 * i) * WI + 2 * j;
-            __builtin_nontemporal_store(aadg_f2bf_pk(d[0][ni][r], d[1][ni][r]), reinterpret_cast<uint32_t*>(row));
-            __builtin_nontemporal_store(aadg_f2bf_pk(d[2][ni][r], d[3][ni][r]), reinterpret_cast<uint32_t*>(row + WI));
+            const uint32_t v0 = aadg_f2bf_pk(d[0][ni][r], d[1][ni][r]), v1 = aadg_f2bf_pk(d[2][ni][r], d[3][ni][r]);
+            if (stream) {                                  // dX (4x dY) too large to stay cached until the BatchNorm backward reads it
+                __builtin_nontemporal_store(v0, reinterpret_cast<uint32_t*>(row));
+                __builtin_nontemporal_store(v1, reinterpret_cast<uint32_t*>(row + WI));
+            } else {
+                *reinterpret_cast<uint32_t*>(row) = v0;
+                *reinterpret_cast<uint32_t*>(row + WI) = v1;
+            }
         }
     }
 }
@@ -192,7 +198,8 @@ int launch(const uint16_t* A9, const uint16_t* DY, uint16_t* DX, int N, int C, i
                                          (int)Cfg::lds_bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_dgrad3x3_s2<WO>), dim3((unsigned)wgs), dim3(256), Cfg::lds_bytes, st, A9, DY, DX, C, M, Ho, tiles_c, tiles_r, (int)pts);
+    hipLaunchKernelGGL((k_dgrad3x3_s2<WO>), dim3((unsigned)wgs), dim3(256), Cfg::lds_bytes, st, A9, DY, DX, C, M, Ho, tiles_c, tiles_r, (int)pts,
+                       (size_t)N * C * 4 * Ho * WO * 2 > ((size_t)128 << 20) ? 1 : 0);
     AADG_LAUNCH_CHECK();
     return 0;
 }

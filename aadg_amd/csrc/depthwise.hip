@@ -25,8 +25,8 @@ template <> struct Elem<float> {
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
     static __device__ __forceinline__ void load4(const float* p, float* v) { load16(p, v); }
-    static __device__ __forceinline__ void store4(float* p, const float* v) {
-        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    static __device__ __forceinline__ void store4(float* p, const float* v, bool stream) {
+        aadg_store_out(p, make_float4(v[0], v[1], v[2], v[3]), stream);
     }
 };
 template <> struct Elem<__hip_bfloat16> {
@@ -45,13 +45,14 @@ template <> struct Elem<__hip_bfloat16> {
         v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
         v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
     }
-    static __device__ __forceinline__ void store4(__hip_bfloat16* p, const float* v) {
+    static __device__ __forceinline__ void store4(__hip_bfloat16* p, const float* v, bool stream) {
         uint2 t;
         t.x = aadg_f2bf_pk(v[0], v[1]);
         t.y = aadg_f2bf_pk(v[2], v[3]);
         typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
         const u32x2_t q = {t.x, t.y};
-        __builtin_nontemporal_store(q, reinterpret_cast<u32x2_t*>(p));      // written once, re-read after more than a cache of traffic
+        // an output too large to stay cached until its consumer reads it: streaming store
+        if (stream) __builtin_nontemporal_store(q, reinterpret_cast<u32x2_t*>(p)); else *reinterpret_cast<uint2*>(p) = t;
     }
 };
 
@@ -62,10 +63,11 @@ struct DwGeom {
     int PP;                     // planes per workgroup (> 1 only when tiles == 1)
     int w4, rows_per_pass;      // W / 4 lanes per row; rows covered by one pass of the workgroup
     int lds_rows;               // rows staged per plane (TH + 2d, clipped to H)
+    int stream;                 // forward: write the output with streaming stores (set by the launcher for outputs > 128 MB)
 };
 inline bool dw_geom(int H, int W, int d, int elems_per_vec, DwGeom* g) {
     if (H <= 0 || W <= 0 || d <= 0 || W > 256 || (W % elems_per_vec) != 0) return false;
-    g->H = H; g->W = W; g->d = d;
+    g->H = H; g->W = W; g->d = d; g->stream = 0;
     int th = 8192 / W;                                   // ~8 output quads per lane
     while (th > 8 && (size_t)(th + 2 * d < H ? th + 2 * d : H) * W * sizeof(float) > 48 * 1024) th /= 2;
     if (th > H) th = H;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256) void k_dw3x3(const T* __restrict__ x, const fl
                     acc[t] = fmaf(k[3 + b], w1[b][t], acc[t]);
                     acc[t] = fmaf(k[6 + b], w2[b][t], acc[t]);
                 }
-            Elem<T>::store4(py + (size_t)(i0 + r) * g.W + j0, acc);
+            Elem<T>::store4(py + (size_t)(i0 + r) * g.W + j0, acc, g.stream != 0);
 #pragma unroll
             for (int b = 0; b < 3; ++b)
 #pragma unroll
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void k_dw3x3(const T* __restrict__ x, const fl
         const int pl = v / nrows, i = r0 + (v - pl * nrows);
         float acc[4];
         dw_quad(L + (size_t)pl * psz, kw + pl * 9, g, R0, i, j0, acc);
-        Elem<T>::store4(y + (size_t)(plane0 + pl) * psz + (size_t)i * g.W + j0, acc);
+        Elem<T>::store4(y + (size_t)(plane0 + pl) * psz + (size_t)i * g.W + j0, acc, g.stream != 0);
     }
 }
 
@@ -331,6 +333,7 @@ int dw_forward(const T* x, const float* w, T* y, int N, int C, int H, int W, int
     if (!dw_geom(H, W, d, Elem<T>::V, &g) || (long long)N * C * g.tiles > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
     const size_t lds = (size_t)g.PP * g.lds_rows * W * sizeof(float);
     const int planes = N * C, groups = (planes + g.PP - 1) / g.PP;
+    g.stream = (size_t)planes * H * W * sizeof(T) > ((size_t)128 << 20) ? 1 : 0;
     hipLaunchKernelGGL((k_dw3x3<T>), dim3((unsigned)(groups * g.tiles)), dim3(256), lds, st, x, w, y, planes, C, g, flip);
     AADG_LAUNCH_CHECK();
     return 0;

@@ -43,7 +43,7 @@ __device__ __forceinline__ void elem(float z, float y, float gscale, float& bce,
 // grid (chunks, N*K)
 __global__ __launch_bounds__(SL_THREADS) void k_seg_partial(const float* __restrict__ logits, const float* __restrict__ labels,
                                                             int HW, float gscale, float* __restrict__ grad,
-                                                            Partial* __restrict__ part) {
+                                                            Partial* __restrict__ part, int stream) {
     const int plane = blockIdx.y;
     const size_t base = (size_t)plane * HW;
     const int c0 = blockIdx.x * SL_CHUNK;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_seg_partial(const float* __restr
             elem(z.y, y.y, gscale, bce, tp, fp, fn, grad ? &g.y : nullptr);
             elem(z.z, y.z, gscale, bce, tp, fp, fn, grad ? &g.z : nullptr);
             elem(z.w, y.w, gscale, bce, tp, fp, fn, grad ? &g.w : nullptr);
-            if (grad) aadg_store_stream(grad + base + i, g);          // written once, read by the backward ~1 GB of traffic later
+            if (grad) aadg_store_out(grad + base + i, g, stream != 0);    // a large gradient is read by the backward only after ~1 GB of other traffic
         }
     } else {
         for (int i = c0 + threadIdx.x; i < c1; i += SL_THREADS) {
@@ -140,7 +140,7 @@ extern "C" int aadg_seg_bce_dice_f32(const float* logits, const float* labels, i
     // d mean_j(BCE_j) / dz: every element of policy j weighs 1 / (M * (N/M) * K * HW)
     const float gscale = (float)(1.0 / ((double)N * K * HW));
     hipLaunchKernelGGL(k_seg_partial, dim3(chunks, N * K), dim3(SL_THREADS), 0, st, logits, labels, HW, gscale,
-                       grad_logits, part);
+                       grad_logits, part, (size_t)N * K * HW * sizeof(float) > ((size_t)128 << 20) ? 1 : 0);
     AADG_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_seg_final, dim3(M + K), dim3(64), 0, st, part, N, K, HW, M, chunks, out_bce, out_dice);
     AADG_LAUNCH_CHECK();

@@ -21,10 +21,12 @@ template <> struct Vec4<float> {
     }
     static constexpr int V16 = 4;                       // elements per 16-byte load
     static __device__ __forceinline__ void ld16(const float* p, float* v) { ld4(p, v); }
-    static __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
-        aadg_store_stream(p, make_float4(a, b, c, d));
+    static __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d, bool stream = false) {
+        aadg_store_out(p, make_float4(a, b, c, d), stream);
     }
-    static __device__ __forceinline__ void st8(float* p, const float* v) { st4(p, v[0], v[1], v[2], v[3]); st4(p + 4, v[4], v[5], v[6], v[7]); }
+    static __device__ __forceinline__ void st8(float* p, const float* v, bool stream = false) {
+        st4(p, v[0], v[1], v[2], v[3], stream); st4(p + 4, v[4], v[5], v[6], v[7], stream);
+    }
     static __device__ __forceinline__ void st1(float* p, float a) { *p = a; }
 };
 template <> struct Vec4<__hip_bfloat16> {
@@ -41,14 +43,14 @@ template <> struct Vec4<__hip_bfloat16> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(u[i] << 16); v[2 * i + 1] = __uint_as_float(u[i] & 0xFFFF0000u); }
     }
-    static __device__ __forceinline__ void st4(__hip_bfloat16* p, float a, float b, float c, float d) {
+    static __device__ __forceinline__ void st4(__hip_bfloat16* p, float a, float b, float c, float d, bool stream = false) {
         uint2 v;
         v.x = aadg_f2bf_pk(a, b);
         v.y = aadg_f2bf_pk(c, d);
         *reinterpret_cast<uint2*>(p) = v;
     }
-    static __device__ __forceinline__ void st8(__hip_bfloat16* p, const float* v) {      // one 16-byte store
-        aadg_store_stream(p, make_uint4(aadg_f2bf_pk(v[0], v[1]), aadg_f2bf_pk(v[2], v[3]), aadg_f2bf_pk(v[4], v[5]), aadg_f2bf_pk(v[6], v[7])));
+    static __device__ __forceinline__ void st8(__hip_bfloat16* p, const float* v, bool stream = false) {      // one 16-byte store
+        aadg_store_out(p, make_uint4(aadg_f2bf_pk(v[0], v[1]), aadg_f2bf_pk(v[2], v[3]), aadg_f2bf_pk(v[4], v[5]), aadg_f2bf_pk(v[6], v[7])), stream);
     }
     static __device__ __forceinline__ void st1(__hip_bfloat16* p, float a) { *p = __float2bfloat16(a); }
 };
@@ -112,7 +114,7 @@ constexpr int UP_LDS_MAX = 4096, UP_ROWS = 32, UP_WHOLE_PLANE = 16384;
 
 template <typename T, int OPI>
 __global__ __launch_bounds__(256) void k_upsample_lds(const T* __restrict__ in, T* __restrict__ out, int h, int w, int H, int W,
-                                                      float sy, float sx, int C, long long out_img_stride, int plane0, int rows) {
+                                                      float sy, float sx, int C, long long out_img_stride, int plane0, int rows, int stream) {
     __shared__ __attribute__((aligned(16))) float P[UP_LDS_MAX];
     const size_t plane = (size_t)plane0 + blockIdx.y;
     const T* pin = in + plane * (size_t)h * w;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void k_upsample_lds(const T* __restrict__ in, 
         }
         T* dst = po + (size_t)Y * W + x0;
         if (vec) {
-            if constexpr (OPI == 8) Vec4<T>::st8(dst, v); else Vec4<T>::st4(dst, v[0], v[1], v[2], v[3]);
+            if constexpr (OPI == 8) Vec4<T>::st8(dst, v, stream != 0); else Vec4<T>::st4(dst, v[0], v[1], v[2], v[3], stream != 0);
         } else {
             for (int k = 0; k < OPI && x0 + k < W; ++k) Vec4<T>::st1(dst + k, v[k]);
         }
@@ -359,6 +361,8 @@ extern "C" int aadg_upsample_bilinear2d_strided(const void* in, void* out, int N
     const bool lds_path = h * w <= UP_LDS_MAX;
     const int rows_per_block = 16;
     const int xgroups = (W + 255) / 256;
+    // an output too large to stay cached until its consumer reads it is written with streaming stores
+    const int stream_out = (size_t)planes * H * W * (dtype == 0 ? 4 : 2) > ((size_t)128 << 20) ? 1 : 0;
     for (int p0 = 0; p0 < planes; p0 += 65535) {          // gridDim.y limit
         const int np = planes - p0 < 65535 ? planes - p0 : 65535;
         if (lds_path) {
@@ -368,13 +372,13 @@ extern "C" int aadg_upsample_bilinear2d_strided(const void* in, void* out, int N
             const bool wide = dtype == 1 && (W & 7) == 0 && (((uintptr_t)out) & 15u) == 0 && (out_image_stride & 7) == 0 && (((long long)H * W) & 7) == 0;
             if (dtype == 0)
                 hipLaunchKernelGGL((k_upsample_lds<float, 4>), gl, dim3(256), 0, st, reinterpret_cast<const float*>(in),
-                                   reinterpret_cast<float*>(out), h, w, H, W, sy, sx, C, out_image_stride, p0, rows);
+                                   reinterpret_cast<float*>(out), h, w, H, W, sy, sx, C, out_image_stride, p0, rows, stream_out);
             else if (wide)
                 hipLaunchKernelGGL((k_upsample_lds<__hip_bfloat16, 8>), gl, dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(in),
-                                   reinterpret_cast<__hip_bfloat16*>(out), h, w, H, W, sy, sx, C, out_image_stride, p0, rows);
+                                   reinterpret_cast<__hip_bfloat16*>(out), h, w, H, W, sy, sx, C, out_image_stride, p0, rows, stream_out);
             else
                 hipLaunchKernelGGL((k_upsample_lds<__hip_bfloat16, 4>), gl, dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(in),
-                                   reinterpret_cast<__hip_bfloat16*>(out), h, w, H, W, sy, sx, C, out_image_stride, p0, rows);
+                                   reinterpret_cast<__hip_bfloat16*>(out), h, w, H, W, sy, sx, C, out_image_stride, p0, rows, stream_out);
         } else {
             const dim3 g(xgroups * ((H + rows_per_block - 1) / rows_per_block), np);
             if (dtype == 0)
