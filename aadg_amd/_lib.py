@@ -1309,12 +1309,27 @@ class WlItem(ctypes.Structure):
 
 _SHADOWS = {}          # id(weight) -> _Shadow
 
+# A shadow is valid while its master weight is unchanged.  In-place ATen ops bump `weight._version` -- but torch's FUSED optimizers
+# (`Adam(fused=True)`: torch._fused_adam_) update the parameters without bumping it (checked on torch 2.10), so every optimizer step of
+# ANY optimizer also advances this epoch (a global post-step hook, installed with the first tracked model).
+_WEIGHTS_EPOCH = [0]
+_STEP_HOOK = []
+
+
+def _install_step_hook():
+    if not _STEP_HOOK:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+
+        def bump(optimizer, args, kwargs):
+            _WEIGHTS_EPOCH[0] += 1
+        _STEP_HOOK.append(register_optimizer_step_post_hook(bump))
+
 
 class _Shadow(object):
-    __slots__ = ("ref", "plain", "fwd", "bwd", "version", "ptr", "flip")
+    __slots__ = ("ref", "plain", "fwd", "bwd", "version", "epoch", "ptr", "flip")
 
     def valid_for(self, weight):
-        return self.version == weight._version and self.ref() is weight
+        return self.version == weight._version and self.epoch == _WEIGHTS_EPOCH[0] and self.ref() is weight
 
 
 def cast_weight(weight, dtype):
@@ -1349,13 +1364,13 @@ class _WeightLayouts(object):
         for i, (w, flip) in enumerate(self.entries):
             Co, Ci, taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
             e = _Shadow()
-            e.ref, e.version, e.ptr, e.flip = weakref.ref(w), -1, w.data_ptr(), flip
+            e.ref, e.version, e.epoch, e.ptr, e.flip = weakref.ref(w), -1, -1, w.data_ptr(), flip
             e.plain = torch.empty(w.shape, dtype=torch.bfloat16, device=dev)
             e.fwd = torch.empty((taps, Co, Ci), dtype=torch.bfloat16, device=dev) if taps > 1 else e.plain.view(1, Co, Ci)
             e.bwd = torch.empty((taps, Ci, Co), dtype=torch.bfloat16, device=dev)
             _SHADOWS[id(w)] = e
             items[i] = WlItem(w.data_ptr(), e.plain.data_ptr(), e.fwd.data_ptr() if taps > 1 else None, e.bwd.data_ptr(), Co, Ci, taps, flip)
-            tiles += [(i, o0, c0) for o0 in range(0, Co, 32) for c0 in range(0, Ci, 32)]
+            tiles += [(i, o0, c0) for o0 in range(0, Co, 32) for c0 in range(0, Ci, 256 if taps == 1 else 32)]
         raw = np.frombuffer(bytes(items), dtype=np.uint8).copy()
         self.items = torch.from_numpy(raw).to(dev)
         self.tiles = torch.tensor(tiles, dtype=torch.int32).to(dev)
@@ -1369,7 +1384,7 @@ class _WeightLayouts(object):
             if e is None or e.ref() is not w or e.ptr != w.data_ptr() or e.plain.device != w.device:
                 stale = True
                 break
-            changed = changed or e.version != w._version
+            changed = changed or e.version != w._version or e.epoch != _WEIGHTS_EPOCH[0]
         if stale:
             self._build()
             changed = True
@@ -1378,7 +1393,8 @@ class _WeightLayouts(object):
         _check(load().aadg_weight_layouts_bf16(self.items.data_ptr(), self.tiles.data_ptr(), self.n_tiles, _stream()),
                "aadg_weight_layouts_bf16")
         for w, _ in self.entries:
-            _SHADOWS[id(w)].version = w._version
+            e = _SHADOWS[id(w)]
+            e.version, e.epoch = w._version, _WEIGHTS_EPOCH[0]
 
 
 def track_bf16_weights(model, module_types):
@@ -1392,6 +1408,7 @@ def track_bf16_weights(model, module_types):
             stride = m.stride[0] if isinstance(m.stride, (tuple, list)) else m.stride
             entries.append((m.weight, 1 if (m.weight.shape[2] == 3 and stride == 1) else 0))
     if entries:
+        _install_step_hook()
         wl = _WeightLayouts(entries)
         model.register_forward_pre_hook(lambda mod, args: wl.refresh())
         model._aadg_weight_layouts = wl

@@ -5,20 +5,21 @@
 //                         (mirrored taps) for the stride-1 3x3 convolution, T' = t for k_dgrad3x3_s2 and for 1x1
 // Before: one `weight.to(bfloat16)` multi-tensor copy plus ~70 `permute(...).contiguous()` launches of 5-7 us per step (one per
 // own convolution and direction), a cost that does not shrink with the per-rank batch.
-// Workgroup = one 32 x 32 (Co x Ci) tile of one layer with all its taps, through LDS so that all three outputs are written in
-// 64-byte runs.
+// Workgroup = one 32 x 32 (Co x Ci) tile of one layer with all its taps (32 x 256 for 1x1 weights), through LDS so that all three
+// outputs are written in 64-byte runs.
 #include "common.h"
 
 namespace {
 
-constexpr int WL_T = 32, WL_MAXT = 9;
+constexpr int WL_T = 32, WL_MAXT = 9, WL_C1 = 256;
 
-__global__ __launch_bounds__(256) void k_weight_layouts(const aadg_wl_item* __restrict__ items, const int32_t* __restrict__ tiles) {
-    __shared__ uint16_t L[WL_T][WL_T * WL_MAXT + 2];
-    const int item = tiles[3 * blockIdx.x], o0 = tiles[3 * blockIdx.x + 1], c0 = tiles[3 * blockIdx.x + 2];
-    const aadg_wl_item it = items[item];
-    const int Co = it.Co, Ci = it.Ci, T = it.taps;
-    const int no = min(WL_T, Co - o0), nc = min(WL_T, Ci - c0);
+// T, NO, NC > 0: compile-time taps / tile extents (full 32 x 32 tiles of 1x1 and 3x3 weights: index arithmetic by constants);
+// 0: run-time values (edge tiles, other tap counts)
+template <int TT, int FULL>
+__device__ __forceinline__ void wl_tile(const aadg_wl_item& it, int o0, int c0, uint16_t (*L)[WL_T * WL_MAXT + 2]) {
+    const int Co = it.Co, Ci = it.Ci, T = TT > 0 ? TT : it.taps;
+    const int ncmax = T == 1 ? WL_C1 : WL_T;                   // in channels per tile: 256 for 1x1 weights (the LDS row holds 288 values)
+    const int no = FULL ? WL_T : min(WL_T, Co - o0), nc = FULL ? (TT == 1 ? WL_C1 : WL_T) : min(ncmax, Ci - c0);
     const int run = nc * T;                                    // contiguous source elements per out channel of the tile
     const float* w = (const float*)it.w;
     uint16_t* plain = (uint16_t*)it.plain;
@@ -32,23 +33,34 @@ __global__ __launch_bounds__(256) void k_weight_layouts(const aadg_wl_item* __re
     __syncthreads();
     uint16_t* fwd = (uint16_t*)it.fwd;
     uint16_t* bwd = (uint16_t*)it.bwd;
+    const int per_tap = no * nc;
     if (fwd != nullptr)
-        for (int e = threadIdx.x; e < T * no * nc; e += 256) {
-            const int t = e / (no * nc), r = e - t * (no * nc), o = r / nc, c = r - o * nc;
+        for (int e = threadIdx.x; e < T * per_tap; e += 256) {
+            const int t = e / per_tap, r = e - t * per_tap, o = r / nc, c = r - o * nc;
             fwd[((size_t)t * Co + o0 + o) * Ci + c0 + c] = L[o][c * T + t];
         }
     if (bwd != nullptr)
-        for (int e = threadIdx.x; e < T * no * nc; e += 256) {
-            const int t = e / (no * nc), r = e - t * (no * nc), c = r / no, o = r - c * no;
+        for (int e = threadIdx.x; e < T * per_tap; e += 256) {
+            const int t = e / per_tap, r = e - t * per_tap, c = r / no, o = r - c * no;
             const int tt = it.flip ? T - 1 - t : t;
             bwd[((size_t)tt * Ci + c0 + c) * Co + o0 + o] = L[o][c * T + t];
         }
 }
 
+__global__ __launch_bounds__(256) void k_weight_layouts(const aadg_wl_item* __restrict__ items, const int32_t* __restrict__ tiles) {
+    __shared__ uint16_t L[WL_T][WL_T * WL_MAXT + 2];
+    const int item = tiles[3 * blockIdx.x], o0 = tiles[3 * blockIdx.x + 1], c0 = tiles[3 * blockIdx.x + 2];
+    const aadg_wl_item it = items[item];
+    const bool full = it.Co - o0 >= WL_T && it.Ci - c0 >= (it.taps == 1 ? WL_C1 : WL_T);
+    if (full && it.taps == 9) wl_tile<9, 1>(it, o0, c0, L);
+    else if (full && it.taps == 1) wl_tile<1, 1>(it, o0, c0, L);
+    else wl_tile<0, 0>(it, o0, c0, L);
+}
+
 }  // namespace
 
 /* items: DEVICE array of aadg_wl_item; tiles: DEVICE int32 [n_tiles][3] = (item, first out channel, first in channel) of every
- * 32 x 32 tile of every item (the caller enumerates them once).  taps <= 9. */
+ * tile of every item: 32 out channels x 32 in channels, 32 x 256 for taps == 1 (the caller enumerates them once).  taps <= 9. */
 extern "C" int aadg_weight_layouts_bf16(const aadg_wl_item* items, const int32_t* tiles, int n_tiles, void* stream) {
     if (items == nullptr || tiles == nullptr || n_tiles < 0) return AADG_E_BADARG;
     if (n_tiles == 0) return 0;

@@ -358,7 +358,8 @@ int aadg_conv1x1_wgrad_bf16(const void* dy, const void* x, float* dweight, int N
  * w [Co][Ci][taps] float32 -> plain [Co][Ci][taps], fwd [taps][Co][Ci], bwd [taps'][Ci][Co] bfloat16 (taps' = taps - 1 - t when flip,
  * the mirrored taps of a stride-1 input gradient; each output may be NULL).  Replaces the reference-side `weight.to(bfloat16)` under
  * autocast plus one permute + contiguous per convolution and direction.  `items` is a DEVICE array, `tiles` a DEVICE int32
- * [n_tiles][3] = (item, first out channel, first in channel) of every 32 x 32 tile of every item; taps <= 9. */
+ * [n_tiles][3] = (item, first out channel, first in channel) of every tile of every item -- 32 out x 32 in channels, 32 x 256 for
+ * taps == 1; taps <= 9. */
 typedef struct aadg_wl_item {
     const void* w;
     void* plain;

@@ -89,7 +89,7 @@ def test_batched_step_bookkeeping(hip):
     bns = [m for m in b.modules() if type(m) is torch.nn.BatchNorm2d]
     assert len(convs) > 40 and len(bns) > 40
     x = torch.randn(4, 3, 64, 64, device="cuda")
-    for step in range(2):
+    for step in range(3):                                  # the checks of step 2 see the refresh after the fused optimizer step
         with torch.autocast("cuda", dtype=torch.bfloat16):
             out, feat = b(x)
         assert torch.isfinite(out.float()).all()
@@ -101,14 +101,22 @@ def test_batched_step_bookkeeping(hip):
             assert torch.equal(fwd, sh.permute(2, 3, 0, 1).reshape(k * k, Co, Ci))
             mirrored = k == 3 and m.stride[0] == 1                # stride-1 input gradient = the forward kernel with mirrored taps
             assert torch.equal(bwd, (sh.flip(2, 3) if mirrored else sh).permute(2, 3, 1, 0).reshape(k * k, Ci, Co))
-        with torch.no_grad():                              # an "optimizer step": stale until the next forward refreshes them
-            for p in b.parameters():
-                p.mul_(0.9)
+        if step != 1:
+            with torch.no_grad():                          # an in-place update: stale until the next forward refreshes them
+                for p in b.parameters():
+                    p.mul_(0.9)
+        else:
+            # torch's fused Adam updates the parameters WITHOUT bumping their version counters: the shadows must still go stale
+            opt = torch.optim.Adam(b.parameters(), lr=1e-2, fused=True)
+            (out.float().square().mean() + feat.float().square().mean()).backward()
+            before = convs[0].weight.detach().clone()
+            opt.step()
+            assert not torch.equal(before, convs[0].weight.detach())
         w = convs[0].weight
         assert torch.equal(hip.cast_weight(w, torch.bfloat16), w.detach().to(torch.bfloat16))      # version changed: falls back to a cast
         assert hip.weight_layout(w, "fwd") is None and hip.weight_layout(w, "bwd") is None          # ... and to per-call copies
-    assert all(m.num_batches_tracked.item() == 2 for m in bns)
+    assert all(m.num_batches_tracked.item() == 3 for m in bns)
     b.eval()
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         b(x)
-    assert all(m.num_batches_tracked.item() == 2 for m in bns)                                      # eval: no bump
+    assert all(m.num_batches_tracked.item() == 3 for m in bns)                                      # eval: no bump
