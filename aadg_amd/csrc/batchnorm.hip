@@ -33,7 +33,7 @@ template <typename T> struct Pack;
 template <> struct Pack<float> {
     static constexpr int N = 4;
     static __device__ __forceinline__ void load(const float* p, float* v) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
+        const float4 t = aadg_load_stream(p);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
     static __device__ __forceinline__ void store(float* p, const float* v, bool stream) {
@@ -46,7 +46,9 @@ template <> struct Pack<float> {
 template <> struct Pack<__hip_bfloat16> {
     static constexpr int N = 8;
     static __device__ __forceinline__ void load(const __hip_bfloat16* p, float* v) {
-        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        // every activation / gradient stream of these kernels is read once per pass: streaming (non-temporal) loads keep them from
+        // flushing L2 / the Infinity Cache on their way through (-1.4 ... -1.8 ms of 98.7 per step at 144 rows, -0.1 of 18.8 at 18 rows)
+        const uint4 t = aadg_load_stream(p);
         const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

@@ -71,6 +71,15 @@ __device__ __forceinline__ void aadg_store_stream(void* p, uint4 v) {
     const aadg_u32x4 q = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(q, reinterpret_cast<aadg_u32x4*>(p));
 }
+// ... and 16-byte streaming loads for inputs that are read once
+__device__ __forceinline__ float4 aadg_load_stream(const float* p) {
+    const aadg_f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const aadg_f32x4*>(p));
+    return make_float4(q.x, q.y, q.z, q.w);
+}
+__device__ __forceinline__ uint4 aadg_load_stream(const void* p) {
+    const aadg_u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const aadg_u32x4*>(p));
+    return make_uint4(q.x, q.y, q.z, q.w);
+}
 __device__ __forceinline__ void aadg_store_out(float* p, float4 v, bool stream) {
     if (stream) aadg_store_stream(p, v); else *reinterpret_cast<float4*>(p) = v;
 }
