@@ -21,7 +21,7 @@ template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int V = 4;     // elements per 16-byte load
     static __device__ __forceinline__ void load16(const float* p, float* v) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
+        const float4 t = aadg_load_stream(p);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
     static __device__ __forceinline__ void load4(const float* p, float* v) { load16(p, v); }
@@ -32,7 +32,7 @@ template <> struct Elem<float> {
 template <> struct Elem<__hip_bfloat16> {
     static constexpr int V = 8;
     static __device__ __forceinline__ void load16(const __hip_bfloat16* p, float* v) {
-        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const uint4 t = aadg_load_stream(p);
         const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

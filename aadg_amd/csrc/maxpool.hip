@@ -14,11 +14,11 @@ namespace {
 template <typename T> struct Px;
 template <> struct Px<float> {
     static __device__ __forceinline__ void load8(const float* p, float* v) {
-        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        const float4 a = aadg_load_stream(p), b = aadg_load_stream(p + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     }
     static __device__ __forceinline__ void load4(const float* p, float* v) {
-        const float4 a = *reinterpret_cast<const float4*>(p);
+        const float4 a = aadg_load_stream(p);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
     }
     static __device__ __forceinline__ float load1(const float* p) { return *p; }
@@ -29,7 +29,7 @@ template <> struct Px<float> {
 };
 template <> struct Px<__hip_bfloat16> {
     static __device__ __forceinline__ void load8(const __hip_bfloat16* p, float* v) {
-        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const uint4 t = aadg_load_stream(p);
         const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

@@ -53,8 +53,8 @@ __global__ __launch_bounds__(SL_THREADS) void k_seg_partial(const float* __restr
     const bool vec = ((HW & 3) == 0) && ((((uintptr_t)logits | (uintptr_t)labels | (uintptr_t)grad) & 15) == 0);
     if (vec) {
         for (int i = c0 + threadIdx.x * 4; i < c1; i += SL_THREADS * 4) {
-            const float4 z = *reinterpret_cast<const float4*>(logits + base + i);
-            const float4 y = *reinterpret_cast<const float4*>(labels + base + i);
+            const float4 z = aadg_load_stream(logits + base + i);       // logits and labels are read once
+            const float4 y = aadg_load_stream(labels + base + i);
             float4 g;
             elem(z.x, y.x, gscale, bce, tp, fp, fn, grad ? &g.x : nullptr);
             elem(z.y, y.y, gscale, bce, tp, fp, fn, grad ? &g.y : nullptr);

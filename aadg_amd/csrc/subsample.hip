@@ -14,11 +14,11 @@ template <typename T> struct Sub;
 template <> struct Sub<float> {
     static constexpr int V = 4;
     static __device__ __forceinline__ void gather(const float* row, float* y) {
-        const float4 a = *reinterpret_cast<const float4*>(row), b = *reinterpret_cast<const float4*>(row + 4);
+        const float4 a = aadg_load_stream(row), b = aadg_load_stream(row + 4);
         *reinterpret_cast<float4*>(y) = make_float4(a.x, a.z, b.x, b.z);
     }
     static __device__ __forceinline__ void scatter(const float* g, float* even_row, float* odd_row) {
-        const float4 v = *reinterpret_cast<const float4*>(g);
+        const float4 v = aadg_load_stream(g);
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(even_row) = make_float4(v.x, 0.f, v.y, 0.f);
         *reinterpret_cast<float4*>(even_row + 4) = make_float4(v.z, 0.f, v.w, 0.f);
@@ -28,13 +28,13 @@ template <> struct Sub<float> {
 template <> struct Sub<__hip_bfloat16> {
     static constexpr int V = 8;
     static __device__ __forceinline__ void gather(const __hip_bfloat16* row, __hip_bfloat16* y) {
-        const uint4 a = *reinterpret_cast<const uint4*>(row), b = *reinterpret_cast<const uint4*>(row + 8);
+        const uint4 a = aadg_load_stream(row), b = aadg_load_stream(row + 8);
         // the even elements are the low halves of each 32-bit pair
         *reinterpret_cast<uint4*>(y) = make_uint4((a.x & 0xFFFFu) | (a.y << 16), (a.z & 0xFFFFu) | (a.w << 16),
                                                   (b.x & 0xFFFFu) | (b.y << 16), (b.z & 0xFFFFu) | (b.w << 16));
     }
     static __device__ __forceinline__ void scatter(const __hip_bfloat16* g, __hip_bfloat16* even_row, __hip_bfloat16* odd_row) {
-        const uint4 v = *reinterpret_cast<const uint4*>(g);
+        const uint4 v = aadg_load_stream(g);
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
         *reinterpret_cast<uint4*>(even_row) = make_uint4(v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16);
         *reinterpret_cast<uint4*>(even_row + 8) = make_uint4(v.z & 0xFFFFu, v.z >> 16, v.w & 0xFFFFu, v.w >> 16);

@@ -38,7 +38,7 @@ template <> struct Vec4<__hip_bfloat16> {
     }
     static constexpr int V16 = 8;
     static __device__ __forceinline__ void ld16(const __hip_bfloat16* p, float* v) {
-        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const uint4 t = aadg_load_stream(p);
         const uint32_t u[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(u[i] << 16); v[2 * i + 1] = __uint_as_float(u[i] & 0xFFFF0000u); }
