@@ -36,6 +36,10 @@ template <> struct Pack<float> {
         const float4 t = aadg_load_stream(p);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
+    static __device__ __forceinline__ void load_keep(const float* p, float* v) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
     static __device__ __forceinline__ void store(float* p, const float* v, bool stream) {
         aadg_store_out(p, make_float4(v[0], v[1], v[2], v[3]), stream);
     }
@@ -49,6 +53,15 @@ template <> struct Pack<__hip_bfloat16> {
         // every activation / gradient stream of these kernels is read once per pass: streaming (non-temporal) loads keep them from
         // flushing L2 / the Infinity Cache on their way through (-1.4 ... -1.8 ms of 98.7 per step at 144 rows, -0.1 of 18.8 at 18 rows)
         const uint4 t = aadg_load_stream(p);
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+        }
+    }
+    static __device__ __forceinline__ void load_keep(const __hip_bfloat16* p, float* v) {      // a stream the next kernel reads again
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
         const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -189,7 +202,7 @@ __global__ __launch_bounds__(256) void k_bn_reduce_fwd(const T* __restrict__ x, 
 #pragma unroll 4
         for (int j = part * plen + threadIdx.x; j < j1; j += blockDim.x) {
             float xv[VEC];
-            if (VEC == 1) xv[0] = Pack<T>::load1(x + base + j); else Pack<T>::load(x + base + (size_t)j * VEC, xv);
+            if (VEC == 1) xv[0] = Pack<T>::load1(x + base + j); else Pack<T>::load_keep(x + base + (size_t)j * VEC, xv);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) { s0 += xv[i]; s1 = fmaf(xv[i], xv[i], s1); }
         }
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(256) void k_bn_reduce_bwd(const T* __restrict__ x, 
             const size_t off = base + (size_t)j * VEC;
             float xv[VEC], gv[VEC], yv[VEC];
             if (VEC == 1) { xv[0] = Pack<T>::load1(x + off); gv[0] = Pack<T>::load1(dyp + j); }
-            else { Pack<T>::load(x + off, xv); Pack<T>::load(dyp + (size_t)j * VEC, gv); }
+            else { Pack<T>::load_keep(x + off, xv); Pack<T>::load_keep(dyp + (size_t)j * VEC, gv); }
             uint32_t mbits = 0;
             if (MK == 1) mbits = mask[strip * len + j];
             if (MK == 2 && y != nullptr) {
