@@ -41,7 +41,9 @@ template <> struct Elem<__hip_bfloat16> {
         }
     }
     static __device__ __forceinline__ void load4(const __hip_bfloat16* p, float* v) {
-        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        typedef uint32_t u32x2_l __attribute__((ext_vector_type(2)));
+        const u32x2_l tq = __builtin_nontemporal_load(reinterpret_cast<const u32x2_l*>(p));       // dy of the weight gradient: read once
+        const uint2 t = make_uint2(tq.x, tq.y);
         v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
         v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
     }
