@@ -11,6 +11,7 @@ What differs from the reference, by design:
   * multi-GPU: rows are sharded over ranks, embeddings are all-gathered once (distributed.py), rewards are
     computed redundantly and identically on every rank.
 """
+import contextlib
 import json
 import os
 import time
@@ -104,41 +105,53 @@ def inner_iteration(config, sample, model, discriminator, dis_criterion, model_o
     with _autocast(args):
         seg_output, feature = model(input)
     feature = feature.detach().float()
-    # action: EMA-branch embeddings (no grad, outside the DDP wrapper: nothing to reduce); bp: online branch trained on the
-    # soft domain codes
-    dis_output, domain_feature, fe_norm = _bare(discriminator)(feature, momentum=True, return_feature=True, return_norm=True)
+    # The reward branch -- EMA-branch embeddings (no grad, outside the DDP wrapper: nothing to reduce) -> all-gather -> Sinkhorn reward ->
+    # (last batch) PPO update -- feeds only the controller.  Its kernels are tiny (k_embed 86 us on 9 workgroups, 18 Sinkhorn problems = 18
+    # workgroups, the collective's latency), so with the fused controller path it runs on the controller's stream, beside the loss and the
+    # backward passes of the segmentation model instead of in front of them.
+    side = getattr(args, '_side_stream', None) if feature.is_cuda else None
+    main = torch.cuda.current_stream() if side is not None else None
+    if side is not None:
+        side.wait_stream(main)                            # the features are complete (and last step's EMA update is)
+        feature.record_stream(side)
+        domain_gt.record_stream(side)
+    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+        dis_output, domain_feature, fe_norm = _bare(discriminator)(feature, momentum=True, return_feature=True, return_norm=True)
+        with torch.no_grad():
+            logp = torch.log_softmax(dis_output, dim=1)
+            dis_loss = -(domain_gt * logp).sum(dim=1).mean()        # mean_j CE(dis_output[j::M], gt[j::M]) = mean over rows
+        # reward: all-gather the local [n_local, 128] embeddings once (back into collate order), then ONE kernel for all M x P problems
+        fe_all = domain_feature.contiguous()
+        if sharded:
+            emulate = bool(getattr(args, 'emulate_shards', 0))
+            if not emulate and not adist.is_dist():
+                raise RuntimeError("row-sharded batch without an initialised process group")
+            fe_all = plan.gather(fe_all, emulate=emulate)
+            fe_norm = None                                   # the gathered rows' norms are recomputed by the reward kernel
+        before = rewards.clone()
+        B = n_rows // (M * n_domains)
+        if n_domains >= 2:                               # a single source domain has no domain pair to compare (BASELINE configs[0])
+            _lib.sinkhorn_rewards(fe_all, n_domains, B, M, rewards=rewards, row_norm=fe_norm)
+        diversity_ot = (rewards - before).sum()
+        if after_rewards is not None:
+            after_rewards()
+    # bp: online branch trained on the soft domain codes
     dis_loss_bp = dis_criterion(discriminator(feature, momentum=False), domain_gt)
     # sigmoid + per-policy BCE + Dice, one fused pass (forward + gradient).  mean_j BCE_j == mean over all rows (every policy
     # owns N/M rows), so a rank whose local rows are not policy-interleaved takes the plain mean of its rows.
     seg_loss, _, dice = _lib.policy_bce_loss(seg_output.float(), mask_gt, 1 if sharded else M)
-    with torch.no_grad():
-        logp = torch.log_softmax(dis_output, dim=1)
-        dis_loss = -(domain_gt * logp).sum(dim=1).mean()            # mean_j CE(dis_output[j::M], gt[j::M]) = mean over rows
     if sharded:
         # DDP averages the ranks' gradients: weight the local means by n_local * G / N (count-weighted mean, RowPlan)
         seg_loss = seg_loss * plan.loss_weight
         dis_loss_bp = dis_loss_bp * plan.loss_weight
-    # reward: all-gather the local [n_local, 128] embeddings once (back into collate order), then ONE kernel for all M x P problems
-    fe_all = domain_feature.contiguous()
-    if sharded:
-        emulate = bool(getattr(args, 'emulate_shards', 0))
-        if not emulate and not adist.is_dist():
-            raise RuntimeError("row-sharded batch without an initialised process group")
-        fe_all = plan.gather(fe_all, emulate=emulate)
-        fe_norm = None                                       # the gathered rows' norms are recomputed by the reward kernel
-    before = rewards.clone()
-    B = n_rows // (M * n_domains)
-    if n_domains >= 2:                                   # a single source domain has no domain pair to compare (BASELINE configs[0])
-        _lib.sinkhorn_rewards(fe_all, n_domains, B, M, rewards=rewards, row_norm=fe_norm)
-    diversity_ot = (rewards - before).sum()
-    if after_rewards is not None:
-        after_rewards()
     model_optimizer.zero_grad(set_to_none=True)
     seg_loss.backward()
     model_optimizer.step()
     dis_optimizer.zero_grad(set_to_none=True)
     dis_loss_bp.backward()
     dis_optimizer.step()
+    if side is not None:
+        main.wait_stream(side)                            # rewards, dis_loss, diversity_ot come from there
     return seg_loss.detach(), dis_loss, diversity_ot, dice
 
 
@@ -302,6 +315,7 @@ class SearchState(object):
         early = {}
         hook = None
         side = None
+        self.args._side_stream = None
         if getattr(self.graphed, 'fused', False) and getattr(self.args, 'early_controller_update', True):
             # The controller kernels (5 PPO epochs + the next sampling: ~0.6 ms on 6 workgroups) touch nothing the backbone touches:
             # they run on a stream of their own, beside the backward passes instead of in front of them (0.6 ms per step on every
@@ -309,6 +323,8 @@ class SearchState(object):
             # it has enqueued those backward passes.
             main = torch.cuda.current_stream()
             side = self._controller_stream(main) if (main.device.type == 'cuda' and os.environ.get('AADG_CTRL_STREAM', '1') != '0') else None
+
+            self.args._side_stream = side if os.environ.get('AADG_REWARD_STREAM', '1') != '0' else None
 
             def hook(normalized):
                 if side is None:
