@@ -135,23 +135,30 @@ def inner_iteration(config, sample, model, discriminator, dis_criterion, model_o
         diversity_ot = (rewards - before).sum()
         if after_rewards is not None:
             after_rewards()
-    # bp: online branch trained on the soft domain codes
-    dis_loss_bp = dis_criterion(discriminator(feature, momentum=False), domain_gt)
+        # bp: online branch trained on the soft domain codes.  It sees only the detached features, so on the side stream its forward,
+        # backward and Adam step (a dozen small launches) also run beside the segmentation model's backward instead of behind it
+        dis_loss_bp = dis_criterion(discriminator(feature, momentum=False), domain_gt)
+        if sharded:
+            dis_loss_bp = dis_loss_bp * plan.loss_weight     # DDP averages the ranks' gradients: count-weighted mean (RowPlan)
+        if side is not None:
+            dis_optimizer.zero_grad(set_to_none=True)
+            dis_loss_bp.backward()
+            dis_optimizer.step()
     # sigmoid + per-policy BCE + Dice, one fused pass (forward + gradient).  mean_j BCE_j == mean over all rows (every policy
     # owns N/M rows), so a rank whose local rows are not policy-interleaved takes the plain mean of its rows.
     seg_loss, _, dice = _lib.policy_bce_loss(seg_output.float(), mask_gt, 1 if sharded else M)
     if sharded:
         # DDP averages the ranks' gradients: weight the local means by n_local * G / N (count-weighted mean, RowPlan)
         seg_loss = seg_loss * plan.loss_weight
-        dis_loss_bp = dis_loss_bp * plan.loss_weight
     model_optimizer.zero_grad(set_to_none=True)
     seg_loss.backward()
     model_optimizer.step()
-    dis_optimizer.zero_grad(set_to_none=True)
-    dis_loss_bp.backward()
-    dis_optimizer.step()
-    if side is not None:
-        main.wait_stream(side)                            # rewards, dis_loss, diversity_ot come from there
+    if side is None:
+        dis_optimizer.zero_grad(set_to_none=True)
+        dis_loss_bp.backward()
+        dis_optimizer.step()
+    else:
+        main.wait_stream(side)                            # rewards, dis_loss, diversity_ot, the discriminator's update come from there
     return seg_loss.detach(), dis_loss, diversity_ot, dice
 
 
