@@ -320,6 +320,93 @@ __global__ __launch_bounds__(256) void k_dw3x3_wgrad(const T* __restrict__ x, co
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// Dilation 1, bfloat16, W in {32, 64, 128}: the weight gradient without LDS and without barriers.  LPR = W / 8 lanes hold one image row
+// (8 pixels = one 16-byte load each); such a lane group streams down a strip of DWR_ROWS rows of one plane, keeping a three-row window
+// of x in registers as packed bfloat16 pairs -- as loaded, and shifted by one pixel to either side (v_alignbit; the pixel of the
+// neighbouring lane through a DPP row shift, zero at the row ends = the padding column) -- and accumulates the nine taps with
+// v_dot2c_f32_bf16 (two pixels per instruction, no unpacking).  Every byte of x and dy is read once (streaming loads; the two halo rows of
+// a strip twice).  grid (split, C): the lane groups of a workgroup take the (image, strip) tasks of channel c round-robin.
+constexpr int DWR_ROWS = 32;
+typedef __bf16 dw_bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float dw_dot2(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dw_bf16x2, a), __builtin_bit_cast(dw_bf16x2, b), c, false);
+}
+
+struct DwRow3 { uint32_t l[4], m[4], r[4]; };       // x[j - 1], x[j], x[j + 1] of a lane's 8 pixels, packed pairs
+
+template <int LPR>
+__device__ __forceinline__ void dw_row_load(const uint16_t* __restrict__ px, int row, int H, int W, int lane_in_row, DwRow3& o) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row >= 0 && row < H) v = aadg_load_stream(px + (size_t)row * W + lane_in_row * 8);
+    o.m[0] = v.x; o.m[1] = v.y; o.m[2] = v.z; o.m[3] = v.w;
+    // neighbours' edge words: DPP shifts within a 16-lane row; a lane group narrower than that masks its own ends
+    uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x111, 0xF, 0xF, true);     // row_shr:1
+    uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x101, 0xF, 0xF, true);     // row_shl:1
+    if (LPR < 16) {
+        if (lane_in_row == 0) prev = 0u;
+        if (lane_in_row == LPR - 1) next = 0u;
+    }
+    o.l[0] = __builtin_amdgcn_alignbit(v.x, prev, 16); o.l[1] = __builtin_amdgcn_alignbit(v.y, v.x, 16);
+    o.l[2] = __builtin_amdgcn_alignbit(v.z, v.y, 16);  o.l[3] = __builtin_amdgcn_alignbit(v.w, v.z, 16);
+    o.r[0] = __builtin_amdgcn_alignbit(v.y, v.x, 16);  o.r[1] = __builtin_amdgcn_alignbit(v.z, v.y, 16);
+    o.r[2] = __builtin_amdgcn_alignbit(v.w, v.z, 16);  o.r[3] = __builtin_amdgcn_alignbit(next, v.w, 16);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void k_dw3x3_wgrad_rows(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int N, int C, int H,
+                                                          float* __restrict__ partial) {
+    constexpr int W = LPR * 8, GROUPS = 256 / LPR;
+    __shared__ float red[4][9];
+    const int c = blockIdx.y, S = gridDim.x;
+    const int grp = threadIdx.x / LPR, lir = threadIdx.x % LPR;
+    const int strips = (H + DWR_ROWS - 1) / DWR_ROWS, tasks = N * strips;
+    const size_t psz = (size_t)H * W;
+    float acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+    for (int t = blockIdx.x * GROUPS + grp; t < tasks; t += S * GROUPS) {
+        const int n = t / strips, st = t - n * strips;
+        const int r0 = st * DWR_ROWS, r1 = min(H, r0 + DWR_ROWS);
+        const uint16_t* px = x + ((size_t)n * C + c) * psz;
+        const uint16_t* pg = dy + ((size_t)n * C + c) * psz;
+        DwRow3 a, b, cc;                                   // rows r - 1, r, r + 1
+        dw_row_load<LPR>(px, r0 - 1, H, W, lir, a);
+        dw_row_load<LPR>(px, r0, H, W, lir, b);
+        uint4 g = aadg_load_stream(pg + (size_t)r0 * W + lir * 8);
+        for (int r = r0; r < r1; ++r) {
+            dw_row_load<LPR>(px, r + 1, H, W, lir, cc);
+            uint4 gn = make_uint4(0, 0, 0, 0);
+            if (r + 1 < r1) gn = aadg_load_stream(pg + (size_t)(r + 1) * W + lir * 8);      // next row's dy in flight during the 36 dots
+            const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[0] = dw_dot2(gw[i], a.l[i], acc[0]);  acc[1] = dw_dot2(gw[i], a.m[i], acc[1]);  acc[2] = dw_dot2(gw[i], a.r[i], acc[2]);
+                acc[3] = dw_dot2(gw[i], b.l[i], acc[3]);  acc[4] = dw_dot2(gw[i], b.m[i], acc[4]);  acc[5] = dw_dot2(gw[i], b.r[i], acc[5]);
+                acc[6] = dw_dot2(gw[i], cc.l[i], acc[6]); acc[7] = dw_dot2(gw[i], cc.m[i], acc[7]); acc[8] = dw_dot2(gw[i], cc.r[i], acc[8]);
+            }
+            a = b; b = cc; g = gn;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = wave_sum(acc[i]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) red[threadIdx.x >> 6][i] = acc[i];
+    __syncthreads();
+    if (threadIdx.x < 9)
+        partial[((size_t)c * DW_MAX_SPLIT + blockIdx.x) * 9 + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// (split, C) grid of the register-window kernel: every lane group gets the same number k of tasks (k = the fewest that keeps split <= DW_MAX_SPLIT)
+static inline int dw_even_split(int tasks, int groups) {
+    const int per = (tasks + groups - 1) / groups;              // lane-group rounds of one channel
+    const int k = (per + DW_MAX_SPLIT - 1) / DW_MAX_SPLIT;
+    const int split = (per + k - 1) / k;
+    return split < 1 ? 1 : split;
+}
+
 __global__ __launch_bounds__(256) void k_dw3x3_wgrad_final(const float* __restrict__ partial, int split, int C, float* __restrict__ dw) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C * 9) return;
@@ -349,6 +436,25 @@ int dw_wgrad(const T* x, const T* dy, float* dw, int N, int C, int H, int W, int
     const int items = (N + g.PP - 1) / g.PP * g.tiles;
     if (split > items) split = items;
     if (split > DW_MAX_SPLIT) split = DW_MAX_SPLIT;
+    if (sizeof(T) == 2 && !aadg_env_flag("AADG_DW_WGRAD_LDS")) {
+        const uint16_t* px = reinterpret_cast<const uint16_t*>(x);
+        const uint16_t* pg = reinterpret_cast<const uint16_t*>(dy);
+        bool done = false;
+        if (d == 1 && (W == 32 || W == 64 || W == 128)) {
+            // the register-window kernel: tasks = (image, 32-row strip), 256 / (W / 8) lane groups per workgroup
+            split = dw_even_split(N * ((H + DWR_ROWS - 1) / DWR_ROWS), 256 / (W / 8));
+            if (W == 128) hipLaunchKernelGGL(k_dw3x3_wgrad_rows<16>, dim3(split, C), dim3(256), 0, st, px, pg, N, C, H, ws);
+            else if (W == 64) hipLaunchKernelGGL(k_dw3x3_wgrad_rows<8>, dim3(split, C), dim3(256), 0, st, px, pg, N, C, H, ws);
+            else hipLaunchKernelGGL(k_dw3x3_wgrad_rows<4>, dim3(split, C), dim3(256), 0, st, px, pg, N, C, H, ws);
+            done = true;
+        }
+        if (done) {
+            AADG_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_dw3x3_wgrad_final, dim3((C * 9 + 255) / 256), dim3(256), 0, st, (const float*)ws, split, C, dw);
+            AADG_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const size_t lds = (size_t)g.PP * g.lds_rows * W * sizeof(float);
     hipLaunchKernelGGL((k_dw3x3_wgrad<T>), dim3(split, C), dim3(256), lds, st, x, dy, N, C, g, ws);
     AADG_LAUNCH_CHECK();

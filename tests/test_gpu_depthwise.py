@@ -49,3 +49,20 @@ def test_module_falls_back_for_stride_2(hip):
     m1 = DepthwiseConv3x3(8, dilation=2).cuda()
     y = m1(x)
     assert torch.allclose(y, F.conv2d(x, m1.weight, None, 1, 2, 2, 8), atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 128, 128), (3, 5, 40, 64), (2, 6, 70, 32), (3, 4, 33, 128), (19, 3, 64, 64), (1, 2, 1, 32)])
+def test_dwconv_weight_gradient_register_window_kernel(hip, shape):
+    """k_dw3x3_wgrad_rows (dilation 1, bfloat16, W in {32, 64, 128}): strips that end inside / at the image, the padding columns at both
+    row ends (lane groups narrower than a DPP row), several tasks per lane group -- against the float32 gradient of the same tensors"""
+    torch.manual_seed(shape[1] + shape[2])
+    N, C, H, W = shape
+    x = torch.randn(shape, device="cuda").to(torch.bfloat16)
+    g = torch.randn(shape, device="cuda").to(torch.bfloat16)
+    w = torch.randn(C, 1, 3, 3, device="cuda", requires_grad=True)
+    xq = x.clone().requires_grad_(True)
+    hip.dwconv3x3(xq, w, 1).backward(g)
+    wr = w.detach().clone().requires_grad_(True)
+    F.conv2d(x.float(), wr, None, 1, 1, 1, C).backward(g.float())
+    assert (w.grad - wr.grad).abs().max().item() <= 2e-4 * wr.grad.abs().max().item() + 1e-4
+
