@@ -988,10 +988,12 @@ __global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ 
     unsigned long long lsum = 0;
     // Neighbouring pixels of a smooth image fall into the same bins, and LDS atomics of one wave on one address serialise: the
     // lanes of a wave therefore take pixels 97 positions apart (97 is prime: a bijection of [0, n) unless 97 divides n)
+    // (index arithmetic without a division per pixel: the running index advances by (256 * stride) mod n; a full-width tile splits it by a shift)
     const int stride = (n % 97) ? 97 : 1;
-    for (int i0 = tid; i0 < n; i0 += 256) {
-        const int i = (int)(((long long)i0 * stride) % n);
-        const int row = i / rw, col = i - row * rw;
+    const int step = (int)((256u * (unsigned)stride) % (unsigned)n);
+    int i = (int)(((unsigned)tid * (unsigned)stride) % (unsigned)n);
+    for (int i0 = tid; i0 < n; i0 += 256, i += step, i -= i >= n ? n : 0) {
+        const int row = rw == 256 ? i >> 8 : i / rw, col = i - row * rw;
         const uint32_t p = cur[(ry0 + row - r_lo) * pw + (cx0 + col - c_lo)];
         const uint32_t r = p & 255, g = (p >> 8) & 255, b = (p >> 16) & 255;
         atomicAdd(&sh[r], 1u); atomicAdd(&sh[256 + g], 1u); atomicAdd(&sh[512 + b], 1u);
