@@ -17,85 +17,100 @@ __all__ = ['ShearX', 'ShearY', 'TranslateX', 'TranslateY', 'HorizontalFlip', 'Ve
            'Hue', 'SamplePairing', 'Equalize', 'Sharpness']
 
 
+def _checked_range(rng, what):
+    if rng is not None and not (0 <= rng[0] < rng[1] <= 1):
+        raise AssertionError("%s must satisfy 0 <= lo < hi <= 1, got %r" % (what, (rng,)))
+    return rng
+
+
 class _Operation(nn.Module):
+    """One stochastic float op.  State (names are the reference's state_dict keys, data/operations.py:28-70):
+    `_magnitude` / `_probability` are nn.Parameters when a range is given (learnable, clamped into the range on every
+    read) and buffers otherwise (frozen); `temperature` is a buffer.  Ops without a magnitude keep `_magnitude = None`."""
+
     def __init__(self, operation: Optional[Callable], initial_magnitude: Optional[float] = None,
                  initial_probability: float = 0.5, magnitude_range: Optional[Tuple[float, float]] = None,
                  probability_range: Optional[Tuple[float, float]] = None, temperature: float = 0.1,
                  flip_magnitude: bool = False, magnitude_scale: float = 1, debug: bool = False):
         super().__init__()
+        if not temperature > 0 or not magnitude_scale > 0:
+            raise AssertionError("temperature and magnitude_scale must be positive")
+        if probability_range is not None and not 0 <= initial_probability <= 1:
+            raise AssertionError("initial_probability outside [0, 1]")
+        has_mag = initial_magnitude is not None
         self.operation = operation
-        self.magnitude_range = None
-        if initial_magnitude is None:
-            self._magnitude = None
-        elif magnitude_range is None:
-            self.register_buffer("_magnitude", torch.empty(1).fill_(initial_magnitude))
-        else:
-            self._magnitude = nn.Parameter(torch.empty(1).fill_(initial_magnitude))
-            assert 0 <= magnitude_range[0] < magnitude_range[1] <= 1
-            self.magnitude_range = magnitude_range
-        self.probability_range = probability_range
-        if probability_range is None:
-            self.register_buffer("_probability", torch.empty(1).fill_(initial_probability))
-        else:
-            assert 0 <= initial_probability <= 1
-            assert 0 <= probability_range[0] < probability_range[1] <= 1
-            self._probability = nn.Parameter(torch.empty(1).fill_(initial_probability))
-        assert 0 < temperature
-        self.register_buffer("temperature", torch.empty(1).fill_(temperature))
-        self.flip_magnitude = flip_magnitude and (self._magnitude is not None)
-        assert 0 < magnitude_scale
         self.magnitude_scale = magnitude_scale
-        self.debug = debug
-        self._py_magnitude = initial_magnitude
-        self._py_probability = initial_probability
+        self.flip_magnitude = bool(flip_magnitude and has_mag)
+        # a range only means something for a magnitude that exists
+        self.magnitude_range = _checked_range(magnitude_range, "magnitude_range") if has_mag else None
+        self.probability_range = _checked_range(probability_range, "probability_range")
+        # registration order = the reference's parameter / state_dict order: magnitude, probability, temperature
+        if has_mag:
+            self._scalar("_magnitude", initial_magnitude, learnable=self.magnitude_range is not None)
+        else:
+            self._magnitude = None
+        self._scalar("_probability", initial_probability, learnable=self.probability_range is not None)
+        self._scalar("temperature", temperature, learnable=False)
+
+    def _scalar(self, name, value, learnable):
+        t = torch.full((1,), float(value))
+        if learnable:
+            setattr(self, name, nn.Parameter(t))
+        else:
+            self.register_buffer(name, t)
+
+    # -- what forward() reads ------------------------------------------------------------------------------------
+    @property
+    def probability(self) -> torch.Tensor:
+        p = self._probability
+        return p if self.probability_range is None else p.clamp(self.probability_range[0], self.probability_range[1])
 
     @property
     def magnitude(self) -> Optional[torch.Tensor]:
-        if self._magnitude is None:
+        m = self._magnitude
+        if m is None:
             return None
-        mag = self._magnitude
         if self.magnitude_range is not None:
-            mag = mag.clamp(*self.magnitude_range)
-        m = mag * self.magnitude_scale
-        self._py_magnitude = m.item()
-        return m
-
-    @property
-    def probability(self) -> torch.Tensor:
-        if self.probability_range is None:
-            return self._probability
-        p = self._probability.clamp(*self.probability_range)
-        self._py_probability = p.item()
-        return p
+            m = m.clamp(self.magnitude_range[0], self.magnitude_range[1])
+        return m * self.magnitude_scale
 
     def get_mask(self, batch_size=None) -> torch.Tensor:
-        size = (batch_size, 1, 1)
-        if self.training:
-            return RelaxedBernoulli(self.temperature, self.probability).rsample(size)
-        return Bernoulli(self.probability).sample(size)
+        """[B,1,1,1] gate per sample: relaxed (differentiable w.r.t. the probability) in training, hard 0/1 in eval"""
+        dist = RelaxedBernoulli(self.temperature, self.probability) if self.training else Bernoulli(self.probability)
+        shape = (batch_size, 1, 1)
+        return dist.rsample(shape) if self.training else dist.sample(shape)
+
+    def _signed_magnitude(self, n, device):
+        mag = self.magnitude
+        if not self.flip_magnitude:
+            return mag
+        # one fair coin per sample: 0 / 1 -> -1 / +1
+        coins = torch.randint(2, (n,), dtype=torch.float32, device=device)
+        return (2 * coins - 1) * mag
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
-        mask = self.get_mask(input.size(0))
-        mag = self.magnitude
-        if self.flip_magnitude:
-            sign = torch.randint(2, (input.size(0),), dtype=torch.float32, device=input.device).mul_(2).sub_(1)
-            mag = sign * mag
+        n = input.size(0)
+        gate = self.get_mask(n)                       # draw order of the reference: gate first, then the signs
+        mag = self._signed_magnitude(n, input.device)
         if self.training:
-            return (mask * self.operation(input, mag) + (1 - mask) * input).clamp_(0, 1)
-        keep = mask.reshape(-1) == 1
-        output = input
-        if torch.is_tensor(mag):
-            mag = mag.repeat(int(keep.sum())) if mag.size(0) == 1 else mag[keep]
-        if bool(keep.any()):
-            output[keep, ...] = self.operation(output[keep, ...], mag)
-        return output.clamp(0, 1)
+            changed = self.operation(input, mag)
+            return (gate * changed + (1 - gate) * input).clamp_(0, 1)
+        # eval: the op overwrites the gated samples of `input` itself
+        rows = gate.reshape(-1).eq(1).nonzero().reshape(-1)
+        if rows.numel():
+            if torch.is_tensor(mag):
+                mag = mag.expand(rows.numel()) if mag.numel() == 1 else mag.index_select(0, rows)
+            input.index_copy_(0, rows, self.operation(input.index_select(0, rows), mag))
+        return input.clamp(0, 1)
 
-    def __repr__(self) -> str:
-        s = self.__class__.__name__
-        s += f"(probability={self._py_probability:.3f} ({'frozen' if self.probability_range is None else 'learnable'}), "
-        if self.magnitude is not None:
-            s += f"magnitude={self._py_magnitude:.3f} ({'frozen' if self.magnitude_range is None else 'learnable'}), "
-        return s + f"temperature={self.temperature.item():.3f})"
+    def extra_repr(self) -> str:
+        def state(t, rng):
+            return "%.3f (%s)" % (float(t.detach()), "frozen" if rng is None else "learnable")
+        parts = ["probability=" + state(self.probability, self.probability_range)]
+        if self._magnitude is not None:
+            parts.append("magnitude=" + state(self.magnitude, self.magnitude_range))
+        parts.append("temperature=%.3f" % float(self.temperature))
+        return ", ".join(parts)
 
 
 def _make(name, fn, has_mag=True, flip=False, scale=1.0):

@@ -71,7 +71,10 @@ def parse():
     ap.add_argument("--backbone", default="resnet50", help="MODEL.BACKBONE for deeplabv3+ configs (the yaml's mobilenet_v2 is the "
                                                            "reference's only reachable encoder; BASELINE configs[1] names ResNet-50)")
     ap.add_argument("--backbone_dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N = 1: fp32,rvs1024,cpu  (auto = all; none = skip)")
+    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N = 1: fop,kernels,rvs1024,cpu,fp32  (auto = all; none = skip)")
+    ap.add_argument("--only_legs", default=None,
+                    help="skip the headline step and print ONE JSON line holding only these legs (fop,kernels,rvs1024): the target of "
+                         "the rocprofv3 runs behind profiles/r03_fop_* and profiles/r03_rvs1024_*")
     ap.add_argument("--no_cpu_baseline", action="store_true", help="same as removing `cpu` from --legs")
     ap.add_argument("--cpu_repeats", type=int, default=20)
     ap.add_argument("--no_sync_bn", action="store_true",
@@ -434,6 +437,105 @@ def time_steps(st, a, world, steps, warmup, first_epoch=0, want_kernel_events=Tr
     return float(t.item()), step_ms, kern_ms, call_ms
 
 
+# float tensor ops of data/functional.py (a9-a12), in registry order of aadg_amd/_lib.py: FOP
+FLOAT_OPS = [("invert", None), ("solarize", 0.5), ("posterize", 0.5), ("gray", None), ("contrast", 0.3), ("auto_contrast", None),
+             ("saturate", 0.3), ("brightness", 0.3), ("hue", 0.2), ("sample_pairing", 0.3), ("equalize", None), ("sharpness", 0.3),
+             ("gaussian_blur3x3", 0.7), ("shear_x", 0.2), ("shear_y", 0.2), ("translate_x", 0.1), ("translate_y", 0.1), ("rotate", 20.0),
+             ("hflip", None), ("vflip", None)]
+STAT_FOPS = ("contrast", "auto_contrast", "equalize")
+
+
+def _event_times(fn, repeats, warm=2):
+    """milliseconds of `repeats` calls of fn, each bracketed by a HIP event pair on the launch stream (torch's current stream,
+    which is the stream every aadg_* entry point of this leg is given)"""
+    import torch
+    for _ in range(warm):
+        fn()
+    ev = lambda: torch.cuda.Event(enable_timing=True)      # noqa: E731
+    pairs = [(ev(), ev()) for _ in range(repeats)]
+    torch.cuda.synchronize()
+    for p in pairs:
+        p[0].record()
+        fn()
+        p[1].record()
+    torch.cuda.synchronize()
+    return [p[0].elapsed_time(p[1]) for p in pairs]
+
+
+def float_ops_leg(B=144, size=512, repeats=10):
+    """Every aadg_fop_f32 op (csrc/tensor_ops.hip; reference data/functional.py:110-280, data/kernels.py:9-35) on a [B,3,size,size]
+    float32 batch: scalar and per-sample magnitudes, HIP events around each call (= all kernels of the op), algorithmic bytes per
+    SURVEY 8(d): 24*H*W per image and op, 36*H*W for the statistics ops (contrast / auto_contrast / equalize: a second read)."""
+    import torch
+    from aadg_amd import _lib
+    from aadg_amd.data.synthetic import make_pool
+    imgs, _ = make_pool(1023, 3, 8, size, size)              # the Fundus-like synthetic images of the headline workload, as [0,1] planes
+    pool = torch.from_numpy(imgs).cuda()
+    x = (pool[torch.arange(B, device="cuda") % pool.shape[0]].permute(0, 3, 1, 2).float() / 255.0).contiguous()
+    del pool
+    perm = torch.randperm(B, device="cuda").to(torch.int32)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1023)
+    res, worst = {}, None
+    for name, m0 in FLOAT_OPS:
+        per_image = (36 if name in STAT_FOPS else 24) * size * size
+        nbytes = per_image * B
+        entry = {"bytes_per_image": per_image}
+        modes = [("scalar", None if m0 is None else torch.tensor([m0], device="cuda"))]
+        if m0 is not None and name != "gaussian_blur3x3":       # the blur's magnitude is one sigma for the batch (data/kernels.py:16-25)
+            modes.append(("per_sample", (torch.rand(B, device="cuda", generator=g) * 0.5 + 0.5) * m0))
+        for mode, mag in modes:
+            kw = {"perm": perm} if name == "sample_pairing" else {}
+            ts = _event_times(lambda: _lib.fop(name, x, mag, **kw), repeats)
+            ms = float(np.median(ts))
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            entry[mode] = {"ms": ms, "ms_min": float(min(ts)), "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
+            if worst is None or gbs < worst[1]:
+                worst = (name + "/" + mode, gbs)
+        res[name] = entry
+    fr = [v["scalar"]["frac"] for v in res.values()]
+    return {"workload": "every data/functional.py op on float32 [%d,3,%d,%d] in [0,1] (augmented synthetic Fundus-like images), out of place"
+                        % (B, size, size),
+            "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "repeats": repeats,
+            "what": "median of %d HIP-event durations around the whole aadg_fop_f32 call (statistics ops: statistics + finalise + apply "
+                    "kernels); achieved = algorithmic bytes (24*H*W*B, 36*H*W*B for contrast / auto_contrast / equalize) / that time"
+                    % repeats,
+            "frac_min": float(min(fr)), "frac_median": float(np.median(fr)), "slowest": {"op": worst[0], "achieved": worst[1]},
+            "ops": res,
+            "rocprof": "profiles/r03_fop_kernel_stats.txt (rocprofv3 --kernel-trace --stats -- python bench.py --only_legs fop), "
+                       "profiles/r03_fop_traffic.json (FETCH_SIZE / WRITE_SIZE passes)"}
+
+
+def hot_kernels_leg(D=3, B=8, M=6, size=512, K=2, repeats=20):
+    """Per-kernel figures of the two other own hot-path kernels north_star names: the one-pass BCE + Dice + gradient kernel
+    (k_seg_partial, HBM-bound: logits + labels read, gradient written = 12 B per element) and the Sinkhorn reward kernel
+    (k_sinkhorn, latency-bound: 73.7 KB in, 24 B out -- microseconds and the launches it replaces)."""
+    import torch
+    from aadg_amd import _lib
+    N = D * B * M
+    z = torch.randn(N, K, size, size, device="cuda")
+    y = (torch.rand(N, K, size, size, device="cuda") > 0.5).float()
+    ts = _event_times(lambda: _lib.seg_bce_dice(z, y, M, want_grad=True), repeats)
+    seg_ms = float(np.median(ts))
+    seg_bytes = 12 * z.numel()
+    fe = torch.nn.functional.leaky_relu(torch.randn(N, 128, device="cuda"), 0.2)
+    rewards = torch.zeros(M, device="cuda")
+    tk = _event_times(lambda: _lib.sinkhorn_rewards(fe, D, B, M, rewards=rewards), repeats)
+    sk_ms = float(np.median(tk))
+    P = D * (D - 1) // 2
+    return {"k_seg_partial+k_seg_final": {
+                "replaces": "sigmoid + M BCELoss launches + 2*M*K torchmetrics F1 passes + autograd backward (search_dg.py:140-142,164-165)",
+                "bound": "hbm", "bytes": seg_bytes, "ms": seg_ms, "achieved": seg_bytes / (seg_ms * 1e-3) / 1e9,
+                "frac": seg_bytes / (seg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "shape": [N, K, size, size], "launches": 2, "launches_replaced_about": 3 * M + 4 * M * K + 2},
+            "k_sinkhorn": {
+                "replaces": "%d geomloss SamplesLoss calls of ~44 KeOps launches + one host sync each (search_dg.py:150-162)" % (M * P),
+                "bound": "latency", "us": sk_ms * 1e3, "us_min": float(min(tk)) * 1e3, "problems": M * P, "workgroups": M * P,
+                "bytes_in": N * 128 * 4, "bytes_out": 4 * M, "launches": 1, "launches_replaced_about": 44 * M * P,
+                "host_syncs_replaced": M * P}}
+
+
+
 def rvs_1024_leg(n_units=144, size=1024):
     """BASELINE configs[2] on the hot path: the RVS pipeline of experiments/rvs_sinkhorn/diversity_ex.yaml (DGRandomScaleCrop
     scale range [0.5, 2], vessel masks, K = 1) with 1024 x 1024 crops from 1024 x 1024 sources, D3 B8 M6 = 144 units."""
@@ -492,6 +594,26 @@ def rvs_1024_leg(n_units=144, size=1024):
                          "stage": {"bytes": sb, "ms": c_ms, "achieved": sb / (c_ms * 1e-3) / 1e9, "frac": sb / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}}
 
 
+def only_legs_main(a):
+    """--only_legs: the extra legs without the headline step (profiling target); ONE JSON line"""
+    import torch
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU product path)"
+    torch.cuda.set_device(0)
+    from aadg_amd import _lib
+    _lib.load()
+    out = {}
+    for leg in a.only_legs.split(","):
+        if leg == "fop":
+            out["float_ops"] = float_ops_leg()
+        elif leg == "kernels":
+            out["kernels"] = hot_kernels_leg()
+        elif leg == "rvs1024":
+            out["rvs_1024"] = rvs_1024_leg()
+        else:
+            raise SystemExit("--only_legs: unknown leg %r" % leg)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1 and not a.shard_of:
@@ -501,7 +623,9 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (a.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    legs = set() if a.legs == "none" else set(("fp32,rvs1024,cpu" if a.legs == "auto" else a.legs).split(","))
+    if a.only_legs:
+        return only_legs_main(a)
+    legs = set() if a.legs == "none" else set(("fop,kernels,fp32,rvs1024,cpu" if a.legs == "auto" else a.legs).split(","))
     if a.no_cpu_baseline:
         legs.discard("cpu")
     if world > 1 or a.shard_of or a.dump_rewards:
@@ -681,6 +805,16 @@ def main():
                                  "Sinkhorn kernel + reward normalise + PPO; backbone and discriminator removed"},
         }
     # ---- extra legs (one GPU only) -------------------------------------------------------------------------------------
+    if rank == 0 and "fop" in legs:
+        try:
+            out["float_ops"] = float_ops_leg()
+        except Exception as e:  # noqa: BLE001
+            out["float_ops"] = {"error": repr(e)}
+    if rank == 0 and "kernels" in legs:
+        try:
+            out["kernels"] = hot_kernels_leg()
+        except Exception as e:  # noqa: BLE001
+            out["kernels"] = {"error": repr(e)}
     if rank == 0 and "rvs1024" in legs:
         try:
             out["rvs_1024"] = rvs_1024_leg()
