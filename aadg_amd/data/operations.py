@@ -99,7 +99,7 @@ class _Operation(nn.Module):
         rows = gate.reshape(-1).eq(1).nonzero().reshape(-1)
         if rows.numel():
             if torch.is_tensor(mag):
-                mag = mag.expand(rows.numel()) if mag.numel() == 1 else mag.index_select(0, rows)
+                mag = mag.repeat(rows.numel()) if mag.numel() == 1 else mag.index_select(0, rows)
             input.index_copy_(0, rows, self.operation(input.index_select(0, rows), mag))
         return input.clamp(0, 1)
 

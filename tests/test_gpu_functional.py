@@ -140,3 +140,86 @@ def test_full_size_roundtrips(hip):
     assert torch.equal(g[:, 0], g[:, 1]) and torch.equal(g[:, 1], g[:, 2])
     e = Fn.equalize(x)
     assert float(e.min()) >= 0 and float(e.max()) <= 1 and abs(float(e.mean()) - 0.5) < 0.02  # flat histogram stays flat
+
+
+def _unaligned_copy(x):
+    """the same values at a 4-byte-aligned (not 16-byte-aligned) address: aadg_fop_f32 takes its one-pixel-per-lane kernels"""
+    buf = torch.empty(x.numel() + 1, device=x.device, dtype=x.dtype)
+    v = buf[1:].view(x.shape)
+    v.copy_(x)
+    assert v.is_contiguous() and v.data_ptr() % 16 == 4
+    return v
+
+
+def test_vector_and_scalar_kernels_agree(hip):
+    """Round 3: every op has a 4-pixels-per-lane kernel (register-window stencil, tiled warps, fused statistics prologue) and a
+    one-pixel-per-lane kernel for shapes / pointers the vector path cannot take.  Same arithmetic, so the results must agree: on a
+    shape with a second, narrow column strip (W = 264), per-sample magnitudes, and an odd shape that only the scalar kernels take
+    (against the torch formulas of data/functional.py where they are one-liners)."""
+    from aadg_amd import _lib
+    from aadg_amd.data import functional as Fn
+    torch.manual_seed(5)
+    B, H, W = 5, 70, 264
+    yy, xx = torch.meshgrid(torch.arange(H, device="cuda"), torch.arange(W, device="cuda"), indexing="ij")
+    smooth = 0.5 + 0.35 * torch.sin(xx / 17.0) * torch.cos(yy / 11.0)
+    x = (smooth[None, None] * torch.tensor([1.0, 0.8, 0.6], device="cuda")[None, :, None, None]
+         + 0.15 * torch.rand(B, 3, H, W, device="cuda")).clamp(0, 1).contiguous()
+    xu = _unaligned_copy(x)
+    perm = torch.tensor([1, 2, 3, 4, 0], device="cuda", dtype=torch.int32)
+    mags = {"solarize": 0.5, "posterize": 0.5, "contrast": 0.3, "saturate": 0.4, "brightness": 0.3, "hue": 0.2, "sample_pairing": 0.3,
+            "sharpness": 0.4, "gaussian_blur3x3": 0.8, "shear_x": 0.2, "shear_y": -0.2, "translate_x": 0.11, "translate_y": -0.07, "rotate": 23.0}
+    for name in _lib.FOP:
+        m0 = mags.get(name)
+        variants = [None] if m0 is None else [torch.tensor([m0], device="cuda")]
+        if m0 is not None and name != "gaussian_blur3x3":
+            variants.append(torch.linspace(0.5, 1.0, B, device="cuda") * m0)
+        for mag in variants:
+            kw = {"perm": perm} if name == "sample_pairing" else {}
+            a = _lib.fop(name, x, mag, **kw)
+            b = _lib.fop(name, xu, mag, **kw)
+            d = (a - b).abs()
+            if name in ("equalize", "auto_contrast", "contrast"):
+                assert float(d.max()) <= 1e-6, (name, float(d.max()))
+            else:
+                assert torch.equal(a, b), (name, float(d.max()))
+    # torch formulas (data/functional.py:158-280) on the vector path
+    m = torch.tensor([0.4], device="cuda")
+    assert torch.equal(Fn.invert(x.clone()), 1 - x)
+    assert torch.equal(Fn.solarize(x.clone(), m).detach(), torch.where(x < m, x, 1 - x))
+    gray = (0.299 * x[:, 0] + 0.587 * x[:, 1] + 0.110 * x[:, 2]).unsqueeze(1).repeat(1, 3, 1, 1)
+    assert torch.allclose(Fn.gray(x.clone()), gray, atol=1e-6)
+    assert torch.allclose(Fn.saturate(x.clone(), m), (gray + (1 - m) * (x - gray)).clamp(0, 1), atol=1e-6)
+    k = torch.ones(3, 3, device="cuda"); k[1, 1] = 5; k /= 13
+    blur = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (1, 1, 1, 1), mode="reflect"), k.repeat(3, 1, 1, 1), groups=3)
+    assert torch.allclose(Fn.sharpness(x.clone(), m, k), (blur + (1 - m) * (x - blur)).clamp(0, 1), atol=1e-5)
+    # odd shape: scalar kernels only
+    xo = torch.rand(3, 3, 33, 37, device="cuda")
+    assert torch.equal(Fn.invert(xo.clone()), 1 - xo) and torch.equal(Fn.hflip(xo.clone()), xo.flip(3))
+    blur = torch.nn.functional.conv2d(torch.nn.functional.pad(xo, (1, 1, 1, 1), mode="reflect"), k.repeat(3, 1, 1, 1), groups=3)
+    assert torch.allclose(Fn.sharpness(xo.clone(), m, k), (blur + (1 - m) * (xo - blur)).clamp(0, 1), atol=1e-5)
+    e = Fn.equalize(xo.clone())
+    assert e.shape == xo.shape and float(e.min()) >= 0 and float(e.max()) <= 1
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 40, 512), (1, 3, 36, 1032), (2, 3, 70, 264)])
+def test_stencil_strips_vs_torch_conv(hip, shape):
+    """The register-window stencil: one 512-wide strip with 8 pixels per lane (no edge loads), several strips with interior edges
+    (1032 = 512 + 512 + 8), 4 pixels per lane (264 = 256 + 8) -- against reflect-pad + depthwise conv2d (data/functional.py:98-106)
+    and against the one-pixel-per-lane kernel (bit-exact: shared arithmetic)."""
+    from aadg_amd import _lib
+    from aadg_amd.data import functional as Fn
+    from aadg_amd.data.kernels import get_gaussian_3x3kernel
+    torch.manual_seed(11)
+    x = torch.rand(*shape, device="cuda")
+    m = torch.tensor([0.35], device="cuda")
+    k = torch.ones(3, 3, device="cuda"); k[1, 1] = 5; k /= 13
+    pad = torch.nn.functional.pad(x, (1, 1, 1, 1), mode="reflect")
+    blur = torch.nn.functional.conv2d(pad, k.repeat(3, 1, 1, 1), groups=3)
+    got = Fn.sharpness(x.clone(), m, k)
+    assert torch.allclose(got, (blur + (1 - m) * (x - blur)).clamp(0, 1), atol=1e-5)
+    assert torch.equal(got, _lib.fop("sharpness", _unaligned_copy(x), m, kernel=k))
+    g = get_gaussian_3x3kernel(torch.tensor([0.9])).cuda()
+    gb = torch.nn.functional.conv2d(pad, g.repeat(3, 1, 1, 1), groups=3).clamp(0, 1)
+    got = _lib.fop("gaussian_blur3x3", x, torch.tensor([0.9], device="cuda"), kernel=g)
+    assert torch.allclose(got, gb, atol=1e-5)
+    assert torch.equal(got, _lib.fop("gaussian_blur3x3", _unaligned_copy(x), torch.tensor([0.9], device="cuda"), kernel=g))
