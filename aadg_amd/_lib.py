@@ -215,7 +215,7 @@ def load():
     lib.aadg_upsample_sum_backward_all.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.aadg_embed_prologue_norm_f32.restype = _i
     lib.aadg_embed_prologue_norm_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]
-    if lib.aadg_abi_version() != 4:
+    if lib.aadg_abi_version() != 5:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -307,7 +307,7 @@ def validate_units(units, P, Hs, Ws):
 def launch_plan(units, Hs, Ws, crop):
     """(classes, stats_mask, order, counts, stat_lists, late_plan) for aadg_aug_u8_forward_ex2 -- mirrors unit_flow() in csrc/aug_u8.hip.
     order: unit indices grouped by tile class (plain up-scaling, up-scaling with a Sharpness stencil, generic, staged);
-    counts = (n_plain, n_sharp, n_generic); stat_lists[k]: the units whose k-th op needs a pixel pass for its image statistics;
+    counts = (n_plain, n_sharp, n_generic, n_generic_sharp: the last ones of the generic run chain a Sharpness stencil); stat_lists[k]: the units whose k-th op needs a pixel pass for its image statistics;
     late: the units with such an op in a slot k >= 1."""
     n_ops = units["n_ops"]
     live = np.arange(MAX_OPS)[None, :] < n_ops[:, None]
@@ -334,9 +334,10 @@ def launch_plan(units, Hs, Ws, crop):
     for k in range(MAX_OPS):
         if pixel_pass[:, k].any():
             stats_mask |= 1 << k
-    cls = np.where(up & (sharp == 0), 0, np.where(up, 1, np.where(generic, 2, 3)))
+    # tile classes in list order: up-scaling plain / with a stencil, down-scaling ("generic") plain / with a stencil, staged
+    cls = np.where(up & (sharp == 0), 0, np.where(up, 1, np.where(generic & (sharp == 0), 2, np.where(generic, 3, 4))))
     order = np.argsort(cls, kind="stable").astype(np.int32)
-    counts = (int((cls == 0).sum()), int((cls == 1).sum()), int((cls == 2).sum()))
+    counts = (int((cls == 0).sum()), int((cls == 1).sum()), int(((cls == 2) | (cls == 3)).sum()), int((cls == 3).sum()))
     stat_lists = [np.nonzero(pixel_pass[:, k])[0].astype(np.int32) for k in range(MAX_OPS)]     # work lists of the histogram kernels
     # "late" units: a slot k >= 1 needs a pixel pass (include/aadg_hip.h: aadg_aug_lists.late_units)
     late = np.nonzero(pixel_pass[:, 1:].any(axis=1))[0].astype(np.int32)
@@ -352,7 +353,7 @@ class AugLists(ctypes.Structure):
     """mirror of `aadg_aug_lists` (include/aadg_hip.h): host struct of device index arrays"""
     _fields_ = [("order", ctypes.c_void_p), ("n_plain", ctypes.c_int32), ("n_sharp", ctypes.c_int32), ("n_generic", ctypes.c_int32),
                 ("stat_units", ctypes.c_void_p * MAX_OPS), ("n_stat", ctypes.c_int32 * MAX_OPS), ("pool_hist", ctypes.c_void_p),
-                ("late_units", ctypes.c_void_p), ("n_late", ctypes.c_int32)]
+                ("late_units", ctypes.c_void_p), ("n_late", ctypes.c_int32), ("n_generic_sharp", ctypes.c_int32)]
 
 
 HIST_STRIDE = 772      # AADG_HIST_STRIDE
@@ -420,7 +421,7 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
     ready = _pinned.get("units_ready")
     if ready is not None:
         ready.synchronize()          # previous copy out of the staging buffer has completed
-    classes, stats_mask, order, (n_plain, n_sharp, n_generic), stat_lists, late = launch_plan(units, Hs, Ws, crop)
+    classes, stats_mask, order, (n_plain, n_sharp, n_generic, n_generic_sharp), stat_lists, late = launch_plan(units, Hs, Ws, crop)
     nb_units = N * UNIT_DTYPE.itemsize                       # a multiple of 4: the int32 list behind it is aligned
     host = stage[:N * _REC].numpy()
     host[:nb_units] = units.view(np.uint8).reshape(-1)
@@ -428,7 +429,7 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
     d_units = torch.empty(N * _REC, dtype=torch.uint8, device=dev)
     lists = AugLists()
     lists.order = d_units.data_ptr() + nb_units
-    lists.n_plain, lists.n_sharp, lists.n_generic = n_plain, n_sharp, n_generic
+    lists.n_plain, lists.n_sharp, lists.n_generic, lists.n_generic_sharp = n_plain, n_sharp, n_generic, n_generic_sharp
     for k, lst in enumerate(stat_lists):
         off = nb_units + 4 * N * (1 + k)
         host[off:off + 4 * lst.size] = lst.view(np.uint8)

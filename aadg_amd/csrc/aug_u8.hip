@@ -1358,6 +1358,276 @@ __global__ __launch_bounds__(256) void k_fused_generic(const uint8_t* __restrict
     if (K == 2) store_out4(ol + plane + off, make_float4(l1[0], l1[1], l1[2], l1[3]), stream_out);
 }
 
+// ------------------------------------------------------------------------------------------------
+// GENERIC units in two passes (round 3): Pillow's own order -- the horizontal pass over every source row the crop window needs,
+// rounded to uint8, then the vertical pass -- as two streaming kernels around a packed RGBX intermediate in the workspace
+// (`hbuf`: [slot][source row][output column] uint32, <= 4 B per source-row x output-column, written once and read ~nty/scale times
+// out of L2 / the Infinity Cache).
+//   * k_gen_hpass: tile = GH_CB output columns x GH_ROWS source rows.  The op chain runs in the LDS patch (build_patch, shared with
+//     the other tile kernels: 256-column patches, so every lane of the patch loader has work), a thread owns an output column and
+//     walks down the patch rows.  No vertical halo: a source row is resampled exactly once (the one-pass tile resamples the
+//     (2*16+4)/32 rows of a 16-row output tile, stages 36 % lane-idle 144-column patches, and 30 % of its workgroups are padding).
+//   * k_gen_vpass: wave <-> output row, lane <-> 4 consecutive columns; the <= 5 taps are 16-byte loads of the intermediate, the row
+//     tables are scalar loads; normalise through the LDS table, NEAREST mask gather, multilabel planes, streaming 16-byte stores;
+//     rows / columns of the padding are constant stores.
+// k_fused_generic (one pass, above) stays selectable with AADG_GENERIC_V1=1; tests compare the two bit for bit.
+// ------------------------------------------------------------------------------------------------
+constexpr int GH_CB = 128;             // output columns per horizontal-pass tile: <= 2 * 128 + 5 source columns (+ halo, alignment) <= 272
+constexpr int GH_NR = 6;               // patch rows per wave of build_patch: 4 * 6 = 24 >= GH_ROWS + 2 * MAX_SHARP
+template <bool SHARP> struct GhRows { static constexpr int value = SHARP ? 18 : 22; };      // source rows per tile (22 x 272 <= PATCH_CAP)
+
+template <int NT>
+__device__ __forceinline__ uint32_t hpass_px(const uint32_t* rowp, const int* hk, int /*lim*/) {
+    int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const uint32_t p = rowp[t];                          // taps beyond the patch have zero coefficients: whatever word lies there
+                                                             // (the next row, or the 8 words of slack behind the buffer) is multiplied by 0
+        s0 += __mul24((int)(p & 255), hk[t]);
+        s1 += __mul24((int)((p >> 8) & 255), hk[t]);
+        s2 += __mul24((int)((p >> 16) & 255), hk[t]);
+    }
+    return (uint32_t)clip8(s0) | ((uint32_t)clip8(s1) << 8) | ((uint32_t)clip8(s2) << 16);
+}
+
+// body of one horizontal-pass tile: (bx, by) = column tile / row block, slot = position in the generic list = the unit's slice of
+// hbuf; A / Bs: PATCH_CAP + 8 words each (Bs only with a stencil), sl: the stage LUTs
+template <bool SHARP>
+__device__ __forceinline__ void gen_hpass_body(const uint8_t* __restrict__ pool, const aadg_unit* __restrict__ units,
+                                               const int* __restrict__ order, int slot, int bx, int by, int Hs, int Ws, int crop,
+                                               const int* __restrict__ tab, const uint8_t* __restrict__ lut,
+                                               size_t lut_stage_stride, uint32_t* __restrict__ hbuf, uint32_t* A, uint32_t* Bs, uint8_t* sl) {
+    constexpr int ROWS = GhRows<SHARP>::value;
+    const int u = order != nullptr ? order[slot] : slot;
+    const aadg_unit& un = units[u];
+    if (unit_flow(true, un, Hs, Ws, crop) != FLOW_GENERIC) return;
+    const int n_ops = un.n_ops;
+    const int s = sharp_count(un, n_ops);
+    if ((s > 0) != SHARP) return;
+    const int tid = threadIdx.x;
+    const int* base = tab + (size_t)u * crop * TAB_STRIDE;
+    const int* xmin_t = base;
+    const int* xk_t = xmin_t + crop;
+    const int* ymin_t = xk_t + (size_t)crop * KMAX;
+    const int w = un.scaled_w, h = un.scaled_h;
+    const int ox = un.crop_x - un.pad, oy = un.crop_y - un.pad;
+    // valid (non-pad) output range of the unit, of this tile's columns
+    const int ufx = max(0, -ox), ulx = min(crop - 1, w - 1 - ox);
+    const int ufy = max(0, -oy), uly = min(crop - 1, h - 1 - oy);
+    if (ufx > ulx || ufy > uly) return;
+    const int x0 = bx * GH_CB;
+    const int fx = max(x0, ufx), lx = min(x0 + GH_CB - 1, ulx);
+    if (fx > lx) return;
+    const int ntx = axis_taps(Ws, w), nty = axis_taps(Hs, h);
+    // source rows the unit's valid output rows read: [ur_lo, ur_hi); this tile's block of them
+    const int ur_lo = ymin_t[ufy], ur_hi = min(Hs, ymin_t[uly] + nty);
+    const int r_lo = ur_lo + by * ROWS;
+    if (r_lo >= ur_hi) return;
+    const int r_hi = min(ur_hi, r_lo + ROWS);
+    const int c_lo = xmin_t[fx], c_hi = min(Ws, xmin_t[lx] + ntx);
+    const int r_lo_h = max(0, r_lo - s), r_hi_h = min(Hs, r_hi + s);
+    const int c_lo_h = max(0, c_lo - s) & ~3, c_hi_h = min(Ws, (c_hi + s + 3) & ~3);
+    const int pw = c_hi_h - c_lo_h;
+    // horizontal pass: thread <-> (output column hc, row parity hg); its taps are loaded before the patch is built
+    const int hc = tid & (GH_CB - 1), hg = tid >> 7;
+    const int xh = x0 + hc;
+    const bool col_ok = xh >= fx && xh <= lx;
+    int hxm = 0, hk[GT_TAPS];
+#pragma unroll
+    for (int t = 0; t < GT_TAPS; ++t) hk[t] = 0;
+    {
+        const int xc = min(max(xh, fx), lx);                  // clamped: no conditional loads
+        hxm = xmin_t[xc];
+#pragma unroll
+        for (int t = 0; t < GT_TAPS; ++t) hk[t] = xk_t[(size_t)xc * KMAX + (t < ntx ? t : 0)];
+#pragma unroll
+        for (int t = 0; t < GT_TAPS; ++t) hk[t] = t < ntx ? hk[t] : 0;
+    }
+    const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
+    const uint32_t* cur = build_patch<GH_NR, 2>(un, n_ops, src, Hs, Ws, r_lo_h, r_hi_h, c_lo_h, c_hi_h, A, SHARP ? Bs : A, lut,
+                                                lut_stage_stride, u, sl);
+    if (!col_ok) return;
+    const int nrows = r_hi - r_lo;
+    const uint32_t* colp = cur + (r_lo - r_lo_h) * pw + (hxm - c_lo_h);
+    const int lim = pw - (hxm - c_lo_h);
+    uint32_t* hout = hbuf + ((size_t)slot * Hs + r_lo) * crop + xh;
+    if (ntx == GT_TAPS) {
+#pragma unroll 2
+        for (int rr = hg; rr < nrows; rr += 2) hout[(size_t)rr * crop] = hpass_px<GT_TAPS>(colp + rr * pw, hk, lim);
+    } else if (ntx == 2) {
+#pragma unroll 2
+        for (int rr = hg; rr < nrows; rr += 2) hout[(size_t)rr * crop] = hpass_px<2>(colp + rr * pw, hk, lim);
+    } else {
+#pragma unroll 2
+        for (int rr = hg; rr < nrows; rr += 2) hout[(size_t)rr * crop] = hpass_px<1>(colp + rr * pw, hk, lim);
+    }
+}
+
+template <bool SHARP>
+__global__ __launch_bounds__(256) void k_gen_hpass(const uint8_t* __restrict__ pool, const aadg_unit* __restrict__ units,
+                                                   const int* __restrict__ order, int slot0, int Hs, int Ws, int crop,
+                                                   const int* __restrict__ tab, const uint8_t* __restrict__ lut,
+                                                   size_t lut_stage_stride, uint32_t* __restrict__ hbuf) {
+    __shared__ __attribute__((aligned(16))) uint32_t A[PATCH_CAP + 8];
+    __shared__ __attribute__((aligned(16))) uint32_t Bs[SHARP ? PATCH_CAP + 8 : 4];
+    __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
+    gen_hpass_body<SHARP>(pool, units, order, slot0 + blockIdx.z, blockIdx.x, blockIdx.y, Hs, Ws, crop, tab, lut, lut_stage_stride, hbuf, A, Bs, sl);
+}
+
+struct __attribute__((packed)) UnalignedU32 { uint32_t v; };
+constexpr int GV_ROWS = 16;            // output rows per vertical-pass workgroup: 4 consecutive rows per wave
+
+// two consecutive output rows of a lane's 4 columns: all loads of both rows (intermediate rows at clamped indices, the mask window)
+// are issued before the first one is used -- a wave has nothing else to cover their latency with
+struct VRow { int y, vym, vyn; int vk[GT_TAPS]; };
+
+template <int NT>
+__device__ __forceinline__ void vpass_pair(const VRow (&row)[2], int nrows_live, const uint32_t* __restrict__ hcol, const uint8_t* __restrict__ msk,
+                                           int Hs, int Ws, int crop, const int* xm, const int* xn, bool win_ok, bool any_col, bool optic, int K,
+                                           const float* lutf, float* oi, float* ol, size_t plane, int xq, bool stream_out) {
+    const float padv = -1.0f;
+    const bool any_row = any_col && (row[0].vym >= 0 || row[1].vym >= 0);      // uniform
+    const bool any_msk = row[0].vyn >= 0 || row[1].vyn >= 0;                   // uniform
+    uint4 hv[2][NT];
+    uint32_t mlo[2] = {0u, 0u}, mhi[2] = {0u, 0u};
+    if (any_row) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int hr = min(max(row[j].vym, 0) + t, Hs - 1);           // zero coefficient beyond the last source row
+                hv[j][t] = *reinterpret_cast<const uint4*>(hcol + (size_t)hr * crop);
+            }
+    }
+    // NEAREST mask bytes: no axis shrinks by more than 2, so the 4 source columns of a lane lie within 8 consecutive bytes -- two
+    // unaligned dword loads instead of four byte gathers (a lane at the row's end, or with a pad column, takes the byte loads below)
+    const int mbase = min(max(xn[0], 0), Ws - 8);
+    if (any_msk) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint8_t* mrow = msk + (size_t)max(row[j].vyn, 0) * Ws + mbase;
+            mlo[j] = reinterpret_cast<const UnalignedU32*>(mrow)->v;
+            mhi[j] = reinterpret_cast<const UnalignedU32*>(mrow + 4)->v;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j >= nrows_live) break;                                            // uniform: the last row pair of the image
+        const VRow& rw = row[j];
+        uint32_t mv[4] = {0u, 0u, 0u, 0u};
+        if (rw.vyn >= 0) {
+            if (win_ok) {
+                const unsigned long long win = ((unsigned long long)mhi[j] << 32) | mlo[j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mv[i] = (uint32_t)(win >> (8 * (xn[i] - mbase))) & 255u;
+            } else {
+                const uint8_t* mrow = msk + (size_t)rw.vyn * Ws;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (xn[i] >= 0) mv[i] = mrow[xn[i]];
+            }
+        }
+        float o[3][4];
+        if (rw.vym >= 0 && any_col) {
+            int acc[4][3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = 1 << (PRECISION_BITS - 1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const uint32_t a[4] = {hv[j][t].x, hv[j][t].y, hv[j][t].z, hv[j][t].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][0] += __mul24((int)(a[i] & 255), rw.vk[t]);
+                    acc[i][1] += __mul24((int)((a[i] >> 8) & 255), rw.vk[t]);
+                    acc[i][2] += __mul24((int)((a[i] >> 16) & 255), rw.vk[t]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o[c][i] = xm[i] >= 0 ? lutf[clip8(acc[i][c])] : padv;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[0][i] = o[1][i] = o[2][i] = padv;
+        }
+        float l0[4], l1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t m = mv[i];
+            if (optic) { l0[i] = m <= 50 ? 1.0f : 0.0f; l1[i] = m <= 200 ? 1.0f : 0.0f; }
+            else { l0[i] = m != 0 ? 1.0f : 0.0f; l1[i] = 0.0f; }
+        }
+        const size_t off = (size_t)rw.y * crop + xq;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            store_out4(oi + c * plane + off, make_float4(o[c][0], o[c][1], o[c][2], o[c][3]), stream_out);
+        store_out4(ol + off, make_float4(l0[0], l0[1], l0[2], l0[3]), stream_out);
+        if (K == 2) store_out4(ol + plane + off, make_float4(l1[0], l1[1], l1[2], l1[3]), stream_out);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gen_vpass(const uint8_t* __restrict__ masks, const aadg_unit* __restrict__ units,
+                                                   const int* __restrict__ order, int Hs, int Ws, int crop, int dataset_in,
+                                                   const int* __restrict__ tab, const uint32_t* __restrict__ hbuf,
+                                                   float* __restrict__ out_img, float* __restrict__ out_lbl) {
+    const int dataset = dataset_in & 0xFF;
+    const bool stream_out = (dataset_in & AUG_STREAM_OUT) != 0;
+    const int slot = blockIdx.z;
+    const int u = order != nullptr ? order[slot] : slot;
+    const aadg_unit& un = units[u];
+    if (unit_flow(true, un, Hs, Ws, crop) != FLOW_GENERIC) return;
+    __shared__ float lutf[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // uniform: the row tables become scalar loads
+    lutf[tid] = normalise_u8(tid);
+    __syncthreads();
+    const int K = dataset == AADG_DATASET_OPTIC ? 2 : 1;
+    const int* base = tab + (size_t)u * crop * TAB_STRIDE;
+    const int* xmin_t = base;
+    const int* xk_t = xmin_t + crop;
+    const int* ymin_t = xk_t + (size_t)crop * KMAX;
+    const int* yk_t = ymin_t + crop;
+    const int* xnn_t = yk_t + (size_t)crop * KMAX;
+    const int* ynn_t = xnn_t + crop;
+    const int xq = blockIdx.x * 256 + 4 * lane;
+    if (xq >= crop) return;
+    const int ybase = blockIdx.y * GV_ROWS + wv * (GV_ROWS / 4);
+    if (ybase >= crop) return;
+    // the row tables of the wave's rows: one batch of scalar loads (rows beyond the image: the last row's entries, not stored)
+    VRow rows[GV_ROWS / 4];
+#pragma unroll
+    for (int r = 0; r < GV_ROWS / 4; ++r) {
+        const int y = min(ybase + r, crop - 1);
+        rows[r].y = y;
+        rows[r].vym = ymin_t[y];
+        rows[r].vyn = ynn_t[y];
+#pragma unroll
+        for (int t = 0; t < GT_TAPS; ++t) rows[r].vk[t] = yk_t[(size_t)y * KMAX + t];
+    }
+    const int4 xm4 = *reinterpret_cast<const int4*>(xmin_t + xq), xn4 = *reinterpret_cast<const int4*>(xnn_t + xq);
+    const int xm[4] = {xm4.x, xm4.y, xm4.z, xm4.w}, xn[4] = {xn4.x, xn4.y, xn4.z, xn4.w};
+    const int nty = axis_taps(Hs, un.scaled_h);
+    const uint8_t* msk = masks + (size_t)un.src * Hs * Ws;
+    const uint32_t* hcol = hbuf + (size_t)slot * Hs * crop + xq;
+    const bool win_ok = xn[0] >= 0 && xn[3] >= 0 && xn[1] >= xn[0] && xn[2] >= xn[0] && xn[3] >= xn[0] && xn[1] - xn[0] < 8 && xn[2] - xn[0] < 8 &&
+                        xn[3] - xn[0] < 8 && xn[0] + 8 <= Ws;
+    // uniform: false for a wave that lies in the pad columns
+    const bool any_col = __any((xm[0] >= 0) | (xm[1] >= 0) | (xm[2] >= 0) | (xm[3] >= 0)) != 0;
+    const size_t plane = (size_t)crop * crop;
+    float* oi = out_img + (size_t)u * 3 * plane;
+    float* ol = out_lbl + (size_t)u * K * plane;
+    const bool optic = dataset == AADG_DATASET_OPTIC;
+#pragma unroll
+    for (int pr = 0; pr < GV_ROWS / 8; ++pr) {
+        const int live = min(2, crop - (ybase + 2 * pr));
+        if (live <= 0) break;
+        const VRow (&pair)[2] = reinterpret_cast<const VRow (&)[2]>(rows[2 * pr]);
+        if (nty == GT_TAPS) vpass_pair<GT_TAPS>(pair, live, hcol, msk, Hs, Ws, crop, xm, xn, win_ok, any_col, optic, K, lutf, oi, ol, plane, xq, stream_out);
+        else if (nty == 2) vpass_pair<2>(pair, live, hcol, msk, Hs, Ws, crop, xm, xn, win_ok, any_col, optic, K, lutf, oi, ol, plane, xq, stream_out);
+        else vpass_pair<1>(pair, live, hcol, msk, Hs, Ws, crop, xm, xn, win_ok, any_col, optic, K, lutf, oi, ol, plane, xq, stream_out);
+    }
+}
+
 // one workgroup per tile
 template <int TH>
 __global__ __launch_bounds__(256) void k_fused(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
@@ -1388,7 +1658,6 @@ __global__ __launch_bounds__(256) void k_fused(const uint8_t* __restrict__ pool,
 //   * 32-bit offsets from uniform base pointers for the stores.
 // Arithmetic and results are those of k_fused (bit-exact with Pillow), which stays selectable (AADG_FUSED_V1=1).
 // ------------------------------------------------------------------------------------------------
-struct __attribute__((packed)) UnalignedU32 { uint32_t v; };
 constexpr int PATCH_CAP_PLAIN = 4608;     // 17 rows x 264 columns: a 256 x 16 tile's patch without a stencil halo
 constexpr int HBUF_ROWS = FT_H + 1;       // source rows a 16-row tile touches when no axis shrinks
 
@@ -1412,7 +1681,7 @@ __device__ __forceinline__ void fused3_body(const uint8_t* __restrict__ pool, co
                                             const aadg_unit* __restrict__ units, int Hs, int Ws, int crop, int dataset_in,
                                             const int* __restrict__ tab, const uint8_t* __restrict__ lut, size_t lut_stage_stride,
                                             float* __restrict__ out_img, float* __restrict__ out_lbl, int u, int half,
-                                            uint32_t* A, uint32_t* B, uint8_t* sl, float* lutf) {
+                                            uint32_t* A, uint32_t* B, uint8_t* sl, float* lutf, int bx, int by) {
     const int dataset = dataset_in & 0xFF;
     const bool stream_out = (dataset_in & AUG_STREAM_OUT) != 0;
     const aadg_unit& un = units[u];
@@ -1433,11 +1702,11 @@ __device__ __forceinline__ void fused3_body(const uint8_t* __restrict__ pool, co
     const uint32_t plane = (uint32_t)crop * (uint32_t)crop;
     float* oi = out_img + (size_t)u * 3 * plane;            // uniform bases, 32-bit lane offsets
     float* ol = out_lbl + (size_t)u * K * plane;
-    const int x0 = blockIdx.x * FT_W, x1 = min(x0 + FT_W, crop);
+    const int x0 = bx * FT_W, x1 = min(x0 + FT_W, crop);
     // A unit that chains Sharpness stencils needs a halo and a ping-pong buffer: its tiles are 8 rows high (two workgroups per
     // 16-row tile), which fits the same two buffers (13 x 268 patch words) instead of a second, larger LDS layout.
     constexpr int TROWS = SHARP ? FT_H / 2 : FT_H;
-    const int y0 = blockIdx.y * FT_H + half * TROWS, y1 = min(y0 + TROWS, crop);
+    const int y0 = by * FT_H + half * TROWS, y1 = min(y0 + TROWS, crop);
     if (y0 >= crop) return;
     const int ox = u_cx - u_pad, oy = u_cy - u_pad;
     const int fx = max(x0, -ox), lx = min(x1 - 1, w - 1 - ox);
@@ -1605,6 +1874,23 @@ __device__ __forceinline__ void fused3_body(const uint8_t* __restrict__ pool, co
     }
 }
 
+// one z-slice of k_fused3's grid: the plain units' tiles, then two 8-row workgroups per 16-row tile of a stencil unit
+__device__ __forceinline__ void fused3_slice(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
+                                             const aadg_unit* __restrict__ units, const int* __restrict__ order,
+                                             const int* __restrict__ order_sharp, int n_plain, int Hs, int Ws, int crop, int dataset,
+                                             const int* __restrict__ tab, const uint8_t* __restrict__ lut, size_t lut_stage_stride,
+                                             float* __restrict__ out_img, float* __restrict__ out_lbl, int bx, int by, int z,
+                                             uint32_t* A, uint32_t* B, uint8_t* sl, float* lutf) {
+    if (z < n_plain) {
+        const int u = order != nullptr ? order[z] : z;
+        fused3_body<false>(pool, masks, units, Hs, Ws, crop, dataset, tab, lut, lut_stage_stride, out_img, out_lbl, u, 0, A, B, sl, lutf, bx, by);
+    } else {
+        const int zz = z - n_plain;
+        const int u = order_sharp != nullptr ? order_sharp[zz >> 1] : (zz >> 1);
+        fused3_body<true>(pool, masks, units, Hs, Ws, crop, dataset, tab, lut, lut_stage_stride, out_img, out_lbl, u, zz & 1, A, B, sl, lutf, bx, by);
+    }
+}
+
 // grid (ceil(crop/256), ceil(crop/16), n_plain + 2 n_sharp): the first n_plain z-slices run the plain body on unit order[z],
 // the rest the Sharpness body, two 8-row workgroups per unit and 16-row tile.  `order` lists the unit indices grouped by
 // class (the caller classifies on the host: `order` = the plain units, `order_sharp` = the Sharpness units); without it every
@@ -1619,19 +1905,12 @@ __global__ __launch_bounds__(256) void k_fused3(const uint8_t* __restrict__ pool
     __shared__ __attribute__((aligned(16))) uint32_t B[HBUF_ROWS * FT_W];
     __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
     __shared__ float lutf[256];
-    const int z = blockIdx.z;
-    if (z < n_plain) {
-        const int u = order != nullptr ? order[z] : z;
-        fused3_body<false>(pool, masks, units, Hs, Ws, crop, dataset, tab, lut, lut_stage_stride, out_img, out_lbl, u, 0, A, B, sl, lutf);
-    } else {
-        const int zz = z - n_plain;
-        const int u = order_sharp != nullptr ? order_sharp[zz >> 1] : (zz >> 1);
-        fused3_body<true>(pool, masks, units, Hs, Ws, crop, dataset, tab, lut, lut_stage_stride, out_img, out_lbl, u, zz & 1, A, B, sl, lutf);
-    }
+    fused3_slice(pool, masks, units, order, order_sharp, n_plain, Hs, Ws, crop, dataset, tab, lut, lut_stage_stride, out_img, out_lbl,
+                 blockIdx.x, blockIdx.y, blockIdx.z, A, B, sl, lutf);
 }
 
 struct WsLayout {
-    size_t hist, lut, tab, buf0, buf1, total;
+    size_t hist, lut, tab, buf0, buf1, hbuf, total;
 };
 WsLayout ws_layout(int N, int Hs, int Ws, int crop) {
     WsLayout l;
@@ -1642,6 +1921,8 @@ WsLayout ws_layout(int N, int Hs, int Ws, int crop) {
     const size_t img = (size_t)Hs * Ws * 3;
     l.buf0 = o; o = aadg_align_up(o + (size_t)N * img, 256);
     l.buf1 = o; o = aadg_align_up(o + (size_t)N * img, 256);
+    // horizontally resampled rows of the down-scaling units (k_gen_hpass -> k_gen_vpass): [unit slot][Hs][crop] packed RGBX
+    l.hbuf = o; o = aadg_align_up(o + (size_t)N * Hs * crop * 4, 256);
     l.total = o;
     return l;
 }
@@ -1657,6 +1938,51 @@ constexpr int HINT_FUSED = 1, HINT_STAGED = 2, HINT_GENERIC = 4;
 bool getenv_flag(const char* name) {
     const char* v = getenv(name);
     return v != nullptr && v[0] != '\0' && v[0] != '0';
+}
+
+// The tile kernels of a call: k_fused3 over the up-scaling units (np plain slices + 2 per stencil unit; order_up == NULL: every unit is
+// offered every kind of slice), and for the ng down-scaling ("generic") units the horizontal pass (units without a stencil, then the
+// last ng_sharp units of the list with the stencil's ping-pong buffer) + the vertical pass -- or the one-pass tile kernel
+// k_fused_generic with AADG_GENERIC_V1=1.
+int launch_tiles(const uint8_t* pool, const uint8_t* masks, const aadg_unit* units, const int* order_up, int np, int ns, const int* order_gen,
+                 int ng, int ng_sharp, int Hs, int Ws, int crop, int dsk, const int* tab, const uint8_t* lut, size_t lut_stage_stride,
+                 uint32_t* hbuf, float* out_img, float* out_lbl, hipStream_t st) {
+    static const bool v1 = getenv_flag("AADG_GENERIC_V1");
+    const int gx = (crop + FT_W - 1) / FT_W, gy = (crop + FT_H - 1) / FT_H, gz = np + 2 * ns;
+    const int* order_sharp = order_up != nullptr ? order_up + np : nullptr;
+    // with the caller's list the stencil units are the last ng_sharp entries; without one every unit is offered to both variants
+    const bool listed = order_gen != nullptr;
+    const int n0 = v1 ? 0 : (listed ? ng - ng_sharp : ng), n1 = v1 ? 0 : (listed ? ng_sharp : ng), s1 = listed ? ng - ng_sharp : 0;
+    const int hx = (crop + GH_CB - 1) / GH_CB, hy0 = (Hs + GhRows<false>::value - 1) / GhRows<false>::value;
+    // (Measured and dropped: k_fused3's tiles and the horizontal-pass tiles interleaved in ONE launch, so that the store-bound and the
+    // issue-bound workgroups share the CUs: 611 us against 376 + 176 us one after the other at 1024 x 1024 -- both are issue-heavy.)
+    if (gz > 0) {
+        hipLaunchKernelGGL(k_fused3, dim3(gx, gy, gz), dim3(256), 0, st, pool, masks, units, order_up, order_sharp, np, Hs, Ws, crop, dsk, tab, lut,
+                           lut_stage_stride, out_img, out_lbl);
+        AADG_LAUNCH_CHECK();
+    }
+    if (n0 > 0) {
+        hipLaunchKernelGGL(k_gen_hpass<false>, dim3(hx, hy0, n0), dim3(256), 0, st, pool, units, order_gen, 0, Hs, Ws, crop, tab, lut,
+                           lut_stage_stride, hbuf);
+        AADG_LAUNCH_CHECK();
+    }
+    if (ng <= 0) return 0;
+    if (v1) {
+        const dim3 g((crop + GT_W - 1) / GT_W, (crop + GT_H - 1) / GT_H, ng);
+        hipLaunchKernelGGL(k_fused_generic, g, dim3(256), 0, st, pool, masks, units, order_gen, Hs, Ws, crop, dsk, tab, lut, lut_stage_stride,
+                           out_img, out_lbl);
+        AADG_LAUNCH_CHECK();
+        return 0;
+    }
+    if (n1 > 0) {
+        hipLaunchKernelGGL(k_gen_hpass<true>, dim3(hx, (Hs + GhRows<true>::value - 1) / GhRows<true>::value, n1), dim3(256), 0, st, pool, units,
+                           order_gen, s1, Hs, Ws, crop, tab, lut, lut_stage_stride, hbuf);
+        AADG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_gen_vpass, dim3((crop + 255) / 256, (crop + GV_ROWS - 1) / GV_ROWS, ng), dim3(256), 0, st, masks, units, order_gen, Hs, Ws,
+                       crop, dsk, tab, hbuf, out_img, out_lbl);
+    AADG_LAUNCH_CHECK();
+    return 0;
 }
 
 // statistics + LUT (+ staged apply) for stages [0, max_ops)
@@ -1769,17 +2095,10 @@ int forward_cached(const uint8_t* pool, const uint8_t* masks, const UnitRef& ur,
             AADG_LAUNCH_CHECK();
         }
     if (ev_before) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_before), st));
-    if (n_plain + 2 * n_sharp > 0) {
-        const dim3 g((crop + FT_W - 1) / FT_W, (crop + FT_H - 1) / FT_H, n_plain + 2 * n_sharp);
-        hipLaunchKernelGGL(k_fused3, g, dim3(256), 0, st, pool, masks, ur.units, ls.order, ls.order + n_plain, n_plain, Hs, Ws, crop, dsk,
-                           tab, lut, lut_stage_stride, out_img, out_lbl);
-        AADG_LAUNCH_CHECK();
-    }
-    if (n_generic > 0) {
-        const dim3 gg((crop + GT_W - 1) / GT_W, (crop + GT_H - 1) / GT_H, n_generic);
-        hipLaunchKernelGGL(k_fused_generic, gg, dim3(256), 0, st, pool, masks, ur.units, ls.order + n_plain + n_sharp, Hs, Ws, crop, dsk,
-                           tab, lut, lut_stage_stride, out_img, out_lbl);
-        AADG_LAUNCH_CHECK();
+    {
+        const int rc = launch_tiles(pool, masks, ur.units, ls.order, n_plain, n_sharp, ls.order + n_plain + n_sharp, n_generic, ls.n_generic_sharp, Hs, Ws,
+                                    crop, dsk, tab, lut, lut_stage_stride, reinterpret_cast<uint32_t*>(ws8 + L.hbuf), out_img, out_lbl, st);
+        if (rc) return rc;
     }
     if (ev_after) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_after), st));
     return 0;
@@ -1815,6 +2134,7 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
     if (dataset != AADG_DATASET_OPTIC && dataset != AADG_DATASET_VESSEL) return AADG_E_BADARG;
     if ((size_t)N * (size_t)crop > (size_t)1 << 28) return AADG_E_BADARG;
     if (order != nullptr && (n_plain < 0 || n_sharp < 0 || n_generic < 0 || (long long)n_plain + n_sharp + n_generic > N)) return AADG_E_BADARG;
+    if (order != nullptr && (lists->n_generic_sharp < 0 || lists->n_generic_sharp > n_generic)) return AADG_E_BADARG;
     const WsLayout L = ws_layout(N, Hs, Ws, crop);
     const int dsk = aug_dataset_arg(dataset, N, crop);
     if (ws_bytes < L.total) return AADG_E_WORKSPACE;
@@ -1852,25 +2172,27 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
             hipLaunchKernelGGL(k_fused<FT_H>, g, dim3(256), 0, st, pool, masks, units, Hs, Ws, crop, dsk, tab, ws8 + L.lut,
                                (size_t)N * 768, out_img, out_lbl);
             AADG_LAUNCH_CHECK();
-        } else {
-            // with the caller's class lists: one z-slice per plain unit, two per Sharpness unit; without: every unit gets all three
-            const int np = order ? n_plain : N, ns = order ? n_sharp : N;
-            if (np + 2 * ns > 0) {
-                const dim3 g2(g.x, g.y, np + 2 * ns);
-                hipLaunchKernelGGL(k_fused3, g2, dim3(256), 0, st, pool, masks, units, order, order ? order + np : nullptr, np, Hs, Ws, crop,
-                                   dsk, tab, ws8 + L.lut, (size_t)N * 768, out_img, out_lbl);
+            if (classes & HINT_GENERIC) {
+                const int rc2 = launch_tiles(pool, masks, units, nullptr, 0, 0, order ? order + n_plain + n_sharp : nullptr, order ? n_generic : N,
+                                             lists ? lists->n_generic_sharp : 0, Hs, Ws, crop, dsk, tab, ws8 + L.lut, (size_t)N * 768,
+                                             reinterpret_cast<uint32_t*>(ws8 + L.hbuf), out_img, out_lbl, st);
+                if (rc2) return rc2;
             }
-            AADG_LAUNCH_CHECK();
+        } else {
+            // with the caller's class lists: one z-slice per plain unit, two per Sharpness unit, the down-scaling units' passes over their
+            // list; without: every unit is offered every kind of slice
+            const int np = order ? n_plain : N, ns = order ? n_sharp : N;
+            const int ng = (classes & HINT_GENERIC) ? (order ? n_generic : N) : 0;
+            const int rc2 = launch_tiles(pool, masks, units, order, np, ns, order ? order + n_plain + n_sharp : nullptr, ng,
+                                         lists ? lists->n_generic_sharp : 0, Hs, Ws, crop, dsk, tab, ws8 + L.lut, (size_t)N * 768,
+                                         reinterpret_cast<uint32_t*>(ws8 + L.hbuf), out_img, out_lbl, st);
+            if (rc2) return rc2;
         }
-    }
-    if (classes & HINT_GENERIC) {
+    } else if (classes & HINT_GENERIC) {
         const int ng = order ? n_generic : N;
-        if (ng > 0) {
-            const dim3 g((crop + GT_W - 1) / GT_W, (crop + GT_H - 1) / GT_H, ng);
-            hipLaunchKernelGGL(k_fused_generic, g, dim3(256), 0, st, pool, masks, units, order ? order + n_plain + n_sharp : nullptr, Hs, Ws,
-                               crop, dsk, tab, ws8 + L.lut, (size_t)N * 768, out_img, out_lbl);
-            AADG_LAUNCH_CHECK();
-        }
+        const int rc2 = launch_tiles(pool, masks, units, nullptr, 0, 0, order ? order + n_plain + n_sharp : nullptr, ng, lists ? lists->n_generic_sharp : 0,
+                                     Hs, Ws, crop, dsk, tab, ws8 + L.lut, (size_t)N * 768, reinterpret_cast<uint32_t*>(ws8 + L.hbuf), out_img, out_lbl, st);
+        if (rc2) return rc2;
     }
     if (classes & HINT_STAGED) {
         const dim3 g((crop + 255) / 256, (crop + FIN_ROWS - 1) / FIN_ROWS, N);

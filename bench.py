@@ -585,10 +585,11 @@ def rvs_1024_leg(n_units=144, size=1024):
     return {"workload": "BASELINE configs[2]: experiments/rvs_sinkhorn/diversity_ex.yaml pipeline, %dx%d crops from %dx%d sources, "
                         "%d units per batch (hot path only: augmentation call)" % (size, size, Hs, Hs, len(units)),
             "units": len(units), "units_by_tile_kernel": {"up_plain": n_flow[0], "up_sharpness": n_flow[1], "generic_downscale": n_flow[2],
-                                                          "staged": len(units) - sum(n_flow)},
+                                                          "generic_with_sharpness": n_flow[3],
+                                                          "staged": len(units) - sum(n_flow[:3])},
             "img_per_s": len(units) / (c_ms * 1e-3),
-            "roofline": {"bound": "hbm", "kernel": "k_fused3 + k_fused_generic (tile kernels of the batch; a 2x shrink reads 4x the source "
-                                                   "pixels per output pixel, so those tiles are LDS / issue bound)",
+            "roofline": {"bound": "hbm", "kernel": "k_fused3 + k_gen_hpass + k_gen_vpass (tile kernels of the batch: up-scaling units in one pass, "
+                                                   "down-scaling units as a horizontal and a vertical streaming pass)",
                          "achieved": kb / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": None, "bytes_per_launch": kb, "kernel_ms": k_ms,
                          "stage": {"bytes": sb, "ms": c_ms, "achieved": sb / (c_ms * 1e-3) / 1e9, "frac": sb / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}}

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AADG_ABI_VERSION 4
+#define AADG_ABI_VERSION 5
 #define AADG_MAX_OPS 4
 
 #define AADG_E_BADARG (-1)
@@ -103,7 +103,9 @@ int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks, int P, int
  * class returns at once but still occupies a slot with its LDS for about a microsecond).
  *   order       int32 [N]: unit indices grouped by tile class -- first the n_plain up-scaling units (both scaled sizes >= the
  *               source's) that chain no Sharpness stencil, then the n_sharp up-scaling units that do, then the n_generic units that
- *               shrink an axis by at most 2x; the remaining (staged) units follow in any order.
+ *               shrink an axis by at most 2x -- among them LAST the n_generic_sharp ones that chain a Sharpness stencil (ABI 5: their
+ *               horizontal pass is a launch of its own, with the stencil's ping-pong buffer) --; the remaining (staged) units follow
+ *               in any order.
  *   stat_units  per op slot k: the n_stat[k] units whose k-th op needs image statistics (AutoContrast / Equalize / Contrast) --
  *               the work list of the histogram kernels of that stage.  stat_units[0] == NULL: no statistics lists.
  *   pool_hist   uint32 [P][AADG_HIST_STRIDE] from aadg_pool_histograms_u8 (or NULL): the policy ops run on the RAW source image
@@ -126,6 +128,7 @@ typedef struct aadg_aug_lists {
      * late_units == NULL: stage by stage for all units. */
     const int32_t* late_units;
     int32_t n_late;
+    int32_t n_generic_sharp;   /* ABI 5: how many of the n_generic units (the last ones in `order`) chain a Sharpness stencil */
 } aadg_aug_lists;
 /* per-image histograms of a source pool [P, Hs, Ws, 3] (what PIL's Image.histogram() / ImageStat.Stat(convert('L')).mean read:
  * data/basic.py AutoContrast / Equalize / Contrast via ImageOps / ImageEnhance) */

@@ -37,7 +37,7 @@ rvs)
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE"; do
     i=$((i+1))
     rocprofv3 --pmc $set -d /tmp/pmc_rvs_sq$i -- python $R/bench.py --only_legs rvs1024 > /dev/null 2>&1
-    python $R/scripts/pmc_by_kernel.py /tmp/pmc_rvs_sq$i "k_fused" > $O/pmc_rvs1024_sq$i.txt
+    python $R/scripts/pmc_by_kernel.py /tmp/pmc_rvs_sq$i "k_" > $O/pmc_rvs1024_sq$i.txt
   done
   cat $O/pmc_rvs1024_sq*.txt > $O/rvs1024_pmc.txt
   ;;

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libaadg_hip.so does not export %s" % name
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.aadg_abi_version() == 4
+    assert lib.aadg_abi_version() == 5
 
 
 def test_unit_struct_layout_matches_header():
@@ -163,4 +163,7 @@ def test_round2_entry_points_validate_arguments():
     assert lib.aadg_upsample_sum(one, z, z, z, 4, one, 4, 8, 8, 0, z) == -1                                # n_low > 3
     assert lib.aadg_upsample_sum_backward(z, one, 4, 2, 2, 8, 8, 1, z) == -1
     assert lib.aadg_pool_histograms_u8(z, 1, 8, 8, one, z) == -1 and lib.aadg_pool_histograms_u8(one, 0, 8, 8, one, z) == -1
-    assert ctypes.sizeof(_lib.AugLists) == 8 + 16 + 8 * _lib.MAX_OPS + 4 * _lib.MAX_OPS + 8 + 8 + 8   # mirror of aadg_aug_lists
+    lists = _lib.AugLists()
+    lists.order, lists.n_generic, lists.n_generic_sharp = 16, 2, 3   # more stencil units than down-scaling units
+    assert lib.aadg_aug_u8_forward_ex2(one, one, 1, 8, 8, one, 4, 2, 8, 0, one, one, one, 1 << 30, z, 0, -1, z, z, ctypes.byref(lists)) == -1
+    assert ctypes.sizeof(_lib.AugLists) == 8 + 16 + 8 * _lib.MAX_OPS + 4 * _lib.MAX_OPS + 8 + 8 + 8   # mirror of aadg_aug_lists (n_generic_sharp fills the tail padding)

@@ -258,11 +258,12 @@ def test_launch_plan_classes_statistics_and_late_units():
         unit([(BRI, 1.1)], sw=40, sh=70),           # 7 shrinks x by < 2: generic class
         unit([(AC, 0), (SHA, 1.2), (EQ, 0)], 20, 64),   # 8 shrinks by > 2: staged; staged units never push forward
         unit([(SHA, 1.2), (SHA, 1.3), (SHA, 1.4)]),     # 9 three stencils: staged
+        unit([(SHA, 1.2)], sw=64, sh=40),               # 10 shrinks y by < 2 with a stencil: generic, listed behind the plain generic units
     ])
     classes, stats_mask, order, counts, stat_lists, late = _lib.launch_plan(units, H, W, crop)
     assert classes == 1 | 2 | 4
-    assert counts == (6, 1, 1)
-    assert sorted(order[:6].tolist()) == [0, 1, 2, 3, 4, 6] and order[6] == 5 and order[7] == 7 and sorted(order[8:].tolist()) == [8, 9]
+    assert counts == (6, 1, 2, 1)
+    assert sorted(order[:6].tolist()) == [0, 1, 2, 3, 4, 6] and order[6] == 5 and order[7] == 7 and order[8] == 10 and sorted(order[9:].tolist()) == [8, 9]
     assert stat_lists[0].tolist() == [1, 2, 8]                 # raw histograms: slot-0 statistics and push-forward sources
     assert stat_lists[1].tolist() == [3, 4] and stat_lists[2].tolist() == [8] and stat_lists[3].size == 0
     assert stats_mask == 0b111
