@@ -949,7 +949,10 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
                             srb += q & 0xFF00FFu;
                             sg += (q >> 8) & 255u;
                         }
-                    const uint32_t r = ((srb & 0xFFFFu) + 6u) / 13u, b = ((srb >> 16) + 6u) / 13u, g = (sg + 6u) / 13u;
+                    // (x + 6) / 13 for x <= 13 * 255: a 24-bit multiply by ceil(2^16 / 13) and a shift (exact for x + 6 <= 3321:
+                    // the error term x * 10 / (13 * 65536) stays below 1/13); a 32-bit division is several quarter-rate multiplies
+                    const uint32_t r = (uint32_t)__mul24((int)((srb & 0xFFFFu) + 6u), 5042) >> 16, b = (uint32_t)__mul24((int)((srb >> 16) + 6u), 5042) >> 16,
+                                   g = (uint32_t)__mul24((int)(sg + 6u), 5042) >> 16;
                     d = r | (g << 8) | (b << 16);
                 }
                 oth[i] = blend3(d, p, alpha, true);
@@ -1373,8 +1376,12 @@ __global__ __launch_bounds__(256) void k_fused_generic(const uint8_t* __restrict
 // k_fused_generic (one pass, above) stays selectable with AADG_GENERIC_V1=1; tests compare the two bit for bit.
 // ------------------------------------------------------------------------------------------------
 constexpr int GH_CB = 128;             // output columns per horizontal-pass tile: <= 2 * 128 + 5 source columns (+ halo, alignment) <= 272
-constexpr int GH_NR = 6;               // patch rows per wave of build_patch: 4 * 6 = 24 >= GH_ROWS + 2 * MAX_SHARP
-template <bool SHARP> struct GhRows { static constexpr int value = SHARP ? 18 : 22; };      // source rows per tile (22 x 272 <= PATCH_CAP)
+constexpr int GH_NR = 4;               // patch rows per wave of build_patch: 4 * GH_NR >= GH_PATCH_ROWS
+constexpr int GH_PATCH_ROWS = 16;      // patch rows; a tile covers 16 - 2 * (stencils of the unit) source rows.  Measured on a fixed 144-unit
+                                       // 1024 x 1024 mix (plain / stencil launch): 22 rows 144 / 93 us, 16 rows 141 / 86 us (20 KB of LDS: 7
+                                       // workgroups per CU), 12 rows 149 / 93 us
+constexpr int GH_CAP = GH_PATCH_ROWS * 272 + 8;      // patch words (272 = widest patch) + the slack the last row's taps may read
+template <bool SHARP> struct GhRows { static constexpr int value = SHARP ? GH_PATCH_ROWS - 2 * MAX_SHARP : GH_PATCH_ROWS; };   // fewest rows per tile (grid size)
 
 template <int NT>
 __device__ __forceinline__ uint32_t hpass_px(const uint32_t* rowp, const int* hk, int /*lim*/) {
@@ -1397,13 +1404,13 @@ __device__ __forceinline__ void gen_hpass_body(const uint8_t* __restrict__ pool,
                                                const int* __restrict__ order, int slot, int bx, int by, int Hs, int Ws, int crop,
                                                const int* __restrict__ tab, const uint8_t* __restrict__ lut,
                                                size_t lut_stage_stride, uint32_t* __restrict__ hbuf, uint32_t* A, uint32_t* Bs, uint8_t* sl) {
-    constexpr int ROWS = GhRows<SHARP>::value;
     const int u = order != nullptr ? order[slot] : slot;
     const aadg_unit& un = units[u];
     if (unit_flow(true, un, Hs, Ws, crop) != FLOW_GENERIC) return;
     const int n_ops = un.n_ops;
     const int s = sharp_count(un, n_ops);
     if ((s > 0) != SHARP) return;
+    const int ROWS = GH_PATCH_ROWS - 2 * s;                // the patch holds the tile's rows + the stencils' halo
     const int tid = threadIdx.x;
     const int* base = tab + (size_t)u * crop * TAB_STRIDE;
     const int* xmin_t = base;
@@ -1468,31 +1475,36 @@ __global__ __launch_bounds__(256) void k_gen_hpass(const uint8_t* __restrict__ p
                                                    const int* __restrict__ order, int slot0, int Hs, int Ws, int crop,
                                                    const int* __restrict__ tab, const uint8_t* __restrict__ lut,
                                                    size_t lut_stage_stride, uint32_t* __restrict__ hbuf) {
-    __shared__ __attribute__((aligned(16))) uint32_t A[PATCH_CAP + 8];
-    __shared__ __attribute__((aligned(16))) uint32_t Bs[SHARP ? PATCH_CAP + 8 : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t A[GH_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t Bs[SHARP ? GH_CAP : 4];
     __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
     gen_hpass_body<SHARP>(pool, units, order, slot0 + blockIdx.z, blockIdx.x, blockIdx.y, Hs, Ws, crop, tab, lut, lut_stage_stride, hbuf, A, Bs, sl);
 }
 
 struct __attribute__((packed)) UnalignedU32 { uint32_t v; };
 constexpr int GV_ROWS = 16;            // output rows per vertical-pass workgroup: 4 consecutive rows per wave
+constexpr int GV_G = 4;                // rows whose loads are issued together (2: 250 us, 4: 245 us; 8 or 32 rows per workgroup: 267 / 282 us)
 
-// two consecutive output rows of a lane's 4 columns: all loads of both rows (intermediate rows at clamped indices, the mask window)
+// GV_G consecutive output rows of a lane's 4 columns: all loads of these rows (intermediate rows at clamped indices, the mask window)
 // are issued before the first one is used -- a wave has nothing else to cover their latency with
 struct VRow { int y, vym, vyn; int vk[GT_TAPS]; };
 
 template <int NT>
-__device__ __forceinline__ void vpass_pair(const VRow (&row)[2], int nrows_live, const uint32_t* __restrict__ hcol, const uint8_t* __restrict__ msk,
+__device__ __forceinline__ void vpass_pair(const VRow (&row)[GV_G], int nrows_live, const uint32_t* __restrict__ hcol, const uint8_t* __restrict__ msk,
                                            int Hs, int Ws, int crop, const int* xm, const int* xn, bool win_ok, bool any_col, bool optic, int K,
                                            const float* lutf, float* oi, float* ol, size_t plane, int xq, bool stream_out) {
     const float padv = -1.0f;
-    const bool any_row = any_col && (row[0].vym >= 0 || row[1].vym >= 0);      // uniform
-    const bool any_msk = row[0].vyn >= 0 || row[1].vyn >= 0;                   // uniform
-    uint4 hv[2][NT];
-    uint32_t mlo[2] = {0u, 0u}, mhi[2] = {0u, 0u};
+    bool any_row = false, any_msk = false;                                     // uniform
+#pragma unroll
+    for (int j = 0; j < GV_G; ++j) { any_row = any_row || row[j].vym >= 0; any_msk = any_msk || row[j].vyn >= 0; }
+    any_row = any_row && any_col;
+    uint4 hv[GV_G][NT];
+    uint32_t mlo[GV_G], mhi[GV_G];
+#pragma unroll
+    for (int j = 0; j < GV_G; ++j) mlo[j] = mhi[j] = 0u;
     if (any_row) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < GV_G; ++j)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int hr = min(max(row[j].vym, 0) + t, Hs - 1);           // zero coefficient beyond the last source row
@@ -1504,15 +1516,15 @@ __device__ __forceinline__ void vpass_pair(const VRow (&row)[2], int nrows_live,
     const int mbase = min(max(xn[0], 0), Ws - 8);
     if (any_msk) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < GV_G; ++j) {
             const uint8_t* mrow = msk + (size_t)max(row[j].vyn, 0) * Ws + mbase;
             mlo[j] = reinterpret_cast<const UnalignedU32*>(mrow)->v;
             mhi[j] = reinterpret_cast<const UnalignedU32*>(mrow + 4)->v;
         }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        if (j >= nrows_live) break;                                            // uniform: the last row pair of the image
+    for (int j = 0; j < GV_G; ++j) {
+        if (j >= nrows_live) break;                                            // uniform: the last rows of the image
         const VRow& rw = row[j];
         uint32_t mv[4] = {0u, 0u, 0u, 0u};
         if (rw.vyn >= 0) {
@@ -1618,10 +1630,10 @@ __global__ __launch_bounds__(256) void k_gen_vpass(const uint8_t* __restrict__ m
     float* ol = out_lbl + (size_t)u * K * plane;
     const bool optic = dataset == AADG_DATASET_OPTIC;
 #pragma unroll
-    for (int pr = 0; pr < GV_ROWS / 8; ++pr) {
-        const int live = min(2, crop - (ybase + 2 * pr));
+    for (int pr = 0; pr < GV_ROWS / 4 / GV_G; ++pr) {
+        const int live = min(GV_G, crop - (ybase + GV_G * pr));
         if (live <= 0) break;
-        const VRow (&pair)[2] = reinterpret_cast<const VRow (&)[2]>(rows[2 * pr]);
+        const VRow (&pair)[GV_G] = reinterpret_cast<const VRow (&)[GV_G]>(rows[GV_G * pr]);
         if (nty == GT_TAPS) vpass_pair<GT_TAPS>(pair, live, hcol, msk, Hs, Ws, crop, xm, xn, win_ok, any_col, optic, K, lutf, oi, ol, plane, xq, stream_out);
         else if (nty == 2) vpass_pair<2>(pair, live, hcol, msk, Hs, Ws, crop, xm, xn, win_ok, any_col, optic, K, lutf, oi, ol, plane, xq, stream_out);
         else vpass_pair<1>(pair, live, hcol, msk, Hs, Ws, crop, xm, xn, win_ok, any_col, optic, K, lutf, oi, ol, plane, xq, stream_out);
