@@ -823,7 +823,11 @@ def _bn_prepare_grads(grads, x, has_res):
 BN_SYNC_REDUCE = None      # callable(float64 device tensor) -> None: in-place SUM over the ranks; None = torch.distributed.all_reduce
 
 
+BN_SYNC_COLLECTIVES = [0]  # all-reduces issued by the BatchNorm layers since the counter was last cleared (bench.py: collectives_per_step)
+
+
 def _bn_sync_reduce(t):
+    BN_SYNC_COLLECTIVES[0] += 1
     if BN_SYNC_REDUCE is not None:
         return BN_SYNC_REDUCE(t)
     import torch.distributed as dist
@@ -885,6 +889,98 @@ class _SyncBatchNormAct(torch.autograd.Function):
         _bn_sync_reduce(sums)
         _check(lib.aadg_bn_sync_backward(2, *args), "aadg_bn_sync_backward(2)")
         return (dx, dres, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None, None)
+
+
+class _SyncBatchNormActGroup(torch.autograd.Function):
+    """k INDEPENDENT BatchNorm (+ activation) layers of one step -- the branches of the ASPP head -- with ONE all-reduce per direction
+    instead of k: statistics kernels of all members, one all-reduce of the concatenated float64 sums, elementwise kernels of all
+    members; the backward receives the k output gradients together (one autograd node) and does the same with [sum g, sum g x^].
+    Members have no fused residual and one consumer.  apply(meta, x_0, weight_0, bias_0, rm_0, rv_0, out_0 | None, x_1, ...) with
+    meta = [(momentum, eps, act), ...]."""
+
+    @staticmethod
+    def forward(ctx, meta, *t):
+        lib = load()
+        k = len(meta)
+        mem = [t[6 * i:6 * i + 6] for i in range(k)]
+        dev = mem[0][0].device
+        Cs = [m[0].shape[1] for m in mem]
+        offs = [0]
+        for C in Cs:
+            offs.append(offs[-1] + 2 * C + 1)
+        sums = torch.empty(offs[-1], dtype=torch.float64, device=dev)
+        calls, ys, saved = [], [], []
+        for i, ((x, weight, bias, rm, rv, out), (momentum, eps, act)) in enumerate(zip(mem, meta)):
+            N, C, H, W = x.shape
+            y = torch.empty_like(x) if out is None else out
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            invstd = torch.empty(C, dtype=torch.float32, device=dev)
+            ws = workspace(lib.aadg_bn_workspace_bytes(C), dev, "bn_group_%d" % i)       # one scratch per member: their kernels interleave
+            calls.append((x.data_ptr(), None, y.data_ptr(), None, _ptr(weight), _ptr(bias), _ptr(rm), _ptr(rv), float(momentum), float(eps),
+                          int(act), N, C, H * W, _BN_DTYPES[x.dtype], mean.data_ptr(), invstd.data_ptr(), sums.data_ptr() + 8 * offs[i],
+                          ws.data_ptr(), ws.numel(), 0 if out is None else out.stride(0), _stream()))
+            ys.append(y)
+            saved += [x, weight, bias, mean, invstd]
+        for a in calls:
+            _check(lib.aadg_bn_sync_forward(1, *a), "aadg_bn_sync_forward(1)")
+        _bn_sync_reduce(sums)
+        for a in calls:
+            _check(lib.aadg_bn_sync_forward(2, *a), "aadg_bn_sync_forward(2)")
+        dirty = [m[5] for m in mem if m[5] is not None]
+        if dirty:
+            ctx.mark_dirty(*dirty)
+        ctx.meta, ctx.offs = meta, offs
+        ctx.save_for_backward(sums, *saved)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = load()
+        fsums, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        k = len(ctx.meta)
+        dev = fsums.device
+        Cs = [saved[5 * i].shape[1] for i in range(k)]
+        boffs = [0]
+        for C in Cs:
+            boffs.append(boffs[-1] + 2 * C)
+        bsums = torch.empty(boffs[-1], dtype=torch.float64, device=dev)
+        calls, outs, keep = [], [], []
+        for i in range(k):
+            x, weight, bias, mean, invstd = saved[5 * i:5 * i + 5]
+            N, C, H, W = x.shape
+            dy, extra, pconst, dy_stride = _bn_prepare_grads((grads[i],), x, False)
+            keep.append(dy)
+            dx = torch.empty_like(x)
+            dw = torch.empty(C, dtype=torch.float32, device=dev)
+            db = torch.empty(C, dtype=torch.float32, device=dev)
+            ws = workspace(lib.aadg_bn_workspace_bytes(C), dev, "bn_group_%d" % i)
+            calls.append((x.data_ptr(), None, None, dy.data_ptr(), None, 0, None, _ptr(weight), _ptr(bias), mean.data_ptr(), invstd.data_ptr(),
+                          int(ctx.meta[i][2]), dx.data_ptr(), None, dw.data_ptr(), db.data_ptr(), N, C, H * W, _BN_DTYPES[x.dtype],
+                          bsums.data_ptr() + 8 * boffs[i], fsums.data_ptr() + 8 * (ctx.offs[i] + 2 * C), ws.data_ptr(), ws.numel(), dy_stride,
+                          _stream()))
+            outs += [dx, dw if weight is not None else None, db if bias is not None else None, None, None, None]
+        for a in calls:
+            _check(lib.aadg_bn_sync_backward(1, *a), "aadg_bn_sync_backward(1)")
+        _bn_sync_reduce(bsums)
+        for a in calls:
+            _check(lib.aadg_bn_sync_backward(2, *a), "aadg_bn_sync_backward(2)")
+        return (None,) + tuple(outs)
+
+
+def sync_batch_norm_act_group(members):
+    """members: [(x, weight, bias, running_mean, running_var, momentum, eps, act, out | None), ...] -- independent training-mode
+    BatchNorm (+ activation) layers whose statistics travel in ONE all-reduce per direction.  Returns the outputs in order."""
+    meta, flat = [], []
+    for (x, weight, bias, rm, rv, momentum, eps, act, out) in members:
+        _require_cuda(x)
+        if not bn_act_supported(x):
+            raise AadgError("sync_batch_norm_act_group: expected contiguous NCHW float32/bfloat16 tensors")
+        if out is not None and (out.shape != x.shape or out.dtype != x.dtype or tuple(out.stride()[1:]) != tuple(x.stride()[1:]) or
+                                out.data_ptr() % 16 or out.stride(0) % 8):
+            raise AadgError("sync_batch_norm_act_group: `out` must be a channel slice of a contiguous NCHW buffer of the same dtype")
+        meta.append((float(momentum), float(eps), int(act)))
+        flat += [x, weight, bias, rm, rv, out]
+    return _SyncBatchNormActGroup.apply(meta, *flat)
 
 
 BN_MAX_EXTRA = 6
@@ -1260,7 +1356,7 @@ class _Conv1x1(torch.autograd.Function):
     def forward(ctx, x, weight):
         wq = cast_weight(weight, x.dtype)
         ctx.save_for_backward(x, wq)
-        ctx.wt = weight_layout(weight, "bwd")            # [1, Ci, Co] of the tracked shadow (this step's weights), or None
+        ctx.wt = _ShadowRef(weight, "bwd")               # [1, Ci, Co] of the tracked shadow (this step's weights)
         Co, Ci = wq.shape[0], wq.shape[1]
         if _own_gemm_1x1(Co, Ci, x.shape[2] * x.shape[3], x.shape[0]):
             return conv1x1_nchw(wq.view(Co, Ci), x)
@@ -1274,7 +1370,8 @@ class _Conv1x1(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             Co, Ci = wq.shape[0], wq.shape[1]
             if _own_gemm_1x1(Ci, Co, dy.shape[2] * dy.shape[3], dy.shape[0]):
-                dx = conv1x1_nchw(ctx.wt[0] if ctx.wt is not None else wq.view(Co, Ci).t().contiguous(), dy)
+                wt = ctx.wt.get()                        # None: untracked, or the shadow has moved on since the forward
+                dx = conv1x1_nchw(wt[0] if wt is not None else wq.view(Co, Ci).t().contiguous(), dy)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
@@ -1315,6 +1412,7 @@ _SHADOWS = {}          # id(weight) -> _Shadow
 # ANY optimizer also advances this epoch (a global post-step hook, installed with the first tracked model).
 _WEIGHTS_EPOCH = [0]
 _STEP_HOOK = []
+_OPT_OWNS = {}         # id(optimizer) -> does it hold a tracked weight (cleared whenever shadows are (re)built)
 
 
 def _install_step_hook():
@@ -1322,7 +1420,14 @@ def _install_step_hook():
         from torch.optim.optimizer import register_optimizer_step_post_hook
 
         def bump(optimizer, args, kwargs):
-            _WEIGHTS_EPOCH[0] += 1
+            # only an optimizer that owns a tracked weight changes one (the discriminator's and the controller's steps run between the
+            # segmentation model's forward and backward)
+            owns = _OPT_OWNS.get(id(optimizer))
+            if owns is None:
+                owns = any(id(p) in _SHADOWS for g in optimizer.param_groups for p in g['params'])
+                _OPT_OWNS[id(optimizer)] = owns
+            if owns:
+                _WEIGHTS_EPOCH[0] += 1
         _STEP_HOOK.append(register_optimizer_step_post_hook(bump))
 
 
@@ -1349,6 +1454,37 @@ def weight_layout(weight, which):
     return e.fwd if which == "fwd" else e.bwd
 
 
+class _ShadowRef(object):
+    """What an autograd function keeps of a shadow layout between forward and backward: the buffer AND the state it was valid in.
+    The buffers are overwritten in place by the next refresh, so a backward that runs after a later forward + optimizer step (deferred
+    backward, checkpointing) must not read them: `get()` then returns None and the caller rebuilds the layout from its saved weights."""
+    __slots__ = ("entry", "tensor", "version", "epoch")
+
+    def __init__(self, weight, which):
+        e = _SHADOWS.get(id(weight))
+        self.entry, self.tensor = None, None
+        if e is not None and e.valid_for(weight):
+            self.entry, self.tensor, self.version, self.epoch = e, (e.fwd if which == "fwd" else e.bwd), e.version, e.epoch
+
+    def get(self):
+        e = self.entry
+        if e is None:
+            return None                     # untracked weight: the caller builds the layout from its own saved cast
+        if e.version != self.version or e.epoch != self.epoch or e.epoch != _WEIGHTS_EPOCH[0]:
+            # the saved bfloat16 cast aliases the shadow too (cast_weight), so the forward's weights are gone: fail loudly
+            raise AadgError("backward of a tracked convolution after its weights changed (optimizer step or invalidate_weight_shadows() "
+                            "between forward and backward): the bfloat16 shadows hold the NEW weights.  Run backward before the step, "
+                            "or build the model without track_bf16_weights")
+        return self.tensor
+
+
+def invalidate_weight_shadows():
+    """Call after changing tracked master weights OUTSIDE a torch.optim step and without bumping their version counter (writes through
+    `.data`, `torch._foreach_*` on `.data`, loading a checkpoint into `.data`): every shadow is rebuilt at the next forward.  In-place
+    ATen ops on the parameter itself and optimizer steps are detected automatically (version counter, global post-step hook)."""
+    _WEIGHTS_EPOCH[0] += 1
+
+
 class _WeightLayouts(object):
     """All tracked weights of one model: shadows, the device item / tile tables of aadg_weight_layouts_bf16, one launch per refresh."""
 
@@ -1359,6 +1495,7 @@ class _WeightLayouts(object):
 
     def _build(self):
         import weakref
+        _OPT_OWNS.clear()
         dev = self.entries[0][0].device
         items = (WlItem * len(self.entries))()
         tiles = []
@@ -1494,7 +1631,7 @@ class _Conv3x3S2(torch.autograd.Function):
     def forward(ctx, x, weight):
         wq = cast_weight(weight, x.dtype)
         ctx.save_for_backward(x, wq)
-        ctx.a9t = weight_layout(weight, "bwd")           # tap-major transposed shadow (this step's weights), or None
+        ctx.a9t = _ShadowRef(weight, "bwd")              # tap-major transposed shadow (this step's weights)
         Co, Ci = wq.shape[0], wq.shape[1]
         if load().aadg_conv3x3s2_nchw_supported(Co, Ci, x.shape[2] // 2, x.shape[3] // 2):
             a9 = weight_layout(weight, "fwd")
@@ -1509,7 +1646,8 @@ class _Conv3x3S2(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             M, C = wq.shape[0], wq.shape[1]
             if load().aadg_conv3x3s2_dgrad_supported(C, M, dy.shape[2], dy.shape[3]):
-                dx = conv3x3s2_dgrad(ctx.a9t if ctx.a9t is not None else wq.permute(2, 3, 1, 0).reshape(9, C, M).contiguous(), dy)
+                a9t = ctx.a9t.get()
+                dx = conv3x3s2_dgrad(a9t if a9t is not None else wq.permute(2, 3, 1, 0).reshape(9, C, M).contiguous(), dy)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
@@ -1566,7 +1704,7 @@ class _Conv3x3(torch.autograd.Function):
     def forward(ctx, x, weight, dilation):
         wq = cast_weight(weight, x.dtype)
         ctx.save_for_backward(x, wq)
-        ctx.a9t = weight_layout(weight, "bwd")           # tap-major transposed shadow (this step's weights), or None
+        ctx.a9t = _ShadowRef(weight, "bwd")              # tap-major transposed shadow (this step's weights)
         ctx.dilation = dilation
         Co, Ci = wq.shape[0], wq.shape[1]
         if _own_conv3x3_fwd(x, Co, Ci, dilation):
@@ -1584,7 +1722,8 @@ class _Conv3x3(torch.autograd.Function):
             Co, Ci = wq.shape[0], wq.shape[1]
             if _own_conv3x3_fwd(dy, Ci, Co, d):
                 # the same kernel on dy with the taps mirrored and the channel roles swapped
-                a9t = ctx.a9t if ctx.a9t is not None else wq.flip(2, 3).permute(2, 3, 1, 0).reshape(9, Ci, Co).contiguous()
+                a9t = ctx.a9t.get()
+                a9t = a9t if a9t is not None else wq.flip(2, 3).permute(2, 3, 1, 0).reshape(9, Ci, Co).contiguous()
                 dx = conv3x3_nchw(a9t, dy, d)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [1, 1], [d, d], [d, d], False, [0, 0], 1,

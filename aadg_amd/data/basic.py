@@ -46,10 +46,12 @@ class DevicePool(object):
             return None
         if not self.images.is_cuda:
             return None
-        if self._hist is None or self._hist_version != self.images._version:      # in-place writes to the pool bump its version
+        # in-place writes to the pool bump its version; rebinding `images` to another tensor changes its address / shape
+        key = (self.images._version, self.images.data_ptr(), tuple(self.images.shape))
+        if self._hist is None or self._hist_version != key:
             from .. import _lib
             self._hist = _lib.pool_histograms(self.images)
-            self._hist_version = self.images._version
+            self._hist_version = key
         return self._hist
 
     def invalidate(self):

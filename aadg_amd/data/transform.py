@@ -388,7 +388,7 @@ def _fast_policy_steps(policy, pool):
                 if value > 0.:
                     rec.append(('cutout', value * pool.size[0]))
             else:
-                key = (fn, value)
+                key = (fn, value, pool.size)       # a probe on an image of this size (Cutout and friends depend on it)
                 st = _STEP_CACHE.get(key)
                 if st is None:                 # (op, magnitude) pairs come from a small discrete set: probe each once
                     probe, _ = fn(ImageRef(pool, 0), MaskRef(pool, 0), value)
@@ -415,6 +415,9 @@ def fast_train_units(dataset, n_items):
     objects, copies and property calls per item.  Returns None when the dataset's pipeline is not the standard one."""
     from .basic import cutout_rect
     from .policy import DGMultiPolicy
+    from .synthetic import SyntheticDGSegmentation
+    if type(dataset) is not SyntheticDGSegmentation:       # the draws below mirror synthetic.py:__getitem__ (pool, n_domains, per_domain)
+        return None
     tfs = getattr(getattr(dataset, 'transforms', None), 'transforms', None)
     if (tfs is None or len(tfs) != 4 or type(tfs[0]) is not DGMultiPolicy or type(tfs[1]) is not DGRandomScaleCrop or
             type(tfs[2]) is not Normalize_dg or type(tfs[3]) is not ToTensor or getattr(dataset, 'phase', 'train') == 'test'):

@@ -89,6 +89,10 @@ def shard_rows(n_rows, rank=None, world_size=None):
     which only feed the warm-up epochs)."""
     if rank is None or world_size is None:
         rank, world_size = world()
+    if n_rows < world_size:
+        # an empty slice would give that rank a mean over zero images: NaN, which DDP then all-reduces into every replica
+        raise ValueError("%d rows cannot be cut over %d ranks (every rank needs at least one row): raise TRAIN.BATCH_SIZE or use "
+                         "fewer GPUs" % (n_rows, world_size))
     cuts = balanced_cuts(n_rows, world_size)
     return cuts[rank], cuts[rank + 1]
 

@@ -87,6 +87,12 @@ def bn_act(bn, x, act=None, residual=None, handles=1, out=None):
                                        bn.eps, _ACT_CODE[act], rc,
                                        handles=handles if (bn.training and torch.is_grad_enabled() and rc is not None) else 1,
                                        out=out if bn.training else None, sync=_BN_SYNC and bn.training)
+    if _BN_SYNC and bn.training and type(bn) is nn.BatchNorm2d:
+        # the DDP wrapper runs with broadcast_buffers=False on the assumption that EVERY BatchNorm layer synchronises its statistics
+        # through the HIP path above; a layer that falls through to plain bn(x) would silently use per-rank statistics
+        raise RuntimeError("--sync_bn: this BatchNorm2d cannot take the synchronised HIP path (momentum=None, track_running_stats=False, "
+                           "a CPU tensor or an unsupported dtype / shape: %s %s); use torch.nn.SyncBatchNorm for it"
+                           % (x.dtype, tuple(x.shape)))
     y = bn(x)
     if residual is not None:
         y = y + residual
@@ -455,13 +461,29 @@ class ASPP(nn.Module):
         if not all(y.is_cuda and y.dtype == ref.dtype and _lib.bn_act_supported(y.contiguous()) for y in convs):
             return None, convs
         buf, parts = _lib.concat_slices(N, [cout] * (len(self.branches) + 1), H, W, ref.dtype, ref.device)
-        outs = []
-        for b, y, part in zip(self.branches, convs, parts):
-            o = bn_act(b[1].bn, y, b[1].act, out=part)
-            outs.append(o if o.data_ptr() == part.data_ptr() else part.copy_(o))     # (a BatchNorm variant without the kernels)
         ip = pooled.to(ref.dtype)[:, :, None, None]
-        for mod in list(self.image_pool)[1:]:                      # [0] is the pooling itself
-            ip = mod(ip)
+        pool_mods = list(self.image_pool)[1:]                      # [0] is the pooling itself
+        if (_BN_SYNC and len(pool_mods) == 2 and type(pool_mods[1]) is BNAct and type(pool_mods[1].bn) is nn.BatchNorm2d and
+                all(b[1].bn.momentum is not None and b[1].bn.track_running_stats for b in self.branches)):
+            # synchronised statistics: the five BatchNorm layers of the head are independent of one another -- ONE all-reduce per
+            # direction for all of them (sync_batch_norm_act_group) instead of five
+            ipc = pool_mods[0](ip).contiguous()
+            bns = [b[1] for b in self.branches] + [pool_mods[1]]
+            xs = [y.contiguous() for y in convs] + [ipc]
+            for m in bns:
+                _bump(m.bn)
+            res = _lib.sync_batch_norm_act_group([(x, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var, m.bn.momentum, m.bn.eps,
+                                                   _ACT_CODE[m.act], part)
+                                                  for x, m, part in zip(xs, bns, list(parts[:-1]) + [None])])
+            outs = list(res[:-1])
+            ip = res[-1]
+        else:
+            outs = []
+            for b, y, part in zip(self.branches, convs, parts):
+                o = bn_act(b[1].bn, y, b[1].act, out=part)
+                outs.append(o if o.data_ptr() == part.data_ptr() else part.copy_(o))     # (a BatchNorm variant without the kernels)
+            for mod in pool_mods:
+                ip = mod(ip)
         outs.append(parts[-1].copy_(ip.expand(-1, -1, H, W)))      # bilinear up-sampling of a 1x1 map = broadcast
         return _lib.concat_from_slices(buf, outs), convs
 

@@ -316,3 +316,60 @@ def test_device_pool_statistics_follow_in_place_writes(hip):
     assert h1 is not h0 and int(h1[1, 7]) == 32 * 32 and int(h1[1, 256 + 7]) == 32 * 32 and torch.equal(h1[0], h0[0])
     cpu = DevicePool(torch.from_numpy(imgs), torch.from_numpy(msks))
     assert cpu.histograms() is None                                       # CPU pools (tests): the statistics passes run per call
+
+
+def _bench_batch(cfg_rel, size, per_domain):
+    """The seeded batch plan of a bench.py leg (same yaml, seed 1023, policies RandomState(1023).randint): pool + unit records."""
+    import os
+    import random
+    from aadg_amd.config.defaults import get_default_config
+    from aadg_amd.data import transform as T
+    from aadg_amd.data.dataloader import get_seg_dg_dataloader
+    from aadg_amd.data.policy import DGMultiPolicy, parse_policies
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = get_default_config()
+    cfg.defrost()
+    cfg.merge_from_file(os.path.join(root, cfg_rel))
+    cfg.SEED = 1023
+    cfg.freeze()
+
+    class A(object):
+        pass
+    args = A()
+    args.crop_size, args.epoch_items = size, 8
+    for fn in (random.seed, np.random.seed, torch.manual_seed):
+        fn(1023)
+    _, loader, _ = get_seg_dg_dataloader(cfg, args, 8, 0, per_domain=per_domain)
+    pol = np.random.RandomState(1023).randint(0, 10, (6, 20))
+    loader.dataset.transforms.transforms[0] = DGMultiPolicy(parse_policies(pol, cfg, None))
+    batch = [loader.dataset[0] for _ in range(8)]
+    flat, refs, M = T.collect_refs(batch, nested=True)
+    return loader.dataset.pool, T.refs_to_units(refs), (0 if cfg.DATASET.NAME == "optic" else 1)
+
+
+def test_bench_batch_512_every_unit_vs_oracle(hip, oracle):
+    """Round 3: ALL 24 + 144 units of the seeded BASELINE configs[1] batch (512 x 512, Fundus pipeline: scale range [1, 1.5], K = 2)
+    against the oracle, bit for bit -- not a sample of them."""
+    pool, units, ds = _bench_batch(os.path.join("experiments", "optic_sinkhorn", "diversity.yaml"), 512, 8)
+    assert len(units) == 24 + 144
+    got_img, got_lbl = hip.aug_u8_forward(pool.images, pool.masks, units, 512, ds, pool_hist=pool.histograms())
+    want_img, want_lbl = oracle.aug_units(pool.images.cpu().numpy(), pool.masks.cpu().numpy(), units, 512, ds)
+    assert np.array_equal(got_img.cpu().numpy(), want_img) and np.array_equal(got_lbl.cpu().numpy(), want_lbl)
+
+
+def test_bench_batch_rvs_1024_56_units_vs_oracle(hip, oracle):
+    """Round 3: every third unit (56 of 168) of the seeded BASELINE configs[2] batch (RVS pipeline, 1024 x 1024 crops, scale range
+    [0.5, 2], K = 1): up-scaling tiles, the two-pass down-scaling flow with and without stencils, large pad regions -- bit for bit."""
+    pool, units, ds = _bench_batch(os.path.join("experiments", "rvs_sinkhorn", "diversity_ex.yaml"), 1024, 8)
+    assert len(units) == 168 and ds == 1
+    sel = np.arange(0, 168, 3)
+    counts = hip.launch_hints(units[sel], 1024, 1024, 1024)[3]
+    assert counts[0] > 0 and counts[1] > 0 and counts[2] > counts[3] > 0            # every tile class is in the sample
+    got_img, got_lbl = hip.aug_u8_forward(pool.images, pool.masks, units[sel], 1024, ds, pool_hist=pool.histograms())
+    want_img, want_lbl = oracle.aug_units(pool.images.cpu().numpy(), pool.masks.cpu().numpy(), units[sel], 1024, ds)
+    assert np.array_equal(got_img.cpu().numpy(), want_img) and np.array_equal(got_lbl.cpu().numpy(), want_lbl)
+    del got_img, got_lbl
+    # the whole batch: deterministic, and the sampled units come out the same inside it
+    a_img, a_lbl = hip.aug_u8_forward(pool.images, pool.masks, units, 1024, ds, pool_hist=pool.histograms())
+    assert np.array_equal(a_img[torch.from_numpy(sel).cuda()].cpu().numpy(), want_img)
+    assert np.array_equal(a_lbl[torch.from_numpy(sel).cuda()].cpu().numpy(), want_lbl)

@@ -37,10 +37,13 @@ def _bench(tmp_path, gpus, tag, extra=()):
 def test_bench_gpus_flag_launches_the_ranks_and_matches_single_rank(tmp_path):
     one, r1 = _bench(tmp_path, 1, "g1")
     assert one["n_gpus"] == 1
-    for gpus, law in ((2, "row"), (2, "unit"), (3, "unit")):
+    # (4, "unit"): 18 (domain, policy) units over 4 ranks = 5 / 5 / 4 / 4 -- the uneven split of BASELINE configs[3], with the HIP kernels
+    for gpus, law in ((2, "row"), (2, "unit"), (3, "unit"), (4, "unit")):
         out, rg = _bench(tmp_path, gpus, "g%d%s" % (gpus, law), ["--placement", law])
         assert out["n_gpus"] == gpus and out["steps"] == 3
         assert "BatchNorm statistics all-reduce" in out["config"]["parallelism"]
+        if gpus == 4:
+            assert "rows per rank 10/10/8/8" in out["config"]["parallelism"], out["config"]["parallelism"]
         # raw rewards = sums of Sinkhorn divergences (the normalised ones divide by their small spread)
         a, b = r1["raw"][0], rg["raw"][0]
         assert max(abs(x - y) for x, y in zip(a, b)) < 1e-4, (gpus, law, a, b)           # step 1: the forward pass is the same function

@@ -51,3 +51,28 @@ def test_module_matches_conv2d_under_autocast(hip):
     # float32 activations (no autocast) keep the library path
     xf = torch.randn(2, 96, 16, 16, device="cuda")
     assert torch.allclose(m(xf), F.conv2d(xf, m.weight), atol=1e-4)
+
+
+def test_tracked_shadow_backward_after_weight_change_fails_loudly(hip):
+    """the bfloat16 shadows of tracked weights are rewritten in place by the next refresh.  A backward that runs after the
+    weights changed (optimizer step, or invalidate_weight_shadows() after a `.data` write) must not silently use the new weights."""
+    from aadg_amd import _lib
+    from aadg_amd.models.deeplab import Conv1x1
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(Conv1x1(64, 64)).cuda()
+    assert _lib.track_bf16_weights(net, (Conv1x1,)) == 1
+    x = torch.randn(2, 64, 64, 64, device="cuda").bfloat16().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = net(x)
+    y.float().sum().backward()                                  # the normal order works
+    w0 = net[0].weight.detach().clone()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = net(x)
+    net[0].weight.data.mul_(0.5)                                # a write the version counter does not see ...
+    _lib.invalidate_weight_shadows()                            # ... announced by the caller
+    with pytest.raises(_lib.AadgError):
+        y.float().sum().backward()
+    with torch.autocast("cuda", dtype=torch.bfloat16):          # the next forward rebuilds the shadow from the new master
+        y2 = net(x)
+    ref = F.conv2d(x.float(), (w0 * 0.5).bfloat16().float())
+    assert (y2.float() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())

@@ -125,3 +125,49 @@ def test_sync_bn_single_rank_is_the_plain_kernel(hip):
     assert torch.equal(a[0], s[0]) and torch.equal(a[1], s[1])
     assert torch.allclose(a[2], s[2], rtol=1e-6, atol=1e-6) and torch.allclose(a[3], s[3], rtol=1e-6, atol=1e-6)
     assert torch.equal(a[4], s[4]) and torch.equal(a[5], s[5])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_grouped_layers_share_one_all_reduce_per_direction(hip, dtype):
+    """Round 3: the five independent BatchNorm layers of the ASPP head travel in ONE all-reduce per direction
+    (sync_batch_norm_act_group).  Same outputs, input / parameter gradients and running statistics as five separate synchronised
+    layers -- including a member that writes into a channel slice of a concatenation buffer and a [N, C, 1, 1] member --, and the
+    collective counter says 2 instead of 10."""
+    torch.manual_seed(5)
+    shapes = [(4, 16, 8, 8), (4, 16, 8, 8), (4, 24, 8, 8), (4, 16, 1, 1)]
+    xs = [(torch.randn(s, device="cuda") * 1.5 + 0.3).to(dtype) for s in shapes]
+    ws = [torch.rand(s[1], device="cuda") + 0.5 for s in shapes]
+    bs = [torch.randn(s[1], device="cuda") * 0.1 for s in shapes]
+    acts = [1, 1, 2, 1]
+    gs = [torch.randn(s, device="cuda").to(dtype) for s in shapes]
+    calls = []
+    hip.BN_SYNC_REDUCE = lambda t: calls.append(t.numel())          # one rank: the sum over the ranks is the local sum
+    try:
+        def leaves():
+            return ([x.detach().clone().requires_grad_(True) for x in xs], [w.detach().clone().requires_grad_(True) for w in ws],
+                    [b.detach().clone().requires_grad_(True) for b in bs], [torch.zeros_like(w) for w in ws], [torch.ones_like(w) for w in ws])
+        # separate layers
+        x1, w1, b1, rm1, rv1 = leaves()
+        hip.BN_SYNC_COLLECTIVES[0] = 0
+        y1 = [hip.batch_norm_act(x, w, b, rm, rv, True, 0.1, 1e-5, a, None, sync=True) for x, w, b, rm, rv, a in zip(x1, w1, b1, rm1, rv1, acts)]
+        torch.autograd.backward(y1, gs)
+        assert hip.BN_SYNC_COLLECTIVES[0] == 2 * len(shapes)
+        # one group; the first two members write into the two halves of a [4, 32, 8, 8] buffer
+        x2, w2, b2, rm2, rv2 = leaves()
+        buf, parts = hip.concat_slices(4, [16, 16], 8, 8, dtype, xs[0].device)
+        outs = [parts[0], parts[1], None, None]
+        calls.clear()
+        hip.BN_SYNC_COLLECTIVES[0] = 0
+        y2 = hip.sync_batch_norm_act_group([(x, w, b, rm, rv, 0.1, 1e-5, a, o) for x, w, b, rm, rv, a, o in zip(x2, w2, b2, rm2, rv2, acts, outs)])
+        assert y2[0].data_ptr() == parts[0].data_ptr() and y2[1].data_ptr() == parts[1].data_ptr()
+        torch.autograd.backward(list(y2), gs)
+        assert hip.BN_SYNC_COLLECTIVES[0] == 2
+        assert calls == [sum(2 * s[1] + 1 for s in shapes), sum(2 * s[1] for s in shapes)]
+    finally:
+        hip.BN_SYNC_REDUCE = None
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for i in range(len(shapes)):
+        assert torch.allclose(y1[i].float(), y2[i].float(), atol=tol), i
+        assert torch.allclose(x1[i].grad.float(), x2[i].grad.float(), atol=tol), i
+        assert torch.allclose(w1[i].grad, w2[i].grad, rtol=1e-4, atol=1e-4) and torch.allclose(b1[i].grad, b2[i].grad, rtol=1e-4, atol=1e-4)
+        assert torch.allclose(rm1[i], rm2[i], atol=1e-6) and torch.allclose(rv1[i], rv2[i], atol=1e-6)

@@ -271,3 +271,21 @@ def test_launch_plan_classes_statistics_and_late_units():
     assert _lib.launch_hints(units, H, W, crop)[3] == counts
     # sizes that are not multiples of 4: everything is staged
     assert _lib.launch_plan(units, 63, 63, 61)[0] == 2
+
+
+def test_shard_rows_refuses_more_ranks_than_rows():
+    """an empty [lo, hi) slice would give that rank a NaN mean loss, which DDP then all-reduces into every replica."""
+    from aadg_amd.distributed import shard_rows
+    assert shard_rows(6, 1, 3) == (2, 4)
+    with pytest.raises(ValueError):
+        shard_rows(2, 0, 3)
+
+
+def test_fast_draw_path_is_for_the_synthetic_dataset_only():
+    """fast_train_units reads SyntheticDGSegmentation internals; any other dataset takes the object path."""
+    from aadg_amd.data import transform as T
+
+    class Other(object):
+        phase = 'train'
+        transforms = None
+    assert T.fast_train_units(Other(), 2) is None
