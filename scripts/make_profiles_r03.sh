@@ -40,6 +40,7 @@ rvs)
     python $R/scripts/pmc_by_kernel.py /tmp/pmc_rvs_sq$i "k_" > $O/pmc_rvs1024_sq$i.txt
   done
   cat $O/pmc_rvs1024_sq*.txt > $O/rvs1024_pmc.txt
+  python $R/scripts/rvs_traffic.py $O/rvs1024_leg.json $O/pmc_rvs1024_FETCH_SIZE.txt $O/pmc_rvs1024_WRITE_SIZE.txt > $O/rvs1024_traffic.json
   ;;
 bench)
   rocprofv3 --kernel-trace --stats -d /tmp/prof_b -- python $R/bench.py --legs none --steps 10 --warmup 3 > $O/bench_under_rocprof.json 2>/dev/null
@@ -50,6 +51,43 @@ bench)
     rocprofv3 --pmc $c -d /tmp/pmc_b_$c -- python $R/bench.py --legs none --steps 5 --warmup 2 > /tmp/bench_$c.json 2>/dev/null
     python $R/scripts/pmc_by_kernel.py /tmp/pmc_b_$c "k_fused3" > $O/pmc_bench_$c.txt
   done
+  # the derived JSON files bench.py quotes (kernel averages of the profiled run, HBM traffic of k_fused3 per unit) -- written BEFORE the
+  # final un-profiled bench run, which reads them
+  python - <<PY
+import json, re
+O = "$O"
+def avg(name):
+    for l in open(O + "/bench_rocprofv3_kernel_stats.txt"):
+        if l.startswith(name + " "):
+            p = l.split()
+            return int(p[1]), float(p[2]) / 1e3
+    return 0, 0.0
+stats = {"file": "r03_bench_rocprofv3_kernel_stats.txt",
+         "command": "rocprofv3 --kernel-trace --stats -- python bench.py --legs none --steps 10 --warmup 3"}
+nf = avg("k_fused3")[0]
+for k in ("k_fused3", "k_luts_tables", "k_hist_fused", "k_lut"):
+    n, a = avg(k)
+    stats[k + "_avg_ms"] = round(a, 4)
+    stats[k + "_calls_per_launch"] = round(n / max(nf, 1), 2)
+json.dump(stats, open(O + "/bench_kernel_stats.json", "w"))
+def pmc(c):
+    t = open(O + "/pmc_bench_%s.txt" % c).read()
+    return float(re.search(r"avg\s+([\d.]+)", t).group(1))
+b = json.load(open("/tmp/bench_FETCH_SIZE.json"))["roofline"]
+f, w, units = pmc("FETCH_SIZE"), pmc("WRITE_SIZE"), b["units_per_launch"]
+hbm = int(2 * f * 1024 + w * 1024)
+json.dump({"kernel": "k_fused3", "size": 512, "units_measured": units,
+           "command": "rocprofv3 --pmc FETCH_SIZE -- python bench.py --legs none --steps 5 --warmup 2   (and a second, separate pass with --pmc WRITE_SIZE); scripts/make_profiles_r03.sh",
+           "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB_raw": w,
+           "correction": "gfx950 FETCH_SIZE counts 64 B per 128 B request: doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE used as is",
+           "hbm_bytes_per_launch": hbm, "hbm_bytes_per_unit": hbm // units, "kernel_bytes": b["bytes_per_launch"],
+           "note": "traffic / bytes the kernel addresses = %.3f; bench.py scales hbm_bytes_per_unit by the units of its launch" % (hbm / b["bytes_per_launch"])},
+          open(O + "/traffic_k_fused3.json", "w"), indent=2)
+PY
+  # the committed copies bench.py reads live in profiles/: refresh them so that the line below quotes THIS run's profile
+  cp $O/bench_kernel_stats.json $R/profiles/r03_bench_kernel_stats.json
+  cp $O/traffic_k_fused3.json $R/profiles/r03_traffic_k_fused3.json
+  if [ -f $O/rvs1024_traffic.json ]; then cp $O/rvs1024_traffic.json $R/profiles/r03_rvs1024_traffic.json; fi
   python $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err
   ;;
 shard8)

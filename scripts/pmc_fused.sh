@@ -5,5 +5,5 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
   tag=$(echo $set | cut -c1-12 | tr ' ' '_')
   rocprofv3 --pmc $set -d /tmp/pmc_${case}_$tag -- python $R/scripts/pmc_case.py $case > /dev/null 2>&1
   echo "== $case : $set"
-  python $R/scripts/pmc_summary.py /tmp/pmc_${case}_$tag "k_fused"
+  python $R/scripts/pmc_by_kernel.py /tmp/pmc_${case}_$tag "k_fused"
 done; done
