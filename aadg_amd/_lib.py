@@ -38,6 +38,7 @@ EXPORTS = [
     "aadg_upsample_bilinear2d_backward_workspace_bytes", "aadg_upsample_bilinear2d_backward_strided",
     "aadg_bn_workspace_bytes", "aadg_bn_mask_bytes", "aadg_bn_forward", "aadg_bn_backward",
     "aadg_bn_sync_forward", "aadg_bn_sync_backward",
+    "aadg_layernorm_supported", "aadg_layernorm_workspace_bytes", "aadg_layernorm_forward", "aadg_layernorm_backward",
     "aadg_dwconv3x3_supported", "aadg_dwconv3x3_workspace_bytes", "aadg_dwconv3x3", "aadg_dwconv3x3_wgrad",
     "aadg_bn_relu_maxpool_supported", "aadg_bn_relu_maxpool_forward", "aadg_bn_relu_maxpool_backward",
     "aadg_conv1x1_nchw_supported", "aadg_conv1x1_nchw_bf16",
@@ -123,6 +124,14 @@ def load():
     lib.aadg_bn_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _c.c_longlong, _vp]
     lib.aadg_bn_backward.restype = _i
     lib.aadg_bn_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _c.c_longlong, _vp]
+    lib.aadg_layernorm_supported.restype = _i
+    lib.aadg_layernorm_supported.argtypes = [_i, _i, _i]
+    lib.aadg_layernorm_workspace_bytes.restype = _sz
+    lib.aadg_layernorm_workspace_bytes.argtypes = [_i, _i]
+    lib.aadg_layernorm_forward.restype = _i
+    lib.aadg_layernorm_forward.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]
+    lib.aadg_layernorm_backward.restype = _i
+    lib.aadg_layernorm_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]
     lib.aadg_bn_sync_forward.restype = _i
     lib.aadg_bn_sync_forward.argtypes = [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz,
                                          _c.c_longlong, _vp]
@@ -1834,6 +1843,72 @@ def embed_prologue(x, w1, b1, w2=None, b2=None, slope=0.2, want_norm=False):
                                      float(slope), fe.data_ptr(), _ptr(out), _stream())
     _check(rc, "aadg_embed_prologue_f32")
     return out, fe
+
+
+# ------------------------------------------------------------------------------------------------
+class _AddLayerNorm(torch.autograd.Function):
+    """(s, y) = (x + rscale * r, LayerNorm(s)) in one pass (csrc/layernorm.hip); r None: y only.  x, r: [..., C] float32 / bfloat16
+    (contiguous), rscale: float32 [B] per-sample factor of r (stochastic depth) or None, gamma / beta: float32 [C]."""
+
+    @staticmethod
+    def forward(ctx, x, r, rscale, gamma, beta, eps):
+        lib = load()
+        C = x.shape[-1]
+        R = x.numel() // C
+        dt = _BN_DTYPES[x.dtype]
+        rps = (R // rscale.numel()) if rscale is not None else 0
+        y = torch.empty_like(x)
+        s = torch.empty_like(x) if r is not None else None
+        mean = torch.empty(R, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(R, dtype=torch.float32, device=x.device)
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        _check(lib.aadg_layernorm_forward(x.data_ptr(), _ptr(r), _ptr(rscale), rps, g32.data_ptr(), b32.data_ptr(), float(eps), _ptr(s),
+                                          y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), R, C, dt, _stream()), "aadg_layernorm_forward")
+        ctx.save_for_backward(s if s is not None else x, g32, mean, rstd, rscale)
+        ctx.has_r, ctx.rps, ctx.gdtype = r is not None, rps, gamma.dtype
+        if s is not None:
+            return s, y
+        return y
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = load()
+        sin, g32, mean, rstd, rscale = ctx.saved_tensors
+        C = sin.shape[-1]
+        R = sin.numel() // C
+        dt = _BN_DTYPES[sin.dtype]
+        if ctx.has_r:
+            ds_extra, dy = grads
+        else:
+            ds_extra, dy = None, grads[0]
+        if dy is None:
+            dy = torch.zeros_like(sin)
+        dy = dy.contiguous()
+        ds_extra = ds_extra.contiguous() if ds_extra is not None else None
+        dx = torch.empty_like(sin)
+        dr = torch.empty_like(sin) if ctx.has_r else None
+        dg = torch.empty(C, dtype=torch.float32, device=sin.device)
+        db = torch.empty(C, dtype=torch.float32, device=sin.device)
+        ws = workspace(lib.aadg_layernorm_workspace_bytes(R, C), sin.device, "layernorm")
+        _check(lib.aadg_layernorm_backward(sin.data_ptr(), dy.data_ptr(), _ptr(ds_extra), g32.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                           _ptr(rscale), ctx.rps, dx.data_ptr(), _ptr(dr), dg.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                           ws.numel(), R, C, dt, _stream()), "aadg_layernorm_backward")
+        return dx, dr, None, dg.to(ctx.gdtype), db.to(ctx.gdtype), None
+
+
+def layernorm_supported(x, C):
+    return (x.is_cuda and x.dtype in _BN_DTYPES and x.is_contiguous() and x.shape[-1] == C and x.data_ptr() % 16 == 0 and
+            bool(load().aadg_layernorm_supported(x.numel() // C, C, _BN_DTYPES[x.dtype])))
+
+
+def add_layer_norm(x, r, rscale, gamma, beta, eps):
+    """r is None: LayerNorm(x).  Else (s, y) with s = x + rscale[sample] * r (rscale None: 1) and y = LayerNorm(s)."""
+    _require_cuda(x, r, rscale)
+    if r is not None and (r.shape != x.shape or r.dtype != x.dtype):
+        raise AadgError("add_layer_norm: x and r must have the same shape and dtype")
+    if not layernorm_supported(x, x.shape[-1]):
+        raise AadgError("add_layer_norm: expected contiguous float32 / bfloat16 [..., C] with C % 8 == 0, C <= 512")
+    return _AddLayerNorm.apply(x, r, rscale, gamma, beta, float(eps))
 
 
 # ------------------------------------------------------------------------------------------------

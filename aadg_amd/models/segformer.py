@@ -13,7 +13,9 @@ names that follow the reference modules (`backbone.block2.1.attn.kv.weight`, `he
 SegFormer checkpoint's state_dict maps onto it.
 
 MI355X-first choices (same function, different schedule):
-  * tokens stay [B, N, C] through a stage (the Linear layers are plain hipBLASLt GEMMs on them); attention is
+  * tokens stay [B, N, C] and bfloat16 through a stage (the Linear layers are plain hipBLASLt GEMMs on them); every residual add
+    is folded into the LayerNorm that follows it (csrc/layernorm.hip: add + stochastic-depth factor + normalise in one pass, in the
+    tokens' own dtype -- no float32 residual stream, no casts around the norms); attention is
     `scaled_dot_product_attention`; the Mix-FFN's depthwise convolution reads the same buffer through a channels-last view;
   * the head never builds the 4 x 768-channel concatenation at stride 4 (14.5 GB in bf16 for 144 images of 512x512):
     a 1x1 convolution commutes with bilinear interpolation, so the fuse convolution's slice for stage i is folded into that
@@ -63,6 +65,29 @@ class DropPath(nn.Module):
         keep = 1.0 - self.drop_prob
         mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
         return x * mask / keep
+
+
+def _dp_scale(dp, x):
+    """Stochastic depth as a per-sample factor of the branch (mask / keep, float32 [B]); None when nothing is dropped."""
+    if isinstance(dp, DropPath) and dp.drop_prob > 0.0 and dp.training:
+        keep = 1.0 - dp.drop_prob
+        return torch.empty(x.shape[0], dtype=torch.float32, device=x.device).bernoulli_(keep) / keep
+    return None
+
+
+def _ln(norm, x, r=None, rscale=None):
+    """(s, LayerNorm(s)) with s = x + rscale[sample] * r (r None: s = x).  On the GPU one HIP pass in the tokens' own dtype
+    (csrc/layernorm.hip: the pending branch joins the residual stream inside the normalisation that follows it -- under autocast
+    torch would add in float32, run layer_norm in float32 and cast the result back for the next Linear)."""
+    if x.is_cuda:
+        from .. import _lib
+        xc = x.contiguous()
+        if _lib.layernorm_supported(xc, xc.shape[-1]) and (r is None or r.dtype == xc.dtype):
+            out = _lib.add_layer_norm(xc, None if r is None else r.contiguous(), rscale, norm.weight, norm.bias, norm.eps)
+            return (xc, out) if r is None else out
+    if r is not None:
+        x = x + (r if rscale is None else r * rscale.to(r.dtype).view(-1, *([1] * (r.dim() - 1))))
+    return x, norm(x)
 
 
 def _tokens_as_map(x, H, W):
@@ -127,7 +152,7 @@ class Attention(nn.Module):
         q = self.q(x).view(B, N, h, d).transpose(1, 2)                                   # [B, h, N, d]
         if self.sr_ratio > 1:
             r = self.sr(_tokens_as_map(x, H, W))                                         # [B, C, H/sr, W/sr]
-            r = self.norm(r.flatten(2).transpose(1, 2))
+            r = _ln(self.norm, r.flatten(2).transpose(1, 2))[1]
         else:
             r = x
         kv = self.kv(r).view(B, -1, 2, h, d).permute(2, 0, 3, 1, 4)                      # [2, B, h, N', d]
@@ -144,9 +169,15 @@ class Block(nn.Module):
         self.norm2 = nn.LayerNorm(dim, eps=1e-6)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
-    def forward(self, x, H, W):
-        x = x + self.drop_path(self.attn(self.norm1(x), H, W))
-        return x + self.drop_path(self.mlp(self.norm2(x), H, W))
+    def forward(self, x, H, W, pend=None, pscale=None):
+        """x: the residual stream, pend (* pscale per sample): the previous block's MLP branch, not yet added.  Returns the stream
+        after this block's attention branch, this block's MLP branch and its stochastic-depth factor: every residual add happens
+        inside the LayerNorm kernel that consumes its result (the stage's final norm takes the last one)."""
+        s, n1 = _ln(self.norm1, x, pend, pscale)
+        a = self.attn(n1, H, W)
+        s, n2 = _ln(self.norm2, s, a, _dp_scale(self.drop_path, a))
+        m = self.mlp(n2, H, W)
+        return s, m, _dp_scale(self.drop_path, m)
 
 
 class OverlapPatchEmbed(nn.Module):
@@ -158,7 +189,7 @@ class OverlapPatchEmbed(nn.Module):
     def forward(self, x):
         x = self.proj(x)
         H, W = x.shape[-2:]
-        return self.norm(x.flatten(2).transpose(1, 2)), H, W
+        return _ln(self.norm, x.flatten(2).transpose(1, 2))[1], H, W
 
 
 class MixVisionTransformer(nn.Module):
@@ -182,9 +213,10 @@ class MixVisionTransformer(nn.Module):
         outs = []
         for i in range(1, 5):
             t, H, W = getattr(self, 'patch_embed%d' % i)(x)
+            pend = ps = None
             for blk in getattr(self, 'block%d' % i):
-                t = blk(t, H, W)
-            t = getattr(self, 'norm%d' % i)(t)
+                t, pend, ps = blk(t, H, W, pend, ps)
+            t = _ln(getattr(self, 'norm%d' % i), t, pend, ps)[1]
             x = _tokens_as_map(t, H, W).contiguous()                  # NCHW stage output (small: C_i at stride 4 ... 32)
             outs.append(x)
         return outs

@@ -203,6 +203,21 @@ int aadg_fop_f32(int fop, const float* in, float* out, const float* mag, int mag
                  size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Residual add + LayerNorm over the last dimension (the pre-norm blocks of the SegFormer backbone, BASELINE configs[4];
+ * mix_transformer.py:96-117): s = x + rscale[row / rows_per_sample] * r (r == NULL: s = x, nothing written to s_out; rscale == NULL: 1),
+ * y = LayerNorm(s) * gamma + beta.  x, r, s_out, y, dy, ds_extra, dx, dr: [R, C] in `dtype` (0 float32, 1 bfloat16); gamma, beta,
+ * mean, rstd, dgamma, dbeta float32.  C % 8 == 0, C <= 512.  Backward: dx = d/ds (LayerNorm gradient + ds_extra), dr = rscale * dx.
+ * ------------------------------------------------------------------------------------------- */
+int aadg_layernorm_supported(int R, int C, int dtype);
+size_t aadg_layernorm_workspace_bytes(int R, int C);
+int aadg_layernorm_forward(const void* x, const void* r, const float* rscale, int rows_per_sample, const float* gamma,
+                           const float* beta, float eps, void* s_out, void* y, float* mean, float* rstd, int R, int C, int dtype,
+                           void* stream);
+int aadg_layernorm_backward(const void* s, const void* dy, const void* ds_extra, const float* gamma, const float* mean,
+                            const float* rstd, const float* rscale, int rows_per_sample, void* dx, void* dr, float* dgamma,
+                            float* dbeta, void* ws, size_t ws_bytes, int R, int C, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Bilinear up-sampling, align_corners = True, NCHW planes (the x4 up-samplings between the augmentation output
  * and the BCE/Dice kernel in DeepLabV3+; same arithmetic as torch.nn.functional.interpolate / ATen
  * upsample_bilinear2d).  in [planes, h, w] -> out [planes, H, W]; dtype 0 = float32, 1 = bfloat16.
