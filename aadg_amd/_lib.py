@@ -39,6 +39,7 @@ EXPORTS = [
     "aadg_bn_workspace_bytes", "aadg_bn_mask_bytes", "aadg_bn_forward", "aadg_bn_backward",
     "aadg_bn_sync_forward", "aadg_bn_sync_backward",
     "aadg_layernorm_supported", "aadg_layernorm_workspace_bytes", "aadg_layernorm_forward", "aadg_layernorm_backward",
+    "aadg_dwconv3x3_gelu_nhwc_supported", "aadg_dwconv3x3_gelu_nhwc_forward", "aadg_dwconv3x3_gelu_nhwc_backward",
     "aadg_dwconv3x3_supported", "aadg_dwconv3x3_workspace_bytes", "aadg_dwconv3x3", "aadg_dwconv3x3_wgrad",
     "aadg_bn_relu_maxpool_supported", "aadg_bn_relu_maxpool_forward", "aadg_bn_relu_maxpool_backward",
     "aadg_conv1x1_nchw_supported", "aadg_conv1x1_nchw_bf16",
@@ -124,6 +125,12 @@ def load():
     lib.aadg_bn_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _c.c_longlong, _vp]
     lib.aadg_bn_backward.restype = _i
     lib.aadg_bn_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _c.c_longlong, _vp]
+    lib.aadg_dwconv3x3_gelu_nhwc_supported.restype = _i
+    lib.aadg_dwconv3x3_gelu_nhwc_supported.argtypes = [_i, _i, _i, _i, _i]
+    lib.aadg_dwconv3x3_gelu_nhwc_forward.restype = _i
+    lib.aadg_dwconv3x3_gelu_nhwc_forward.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
+    lib.aadg_dwconv3x3_gelu_nhwc_backward.restype = _i
+    lib.aadg_dwconv3x3_gelu_nhwc_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.aadg_layernorm_supported.restype = _i
     lib.aadg_layernorm_supported.argtypes = [_i, _i, _i]
     lib.aadg_layernorm_workspace_bytes.restype = _sz
@@ -1843,6 +1850,52 @@ def embed_prologue(x, w1, b1, w2=None, b2=None, slope=0.2, want_norm=False):
                                      float(slope), fe.data_ptr(), _ptr(out), _stream())
     _check(rc, "aadg_embed_prologue_f32")
     return out, fe
+
+
+# ------------------------------------------------------------------------------------------------
+class _DwGeluNHWC(torch.autograd.Function):
+    """GELU(depthwise3x3(h) + bias) on tokens h [B, H*W, C] (csrc/dwconv_nhwc.hip); weight [C,1,3,3], bias [C] are the float32 masters."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, H, W):
+        lib = load()
+        B, N, C = h.shape
+        w9 = weight.detach().float().reshape(C, 9).t().contiguous()
+        b32 = bias.detach().float().contiguous()
+        out = torch.empty_like(h)
+        _check(lib.aadg_dwconv3x3_gelu_nhwc_forward(h.data_ptr(), w9.data_ptr(), b32.data_ptr(), out.data_ptr(), B, H, W, C,
+                                                    _BN_DTYPES[h.dtype], _stream()), "aadg_dwconv3x3_gelu_nhwc_forward")
+        ctx.save_for_backward(h, w9, b32)
+        ctx.hw, ctx.wdtype, ctx.bdtype = (H, W), weight.dtype, bias.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = load()
+        h, w9, b32 = ctx.saved_tensors
+        B, N, C = h.shape
+        H, W = ctx.hw
+        dout = dout.contiguous()
+        g, dh = torch.empty_like(h), torch.empty_like(h)
+        dw9 = torch.empty((9, C), dtype=torch.float32, device=h.device)
+        db = torch.empty(C, dtype=torch.float32, device=h.device)
+        _check(lib.aadg_dwconv3x3_gelu_nhwc_backward(h.data_ptr(), w9.data_ptr(), b32.data_ptr(), dout.data_ptr(), g.data_ptr(), dh.data_ptr(),
+                                                     dw9.data_ptr(), db.data_ptr(), B, H, W, C, _BN_DTYPES[h.dtype], _stream()),
+               "aadg_dwconv3x3_gelu_nhwc_backward")
+        return dh, dw9.t().reshape(C, 1, 3, 3).to(ctx.wdtype), db.to(ctx.bdtype), None, None
+
+
+def dwconv3x3_gelu_nhwc_supported(h, H, W):
+    return (h.is_cuda and h.dim() == 3 and h.dtype in _BN_DTYPES and h.is_contiguous() and h.shape[1] == H * W and h.data_ptr() % 16 == 0 and
+            bool(load().aadg_dwconv3x3_gelu_nhwc_supported(h.shape[0], H, W, h.shape[2], _BN_DTYPES[h.dtype])))
+
+
+def dwconv3x3_gelu_nhwc(h, weight, bias, H, W):
+    """GELU(depthwise 3x3 (padding 1) of the tokens h [B, H*W, C] viewed as [B, H, W, C] + bias), token layout in and out."""
+    _require_cuda(h, weight, bias)
+    if not dwconv3x3_gelu_nhwc_supported(h, H, W) or tuple(weight.shape) != (h.shape[2], 1, 3, 3):
+        raise AadgError("dwconv3x3_gelu_nhwc: expected contiguous float32 / bfloat16 tokens [B, H*W, C], C % 8 == 0, weight [C,1,3,3]")
+    return _DwGeluNHWC.apply(h, weight, bias, int(H), int(W))
 
 
 # ------------------------------------------------------------------------------------------------

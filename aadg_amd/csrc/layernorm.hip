@@ -169,13 +169,26 @@ __global__ __launch_bounds__(LN_THREADS) void k_ln_bwd(const T* __restrict__ s, 
     }
 }
 
+// column sums over the workgroups' partial records: a workgroup owns 16 columns, 16 groups of 16 lanes each walk every 16th record
+// (independent loads, unrolled), LDS tree over the groups -- fixed order, no atomics.  (One thread per column walking all records one
+// after the other took 225 us per call at 1024 records: 12 ms per SegFormer step.)
 __global__ __launch_bounds__(256) void k_ln_bwd_final(const float* __restrict__ part, int nblk, int C, float* __restrict__ dgamma,
                                                       float* __restrict__ dbeta) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * C) return;
+    const int col = blockIdx.x * 16 + (threadIdx.x & 15), grp = threadIdx.x >> 4;
     float a = 0.f;
-    for (int b = 0; b < nblk; ++b) a += part[(size_t)b * 2 * C + i];
-    if (i < C) dgamma[i] = a; else dbeta[i - C] = a;
+    if (col < 2 * C) {
+#pragma unroll 8
+        for (int b = grp; b < nblk; b += 16) a += part[(size_t)b * 2 * C + col];
+    }
+    __shared__ float red[16][17];
+    red[grp][threadIdx.x & 15] = a;
+    __syncthreads();
+    if (threadIdx.x < 16 && col < 2 * C) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
+        if (col < C) dgamma[col] = t; else dbeta[col - C] = t;
+    }
 }
 
 int ln_lpr(int C) { return C <= 64 ? 8 : (C <= 128 ? 16 : 64); }
@@ -242,7 +255,7 @@ extern "C" int aadg_layernorm_backward(const void* s, const void* dy, const void
     else
         LN_LAUNCH(k_ln_bwd, uint16_t, dim3(nblk), cp<uint16_t>(s), cp<uint16_t>(dy), cp<uint16_t>(ds_extra), gamma, mean, rstd, rscale, rows_per_sample, mp<uint16_t>(dx), mp<uint16_t>(dr), part, R, C);
     AADG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ln_bwd_final, dim3((2 * C + 255) / 256), dim3(256), 0, st, part, nblk, C, dgamma, dbeta);
+    hipLaunchKernelGGL(k_ln_bwd_final, dim3((2 * C + 15) / 16), dim3(256), 0, st, part, nblk, C, dgamma, dbeta);
     AADG_LAUNCH_CHECK();
     return 0;
 }

@@ -127,7 +127,14 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
 
     def forward(self, x, H, W):
-        return self.fc2(self.act(self.dwconv(self.fc1(x), H, W)))
+        h = self.fc1(x)
+        if h.is_cuda and type(self.act) is nn.GELU and getattr(self.act, 'approximate', 'none') == 'none':
+            from .. import _lib
+            hc = h.contiguous()
+            if _lib.dwconv3x3_gelu_nhwc_supported(hc, H, W):
+                # depthwise 3x3 + bias + GELU in the tokens' own layout, one pass (csrc/dwconv_nhwc.hip): no NCHW round trip
+                return self.fc2(_lib.dwconv3x3_gelu_nhwc(hc, self.dwconv.dwconv.weight, self.dwconv.dwconv.bias, H, W))
+        return self.fc2(self.act(self.dwconv(h, H, W)))
 
 
 class Attention(nn.Module):

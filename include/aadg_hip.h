@@ -203,6 +203,18 @@ int aadg_fop_f32(int fop, const float* in, float* out, const float* mag, int mag
                  size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Depthwise 3x3 (stride 1, zero padding 1) + bias + exact GELU on token-layout activations [B, H, W, C] (C fastest): the middle of
+ * SegFormer's Mix-FFN (mix_transformer.py:19-46,149-159) without the NCHW round trip.  dtype 0 float32, 1 bfloat16; C % 8 == 0.
+ * w9 = the [C,1,3,3] weight as [9][C] float32 (tap-major), bias float32 [C].
+ * backward: g = scratch of h's shape / dtype; dh = gradient w.r.t. h; dw9 [9][C], db [C] float32 (overwritten; float32 atomics).
+ * ------------------------------------------------------------------------------------------- */
+int aadg_dwconv3x3_gelu_nhwc_supported(int B, int H, int W, int C, int dtype);
+int aadg_dwconv3x3_gelu_nhwc_forward(const void* h, const float* w9, const float* bias, void* out, int B, int H, int W, int C, int dtype,
+                                     void* stream);
+int aadg_dwconv3x3_gelu_nhwc_backward(const void* h, const float* w9, const float* bias, const void* dout, void* g, void* dh, float* dw9,
+                                      float* db, int B, int H, int W, int C, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Residual add + LayerNorm over the last dimension (the pre-norm blocks of the SegFormer backbone, BASELINE configs[4];
  * mix_transformer.py:96-117): s = x + rscale[row / rows_per_sample] * r (r == NULL: s = x, nothing written to s_out; rscale == NULL: 1),
  * y = LayerNorm(s) * gamma + beta.  x, r, s_out, y, dy, ds_extra, dx, dr: [R, C] in `dtype` (0 float32, 1 bfloat16); gamma, beta,
