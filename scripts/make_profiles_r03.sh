@@ -1,5 +1,5 @@
 # Round-3 profile artefacts (run through gpurun; results land in gpurun_out/r3/<tag>/, copy the ones to keep into profiles/).
-#   bash scripts/make_profiles_r03.sh <tag> [parts]      parts: any of  fop rvs bench shard8  (default: fop rvs)
+#   bash scripts/make_profiles_r03.sh <tag> [parts]      parts: any of  fop rvs bench shard8 segformer  (default: fop rvs)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-final}
@@ -89,6 +89,15 @@ PY
   cp $O/traffic_k_fused3.json $R/profiles/r03_traffic_k_fused3.json
   if [ -f $O/rvs1024_traffic.json ]; then cp $O/rvs1024_traffic.json $R/profiles/r03_rvs1024_traffic.json; fi
   python $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+  ;;
+segformer)
+  # BASELINE configs[4] (SegFormer-B2, 8 domains, bf16): the 48 rows of one of 8 ranks on one GPU
+  SF="--legs none --cfg experiments/merged_sinkhorn/segformer_b2_d8.yaml --shard_of 8"
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_sf -- python $R/bench.py $SF --steps 9 --warmup 2 > /dev/null 2>&1
+  DBS=$(find /tmp/prof_sf -name "*.db" | head -1)
+  python $R/scripts/prof_summary.py $DBS $O/segformer_48rows_kernel_stats.txt > /dev/null
+  python $R/scripts/busy_summary.py $DBS "k_upsample_sum_plane" 3 6 > $O/segformer_48rows_busy.txt
+  python $R/bench.py $SF --steps 20 --warmup 3 > $O/segformer_48rows.json 2>/dev/null
   ;;
 shard8)
   rocprofv3 --kernel-trace --stats -d /tmp/prof_s8 -- python $R/bench.py --legs none --shard_of 8 --steps 30 --warmup 5 > $O/shard8_under_rocprof.json 2>/dev/null
