@@ -35,8 +35,10 @@ __device__ __forceinline__ void elem(float z, float y, float gscale, float& bce,
     const int pr = p > 0.5f, gt = ((long)y) != 0;        // argmax([1-p, p]) == 1  <=>  p > 0.5
     tp += pr & gt; fp += pr & (gt ^ 1); fn += (pr ^ 1) & gt;
     if (g) {
+        // BCELoss backward (p - y) / max(p (1 - p), 1e-12) x sigmoid backward p (1 - p): the quotient is 1 unless the product
+        // underflows the eps (|z| > 27) -- a select instead of a quarter-rate reciprocal
         const float pq = p * (1.0f - p);
-        *g = gscale * (p - y) * __frcp_rn(fmaxf(pq, 1e-12f)) * pq;  // BCELoss backward (eps 1e-12) x sigmoid backward
+        *g = gscale * (p - y) * (pq >= 1e-12f ? 1.0f : pq * 1e12f);
     }
 }
 
