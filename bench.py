@@ -875,6 +875,10 @@ def main():
                                 "what": "the same kernel / call timed the same way in the hot_path loop (no backbone kernels between two calls)"}
         if traffic:
             roof["traffic_source"] = "profiles/r03_traffic_k_fused3.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes), per unit x units"
+        if prof:
+            # the other kernels of the call (latency-bound: tables + byte maps of every unit, histogram pass + maps of the late units)
+            roof["stage"]["kernels_rocprof_avg_us"] = {k[:-7]: round(v * 1e3, 1) for k, v in prof.items() if k.endswith("_avg_ms")}
+            roof["stage"]["kernels_rocprof_calls_per_launch"] = {k[:-17]: v for k, v in prof.items() if k.endswith("_calls_per_launch")}
         if prof and prof.get("k_fused3_avg_ms"):
             roof["rocprof"] = {"kernel_avg_ms": prof["k_fused3_avg_ms"], "frac": kbytes / (prof["k_fused3_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "file": "profiles/" + prof.get("file", "r03_bench_rocprofv3_kernel_stats.txt"),

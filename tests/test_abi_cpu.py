@@ -167,3 +167,28 @@ def test_round2_entry_points_validate_arguments():
     lists.order, lists.n_generic, lists.n_generic_sharp = 16, 2, 3   # more stencil units than down-scaling units
     assert lib.aadg_aug_u8_forward_ex2(one, one, 1, 8, 8, one, 4, 2, 8, 0, one, one, one, 1 << 30, z, 0, -1, z, z, ctypes.byref(lists)) == -1
     assert ctypes.sizeof(_lib.AugLists) == 8 + 16 + 8 * _lib.MAX_OPS + 4 * _lib.MAX_OPS + 8 + 8 + 8   # mirror of aadg_aug_lists (n_generic_sharp fills the tail padding)
+
+
+def test_round3_entry_points_validate_arguments():
+    """aadg_layernorm_* and aadg_dwconv3x3_gelu_nhwc_* (SegFormer blocks) reject bad arguments on the host, without a GPU; the float-op
+    entry point keeps its contract (workspace only for the statistics ops)."""
+    import ctypes
+    from aadg_amd import _lib
+    lib = _lib.load()
+    z, one = ctypes.c_void_p(0), ctypes.c_void_p(16)
+    f = ctypes.c_float
+    assert lib.aadg_layernorm_supported(100, 320, 1) == 1 and lib.aadg_layernorm_supported(100, 36, 1) == 0
+    assert lib.aadg_layernorm_supported(100, 520, 0) == 0 and lib.aadg_layernorm_supported(100, 64, 2) == 0
+    assert lib.aadg_layernorm_workspace_bytes(1000, 128) > 0
+    assert lib.aadg_layernorm_forward(z, z, z, 0, one, one, f(1e-6), z, one, one, one, 8, 64, 1, z) == -1            # no input
+    assert lib.aadg_layernorm_forward(one, one, z, 0, one, one, f(1e-6), z, one, one, one, 8, 64, 1, z) == -1        # residual without s_out
+    assert lib.aadg_layernorm_forward(one, z, z, 0, one, one, f(1e-6), z, one, one, one, 8, 36, 1, z) == -3          # C % 8 != 0
+    assert lib.aadg_layernorm_forward(one, one, one, 3, one, one, f(1e-6), one, one, one, one, 8, 64, 1, z) == -1    # rows not a multiple of rows_per_sample
+    assert lib.aadg_layernorm_backward(one, one, z, one, one, one, z, 0, one, z, one, one, one, 16, 1000, 128, 1, z) == -2   # workspace too small
+    assert lib.aadg_dwconv3x3_gelu_nhwc_supported(2, 16, 16, 64, 1) == 1 and lib.aadg_dwconv3x3_gelu_nhwc_supported(2, 16, 16, 60, 1) == 0
+    assert lib.aadg_dwconv3x3_gelu_nhwc_forward(one, one, z, one, 2, 16, 16, 64, 1, z) == -1                          # no bias
+    assert lib.aadg_dwconv3x3_gelu_nhwc_forward(one, one, one, one, 2, 16, 16, 60, 1, z) == -3
+    assert lib.aadg_dwconv3x3_gelu_nhwc_backward(one, one, one, one, z, one, one, one, 2, 16, 16, 64, 1, z) == -1     # no scratch for g
+    assert lib.aadg_fop_workspace_bytes(144, 512, 512) > 0
+    assert lib.aadg_fop_f32(_lib.FOP["contrast"], one, one, one, 1, z, z, 2, 3, 8, 8, z, 0, z) == -1                  # statistics op without workspace
+    assert lib.aadg_fop_f32(_lib.FOP["contrast"], one, one, one, 1, z, z, 2, 3, 8, 8, one, 8, z) == -2                # ... with a too small one
