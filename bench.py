@@ -556,7 +556,30 @@ def hot_kernels_leg(D=3, B=8, M=6, size=512, K=2, repeats=20):
                 "note": "event times include the host-side launch sequence of the call (3 + 11 launches)"}
     except Exception as e:  # noqa: BLE001
         ctrl = {"error": repr(e)}
-    return {"k_embed": {"replaces": "EMA discriminator branch: 2 GEMMs + 2 bias adds + LeakyReLU + row norms (models/discriminator.py:48-51)",
+    # the scaled synthetic of SURVEY 8(d): 3 problems of 4096 x 4096 points, E = 128 -- the cost matrices no longer fit LDS, the large-cloud
+    # kernels (csrc/sinkhorn_big.hip) build them on the matrix cores (float32) and sweep them out of HBM / L2
+    big = None
+    try:
+        n_pts = 4096
+        xb = torch.nn.functional.leaky_relu(torch.randn(D * n_pts, 128, device="cuda") * 0.5 +
+                                            torch.randn(D, 1, 128, device="cuda").repeat(1, n_pts, 1).view(-1, 128), 0.2)
+        rows_i = torch.arange(D * n_pts, dtype=torch.int32, device="cuda")
+        off_i = torch.arange(0, (D + 1) * n_pts, n_pts, dtype=torch.int32, device="cuda")
+        pxy = torch.tensor([v for a_ in range(D) for b_ in range(a_ + 1, D) for v in (a_, b_)], dtype=torch.int32, device="cuda")
+        tb = _event_times(lambda: _lib.sinkhorn_divergence(xb, rows_i, off_i, pxy, n_pts), 5)
+        big_ms = float(np.median(tb))
+        gemm_flop = P * 4 * 2.0 * n_pts * n_pts * 128
+        sweep_bytes = P * 4 * n_pts * n_pts * 4
+        big = {"workload": "%d problems of %d x %d points, E = 128, blur 0.05, scaling 0.5 (33 sweeps)" % (P, n_pts, n_pts), "ms": big_ms,
+               "cost_build_gflop": gemm_flop / 1e9, "bytes_per_full_symmetric_sweep": sweep_bytes,
+               "cost_build_ms_at_f32_mfma_peak_157TF": gemm_flop / 157e12 * 1e3,
+               "note": "per-kernel split in DESIGN.md section 4 (k_big_cost 1.09 ms = 47 TFLOP/s float32 MFMA, k_big_sweep 3.7 TB/s on the full "
+                       "symmetric sweeps); the debias sweeps are smaller than a full one"}
+        del xb
+    except Exception as e:  # noqa: BLE001
+        big = {"error": repr(e)}
+    return {"sinkhorn_large_clouds": big,
+            "k_embed": {"replaces": "EMA discriminator branch: 2 GEMMs + 2 bias adds + LeakyReLU + row norms (models/discriminator.py:48-51)",
                         "bound": "latency / L2 (1 MB of weights, %d rows)" % N, "us": float(np.median(te)) * 1e3, "launches": 1,
                         "bytes": int(x.numel() * 4 + w1.numel() * 4 + N * 128 * 4)},
             "controller": ctrl,
