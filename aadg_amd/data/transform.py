@@ -432,10 +432,14 @@ def fast_train_units(dataset, n_items):
     for p, f in zip(policies, fast):
         p._fast = f
     s0, s1 = sc.scale_range[0], sc.scale_range[1]
-    draw_crop = sc.crop.draw
     K = _lib.MAX_OPS
-    rnd, uni, choice = random.random, random.uniform, random.choice
+    # python's generator, one frame per draw instead of three: uniform(a, b) = a + (b - a) * random(), randint(a, b) =
+    # a + _randbelow(b - a + 1), choice(seq) = seq[_randbelow(len(seq))] (CPython random.py) -- the same stream, position by position
+    rnd, below = random.random, random._inst._randbelow
     np_choice, np_uniform = np.random.choice, np.random.uniform
+    crop_h, crop_w = sc.crop.size
+    crop_pad = sc.crop.padding
+    ds = s1 - s0
     S = n_items * D
     n = S + S * M
     src, n_ops, geo = [0] * n, [0] * n, [None] * n
@@ -459,8 +463,9 @@ def fast_train_units(dataset, n_items):
                 if len(q) > 10:
                     q.pop(0)
                 else:
-                    choice(q)
-                steps = choice(fast[j])
+                    below(len(q))                                   # the CutMix-queue draw (its value is unused: data/policy.py:17-21)
+                fj = fast[j]
+                steps = fj[below(len(fj))]
                 row = base + j
                 src[row] = pidx
                 k = 0
@@ -480,9 +485,19 @@ def fast_train_units(dataset, n_items):
             for row in [s] + list(range(base, base + M)):
                 w, h = W0, H0
                 if rnd() > 0.2:
-                    w = int(uni(s0, s1) * W0)
-                    h = int(uni(s0, s1) * H0)
-                pad, x1, y1 = draw_crop(w, h)
+                    w = int((s0 + ds * rnd()) * W0)
+                    h = int((s0 + ds * rnd()) * H0)
+                # RandomCrop.draw (data/transform.py:38-53), inlined
+                pad = 0
+                pw, ph = w, h
+                if crop_pad > 0 or w < crop_h or h < crop_w:
+                    pad = int(max(crop_pad, (crop_h - w) // 2 + 5, (crop_w - h) // 2 + 5))
+                    pw, ph = w + 2 * pad, h + 2 * pad
+                if pw == crop_w and ph == crop_h:
+                    x1 = y1 = 0
+                else:
+                    x1 = below(pw - crop_w + 1)
+                    y1 = below(ph - crop_h + 1)
                 geo[row] = (w, h, pad, x1, y1)
             # -- ToTensor: the soft domain code
             dcs.append(SoftLable(ToMultiLabel(d, tt.n)).astype(np.float32))
