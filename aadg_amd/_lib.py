@@ -983,6 +983,79 @@ class _SyncBatchNormActGroup(torch.autograd.Function):
         return (None,) + tuple(outs)
 
 
+class _SyncBatchNormShortcutPair(torch.autograd.Function):
+    """relu(bn_main(a) + bn_short(b)): the tail of a bottleneck whose shortcut is a projection (1x1 convolution + BatchNorm).  The two
+    layers read independent tensors in the forward, and in the backward both receive the SAME masked gradient (the main layer's phase 1
+    writes it as `dres`), so their sums travel in ONE all-reduce per direction instead of two.  Same kernels as two _SyncBatchNormAct
+    nodes; the shortcut's normalised output is the main layer's fused residual and is not kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, a, b, wa, ba, rma, rva, wb, bb, rmb, rvb, mom_a, eps_a, mom_b, eps_b, act, handles):
+        lib = load()
+        N, C, H, W = a.shape
+        dev, dt = a.device, _BN_DTYPES[a.dtype]
+        y, idt = torch.empty_like(a), torch.empty_like(a)
+        stat = [torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4)]        # mean_a, invstd_a, mean_b, invstd_b
+        sums = torch.empty(2 * (2 * C + 1), dtype=torch.float64, device=dev)
+        ws_a = workspace(lib.aadg_bn_workspace_bytes(C), dev, "bn_group_0")
+        ws_b = workspace(lib.aadg_bn_workspace_bytes(C), dev, "bn_group_1")
+        mask = None
+        nb = lib.aadg_bn_mask_bytes(N, C, H * W, dt)
+        if nb and (a.data_ptr() | idt.data_ptr() | y.data_ptr()) % 16 == 0:
+            mask = torch.empty(nb, dtype=torch.uint8, device=dev)
+        call_b = (b.data_ptr(), None, idt.data_ptr(), None, _ptr(wb), _ptr(bb), _ptr(rmb), _ptr(rvb), mom_b, eps_b, ACT_NONE, N, C, H * W, dt,
+                  stat[2].data_ptr(), stat[3].data_ptr(), sums.data_ptr() + 8 * (2 * C + 1), ws_b.data_ptr(), ws_b.numel(), 0, _stream())
+        call_a = (a.data_ptr(), idt.data_ptr(), y.data_ptr(), _ptr(mask), _ptr(wa), _ptr(ba), _ptr(rma), _ptr(rva), mom_a, eps_a, act, N, C, H * W, dt,
+                  stat[0].data_ptr(), stat[1].data_ptr(), sums.data_ptr(), ws_a.data_ptr(), ws_a.numel(), 0, _stream())
+        _check(lib.aadg_bn_sync_forward(1, *call_a), "aadg_bn_sync_forward(1)")
+        _check(lib.aadg_bn_sync_forward(1, *call_b), "aadg_bn_sync_forward(1)")
+        _bn_sync_reduce(sums)
+        _check(lib.aadg_bn_sync_forward(2, *call_b), "aadg_bn_sync_forward(2)")          # the shortcut first: it is the main layer's residual
+        _check(lib.aadg_bn_sync_forward(2, *call_a), "aadg_bn_sync_forward(2)")
+        ctx.act = act
+        ctx.save_for_backward(a, b, y if mask is None else None, mask, wa, ba, wb, bb, sums, *stat)
+        if handles > 1:
+            return (y,) + tuple(y.view_as(y) for _ in range(handles - 1))
+        return y
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = load()
+        a, b, y, mask, wa, ba, wb, bb, fsums, mean_a, invstd_a, mean_b, invstd_b = ctx.saved_tensors
+        N, C, H, W = a.shape
+        dev, dt = a.device, _BN_DTYPES[a.dtype]
+        dy, extra, pconst, dy_stride = _bn_prepare_grads(grads, a, True)
+        da, db_, g = torch.empty_like(a), torch.empty_like(b), torch.empty_like(a)
+        par = [torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4)]         # dweight_a, dbias_a, dweight_b, dbias_b
+        sums = torch.empty(4 * C, dtype=torch.float64, device=dev)
+        ws_a = workspace(lib.aadg_bn_workspace_bytes(C), dev, "bn_group_0")
+        ws_b = workspace(lib.aadg_bn_workspace_bytes(C), dev, "bn_group_1")
+        extra_arr = _ptr_array(extra) if extra else None
+        call_a = (a.data_ptr(), _ptr(y), _ptr(mask), dy.data_ptr(), extra_arr, len(extra), _ptr(pconst), _ptr(wa), _ptr(ba), mean_a.data_ptr(),
+                  invstd_a.data_ptr(), ctx.act, da.data_ptr(), g.data_ptr(), par[0].data_ptr(), par[1].data_ptr(), N, C, H * W, dt,
+                  sums.data_ptr(), fsums.data_ptr() + 16 * C, ws_a.data_ptr(), ws_a.numel(), dy_stride, _stream())
+        call_b = (b.data_ptr(), None, None, g.data_ptr(), None, 0, None, _ptr(wb), _ptr(bb), mean_b.data_ptr(), invstd_b.data_ptr(), ACT_NONE,
+                  db_.data_ptr(), None, par[2].data_ptr(), par[3].data_ptr(), N, C, H * W, dt, sums.data_ptr() + 16 * C,
+                  fsums.data_ptr() + 8 * (2 * C + 1) + 16 * C, ws_b.data_ptr(), ws_b.numel(), 0, _stream())
+        _check(lib.aadg_bn_sync_backward(1, *call_a), "aadg_bn_sync_backward(1)")         # writes g = the masked, summed gradient
+        _check(lib.aadg_bn_sync_backward(1, *call_b), "aadg_bn_sync_backward(1)")
+        _bn_sync_reduce(sums)
+        _check(lib.aadg_bn_sync_backward(2, *call_a), "aadg_bn_sync_backward(2)")
+        _check(lib.aadg_bn_sync_backward(2, *call_b), "aadg_bn_sync_backward(2)")
+        return (da, db_, par[0] if wa is not None else None, par[1] if ba is not None else None, None, None,
+                par[2] if wb is not None else None, par[3] if bb is not None else None, None, None, None, None, None, None, None, None)
+
+
+def sync_batch_norm_shortcut_pair(a, main, b, short, act=ACT_RELU, handles=1):
+    """act(bn_main(a) + bn_short(b)) in training mode with synchronised statistics and one all-reduce per direction for the two layers;
+    main / short = (weight, bias, running_mean, running_var, momentum, eps).  handles as batch_norm_act."""
+    _require_cuda(a, b)
+    if a.shape != b.shape or a.dtype != b.dtype or not bn_act_supported(a, b):
+        raise AadgError("sync_batch_norm_shortcut_pair: expected two contiguous NCHW float32/bfloat16 tensors of one shape")
+    return _SyncBatchNormShortcutPair.apply(a, b, main[0], main[1], main[2], main[3], short[0], short[1], short[2], short[3],
+                                            float(main[4]), float(main[5]), float(short[4]), float(short[5]), int(act), int(handles))
+
+
 def sync_batch_norm_act_group(members):
     """members: [(x, weight, bias, running_mean, running_var, momentum, eps, act, out | None), ...] -- independent training-mode
     BatchNorm (+ activation) layers whose statistics travel in ONE all-reduce per direction.  Returns the outputs in order."""

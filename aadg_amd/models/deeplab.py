@@ -263,10 +263,32 @@ class Bottleneck(nn.Module):
         one per consumer (conv1 / residual branch or downsample), so that their gradients reach the producing BatchNorm
         kernel separately and are summed there instead of by autograd adds over the whole activation."""
         x_main, x_res = (x[0], x[1]) if isinstance(x, tuple) else (x, x)
+        if self._pairs_shortcut(x_res):
+            # synchronised statistics: bn3 and the projection shortcut's BatchNorm share one all-reduce per direction
+            from .. import _lib
+            short = self.downsample[0](x_res).contiguous()
+            out = bn_act(self.bn1, self.conv1(x_main), 'relu')
+            out = bn_act(self.bn2, self.conv2(out), 'relu')
+            main = self.conv3(out).contiguous()
+            bns = self.downsample[1].bn
+            if main.shape == short.shape and _lib.bn_act_supported(main, short):
+                _bump(self.bn3)
+                _bump(bns)
+                return _lib.sync_batch_norm_shortcut_pair(
+                    main, (self.bn3.weight, self.bn3.bias, self.bn3.running_mean, self.bn3.running_var, self.bn3.momentum, self.bn3.eps),
+                    short, (bns.weight, bns.bias, bns.running_mean, bns.running_var, bns.momentum, bns.eps), _ACT_CODE['relu'], handles)
+            return bn_act(self.bn3, main, 'relu', residual=bn_act(bns, short, None), handles=handles)
         idt = x_res if self.downsample is None else self.downsample(x_res)
         out = bn_act(self.bn1, self.conv1(x_main), 'relu')
         out = bn_act(self.bn2, self.conv2(out), 'relu')
         return bn_act(self.bn3, self.conv3(out), 'relu', residual=idt, handles=handles)
+
+    def _pairs_shortcut(self, x):
+        d = self.downsample
+        if not (_BN_SYNC and self.training and torch.is_grad_enabled() and x.is_cuda and isinstance(d, nn.Sequential) and len(d) == 2 and
+                type(d[1]) is BNAct and d[1].act is None):
+            return False
+        return all(type(bn) is nn.BatchNorm2d and bn.momentum is not None and bn.track_running_stats for bn in (self.bn3, d[1].bn))
 
 
 class _Stage(nn.Sequential):

@@ -171,3 +171,46 @@ def test_grouped_layers_share_one_all_reduce_per_direction(hip, dtype):
         assert torch.allclose(x1[i].grad.float(), x2[i].grad.float(), atol=tol), i
         assert torch.allclose(w1[i].grad, w2[i].grad, rtol=1e-4, atol=1e-4) and torch.allclose(b1[i].grad, b2[i].grad, rtol=1e-4, atol=1e-4)
         assert torch.allclose(rm1[i], rm2[i], atol=1e-6) and torch.allclose(rv1[i], rv2[i], atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_projection_shortcut_pair_shares_one_all_reduce_per_direction(hip, dtype):
+    """relu(bn3(a) + bn_short(b)) -- the tail of a bottleneck with a projection shortcut: `sync_batch_norm_shortcut_pair` gives the
+    outputs, gradients (two consumers of the output) and running statistics of two separate synchronised layers with 2 collectives
+    instead of 4."""
+    torch.manual_seed(11)
+    shape = (6, 32, 8, 8)
+    a0 = (torch.randn(shape, device="cuda") * 1.3 + 0.2).to(dtype)
+    b0 = (torch.randn(shape, device="cuda") * 0.7 - 0.1).to(dtype)
+    g0, g1 = torch.randn(shape, device="cuda").to(dtype), torch.randn(shape, device="cuda").to(dtype)
+    calls = []
+    hip.BN_SYNC_REDUCE = lambda t: calls.append(t.numel())
+    try:
+        def leaves():
+            t = [a0.detach().clone().requires_grad_(True), b0.detach().clone().requires_grad_(True)]
+            for k in range(2):
+                t += [(torch.rand(32, device="cuda") * 0 + 0.5 + 0.1 * k).requires_grad_(True), torch.full((32,), 0.05 * (k + 1), device="cuda").requires_grad_(True),
+                      torch.zeros(32, device="cuda"), torch.ones(32, device="cuda")]
+            return t
+        a1, b1, wa1, ba1, rma1, rva1, wb1, bb1, rmb1, rvb1 = leaves()
+        hip.BN_SYNC_COLLECTIVES[0] = 0
+        idt = hip.batch_norm_act(b1, wb1, bb1, rmb1, rvb1, True, 0.1, 1e-5, 0, None, sync=True)
+        y1 = hip.batch_norm_act(a1, wa1, ba1, rma1, rva1, True, 0.2, 1e-5, 1, idt, handles=2, sync=True)
+        torch.autograd.backward(list(y1), [g0, g1])
+        assert hip.BN_SYNC_COLLECTIVES[0] == 4
+        a2, b2, wa2, ba2, rma2, rva2, wb2, bb2, rmb2, rvb2 = leaves()
+        calls.clear()
+        hip.BN_SYNC_COLLECTIVES[0] = 0
+        y2 = hip.sync_batch_norm_shortcut_pair(a2, (wa2, ba2, rma2, rva2, 0.2, 1e-5), b2, (wb2, bb2, rmb2, rvb2, 0.1, 1e-5), 1, handles=2)
+        torch.autograd.backward(list(y2), [g0, g1])
+        assert hip.BN_SYNC_COLLECTIVES[0] == 2 and calls == [2 * (2 * 32 + 1), 4 * 32]
+    finally:
+        hip.BN_SYNC_REDUCE = None
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert torch.allclose(y1[0].float(), y2[0].float(), atol=tol)
+    for u, v in ((a1, a2), (b1, b2)):
+        assert torch.allclose(u.grad.float(), v.grad.float(), atol=tol)
+    for u, v in ((wa1, wa2), (ba1, ba2), (wb1, wb2), (bb1, bb2)):
+        assert torch.allclose(u.grad, v.grad, rtol=1e-4, atol=1e-4)
+    for u, v in ((rma1, rma2), (rva1, rva2), (rmb1, rmb2), (rvb1, rvb2)):
+        assert torch.allclose(u, v, atol=1e-6)
