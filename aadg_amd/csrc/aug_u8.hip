@@ -926,39 +926,68 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
         lds_ops(cur, 0, j0, 256);
         __syncthreads();
     }
+    // Sharpness passes: wave <-> (64-column chunk, row segment), a lane walks DOWN its column with the horizontal 3-sums of the
+    // previous / current / next row in registers: 3 LDS reads and ~50 instructions per pixel instead of 9 and ~80 (each pixel as the
+    // centre of its own 3 x 3 gather).  Narrow patches split the rows so that all four waves have work.
+    const int nch = (pw + 63) >> 6;
+    const int nseg = nch >= 3 ? 1 : (nch == 2 ? 2 : 4);
+    const int seg_rows = (ph + nseg - 1) / nseg;
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);
+    auto my_items = [&](auto body) {              // body(chunk, first row, end row) for the items of this wave
+        int it = 0;
+        for (int sg = 0; sg < nseg; ++sg)
+            for (int c = 0; c < nch; ++c, ++it)
+                if ((it & 3) == wvs) {
+                    const int ra = sg * seg_rows, rb = min(ph, ra + seg_rows);
+                    if (ra < rb) body(c, ra, rb);
+                }
+    };
     while (j0 < nops) {                           // op j0 is a Sharpness stencil
         const float alpha = un.farg[j0];
         int j1 = j0 + 1;
         while (j1 < nops && !is_stencil(un, j1)) ++j1;
-        for (int row = wv; row < ph; row += 4) {
-            const int y = r_lo + row;
-            const bool row_in = y > 0 && y < Hs - 1 && row > 0 && row < ph - 1;
-#pragma unroll 2
-            for (int col = lane; col < pw; col += 64) {
-                const int i = row * pw + col;
-                const int x = c_lo + col;
-                const uint32_t p = cur[i];
-                uint32_t d = p;   // ImageFilter.SMOOTH copies the 1-pixel image border
-                if (row_in && x > 0 && x < Ws - 1 && col > 0 && col < pw - 1) {
-                    uint32_t srb = 4u * (p & 0xFF00FFu), sg = 4u * ((p >> 8) & 255u);   // centre weight 5 = 4 + 1
-#pragma unroll
-                    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            const uint32_t q = cur[i + dy * pw + dx];
-                            srb += q & 0xFF00FFu;
-                            sg += (q >> 8) & 255u;
-                        }
-                    // (x + 6) / 13 for x <= 13 * 255: a 24-bit multiply by ceil(2^16 / 13) and a shift (exact for x + 6 <= 3321:
-                    // the error term x * 10 / (13 * 65536) stays below 1/13); a 32-bit division is several quarter-rate multiplies
-                    const uint32_t r = (uint32_t)__mul24((int)((srb & 0xFFFFu) + 6u), 5042) >> 16, b = (uint32_t)__mul24((int)((srb >> 16) + 6u), 5042) >> 16,
-                                   g = (uint32_t)__mul24((int)(sg + 6u), 5042) >> 16;
-                    d = r | (g << 8) | (b << 16);
-                }
-                oth[i] = blend3(d, p, alpha, true);
+        my_items([&](int c, int ra, int rb) {
+            const int col = 64 * c + lane;
+            const bool act = col < pw;
+            const int cc = min(col, pw - 1), cm = max(cc - 1, 0), cp = min(cc + 1, pw - 1);
+            const int x = c_lo + cc;
+            const bool col_in = x > 0 && x < Ws - 1 && cc > 0 && cc < pw - 1;   // ImageFilter.SMOOTH copies the 1-pixel image border
+            uint32_t h0rb = 0, h0g = 0, h1rb, h1g, h2rb = 0, h2g = 0, p1, p2 = 0;
+            auto hrow = [&](int r, uint32_t& hrb, uint32_t& hg, uint32_t& pc) {
+                const uint32_t* rp = cur + r * pw;
+                const uint32_t q0 = rp[cm], q1 = rp[cc], q2 = rp[cp];
+                pc = q1;
+                hrb = (q0 & 0xFF00FFu) + (q1 & 0xFF00FFu) + (q2 & 0xFF00FFu);
+                hg = ((q0 >> 8) & 255u) + ((q1 >> 8) & 255u) + ((q2 >> 8) & 255u);
+            };
+            if (ra > 0) { uint32_t t; hrow(ra - 1, h0rb, h0g, t); }
+            hrow(ra, h1rb, h1g, p1);
+            for (int r = ra; r < rb; ++r) {
+                if (r + 1 < ph) hrow(r + 1, h2rb, h2g, p2);
+                const int y = r_lo + r;
+                const bool in = col_in && y > 0 && y < Hs - 1 && r > 0 && r < ph - 1;
+                const uint32_t srb = h0rb + h1rb + h2rb + 4u * (p1 & 0xFF00FFu), sg = h0g + h1g + h2g + 4u * ((p1 >> 8) & 255u);   // centre weight 5 = 4 + 1
+                // (x + 6) / 13 for x <= 13 * 255: a 24-bit multiply by ceil(2^16 / 13) and a shift (exact for x + 6 <= 3321:
+                // the error term x * 10 / (13 * 65536) stays below 1/13); a 32-bit division is several quarter-rate multiplies
+                const uint32_t cr = (uint32_t)__mul24((int)((srb & 0xFFFFu) + 6u), 5042) >> 16, cb = (uint32_t)__mul24((int)((srb >> 16) + 6u), 5042) >> 16,
+                               cg = (uint32_t)__mul24((int)(sg + 6u), 5042) >> 16;
+                const uint32_t d = in ? (cr | (cg << 8) | (cb << 16)) : p1;
+                if (act) oth[r * pw + col] = blend3(d, p1, alpha, true);
+                h0rb = h1rb; h0g = h1g; h1rb = h2rb; h1g = h2g; p1 = p2;
             }
-        }
-        lds_ops(oth, j0 + 1, j1, 0);              // same lane <-> pixel mapping as the pass above: no barrier needed
+        });
+        // the pointwise ops that follow run on the pixels this lane has just written: no barrier needed
+        for (int j = j0 + 1; j < j1; ++j)
+            dispatch_op(un, j, sl_all, [&](auto f) {
+                my_items([&](int c, int ra, int rb) {
+                    const int col = 64 * c + lane;
+                    if (col < pw)
+                        for (int r = ra; r < rb; ++r) {
+                            const int i = r * pw + col;
+                            oth[i] = f(oth[i], r_lo + r, c_lo + col);
+                        }
+                });
+            });
         uint32_t* t = cur; cur = oth; oth = t;
         __syncthreads();
         j0 = j1;
