@@ -1223,8 +1223,13 @@ constexpr int GT_W = 64, GT_H = 16, GT_TAPS = 5;
 __device__ __forceinline__ int axis_taps(int inSize, int outSize) {
     if (inSize == outSize) return 1;
     if (outSize > inSize) return 2;
-    const double scale = (double)inSize / (double)outSize;      // in (1, 2]
-    return (int)ceil(scale) * 2 + 1;                            // Pillow ksize; 5 for scale <= 2
+    // down-scaling by at most 2: Pillow allocates ksize = 2 * ceil(support) + 1 = 5 coefficients per output, but only
+    // xmax - xmin = floor(c + s + 0.5) - floor(c - s + 0.5) <= floor(2 s) + 1 of them are used (support s = inSize / outSize): 3 while
+    // s < 1.5, 4 while s < 2.  The comparisons are strict (s at least 1 / outSize below the bound), so the rounding of the double
+    // expressions cannot add a tap; exactly s = 2 keeps all five slots.
+    if (3 * outSize > 2 * inSize) return 3;
+    if (2 * outSize > inSize) return 4;
+    return GT_TAPS;
 }
 
 __global__ __launch_bounds__(256) void k_fused_generic(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
@@ -1402,7 +1407,7 @@ __global__ __launch_bounds__(256) void k_fused_generic(const uint8_t* __restrict
 //   * k_gen_vpass: wave <-> output row, lane <-> 4 consecutive columns; the <= 5 taps are 16-byte loads of the intermediate, the row
 //     tables are scalar loads; normalise through the LDS table, NEAREST mask gather, multilabel planes, streaming 16-byte stores;
 //     rows / columns of the padding are constant stores.
-// k_fused_generic (one pass, above) stays selectable with AADG_GENERIC_V1=1; tests compare the two bit for bit.
+// k_fused_generic (one pass, above) stays selectable with AADG_GENERIC_V1=1; tests/test_gpu_aug_variants.py compares the two bit for bit.
 // ------------------------------------------------------------------------------------------------
 constexpr int GH_CB = 128;             // output columns per horizontal-pass tile: <= 2 * 128 + 5 source columns (+ halo, alignment) <= 272
 constexpr int GH_NR = 4;               // patch rows per wave of build_patch: 4 * GH_NR >= GH_PATCH_ROWS
@@ -1412,18 +1417,28 @@ constexpr int GH_PATCH_ROWS = 16;      // patch rows; a tile covers 16 - 2 * (st
 constexpr int GH_CAP = GH_PATCH_ROWS * 272 + 8;      // patch words (272 = widest patch) + the slack the last row's taps may read
 template <bool SHARP> struct GhRows { static constexpr int value = SHARP ? GH_PATCH_ROWS - 2 * MAX_SHARP : GH_PATCH_ROWS; };   // fewest rows per tile (grid size)
 
+// coefficient k (<= 2^22) -> 4k as an unsigned 24-bit multiplier.  4k = 2^24 only for a single tap of weight one (k1 <= 1):
+// with 2^24 - 1 the sum is c0 * 2^24 + (2^23 + 4 c1 k1 - c0), whose byte 3 is still c0 because 0 < 2^23 + 4 c1 k1 - c0 < 2^24.
+__device__ __forceinline__ uint32_t prescale4(int k) {
+    const uint32_t q = (uint32_t)k << 2;
+    return q > 0xFFFFFFu ? 0xFFFFFFu : q;
+}
+
+// one output of the horizontal pass: coefficients scaled by 4 (prescale4), so that byte 3 of each 32-bit sum IS the rounded channel
+// value ((2^21 + sum c k) >> 22, never above 255 for non-negative coefficients that sum to 2^22) and two v_perm_b32 pack the word
 template <int NT>
-__device__ __forceinline__ uint32_t hpass_px(const uint32_t* rowp, const int* hk, int /*lim*/) {
-    int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+__device__ __forceinline__ uint32_t hpass_px(const uint32_t* rowp, const uint32_t* hk) {
+    uint32_t s0 = 1u << 23, s1 = s0, s2 = s0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const uint32_t p = rowp[t];                          // taps beyond the patch have zero coefficients: whatever word lies there
                                                              // (the next row, or the 8 words of slack behind the buffer) is multiplied by 0
-        s0 += __mul24((int)(p & 255), hk[t]);
-        s1 += __mul24((int)((p >> 8) & 255), hk[t]);
-        s2 += __mul24((int)((p >> 16) & 255), hk[t]);
+        s0 += __umul24(p & 255u, hk[t]);
+        s1 += __umul24((p >> 8) & 255u, hk[t]);
+        s2 += __umul24((p >> 16) & 255u, hk[t]);
     }
-    return (uint32_t)clip8(s0) | ((uint32_t)clip8(s1) << 8) | ((uint32_t)clip8(s2) << 16);
+    const uint32_t rg = __builtin_amdgcn_perm(s1, s0, 0x0c0c0703u);      // [s0.b3, s1.b3, 0, 0]
+    return __builtin_amdgcn_perm(s2, rg, 0x0c070100u);                  // [rg.b0, rg.b1, s2.b3, 0]
 }
 
 // body of one horizontal-pass tile: (bx, by) = column tile / row block, slot = position in the generic list = the unit's slice of
@@ -1468,16 +1483,16 @@ __device__ __forceinline__ void gen_hpass_body(const uint8_t* __restrict__ pool,
     const int hc = tid & (GH_CB - 1), hg = tid >> 7;
     const int xh = x0 + hc;
     const bool col_ok = xh >= fx && xh <= lx;
-    int hxm = 0, hk[GT_TAPS];
-#pragma unroll
-    for (int t = 0; t < GT_TAPS; ++t) hk[t] = 0;
+    int hxm = 0;
+    uint32_t hk[GT_TAPS];
     {
         const int xc = min(max(xh, fx), lx);                  // clamped: no conditional loads
         hxm = xmin_t[xc];
+        int kraw[GT_TAPS];
 #pragma unroll
-        for (int t = 0; t < GT_TAPS; ++t) hk[t] = xk_t[(size_t)xc * KMAX + (t < ntx ? t : 0)];
+        for (int t = 0; t < GT_TAPS; ++t) kraw[t] = xk_t[(size_t)xc * KMAX + (t < ntx ? t : 0)];
 #pragma unroll
-        for (int t = 0; t < GT_TAPS; ++t) hk[t] = t < ntx ? hk[t] : 0;
+        for (int t = 0; t < GT_TAPS; ++t) hk[t] = t < ntx ? prescale4(kraw[t]) : 0u;
     }
     const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
     const uint32_t* cur = build_patch<GH_NR, 2>(un, n_ops, src, Hs, Ws, r_lo_h, r_hi_h, c_lo_h, c_hi_h, A, SHARP ? Bs : A, lut,
@@ -1485,18 +1500,17 @@ __device__ __forceinline__ void gen_hpass_body(const uint8_t* __restrict__ pool,
     if (!col_ok) return;
     const int nrows = r_hi - r_lo;
     const uint32_t* colp = cur + (r_lo - r_lo_h) * pw + (hxm - c_lo_h);
-    const int lim = pw - (hxm - c_lo_h);
     uint32_t* hout = hbuf + ((size_t)slot * Hs + r_lo) * crop + xh;
-    if (ntx == GT_TAPS) {
-#pragma unroll 2
-        for (int rr = hg; rr < nrows; rr += 2) hout[(size_t)rr * crop] = hpass_px<GT_TAPS>(colp + rr * pw, hk, lim);
-    } else if (ntx == 2) {
-#pragma unroll 2
-        for (int rr = hg; rr < nrows; rr += 2) hout[(size_t)rr * crop] = hpass_px<2>(colp + rr * pw, hk, lim);
-    } else {
-#pragma unroll 2
-        for (int rr = hg; rr < nrows; rr += 2) hout[(size_t)rr * crop] = hpass_px<1>(colp + rr * pw, hk, lim);
+#define AADG_HPASS_ROWS(NT)                                                                                              \
+    _Pragma("unroll 2") for (int rr = hg; rr < nrows; rr += 2) hout[(size_t)rr * crop] = hpass_px<NT>(colp + rr * pw, hk)
+    switch (ntx) {                                            // uniform per unit
+        case 1: AADG_HPASS_ROWS(1); break;
+        case 2: AADG_HPASS_ROWS(2); break;
+        case 3: AADG_HPASS_ROWS(3); break;
+        case 4: AADG_HPASS_ROWS(4); break;
+        default: AADG_HPASS_ROWS(GT_TAPS); break;
     }
+#undef AADG_HPASS_ROWS
 }
 
 template <bool SHARP>
@@ -1608,12 +1622,12 @@ __device__ __forceinline__ void vpass_pair(const VRow (&row)[GV_G], int nrows_li
 }
 
 __global__ __launch_bounds__(256) void k_gen_vpass(const uint8_t* __restrict__ masks, const aadg_unit* __restrict__ units,
-                                                   const int* __restrict__ order, int Hs, int Ws, int crop, int dataset_in,
+                                                   const int* __restrict__ order, int slot0, int Hs, int Ws, int crop, int dataset_in,
                                                    const int* __restrict__ tab, const uint32_t* __restrict__ hbuf,
                                                    float* __restrict__ out_img, float* __restrict__ out_lbl) {
     const int dataset = dataset_in & 0xFF;
     const bool stream_out = (dataset_in & AUG_STREAM_OUT) != 0;
-    const int slot = blockIdx.z;
+    const int slot = slot0 + blockIdx.z;
     const int u = order != nullptr ? order[slot] : slot;
     const aadg_unit& un = units[u];
     if (unit_flow(true, un, Hs, Ws, crop) != FLOW_GENERIC) return;
@@ -1663,9 +1677,15 @@ __global__ __launch_bounds__(256) void k_gen_vpass(const uint8_t* __restrict__ m
         const int live = min(GV_G, crop - (ybase + GV_G * pr));
         if (live <= 0) break;
         const VRow (&pair)[GV_G] = reinterpret_cast<const VRow (&)[GV_G]>(rows[GV_G * pr]);
-        if (nty == GT_TAPS) vpass_pair<GT_TAPS>(pair, live, hcol, msk, Hs, Ws, crop, xm, xn, win_ok, any_col, optic, K, lutf, oi, ol, plane, xq, stream_out);
-        else if (nty == 2) vpass_pair<2>(pair, live, hcol, msk, Hs, Ws, crop, xm, xn, win_ok, any_col, optic, K, lutf, oi, ol, plane, xq, stream_out);
-        else vpass_pair<1>(pair, live, hcol, msk, Hs, Ws, crop, xm, xn, win_ok, any_col, optic, K, lutf, oi, ol, plane, xq, stream_out);
+#define AADG_VPASS(NT) vpass_pair<NT>(pair, live, hcol, msk, Hs, Ws, crop, xm, xn, win_ok, any_col, optic, K, lutf, oi, ol, plane, xq, stream_out)
+        switch (nty) {                                        // uniform per unit
+            case 1: AADG_VPASS(1); break;
+            case 2: AADG_VPASS(2); break;
+            case 3: AADG_VPASS(3); break;
+            case 4: AADG_VPASS(4); break;
+            default: AADG_VPASS(GT_TAPS); break;
+        }
+#undef AADG_VPASS
     }
 }
 
@@ -1701,13 +1721,6 @@ __global__ __launch_bounds__(256) void k_fused(const uint8_t* __restrict__ pool,
 // ------------------------------------------------------------------------------------------------
 constexpr int PATCH_CAP_PLAIN = 4608;     // 17 rows x 264 columns: a 256 x 16 tile's patch without a stencil halo
 constexpr int HBUF_ROWS = FT_H + 1;       // source rows a 16-row tile touches when no axis shrinks
-
-// coefficient k (<= 2^22) -> 4k as an unsigned 24-bit multiplier.  4k = 2^24 only for a single tap of weight one (k1 <= 1):
-// with 2^24 - 1 the sum is c0 * 2^24 + (2^23 + 4 c1 k1 - c0), whose byte 3 is still c0 because 0 < 2^23 + 4 c1 k1 - c0 < 2^24.
-__device__ __forceinline__ uint32_t prescale4(int k) {
-    const uint32_t q = (uint32_t)k << 2;
-    return q > 0xFFFFFFu ? 0xFFFFFFu : q;
-}
 
 // number of Sharpness stencils of a unit, all four op slots read unconditionally (independent scalar loads, one wait)
 __device__ __forceinline__ int sharp_count4(const aadg_unit& un, int n_ops) {
@@ -1950,6 +1963,21 @@ __global__ __launch_bounds__(256) void k_fused3(const uint8_t* __restrict__ pool
                  blockIdx.x, blockIdx.y, blockIdx.z, A, B, sl, lutf);
 }
 
+// list slots per chunk of the two-pass generic flow: as many as keep the chunk's intermediate (Hs x crop words per slot) within 128 MB, half of
+// the Infinity Cache -- 32 slots at 1024 x 1024 (measured there, 86 generic units of 168: all at once 0.914 ms for the batch's tile kernels,
+// chunks of 8 / 16 / 24 / 32 / 48 / 64 slots 0.971 / 0.909 / 0.870 / 0.862 / 0.910 / 0.931 ms).  AADG_GEN_CHUNK overrides the slot count.
+// The workspace holds one chunk's intermediate.
+int gen_chunk(int Hs, int crop) {
+    static const int forced = [] {
+        const char* v = getenv("AADG_GEN_CHUNK");
+        return v != nullptr ? atoi(v) : 0;
+    }();
+    if (forced > 0) return forced;
+    const size_t per_slot = (size_t)Hs * crop * 4;
+    const size_t n = ((size_t)128 << 20) / (per_slot ? per_slot : 1);
+    return n < 4 ? 4 : (n > 4096 ? 4096 : (int)n);
+}
+
 struct WsLayout {
     size_t hist, lut, tab, buf0, buf1, hbuf, total;
 };
@@ -1963,7 +1991,7 @@ WsLayout ws_layout(int N, int Hs, int Ws, int crop) {
     l.buf0 = o; o = aadg_align_up(o + (size_t)N * img, 256);
     l.buf1 = o; o = aadg_align_up(o + (size_t)N * img, 256);
     // horizontally resampled rows of the down-scaling units (k_gen_hpass -> k_gen_vpass): [unit slot][Hs][crop] packed RGBX
-    l.hbuf = o; o = aadg_align_up(o + (size_t)N * Hs * crop * 4, 256);
+    l.hbuf = o; o = aadg_align_up(o + (size_t)(N < gen_chunk(Hs, crop) ? N : gen_chunk(Hs, crop)) * Hs * crop * 4, 256);      // one chunk of generic units
     l.total = o;
     return l;
 }
@@ -1993,18 +2021,13 @@ int launch_tiles(const uint8_t* pool, const uint8_t* masks, const aadg_unit* uni
     const int* order_sharp = order_up != nullptr ? order_up + np : nullptr;
     // with the caller's list the stencil units are the last ng_sharp entries; without one every unit is offered to both variants
     const bool listed = order_gen != nullptr;
-    const int n0 = v1 ? 0 : (listed ? ng - ng_sharp : ng), n1 = v1 ? 0 : (listed ? ng_sharp : ng), s1 = listed ? ng - ng_sharp : 0;
+    const int n0 = listed ? ng - ng_sharp : ng, s1 = listed ? ng - ng_sharp : 0;
     const int hx = (crop + GH_CB - 1) / GH_CB, hy0 = (Hs + GhRows<false>::value - 1) / GhRows<false>::value;
     // (Measured and dropped: k_fused3's tiles and the horizontal-pass tiles interleaved in ONE launch, so that the store-bound and the
     // issue-bound workgroups share the CUs: 611 us against 376 + 176 us one after the other at 1024 x 1024 -- both are issue-heavy.)
     if (gz > 0) {
         hipLaunchKernelGGL(k_fused3, dim3(gx, gy, gz), dim3(256), 0, st, pool, masks, units, order_up, order_sharp, np, Hs, Ws, crop, dsk, tab, lut,
                            lut_stage_stride, out_img, out_lbl);
-        AADG_LAUNCH_CHECK();
-    }
-    if (n0 > 0) {
-        hipLaunchKernelGGL(k_gen_hpass<false>, dim3(hx, hy0, n0), dim3(256), 0, st, pool, units, order_gen, 0, Hs, Ws, crop, tab, lut,
-                           lut_stage_stride, hbuf);
         AADG_LAUNCH_CHECK();
     }
     if (ng <= 0) return 0;
@@ -2015,14 +2038,32 @@ int launch_tiles(const uint8_t* pool, const uint8_t* masks, const aadg_unit* uni
         AADG_LAUNCH_CHECK();
         return 0;
     }
-    if (n1 > 0) {
-        hipLaunchKernelGGL(k_gen_hpass<true>, dim3(hx, (Hs + GhRows<true>::value - 1) / GhRows<true>::value, n1), dim3(256), 0, st, pool, units,
-                           order_gen, s1, Hs, Ws, crop, tab, lut, lut_stage_stride, hbuf);
+    // The generic units go through the two passes in chunks of gen_chunk() list slots that share ONE slice of the intermediate: what the
+    // horizontal pass writes is read back by the vertical pass while it is still in the Infinity Cache (256 MB; 4 MB per unit at
+    // 1024 x 1024), instead of after the whole batch's intermediate has gone to HBM and come back.
+    const int chunk = gen_chunk(Hs, crop);
+    const size_t slot_words = (size_t)Hs * crop;
+    const int hy1 = (Hs + GhRows<true>::value - 1) / GhRows<true>::value;
+    for (int a = 0; a < ng; a += chunk) {
+        const int b = min(ng, a + chunk);
+        uint32_t* hb = hbuf - (size_t)a * slot_words;                 // slot s of this chunk lives at hbuf + (s - a) * slot_words
+        // listed: plain units are slots [0, n0), stencil units [s1, ng); unlisted: every slot is offered to both variants
+        const int p0 = a, p1 = min(b, n0);
+        const int q0 = max(a, s1), q1 = b;
+        if (p1 > p0) {
+            hipLaunchKernelGGL(k_gen_hpass<false>, dim3(hx, hy0, p1 - p0), dim3(256), 0, st, pool, units, order_gen, p0, Hs, Ws, crop, tab, lut,
+                               lut_stage_stride, hb);
+            AADG_LAUNCH_CHECK();
+        }
+        if (q1 > q0) {
+            hipLaunchKernelGGL(k_gen_hpass<true>, dim3(hx, hy1, q1 - q0), dim3(256), 0, st, pool, units, order_gen, q0, Hs, Ws, crop, tab, lut,
+                               lut_stage_stride, hb);
+            AADG_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(k_gen_vpass, dim3((crop + 255) / 256, (crop + GV_ROWS - 1) / GV_ROWS, b - a), dim3(256), 0, st, masks, units, order_gen, a,
+                           Hs, Ws, crop, dsk, tab, hb, out_img, out_lbl);
         AADG_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_gen_vpass, dim3((crop + 255) / 256, (crop + GV_ROWS - 1) / GV_ROWS, ng), dim3(256), 0, st, masks, units, order_gen, Hs, Ws,
-                       crop, dsk, tab, hbuf, out_img, out_lbl);
-    AADG_LAUNCH_CHECK();
     return 0;
 }
 
