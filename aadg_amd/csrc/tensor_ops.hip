@@ -22,8 +22,8 @@
 //   * the 3x3 stencil streams down row strips with a three-row register window (neighbour columns by wave shuffles,
 //     no LDS, no barriers);
 //   * translate_x / translate_y / shear_x read their taps with one 16-byte load per source row at a 4-byte-aligned address (taps of
-//     weight zero are not loaded); shear_y walks 4 columns x 2 rows per lane over aligned row loads; rotate stages the footprint of a
-//     32 x 32 tile in LDS, plane after plane, the next plane in flight; coordinates and weights serve the three planes.
+//     weight zero are not loaded); rotate and shear_y stage the footprint of a 32 x 32 tile in LDS, plane after plane, the next plane in
+//     flight; coordinates and weights serve the three planes; their workgroups are numbered image-major per XCD (one L2 per image);
 // Shapes the vector paths cannot take (W % 4 != 0, W < 8, unaligned pointers) go through the `_any` kernels (one pixel per lane),
 // which share the per-pixel arithmetic with the vector kernels (tests/test_gpu_functional.py compares them bit for bit).
 #include "common.h"
@@ -453,6 +453,22 @@ __device__ __forceinline__ RowWin<NPX> stencil_load_row(const float* __restrict_
     return o;
 }
 
+// 1-D grids in group-major order per XCD.  Consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2; with the plain
+// (x, y, image) order neighbouring workgroups of one image -- whose source footprints overlap (halo rows, rotated boxes, row pairs) -- sit on
+// eight different L2s and every one of them fetches the overlap again (rotate: 2.4 x the source bytes from the fabric).  Here workgroup id L
+// works for group 8 * (L / 8 / per_group) + L % 8 (group = image or plane), so a group's workgroups share one L2; the last groups % 8
+// groups keep the plain order.
+__device__ __forceinline__ void xcd_group_major(int L, int per_group, int groups, int& g, int& t) {
+    if (L < per_group * (groups & ~7)) {
+        const int j = L >> 3;
+        g = (j / per_group) * 8 + (L & 7);
+        t = j % per_group;
+    } else {
+        g = L / per_group;
+        t = L % per_group;
+    }
+}
+
 template <int FOP, int NPX, int ROWS, bool STREAM>
 __global__ __launch_bounds__(TO_THREADS) void k_fop_stencil_rows(const float* __restrict__ in, float* __restrict__ out,
                                                                  const float* __restrict__ mag, int mag_n,
@@ -547,7 +563,7 @@ __device__ __forceinline__ Affine affine_of(float m, int H, int W) {
     return A;
 }
 
-// rotate: 32 x 32 output tile per workgroup, lane <-> 4 consecutive columns of one row.  The source footprint of the tile (bounding box
+// rotate / shear_y: 32 x 32 output tile per workgroup, lane <-> 4 consecutive columns of one row.  The source footprint of the tile (bounding box
 // of its four corners + margin: at most 56 x 50 pixels at any angle) is staged in LDS with 16-byte row loads, positions outside the
 // image as zeros -- so a tap needs neither a validity test nor a clamp, and coordinates and weights are computed once for the three
 // planes.  (4-byte gathers through the texture path deliver 0.16-0.28 of the HBM roofline for this access pattern, whatever the lane
@@ -558,11 +574,15 @@ __device__ __forceinline__ Affine affine_of(float m, int H, int W) {
 constexpr int ROT_T = 32, ROT_G = 14, ROT_PITCH = 4 * ROT_G + 1, ROT_ROWS = 50, ROT_PASSES = (ROT_ROWS + 15) / 16;
 template <int FOP, bool STREAM>
 __global__ __launch_bounds__(TO_THREADS) void k_fop_affine_tile(const float* __restrict__ in, float* __restrict__ out,
-                                                                const float* __restrict__ mag, int mag_n, int H, int W) {
-    const int b = blockIdx.z, HW = H * W, tid = threadIdx.x;
+                                                                const float* __restrict__ mag, int mag_n, int H, int W, int B) {
+    // 1-D grid, image-major per XCD (xcd_group_major): the tiles of one image share one L2
+    const int gxn = (W + ROT_T - 1) / ROT_T, tiles = gxn * ((H + ROT_T - 1) / ROT_T);
+    int b, t;
+    xcd_group_major(blockIdx.x, tiles, B, b, t);
+    const int HW = H * W, tid = threadIdx.x;
     const float* pin = in + (size_t)b * 3 * HW;
     float* po = out + (size_t)b * 3 * HW;
-    const int tx0 = blockIdx.x * ROT_T, ty0 = blockIdx.y * ROT_T;
+    const int tx0 = (t % gxn) * ROT_T, ty0 = (t / gxn) * ROT_T;
     const int x = tx0 + 4 * (tid & 7), y = ty0 + (tid >> 3);
     const float m = mag ? mag[mag_n == 1 ? 0 : b] : 0.0f;
     const Affine A = affine_of<FOP>(m, H, W);
@@ -580,8 +600,9 @@ __global__ __launch_bounds__(TO_THREADS) void k_fop_affine_tile(const float* __r
     const int bx0 = ((int)floorf(fminf(fmaxf(sxmin, -big), big)) - 1) & ~3;
     const int by0 = (int)floorf(fminf(fmaxf(symin, -big), big)) - 1;
     // a rotation always fits; a shear beyond |m| ~ 0.45 does not: those workgroups gather their taps from global memory (uniform branch)
-    const bool fits = FOP == AADG_FOP_ROTATE ||
-                      ((int)floorf(fminf(fmaxf(sxmax, -big), big)) + 2 - bx0 < 4 * ROT_G && (int)floorf(fminf(fmaxf(symax, -big), big)) + 2 - by0 < ROT_ROWS);
+    // columns / rows of the box this tile really touches (a small angle needs 34 x 34 of the 56 x 50)
+    const int need_x = (int)floorf(fminf(fmaxf(sxmax, -big), big)) + 3 - bx0, need_y = (int)floorf(fminf(fmaxf(symax, -big), big)) + 3 - by0;
+    const bool fits = FOP == AADG_FOP_ROTATE || (need_x <= 4 * ROT_G && need_y <= ROT_ROWS);
     if (!fits) {
         if (x >= W || y >= H) return;
 #pragma unroll
@@ -606,13 +627,13 @@ __global__ __launch_bounds__(TO_THREADS) void k_fop_affine_tile(const float* __r
     // staging: 16 column groups x 16 rows per pass; W % 4 == 0 and gx % 4 == 0, so a group is inside or outside the image as a whole
     const int g = tid & 15, r0 = tid >> 4;
     const int gx = bx0 + 4 * g;
-    const bool col_in = g < ROT_G && gx >= 0 && gx < W;
+    const bool col_in = g < ROT_G && 4 * g < need_x && gx >= 0 && gx < W;
     int goff[ROT_PASSES];
     bool gin[ROT_PASSES];
 #pragma unroll
     for (int p = 0; p < ROT_PASSES; ++p) {
         const int r = r0 + 16 * p, gy = by0 + r;
-        gin[p] = col_in && r < ROT_ROWS && gy >= 0 && gy < H;
+        gin[p] = col_in && r < ROT_ROWS && r < need_y && gy >= 0 && gy < H;
         goff[p] = gin[p] ? gy * W + gx : 0;
     }
     float4 stage[ROT_PASSES];
@@ -755,82 +776,6 @@ __global__ __launch_bounds__(TO_THREADS) void k_fop_warp_rows(const float* __res
     }
 }
 
-// shear_y without LDS: the source column IS the output column (sx = x exactly, wx = 0) and the source row of a pixel moves down by
-// exactly one per output row, so a lane that owns 4 columns x SY_R consecutive rows needs SY_R + 2 aligned 16-byte row loads per plane
-// (rows ymin .. ymin + SY_R + 1; the row offsets of its 4 columns differ by at most one step when |m| < 1/3) instead of three per
-// output row.  Workgroup tile: 32 columns (one cache line) x 32 * SY_R rows -- the lines a tile touches are used completely.
-// Every pixel still evaluates its own coordinates with the generic formula and the lane verifies the structure; otherwise per-tap path.
-// With wx = 0 the reference expression (1-wy)*((1-wx)*a + wx*b) + wy*((1-wx)*c + wx*d) equals (1-wy)*a + wy*c bit for bit (finite taps).
-constexpr int SY_R = 2, SY_LX = 16;     // measured at [144,3,512,512]: (rows per lane, lanes per row) (4,8) 0.243 ms, (4,16) 0.211, (4,32) 0.219, (2,16) 0.198, (1,16) 0.209
-template <bool STREAM>
-__global__ __launch_bounds__(TO_THREADS) void k_fop_shear_y_cols(const float* __restrict__ in, float* __restrict__ out,
-                                                                 const float* __restrict__ mag, int mag_n, int H, int W) {
-    const int b = blockIdx.z, HW = H * W;
-    const float* pin = in + (size_t)b * 3 * HW;
-    float* po = out + (size_t)b * 3 * HW;
-    const int x = blockIdx.x * (4 * SY_LX) + 4 * (threadIdx.x % SY_LX), y = (blockIdx.y * (TO_THREADS / SY_LX) + threadIdx.x / SY_LX) * SY_R;
-    if (x >= W || y >= H) return;
-    const float m = mag ? mag[mag_n == 1 ? 0 : b] : 0.0f;
-    const Affine A = affine_of<AADG_FOP_SHEAR_Y>(m, H, W);
-    const float big = 1.0e6f;
-    int x0[SY_R][4], y0[SY_R][4];
-    float wx[SY_R][4], wy[SY_R][4];
-    bool fast = y + SY_R <= H;
-    int ymin = 0x7fffffff;
-#pragma unroll
-    for (int j = 0; j < SY_R; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float dx = (float)(x + i) - A.cx - A.tx, dy = (float)(y + j) - A.cy - A.ty;
-            const float sx = A.i00 * dx + A.i01 * dy + A.cx, sy = A.i10 * dx + A.i11 * dy + A.cy;
-            const float fx = floorf(fminf(fmaxf(sx, -big), big)), fy = floorf(fminf(fmaxf(sy, -big), big));
-            x0[j][i] = (int)fx; y0[j][i] = (int)fy;
-            wx[j][i] = sx - fx; wy[j][i] = sy - fy;
-            fast = fast && x0[j][i] == x + i && wx[j][i] == 0.f;
-            if (j == 0) ymin = min(ymin, y0[0][i]);
-        }
-#pragma unroll
-    for (int j = 0; j < SY_R; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fast = fast && (unsigned)(y0[j][i] - j - ymin) <= 1u;
-    fast = fast && ymin >= 0 && ymin + SY_R + 1 < H;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float* pc = pin + c * HW;
-        float o[SY_R][4];
-        if (fast) {
-            float q[SY_R + 2][4];
-#pragma unroll
-            for (int r = 0; r < SY_R + 2; ++r) {
-                const float4 u = *reinterpret_cast<const float4*>(pc + (ymin + r) * W + x);
-                q[r][0] = u.x; q[r][1] = u.y; q[r][2] = u.z; q[r][3] = u.w;
-            }
-#pragma unroll
-            for (int j = 0; j < SY_R; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bool lo = y0[j][i] == ymin + j;
-                    const float a = lo ? q[j][i] : q[j + 1][i], cq = lo ? q[j + 1][i] : q[j + 2][i];
-                    o[j][i] = clamp01((1.f - wy[j][i]) * a + wy[j][i] * cq);
-                }
-        } else {
-#pragma unroll
-            for (int j = 0; j < SY_R; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    auto at = [&](int yy, int xx) -> float { return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? pc[yy * W + xx] : 0.0f; };
-                    const float wxx = wx[j][i], wyy = wy[j][i];
-                    const int xx = x0[j][i], yy = y0[j][i];
-                    o[j][i] = clamp01((1.f - wyy) * ((1.f - wxx) * at(yy, xx) + wxx * at(yy, xx + 1)) +
-                                      wyy * ((1.f - wxx) * at(yy + 1, xx) + wxx * at(yy + 1, xx + 1)));
-                }
-        }
-#pragma unroll
-        for (int j = 0; j < SY_R; ++j)
-            if (y + j < H) aadg_store_out(po + c * HW + (y + j) * W + x, make_float4(o[j][0], o[j][1], o[j][2], o[j][3]), STREAM);
-    }
-}
-
 // flips: 16 bytes per lane and plane row; grid (chunks, B*3)
 template <int FOP, bool STREAM>
 __global__ __launch_bounds__(TO_THREADS) void k_fop_flip(const float* __restrict__ in, float* __restrict__ out, int H, int W) {
@@ -946,14 +891,10 @@ int launch_warp(bool vec, bool stream_io, const float* in, float* out, const flo
         const dim3 g(point_chunks(H * W), B * 3);
         if (stream_io) hipLaunchKernelGGL((k_fop_flip<FOP, true>), g, dim3(TO_THREADS), 0, st, in, out, H, W);
         else hipLaunchKernelGGL((k_fop_flip<FOP, false>), g, dim3(TO_THREADS), 0, st, in, out, H, W);
-    } else if constexpr (FOP == AADG_FOP_SHEAR_Y) {
-        const dim3 g((W + 4 * SY_LX - 1) / (4 * SY_LX), (H + (TO_THREADS / SY_LX) * SY_R - 1) / ((TO_THREADS / SY_LX) * SY_R), B);
-        if (stream_io) hipLaunchKernelGGL(k_fop_shear_y_cols<true>, g, dim3(TO_THREADS), 0, st, in, out, mag, mag_n, H, W);
-        else hipLaunchKernelGGL(k_fop_shear_y_cols<false>, g, dim3(TO_THREADS), 0, st, in, out, mag, mag_n, H, W);
-    } else if constexpr (FOP == AADG_FOP_ROTATE) {
-        const dim3 g((W + ROT_T - 1) / ROT_T, (H + ROT_T - 1) / ROT_T, B);
-        if (stream_io) hipLaunchKernelGGL((k_fop_affine_tile<FOP, true>), g, dim3(TO_THREADS), 0, st, in, out, mag, mag_n, H, W);
-        else hipLaunchKernelGGL((k_fop_affine_tile<FOP, false>), g, dim3(TO_THREADS), 0, st, in, out, mag, mag_n, H, W);
+    } else if constexpr (FOP == AADG_FOP_ROTATE || FOP == AADG_FOP_SHEAR_Y) {
+        const dim3 g((unsigned)(((W + ROT_T - 1) / ROT_T) * ((H + ROT_T - 1) / ROT_T)) * (unsigned)B);
+        if (stream_io) hipLaunchKernelGGL((k_fop_affine_tile<FOP, true>), g, dim3(TO_THREADS), 0, st, in, out, mag, mag_n, H, W, B);
+        else hipLaunchKernelGGL((k_fop_affine_tile<FOP, false>), g, dim3(TO_THREADS), 0, st, in, out, mag, mag_n, H, W, B);
     } else {
         const dim3 g((W + 255) / 256, (H + 3) / 4, B);
         if (stream_io) hipLaunchKernelGGL((k_fop_warp_rows<FOP, true>), g, dim3(TO_THREADS), 0, st, in, out, mag, mag_n, H, W);
