@@ -1501,7 +1501,9 @@ _SHADOWS = {}          # id(weight) -> _Shadow
 # ANY optimizer also advances this epoch (a global post-step hook, installed with the first tracked model).
 _WEIGHTS_EPOCH = [0]
 _STEP_HOOK = []
-_OPT_OWNS = {}         # id(optimizer) -> does it hold a tracked weight (cleared whenever shadows are (re)built)
+_SHADOW_GEN = [0]      # advanced whenever a set of shadows is (re)built
+_OPT_OWNS = __import__('weakref').WeakKeyDictionary()   # optimizer -> (shadow generation, does it hold a tracked weight); keyed by the
+                                                        # object, not its id: ids are reused once an optimizer / a parameter has died
 
 
 def _install_step_hook():
@@ -1511,11 +1513,14 @@ def _install_step_hook():
         def bump(optimizer, args, kwargs):
             # only an optimizer that owns a tracked weight changes one (the discriminator's and the controller's steps run between the
             # segmentation model's forward and backward)
-            owns = _OPT_OWNS.get(id(optimizer))
-            if owns is None:
-                owns = any(id(p) in _SHADOWS for g in optimizer.param_groups for p in g['params'])
-                _OPT_OWNS[id(optimizer)] = owns
-            if owns:
+            ent = _OPT_OWNS.get(optimizer)
+            if ent is None or ent[0] != _SHADOW_GEN[0]:
+                def tracked(p):
+                    e = _SHADOWS.get(id(p))
+                    return e is not None and e.ref() is p
+                ent = (_SHADOW_GEN[0], any(tracked(p) for g in optimizer.param_groups for p in g['params']))
+                _OPT_OWNS[optimizer] = ent
+            if ent[1]:
                 _WEIGHTS_EPOCH[0] += 1
         _STEP_HOOK.append(register_optimizer_step_post_hook(bump))
 
@@ -1584,7 +1589,7 @@ class _WeightLayouts(object):
 
     def _build(self):
         import weakref
-        _OPT_OWNS.clear()
+        _SHADOW_GEN[0] += 1
         dev = self.entries[0][0].device
         items = (WlItem * len(self.entries))()
         tiles = []

@@ -76,3 +76,43 @@ def test_tracked_shadow_backward_after_weight_change_fails_loudly(hip):
         y2 = net(x)
     ref = F.conv2d(x.float(), (w0 * 0.5).bfloat16().float())
     assert (y2.float() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+
+
+def test_foreign_optimizer_steps_do_not_invalidate_shadows(hip):
+    """The discriminator's and the controller's optimizers step between the model's forward and backward.  Ownership of a tracked
+    weight is decided on the objects: neither a recycled optimizer id nor a parameter whose id once belonged to a tracked weight
+    (a stale table entry whose weak reference is dead) may turn a foreign optimizer's step into an invalidation."""
+    import gc
+    from aadg_amd import _lib
+    from aadg_amd.models.deeplab import Conv1x1
+    torch.manual_seed(4)
+    net = torch.nn.Sequential(Conv1x1(64, 64)).cuda()
+    assert _lib.track_bf16_weights(net, (Conv1x1,)) == 1
+    x = torch.randn(2, 64, 32, 32, device="cuda").bfloat16().requires_grad_(True)
+    other = torch.nn.Linear(8, 8).cuda()
+    # a stale entry under the id of a foreign parameter, as left behind by a dead tracked weight whose id was reused
+    dead = torch.nn.Parameter(torch.zeros(1, device="cuda"))
+    stale = _lib._Shadow()
+    stale.ref = __import__("weakref").ref(dead)
+    del dead
+    gc.collect()
+    _lib._SHADOWS[id(other.weight)] = stale
+    try:
+        for _ in range(3):                                      # fresh optimizer objects: ids get recycled
+            opt = torch.optim.Adam(other.parameters(), lr=1e-3)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = net(x)
+            other(torch.randn(4, 8, device="cuda")).sum().backward()
+            opt.step()                                          # between the tracked model's forward and backward
+            y.float().sum().backward()                          # must not raise
+            del opt
+            gc.collect()
+        own = torch.optim.SGD(net.parameters(), lr=0.1)         # the owner's step does invalidate
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = net(x)
+        net[0].weight.grad = torch.zeros_like(net[0].weight)
+        own.step()
+        with pytest.raises(_lib.AadgError):
+            y.float().sum().backward()
+    finally:
+        _lib._SHADOWS.pop(id(other.weight), None)

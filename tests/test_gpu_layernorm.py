@@ -45,7 +45,7 @@ def test_add_layer_norm_matches_float32_reference(hip, B, T, C, dtype, mode):
     else:
         torch.autograd.backward([sref, yref], [gs.float(), gy.float()])
     tol = 1e-5 if dtype == torch.float32 else 2 ** -7
-    scale = lambda t: max(1.0, float(t.abs().max()))                                  # noqa: E731
+    scale = lambda t: max(1.0, float(t.detach().abs().max()))                                  # noqa: E731
     assert (y.float() - yref).abs().max().item() <= tol * scale(yref)
     if r is not None:
         assert (s.float() - sref).abs().max().item() <= tol * scale(sref)
