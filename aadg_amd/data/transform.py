@@ -433,10 +433,16 @@ def fast_train_units(dataset, n_items):
         p._fast = f
     s0, s1 = sc.scale_range[0], sc.scale_range[1]
     K = _lib.MAX_OPS
-    # python's generator, one frame per draw instead of three: uniform(a, b) = a + (b - a) * random(), randint(a, b) =
-    # a + _randbelow(b - a + 1), choice(seq) = seq[_randbelow(len(seq))] (CPython random.py) -- the same stream, position by position
-    rnd, below = random.random, random._inst._randbelow
-    np_choice, np_uniform = np.random.choice, np.random.uniform
+    # python's generator without a frame per draw: uniform(a, b) = a + (b - a) * random(), randint(a, b) = a + _randbelow(b - a + 1),
+    # choice(seq) = seq[_randbelow(len(seq))], and _randbelow(n) itself (CPython random.py, _randbelow_with_getrandbits):
+    #     k = n.bit_length(); r = getrandbits(k); while r >= n: r = getrandbits(k)
+    # written out at its four call sites -- the same stream, position by position (tests/test_host_cpu.py compares the records and the
+    # generators' end states with the object path)
+    rnd, getbits = random.random, random._inst.getrandbits
+    assert random._inst._randbelow.__func__ is random.Random._randbelow_with_getrandbits
+    # numpy's legacy generator: choice(n, 1)[0] draws randint(0, n) (mtrand: `idx = self.randint(0, pop_size, size=size)`), the scalar call
+    # consumes the same words of the stream without building two arrays; uniform(low) = low + (1.0 - low) * random_sample()
+    np_randint, np_sample = np.random.randint, np.random.random_sample
     crop_h, crop_w = sc.crop.size
     crop_pad = sc.crop.padding
     ds = s1 - s0
@@ -448,33 +454,46 @@ def fast_train_units(dataset, n_items):
     farg = [[0.0] * K for _ in range(n)]
     rect = [[(0, 0, -1, -1)] * K for _ in range(n)]
     names, dcs = [], []
+    queues = [p.queue for p in policies]
+    nsub = [len(f) for f in fast]
+    ksub = [m.bit_length() for m in nsub]
+    n_code = tt.n
+    last_code = n_code - 1
+    wlow, hlow = 1.0 - W0, 1.0 - H0
     s = 0
     for _ in range(n_items):
         for d in range(D):
-            index = int(np_choice(per, 1)[0])                       # synthetic.py: one random image per source domain
+            index = int(np_randint(0, per))                         # synthetic.py: np.random.choice(per, 1)[0], one random image per source domain
             pidx = d * per + index
             names.append('synth_d%d_%04d' % (d, index))
             # -- DGMultiPolicy: per policy the CutMix-queue draw, the sub-policy draw, Cutout's two numpy draws
             base = S + s * M
             for j in range(M):
-                pol = policies[j]
-                q = pol.queue
+                q = queues[j]
                 q.append(None)
-                if len(q) > 10:
+                nq = len(q)
+                if nq > 10:
                     q.pop(0)
-                else:
-                    below(len(q))                                   # the CutMix-queue draw (its value is unused: data/policy.py:17-21)
-                fj = fast[j]
-                steps = fj[below(len(fj))]
+                else:                                               # the CutMix-queue draw (its value is unused: data/policy.py:17-21)
+                    kq = nq.bit_length()
+                    r = getbits(kq)
+                    while r >= nq:
+                        r = getbits(kq)
+                m, kq = nsub[j], ksub[j]                            # the sub-policy draw
+                r = getbits(kq)
+                while r >= m:
+                    r = getbits(kq)
                 row = base + j
                 src[row] = pidx
                 k = 0
                 oi, ii, fi, ri = op[row], iarg[row], farg[row], rect[row]
-                for st in steps:
+                for st in fast[j][r]:
                     if st[0] == 'cutout':
-                        x0 = np_uniform(W0)
-                        y0 = np_uniform(H0)
-                        st = (9, 0, 0.0, cutout_rect(W0, H0, st[1], x0, y0))
+                        # CutoutAbs (data/basic.py:153-163): np.random.uniform(w), np.random.uniform(h), then cutout_rect
+                        v = st[1]
+                        x0 = int(max(0, W0 + wlow * np_sample() - v / 2.))
+                        y0 = int(max(0, H0 + hlow * np_sample() - v / 2.))
+                        st = (9, 0, 0.0, (x0, y0, min(int(min(W0, x0 + v)), W0 - 1), min(int(min(H0, y0 + v)), H0 - 1)))
                     if k >= K:
                         raise RuntimeError("more than %d ops per sub-policy are not supported" % K)
                     oi[k], ii[k], fi[k], ri[k] = st
@@ -482,7 +501,8 @@ def fast_train_units(dataset, n_items):
                 n_ops[row] = k
             # -- DGRandomScaleCrop: the original first, then every augmented image (scale draw, then crop draw)
             src[s] = pidx
-            for row in [s] + list(range(base, base + M)):
+            row = s
+            for jj in range(M + 1):
                 w, h = W0, H0
                 if rnd() > 0.2:
                     w = int((s0 + ds * rnd()) * W0)
@@ -496,11 +516,31 @@ def fast_train_units(dataset, n_items):
                 if pw == crop_w and ph == crop_h:
                     x1 = y1 = 0
                 else:
-                    x1 = below(pw - crop_w + 1)
-                    y1 = below(ph - crop_h + 1)
+                    m = pw - crop_w + 1                             # random.randint(0, pw - crop_w)
+                    kq = m.bit_length()
+                    x1 = getbits(kq)
+                    while x1 >= m:
+                        x1 = getbits(kq)
+                    m = ph - crop_h + 1
+                    kq = m.bit_length()
+                    y1 = getbits(kq)
+                    while y1 >= m:
+                        y1 = getbits(kq)
                 geo[row] = (w, h, pad, x1, y1)
-            # -- ToTensor: the soft domain code
-            dcs.append(SoftLable(ToMultiLabel(d, tt.n)).astype(np.float32))
+                row = base + jj
+            # -- ToTensor: the soft domain code (SoftLable(ToMultiLabel(d, n)): the true class U[0.8, 1], the others share the rest)
+            code = [0.0] * n_code
+            used = 0.8 + rnd() * 0.2
+            code[d] = used
+            for i in range(n_code):
+                if i != d:
+                    if i == last_code:
+                        code[i] = 1 - used
+                    else:
+                        t = rnd() * (1 - used)
+                        code[i] = t
+                        used += t
+            dcs.append(code)
             s += 1
     units = np.zeros(n, dtype=_lib.UNIT_DTYPE)
     units['src'] = src
@@ -511,7 +551,7 @@ def fast_train_units(dataset, n_items):
     units['rect'] = rect
     g = np.asarray(geo, dtype=np.int64)
     units['scaled_w'], units['scaled_h'], units['pad'], units['crop_x'], units['crop_y'] = g[:, 0], g[:, 1], g[:, 2], g[:, 3], g[:, 4]
-    dc_single = np.stack(dcs)
+    dc_single = np.array(dcs, dtype=np.float64).astype(np.float32)
     return units, np.repeat(dc_single, M, axis=0), dc_single, names, M, nz.dataset_name
 
 
