@@ -30,6 +30,7 @@ EXPORTS = [
     "aadg_abi_version",
     "aadg_aug_u8_workspace_bytes", "aadg_aug_u8_forward", "aadg_aug_u8_forward_ex", "aadg_aug_u8_forward_ex2", "aadg_op_u8",
     "aadg_pool_histograms_u8",
+    "aadg_aug_u8_plan",
     "aadg_sinkhorn_workspace_bytes", "aadg_sinkhorn_divergence_f32", "aadg_sinkhorn_rewards_f32", "aadg_sinkhorn_rewards_norm_f32",
     "aadg_normalize_rewards_f32",
     "aadg_seg_loss_workspace_bytes", "aadg_seg_bce_dice_f32",
@@ -83,6 +84,8 @@ def load():
     lib.aadg_aug_u8_forward_ex2.argtypes = lib.aadg_aug_u8_forward_ex.argtypes + [_vp]
     lib.aadg_pool_histograms_u8.restype = _i
     lib.aadg_pool_histograms_u8.argtypes = [_vp, _i, _i, _i, _vp, _vp]
+    lib.aadg_aug_u8_plan.restype = _i
+    lib.aadg_aug_u8_plan.argtypes = [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]
     lib.aadg_op_u8.restype = _i
     lib.aadg_op_u8.argtypes = [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp]
     lib.aadg_sinkhorn_workspace_bytes.restype = _sz
@@ -422,8 +425,12 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
     P, Hs, Ws, _ = pool.shape
     if tuple(masks.shape) != (P, Hs, Ws):
         raise AadgError("masks shape must match pool")
-    max_ops = validate_units(units, P, Hs, Ws)
+    units = np.asarray(units)
+    if units.dtype != UNIT_DTYPE:
+        raise AadgError("units must have UNIT_DTYPE")
     N = units.shape[0]
+    if N == 0:
+        raise AadgError("empty unit list")
     K = 2 if dataset == DATASET_OPTIC else 1
     dev = pool.device
     if out_img is None:
@@ -432,33 +439,36 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
         out_lbl = torch.empty((N, K, crop, crop), dtype=torch.float32, device=dev)
     _require_cuda(out_img, out_lbl)
     # units: host records -> pinned staging -> async H2D on the launch stream (no host sync)
-    units = np.ascontiguousarray(units, dtype=UNIT_DTYPE)
+    units = np.ascontiguousarray(units)
     stage = _pinned_units(N)
     ready = _pinned.get("units_ready")
     if ready is not None:
         ready.synchronize()          # previous copy out of the staging buffer has completed
-    classes, stats_mask, order, (n_plain, n_sharp, n_generic, n_generic_sharp), stat_lists, late = launch_plan(units, Hs, Ws, crop)
-    nb_units = N * UNIT_DTYPE.itemsize                       # a multiple of 4: the int32 list behind it is aligned
+    nb_units = N * UNIT_DTYPE.itemsize                       # a multiple of 4: the int32 lists behind it are aligned
     host = stage[:N * _REC].numpy()
     host[:nb_units] = units.view(np.uint8).reshape(-1)
-    host[nb_units:nb_units + 4 * N] = order.view(np.uint8)
+    # validation + work lists (tile-class order, per-slot statistics lists, late list) by the library's host-side planner, written
+    # straight into the staging buffer behind the records: [order N][stat_units MAX_OPS x N][late N] int32
+    base = stage.data_ptr()
+    summary = (ctypes.c_int32 * (8 + MAX_OPS))()
+    rc = lib.aadg_aug_u8_plan(base, N, P, Hs, Ws, crop, base + nb_units, base + nb_units + 4 * N, base + nb_units + 4 * N * (1 + MAX_OPS), summary)
+    if rc != 0:
+        validate_units(units, P, Hs, Ws)                     # raises with the reason
+        _check(rc, "aadg_aug_u8_plan")
+    n_plain, n_sharp, n_generic, n_generic_sharp, n_late, classes, stats_mask, max_ops = summary[:8]
     d_units = torch.empty(N * _REC, dtype=torch.uint8, device=dev)
     lists = AugLists()
     lists.order = d_units.data_ptr() + nb_units
     lists.n_plain, lists.n_sharp, lists.n_generic, lists.n_generic_sharp = n_plain, n_sharp, n_generic, n_generic_sharp
-    for k, lst in enumerate(stat_lists):
-        off = nb_units + 4 * N * (1 + k)
-        host[off:off + 4 * lst.size] = lst.view(np.uint8)
-        lists.stat_units[k] = d_units.data_ptr() + off
-        lists.n_stat[k] = int(lst.size)
+    for k in range(MAX_OPS):
+        lists.stat_units[k] = d_units.data_ptr() + nb_units + 4 * N * (1 + k)
+        lists.n_stat[k] = summary[8 + k]
     if pool_hist is not None:
         if pool_hist.dtype != torch.int32 or tuple(pool_hist.shape) != (P, HIST_STRIDE) or not pool_hist.is_cuda:
             raise AadgError("pool_hist must be pool_histograms(pool): int32 [P, %d] on the device" % HIST_STRIDE)
         lists.pool_hist = pool_hist.data_ptr()
-        off = nb_units + 4 * N * (1 + MAX_OPS)
-        host[off:off + 4 * late.size] = late.view(np.uint8)
-        lists.late_units = d_units.data_ptr() + off
-        lists.n_late = int(late.size)
+        lists.late_units = d_units.data_ptr() + nb_units + 4 * N * (1 + MAX_OPS)
+        lists.n_late = n_late
     d_units.copy_(stage[:N * _REC], non_blocking=True)          # records + work lists: one H2D copy
     ready = torch.cuda.Event()
     ready.record()
@@ -469,7 +479,7 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
     if PROFILE_MIX is not None:
         live = np.arange(MAX_OPS)[None, :] < units["n_ops"][:, None]
         PROFILE_MIX.append({"units": int(N), "ops": int(live.sum()), "sharpness_ops": int(((units["op"] == 8) & live).sum()),
-                            "sharpness_units": int(n_sharp), "stat_ops": int(sum(l.size for l in stat_lists)), "late_units": int(late.size),
+                            "sharpness_units": int(n_sharp), "stat_ops": int(sum(summary[8:8 + MAX_OPS])), "late_units": int(n_late),
                             "upscaled": int(((units["scaled_w"] != Ws) | (units["scaled_h"] != Hs)).sum())})
     if PROFILE_EVENTS is not None:
         ev0, ev1 = PROFILE_EVENTS[0].cuda_event, PROFILE_EVENTS[1].cuda_event

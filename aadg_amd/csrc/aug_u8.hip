@@ -2186,6 +2186,75 @@ int forward_cached(const uint8_t* pool, const uint8_t* masks, const UnitRef& ur,
     return 0;
 }
 
+// Host-side planning of one aadg_aug_u8_forward_ex2 call (no GPU work): checks the unit records against what the kernels rely on and
+// derives the work lists of `aadg_aug_lists` from them -- the same rules as unit_flow() / stats_by_pushforward() above, restated on the
+// host records (aadg_amd/_lib.py: launch_plan is the Python statement of it; tests/test_abi_cpu.py compares the two).
+extern "C" int aadg_aug_u8_plan(const aadg_unit* units, int N, int P, int Hs, int Ws, int crop, int32_t* order, int32_t* stat_units,
+                                int32_t* late_units, int32_t* summary) {
+    if (units == nullptr || order == nullptr || stat_units == nullptr || late_units == nullptr || summary == nullptr) return AADG_E_BADARG;
+    if (N <= 0 || P <= 0 || Hs <= 0 || Ws <= 0 || crop <= 0) return AADG_E_BADARG;
+    const bool tiles_ok = !((Ws & 3) || (crop & 3));
+    int n_cls[5] = {0, 0, 0, 0, 0}, n_stat[AADG_MAX_OPS], n_late = 0, max_ops = 0, classes = 0, stats_mask = 0;
+    for (int k = 0; k < AADG_MAX_OPS; ++k) n_stat[k] = 0;
+    // pass 1: validation, class and statistics lists (late_units doubles as the per-unit class until the counting sort below)
+    for (int i = 0; i < N; ++i) {
+        const aadg_unit& u = units[i];
+        if (u.src < 0 || u.src >= P || u.n_ops < 0 || u.n_ops > AADG_MAX_OPS) return AADG_E_BADARG;
+        if (u.scaled_w < 1 || u.scaled_h < 1 || (long long)u.scaled_w * 3 < Ws || (long long)u.scaled_h * 3 < Hs) return AADG_E_BADARG;
+        int sharp = 0;
+        for (int k = 0; k < u.n_ops; ++k) {
+            const int op = u.op[k];
+            if (op < 0 || op >= AADG_OP_COUNT) return AADG_E_BADARG;
+            if (op == AADG_OP_CUTOUT && (u.rect[k][0] < 0 || u.rect[k][1] < 0 || u.rect[k][2] >= Ws || u.rect[k][3] >= Hs)) return AADG_E_BADARG;
+            if (op == AADG_OP_POSTERIZE && (u.iarg[k] < 0 || u.iarg[k] > 8)) return AADG_E_BADARG;
+            if (op == AADG_OP_SHARPNESS && u.farg[k] != 1.0f) ++sharp;
+        }
+        if (u.n_ops > max_ops) max_ops = u.n_ops;
+        const bool ok = tiles_ok && sharp <= MAX_SHARP;
+        const bool up = ok && u.scaled_w >= Ws && u.scaled_h >= Hs;
+        const bool generic = ok && !up && 2 * (long long)u.scaled_w >= Ws && 2 * (long long)u.scaled_h >= Hs;
+        const int cls = up ? (sharp == 0 ? 0 : 1) : generic ? (sharp == 0 ? 2 : 3) : 4;
+        classes |= up ? HINT_FUSED : generic ? HINT_GENERIC : HINT_STAGED;
+        ++n_cls[cls];
+        // statistics: a pixel pass per op that needs the image's statistics, unless the histogram can be pushed forward from the raw
+        // image's (AutoContrast / Equalize in a slot k >= 1 behind per-channel byte maps only, tile-flow units); the raw histogram is
+        // then the source: slot 0 gets the pass
+        bool prefix_lut = true, any_push = false, late = false;
+        bool pass[AADG_MAX_OPS];
+        for (int k = 0; k < AADG_MAX_OPS; ++k) {
+            const bool live = k < u.n_ops;
+            const int op = u.op[k];
+            const bool needs = live && (op == AADG_OP_AUTOCONTRAST || op == AADG_OP_EQUALIZE || op == AADG_OP_CONTRAST);
+            const bool push = k >= 1 && live && (op == AADG_OP_AUTOCONTRAST || op == AADG_OP_EQUALIZE) && prefix_lut && (up || generic);
+            pass[k] = needs && !push;
+            any_push = any_push || push;
+            prefix_lut = prefix_lut && (op == AADG_OP_AUTOCONTRAST || op == AADG_OP_INVERT || op == AADG_OP_EQUALIZE || op == AADG_OP_SOLARIZE ||
+                                        op == AADG_OP_POSTERIZE || op == AADG_OP_CONTRAST || op == AADG_OP_BRIGHTNESS);
+        }
+        pass[0] = pass[0] || any_push;
+        for (int k = 0; k < AADG_MAX_OPS; ++k)
+            if (pass[k]) {
+                stat_units[(size_t)k * N + n_stat[k]++] = i;
+                stats_mask |= 1 << k;
+                late = late || k >= 1;
+            }
+        late_units[i] = cls | (late ? 8 : 0);
+    }
+    // pass 2: stable counting sort by class; the late list in place (its write position never passes the read position)
+    int off[5];
+    off[0] = 0;
+    for (int c = 1; c < 5; ++c) off[c] = off[c - 1] + n_cls[c - 1];
+    for (int i = 0; i < N; ++i) {
+        const int v = late_units[i];
+        order[off[v & 7]++] = i;
+        if (v & 8) late_units[n_late++] = i;
+    }
+    summary[0] = n_cls[0]; summary[1] = n_cls[1]; summary[2] = n_cls[2] + n_cls[3]; summary[3] = n_cls[3];
+    summary[4] = n_late; summary[5] = classes; summary[6] = stats_mask; summary[7] = max_ops;
+    for (int k = 0; k < AADG_MAX_OPS; ++k) summary[8 + k] = n_stat[k];
+    return 0;
+}
+
 extern "C" int aadg_pool_histograms_u8(const uint8_t* pool, int P, int Hs, int Ws, uint32_t* hist, void* stream) {
     if (pool == nullptr || hist == nullptr || P <= 0 || Hs <= 0 || Ws <= 0) return AADG_E_BADARG;
     hipStream_t st = (hipStream_t)stream;

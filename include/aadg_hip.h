@@ -139,6 +139,15 @@ int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks, int P, in
                             int classes_hint, int stats_mask_hint, void* ev_before_final, void* ev_after_final,
                             const aadg_aug_lists* lists);
 
+/* Host-side planning of one aadg_aug_u8_forward_ex2 call: validates the unit records (AADG_E_BADARG: source index, op count / ids,
+ * scale factor below 1/3, Cutout box not clipped to the image, Posterize bits) and fills the work lists `aadg_aug_lists` carries -- no GPU
+ * work, host pointers (the caller copies the lists to the device next to the records).
+ *   order [N]: unit indices by tile class;  stat_units [AADG_MAX_OPS][N]: per op slot the units that need a statistics pass;
+ *   late_units [N];  summary [8 + AADG_MAX_OPS] = n_plain, n_sharp, n_generic, n_generic_sharp, n_late, classes_hint, stats_mask_hint,
+ *   max_ops, n_stat[0 .. AADG_MAX_OPS).  (The reference does this work implicitly, op by op, in PIL: data/policy.py:45-61.) */
+int aadg_aug_u8_plan(const aadg_unit* units, int N, int P, int Hs, int Ws, int crop, int32_t* order, int32_t* stat_units,
+                     int32_t* late_units, int32_t* summary);
+
 /* One registry op on one image, replaces fn(img, mask, v) of augment_list()
  * (data/basic.py:70-120,137-167) for uint8 HWC tensors.  ws >= aadg_aug_u8_workspace_bytes(1,H,W,0);
  * in != out. */

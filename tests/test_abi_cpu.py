@@ -192,3 +192,63 @@ def test_round3_entry_points_validate_arguments():
     assert lib.aadg_fop_workspace_bytes(144, 512, 512) > 0
     assert lib.aadg_fop_f32(_lib.FOP["contrast"], one, one, one, 1, z, z, 2, 3, 8, 8, z, 0, z) == -1                  # statistics op without workspace
     assert lib.aadg_fop_f32(_lib.FOP["contrast"], one, one, one, 1, z, z, 2, 3, 8, 8, one, 8, z) == -2                # ... with a too small one
+
+
+def test_host_planner_matches_python_statement():
+    """aadg_aug_u8_plan (host code of the library: validation + work lists of one augmentation call) against the Python statement of the
+    same rules (_lib.launch_plan / validate_units) on random unit records of every flow, and its refusal of bad records."""
+    import ctypes
+    import numpy as np
+    from aadg_amd import _lib
+    from helpers import random_units
+    lib = _lib.load()
+    K = _lib.MAX_OPS
+    rs = np.random.RandomState(11)
+    for (H, crop, sr, L, N) in ((64, 64, (1.0, 1.5), 2, 97), (96, 64, (0.5, 2.0), 4, 160), (128, 96, (0.34, 0.6), 3, 50), (33, 31, (1.0, 1.5), 2, 40),
+                                (64, 64, (0.5, 2.0), 4, 1)):
+        P = 7
+        units = random_units(rs, N, P, H, H, crop, sr, L=L)
+        # more Sharpness (stencil classes) and statistics ops in late slots than the uniform op draw gives
+        for i in range(0, N, 4):
+            u = units[i]
+            for k in range(int(u["n_ops"])):
+                if rs.rand() < 0.5:
+                    u["op"][k] = 8
+                    u["farg"][k] = np.float32(1.0 if rs.rand() < 0.2 else 1.5)
+        cont = np.ascontiguousarray(units)
+        order = np.full(N, -1, np.int32)
+        stat = np.full((K, N), -1, np.int32)
+        late = np.full(N, -1, np.int32)
+        summary = (ctypes.c_int32 * (8 + K))()
+        rc = lib.aadg_aug_u8_plan(cont.ctypes.data, N, P, H, H, crop, order.ctypes.data, stat.ctypes.data, late.ctypes.data, summary)
+        assert rc == 0
+        classes, stats_mask, want_order, counts, stat_lists, want_late = _lib.launch_plan(units, H, H, crop)
+        assert tuple(summary[:4]) == tuple(counts) and summary[5] == classes and summary[6] == stats_mask
+        assert summary[7] == _lib.validate_units(units, P, H, H)
+        assert np.array_equal(order, want_order)
+        for k in range(K):
+            assert summary[8 + k] == stat_lists[k].size and np.array_equal(stat[k, :stat_lists[k].size], stat_lists[k])
+        assert summary[4] == want_late.size and np.array_equal(late[:want_late.size], want_late)
+
+    def refused(mutate):
+        units = random_units(np.random.RandomState(3), 8, 4, 64, 64, 64, (1.0, 1.5))
+        units["n_ops"][:] = 2
+        mutate(units)
+        cont = np.ascontiguousarray(units)
+        bufs = [np.zeros(8 * (K if i == 1 else 1), np.int32) for i in range(3)]
+        rc = lib.aadg_aug_u8_plan(cont.ctypes.data, 8, 4, 64, 64, 64, bufs[0].ctypes.data, bufs[1].ctypes.data, bufs[2].ctypes.data,
+                                  (ctypes.c_int32 * (8 + K))())
+        with pytest.raises(_lib.AadgError):
+            _lib.validate_units(units, 4, 64, 64)
+        return rc
+    bad = _lib.load().aadg_aug_u8_plan(None, 1, 1, 8, 8, 8, None, None, None, None)
+    assert bad != 0
+
+    def src(u): u["src"][3] = 4
+    def nops(u): u["n_ops"][2] = K + 1
+    def opid(u): u["op"][5][1] = 10
+    def scale(u): u["scaled_w"][1] = 21
+    def rect(u): u["op"][0][0] = 9; u["rect"][0][0] = (0, 0, 64, 10)
+    def bits(u): u["op"][6][1] = 4; u["iarg"][6][1] = 9
+    for m in (src, nops, opid, scale, rect, bits):
+        assert refused(m) != 0, m.__name__
