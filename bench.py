@@ -942,7 +942,7 @@ def main():
                                "embedding_all_gather": 1, "policy_broadcast": 2,
                                "gradient_all_reduce": "DDP buckets (segmentation model + discriminator), overlapped with backward"},
                            "note": "BatchNorm: one float64 all-reduce of [2C + 1] / [2C] sums per layer and direction; the five independent "
-                                   "layers of the ASPP head share one.  Every other layer's all-reduce lies on a dependency chain "
+                                   "layers of the ASPP head share one, a bottleneck's projection-shortcut layer travels with the main path's last one.  Every other layer's all-reduce lies on a dependency chain "
                                    "(statistics -> normalise -> next layer's input), so the count cannot drop further without changing "
                                    "what is normalised"}},
             "roofline": roof,
