@@ -1017,21 +1017,29 @@ __global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ 
     const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
     const uint32_t* cur = build_patch<6, 1>(un, stage, src, Hs, Ws, r_lo, r_hi, c_lo, c_hi, A, B, lut, lut_stage_stride, u, sl);
     const int pw = c_hi - c_lo, rw = cx1 - cx0, n = (ry1 - ry0) * rw;
-    unsigned long long lsum = 0;
+    uint32_t lsum32 = 0;                                  // <= 64 pixels per thread x 255
     // Neighbouring pixels of a smooth image fall into the same bins, and LDS atomics of one wave on one address serialise: the
     // lanes of a wave therefore take pixels 97 positions apart (97 is prime: a bijection of [0, n) unless 97 divides n)
     // (index arithmetic without a division per pixel: the running index advances by (256 * stride) mod n; a full-width tile splits it by a shift)
     const int stride = (n % 97) ? 97 : 1;
     const int step = (int)((256u * (unsigned)stride) % (unsigned)n);
     int i = (int)(((unsigned)tid * (unsigned)stride) % (unsigned)n);
-    for (int i0 = tid; i0 < n; i0 += 256, i += step, i -= i >= n ? n : 0) {
-        const int row = rw == 256 ? i >> 8 : i / rw, col = i - row * rw;
-        const uint32_t p = cur[(ry0 + row - r_lo) * pw + (cx0 + col - c_lo)];
+    const uint32_t* origin = cur + (ry0 - r_lo) * pw + (cx0 - c_lo);
+    auto count = [&](uint32_t p) {
         const uint32_t r = p & 255, g = (p >> 8) & 255, b = (p >> 16) & 255;
         atomicAdd(&sh[r], 1u); atomicAdd(&sh[256 + g], 1u); atomicAdd(&sh[512 + b], 1u);
-        lsum += rgb2l(r, g, b);
+        lsum32 += rgb2l(r, g, b);
+    };
+    if (rw == 256) {                                      // uniform: full-width tile, the index splits by a shift
+#pragma unroll 4
+        for (int i0 = tid; i0 < n; i0 += 256, i += step, i -= i >= n ? n : 0) count(origin[(i >> 8) * pw + (i & 255)]);
+    } else {
+        for (int i0 = tid; i0 < n; i0 += 256, i += step, i -= i >= n ? n : 0) {
+            const int row = i / rw;
+            count(origin[row * pw + (i - row * rw)]);
+        }
     }
-    lsum = wave_sum(lsum);
+    unsigned long long lsum = wave_sum((unsigned long long)lsum32);
     __syncthreads();
     uint32_t* gh = hist + (size_t)u * HIST_STRIDE;
     for (int i = tid; i < 768; i += 256) if (sh[i]) atomicAdd(&gh[i], sh[i]);
