@@ -186,15 +186,39 @@ __device__ __forceinline__ void sample_prologue(const Part* __restrict__ part, i
     (void)nplanes;
 }
 
+// sample_pairing reads every image twice: as itself and as the partner of the sample that perm maps onto it.  Walking the samples along
+// the cycles of perm (b, perm[b], perm[perm[b]], ...) makes the image fetched as a partner at one step the "self" image of the next, so the second
+// read finds it in the Infinity Cache instead of HBM (the batch is larger than the cache: in index order half of the second reads miss).
+// One workgroup; perm staged in LDS; every sample appears exactly once whatever perm holds (out-of-range entries end a chain).
+constexpr int PAIR_ORDER_MAX = 8192;
+__global__ __launch_bounds__(256) void k_fop_pair_order(const int* __restrict__ perm, int B, int* __restrict__ order) {
+    __shared__ int sp[PAIR_ORDER_MAX];
+    __shared__ unsigned char seen[PAIR_ORDER_MAX];
+    for (int i = threadIdx.x; i < B; i += 256) { sp[i] = perm[i]; seen[i] = 0; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int n = 0;
+    for (int start = 0; start < B; ++start) {
+        int b = start;
+        while (b >= 0 && b < B && !seen[b]) {
+            seen[b] = 1;
+            order[n++] = b;
+            b = sp[b];
+        }
+    }
+}
+
 // ---- pointwise / LUT apply kernel: grid (chunks, B); a lane owns 4 consecutive pixels x 3 planes, UNR groups in flight ------------
 template <int FOP, bool STREAM>
 __global__ __launch_bounds__(TO_THREADS) void k_fop_point(const float* __restrict__ in, float* __restrict__ out,
                                                           const float* __restrict__ mag, int mag_n, const int* __restrict__ perm,
                                                           const Part* __restrict__ part, int chunks, const unsigned int* __restrict__ hist,
-                                                          int HW) {
+                                                          int HW, const int* __restrict__ order) {
     constexpr bool STAT = FOP == AADG_FOP_CONTRAST || FOP == AADG_FOP_AUTO_CONTRAST || FOP == AADG_FOP_EQUALIZE;
-    // statistics ops: opposite sample order to the statistics pass (its last samples are the ones the caches still hold)
-    const int b = STAT ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+    // statistics ops: opposite sample order to the statistics pass (its last samples are the ones the caches still hold);
+    // sample_pairing: along the cycles of perm (k_fop_pair_order)
+    const int b = STAT ? (int)gridDim.y - 1 - (int)blockIdx.y
+                       : (FOP == AADG_FOP_SAMPLE_PAIRING && order != nullptr) ? order[blockIdx.y] : (int)blockIdx.y;
     const int nplanes = gridDim.y * 3;
     const size_t base = (size_t)b * 3 * HW;
     const float m = mag ? mag[mag_n == 1 ? 0 : b] : 0.0f;
@@ -214,7 +238,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_fop_point(const float* __restric
             if (g < ngroups) {
                 const int i0 = g << 2;
                 // STAT ops re-read what the statistics pass has just read: ordinary loads (cache hits wanted); everything else is read once
-                if (STREAM && !STAT) { a[u] = aadg_load_stream(pin + i0); c[u] = aadg_load_stream(pin + HW + i0); d[u] = aadg_load_stream(pin + 2 * HW + i0); }
+                if (STREAM && !STAT && FOP != AADG_FOP_SAMPLE_PAIRING) { a[u] = aadg_load_stream(pin + i0); c[u] = aadg_load_stream(pin + HW + i0); d[u] = aadg_load_stream(pin + 2 * HW + i0); }
                 else {
                     a[u] = *reinterpret_cast<const float4*>(pin + i0); c[u] = *reinterpret_cast<const float4*>(pin + HW + i0);
                     d[u] = *reinterpret_cast<const float4*>(pin + 2 * HW + i0);
@@ -852,11 +876,15 @@ constexpr size_t FOP_STREAM_BYTES = (size_t)128 << 20;     // batches beyond thi
 
 template <int FOP>
 int launch_point(bool vec, bool stream_io, const float* in, float* out, const float* mag, int mag_n, const int32_t* perm, const Part* part,
-                 int chunks, const unsigned int* hist, int B, int HW, hipStream_t st) {
+                 int chunks, const unsigned int* hist, int B, int HW, hipStream_t st, int* order = nullptr) {
     const dim3 g(point_chunks(HW), B);
+    if (order != nullptr) {
+        hipLaunchKernelGGL(k_fop_pair_order, dim3(1), dim3(256), 0, st, perm, B, order);
+        AADG_LAUNCH_CHECK();
+    }
     if (!vec) hipLaunchKernelGGL(k_fop_point_any<FOP>, g, dim3(TO_THREADS), 0, st, in, out, mag, mag_n, perm, part, chunks, hist, HW);
-    else if (stream_io) hipLaunchKernelGGL((k_fop_point<FOP, true>), g, dim3(TO_THREADS), 0, st, in, out, mag, mag_n, perm, part, chunks, hist, HW);
-    else hipLaunchKernelGGL((k_fop_point<FOP, false>), g, dim3(TO_THREADS), 0, st, in, out, mag, mag_n, perm, part, chunks, hist, HW);
+    else if (stream_io) hipLaunchKernelGGL((k_fop_point<FOP, true>), g, dim3(TO_THREADS), 0, st, in, out, mag, mag_n, perm, part, chunks, hist, HW, order);
+    else hipLaunchKernelGGL((k_fop_point<FOP, false>), g, dim3(TO_THREADS), 0, st, in, out, mag, mag_n, perm, part, chunks, hist, HW, order);
     AADG_LAUNCH_CHECK();
     return 0;
 }
@@ -977,7 +1005,11 @@ extern "C" int aadg_fop_f32(int fop, const float* in, float* out, const float* m
         FOP_CASE(AADG_FOP_SATURATE, launch_point<AADG_FOP_SATURATE>(vec_px, stream_io, in, out, mag, mag_n, perm, part, chunks, hist, B, HW, st));
         FOP_CASE(AADG_FOP_BRIGHTNESS, launch_point<AADG_FOP_BRIGHTNESS>(vec_px, stream_io, in, out, mag, mag_n, perm, part, chunks, hist, B, HW, st));
         FOP_CASE(AADG_FOP_HUE, launch_point<AADG_FOP_HUE>(vec_px, stream_io, in, out, mag, mag_n, perm, part, chunks, hist, B, HW, st));
-        FOP_CASE(AADG_FOP_SAMPLE_PAIRING, launch_point<AADG_FOP_SAMPLE_PAIRING>(vec_px, stream_io, in, out, mag, mag_n, perm, part, chunks, hist, B, HW, st));
+        case AADG_FOP_SAMPLE_PAIRING: {
+            // with a workspace (>= 4 B bytes) the samples are walked along the cycles of perm; without one, in index order
+            int* order = (vec_px && stream_io && ws != nullptr && ws_bytes >= (size_t)B * 4 && B <= PAIR_ORDER_MAX) ? reinterpret_cast<int*>(ws) : nullptr;
+            return launch_point<AADG_FOP_SAMPLE_PAIRING>(vec_px, stream_io, in, out, mag, mag_n, perm, part, chunks, hist, B, HW, st, order);
+        }
         default: return launch_point<AADG_FOP_EQUALIZE>(vec_px, stream_io, in, out, mag, mag_n, perm, part, chunks, hist, B, HW, st);
     }
 #undef FOP_CASE

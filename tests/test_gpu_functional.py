@@ -223,3 +223,27 @@ def test_stencil_strips_vs_torch_conv(hip, shape):
     got = _lib.fop("gaussian_blur3x3", x, torch.tensor([0.9], device="cuda"), kernel=g)
     assert torch.allclose(got, gb, atol=1e-5)
     assert torch.equal(got, _lib.fop("gaussian_blur3x3", _unaligned_copy(x), torch.tensor([0.9], device="cuda"), kernel=g))
+
+
+def test_sample_pairing_walks_the_cycles_of_perm(hip):
+    """Batches beyond the streaming threshold (128 MB) take sample_pairing along the cycles of perm (k_fop_pair_order: the partner image of
+    one step is the self image of the next, found in the Infinity Cache).  The result must be what the index-order path gives: every
+    output sample equals the op on the two-image batch [x[b], x[perm[b]]] (small batch: plain order) -- for a permutation with several
+    cycles and fixed points, and for a `perm` that is not a permutation."""
+    torch.manual_seed(9)
+    B, H = 48, 512                                              # 48 x 3 x 512 x 512 x 4 B = 151 MB
+    x = torch.rand(B, 3, H, H, device="cuda")
+    mag = torch.rand(B, device="cuda") * 0.4
+    swap = torch.tensor([1, 0], device="cuda", dtype=torch.int32)
+    perms = [torch.randperm(B, device="cuda").to(torch.int32)]
+    p = torch.arange(B, device="cuda", dtype=torch.int32)
+    p[:10] = torch.roll(p[:10], 1)                              # one 10-cycle, a 3-cycle, fixed points elsewhere
+    p[20:23] = torch.roll(p[20:23], -1)
+    perms.append(p)
+    perms.append(torch.randint(0, B, (B,), device="cuda", dtype=torch.int32))      # repeated partners
+    for perm in perms:
+        got = hip.fop("sample_pairing", x, mag, perm=perm)
+        for b in (0, 1, 5, 9, 21, 30, B - 1):
+            pair = torch.stack([x[b], x[int(perm[b])]])
+            want = hip.fop("sample_pairing", pair, mag[b].repeat(2), perm=swap)[0]
+            assert torch.equal(got[b], want), b
