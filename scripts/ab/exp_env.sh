@@ -1,4 +1,4 @@
-# rvs1024 leg with the current library under different environment settings: bash scripts/exp_env.sh VAR v1 v2 ...
+# rvs1024 leg with the current library under different environment settings: bash scripts/ab/exp_env.sh VAR v1 v2 ...
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/exp
 VAR=$1; shift

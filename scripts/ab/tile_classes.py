@@ -2,7 +2,7 @@
 whole augmentation call timed with events; GB/s over the algorithmic bytes (source + mask once, 4 float planes out: vessel, K = 1)."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from aadg_amd import _lib
 from helpers import random_units, synth_pool
