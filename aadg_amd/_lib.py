@@ -234,7 +234,7 @@ def load():
     lib.aadg_upsample_sum_backward_all.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.aadg_embed_prologue_norm_f32.restype = _i
     lib.aadg_embed_prologue_norm_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]
-    if lib.aadg_abi_version() != 5:
+    if lib.aadg_abi_version() != 6:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AADG_ABI_VERSION 5
+#define AADG_ABI_VERSION 6
 #define AADG_MAX_OPS 4
 
 #define AADG_E_BADARG (-1)
@@ -139,7 +139,7 @@ int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks, int P, in
                             int classes_hint, int stats_mask_hint, void* ev_before_final, void* ev_after_final,
                             const aadg_aug_lists* lists);
 
-/* Host-side planning of one aadg_aug_u8_forward_ex2 call: validates the unit records (AADG_E_BADARG: source index, op count / ids,
+/* (ABI 6) Host-side planning of one aadg_aug_u8_forward_ex2 call: validates the unit records (AADG_E_BADARG: source index, op count / ids,
  * scale factor below 1/3, Cutout box not clipped to the image, Posterize bits) and fills the work lists `aadg_aug_lists` carries -- no GPU
  * work, host pointers (the caller copies the lists to the device next to the records).
  *   order [N]: unit indices by tile class;  stat_units [AADG_MAX_OPS][N]: per op slot the units that need a statistics pass;
