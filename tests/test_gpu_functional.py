@@ -247,3 +247,17 @@ def test_sample_pairing_walks_the_cycles_of_perm(hip):
             pair = torch.stack([x[b], x[int(perm[b])]])
             want = hip.fop("sample_pairing", pair, mag[b].repeat(2), perm=swap)[0]
             assert torch.equal(got[b], want), b
+
+
+def test_tile_kernel_image_major_numbering(hip):
+    """rotate / shear_y number their tile workgroups image-major per XCD for the first 8 * (B // 8) images and in the plain order for the
+    rest: B = 11 exercises both, B = 16 only the first -- against the one-pixel-per-lane kernels (same arithmetic, plain grid), with
+    per-sample magnitudes so that a tile mapped to the wrong image cannot go unnoticed."""
+    from aadg_amd import _lib
+    torch.manual_seed(6)
+    for B in (11, 16):
+        x = torch.rand(B, 3, 96, 136, device="cuda")
+        xu = _unaligned_copy(x)
+        for name, top in (("rotate", 30.0), ("shear_y", 0.3)):
+            mag = torch.linspace(-1.0, 1.0, B, device="cuda") * top
+            assert torch.equal(_lib.fop(name, x, mag), _lib.fop(name, xu, mag)), (name, B)
