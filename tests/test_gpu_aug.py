@@ -373,3 +373,36 @@ def test_bench_batch_rvs_1024_56_units_vs_oracle(hip, oracle):
     a_img, a_lbl = hip.aug_u8_forward(pool.images, pool.masks, units, 1024, ds, pool_hist=pool.histograms())
     assert np.array_equal(a_img[torch.from_numpy(sel).cuda()].cpu().numpy(), want_img)
     assert np.array_equal(a_lbl[torch.from_numpy(sel).cuda()].cpu().numpy(), want_lbl)
+
+
+def test_tap_class_boundaries_vs_oracle(hip, oracle):
+    """Round 3: the down-scaling passes use 3 / 4 / 5 resampling taps by scale (csrc/aug_u8.hip: axis_taps).  Every size around the class
+    boundaries of a 96-pixel axis -- 3 w > 2 W (65 | 64), 2 w > W (49 | 48: exactly half keeps Pillow's five slots), the unscaled and the
+    up-scaled axis -- on either axis, with and without a Sharpness stencil in front, against the oracle bit for bit."""
+    from aadg_amd._lib import UNIT_DTYPE
+    rs = np.random.RandomState(21)
+    H = W = crop = 96
+    P = 4
+    imgs, msks = synth_pool(rs, P, H, W, vessel=True)
+    sizes = [48, 49, 50, 63, 64, 65, 66, 80, 95, 96, 97, 130, 192]
+    recs = []
+    for i, (w, h) in enumerate([(a, b) for a in sizes for b in sizes if min(a, b) < 96]):
+        u = np.zeros((), UNIT_DTYPE)
+        u["rect"][:, 2:] = -1
+        u["src"] = i % P
+        if i % 3 == 1:
+            u["n_ops"] = 1; u["op"][0] = 8; u["farg"][0] = np.float32(1.6)
+        elif i % 3 == 2:
+            u["n_ops"] = 2; u["op"][0] = 7; u["farg"][0] = np.float32(1.3); u["op"][1] = 8; u["farg"][1] = np.float32(0.4)
+        u["scaled_w"], u["scaled_h"] = w, h
+        pad = max((crop - w) // 2 + 5, (crop - h) // 2 + 5) if (w < crop or h < crop) else 0
+        u["pad"] = pad
+        u["crop_x"] = rs.randint(0, w + 2 * pad - crop + 1)
+        u["crop_y"] = rs.randint(0, h + 2 * pad - crop + 1)
+        recs.append(u)
+    units = np.array(recs, dtype=UNIT_DTYPE)
+    got_img, got_lbl = hip.aug_u8_forward(torch.from_numpy(imgs).cuda(), torch.from_numpy(msks).cuda(), units, crop, 1)
+    want_img, want_lbl = oracle.aug_units(imgs, msks, units, crop, 1)
+    bad = [i for i in range(len(units)) if not np.array_equal(got_img[i].cpu().numpy(), want_img[i])]
+    assert not bad, [(int(units[i]["scaled_w"]), int(units[i]["scaled_h"])) for i in bad[:8]]
+    assert np.array_equal(got_lbl.cpu().numpy(), want_lbl)
