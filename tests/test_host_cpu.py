@@ -289,3 +289,21 @@ def test_fast_draw_path_is_for_the_synthetic_dataset_only():
         phase = 'train'
         transforms = None
     assert T.fast_train_units(Other(), 2) is None
+
+
+def test_pillow_tap_count_bound_behind_axis_taps():
+    """csrc/aug_u8.hip: axis_taps gives the down-scaling passes 3 taps while 3 out > 2 in, 4 while 2 out > in, else Pillow's 5 slots.
+    Pillow's precompute_coeffs (Resample.c) uses xmax - xmin = int(c + s + 0.5) - int(c - s + 0.5) coefficients per output (clipped to the
+    image), in double arithmetic; checked here for every (in, out) with in <= 300 and for the bench sizes."""
+    import numpy as np
+    ins = list(range(8, 301)) + [512, 768, 1000, 1024]
+    for n_in in ins:
+        for n_out in range((n_in + 1) // 2, n_in):
+            scale = n_in / n_out
+            support = 1.0 * max(scale, 1.0)
+            c = (np.arange(n_out, dtype=np.float64) + 0.5) * scale
+            xmin = np.maximum((c - support + 0.5).astype(np.int64), 0)
+            xmax = np.minimum((c + support + 0.5).astype(np.int64), n_in)
+            taps = int((xmax - xmin).max())
+            bound = 3 if 3 * n_out > 2 * n_in else (4 if 2 * n_out > n_in else 5)
+            assert taps <= bound, (n_in, n_out, taps, bound)
