@@ -846,7 +846,8 @@ def _bn_prepare_grads(grads, x, has_res):
 
 
 # ---- synchronised statistics (data-parallel ranks): the all-reduce sits between the statistics and the elementwise kernels ----
-BN_SYNC_REDUCE = None      # callable(float64 device tensor) -> None: in-place SUM over the ranks; None = torch.distributed.all_reduce
+BN_SYNC_REDUCE = None      # callable(float64 device tensor) -> None: in-place SUM over the ranks; None = all-reduce on the small-collectives
+                           # process group (aadg_amd/distributed.py: small_group -- never queued behind a DDP gradient bucket)
 
 
 BN_SYNC_COLLECTIVES = [0]  # all-reduces issued by the BatchNorm layers since the counter was last cleared (bench.py: collectives_per_step)
@@ -856,8 +857,8 @@ def _bn_sync_reduce(t):
     BN_SYNC_COLLECTIVES[0] += 1
     if BN_SYNC_REDUCE is not None:
         return BN_SYNC_REDUCE(t)
-    import torch.distributed as dist
-    dist.all_reduce(t)
+    from . import distributed as adist
+    adist.small_all_reduce(t, kind="batchnorm_statistics_all_reduce")
 
 
 class _SyncBatchNormAct(torch.autograd.Function):

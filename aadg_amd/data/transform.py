@@ -310,15 +310,16 @@ def collect_refs(batch, nested):
     return batch, refs, M
 
 
-_ROW_SHARD = (0, 1, 'unit')   # (rank, world, placement law): which collate rows this process materialises
+_ROW_SHARD = (0, 1, 'unit', False)   # (rank, world, placement law, force): which collate rows this process materialises
 _PLANS = {}
 
 
-def set_row_shard(rank, world_size, law='unit'):
+def set_row_shard(rank, world_size, law='unit', force=False):
     """Multi-GPU: every rank draws the SAME batch plan (same seeds -> same draws, no communication) but
-    materialises only the rows of its (domain, policy) units (aadg_amd/distributed.py: RowPlan)."""
+    materialises only the rows of its (domain, policy) units (aadg_amd/distributed.py: RowPlan).  `force`: a one-rank job
+    takes the sharded code path too (bench.py --force_dist)."""
     global _ROW_SHARD
-    _ROW_SHARD = (int(rank), int(world_size), law)
+    _ROW_SHARD = (int(rank), int(world_size), law, bool(force))
 
 
 def row_plan(D, B, M):
@@ -336,8 +337,8 @@ def _collate(batch, nested):
     batch, refs, M = collect_refs(batch, nested)
     S = len(batch)
     new_batch = {'img_name': [b['img_name'] for b in batch]}
-    rank, world, _ = _ROW_SHARD
-    if M and world > 1:
+    rank, world, _, force = _ROW_SHARD
+    if M and (world > 1 or force):
         # training batch of a sharded job: this rank's slice of the un-augmented rows (warm-up epochs) and the rows of its
         # (domain, policy) units, in the plan's local order
         from ..distributed import shard_rows
@@ -566,9 +567,9 @@ def fast_train_collate(dataset, n_items):
     S = n_items * D
     pool = dataset.pool
     crop = int(dataset.transforms.transforms[1].crop.size[0])
-    rank, world, _ = _ROW_SHARD
+    rank, world, _, force = _ROW_SHARD
     plan = row_plan(D, n_items, M)
-    if world > 1:
+    if world > 1 or force:
         from ..distributed import shard_rows
         lo_s, hi_s = shard_rows(S, rank, world)
         sel = np.concatenate([np.arange(lo_s, hi_s), S + plan.rows])

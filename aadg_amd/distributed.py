@@ -44,7 +44,78 @@ def world():
     return (dist.get_rank(), dist.get_world_size()) if is_dist() else (0, 1)
 
 
-def all_gather(tensors):
+# ---- a communicator of its own for the small, latency-bound collectives -------------------------------------------------------
+# The BatchNorm statistics all-reduces (108 per step, <= 32 KB each, every one between two dependent kernels), the embedding
+# all-gather (<= 25 KB per rank) and the policy broadcasts would otherwise queue on the default process group's RCCL stream behind
+# whatever 25 MB DDP gradient bucket is in flight there (head-of-line blocking in the backward pass).  `small_group()` is a second
+# process group over the same ranks: with the nccl (= RCCL) backend it owns its own communicator and its own stream.  Created lazily
+# on first use, collectively (every rank takes the same code path); AADG_SMALL_GROUP=0 keeps everything on the default group.
+_SMALL = {"group": None, "made": False}
+
+
+def small_group():
+    """process group for the small collectives (None = the default group: not distributed, disabled, or creation failed)"""
+    import os
+    if not is_dist() or os.environ.get("AADG_SMALL_GROUP", "1") == "0":
+        return None
+    if not _SMALL["made"]:
+        _SMALL["made"] = True
+        try:
+            _SMALL["group"] = dist.new_group(ranks=list(range(dist.get_world_size())), backend=dist.get_backend())
+        except Exception as e:  # noqa: BLE001 -- an old backend without sub-groups: stay on the default group
+            import sys
+            print("aadg_amd.distributed: new_group failed (%r); small collectives stay on the default group" % (e,), file=sys.stderr)
+            _SMALL["group"] = None
+    return _SMALL["group"]
+
+
+def reset_groups():
+    """forget the cached group (after destroy_process_group; tests that re-initialise the process group in one interpreter)"""
+    _SMALL["group"], _SMALL["made"] = None, False
+
+
+class _CollectiveTimer(object):
+    """GPU-side duration of the small collectives (HIP events on the issuing stream around each call: what a dependent kernel waits
+    for, including the wait for the slowest peer).  Off by default; bench.py switches it on for a few extra steps AFTER the timed
+    region of a multi-rank run, so the headline is not perturbed by ~220 event records per step."""
+
+    def __init__(self):
+        self.enabled, self.pairs = False, []
+
+    def run(self, kind, fn, *args, **kw):
+        if not (self.enabled and torch.cuda.is_available()):
+            return fn(*args, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*args, **kw)
+        e1.record()
+        self.pairs.append((kind, e0, e1))
+        return out
+
+    def drain(self):
+        """-> {kind: (count, total ms)} of the bracketed collectives since the last drain (synchronises the device)"""
+        torch.cuda.synchronize()
+        res = {}
+        for kind, e0, e1 in self.pairs:
+            c, t = res.get(kind, (0, 0.0))
+            res[kind] = (c + 1, t + e0.elapsed_time(e1))
+        self.pairs = []
+        return res
+
+
+COLLECTIVE_TIMER = _CollectiveTimer()
+
+
+def small_all_reduce(t, kind="all_reduce"):
+    """in-place SUM of a small tensor over the ranks on the small-collectives group"""
+    return COLLECTIVE_TIMER.run(kind, dist.all_reduce, t, group=small_group())
+
+
+def small_broadcast(t, src=0, kind="broadcast"):
+    return COLLECTIVE_TIMER.run(kind, dist.broadcast, t, src, group=small_group())
+
+
+def all_gather(tensors, group=None):
     """list of tensors -> list of tensors concatenated over ranks on dim 0 (distributed.py:34-54).
     Uses one all_gather_into_tensor per entry (a single contiguous receive buffer, no per-rank list)."""
     if not is_dist():
@@ -55,9 +126,9 @@ def all_gather(tensors):
         t = t.contiguous()
         buf = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         if hasattr(dist, "all_gather_into_tensor") and dist.get_backend() != "gloo":
-            dist.all_gather_into_tensor(buf, t)
+            COLLECTIVE_TIMER.run("all_gather", dist.all_gather_into_tensor, buf, t, group=group)
         else:
-            dist.all_gather(list(buf.chunk(ws, dim=0)), t)
+            COLLECTIVE_TIMER.run("all_gather", dist.all_gather, list(buf.chunk(ws, dim=0)), t, group=group)
         out.append(buf)
     return out
 
@@ -73,6 +144,21 @@ def all_reduce(tensors, average=True):
         for t in tensors:
             t.mul_(inv)
     return tensors
+
+
+def describe():
+    """what a reader of a bench line needs to know about the process group (bench.py: config.distributed)"""
+    info = {"initialized": bool(is_dist()), "world_size": 1, "rank": 0, "backend": None, "rccl_version": None, "small_collectives_group": None}
+    try:
+        v = torch.cuda.nccl.version()
+        info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:  # noqa: BLE001 -- CPU-only build
+        pass
+    if is_dist():
+        info.update(world_size=dist.get_world_size(), rank=dist.get_rank(), backend=str(dist.get_backend()))
+        g = small_group()
+        info["small_collectives_group"] = "own process group (own RCCL communicator + stream)" if g is not None else "default group"
+    return info
 
 
 def balanced_cuts(n, parts):
@@ -108,13 +194,16 @@ class RowPlan(object):
     loss_weight n_local * G / N  factor on the local-mean loss so that DDP's average over ranks is the global mean
     """
 
-    def __init__(self, D, B, M, rank=0, world_size=1, law='unit'):
+    def __init__(self, D, B, M, rank=0, world_size=1, law='unit', force=False):
         if law not in ('unit', 'row'):
             raise ValueError("placement law must be 'unit' or 'row'")
         self.D, self.B, self.M, self.rank, self.world, self.law = D, B, M, int(rank), int(world_size), law
         N = D * B * M
         self.n_rows = N
-        if self.world == 1:
+        # force: a one-rank job that still takes the sharded code path (domain-major local order, padded all-gather,
+        # index_select back into collate order) -- bench.py --force_dist: the first RCCL execution of this path on a one-GPU box
+        self.force = bool(force)
+        if self.world == 1 and not self.force:
             # single GPU: collate order itself (the reference's row law), nothing to gather
             self.order = np.arange(N, dtype=np.int64)
             self.cuts = [0, N]
@@ -145,7 +234,7 @@ class RowPlan(object):
 
     @property
     def sharded(self):
-        return self.world > 1
+        return self.world > 1 or self.force
 
     def units(self, rank=None):
         """(domain, policy) units touched by `rank` (whole units under the 'unit' law)."""
@@ -179,5 +268,5 @@ class RowPlan(object):
                 r, o = take // self.max_count, take % self.max_count
                 take = r * self.max_count + o % self.n_local
         else:
-            flat = all_gather([local])[0]
+            flat = all_gather([local], group=small_group())[0]
         return flat.index_select(0, take)

@@ -244,12 +244,12 @@ class SearchState(object):
         self.controller, self.M, _ = load_ddp_controller(ngpus_per_node, args, config)
         self.discriminator, _, _ = load_ddp_discriminator(ngpus_per_node, args, config)
         rank, world = adist.world()
-        T.set_row_shard(rank, world, getattr(args, 'placement', 'unit'))
+        T.set_row_shard(rank, world, getattr(args, 'placement', 'unit'), force=bool(getattr(args, 'force_sharded', False)))
         if adist.is_dist():
             # the controller is replicated, not wrapped (identical rewards -> identical updates); DDP broadcast the wrapped
             # modules' state at construction, do the same for it
             for t in list(self.controller.parameters()) + list(self.controller.buffers()):
-                torch.distributed.broadcast(t.data, 0)
+                torch.distributed.broadcast(t.data, 0)             # once, at construction: the default group
         _, self.train_loader, self.test_loader = get_seg_dg_dataloader(config, args, self.batch_size, workers)
         self.model_optimizer, self.model_lrscheduler, self.controller_optimizer = \
             get_optimizer_scheduler(self.controller, self.model, config)
@@ -282,11 +282,11 @@ class SearchState(object):
         if adist.is_dist():
             # the controller is replicated, not wrapped: make rank 0's draw authoritative and re-derive the
             # log-probs for it -- evaluate() equals sample()'s log-prob for the same actions
-            torch.distributed.broadcast(policies, 0)
+            adist.small_broadcast(policies, 0, kind="policy_broadcast")
             if self.graphed is not None:
                 # the replicas' parameters are identical, so rank 0's log-probs of rank 0's draw are THE log-probs:
                 # ship the [M] vector instead of re-evaluating the controller on every rank
-                torch.distributed.broadcast(self.graphed.old_log_probs, 0)
+                adist.small_broadcast(self.graphed.old_log_probs, 0, kind="policy_broadcast")
             else:
                 log_probs = self.controller.evaluate(policies, self.M)
         if async_host:

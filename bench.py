@@ -86,6 +86,15 @@ def parse():
                          "(18 rows per rank at 8 GPUs); both give one source domain per GPU at N = 3")
     ap.add_argument("--dist_backend", default="nccl", help="nccl (= RCCL) by default; gloo for single-GPU functional tests")
     ap.add_argument("--all_ranks_on_gpu0", action="store_true", help="functional test of the N>1 path on a 1-GPU box")
+    ap.add_argument("--force_dist", action="store_true",
+                    help="--gpus 1 only: run the ONE rank through the whole distributed path -- process group over --dist_backend (nccl = RCCL) "
+                         "with device_id, row plan in sharded order, padded all_gather_into_tensor of the embeddings, float64 BatchNorm "
+                         "statistics all-reduce between the HIP kernels, DDP-wrapped model and discriminator, policy broadcast -- so that "
+                         "the first RCCL execution of this code does not have to wait for a multi-GPU box")
+    ap.add_argument("--detail", default=None,
+                    help="write the long per-step / per-op arrays (roofline.per_step, float_ops.ops, cpu_baseline.by_workers, ...) to this JSON "
+                         "file; default gpurun_out/bench_detail.json when that directory exists, else not written.  The printed line "
+                         "keeps the summaries and stays below 8 KB")
     ap.add_argument("--dump_rewards", default=None, help="write the rewards of every timed step to this JSON file (tests)")
     ap.add_argument("--no_dropout", action="store_true", help="tests: make the step a deterministic function of the seed")
     ap.add_argument("--no_pool_stats", action="store_true",
@@ -313,9 +322,10 @@ def build_state(a, local_rank, world, backbone_dtype=None):
     cfg.PRINT_FREQ = 10 ** 9
     cfg.freeze()
     args = Args()
-    args.gpu, args.workers, args.distributed = local_rank, 0, world > 1
+    args.gpu, args.workers, args.distributed = local_rank, 0, world > 1 or a.force_dist
     args.crop_size, args.backbone_dtype, args.epoch_items = a.size, backbone_dtype or a.backbone_dtype, a.batch
-    args.sync_bn = world > 1 and not a.no_sync_bn
+    args.sync_bn = (world > 1 or a.force_dist) and not a.no_sync_bn
+    args.force_sharded = bool(a.force_dist)
     args.placement = a.placement
     st = SearchState(local_rank, world, cfg, args)
     if a.no_dropout:
@@ -383,7 +393,7 @@ def time_steps(st, a, world, steps, warmup, first_epoch=0, want_kernel_events=Tr
     from aadg_amd import _lib
 
     def sync():
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -429,7 +439,7 @@ def time_steps(st, a, world, steps, warmup, first_epoch=0, want_kernel_events=Tr
     sync()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     kern_ms = [p[0].elapsed_time(p[1]) for p in kpairs] if want_kernel_events else []
@@ -664,10 +674,15 @@ def rvs_1024_leg(n_units=144, size=1024):
                                    "frac_survey_8d_bytes": sb / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}}
 
 
-def precision_check(st_lo, st_hi, M, D, batch):
-    """What the reduced-precision backbone does to the quantities the SEARCH consumes: the same weights, the same
-    seeded batch, dropout off, forward passes only -- backbone under bfloat16 autocast (st_lo, the headline) against float32 (st_hi,
-    the reference's precision): raw Sinkhorn rewards [M] (what the controller is rewarded with), per-policy BCE [M], Dice [K]."""
+NORTH_STAR_TOL = 1e-4          # BASELINE.json north_star: "Dice/Sinkhorn within 1e-4 fp32"
+
+
+def precision_check(st_lo, st_hi, M, D, batch, n_batches=3):
+    """What the reduced-precision backbone does to the quantities the SEARCH consumes: the same weights,
+    `n_batches` seeded batches (their own policies), dropout off, forward passes only -- backbone under bfloat16 autocast (st_lo, the
+    headline) against float32 (st_hi, the reference's precision): raw Sinkhorn rewards [M] (what the controller is rewarded with),
+    per-policy BCE [M], Dice [K].  `within_north_star_1e-4` says whether the bf16 backbone stays inside the tolerance north_star states
+    for Dice / Sinkhorn against the float32 path on every one of the batches."""
     import torch
     from aadg_amd import _lib
     from aadg_amd.data.policy import DGMultiPolicy, parse_policies
@@ -689,27 +704,40 @@ def precision_check(st_lo, st_hi, M, D, batch):
             m.p = p0
         return rewards.double().cpu().numpy(), bce.double().cpu().numpy(), dice.double().cpu().numpy()
 
-    _bare(st_hi.model).load_state_dict(_bare(st_lo.model).state_dict())
-    _bare(st_hi.discriminator).load_state_dict(_bare(st_lo.discriminator).state_dict())
-    pol = np.random.RandomState(1023).randint(0, 10, (M, 20))
-    for seed_fn in (random.seed, np.random.seed, torch.manual_seed):
-        seed_fn(4242)
-    st_lo.train_loader.dataset.transforms.transforms[0] = DGMultiPolicy(parse_policies(pol, st_lo.config, None))
-    sample = next(iter(st_lo.train_loader))
-    r_lo, b_lo, d_lo = quantities(st_lo, sample)
-    r_hi, b_hi, d_hi = quantities(st_hi, sample)
-
     def norm(r):
         return (r - r.mean()) / (r.std(ddof=1) + 1e-5)
-    return {"what": "same weights, same seeded batch (%d images), dropout off, forward only: backbone under bfloat16 autocast vs float32; "
-                    "rewards = raw Sinkhorn sums per policy (search_dg.py:150-162), bce = per-policy BCE (:140-142), dice = samplewise "
-                    "Dice per class (:164-165)" % sample['aug_images'].shape[0],
-            "rewards_bf16": r_lo.tolist(), "rewards_fp32": r_hi.tolist(),
-            "reward_abs_max_diff": float(np.abs(r_lo - r_hi).max()), "reward_rel_max_diff": float((np.abs(r_lo - r_hi) / np.abs(r_hi)).max()),
-            "normalized_reward_abs_max_diff": float(np.abs(norm(r_lo) - norm(r_hi)).max()),
-            "reward_ranking_equal": bool((np.argsort(r_lo) == np.argsort(r_hi)).all()),
-            "bce_abs_max_diff": float(np.abs(b_lo - b_hi).max()), "bce_rel_max_diff": float((np.abs(b_lo - b_hi) / np.abs(b_hi)).max()),
-            "dice_abs_max_diff": float(np.abs(d_lo - d_hi).max())}
+
+    _bare(st_hi.model).load_state_dict(_bare(st_lo.model).state_dict())
+    _bare(st_hi.discriminator).load_state_dict(_bare(st_lo.discriminator).state_dict())
+    per, n_img = [], 0
+    for i in range(n_batches):
+        pol = np.random.RandomState(1023 + i).randint(0, 10, (M, 20))
+        for seed_fn in (random.seed, np.random.seed, torch.manual_seed):
+            seed_fn(4242 + i)
+        st_lo.train_loader.dataset.transforms.transforms[0] = DGMultiPolicy(parse_policies(pol, st_lo.config, None))
+        sample = next(iter(st_lo.train_loader))
+        n_img = int(sample['aug_images'].shape[0])
+        r_lo, b_lo, d_lo = quantities(st_lo, sample)
+        r_hi, b_hi, d_hi = quantities(st_hi, sample)
+        per.append({"reward_abs": float(np.abs(r_lo - r_hi).max()), "reward_rel": float((np.abs(r_lo - r_hi) / np.abs(r_hi)).max()),
+                    "normalized_reward_abs": float(np.abs(norm(r_lo) - norm(r_hi)).max()),
+                    "ranking_equal": bool((np.argsort(r_lo) == np.argsort(r_hi)).all()),
+                    "bce_abs": float(np.abs(b_lo - b_hi).max()), "bce_rel": float((np.abs(b_lo - b_hi) / np.abs(b_hi)).max()),
+                    "dice_abs": float(np.abs(d_lo - d_hi).max()),
+                    "rewards_bf16": [round(float(v), 7) for v in r_lo], "rewards_fp32": [round(float(v), 7) for v in r_hi]})
+        del sample
+    worst = lambda k: max(p_[k] for p_ in per)          # noqa: E731
+    return {"what": "same weights, %d seeded batches of %d images (own policies each), dropout off, forward only: backbone under bfloat16 "
+                    "autocast vs float32; rewards = raw Sinkhorn sums per policy (search_dg.py:150-162), bce = per-policy BCE (:140-142), "
+                    "dice = samplewise Dice per class (:164-165); maxima over the batches" % (n_batches, n_img),
+            "batches": n_batches, "north_star_tolerance": NORTH_STAR_TOL,
+            "reward_abs_max_diff": worst("reward_abs"), "reward_rel_max_diff": worst("reward_rel"),
+            "normalized_reward_abs_max_diff": worst("normalized_reward_abs"),
+            "reward_ranking_equal": all(p_["ranking_equal"] for p_ in per),
+            "bce_abs_max_diff": worst("bce_abs"), "bce_rel_max_diff": worst("bce_rel"), "dice_abs_max_diff": worst("dice_abs"),
+            "within_north_star_1e-4": {"rewards": bool(worst("reward_abs") <= NORTH_STAR_TOL), "dice": bool(worst("dice_abs") <= NORTH_STAR_TOL),
+                                       "bce": bool(worst("bce_abs") <= NORTH_STAR_TOL)},
+            "per_batch": per}
 
 
 def only_legs_main(a):
@@ -746,7 +774,7 @@ def main():
     legs = set() if a.legs == "none" else set(("fop,kernels,fp32,rvs1024,cpu" if a.legs == "auto" else a.legs).split(","))
     if a.no_cpu_baseline:
         legs.discard("cpu")
-    if world > 1 or a.shard_of or a.dump_rewards:
+    if world > 1 or a.shard_of or a.dump_rewards or a.force_dist:
         legs = set()
     # worker processes of the CPU leg: forked before this process touches the GPU
     pools = None
@@ -769,8 +797,16 @@ def main():
     if world > 1 and not a.all_ranks_on_gpu0 and a.dist_backend != "nccl":
         raise SystemExit("bench.py --gpus %d: the multi-GPU measurement runs over RCCL (--dist_backend nccl); %s is for the "
                          "--all_ranks_on_gpu0 functional test only" % (world, a.dist_backend))
-    if world > 1:
+    if a.force_dist and world != 1:
+        raise SystemExit("bench.py --force_dist is the one-rank run of the distributed path (--gpus 1)")
+    dist_on = world > 1 or a.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.force_dist:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if a.dist_backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -800,9 +836,22 @@ def main():
     bn_collectives = LAST_BN_COLLECTIVES
 
     def sync():
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    # ---- N > 1 (or --force_dist): GPU-side time of the small collectives, a few extra steps AFTER the timed region -------------
+    coll = None
+    if dist_on:
+        from aadg_amd import distributed as adist
+        adist.COLLECTIVE_TIMER.enabled = True
+        n_extra = 3
+        for i in range(n_extra):
+            st.search_step(a.warmup + a.steps + i, max_iters=1)
+        got = adist.COLLECTIVE_TIMER.drain()
+        adist.COLLECTIVE_TIMER.enabled = False
+        coll = {k: {"calls_per_step": c / n_extra, "ms_per_step": t / n_extra} for k, (c, t) in got.items()}
+        sync()
 
     # ---- the same step with the backbone removed (only what this repo implements) ------------------
     from aadg_amd.data import transform as T
@@ -811,31 +860,47 @@ def main():
     z = torch.randn(plan.n_local, K, a.size, a.size, device="cuda", requires_grad=True)
     fe = torch.nn.functional.leaky_relu(torch.randn(n_rows, 128, device="cuda"), 0.2)
     rewards = torch.zeros(M, device="cuda")
+    ev = lambda: torch.cuda.Event(enable_timing=True)      # noqa: E731
+    STAGES = ("controller_sample", "augmentation_call", "bce_dice_fwd_bwd", "sinkhorn_rewards", "normalise_ppo_update")
 
-    def hot_step():
+    def hot_step(marks=None):
+        """marks: 2 * len(STAGES) events recorded around the stages (the GPU time of each stage's kernels incl. the gaps between them)"""
+        k = 0
+
+        def mark():
+            nonlocal k
+            if marks is not None:
+                marks[k].record()
+                k += 1
+        mark()
         if st.graphed is not None:
             policies, _, _, log_probs, entropies = st.graphed.sample()
         else:
             policies, _, _, log_probs, entropies = st.controller(M)
+        mark()
         parsed = parse_policies(policies.cpu().numpy(), cfg, None)
         st.train_loader.dataset.transforms.transforms[0] = DGMultiPolicy(parsed)
+        mark()
         sample = next(iter(st.train_loader))
+        mark(); mark()
         loss, _, _ = _lib.policy_bce_loss(z, sample['aug_labels'], 1 if plan.sharded else M)
         loss.backward()
+        mark(); mark()
         rewards.zero_()
         if D >= 2:
             _lib.sinkhorn_rewards(fe, D, a.batch, M, rewards=rewards)
+        mark(); mark()
         if st.graphed is not None:
             st.graphed.update(_lib.normalize_rewards(rewards), entropies)
         else:
             st.controller_criterion(st.controller, policies, log_probs, entropies, _lib.normalize_rewards(rewards))
+        mark()
         return sample
 
     for _ in range(2):
         hot_step()
     sync()
     HK = max(a.steps, 10)
-    ev = lambda: torch.cuda.Event(enable_timing=True)      # noqa: E731
     hk_pairs = [(ev(), ev(), ev(), ev()) for _ in range(HK)]
     for p in hk_pairs:
         for e in p:
@@ -850,6 +915,18 @@ def main():
     hot_ms = (time.perf_counter() - t0) / HK * 1e3
     hot_kern_ms = sum(p[0].elapsed_time(p[1]) for p in hk_pairs) / HK
     hot_call_ms = sum(p[2].elapsed_time(p[3]) for p in hk_pairs) / HK
+    # a second pass with events around every stage: where the GPU time of a hot-path step goes, and what is left for the host
+    HS = 10
+    smarks = [[ev() for _ in range(2 * len(STAGES))] for _ in range(HS)]
+    for row in smarks:
+        for e in row:
+            e.record()
+    sync()
+    for i in range(HS):
+        hot_step(smarks[i])
+    sync()
+    stage_ms = {name: float(np.mean([row[2 * k].elapsed_time(row[2 * k + 1]) for row in smarks])) for k, name in enumerate(STAGES)}
+    hot_gpu_ms = float(sum(stage_ms.values()))
 
     # bytes of one launch (this rank's slice of one batch plan): the tile kernel's own, and SURVEY 8(d)'s for the whole call
     batch = [st.train_loader.dataset[0] for _ in range(a.batch)]
@@ -862,64 +939,80 @@ def main():
     kbytes = unit_bytes(units, Hs, Hs, a.size, K, False)
     sbytes = unit_bytes(units, Hs, Hs, a.size, K, True)
     achieved = kbytes / (kern_ms * 1e-3) / 1e9
+    call_bytes = kbytes if not a.no_pool_stats else sbytes
 
     out = None
+    detail = {}
     if rank == 0 and a.dump_rewards:
         with open(a.dump_rewards, "w") as f:
             json.dump({"normalized": [n.tolist() for n, _ in dump], "raw": [r.tolist() for _, r in dump]}, f)
     if rank == 0:
-        traffic = committed("r03_traffic_k_fused3.json") or committed("r02_traffic_k_fused3.json")
-        prof = committed("r03_bench_kernel_stats.json") or committed("r02_bench_kernel_stats.json")
+        traffic = committed("r04_traffic_k_fused3.json") or committed("r03_traffic_k_fused3.json")
+        prof = committed("r04_bench_kernel_stats.json") or committed("r03_bench_kernel_stats.json")
+        # `roofline`: flat scalars first (the driver's record keeps scalars of this block), nested blocks after them
         roof = {"bound": "hbm", "kernel": "k_fused3 (LDS-tiled op chain + Pillow-exact resample + crop + normalise + CHW float32 store)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": int(traffic["hbm_bytes_per_unit"] * len(units)) if traffic and traffic.get("size") == a.size else None,
                 "bytes_per_launch": kbytes, "kernel_ms": kern_ms, "units_per_launch": len(units),
-                "what": "bytes the bracketed kernel moves (source + mask read once, %d float32 planes written once) / mean of %d "
-                        "per-step HIP-event durations around exactly that kernel" % (3 + K, a.steps),
-                "stage": {"what": "SURVEY 8(d) algorithmic bytes of the whole augmentation call (source counted twice for units with a "
-                                  "statistics op) / events around ALL its kernels: k_lut_tables (or k_hist_tables + k_lut), k_hist_fused, "
-                                  "k_lut, tile kernels",
-                          "bytes": kbytes if not a.no_pool_stats else sbytes, "ms": call_ms,
-                          "achieved": (kbytes if not a.no_pool_stats else sbytes) / (call_ms * 1e-3) / 1e9,
-                          # with the per-pool statistics cache the timed call reads the source ONCE: its fraction is priced on those bytes
-                          # (the round-2 line priced the cached call on SURVEY 8(d)'s twice-read bytes: kept as frac_survey_8d_bytes)
-                          "frac": (kbytes if not a.no_pool_stats else sbytes) / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                          "frac_survey_8d_bytes": sbytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                          "pool_statistics": ("cached" if not a.no_pool_stats else "per call") +
-                                             ": the policy ops see the raw pool image, so its histogram / mean is computed once per resident "
-                                             "pool image (aadg_pool_histograms_u8, outside the timed call) instead of once per unit and call; "
-                                             "--no_pool_stats times the call with the per-unit statistics pass"}}
-        # the same launches in the hot-path leg below (backbone removed): the duration of this instruction-issue-bound kernel follows the
-        # core clock the power management leaves it, i.e. what ran before it -- after a step of MFMA-dense backbone kernels it runs
-        # ~10 % slower than after the library's slower convolutions or in the hot-path loop
-        # the kernel's duration follows the op mix the controller sampled for the step (every Sharpness op is a 3x3 stencil over the LDS
-        # patch + a barrier; bytes per launch are the same for every mix): per timed step, duration next to the mix
-        roof["per_step"] = [dict(m, kernel_us=round(k * 1e3, 1), call_us=round(c * 1e3, 1)) for m, k, c in zip(main_mixes, kern_ms_l, call_ms_l)]
-        roof["hot_path_leg"] = {"kernel_ms": hot_kern_ms, "frac": kbytes / (hot_kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "stage_ms": hot_call_ms,
-                                "stage_frac": (kbytes if not a.no_pool_stats else sbytes) / (hot_call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "what": "the same kernel / call timed the same way in the hot_path loop (no backbone kernels between two calls)"}
+                "what": "bytes the bracketed kernel moves (source + mask once, %d float32 planes once) / mean of %d per-step HIP-event "
+                        "durations around it" % (3 + K, a.steps),
+                # the whole augmentation call (tables + byte maps + histogram pass of the late units + tile kernels), events around all of it
+                "stage_ms": call_ms, "stage_frac": call_bytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                # the step with the backbone removed = what this repository implements; SURVEY 8(d): the >= 40 steps/s target of
+                # north_star is only physically meaningful for this figure (144 x 512^2 R50-DLv3+ fwd+bwd alone is >~ 40 TFLOP)
+                "hot_path_ms_per_step": hot_ms, "hot_path_steps_per_s": 1e3 / hot_ms, "hot_path_target_steps_per_s": 40.0,
+                "hot_path_gpu_ms": hot_gpu_ms, "hot_path_host_ms": max(hot_ms - hot_gpu_ms, 0.0),
+                "hot_path_kernel_frac": kbytes / (hot_kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "hot_path_stage_frac": call_bytes / (hot_call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        roof["hot_path"] = {"ms_per_step": hot_ms, "steps_per_s": 1e3 / hot_ms, "img_per_s": n_rows * 1e3 / hot_ms,
+                            "target_steps_per_s": 40.0, "meets_target": bool(1e3 / hot_ms >= 40.0),
+                            "gpu_ms_by_stage": {k: round(v, 4) for k, v in stage_ms.items()}, "gpu_ms": hot_gpu_ms,
+                            "host_ms": max(hot_ms - hot_gpu_ms, 0.0),
+                            "kernel_ms": hot_kern_ms, "kernel_frac": kbytes / (hot_kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "stage_ms": hot_call_ms, "stage_frac": call_bytes / (hot_call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "what": "controller sample + parse + draw + augmentation call + BCE/Dice kernel (fwd + bwd) + Sinkhorn kernel + "
+                                    "reward normalise + PPO update; backbone and discriminator removed.  gpu_ms = HIP events around each "
+                                    "stage's launches (separate pass), host_ms = the rest of the wall time per step (policy D2H wait, draws, "
+                                    "plan, launches)"}
+        roof["stage"] = {"what": "algorithmic bytes of the whole augmentation call / events around ALL its kernels (k_luts_tables, k_hist_fused, "
+                                 "k_lut, tile kernels); source counted once: the raw images' statistics come from the per-pool cache "
+                                 "(aadg_pool_histograms_u8, computed once per resident pool outside the timed call; --no_pool_stats times "
+                                 "the per-call variant and prices the source twice, SURVEY 8(d))",
+                         "bytes": call_bytes, "ms": call_ms, "achieved": call_bytes / (call_ms * 1e-3) / 1e9,
+                         "frac": call_bytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_survey_8d_bytes": sbytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "pool_statistics": "cached" if not a.no_pool_stats else "per call"}
+        detail["roofline.per_step"] = [dict(m, kernel_us=round(k * 1e3, 1), call_us=round(c * 1e3, 1))
+                                       for m, k, c in zip(main_mixes, kern_ms_l, call_ms_l)]
         if traffic:
-            roof["traffic_source"] = "profiles/r03_traffic_k_fused3.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes), per unit x units"
+            roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes), per unit x units" % traffic.get("file", "r03_traffic_k_fused3.json")
         if prof:
-            # the other kernels of the call (latency-bound: tables + byte maps of every unit, histogram pass + maps of the late units)
-            roof["stage"]["kernels_rocprof_avg_us"] = {k[:-7]: round(v * 1e3, 1) for k, v in prof.items() if k.endswith("_avg_ms")}
-            roof["stage"]["kernels_rocprof_calls_per_launch"] = {k[:-17]: v for k, v in prof.items() if k.endswith("_calls_per_launch")}
+            detail["roofline.stage.kernels_rocprof_avg_us"] = {k[:-7]: round(v * 1e3, 1) for k, v in prof.items() if k.endswith("_avg_ms")}
         if prof and prof.get("k_fused3_avg_ms"):
-            roof["rocprof"] = {"kernel_avg_ms": prof["k_fused3_avg_ms"], "frac": kbytes / (prof["k_fused3_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "file": "profiles/" + prof.get("file", "r03_bench_rocprofv3_kernel_stats.txt"),
-                               "note": "average duration of the same kernel in the committed rocprofv3 --kernel-trace --stats run of this "
-                                       "command (another box of the pool)"}
+            roof["rocprof_kernel_avg_ms"] = prof["k_fused3_avg_ms"]
+            roof["rocprof_frac"] = kbytes / (prof["k_fused3_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            roof["rocprof_file"] = "profiles/" + prof.get("file", "r03_bench_rocprofv3_kernel_stats.txt")
+        from aadg_amd import distributed as adist
+        dinfo = adist.describe()
+        dinfo["forced_one_rank_run_of_the_distributed_path"] = bool(a.force_dist)
+        if dist_on:
+            dinfo["collectives_per_step"] = {"batchnorm_statistics_all_reduce": bn_collectives, "embedding_all_gather": 1, "policy_broadcast": 2,
+                                             "gradient_all_reduce": "DDP buckets (segmentation model + discriminator), overlapped with backward"}
+            dinfo["small_collectives_gpu_ms_per_step"] = coll
+            dinfo["small_collectives_gpu_ms_per_step_total"] = float(sum(v["ms_per_step"] for v in coll.values())) if coll else None
+            dinfo["note"] = ("BatchNorm: one float64 all-reduce of [2C + 1] / [2C] sums per layer and direction (ASPP's five layers share one, a "
+                             "projection shortcut travels with its main path); issued on a process group of their own so that they never "
+                             "queue behind a DDP gradient bucket; ms = HIP events around each call on the issuing stream in 3 extra steps "
+                             "after the timed region (includes waiting for the slowest peer)")
         out = {
             "metric": "policy-search steps/sec", "value": 1e3 / ms_per_step, "unit": "steps/s",
-            "n_gpus": torch.distributed.get_world_size() if world > 1 else 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8+f32 (augmentation / Sinkhorn / loss / controller kernels: the reference's own types); backbone convolutions %s"
-                     % ("under bfloat16 autocast with float32 master weights and float32 BatchNorm statistics -- NARROWER than the reference's "
-                        "float32 for this config: `fp32_backbone` is the same step at the reference's precision and `precision` bounds what "
-                        "the narrower backbone does to the quantities the search consumes on THIS run's weights and batch (round-3 runs: raw "
-                        "rewards within 0.1-0.7 %%, per-policy BCE within 0.01-0.05 %%, Dice within 0.0004-0.0012, reward ranking equal); "
-                        "tests/test_gpu_precision.py asserts rewards within 5 %%, BCE within 1 %%, Dice within 0.01 at a reduced config)"
+                     % ("under bfloat16 autocast (float32 master weights and BatchNorm statistics) -- NARROWER than the reference's float32: "
+                        "`fp32_backbone` is the same step at the reference's precision, `precision` bounds the effect on rewards / BCE / "
+                        "Dice on this run's weights (3 seeded batches, flags against north_star's 1e-4)"
                         if a.backbone_dtype == "bf16" else "float32 (the reference's precision)"),
             "data": "synthetic",
             "inner_loop_img_per_s": n_rows * 1e3 / ms_per_step,
@@ -930,45 +1023,47 @@ def main():
                                       else os.path.basename(a.cfg), cfg.MODEL.NAME, cfg.MODEL.BACKBONE, D, cfg.DATASET.NAME, a.size, a.size,
                                       a.batch, M, n_rows, cfg.CONTROLLER.LOSS.upper()),
                        "images_per_step": n_rows,
-                       "parallelism": "1 GPU" if world == 1 else
-                                      "%d GPUs: domain-major (domain, policy) units cut by %s (rows per rank %s), one embedding all-gather + DDP "
+                       "parallelism": "1 GPU" if world == 1 and not a.force_dist else
+                                      "%d GPU(s): domain-major (domain, policy) units cut by %s (rows per rank %s), one embedding all-gather + DDP "
                                       "gradient all-reduce%s" % (world, a.placement, "/".join(str(c) for c in plan.counts),
                                                                    "" if a.no_sync_bn else " + BatchNorm statistics all-reduce"),
                        "backbone_dtype": a.backbone_dtype,
-                       "distributed": None if world == 1 else {
-                           "world_size": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
-                           "collectives_per_step": {
-                               "batchnorm_statistics_all_reduce": bn_collectives,
-                               "embedding_all_gather": 1, "policy_broadcast": 2,
-                               "gradient_all_reduce": "DDP buckets (segmentation model + discriminator), overlapped with backward"},
-                           "note": "BatchNorm: one float64 all-reduce of [2C + 1] / [2C] sums per layer and direction; the five independent "
-                                   "layers of the ASPP head share one, a bottleneck's projection-shortcut layer travels with the main path's last one.  Every other layer's all-reduce lies on a dependency chain "
-                                   "(statistics -> normalise -> next layer's input), so the count cannot drop further without changing "
-                                   "what is normalised"}},
+                       "world_size": dinfo["world_size"], "dist_backend": dinfo["backend"], "rccl_version": dinfo["rccl_version"],
+                       "distributed": dinfo},
             "roofline": roof,
-            "hot_path": {"ms_per_step": hot_ms, "steps_per_s": 1e3 / hot_ms, "img_per_s": n_rows * 1e3 / hot_ms,
-                         "what": "controller sample + parse + draw + augmentation kernels + BCE/Dice kernel (fwd+bwd) + "
-                                 "Sinkhorn kernel + reward normalise + PPO; backbone and discriminator removed"},
+            "hot_path": {"ms_per_step": hot_ms, "steps_per_s": 1e3 / hot_ms, "img_per_s": n_rows * 1e3 / hot_ms},
         }
     # ---- extra legs (one GPU only) -------------------------------------------------------------------------------------
     if rank == 0 and "fop" in legs:
         try:
-            out["float_ops"] = float_ops_leg()
+            leg = float_ops_leg()
+            detail["float_ops.ops"] = leg.pop("ops")
+            out["float_ops"] = leg
+            out["roofline"]["float_ops_frac_median"], out["roofline"]["float_ops_frac_min"] = leg["frac_median"], leg["frac_min"]
         except Exception as e:  # noqa: BLE001
             out["float_ops"] = {"error": repr(e)}
     if rank == 0 and "kernels" in legs:
         try:
-            out["kernels"] = hot_kernels_leg()
+            leg = hot_kernels_leg()
+            out["kernels"] = leg
+            out["roofline"]["k_seg_frac"] = leg["k_seg_partial+k_seg_final"]["frac"]
+            out["roofline"]["k_sinkhorn_us"] = leg["k_sinkhorn"]["us"]
         except Exception as e:  # noqa: BLE001
             out["kernels"] = {"error": repr(e)}
     if rank == 0 and "rvs1024" in legs:
         try:
-            out["rvs_1024"] = rvs_1024_leg()
+            leg = rvs_1024_leg()
+            out["rvs_1024"] = leg
+            out["roofline"]["rvs1024_tile_kernels_frac"] = leg["roofline"]["frac"]
+            out["roofline"]["rvs1024_call_frac"] = leg["roofline"]["stage"]["frac"]
+            out["roofline"]["rvs1024_call_ms"] = leg["roofline"]["stage"]["ms"]
         except Exception as e:  # noqa: BLE001  -- an extra leg must not take the headline line down with it
             out["rvs_1024"] = {"error": repr(e)}
     if rank == 0 and "cpu" in legs:
         try:
-            out["cpu_baseline"] = cpu_baseline(pools, cfg, st, a)
+            leg = cpu_baseline(pools, cfg, st, a)
+            detail["cpu_baseline.by_workers"] = leg.pop("by_workers")
+            out["cpu_baseline"] = leg
         except Exception as e:  # noqa: BLE001
             out["cpu_baseline"] = {"error": repr(e)}
         finally:
@@ -983,7 +1078,13 @@ def main():
             with contextlib.redirect_stdout(sys.stderr):
                 _, st32 = build_state(a, local_rank, world, backbone_dtype="fp32")
             try:
-                out["precision"] = precision_check(st, st32, M, D, a.batch)
+                leg = precision_check(st, st32, M, D, a.batch)
+                detail["precision.per_batch"] = leg.pop("per_batch")
+                out["precision"] = leg
+                out["roofline"]["precision_reward_abs_max_diff"] = leg["reward_abs_max_diff"]
+                out["roofline"]["precision_dice_abs_max_diff"] = leg["dice_abs_max_diff"]
+                out["roofline"]["precision_within_north_star_1e-4"] = bool(leg["within_north_star_1e-4"]["rewards"] and
+                                                                          leg["within_north_star_1e-4"]["dice"])
             except Exception as e:  # noqa: BLE001
                 out["precision"] = {"error": repr(e)}
             del st
@@ -994,11 +1095,22 @@ def main():
                                     "step_ms": _stats(sm32),
                                     "what": "the same step with the backbone convolutions in float32 (the reference's precision for this "
                                             "config); everything else unchanged"}
+            out["roofline"]["fp32_backbone_steps_per_s"] = n32 / el32
         except Exception as e:  # noqa: BLE001
             out["fp32_backbone"] = {"error": repr(e)}
     if rank == 0:
+        path = a.detail
+        if path is None and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+            path = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+        if path:
+            try:
+                with open(path, "w") as f:
+                    json.dump(detail, f)
+                out["detail_file"] = os.path.relpath(path, ROOT)
+            except OSError:
+                pass
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

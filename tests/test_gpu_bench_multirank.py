@@ -65,3 +65,25 @@ def test_ddp_sync_bn_gradients_match_single_process(name, dtype, world):
            "--master-port", str(port), os.path.join(ROOT, "tests", "gpu_ddp_worker.py"), name, dtype]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=1500)
     assert p.returncode == 0, p.stdout.decode()[-4000:]
+
+
+def test_force_dist_one_rank_over_rccl(tmp_path):
+    """Round 4: `bench.py --gpus 1 --force_dist --dist_backend nccl` runs the ONE rank through the whole
+    distributed path over RCCL -- init_process_group("nccl", device_id=...), the row plan in sharded (domain-major) order, the padded
+    all_gather_into_tensor of the embeddings and the float64 BatchNorm statistics all-reduce on the small-collectives process group,
+    the policy broadcasts, DDP-wrapped model and discriminator -- and must compute the same rewards as the plain run."""
+    one, r1 = _bench(tmp_path, 1, "plain")
+    assert one["config"]["distributed"]["initialized"] is False and one["config"]["world_size"] == 1
+    out, rg = _bench(tmp_path, 1, "rccl", ["--force_dist", "--dist_backend", "nccl"])
+    d = out["config"]["distributed"]
+    assert d["initialized"] and d["backend"] == "nccl" and d["world_size"] == 1 and d["rccl_version"], d
+    assert d["forced_one_rank_run_of_the_distributed_path"] and "own process group" in d["small_collectives_group"], d
+    assert d["collectives_per_step"]["batchnorm_statistics_all_reduce"] > 50, d           # MobileNetV2: 52 layers, both directions
+    t = d["small_collectives_gpu_ms_per_step"]
+    assert t["all_gather"]["calls_per_step"] == 1 and t["policy_broadcast"]["calls_per_step"] == 2, t
+    assert t["batchnorm_statistics_all_reduce"]["calls_per_step"] == d["collectives_per_step"]["batchnorm_statistics_all_reduce"], t
+    assert "BatchNorm statistics all-reduce" in out["config"]["parallelism"]
+    a, b = r1["raw"][0], rg["raw"][0]
+    assert max(abs(x - y) for x, y in zip(a, b)) < 1e-4, (a, b)
+    for a, b in zip(r1["raw"][1:], rg["raw"][1:]):
+        assert max(abs(x - y) for x, y in zip(a, b)) < 0.25 * max(abs(x) for x in a), (a, b)
