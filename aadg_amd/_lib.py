@@ -234,7 +234,7 @@ def load():
     lib.aadg_upsample_sum_backward_all.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.aadg_embed_prologue_norm_f32.restype = _i
     lib.aadg_embed_prologue_norm_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]
-    if lib.aadg_abi_version() != 6:
+    if lib.aadg_abi_version() != 7:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -324,7 +324,7 @@ def validate_units(units, P, Hs, Ws):
 
 
 def launch_plan(units, Hs, Ws, crop):
-    """(classes, stats_mask, order, counts, stat_lists, late_plan) for aadg_aug_u8_forward_ex2 -- mirrors unit_flow() in csrc/aug_u8.hip.
+    """(classes, stats_mask, order, counts, stat_lists, late, n_stat_stencil) for aadg_aug_u8_forward_ex2 -- mirrors unit_flow() in csrc/aug_u8.hip.
     order: unit indices grouped by tile class (plain up-scaling, up-scaling with a Sharpness stencil, generic, staged);
     counts = (n_plain, n_sharp, n_generic, n_generic_sharp: the last ones of the generic run chain a Sharpness stencil); stat_lists[k]: the units whose k-th op needs a pixel pass for its image statistics;
     late: the units with such an op in a slot k >= 1."""
@@ -357,10 +357,18 @@ def launch_plan(units, Hs, Ws, crop):
     cls = np.where(up & (sharp == 0), 0, np.where(up, 1, np.where(generic & (sharp == 0), 2, np.where(generic, 3, 4))))
     order = np.argsort(cls, kind="stable").astype(np.int32)
     counts = (int((cls == 0).sum()), int((cls == 1).sum()), int(((cls == 2) | (cls == 3)).sum()), int((cls == 3).sum()))
-    stat_lists = [np.nonzero(pixel_pass[:, k])[0].astype(np.int32) for k in range(MAX_OPS)]     # work lists of the histogram kernels
+    # work lists of the histogram kernels; slot k's list starts with the units that have a Sharpness stencil among ops [0, k) (ABI 7:
+    # aadg_aug_lists.n_stat_stencil -- their tiles get a workgroup each), both parts in ascending unit order
+    stencil = (units["op"] == 8) & (units["farg"] != np.float32(1.0)) & live
+    stat_lists, n_stencil = [], []
+    for k in range(MAX_OPS):
+        idx = np.nonzero(pixel_pass[:, k])[0]
+        before = stencil[idx, :k].any(axis=1) if k > 0 else np.zeros(idx.size, bool)
+        stat_lists.append(np.concatenate([idx[before], idx[~before]]).astype(np.int32))
+        n_stencil.append(int(before.sum()))
     # "late" units: a slot k >= 1 needs a pixel pass (include/aadg_hip.h: aadg_aug_lists.late_units)
     late = np.nonzero(pixel_pass[:, 1:].any(axis=1))[0].astype(np.int32)
-    return classes, stats_mask, order, counts, stat_lists, late
+    return classes, stats_mask, order, counts, stat_lists, late, n_stencil
 
 
 def launch_hints(units, Hs, Ws, crop):
@@ -372,7 +380,8 @@ class AugLists(ctypes.Structure):
     """mirror of `aadg_aug_lists` (include/aadg_hip.h): host struct of device index arrays"""
     _fields_ = [("order", ctypes.c_void_p), ("n_plain", ctypes.c_int32), ("n_sharp", ctypes.c_int32), ("n_generic", ctypes.c_int32),
                 ("stat_units", ctypes.c_void_p * MAX_OPS), ("n_stat", ctypes.c_int32 * MAX_OPS), ("pool_hist", ctypes.c_void_p),
-                ("late_units", ctypes.c_void_p), ("n_late", ctypes.c_int32), ("n_generic_sharp", ctypes.c_int32)]
+                ("late_units", ctypes.c_void_p), ("n_late", ctypes.c_int32), ("n_generic_sharp", ctypes.c_int32),
+                ("n_stat_stencil", ctypes.c_int32 * MAX_OPS)]
 
 
 HIST_STRIDE = 772      # AADG_HIST_STRIDE
@@ -450,7 +459,7 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
     # validation + work lists (tile-class order, per-slot statistics lists, late list) by the library's host-side planner, written
     # straight into the staging buffer behind the records: [order N][stat_units MAX_OPS x N][late N] int32
     base = stage.data_ptr()
-    summary = (ctypes.c_int32 * (8 + MAX_OPS))()
+    summary = (ctypes.c_int32 * (8 + 2 * MAX_OPS))()
     rc = lib.aadg_aug_u8_plan(base, N, P, Hs, Ws, crop, base + nb_units, base + nb_units + 4 * N, base + nb_units + 4 * N * (1 + MAX_OPS), summary)
     if rc != 0:
         validate_units(units, P, Hs, Ws)                     # raises with the reason
@@ -463,6 +472,7 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
     for k in range(MAX_OPS):
         lists.stat_units[k] = d_units.data_ptr() + nb_units + 4 * N * (1 + k)
         lists.n_stat[k] = summary[8 + k]
+        lists.n_stat_stencil[k] = summary[8 + MAX_OPS + k]
     if pool_hist is not None:
         if pool_hist.dtype != torch.int32 or tuple(pool_hist.shape) != (P, HIST_STRIDE) or not pool_hist.is_cuda:
             raise AadgError("pool_hist must be pool_histograms(pool): int32 [P, %d] on the device" % HIST_STRIDE)

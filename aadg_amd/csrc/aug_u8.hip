@@ -28,6 +28,8 @@
 //   k_hist / k_lut / k_apply per op stage, then k_tables and k_final (gathers from global memory).
 #include <stdlib.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -478,119 +480,127 @@ __device__ __forceinline__ void tables_coeff_body(const UnitRef& ur, int Hs, int
         for (int t = 0; t < KMAX; ++t) kk[t] = k[t];
     }
 }
-// the NEAREST index tables of unit u (labels).  ImagingScaleAffine accumulates xo += a0 in double, SEQUENTIALLY (the rounding of the
-// running sum decides exact ties), so one lane walks each axis (~770 dependent additions: the long pole of the tables, which is why
-// k_luts_tables gives it a workgroup of its own); results are staged in LDS and written out coalesced by the whole block.
-__device__ __forceinline__ void tables_nn_body(const UnitRef& ur, int Hs, int Ws, int crop, int* tab, int u, int* nn_lds /* 2 * crop ints */) {
+// The NEAREST index tables of unit u (labels).  ImagingScaleAffine accumulates xo += a0 in double, SEQUENTIALLY: the rounding of the
+// running sum decides exact ties, so the index is NOT floor((i + 0.5) * in / out).  Rounds 1-3 let one lane per axis walk the sum
+// (~1000 dependent additions: 13 / 25 us for 512 / 1024-pixel crops, the long pole of the tables launch).
+// Round 4: the same values WITHOUT the serial chain.  xo_{i+1} = fl(xo_i + a0) is a rounding per step, but inside one binade
+// [2^e, 2^(e+1)) every xo is a multiple of u = 2^(e-52) and a0 = q u + r is fixed, so fl() adds the SAME multiple of u at every step:
+// q or q + 1 by r against u / 2 -- and for r = u / 2 exactly (a tie; common: a0's last mantissa bit) round-to-even makes the first
+// result even, after which the increment is constant too (q even: q; q odd: q + 1).  So per binade: two real additions give
+// xo_{i+1}, xo_{i+2} (the steady increment d = xo_{i+2} - xo_{i+1}, exact), the rest of the binade is the arithmetic sequence
+// m1 + j dm in units of u (integers below 2^53), and the step that leaves the binade is again a real addition.  <= 14 binades
+// between a0 / 2 and 2048: one lane per axis builds <= 32 segments (lo, hi, m1, dm, shift) in ~1 us, then every lane reads its own
+// index off them -- instead of ~1000 dependent additions (13 / 25 us for 512 / 1024-pixel crops: the long pole of k_luts_tables).
+// Equal to the sequential walk for every index of every size pair tried on the host (2423 pairs: all output sizes in [in / 3, 3 in]
+// for in = 33, 64, 96 and every 7th for in = 300 .. 2048) and bit-exact against the oracle's walk in the GPU tests.
+constexpr int NN_SEGS = 40;
+struct NnSegs {
+    int lo[NN_SEGS], hi[NN_SEGS], sh[NN_SEGS], n;
+    long long m1[NN_SEGS], dm[NN_SEGS];
+};
+__device__ __forceinline__ int f64_exponent(double x) { return (int)((__double_as_longlong(x) >> 52) & 0x7FF) - 1023; }
+__device__ __forceinline__ double f64_pow2(int e) { return __longlong_as_double((long long)(e + 1023) << 52); }
+__device__ __forceinline__ long long f64_mantissa(double x) { return (__double_as_longlong(x) & ((1ll << 52) - 1)) | (1ll << 52); }
+// segments covering source indices [0, lim) of the walk for inSize -> outSize (inSize != outSize)
+__device__ void nn_build_segments(int inSize, int outSize, int lim, NnSegs& S) {
+    const double a0 = (double)inSize / (double)outSize;
+    double x = 0.0 + a0 * 0.5;
+    int i = 0, n = 0;
+    auto single = [&](int idx, double v) {
+        S.lo[n] = S.hi[n] = idx; S.m1[n] = f64_mantissa(v); S.dm[n] = 0; S.sh[n] = 52 - f64_exponent(v); ++n;
+    };
+    while (i < lim && n + 2 <= NN_SEGS) {
+        const int e = f64_exponent(x);
+        const double top = f64_pow2(e + 1);
+        single(i, x);
+        const double x1 = x + a0;
+        if (x1 >= top) { i += 1; x = x1; continue; }
+        const double x2 = x1 + a0;
+        if (x2 >= top) { single(i + 1, x1); i += 2; x = x2; continue; }
+        const long long m1 = f64_mantissa(x1);
+        const long long dm = (long long)((x2 - x1) * f64_pow2(52 - e));           // exact: a multiple of u below 2^(e+1)
+        const long long room = ((1ll << 53) - 1) - m1;
+        long long j = (long long)((double)room * __builtin_amdgcn_rcp((double)dm));      // approximate quotient, put right below
+        j = j < 0 ? 0 : j;
+        while (j * dm > room) --j;
+        while ((j + 1) * dm <= room) ++j;
+        S.lo[n] = i + 1; S.hi[n] = i + 1 + (int)j; S.m1[n] = m1; S.dm[n] = dm; S.sh[n] = 52 - e; ++n;
+        const double x_last = (double)(m1 + j * dm) * f64_pow2(e - 52);           // exact
+        x = x_last + a0;
+        i += 2 + (int)j;
+    }
+    S.n = n;
+}
+__device__ __forceinline__ void tables_nn_body_closed(const UnitRef& ur, int Hs, int Ws, int crop, int* tab, int u, NnSegs* segs /* 2, LDS */) {
     const aadg_unit& un = pick(ur, u);
     int* base = tab + (size_t)u * crop * TAB_STRIDE;
     int* xnn = base + 2 * (crop + (size_t)crop * KMAX);
     int* ynn = xnn + crop;
     const int w = un.scaled_w, h = un.scaled_h;
     const int ox = un.crop_x - un.pad, oy = un.crop_y - un.pad;
-    for (int i = threadIdx.x; i < 2 * crop; i += 256) nn_lds[i] = -1;
-    __syncthreads();
-    if (threadIdx.x == 0 || threadIdx.x == 64) {
-        const bool isx = threadIdx.x == 0;
+    const int tid = threadIdx.x;
+    if (tid == 0 || tid == 64) {
+        const bool isx = tid == 0;
         const int outSize = isx ? w : h, inSize = isx ? Ws : Hs, off = isx ? ox : oy;
-        int* nn = nn_lds + (isx ? 0 : crop);
-        const double a0 = (double)inSize / (double)outSize;
-        double xo = 0.0 + a0 * 0.5;
-        int lim = off + crop;
-        if (lim > outSize) lim = outSize;
-        if (inSize == outSize) {       // a0 == 1: xo = s + 0.5 exactly
-            for (int sidx = off < 0 ? 0 : off; sidx < lim; ++sidx) nn[sidx - off] = sidx;
-        } else {
-            int sidx = 0;
-            const int skip = off < lim ? off : lim;
-#pragma unroll 8
-            for (; sidx < skip; ++sidx) xo += a0;
-            // xo > 0 always (a0 > 0); values reaching inSize cannot occur for a full-image box
-#pragma unroll 8
-            for (; sidx < lim; ++sidx) {
-                const int xin = (int)xo;
-                nn[sidx - off] = xin < inSize ? xin : -1;
-                xo += a0;
-            }
-        }
+        segs[isx ? 0 : 1].n = 0;
+        if (inSize != outSize) nn_build_segments(inSize, outSize, min(off + crop, outSize), segs[isx ? 0 : 1]);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < crop; i += 256) { xnn[i] = nn_lds[i]; ynn[i] = nn_lds[crop + i]; }
-}
-// The same with the walking lane doing nothing but the additions: it stores the running sums (doubles) and the whole workgroup
-// converts them afterwards.  The walk is one wave with one live lane, so its time is instructions x ~5 cycles, not arithmetic:
-// add + convert + compare + select + store per step took 20 us for a 512-wide crop at offset ~250, add + store takes ~8.
-__device__ __forceinline__ void tables_nn_body_wide(const UnitRef& ur, int Hs, int Ws, int crop, int* tab, int u, double* xs /* 2 * crop */) {
-    const aadg_unit& un = pick(ur, u);
-    int* base = tab + (size_t)u * crop * TAB_STRIDE;
-    int* xnn = base + 2 * (crop + (size_t)crop * KMAX);
-    int* ynn = xnn + crop;
-    const int w = un.scaled_w, h = un.scaled_h;
-    const int ox = un.crop_x - un.pad, oy = un.crop_y - un.pad;
-    if (threadIdx.x == 0 || threadIdx.x == 64) {
-        const bool isx = threadIdx.x == 0;
-        const int outSize = isx ? w : h, inSize = isx ? Ws : Hs, off = isx ? ox : oy;
-        if (inSize != outSize) {
-            double* x = xs + (isx ? 0 : crop);
-            const double a0 = (double)inSize / (double)outSize;
-            double xo = 0.0 + a0 * 0.5;
-            int lim = off + crop;
-            if (lim > outSize) lim = outSize;
-            int sidx = 0;
-            const int skip = off < lim ? off : lim;
-#pragma unroll 8
-            for (; sidx < skip; ++sidx) xo += a0;
-#pragma unroll 8
-            for (; sidx < lim; ++sidx) {
-                x[sidx - off] = xo;
-                xo += a0;
-            }
-        }
+    // waves 0-1 write the x table, waves 2-3 the y table.  Segments outer, indices inner: a segment's five words are read once (one LDS
+    // round trip), then the 128 lanes of the axis stride over the part of the crop window it covers.  (Indices outer -- every lane
+    // scanning the list for its own index -- is a chain of dependent LDS reads per index: 16 us at 1024 pixels, slower than the walk.)
+    const int ax = tid >> 7, l = tid & 127;
+    const NnSegs& S = segs[ax];
+    const int outSize = ax == 0 ? w : h, inSize = ax == 0 ? Ws : Hs, off = ax == 0 ? ox : oy;
+    int* out = ax == 0 ? xnn : ynn;
+    const int lim = min(off + crop, outSize), start = max(off, 0);      // live source indices: [start, lim)
+    for (int o = l; o < crop; o += 128) {                               // everything outside the scaled image: no label
+        const int sidx = o + off;
+        if (sidx < start || sidx >= lim) out[o] = -1;
+        else if (inSize == outSize) out[o] = sidx;                      // a0 == 1: xo = s + 0.5 exactly
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * crop; i += 256) {
-        const bool isx = i < crop;
-        const int o = isx ? i : i - crop;
-        const int outSize = isx ? w : h, inSize = isx ? Ws : Hs, off = isx ? ox : oy;
-        const int lim = min(off + crop, outSize), sidx = o + off;
-        int v = -1;
-        if (sidx >= 0 && sidx >= min(off, lim) && sidx < lim) {
-            if (inSize == outSize) v = sidx;               // a0 == 1: xo = s + 0.5 exactly
-            else {
-                const int xin = (int)xs[i];
-                v = xin < inSize ? xin : -1;
-            }
+    if (inSize == outSize) return;
+    const int nseg = S.n;
+    const bool before = (tid & 63) < nseg && S.hi[tid & 63] < start;
+    const int first = __popcll(__ballot(before));                       // the first segment that reaches into the window
+    for (int t = first; t < nseg; ++t) {
+        const int lo = S.lo[t], hi = S.hi[t], sh = S.sh[t];
+        const long long m1 = S.m1[t], dm = S.dm[t];
+        const int a = max(lo, start), bnd = min(hi, lim - 1);
+        for (int sidx = a + l; sidx <= bnd; sidx += 128) {
+            const long long m = m1 + (long long)(sidx - lo) * dm;
+            const int xin = sh >= 64 ? 0 : (int)(m >> sh);               // sh > 52: values below 1
+            out[sidx - off] = xin < inSize ? xin : -1;
         }
-        (isx ? xnn : ynn)[o] = v;
+        if (hi >= lim - 1) break;
     }
 }
-__device__ __forceinline__ void tables_body(const UnitRef& ur, int Hs, int Ws, int crop, int* tab, int u, int* nn_lds /* 2 * crop ints */) {
+__device__ __forceinline__ void tables_body(const UnitRef& ur, int Hs, int Ws, int crop, int* tab, int u) {
+    __shared__ NnSegs segs[2];
     tables_coeff_body(ur, Hs, Ws, crop, tab, u);
-    tables_nn_body(ur, Hs, Ws, crop, tab, u, nn_lds);
+    tables_nn_body_closed(ur, Hs, Ws, crop, tab, u, segs);
 }
 __global__ __launch_bounds__(256) void k_tables(UnitRef ur, int Hs, int Ws, int crop, int* tab) {
-    extern __shared__ int nn_dyn[];   // 2 * crop ints
-    tables_body(ur, Hs, Ws, crop, tab, blockIdx.x, nn_dyn);
+    tables_body(ur, Hs, Ws, crop, tab, blockIdx.x);
 }
 // The coefficient / index tables depend on the unit records only, the stage-0 histograms on the records and the source images:
 // one launch for both (blocks [0, chunks * nstat): histogram chunks; the next N blocks: one unit's tables each) instead of two
-// latency-bound kernels back to back.  2 * crop ints of table scratch fit the histogram's 12 KiB for crop <= 1536.
+// latency-bound kernels back to back.
 __global__ __launch_bounds__(256) void k_hist_tables(Bufs bufs, UnitRef ur, const int* __restrict__ ulist, int nstat, int chunks, int npix,
                                                      int Hs, int Ws, int crop, uint32_t* hist, int* tab) {
     __shared__ uint32_t sh[4][768];
     const int b = blockIdx.x, nh = chunks * nstat;
     if (b < nh) hist_body(bufs, ur, ulist, 0, npix, Hs, Ws, crop, hist, b % chunks, b / chunks, chunks, sh);
-    else tables_body(ur, Hs, Ws, crop, tab, b - nh, reinterpret_cast<int*>(&sh[0][0]));
+    else tables_body(ur, Hs, Ws, crop, tab, b - nh);
 }
 
 // With the pool's histograms cached by the caller, the stage-0 byte maps depend on the unit records and the cache only -- like the
-// tables: one launch for both (blocks [0, N): one unit's stage-0 map each; the next N: its tables).  crop <= 1536.
+// tables: one launch for both (blocks [0, N): one unit's stage-0 map each; the next N: its tables).
 __global__ __launch_bounds__(256) void k_lut_tables(UnitRef ur, int N, int npix, int Hs, int Ws, int crop, const uint32_t* pool_hist,
                                                     uint8_t* lut, int* tab) {
-    __shared__ int nn[2 * 1536];
     const int b = blockIdx.x;
     if (b < N) lut_body(ur, 0, N, b, npix, Hs, Ws, crop, pool_hist, pool_hist, pool_hist, lut);
-    else tables_body(ur, Hs, Ws, crop, tab, b - N, nn);
+    else tables_body(ur, Hs, Ws, crop, tab, b - N);
 }
 
 // The same with EVERY stage's map that does not wait for a pixel pass (blocks [0, N): unit u, stages in order -- a later stage's
@@ -599,10 +609,10 @@ __global__ __launch_bounds__(256) void k_lut_tables(UnitRef ur, int N, int npix,
 // unit b - N's tap tables; [2N, 3N): its NEAREST tables (a serial walk: own workgroup so that the taps do not wait behind it).
 __global__ __launch_bounds__(256) void k_luts_tables(UnitRef ur, int N, int max_ops, int npix, int Hs, int Ws, int crop,
                                                      const uint32_t* pool_hist, uint8_t* lut, int* tab, uint32_t* hist_zero) {
-    __shared__ double nn[2 * 1536];
+    __shared__ NnSegs nn[2];
     const int b = blockIdx.x;
     if (b >= 2 * N) {
-        tables_nn_body_wide(ur, Hs, Ws, crop, tab, b - 2 * N, nn);
+        tables_nn_body_closed(ur, Hs, Ws, crop, tab, b - 2 * N, nn);
         return;
     }
     if (b >= N) {
@@ -929,26 +939,39 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
     // Sharpness passes: wave <-> (64-column chunk, row segment), a lane walks DOWN its column with the horizontal 3-sums of the
     // previous / current / next row in registers: 3 LDS reads and ~50 instructions per pixel instead of 9 and ~80 (each pixel as the
     // centre of its own 3 x 3 gather).  Narrow patches split the rows so that all four waves have work.
-    const int nch = (pw + 63) >> 6;
+    // Work items: (64-column chunk, row segment) pairs dealt round-robin to the four waves.  A patch is typically 256 + 8 columns wide
+    // (the halo, rounded to groups of 4): its fifth chunk holds 8 live columns, and as a chunk of its own it DOUBLED the stencil time
+    // of the wave that got it (5 items on 4 waves; the wave-0 SIMD of a CU then carries twice the instructions of the others --
+    // the statistics pass of a stencil tile took ~20 us).  A last chunk of <= 32 columns is therefore folded: its lanes are
+    // (column, row segment) pairs -- 8 columns x 8 segments, 16 x 4 or 32 x 2 -- so that it costs rows / 8 .. rows / 2 (+ 2 halo rows).
+    const int nfull = pw >> 6, wlast = pw & 63;
+    const bool fold = wlast > 0 && wlast <= 32 && nfull > 0;
+    const int nch = fold ? nfull : (pw + 63) >> 6;
     const int nseg = nch >= 3 ? 1 : (nch == 2 ? 2 : 4);
     const int seg_rows = (ph + nseg - 1) / nseg;
     const int wvs = __builtin_amdgcn_readfirstlane(wv);
-    auto my_items = [&](auto body) {              // body(chunk, first row, end row) for the items of this wave
+    const int fshift = wlast <= 8 ? 3 : (wlast <= 16 ? 4 : 5);          // folded chunk: log2 of its padded width
+    const int frows = (ph + (64 >> fshift) - 1) >> (6 - fshift);        // rows per lane segment
+    auto my_items = [&](auto body) {              // body(column of this lane, first row, end row) for the items of this wave
         int it = 0;
         for (int sg = 0; sg < nseg; ++sg)
             for (int c = 0; c < nch; ++c, ++it)
                 if ((it & 3) == wvs) {
                     const int ra = sg * seg_rows, rb = min(ph, ra + seg_rows);
-                    if (ra < rb) body(c, ra, rb);
+                    if (ra < rb) body(64 * c + lane, ra, rb);
                 }
+        if (fold && (it & 3) == wvs) {
+            const int ra = (lane >> fshift) * frows, rb = min(ph, ra + frows);
+            body(64 * nfull + (lane & ((1 << fshift) - 1)), ra, rb);         // ra >= rb: nothing to do for this lane
+        }
     };
     while (j0 < nops) {                           // op j0 is a Sharpness stencil
         const float alpha = un.farg[j0];
         int j1 = j0 + 1;
         while (j1 < nops && !is_stencil(un, j1)) ++j1;
-        my_items([&](int c, int ra, int rb) {
-            const int col = 64 * c + lane;
-            const bool act = col < pw;
+        my_items([&](int col, int ra, int rb) {
+            const bool act = col < pw && ra < rb;
+            ra = min(ra, ph - 1);                                             // idle lanes of a folded chunk read in range
             const int cc = min(col, pw - 1), cm = max(cc - 1, 0), cp = min(cc + 1, pw - 1);
             const int x = c_lo + cc;
             const bool col_in = x > 0 && x < Ws - 1 && cc > 0 && cc < pw - 1;   // ImageFilter.SMOOTH copies the 1-pixel image border
@@ -979,8 +1002,7 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
         // the pointwise ops that follow run on the pixels this lane has just written: no barrier needed
         for (int j = j0 + 1; j < j1; ++j)
             dispatch_op(un, j, sl_all, [&](auto f) {
-                my_items([&](int c, int ra, int rb) {
-                    const int col = 64 * c + lane;
+                my_items([&](int col, int ra, int rb) {
                     if (col < pw)
                         for (int r = ra; r < rb; ++r) {
                             const int i = r * pw + col;
@@ -995,55 +1017,282 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
     return cur;
 }
 
-// k_hist_fused: grid (ceil(Ws/256), ceil(Hs/16), N); histogram of the image after `stage` ops (stage >= 1)
+// k_hist_fused: grid (ceil(Ws/256), ceil(Hs/16), units of the stage's statistics list); statistics of the image after `stage` ops
+// (stage >= 1) for the "late" units -- the ones whose statistics can neither come from the pool cache nor be pushed forward.
+//
+// Round 4.  The round-2/3 kernel rebuilt every 256 x 16 tile in LDS through build_patch and counted all three channels of every pixel
+// with LDS atomics whatever the op needed: 131 us per 168-unit batch at 1024 x 1024 (0.7 TB/s), 29 us at 512 x 512.  What the op in
+// slot `stage` reads decides the work now (uniform per workgroup):
+//   Contrast      only the sum of L (ImageStat mean of convert('L'))      -> per-lane sums, no histogram
+//   AutoContrast  only the smallest / largest value present per channel   -> per-lane min / max; the workgroup marks those two bins
+//                 (k_lut's AutoContrast branch reads nothing else of the histogram)
+//   Equalize      the per-channel histograms                               -> LDS atomics into 4 interleaved copies per bin
+// and what stands in front of it decides the data flow:
+//   no Sharpness stencil among ops [0, stage) (pointwise ops only: byte maps, Color, Cutout; 80 % of the late units, Contrast behind
+//   a byte map alone is 45 %): the tile is STREAMED -- 12-byte loads straight from the source image, the ops applied in registers,
+//   nothing staged in LDS, no barrier between load and count;
+//   with a stencil: the LDS patch (build_patch), as before.
+enum { ST_CONTRAST = 0, ST_AUTOCONTRAST = 1, ST_EQUALIZE = 2 };
+constexpr int HF_COPIES = 2;      // interleaved sub-histograms: lanes of a wave that hit one bin spread over 2 banks / addresses
+
+template <int KIND>
+struct StatAcc {
+    uint32_t lsum;
+    uint32_t lo_r, lo_g, lo_b, hi_r, hi_g, hi_b;
+    uint32_t* sh;
+    __device__ __forceinline__ StatAcc(uint32_t* sh_) : lsum(0), lo_r(255), lo_g(255), lo_b(255), hi_r(0), hi_g(0), hi_b(0),
+                                                        sh(sh_ + (threadIdx.x & (HF_COPIES - 1))) {}
+    __device__ __forceinline__ void add(uint32_t p) {
+        const uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u;
+        if (KIND == ST_CONTRAST) lsum += rgb2l(r, g, b);
+        else if (KIND == ST_AUTOCONTRAST) {
+            lo_r = min(lo_r, r); hi_r = max(hi_r, r); lo_g = min(lo_g, g); hi_g = max(hi_g, g); lo_b = min(lo_b, b); hi_b = max(hi_b, b);
+        } else {
+            atomicAdd(&sh[r * HF_COPIES], 1u); atomicAdd(&sh[(256 + g) * HF_COPIES], 1u); atomicAdd(&sh[(512 + b) * HF_COPIES], 1u);
+        }
+    }
+};
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    return v;
+}
+// the workgroup's result -> this unit's row of the stage's statistics (rows are zeroed by k_luts_tables).  `red`: 32 words of LDS.
+template <int KIND>
+__device__ __forceinline__ void stat_flush(StatAcc<KIND>& acc, uint32_t* sh, uint32_t* red, uint32_t* gh, bool any) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (KIND == ST_CONTRAST) {
+        const unsigned long long ws = wave_sum((unsigned long long)acc.lsum);
+        if (lane == 0) reinterpret_cast<unsigned long long*>(red)[wv] = ws;
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long* r64 = reinterpret_cast<const unsigned long long*>(red);
+            const unsigned long long t = r64[0] + r64[1] + r64[2] + r64[3];
+            if (t) atomicAdd(reinterpret_cast<unsigned long long*>(gh + 768), t);
+        }
+    } else if (KIND == ST_AUTOCONTRAST) {
+        uint32_t v[6] = {acc.lo_r, acc.lo_g, acc.lo_b, 255u - acc.hi_r, 255u - acc.hi_g, 255u - acc.hi_b};     // six minima
+#pragma unroll
+        for (int t = 0; t < 6; ++t) v[t] = wave_min_u32(v[t]);
+        if (lane == 0)
+#pragma unroll
+            for (int t = 0; t < 6; ++t) red[wv * 6 + t] = v[t];
+        __syncthreads();
+        if (tid < 6 && any) {
+            const uint32_t m = min(min(red[tid], red[6 + tid]), min(red[12 + tid], red[18 + tid]));
+            const int c = tid % 3;
+            const uint32_t bin = tid < 3 ? m : 255u - m;
+            atomicOr(&gh[256 * c + bin], 1u);           // a marker: AutoContrast's map depends on the occupied extremes only
+        }
+    } else {
+        __syncthreads();
+        for (int i = tid; i < 768; i += 256) {
+            const uint2 c2 = *reinterpret_cast<const uint2*>(&sh[i * HF_COPIES]);
+            const uint32_t v = c2.x + c2.y;
+            if (v) atomicAdd(&gh[i], v);
+        }
+    }
+}
+
+// A workgroup walks tiles blockIdx.x, blockIdx.x + G, ... of its unit (G = gridDim.x) with its counts in registers / LDS and adds them
+// to the unit's row ONCE: the first version flushed per tile, and the 64 (512 x 512) / 256 (1024 x 1024) workgroups of a unit then
+// queued on the same few words of its row -- device-scope atomics on one address complete ~0.35 us apart, which WAS the kernel's
+// duration (29 / 94 us).
+//
+// streamed tiles: rows [ry0, ry1) x columns [cx0, cx1) (cx0, cx1 multiples of 4), ops [0, stage) all pointwise; the next tile's loads
+// are in flight while the current tile is counted
+struct StatRegs { uint32_t a[4], b[4], c[4]; };
+__device__ __forceinline__ void stat_tile_bounds(int t, int tx, int Hs, int Ws, int& ry0, int& ry1, int& cx0, int& cx1) {
+    const int by = t / tx, bx = t - by * tx;
+    ry0 = by * 16; ry1 = min(ry0 + 16, Hs);
+    cx0 = bx * 256; cx1 = min(cx0 + 256, Ws);
+}
+__device__ __forceinline__ void stat_load_tile(StatRegs& r, const uint8_t* __restrict__ src, int Ws, int ry0, int ry1, int cx0, int cx1) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q4 = (cx1 - cx0) >> 2, ph = ry1 - ry0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = wv + 4 * k;
+        r.a[k] = r.b[k] = r.c[k] = 0;
+        if (row < ph && lane < q4) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(src + ((size_t)(ry0 + row) * Ws + cx0) * 3 + 12 * lane);
+            r.a[k] = p[0]; r.b[k] = p[1]; r.c[k] = p[2];
+        }
+    }
+}
+template <int KIND>
+__device__ __forceinline__ void stat_stream_unit(const aadg_unit& un, int stage, const uint8_t* __restrict__ src, int Hs, int Ws,
+                                                 const uint8_t* __restrict__ lut, size_t lut_stage_stride, int u,
+                                                 uint8_t* sl_all, uint32_t* sh, uint32_t* red, uint32_t* gh, int t0, int G) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tx = (Ws + 255) >> 8, ntiles = tx * ((Hs + 15) >> 4);
+    int t = t0;
+    if (t >= ntiles) return;
+    int ry0, ry1, cx0, cx1;
+    stat_tile_bounds(t, tx, Hs, Ws, ry0, ry1, cx0, cx1);
+    StatRegs cur;
+    stat_load_tile(cur, src, Ws, ry0, ry1, cx0, cx1);
+    bool any_lut = false;
+#pragma unroll
+    for (int j = 0; j < AADG_MAX_OPS; ++j)
+        if (j < stage && needs_lds_lut(un.op[j])) {
+            any_lut = true;
+            if (tid < 192) reinterpret_cast<uint32_t*>(sl_all + j * 768)[tid] =
+                reinterpret_cast<const uint32_t*>(lut + (size_t)j * lut_stage_stride + (size_t)u * 768)[tid];
+        }
+    if (KIND == ST_EQUALIZE)
+        for (int i = tid; i < 768 * HF_COPIES; i += 256) sh[i] = 0;
+    if (any_lut || KIND == ST_EQUALIZE) __syncthreads();
+    StatAcc<KIND> acc(sh);
+    while (true) {
+        const int tn = t + G;
+        int ny0 = 0, ny1 = 0, nx0 = 0, nx1 = 0;
+        StatRegs nxt;
+        if (tn < ntiles) {                                   // uniform
+            stat_tile_bounds(tn, tx, Hs, Ws, ny0, ny1, nx0, nx1);
+            stat_load_tile(nxt, src, Ws, ny0, ny1, nx0, nx1);
+        }
+        uint32_t px[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t a = cur.a[k], b = cur.b[k], c = cur.c[k];
+            px[k][0] = a & 0xFFFFFFu; px[k][1] = (a >> 24) | ((b & 0xFFFFu) << 8);
+            px[k][2] = (b >> 16) | ((c & 0xFFu) << 16); px[k][3] = c >> 8;
+        }
+        for (int j = 0; j < stage; ++j)
+            dispatch_op(un, j, sl_all, [&](auto f) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) px[k][q] = f(px[k][q], ry0 + wv + 4 * k, cx0 + 4 * lane + q);
+            });
+        const int q4 = (cx1 - cx0) >> 2, ph = ry1 - ry0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (wv + 4 * k < ph && lane < q4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc.add(px[k][q]);
+            }
+        if (tn >= ntiles) break;
+        t = tn; ry0 = ny0; ry1 = ny1; cx0 = nx0; cx1 = nx1; cur = nxt;
+    }
+    stat_flush<KIND>(acc, sh, red, gh, true);
+}
+
+// tiles behind a Sharpness stencil: the image after `stage` ops is rebuilt in LDS (halo of one pixel per stencil)
+template <int KIND>
+__device__ __forceinline__ void stat_patch_unit(const aadg_unit& un, int stage, int s, const uint8_t* __restrict__ src, int Hs, int Ws,
+                                                uint32_t* A, uint32_t* B, const uint8_t* __restrict__ lut,
+                                                size_t lut_stage_stride, int u, uint8_t* sl_all, uint32_t* sh, uint32_t* red, uint32_t* gh,
+                                                int t0, int G) {
+    const int tid = threadIdx.x;
+    const int tx = (Ws + 255) >> 8, ntiles = tx * ((Hs + 15) >> 4);
+    if (t0 >= ntiles) return;
+    if (KIND == ST_EQUALIZE)
+        for (int i = tid; i < 768 * HF_COPIES; i += 256) sh[i] = 0;      // build_patch's barriers order this before the counting
+    StatAcc<KIND> acc(sh);
+    for (int t = t0; t < ntiles; t += G) {
+        int ry0, ry1, cx0, cx1;
+        stat_tile_bounds(t, tx, Hs, Ws, ry0, ry1, cx0, cx1);
+        const int r_lo = max(0, ry0 - s), r_hi = min(Hs, ry1 + s);
+        const int c_lo = max(0, cx0 - s) & ~3, c_hi = min(Ws, (cx1 + s + 3) & ~3);
+        if (t != t0) __syncthreads();                         // the previous tile's readers are done with A / B
+        const uint32_t* cur = build_patch<6, 1>(un, stage, src, Hs, Ws, r_lo, r_hi, c_lo, c_hi, A, B, lut, lut_stage_stride, u, sl_all);
+        const int pw = c_hi - c_lo, rw = cx1 - cx0, n = (ry1 - ry0) * rw;
+        const uint32_t* origin = cur + (ry0 - r_lo) * pw + (cx0 - c_lo);
+        if (KIND == ST_EQUALIZE) {
+            // Neighbouring pixels of a smooth image fall into the same bins, and LDS atomics of one wave on one address serialise: the
+            // lanes of a wave take pixels 97 positions apart (97 is prime: a bijection of [0, n) unless 97 divides n); the running index
+            // advances by (256 * stride) mod n -- no division per pixel; a full-width tile splits it by a shift
+            const int stride = (n % 97) ? 97 : 1;
+            const int step = (int)((256u * (unsigned)stride) % (unsigned)n);
+            int i = (int)(((unsigned)tid * (unsigned)stride) % (unsigned)n);
+            if (rw == 256) {
+#pragma unroll 4
+                for (int i0 = tid; i0 < n; i0 += 256, i += step, i -= i >= n ? n : 0) acc.add(origin[(i >> 8) * pw + (i & 255)]);
+            } else {
+                for (int i0 = tid; i0 < n; i0 += 256, i += step, i -= i >= n ? n : 0) {
+                    const int row = i / rw;
+                    acc.add(origin[row * pw + (i - row * rw)]);
+                }
+            }
+        } else {
+            // sums / extremes: plain row-major reads (conflict-free), wave <-> rows wave, wave + 4, ...
+            const int lane = tid & 63, wv = tid >> 6;
+            for (int row = wv; row < ry1 - ry0; row += 4)
+#pragma unroll 4
+                for (int col = lane; col < rw; col += 64) acc.add(origin[row * pw + col]);
+        }
+    }
+    stat_flush<KIND>(acc, sh, red, gh, true);
+}
+
+constexpr int HF_PATCH = 5280;        // 20 rows (16 + two stencil halos) x 264 columns (256 + halos, rounded to groups of 4)
+// 1-D grid.  The first n_sten entries of the list are units with a stencil in front of the op (aadg_aug_u8_plan puts them first): each
+// of their tiles is a workgroup of its own (workgroups [0, n_sten * tiles): the long work is dispatched first); the other units get G
+// workgroups each that walk their tiles with stride G.  (All units handled like the second kind: a stencil unit's 256 tiles behind
+// ~30 workgroups were the long pole of the launch -- 129 us against 94 us per 1024 x 1024 batch.)
 __global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ pool, const aadg_unit* __restrict__ units,
-                                                    const int* __restrict__ ulist, int stage, int Hs, int Ws, int crop,
+                                                    const int* __restrict__ ulist, int n_sten, int G, int stage, int Hs, int Ws, int crop,
                                                     const uint8_t* __restrict__ lut, size_t lut_stage_stride, uint32_t* hist) {
-    const int u = ulist != nullptr ? ulist[blockIdx.z] : blockIdx.z;      // ulist: the units whose op `stage` needs statistics
+    const int ntiles = ((Ws + 255) >> 8) * ((Hs + 15) >> 4);
+    int id = blockIdx.x, slot, t0, stride;
+    if (id < n_sten * ntiles) {
+        slot = id / ntiles; t0 = id - slot * ntiles; stride = ntiles;
+    } else {
+        id -= n_sten * ntiles;
+        slot = id / G; t0 = id - slot * G; stride = G; slot += n_sten;
+    }
+    const int u = ulist != nullptr ? ulist[slot] : slot;          // ulist: the units whose op `stage` needs statistics
     const aadg_unit& un = units[u];
     if (un.n_ops <= stage || !op_needs_stats(un.op[stage]) || !unit_fusable(true, un, Hs, Ws, crop)) return;
     if (stats_by_pushforward(un, stage, true)) return;            // k_lut derives this stage's histogram from the raw one
-    __shared__ __attribute__((aligned(16))) uint32_t A[5632];
-    __shared__ __attribute__((aligned(16))) uint32_t B[5632];
+    __shared__ __attribute__((aligned(16))) uint32_t A[HF_PATCH];
+    __shared__ __attribute__((aligned(16))) uint32_t B[HF_PATCH];
     __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
-    __shared__ uint32_t sh[768];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 768; i += 256) sh[i] = 0;
-    const int ry0 = blockIdx.y * 16, ry1 = min(ry0 + 16, Hs);
-    const int cx0 = blockIdx.x * 256, cx1 = min(cx0 + 256, Ws);
+    __shared__ __attribute__((aligned(16))) uint32_t red[32];
+    __shared__ __attribute__((aligned(16))) uint32_t shx[768 * HF_COPIES];      // Equalize: accumulates over the workgroup's tiles
     const int s = sharp_count(un, stage);
-    const int r_lo = max(0, ry0 - s), r_hi = min(Hs, ry1 + s);
-    const int c_lo = max(0, cx0 - s) & ~3, c_hi = min(Ws, (cx1 + s + 3) & ~3);
     const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
-    const uint32_t* cur = build_patch<6, 1>(un, stage, src, Hs, Ws, r_lo, r_hi, c_lo, c_hi, A, B, lut, lut_stage_stride, u, sl);
-    const int pw = c_hi - c_lo, rw = cx1 - cx0, n = (ry1 - ry0) * rw;
-    uint32_t lsum32 = 0;                                  // <= 64 pixels per thread x 255
-    // Neighbouring pixels of a smooth image fall into the same bins, and LDS atomics of one wave on one address serialise: the
-    // lanes of a wave therefore take pixels 97 positions apart (97 is prime: a bijection of [0, n) unless 97 divides n)
-    // (index arithmetic without a division per pixel: the running index advances by (256 * stride) mod n; a full-width tile splits it by a shift)
-    const int stride = (n % 97) ? 97 : 1;
-    const int step = (int)((256u * (unsigned)stride) % (unsigned)n);
-    int i = (int)(((unsigned)tid * (unsigned)stride) % (unsigned)n);
-    const uint32_t* origin = cur + (ry0 - r_lo) * pw + (cx0 - c_lo);
-    auto count = [&](uint32_t p) {
-        const uint32_t r = p & 255, g = (p >> 8) & 255, b = (p >> 16) & 255;
-        atomicAdd(&sh[r], 1u); atomicAdd(&sh[256 + g], 1u); atomicAdd(&sh[512 + b], 1u);
-        lsum32 += rgb2l(r, g, b);
-    };
-    if (rw == 256) {                                      // uniform: full-width tile, the index splits by a shift
-#pragma unroll 4
-        for (int i0 = tid; i0 < n; i0 += 256, i += step, i -= i >= n ? n : 0) count(origin[(i >> 8) * pw + (i & 255)]);
-    } else {
-        for (int i0 = tid; i0 < n; i0 += 256, i += step, i -= i >= n ? n : 0) {
-            const int row = i / rw;
-            count(origin[row * pw + (i - row * rw)]);
-        }
-    }
-    unsigned long long lsum = wave_sum((unsigned long long)lsum32);
-    __syncthreads();
     uint32_t* gh = hist + (size_t)u * HIST_STRIDE;
-    for (int i = tid; i < 768; i += 256) if (sh[i]) atomicAdd(&gh[i], sh[i]);
-    if ((tid & 63) == 0 && lsum) atomicAdd(reinterpret_cast<unsigned long long*>(gh + 768), lsum);
+    const int op = un.op[stage];
+    if (s == 0) {
+        if (op == AADG_OP_CONTRAST) stat_stream_unit<ST_CONTRAST>(un, stage, src, Hs, Ws, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride);
+        else if (op == AADG_OP_AUTOCONTRAST) stat_stream_unit<ST_AUTOCONTRAST>(un, stage, src, Hs, Ws, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride);
+        else stat_stream_unit<ST_EQUALIZE>(un, stage, src, Hs, Ws, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride);
+    } else {
+        if (op == AADG_OP_CONTRAST) stat_patch_unit<ST_CONTRAST>(un, stage, s, src, Hs, Ws, A, B, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride);
+        else if (op == AADG_OP_AUTOCONTRAST) stat_patch_unit<ST_AUTOCONTRAST>(un, stage, s, src, Hs, Ws, A, B, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride);
+        else stat_patch_unit<ST_EQUALIZE>(un, stage, s, src, Hs, Ws, A, B, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride);
+    }
+}
+// launch of the statistics pass of one stage: nstat list entries, the first n_sten of them stencil units (n_sten = nstat: no list
+// order known -- every unit's tiles get their own workgroups)
+static inline int launch_hist_fused(const uint8_t* pool, const aadg_unit* units, const int* ulist, int nstat, int n_sten, int stage, int Hs,
+                                    int Ws, int crop, const uint8_t* lut, size_t lut_stage_stride, uint32_t* hist, hipStream_t st) {
+    const int ntiles = ((Ws + 255) / 256) * ((Hs + 15) / 16);
+    const int n_rest = nstat - n_sten;
+    // the other units: enough workgroups to fill what the stencil tiles leave of the chip's 768 slots (3 per CU), and never more than
+    // 8 tiles per workgroup (a stencil tile takes ~15 us, a streamed one ~1.5: the walkers must not outlast the stencil tiles --
+    // with 8 workgroups per unit, 32 tiles each at 1024 x 1024, they did: 149 us per batch)
+    int G = 1;
+    if (n_rest > 0) {
+        const long long room = 768 - (long long)n_sten * ntiles;
+        G = (int)((room > 0 ? room : 0) / n_rest);
+        const int g_min = (ntiles + 7) / 8;
+        G = G < g_min ? g_min : G;
+        G = G > ntiles ? ntiles : G;
+    }
+    const long long grid = (long long)n_sten * ntiles + (long long)n_rest * G;
+    if (grid <= 0 || grid > 0x7FFFFFFFll) return AADG_E_BADARG;
+    hipLaunchKernelGGL(k_hist_fused, dim3((unsigned)grid), dim3(256), 0, st, pool, units, ulist, n_sten, G, stage, Hs, Ws, crop, lut, lut_stage_stride, hist);
+    AADG_LAUNCH_CHECK();
+    return 0;
 }
 
 // np.float32(v) / 127.5 - 1.0 for an integer 0 <= v <= 255, bit-exact without a division: one Newton step on
@@ -2100,7 +2349,7 @@ int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int c
         const int nstat = ulist != nullptr ? lists->n_stat[k] : N;
         uint32_t* hist = hist0 + (size_t)k * hist_stage;
         if (k == 0 && pool_hist != nullptr) {
-            if (tab != nullptr && crop <= 1536) {
+            if (tab != nullptr) {
                 hipLaunchKernelGGL(k_lut_tables, dim3(2 * N), dim3(256), 0, st, ur, N, npix, Hs, Ws, crop, pool_hist, lut, tab);
                 AADG_LAUNCH_CHECK();
                 *tables_done = true;
@@ -2111,7 +2360,7 @@ int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int c
                 continue;
             }
         } else if ((stats_mask & (1 << k)) && nstat > 0) {
-            if (k == 0 && tab != nullptr && 2 * crop <= 4 * 768) {
+            if (k == 0 && tab != nullptr) {
                 // stage-0 histograms and the resampling tables in one launch
                 hipLaunchKernelGGL(k_hist_tables, dim3(g.x * nstat + N), dim3(256), 0, st, bufs, ur, ulist, nstat, (int)g.x, npix, Hs, Ws,
                                    crop, hist, tab);
@@ -2122,9 +2371,9 @@ int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int c
                 AADG_LAUNCH_CHECK();
             }
             if (k > 0 && (classes & (HINT_FUSED | HINT_GENERIC))) {
-                const dim3 gf((Ws + 255) / 256, (Hs + 15) / 16, nstat);
-                hipLaunchKernelGGL(k_hist_fused, gf, dim3(256), 0, st, bufs.pool, ur.units, ulist, k, Hs, Ws, crop, lut, lut_stage_stride, hist);
-                AADG_LAUNCH_CHECK();
+                const int n_sten = (ulist != nullptr && lists->n_stat_stencil[k] >= 0 && lists->n_stat_stencil[k] <= nstat) ? lists->n_stat_stencil[k] : nstat;
+                const int rc = launch_hist_fused(bufs.pool, ur.units, ulist, nstat, n_sten, k, Hs, Ws, crop, lut, lut_stage_stride, hist, st);
+                if (rc) return rc;
             }
         }
         hipLaunchKernelGGL(k_lut, dim3(N), dim3(256), 0, st, ur, k, N, (const int*)nullptr, npix, Hs, Ws, crop, (const uint32_t*)hist0,
@@ -2176,9 +2425,9 @@ int forward_cached(const uint8_t* pool, const uint8_t* masks, const UnitRef& ur,
         for (int k = 1; k < max_ops; ++k) {
             uint32_t* hist = hist0 + (size_t)k * hist_stage;
             if (((stats_mask >> k) & 1) && ls.n_stat[k] > 0) {
-                const dim3 gf((Ws + 255) / 256, (Hs + 15) / 16, ls.n_stat[k]);
-                hipLaunchKernelGGL(k_hist_fused, gf, dim3(256), 0, st, pool, ur.units, ls.stat_units[k], k, Hs, Ws, crop, lut, lut_stage_stride, hist);
-                AADG_LAUNCH_CHECK();
+                const int rc = launch_hist_fused(pool, ur.units, ls.stat_units[k], ls.n_stat[k], ls.n_stat_stencil[k], k, Hs, Ws, crop, lut,
+                                                 lut_stage_stride, hist, st);
+                if (rc) return rc;
             }
             hipLaunchKernelGGL(k_lut, dim3(n_late), dim3(256), 0, st, ur, k, N, ls.late_units, npix, Hs, Ws, crop, (const uint32_t*)hist0,
                                (const uint32_t*)hist, ls.pool_hist, lut);
@@ -2202,19 +2451,22 @@ extern "C" int aadg_aug_u8_plan(const aadg_unit* units, int N, int P, int Hs, in
     if (units == nullptr || order == nullptr || stat_units == nullptr || late_units == nullptr || summary == nullptr) return AADG_E_BADARG;
     if (N <= 0 || P <= 0 || Hs <= 0 || Ws <= 0 || crop <= 0) return AADG_E_BADARG;
     const bool tiles_ok = !((Ws & 3) || (crop & 3));
-    int n_cls[5] = {0, 0, 0, 0, 0}, n_stat[AADG_MAX_OPS], n_late = 0, max_ops = 0, classes = 0, stats_mask = 0;
-    for (int k = 0; k < AADG_MAX_OPS; ++k) n_stat[k] = 0;
+    int n_cls[5] = {0, 0, 0, 0, 0}, n_stat[AADG_MAX_OPS], n_sten[AADG_MAX_OPS], n_late = 0, max_ops = 0, classes = 0, stats_mask = 0;
+    for (int k = 0; k < AADG_MAX_OPS; ++k) n_stat[k] = n_sten[k] = 0;
     // pass 1: validation, class and statistics lists (late_units doubles as the per-unit class until the counting sort below)
     for (int i = 0; i < N; ++i) {
         const aadg_unit& u = units[i];
         if (u.src < 0 || u.src >= P || u.n_ops < 0 || u.n_ops > AADG_MAX_OPS) return AADG_E_BADARG;
         if (u.scaled_w < 1 || u.scaled_h < 1 || (long long)u.scaled_w * 3 < Ws || (long long)u.scaled_h * 3 < Hs) return AADG_E_BADARG;
         int sharp = 0;
+        int sharp_before[AADG_MAX_OPS];             // Sharpness stencils among ops [0, k)
+        for (int k = 0; k < AADG_MAX_OPS; ++k) sharp_before[k] = 0;
         for (int k = 0; k < u.n_ops; ++k) {
             const int op = u.op[k];
             if (op < 0 || op >= AADG_OP_COUNT) return AADG_E_BADARG;
             if (op == AADG_OP_CUTOUT && (u.rect[k][0] < 0 || u.rect[k][1] < 0 || u.rect[k][2] >= Ws || u.rect[k][3] >= Hs)) return AADG_E_BADARG;
             if (op == AADG_OP_POSTERIZE && (u.iarg[k] < 0 || u.iarg[k] > 8)) return AADG_E_BADARG;
+            sharp_before[k] = sharp;
             if (op == AADG_OP_SHARPNESS && u.farg[k] != 1.0f) ++sharp;
         }
         if (u.n_ops > max_ops) max_ops = u.n_ops;
@@ -2243,10 +2495,28 @@ extern "C" int aadg_aug_u8_plan(const aadg_unit* units, int N, int P, int Hs, in
         for (int k = 0; k < AADG_MAX_OPS; ++k)
             if (pass[k]) {
                 stat_units[(size_t)k * N + n_stat[k]++] = i;
+                if (sharp_before[k] > 0) ++n_sten[k];
                 stats_mask |= 1 << k;
                 late = late || k >= 1;
             }
         late_units[i] = cls | (late ? 8 : 0);
+    }
+    // slot k's list: the units with a Sharpness stencil in front of the op FIRST (k_hist_fused gives each of their tiles a workgroup of
+    // its own), the others behind them; both parts keep the ascending unit order (stable partition; mixed lists are rare)
+    for (int k = 1; k < AADG_MAX_OPS; ++k) {
+        if (n_sten[k] == 0 || n_sten[k] == n_stat[k]) continue;
+        int32_t* row = stat_units + (size_t)k * N;
+        std::vector<int32_t> rest;
+        rest.reserve((size_t)(n_stat[k] - n_sten[k]));
+        int w = 0;
+        for (int t = 0; t < n_stat[k]; ++t) {
+            const aadg_unit& u = units[row[t]];
+            int sb = 0;
+            for (int j = 0; j < k; ++j) sb += (u.op[j] == AADG_OP_SHARPNESS && u.farg[j] != 1.0f) ? 1 : 0;
+            if (sb > 0) row[w++] = row[t];
+            else rest.push_back(row[t]);
+        }
+        for (size_t t = 0; t < rest.size(); ++t) row[w++] = rest[t];
     }
     // pass 2: stable counting sort by class; the late list in place (its write position never passes the read position)
     int off[5];
@@ -2260,6 +2530,7 @@ extern "C" int aadg_aug_u8_plan(const aadg_unit* units, int N, int P, int Hs, in
     summary[0] = n_cls[0]; summary[1] = n_cls[1]; summary[2] = n_cls[2] + n_cls[3]; summary[3] = n_cls[3];
     summary[4] = n_late; summary[5] = classes; summary[6] = stats_mask; summary[7] = max_ops;
     for (int k = 0; k < AADG_MAX_OPS; ++k) summary[8 + k] = n_stat[k];
+    for (int k = 0; k < AADG_MAX_OPS; ++k) summary[8 + AADG_MAX_OPS + k] = n_sten[k];
     return 0;
 }
 
@@ -2286,7 +2557,8 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
     const int n_plain = lists ? lists->n_plain : 0, n_sharp = lists ? lists->n_sharp : 0, n_generic = lists ? lists->n_generic : 0;
     if (lists != nullptr)
         for (int k = 0; k < AADG_MAX_OPS; ++k)
-            if (lists->n_stat[k] < 0 || lists->n_stat[k] > N || (lists->n_stat[k] > 0 && lists->stat_units[k] == nullptr)) return AADG_E_BADARG;
+            if (lists->n_stat[k] < 0 || lists->n_stat[k] > N || (lists->n_stat[k] > 0 && lists->stat_units[k] == nullptr) ||
+                lists->n_stat_stencil[k] < 0 || lists->n_stat_stencil[k] > lists->n_stat[k]) return AADG_E_BADARG;
     if (!pool || !masks || !units || !out_img || !out_lbl || !ws) return AADG_E_BADARG;
     if (P <= 0 || Hs <= 0 || Ws <= 0 || N <= 0 || crop <= 0) return AADG_E_BADARG;
     if (max_ops < 0 || max_ops > AADG_MAX_OPS) return AADG_E_BADARG;
@@ -2313,7 +2585,7 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
     if (stats_mask & ~1) stats_mask |= 1;      // a later stage's statistics may be pushed forward from the raw image's histogram
     int* tab = reinterpret_cast<int*>(ws8 + L.tab);
     if (lists != nullptr && lists->pool_hist != nullptr && lists->late_units != nullptr && order != nullptr &&
-        lists->stat_units[0] != nullptr && !(classes & HINT_STAGED) && crop <= 1536)
+        lists->stat_units[0] != nullptr && !(classes & HINT_STAGED))
         return forward_cached(pool, masks, ur, N, Hs, Ws, max_ops, crop, dataset, out_img, out_lbl, ws8, L, st, classes, stats_mask,
                               ev_before_final, ev_after_final, *lists);
     bool tables_done = false;
@@ -2321,7 +2593,7 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
                         (lists != nullptr && lists->stat_units[0] != nullptr) ? lists : nullptr, tab, &tables_done, lists);
     if (rc) return rc;
     if (!tables_done) {
-        hipLaunchKernelGGL(k_tables, dim3(N), dim3(256), 2 * crop * sizeof(int), st, ur, Hs, Ws, crop, tab);
+        hipLaunchKernelGGL(k_tables, dim3(N), dim3(256), 0, st, ur, Hs, Ws, crop, tab);
         AADG_LAUNCH_CHECK();
     }
     if (ev_before_final) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_before_final), st));

@@ -295,12 +295,11 @@ def cpu_baseline(pools, cfg, st, a):
         total = [x + yv + r + c for x, yv, r, c in zip(ta, tl, t_rew, t_ctl)]
         legs[w] = {"workers": w, "steps_per_s": 1.0 / float(np.median(total)),
                    "seconds_per_step": _stats(total), "augment_s": _stats(ta), "loss_s": _stats(tl),
-                   "sample": "%d of %d augmentation units, BCE/Dice on %d of %d images, scaled to the batch" % (n_aug, n_all, n_loss, n_all)}
+                   "sample": "%d of %d augmentation units, BCE/Dice on %d of %d images, scaled" % (n_aug, n_all, n_loss, n_all)}
     top = legs[pools.sizes[0]]
-    return {"value": top["steps_per_s"], "unit": "hot-path steps/s (controller sample + PPO, augmentation, Sinkhorn reward, BCE/Dice of one "
-                                                 "%d-image batch; backbone excluded)" % n_all,
+    return {"value": top["steps_per_s"], "unit": "hot-path steps/s (controller + augmentation + Sinkhorn + BCE/Dice of a %d-image batch; no backbone)" % n_all,
             "cores": pools.sizes[0], "host_cores_available": pools.cores, "host_cpu_quota": pools.quota, "kind": "port", "repeats": R,
-            "sample": "W = %d worker processes: %s; reward: %d Sinkhorn problems in one process; controller: eager torch-CPU"
+            "sample": "W = %d processes: %s; %d Sinkhorn problems + eager torch-CPU controller in one process"
                       % (pools.sizes[0], top["sample"], M * D * (D - 1) // 2),
             "seconds_per_step": top["seconds_per_step"], "augment_s": top["augment_s"], "loss_s": top["loss_s"],
             "reward_s": _stats(t_rew), "controller_s": _stats(t_ctl),
@@ -606,9 +605,12 @@ def hot_kernels_leg(D=3, B=8, M=6, size=512, K=2, repeats=20):
 
 
 
-def rvs_1024_leg(n_units=144, size=1024):
+def rvs_1024_leg(n_units=144, size=1024, cfg_rel=os.path.join("experiments", "rvs_sinkhorn", "diversity_ex.yaml"), K=1,
+                 label="BASELINE configs[2]"):
     """BASELINE configs[2] on the hot path: the RVS pipeline of experiments/rvs_sinkhorn/diversity_ex.yaml (DGRandomScaleCrop
-    scale range [0.5, 2], vessel masks, K = 1) with 1024 x 1024 crops from 1024 x 1024 sources, D3 B8 M6 = 144 units."""
+    scale range [0.5, 2], vessel masks, K = 1) with 1024 x 1024 crops from 1024 x 1024 sources, D3 B8 M6 = 144 units.
+    (--only_legs aug512: the same loop on BASELINE configs[1]'s pipeline -- 512 x 512, scale range [1, 1.5], K = 2 -- the
+    rocprofv3 target for the 512 x 512 augmentation call without the backbone around it.)"""
     import torch
     from aadg_amd import _lib
     from aadg_amd.config.defaults import get_default_config
@@ -617,7 +619,7 @@ def rvs_1024_leg(n_units=144, size=1024):
     from aadg_amd.data.policy import DGMultiPolicy, parse_policies
     cfg = get_default_config()
     cfg.defrost()
-    cfg.merge_from_file(os.path.join(ROOT, "experiments", "rvs_sinkhorn", "diversity_ex.yaml"))
+    cfg.merge_from_file(os.path.join(ROOT, cfg_rel))
     cfg.SEED = 1023
     cfg.freeze()
     args = Args()
@@ -652,12 +654,12 @@ def rvs_1024_leg(n_units=144, size=1024):
     units = T.refs_to_units(refs)
     Hs = loader.dataset.pool.images.shape[1]
     n_flow = _lib.launch_hints(units, Hs, Hs, size)[3]
-    kb = unit_bytes(units, Hs, Hs, size, 1, False)
-    sb = unit_bytes(units, Hs, Hs, size, 1, True)
+    kb = unit_bytes(units, Hs, Hs, size, K, False)
+    sb = unit_bytes(units, Hs, Hs, size, K, True)
     k_ms, c_ms = float(np.mean([p[0].elapsed_time(p[1]) for p in kp])), float(np.mean([p[0].elapsed_time(p[1]) for p in cp]))
-    tr = committed("r03_rvs1024_traffic.json")
-    return {"workload": "BASELINE configs[2]: experiments/rvs_sinkhorn/diversity_ex.yaml pipeline, %dx%d crops from %dx%d sources, "
-                        "%d units per batch (hot path only: augmentation call)" % (size, size, Hs, Hs, len(units)),
+    tr = (committed("r04_rvs1024_traffic.json") or committed("r03_rvs1024_traffic.json")) if size == 1024 else None
+    return {"workload": "%s: %s pipeline, %dx%d crops from %dx%d sources, "
+                        "%d units per batch (hot path only: augmentation call)" % (label, cfg_rel, size, size, Hs, Hs, len(units)),
             "units": len(units), "units_by_tile_kernel": {"up_plain": n_flow[0], "up_sharpness": n_flow[1], "generic_downscale": n_flow[2],
                                                           "generic_with_sharpness": n_flow[3],
                                                           "staged": len(units) - sum(n_flow[:3])},
@@ -755,6 +757,9 @@ def only_legs_main(a):
             out["kernels"] = hot_kernels_leg()
         elif leg == "rvs1024":
             out["rvs_1024"] = rvs_1024_leg()
+        elif leg == "aug512":
+            out["aug_512"] = rvs_1024_leg(size=512, cfg_rel=os.path.join("experiments", "optic_sinkhorn", "diversity.yaml"), K=2,
+                                          label="BASELINE configs[1]")
         else:
             raise SystemExit("--only_legs: unknown leg %r" % leg)
     print(json.dumps(out), flush=True)
@@ -915,17 +920,33 @@ def main():
     hot_ms = (time.perf_counter() - t0) / HK * 1e3
     hot_kern_ms = sum(p[0].elapsed_time(p[1]) for p in hk_pairs) / HK
     hot_call_ms = sum(p[2].elapsed_time(p[3]) for p in hk_pairs) / HK
-    # a second pass with events around every stage: where the GPU time of a hot-path step goes, and what is left for the host
+    # a second pass with events around every stage: the GPU time of each stage's kernels.  The host is the slower side of this loop, so
+    # every stage is queued behind a blocker (a spin kernel of ~3 ms, torch.cuda._sleep): the stage's launches are all enqueued while
+    # the blocker runs and then execute back to back -- the event pair (recorded behind the blocker / behind the last launch) brackets
+    # kernel time only, not the host's draws and launch calls.
+    cyc = 1 << 20
+    e0, e1 = ev(), ev()
+    torch.cuda._sleep(cyc); sync()
+    e0.record(); torch.cuda._sleep(cyc); e1.record(); sync()
+    cyc = max(1 << 16, int(cyc * 3.0 / max(e0.elapsed_time(e1), 1e-3)))       # ~3 ms
     HS = 10
     smarks = [[ev() for _ in range(2 * len(STAGES))] for _ in range(HS)]
     for row in smarks:
         for e in row:
             e.record()
     sync()
+
+    class _Blocked(list):
+        """marks whose even entries (stage starts) are recorded behind a fresh blocker"""
+        def __getitem__(self, k):
+            e = list.__getitem__(self, k)
+            if k % 2 == 0:
+                torch.cuda._sleep(cyc)
+            return e
     for i in range(HS):
-        hot_step(smarks[i])
+        hot_step(_Blocked(smarks[i]))
     sync()
-    stage_ms = {name: float(np.mean([row[2 * k].elapsed_time(row[2 * k + 1]) for row in smarks])) for k, name in enumerate(STAGES)}
+    stage_ms = {name: float(np.median([row[2 * k].elapsed_time(row[2 * k + 1]) for row in smarks])) for k, name in enumerate(STAGES)}
     hot_gpu_ms = float(sum(stage_ms.values()))
 
     # bytes of one launch (this rank's slice of one batch plan): the tile kernel's own, and SURVEY 8(d)'s for the whole call
@@ -971,13 +992,10 @@ def main():
                             "kernel_ms": hot_kern_ms, "kernel_frac": kbytes / (hot_kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "stage_ms": hot_call_ms, "stage_frac": call_bytes / (hot_call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "what": "controller sample + parse + draw + augmentation call + BCE/Dice kernel (fwd + bwd) + Sinkhorn kernel + "
-                                    "reward normalise + PPO update; backbone and discriminator removed.  gpu_ms = HIP events around each "
-                                    "stage's launches (separate pass), host_ms = the rest of the wall time per step (policy D2H wait, draws, "
-                                    "plan, launches)"}
-        roof["stage"] = {"what": "algorithmic bytes of the whole augmentation call / events around ALL its kernels (k_luts_tables, k_hist_fused, "
-                                 "k_lut, tile kernels); source counted once: the raw images' statistics come from the per-pool cache "
-                                 "(aadg_pool_histograms_u8, computed once per resident pool outside the timed call; --no_pool_stats times "
-                                 "the per-call variant and prices the source twice, SURVEY 8(d))",
+                                    "reward normalise + PPO update; backbone and discriminator removed.  gpu_ms = kernel time of the stages "
+                                    "(events behind a blocker kernel, separate pass), host_ms = wall time per step minus that"}
+        roof["stage"] = {"what": "bytes of the whole augmentation call / events around ALL its kernels; source counted once (pool statistics "
+                                 "cached per resident pool; --no_pool_stats = per-call variant, source priced twice as SURVEY 8(d))",
                          "bytes": call_bytes, "ms": call_ms, "achieved": call_bytes / (call_ms * 1e-3) / 1e9,
                          "frac": call_bytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "frac_survey_8d_bytes": sbytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -1099,6 +1117,18 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["fp32_backbone"] = {"error": repr(e)}
     if rank == 0:
+        # the prose of the extra legs (what a figure replaces, how it was taken) goes to the detail file: the line stays below 8 KB
+        def strip(obj, prefix):
+            if isinstance(obj, dict):
+                for k in list(obj):
+                    v = obj[k]
+                    if isinstance(v, str) and len(v) > 64 and k in ("replaces", "note", "what", "workload", "bound", "rocprof", "traffic_source", "kernel"):
+                        detail[prefix + "." + k] = obj.pop(k)
+                    else:
+                        strip(v, prefix + "." + k)
+        for leg in ("float_ops", "kernels", "rvs_1024", "precision", "fp32_backbone"):
+            if leg in out:
+                strip(out[leg], leg)
         path = a.detail
         if path is None and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
             path = os.path.join(ROOT, "gpurun_out", "bench_detail.json")

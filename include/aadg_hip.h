@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AADG_ABI_VERSION 6
+#define AADG_ABI_VERSION 7
 #define AADG_MAX_OPS 4
 
 #define AADG_E_BADARG (-1)
@@ -129,6 +129,10 @@ typedef struct aadg_aug_lists {
     const int32_t* late_units;
     int32_t n_late;
     int32_t n_generic_sharp;   /* ABI 5: how many of the n_generic units (the last ones in `order`) chain a Sharpness stencil */
+    /* ABI 7: how many of the n_stat[k] units of stat_units[k] -- the FIRST ones -- have a Sharpness stencil among ops [0, k): the
+     * statistics pass gives each of their tiles a workgroup of its own (the image after k ops is rebuilt in LDS) and streams the
+     * others.  A wrong split costs time, not correctness (the kernel chooses the data flow from the unit record). */
+    int32_t n_stat_stencil[AADG_MAX_OPS];
 } aadg_aug_lists;
 /* per-image histograms of a source pool [P, Hs, Ws, 3] (what PIL's Image.histogram() / ImageStat.Stat(convert('L')).mean read:
  * data/basic.py AutoContrast / Equalize / Contrast via ImageOps / ImageEnhance) */
@@ -143,8 +147,8 @@ int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks, int P, in
  * scale factor below 1/3, Cutout box not clipped to the image, Posterize bits) and fills the work lists `aadg_aug_lists` carries -- no GPU
  * work, host pointers (the caller copies the lists to the device next to the records).
  *   order [N]: unit indices by tile class;  stat_units [AADG_MAX_OPS][N]: per op slot the units that need a statistics pass;
- *   late_units [N];  summary [8 + AADG_MAX_OPS] = n_plain, n_sharp, n_generic, n_generic_sharp, n_late, classes_hint, stats_mask_hint,
- *   max_ops, n_stat[0 .. AADG_MAX_OPS).  (The reference does this work implicitly, op by op, in PIL: data/policy.py:45-61.) */
+ *   late_units [N];  summary [8 + 2 * AADG_MAX_OPS] = n_plain, n_sharp, n_generic, n_generic_sharp, n_late, classes_hint, stats_mask_hint,
+ *   max_ops, n_stat[0 .. AADG_MAX_OPS), n_stat_stencil[0 .. AADG_MAX_OPS) (ABI 7; stat_units[k] lists the stencil units first).  (The reference does this work implicitly, op by op, in PIL: data/policy.py:45-61.) */
 int aadg_aug_u8_plan(const aadg_unit* units, int N, int P, int Hs, int Ws, int crop, int32_t* order, int32_t* stat_units,
                      int32_t* late_units, int32_t* summary);
 

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libaadg_hip.so does not export %s" % name
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.aadg_abi_version() == 6
+    assert lib.aadg_abi_version() == 7
 
 
 def test_unit_struct_layout_matches_header():
@@ -166,7 +166,10 @@ def test_round2_entry_points_validate_arguments():
     lists = _lib.AugLists()
     lists.order, lists.n_generic, lists.n_generic_sharp = 16, 2, 3   # more stencil units than down-scaling units
     assert lib.aadg_aug_u8_forward_ex2(one, one, 1, 8, 8, one, 4, 2, 8, 0, one, one, one, 1 << 30, z, 0, -1, z, z, ctypes.byref(lists)) == -1
-    assert ctypes.sizeof(_lib.AugLists) == 8 + 16 + 8 * _lib.MAX_OPS + 4 * _lib.MAX_OPS + 8 + 8 + 8   # mirror of aadg_aug_lists (n_generic_sharp fills the tail padding)
+    lists = _lib.AugLists()
+    lists.stat_units[1], lists.n_stat[1], lists.n_stat_stencil[1] = 16, 2, 3   # ABI 7: more stencil units than the list holds
+    assert lib.aadg_aug_u8_forward_ex2(one, one, 1, 8, 8, one, 4, 2, 8, 0, one, one, one, 1 << 30, z, 0, -1, z, z, ctypes.byref(lists)) == -1
+    assert ctypes.sizeof(_lib.AugLists) == 8 + 16 + 8 * _lib.MAX_OPS + 4 * _lib.MAX_OPS + 8 + 8 + 8 + 4 * _lib.MAX_OPS   # mirror of aadg_aug_lists (n_generic_sharp fills the padding behind n_late; ABI 7: n_stat_stencil)
 
 
 def test_round3_entry_points_validate_arguments():
@@ -204,6 +207,7 @@ def test_host_planner_matches_python_statement():
     lib = _lib.load()
     K = _lib.MAX_OPS
     rs = np.random.RandomState(11)
+    seen_mixed = False
     for (H, crop, sr, L, N) in ((64, 64, (1.0, 1.5), 2, 97), (96, 64, (0.5, 2.0), 4, 160), (128, 96, (0.34, 0.6), 3, 50), (33, 31, (1.0, 1.5), 2, 40),
                                 (64, 64, (0.5, 2.0), 4, 1)):
         P = 7
@@ -219,16 +223,19 @@ def test_host_planner_matches_python_statement():
         order = np.full(N, -1, np.int32)
         stat = np.full((K, N), -1, np.int32)
         late = np.full(N, -1, np.int32)
-        summary = (ctypes.c_int32 * (8 + K))()
+        summary = (ctypes.c_int32 * (8 + 2 * K))()
         rc = lib.aadg_aug_u8_plan(cont.ctypes.data, N, P, H, H, crop, order.ctypes.data, stat.ctypes.data, late.ctypes.data, summary)
         assert rc == 0
-        classes, stats_mask, want_order, counts, stat_lists, want_late = _lib.launch_plan(units, H, H, crop)
+        classes, stats_mask, want_order, counts, stat_lists, want_late, n_sten = _lib.launch_plan(units, H, H, crop)
         assert tuple(summary[:4]) == tuple(counts) and summary[5] == classes and summary[6] == stats_mask
         assert summary[7] == _lib.validate_units(units, P, H, H)
         assert np.array_equal(order, want_order)
         for k in range(K):
             assert summary[8 + k] == stat_lists[k].size and np.array_equal(stat[k, :stat_lists[k].size], stat_lists[k])
+            assert summary[8 + K + k] == n_sten[k]                       # ABI 7: stencil units first
+        seen_mixed = seen_mixed or any(0 < n_sten[k] < stat_lists[k].size for k in range(1, K))
         assert summary[4] == want_late.size and np.array_equal(late[:want_late.size], want_late)
+    assert seen_mixed                 # a list with both kinds of unit was among the cases
 
     def refused(mutate):
         units = random_units(np.random.RandomState(3), 8, 4, 64, 64, 64, (1.0, 1.5))
@@ -237,7 +244,7 @@ def test_host_planner_matches_python_statement():
         cont = np.ascontiguousarray(units)
         bufs = [np.zeros(8 * (K if i == 1 else 1), np.int32) for i in range(3)]
         rc = lib.aadg_aug_u8_plan(cont.ctypes.data, 8, 4, 64, 64, 64, bufs[0].ctypes.data, bufs[1].ctypes.data, bufs[2].ctypes.data,
-                                  (ctypes.c_int32 * (8 + K))())
+                                  (ctypes.c_int32 * (8 + 2 * K))())
         with pytest.raises(_lib.AadgError):
             _lib.validate_units(units, 4, 64, 64)
         return rc

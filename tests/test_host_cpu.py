@@ -260,7 +260,7 @@ def test_launch_plan_classes_statistics_and_late_units():
         unit([(SHA, 1.2), (SHA, 1.3), (SHA, 1.4)]),     # 9 three stencils: staged
         unit([(SHA, 1.2)], sw=64, sh=40),               # 10 shrinks y by < 2 with a stencil: generic, listed behind the plain generic units
     ])
-    classes, stats_mask, order, counts, stat_lists, late = _lib.launch_plan(units, H, W, crop)
+    classes, stats_mask, order, counts, stat_lists, late, _ = _lib.launch_plan(units, H, W, crop)
     assert classes == 1 | 2 | 4
     assert counts == (6, 1, 2, 1)
     assert sorted(order[:6].tolist()) == [0, 1, 2, 3, 4, 6] and order[6] == 5 and order[7] == 7 and order[8] == 10 and sorted(order[9:].tolist()) == [8, 9]
