@@ -33,7 +33,7 @@ EXPORTS = [
     "aadg_aug_u8_plan",
     "aadg_sinkhorn_workspace_bytes", "aadg_sinkhorn_divergence_f32", "aadg_sinkhorn_rewards_f32", "aadg_sinkhorn_rewards_norm_f32",
     "aadg_normalize_rewards_f32",
-    "aadg_seg_loss_workspace_bytes", "aadg_seg_bce_dice_f32",
+    "aadg_seg_loss_workspace_bytes", "aadg_seg_bce_dice_f32", "aadg_seg_bce_dice_scaled_f32",
     "aadg_fop_workspace_bytes", "aadg_fop_f32",
     "aadg_upsample_bilinear2d", "aadg_upsample_bilinear2d_strided", "aadg_upsample_bilinear2d_backward_supported", "aadg_upsample_bilinear2d_backward",
     "aadg_upsample_bilinear2d_backward_workspace_bytes", "aadg_upsample_bilinear2d_backward_strided",
@@ -103,6 +103,8 @@ def load():
         lib.aadg_seg_loss_workspace_bytes.argtypes = [_i, _i, _i]
         lib.aadg_seg_bce_dice_f32.restype = _i
         lib.aadg_seg_bce_dice_f32.argtypes = [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]
+        lib.aadg_seg_bce_dice_scaled_f32.restype = _i
+        lib.aadg_seg_bce_dice_scaled_f32.argtypes = [_vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp, _vp, _vp, _sz, _vp]
     if hasattr(lib, "aadg_fop_f32"):
         lib.aadg_fop_workspace_bytes.restype = _sz
         lib.aadg_fop_workspace_bytes.argtypes = [_i, _i, _i]
@@ -266,7 +268,14 @@ def _require_cuda(*tensors):
             raise AadgError("aadg_amd kernels need contiguous tensors")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """the hipStream_t torch currently launches on (every aadg_* entry point is given it).  torch.cuda.current_stream() builds a
+    Stream object per call (~8 us, ~10 calls per hot-path step); the raw getter returns the handle itself."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -577,8 +586,8 @@ def normalize_rewards(rewards):
 
 
 # ------------------------------------------------------------------------------------------------
-def seg_bce_dice(logits, labels, M, want_grad=False):
-    """logits/labels f32 [N,K,H,W] -> (bce [M], dice [K], grad or None); grad = d(mean_j bce_j)/d logits."""
+def seg_bce_dice(logits, labels, M, want_grad=False, grad_scale=1.0):
+    """logits/labels f32 [N,K,H,W] -> (bce [M], dice [K], grad or None); grad = d(grad_scale * mean_j bce_j)/d logits."""
     lib = load()
     _require_cuda(logits, labels)
     if logits.dtype != torch.float32 or labels.dtype != torch.float32 or logits.shape != labels.shape or logits.dim() < 3:
@@ -592,9 +601,9 @@ def seg_bce_dice(logits, labels, M, want_grad=False):
     grad = torch.empty_like(logits) if want_grad else None
     nb = lib.aadg_seg_loss_workspace_bytes(N, K, HW)
     ws = workspace(nb, logits.device, "segloss")
-    rc = lib.aadg_seg_bce_dice_f32(logits.data_ptr(), labels.data_ptr(), N, K, HW, M, bce.data_ptr(), dice.data_ptr(),
-                                   _ptr(grad), ws.data_ptr(), ws.numel(), _stream())
-    _check(rc, "aadg_seg_bce_dice_f32")
+    rc = lib.aadg_seg_bce_dice_scaled_f32(logits.data_ptr(), labels.data_ptr(), N, K, HW, M, float(grad_scale), bce.data_ptr(),
+                                          dice.data_ptr(), _ptr(grad), ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "aadg_seg_bce_dice_scaled_f32")
     return bce, dice, grad
 
 
@@ -617,6 +626,20 @@ class _PolicyBCE(torch.autograd.Function):
 def policy_bce_loss(logits, labels, M):
     """Drop-in for search_dg.py:140-142 (+ the Dice monitor of :164-165): returns (seg_loss, bce[M], dice[K])."""
     return _PolicyBCE.apply(logits, labels, M)
+
+
+def policy_bce_backward(logits, labels, M, scale=1.0):
+    """The segmentation loss of search_dg.py:140-142 AND its backward pass in one call: computes scale * mean_j BCE_j, the Dice monitor
+    and d loss / d logits in ONE fused pass over logits / labels, then starts the backward pass of the graph behind `logits` from
+    that gradient (`logits.backward(grad)`).  Equivalent to `(scale * policy_bce_loss(...)[0]).backward()` without autograd's
+    `grad * d loss` product -- a read + write of the whole [N,K,H,W] gradient (0.6 GB at 144 x 2 x 512 x 512) that multiplied it by
+    a scalar the kernel can apply itself.  Returns (scale * loss (detached), bce [M], dice [K])."""
+    z = logits if logits.dtype == torch.float32 else logits.float()         # a differentiable cast under autocast
+    z = z if z.is_contiguous() else z.contiguous()
+    bce, dice, grad = seg_bce_dice(z.detach(), labels.contiguous(), M, want_grad=True, grad_scale=scale)
+    if z.requires_grad:
+        z.backward(grad)
+    return bce.mean() * scale, bce, dice
 
 
 # ------------------------------------------------------------------------------------------------

@@ -139,21 +139,27 @@ extern "C" size_t aadg_seg_loss_workspace_bytes(int N, int K, int HW) {
     return aadg_align_up((size_t)N * K * chunks_of(HW) * sizeof(Partial), 256);
 }
 
-extern "C" int aadg_seg_bce_dice_f32(const float* logits, const float* labels, int N, int K, int HW, int M,
-                                     float* out_bce, float* out_dice, float* grad_logits, void* ws, size_t ws_bytes,
-                                     void* stream) {
+extern "C" int aadg_seg_bce_dice_scaled_f32(const float* logits, const float* labels, int N, int K, int HW, int M, float grad_scale,
+                                            float* out_bce, float* out_dice, float* grad_logits, void* ws, size_t ws_bytes,
+                                            void* stream) {
     if (!logits || !labels || !out_bce || !out_dice || !ws) return AADG_E_BADARG;
     if (N <= 0 || K <= 0 || HW <= 0 || M <= 0 || M > N || N % M) return AADG_E_BADARG;
     if (ws_bytes < aadg_seg_loss_workspace_bytes(N, K, HW)) return AADG_E_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int chunks = chunks_of(HW);
     Partial* part = reinterpret_cast<Partial*>(ws);
-    // d mean_j(BCE_j) / dz: every element of policy j weighs 1 / (M * (N/M) * K * HW)
-    const float gscale = (float)(1.0 / ((double)N * K * HW));
+    // d (grad_scale * mean_j(BCE_j)) / dz: every element of policy j weighs grad_scale / (M * (N/M) * K * HW)
+    const float gscale = (float)((double)grad_scale / ((double)N * K * HW));
     hipLaunchKernelGGL(k_seg_partial, dim3(chunks, N * K), dim3(SL_THREADS), 0, st, logits, labels, HW, gscale,
                        grad_logits, part, (size_t)N * K * HW * sizeof(float) > ((size_t)128 << 20) ? 1 : 0);
     AADG_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_seg_final, dim3(M + K), dim3(256), 0, st, part, N, K, HW, M, chunks, out_bce, out_dice);
     AADG_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int aadg_seg_bce_dice_f32(const float* logits, const float* labels, int N, int K, int HW, int M,
+                                     float* out_bce, float* out_dice, float* grad_logits, void* ws, size_t ws_bytes,
+                                     void* stream) {
+    return aadg_seg_bce_dice_scaled_f32(logits, labels, N, K, HW, M, 1.0f, out_bce, out_dice, grad_logits, ws, ws_bytes, stream);
 }

@@ -21,6 +21,17 @@ class DeviceBatchLoader(object):
         n = len(self.dataset)
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
+    def predraw(self, fresh_policies=True):
+        """Draw the policy-independent part of the NEXT training batch now (python's generator: sub-policy choices, scale / crop
+        geometry, soft domain codes -- data/transform.py: predraw_train_batch), e.g. while the GPU is still busy with the previous
+        step and the controller's next sample has not reached the host yet.  The batch itself is completed by the next __iter__
+        step.  `fresh_policies`: a new DGMultiPolicy will have been injected by then (search_dg.py:341).  No-op (False) for
+        pipelines other than the standard training one."""
+        if self.collate_fn is train_dg_collate_fn and getattr(self.dataset, 'phase', None) == 'train' and self.drop_last:
+            from .transform import predraw_train_batch
+            return predraw_train_batch(self.dataset, self.batch_size, fresh_policies)
+        return False
+
     def __iter__(self):
         n = len(self.dataset)
         order = np.random.permutation(n) if self.shuffle else np.arange(n)

@@ -373,135 +373,124 @@ def _collate(batch, nested):
 # ------------------------------------------------------------------------------------------------
 # Fast draw path: the standard training pipeline without per-image objects
 # ------------------------------------------------------------------------------------------------
-def _fast_policy_steps(policy, pool):
-    """Per sub-policy: the op records Policy.__call__ would leave on an ImageRef, captured by running every op function ONCE on a
-    probe ref (same argument conversions and asserts as the object path); Cutout is position dependent and stays symbolic:
-    ('cutout', v_abs) with v_abs = v * width, or nothing when v <= 0 (data/basic.py:137-146)."""
-    from . import basic
-    if policy._compiled is None:
-        policy._compiled = policy._compile()
-    out = []
-    for steps in policy._compiled:
-        rec = []
-        for fn, value in steps:
-            if fn is basic.Cutout:
-                assert 0.0 <= value <= 0.2
-                if value > 0.:
-                    rec.append(('cutout', value * pool.size[0]))
-            else:
-                key = (fn, value, pool.size)       # a probe on an image of this size (Cutout and friends depend on it)
-                st = _STEP_CACHE.get(key)
-                if st is None:                 # (op, magnitude) pairs come from a small discrete set: probe each once
-                    probe, _ = fn(ImageRef(pool, 0), MaskRef(pool, 0), value)
-                    st = probe.ops[-1]
-                    if len(_STEP_CACHE) < 4096:
-                        _STEP_CACHE[key] = st
-                rec.append(st)
-        out.append(rec)
-    return out
+_NAMED_STEP_CACHE = {}
+_UNIT_WORDS = _lib.UNIT_DTYPE.itemsize // 4                   # a unit record as int32 words: src, n_ops, op[K], iarg[K], farg[K], rect[K][4], geometry[5]
 
 
-_STEP_CACHE = {}
+def _named_step(name, level, size, pool):
+    """The op record of one (op name, level) step as Policy.__call__ would leave it on an ImageRef, as int32 words (op, iarg, bits of
+    the float32 farg) -- ('cutout', v_abs) for Cutout (position dependent), None for a Cutout of size 0 -- cached by (name, level,
+    image size): the controller's (op, magnitude) pairs come from a small discrete set."""
+    key = (name, level, size)
+    st = _NAMED_STEP_CACHE.get(key, key)
+    if st is key:
+        from . import basic
+        if name == 'CutMix':
+            raise KeyError(name)                               # not in augment_dict in the reference either (data/basic.py:253)
+        fn, low, high = basic.get_augment(name)
+        value = level * (high - low) + low                     # as apply_augment computes it (data/basic.py:258-260)
+        if fn is basic.Cutout:
+            assert 0.0 <= value <= 0.2
+            st = ('cutout', value * size[0]) if value > 0. else None
+        else:
+            probe, _ = fn(ImageRef(pool, 0), MaskRef(pool, 0), value)     # same argument conversions and asserts as the object path
+            o, i, f, r = probe.ops[-1]
+            assert tuple(r) == (0, 0, -1, -1)
+            st = (int(o), int(i), int(np.array([f], np.float32).view(np.int32)[0]))
+        if len(_NAMED_STEP_CACHE) < 8192:
+            _NAMED_STEP_CACHE[key] = st
+    return st
 
 
-def fast_train_units(dataset, n_items):
-    """Draws `n_items` training items (one image per source domain each) of the STANDARD pipeline
-    [DGMultiPolicy, DGRandomScaleCrop, Normalize_dg, ToTensor] and returns the packed unit records directly:
-
-        (units UNIT_DTYPE [S + S*M] in output-row order, dc float32 [S*M, n], dc_single float32 [S, n], names, M, kind)
-
-    with S = n_items * n_domains.  Every random draw is made by the same function, with the same arguments and in the same
-    order as the object path (synthetic.py:__getitem__ -> Policy.__call__ -> DGRandomScaleCrop -> ToTensor), so a seeded run
-    produces identical records (tests/test_host_cpu.py::test_fast_draw_equals_object_path); what is skipped is the ~70 ImageRef
-    objects, copies and property calls per item.  Returns None when the dataset's pipeline is not the standard one."""
-    from .basic import cutout_rect
-    from .policy import DGMultiPolicy
-    from .synthetic import SyntheticDGSegmentation
-    if type(dataset) is not SyntheticDGSegmentation:       # the draws below mirror synthetic.py:__getitem__ (pool, n_domains, per_domain)
-        return None
-    tfs = getattr(getattr(dataset, 'transforms', None), 'transforms', None)
-    if (tfs is None or len(tfs) != 4 or type(tfs[0]) is not DGMultiPolicy or type(tfs[1]) is not DGRandomScaleCrop or
-            type(tfs[2]) is not Normalize_dg or type(tfs[3]) is not ToTensor or getattr(dataset, 'phase', 'train') == 'test'):
-        return None
-    mp, sc, nz, tt = tfs
-    pool = dataset.pool
-    W0, H0 = pool.size
-    D, per = dataset.n_domains, dataset.per_domain
-    policies = mp.policies
-    M = len(policies)
-    fast = [getattr(p, '_fast', None) or _fast_policy_steps(p, pool) for p in policies]
-    for p, f in zip(policies, fast):
-        p._fast = f
-    s0, s1 = sc.scale_range[0], sc.scale_range[1]
+def _policy_tables(mp, pool):
+    """Per DGMultiPolicy: (sub-policies per policy, record templates int32 [M, nsub, 35] -- the unit record of every (policy,
+    sub-policy) pair with src and geometry left open --, per pair the Cutout steps as (slot, v_abs) (position dependent: their
+    boxes are drawn per unit), any Cutout at all)."""
+    tabs = getattr(mp, '_fast_tables', None)
+    if tabs is not None:
+        return tabs
+    from array import array
     K = _lib.MAX_OPS
+    size = pool.size
+    nsub = [len(p.policy) for p in mp.policies]
+    ns = max(nsub)
+    words, cut = array('i'), []
+    any_cut = False
+    tail = [0, 0, -1, -1] * K + [0] * 5                          # no Cutout box; geometry left open
+    empty = [0, 0] + [0] * (3 * K) + tail
+    for p in mp.policies:
+        c_j = []
+        for sub in p.policy:
+            o, i, fb, cs, k = [0] * K, [0] * K, [0] * K, (), 0
+            for name, level in sub:
+                st = _named_step(name, level, size, pool)
+                if st is None:
+                    continue
+                if k >= K:
+                    raise RuntimeError("more than %d ops per sub-policy are not supported" % K)
+                if st[0] == 'cutout':
+                    o[k] = 9
+                    cs += ((k, st[1]),)
+                else:
+                    o[k], i[k], fb[k] = st
+                k += 1
+            words.extend([0, k] + o + i + fb + tail)
+            c_j.append(cs)
+            any_cut = any_cut or bool(cs)
+        for _ in range(ns - len(p.policy)):
+            words.extend(empty)
+            c_j.append(())
+        cut.append(c_j)
+    templ = np.frombuffer(words, dtype=np.int32).reshape(len(cut), ns, _UNIT_WORDS)
+    tabs = mp._fast_tables = (tuple(nsub), templ, cut, any_cut)
+    return tabs
+
+
+def _draw_python_stream(n_items, D, M, nsub, queue_lens, sc, n_code, W0, H0):
+    """Phase A of a training batch: every draw the pipeline makes from python's `random` generator, in the pipeline's order --
+    per (item, domain): per policy the CutMix-queue draw and the sub-policy draw (data/policy.py:17-23), then DGRandomScaleCrop for
+    the original and each augmented image (data/transform.py:104-131), then ToTensor's soft domain code (:260-274).  None of them
+    depends on what the policies CONTAIN (only on how many sub-policies each has and on the length of its CutMix queue), so this
+    phase can run before the controller's sample has reached the host (DeviceBatchLoader.predraw).  numpy's generator -- the image
+    index and Cutout's box -- is phase B (fast_train_units): its consumption follows the chosen sub-policies."""
     # python's generator without a frame per draw: uniform(a, b) = a + (b - a) * random(), randint(a, b) = a + _randbelow(b - a + 1),
     # choice(seq) = seq[_randbelow(len(seq))], and _randbelow(n) itself (CPython random.py, _randbelow_with_getrandbits):
     #     k = n.bit_length(); r = getrandbits(k); while r >= n: r = getrandbits(k)
-    # written out at its four call sites -- the same stream, position by position (tests/test_host_cpu.py compares the records and the
+    # written out at its call sites -- the same stream, position by position (tests/test_host_cpu.py compares the records and the
     # generators' end states with the object path)
     rnd, getbits = random.random, random._inst.getrandbits
-    assert random._inst._randbelow.__func__ is random.Random._randbelow_with_getrandbits
-    # numpy's legacy generator: choice(n, 1)[0] draws randint(0, n) (mtrand: `idx = self.randint(0, pop_size, size=size)`), the scalar call
-    # consumes the same words of the stream without building two arrays; uniform(low) = low + (1.0 - low) * random_sample()
-    np_randint, np_sample = np.random.randint, np.random.random_sample
+    s0, s1 = sc.scale_range[0], sc.scale_range[1]
     crop_h, crop_w = sc.crop.size
     crop_pad = sc.crop.padding
     ds = s1 - s0
     S = n_items * D
     n = S + S * M
-    src, n_ops, geo = [0] * n, [0] * n, [None] * n
-    op = [[0] * K for _ in range(n)]
-    iarg = [[0] * K for _ in range(n)]
-    farg = [[0.0] * K for _ in range(n)]
-    rect = [[(0, 0, -1, -1)] * K for _ in range(n)]
-    names, dcs = [], []
-    queues = [p.queue for p in policies]
-    nsub = [len(f) for f in fast]
+    geo = [0] * (5 * n)
+    R = [0] * (S * M)
+    dcs = []
+    qlen = list(queue_lens)
     ksub = [m.bit_length() for m in nsub]
-    n_code = tt.n
     last_code = n_code - 1
-    wlow, hlow = 1.0 - W0, 1.0 - H0
     s = 0
     for _ in range(n_items):
         for d in range(D):
-            index = int(np_randint(0, per))                         # synthetic.py: np.random.choice(per, 1)[0], one random image per source domain
-            pidx = d * per + index
-            names.append('synth_d%d_%04d' % (d, index))
-            # -- DGMultiPolicy: per policy the CutMix-queue draw, the sub-policy draw, Cutout's two numpy draws
             base = S + s * M
             for j in range(M):
-                q = queues[j]
-                q.append(None)
-                nq = len(q)
+                nq = qlen[j] + 1                                    # q.append(sample)
                 if nq > 10:
-                    q.pop(0)
+                    nq = 10                                         # q.pop(0): no draw
                 else:                                               # the CutMix-queue draw (its value is unused: data/policy.py:17-21)
                     kq = nq.bit_length()
                     r = getbits(kq)
                     while r >= nq:
                         r = getbits(kq)
+                qlen[j] = nq
                 m, kq = nsub[j], ksub[j]                            # the sub-policy draw
                 r = getbits(kq)
                 while r >= m:
                     r = getbits(kq)
-                row = base + j
-                src[row] = pidx
-                k = 0
-                oi, ii, fi, ri = op[row], iarg[row], farg[row], rect[row]
-                for st in fast[j][r]:
-                    if st[0] == 'cutout':
-                        # CutoutAbs (data/basic.py:153-163): np.random.uniform(w), np.random.uniform(h), then cutout_rect
-                        v = st[1]
-                        x0 = int(max(0, W0 + wlow * np_sample() - v / 2.))
-                        y0 = int(max(0, H0 + hlow * np_sample() - v / 2.))
-                        st = (9, 0, 0.0, (x0, y0, min(int(min(W0, x0 + v)), W0 - 1), min(int(min(H0, y0 + v)), H0 - 1)))
-                    if k >= K:
-                        raise RuntimeError("more than %d ops per sub-policy are not supported" % K)
-                    oi[k], ii[k], fi[k], ri[k] = st
-                    k += 1
-                n_ops[row] = k
+                R[s * M + j] = r
             # -- DGRandomScaleCrop: the original first, then every augmented image (scale draw, then crop draw)
-            src[s] = pidx
             row = s
             for jj in range(M + 1):
                 w, h = W0, H0
@@ -518,16 +507,19 @@ def fast_train_units(dataset, n_items):
                     x1 = y1 = 0
                 else:
                     m = pw - crop_w + 1                             # random.randint(0, pw - crop_w)
+                    m2 = ph - crop_h + 1
+                    if m <= 0 or m2 <= 0:
+                        raise ValueError("empty range for randrange() (0, %d, %d)" % (min(m, m2), min(m, m2)))   # what random.randint raises
                     kq = m.bit_length()
                     x1 = getbits(kq)
                     while x1 >= m:
                         x1 = getbits(kq)
-                    m = ph - crop_h + 1
-                    kq = m.bit_length()
+                    kq = m2.bit_length()
                     y1 = getbits(kq)
-                    while y1 >= m:
+                    while y1 >= m2:
                         y1 = getbits(kq)
-                geo[row] = (w, h, pad, x1, y1)
+                g5 = 5 * row
+                geo[g5], geo[g5 + 1], geo[g5 + 2], geo[g5 + 3], geo[g5 + 4] = w, h, pad, x1, y1
                 row = base + jj
             # -- ToTensor: the soft domain code (SoftLable(ToMultiLabel(d, n)): the true class U[0.8, 1], the others share the rest)
             code = [0.0] * n_code
@@ -543,17 +535,128 @@ def fast_train_units(dataset, n_items):
                         used += t
             dcs.append(code)
             s += 1
-    units = np.zeros(n, dtype=_lib.UNIT_DTYPE)
-    units['src'] = src
-    units['n_ops'] = n_ops
-    units['op'] = op
-    units['iarg'] = iarg
-    units['farg'] = farg
-    units['rect'] = rect
-    g = np.asarray(geo, dtype=np.int64)
-    units['scaled_w'], units['scaled_h'], units['pad'], units['crop_x'], units['crop_y'] = g[:, 0], g[:, 1], g[:, 2], g[:, 3], g[:, 4]
-    dc_single = np.array(dcs, dtype=np.float64).astype(np.float32)
+    from array import array
+    return {'n_items': n_items, 'D': D, 'M': M, 'nsub': tuple(nsub), 'queue_before': tuple(queue_lens), 'queue_after': tuple(qlen),
+            'R': R, 'R_np': np.frombuffer(array('q', R), dtype=np.int64), 'geo': np.frombuffer(array('i', geo), dtype=np.int32).reshape(n, 5),
+            'dcs': dcs}
+
+
+def _standard_pipeline(dataset):
+    """(multi-policy, scale-crop, normalize, to-tensor) of the STANDARD training pipeline, or None"""
+    from .policy import DGMultiPolicy
+    from .synthetic import SyntheticDGSegmentation
+    if type(dataset) is not SyntheticDGSegmentation:       # the draws mirror synthetic.py:__getitem__ (pool, n_domains, per_domain)
+        return None
+    tfs = getattr(getattr(dataset, 'transforms', None), 'transforms', None)
+    if (tfs is None or len(tfs) != 4 or type(tfs[0]) is not DGMultiPolicy or type(tfs[1]) is not DGRandomScaleCrop or
+            type(tfs[2]) is not Normalize_dg or type(tfs[3]) is not ToTensor or getattr(dataset, 'phase', 'train') == 'test'):
+        return None
+    if random._inst._randbelow.__func__ is not random.Random._randbelow_with_getrandbits:
+        return None                                          # another interpreter's random.py: take the object path
+    return tfs
+
+
+def predraw_train_batch(dataset, n_items, fresh_policies=True):
+    """Phase A of the NEXT training batch, drawn ahead of time (python's generator only: see _draw_python_stream).  `fresh_policies`:
+    the batch will be drawn through NEWLY injected policies (search_dg.py:341 installs a new DGMultiPolicy per epoch: empty CutMix
+    queues); False: through the objects installed now.  fast_train_units checks the assumption when it consumes the draw.
+    Returns False (and draws nothing) when the pipeline is not the standard one."""
+    tfs = _standard_pipeline(dataset)
+    if tfs is None or getattr(dataset, '_predrawn', None) is not None:
+        return False
+    mp, sc, nz, tt = tfs
+    nsub = _policy_tables(mp, dataset.pool)[0]
+    qlens = [0] * len(mp.policies) if fresh_policies else [len(p.queue) for p in mp.policies]
+    W0, H0 = dataset.pool.size
+    dataset._predrawn = _draw_python_stream(n_items, dataset.n_domains, len(mp.policies), nsub, qlens, sc, tt.n, W0, H0)
+    return True
+
+
+def fast_train_units(dataset, n_items):
+    """Draws `n_items` training items (one image per source domain each) of the STANDARD pipeline
+    [DGMultiPolicy, DGRandomScaleCrop, Normalize_dg, ToTensor] and returns the packed unit records directly:
+
+        (units UNIT_DTYPE [S + S*M] in output-row order, dc float32 [S*M, n], dc_single float32 [S, n], names, M, kind)
+
+    with S = n_items * n_domains.  Every random draw is made by the same function, with the same arguments and -- per generator --
+    in the same order as the object path (synthetic.py:__getitem__ -> Policy.__call__ -> DGRandomScaleCrop -> ToTensor), so a
+    seeded run produces identical records (tests/test_host_cpu.py::test_fast_draw_equals_object_path); what is skipped is the ~70
+    ImageRef objects, copies and property calls per item.  Two phases (round 4): A = python's generator (policy-content
+    independent, may have been drawn ahead by predraw_train_batch), B = numpy's generator (image index, Cutout boxes) + the
+    records, assembled from per-policy tables with array indexing.  Returns None when the pipeline is not the standard one."""
+    tfs = _standard_pipeline(dataset)
+    if tfs is None:
+        return None
+    mp, sc, nz, tt = tfs
+    pool = dataset.pool
+    W0, H0 = pool.size
+    D, per = dataset.n_domains, dataset.per_domain
+    policies = mp.policies
+    M = len(policies)
+    nsub, templ, cut, any_cut = _policy_tables(mp, pool)
+    qlens = tuple(len(p.queue) for p in policies)
+    A = getattr(dataset, '_predrawn', None)
+    dataset._predrawn = None
+    if A is not None:
+        if (A['n_items'], A['D'], A['M'], A['nsub'], A['queue_before']) != (n_items, D, M, nsub, qlens):
+            raise RuntimeError("the batch drawn ahead (predraw_train_batch) does not fit the pipeline it is consumed by: %r vs %r"
+                               % ((A['n_items'], A['D'], A['M'], A['nsub'], A['queue_before']), (n_items, D, M, nsub, qlens)))
+    else:
+        A = _draw_python_stream(n_items, D, M, nsub, qlens, sc, tt.n, W0, H0)
+    for p, nq in zip(policies, A['queue_after']):              # the CutMix queues' state after the batch (their content is never read)
+        del p.queue[:]
+        p.queue.extend([None] * nq)
+    S = n_items * D
+    n = S + S * M
+    # ---- phase B: numpy's legacy generator.  choice(n, 1)[0] draws randint(0, n) (mtrand: `idx = self.randint(0, pop_size, size=size)`);
+    # the scalar call consumes the same words of the stream without building two arrays; uniform(low) = low + (1.0 - low) * random_sample()
+    np_randint, np_sample = np.random.randint, np.random.random_sample
+    wlow, hlow = 1.0 - W0, 1.0 - H0
+    R = A['R']
+    pidx = [0] * S
+    names = []
+    rects = []                                                  # (row, first rect word, box) of the Cutout steps
+    cut_j = [j for j in range(M) if any(cut[j])] if any_cut else []
+    s = 0
+    for _ in range(n_items):
+        for d in range(D):
+            index = int(np_randint(0, per))                     # synthetic.py: np.random.choice(per, 1)[0], one random image per source domain
+            pidx[s] = d * per + index
+            names.append('synth_d%d_%04d' % (d, index))
+            for j in cut_j:
+                for k, v in cut[j][R[s * M + j]]:
+                    # CutoutAbs (data/basic.py:153-163): np.random.uniform(w), np.random.uniform(h), then cutout_rect
+                    x0 = int(max(0, W0 + wlow * np_sample() - v / 2.))
+                    y0 = int(max(0, H0 + hlow * np_sample() - v / 2.))
+                    rects.append((S + s * M + j, 2 + 3 * _lib.MAX_OPS + 4 * k,
+                                  (x0, y0, min(int(min(W0, x0 + v)), W0 - 1), min(int(min(H0, y0 + v)), H0 - 1))))
+            s += 1
+    # the records as int32 words: the (policy, sub-policy) templates picked by the draws, then source index, geometry and Cutout boxes
+    U = np.empty((n, _UNIT_WORDS), np.int32)
+    U[:S] = templ[0, 0]
+    U[:S, 1:2 + 3 * _lib.MAX_OPS] = 0                           # the un-augmented images: no ops
+    sel = _plan_index(S, M)
+    U[S:] = templ[sel, A['R_np']]
+    pidx = np.asarray(pidx, dtype=np.int32)
+    U[:S, 0] = pidx
+    U[S:, 0] = np.repeat(pidx, M)
+    U[:, _UNIT_WORDS - 5:] = A['geo']
+    for row, w0, box in rects:
+        U[row, w0:w0 + 4] = box
+    units = U.reshape(-1).view(_lib.UNIT_DTYPE)
+    dc_single = np.array(A['dcs'], dtype=np.float64).astype(np.float32)
     return units, np.repeat(dc_single, M, axis=0), dc_single, names, M, nz.dataset_name
+
+
+_PLAN_INDEX = {}
+
+
+def _plan_index(S, M):
+    """policy index of every augmented row: 0 .. M-1 repeated S times (cached)"""
+    v = _PLAN_INDEX.get((S, M))
+    if v is None:
+        v = _PLAN_INDEX[(S, M)] = np.tile(np.arange(M, dtype=np.intp), S)
+    return v
 
 
 def fast_train_collate(dataset, n_items):

@@ -144,14 +144,12 @@ def inner_iteration(config, sample, model, discriminator, dis_criterion, model_o
             dis_optimizer.zero_grad(set_to_none=True)
             dis_loss_bp.backward()
             dis_optimizer.step()
-    # sigmoid + per-policy BCE + Dice, one fused pass (forward + gradient).  mean_j BCE_j == mean over all rows (every policy
-    # owns N/M rows), so a rank whose local rows are not policy-interleaved takes the plain mean of its rows.
-    seg_loss, _, dice = _lib.policy_bce_loss(seg_output.float(), mask_gt, 1 if sharded else M)
-    if sharded:
-        # DDP averages the ranks' gradients: weight the local means by n_local * G / N (count-weighted mean, RowPlan)
-        seg_loss = seg_loss * plan.loss_weight
+    # sigmoid + per-policy BCE + Dice + d loss / d logits, one fused pass; the backward pass starts from the kernel's gradient
+    # (_lib.policy_bce_backward).  mean_j BCE_j == mean over all rows (every policy owns N/M rows), so a rank whose local rows are not
+    # policy-interleaved takes the plain mean of its rows.  DDP averages the ranks' gradients: the local mean is weighted by
+    # n_local * G / N (count-weighted mean, RowPlan) -- inside the kernel.
     model_optimizer.zero_grad(set_to_none=True)
-    seg_loss.backward()
+    seg_loss, _, dice = _lib.policy_bce_backward(seg_output, mask_gt, 1 if sharded else M, plan.loss_weight if sharded else 1.0)
     model_optimizer.step()
     if side is None:
         dis_optimizer.zero_grad(set_to_none=True)
@@ -362,6 +360,11 @@ class SearchState(object):
             losses = self.controller_criterion(self.controller, policies, log_probs, entropies, normalized_rewards)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)  # what this step returns (losses, probabilities) was produced there
+        if getattr(self.args, 'predraw', True):
+            # everything of this step is enqueued: draw the policy-independent part of the next epoch's first batch (python's
+            # generator: sub-policy choices, geometry, soft codes) while the GPU works -- the next step then only completes the records
+            # once the sampled policies have reached the host.  The next epoch injects a new DGMultiPolicy (above): fresh CutMix queues.
+            self.train_loader.predraw(fresh_policies=True)
         return parsed, op_probs, mag_probs, normalized_rewards, losses
 
     def _controller_stream(self, main):

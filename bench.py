@@ -321,10 +321,11 @@ def build_state(a, local_rank, world, backbone_dtype=None):
     cfg.PRINT_FREQ = 10 ** 9
     cfg.freeze()
     args = Args()
-    args.gpu, args.workers, args.distributed = local_rank, 0, world > 1 or a.force_dist
+    force = bool(getattr(a, 'force_dist', False))
+    args.gpu, args.workers, args.distributed = local_rank, 0, world > 1 or force
     args.crop_size, args.backbone_dtype, args.epoch_items = a.size, backbone_dtype or a.backbone_dtype, a.batch
-    args.sync_bn = (world > 1 or a.force_dist) and not a.no_sync_bn
-    args.force_sharded = bool(a.force_dist)
+    args.sync_bn = (world > 1 or force) and not a.no_sync_bn
+    args.force_sharded = force
     args.placement = a.placement
     st = SearchState(local_rank, world, cfg, args)
     if a.no_dropout:
@@ -862,14 +863,19 @@ def main():
     from aadg_amd.data import transform as T
     from aadg_amd.data.policy import DGMultiPolicy, parse_policies
     plan = T.row_plan(D, a.batch, M)                      # this rank's rows of the batch (aadg_amd/distributed.py: RowPlan)
-    z = torch.randn(plan.n_local, K, a.size, a.size, device="cuda", requires_grad=True)
+    z = torch.randn(plan.n_local, K, a.size, a.size, device="cuda")
     fe = torch.nn.functional.leaky_relu(torch.randn(n_rows, 128, device="cuda"), 0.2)
     rewards = torch.zeros(M, device="cuda")
     ev = lambda: torch.cuda.Event(enable_timing=True)      # noqa: E731
     STAGES = ("controller_sample", "augmentation_call", "bce_dice_fwd_bwd", "sinkhorn_rewards", "normalise_ppo_update")
+    # (mark order in hot_step: sample [0,1], augmentation [2,3], loss [4,5], Sinkhorn [6,7], update [8,9])
 
     def hot_step(marks=None):
-        """marks: 2 * len(STAGES) events recorded around the stages (the GPU time of each stage's kernels incl. the gaps between them)"""
+        """One hot-path step, organised like SearchState.search_step / inner_iteration: the augmentation call on the main stream; the
+        reward branch (Sinkhorn rewards -> normalise -> PPO update -> next sample, async copy of the policies to the host) on the
+        controller's side stream as soon as the batch exists; the segmentation loss (forward + backward) beside it on the main
+        stream; the next batch's policy-independent draws while the GPU works.
+        marks (stage timing pass): 2 * len(STAGES) events recorded around the stages, everything on ONE stream in sequence."""
         k = 0
 
         def mark():
@@ -877,31 +883,62 @@ def main():
             if marks is not None:
                 marks[k].record()
                 k += 1
+        serial = marks is not None or st.graphed is None or not getattr(st.graphed, 'fused', False)
         mark()
-        if st.graphed is not None:
-            policies, _, _, log_probs, entropies = st.graphed.sample()
+        nxt, hot_state['prefetched'] = hot_state.get('prefetched'), None
+        if nxt is None:
+            if st.graphed is not None:
+                policies, _, _, log_probs, entropies = st.graphed.sample()
+            else:
+                policies, _, _, log_probs, entropies = st.controller(M)
+            mark()
+            host_pol = policies.cpu().numpy()
         else:
-            policies, _, _, log_probs, entropies = st.controller(M)
-        mark()
-        parsed = parse_policies(policies.cpu().numpy(), cfg, None)
+            policies, _, _, log_probs, entropies, fetch = nxt
+            mark()
+            host_pol = fetch()                                # the copy was enqueued on the side stream behind the previous update
+        parsed = parse_policies(host_pol, cfg, None)
         st.train_loader.dataset.transforms.transforms[0] = DGMultiPolicy(parsed)
         mark()
         sample = next(iter(st.train_loader))
-        mark(); mark()
-        loss, _, _ = _lib.policy_bce_loss(z, sample['aug_labels'], 1 if plan.sharded else M)
-        loss.backward()
-        mark(); mark()
-        rewards.zero_()
-        if D >= 2:
-            _lib.sinkhorn_rewards(fe, D, a.batch, M, rewards=rewards)
-        mark(); mark()
-        if st.graphed is not None:
-            st.graphed.update(_lib.normalize_rewards(rewards), entropies)
-        else:
-            st.controller_criterion(st.controller, policies, log_probs, entropies, _lib.normalize_rewards(rewards))
         mark()
+        main = torch.cuda.current_stream()
+        side = None if serial else st._controller_stream(main)
+
+        def reward_branch():
+            rewards.zero_()
+            if D >= 2:
+                _lib.sinkhorn_rewards(fe, D, a.batch, M, rewards=rewards)
+            mark(); mark()
+            if st.graphed is not None:
+                st.graphed.update(_lib.normalize_rewards(rewards), entropies)
+            else:
+                st.controller_criterion(st.controller, policies, log_probs, entropies, _lib.normalize_rewards(rewards))
+            mark()
+
+        def loss_branch():
+            # the loss, the Dice monitor and d loss / d logits in one fused pass, as inner_iteration takes them (the backward pass it
+            # starts belongs to the backbone: removed here)
+            _lib.seg_bce_dice(z, sample['aug_labels'], 1 if plan.sharded else M, want_grad=True)
+
+        if side is None:
+            mark()
+            loss_branch()
+            mark(); mark()
+            reward_branch()
+        else:
+            side.wait_stream(main)                            # the batch (in the full step: the features computed from it) exists
+            with torch.cuda.stream(side):
+                reward_branch()
+                hot_state['prefetched'] = st._sample_policies(async_host=True)
+            loss_branch()
+            main.wait_stream(side)
+        # the next batch's policy-independent draws (python's generator) while the GPU works through this step's kernels: the next
+        # step then only waits for the sampled policies, completes the records and launches
+        st.train_loader.predraw(fresh_policies=True)
         return sample
 
+    hot_state = {}
     for _ in range(2):
         hot_step()
     sync()
@@ -944,6 +981,7 @@ def main():
                 torch.cuda._sleep(cyc)
             return e
     for i in range(HS):
+        hot_state['prefetched'] = None                     # the stage pass samples inside its own bracket
         hot_step(_Blocked(smarks[i]))
     sync()
     stage_ms = {name: float(np.median([row[2 * k].elapsed_time(row[2 * k + 1]) for row in smarks])) for k, name in enumerate(STAGES)}

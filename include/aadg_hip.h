@@ -195,6 +195,13 @@ size_t aadg_seg_loss_workspace_bytes(int N, int K, int HW);
 int aadg_seg_bce_dice_f32(const float* logits, const float* labels, int N, int K, int HW, int M,
                           float* out_bce, float* out_dice, float* grad_logits, void* ws,
                           size_t ws_bytes, void* stream);
+/* (ABI 7) the same with the gradient of grad_scale * mean_j BCE_j: the factor a caller would otherwise apply to the loss before
+ * calling backward (count-weighted mean of a row-sharded batch: aadg_amd/distributed.py RowPlan.loss_weight) -- autograd's
+ * `grad * d loss` is then not needed: the gradient is handed to logits.backward() as written by the kernel (one pass over the
+ * [N,K,HW] tensor less per step).  out_bce / out_dice are NOT scaled. */
+int aadg_seg_bce_dice_scaled_f32(const float* logits, const float* labels, int N, int K, int HW, int M, float grad_scale,
+                                 float* out_bce, float* out_dice, float* grad_logits, void* ws,
+                                 size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Float tensor ops, data/functional.py (batched [B,3,H,W] float in [0,1], mag scalar or [B]).

@@ -41,3 +41,35 @@ def test_full_size_property(hip):
     # wrong-side loss is 20 where y=1 and 100 where y=0; compare with torch's own fp32 result
     ref = torch.nn.functional.binary_cross_entropy(torch.sigmoid(-z), y)
     assert torch.all(dice == 0.0) and abs(bce.mean().item() - ref.item()) < 1e-3
+
+
+@pytest.mark.parametrize("scale,dtype", [(1.0, torch.float32), (0.75, torch.float32), (1.25, torch.bfloat16)])
+def test_loss_and_backward_in_one_call(hip, scale, dtype):
+    """Round 4: _lib.policy_bce_backward = the loss, the Dice monitor and the backward pass started from the kernel's own gradient
+    (grad_scale folded into the kernel: aadg_seg_bce_dice_scaled_f32) -- against `(scale * policy_bce_loss(...)).backward()`, the
+    autograd route it replaces, through a small differentiable producer (what the backbone is in the search step), float32 and a
+    bfloat16 producer (autocast: the cast node is part of the graph)."""
+    torch.manual_seed(3)
+    N, K, H, W, M = 12, 2, 24, 40, 6
+    x = torch.randn(N, 3, H, W, device="cuda")
+    y = (torch.rand(N, K, H, W, device="cuda") > 0.6).float()
+    conv = torch.nn.Conv2d(3, K, 3, padding=1).cuda()
+
+    def produce():
+        out = conv(x)
+        return out.to(dtype) if dtype != torch.float32 else out
+
+    conv.zero_grad()
+    loss_a, bce_a, dice_a = hip.policy_bce_loss(produce().float(), y, M)
+    (loss_a * scale).backward()
+    want = [p.grad.clone() for p in conv.parameters()]
+    conv.zero_grad()
+    loss_b, bce_b, dice_b = hip.policy_bce_backward(produce(), y, M, scale)
+    got = [p.grad for p in conv.parameters()]
+    assert abs(loss_b.item() - scale * loss_a.item()) <= 1e-6 * max(1.0, abs(loss_a.item()))
+    assert torch.equal(bce_a.detach(), bce_b) and torch.equal(dice_a, dice_b)
+    for g, w in zip(got, want):
+        assert (g - w).abs().max().item() <= 2e-6 * max(1.0, w.abs().max().item()), (g - w).abs().max().item()
+    # no graph behind the logits: the losses still come back, nothing to propagate
+    loss_c, _, _ = hip.policy_bce_backward(produce().detach(), y, M, scale)
+    assert abs(loss_c.item() - loss_b.item()) < 1e-7

@@ -232,6 +232,53 @@ def test_fast_draw_equals_object_path():
     assert T.fast_train_units(ds, 2) is None
 
 
+def test_batch_drawn_ahead_equals_batch_drawn_in_place():
+    """Round 4: predraw_train_batch draws the python-generator part of the NEXT batch (sub-policy choices, scale / crop geometry, soft
+    codes) before the policies are known -- these draws do not depend on what the policies contain.  The batch completed later must
+    be the batch drawn in one go: same records, codes, names and generator states, for freshly injected policies (the search loop:
+    a new DGMultiPolicy per epoch) and for policies that stay (their CutMix queues carry over); a draw that does not fit the pipeline
+    state it is consumed in is refused."""
+    import random
+    import numpy as np
+    from helpers import Cfg
+    from aadg_amd.data import transform as T
+    from aadg_amd.data.policy import DGMultiPolicy, parse_policies
+    from aadg_amd.data.synthetic import SyntheticDGSegmentation
+    tr, _ = T.get_dg_segtransform('optic', 48, 3)
+    ds = SyntheticDGSegmentation(3, 3, 48, 'optic', 'train', tr, device='cpu')
+    for seed in range(3):
+        runs = []
+        for ahead in (False, True):
+            random.seed(seed)
+            np.random.seed(seed)
+            res = []
+            for step in range(4):
+                pol = np.random.RandomState(100 * seed + step).randint(0, 10, (6, 20))      # policies with and without Cutout
+                if ahead and step > 0:
+                    pass                                            # drawn at the end of the previous step (below)
+                if step % 2 == 0 or step == 1:
+                    ds.transforms.transforms[0] = DGMultiPolicy(parse_policies(pol, Cfg(), None))      # fresh policies: empty queues
+                res.append(T.fast_train_units(ds, 3))
+                if ahead:
+                    # the next step injects fresh policies unless it is step 3 (which keeps step 2's objects: queues carry over)
+                    assert T.predraw_train_batch(ds, 3, fresh_policies=(step + 1) != 3)
+            if ahead:
+                ds._predrawn = None                                 # the last draw ahead is never consumed: drop it, compare states before it
+            runs.append(res)
+        a, b = runs
+        for (u1, d1, s1, n1, M1, k1), (u2, d2, s2, n2, M2, k2) in zip(a, b):
+            assert u1.tobytes() == u2.tobytes() and np.array_equal(d1, d2) and np.array_equal(s1, s2) and n1 == n2
+    # consumed in another state than it was drawn for: refused, loudly
+    ds.transforms.transforms[0] = DGMultiPolicy(parse_policies(np.random.RandomState(0).randint(0, 10, (6, 20)), Cfg(), None))
+    T.fast_train_units(ds, 3)                                        # queues now hold 9 entries
+    assert T.predraw_train_batch(ds, 3, fresh_policies=True)         # ... but the draw assumes empty ones
+    with pytest.raises(RuntimeError):
+        T.fast_train_units(ds, 3)
+    assert T.predraw_train_batch(ds, 2, fresh_policies=False)
+    with pytest.raises(RuntimeError):
+        T.fast_train_units(ds, 3)                                    # another batch size
+
+
 def test_launch_plan_classes_statistics_and_late_units():
     """aadg_amd._lib.launch_plan mirrors unit_flow() / stats_by_pushforward() of csrc/aug_u8.hip on the host: hand-built unit records,
     one per rule (class by scale and Sharpness count; which slots need a pixel pass; which units are 'late')."""
