@@ -390,7 +390,7 @@ class AugLists(ctypes.Structure):
     _fields_ = [("order", ctypes.c_void_p), ("n_plain", ctypes.c_int32), ("n_sharp", ctypes.c_int32), ("n_generic", ctypes.c_int32),
                 ("stat_units", ctypes.c_void_p * MAX_OPS), ("n_stat", ctypes.c_int32 * MAX_OPS), ("pool_hist", ctypes.c_void_p),
                 ("late_units", ctypes.c_void_p), ("n_late", ctypes.c_int32), ("n_generic_sharp", ctypes.c_int32),
-                ("n_stat_stencil", ctypes.c_int32 * MAX_OPS)]
+                ("n_stat_stencil", ctypes.c_int32 * MAX_OPS), ("gen_chunk", ctypes.c_int32)]
 
 
 HIST_STRIDE = 772      # AADG_HIST_STRIDE
@@ -432,9 +432,9 @@ def _pinned_units(n):
     return buf
 
 
-def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None, pool_hist=None):
+def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None, pool_hist=None, gen_chunk=0):
     """pool u8 [P,Hs,Ws,3], masks u8 [P,Hs,Ws] (device), units numpy UNIT_DTYPE[N]; pool_hist: pool_histograms(pool) or None
-    (None: the statistics passes of the call read the source images themselves).
+    (None: the statistics passes of the call read the source images themselves); gen_chunk: aadg_aug_lists.gen_chunk (0 = default).
     Returns (aug_images f32 [N,3,crop,crop], aug_labels f32 [N,K,crop,crop]) on the device."""
     lib = load()
     _require_cuda(pool, masks)
@@ -478,6 +478,7 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
     lists = AugLists()
     lists.order = d_units.data_ptr() + nb_units
     lists.n_plain, lists.n_sharp, lists.n_generic, lists.n_generic_sharp = n_plain, n_sharp, n_generic, n_generic_sharp
+    lists.gen_chunk = int(gen_chunk)
     for k in range(MAX_OPS):
         lists.stat_units[k] = d_units.data_ptr() + nb_units + 4 * N * (1 + k)
         lists.n_stat[k] = summary[8 + k]
@@ -1538,89 +1539,61 @@ class WlItem(ctypes.Structure):
                 ("Co", ctypes.c_int32), ("Ci", ctypes.c_int32), ("taps", ctypes.c_int32), ("flip", ctypes.c_int32)]
 
 
-_SHADOWS = {}          # id(weight) -> _Shadow
-
-# A shadow is valid while its master weight is unchanged.  In-place ATen ops bump `weight._version` -- but torch's FUSED optimizers
-# (`Adam(fused=True)`: torch._fused_adam_) update the parameters without bumping it (checked on torch 2.10), so every optimizer step of
-# ANY optimizer also advances this epoch (a global post-step hook, installed with the first tracked model).
-_WEIGHTS_EPOCH = [0]
-_STEP_HOOK = []
-_SHADOW_GEN = [0]      # advanced whenever a set of shadows is (re)built
-_OPT_OWNS = __import__('weakref').WeakKeyDictionary()   # optimizer -> (shadow generation, does it hold a tracked weight); keyed by the
-                                                        # object, not its id: ids are reused once an optimizer / a parameter has died
-
-
-def _install_step_hook():
-    if not _STEP_HOOK:
-        from torch.optim.optimizer import register_optimizer_step_post_hook
-
-        def bump(optimizer, args, kwargs):
-            # only an optimizer that owns a tracked weight changes one (the discriminator's and the controller's steps run between the
-            # segmentation model's forward and backward)
-            ent = _OPT_OWNS.get(optimizer)
-            if ent is None or ent[0] != _SHADOW_GEN[0]:
-                def tracked(p):
-                    e = _SHADOWS.get(id(p))
-                    return e is not None and e.ref() is p
-                ent = (_SHADOW_GEN[0], any(tracked(p) for g in optimizer.param_groups for p in g['params']))
-                _OPT_OWNS[optimizer] = ent
-            if ent[1]:
-                _WEIGHTS_EPOCH[0] += 1
-        _STEP_HOOK.append(register_optimizer_step_post_hook(bump))
-
-
+# Ownership and validity (round 4: no table keyed by id(), no global optimizer hook, no version / epoch bookkeeping).  A shadow hangs on
+# its parameter (`weight._aadg_shadow`) and belongs to the `_WeightLayouts` of ONE model.  The model's forward pre-hook rebuilds ALL
+# shadows from the master weights -- unconditionally: 80 us per forward, and the only rule that is right for every way a weight can
+# change (torch's fused optimizers do not even bump the version counter) -- and opens the scope in which they are trusted; the forward
+# post-hook closes it.  Outside a tracked model's forward, `cast_weight` / `weight_layout` fall back to per-call copies.  What an
+# autograd function keeps for its backward is a `_ShadowRef`: the buffers stay valid until the owner's NEXT refresh overwrites them
+# (`generation`), whatever optimizer steps happen in between.
 class _Shadow(object):
-    __slots__ = ("ref", "plain", "fwd", "bwd", "version", "epoch", "ptr", "flip")
+    __slots__ = ("owner", "plain", "fwd", "bwd", "ptr", "flip")
 
-    def valid_for(self, weight):
-        return self.version == weight._version and self.epoch == _WEIGHTS_EPOCH[0] and self.ref() is weight
+
+def _shadow_of(weight):
+    e = getattr(weight, "_aadg_shadow", None)
+    if e is not None and e.owner.active and e.ptr == weight.data_ptr():
+        return e
+    return None
 
 
 def cast_weight(weight, dtype):
-    e = _SHADOWS.get(id(weight))
-    if e is not None and dtype == torch.bfloat16 and e.valid_for(weight):
-        return e.plain
-    return weight.to(dtype)
+    e = _shadow_of(weight) if dtype == torch.bfloat16 else None
+    return e.plain if e is not None else weight.to(dtype)
 
 
 def weight_layout(weight, which):
     """The tracked bfloat16 copy of `weight` [Co, Ci, kh, kw] in layout 'fwd' ([taps, Co, Ci]) or 'bwd' ([taps, Ci, Co]; taps mirrored
-    for a stride-1 3x3 convolution), or None when the weight is not tracked / its shadow is stale."""
-    e = _SHADOWS.get(id(weight))
-    if e is None or not e.valid_for(weight):
+    for a stride-1 3x3 convolution), or None when the weight is not tracked or the call is not inside its model's forward."""
+    e = _shadow_of(weight)
+    if e is None:
         return None
     return e.fwd if which == "fwd" else e.bwd
 
 
 class _ShadowRef(object):
-    """What an autograd function keeps of a shadow layout between forward and backward: the buffer AND the state it was valid in.
-    The buffers are overwritten in place by the next refresh, so a backward that runs after a later forward + optimizer step (deferred
-    backward, checkpointing) must not read them: `get()` then returns None and the caller rebuilds the layout from its saved weights."""
-    __slots__ = ("entry", "tensor", "version", "epoch")
+    """What an autograd function keeps of a shadow layout between forward and backward: the buffer and the owner's refresh generation
+    it was written in.  The buffers are overwritten in place by the owner's next refresh (= the model's next forward), and the saved
+    bfloat16 cast aliases the shadow too, so a backward that runs after a LATER forward of the same model (deferred backward,
+    activation checkpointing, two forwards before one backward) cannot be served: `get()` fails loudly (AadgError) instead of
+    computing with the newer weights.  `get()` returns None only for an untracked weight (the caller builds the layout itself)."""
+    __slots__ = ("entry", "tensor", "generation")
 
     def __init__(self, weight, which):
-        e = _SHADOWS.get(id(weight))
-        self.entry, self.tensor = None, None
-        if e is not None and e.valid_for(weight):
-            self.entry, self.tensor, self.version, self.epoch = e, (e.fwd if which == "fwd" else e.bwd), e.version, e.epoch
+        e = _shadow_of(weight)
+        self.entry, self.tensor, self.generation = None, None, -1
+        if e is not None:
+            self.entry, self.tensor, self.generation = e, (e.fwd if which == "fwd" else e.bwd), e.owner.generation
 
     def get(self):
         e = self.entry
         if e is None:
             return None                     # untracked weight: the caller builds the layout from its own saved cast
-        if e.version != self.version or e.epoch != self.epoch or e.epoch != _WEIGHTS_EPOCH[0]:
-            # the saved bfloat16 cast aliases the shadow too (cast_weight), so the forward's weights are gone: fail loudly
-            raise AadgError("backward of a tracked convolution after its weights changed (optimizer step or invalidate_weight_shadows() "
-                            "between forward and backward): the bfloat16 shadows hold the NEW weights.  Run backward before the step, "
+        if e.owner.generation != self.generation:
+            raise AadgError("backward of a tracked convolution after a later forward of its model: the bfloat16 weight shadows were "
+                            "rebuilt in place and hold that forward's weights.  Run each backward before the model's next forward, "
                             "or build the model without track_bf16_weights")
         return self.tensor
-
-
-def invalidate_weight_shadows():
-    """Call after changing tracked master weights OUTSIDE a torch.optim step and without bumping their version counter (writes through
-    `.data`, `torch._foreach_*` on `.data`, loading a checkpoint into `.data`): every shadow is rebuilt at the next forward.  In-place
-    ATen ops on the parameter itself and optimizer steps are detected automatically (version counter, global post-step hook)."""
-    _WEIGHTS_EPOCH[0] += 1
 
 
 class _WeightLayouts(object):
@@ -1630,21 +1603,21 @@ class _WeightLayouts(object):
         self.entries = entries              # [(weight, flip)]
         self.items = self.tiles = None
         self.n_tiles = 0
+        self.generation = 0                 # refreshes so far: what a _ShadowRef compares
+        self.active = False                 # inside the model's forward: the shadows hold the current master weights
 
     def _build(self):
-        import weakref
-        _SHADOW_GEN[0] += 1
         dev = self.entries[0][0].device
         items = (WlItem * len(self.entries))()
         tiles = []
         for i, (w, flip) in enumerate(self.entries):
             Co, Ci, taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
             e = _Shadow()
-            e.ref, e.version, e.epoch, e.ptr, e.flip = weakref.ref(w), -1, -1, w.data_ptr(), flip
+            e.owner, e.ptr, e.flip = self, w.data_ptr(), flip
             e.plain = torch.empty(w.shape, dtype=torch.bfloat16, device=dev)
             e.fwd = torch.empty((taps, Co, Ci), dtype=torch.bfloat16, device=dev) if taps > 1 else e.plain.view(1, Co, Ci)
             e.bwd = torch.empty((taps, Ci, Co), dtype=torch.bfloat16, device=dev)
-            _SHADOWS[id(w)] = e
+            w._aadg_shadow = e
             items[i] = WlItem(w.data_ptr(), e.plain.data_ptr(), e.fwd.data_ptr() if taps > 1 else None, e.bwd.data_ptr(), Co, Ci, taps, flip)
             tiles += [(i, o0, c0) for o0 in range(0, Co, 32) for c0 in range(0, Ci, 256 if taps == 1 else 32)]
         raw = np.frombuffer(bytes(items), dtype=np.uint8).copy()
@@ -1653,24 +1626,23 @@ class _WeightLayouts(object):
         self.n_tiles = len(tiles)
 
     def refresh(self):
+        """all shadows <- the master weights as they are now (one launch); opens the scope in which they are served"""
         stale = self.items is None
-        changed = False
-        for w, _ in self.entries:
-            e = _SHADOWS.get(id(w))
-            if e is None or e.ref() is not w or e.ptr != w.data_ptr() or e.plain.device != w.device:
-                stale = True
-                break
-            changed = changed or e.version != w._version or e.epoch != _WEIGHTS_EPOCH[0]
+        if not stale:
+            for w, _ in self.entries:
+                e = getattr(w, "_aadg_shadow", None)
+                if e is None or e.owner is not self or e.ptr != w.data_ptr() or e.plain.device != w.device:
+                    stale = True                   # storage moved (.to(), load into new tensors) or taken over by another tracker
+                    break
         if stale:
             self._build()
-            changed = True
-        if not changed:
-            return
         _check(load().aadg_weight_layouts_bf16(self.items.data_ptr(), self.tiles.data_ptr(), self.n_tiles, _stream()),
                "aadg_weight_layouts_bf16")
-        for w, _ in self.entries:
-            e = _SHADOWS[id(w)]
-            e.version, e.epoch = w._version, _WEIGHTS_EPOCH[0]
+        self.generation += 1
+        self.active = True
+
+    def close(self):
+        self.active = False
 
 
 def track_bf16_weights(model, module_types):
@@ -1684,18 +1656,25 @@ def track_bf16_weights(model, module_types):
             stride = m.stride[0] if isinstance(m.stride, (tuple, list)) else m.stride
             entries.append((m.weight, 1 if (m.weight.shape[2] == 3 and stride == 1) else 0))
     if entries:
-        _install_step_hook()
         wl = _WeightLayouts(entries)
         model.register_forward_pre_hook(lambda mod, args: wl.refresh())
+        model.register_forward_hook(lambda mod, args, out: wl.close(), always_call=True)
         model._aadg_weight_layouts = wl
     return len(entries)
 
 
 def refresh_bf16_weights(model):
-    """The pre-hook's work, callable directly (tests / callers that run sub-modules of a tracked model on their own)."""
+    """The pre-hook's work, callable directly by a caller that runs sub-modules of a tracked model on their own: rebuilds the shadows
+    and leaves them trusted until `release_bf16_weights(model)` (or the model's next full forward)."""
     wl = getattr(model, "_aadg_weight_layouts", None)
     if wl is not None:
         wl.refresh()
+
+
+def release_bf16_weights(model):
+    wl = getattr(model, "_aadg_weight_layouts", None)
+    if wl is not None:
+        wl.close()
 
 
 def conv3x3_wgrad(dy, x, dilation=1):

@@ -1305,177 +1305,10 @@ __device__ __forceinline__ float normalise_u8(int v) {
     return __fsub_rn(__fmaf_rn(e, r, q0), 1.0f);
 }
 
-// k_fused: grid (ceil(crop/256), ceil(crop/TH), N).  Memory round trips are kept to three dependent levels:
-// unit record -> all table entries / LUTs (issued together) -> source patch; the mask gather of the vertical
-// phase is issued before the arithmetic it is independent of.
-template <int TH>
-__device__ __forceinline__ void fused_tile(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
-                                           const aadg_unit* __restrict__ units, int Hs, int Ws, int crop, int dataset_in,
-                                           const int* __restrict__ tab, const uint8_t* __restrict__ lut,
-                                           size_t lut_stage_stride, float* __restrict__ out_img, float* __restrict__ out_lbl,
-                                           int u, int bx, int by, uint32_t* A, uint32_t* B, uint8_t* sl, const float* lutf) {
-    const int dataset = dataset_in & 0xFF;
-    const bool stream_out = (dataset_in & AUG_STREAM_OUT) != 0;
-    constexpr int ROWS_PER_WAVE = TH / 4;
-    const aadg_unit& un = units[u];
-    if (unit_flow(true, un, Hs, Ws, crop) != FLOW_UP) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-
-    const int K = dataset == AADG_DATASET_OPTIC ? 2 : 1;
-    const int* base = tab + (size_t)u * crop * TAB_STRIDE;
-    const int* xmin_t = base;
-    const int* xk_t = xmin_t + crop;
-    const int* ymin_t = xk_t + (size_t)crop * KMAX;
-    const int* yk_t = ymin_t + crop;
-    const int* xnn_t = yk_t + (size_t)crop * KMAX;
-    const int* ynn_t = xnn_t + crop;
-
-    const int x0 = bx * FT_W, x1 = min(x0 + FT_W, crop);
-    const int y0 = by * TH, y1 = min(y0 + TH, crop);
-    const int w = un.scaled_w, h = un.scaled_h, n_ops = un.n_ops;
-    const int ox = un.crop_x - un.pad, oy = un.crop_y - un.pad;
-    // valid (non-pad) output range of this tile: scaled coordinate s = o + off must lie in [0, size)
-    const int fx = max(x0, -ox), lx = min(x1 - 1, w - 1 - ox);
-    const int fy = max(y0, -oy), ly = min(y1 - 1, h - 1 - oy);
-    const bool any = fx <= lx && fy <= ly;
-    const int ntx = w == Ws ? 1 : 2, nty = h == Hs ? 1 : 2;   // taps of an up-scaling BILINEAR axis: <= 2
-
-    // ---- level 2 loads, all independent: tile bounds, per-thread x tables, per-wave y tables, LUTs ----------
-    // tile bounds in the source image (uniform addresses: scalar loads)
-    int t_rlo = 0, t_rhi = 0, t_clo = 0, t_chi = 0;
-    if (any) { t_rlo = ymin_t[fy]; t_rhi = ymin_t[ly]; t_clo = xmin_t[fx]; t_chi = xmin_t[lx]; }
-    const int xh = x0 + tid;                         // horizontal pass: thread <-> output column
-    int hxm = -1, hk0 = 0, hk1 = 0;
-    if (any && xh >= fx && xh <= lx) {
-        hxm = xmin_t[xh];
-        hk0 = xk_t[(size_t)xh * KMAX];
-        hk1 = ntx > 1 ? xk_t[(size_t)xh * KMAX + 1] : 0;
-    }
-    const int xq = x0 + 4 * lane;                    // vertical pass: lane <-> 4 consecutive columns
-    const bool col_ok = xq < crop;
-    int4 xm4 = make_int4(-1, -1, -1, -1), xn4 = make_int4(-1, -1, -1, -1);
-    if (col_ok) {
-        xm4 = *reinterpret_cast<const int4*>(xmin_t + xq);
-        xn4 = *reinterpret_cast<const int4*>(xnn_t + xq);
-    }
-    int vym[ROWS_PER_WAVE], vk0[ROWS_PER_WAVE], vk1[ROWS_PER_WAVE], vyn[ROWS_PER_WAVE];
-#pragma unroll
-    for (int r = 0; r < ROWS_PER_WAVE; ++r) {
-        const int y = y0 + wv + 4 * r;
-        vym[r] = -1; vk0[r] = vk1[r] = 0; vyn[r] = -1;
-        if (y < y1) {
-            vym[r] = ymin_t[y];
-            vyn[r] = ynn_t[y];
-            vk0[r] = yk_t[(size_t)y * KMAX];
-            vk1[r] = nty > 1 ? yk_t[(size_t)y * KMAX + 1] : 0;
-        }
-    }
-
-    int r_lo = 0;
-    uint32_t* Hbuf = B;
-    if (any) {
-        r_lo = t_rlo;
-        const int r_hi = min(Hs, t_rhi + nty);
-        const int c_hi = min(Ws, t_chi + ntx);
-        const int s = sharp_count(un, n_ops);
-        const int r_lo_h = max(0, r_lo - s), r_hi_h = min(Hs, r_hi + s);
-        const int c_lo_h = max(0, t_clo - s) & ~3, c_hi_h = min(Ws, (c_hi + s + 3) & ~3);
-        const int pw = c_hi_h - c_lo_h;
-        const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
-        const uint32_t* cur = build_patch<6, 1>(un, n_ops, src, Hs, Ws, r_lo_h, r_hi_h, c_lo_h, c_hi_h, A, B, lut, lut_stage_stride, u, sl);
-        Hbuf = cur == A ? B : A;
-        // ---- horizontal pass ---------------------------------------------------------------------------
-        const int nrows = r_hi - r_lo;
-        if (hxm >= 0) {
-            const uint32_t* col = cur + (r_lo - r_lo_h) * pw + (hxm - c_lo_h);
-            const int d1 = hk1 ? 1 : 0;             // no second tap (identity axis / right image edge): re-read the first
-#pragma unroll 4                                    // LDS latency of 4 rows in flight (0.219 -> 0.201 ms per batch)
-            for (int rr = 0; rr < nrows; ++rr) {
-                const uint32_t p0 = col[rr * pw];
-                const uint32_t p1 = col[rr * pw + d1];
-                const int half = 1 << (PRECISION_BITS - 1);
-                // pixel (8 bit) x coefficient (<= 2^22): 24-bit multiplies are full rate, v_mul_lo_u32 is not
-                const uint32_t s0 = half + __mul24((int)(p0 & 255), hk0) + __mul24((int)(p1 & 255), hk1);
-                const uint32_t s1 = half + __mul24((int)((p0 >> 8) & 255), hk0) + __mul24((int)((p1 >> 8) & 255), hk1);
-                const uint32_t s2 = half + __mul24((int)((p0 >> 16) & 255), hk0) + __mul24((int)((p1 >> 16) & 255), hk1);
-                // <= 2 non-negative taps with k0 + k1 <= 2^22 + 1: 0 < s < 256 * 2^22, so Pillow's clip8 is the identity here
-                Hbuf[rr * FT_W + tid] = (s0 >> 22) | ((s1 >> 14) & 0xFF00u) | ((s2 >> 6) & 0xFF0000u);
-            }
-        } else {
-            for (int rr = 0; rr < nrows; ++rr) Hbuf[rr * FT_W + tid] = 0u;
-        }
-    }
-    // mask bytes for this wave's rows (needs only the NEAREST tables): in flight across the barrier
-    const uint8_t* msk = masks + (size_t)un.src * Hs * Ws;
-    const int xn[4] = {xn4.x, xn4.y, xn4.z, xn4.w};
-    uint32_t mv[ROWS_PER_WAVE][4];
-#pragma unroll
-    for (int r = 0; r < ROWS_PER_WAVE; ++r)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            mv[r][i] = 0;
-            if (vyn[r] >= 0 && xn[i] >= 0) mv[r][i] = msk[(size_t)vyn[r] * Ws + xn[i]];
-        }
-    __syncthreads();
-
-    // ---- vertical pass + normalise + store: wave <-> output row, lane <-> 4 consecutive columns -----------
-    if (!col_ok) return;
-    const size_t plane = (size_t)crop * crop;
-    float* oi = out_img + (size_t)u * 3 * plane;
-    float* ol = out_lbl + (size_t)u * K * plane;
-    const float padv = -1.0f;                    // normalise(0)
-    const uint32_t lbl_t0 = dataset == AADG_DATASET_OPTIC ? 50u : 0u;
-    const bool lbl_flip = dataset != AADG_DATASET_OPTIC;
-#pragma unroll
-    for (int r = 0; r < ROWS_PER_WAVE; ++r) {
-        const int y = y0 + wv + 4 * r;
-        if (y >= y1) break;
-        const int ym = vym[r];
-        float o[3][4];
-        if (ym >= 0) {
-            const int ky0 = vk0[r], ky1 = vk1[r];
-            const uint4 h0 = *reinterpret_cast<const uint4*>(Hbuf + (ym - r_lo) * FT_W + 4 * lane);
-            const uint4 h1 = *reinterpret_cast<const uint4*>(Hbuf + (ym + (ky1 ? 1 : 0) - r_lo) * FT_W + 4 * lane);
-            const uint32_t a0[4] = {h0.x, h0.y, h0.z, h0.w};
-            const uint32_t a1[4] = {h1.x, h1.y, h1.z, h1.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const uint32_t v = (1u << (PRECISION_BITS - 1)) + __mul24((int)((a0[i] >> (8 * c)) & 255), ky0) +
-                                       __mul24((int)((a1[i] >> (8 * c)) & 255), ky1);
-                    o[c][i] = lutf[v >> 22];     // no clip needed (see the horizontal pass); pad columns: H == 0 -> lutf[0] == -1.0
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[0][i] = o[1][i] = o[2][i] = padv;
-        }
-        // multilabel planes without per-pixel branches: optic  l0 = (m <= 50), l1 = (m <= 200);
-        //                                                vessel l0 = (m >= 1) == !(m <= 0)
-        float l0[4], l1[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t m = mv[r][i];
-            l0[i] = ((m <= lbl_t0) != lbl_flip) ? 1.0f : 0.0f;
-            l1[i] = m <= 200u ? 1.0f : 0.0f;
-        }
-        const size_t off = (size_t)y * crop + xq;
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            store_out4(oi + c * plane + off, make_float4(o[c][0], o[c][1], o[c][2], o[c][3]), stream_out);
-        store_out4(ol + off, make_float4(l0[0], l0[1], l0[2], l0[3]), stream_out);
-        if (K == 2) store_out4(ol + plane + off, make_float4(l1[0], l1[1], l1[2], l1[3]), stream_out);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// GENERIC fused tile: any axis scale in [1/2, inf) (Pillow's antialiased BILINEAR: up to 5 taps when shrinking
-// by 2).  Tile = 64 x 16 outputs: the source patch of a 2x down-scale (<= 41 x 144 pixels) fits the same two
-// 24 KiB LDS buffers as the UP tile.  Horizontal: thread <-> (column, row group); vertical: a wave covers
-// 4 rows x 64 columns (16 lanes x float4 per row).
+// Down-scaling ("generic") units: any axis scale in [1/2, 1) (Pillow's antialiased BILINEAR: up to 5 taps when shrinking by 2).
 // ------------------------------------------------------------------------------------------------
-constexpr int GT_W = 64, GT_H = 16, GT_TAPS = 5;
+constexpr int GT_TAPS = 5;
 
 __device__ __forceinline__ int axis_taps(int inSize, int outSize) {
     if (inSize == outSize) return 1;
@@ -1487,169 +1320,6 @@ __device__ __forceinline__ int axis_taps(int inSize, int outSize) {
     if (3 * outSize > 2 * inSize) return 3;
     if (2 * outSize > inSize) return 4;
     return GT_TAPS;
-}
-
-__global__ __launch_bounds__(256) void k_fused_generic(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
-                                                       const aadg_unit* __restrict__ units, const int* __restrict__ order,
-                                                       int Hs, int Ws, int crop, int dataset_in,
-                                                       const int* __restrict__ tab, const uint8_t* __restrict__ lut,
-                                                       size_t lut_stage_stride, float* __restrict__ out_img,
-                                                       float* __restrict__ out_lbl) {
-    const int dataset = dataset_in & 0xFF;
-    const bool stream_out = (dataset_in & AUG_STREAM_OUT) != 0;
-    const int u = order != nullptr ? order[blockIdx.z] : blockIdx.z;      // order: the units of this class (caller's list)
-    const aadg_unit& un = units[u];
-    if (unit_flow(true, un, Hs, Ws, crop) != FLOW_GENERIC) return;
-    __shared__ __attribute__((aligned(16))) uint32_t A[PATCH_CAP];
-    __shared__ __attribute__((aligned(16))) uint32_t B[PATCH_CAP];
-    __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
-    __shared__ float lutf[256];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    lutf[tid] = normalise_u8(tid);
-
-    const int K = dataset == AADG_DATASET_OPTIC ? 2 : 1;
-    const int* base = tab + (size_t)u * crop * TAB_STRIDE;
-    const int* xmin_t = base;
-    const int* xk_t = xmin_t + crop;
-    const int* ymin_t = xk_t + (size_t)crop * KMAX;
-    const int* yk_t = ymin_t + crop;
-    const int* xnn_t = yk_t + (size_t)crop * KMAX;
-    const int* ynn_t = xnn_t + crop;
-
-    const int x0 = blockIdx.x * GT_W, x1 = min(x0 + GT_W, crop);
-    const int y0 = blockIdx.y * GT_H, y1 = min(y0 + GT_H, crop);
-    const int w = un.scaled_w, h = un.scaled_h, n_ops = un.n_ops;
-    const int ox = un.crop_x - un.pad, oy = un.crop_y - un.pad;
-    const int fx = max(x0, -ox), lx = min(x1 - 1, w - 1 - ox);
-    const int fy = max(y0, -oy), ly = min(y1 - 1, h - 1 - oy);
-    const bool any = fx <= lx && fy <= ly;
-    const int ntx = axis_taps(Ws, w), nty = axis_taps(Hs, h);
-
-    // horizontal pass: thread <-> (output column hc, row group hg)
-    const int hc = tid & (GT_W - 1), hg = tid >> 6;
-    const int xh = x0 + hc;
-    int hxm = -1, hk[GT_TAPS];
-#pragma unroll
-    for (int t = 0; t < GT_TAPS; ++t) hk[t] = 0;
-    if (any && xh >= fx && xh <= lx) {
-        hxm = xmin_t[xh];
-#pragma unroll
-        for (int t = 0; t < GT_TAPS; ++t) if (t < ntx) hk[t] = xk_t[(size_t)xh * KMAX + t];
-    }
-    // vertical pass: lane <-> (row-in-wave vr = lane >> 4, 4 consecutive columns)
-    const int vr = lane >> 4, xq = x0 + 4 * (lane & 15);
-    const bool col_ok = xq < crop;
-    int4 xm4 = make_int4(-1, -1, -1, -1), xn4 = make_int4(-1, -1, -1, -1);
-    if (col_ok) {
-        xm4 = *reinterpret_cast<const int4*>(xmin_t + xq);
-        xn4 = *reinterpret_cast<const int4*>(xnn_t + xq);
-    }
-    const int yv = y0 + wv * 4 + vr;                 // this lane's output row (one row per lane group, one pass)
-    const bool row_ok = yv < y1;
-    int vym = -1, vyn = -1, vk[GT_TAPS];
-#pragma unroll
-    for (int t = 0; t < GT_TAPS; ++t) vk[t] = 0;
-    if (row_ok) {
-        vym = ymin_t[yv];
-        vyn = ynn_t[yv];
-#pragma unroll
-        for (int t = 0; t < GT_TAPS; ++t) if (t < nty) vk[t] = yk_t[(size_t)yv * KMAX + t];
-    }
-
-    int r_lo = 0, nrows = 0;
-    uint32_t* Hbuf = B;
-    if (any) {
-        r_lo = ymin_t[fy];
-        const int r_hi = min(Hs, ymin_t[ly] + nty);
-        const int c_lo = xmin_t[fx], c_hi = min(Ws, xmin_t[lx] + ntx);
-        const int s = sharp_count(un, n_ops);
-        const int r_lo_h = max(0, r_lo - s), r_hi_h = min(Hs, r_hi + s);
-        const int c_lo_h = max(0, c_lo - s) & ~3, c_hi_h = min(Ws, (c_hi + s + 3) & ~3);
-        const int pw = c_hi_h - c_lo_h;
-        const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
-        const uint32_t* cur = build_patch<11, 0>(un, n_ops, src, Hs, Ws, r_lo_h, r_hi_h, c_lo_h, c_hi_h, A, B, lut,
-                                                     lut_stage_stride, u, sl);
-        Hbuf = cur == A ? B : A;
-        nrows = r_hi - r_lo;
-        const int pcols = c_hi_h - c_lo_h;
-#pragma unroll 2
-        for (int rr = hg; rr < nrows; rr += 4) {
-            uint32_t packed = 0u;
-            if (hxm >= 0) {
-                const uint32_t* rowp = cur + (r_lo - r_lo_h + rr) * pw + (hxm - c_lo_h);
-                const int lim = pcols - (hxm - c_lo_h);          // taps beyond the patch have zero coefficients
-                int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
-#pragma unroll
-                for (int t = 0; t < GT_TAPS; ++t) {
-                    if (t < ntx) {
-                        const uint32_t p = rowp[t < lim ? t : 0];
-                        s0 += __mul24((int)(p & 255), hk[t]);
-                        s1 += __mul24((int)((p >> 8) & 255), hk[t]);
-                        s2 += __mul24((int)((p >> 16) & 255), hk[t]);
-                    }
-                }
-                packed = (uint32_t)clip8(s0) | ((uint32_t)clip8(s1) << 8) | ((uint32_t)clip8(s2) << 16);
-            }
-            Hbuf[rr * GT_W + hc] = packed;
-        }
-    }
-    // mask bytes (NEAREST tables only)
-    const uint8_t* msk = masks + (size_t)un.src * Hs * Ws;
-    const int xn[4] = {xn4.x, xn4.y, xn4.z, xn4.w};
-    uint32_t mv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        mv[i] = 0;
-        if (row_ok && vyn >= 0 && xn[i] >= 0) mv[i] = msk[(size_t)vyn * Ws + xn[i]];
-    }
-    __syncthreads();
-    if (!col_ok || !row_ok) return;
-    const int xm[4] = {xm4.x, xm4.y, xm4.z, xm4.w};
-    const size_t plane = (size_t)crop * crop;
-    float* oi = out_img + (size_t)u * 3 * plane;
-    float* ol = out_lbl + (size_t)u * K * plane;
-    const float padv = -1.0f;
-    float o[3][4];
-    if (vym >= 0) {
-        int acc[4][3];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = 1 << (PRECISION_BITS - 1);
-#pragma unroll
-        for (int t = 0; t < GT_TAPS; ++t) {
-            if (t < nty) {
-                int hr = vym + t - r_lo;
-                hr = hr < nrows ? hr : nrows - 1;                // zero coefficient beyond the last row
-                const uint4 hv = *reinterpret_cast<const uint4*>(Hbuf + hr * GT_W + 4 * (lane & 15));
-                const uint32_t a[4] = {hv.x, hv.y, hv.z, hv.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc[i][0] += __mul24((int)(a[i] & 255), vk[t]);
-                    acc[i][1] += __mul24((int)((a[i] >> 8) & 255), vk[t]);
-                    acc[i][2] += __mul24((int)((a[i] >> 16) & 255), vk[t]);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) o[c][i] = xm[i] >= 0 ? lutf[clip8(acc[i][c])] : padv;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[0][i] = o[1][i] = o[2][i] = padv;
-    }
-    float l0[4], l1[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t m = mv[i];
-        if (dataset == AADG_DATASET_OPTIC) { l0[i] = m <= 50 ? 1.0f : 0.0f; l1[i] = m <= 200 ? 1.0f : 0.0f; }
-        else { l0[i] = m != 0 ? 1.0f : 0.0f; l1[i] = 0.0f; }
-    }
-    const size_t off = (size_t)yv * crop + xq;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-        store_out4(oi + c * plane + off, make_float4(o[c][0], o[c][1], o[c][2], o[c][3]), stream_out);
-    store_out4(ol + off, make_float4(l0[0], l0[1], l0[2], l0[3]), stream_out);
-    if (K == 2) store_out4(ol + plane + off, make_float4(l1[0], l1[1], l1[2], l1[3]), stream_out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1664,7 +1334,7 @@ __global__ __launch_bounds__(256) void k_fused_generic(const uint8_t* __restrict
 //   * k_gen_vpass: wave <-> output row, lane <-> 4 consecutive columns; the <= 5 taps are 16-byte loads of the intermediate, the row
 //     tables are scalar loads; normalise through the LDS table, NEAREST mask gather, multilabel planes, streaming 16-byte stores;
 //     rows / columns of the padding are constant stores.
-// k_fused_generic (one pass, above) stays selectable with AADG_GENERIC_V1=1; tests/test_gpu_aug_variants.py compares the two bit for bit.
+// (The one-pass tile of rounds 1-2, k_fused_generic, is gone since round 4; its measurements are in DESIGN.md section 4.)
 // ------------------------------------------------------------------------------------------------
 constexpr int GH_CB = 128;             // output columns per horizontal-pass tile: <= 2 * 128 + 5 source columns (+ halo, alignment) <= 272
 constexpr int GH_NR = 4;               // patch rows per wave of build_patch: 4 * GH_NR >= GH_PATCH_ROWS
@@ -1946,23 +1616,8 @@ __global__ __launch_bounds__(256) void k_gen_vpass(const uint8_t* __restrict__ m
     }
 }
 
-// one workgroup per tile
-template <int TH>
-__global__ __launch_bounds__(256) void k_fused(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
-                                               const aadg_unit* __restrict__ units, int Hs, int Ws, int crop, int dataset,
-                                               const int* __restrict__ tab, const uint8_t* __restrict__ lut,
-                                               size_t lut_stage_stride, float* __restrict__ out_img, float* __restrict__ out_lbl) {
-    __shared__ __attribute__((aligned(16))) uint32_t A[PATCH_CAP];
-    __shared__ __attribute__((aligned(16))) uint32_t B[PATCH_CAP];
-    __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
-    __shared__ float lutf[256];
-    lutf[threadIdx.x] = normalise_u8(threadIdx.x);
-    fused_tile<TH>(pool, masks, units, Hs, Ws, crop, dataset, tab, lut, lut_stage_stride, out_img, out_lbl, blockIdx.z,
-                   blockIdx.x, blockIdx.y, A, B, sl, lutf);
-}
-
 // ------------------------------------------------------------------------------------------------
-// k_fused3 (round 2): the UP tile of k_fused with a leaner instruction stream and a smaller footprint.
+// k_fused3 (round 2): the UP tile (round 1: k_fused) with a leaner instruction stream and a smaller footprint.
 //   * 39 KiB of LDS (an 18 KiB patch + a 17 KiB buffer for the horizontally resampled rows) and <= 128 VGPRs: 4 workgroups per
 //     CU instead of 3.  Units that chain Sharpness stencils (19 %) need a halo and a ping-pong buffer: their tile is processed
 //     as two 8-row halves that fit the same two buffers;
@@ -1974,7 +1629,7 @@ __global__ __launch_bounds__(256) void k_fused(const uint8_t* __restrict__ pool,
 //   * the mask bytes of a lane's 4 columns lie within 4 consecutive source bytes (scale >= 1): one dword load per row
 //     instead of four byte loads;
 //   * 32-bit offsets from uniform base pointers for the stores.
-// Arithmetic and results are those of k_fused (bit-exact with Pillow), which stays selectable (AADG_FUSED_V1=1).
+// Arithmetic and results are those of the round-1 tile (bit-exact with Pillow).
 // ------------------------------------------------------------------------------------------------
 constexpr int PATCH_CAP_PLAIN = 4608;     // 17 rows x 264 columns: a 256 x 16 tile's patch without a stencil halo
 constexpr int HBUF_ROWS = FT_H + 1;       // source rows a 16-row tile touches when no axis shrinks
@@ -2222,14 +1877,9 @@ __global__ __launch_bounds__(256) void k_fused3(const uint8_t* __restrict__ pool
 
 // list slots per chunk of the two-pass generic flow: as many as keep the chunk's intermediate (Hs x crop words per slot) within 128 MB, half of
 // the Infinity Cache -- 32 slots at 1024 x 1024 (measured there, 86 generic units of 168: all at once 0.914 ms for the batch's tile kernels,
-// chunks of 8 / 16 / 24 / 32 / 48 / 64 slots 0.971 / 0.909 / 0.870 / 0.862 / 0.910 / 0.931 ms).  AADG_GEN_CHUNK overrides the slot count.
-// The workspace holds one chunk's intermediate.
+// chunks of 8 / 16 / 24 / 32 / 48 / 64 slots 0.971 / 0.909 / 0.870 / 0.862 / 0.910 / 0.931 ms).  aadg_aug_lists.gen_chunk (ABI 7) asks for
+// FEWER slots per chunk (tests: chunk boundaries).  The workspace holds one chunk's intermediate.
 int gen_chunk(int Hs, int crop) {
-    static const int forced = [] {
-        const char* v = getenv("AADG_GEN_CHUNK");
-        return v != nullptr ? atoi(v) : 0;
-    }();
-    if (forced > 0) return forced;
     const size_t per_slot = (size_t)Hs * crop * 4;
     const size_t n = ((size_t)128 << 20) / (per_slot ? per_slot : 1);
     return n < 4 ? 4 : (n > 4096 ? 4096 : (int)n);
@@ -2261,19 +1911,13 @@ int chunks_for(int npix) {
 // hints from a caller that has the unit records on the host (all bits set = unknown, launch everything)
 constexpr int HINT_FUSED = 1, HINT_STAGED = 2, HINT_GENERIC = 4;
 
-bool getenv_flag(const char* name) {
-    const char* v = getenv(name);
-    return v != nullptr && v[0] != '\0' && v[0] != '0';
-}
-
 // The tile kernels of a call: k_fused3 over the up-scaling units (np plain slices + 2 per stencil unit; order_up == NULL: every unit is
 // offered every kind of slice), and for the ng down-scaling ("generic") units the horizontal pass (units without a stencil, then the
-// last ng_sharp units of the list with the stencil's ping-pong buffer) + the vertical pass -- or the one-pass tile kernel
-// k_fused_generic with AADG_GENERIC_V1=1.
+// last ng_sharp units of the list with the stencil's ping-pong buffer) + the vertical pass.  chunk_req: list slots per chunk of the
+// two passes (0 = gen_chunk(); never more than that: the workspace holds one default chunk).
 int launch_tiles(const uint8_t* pool, const uint8_t* masks, const aadg_unit* units, const int* order_up, int np, int ns, const int* order_gen,
                  int ng, int ng_sharp, int Hs, int Ws, int crop, int dsk, const int* tab, const uint8_t* lut, size_t lut_stage_stride,
-                 uint32_t* hbuf, float* out_img, float* out_lbl, hipStream_t st) {
-    static const bool v1 = getenv_flag("AADG_GENERIC_V1");
+                 uint32_t* hbuf, float* out_img, float* out_lbl, hipStream_t st, int chunk_req = 0) {
     const int gx = (crop + FT_W - 1) / FT_W, gy = (crop + FT_H - 1) / FT_H, gz = np + 2 * ns;
     const int* order_sharp = order_up != nullptr ? order_up + np : nullptr;
     // with the caller's list the stencil units are the last ng_sharp entries; without one every unit is offered to both variants
@@ -2288,17 +1932,10 @@ int launch_tiles(const uint8_t* pool, const uint8_t* masks, const aadg_unit* uni
         AADG_LAUNCH_CHECK();
     }
     if (ng <= 0) return 0;
-    if (v1) {
-        const dim3 g((crop + GT_W - 1) / GT_W, (crop + GT_H - 1) / GT_H, ng);
-        hipLaunchKernelGGL(k_fused_generic, g, dim3(256), 0, st, pool, masks, units, order_gen, Hs, Ws, crop, dsk, tab, lut, lut_stage_stride,
-                           out_img, out_lbl);
-        AADG_LAUNCH_CHECK();
-        return 0;
-    }
     // The generic units go through the two passes in chunks of gen_chunk() list slots that share ONE slice of the intermediate: what the
     // horizontal pass writes is read back by the vertical pass while it is still in the Infinity Cache (256 MB; 4 MB per unit at
     // 1024 x 1024), instead of after the whole batch's intermediate has gone to HBM and come back.
-    const int chunk = gen_chunk(Hs, crop);
+    const int chunk = (chunk_req > 0 && chunk_req < gen_chunk(Hs, crop)) ? chunk_req : gen_chunk(Hs, crop);
     const size_t slot_words = (size_t)Hs * crop;
     const int hy1 = (Hs + GhRows<true>::value - 1) / GhRows<true>::value;
     for (int a = 0; a < ng; a += chunk) {
@@ -2392,7 +2029,7 @@ int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int c
 // The call with the pool's statistics cached and the caller's late list (no staged units).  The first launch builds the tables and every
 // byte map that waits for no pixel pass (all of them for most units).  What is left is the late units' chain -- per slot k >= 1: histogram
 // pass over the image after k ops, then the maps of the late units -- and the tiles:
-//     k_luts_tables | k_hist_fused(1) k_lut(1, late) ... | k_fused3(all units) | k_fused_generic
+//     k_luts_tables | k_hist_fused(1) k_lut(1, late) ... | k_fused3 (up-scaling units) | k_gen_hpass + k_gen_vpass (down-scaling units, in chunks)
 // (Measured and dropped: the chain and the late units' tiles on a second, highest-priority stream beside the tile kernel of the other
 // units -- 268 instead of 278 us per 168-unit call once k_hist_fused fitted the LDS slot a retiring tile workgroup leaves (35 KiB; with
 // 51 KiB it starved until the tile kernel had drained).  3.5 % of the call for a fork / join, a second kernel name and a tile-kernel
@@ -2436,7 +2073,7 @@ int forward_cached(const uint8_t* pool, const uint8_t* masks, const UnitRef& ur,
     if (ev_before) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_before), st));
     {
         const int rc = launch_tiles(pool, masks, ur.units, ls.order, n_plain, n_sharp, ls.order + n_plain + n_sharp, n_generic, ls.n_generic_sharp, Hs, Ws,
-                                    crop, dsk, tab, lut, lut_stage_stride, reinterpret_cast<uint32_t*>(ws8 + L.hbuf), out_img, out_lbl, st);
+                                    crop, dsk, tab, lut, lut_stage_stride, reinterpret_cast<uint32_t*>(ws8 + L.hbuf), out_img, out_lbl, st, ls.gen_chunk);
         if (rc) return rc;
     }
     if (ev_after) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_after), st));
@@ -2559,6 +2196,7 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
         for (int k = 0; k < AADG_MAX_OPS; ++k)
             if (lists->n_stat[k] < 0 || lists->n_stat[k] > N || (lists->n_stat[k] > 0 && lists->stat_units[k] == nullptr) ||
                 lists->n_stat_stencil[k] < 0 || lists->n_stat_stencil[k] > lists->n_stat[k]) return AADG_E_BADARG;
+    if (lists != nullptr && lists->gen_chunk < 0) return AADG_E_BADARG;
     if (!pool || !masks || !units || !out_img || !out_lbl || !ws) return AADG_E_BADARG;
     if (P <= 0 || Hs <= 0 || Ws <= 0 || N <= 0 || crop <= 0) return AADG_E_BADARG;
     if (max_ops < 0 || max_ops > AADG_MAX_OPS) return AADG_E_BADARG;
@@ -2597,32 +2235,21 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
         AADG_LAUNCH_CHECK();
     }
     if (ev_before_final) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_before_final), st));
+    const int chunk_req = lists ? lists->gen_chunk : 0;
     if (classes & HINT_FUSED) {
-        const dim3 g((crop + FT_W - 1) / FT_W, (crop + FT_H - 1) / FT_H, N);
-        if (getenv_flag("AADG_FUSED_V1")) {
-            hipLaunchKernelGGL(k_fused<FT_H>, g, dim3(256), 0, st, pool, masks, units, Hs, Ws, crop, dsk, tab, ws8 + L.lut,
-                               (size_t)N * 768, out_img, out_lbl);
-            AADG_LAUNCH_CHECK();
-            if (classes & HINT_GENERIC) {
-                const int rc2 = launch_tiles(pool, masks, units, nullptr, 0, 0, order ? order + n_plain + n_sharp : nullptr, order ? n_generic : N,
-                                             lists ? lists->n_generic_sharp : 0, Hs, Ws, crop, dsk, tab, ws8 + L.lut, (size_t)N * 768,
-                                             reinterpret_cast<uint32_t*>(ws8 + L.hbuf), out_img, out_lbl, st);
-                if (rc2) return rc2;
-            }
-        } else {
-            // with the caller's class lists: one z-slice per plain unit, two per Sharpness unit, the down-scaling units' passes over their
-            // list; without: every unit is offered every kind of slice
-            const int np = order ? n_plain : N, ns = order ? n_sharp : N;
-            const int ng = (classes & HINT_GENERIC) ? (order ? n_generic : N) : 0;
-            const int rc2 = launch_tiles(pool, masks, units, order, np, ns, order ? order + n_plain + n_sharp : nullptr, ng,
-                                         lists ? lists->n_generic_sharp : 0, Hs, Ws, crop, dsk, tab, ws8 + L.lut, (size_t)N * 768,
-                                         reinterpret_cast<uint32_t*>(ws8 + L.hbuf), out_img, out_lbl, st);
-            if (rc2) return rc2;
-        }
+        // with the caller's class lists: one z-slice per plain unit, two per Sharpness unit, the down-scaling units' passes over their
+        // list; without: every unit is offered every kind of slice
+        const int np = order ? n_plain : N, ns = order ? n_sharp : N;
+        const int ng = (classes & HINT_GENERIC) ? (order ? n_generic : N) : 0;
+        const int rc2 = launch_tiles(pool, masks, units, order, np, ns, order ? order + n_plain + n_sharp : nullptr, ng,
+                                     lists ? lists->n_generic_sharp : 0, Hs, Ws, crop, dsk, tab, ws8 + L.lut, (size_t)N * 768,
+                                     reinterpret_cast<uint32_t*>(ws8 + L.hbuf), out_img, out_lbl, st, chunk_req);
+        if (rc2) return rc2;
     } else if (classes & HINT_GENERIC) {
         const int ng = order ? n_generic : N;
         const int rc2 = launch_tiles(pool, masks, units, nullptr, 0, 0, order ? order + n_plain + n_sharp : nullptr, ng, lists ? lists->n_generic_sharp : 0,
-                                     Hs, Ws, crop, dsk, tab, ws8 + L.lut, (size_t)N * 768, reinterpret_cast<uint32_t*>(ws8 + L.hbuf), out_img, out_lbl, st);
+                                     Hs, Ws, crop, dsk, tab, ws8 + L.lut, (size_t)N * 768, reinterpret_cast<uint32_t*>(ws8 + L.hbuf), out_img, out_lbl,
+                                     st, chunk_req);
         if (rc2) return rc2;
     }
     if (classes & HINT_STAGED) {

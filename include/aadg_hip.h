@@ -133,6 +133,10 @@ typedef struct aadg_aug_lists {
      * statistics pass gives each of their tiles a workgroup of its own (the image after k ops is rebuilt in LDS) and streams the
      * others.  A wrong split costs time, not correctness (the kernel chooses the data flow from the unit record). */
     int32_t n_stat_stencil[AADG_MAX_OPS];
+    /* ABI 7: list slots per chunk of the two-pass flow of the down-scaling units (the horizontally resampled rows of one chunk share one
+     * slice of the workspace).  0 = the library's choice (as many as keep a chunk's intermediate within 128 MB); a smaller positive
+     * value is honoured (tests of the chunk boundaries), a larger one is clamped to the library's. */
+    int32_t gen_chunk;
 } aadg_aug_lists;
 /* per-image histograms of a source pool [P, Hs, Ws, 3] (what PIL's Image.histogram() / ImageStat.Stat(convert('L')).mean read:
  * data/basic.py AutoContrast / Equalize / Contrast via ImageOps / ImageEnhance) */

@@ -169,7 +169,10 @@ def test_round2_entry_points_validate_arguments():
     lists = _lib.AugLists()
     lists.stat_units[1], lists.n_stat[1], lists.n_stat_stencil[1] = 16, 2, 3   # ABI 7: more stencil units than the list holds
     assert lib.aadg_aug_u8_forward_ex2(one, one, 1, 8, 8, one, 4, 2, 8, 0, one, one, one, 1 << 30, z, 0, -1, z, z, ctypes.byref(lists)) == -1
-    assert ctypes.sizeof(_lib.AugLists) == 8 + 16 + 8 * _lib.MAX_OPS + 4 * _lib.MAX_OPS + 8 + 8 + 8 + 4 * _lib.MAX_OPS   # mirror of aadg_aug_lists (n_generic_sharp fills the padding behind n_late; ABI 7: n_stat_stencil)
+    lists = _lib.AugLists()
+    lists.gen_chunk = -1
+    assert lib.aadg_aug_u8_forward_ex2(one, one, 1, 8, 8, one, 4, 2, 8, 0, one, one, one, 1 << 30, z, 0, -1, z, z, ctypes.byref(lists)) == -1
+    assert ctypes.sizeof(_lib.AugLists) == 8 + 16 + 8 * _lib.MAX_OPS + 4 * _lib.MAX_OPS + 8 + 8 + 8 + 4 * _lib.MAX_OPS + 8   # mirror of aadg_aug_lists (n_generic_sharp fills the padding behind n_late; ABI 7: n_stat_stencil, gen_chunk + tail padding)
 
 
 def test_round3_entry_points_validate_arguments():

@@ -93,28 +93,37 @@ def test_batched_step_bookkeeping(hip):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             out, feat = b(x)
         assert torch.isfinite(out.float()).all()
-        for m in convs:                                    # the shadow IS what the forward used, and it is the rounded master
-            sh = hip.cast_weight(m.weight, torch.bfloat16)
+        # outside the model's forward the shadows are not served (round 4: they are trusted only between the forward pre-hook, which
+        # rebuilds them, and the post-hook) ...
+        assert all(hip.weight_layout(m.weight, "fwd") is None for m in convs[:4])
+        # ... but the buffers are there: what the forward used IS the rounded master, in every layout the kernels read
+        for m in convs:
+            e = m.weight._aadg_shadow
+            sh = e.plain
             assert sh.data_ptr() != m.weight.data_ptr() and torch.equal(sh, m.weight.detach().to(torch.bfloat16))
             Co, Ci, k = m.weight.shape[0], m.weight.shape[1], m.weight.shape[2]
-            fwd, bwd = hip.weight_layout(m.weight, "fwd"), hip.weight_layout(m.weight, "bwd")   # the layouts the kernels read
-            assert torch.equal(fwd, sh.permute(2, 3, 0, 1).reshape(k * k, Co, Ci))
+            assert torch.equal(e.fwd, sh.permute(2, 3, 0, 1).reshape(k * k, Co, Ci))
             mirrored = k == 3 and m.stride[0] == 1                # stride-1 input gradient = the forward kernel with mirrored taps
-            assert torch.equal(bwd, (sh.flip(2, 3) if mirrored else sh).permute(2, 3, 1, 0).reshape(k * k, Ci, Co))
+            assert torch.equal(e.bwd, (sh.flip(2, 3) if mirrored else sh).permute(2, 3, 1, 0).reshape(k * k, Ci, Co))
         if step != 1:
-            with torch.no_grad():                          # an in-place update: stale until the next forward refreshes them
+            with torch.no_grad():                          # an in-place update: the next forward rebuilds the shadows from it
                 for p in b.parameters():
                     p.mul_(0.9)
         else:
-            # torch's fused Adam updates the parameters WITHOUT bumping their version counters: the shadows must still go stale
+            # torch's fused Adam updates the parameters WITHOUT bumping their version counters: the next forward must still see them
+            # (the refresh is unconditional: no version / epoch bookkeeping to fool)
             opt = torch.optim.Adam(b.parameters(), lr=1e-2, fused=True)
-            (out.float().square().mean() + feat.float().square().mean()).backward()
+            (out.float().square().mean() + feat.float().square().mean()).backward()     # the backward of THIS forward: served
             before = convs[0].weight.detach().clone()
             opt.step()
             assert not torch.equal(before, convs[0].weight.detach())
         w = convs[0].weight
-        assert torch.equal(hip.cast_weight(w, torch.bfloat16), w.detach().to(torch.bfloat16))      # version changed: falls back to a cast
-        assert hip.weight_layout(w, "fwd") is None and hip.weight_layout(w, "bwd") is None          # ... and to per-call copies
+        assert torch.equal(hip.cast_weight(w, torch.bfloat16), w.detach().to(torch.bfloat16))      # outside a forward: a plain cast
+        hip.refresh_bf16_weights(b)                                                                  # a caller-opened scope
+        assert hip.cast_weight(w, torch.bfloat16).data_ptr() == w._aadg_shadow.plain.data_ptr()
+        assert torch.equal(hip.weight_layout(w, "fwd").reshape(-1), w._aadg_shadow.fwd.reshape(-1))
+        hip.release_bf16_weights(b)
+        assert hip.weight_layout(w, "fwd") is None
     assert all(m.num_batches_tracked.item() == 3 for m in bns)
     b.eval()
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):

@@ -53,66 +53,60 @@ def test_module_matches_conv2d_under_autocast(hip):
     assert torch.allclose(m(xf), F.conv2d(xf, m.weight), atol=1e-4)
 
 
-def test_tracked_shadow_backward_after_weight_change_fails_loudly(hip):
-    """the bfloat16 shadows of tracked weights are rewritten in place by the next refresh.  A backward that runs after the
-    weights changed (optimizer step, or invalidate_weight_shadows() after a `.data` write) must not silently use the new weights."""
+def test_tracked_shadows_follow_the_weights_and_guard_late_backwards(hip):
+    """The bfloat16 shadows of tracked weights are rebuilt IN PLACE by every forward of their model (round 4: unconditionally -- no
+    version / epoch bookkeeping, no optimizer hooks).  So (1) whatever changed a master weight -- a `.data` write, torch's fused Adam,
+    neither of which bumps the version counter -- the next forward sees it; (2) an optimizer step BETWEEN a forward and its backward is
+    harmless: the backward reads the buffers as the forward left them; (3) a backward that runs after a LATER forward of the model
+    must not silently use that forward's weights: it fails loudly."""
     from aadg_amd import _lib
     from aadg_amd.models.deeplab import Conv1x1
     torch.manual_seed(3)
     net = torch.nn.Sequential(Conv1x1(64, 64)).cuda()
     assert _lib.track_bf16_weights(net, (Conv1x1,)) == 1
     x = torch.randn(2, 64, 64, 64, device="cuda").bfloat16().requires_grad_(True)
-    with torch.autocast("cuda", dtype=torch.bfloat16):
-        y = net(x)
-    y.float().sum().backward()                                  # the normal order works
-    w0 = net[0].weight.detach().clone()
-    with torch.autocast("cuda", dtype=torch.bfloat16):
-        y = net(x)
-    net[0].weight.data.mul_(0.5)                                # a write the version counter does not see ...
-    _lib.invalidate_weight_shadows()                            # ... announced by the caller
-    with pytest.raises(_lib.AadgError):
-        y.float().sum().backward()
-    with torch.autocast("cuda", dtype=torch.bfloat16):          # the next forward rebuilds the shadow from the new master
-        y2 = net(x)
-    ref = F.conv2d(x.float(), (w0 * 0.5).bfloat16().float())
-    assert (y2.float() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
 
-
-def test_foreign_optimizer_steps_do_not_invalidate_shadows(hip):
-    """The discriminator's and the controller's optimizers step between the model's forward and backward.  Ownership of a tracked
-    weight is decided on the objects: neither a recycled optimizer id nor a parameter whose id once belonged to a tracked weight
-    (a stale table entry whose weak reference is dead) may turn a foreign optimizer's step into an invalidation."""
-    import gc
-    from aadg_amd import _lib
-    from aadg_amd.models.deeplab import Conv1x1
-    torch.manual_seed(4)
-    net = torch.nn.Sequential(Conv1x1(64, 64)).cuda()
-    assert _lib.track_bf16_weights(net, (Conv1x1,)) == 1
-    x = torch.randn(2, 64, 32, 32, device="cuda").bfloat16().requires_grad_(True)
-    other = torch.nn.Linear(8, 8).cuda()
-    # a stale entry under the id of a foreign parameter, as left behind by a dead tracked weight whose id was reused
-    dead = torch.nn.Parameter(torch.zeros(1, device="cuda"))
-    stale = _lib._Shadow()
-    stale.ref = __import__("weakref").ref(dead)
-    del dead
-    gc.collect()
-    _lib._SHADOWS[id(other.weight)] = stale
-    try:
-        for _ in range(3):                                      # fresh optimizer objects: ids get recycled
-            opt = torch.optim.Adam(other.parameters(), lr=1e-3)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                y = net(x)
-            other(torch.randn(4, 8, device="cuda")).sum().backward()
-            opt.step()                                          # between the tracked model's forward and backward
-            y.float().sum().backward()                          # must not raise
-            del opt
-            gc.collect()
-        own = torch.optim.SGD(net.parameters(), lr=0.1)         # the owner's step does invalidate
+    def fwd():
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            y = net(x)
-        net[0].weight.grad = torch.zeros_like(net[0].weight)
-        own.step()
-        with pytest.raises(_lib.AadgError):
-            y.float().sum().backward()
-    finally:
-        _lib._SHADOWS.pop(id(other.weight), None)
+            return net(x)
+
+    def ref_out(w):
+        return F.conv2d(x.detach().float(), w.bfloat16().float())
+
+    fwd().float().sum().backward()                                  # the normal order works
+    # (1) changes the version counter does not see
+    w0 = net[0].weight.detach().clone()
+    net[0].weight.data.mul_(0.5)
+    y = fwd()
+    assert (y.float() - ref_out(w0 * 0.5)).abs().max().item() <= 2e-2 * max(1.0, ref_out(w0 * 0.5).abs().max().item())
+    # (2) a fused optimizer step between forward and backward: the input gradient is that of the forward's weights
+    w1 = net[0].weight.detach().clone()
+    opt = torch.optim.Adam(net.parameters(), lr=0.1, fused=True)
+    x.grad = None
+    net.zero_grad()
+    y = fwd()
+    net[0].weight.grad = torch.ones_like(net[0].weight)
+    opt.step()
+    assert not torch.equal(net[0].weight.detach(), w1)
+    net.zero_grad()
+    y.float().sum().backward()
+    want_dx = torch.nn.functional.conv_transpose2d(torch.ones_like(y).float(), w1.bfloat16().float())
+    assert (x.grad.float() - want_dx).abs().max().item() <= 2e-2 * max(1.0, want_dx.abs().max().item())
+    y3 = fwd()                                                      # ... and the next forward runs on the stepped weights
+    w2 = net[0].weight.detach()
+    assert (y3.float() - ref_out(w2)).abs().max().item() <= 2e-2 * max(1.0, ref_out(w2).abs().max().item())
+    # (3) two forwards, then the backward of the first
+    ya = fwd()
+    yb = fwd()
+    with pytest.raises(_lib.AadgError):
+        ya.float().sum().backward()
+    yb.float().sum().backward()                                     # the latest forward's backward is served
+    # a foreign model's optimizer steps and forwards are nobody's business
+    other = torch.nn.Sequential(Conv1x1(64, 64)).cuda()
+    assert _lib.track_bf16_weights(other, (Conv1x1,)) == 1
+    yc = fwd()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        other(x.detach()).float().sum().backward()
+    torch.optim.SGD(other.parameters(), lr=0.1).step()
+    yc.float().sum().backward()
+
