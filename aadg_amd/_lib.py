@@ -2057,11 +2057,20 @@ def layernorm_supported(x, C):
 
 def add_layer_norm(x, r, rscale, gamma, beta, eps):
     """r is None: LayerNorm(x).  Else (s, y) with s = x + rscale[sample] * r (rscale None: 1) and y = LayerNorm(s)."""
-    _require_cuda(x, r, rscale)
     if r is not None and (r.shape != x.shape or r.dtype != x.dtype):
         raise AadgError("add_layer_norm: x and r must have the same shape and dtype")
+    if r is not None and not r.is_contiguous():
+        r = r.contiguous()                       # the kernel reads r with row stride C (a transposed / sliced branch output is copied once)
+    _require_cuda(x, r, rscale)
     if not layernorm_supported(x, x.shape[-1]):
         raise AadgError("add_layer_norm: expected contiguous float32 / bfloat16 [..., C] with C % 8 == 0, C <= 512")
+    if rscale is not None:
+        # one float32 factor per sample (stochastic depth): R rows split evenly over rscale.numel() samples, sample-major
+        R = x.numel() // x.shape[-1]
+        if rscale.dtype != torch.float32 or not rscale.is_contiguous() or rscale.numel() == 0 or R % rscale.numel() != 0 or \
+                (x.dim() >= 2 and rscale.numel() != x.shape[0]):
+            raise AadgError("add_layer_norm: rscale must be a contiguous float32 vector with one factor per sample (x.shape[0] = %d), got %s %s"
+                            % (x.shape[0], rscale.dtype, tuple(rscale.shape)))
     return _AddLayerNorm.apply(x, r, rscale, gamma, beta, float(eps))
 
 

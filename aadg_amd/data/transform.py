@@ -559,7 +559,9 @@ def _standard_pipeline(dataset):
 def predraw_train_batch(dataset, n_items, fresh_policies=True):
     """Phase A of the NEXT training batch, drawn ahead of time (python's generator only: see _draw_python_stream).  `fresh_policies`:
     the batch will be drawn through NEWLY injected policies (search_dg.py:341 installs a new DGMultiPolicy per epoch: empty CutMix
-    queues); False: through the objects installed now.  fast_train_units checks the assumption when it consumes the draw.
+    queues); False: through the objects installed now.  fast_train_units checks the assumption when it consumes the draw; a draw
+    that does not fit is taken back (the generator's state is restored) and redone in place, so drawing ahead never changes what a
+    seeded run produces -- provided nothing else drew from python's `random` in between.
     Returns False (and draws nothing) when the pipeline is not the standard one."""
     tfs = _standard_pipeline(dataset)
     if tfs is None or getattr(dataset, '_predrawn', None) is not None:
@@ -568,7 +570,9 @@ def predraw_train_batch(dataset, n_items, fresh_policies=True):
     nsub = _policy_tables(mp, dataset.pool)[0]
     qlens = [0] * len(mp.policies) if fresh_policies else [len(p.queue) for p in mp.policies]
     W0, H0 = dataset.pool.size
+    before = random.getstate()                                 # to take the draw back if it turns out not to fit (fast_train_units)
     dataset._predrawn = _draw_python_stream(n_items, dataset.n_domains, len(mp.policies), nsub, qlens, sc, tt.n, W0, H0)
+    dataset._predrawn['generator_before'] = before
     return True
 
 
@@ -597,11 +601,13 @@ def fast_train_units(dataset, n_items):
     qlens = tuple(len(p.queue) for p in policies)
     A = getattr(dataset, '_predrawn', None)
     dataset._predrawn = None
-    if A is not None:
-        if (A['n_items'], A['D'], A['M'], A['nsub'], A['queue_before']) != (n_items, D, M, nsub, qlens):
-            raise RuntimeError("the batch drawn ahead (predraw_train_batch) does not fit the pipeline it is consumed by: %r vs %r"
-                               % ((A['n_items'], A['D'], A['M'], A['nsub'], A['queue_before']), (n_items, D, M, nsub, qlens)))
-    else:
+    if A is not None and (A['n_items'], A['D'], A['M'], A['nsub'], A['queue_before']) != (n_items, D, M, nsub, qlens):
+        # drawn for another pipeline state than the one consuming it (e.g. the caller kept the policies instead of injecting new ones:
+        # other CutMix-queue lengths, hence another number of draws): take the draw back -- python's generator returns to where it
+        # stood before predraw_train_batch -- and draw in place, as if nothing had been drawn ahead
+        random.setstate(A['generator_before'])
+        A = None
+    if A is None:
         A = _draw_python_stream(n_items, D, M, nsub, qlens, sc, tt.n, W0, H0)
     for p, nq in zip(policies, A['queue_after']):              # the CutMix queues' state after the batch (their content is never read)
         del p.queue[:]

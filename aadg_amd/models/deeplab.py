@@ -486,7 +486,7 @@ class ASPP(nn.Module):
         ip = pooled.to(ref.dtype)[:, :, None, None]
         pool_mods = list(self.image_pool)[1:]                      # [0] is the pooling itself
         if (_BN_SYNC and len(pool_mods) == 2 and type(pool_mods[1]) is BNAct and type(pool_mods[1].bn) is nn.BatchNorm2d and
-                all(b[1].bn.momentum is not None and b[1].bn.track_running_stats for b in self.branches)):
+                all(bn.momentum is not None and bn.track_running_stats for bn in [b[1].bn for b in self.branches] + [pool_mods[1].bn])):
             # synchronised statistics: the five BatchNorm layers of the head are independent of one another -- ONE all-reduce per
             # direction for all of them (sync_batch_norm_act_group) instead of five
             ipc = pool_mods[0](ip).contiguous()

@@ -256,6 +256,12 @@ class SegFormerHead(nn.Module):
         self.dropout = nn.Dropout2d(dropout)
         self.linear_pred = nn.Conv2d(dim, num_classes, 1)
         self.apply(_init)
+        # the classifier is not the backbone's business: the fan-out rule of _init (mix_transformer.py's _init_weights) gives a K-channel
+        # 1x1 convolution weights of std sqrt(2 / K) = 1 -- logits of +-20 at initialisation, BCE ~ 45 and a bf16 / float32 comparison
+        # that measures saturation, not rounding (round 4, tests/test_gpu_precision.py).  mmseg initialises a head's classifier with
+        # normal(0, 0.01) and a zero bias (decode_head.py:135-137)
+        nn.init.normal_(self.linear_pred.weight, 0.0, 0.01)
+        nn.init.zeros_(self.linear_pred.bias)
 
     def forward(self, feats):
         c1 = feats[0]

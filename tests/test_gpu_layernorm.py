@@ -60,3 +60,24 @@ def test_layer_norm_rejects_what_it_does_not_cover(hip):
     assert not hip.layernorm_supported(x, 520) and not hip.layernorm_supported(torch.randn(4, 10, 36, device="cuda"), 36)
     with pytest.raises(hip.AadgError):
         hip.add_layer_norm(x, None, None, torch.ones(520, device="cuda"), torch.zeros(520, device="cuda"), 1e-6)
+
+
+def test_add_layer_norm_validates_branch_and_scale(hip):
+    """the public wrapper checks what the kernel relies on -- a branch `r` that is not contiguous is copied (the kernel
+    reads it with row stride C: a transposed view used to give silently wrong sums), and the per-sample stochastic-depth factors
+    must be a contiguous float32 vector with one entry per sample."""
+    torch.manual_seed(0)
+    B, T, C = 2, 16, 64
+    x = torch.randn(B, T, C, device="cuda")
+    rt = torch.randn(B, C, T, device="cuda").transpose(1, 2)            # [B, T, C] view with strides (C*T, 1, T)
+    assert not rt.is_contiguous()
+    g, b = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    s1, y1 = hip.add_layer_norm(x, rt, None, g, b, 1e-6)
+    s2, y2 = hip.add_layer_norm(x, rt.contiguous(), None, g, b, 1e-6)
+    assert torch.equal(s1, s2) and torch.equal(y1, y2) and torch.allclose(s1, x + rt, atol=1e-6)
+    sc = torch.tensor([0.5, 2.0], device="cuda")
+    s3, _ = hip.add_layer_norm(x, rt, sc, g, b, 1e-6)
+    assert torch.allclose(s3, x + rt * sc.view(B, 1, 1), atol=1e-6)
+    for bad in (sc.double(), sc.half(), torch.ones(3, device="cuda"), torch.ones(B, 2, device="cuda")[:, 0], torch.ones(0, device="cuda")):
+        with pytest.raises(hip.AadgError):
+            hip.add_layer_norm(x, rt, bad, g, b, 1e-6)

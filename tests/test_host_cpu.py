@@ -268,15 +268,22 @@ def test_batch_drawn_ahead_equals_batch_drawn_in_place():
         a, b = runs
         for (u1, d1, s1, n1, M1, k1), (u2, d2, s2, n2, M2, k2) in zip(a, b):
             assert u1.tobytes() == u2.tobytes() and np.array_equal(d1, d2) and np.array_equal(s1, s2) and n1 == n2
-    # consumed in another state than it was drawn for: refused, loudly
-    ds.transforms.transforms[0] = DGMultiPolicy(parse_policies(np.random.RandomState(0).randint(0, 10, (6, 20)), Cfg(), None))
-    T.fast_train_units(ds, 3)                                        # queues now hold 9 entries
-    assert T.predraw_train_batch(ds, 3, fresh_policies=True)         # ... but the draw assumes empty ones
-    with pytest.raises(RuntimeError):
-        T.fast_train_units(ds, 3)
-    assert T.predraw_train_batch(ds, 2, fresh_policies=False)
-    with pytest.raises(RuntimeError):
-        T.fast_train_units(ds, 3)                                    # another batch size
+    # consumed in another state than it was drawn for: the draw is taken back (generator restored) and redone in place -- the batch is
+    # the one a run without any drawing ahead produces
+    def batch(ahead, n_ahead, fresh):
+        random.seed(5)
+        np.random.seed(5)
+        ds._predrawn = None
+        ds.transforms.transforms[0] = DGMultiPolicy(parse_policies(np.random.RandomState(0).randint(0, 10, (6, 20)), Cfg(), None))
+        first = T.fast_train_units(ds, 3)                             # queues now hold 9 entries
+        if ahead:
+            assert T.predraw_train_batch(ds, n_ahead, fresh_policies=fresh)
+        second = T.fast_train_units(ds, 3)
+        return first[0].tobytes() + second[0].tobytes(), random.random(), np.random.rand()
+    want = batch(False, 0, False)
+    assert batch(True, 3, True) == want                               # assumed fresh policies, but the old ones stayed
+    assert batch(True, 2, False) == want                              # another batch size
+    assert batch(True, 3, False) == want                              # and a draw that fits
 
 
 def test_launch_plan_classes_statistics_and_late_units():
