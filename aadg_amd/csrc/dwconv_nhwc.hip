@@ -11,7 +11,9 @@
 //   forward   out = GELU(dw(h) + bias)
 //   backward  g = dout * GELU'(dw(h) + bias)        (z is recomputed, not stored)
 //             dh = dw^T(g)                          (the same walk over g with mirrored taps)
-//             dw[tap][c] = sum g * h(tap), db[c] = sum g        (float32 atomics into [9][C] / [C])
+//             dw[tap][c] = sum g * h(tap), db[c] = sum g        (float32 atomics into [9][C] / [C]: the order in which the
+//             workgroups' partial sums arrive is not fixed, so dw / db are NOT bit-reproducible from run to run -- last-bit
+//             differences, unlike the fixed-order reductions of csrc/layernorm.hip)
 // HBM-bound by design, issue-heavy in practice (72 multiply-adds + 8 erf per 16 bytes).  C % 8 == 0.
 #include "common.h"
 

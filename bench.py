@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--legs", default="auto", help="comma list of extra legs at N = 1: fop,kernels,rvs1024,cpu,fp32  (auto = all; none = skip)")
     ap.add_argument("--only_legs", default=None,
                     help="skip the headline step and print ONE JSON line holding only these legs (fop,kernels,rvs1024): the target of "
-                         "the rocprofv3 runs behind profiles/r03_fop_* and profiles/r03_rvs1024_*")
+                         "the rocprofv3 runs behind profiles/r04_fop_*, profiles/r04_aug512_* and profiles/r04_rvs1024_*")
     ap.add_argument("--no_cpu_baseline", action="store_true", help="same as removing `cpu` from --legs")
     ap.add_argument("--cpu_repeats", type=int, default=20)
     ap.add_argument("--no_sync_bn", action="store_true",
@@ -515,8 +515,8 @@ def float_ops_leg(B=144, size=512, repeats=10):
                     % repeats,
             "frac_min": float(min(fr)), "frac_median": float(np.median(fr)), "slowest": {"op": worst[0], "achieved": worst[1]},
             "ops": res,
-            "rocprof": "profiles/r03_fop_kernel_stats.txt (rocprofv3 --kernel-trace --stats -- python bench.py --only_legs fop), "
-                       "profiles/r03_fop_traffic.json (FETCH_SIZE / WRITE_SIZE passes)"}
+            "rocprof": "profiles/r04_fop_kernel_stats.txt (rocprofv3 --kernel-trace --stats -- python bench.py --only_legs fop), "
+                       "profiles/r04_fop_traffic.json (FETCH_SIZE / WRITE_SIZE passes)"}
 
 
 def hot_kernels_leg(D=3, B=8, M=6, size=512, K=2, repeats=20):
@@ -669,7 +669,7 @@ def rvs_1024_leg(n_units=144, size=1024, cfg_rel=os.path.join("experiments", "rv
                                                    "down-scaling units as a horizontal and a vertical streaming pass)",
                          "achieved": kb / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": int(tr["hbm_bytes_per_unit"] * len(units)) if tr else None,
-                         "traffic_source": "profiles/r03_rvs1024_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes, summed "
+                         "traffic_source": "profiles/r04_rvs1024_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes, summed "
                                            "over the tile kernels), per unit x units" if tr else None,
                          "bytes_per_launch": kb, "kernel_ms": k_ms,
                          # the raw images' statistics come from the per-pool cache: the call reads the source once
@@ -1041,13 +1041,13 @@ def main():
         detail["roofline.per_step"] = [dict(m, kernel_us=round(k * 1e3, 1), call_us=round(c * 1e3, 1))
                                        for m, k, c in zip(main_mixes, kern_ms_l, call_ms_l)]
         if traffic:
-            roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes), per unit x units" % traffic.get("file", "r03_traffic_k_fused3.json")
+            roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes), per unit x units" % traffic.get("file", "r04_traffic_k_fused3.json")
         if prof:
             detail["roofline.stage.kernels_rocprof_avg_us"] = {k[:-7]: round(v * 1e3, 1) for k, v in prof.items() if k.endswith("_avg_ms")}
         if prof and prof.get("k_fused3_avg_ms"):
             roof["rocprof_kernel_avg_ms"] = prof["k_fused3_avg_ms"]
             roof["rocprof_frac"] = kbytes / (prof["k_fused3_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-            roof["rocprof_file"] = "profiles/" + prof.get("file", "r03_bench_rocprofv3_kernel_stats.txt")
+            roof["rocprof_file"] = "profiles/" + prof.get("file", "r04_bench_rocprofv3_kernel_stats.txt")
         from aadg_amd import distributed as adist
         dinfo = adist.describe()
         dinfo["forced_one_rank_run_of_the_distributed_path"] = bool(a.force_dist)

@@ -1,0 +1,9 @@
+# the RVS-1024 leg for library variants on ONE box: bash scripts/ab/exp_rvs.sh [tag ...]  (tree = the built library)
+cd $GRAFT_REPO_ROOT
+for v in ${@:-tree}; do
+  if [ "$v" = tree ]; then unset AADG_LIB_PATH; else export AADG_LIB_PATH=$PWD/exp_libs/$v.so; fi
+  python bench.py --only_legs rvs1024 2>/dev/null | python -c "
+import json,sys
+r=json.loads(sys.stdin.read().strip().splitlines()[-1])['rvs_1024']['roofline']
+print('$v', 'tile kernels %.4f ms frac %.3f | call %.4f ms frac %.3f' % (r['kernel_ms'], r['frac'], r['stage']['ms'], r['stage']['frac']))"
+done

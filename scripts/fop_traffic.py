@@ -1,4 +1,4 @@
-"""profiles/r03_fop_traffic.json: HBM bytes per dispatch of every k_fop_* kernel from the two PMC passes (FETCH_SIZE doubled on
+"""profiles/r04_fop_traffic.json: HBM bytes per dispatch of every k_fop_* kernel from the two PMC passes (FETCH_SIZE doubled on
 gfx950, WRITE_SIZE as is: MI355X_MICROARCH.md, HBM section) next to the bytes the float_ops leg prices the op at.
     python fop_traffic.py fop_leg.json pmc_fop_FETCH_SIZE.txt pmc_fop_WRITE_SIZE.txt"""
 import json

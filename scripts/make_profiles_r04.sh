@@ -1,10 +1,10 @@
-# Round-3 profile artefacts (run through gpurun; results land in gpurun_out/r3/<tag>/, copy the ones to keep into profiles/).
-#   bash scripts/make_profiles_r03.sh <tag> [parts]      parts: any of  fop rvs bench shard8 segformer  (default: fop rvs)
+# Round-4 profile artefacts (run through gpurun; results land in gpurun_out/r4/<tag>/, copy the ones to keep into profiles/).
+#   bash scripts/make_profiles_r04.sh <tag> [parts]      parts: any of  fop aug512 rvs bench shard8 segformer  (default: fop aug512 rvs)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-final}
-PARTS=${2:-"fop rvs"}
-O=$R/gpurun_out/r3/$TAG
+PARTS=${2:-"fop aug512 rvs"}
+O=$R/gpurun_out/r4/$TAG
 mkdir -p $O
 
 for part in $PARTS; do
@@ -20,6 +20,15 @@ fop)
     python $R/scripts/pmc_by_kernel.py /tmp/pmc_fop_$c > $O/pmc_fop_$c.txt
   done
   python $R/scripts/fop_traffic.py $O/fop_leg.json $O/pmc_fop_FETCH_SIZE.txt $O/pmc_fop_WRITE_SIZE.txt > $O/fop_traffic.json
+  ;;
+aug512)
+  # BASELINE configs[1]'s augmentation call on its own (the seeded hot-path batches, no backbone around it): per-kernel durations
+  python $R/bench.py --only_legs aug512 > $O/aug512_leg.json 2> $O/aug512_leg.err
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_a5 -- python $R/bench.py --only_legs aug512 > /dev/null 2>&1
+  DB=$(find /tmp/prof_a5 -name "*.db" | head -1)
+  python $R/scripts/prof_summary.py $DB $O/aug512_kernel_stats.txt > /dev/null
+  # the statistics pass by late-unit class (scripts/ab/stat_classes.py)
+  bash $R/scripts/ab/stat_classes.sh > $O/stat_pass_classes.txt 2>&1
   ;;
 rvs)
   # BASELINE configs[2]: RVS pipeline at 1024 x 1024, the tile kernels' durations, traffic and issue counters
@@ -62,7 +71,7 @@ def avg(name):
             p = l.split()
             return int(p[1]), float(p[2]) / 1e3
     return 0, 0.0
-stats = {"file": "r03_bench_rocprofv3_kernel_stats.txt",
+stats = {"file": "r04_bench_rocprofv3_kernel_stats.txt",
          "command": "rocprofv3 --kernel-trace --stats -- python bench.py --legs none --steps 10 --warmup 3"}
 nf = avg("k_fused3")[0]
 for k in ("k_fused3", "k_luts_tables", "k_hist_fused", "k_lut"):
@@ -76,8 +85,8 @@ def pmc(c):
 b = json.load(open("/tmp/bench_FETCH_SIZE.json"))["roofline"]
 f, w, units = pmc("FETCH_SIZE"), pmc("WRITE_SIZE"), b["units_per_launch"]
 hbm = int(2 * f * 1024 + w * 1024)
-json.dump({"kernel": "k_fused3", "size": 512, "units_measured": units,
-           "command": "rocprofv3 --pmc FETCH_SIZE -- python bench.py --legs none --steps 5 --warmup 2   (and a second, separate pass with --pmc WRITE_SIZE); scripts/make_profiles_r03.sh",
+json.dump({"kernel": "k_fused3", "file": "r04_traffic_k_fused3.json", "size": 512, "units_measured": units,
+           "command": "rocprofv3 --pmc FETCH_SIZE -- python bench.py --legs none --steps 5 --warmup 2   (and a second, separate pass with --pmc WRITE_SIZE); scripts/make_profiles_r04.sh",
            "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB_raw": w,
            "correction": "gfx950 FETCH_SIZE counts 64 B per 128 B request: doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE used as is",
            "hbm_bytes_per_launch": hbm, "hbm_bytes_per_unit": hbm // units, "kernel_bytes": b["bytes_per_launch"],
@@ -85,9 +94,9 @@ json.dump({"kernel": "k_fused3", "size": 512, "units_measured": units,
           open(O + "/traffic_k_fused3.json", "w"), indent=2)
 PY
   # the committed copies bench.py reads live in profiles/: refresh them so that the line below quotes THIS run's profile
-  cp $O/bench_kernel_stats.json $R/profiles/r03_bench_kernel_stats.json
-  cp $O/traffic_k_fused3.json $R/profiles/r03_traffic_k_fused3.json
-  if [ -f $O/rvs1024_traffic.json ]; then cp $O/rvs1024_traffic.json $R/profiles/r03_rvs1024_traffic.json; fi
+  cp $O/bench_kernel_stats.json $R/profiles/r04_bench_kernel_stats.json
+  cp $O/traffic_k_fused3.json $R/profiles/r04_traffic_k_fused3.json
+  if [ -f $O/rvs1024_traffic.json ]; then cp $O/rvs1024_traffic.json $R/profiles/r04_rvs1024_traffic.json; fi
   python $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err
   ;;
 segformer)
