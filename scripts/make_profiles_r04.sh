@@ -97,7 +97,7 @@ PY
   cp $O/bench_kernel_stats.json $R/profiles/r04_bench_kernel_stats.json
   cp $O/traffic_k_fused3.json $R/profiles/r04_traffic_k_fused3.json
   if [ -f $O/rvs1024_traffic.json ]; then cp $O/rvs1024_traffic.json $R/profiles/r04_rvs1024_traffic.json; fi
-  python $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+  python $R/bench.py --detail $O/bench_detail.json > $O/bench_n1.json 2> $O/bench_n1.err
   ;;
 segformer)
   # BASELINE configs[4] (SegFormer-B2, 8 domains, bf16): the 48 rows of one of 8 ranks on one GPU

@@ -203,8 +203,30 @@ def worker(rank, world, port, out_dir):
     lp = ctrl.evaluate(policies, M)
     all_lp = adist.all_gather([lp.detach()])[0].view(world, M)
     assert all(torch.allclose(all_lp[0], all_lp[r], atol=1e-6) for r in range(world))
+    # round 4: the small collectives' own process group (a second communicator over the same ranks), the policy broadcast and the
+    # BatchNorm-statistics all-reduce through it, what bench.py prints about the job, and the GPU-side timer switched off on CPU
+    g = adist.small_group()
+    assert g is not None and g is adist.small_group() and g is not dist.group.WORLD
+    d = adist.describe()
+    assert d["initialized"] and d["world_size"] == world and d["rank"] == rank and d["backend"] == "gloo"
+    assert "own process group" in d["small_collectives_group"]
+    v = torch.full((5,), float(rank + 1), dtype=torch.float64)
+    adist.small_all_reduce(v, kind="batchnorm_statistics_all_reduce")
+    assert torch.equal(v, torch.full((5,), world * (world + 1) / 2.0, dtype=torch.float64))
+    p2 = torch.full((3,), rank, dtype=torch.int64)
+    adist.small_broadcast(p2, 0, kind="policy_broadcast")
+    assert torch.equal(p2, torch.zeros(3, dtype=torch.int64))
+    from aadg_amd import _lib as L
+    before = L.BN_SYNC_COLLECTIVES[0]
+    w = torch.ones(4, dtype=torch.float64) * (rank + 1)
+    L._bn_sync_reduce(w)                                # what the BatchNorm kernels' wrapper calls between its two phases
+    assert torch.equal(w, torch.full((4,), world * (world + 1) / 2.0, dtype=torch.float64)) and L.BN_SYNC_COLLECTIVES[0] == before + 1
+    os.environ["AADG_SMALL_GROUP"] = "0"
+    assert adist.small_group() is None                  # opt-out: everything on the default group
+    del os.environ["AADG_SMALL_GROUP"]
     open(os.path.join(out_dir, "ok_%d" % rank), "w").write("ok")
     dist.destroy_process_group()
+    adist.reset_groups()
 
 
 if __name__ == "__main__":

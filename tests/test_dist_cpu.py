@@ -27,3 +27,21 @@ def test_unit_sharded_exchange(tmp_path, world):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
         assert os.path.exists(os.path.join(str(tmp_path), "ok_%d" % r))
+
+
+def test_forced_one_rank_plan_takes_the_sharded_path():
+    """bench.py --force_dist: a ONE-rank RowPlan with force=True keeps the sharded code path -- domain-major local order, padded
+    gather buffer, index_select back into collate order -- so that the first RCCL run of that path needs no second GPU."""
+    import numpy as np
+    import torch
+    from aadg_amd.distributed import RowPlan
+    D, B, M = 3, 2, 6
+    N = D * B * M
+    plain, forced = RowPlan(D, B, M), RowPlan(D, B, M, 0, 1, 'unit', force=True)
+    assert not plain.sharded and forced.sharded and forced.world == 1 and forced.counts == [N] and forced.loss_weight == 1.0
+    assert np.array_equal(np.sort(forced.rows), np.arange(N)) and not np.array_equal(forced.rows, np.arange(N))   # domain-major order
+    d = forced.rows // M % D
+    assert np.array_equal(d, np.sort(d))                                   # all rows of domain 0, then 1, then 2
+    local = torch.arange(N, dtype=torch.float32)[torch.from_numpy(forced.rows)].view(N, 1)      # "embeddings" of the local rows
+    back = forced.gather(local)                                            # no process group: all_gather degenerates to a copy
+    assert torch.equal(back.view(-1), torch.arange(N, dtype=torch.float32))

@@ -137,16 +137,18 @@ def test_large_clouds_matrix_core_path(hip, oracle):
 
 
 def test_scaled_synthetic_4096(hip, oracle):
-    """SURVEY 8d scaled synthetic: 4096 points per cloud, E = 128 (one problem).  Oracle on a 1024-point subsample is
-    too different a problem to compare, so check invariants at full size: symmetry and S(x,x) = 0."""
+    """SURVEY 8d scaled synthetic: 4096 points per cloud, E = 128.  Invariants at full size (symmetry, S(x,x) = 0) and -- round 4 --
+    S(x,y) against the oracle at the full size too (one problem: the scalar oracle needs ~12 s for it)."""
     rs = np.random.RandomState(12)
     n, E = 4096, 128
     x = rs.randn(2 * n, E).astype(np.float32) * 0.5 + rs.randn(E).astype(np.float32)
-    x = np.where(x > 0, x, 0.2 * x)
+    x = np.where(x > 0, x, 0.2 * x).astype(np.float32)
     rows, off, pxy = _tables([n, n], [(0, 1), (1, 0), (0, 0)], "cuda")
     got = hip.sinkhorn_divergence(torch.from_numpy(x).cuda(), rows, off, pxy, n).cpu().numpy()
     assert np.isfinite(got).all() and got[0] > 0
     assert abs(got[0] - got[1]) <= 1e-4 * max(1.0, abs(got[0])) and abs(got[2]) <= 1e-4
+    want = oracle.sinkhorn_divergence(x[:n], x[n:])
+    assert abs(got[0] - want) <= 1e-4 * max(1.0, abs(want)), (got[0], want)          # north_star: Sinkhorn within 1e-4 fp32
 
 
 def test_large_clouds_1024_points_vs_oracle(hip, oracle):
