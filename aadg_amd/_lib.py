@@ -1469,7 +1469,7 @@ CONV1X1_SMALL_BATCH = int(os.environ.get("AADG_CONV1X1_SMALL_BATCH", "40"))
 
 def _own_gemm_1x1(M, K, HW, N=None):
     """Shapes (out channels M, reduction K, N images) on which the matrix-core kernel of csrc/conv1x1_fwd.hip beats the library
-    GEMM on an MI355X (scripts/quick_time_conv1x1_own.py at NB = 144 / 72 / 36 / 18).  At the full batch: the bandwidth-bound
+    GEMM on an MI355X (a round-2 timing script at NB = 144 / 72 / 36 / 18).  At the full batch: the bandwidth-bound
     ones -- few output channels, or a short reduction -- plus the 1024 -> 256 / 304 -> 256 layers; the compute-bound late layers
     stay with hipBLASLt.  At a per-rank batch (N <= 40 images: one GEMM per image, hipBLASLt's 256 x 256 tiles leave the chip
     half empty) everything but the largest weights (M K >= 2^20: 512 <-> 2048, 1024 <-> 2048): 2.37 + 2.69 -> 2.0 + 2.0 ms of
