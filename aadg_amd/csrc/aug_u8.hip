@@ -1128,9 +1128,9 @@ __device__ __forceinline__ void stat_load_tile(StatRegs& r, const uint8_t* __res
 template <int KIND>
 __device__ __forceinline__ void stat_stream_unit(const aadg_unit& un, int stage, const uint8_t* __restrict__ src, int Hs, int Ws,
                                                  const uint8_t* __restrict__ lut, size_t lut_stage_stride, int u,
-                                                 uint8_t* sl_all, uint32_t* sh, uint32_t* red, uint32_t* gh, int t0, int G) {
+                                                 uint8_t* sl_all, uint32_t* sh, uint32_t* red, uint32_t* gh, int t0, int G, int tend) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tx = (Ws + 255) >> 8, ntiles = tx * ((Hs + 15) >> 4);
+    const int tx = (Ws + 255) >> 8, ntiles = min(tend, tx * ((Hs + 15) >> 4));        // tiles t0, t0 + G, ... below tend
     int t = t0;
     if (t >= ntiles) return;
     int ry0, ry1, cx0, cx1;
@@ -1189,9 +1189,9 @@ template <int KIND>
 __device__ __forceinline__ void stat_patch_unit(const aadg_unit& un, int stage, int s, const uint8_t* __restrict__ src, int Hs, int Ws,
                                                 uint32_t* A, uint32_t* B, const uint8_t* __restrict__ lut,
                                                 size_t lut_stage_stride, int u, uint8_t* sl_all, uint32_t* sh, uint32_t* red, uint32_t* gh,
-                                                int t0, int G) {
+                                                int t0, int G, int tend) {
     const int tid = threadIdx.x;
-    const int tx = (Ws + 255) >> 8, ntiles = tx * ((Hs + 15) >> 4);
+    const int tx = (Ws + 255) >> 8, ntiles = min(tend, tx * ((Hs + 15) >> 4));
     if (t0 >= ntiles) return;
     if (KIND == ST_EQUALIZE)
         for (int i = tid; i < 768 * HF_COPIES; i += 256) sh[i] = 0;      // build_patch's barriers order this before the counting
@@ -1232,20 +1232,128 @@ __device__ __forceinline__ void stat_patch_unit(const aadg_unit& un, int stage, 
     stat_flush<KIND>(acc, sh, red, gh, true);
 }
 
+// A 256 x 64 block behind exactly ONE Sharpness stencil (the common late case: op 0 = Sharpness, op 1 reads statistics), without LDS:
+// wave <-> 16 rows of the block, lane <-> 4 consecutive pixels; the wave walks DOWN with the horizontal 3-sums of the previous /
+// current / next row in registers (the arithmetic of build_patch's stencil pass, term for term), the neighbours of a lane's outer
+// pixels come from the adjacent lanes (shuffles), those of the strip's outer columns from one extra 3-byte load per row.  The
+// pointwise ops in front of the stencil are applied as the rows are loaded, the ones behind it to the stencil's outputs, and the
+// result goes straight into the counts -- no patch, no barrier, 18 row loads per 16 rows instead of a 20-row patch per 16-row tile
+// with one of four waves doing two of its five column chunks.
+template <int KIND>
+__device__ __forceinline__ void stat_strip_block(const aadg_unit& un, int stage, int js, const uint8_t* __restrict__ src, int Hs, int Ws,
+                                                 int bx, int by, const uint8_t* __restrict__ lut, size_t lut_stage_stride, int u,
+                                                 uint8_t* sl_all, uint32_t* sh, uint32_t* red, uint32_t* gh) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    bool any_lut = false;
+#pragma unroll
+    for (int j = 0; j < AADG_MAX_OPS; ++j)
+        if (j < stage && needs_lds_lut(un.op[j])) {
+            any_lut = true;
+            if (tid < 192) reinterpret_cast<uint32_t*>(sl_all + j * 768)[tid] =
+                reinterpret_cast<const uint32_t*>(lut + (size_t)j * lut_stage_stride + (size_t)u * 768)[tid];
+        }
+    if (KIND == ST_EQUALIZE)
+        for (int i = tid; i < 768 * HF_COPIES; i += 256) sh[i] = 0;
+    if (any_lut || KIND == ST_EQUALIZE) __syncthreads();
+    StatAcc<KIND> acc(sh);
+    const int c0 = bx * 256, x0 = c0 + 4 * lane;
+    const int r0 = by * 64 + wv * 16, r1 = min(Hs, r0 + 16);
+    const bool live = x0 < Ws;                                   // Ws % 4 == 0: a lane's four pixels are inside together
+    const bool edge_l = lane == 0 && x0 > 0, edge_r = live && (lane == 63 || x0 + 4 >= Ws) && x0 + 4 < Ws;
+    const float alpha = un.farg[js];
+    // one source row: the lane's four pixels after ops [0, js), the pixel to their left and to their right
+    auto load_row = [&](int y, uint32_t (&p)[4], uint32_t& pl, uint32_t& pr) {
+        const uint8_t* rowp = src + ((size_t)y * Ws + x0) * 3;
+        uint32_t a = 0, b = 0, c = 0, el = 0, er = 0;
+        if (live) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(rowp);
+            a = q[0]; b = q[1]; c = q[2];
+        }
+        if (edge_l) el = (uint32_t)rowp[-3] | ((uint32_t)rowp[-2] << 8) | ((uint32_t)rowp[-1] << 16);
+        if (edge_r) er = (uint32_t)rowp[12] | ((uint32_t)rowp[13] << 8) | ((uint32_t)rowp[14] << 16);
+        p[0] = a & 0xFFFFFFu; p[1] = (a >> 24) | ((b & 0xFFFFu) << 8);
+        p[2] = (b >> 16) | ((c & 0xFFu) << 16); p[3] = c >> 8;
+        for (int j = 0; j < js; ++j)
+            dispatch_op(un, j, sl_all, [&](auto f) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) p[t] = f(p[t], y, x0 + t);
+                el = f(el, y, x0 - 1);
+                er = f(er, y, x0 + 4);
+            });
+        const uint32_t from_l = (uint32_t)__shfl_up((int)p[3], 1, 64), from_r = (uint32_t)__shfl_down((int)p[0], 1, 64);
+        pl = edge_l ? el : from_l;
+        pr = edge_r ? er : from_r;
+    };
+    auto hsums = [&](const uint32_t (&p)[4], uint32_t pl, uint32_t pr, uint32_t (&hrb)[4], uint32_t (&hg)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t q0 = t == 0 ? pl : p[t - 1], q1 = p[t], q2 = t == 3 ? pr : p[t + 1];
+            hrb[t] = (q0 & 0xFF00FFu) + (q1 & 0xFF00FFu) + (q2 & 0xFF00FFu);
+            hg[t] = ((q0 >> 8) & 255u) + ((q1 >> 8) & 255u) + ((q2 >> 8) & 255u);
+        }
+    };
+    if (r0 < r1) {                                               // uniform per wave
+        uint32_t h0rb[4] = {0, 0, 0, 0}, h0g[4] = {0, 0, 0, 0}, h1rb[4], h1g[4], h2rb[4] = {0, 0, 0, 0}, h2g[4] = {0, 0, 0, 0};
+        uint32_t p1[4], p2[4] = {0, 0, 0, 0}, pl, pr;
+        if (r0 > 0) {
+            uint32_t p0[4];
+            load_row(r0 - 1, p0, pl, pr);
+            hsums(p0, pl, pr, h0rb, h0g);
+        }
+        load_row(r0, p1, pl, pr);
+        hsums(p1, pl, pr, h1rb, h1g);
+        for (int y = r0; y < r1; ++y) {
+            if (y + 1 < Hs) {
+                load_row(y + 1, p2, pl, pr);
+                hsums(p2, pl, pr, h2rb, h2g);
+            }
+            uint32_t o[4];
+            const bool row_in = y > 0 && y < Hs - 1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int x = x0 + t;
+                const bool in = row_in && x > 0 && x < Ws - 1;   // ImageFilter.SMOOTH copies the 1-pixel image border
+                const uint32_t srb = h0rb[t] + h1rb[t] + h2rb[t] + 4u * (p1[t] & 0xFF00FFu), sg = h0g[t] + h1g[t] + h2g[t] + 4u * ((p1[t] >> 8) & 255u);
+                const uint32_t cr = (uint32_t)__mul24((int)((srb & 0xFFFFu) + 6u), 5042) >> 16, cb = (uint32_t)__mul24((int)((srb >> 16) + 6u), 5042) >> 16,
+                               cg = (uint32_t)__mul24((int)(sg + 6u), 5042) >> 16;
+                const uint32_t d = in ? (cr | (cg << 8) | (cb << 16)) : p1[t];
+                o[t] = blend3(d, p1[t], alpha, true);
+            }
+            for (int j = js + 1; j < stage; ++j)
+                dispatch_op(un, j, sl_all, [&](auto f) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[t] = f(o[t], y, x0 + t);
+                });
+            if (live) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc.add(o[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { h0rb[t] = h1rb[t]; h0g[t] = h1g[t]; h1rb[t] = h2rb[t]; h1g[t] = h2g[t]; p1[t] = p2[t]; }
+        }
+    }
+    stat_flush<KIND>(acc, sh, red, gh, true);
+}
+
 constexpr int HF_PATCH = 5280;        // 20 rows (16 + two stencil halos) x 264 columns (256 + halos, rounded to groups of 4)
 // 1-D grid.  The first n_sten entries of the list are units with a stencil in front of the op (aadg_aug_u8_plan puts them first): each
-// of their tiles is a workgroup of its own (workgroups [0, n_sten * tiles): the long work is dispatched first); the other units get G
-// workgroups each that walk their tiles with stride G.  (All units handled like the second kind: a stencil unit's 256 tiles behind
-// ~30 workgroups were the long pole of the launch -- 129 us against 94 us per 1024 x 1024 batch.)
+// 256 x 64 block of theirs is a workgroup of its own (workgroups [0, n_sten * blocks): the long work is dispatched first) -- one stencil:
+// the register walk above; more than one: the block's four 16-row tiles through the LDS patch --; the other units get G workgroups each
+// that walk their 256 x 16 tiles with stride G.  (All units handled like the second kind: a stencil unit's 256 tiles behind ~30
+// workgroups were the long pole of the launch -- 129 us against 94 us per 1024 x 1024 batch.)
 __global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ pool, const aadg_unit* __restrict__ units,
                                                     const int* __restrict__ ulist, int n_sten, int G, int stage, int Hs, int Ws, int crop,
                                                     const uint8_t* __restrict__ lut, size_t lut_stage_stride, uint32_t* hist) {
-    const int ntiles = ((Ws + 255) >> 8) * ((Hs + 15) >> 4);
-    int id = blockIdx.x, slot, t0, stride;
-    if (id < n_sten * ntiles) {
-        slot = id / ntiles; t0 = id - slot * ntiles; stride = ntiles;
+    const int tx = (Ws + 255) >> 8, ntiles = tx * ((Hs + 15) >> 4), nblocks = tx * ((Hs + 63) >> 6);
+    int id = blockIdx.x, slot, t0, stride, tend = ntiles, bx = 0, by = 0;
+    const bool block_wg = id < n_sten * nblocks;
+    if (block_wg) {
+        slot = id / nblocks;
+        const int blk = id - slot * nblocks;
+        by = blk / tx; bx = blk - by * tx;
+        t0 = by * 4 * tx + bx; stride = tx; tend = min(ntiles, t0 + 4 * tx);       // the block's four 16-row tiles
     } else {
-        id -= n_sten * ntiles;
+        id -= n_sten * nblocks;
         slot = id / G; t0 = id - slot * G; stride = G; slot += n_sten;
     }
     const int u = ulist != nullptr ? ulist[slot] : slot;          // ulist: the units whose op `stage` needs statistics
@@ -1262,33 +1370,39 @@ __global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ 
     uint32_t* gh = hist + (size_t)u * HIST_STRIDE;
     const int op = un.op[stage];
     if (s == 0) {
-        if (op == AADG_OP_CONTRAST) stat_stream_unit<ST_CONTRAST>(un, stage, src, Hs, Ws, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride);
-        else if (op == AADG_OP_AUTOCONTRAST) stat_stream_unit<ST_AUTOCONTRAST>(un, stage, src, Hs, Ws, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride);
-        else stat_stream_unit<ST_EQUALIZE>(un, stage, src, Hs, Ws, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride);
+        if (op == AADG_OP_CONTRAST) stat_stream_unit<ST_CONTRAST>(un, stage, src, Hs, Ws, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride, tend);
+        else if (op == AADG_OP_AUTOCONTRAST) stat_stream_unit<ST_AUTOCONTRAST>(un, stage, src, Hs, Ws, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride, tend);
+        else stat_stream_unit<ST_EQUALIZE>(un, stage, src, Hs, Ws, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride, tend);
+    } else if (s == 1 && block_wg) {
+        int js = 0;
+        while (!is_stencil(un, js)) ++js;
+        if (op == AADG_OP_CONTRAST) stat_strip_block<ST_CONTRAST>(un, stage, js, src, Hs, Ws, bx, by, lut, lut_stage_stride, u, sl, shx, red, gh);
+        else if (op == AADG_OP_AUTOCONTRAST) stat_strip_block<ST_AUTOCONTRAST>(un, stage, js, src, Hs, Ws, bx, by, lut, lut_stage_stride, u, sl, shx, red, gh);
+        else stat_strip_block<ST_EQUALIZE>(un, stage, js, src, Hs, Ws, bx, by, lut, lut_stage_stride, u, sl, shx, red, gh);
     } else {
-        if (op == AADG_OP_CONTRAST) stat_patch_unit<ST_CONTRAST>(un, stage, s, src, Hs, Ws, A, B, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride);
-        else if (op == AADG_OP_AUTOCONTRAST) stat_patch_unit<ST_AUTOCONTRAST>(un, stage, s, src, Hs, Ws, A, B, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride);
-        else stat_patch_unit<ST_EQUALIZE>(un, stage, s, src, Hs, Ws, A, B, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride);
+        if (op == AADG_OP_CONTRAST) stat_patch_unit<ST_CONTRAST>(un, stage, s, src, Hs, Ws, A, B, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride, tend);
+        else if (op == AADG_OP_AUTOCONTRAST) stat_patch_unit<ST_AUTOCONTRAST>(un, stage, s, src, Hs, Ws, A, B, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride, tend);
+        else stat_patch_unit<ST_EQUALIZE>(un, stage, s, src, Hs, Ws, A, B, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride, tend);
     }
 }
 // launch of the statistics pass of one stage: nstat list entries, the first n_sten of them stencil units (n_sten = nstat: no list
 // order known -- every unit's tiles get their own workgroups)
 static inline int launch_hist_fused(const uint8_t* pool, const aadg_unit* units, const int* ulist, int nstat, int n_sten, int stage, int Hs,
                                     int Ws, int crop, const uint8_t* lut, size_t lut_stage_stride, uint32_t* hist, hipStream_t st) {
-    const int ntiles = ((Ws + 255) / 256) * ((Hs + 15) / 16);
+    const int ntiles = ((Ws + 255) / 256) * ((Hs + 15) / 16), nblocks = ((Ws + 255) / 256) * ((Hs + 63) / 64);
     const int n_rest = nstat - n_sten;
-    // the other units: enough workgroups to fill what the stencil tiles leave of the chip's 768 slots (3 per CU), and never more than
-    // 8 tiles per workgroup (a stencil tile takes ~15 us, a streamed one ~1.5: the walkers must not outlast the stencil tiles --
-    // with 8 workgroups per unit, 32 tiles each at 1024 x 1024, they did: 149 us per batch)
+    // the other units: enough workgroups to fill what the stencil blocks leave of the chip's 768 slots (3 per CU), and never more than
+    // 8 tiles per workgroup (the walkers must not outlast the stencil blocks -- with 8 workgroups per unit, 32 tiles each at
+    // 1024 x 1024, they did: 149 us per batch)
     int G = 1;
     if (n_rest > 0) {
-        const long long room = 768 - (long long)n_sten * ntiles;
+        const long long room = 768 - (long long)n_sten * nblocks;
         G = (int)((room > 0 ? room : 0) / n_rest);
         const int g_min = (ntiles + 7) / 8;
         G = G < g_min ? g_min : G;
         G = G > ntiles ? ntiles : G;
     }
-    const long long grid = (long long)n_sten * ntiles + (long long)n_rest * G;
+    const long long grid = (long long)n_sten * nblocks + (long long)n_rest * G;
     if (grid <= 0 || grid > 0x7FFFFFFFll) return AADG_E_BADARG;
     hipLaunchKernelGGL(k_hist_fused, dim3((unsigned)grid), dim3(256), 0, st, pool, units, ulist, n_sten, G, stage, Hs, Ws, crop, lut, lut_stage_stride, hist);
     AADG_LAUNCH_CHECK();

@@ -961,11 +961,13 @@ def main():
     # every stage is queued behind a blocker (a spin kernel of ~3 ms, torch.cuda._sleep): the stage's launches are all enqueued while
     # the blocker runs and then execute back to back -- the event pair (recorded behind the blocker / behind the last launch) brackets
     # kernel time only, not the host's draws and launch calls.
+    blocker = getattr(torch.cuda, "_sleep", None)            # a spin kernel of N device clock ticks (private API: guarded)
     cyc = 1 << 20
-    e0, e1 = ev(), ev()
-    torch.cuda._sleep(cyc); sync()
-    e0.record(); torch.cuda._sleep(cyc); e1.record(); sync()
-    cyc = max(1 << 16, int(cyc * 3.0 / max(e0.elapsed_time(e1), 1e-3)))       # ~3 ms
+    if blocker is not None:
+        e0, e1 = ev(), ev()
+        blocker(cyc); sync()
+        e0.record(); blocker(cyc); e1.record(); sync()
+        cyc = max(1 << 16, int(cyc * 3.0 / max(e0.elapsed_time(e1), 1e-3)))       # ~3 ms
     HS = 10
     smarks = [[ev() for _ in range(2 * len(STAGES))] for _ in range(HS)]
     for row in smarks:
@@ -977,8 +979,8 @@ def main():
         """marks whose even entries (stage starts) are recorded behind a fresh blocker"""
         def __getitem__(self, k):
             e = list.__getitem__(self, k)
-            if k % 2 == 0:
-                torch.cuda._sleep(cyc)
+            if k % 2 == 0 and blocker is not None:
+                blocker(cyc)
             return e
     for i in range(HS):
         hot_state['prefetched'] = None                     # the stage pass samples inside its own bracket
@@ -1029,9 +1031,11 @@ def main():
                             "host_ms": max(hot_ms - hot_gpu_ms, 0.0),
                             "kernel_ms": hot_kern_ms, "kernel_frac": kbytes / (hot_kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "stage_ms": hot_call_ms, "stage_frac": call_bytes / (hot_call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "what": "controller sample + parse + draw + augmentation call + BCE/Dice kernel (fwd + bwd) + Sinkhorn kernel + "
-                                    "reward normalise + PPO update; backbone and discriminator removed.  gpu_ms = kernel time of the stages "
-                                    "(events behind a blocker kernel, separate pass), host_ms = wall time per step minus that"}
+                            "stage_times_behind_blocker": blocker is not None,
+                            "what": "controller sample + parse + draw + augmentation call + BCE/Dice kernel (loss + gradient) + Sinkhorn kernel + "
+                                    "reward normalise + PPO update, reward branch on the controller's stream; backbone and discriminator "
+                                    "removed.  gpu_ms = kernel time of the stages (events behind a blocker kernel, separate serial pass), "
+                                    "host_ms = wall time per step minus that"}
         roof["stage"] = {"what": "bytes of the whole augmentation call / events around ALL its kernels; source counted once (pool statistics "
                                  "cached per resident pool; --no_pool_stats = per-call variant, source priced twice as SURVEY 8(d))",
                          "bytes": call_bytes, "ms": call_ms, "achieved": call_bytes / (call_ms * 1e-3) / 1e9,
