@@ -1242,8 +1242,10 @@ __device__ __forceinline__ void stat_patch_unit(const aadg_unit& un, int stage, 
 template <int KIND>
 __device__ __forceinline__ void stat_strip_block(const aadg_unit& un, int stage, int js, const uint8_t* __restrict__ src, int Hs, int Ws,
                                                  int bx, int by, const uint8_t* __restrict__ lut, size_t lut_stage_stride, int u,
-                                                 uint8_t* sl_all, uint32_t* sh, uint32_t* red, uint32_t* gh) {
+                                                 uint8_t* sl_all, uint32_t* sh, uint32_t* red, uint32_t* gh, bool block_wg, int t0,
+                                                 int stride, int tend) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (!block_wg && t0 >= tend) return;
     bool any_lut = false;
 #pragma unroll
     for (int j = 0; j < AADG_MAX_OPS; ++j)
@@ -1256,8 +1258,13 @@ __device__ __forceinline__ void stat_strip_block(const aadg_unit& un, int stage,
         for (int i = tid; i < 768 * HF_COPIES; i += 256) sh[i] = 0;
     if (any_lut || KIND == ST_EQUALIZE) __syncthreads();
     StatAcc<KIND> acc(sh);
-    const int c0 = bx * 256, x0 = c0 + 4 * lane;
-    const int r0 = by * 64 + wv * 16, r1 = min(Hs, r0 + 16);
+    const int tx = (Ws + 255) >> 8;
+    // a block workgroup: ONE pass, wave <-> 16 rows of the 256 x 64 block; a walker (a caller's list that did not put this unit among the
+    // stencil units: correct, only slower): its 16-row tiles one after the other, wave <-> 4 rows
+    for (int tile = t0; tile < tend; tile += stride) {
+    const int tby = tile / tx, tbx = tile - tby * tx;
+    const int c0 = (block_wg ? bx : tbx) * 256, x0 = c0 + 4 * lane;
+    const int r0 = block_wg ? by * 64 + wv * 16 : tby * 16 + wv * 4, r1 = min(Hs, r0 + (block_wg ? 16 : 4));
     const bool live = x0 < Ws;                                   // Ws % 4 == 0: a lane's four pixels are inside together
     const bool edge_l = lane == 0 && x0 > 0, edge_r = live && (lane == 63 || x0 + 4 >= Ws) && x0 + 4 < Ws;
     const float alpha = un.farg[js];
@@ -1332,6 +1339,8 @@ __device__ __forceinline__ void stat_strip_block(const aadg_unit& un, int stage,
             for (int t = 0; t < 4; ++t) { h0rb[t] = h1rb[t]; h0g[t] = h1g[t]; h1rb[t] = h2rb[t]; h1g[t] = h2g[t]; p1[t] = p2[t]; }
         }
     }
+    if (block_wg) break;
+    }
     stat_flush<KIND>(acc, sh, red, gh, true);
 }
 
@@ -1341,6 +1350,10 @@ constexpr int HF_PATCH = 5280;        // 20 rows (16 + two stencil halos) x 264 
 // the register walk above; more than one: the block's four 16-row tiles through the LDS patch --; the other units get G workgroups each
 // that walk their 256 x 16 tiles with stride G.  (All units handled like the second kind: a stencil unit's 256 tiles behind ~30
 // workgroups were the long pole of the launch -- 129 us against 94 us per 1024 x 1024 batch.)
+// PATCH: the instantiation for slots k >= 2 carries the two LDS patch buffers (two stencils in front of the op need k >= 2); slot 1 -- the
+// only late slot of the reference's configurations (CONTROLLER.L = 2) -- runs the instantiation without them: 9 KB of LDS instead of
+// 51, i.e. the streamed tiles are not held to three workgroups per CU by buffers they never touch.
+template <bool PATCH>
 __global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ pool, const aadg_unit* __restrict__ units,
                                                     const int* __restrict__ ulist, int n_sten, int G, int stage, int Hs, int Ws, int crop,
                                                     const uint8_t* __restrict__ lut, size_t lut_stage_stride, uint32_t* hist) {
@@ -1360,8 +1373,8 @@ __global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ 
     const aadg_unit& un = units[u];
     if (un.n_ops <= stage || !op_needs_stats(un.op[stage]) || !unit_fusable(true, un, Hs, Ws, crop)) return;
     if (stats_by_pushforward(un, stage, true)) return;            // k_lut derives this stage's histogram from the raw one
-    __shared__ __attribute__((aligned(16))) uint32_t A[HF_PATCH];
-    __shared__ __attribute__((aligned(16))) uint32_t B[HF_PATCH];
+    __shared__ __attribute__((aligned(16))) uint32_t A[PATCH ? HF_PATCH : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t B[PATCH ? HF_PATCH : 4];
     __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
     __shared__ __attribute__((aligned(16))) uint32_t red[32];
     __shared__ __attribute__((aligned(16))) uint32_t shx[768 * HF_COPIES];      // Equalize: accumulates over the workgroup's tiles
@@ -1373,13 +1386,13 @@ __global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ 
         if (op == AADG_OP_CONTRAST) stat_stream_unit<ST_CONTRAST>(un, stage, src, Hs, Ws, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride, tend);
         else if (op == AADG_OP_AUTOCONTRAST) stat_stream_unit<ST_AUTOCONTRAST>(un, stage, src, Hs, Ws, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride, tend);
         else stat_stream_unit<ST_EQUALIZE>(un, stage, src, Hs, Ws, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride, tend);
-    } else if (s == 1 && block_wg) {
+    } else if (s == 1) {
         int js = 0;
         while (!is_stencil(un, js)) ++js;
-        if (op == AADG_OP_CONTRAST) stat_strip_block<ST_CONTRAST>(un, stage, js, src, Hs, Ws, bx, by, lut, lut_stage_stride, u, sl, shx, red, gh);
-        else if (op == AADG_OP_AUTOCONTRAST) stat_strip_block<ST_AUTOCONTRAST>(un, stage, js, src, Hs, Ws, bx, by, lut, lut_stage_stride, u, sl, shx, red, gh);
-        else stat_strip_block<ST_EQUALIZE>(un, stage, js, src, Hs, Ws, bx, by, lut, lut_stage_stride, u, sl, shx, red, gh);
-    } else {
+        if (op == AADG_OP_CONTRAST) stat_strip_block<ST_CONTRAST>(un, stage, js, src, Hs, Ws, bx, by, lut, lut_stage_stride, u, sl, shx, red, gh, block_wg, t0, stride, tend);
+        else if (op == AADG_OP_AUTOCONTRAST) stat_strip_block<ST_AUTOCONTRAST>(un, stage, js, src, Hs, Ws, bx, by, lut, lut_stage_stride, u, sl, shx, red, gh, block_wg, t0, stride, tend);
+        else stat_strip_block<ST_EQUALIZE>(un, stage, js, src, Hs, Ws, bx, by, lut, lut_stage_stride, u, sl, shx, red, gh, block_wg, t0, stride, tend);
+    } else if (PATCH) {
         if (op == AADG_OP_CONTRAST) stat_patch_unit<ST_CONTRAST>(un, stage, s, src, Hs, Ws, A, B, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride, tend);
         else if (op == AADG_OP_AUTOCONTRAST) stat_patch_unit<ST_AUTOCONTRAST>(un, stage, s, src, Hs, Ws, A, B, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride, tend);
         else stat_patch_unit<ST_EQUALIZE>(un, stage, s, src, Hs, Ws, A, B, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride, tend);
@@ -1396,7 +1409,7 @@ static inline int launch_hist_fused(const uint8_t* pool, const aadg_unit* units,
     // 1024 x 1024, they did: 149 us per batch)
     int G = 1;
     if (n_rest > 0) {
-        const long long room = 768 - (long long)n_sten * nblocks;
+        const long long room = (stage >= 2 ? 768 : 1536) - (long long)n_sten * nblocks;       // 3 / 6 workgroups per CU
         G = (int)((room > 0 ? room : 0) / n_rest);
         const int g_min = (ntiles + 7) / 8;
         G = G < g_min ? g_min : G;
@@ -1404,7 +1417,10 @@ static inline int launch_hist_fused(const uint8_t* pool, const aadg_unit* units,
     }
     const long long grid = (long long)n_sten * nblocks + (long long)n_rest * G;
     if (grid <= 0 || grid > 0x7FFFFFFFll) return AADG_E_BADARG;
-    hipLaunchKernelGGL(k_hist_fused, dim3((unsigned)grid), dim3(256), 0, st, pool, units, ulist, n_sten, G, stage, Hs, Ws, crop, lut, lut_stage_stride, hist);
+    if (stage >= 2)
+        hipLaunchKernelGGL(k_hist_fused<true>, dim3((unsigned)grid), dim3(256), 0, st, pool, units, ulist, n_sten, G, stage, Hs, Ws, crop, lut, lut_stage_stride, hist);
+    else
+        hipLaunchKernelGGL(k_hist_fused<false>, dim3((unsigned)grid), dim3(256), 0, st, pool, units, ulist, n_sten, G, stage, Hs, Ws, crop, lut, lut_stage_stride, hist);
     AADG_LAUNCH_CHECK();
     return 0;
 }

@@ -412,3 +412,75 @@ def test_tap_class_boundaries_vs_oracle(hip, oracle):
     bad = [i for i in range(len(units)) if not np.array_equal(got_img[i].cpu().numpy(), want_img[i])]
     assert not bad, [(int(units[i]["scaled_w"]), int(units[i]["scaled_h"])) for i in bad[:8]]
     assert np.array_equal(got_lbl.cpu().numpy(), want_lbl)
+
+
+def test_statistics_pass_is_correct_for_any_list_split(hip, oracle):
+    """aadg_aug_lists.n_stat_stencil (ABI 7) tells the statistics pass which units of a slot's list -- the first ones -- have a
+    Sharpness stencil in front of the op; the promise of include/aadg_hip.h is that a wrong split costs time, never correctness (the
+    kernel chooses the data flow from the unit record).  The same late units -- byte map / Color / Cutout / Sharpness in front of
+    Contrast / AutoContrast / Equalize, on a 200 x 264 image (partial last block row, a second, narrow column strip) -- with the
+    planner's split, with no unit declared a stencil unit and with every unit declared one: identical bytes, equal to the oracle."""
+    from aadg_amd._lib import UNIT_DTYPE
+    rs = np.random.RandomState(5)
+    H, W, crop, P = 200, 264, 200, 5
+    imgs = np.stack([synth_pool(rs, 1, H, W)[0][0] for _ in range(P)])
+    msks = np.stack([synth_pool(rs, 1, H, W)[1][0] for _ in range(P)])
+    recs = []
+    from aadg_amd.data.basic import cutout_rect
+    for op0 in (7, 6, 9, 8, 3):
+        for op1 in (5, 0, 2):
+            for rep in range(2):
+                u = np.zeros((), UNIT_DTYPE)
+                u["rect"][:, 2:] = -1
+                u["src"] = rs.randint(P)
+                u["n_ops"] = 2
+                u["op"][0] = op0
+                u["farg"][0] = np.float32(1.4 if op0 != 8 else (1.7, 0.3)[rep])
+                if op0 == 9:
+                    u["rect"][0] = cutout_rect(W, H, 0.15 * W, rs.uniform(W), rs.uniform(H))
+                if op0 == 3:
+                    u["iarg"][0] = 100
+                u["op"][1] = op1
+                u["farg"][1] = np.float32(1.3)
+                u["scaled_w"], u["scaled_h"] = (W, H) if rep == 0 else (int(1.2 * W), int(1.3 * H))
+                u["crop_x"] = rs.randint(0, int(u["scaled_w"]) - crop + 1)
+                u["crop_y"] = rs.randint(0, int(u["scaled_h"]) - crop + 1)
+                recs.append(u)
+    units = np.array(recs, dtype=UNIT_DTYPE)
+    d_img, d_msk = torch.from_numpy(imgs).cuda(), torch.from_numpy(msks).cuda()
+    ph = hip.pool_histograms(d_img)
+    want_img, want_lbl = oracle.aug_units(imgs, msks, units, crop, 1)
+    base = hip.aug_u8_forward(d_img, d_msk, units, crop, 1, pool_hist=ph)
+    assert np.array_equal(base[0].cpu().numpy(), want_img) and np.array_equal(base[1].cpu().numpy(), want_lbl)
+    n_sten = hip.launch_plan(units, H, W, crop)[6]
+    assert 0 < n_sten[1] < hip.launch_plan(units, H, W, crop)[4][1].size               # a mixed list
+    for mode in ("none", "all"):
+        got = _aug_with_forced_split(hip, d_img, d_msk, units, crop, ph, mode)
+        assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1]), mode
+
+
+def _aug_with_forced_split(hip, d_img, d_msk, units, crop, ph, mode):
+    """aug_u8_forward with aadg_aug_lists.n_stat_stencil overridden ('none': 0 for every slot, 'all': n_stat) -- the planner is wrapped
+    for the duration of the call so that its summary carries the forced counts."""
+    import ctypes
+    from aadg_amd import _lib
+    lib = _lib.load()
+    real = lib.aadg_aug_u8_plan
+    K = _lib.MAX_OPS
+
+    def plan(*args):
+        rc = real(*args)
+        summary = args[-1]
+        for k in range(K):
+            summary[8 + K + k] = 0 if mode == "none" else summary[8 + k]
+        return rc
+
+    class Proxy(object):
+        def __getattr__(self, name):
+            return plan if name == "aadg_aug_u8_plan" else getattr(lib, name)
+    orig_load = _lib.load
+    _lib.load = lambda: Proxy()
+    try:
+        return hip.aug_u8_forward(d_img, d_msk, units, crop, 1, pool_hist=ph)
+    finally:
+        _lib.load = orig_load
