@@ -95,6 +95,13 @@ __device__ __forceinline__ int sharp_count(const aadg_unit& un, int upto) {
     for (int k = 0; k < upto; ++k) s += (un.op[k] == AADG_OP_SHARPNESS && un.farg[k] != 1.0f) ? 1 : 0;
     return s;
 }
+// number of Sharpness stencils of a unit, all four op slots read unconditionally (independent scalar loads, one wait)
+__device__ __forceinline__ int sharp_count4(const aadg_unit& un, int n_ops) {
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < AADG_MAX_OPS; ++k) s += (k < n_ops && un.op[k] == AADG_OP_SHARPNESS && un.farg[k] != 1.0f) ? 1 : 0;
+    return s;
+}
 // data flow of a unit: 0 = staged, 1 = fused "UP" tile (no down-scaling: <= 2 taps per axis), 2 = fused
 // "GENERIC" tile (down-scaling by at most 2x on either axis: <= 5 taps)
 enum { FLOW_STAGED = 0, FLOW_UP = 1, FLOW_GENERIC = 2 };
@@ -818,6 +825,93 @@ __device__ __forceinline__ uint32_t pointwise_op(const aadg_unit& un, int j, uin
     return r;
 }
 
+// The Sharpness passes of a patch (ops [j0, nops) with op j0 a stencil, the pointwise ops between / behind the stencils applied by the
+// lane that has just written the pixel): `cur` holds rows [r_lo, r_lo + ph) x columns [c_lo, c_lo + pw) after ops [0, j0), `oth` is the
+// ping-pong buffer.  Returns the buffer that holds the result; every pass ends with a barrier.
+__device__ __forceinline__ uint32_t* patch_stencil_passes(const aadg_unit& un, int nops, int j0, int Hs, int Ws, int r_lo, int c_lo, int ph, int pw,
+                                                          uint32_t* cur, uint32_t* oth, const uint8_t* sl_all) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // Sharpness passes: wave <-> (64-column chunk, row segment), a lane walks DOWN its column with the horizontal 3-sums of the
+    // previous / current / next row in registers: 3 LDS reads and ~50 instructions per pixel instead of 9 and ~80 (each pixel as the
+    // centre of its own 3 x 3 gather).  Narrow patches split the rows so that all four waves have work.
+    // Work items: (64-column chunk, row segment) pairs dealt round-robin to the four waves.  A patch is typically 256 + 8 columns wide
+    // (the halo, rounded to groups of 4): its fifth chunk holds 8 live columns, and as a chunk of its own it DOUBLED the stencil time
+    // of the wave that got it (5 items on 4 waves; the wave-0 SIMD of a CU then carries twice the instructions of the others --
+    // the statistics pass of a stencil tile took ~20 us).  A last chunk of <= 32 columns is therefore folded: its lanes are
+    // (column, row segment) pairs -- 8 columns x 8 segments, 16 x 4 or 32 x 2 -- so that it costs rows / 8 .. rows / 2 (+ 2 halo rows).
+    const int nfull = pw >> 6, wlast = pw & 63;
+    const bool fold = wlast > 0 && wlast <= 32 && nfull > 0;
+    const int nch = fold ? nfull : (pw + 63) >> 6;
+    const int nseg = nch >= 3 ? 1 : (nch == 2 ? 2 : 4);
+    const int seg_rows = (ph + nseg - 1) / nseg;
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);
+    const int fshift = wlast <= 8 ? 3 : (wlast <= 16 ? 4 : 5);          // folded chunk: log2 of its padded width
+    const int frows = (ph + (64 >> fshift) - 1) >> (6 - fshift);        // rows per lane segment
+    auto my_items = [&](auto body) {              // body(column of this lane, first row, end row) for the items of this wave
+        int it = 0;
+        for (int sg = 0; sg < nseg; ++sg)
+            for (int c = 0; c < nch; ++c, ++it)
+                if ((it & 3) == wvs) {
+                    const int ra = sg * seg_rows, rb = min(ph, ra + seg_rows);
+                    if (ra < rb) body(64 * c + lane, ra, rb);
+                }
+        if (fold && (it & 3) == wvs) {
+            const int ra = (lane >> fshift) * frows, rb = min(ph, ra + frows);
+            body(64 * nfull + (lane & ((1 << fshift) - 1)), ra, rb);         // ra >= rb: nothing to do for this lane
+        }
+    };
+    while (j0 < nops) {                           // op j0 is a Sharpness stencil
+        const float alpha = un.farg[j0];
+        int j1 = j0 + 1;
+        while (j1 < nops && !is_stencil(un, j1)) ++j1;
+        my_items([&](int col, int ra, int rb) {
+            const bool act = col < pw && ra < rb;
+            ra = min(ra, ph - 1);                                             // idle lanes of a folded chunk read in range
+            const int cc = min(col, pw - 1), cm = max(cc - 1, 0), cp = min(cc + 1, pw - 1);
+            const int x = c_lo + cc;
+            const bool col_in = x > 0 && x < Ws - 1 && cc > 0 && cc < pw - 1;   // ImageFilter.SMOOTH copies the 1-pixel image border
+            uint32_t h0rb = 0, h0g = 0, h1rb, h1g, h2rb = 0, h2g = 0, p1, p2 = 0;
+            auto hrow = [&](int r, uint32_t& hrb, uint32_t& hg, uint32_t& pc) {
+                const uint32_t* rp = cur + r * pw;
+                const uint32_t q0 = rp[cm], q1 = rp[cc], q2 = rp[cp];
+                pc = q1;
+                hrb = (q0 & 0xFF00FFu) + (q1 & 0xFF00FFu) + (q2 & 0xFF00FFu);
+                hg = ((q0 >> 8) & 255u) + ((q1 >> 8) & 255u) + ((q2 >> 8) & 255u);
+            };
+            if (ra > 0) { uint32_t t; hrow(ra - 1, h0rb, h0g, t); }
+            hrow(ra, h1rb, h1g, p1);
+            for (int r = ra; r < rb; ++r) {
+                if (r + 1 < ph) hrow(r + 1, h2rb, h2g, p2);
+                const int y = r_lo + r;
+                const bool in = col_in && y > 0 && y < Hs - 1 && r > 0 && r < ph - 1;
+                const uint32_t srb = h0rb + h1rb + h2rb + 4u * (p1 & 0xFF00FFu), sg = h0g + h1g + h2g + 4u * ((p1 >> 8) & 255u);   // centre weight 5 = 4 + 1
+                // (x + 6) / 13 for x <= 13 * 255: a 24-bit multiply by ceil(2^16 / 13) and a shift (exact for x + 6 <= 3321:
+                // the error term x * 10 / (13 * 65536) stays below 1/13); a 32-bit division is several quarter-rate multiplies
+                const uint32_t cr = (uint32_t)__mul24((int)((srb & 0xFFFFu) + 6u), 5042) >> 16, cb = (uint32_t)__mul24((int)((srb >> 16) + 6u), 5042) >> 16,
+                               cg = (uint32_t)__mul24((int)(sg + 6u), 5042) >> 16;
+                const uint32_t d = in ? (cr | (cg << 8) | (cb << 16)) : p1;
+                if (act) oth[r * pw + col] = blend3(d, p1, alpha, true);
+                h0rb = h1rb; h0g = h1g; h1rb = h2rb; h1g = h2g; p1 = p2;
+            }
+        });
+        // the pointwise ops that follow run on the pixels this lane has just written: no barrier needed
+        for (int j = j0 + 1; j < j1; ++j)
+            dispatch_op(un, j, sl_all, [&](auto f) {
+                my_items([&](int col, int ra, int rb) {
+                    if (col < pw)
+                        for (int r = ra; r < rb; ++r) {
+                            const int i = r * pw + col;
+                            oth[i] = f(oth[i], r_lo + r, c_lo + col);
+                        }
+                });
+            });
+        uint32_t* t = cur; cur = oth; oth = t;
+        __syncthreads();
+        j0 = j1;
+    }
+    return cur;
+}
+
 // Loads the patch (12-byte vector loads, all issued up front), applies the leading pointwise ops while the
 // pixels are still in registers, stores RGBX words to LDS; every Sharpness op then costs one LDS ping-pong
 // pass, after which the pointwise ops that follow it run in place on the lane's own pixels.
@@ -936,84 +1030,7 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
         lds_ops(cur, 0, j0, 256);
         __syncthreads();
     }
-    // Sharpness passes: wave <-> (64-column chunk, row segment), a lane walks DOWN its column with the horizontal 3-sums of the
-    // previous / current / next row in registers: 3 LDS reads and ~50 instructions per pixel instead of 9 and ~80 (each pixel as the
-    // centre of its own 3 x 3 gather).  Narrow patches split the rows so that all four waves have work.
-    // Work items: (64-column chunk, row segment) pairs dealt round-robin to the four waves.  A patch is typically 256 + 8 columns wide
-    // (the halo, rounded to groups of 4): its fifth chunk holds 8 live columns, and as a chunk of its own it DOUBLED the stencil time
-    // of the wave that got it (5 items on 4 waves; the wave-0 SIMD of a CU then carries twice the instructions of the others --
-    // the statistics pass of a stencil tile took ~20 us).  A last chunk of <= 32 columns is therefore folded: its lanes are
-    // (column, row segment) pairs -- 8 columns x 8 segments, 16 x 4 or 32 x 2 -- so that it costs rows / 8 .. rows / 2 (+ 2 halo rows).
-    const int nfull = pw >> 6, wlast = pw & 63;
-    const bool fold = wlast > 0 && wlast <= 32 && nfull > 0;
-    const int nch = fold ? nfull : (pw + 63) >> 6;
-    const int nseg = nch >= 3 ? 1 : (nch == 2 ? 2 : 4);
-    const int seg_rows = (ph + nseg - 1) / nseg;
-    const int wvs = __builtin_amdgcn_readfirstlane(wv);
-    const int fshift = wlast <= 8 ? 3 : (wlast <= 16 ? 4 : 5);          // folded chunk: log2 of its padded width
-    const int frows = (ph + (64 >> fshift) - 1) >> (6 - fshift);        // rows per lane segment
-    auto my_items = [&](auto body) {              // body(column of this lane, first row, end row) for the items of this wave
-        int it = 0;
-        for (int sg = 0; sg < nseg; ++sg)
-            for (int c = 0; c < nch; ++c, ++it)
-                if ((it & 3) == wvs) {
-                    const int ra = sg * seg_rows, rb = min(ph, ra + seg_rows);
-                    if (ra < rb) body(64 * c + lane, ra, rb);
-                }
-        if (fold && (it & 3) == wvs) {
-            const int ra = (lane >> fshift) * frows, rb = min(ph, ra + frows);
-            body(64 * nfull + (lane & ((1 << fshift) - 1)), ra, rb);         // ra >= rb: nothing to do for this lane
-        }
-    };
-    while (j0 < nops) {                           // op j0 is a Sharpness stencil
-        const float alpha = un.farg[j0];
-        int j1 = j0 + 1;
-        while (j1 < nops && !is_stencil(un, j1)) ++j1;
-        my_items([&](int col, int ra, int rb) {
-            const bool act = col < pw && ra < rb;
-            ra = min(ra, ph - 1);                                             // idle lanes of a folded chunk read in range
-            const int cc = min(col, pw - 1), cm = max(cc - 1, 0), cp = min(cc + 1, pw - 1);
-            const int x = c_lo + cc;
-            const bool col_in = x > 0 && x < Ws - 1 && cc > 0 && cc < pw - 1;   // ImageFilter.SMOOTH copies the 1-pixel image border
-            uint32_t h0rb = 0, h0g = 0, h1rb, h1g, h2rb = 0, h2g = 0, p1, p2 = 0;
-            auto hrow = [&](int r, uint32_t& hrb, uint32_t& hg, uint32_t& pc) {
-                const uint32_t* rp = cur + r * pw;
-                const uint32_t q0 = rp[cm], q1 = rp[cc], q2 = rp[cp];
-                pc = q1;
-                hrb = (q0 & 0xFF00FFu) + (q1 & 0xFF00FFu) + (q2 & 0xFF00FFu);
-                hg = ((q0 >> 8) & 255u) + ((q1 >> 8) & 255u) + ((q2 >> 8) & 255u);
-            };
-            if (ra > 0) { uint32_t t; hrow(ra - 1, h0rb, h0g, t); }
-            hrow(ra, h1rb, h1g, p1);
-            for (int r = ra; r < rb; ++r) {
-                if (r + 1 < ph) hrow(r + 1, h2rb, h2g, p2);
-                const int y = r_lo + r;
-                const bool in = col_in && y > 0 && y < Hs - 1 && r > 0 && r < ph - 1;
-                const uint32_t srb = h0rb + h1rb + h2rb + 4u * (p1 & 0xFF00FFu), sg = h0g + h1g + h2g + 4u * ((p1 >> 8) & 255u);   // centre weight 5 = 4 + 1
-                // (x + 6) / 13 for x <= 13 * 255: a 24-bit multiply by ceil(2^16 / 13) and a shift (exact for x + 6 <= 3321:
-                // the error term x * 10 / (13 * 65536) stays below 1/13); a 32-bit division is several quarter-rate multiplies
-                const uint32_t cr = (uint32_t)__mul24((int)((srb & 0xFFFFu) + 6u), 5042) >> 16, cb = (uint32_t)__mul24((int)((srb >> 16) + 6u), 5042) >> 16,
-                               cg = (uint32_t)__mul24((int)(sg + 6u), 5042) >> 16;
-                const uint32_t d = in ? (cr | (cg << 8) | (cb << 16)) : p1;
-                if (act) oth[r * pw + col] = blend3(d, p1, alpha, true);
-                h0rb = h1rb; h0g = h1g; h1rb = h2rb; h1g = h2g; p1 = p2;
-            }
-        });
-        // the pointwise ops that follow run on the pixels this lane has just written: no barrier needed
-        for (int j = j0 + 1; j < j1; ++j)
-            dispatch_op(un, j, sl_all, [&](auto f) {
-                my_items([&](int col, int ra, int rb) {
-                    if (col < pw)
-                        for (int r = ra; r < rb; ++r) {
-                            const int i = r * pw + col;
-                            oth[i] = f(oth[i], r_lo + r, c_lo + col);
-                        }
-                });
-            });
-        uint32_t* t = cur; cur = oth; oth = t;
-        __syncthreads();
-        j0 = j1;
-    }
+    cur = patch_stencil_passes(un, nops, j0, Hs, Ws, r_lo, c_lo, ph, pw, cur, oth, sl_all);
     return cur;
 }
 
@@ -1498,28 +1515,108 @@ __device__ __forceinline__ uint32_t hpass_px(const uint32_t* rowp, const uint32_
     return __builtin_amdgcn_perm(s2, rg, 0x0c070100u);                  // [rg.b0, rg.b1, s2.b3, 0]
 }
 
-// body of one horizontal-pass tile: (bx, by) = column tile / row block, slot = position in the generic list = the unit's slice of
-// hbuf; A / Bs: PATCH_CAP + 8 words each (Bs only with a stencil), sl: the stage LUTs
+// ---- plain units (no stencil): GH_NB consecutive row blocks per workgroup, software-pipelined ----
+// A horizontal-pass workgroup is a chain of dependent round trips -- unit record -> tables -> source rows -> LDS -> stores -- of ~8 us for
+// 2048 outputs, and a CU already holds 7 of them (28 of 32 waves): the kernel ran at a third of what its traffic allows.  The plain variant
+// therefore walks GH_NB row blocks of its column tile: the unit record, the tables, the taps and the byte maps are read once, and the source
+// rows of block i + 1 are in flight (registers) while block i goes through LDS -- plain loads survive __syncthreads().
+constexpr int GH_NB = 1;
+struct GhRegs { uint32_t a[GH_NR], b[GH_NR], c[GH_NR], wa, wb, wc; };
+
+// the loads of one row block: rows [0, ph) x pixel groups [0, q4) of the block at blk (uniform pointer: first row, column c_lo);
+// thread <-> (row = wave + 4k, group = lane), the groups beyond 64 (patches wider than 256 pixels: uniform `wide`) by thread
+// t <-> (row t >> 2, group 64 + (t & 3)).  Addresses are clamped into the block: no load is conditional per lane; a uniform base and a
+// 32-bit lane offset per load.  Three dwords per pixel group (typed as one 12-byte vector).
+struct __attribute__((packed, aligned(4))) U32x3 { uint32_t x, y, z; };
+__device__ __forceinline__ void gh_fetch(GhRegs& R, const uint8_t* __restrict__ blk, int row_bytes, int ph, int q4, bool wide) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t goff = 12u * (uint32_t)min(lane, q4 - 1);
+#pragma unroll
+    for (int k = 0; k < GH_NR; ++k) {
+        const uint8_t* rowp = blk + (size_t)min(wv + 4 * k, ph - 1) * row_bytes;      // uniform
+        const U32x3 v = *reinterpret_cast<const U32x3*>(rowp + goff);
+        R.a[k] = v.x; R.b[k] = v.y; R.c[k] = v.z;
+    }
+    if (wide) {
+        const uint32_t toff = (uint32_t)min(tid >> 2, ph - 1) * (uint32_t)row_bytes + 12u * (uint32_t)min(64 + (tid & 3), q4 - 1);
+        const U32x3 v = *reinterpret_cast<const U32x3*>(blk + toff);
+        R.wa = v.x; R.wb = v.y; R.wc = v.z;
+    }
+}
+
+// registers of a fetched block -> RGBX pixels of the lane (px: rows wave + 4k, pt: the group beyond column 256)
+__device__ __forceinline__ void gh_unpack(const GhRegs& R, uint32_t (&px)[GH_NR][4], uint32_t (&pt)[4]) {
+#pragma unroll
+    for (int k = 0; k < GH_NR; ++k) {
+        const uint32_t a = R.a[k], b = R.b[k], c = R.c[k];
+        px[k][0] = a & 0xFFFFFFu; px[k][1] = (a >> 24) | ((b & 0xFFFFu) << 8);
+        px[k][2] = (b >> 16) | ((c & 0xFFu) << 16); px[k][3] = c >> 8;
+    }
+    pt[0] = R.wa & 0xFFFFFFu; pt[1] = (R.wa >> 24) | ((R.wb & 0xFFFFu) << 8);
+    pt[2] = (R.wb >> 16) | ((R.wc & 0xFFu) << 16); pt[3] = R.wc >> 8;
+}
+
+// pixels -> leading pointwise ops [0, nops) -> LDS patch A[ph][pw]; ends with a barrier
+__device__ __forceinline__ void gh_stage(uint32_t (&px)[GH_NR][4], const uint32_t (&pt)[4], const aadg_unit& un, int nops, int r0, int ph,
+                                         int c_lo, int pw, uint32_t* A, const uint8_t* sl_all) {
+    const int tid = threadIdx.x, lane = tid & 63, q4 = pw >> 2;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int j = 0; j < nops; ++j)
+        dispatch_op(un, j, sl_all, [&](auto f) {
+#pragma unroll
+            for (int k = 0; k < GH_NR; ++k) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) px[k][t] = f(px[k][t], r0 + wv + 4 * k, c_lo + 4 * lane + t);
+                __builtin_amdgcn_sched_barrier(0);              // one row's byte-map reads in flight at a time (registers)
+            }
+        });
+    uint32_t* Al = A + 4 * lane;
+#pragma unroll
+    for (int k = 0; k < GH_NR; ++k) {
+        const int row = wv + 4 * k;                             // uniform
+        if (row < ph && lane < q4) *reinterpret_cast<uint4*>(Al + row * pw) = make_uint4(px[k][0], px[k][1], px[k][2], px[k][3]);
+    }
+    const bool wide = pw > 256;                                // uniform
+    if (wide) {
+        const int trow = tid >> 2, tgrp = 64 + (tid & 3);
+        if (trow < ph && tgrp < q4)                            // stored raw, the ops run on them in LDS below
+            *reinterpret_cast<uint4*>(&A[trow * pw + 4 * tgrp]) = make_uint4(pt[0], pt[1], pt[2], pt[3]);
+    }
+    __syncthreads();
+    if (wide && nops > 0) {
+        for (int j = 0; j < nops; ++j)
+            dispatch_op(un, j, sl_all, [&](auto f) {
+                for (int row = wv; row < ph; row += 4)
+                    for (int col = 256 + lane; col < pw; col += 64) {
+                        const int i = row * pw + col;
+                        A[i] = f(A[i], r0 + row, c_lo + col);
+                    }
+            });
+        __syncthreads();
+    }
+}
+
 template <bool SHARP>
-__device__ __forceinline__ void gen_hpass_body(const uint8_t* __restrict__ pool, const aadg_unit* __restrict__ units,
-                                               const int* __restrict__ order, int slot, int bx, int by, int Hs, int Ws, int crop,
+__device__ __forceinline__ void gen_hpass_pipe(const uint8_t* __restrict__ pool, const aadg_unit* __restrict__ units,
+                                               const int* __restrict__ order, int slot, int bx, int by0, int Hs, int Ws, int crop,
                                                const int* __restrict__ tab, const uint8_t* __restrict__ lut,
                                                size_t lut_stage_stride, uint32_t* __restrict__ hbuf, uint32_t* A, uint32_t* Bs, uint8_t* sl) {
     const int u = order != nullptr ? order[slot] : slot;
     const aadg_unit& un = units[u];
-    if (unit_flow(true, un, Hs, Ws, crop) != FLOW_GENERIC) return;
-    const int n_ops = un.n_ops;
-    const int s = sharp_count(un, n_ops);
-    if ((s > 0) != SHARP) return;
-    const int ROWS = GH_PATCH_ROWS - 2 * s;                // the patch holds the tile's rows + the stencils' halo
+    // the record's fields in one batch of scalar loads
+    const int n_ops = un.n_ops, w = un.scaled_w, h = un.scaled_h, u_pad = un.pad, u_cx = un.crop_x, u_cy = un.crop_y, u_src = un.src;
+    const int sc = sharp_count4(un, n_ops);
+    if ((Ws & 3) || (crop & 3) || sc > MAX_SHARP || (w >= Ws && h >= Hs) || 2 * w < Ws || 2 * h < Hs) return;      // not a FLOW_GENERIC unit
+    if ((sc > 0) != SHARP) return;                              // the other variant owns this unit
+    const int s = SHARP ? sc : 0;
+    const int ROWS = GH_PATCH_ROWS - 2 * s;                     // the patch holds the block's rows + the stencils' halo
     const int tid = threadIdx.x;
     const int* base = tab + (size_t)u * crop * TAB_STRIDE;
     const int* xmin_t = base;
     const int* xk_t = xmin_t + crop;
     const int* ymin_t = xk_t + (size_t)crop * KMAX;
-    const int w = un.scaled_w, h = un.scaled_h;
-    const int ox = un.crop_x - un.pad, oy = un.crop_y - un.pad;
-    // valid (non-pad) output range of the unit, of this tile's columns
+    const int ox = u_cx - u_pad, oy = u_cy - u_pad;
     const int ufx = max(0, -ox), ulx = min(crop - 1, w - 1 - ox);
     const int ufy = max(0, -oy), uly = min(crop - 1, h - 1 - oy);
     if (ufx > ulx || ufy > uly) return;
@@ -1527,58 +1624,95 @@ __device__ __forceinline__ void gen_hpass_body(const uint8_t* __restrict__ pool,
     const int fx = max(x0, ufx), lx = min(x0 + GH_CB - 1, ulx);
     if (fx > lx) return;
     const int ntx = axis_taps(Ws, w), nty = axis_taps(Hs, h);
-    // source rows the unit's valid output rows read: [ur_lo, ur_hi); this tile's block of them
-    const int ur_lo = ymin_t[ufy], ur_hi = min(Hs, ymin_t[uly] + nty);
-    const int r_lo = ur_lo + by * ROWS;
-    if (r_lo >= ur_hi) return;
-    const int r_hi = min(ur_hi, r_lo + ROWS);
-    const int c_lo = xmin_t[fx], c_hi = min(Ws, xmin_t[lx] + ntx);
-    const int r_lo_h = max(0, r_lo - s), r_hi_h = min(Hs, r_hi + s);
-    const int c_lo_h = max(0, c_lo - s) & ~3, c_hi_h = min(Ws, (c_hi + s + 3) & ~3);
-    const int pw = c_hi_h - c_lo_h;
-    // horizontal pass: thread <-> (output column hc, row parity hg); its taps are loaded before the patch is built
-    const int hc = tid & (GH_CB - 1), hg = tid >> 7;
+    // one batch of scalar loads: the row range of the unit, the column range of the tile
+    const int t_rlo = ymin_t[ufy], t_rhi = ymin_t[uly], t_clo = xmin_t[fx], t_chi = xmin_t[lx];
+    // the byte maps of the LUT-class ops (every stage's slot exists in the workspace: no load is conditional) and the taps of the
+    // thread's output column: issued before the first wait
+    uint32_t lreg[AADG_MAX_OPS];
+    {
+        const uint32_t* lp = reinterpret_cast<const uint32_t*>(lut + (size_t)u * 768) + min(tid, 191);
+#pragma unroll
+        for (int j = 0; j < AADG_MAX_OPS; ++j) lreg[j] = lp[j * (lut_stage_stride >> 2)];
+    }
+    // horizontal pass: thread <-> (output column hc, row parity hg: uniform per wave)
+    const int hc = tid & (GH_CB - 1);
+    const int hg = __builtin_amdgcn_readfirstlane(tid >> 7);
     const int xh = x0 + hc;
     const bool col_ok = xh >= fx && xh <= lx;
-    int hxm = 0;
+    const int xc = min(max(xh, fx), lx);
+    int hxm = xmin_t[xc];
+    int kraw[GT_TAPS];
+#pragma unroll
+    for (int t = 0; t < GT_TAPS; ++t) kraw[t] = xk_t[(size_t)xc * KMAX + t];
+    const int ur_lo = t_rlo, ur_hi = min(Hs, t_rhi + nty);
+    const int r_first = ur_lo + by0 * GH_NB * ROWS;
+    if (r_first >= ur_hi) return;
+    // patch columns: the taps' range + the stencils' halo, clipped to the image, in groups of 4
+    const int c_lo = max(0, t_clo - s) & ~3, c_hi4 = min(Ws, (min(Ws, t_chi + ntx) + s + 3) & ~3);
+    const int pw = c_hi4 - c_lo, q4 = pw >> 2;
+    const bool wide = pw > 256;
+    const int row_bytes = Ws * 3;
+    const uint8_t* img = pool + (size_t)u_src * Hs * row_bytes + (size_t)c_lo * 3;     // uniform: row 0 of the source, column c_lo
+    // patch rows of the block that starts at source row r: [max(0, r - s), min(Hs, min(ur_hi, r + ROWS) + s))
+    auto blk_lo = [&](int r) { return max(0, r - s); };
+    auto blk_hi = [&](int r) { return min(Hs, min(ur_hi, r + ROWS) + s); };
+    GhRegs R;
+    R.wa = R.wb = R.wc = 0;
+    gh_fetch(R, img + (size_t)blk_lo(r_first) * row_bytes, row_bytes, blk_hi(r_first) - blk_lo(r_first), q4, wide);
     uint32_t hk[GT_TAPS];
-    {
-        const int xc = min(max(xh, fx), lx);                  // clamped: no conditional loads
-        hxm = xmin_t[xc];
-        int kraw[GT_TAPS];
 #pragma unroll
-        for (int t = 0; t < GT_TAPS; ++t) kraw[t] = xk_t[(size_t)xc * KMAX + (t < ntx ? t : 0)];
+    for (int t = 0; t < GT_TAPS; ++t) hk[t] = t < ntx ? prescale4(kraw[t]) : 0u;
+    hxm -= c_lo;                                                // LDS column of the first tap
+    if (tid < 192) {
 #pragma unroll
-        for (int t = 0; t < GT_TAPS; ++t) hk[t] = t < ntx ? prescale4(kraw[t]) : 0u;
+        for (int j = 0; j < AADG_MAX_OPS; ++j) reinterpret_cast<uint32_t*>(sl + j * 768)[tid] = lreg[j];
     }
-    const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
-    const uint32_t* cur = build_patch<GH_NR, 2>(un, n_ops, src, Hs, Ws, r_lo_h, r_hi_h, c_lo_h, c_hi_h, A, SHARP ? Bs : A, lut,
-                                                lut_stage_stride, u, sl);
-    if (!col_ok) return;
-    const int nrows = r_hi - r_lo;
-    const uint32_t* colp = cur + (r_lo - r_lo_h) * pw + (hxm - c_lo_h);
-    uint32_t* hout = hbuf + ((size_t)slot * Hs + r_lo) * crop + xh;
+    int j0 = n_ops;                                             // leading pointwise segment [0, j0)
+    if (SHARP) {
+        j0 = 0;
+        while (j0 < n_ops && !is_stencil(un, j0)) ++j0;
+    }
+    uint32_t* hrow = hbuf + ((size_t)slot * Hs + r_first) * crop + x0;      // uniform: row r_lo of the intermediate, column x0
+    __syncthreads();                                            // the byte maps are in LDS
+#pragma unroll 1
+    for (int r_lo = r_first, i = 0; i < GH_NB && r_lo < ur_hi; ++i, r_lo += ROWS) {
+        const int nrows = min(ROWS, ur_hi - r_lo);
+        const int p_lo = blk_lo(r_lo), ph = blk_hi(r_lo) - p_lo;
+        uint32_t px[GH_NR][4], pt[4];
+        gh_unpack(R, px, pt);
+        // the next block's rows are in flight while this one goes through LDS (plain loads survive the barriers)
+        const int r_nx = r_lo + ROWS;
+        if (i + 1 < GH_NB && r_nx < ur_hi) gh_fetch(R, img + (size_t)blk_lo(r_nx) * row_bytes, row_bytes, blk_hi(r_nx) - blk_lo(r_nx), q4, wide);
+        gh_stage(px, pt, un, j0, p_lo, ph, c_lo, pw, A, sl);
+        const uint32_t* cur = A;
+        if (SHARP) cur = patch_stencil_passes(un, n_ops, j0, Hs, Ws, p_lo, c_lo, ph, pw, A, Bs, sl);
+        if (col_ok) {
+            const uint32_t* colp = cur + (r_lo - p_lo) * pw + hxm;
 #define AADG_HPASS_ROWS(NT)                                                                                              \
-    _Pragma("unroll 2") for (int rr = hg; rr < nrows; rr += 2) hout[(size_t)rr * crop] = hpass_px<NT>(colp + rr * pw, hk)
-    switch (ntx) {                                            // uniform per unit
-        case 1: AADG_HPASS_ROWS(1); break;
-        case 2: AADG_HPASS_ROWS(2); break;
-        case 3: AADG_HPASS_ROWS(3); break;
-        case 4: AADG_HPASS_ROWS(4); break;
-        default: AADG_HPASS_ROWS(GT_TAPS); break;
-    }
+    _Pragma("unroll 2") for (int rr = hg; rr < nrows; rr += 2) (hrow + (size_t)rr * crop)[hc] = hpass_px<NT>(colp + rr * pw, hk)
+            switch (ntx) {                                        // uniform per unit
+                case 1: AADG_HPASS_ROWS(1); break;
+                case 2: AADG_HPASS_ROWS(2); break;
+                case 3: AADG_HPASS_ROWS(3); break;
+                case 4: AADG_HPASS_ROWS(4); break;
+                default: AADG_HPASS_ROWS(GT_TAPS); break;
+            }
 #undef AADG_HPASS_ROWS
+        }
+        hrow += (size_t)ROWS * crop;
+        __syncthreads();                                        // the patch is free for the next block
+    }
 }
 
 template <bool SHARP>
-__global__ __launch_bounds__(256) void k_gen_hpass(const uint8_t* __restrict__ pool, const aadg_unit* __restrict__ units,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHARP ? 4 : 5))) void k_gen_hpass(const uint8_t* __restrict__ pool, const aadg_unit* __restrict__ units,
                                                    const int* __restrict__ order, int slot0, int Hs, int Ws, int crop,
                                                    const int* __restrict__ tab, const uint8_t* __restrict__ lut,
                                                    size_t lut_stage_stride, uint32_t* __restrict__ hbuf) {
     __shared__ __attribute__((aligned(16))) uint32_t A[GH_CAP];
     __shared__ __attribute__((aligned(16))) uint32_t Bs[SHARP ? GH_CAP : 4];
     __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
-    gen_hpass_body<SHARP>(pool, units, order, slot0 + blockIdx.z, blockIdx.x, blockIdx.y, Hs, Ws, crop, tab, lut, lut_stage_stride, hbuf, A, Bs, sl);
+    gen_hpass_pipe<SHARP>(pool, units, order, slot0 + blockIdx.z, blockIdx.x, blockIdx.y, Hs, Ws, crop, tab, lut, lut_stage_stride, hbuf, A, Bs, sl);
 }
 
 struct __attribute__((packed)) UnalignedU32 { uint32_t v; };
@@ -1764,13 +1898,6 @@ __global__ __launch_bounds__(256) void k_gen_vpass(const uint8_t* __restrict__ m
 constexpr int PATCH_CAP_PLAIN = 4608;     // 17 rows x 264 columns: a 256 x 16 tile's patch without a stencil halo
 constexpr int HBUF_ROWS = FT_H + 1;       // source rows a 16-row tile touches when no axis shrinks
 
-// number of Sharpness stencils of a unit, all four op slots read unconditionally (independent scalar loads, one wait)
-__device__ __forceinline__ int sharp_count4(const aadg_unit& un, int n_ops) {
-    int s = 0;
-#pragma unroll
-    for (int k = 0; k < AADG_MAX_OPS; ++k) s += (k < n_ops && un.op[k] == AADG_OP_SHARPNESS && un.farg[k] != 1.0f) ? 1 : 0;
-    return s;
-}
 
 template <bool SHARP>
 __device__ __forceinline__ void fused3_body(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
@@ -2075,12 +2202,12 @@ int launch_tiles(const uint8_t* pool, const uint8_t* masks, const aadg_unit* uni
         const int p0 = a, p1 = min(b, n0);
         const int q0 = max(a, s1), q1 = b;
         if (p1 > p0) {
-            hipLaunchKernelGGL(k_gen_hpass<false>, dim3(hx, hy0, p1 - p0), dim3(256), 0, st, pool, units, order_gen, p0, Hs, Ws, crop, tab, lut,
+            hipLaunchKernelGGL(k_gen_hpass<false>, dim3(hx, (hy0 + GH_NB - 1) / GH_NB, p1 - p0), dim3(256), 0, st, pool, units, order_gen, p0, Hs, Ws, crop, tab, lut,
                                lut_stage_stride, hb);
             AADG_LAUNCH_CHECK();
         }
         if (q1 > q0) {
-            hipLaunchKernelGGL(k_gen_hpass<true>, dim3(hx, hy1, q1 - q0), dim3(256), 0, st, pool, units, order_gen, q0, Hs, Ws, crop, tab, lut,
+            hipLaunchKernelGGL(k_gen_hpass<true>, dim3(hx, (hy1 + GH_NB - 1) / GH_NB, q1 - q0), dim3(256), 0, st, pool, units, order_gen, q0, Hs, Ws, crop, tab, lut,
                                lut_stage_stride, hb);
             AADG_LAUNCH_CHECK();
         }
