@@ -26,6 +26,7 @@
 //
 //  STAGED (everything else; also the eager single-op entry point): u8 intermediates in the workspace.
 //   k_hist / k_lut / k_apply per op stage, then k_tables and k_final (gathers from global memory).
+#include <stddef.h>
 #include <stdlib.h>
 
 #include <vector>
@@ -761,12 +762,29 @@ __global__ __launch_bounds__(256) void k_final(Bufs bufs, const uint8_t* masks, 
 // Pixels within `sharp_count` of a patch edge that is not an image edge are NOT valid afterwards.
 // Returns the buffer (A or B) that holds the result.  Ends with a __syncthreads().
 // ------------------------------------------------------------------------------------------------
+// three dwords of a pixel group (12 bytes, 4-byte aligned)
+struct __attribute__((packed, aligned(4))) U32x3 { uint32_t x, y, z; };
 __device__ __forceinline__ uint32_t blend3(uint32_t deg, uint32_t img, float alpha, bool interp) {
     const uint32_t r = blend_px((int)(deg & 255), (int)(img & 255), alpha, interp);
     const uint32_t g = blend_px((int)((deg >> 8) & 255), (int)((img >> 8) & 255), alpha, interp);
     const uint32_t b = blend_px((int)((deg >> 16) & 255), (int)((img >> 16) & 255), alpha, interp);
     return r | (g << 8) | (b << 16);
 }
+
+// A word of the (uniform) unit record at an index known only at run time, through the scalar cache.  The compiler reads `un.op[j]` with a
+// run-time j behind a barrier as a VECTOR load with a full wait (it no longer treats the record as invariant there): one L2 round trip per
+// field, in series, in front of every tile's op chain.  The record was read by the prologue's scalar loads, so these hit the scalar cache.
+__device__ __forceinline__ uint32_t unit_word(const aadg_unit& un, uint32_t byte_off) {
+    uint32_t v;
+    const aadg_unit* p = &un;
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p), "s"(byte_off) : "memory");
+    return v;
+}
+__device__ __forceinline__ int unit_op(const aadg_unit& un, int j) { return (int)unit_word(un, 8u + 4u * (uint32_t)j); }
+__device__ __forceinline__ int unit_iarg(const aadg_unit& un, int j) { return (int)unit_word(un, 24u + 4u * (uint32_t)j); }
+__device__ __forceinline__ float unit_farg(const aadg_unit& un, int j) { return __uint_as_float(unit_word(un, 40u + 4u * (uint32_t)j)); }
+static_assert(offsetof(aadg_unit, op) == 8 && offsetof(aadg_unit, iarg) == 24 && offsetof(aadg_unit, farg) == 40 && offsetof(aadg_unit, rect) == 56,
+              "unit_word offsets follow include/aadg_hip.h");
 
 // ops whose per-channel byte map is staged in LDS (768 bytes per stage, built by k_lut): the three statistics ops,
 // Brightness and Solarize.  Invert / Posterize are one integer instruction per pixel; Color mixes channels and
@@ -775,7 +793,7 @@ __device__ __forceinline__ bool needs_lds_lut(int op) {
     return op_needs_stats(op) || op == AADG_OP_BRIGHTNESS || op == AADG_OP_SOLARIZE;
 }
 __device__ __forceinline__ bool is_stencil(const aadg_unit& un, int j) {
-    return un.op[j] == AADG_OP_SHARPNESS && un.farg[j] != 1.0f;
+    return unit_op(un, j) == AADG_OP_SHARPNESS && unit_farg(un, j) != 1.0f;
 }
 
 // One pointwise op applied to a set of pixels.  The op is uniform per workgroup: the dispatch happens ONCE here and
@@ -783,13 +801,13 @@ __device__ __forceinline__ bool is_stencil(const aadg_unit& un, int j) {
 // LDS region) -- no per-pixel switch, no per-pixel checks of uniform parameters.
 template <typename Each>
 __device__ __forceinline__ void dispatch_op(const aadg_unit& un, int j, const uint8_t* sl_all, Each each) {
-    const int op = un.op[j];
+    const int op = unit_op(un, j);
     switch (op) {
         case AADG_OP_INVERT:
             each([](uint32_t p, int, int) { return ~p & 0xFFFFFFu; });
             break;
         case AADG_OP_POSTERIZE: {
-            const uint32_t m = (0xFFu & ~((1u << (8 - un.iarg[j])) - 1u)) * 0x010101u;
+            const uint32_t m = (0xFFu & ~((1u << (8 - unit_iarg(un, j))) - 1u)) * 0x010101u;
             each([m](uint32_t p, int, int) { return p & m; });
             break;
         }
@@ -801,7 +819,7 @@ __device__ __forceinline__ void dispatch_op(const aadg_unit& un, int j, const ui
             break;
         }
         case AADG_OP_COLOR: {
-            const float alpha = un.farg[j];
+            const float alpha = unit_farg(un, j);
             each([alpha](uint32_t p, int, int) {
                 const uint32_t l = rgb2l(p & 255u, (p >> 8) & 255u, (p >> 16) & 255u);
                 return blend3(l * 0x010101u, p, alpha, true);
@@ -809,7 +827,8 @@ __device__ __forceinline__ void dispatch_op(const aadg_unit& un, int j, const ui
             break;
         }
         case AADG_OP_CUTOUT: {
-            const int x0 = un.rect[j][0], y0 = un.rect[j][1], x1 = un.rect[j][2], y1 = un.rect[j][3];
+            const uint32_t ro = 56u + 16u * (uint32_t)j;
+            const int x0 = (int)unit_word(un, ro), y0 = (int)unit_word(un, ro + 4), x1 = (int)unit_word(un, ro + 8), y1 = (int)unit_word(un, ro + 12);
             each([=](uint32_t p, int y, int x) { return (x >= x0 && x <= x1 && y >= y0 && y <= y1) ? 0x7F7F7Fu : p; });
             break;
         }
@@ -861,7 +880,7 @@ __device__ __forceinline__ uint32_t* patch_stencil_passes(const aadg_unit& un, i
         }
     };
     while (j0 < nops) {                           // op j0 is a Sharpness stencil
-        const float alpha = un.farg[j0];
+        const float alpha = unit_farg(un, j0);
         int j1 = j0 + 1;
         while (j1 < nops && !is_stencil(un, j1)) ++j1;
         my_items([&](int col, int ra, int rb) {
@@ -922,55 +941,59 @@ __device__ __forceinline__ uint32_t* build_patch(const aadg_unit& un, int nops, 
                                  int r_lo, int r_hi, int c_lo, int c_hi, uint32_t* A, uint32_t* B,
                                  const uint8_t* __restrict__ lut, size_t lut_stage_stride, int u, uint8_t* sl_all) {
     const int tid = threadIdx.x;
+    // No load of the prologue is conditional per lane: addresses are clamped into the patch / the byte-map slots (every stage's slot exists
+    // in the workspace) and what an idle lane fetched is dropped at the LDS store.  Conditional loads became branches with a wait at every
+    // join -- a chain of round trips in front of every tile (the horizontal pass of the down-scaling units: 78 -> 54 us per chunk).
     uint32_t lreg[AADG_MAX_OPS];
     bool any_lut = false;
+    {
+        const uint32_t* lp = reinterpret_cast<const uint32_t*>(lut + (size_t)u * 768) + min(tid, 191);
 #pragma unroll
-    for (int j = 0; j < AADG_MAX_OPS; ++j) {
-        lreg[j] = 0;
-        if (j < nops && needs_lds_lut(un.op[j])) {
-            any_lut = true;
-            if (tid < 192) lreg[j] = reinterpret_cast<const uint32_t*>(lut + (size_t)j * lut_stage_stride + (size_t)u * 768)[tid];
+        for (int j = 0; j < AADG_MAX_OPS; ++j) {
+            lreg[j] = lp[j * (lut_stage_stride >> 2)];
+            any_lut = any_lut || (j < nops && needs_lds_lut(un.op[j]));
         }
     }
     const int pw = c_hi - c_lo, ph = r_hi - r_lo, q4 = pw >> 2;
     // thread <-> (row = wave + 4k, group of 4 pixels = lane (+64)): no integer divisions.  All loads of this
     // thread are issued before the first use.
     const int lane = tid & 63, wv = tid >> 6;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
     // NR = rows per wave (4 * NR >= patch rows); WIDE = patch may be wider than 256 pixels
     constexpr bool WIDE = WMODE != 0;
     constexpr int NW = WMODE == 1 ? NR : 1;
     uint32_t ra[NR], rb[NR], rc[NR], rd[NW], re[NW], rf[NW];
+    const bool wide = WIDE && pw > 256;                         // uniform
     const bool has2 = WMODE == 1 && lane + 64 < q4;
     // WMODE 2: thread t < 4 * rows fetches group 64 + (t & 3) of row t >> 2
     const int trow = tid >> 2, tgrp = 64 + (tid & 3);
     const bool tail = WMODE == 2 && trow < ph && tgrp < q4;
     uint32_t wa = 0, wb = 0, wc = 0;
+    const int row_bytes = Ws * 3;
+    const uint8_t* blk = src + ((size_t)r_lo * Ws + c_lo) * 3;  // uniform
+    const uint32_t goff = 12u * (uint32_t)min(lane, q4 - 1), goff2 = 12u * (uint32_t)min(lane + 64, q4 - 1);
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-        const int row = wv + 4 * k;
-        ra[k] = rb[k] = rc[k] = 0;
-        if (WMODE == 1) rd[k % NW] = re[k % NW] = rf[k % NW] = 0;
-        if (row < ph) {
-            const uint8_t* rowp = src + ((size_t)(r_lo + row) * Ws + c_lo) * 3;
-            if (lane < q4) {
-                const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + 12 * lane);
-                ra[k] = p[0]; rb[k] = p[1]; rc[k] = p[2];
-            }
-            if (WMODE == 1 && has2) {
-                const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + 12 * (lane + 64));
-                rd[k % NW] = p[0]; re[k % NW] = p[1]; rf[k % NW] = p[2];
+        const uint8_t* rowp = blk + (size_t)min(wvu + 4 * k, ph - 1) * row_bytes;      // uniform
+        const U32x3 v = *reinterpret_cast<const U32x3*>(rowp + goff);
+        ra[k] = v.x; rb[k] = v.y; rc[k] = v.z;
+        if (WMODE == 1) {
+            rd[k % NW] = re[k % NW] = rf[k % NW] = 0;
+            if (wide) {
+                const U32x3 v2 = *reinterpret_cast<const U32x3*>(rowp + goff2);
+                rd[k % NW] = v2.x; re[k % NW] = v2.y; rf[k % NW] = v2.z;
             }
         }
     }
-    if (tail) {
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(src + ((size_t)(r_lo + trow) * Ws + c_lo) * 3 + 12 * tgrp);
-        wa = p[0]; wb = p[1]; wc = p[2];
+    if (WMODE == 2 && wide) {
+        const U32x3 v = *reinterpret_cast<const U32x3*>(blk + (uint32_t)min(trow, ph - 1) * (uint32_t)row_bytes + 12u * (uint32_t)min(tgrp, q4 - 1));
+        wa = v.x; wb = v.y; wc = v.z;
     }
     if (any_lut) {
+        if (tid < 192) {
 #pragma unroll
-        for (int j = 0; j < AADG_MAX_OPS; ++j)
-            if (j < nops && needs_lds_lut(un.op[j]) && tid < 192)
-                reinterpret_cast<uint32_t*>(sl_all + j * 768)[tid] = lreg[j];
+            for (int j = 0; j < AADG_MAX_OPS; ++j) reinterpret_cast<uint32_t*>(sl_all + j * 768)[tid] = lreg[j];
+        }
         __syncthreads();
     }
     int j0 = 0;                                   // leading pointwise segment [0, j0)
@@ -1284,7 +1307,7 @@ __device__ __forceinline__ void stat_strip_block(const aadg_unit& un, int stage,
     const int r0 = block_wg ? by * 64 + wv * 16 : tby * 16 + wv * 4, r1 = min(Hs, r0 + (block_wg ? 16 : 4));
     const bool live = x0 < Ws;                                   // Ws % 4 == 0: a lane's four pixels are inside together
     const bool edge_l = lane == 0 && x0 > 0, edge_r = live && (lane == 63 || x0 + 4 >= Ws) && x0 + 4 < Ws;
-    const float alpha = un.farg[js];
+    const float alpha = unit_farg(un, js);
     // one source row: the lane's four pixels after ops [0, js), the pixel to their left and to their right
     auto load_row = [&](int y, uint32_t (&p)[4], uint32_t& pl, uint32_t& pr) {
         const uint8_t* rowp = src + ((size_t)y * Ws + x0) * 3;
@@ -1527,7 +1550,6 @@ struct GhRegs { uint32_t a[GH_NR], b[GH_NR], c[GH_NR], wa, wb, wc; };
 // thread <-> (row = wave + 4k, group = lane), the groups beyond 64 (patches wider than 256 pixels: uniform `wide`) by thread
 // t <-> (row t >> 2, group 64 + (t & 3)).  Addresses are clamped into the block: no load is conditional per lane; a uniform base and a
 // 32-bit lane offset per load.  Three dwords per pixel group (typed as one 12-byte vector).
-struct __attribute__((packed, aligned(4))) U32x3 { uint32_t x, y, z; };
 __device__ __forceinline__ void gh_fetch(GhRegs& R, const uint8_t* __restrict__ blk, int row_bytes, int ph, int q4, bool wide) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1950,7 +1972,6 @@ __device__ __forceinline__ void fused3_body(const uint8_t* __restrict__ pool, co
             if (K == 2) store_out4(ol + plane + off, make_float4(1.0f, 1.0f, 1.0f, 1.0f), stream_out);
         }
     };
-    if (fx > lx) { pad_rows(y0, y1); return; }              // no valid column in this tile
     const int* base = tab + (size_t)u * crop * TAB_STRIDE;
     const int* xmin_t = base;
     const int* xk_t = xmin_t + crop;
@@ -1960,16 +1981,34 @@ __device__ __forceinline__ void fused3_body(const uint8_t* __restrict__ pool, co
     const int* ynn_t = xnn_t + crop;
     const bool resx = w != Ws, resy = h != Hs;              // an unchanged axis is not resampled (one tap of weight one)
 
-    // ---- column tables.  Every index is clamped into the table, so no load here is conditional (no control flow, no wait
-    //      between the loads); validity is applied to the values afterwards ----
-    const int t_clo = xmin_t[fx], t_chi = xmin_t[lx];       // scalar loads
+    // ---- every table entry of the tile in ONE batch of loads, in front of the first branch that depends on one.  Every index is clamped
+    //      into the table, so no load is conditional (no control flow, no wait between the loads); validity is applied to the values ----
+    const int ya = y0, yb = y1;
+    const int fy = max(ya, -oy), ly = min(yb - 1, h - 1 - oy);
+    const int cl = crop - 1;
+    const int t_clo = xmin_t[min(max(fx, 0), cl)], t_chi = xmin_t[min(max(lx, 0), cl)];       // scalar loads
+    const int t_rlo = ymin_t[min(max(fy, 0), cl)], t_rhi = ymin_t[min(max(ly, 0), cl)];
+    int vym[RPW], vyn[RPW];
+    uint32_t vk0[RPW], vk1[RPW];
+    // row tables: uniform per wave, but read as VECTOR loads (index from the lane's own id): as scalar loads they came back one by one --
+    // the compiler had no SGPRs left to hold twelve results and put a wait behind each -- five L2 round trips in series per tile
+    const int wvv = tid >> 6;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int yc = min(ya + wvv + 4 * r, yb - 1);
+        vym[r] = ymin_t[yc];
+        vyn[r] = ynn_t[yc];
+        const int2 ky = *reinterpret_cast<const int2*>(yk_t + (size_t)yc * KMAX);
+        vk0[r] = prescale4(ky.x); vk1[r] = prescale4(ky.y);
+    }
     const int xh = x0 + tid;                                // horizontal pass: thread <-> output column
-    const int xhc = min(max(xh, fx), lx);
+    const int xhc = min(max(min(max(xh, fx), lx), 0), cl);
     int hxm = xmin_t[xhc];
     const int2 kk = *reinterpret_cast<const int2*>(xk_t + (size_t)xhc * KMAX);
-    const uint32_t hk0 = prescale4(kk.x), hk1 = prescale4(kk.y);
-    if (xh != xhc) hxm = -1;                                // pad column
     const int4 xn4 = *reinterpret_cast<const int4*>(xnn_t + min(xq, crop - 4));
+    if (fx > lx || fy > ly) { pad_rows(y0, y1); return; }   // no valid column / row in this tile
+    const uint32_t hk0 = prescale4(kk.x), hk1 = prescale4(kk.y);
+    if (xh < fx || xh > lx) hxm = -1;                       // pad column
     const int xn[4] = {xn4.x, xn4.y, xn4.z, xn4.w};
     const uint8_t* msk = masks + (size_t)u_src * Hs * Ws;
     const uint8_t* src = pool + (size_t)u_src * Hs * Ws * 3;
@@ -1978,21 +2017,6 @@ __device__ __forceinline__ void fused3_body(const uint8_t* __restrict__ pool, co
     const char* lutb = reinterpret_cast<const char*>(lutf);
 
     {
-        const int ya = y0, yb = y1;
-        const int fy = max(ya, -oy), ly = min(yb - 1, h - 1 - oy);
-        if (fy > ly) { pad_rows(ya, yb); return; }
-        // ---- row tables (uniform per wave: scalar loads) ----
-        const int t_rlo = ymin_t[fy], t_rhi = ymin_t[ly];
-        int vym[RPW], vyn[RPW];
-        uint32_t vk0[RPW], vk1[RPW];
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const int yc = min(ya + wv + 4 * r, yb - 1);
-            vym[r] = ymin_t[yc];
-            vyn[r] = ynn_t[yc];
-            const int2 ky = *reinterpret_cast<const int2*>(yk_t + (size_t)yc * KMAX);
-            vk0[r] = prescale4(ky.x); vk1[r] = prescale4(ky.y);
-        }
         // ---- patch -> LDS with the op chain applied, then the horizontal pass into the other buffer ----
         const int r_lo = t_rlo;
         const int nty = resy ? 2 : 1, ntx = resx ? 2 : 1;
