@@ -77,23 +77,32 @@ __device__ __forceinline__ bool op_is_lut(int op) {
 // after k ops is the push-forward of the RAW image's histogram through the composed maps: hist_k[c][L_{k-1}(...L_0(v))] += hist_0[c][v].
 // k_lut does that from the stage-0 histogram and the earlier stages' LUTs -- no pixel pass (k_hist_fused) for such a stage.  Fused-flow
 // units only (the staged flow materialises its intermediate images and histograms them directly).  Mirrored by launch_hints() on the host.
+// (the helpers below read op[0..3] / farg[0..3] at CONSTANT indices and select: a run-time index made every call a chain of dependent
+//  scalar loads, each with its own wait, in front of the first pixel load of a workgroup)
+__device__ __forceinline__ int unit_op_sel(const aadg_unit& un, int j) {
+    const int a = un.op[0], b = un.op[1], c = un.op[2], d = un.op[3];
+    return j == 0 ? a : (j == 1 ? b : (j == 2 ? c : d));
+}
 __device__ __forceinline__ bool stats_by_pushforward(const aadg_unit& un, int k, bool fused_flow) {
     if (!fused_flow || k < 1 || k >= un.n_ops) return false;
-    if (un.op[k] != AADG_OP_AUTOCONTRAST && un.op[k] != AADG_OP_EQUALIZE) return false;
-    for (int j = 0; j < k; ++j)
-        if (!op_is_lut(un.op[j])) return false;
-    return true;
+    const int opk = unit_op_sel(un, k);
+    bool all_lut = true;
+#pragma unroll
+    for (int j = 0; j < AADG_MAX_OPS; ++j) all_lut = all_lut && (j >= k || op_is_lut(un.op[j]));
+    return (opk == AADG_OP_AUTOCONTRAST || opk == AADG_OP_EQUALIZE) && all_lut;
 }
 __device__ __forceinline__ bool any_pushforward(const aadg_unit& un, bool fused_flow) {
-    for (int k = 1; k < un.n_ops && k < AADG_MAX_OPS; ++k)
-        if (stats_by_pushforward(un, k, fused_flow)) return true;
-    return false;
+    bool any = false;
+#pragma unroll
+    for (int k = 1; k < AADG_MAX_OPS; ++k) any = any || stats_by_pushforward(un, k, fused_flow);
+    return any;
 }
 
 // does this unit take the fused (LDS-resident) data flow?  Must agree across all kernels of a call.
 __device__ __forceinline__ int sharp_count(const aadg_unit& un, int upto) {
     int s = 0;
-    for (int k = 0; k < upto; ++k) s += (un.op[k] == AADG_OP_SHARPNESS && un.farg[k] != 1.0f) ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < AADG_MAX_OPS; ++k) s += (k < upto && un.op[k] == AADG_OP_SHARPNESS && un.farg[k] != 1.0f) ? 1 : 0;
     return s;
 }
 // number of Sharpness stencils of a unit, all four op slots read unconditionally (independent scalar loads, one wait)
@@ -762,6 +771,7 @@ __global__ __launch_bounds__(256) void k_final(Bufs bufs, const uint8_t* masks, 
 // Pixels within `sharp_count` of a patch edge that is not an image edge are NOT valid afterwards.
 // Returns the buffer (A or B) that holds the result.  Ends with a __syncthreads().
 // ------------------------------------------------------------------------------------------------
+struct __attribute__((packed)) UnalignedU32 { uint32_t v; };
 // three dwords of a pixel group (12 bytes, 4-byte aligned)
 struct __attribute__((packed, aligned(4))) U32x3 { uint32_t x, y, z; };
 __device__ __forceinline__ uint32_t blend3(uint32_t deg, uint32_t img, float alpha, bool interp) {
@@ -1153,16 +1163,28 @@ __device__ __forceinline__ void stat_tile_bounds(int t, int tx, int Hs, int Ws, 
     cx0 = bx * 256; cx1 = min(cx0 + 256, Ws);
 }
 __device__ __forceinline__ void stat_load_tile(StatRegs& r, const uint8_t* __restrict__ src, int Ws, int ry0, int ry1, int cx0, int cx1) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q4 = (cx1 - cx0) >> 2, ph = ry1 - ry0;
+    // addresses clamped into the tile: no load is conditional (what an idle lane fetched is not counted)
+    const uint8_t* blk = src + ((size_t)ry0 * Ws + cx0) * 3;        // uniform
+    const uint32_t goff = 12u * (uint32_t)min(lane, q4 - 1);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int row = wv + 4 * k;
-        r.a[k] = r.b[k] = r.c[k] = 0;
-        if (row < ph && lane < q4) {
-            const uint32_t* p = reinterpret_cast<const uint32_t*>(src + ((size_t)(ry0 + row) * Ws + cx0) * 3 + 12 * lane);
-            r.a[k] = p[0]; r.b[k] = p[1]; r.c[k] = p[2];
-        }
+        const U32x3 v = *reinterpret_cast<const U32x3*>(blk + (size_t)min(wv + 4 * k, ph - 1) * (Ws * 3) + goff);
+        r.a[k] = v.x; r.b[k] = v.y; r.c[k] = v.z;
+    }
+}
+// the byte maps of stages [0, AADG_MAX_OPS) of unit u -> LDS (every stage's slot exists in the workspace: unconditional loads)
+__device__ __forceinline__ void stat_stage_luts(const uint8_t* __restrict__ lut, size_t lut_stage_stride, int u, uint8_t* sl_all) {
+    const int tid = threadIdx.x;
+    const uint32_t* lp = reinterpret_cast<const uint32_t*>(lut + (size_t)u * 768) + min(tid, 191);
+    uint32_t lreg[AADG_MAX_OPS];
+#pragma unroll
+    for (int j = 0; j < AADG_MAX_OPS; ++j) lreg[j] = lp[j * (lut_stage_stride >> 2)];
+    if (tid < 192) {
+#pragma unroll
+        for (int j = 0; j < AADG_MAX_OPS; ++j) reinterpret_cast<uint32_t*>(sl_all + j * 768)[tid] = lreg[j];
     }
 }
 template <int KIND>
@@ -1177,17 +1199,10 @@ __device__ __forceinline__ void stat_stream_unit(const aadg_unit& un, int stage,
     stat_tile_bounds(t, tx, Hs, Ws, ry0, ry1, cx0, cx1);
     StatRegs cur;
     stat_load_tile(cur, src, Ws, ry0, ry1, cx0, cx1);
-    bool any_lut = false;
-#pragma unroll
-    for (int j = 0; j < AADG_MAX_OPS; ++j)
-        if (j < stage && needs_lds_lut(un.op[j])) {
-            any_lut = true;
-            if (tid < 192) reinterpret_cast<uint32_t*>(sl_all + j * 768)[tid] =
-                reinterpret_cast<const uint32_t*>(lut + (size_t)j * lut_stage_stride + (size_t)u * 768)[tid];
-        }
+    stat_stage_luts(lut, lut_stage_stride, u, sl_all);
     if (KIND == ST_EQUALIZE)
         for (int i = tid; i < 768 * HF_COPIES; i += 256) sh[i] = 0;
-    if (any_lut || KIND == ST_EQUALIZE) __syncthreads();
+    __syncthreads();
     StatAcc<KIND> acc(sh);
     while (true) {
         const int tn = t + G;
@@ -1286,17 +1301,10 @@ __device__ __forceinline__ void stat_strip_block(const aadg_unit& un, int stage,
                                                  int stride, int tend) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (!block_wg && t0 >= tend) return;
-    bool any_lut = false;
-#pragma unroll
-    for (int j = 0; j < AADG_MAX_OPS; ++j)
-        if (j < stage && needs_lds_lut(un.op[j])) {
-            any_lut = true;
-            if (tid < 192) reinterpret_cast<uint32_t*>(sl_all + j * 768)[tid] =
-                reinterpret_cast<const uint32_t*>(lut + (size_t)j * lut_stage_stride + (size_t)u * 768)[tid];
-        }
+    stat_stage_luts(lut, lut_stage_stride, u, sl_all);
     if (KIND == ST_EQUALIZE)
         for (int i = tid; i < 768 * HF_COPIES; i += 256) sh[i] = 0;
-    if (any_lut || KIND == ST_EQUALIZE) __syncthreads();
+    __syncthreads();
     StatAcc<KIND> acc(sh);
     const int tx = (Ws + 255) >> 8;
     // a block workgroup: ONE pass, wave <-> 16 rows of the 256 x 64 block; a walker (a caller's list that did not put this unit among the
@@ -1308,16 +1316,22 @@ __device__ __forceinline__ void stat_strip_block(const aadg_unit& un, int stage,
     const bool live = x0 < Ws;                                   // Ws % 4 == 0: a lane's four pixels are inside together
     const bool edge_l = lane == 0 && x0 > 0, edge_r = live && (lane == 63 || x0 + 4 >= Ws) && x0 + 4 < Ws;
     const float alpha = unit_farg(un, js);
-    // one source row: the lane's four pixels after ops [0, js), the pixel to their left and to their right
-    auto load_row = [&](int y, uint32_t (&p)[4], uint32_t& pl, uint32_t& pr) {
-        const uint8_t* rowp = src + ((size_t)y * Ws + x0) * 3;
-        uint32_t a = 0, b = 0, c = 0, el = 0, er = 0;
-        if (live) {
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(rowp);
-            a = q[0]; b = q[1]; c = q[2];
-        }
-        if (edge_l) el = (uint32_t)rowp[-3] | ((uint32_t)rowp[-2] << 8) | ((uint32_t)rowp[-1] << 16);
-        if (edge_r) er = (uint32_t)rowp[12] | ((uint32_t)rowp[13] << 8) | ((uint32_t)rowp[14] << 16);
+    // One source row = three loads per lane: its four pixels (12 bytes) and the dwords that hold the pixel to their left / right (only the
+    // strip's outer lanes use them; the others read a word of their own pixels: no load is conditional).  The rows are fetched FOUR AHEAD
+    // of the walk: a wave that waited for each row before it asked for the next spent 18 memory round trips per 16 rows.
+    struct RowRaw { U32x3 m; uint32_t l, r; };
+    const int x0c = min(x0, Ws - 4);
+    const int loff = edge_l ? -4 : 0, roff = edge_r ? 11 : 8;
+    auto fetch_row = [&](RowRaw& R, int y) {
+        const uint8_t* rowp = src + ((size_t)min(max(y, 0), Hs - 1) * Ws + x0c) * 3;
+        R.m = *reinterpret_cast<const U32x3*>(rowp);
+        R.l = reinterpret_cast<const UnalignedU32*>(rowp + loff)->v;
+        R.r = reinterpret_cast<const UnalignedU32*>(rowp + roff)->v;
+    };
+    // the lane's four pixels after ops [0, js), the pixel to their left and to their right
+    auto decode_row = [&](const RowRaw& R, int y, uint32_t (&p)[4], uint32_t& pl, uint32_t& pr) {
+        const uint32_t a = R.m.x, b = R.m.y, c = R.m.z;
+        uint32_t el = R.l >> 8, er = R.r >> 8;
         p[0] = a & 0xFFFFFFu; p[1] = (a >> 24) | ((b & 0xFFFFu) << 8);
         p[2] = (b >> 16) | ((c & 0xFFu) << 16); p[3] = c >> 8;
         for (int j = 0; j < js; ++j)
@@ -1340,43 +1354,51 @@ __device__ __forceinline__ void stat_strip_block(const aadg_unit& un, int stage,
         }
     };
     if (r0 < r1) {                                               // uniform per wave
-        uint32_t h0rb[4] = {0, 0, 0, 0}, h0g[4] = {0, 0, 0, 0}, h1rb[4], h1g[4], h2rb[4] = {0, 0, 0, 0}, h2g[4] = {0, 0, 0, 0};
-        uint32_t p1[4], p2[4] = {0, 0, 0, 0}, pl, pr;
-        if (r0 > 0) {
-            uint32_t p0[4];
-            load_row(r0 - 1, p0, pl, pr);
-            hsums(p0, pl, pr, h0rb, h0g);
-        }
-        load_row(r0, p1, pl, pr);
-        hsums(p1, pl, pr, h1rb, h1g);
-        for (int y = r0; y < r1; ++y) {
-            if (y + 1 < Hs) {
-                load_row(y + 1, p2, pl, pr);
-                hsums(p2, pl, pr, h2rb, h2g);
+        // events e = 0 .. ne - 1 <-> source rows r0 - 1 + e (rows outside the image: a clamped row whose values the border rule never uses);
+        // event e >= 2 completes the 3 x 3 neighbourhood of row r0 + e - 2
+        const int ne = r1 - r0 + 2;
+        uint32_t h0rb[4] = {0, 0, 0, 0}, h0g[4] = {0, 0, 0, 0}, h1rb[4] = {0, 0, 0, 0}, h1g[4] = {0, 0, 0, 0}, h2rb[4], h2g[4];
+        uint32_t p1[4] = {0, 0, 0, 0}, p2[4], pl, pr;
+        RowRaw buf[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fetch_row(buf[q], r0 - 1 + q);
+        for (int e0 = 0; e0 < ne; e0 += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = e0 + q;
+                if (e < ne) {                                    // uniform
+                    const int yn = r0 - 1 + e;
+                    decode_row(buf[q], yn, p2, pl, pr);
+                    fetch_row(buf[q], yn + 4);
+                    hsums(p2, pl, pr, h2rb, h2g);
+                    if (e >= 2) {
+                        const int y = yn - 1;
+                        uint32_t o[4];
+                        const bool row_in = y > 0 && y < Hs - 1;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int x = x0 + t;
+                            const bool in = row_in && x > 0 && x < Ws - 1;   // ImageFilter.SMOOTH copies the 1-pixel image border
+                            const uint32_t srb = h0rb[t] + h1rb[t] + h2rb[t] + 4u * (p1[t] & 0xFF00FFu), sg = h0g[t] + h1g[t] + h2g[t] + 4u * ((p1[t] >> 8) & 255u);
+                            const uint32_t cr = (uint32_t)__mul24((int)((srb & 0xFFFFu) + 6u), 5042) >> 16, cb = (uint32_t)__mul24((int)((srb >> 16) + 6u), 5042) >> 16,
+                                           cg = (uint32_t)__mul24((int)(sg + 6u), 5042) >> 16;
+                            const uint32_t d = in ? (cr | (cg << 8) | (cb << 16)) : p1[t];
+                            o[t] = blend3(d, p1[t], alpha, true);
+                        }
+                        for (int j = js + 1; j < stage; ++j)
+                            dispatch_op(un, j, sl_all, [&](auto f) {
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) o[t] = f(o[t], y, x0 + t);
+                            });
+                        if (live) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) acc.add(o[t]);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { h0rb[t] = h1rb[t]; h0g[t] = h1g[t]; h1rb[t] = h2rb[t]; h1g[t] = h2g[t]; p1[t] = p2[t]; }
+                }
             }
-            uint32_t o[4];
-            const bool row_in = y > 0 && y < Hs - 1;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int x = x0 + t;
-                const bool in = row_in && x > 0 && x < Ws - 1;   // ImageFilter.SMOOTH copies the 1-pixel image border
-                const uint32_t srb = h0rb[t] + h1rb[t] + h2rb[t] + 4u * (p1[t] & 0xFF00FFu), sg = h0g[t] + h1g[t] + h2g[t] + 4u * ((p1[t] >> 8) & 255u);
-                const uint32_t cr = (uint32_t)__mul24((int)((srb & 0xFFFFu) + 6u), 5042) >> 16, cb = (uint32_t)__mul24((int)((srb >> 16) + 6u), 5042) >> 16,
-                               cg = (uint32_t)__mul24((int)(sg + 6u), 5042) >> 16;
-                const uint32_t d = in ? (cr | (cg << 8) | (cb << 16)) : p1[t];
-                o[t] = blend3(d, p1[t], alpha, true);
-            }
-            for (int j = js + 1; j < stage; ++j)
-                dispatch_op(un, j, sl_all, [&](auto f) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) o[t] = f(o[t], y, x0 + t);
-                });
-            if (live) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc.add(o[t]);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { h0rb[t] = h1rb[t]; h0g[t] = h1g[t]; h1rb[t] = h2rb[t]; h1g[t] = h2g[t]; p1[t] = p2[t]; }
         }
     }
     if (block_wg) break;
@@ -1411,24 +1433,41 @@ __global__ __launch_bounds__(256) void k_hist_fused(const uint8_t* __restrict__ 
     }
     const int u = ulist != nullptr ? ulist[slot] : slot;          // ulist: the units whose op `stage` needs statistics
     const aadg_unit& un = units[u];
-    if (un.n_ops <= stage || !op_needs_stats(un.op[stage]) || !unit_fusable(true, un, Hs, Ws, crop)) return;
-    if (stats_by_pushforward(un, stage, true)) return;            // k_lut derives this stage's histogram from the raw one
+    // the head of the record in ONE batch of scalar loads, every predicate from those registers, one exit
+    const int n_ops = un.n_ops, u_src = un.src, sw = un.scaled_w, shh = un.scaled_h;
+    int ops[AADG_MAX_OPS];
+    bool sten[AADG_MAX_OPS];
+#pragma unroll
+    for (int k = 0; k < AADG_MAX_OPS; ++k) {                    // (no short circuit: farg[k] is loaded whatever op[k] is)
+        ops[k] = un.op[k];
+        const float fk = un.farg[k];
+        sten[k] = (ops[k] == AADG_OP_SHARPNESS) & (fk != 1.0f);
+    }
+    const int op = stage == 0 ? ops[0] : (stage == 1 ? ops[1] : (stage == 2 ? ops[2] : ops[3]));
+    int sc_all = 0, s = 0, js = 0;
+    bool lut_before = true;
+#pragma unroll
+    for (int k = AADG_MAX_OPS - 1; k >= 0; --k) {
+        sc_all += (k < n_ops && sten[k]) ? 1 : 0;
+        s += (k < stage && sten[k]) ? 1 : 0;
+        js = (k < stage && sten[k]) ? k : js;                   // the first stencil's slot
+        lut_before = lut_before && (k >= stage || op_is_lut(ops[k]));
+    }
+    const bool fusable = !(Ws & 3) && !(crop & 3) && sc_all <= MAX_SHARP && 2 * sw >= Ws && 2 * shh >= Hs;      // unit_flow(...) != FLOW_STAGED
+    const bool pushfwd = stage >= 1 && (op == AADG_OP_AUTOCONTRAST || op == AADG_OP_EQUALIZE) && lut_before;      // stats_by_pushforward: k_lut derives it
+    if (n_ops <= stage || !op_needs_stats(op) || !fusable || pushfwd) return;
     __shared__ __attribute__((aligned(16))) uint32_t A[PATCH ? HF_PATCH : 4];
     __shared__ __attribute__((aligned(16))) uint32_t B[PATCH ? HF_PATCH : 4];
     __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
     __shared__ __attribute__((aligned(16))) uint32_t red[32];
     __shared__ __attribute__((aligned(16))) uint32_t shx[768 * HF_COPIES];      // Equalize: accumulates over the workgroup's tiles
-    const int s = sharp_count(un, stage);
-    const uint8_t* src = pool + (size_t)un.src * Hs * Ws * 3;
+    const uint8_t* src = pool + (size_t)u_src * Hs * Ws * 3;
     uint32_t* gh = hist + (size_t)u * HIST_STRIDE;
-    const int op = un.op[stage];
     if (s == 0) {
         if (op == AADG_OP_CONTRAST) stat_stream_unit<ST_CONTRAST>(un, stage, src, Hs, Ws, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride, tend);
         else if (op == AADG_OP_AUTOCONTRAST) stat_stream_unit<ST_AUTOCONTRAST>(un, stage, src, Hs, Ws, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride, tend);
         else stat_stream_unit<ST_EQUALIZE>(un, stage, src, Hs, Ws, lut, lut_stage_stride, u, sl, shx, red, gh, t0, stride, tend);
     } else if (s == 1) {
-        int js = 0;
-        while (!is_stencil(un, js)) ++js;
         if (op == AADG_OP_CONTRAST) stat_strip_block<ST_CONTRAST>(un, stage, js, src, Hs, Ws, bx, by, lut, lut_stage_stride, u, sl, shx, red, gh, block_wg, t0, stride, tend);
         else if (op == AADG_OP_AUTOCONTRAST) stat_strip_block<ST_AUTOCONTRAST>(un, stage, js, src, Hs, Ws, bx, by, lut, lut_stage_stride, u, sl, shx, red, gh, block_wg, t0, stride, tend);
         else stat_strip_block<ST_EQUALIZE>(un, stage, js, src, Hs, Ws, bx, by, lut, lut_stage_stride, u, sl, shx, red, gh, block_wg, t0, stride, tend);
@@ -1737,7 +1776,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHARP ? 4 :
     gen_hpass_pipe<SHARP>(pool, units, order, slot0 + blockIdx.z, blockIdx.x, blockIdx.y, Hs, Ws, crop, tab, lut, lut_stage_stride, hbuf, A, Bs, sl);
 }
 
-struct __attribute__((packed)) UnalignedU32 { uint32_t v; };
 constexpr int GV_ROWS = 16;            // output rows per vertical-pass workgroup: 4 consecutive rows per wave
 constexpr int GV_G = 4;                // rows whose loads are issued together (2: 250 us, 4: 245 us; 8 or 32 rows per workgroup: 267 / 282 us)
 
