@@ -170,6 +170,8 @@ def worker(rank, world, port, out_dir):
     from oracle import oracle as O
     _lib.aug_u8_forward = oracle_materialize          # test-only: CPU checker stands in for the HIP launch
     D, B, M, size, crop = 3, 2, 6, 24, 24             # 18 (domain, policy) units: uneven over 4 ranks (5/5/4/4)
+    if world > D * B:                                  # 8 ranks (3/3/2/2/2/2/2/2 units): the un-augmented images need a row per rank
+        B = 3
     # single-process truth (every rank computes it: shard = whole)
     T.set_row_shard(0, 1)
     full = T.train_dg_collate_fn(build_batch(11, D, B, M, size, crop))

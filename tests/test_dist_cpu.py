@@ -1,4 +1,4 @@
-"""CPU suite, part 5: the N>1 path over gloo, world sizes 2, 3 and 4 (see tests/dist_worker.py)."""
+"""CPU suite, part 5: the N>1 path over gloo, world sizes 2, 3, 4 and 8 (see tests/dist_worker.py)."""
 import os
 import socket
 import subprocess
@@ -16,9 +16,9 @@ def _free_port():
 import pytest
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_unit_sharded_exchange(tmp_path, world):
-    """G = 2 (9/9 units), G = 3 (one source domain per rank), G = 4 (uneven: 5/5/4/4 units) -- SURVEY 8e."""
+    """G = 2 (9/9 units), G = 3 (one source domain per rank), G = 4 (uneven: 5/5/4/4 units), G = 8 (the node of the scaling run: 3/3/2/2/2/2/2/2) -- SURVEY 8e."""
     port = _free_port()
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(tmp_path)],

@@ -18,10 +18,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(tmp_path, gpus, tag, extra=()):
+def _bench(tmp_path, gpus, tag, extra=(), batch=2):
     dump = os.path.join(str(tmp_path), "rewards_%s.json" % tag)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "0", "--size", "64",
-           "--batch", "2", "--backbone", "mobilenet_v2", "--backbone_dtype", "fp32", "--no_cpu_baseline", "--no_dropout",
+           "--batch", str(batch), "--backbone", "mobilenet_v2", "--backbone_dtype", "fp32", "--no_cpu_baseline", "--no_dropout",
            "--dump_rewards", dump] + list(extra)
     if gpus > 1:
         cmd.append("--all_ranks_on_gpu0")
@@ -49,6 +49,17 @@ def test_bench_gpus_flag_launches_the_ranks_and_matches_single_rank(tmp_path):
         assert max(abs(x - y) for x, y in zip(a, b)) < 1e-4, (gpus, law, a, b)           # step 1: the forward pass is the same function
         for a, b in zip(r1["raw"][1:], rg["raw"][1:]):
             assert max(abs(x - y) for x, y in zip(a, b)) < 0.25 * max(abs(x) for x in a), (gpus, law, a, b)
+
+
+def test_bench_eight_ranks_like_the_scaling_run(tmp_path):
+    """The world size of the driver's scaling run (8 ranks: 18 units = 3/3/2/2/2/2/2/2, ragged padded gather) with the HIP kernels, all
+    ranks on the one GPU of the test box: first-step rewards equal the single rank's."""
+    one, r1 = _bench(tmp_path, 1, "g1b3", batch=3)
+    out, rg = _bench(tmp_path, 8, "g8unit", ["--placement", "unit"], batch=3)
+    assert out["n_gpus"] == 8 and out["steps"] == 3 and out["config"]["distributed"]["world_size"] == 8
+    assert "rows per rank 9/9/6/6/6/6/6/6" in out["config"]["parallelism"], out["config"]["parallelism"]
+    a, b = r1["raw"][0], rg["raw"][0]
+    assert max(abs(x - y) for x, y in zip(a, b)) < 1e-4, (a, b)
 
 
 @pytest.mark.parametrize("name,dtype,world", [("mobilenet_v2", "fp32", 3), ("resnet50", "fp32", 2), ("resnet50", "bf16", 3)])
