@@ -66,11 +66,12 @@ bench)
 import json, re
 O = "$O"
 def avg(name):
+    n, tot = 0, 0.0                      # every instantiation of a template kernel (k_hist_fused<false> / <true>)
     for l in open(O + "/bench_rocprofv3_kernel_stats.txt"):
-        if l.startswith(name + " "):
-            p = l.split()
-            return int(p[1]), float(p[2]) / 1e3
-    return 0, 0.0
+        if l.startswith(name + " ") or l.startswith(name + "<"):
+            p = l[len(l.split()[0]):].split()
+            n += int(p[0]); tot += int(p[0]) * float(p[1]) / 1e3
+    return n, (tot / n if n else 0.0)
 stats = {"file": "r04_bench_rocprofv3_kernel_stats.txt",
          "command": "rocprofv3 --kernel-trace --stats -- python bench.py --legs none --steps 10 --warmup 3"}
 nf = avg("k_fused3")[0]
