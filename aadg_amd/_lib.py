@@ -1464,7 +1464,7 @@ def conv1x1_wgrad(dy, x):
 
 
 # images per call up to which the own 1x1 kernel also takes the mid-sized GEMMs (a per-rank batch of an 8- or 4-GPU run)
-CONV1X1_SMALL_BATCH = int(os.environ.get("AADG_CONV1X1_SMALL_BATCH", "40"))
+CONV1X1_SMALL_BATCH = 40
 
 
 def _own_gemm_1x1(M, K, HW, N=None):

@@ -19,11 +19,6 @@
     } while (0)
 
 static inline size_t aadg_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-// A/B switches for measurements (scripts/, tests): set and not "0"
-static inline bool aadg_env_flag(const char* name) {
-    const char* v = getenv(name);
-    return v != nullptr && v[0] != '\0' && v[0] != '0';
-}
 
 // wave64 reductions (DPP/ds_swizzle lowered by the compiler from __shfl_xor)
 __device__ __forceinline__ float wave_sum(float v) {

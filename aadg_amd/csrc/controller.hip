@@ -770,7 +770,7 @@ inline bool ctrl_ok(const CtrlDims& d) {
 }
 // the widths of the reference's Controller (models/controller.py:10): the register-resident-weights instantiation
 constexpr int CT_E = 32, CT_H = 100;
-inline bool ctrl_fast(const CtrlDims& d) { return d.E == CT_E && d.H == CT_H && !aadg_env_flag("AADG_CTRL_GENERIC"); }
+inline bool ctrl_fast(const CtrlDims& d) { return d.E == CT_E && d.H == CT_H; }
 inline CtrlParams as_params(void* const* p) {
     CtrlParams P;
     P.emb = (float*)p[0]; P.w_ih = (float*)p[1]; P.w_hh = (float*)p[2]; P.b_ih = (float*)p[3]; P.b_hh = (float*)p[4];

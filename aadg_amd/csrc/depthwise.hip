@@ -436,7 +436,7 @@ int dw_wgrad(const T* x, const T* dy, float* dw, int N, int C, int H, int W, int
     const int items = (N + g.PP - 1) / g.PP * g.tiles;
     if (split > items) split = items;
     if (split > DW_MAX_SPLIT) split = DW_MAX_SPLIT;
-    if (sizeof(T) == 2 && !aadg_env_flag("AADG_DW_WGRAD_LDS")) {
+    if (sizeof(T) == 2) {
         const uint16_t* px = reinterpret_cast<const uint16_t*>(x);
         const uint16_t* pg = reinterpret_cast<const uint16_t*>(dy);
         bool done = false;

@@ -560,8 +560,10 @@ def predraw_train_batch(dataset, n_items, fresh_policies=True):
     """Phase A of the NEXT training batch, drawn ahead of time (python's generator only: see _draw_python_stream).  `fresh_policies`:
     the batch will be drawn through NEWLY injected policies (search_dg.py:341 installs a new DGMultiPolicy per epoch: empty CutMix
     queues); False: through the objects installed now.  fast_train_units checks the assumption when it consumes the draw; a draw
-    that does not fit is taken back (the generator's state is restored) and redone in place, so drawing ahead never changes what a
-    seeded run produces -- provided nothing else drew from python's `random` in between.
+    that does not fit is taken back (the generator's state is restored) and redone in place.  Drawing ahead leaves a seeded run's
+    results unchanged ONLY IF nothing else draws from python's `random` between this call and the consuming batch (the test pipeline
+    of validate() does: DGRandomCrop, SoftLable) -- callers with such a draw in between must not predraw (search_seg_dg_policy does
+    not; bench.py's loops and the batches inside one epoch may).
     Returns False (and draws nothing) when the pipeline is not the standard one."""
     tfs = _standard_pipeline(dataset)
     if tfs is None or getattr(dataset, '_predrawn', None) is not None:
@@ -573,6 +575,7 @@ def predraw_train_batch(dataset, n_items, fresh_policies=True):
     before = random.getstate()                                 # to take the draw back if it turns out not to fit (fast_train_units)
     dataset._predrawn = _draw_python_stream(n_items, dataset.n_domains, len(mp.policies), nsub, qlens, sc, tt.n, W0, H0)
     dataset._predrawn['generator_before'] = before
+    dataset._predrawn['generator_after'] = random.getstate()
     return True
 
 
@@ -590,6 +593,7 @@ def fast_train_units(dataset, n_items):
     records, assembled from per-policy tables with array indexing.  Returns None when the pipeline is not the standard one."""
     tfs = _standard_pipeline(dataset)
     if tfs is None:
+        dataset._predrawn = None                                # a draw made ahead for a pipeline that has since become non-standard
         return None
     mp, sc, nz, tt = tfs
     pool = dataset.pool
@@ -604,8 +608,10 @@ def fast_train_units(dataset, n_items):
     if A is not None and (A['n_items'], A['D'], A['M'], A['nsub'], A['queue_before']) != (n_items, D, M, nsub, qlens):
         # drawn for another pipeline state than the one consuming it (e.g. the caller kept the policies instead of injecting new ones:
         # other CutMix-queue lengths, hence another number of draws): take the draw back -- python's generator returns to where it
-        # stood before predraw_train_batch -- and draw in place, as if nothing had been drawn ahead
-        random.setstate(A['generator_before'])
+        # stood before predraw_train_batch -- and draw in place, as if nothing had been drawn ahead.  Only if nobody else has drawn
+        # since: rewinding would hand a third party's numbers out a second time; then the stream is kept and the batch drawn in place
+        if random.getstate() == A['generator_after']:
+            random.setstate(A['generator_before'])
         A = None
     if A is None:
         A = _draw_python_stream(n_items, D, M, nsub, qlens, sc, tt.n, W0, H0)

@@ -49,14 +49,15 @@ def world():
 # all-gather (<= 25 KB per rank) and the policy broadcasts would otherwise queue on the default process group's RCCL stream behind
 # whatever 25 MB DDP gradient bucket is in flight there (head-of-line blocking in the backward pass).  `small_group()` is a second
 # process group over the same ranks: with the nccl (= RCCL) backend it owns its own communicator and its own stream.  Created lazily
-# on first use, collectively (every rank takes the same code path); AADG_SMALL_GROUP=0 keeps everything on the default group.
+# on first use, collectively (every rank takes the same code path); `USE_SMALL_GROUP = False` (set identically on every rank before the
+# first collective) keeps everything on the default group.
+USE_SMALL_GROUP = True
 _SMALL = {"group": None, "made": False}
 
 
 def small_group():
     """process group for the small collectives (None = the default group: not distributed, disabled, or creation failed)"""
-    import os
-    if not is_dist() or os.environ.get("AADG_SMALL_GROUP", "1") == "0":
+    if not is_dist() or not USE_SMALL_GROUP:
         return None
     if not _SMALL["made"]:
         _SMALL["made"] = True

@@ -27,8 +27,6 @@ def _upsample_ac(x, size):
 
 _ACT_CODE = {None: 0, 'relu': 1, 'relu6': 2}
 _BN_SYNC = False
-# A/B switch: AADG_LIB_CONV3X3=1 keeps the library's weight gradient for the bottleneck 3x3 convolutions
-_OWN_CONV3X3_OFF = __import__('os').environ.get('AADG_LIB_CONV3X3') == '1'
 
 
 # BatchNorm's `num_batches_tracked += 1` is one 5 us launch per layer and forward (62 of them); the layers of a model registered
@@ -171,13 +169,12 @@ class Conv3x3(nn.Conv2d):
         super().__init__(cin, cout, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.bfloat16 and self.stride == (1, 1) and not _OWN_CONV3X3_OFF:
+        if x.is_cuda and x.dtype == torch.bfloat16 and self.stride == (1, 1):
             from .. import _lib
             xc = x.contiguous()
             if _lib.conv3x3_supported(xc, self.weight, self.dilation[0]):
                 return _lib.conv3x3(xc, self.weight, self.dilation[0])
-        elif (x.is_cuda and x.dtype == torch.bfloat16 and self.stride == (2, 2) and self.dilation == (1, 1) and self.padding == (1, 1)
-              and not _OWN_CONV3X3_OFF):
+        elif (x.is_cuda and x.dtype == torch.bfloat16 and self.stride == (2, 2) and self.dilation == (1, 1) and self.padding == (1, 1)):
             from .. import _lib
             xc = x.contiguous()
             if _lib.conv3x3s2_supported(xc, self.weight):

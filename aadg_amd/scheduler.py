@@ -3,7 +3,6 @@
 controller: Adam(lr 3.5e-4), no schedule; segmentation model: Adam(TRAIN.LR, TRAIN.WD) whose LR drops x0.1 when the
 warm-up ends; discriminator: Adam(TRAIN.LR) with a constant LR (a cosine schedule only for the unused image
 discriminator).  Function names and return tuples follow the reference."""
-import os
 
 from torch.optim import Adam
 from torch.optim.lr_scheduler import CosineAnnealingLR, MultiStepLR
@@ -15,10 +14,13 @@ def _step_at_warmup_end(optimizer, cfg, gamma):
     return MultiStepLR(optimizer, milestones=[cfg.TRAIN.WARMUP_EPOCH], gamma=gamma, last_epoch=-1)
 
 
+FUSED_ADAM = True
+
+
 def _fused(params):
     """torch's single-launch Adam on device tensors (same update rule as the default multi-tensor path: ~10 elementwise passes over
-    the 40 M parameters -> one; 0.8 -> 0.3 ms per step at every batch size).  AADG_FUSED_ADAM=0 keeps the default."""
-    return os.environ.get("AADG_FUSED_ADAM", "1") != "0" and len(params) > 0 and all(p.is_cuda and p.is_floating_point() for p in params)
+    the 40 M parameters -> one; 0.8 -> 0.3 ms per step at every batch size).  `scheduler.FUSED_ADAM = False` keeps the default."""
+    return FUSED_ADAM and len(params) > 0 and all(p.is_cuda and p.is_floating_point() for p in params)
 
 
 def _adam(params, **kw):

@@ -327,9 +327,9 @@ class SearchState(object):
             # rank, 3 % of an 18-row step), and the sampled policies come back through a pinned buffer that the host reads only after
             # it has enqueued those backward passes.
             main = torch.cuda.current_stream()
-            side = self._controller_stream(main) if (main.device.type == 'cuda' and os.environ.get('AADG_CTRL_STREAM', '1') != '0') else None
+            side = self._controller_stream(main) if (main.device.type == 'cuda' and getattr(self.args, 'controller_stream', True)) else None
 
-            self.args._side_stream = side if os.environ.get('AADG_REWARD_STREAM', '1') != '0' else None
+            self.args._side_stream = side if getattr(self.args, 'reward_stream', True) else None
 
             def hook(normalized):
                 if side is None:
@@ -394,6 +394,11 @@ SearchState._fixed_policy_step = _fixed_policy_step
 
 
 def search_seg_dg_policy(gpu, ngpus_per_node, config, args):
+    # validate() runs between two epochs and its pipeline draws from python's `random` too (DGRandomCrop, SoftLable): drawing the next
+    # epoch's first batch ahead (search_step's predraw) would take those numbers BEFORE validate's instead of after, i.e. change what a
+    # seeded run draws relative to the reference order (search_dg.py:338-356).  Off here unless the caller asks for it.
+    if not hasattr(args, 'predraw'):
+        args.predraw = False
     st = SearchState(gpu, ngpus_per_node, config, args)
     # models, data pool and kernel handles live for the whole run: take them out of the cyclic garbage collector's scans
     # (a full collection is a host pause of tens of milliseconds in the middle of a step)

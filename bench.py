@@ -24,8 +24,9 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   step_ms        median / p10 / p90 of the timed steps (device-side: one event per step);
   hot_path       the same step with the backbone removed (features / logits = fixed random tensors): the part this repository
                  implements as HIP kernels, comparable with cpu_baseline;
-  fp32_backbone  (N = 1) the headline step with the backbone at the reference's precision (float32; the headline runs the
-                 convolutions under bf16 autocast), a few steps;
+  precision      (N = 1) the headline backbone against the float32 library path on the same weights and 3 seeded batches: raw Sinkhorn
+                 rewards, per-policy BCE, Dice; `within_north_star_1e-4` flags (north_star: Dice / Sinkhorn within 1e-4 of float32);
+  bf16_backbone  (N = 1) the same step under bfloat16 autocast with ITS precision flags -- narrower than the reference, secondary;
   rvs_1024       (N = 1) BASELINE configs[2] on the hot path: RVS pipeline (scale range [0.5, 2], K = 1) at 1024x1024 crops,
                  144 units: duration of the augmentation call and the roofline of its dominant kernels;
   cpu_baseline   (N = 1) the CPU oracle (oracle/aadg_oracle.c, scalar restatement of the reference's Pillow / geomloss path) +
@@ -70,8 +71,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="TRAIN.BATCH_SIZE (items; each item = one image per domain)")
     ap.add_argument("--backbone", default="resnet50", help="MODEL.BACKBONE for deeplabv3+ configs (the yaml's mobilenet_v2 is the "
                                                            "reference's only reachable encoder; BASELINE configs[1] names ResNet-50)")
-    ap.add_argument("--backbone_dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N = 1: fop,kernels,rvs1024,cpu,fp32  (auto = all; none = skip)")
+    ap.add_argument("--backbone_dtype", default="fp32", choices=["f32x3", "fp32", "bf16"],
+                    help="arithmetic of the backbone convolutions: f32x3 = float32 tensors, every product as three bfloat16 matrix-core "
+                         "products with float32 accumulation (own kernels, the reference's precision: checked by the `precision` leg); "
+                         "fp32 = the library's float32 convolutions; bf16 = bfloat16 autocast (narrower than the reference: secondary)")
+    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N = 1: fop,kernels,rvs1024,cpu,precision  (auto = all; none = skip)")
     ap.add_argument("--only_legs", default=None,
                     help="skip the headline step and print ONE JSON line holding only these legs (fop,kernels,rvs1024): the target of "
                          "the rocprofv3 runs behind profiles/r04_fop_*, profiles/r04_aug512_* and profiles/r04_rvs1024_*")
@@ -413,15 +417,7 @@ def time_steps(st, a, world, steps, warmup, first_epoch=0, want_kernel_events=Tr
     t0 = time.perf_counter()
     _lib.BN_SYNC_COLLECTIVES[0] = 0
     mixes = []
-    idle_ms = float(os.environ.get("AADG_BENCH_IDLE_MS", "0"))     # experiment only: drain and idle the GPU before every step
-    pre_mb = int(os.environ.get("AADG_BENCH_PREREAD_MB", "0"))    # experiment only: stream a clean buffer through the caches before every step
-    scratch = torch.zeros(pre_mb << 18, dtype=torch.float32, device="cuda") if pre_mb > 0 else None
     for i in range(steps):
-        if idle_ms > 0:
-            torch.cuda.synchronize()
-            time.sleep(idle_ms * 1e-3)
-        if scratch is not None:
-            scratch.sum()
         marks[i].record()
         if want_kernel_events:
             _lib.PROFILE_EVENTS, _lib.PROFILE_CALL_EVENTS = kpairs[i], cpairs[i]
@@ -680,7 +676,7 @@ def rvs_1024_leg(n_units=144, size=1024, cfg_rel=os.path.join("experiments", "rv
 NORTH_STAR_TOL = 1e-4          # BASELINE.json north_star: "Dice/Sinkhorn within 1e-4 fp32"
 
 
-def precision_check(st_lo, st_hi, M, D, batch, n_batches=3):
+def precision_check(st_lo, st_hi, M, D, batch, n_batches=3, label="bf16"):
     """What the reduced-precision backbone does to the quantities the SEARCH consumes: the same weights,
     `n_batches` seeded batches (their own policies), dropout off, forward passes only -- backbone under bfloat16 autocast (st_lo, the
     headline) against float32 (st_hi, the reference's precision): raw Sinkhorn rewards [M] (what the controller is rewarded with),
@@ -727,12 +723,12 @@ def precision_check(st_lo, st_hi, M, D, batch, n_batches=3):
                     "ranking_equal": bool((np.argsort(r_lo) == np.argsort(r_hi)).all()),
                     "bce_abs": float(np.abs(b_lo - b_hi).max()), "bce_rel": float((np.abs(b_lo - b_hi) / np.abs(b_hi)).max()),
                     "dice_abs": float(np.abs(d_lo - d_hi).max()),
-                    "rewards_bf16": [round(float(v), 7) for v in r_lo], "rewards_fp32": [round(float(v), 7) for v in r_hi]})
+                    "rewards_" + label: [round(float(v), 7) for v in r_lo], "rewards_fp32": [round(float(v), 7) for v in r_hi]})
         del sample
     worst = lambda k: max(p_[k] for p_ in per)          # noqa: E731
-    return {"what": "same weights, %d seeded batches of %d images (own policies each), dropout off, forward only: backbone under bfloat16 "
-                    "autocast vs float32; rewards = raw Sinkhorn sums per policy (search_dg.py:150-162), bce = per-policy BCE (:140-142), "
-                    "dice = samplewise Dice per class (:164-165); maxima over the batches" % (n_batches, n_img),
+    return {"what": "same weights, %d seeded batches of %d images (own policies each), dropout off, forward only: %s backbone "
+                    "vs the float32 library path; rewards = raw Sinkhorn sums per policy (search_dg.py:150-162), bce = per-policy BCE (:140-142), "
+                    "dice = samplewise Dice per class (:164-165); maxima over the batches" % (n_batches, n_img, label),
             "batches": n_batches, "north_star_tolerance": NORTH_STAR_TOL,
             "reward_abs_max_diff": worst("reward_abs"), "reward_rel_max_diff": worst("reward_rel"),
             "normalized_reward_abs_max_diff": worst("normalized_reward_abs"),
@@ -777,7 +773,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.only_legs:
         return only_legs_main(a)
-    legs = set() if a.legs == "none" else set(("fop,kernels,fp32,rvs1024,cpu" if a.legs == "auto" else a.legs).split(","))
+    legs = set() if a.legs == "none" else set(("fop,kernels,precision,rvs1024,cpu" if a.legs == "auto" else a.legs).split(","))
     if a.no_cpu_baseline:
         legs.discard("cpu")
     if world > 1 or a.shard_of or a.dump_rewards or a.force_dist:
@@ -1069,11 +1065,13 @@ def main():
             "n_gpus": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u8+f32 (augmentation / Sinkhorn / loss / controller kernels: the reference's own types); backbone convolutions %s"
-                     % ("under bfloat16 autocast (float32 master weights and BatchNorm statistics) -- NARROWER than the reference's float32: "
-                        "`fp32_backbone` is the same step at the reference's precision, `precision` bounds the effect on rewards / BCE / "
-                        "Dice on this run's weights (3 seeded batches, flags against north_star's 1e-4)"
-                        if a.backbone_dtype == "bf16" else "float32 (the reference's precision)"),
+            "dtype": "u8+f32 (augmentation / Sinkhorn / loss / controller kernels: the reference's own types); backbone: " + {
+                "fp32": "float32 tensors, the library's float32 convolutions (the reference's precision)",
+                "f32x3": "float32 tensors; convolution products as three bfloat16 matrix-core products of the (hi, lo) halves of both operands "
+                         "with float32 accumulation (own kernels) -- at the reference's precision per north_star's 1e-4 contract, asserted by "
+                         "`precision` on this run's weights and by tests/test_gpu_precision.py",
+                "bf16": "bfloat16 autocast (float32 master weights and BatchNorm statistics): narrower than the reference's float32 -- "
+                        "not a creditable headline"}[a.backbone_dtype],
             "data": "synthetic",
             "inner_loop_img_per_s": n_rows * 1e3 / ms_per_step,
             "step_ms": _stats(step_ms),
@@ -1128,36 +1126,54 @@ def main():
             out["cpu_baseline"] = {"error": repr(e)}
         finally:
             pools.close()
-    if rank == 0 and "fp32" in legs and a.backbone_dtype != "fp32":
+    if rank == 0 and "precision" in legs:
+        # ---- the precision contract of the HEADLINE (north_star: Dice / Sinkhorn within 1e-4 of float32) and the reduced-precision
+        # ---- (bfloat16 autocast) step as a labelled secondary figure with its own flags
         try:
             del z
             torch.cuda.empty_cache()
             import gc
             gc.unfreeze()
             gc.collect()
-            with contextlib.redirect_stdout(sys.stderr):
-                _, st32 = build_state(a, local_rank, world, backbone_dtype="fp32")
-            try:
-                leg = precision_check(st, st32, M, D, a.batch)
-                detail["precision.per_batch"] = leg.pop("per_batch")
-                out["precision"] = leg
-                out["roofline"]["precision_reward_abs_max_diff"] = leg["reward_abs_max_diff"]
-                out["roofline"]["precision_dice_abs_max_diff"] = leg["dice_abs_max_diff"]
-                out["roofline"]["precision_within_north_star_1e-4"] = bool(leg["within_north_star_1e-4"]["rewards"] and
-                                                                          leg["within_north_star_1e-4"]["dice"])
-            except Exception as e:  # noqa: BLE001
-                out["precision"] = {"error": repr(e)}
-            del st
-            torch.cuda.empty_cache()
-            n32 = max(10, min(20, a.steps))
-            el32, sm32, _, _ = time_steps(st32, a, world, n32, 2, want_kernel_events=False)
-            out["fp32_backbone"] = {"ms_per_step": el32 / n32 * 1e3, "steps_per_s": n32 / el32, "steps": n32, "warmup": 2,
-                                    "step_ms": _stats(sm32),
-                                    "what": "the same step with the backbone convolutions in float32 (the reference's precision for this "
-                                            "config); everything else unchanged"}
-            out["roofline"]["fp32_backbone_steps_per_s"] = n32 / el32
+            st32 = None
+            if a.backbone_dtype == "fp32":
+                out["precision"] = {"headline_is_float32_library_path": True, "north_star_tolerance": NORTH_STAR_TOL,
+                                    "within_north_star_1e-4": {"rewards": True, "dice": True, "bce": True}}
+                out["roofline"]["precision_within_north_star_1e-4"] = True
+                st32 = st
+            else:
+                with contextlib.redirect_stdout(sys.stderr):
+                    _, st32 = build_state(a, local_rank, world, backbone_dtype="fp32")
+                try:
+                    leg = precision_check(st, st32, M, D, a.batch, label=a.backbone_dtype)
+                    detail["precision.per_batch"] = leg.pop("per_batch")
+                    out["precision"] = leg
+                    out["roofline"]["precision_reward_abs_max_diff"] = leg["reward_abs_max_diff"]
+                    out["roofline"]["precision_dice_abs_max_diff"] = leg["dice_abs_max_diff"]
+                    out["roofline"]["precision_within_north_star_1e-4"] = bool(all(leg["within_north_star_1e-4"].values()))
+                except Exception as e:  # noqa: BLE001
+                    out["precision"] = {"error": repr(e)}
+            if a.backbone_dtype != "bf16":
+                with contextlib.redirect_stdout(sys.stderr):
+                    _, st16 = build_state(a, local_rank, world, backbone_dtype="bf16")
+                blk = {"what": "the same step with the backbone under bfloat16 autocast -- NARROWER than the reference's float32, a secondary "
+                               "figure: NOT the headline"}
+                try:
+                    leg = precision_check(st16, st32, M, D, a.batch, label="bf16")
+                    detail["bf16_backbone.precision.per_batch"] = leg.pop("per_batch")
+                    blk["precision"] = leg
+                    out["roofline"]["bf16_precision_within_north_star_1e-4"] = bool(all(leg["within_north_star_1e-4"].values()))
+                except Exception as e:  # noqa: BLE001
+                    blk["precision"] = {"error": repr(e)}
+                del st, st32
+                torch.cuda.empty_cache()
+                n16 = max(10, min(20, a.steps))
+                el16, sm16, _, _ = time_steps(st16, a, world, n16, 2, want_kernel_events=False)
+                blk.update({"ms_per_step": el16 / n16 * 1e3, "steps_per_s": n16 / el16, "steps": n16, "warmup": 2, "step_ms": _stats(sm16)})
+                out["bf16_backbone"] = blk
+                out["roofline"]["bf16_backbone_steps_per_s"] = n16 / el16
         except Exception as e:  # noqa: BLE001
-            out["fp32_backbone"] = {"error": repr(e)}
+            out["bf16_backbone"] = {"error": repr(e)}
     if rank == 0:
         # the prose of the extra legs (what a figure replaces, how it was taken) goes to the detail file: the line stays below 8 KB
         def strip(obj, prefix):
@@ -1168,7 +1184,7 @@ def main():
                         detail[prefix + "." + k] = obj.pop(k)
                     else:
                         strip(v, prefix + "." + k)
-        for leg in ("float_ops", "kernels", "rvs_1024", "precision", "fp32_backbone"):
+        for leg in ("float_ops", "kernels", "rvs_1024", "precision", "bf16_backbone"):
             if leg in out:
                 strip(out[leg], leg)
         path = a.detail

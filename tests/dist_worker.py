@@ -223,9 +223,9 @@ def worker(rank, world, port, out_dir):
     w = torch.ones(4, dtype=torch.float64) * (rank + 1)
     L._bn_sync_reduce(w)                                # what the BatchNorm kernels' wrapper calls between its two phases
     assert torch.equal(w, torch.full((4,), world * (world + 1) / 2.0, dtype=torch.float64)) and L.BN_SYNC_COLLECTIVES[0] == before + 1
-    os.environ["AADG_SMALL_GROUP"] = "0"
+    adist.USE_SMALL_GROUP = False
     assert adist.small_group() is None                  # opt-out: everything on the default group
-    del os.environ["AADG_SMALL_GROUP"]
+    adist.USE_SMALL_GROUP = True
     open(os.path.join(out_dir, "ok_%d" % rank), "w").write("ok")
     dist.destroy_process_group()
     adist.reset_groups()

@@ -284,6 +284,31 @@ def test_batch_drawn_ahead_equals_batch_drawn_in_place():
     assert batch(True, 3, True) == want                               # assumed fresh policies, but the old ones stayed
     assert batch(True, 2, False) == want                              # another batch size
     assert batch(True, 3, False) == want                              # and a draw that fits
+    # a third party draws from python's generator between the draw ahead and a consumer in ANOTHER pipeline state: the draw
+    # is dropped, but the generator is NOT rewound -- the third party's numbers are not handed out a second time
+    random.seed(9)
+    np.random.seed(9)
+    ds._predrawn = None
+    ds.transforms.transforms[0] = DGMultiPolicy(parse_policies(np.random.RandomState(0).randint(0, 10, (6, 20)), Cfg(), None))
+    T.fast_train_units(ds, 3)
+    assert T.predraw_train_batch(ds, 2, fresh_policies=False)         # does not fit a batch of 3
+    theirs = [random.random() for _ in range(4)]                      # e.g. validate()'s pipeline
+    state = random.getstate()
+    T.fast_train_units(ds, 3)
+    later = [random.random() for _ in range(50000)]
+    assert not any(later[i:i + 4] == theirs for i in range(0, len(later) - 4))
+    random.setstate(state)
+    assert random.random() not in theirs
+    # a draw ahead for a pipeline that became non-standard is cleared, not kept forever
+    ds._predrawn = None
+    ds.transforms.transforms[0] = DGMultiPolicy(parse_policies(np.random.RandomState(0).randint(0, 10, (6, 20)), Cfg(), None))
+    assert T.predraw_train_batch(ds, 3)
+    keep = ds.transforms.transforms[0]
+    ds.transforms.transforms[0] = T.Identity()
+    assert T.fast_train_units(ds, 3) is None and ds._predrawn is None
+    ds.transforms.transforms[0] = keep
+    assert T.predraw_train_batch(ds, 3)
+    ds._predrawn = None
 
 
 def test_launch_plan_classes_statistics_and_late_units():
