@@ -56,6 +56,8 @@ EXPORTS = [
     "aadg_upsample_sum_backward_all_supported", "aadg_upsample_sum_backward_all",
     "aadg_upsample_sum", "aadg_upsample_sum_backward",
     "aadg_weight_layouts_bf16",
+    "aadg_weight_layouts_split_bf16", "aadg_conv1x1_nchw_f32x3", "aadg_conv1x1_wgrad_f32x3", "aadg_conv3x3_nchw_f32x3",
+    "aadg_conv3x3_wgrad_f32x3",
 ]
 
 _lib = None
@@ -236,7 +238,17 @@ def load():
     lib.aadg_upsample_sum_backward_all.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.aadg_embed_prologue_norm_f32.restype = _i
     lib.aadg_embed_prologue_norm_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]
-    if lib.aadg_abi_version() != 7:
+    lib.aadg_weight_layouts_split_bf16.restype = _i
+    lib.aadg_weight_layouts_split_bf16.argtypes = [_vp, _vp, _i, _vp]
+    lib.aadg_conv1x1_nchw_f32x3.restype = _i
+    lib.aadg_conv1x1_nchw_f32x3.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
+    lib.aadg_conv1x1_wgrad_f32x3.restype = _i
+    lib.aadg_conv1x1_wgrad_f32x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp]
+    lib.aadg_conv3x3_nchw_f32x3.restype = _i
+    lib.aadg_conv3x3_nchw_f32x3.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
+    lib.aadg_conv3x3_wgrad_f32x3.restype = _i
+    lib.aadg_conv3x3_wgrad_f32x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
+    if lib.aadg_abi_version() != 8:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -1547,7 +1559,7 @@ class WlItem(ctypes.Structure):
 # autograd function keeps for its backward is a `_ShadowRef`: the buffers stay valid until the owner's NEXT refresh overwrites them
 # (`generation`), whatever optimizer steps happen in between.
 class _Shadow(object):
-    __slots__ = ("owner", "plain", "fwd", "bwd", "ptr", "flip")
+    __slots__ = ("owner", "plain", "fwd", "bwd", "ptr", "flip", "split")
 
 
 def _shadow_of(weight):
@@ -1559,16 +1571,33 @@ def _shadow_of(weight):
 
 def cast_weight(weight, dtype):
     e = _shadow_of(weight) if dtype == torch.bfloat16 else None
-    return e.plain if e is not None else weight.to(dtype)
+    return e.plain if (e is not None and not e.split) else weight.to(dtype)
 
 
 def weight_layout(weight, which):
     """The tracked bfloat16 copy of `weight` [Co, Ci, kh, kw] in layout 'fwd' ([taps, Co, Ci]) or 'bwd' ([taps, Ci, Co]; taps mirrored
     for a stride-1 3x3 convolution), or None when the weight is not tracked or the call is not inside its model's forward."""
     e = _shadow_of(weight)
-    if e is None:
+    if e is None or e.split:
         return None
     return e.fwd if which == "fwd" else e.bwd
+
+
+def split_weight(w):
+    """float32 tensor -> [2, ...] bfloat16: hi = bf16(w), lo = bf16(w - hi) -- the per-call form of aadg_weight_layouts_split_bf16
+    for a weight that is not tracked"""
+    hi = w.to(torch.bfloat16)
+    return torch.stack([hi, (w - hi.float()).to(torch.bfloat16)]).contiguous()
+
+
+def split_layout(weight, which):
+    """The tracked (hi, lo) bfloat16 halves of the float32 `weight` [Co, Ci, kh, kw] for the f32x3 kernels -- 'plain' [2, Co, Ci, kh, kw],
+    'fwd' [2, taps, Co, Ci] or 'bwd' [2, taps, Ci, Co] (taps mirrored for a stride-1 3x3) -- or None when the weight is not tracked in
+    split mode / the call is not inside its model's forward."""
+    e = _shadow_of(weight)
+    if e is None or not e.split:
+        return None
+    return {"plain": e.plain, "fwd": e.fwd, "bwd": e.bwd}[which]
 
 
 class _ShadowRef(object):
@@ -1579,10 +1608,10 @@ class _ShadowRef(object):
     computing with the newer weights.  `get()` returns None only for an untracked weight (the caller builds the layout itself)."""
     __slots__ = ("entry", "tensor", "generation")
 
-    def __init__(self, weight, which):
+    def __init__(self, weight, which, split=False):
         e = _shadow_of(weight)
         self.entry, self.tensor, self.generation = None, None, -1
-        if e is not None:
+        if e is not None and e.split == split:
             self.entry, self.tensor, self.generation = e, (e.fwd if which == "fwd" else e.bwd), e.owner.generation
 
     def get(self):
@@ -1599,8 +1628,9 @@ class _ShadowRef(object):
 class _WeightLayouts(object):
     """All tracked weights of one model: shadows, the device item / tile tables of aadg_weight_layouts_bf16, one launch per refresh."""
 
-    def __init__(self, entries):
+    def __init__(self, entries, split=False):
         self.entries = entries              # [(weight, flip)]
+        self.split = bool(split)            # (hi, lo) halves for the f32x3 kernels instead of one bfloat16 cast
         self.items = self.tiles = None
         self.n_tiles = 0
         self.generation = 0                 # refreshes so far: what a _ShadowRef compares
@@ -1613,10 +1643,11 @@ class _WeightLayouts(object):
         for i, (w, flip) in enumerate(self.entries):
             Co, Ci, taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
             e = _Shadow()
-            e.owner, e.ptr, e.flip = self, w.data_ptr(), flip
-            e.plain = torch.empty(w.shape, dtype=torch.bfloat16, device=dev)
-            e.fwd = torch.empty((taps, Co, Ci), dtype=torch.bfloat16, device=dev) if taps > 1 else e.plain.view(1, Co, Ci)
-            e.bwd = torch.empty((taps, Ci, Co), dtype=torch.bfloat16, device=dev)
+            e.owner, e.ptr, e.flip, e.split = self, w.data_ptr(), flip, self.split
+            lead = (2,) if self.split else ()          # split: the hi plane, then the lo plane
+            e.plain = torch.empty(lead + tuple(w.shape), dtype=torch.bfloat16, device=dev)
+            e.fwd = torch.empty(lead + (taps, Co, Ci), dtype=torch.bfloat16, device=dev) if taps > 1 else e.plain.view(lead + (1, Co, Ci))
+            e.bwd = torch.empty(lead + (taps, Ci, Co), dtype=torch.bfloat16, device=dev)
             w._aadg_shadow = e
             items[i] = WlItem(w.data_ptr(), e.plain.data_ptr(), e.fwd.data_ptr() if taps > 1 else None, e.bwd.data_ptr(), Co, Ci, taps, flip)
             tiles += [(i, o0, c0) for o0 in range(0, Co, 32) for c0 in range(0, Ci, 256 if taps == 1 else 32)]
@@ -1636,8 +1667,8 @@ class _WeightLayouts(object):
                     break
         if stale:
             self._build()
-        _check(load().aadg_weight_layouts_bf16(self.items.data_ptr(), self.tiles.data_ptr(), self.n_tiles, _stream()),
-               "aadg_weight_layouts_bf16")
+        fn = load().aadg_weight_layouts_split_bf16 if self.split else load().aadg_weight_layouts_bf16
+        _check(fn(self.items.data_ptr(), self.tiles.data_ptr(), self.n_tiles, _stream()), "aadg_weight_layouts_bf16")
         self.generation += 1
         self.active = True
 
@@ -1645,10 +1676,13 @@ class _WeightLayouts(object):
         self.active = False
 
 
-def track_bf16_weights(model, module_types):
+def track_bf16_weights(model, module_types, split=False):
     """Registers the float32 weights of `model`'s modules of the given types (1x1 / 3x3 convolutions: weight [Co, Ci, k, k], k*k <= 9)
     for the batched bfloat16 casts / re-layouts (CUDA models only).  A 3x3 module with stride 1 gets the mirrored-tap 'bwd' layout
-    (its input gradient is the forward kernel on dY), any other the plain transposed one."""
+    (its input gradient is the forward kernel on dY), any other the plain transposed one.  split = True: the layouts are the
+    (hi, lo) bfloat16 halves the f32x3 kernels read (float32 activations, float32-grade products)."""
+    if getattr(model, "_aadg_weight_layouts", None) is not None:
+        raise AadgError("track_bf16_weights: this model's weights are tracked already")
     entries = []
     for m in model.modules():
         if isinstance(m, module_types) and m.weight.dtype == torch.float32 and m.weight.is_cuda and m.weight.dim() == 4 and \
@@ -1656,7 +1690,7 @@ def track_bf16_weights(model, module_types):
             stride = m.stride[0] if isinstance(m.stride, (tuple, list)) else m.stride
             entries.append((m.weight, 1 if (m.weight.shape[2] == 3 and stride == 1) else 0))
     if entries:
-        wl = _WeightLayouts(entries)
+        wl = _WeightLayouts(entries, split=split)
         model.register_forward_pre_hook(lambda mod, args: wl.refresh())
         model.register_forward_hook(lambda mod, args, out: wl.close(), always_call=True)
         model._aadg_weight_layouts = wl
@@ -1861,6 +1895,159 @@ def conv3x3(x, weight, dilation=1):
     if not conv3x3_supported(x, weight, dilation):
         raise AadgError("conv3x3: unsupported shape / dtype / layout")
     return _Conv3x3.apply(x, weight, int(dilation))
+
+
+# ------------------------------------------------------------------------------------------------
+# "f32x3": the backbone convolutions on float32 tensors at float32 precision (the reference's: search_dg.py:123-206 runs the model in
+# float32).  gfx950 has no tf32 and a float32 MFMA at 1/16 of the bfloat16 rate; every operand is split into bfloat16 halves
+# x = hi + lo and every product formed as hi*hi + hi*lo + lo*hi on the bfloat16 matrix cores with float32 accumulation (csrc/common.h:
+# aadg_split4; the X3 instantiations of the convolution kernels).  Activations are split inside the kernels while they are staged in
+# LDS; the weights come pre-split from the tracked shadows (track_bf16_weights(..., split=True)) or, untracked, from split_weight().
+def conv1x1_nchw_x3(a2, x):
+    """out [N, M, H, W] float32 = a [M, K] applied to the channels of x [N, K, H, W] float32; a2 [2, M, K] bfloat16 = (hi, lo) of a"""
+    _require_cuda(a2, x)
+    N, K, H, W = x.shape
+    M = a2.shape[1]
+    if (a2.dtype != torch.bfloat16 or x.dtype != torch.float32 or a2.dim() != 3 or a2.shape[0] != 2 or a2.shape[2] != K or
+            not (a2.is_contiguous() and x.is_contiguous()) or not load().aadg_conv1x1_nchw_supported(M, K, H * W)):
+        raise AadgError("conv1x1_nchw_x3: unsupported shape / dtype / layout")
+    out = torch.empty((N, M, H, W), dtype=torch.float32, device=x.device)
+    _check(load().aadg_conv1x1_nchw_f32x3(a2[0].data_ptr(), a2[1].data_ptr(), x.data_ptr(), out.data_ptr(), N, M, K, H * W, _stream()),
+           "aadg_conv1x1_nchw_f32x3")
+    return out
+
+
+def conv1x1_wgrad_x3(dy, x):
+    """dW [Co, Ci] float32 of a 1x1 / stride-1 convolution from NCHW float32 dy [N,Co,H,W] and x [N,Ci,H,W]"""
+    _require_cuda(dy, x)
+    if dy.dtype != torch.float32 or x.dtype != torch.float32 or not (dy.is_contiguous() and x.is_contiguous()):
+        raise AadgError("conv1x1_wgrad_x3: expected contiguous NCHW float32 tensors")
+    N, Co, H, W = dy.shape
+    Ci = x.shape[1]
+    if x.shape[0] != N or x.shape[2:] != dy.shape[2:]:
+        raise AadgError("conv1x1_wgrad_x3: shape mismatch")
+    dw = torch.empty((Co, Ci), dtype=torch.float32, device=x.device)
+    _check(load().aadg_conv1x1_wgrad_f32x3(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, Co, Ci, H * W, _stream()), "aadg_conv1x1_wgrad_f32x3")
+    return dw
+
+
+class _Conv1x1X3(torch.autograd.Function):
+    """1x1 / stride-1 convolution without bias on NCHW float32 activations at float32 precision: forward, input gradient
+    (csrc/conv1x1_fwd.hip, X3) and weight gradient (csrc/conv1x1_wgrad.hip, X3).  `weight` is the float32 parameter."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        Co, Ci = weight.shape[0], weight.shape[1]
+        a2 = split_layout(weight, "plain")
+        a2 = a2.view(2, Co, Ci) if a2 is not None else split_weight(weight.detach().reshape(Co, Ci))
+        ctx.save_for_backward(x, weight)
+        ctx.wt = _ShadowRef(weight, "bwd", split=True)          # [2, 1, Ci, Co] of the tracked shadow (this step's weights)
+        return conv1x1_nchw_x3(a2, x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        Co, Ci = weight.shape[0], weight.shape[1]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = ctx.wt.get()
+            at = wt.view(2, Ci, Co) if wt is not None else split_weight(weight.detach().reshape(Co, Ci).t().contiguous())
+            dx = conv1x1_nchw_x3(at, dy)
+        if ctx.needs_input_grad[1]:
+            dw = conv1x1_wgrad_x3(dy, x).view(weight.shape)
+        return dx, dw
+
+
+def conv1x1_x3_supported(x, weight):
+    HW = x.shape[2] * x.shape[3] if x.dim() == 4 else 0
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous() and weight.dtype == torch.float32 and
+            weight.dim() == 4 and weight.shape[2] == 1 and weight.shape[3] == 1 and HW % 32 == 0 and weight.shape[0] % 8 == 0 and
+            bool(load().aadg_conv1x1_nchw_supported(weight.shape[0], weight.shape[1], HW)))
+
+
+def conv1x1_x3(x, weight):
+    _require_cuda(x, weight)
+    if not conv1x1_x3_supported(x, weight):
+        raise AadgError("conv1x1_x3: unsupported shape / dtype / layout")
+    return _Conv1x1X3.apply(x, weight)
+
+
+def conv3x3_nchw_x3(a9, x, dilation=1):
+    """out [N, M, H, W] float32 = 3x3 convolution (stride 1, padding = dilation) of x [N, K, H, W] float32; a9 [2, 9, M, K] bfloat16 =
+    (hi, lo) of the tap-major weights"""
+    _require_cuda(a9, x)
+    if a9.dtype != torch.bfloat16 or x.dtype != torch.float32 or not (a9.is_contiguous() and x.is_contiguous()) or a9.dim() != 4:
+        raise AadgError("conv3x3_nchw_x3: expected contiguous bfloat16 a9 [2,9,M,K] and NCHW float32 x")
+    N, K, H, W = x.shape
+    M = a9.shape[2]
+    if a9.shape[0] != 2 or a9.shape[1] != 9 or a9.shape[3] != K:
+        raise AadgError("conv3x3_nchw_x3: shape mismatch")
+    out = torch.empty((N, M, H, W), dtype=torch.float32, device=x.device)
+    _check(load().aadg_conv3x3_nchw_f32x3(a9[0].data_ptr(), a9[1].data_ptr(), x.data_ptr(), out.data_ptr(), N, M, K, H, W, int(dilation),
+                                          _stream()), "aadg_conv3x3_nchw_f32x3")
+    return out
+
+
+def conv3x3_wgrad_x3(dy, x, dilation=1):
+    """dW [Co, Ci, 3, 3] float32 of a 3x3 / stride-1 / padding = dilation convolution from NCHW float32 dy, x"""
+    _require_cuda(dy, x)
+    if dy.dtype != torch.float32 or x.dtype != torch.float32 or not (dy.is_contiguous() and x.is_contiguous()):
+        raise AadgError("conv3x3_wgrad_x3: expected contiguous NCHW float32 tensors")
+    N, Co, H, W = dy.shape
+    Ci = x.shape[1]
+    if x.shape[0] != N or x.shape[2:] != dy.shape[2:]:
+        raise AadgError("conv3x3_wgrad_x3: shape mismatch")
+    dw9 = torch.empty((9, Co, Ci), dtype=torch.float32, device=x.device)
+    _check(load().aadg_conv3x3_wgrad_f32x3(dy.data_ptr(), x.data_ptr(), dw9.data_ptr(), N, Co, Ci, H, W, int(dilation), _stream()),
+           "aadg_conv3x3_wgrad_f32x3")
+    return dw9.permute(1, 2, 0).reshape(Co, Ci, 3, 3)
+
+
+class _Conv3x3X3(torch.autograd.Function):
+    """3x3 / stride-1 / padding = dilation convolution without bias on NCHW float32 activations at float32 precision
+    (csrc/conv3x3_fwd.hip and csrc/conv3x3_wgrad.hip, X3).  `weight` is the float32 parameter."""
+
+    @staticmethod
+    def forward(ctx, x, weight, dilation):
+        Co, Ci = weight.shape[0], weight.shape[1]
+        a9 = split_layout(weight, "fwd")
+        if a9 is None:
+            a9 = split_weight(weight.detach().permute(2, 3, 0, 1).reshape(9, Co, Ci).contiguous())
+        ctx.save_for_backward(x, weight)
+        ctx.a9t = _ShadowRef(weight, "bwd", split=True)
+        ctx.dilation = dilation
+        return conv3x3_nchw_x3(a9, x, dilation)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        d = ctx.dilation
+        dy = dy.contiguous()
+        Co, Ci = weight.shape[0], weight.shape[1]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            a9t = ctx.a9t.get()
+            if a9t is None:
+                a9t = split_weight(weight.detach().flip(2, 3).permute(2, 3, 1, 0).reshape(9, Ci, Co).contiguous())
+            dx = conv3x3_nchw_x3(a9t, dy, d)
+        if ctx.needs_input_grad[1]:
+            dw = conv3x3_wgrad_x3(dy, x, d)
+        return dx, dw, None
+
+
+def conv3x3_x3_supported(x, weight, dilation):
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous() and weight.dtype == torch.float32 and
+            tuple(weight.shape[2:]) == (3, 3) and weight.shape[0] % 8 == 0 and not (x.shape[3] == 128 and int(dilation) == 2) and
+            bool(load().aadg_conv3x3_nchw_supported(weight.shape[0], weight.shape[1], x.shape[2], x.shape[3], int(dilation))) and
+            bool(load().aadg_conv3x3_wgrad_supported(weight.shape[0], weight.shape[1], x.shape[2], x.shape[3], int(dilation))))
+
+
+def conv3x3_x3(x, weight, dilation=1):
+    _require_cuda(x, weight)
+    if not conv3x3_x3_supported(x, weight, dilation):
+        raise AadgError("conv3x3_x3: unsupported shape / dtype / layout")
+    return _Conv3x3X3.apply(x, weight, int(dilation))
 
 
 # ------------------------------------------------------------------------------------------------

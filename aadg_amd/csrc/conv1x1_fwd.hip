@@ -32,38 +32,53 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const uint16_t* p) {
     return v;
 }
 
-// WR x WC waves; wave tile (32 MI) x (32 NI); BM = 32 MI WR, BP = 32 NI WC = 256
-template <int WR, int WC, int MI, int NI>
-__global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restrict__ A, const uint16_t* __restrict__ IN,
-                                                      uint16_t* __restrict__ OUT, int M, int K, int HW, int tiles_p, int tiles_m) {
+// WR x WC waves; wave tile (32 MI) x (32 NI); BM = 32 MI WR, BP = 32 NI WC = 256.
+//
+// X3 = true ("f32x3"): IN / OUT are float32 and A comes pre-split as two bfloat16 planes (A = hi, A_lo = lo; csrc/weight_layouts.hip).
+// A loaded float4 of IN (4 pixels of one channel) is split into (hi, lo) bfloat16 halves while it goes to LDS -- two planes of the same
+// [k][pixel] layout, read with the same transpose reads -- and every fragment pair is multiplied as hi*hi + hi*lo + lo*hi (float32
+// accumulation): float32-grade products at a third of the bfloat16 rate.  K-step 32 (both planes of both operands: 55 KB of LDS).
+template <int WR, int WC, int MI, int NI, bool X3>
+__global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restrict__ A, const uint16_t* __restrict__ A_lo,
+                                                         const void* __restrict__ IN_, void* __restrict__ OUT_, int M, int K, int HW,
+                                                         int tiles_p, int tiles_m) {
     static_assert(WR * WC == 4 && 32 * NI * WC == CF_BP, "4 waves, 256 pixels");
     constexpr int BM = 32 * MI * WR;
-    constexpr int LA = BM * 8 / 256, LB = CF_BK * (CF_BP / 8) / 256;       // 16-byte chunks per thread and K-step
-    __shared__ __attribute__((aligned(16))) uint16_t As[BM * CF_APITCH];
-    __shared__ __attribute__((aligned(16))) uint16_t Bs[CF_BK * CF_BPITCH];
+    constexpr int BK = X3 ? 32 : CF_BK, APITCH = BK + 8, PL = X3 ? 2 : 1;
+    constexpr int AC = BK / 8;                                             // 16-byte chunks per A row and plane
+    constexpr int LA = BM * AC * PL / 256;                                 // A chunks per thread and K-step
+    constexpr int LB = X3 ? BK * (CF_BP / 4) / 256 : BK * (CF_BP / 8) / 256;   // IN chunks (16 bytes: 4 float32 / 8 bfloat16 pixels)
+    __shared__ __attribute__((aligned(16))) uint16_t As[PL * BM * APITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[PL * BK * CF_BPITCH];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv / WC, wc = wv - wr * WC;
     // grid: pixel tile fastest, then output-channel tile, then image: the workgroups that share an IN tile are neighbours
     const int tp = blockIdx.x % tiles_p, t2 = blockIdx.x / tiles_p;
     const int tm = t2 % tiles_m, n = t2 / tiles_m;
     const int m0 = tm * BM, p0 = tp * CF_BP;
-    const uint16_t* inn = IN + (size_t)n * K * HW;
-    uint16_t* outn = OUT + (size_t)n * M * HW;
+    const uint16_t* inn = reinterpret_cast<const uint16_t*>(IN_) + (size_t)n * K * HW * (X3 ? 2 : 1);
+    const float* innf = reinterpret_cast<const float*>(IN_) + (size_t)n * K * HW;
 
     uint4 ra[LA], rb[LB];
-#define CF_FETCH(k0_)                                                                                              \
-    do {                                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                           \
-            const int id = tid + 256 * i, row = id >> 3, c = (id & 7) * 8;                                         \
-            const int m = m0 + row, k = (k0_) + c;                                                                 \
-            ra[i] = (m < M && k < K) ? *reinterpret_cast<const uint4*>(A + (size_t)m * K + k) : make_uint4(0, 0, 0, 0); \
-        }                                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < LB; ++i) {                                                           \
-            const int id = tid + 256 * i, row = id >> 5, c = (id & 31) * 8;                                        \
-            const int k = (k0_) + row, p = p0 + c;                                                                 \
-            rb[i] = (k < K && p < HW) ? *reinterpret_cast<const uint4*>(inn + (size_t)k * HW + p) : make_uint4(0, 0, 0, 0); \
-        }                                                                                                          \
-    } while (0)
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int id = tid + 256 * i, pl = id / (BM * AC), r = id - pl * (BM * AC), row = r / AC, c = (r - row * AC) * 8;
+            const int m = m0 + row, k = k0 + c;
+            ra[i] = (m < M && k < K) ? *reinterpret_cast<const uint4*>((pl ? A_lo : A) + (size_t)m * K + k) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int id = tid + 256 * i;
+            if (X3) {
+                const int row = id >> 6, c = (id & 63) * 4, k = k0 + row, p = p0 + c;
+                rb[i] = (k < K && p < HW) ? *reinterpret_cast<const uint4*>(innf + (size_t)k * HW + p) : make_uint4(0, 0, 0, 0);
+            } else {
+                const int row = id >> 5, c = (id & 31) * 8, k = k0 + row, p = p0 + c;
+                rb[i] = (k < K && p < HW) ? *reinterpret_cast<const uint4*>(inn + (size_t)k * HW + p) : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
 
     f32x16 d[MI][NI];
 #pragma unroll
@@ -74,54 +89,93 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
             for (int r = 0; r < 16; ++r) d[mi][ni][r] = 0.0f;
 
     const int g = lane >> 5, i16 = lane & 15, gi = (lane >> 4) & 1;
-    const uint16_t* a_base = As + (wr * 32 * MI + (lane & 31)) * CF_APITCH + 8 * g;
+    const uint16_t* a_base = As + (wr * 32 * MI + (lane & 31)) * APITCH + 8 * g;
     // transpose-read address of this lane: row (8 g + i16 / 4) of the K-sub-step, columns 16 gi + 4 (i16 % 4) of the N tile
     const uint16_t* b_base = Bs + (8 * g + (i16 >> 2)) * CF_BPITCH + wc * 32 * NI + 16 * gi + 4 * (i16 & 3);
 
-    CF_FETCH(0);
-    for (int k0 = 0; k0 < K; k0 += CF_BK) {
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
         __syncthreads();                                  // the previous step's fragment reads are done
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            const int id = tid + 256 * i;
-            *reinterpret_cast<uint4*>(As + (id >> 3) * CF_APITCH + (id & 7) * 8) = ra[i];
+            const int id = tid + 256 * i, pl = id / (BM * AC), r = id - pl * (BM * AC), row = r / AC, c = (r - row * AC) * 8;
+            *reinterpret_cast<uint4*>(As + pl * BM * APITCH + row * APITCH + c) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             const int id = tid + 256 * i;
-            *reinterpret_cast<uint4*>(Bs + (id >> 5) * CF_BPITCH + (id & 31) * 8) = rb[i];
+            if (X3) {
+                uint2 hi, lo;
+                aadg_split4(make_float4(__uint_as_float(rb[i].x), __uint_as_float(rb[i].y), __uint_as_float(rb[i].z), __uint_as_float(rb[i].w)),
+                            hi, lo);
+                uint16_t* dst = Bs + (id >> 6) * CF_BPITCH + (id & 63) * 4;
+                *reinterpret_cast<uint2*>(dst) = hi;
+                *reinterpret_cast<uint2*>(dst + BK * CF_BPITCH) = lo;
+            } else {
+                *reinterpret_cast<uint4*>(Bs + (id >> 5) * CF_BPITCH + (id & 31) * 8) = rb[i];
+            }
         }
         __syncthreads();
-        if (k0 + CF_BK < K) CF_FETCH(k0 + CF_BK);         // in flight during the MFMAs below
+        if (k0 + BK < K) fetch(k0 + BK);                  // in flight during the MFMAs below
 #pragma unroll
-        for (int ks = 0; ks < CF_BK / 16; ++ks) {
-            bf16x8 a[MI], b[NI];
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 a[PL][MI], b[PL][NI];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                a[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a_base + 32 * mi * CF_APITCH + 16 * ks));
-            u32x2 lo[NI], hi[NI];
+            for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                lo[ni] = lds_read_tr16(b_base + (16 * ks) * CF_BPITCH + 32 * ni);
-                hi[ni] = lds_read_tr16(b_base + (16 * ks + 4) * CF_BPITCH + 32 * ni);
-            }
+                for (int mi = 0; mi < MI; ++mi)
+                    a[pl][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a_base + pl * BM * APITCH + 32 * mi * APITCH + 16 * ks));
+            u32x2 lo[PL][NI], hi[PL][NI];
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    lo[pl][ni] = lds_read_tr16(b_base + pl * BK * CF_BPITCH + (16 * ks) * CF_BPITCH + 32 * ni);
+                    hi[pl][ni] = lds_read_tr16(b_base + pl * BK * CF_BPITCH + (16 * ks + 4) * CF_BPITCH + 32 * ni);
+                }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // the transpose reads are opaque to the compiler's wait-count bookkeeping: pin their results behind the wait (volatile asm
             // statements keep their order), or the scheduler may move an MFMA that uses them above it
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(lo[ni]), "+v"(hi[ni]));
+            for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[ni] = __builtin_bit_cast(bf16x8, make_uint4(lo[ni].x, lo[ni].y, hi[ni].x, hi[ni].y));
+                for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(lo[pl][ni]), "+v"(hi[pl][ni]));
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    b[pl][ni] = __builtin_bit_cast(bf16x8, make_uint4(lo[pl][ni].x, lo[pl][ni].y, hi[pl][ni].x, hi[pl][ni].y));
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], d[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < NI; ++ni) {
+                    if (X3) {                              // the small cross terms first, the hi * hi product last
+                        d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PL - 1][mi], b[0][ni], d[mi][ni], 0, 0, 0);
+                        d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[PL - 1][ni], d[mi][ni], 0, 0, 0);
+                    }
+                    d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[0][ni], d[mi][ni], 0, 0, 0);
+                }
         }
     }
-#undef CF_FETCH
-    // C/D layout: column (pixel) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); lanes p / p + 1 trade
-    // registers r / r + 1 so that each stores two adjacent pixels of one channel row (4-byte stores)
+    // C/D layout: column (pixel) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int jj = lane & 31;
+    if (X3) {
+        // float32 out: the 32 lanes of a row store 128 contiguous bytes
+        float* outf = reinterpret_cast<float*>(OUT_) + (size_t)n * M * HW;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * 32 * MI + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    const int p = p0 + wc * 32 * NI + 32 * ni + jj;
+                    if (m < M && p < HW) outf[(size_t)m * HW + p] = d[mi][ni][r];
+                }
+        return;
+    }
+    // bfloat16 out: lanes p / p + 1 trade registers r / r + 1 so that each stores two adjacent pixels of one channel row (4-byte stores)
+    uint16_t* outn = reinterpret_cast<uint16_t*>(OUT_) + (size_t)n * M * HW;
     const bool odd = jj & 1;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -140,13 +194,14 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
             }
 }
 
-template <int WR, int WC, int MI, int NI>
-int launch(const uint16_t* A, const uint16_t* IN, uint16_t* OUT, int N, int M, int K, int HW, hipStream_t st) {
+template <int WR, int WC, int MI, int NI, bool X3>
+int launch(const uint16_t* A, const uint16_t* A_lo, const void* IN, void* OUT, int N, int M, int K, int HW, hipStream_t st) {
     constexpr int BM = 32 * MI * WR;
     const int tiles_p = (HW + CF_BP - 1) / CF_BP, tiles_m = (M + BM - 1) / BM;
     const long long wgs = (long long)N * tiles_p * tiles_m;
     if (wgs > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
-    hipLaunchKernelGGL((k_conv1x1_nchw<WR, WC, MI, NI>), dim3((unsigned)wgs), dim3(256), 0, st, A, IN, OUT, M, K, HW, tiles_p, tiles_m);
+    hipLaunchKernelGGL((k_conv1x1_nchw<WR, WC, MI, NI, X3>), dim3((unsigned)wgs), dim3(256), 0, st, A, A_lo, IN, OUT, M, K, HW, tiles_p,
+                       tiles_m);
     AADG_LAUNCH_CHECK();
     return 0;
 }
@@ -165,8 +220,20 @@ extern "C" int aadg_conv1x1_nchw_bf16(const void* a, const void* in, void* out, 
     if (!aadg_conv1x1_nchw_supported(M, K, HW)) return AADG_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const uint16_t* pa = (const uint16_t*)a;
-    const uint16_t* pi = (const uint16_t*)in;
-    uint16_t* po = (uint16_t*)out;
-    if (M <= 64) return launch<1, 4, 2, 2>(pa, pi, po, N, M, K, HW, st);             // 64 x 256 tile
-    return launch<2, 2, 2, 4>(pa, pi, po, N, M, K, HW, st);                         // 128 x 256 tile
+    if (M <= 64) return launch<1, 4, 2, 2, false>(pa, nullptr, in, out, N, M, K, HW, st);             // 64 x 256 tile
+    return launch<2, 2, 2, 4, false>(pa, nullptr, in, out, N, M, K, HW, st);                         // 128 x 256 tile
+}
+
+/* The same contraction at float32 precision ("f32x3"): in / out float32 NCHW; a_hi / a_lo = the bfloat16 (hi, lo) halves of the
+ * float32 operand a [M, K] (aadg_weight_layouts_split_bf16); products hi*hi + hi*lo + lo*hi on the matrix cores, float32 accumulation */
+extern "C" int aadg_conv1x1_nchw_f32x3(const void* a_hi, const void* a_lo, const float* in, float* out, int N, int M, int K, int HW,
+                                       void* stream) {
+    if (a_hi == nullptr || a_lo == nullptr || in == nullptr || out == nullptr || N <= 0) return AADG_E_BADARG;
+    if ((((uintptr_t)a_hi | (uintptr_t)a_lo | (uintptr_t)in | (uintptr_t)out) & 15u) != 0) return AADG_E_BADARG;
+    if (!aadg_conv1x1_nchw_supported(M, K, HW)) return AADG_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const uint16_t* ph = (const uint16_t*)a_hi;
+    const uint16_t* pl = (const uint16_t*)a_lo;
+    if (M <= 64) return launch<1, 4, 2, 2, true>(ph, pl, in, out, N, M, K, HW, st);
+    return launch<2, 2, 2, 4, true>(ph, pl, in, out, N, M, K, HW, st);
 }

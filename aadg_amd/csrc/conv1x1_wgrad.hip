@@ -12,6 +12,7 @@
 //
 // float32 accumulation; the split-K partials are combined with hardware float atomics (order-dependent in the last bit).
 #include <hip/hip_bf16.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -27,10 +28,18 @@ constexpr int WG_PITCH = WG_BK + 8;       // LDS row pitch in elements (144 byte
 // Per 16-wide K sub-step a wave reads MI + NI fragments from LDS for MI * NI MFMAs, and a workgroup pulls (BM + BN) * 128
 // bytes per 64-wide K step through L2 for BM * BN * 128 flops: the 256 x 256 tile (8 waves of 128 x 64) halves both ratios
 // relative to 128 x 128 (4 waves of 64 x 64), which is what the channel-rich late layers (>= 256 x 256 weights) are bound by.
-template <int WR, int WC, int MI, int NI>
-__global__ __launch_bounds__(64 * WR * WC) void k_wgrad1x1(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X,
+//
+// X3 = true ("f32x3"): dY / X are float32.  A K-step is still 128 bytes per row = 32 pixels; every loaded float4 becomes one 16-byte LDS
+// chunk [hi0..3][lo0..3] (aadg_split4), so the 8 K-values of a fragment are the hi halves of two neighbouring chunks and their lo
+// halves come with the same two reads; products hi*hi + hi*lo + lo*hi, float32 accumulation.
+template <int WR, int WC, int MI, int NI, bool X3>
+__global__ __launch_bounds__(64 * WR * WC) void k_wgrad1x1(const void* __restrict__ dY_, const void* __restrict__ X_,
                                                            float* __restrict__ acc, int Co, int Ci, int HW, int tiles, int tiles_n,
                                                            int steps_total, int steps_per_block) {
+    typedef typename std::conditional<X3, float, uint16_t>::type elem_t;
+    const elem_t* dY = reinterpret_cast<const elem_t*>(dY_);
+    const elem_t* X = reinterpret_cast<const elem_t*>(X_);
+    constexpr int BKE = X3 ? 32 : WG_BK;                       // K elements (pixels) per step: 128 bytes of a row either way
     constexpr int NT = 64 * WR * WC;
     constexpr int BM = 32 * MI * WR, BN = 32 * NI * WC, R = BM + BN, LPT = R * 8 / NT, LPT_A = BM * 8 / NT;
     static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "a staging slot is entirely dY or entirely X");
@@ -46,26 +55,26 @@ __global__ __launch_bounds__(64 * WR * WC) void k_wgrad1x1(const uint16_t* __res
     const int m0 = tm * BM, n0 = tn * BN;
     const int s0 = slice * steps_per_block, s1 = min(steps_total, s0 + steps_per_block);
     if (s0 >= s1) return;
-    const int spi = HW / WG_BK;           // steps per image
+    const int spi = HW / BKE;             // steps per image
 
     // this thread's LPT (row, 16-byte chunk) slots of the staged tile; rows beyond Co / Ci read as zero
-    const uint16_t* src[LPT];
-    const int row0 = tid >> 3, c8 = (tid & 7) * 8;
+    const elem_t* src[LPT];
+    const int row0 = tid >> 3, c8 = (tid & 7) * 8, cg = (tid & 7) * (BKE / 8);     // chunk offset in LDS / in the global row (elements)
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
         const int row = row0 + (NT / 8) * i;
         if (i < LPT_A) {
             const int m = m0 + row;
-            src[i] = m < Co ? dY + (size_t)m * HW + c8 : nullptr;
+            src[i] = m < Co ? dY + (size_t)m * HW + cg : nullptr;
         } else {
             const int n = n0 + row - BM;
-            src[i] = n < Ci ? X + (size_t)n * HW + c8 : nullptr;
+            src[i] = n < Ci ? X + (size_t)n * HW + cg : nullptr;
         }
     }
     const size_t stride_a = (size_t)Co * HW, stride_b = (size_t)Ci * HW;
     uint4 stage[LPT];
     auto fetch = [&](int step) {
-        const int n = step / spi, kk = (step - n * spi) * WG_BK;
+        const int n = step / spi, kk = (step - n * spi) * BKE;
 #pragma unroll
         for (int i = 0; i < LPT; ++i)
             stage[i] = src[i] != nullptr ? *reinterpret_cast<const uint4*>(src[i] + (size_t)n * (i < LPT_A ? stride_a : stride_b) + kk)
@@ -87,9 +96,45 @@ __global__ __launch_bounds__(64 * WR * WC) void k_wgrad1x1(const uint16_t* __res
     for (int step = s0; step < s1; ++step) {
         uint16_t* L = lds + (size_t)buf * R * WG_PITCH;
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) *reinterpret_cast<uint4*>(L + st_off + (NT / 8) * i * WG_PITCH) = stage[i];
+        for (int i = 0; i < LPT; ++i) {
+            uint4 v = stage[i];
+            if (X3) {
+                uint2 hi, lo;
+                aadg_split4(make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)), hi, lo);
+                v = make_uint4(hi.x, hi.y, lo.x, lo.y);
+            }
+            *reinterpret_cast<uint4*>(L + st_off + (NT / 8) * i * WG_PITCH) = v;
+        }
         __syncthreads();
         if (step + 1 < s1) fetch(step + 1);              // in flight during the MFMAs below
+        if (X3) {
+#pragma unroll
+            for (int ks = 0; ks < BKE / 16; ++ks) {
+                bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const uint16_t* p = L + (a_row + 32 * mi) * WG_PITCH + ks * 32 + 2 * koff;
+                    const uint4 q0 = *reinterpret_cast<const uint4*>(p), q1 = *reinterpret_cast<const uint4*>(p + 8);
+                    ah[mi] = __builtin_bit_cast(bf16x8, make_uint4(q0.x, q0.y, q1.x, q1.y));
+                    al[mi] = __builtin_bit_cast(bf16x8, make_uint4(q0.z, q0.w, q1.z, q1.w));
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const uint16_t* p = L + (b_row + 32 * ni) * WG_PITCH + ks * 32 + 2 * koff;
+                    const uint4 q0 = *reinterpret_cast<const uint4*>(p), q1 = *reinterpret_cast<const uint4*>(p + 8);
+                    bh[ni] = __builtin_bit_cast(bf16x8, make_uint4(q0.x, q0.y, q1.x, q1.y));
+                    bl[ni] = __builtin_bit_cast(bf16x8, make_uint4(q0.z, q0.w, q1.z, q1.w));
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], d[mi][ni], 0, 0, 0);
+                        d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], d[mi][ni], 0, 0, 0);
+                        d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], d[mi][ni], 0, 0, 0);
+                    }
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < WG_BK / 16; ++ks) {
             bf16x8 a[MI], b[NI];
@@ -121,11 +166,12 @@ __global__ __launch_bounds__(64 * WR * WC) void k_wgrad1x1(const uint16_t* __res
 }
 
 // target_wgs: workgroups aimed at (every one of them ends with BM * BN float atomics: the big tile runs one per CU)
-template <int WR, int WC, int MI, int NI>
-int launch(const uint16_t* dY, const uint16_t* X, float* acc, int N, int Co, int Ci, int HW, int target_wgs, hipStream_t st) {
+template <int WR, int WC, int MI, int NI, bool X3>
+int launch(const void* dY, const void* X, float* acc, int N, int Co, int Ci, int HW, int target_wgs, hipStream_t st) {
+    constexpr int BKE = X3 ? 32 : WG_BK;
     constexpr int BM = 32 * MI * WR, BN = 32 * NI * WC, R = BM + BN, NT = 64 * WR * WC;
     const int tiles_m = (Co + BM - 1) / BM, tiles_n = (Ci + BN - 1) / BN, tiles = tiles_m * tiles_n;
-    const int steps_total = N * (HW / WG_BK);
+    const int steps_total = N * (HW / BKE);
     int split = (target_wgs + tiles - 1) / tiles;
     // K-steps per workgroup: each workgroup ends with BM x BN float atomics (the cost of several K-steps), so 32 steps when the
     // reduction is long enough to still fill the chip (N = 144: 4.66 -> 4.46 ms over the 16 backbone shapes against 8), fewer --
@@ -140,13 +186,13 @@ int launch(const uint16_t* dY, const uint16_t* X, float* acc, int N, int Co, int
     const size_t lds = (size_t)2 * R * WG_PITCH * sizeof(uint16_t);
     static bool attr_set = false;                            // per instantiation; idempotent
     if (!attr_set) {
-        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad1x1<WR, WC, MI, NI>),
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad1x1<WR, WC, MI, NI, X3>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     AADG_HIP_TRY(hipMemsetAsync(acc, 0, (size_t)Co * Ci * sizeof(float), st));
     const int slice_groups = (split + 7) / 8;                 // slices are padded to a multiple of 8 (empty ones exit at once)
-    hipLaunchKernelGGL((k_wgrad1x1<WR, WC, MI, NI>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(NT), lds, st, dY, X, acc, Co, Ci,
+    hipLaunchKernelGGL((k_wgrad1x1<WR, WC, MI, NI, X3>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(NT), lds, st, dY, X, acc, Co, Ci,
                        HW, tiles, tiles_n, steps_total, steps_per_block);
     AADG_LAUNCH_CHECK();
     return 0;
@@ -158,18 +204,32 @@ extern "C" int aadg_conv1x1_wgrad_supported(int Co, int Ci, int HW) {
     return Co > 0 && Ci > 0 && HW >= WG_BK && (HW % WG_BK) == 0 ? 1 : 0;
 }
 
+namespace {
+template <bool X3>
+int wgrad1x1_dispatch(const void* a, const void* b, float* dweight, int N, int Co, int Ci, int HW, hipStream_t st) {
+    constexpr int BKE = X3 ? 32 : WG_BK;
+    if (Co <= 64) return launch<1, 4, 2, 2, X3>(a, b, dweight, N, Co, Ci, HW, 1024, st);
+    if (Ci <= 64) return launch<4, 1, 2, 2, X3>(a, b, dweight, N, Co, Ci, HW, 1024, st);
+    // the 256 x 256 tile needs a reduction long enough for ~one workgroup per CU at >= 32 steps each
+    const long long big_wgs = (long long)(Co / 256) * (Ci / 256) * ((long long)N * (HW / BKE) / 32);
+    if (Co >= 256 && Ci >= 256 && (Co % 256) == 0 && (Ci % 256) == 0 && (long long)Co * Ci >= 512 * 512 && big_wgs >= 192)
+        return launch<2, 4, 4, 2, X3>(a, b, dweight, N, Co, Ci, HW, 256, st);
+    return launch<2, 2, 2, 2, X3>(a, b, dweight, N, Co, Ci, HW, 1024, st);
+}
+}  // namespace
+
 extern "C" int aadg_conv1x1_wgrad_bf16(const void* dy, const void* x, float* dweight, int N, int Co, int Ci, int HW, void* stream) {
     if (dy == nullptr || x == nullptr || dweight == nullptr || N <= 0) return AADG_E_BADARG;
     if ((((uintptr_t)dy | (uintptr_t)x) & 15u) != 0) return AADG_E_BADARG;
     if (!aadg_conv1x1_wgrad_supported(Co, Ci, HW) || (long long)N * (HW / WG_BK) > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    const uint16_t* a = (const uint16_t*)dy;
-    const uint16_t* b = (const uint16_t*)x;
-    if (Co <= 64) return launch<1, 4, 2, 2>(a, b, dweight, N, Co, Ci, HW, 1024, st);
-    if (Ci <= 64) return launch<4, 1, 2, 2>(a, b, dweight, N, Co, Ci, HW, 1024, st);
-    // the 256 x 256 tile needs a reduction long enough for ~one workgroup per CU at >= 32 steps each
-    const long long big_wgs = (long long)(Co / 256) * (Ci / 256) * ((long long)N * (HW / WG_BK) / 32);
-    if (Co >= 256 && Ci >= 256 && (Co % 256) == 0 && (Ci % 256) == 0 && (long long)Co * Ci >= 512 * 512 && big_wgs >= 192)
-        return launch<2, 4, 4, 2>(a, b, dweight, N, Co, Ci, HW, 256, st);
-    return launch<2, 2, 2, 2>(a, b, dweight, N, Co, Ci, HW, 1024, st);
+    return wgrad1x1_dispatch<false>(dy, x, dweight, N, Co, Ci, HW, (hipStream_t)stream);
+}
+
+/* dW [Co, Ci] float32 from float32 NCHW dy / x at float32 precision ("f32x3": three bfloat16 matrix-core products per pair of
+ * (hi, lo)-split operands, float32 accumulation).  HW % 32 == 0. */
+extern "C" int aadg_conv1x1_wgrad_f32x3(const float* dy, const float* x, float* dweight, int N, int Co, int Ci, int HW, void* stream) {
+    if (dy == nullptr || x == nullptr || dweight == nullptr || N <= 0) return AADG_E_BADARG;
+    if ((((uintptr_t)dy | (uintptr_t)x) & 15u) != 0) return AADG_E_BADARG;
+    if (Co <= 0 || Ci <= 0 || HW < 32 || (HW % 32) != 0 || (long long)N * (HW / 32) > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
+    return wgrad1x1_dispatch<true>(dy, x, dweight, N, Co, Ci, HW, (hipStream_t)stream);
 }

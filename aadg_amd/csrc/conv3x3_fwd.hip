@@ -38,26 +38,33 @@ __device__ __forceinline__ u32x2 lds_tr16(const uint16_t* p) {
     return v;
 }
 
-template <int W, int D, int MI>
+// X3 = true ("f32x3"): IN / OUT are float32, A9 comes pre-split as two bfloat16 planes (hi, lo).  A staged 8-pixel chunk (two float4
+// loads) is split into its (hi, lo) bfloat16 halves (aadg_split4) and both halves go through the same three-copy staging into two planes
+// of the same layout; every fragment pair is multiplied as hi*hi + hi*lo + lo*hi with float32 accumulation.  Both planes of both operands
+// are 132-157 KB of LDS: one workgroup per CU, 108 MFMAs per wave and K-step.
+template <int W, int D, int MI, bool X3 = false>
 struct C3Cfg {
     static constexpr int BM = 32 * MI;                              // MI 32-row tiles per wave; the four waves share the m range
     static constexpr int ROWS = C3_PIX / W;                         // image rows per tile
     static constexpr int SPX = (ROWS + 2 * D) * W;                  // staged pixels per channel
     static constexpr int BP = ((SPX + 127) / 128) * 128 + 16;       // pitch: 32 bytes (mod 256): the 4 rows of a transpose read hit distinct banks
-    static constexpr int A_EL = 9 * 32 * MI * C3_APITCH, B_EL = 3 * C3_BK * BP;
-    static constexpr size_t lds_bytes = (size_t)(A_EL + B_EL) * sizeof(uint16_t);
+    static constexpr int PL = X3 ? 2 : 1;                           // operand planes in LDS
+    static constexpr int A_EL = 9 * 32 * MI * C3_APITCH, B_EL = 3 * C3_BK * BP;       // per plane
+    static constexpr size_t lds_bytes = (size_t)PL * (A_EL + B_EL) * sizeof(uint16_t);
 };
 
-template <int W, int D, int MI>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_nchw(const uint16_t* __restrict__ A9, const uint16_t* __restrict__ IN,
-                                                         uint16_t* __restrict__ OUT, int M, int K, int H, int tiles_m, int tiles_r, int pts) {
-    using C = C3Cfg<W, D, MI>;
+template <int W, int D, int MI, bool X3>
+__global__ __launch_bounds__(256, X3 ? 1 : 2) void k_conv3x3_nchw(const uint16_t* __restrict__ A9, const uint16_t* __restrict__ A9_lo,
+                                                                  const void* __restrict__ IN_, void* __restrict__ OUT_, int M, int K, int H,
+                                                                  int tiles_m, int tiles_r, int pts) {
+    using C = C3Cfg<W, D, MI, X3>;
+    constexpr int PL = C::PL;
     constexpr int BM = 32 * MI, ROWS = C::ROWS, BP = C::BP, NI = 2, CPR = W / 8, SR = ROWS + 2 * D;
     constexpr int NA = 9 * BM * 2, LA = (NA + 255) / 256;            // 16-byte chunks of the A tile (9 taps x BM rows x 2) per K-step
     constexpr int NB = C3_BK * SR * CPR, LB = (NB + 255) / 256;      // ... of the IN tile
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-    uint16_t* As = lds;                    // [9][BM][C3_APITCH]
-    uint16_t* Bs = lds + C::A_EL;          // [3 copies][16][BP]
+    uint16_t* As = lds;                    // [PL][9][BM][C3_APITCH]
+    uint16_t* Bs = lds + PL * C::A_EL;     // [PL][3 copies][16][BP]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // XCD-aware decode: the out-channel tiles of one pixel tile run on one XCD and share the IN tile through its L2
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -66,28 +73,41 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_nchw(const uint16_t* __restr
     const int n = pt / tiles_r, tr = pt - n * tiles_r;
     const int m0 = tm * BM, y0 = tr * ROWS;
     const size_t HW = (size_t)H * W;
-    const uint16_t* inn = IN + (size_t)n * K * HW;
-    uint16_t* outn = OUT + (size_t)n * M * HW;
+    const uint16_t* inn = reinterpret_cast<const uint16_t*>(IN_) + (X3 ? 0 : (size_t)n * K * HW);
+    const float* innf = reinterpret_cast<const float*>(IN_) + (X3 ? (size_t)n * K * HW : 0);
 
-    uint4 ra[LA], rb[LB];
+    uint4 ra[PL][LA], rb[PL][LB];          // X3: rb[0] / rb[1] = pixels 0..3 / 4..7 of the chunk as float32
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const int id = tid + 256 * i;
-            ra[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) ra[pl][i] = make_uint4(0, 0, 0, 0);
             if (id < NA) {
                 const int t = id / (BM * 2), r = id - t * (BM * 2), m = m0 + (r >> 1), k = k0 + (r & 1) * 8;
-                if (m < M && k < K) ra[i] = *reinterpret_cast<const uint4*>(A9 + ((size_t)t * M + m) * K + k);
+                if (m < M && k < K) {
+                    ra[0][i] = *reinterpret_cast<const uint4*>(A9 + ((size_t)t * M + m) * K + k);
+                    if (X3) ra[PL - 1][i] = *reinterpret_cast<const uint4*>(A9_lo + ((size_t)t * M + m) * K + k);
+                }
             }
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             const int id = tid + 256 * i;
-            rb[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) rb[pl][i] = make_uint4(0, 0, 0, 0);
             if (id < NB) {
                 const int cc = id / (SR * CPR), r2 = id - cc * (SR * CPR), rr = r2 / CPR, ch = r2 - rr * CPR;
                 const int k = k0 + cc, yy = y0 - D + rr;
-                if (k < K && yy >= 0 && yy < H) rb[i] = *reinterpret_cast<const uint4*>(inn + ((size_t)k * H + yy) * W + ch * 8);
+                if (k < K && yy >= 0 && yy < H) {
+                    if (X3) {
+                        const float* src = innf + ((size_t)k * H + yy) * W + ch * 8;
+                        rb[0][i] = *reinterpret_cast<const uint4*>(src);
+                        rb[PL - 1][i] = *reinterpret_cast<const uint4*>(src + 4);
+                    } else {
+                        rb[0][i] = *reinterpret_cast<const uint4*>(inn + ((size_t)k * H + yy) * W + ch * 8);
+                    }
+                }
             }
         }
     };
@@ -111,74 +131,120 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_nchw(const uint16_t* __restr
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const int id = tid + 256 * i;
-            if (id < NA) *reinterpret_cast<uint4*>(As + (id >> 1) * C3_APITCH + (id & 1) * 8) = ra[i];
+            if (id < NA) {
+#pragma unroll
+                for (int pl = 0; pl < PL; ++pl) *reinterpret_cast<uint4*>(As + pl * C::A_EL + (id >> 1) * C3_APITCH + (id & 1) * 8) = ra[pl][i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             const int id = tid + 256 * i;
             // neighbouring chunks of the image row sit in the neighbouring lanes (CPR divides 64): the pixel(s) shifted in
-            const uint4 v = rb[i];
-            uint32_t left = __shfl_up(v.w, 1, 64), right = __shfl_down(v.x, 1, 64);
-            if (id < NB) {
-                const int cc = id / (SR * CPR), r2 = id - cc * (SR * CPR), ch = r2 % CPR;
-                if (ch == 0) left = 0u;                    // the padding columns
-                if (ch == CPR - 1) right = 0u;
-                uint16_t* dst = Bs + cc * BP + r2 * 8;
-                uint4 vm, vp;                              // vm[p] = IN[p - D], vp[p] = IN[p + D]
-                if (D == 1) {
-                    const uint32_t s1 = __builtin_amdgcn_alignbit(v.y, v.x, 16), s2 = __builtin_amdgcn_alignbit(v.z, v.y, 16),
-                                   s3 = __builtin_amdgcn_alignbit(v.w, v.z, 16);
-                    vm = make_uint4(__builtin_amdgcn_alignbit(v.x, left, 16), s1, s2, s3);
-                    vp = make_uint4(s1, s2, s3, __builtin_amdgcn_alignbit(right, v.w, 16));
-                } else {
-                    vm = make_uint4(left, v.x, v.y, v.z);
-                    vp = make_uint4(v.y, v.z, v.w, right);
+            uint4 vv[PL];
+            if (X3) {
+                uint2 h0, l0, h1, l1;
+                const uint4 q0 = rb[0][i], q1 = rb[PL - 1][i];
+                aadg_split4(make_float4(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w)), h0, l0);
+                aadg_split4(make_float4(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q1.w)), h1, l1);
+                vv[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                vv[PL - 1] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            } else {
+                vv[0] = rb[0][i];
+            }
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) {
+                const uint4 v = vv[pl];
+                uint32_t left = __shfl_up(v.w, 1, 64), right = __shfl_down(v.x, 1, 64);
+                if (id < NB) {
+                    const int cc = id / (SR * CPR), r2 = id - cc * (SR * CPR), ch = r2 % CPR;
+                    if (ch == 0) left = 0u;                    // the padding columns
+                    if (ch == CPR - 1) right = 0u;
+                    uint16_t* dst = Bs + pl * C::B_EL + cc * BP + r2 * 8;
+                    uint4 vm, vp;                              // vm[p] = IN[p - D], vp[p] = IN[p + D]
+                    if (D == 1) {
+                        const uint32_t s1 = __builtin_amdgcn_alignbit(v.y, v.x, 16), s2 = __builtin_amdgcn_alignbit(v.z, v.y, 16),
+                                       s3 = __builtin_amdgcn_alignbit(v.w, v.z, 16);
+                        vm = make_uint4(__builtin_amdgcn_alignbit(v.x, left, 16), s1, s2, s3);
+                        vp = make_uint4(s1, s2, s3, __builtin_amdgcn_alignbit(right, v.w, 16));
+                    } else {
+                        vm = make_uint4(left, v.x, v.y, v.z);
+                        vp = make_uint4(v.y, v.z, v.w, right);
+                    }
+                    *reinterpret_cast<uint4*>(dst) = vm;                               // copy 0: tap kw = 0
+                    *reinterpret_cast<uint4*>(dst + C3_BK * BP) = v;                   // copy 1: kw = 1
+                    *reinterpret_cast<uint4*>(dst + 2 * C3_BK * BP) = vp;              // copy 2: kw = 2
                 }
-                *reinterpret_cast<uint4*>(dst) = vm;                               // copy 0: tap kw = 0
-                *reinterpret_cast<uint4*>(dst + C3_BK * BP) = v;                   // copy 1: kw = 1
-                *reinterpret_cast<uint4*>(dst + 2 * C3_BK * BP) = vp;              // copy 2: kw = 2
             }
         }
         __syncthreads();
         if (k0 + C3_BK < K) fetch(k0 + C3_BK);            // in flight during the MFMAs below
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-            bf16x8 a[3][MI];
-            u32x2 lo[3][NI], hi[3][NI];
+            bf16x8 a[PL][3][MI];
+            u32x2 lo[PL][3][NI], hi[PL][3][NI];
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
+            for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    a[kw][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a_base + ((kh * 3 + kw) * BM + 32 * mi) * C3_APITCH));
+                for (int kw = 0; kw < 3; ++kw) {
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const uint16_t* p = b_base + kw * C3_BK * BP + kh * D * W + 32 * ni;
-                    lo[kw][ni] = lds_tr16(p);
-                    hi[kw][ni] = lds_tr16(p + 4 * BP);
+                    for (int mi = 0; mi < MI; ++mi)
+                        a[pl][kw][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a_base + pl * C::A_EL +
+                                                                                                  ((kh * 3 + kw) * BM + 32 * mi) * C3_APITCH));
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const uint16_t* p = b_base + pl * C::B_EL + kw * C3_BK * BP + kh * D * W + 32 * ni;
+                        lo[pl][kw][ni] = lds_tr16(p);
+                        hi[pl][kw][ni] = lds_tr16(p + 4 * BP);
+                    }
                 }
-            }
             // the transpose reads are opaque to the compiler's wait-count bookkeeping; tying their results to the wait keeps the
             // scheduler from moving an MFMA that uses them above it (it did: the second pixel tile of every wave came out wrong)
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(lo[0][0]), "+v"(lo[0][1]), "+v"(lo[1][0]), "+v"(lo[1][1]), "+v"(lo[2][0]), "+v"(lo[2][1]), "+v"(hi[0][0]),
-                           "+v"(hi[0][1]), "+v"(hi[1][0]), "+v"(hi[1][1]), "+v"(hi[2][0]), "+v"(hi[2][1])
-                         :
-                         : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(lo[pl][kw][ni]), "+v"(hi[pl][kw][ni]));
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    const bf16x8 b = __builtin_bit_cast(bf16x8, make_uint4(lo[kw][ni].x, lo[kw][ni].y, hi[kw][ni].x, hi[kw][ni].y));
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, make_uint4(lo[0][kw][ni].x, lo[0][kw][ni].y, hi[0][kw][ni].x, hi[0][kw][ni].y));
+                    if (X3) {
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, make_uint4(lo[PL - 1][kw][ni].x, lo[PL - 1][kw][ni].y, hi[PL - 1][kw][ni].x,
+                                                                                hi[PL - 1][kw][ni].y));
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kw][mi], b, d[mi][ni], 0, 0, 0);
+                        for (int mi = 0; mi < MI; ++mi) {
+                            d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PL - 1][kw][mi], b, d[mi][ni], 0, 0, 0);
+                            d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][kw][mi], bl, d[mi][ni], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][kw][mi], b, d[mi][ni], 0, 0, 0);
                 }
         }
     }
     // C/D layout: column (pixel) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); lanes p / p + 1 trade
     // registers r / r + 1 so that each stores two adjacent pixels of one channel row (4-byte stores)
     const int jj = lane & 31;
-    const bool odd = jj & 1;
     const size_t p_tile = (size_t)y0 * W + wv * 64;
+    if (X3) {
+        float* outf = reinterpret_cast<float*>(OUT_) + (size_t)n * M * HW;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    const size_t p = p_tile + 32 * ni + jj;
+                    if (m < M && p < HW) outf[(size_t)m * HW + p] = d[mi][ni][r];
+                }
+        return;
+    }
+    uint16_t* outn = reinterpret_cast<uint16_t*>(OUT_) + (size_t)n * M * HW;
+    const bool odd = jj & 1;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -196,9 +262,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_nchw(const uint16_t* __restr
             }
 }
 
-template <int W, int D, int MI>
-int launch(const uint16_t* A9, const uint16_t* IN, uint16_t* OUT, int N, int M, int K, int H, hipStream_t st) {
-    using C = C3Cfg<W, D, MI>;
+template <int W, int D, int MI, bool X3>
+int launch(const uint16_t* A9, const uint16_t* A9_lo, const void* IN, void* OUT, int N, int M, int K, int H, hipStream_t st) {
+    using C = C3Cfg<W, D, MI, X3>;
     constexpr int BM = 32 * MI;
     const int tiles_m = (M + BM - 1) / BM, tiles_r = (H + C::ROWS - 1) / C::ROWS;
     const long long pts = (long long)N * tiles_r, groups = (pts + 7) / 8;
@@ -206,11 +272,12 @@ int launch(const uint16_t* A9, const uint16_t* IN, uint16_t* OUT, int N, int M, 
     if (wgs > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
     static bool attr_set = false;                            // per instantiation; idempotent
     if (!attr_set) {
-        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_nchw<W, D, MI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_nchw<W, D, MI, X3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::lds_bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv3x3_nchw<W, D, MI>), dim3((unsigned)wgs), dim3(256), C::lds_bytes, st, A9, IN, OUT, M, K, H, tiles_m, tiles_r, (int)pts);
+    hipLaunchKernelGGL((k_conv3x3_nchw<W, D, MI, X3>), dim3((unsigned)wgs), dim3(256), C::lds_bytes, st, A9, A9_lo, IN, OUT, M, K, H, tiles_m,
+                       tiles_r, (int)pts);
     AADG_LAUNCH_CHECK();
     return 0;
 }
@@ -221,17 +288,10 @@ extern "C" int aadg_conv3x3_nchw_supported(int M, int K, int H, int W, int dilat
     return M > 0 && K > 0 && (K % 8) == 0 && H > 0 && (W == 32 || W == 64 || W == 128) && (dilation == 1 || dilation == 2) ? 1 : 0;
 }
 
-/* out [N, M, H, W] = conv3x3(in [N, K, H, W]; a9 [9, M, K] tap-major), stride 1, padding = dilation; all bfloat16, float32
- * accumulation */
-extern "C" int aadg_conv3x3_nchw_bf16(const void* a9, const void* in, void* out, int N, int M, int K, int H, int W, int dilation,
-                                      void* stream) {
-    if (a9 == nullptr || in == nullptr || out == nullptr || N <= 0) return AADG_E_BADARG;
-    if ((((uintptr_t)a9 | (uintptr_t)in | (uintptr_t)out) & 15u) != 0) return AADG_E_BADARG;
-    if (!aadg_conv3x3_nchw_supported(M, K, H, W, dilation)) return AADG_E_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    const uint16_t* pa = (const uint16_t*)a9;
-    const uint16_t* pi = (const uint16_t*)in;
-    uint16_t* po = (uint16_t*)out;
+namespace {
+template <bool X3>
+int conv3x3_dispatch(const uint16_t* pa, const uint16_t* pl, const void* in, void* out, int N, int M, int K, int H, int W, int dilation,
+                     hipStream_t st) {
     // Measured, not kept: a 128-channel tile (MI = 4) halves the weight-fragment reads per MFMA but needs 94 KB of LDS = one workgroup per CU:
     // 10-25 % slower.  Ablations (results wrong, timing only): a third of the weight-fragment reads, or a third of the transpose reads: no
     // change -- LDS read bandwidth is not the limit; skipping the per-step staging of the weight tile (stores): 15-18 % faster -- the serial
@@ -244,11 +304,33 @@ extern "C" int aadg_conv3x3_nchw_bf16(const void* a9, const void* in, void* out,
     // one K-step of MFMAs does not cover the load latency; loads two steps ahead need a second register set (> 256 VGPRs at two waves
     // per SIMD with this tile).  Next: a 128 x 256 tile on 8 waves (weights amortised over twice the MFMAs at the same LDS reads per MFMA).
     if (dilation == 1) {
-        if (W == 32) return launch<32, 1, 2>(pa, pi, po, N, M, K, H, st);
-        if (W == 64) return launch<64, 1, 2>(pa, pi, po, N, M, K, H, st);
-        return launch<128, 1, 2>(pa, pi, po, N, M, K, H, st);
+        if (W == 32) return launch<32, 1, 2, X3>(pa, pl, in, out, N, M, K, H, st);
+        if (W == 64) return launch<64, 1, 2, X3>(pa, pl, in, out, N, M, K, H, st);
+        return launch<128, 1, 2, X3>(pa, pl, in, out, N, M, K, H, st);
     }
-    if (W == 32) return launch<32, 2, 2>(pa, pi, po, N, M, K, H, st);
-    if (W == 64) return launch<64, 2, 2>(pa, pi, po, N, M, K, H, st);
-    return launch<128, 2, 2>(pa, pi, po, N, M, K, H, st);
+    if (W == 32) return launch<32, 2, 2, X3>(pa, pl, in, out, N, M, K, H, st);
+    if (W == 64) return launch<64, 2, 2, X3>(pa, pl, in, out, N, M, K, H, st);
+    return launch<128, 2, 2, X3>(pa, pl, in, out, N, M, K, H, st);
+}
+}  // namespace
+
+
+/* out [N, M, H, W] = conv3x3(in [N, K, H, W]; a9 [9, M, K] tap-major), stride 1, padding = dilation; all bfloat16, float32
+ * accumulation */
+extern "C" int aadg_conv3x3_nchw_bf16(const void* a9, const void* in, void* out, int N, int M, int K, int H, int W, int dilation,
+                                      void* stream) {
+    if (a9 == nullptr || in == nullptr || out == nullptr || N <= 0) return AADG_E_BADARG;
+    if ((((uintptr_t)a9 | (uintptr_t)in | (uintptr_t)out) & 15u) != 0) return AADG_E_BADARG;
+    if (!aadg_conv3x3_nchw_supported(M, K, H, W, dilation)) return AADG_E_UNSUPPORTED;
+    return conv3x3_dispatch<false>((const uint16_t*)a9, nullptr, in, out, N, M, K, H, W, dilation, (hipStream_t)stream);
+}
+
+/* The same convolution at float32 precision ("f32x3"): in / out float32 NCHW; a9_hi / a9_lo = the bfloat16 (hi, lo) halves of the float32
+ * tap-major weights [9, M, K] (aadg_weight_layouts_split_bf16); hi*hi + hi*lo + lo*hi on the matrix cores, float32 accumulation */
+extern "C" int aadg_conv3x3_nchw_f32x3(const void* a9_hi, const void* a9_lo, const float* in, float* out, int N, int M, int K, int H, int W,
+                                       int dilation, void* stream) {
+    if (a9_hi == nullptr || a9_lo == nullptr || in == nullptr || out == nullptr || N <= 0) return AADG_E_BADARG;
+    if ((((uintptr_t)a9_hi | (uintptr_t)a9_lo | (uintptr_t)in | (uintptr_t)out) & 15u) != 0) return AADG_E_BADARG;
+    if (!aadg_conv3x3_nchw_supported(M, K, H, W, dilation)) return AADG_E_UNSUPPORTED;
+    return conv3x3_dispatch<true>((const uint16_t*)a9_hi, (const uint16_t*)a9_lo, in, out, N, M, K, H, W, dilation, (hipStream_t)stream);
 }

@@ -19,6 +19,7 @@
 // float32 accumulation, split-K partials combined with hardware float atomics into acc[9][Co][Ci] (tap-major: the atomics of a wave
 // are contiguous over the in-channel index).
 #include <hip/hip_bf16.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -29,79 +30,103 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int W3_BM = 64, W3_BN = 64;
 
-template <int W, int D>
+// X3 = true ("f32x3"): dY / X are float32; a loaded float4 (4 pixels) is split into (hi, lo) bfloat16 halves on its way to LDS (two planes
+// of the layout below) and the tap fragments are built per plane; products hi*hi + hi*lo + lo*hi, float32 accumulation.  Both planes are
+// 77-148 KB of LDS (one workgroup per CU); at W = 128 (and W = 64, D = 2) the tile is 64 x 32 channels and the two waves of a channel pair split the row's
+// K-sub-steps between them.
+template <int W, int D, bool X3 = false>
 struct W3Cfg {
+    static constexpr int PL = X3 ? 2 : 1;
+    static constexpr int BN = (X3 && (W == 128 || (W == 64 && D == 2))) ? 32 : W3_BN;       // in-channel tile (both planes must fit the LDS)
     static constexpr int R = 2 * D + 2;             // ring slots: rows y - D .. y + D in use, one being replaced
     static constexpr int PA = W + 8;                // dY row pitch (elements): 2 W + 16 bytes = 4 (mod 8) words -> conflict-free b128
     static constexpr int PX = W + 24;               // X row pitch: 8 pad | W data | 2 halo | pad; data 16-byte aligned, pitch = 4 (mod 8) words
-    static constexpr int LPT = W / 32;              // 16-byte chunks per thread and staged row set (64 rows x W / 8 chunks / 256 threads)
-    static constexpr size_t lds_bytes = ((size_t)2 * W3_BM * PA + (size_t)R * W3_BN * PX) * sizeof(uint16_t);
+    static constexpr int CPR = X3 ? W / 4 : W / 8;  // 16-byte global chunks per row (4 float32 / 8 bfloat16 pixels)
+    static constexpr int LPA = W3_BM * CPR / 256;   // chunks per thread of a staged dY row set
+    static constexpr int LPX = BN * CPR / 256;      // ... of an X row set
+    static constexpr size_t lds_bytes = (size_t)PL * ((size_t)2 * W3_BM * PA + (size_t)R * BN * PX) * sizeof(uint16_t);
 };
 
 __device__ __forceinline__ bf16x8 frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     return __builtin_bit_cast(bf16x8, make_uint4(a, b, c, d));
 }
 
-template <int W, int D>
-__global__ __launch_bounds__(256, W == 128 ? 1 : 2) void k_wgrad3x3(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, float* __restrict__ acc,
+template <int W, int D, bool X3>
+__global__ __launch_bounds__(256, (W == 128 || X3) ? 1 : 2) void k_wgrad3x3(const void* __restrict__ dY_, const void* __restrict__ X_,
+                                                  float* __restrict__ acc,
                                                   int Co, int Ci, int H, int tiles, int tiles_n, int rows_total, int rows_per_block) {
-    using C = W3Cfg<W, D>;
-    constexpr int R = C::R, PA = C::PA, PX = C::PX, LPT = C::LPT, CPR = W / 8;       // CPR: chunks per row
+    using C = W3Cfg<W, D, X3>;
+    typedef typename std::conditional<X3, float, uint16_t>::type elem_t;
+    const elem_t* dY = reinterpret_cast<const elem_t*>(dY_);
+    const elem_t* X = reinterpret_cast<const elem_t*>(X_);
+    constexpr int R = C::R, PA = C::PA, PX = C::PX, LPA = C::LPA, LPX = C::LPX, CPR = C::CPR, PL = C::PL, BN = C::BN;
+    constexpr int EPC = X3 ? 4 : 8;                       // pixels per 16-byte global chunk
+    constexpr bool KSPLIT = BN == 32;                     // the waves (wr, 0) / (wr, 1) share a 32 x 32 tile and split the K-sub-steps
+    constexpr int A_PLANE = 2 * W3_BM * PA, X_PLANE = R * BN * PX;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-    uint16_t* dYs = lds;                                  // [2][64][PA]
-    uint16_t* Xs = lds + 2 * W3_BM * PA;                  // [R][64][PX]
+    uint16_t* dYs = lds;                                  // [PL][2][64][PA]
+    uint16_t* Xs = lds + PL * A_PLANE;                    // [PL][R][BN][PX]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv >> 1, wc = wv & 1;
     // XCD-aware decode (as conv1x1_wgrad.hip): the tiles that stream the same rows of dY / X share an XCD's L2
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int tile = q % tiles, slice = (q / tiles) * 8 + xcd;
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * W3_BM, n0 = tn * W3_BN;
+    const int m0 = tm * W3_BM, n0 = tn * BN;
     const int g0 = slice * rows_per_block, g1 = min(rows_total, g0 + rows_per_block);
     if (g0 >= g1) return;
 
     // zero the pad / halo words of every X row once (data stores never touch them)
-    for (int i = tid; i < R * W3_BN; i += 256) {
+    for (int i = tid; i < PL * R * BN; i += 256) {
         uint16_t* row = Xs + (size_t)i * PX;
         *reinterpret_cast<uint4*>(row) = make_uint4(0, 0, 0, 0);
         *reinterpret_cast<uint4*>(row + 8 + W) = make_uint4(0, 0, 0, 0);
         *reinterpret_cast<uint4*>(row + 16 + W) = make_uint4(0, 0, 0, 0);
     }
 
-    // this thread's chunks of a staged 64-row set: (row, 8 pixels)
-    int srow[LPT], sc8[LPT];
-#pragma unroll
-    for (int i = 0; i < LPT; ++i) {
-        const int id = tid + 256 * i;
-        srow[i] = id / CPR;
-        sc8[i] = (id - srow[i] * CPR) * 8;
-    }
     const size_t HW = (size_t)H * W;
     auto load_dy = [&](int n, int y, uint4* st) {
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int m = m0 + srow[i];
-            st[i] = m < Co ? *reinterpret_cast<const uint4*>(dY + ((size_t)n * Co + m) * HW + (size_t)y * W + sc8[i]) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < LPA; ++i) {
+            const int id = tid + 256 * i, row = id / CPR, c = (id - row * CPR) * EPC, m = m0 + row;
+            st[i] = m < Co ? *reinterpret_cast<const uint4*>(dY + ((size_t)n * Co + m) * HW + (size_t)y * W + c) : make_uint4(0, 0, 0, 0);
         }
     };
     auto load_x = [&](int n, int y, uint4* st) {             // rows outside the image: zeros
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int c = n0 + srow[i];
-            st[i] = (c < Ci && y >= 0 && y < H) ? *reinterpret_cast<const uint4*>(X + ((size_t)n * Ci + c) * HW + (size_t)y * W + sc8[i])
-                                                : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < LPX; ++i) {
+            const int id = tid + 256 * i, row = id / CPR, c = (id - row * CPR) * EPC, ch = n0 + row;
+            st[i] = (ch < Ci && y >= 0 && y < H) ? *reinterpret_cast<const uint4*>(X + ((size_t)n * Ci + ch) * HW + (size_t)y * W + c)
+                                                 : make_uint4(0, 0, 0, 0);
         }
     };
     auto slot_of = [&](int y) { return (y + 2 * R) % R; };
+    // one staged chunk -> LDS: bfloat16 as loaded (16 bytes), float32 split into its hi / lo halves (8 bytes into each plane)
+    auto put = [&](uint16_t* dst, int plane_el, uint4 v) {
+        if (X3) {
+            uint2 hi, lo;
+            aadg_split4(make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)), hi, lo);
+            *reinterpret_cast<uint2*>(dst) = hi;
+            *reinterpret_cast<uint2*>(dst + plane_el) = lo;
+        } else {
+            *reinterpret_cast<uint4*>(dst) = v;
+        }
+    };
     auto store_x = [&](int y, const uint4* st) {
-        uint16_t* base = Xs + (size_t)slot_of(y) * W3_BN * PX;
+        uint16_t* base = Xs + (size_t)slot_of(y) * BN * PX;
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) *reinterpret_cast<uint4*>(base + srow[i] * PX + 8 + sc8[i]) = st[i];
+        for (int i = 0; i < LPX; ++i) {
+            const int id = tid + 256 * i, row = id / CPR, c = (id - row * CPR) * EPC;
+            put(base + row * PX + 8 + c, X_PLANE, st[i]);
+        }
     };
     auto store_dy = [&](int buf, const uint4* st) {
         uint16_t* base = dYs + (size_t)buf * W3_BM * PA;
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) *reinterpret_cast<uint4*>(base + srow[i] * PA + sc8[i]) = st[i];
+        for (int i = 0; i < LPA; ++i) {
+            const int id = tid + 256 * i, row = id / CPR, c = (id - row * CPR) * EPC;
+            put(base + row * PA + c, A_PLANE, st[i]);
+        }
     };
 
     f32x16 d[9];
@@ -110,9 +135,9 @@ __global__ __launch_bounds__(256, W == 128 ? 1 : 2) void k_wgrad3x3(const uint16
 #pragma unroll
         for (int r = 0; r < 16; ++r) d[t][r] = 0.0f;
 
-    const int a_row = wr * 32 + (lane & 31), b_row = wc * 32 + (lane & 31), koff = (lane >> 5) * 8;
+    const int a_row = wr * 32 + (lane & 31), b_row = (KSPLIT ? 0 : wc * 32) + (lane & 31), koff = (lane >> 5) * 8;
     const bool hi_half = lane >= 32;
-    uint4 sdy[LPT], sx[LPT];
+    uint4 sdy[LPA], sx[LPX];
     int buf = 0;
     for (int g = g0; g < g1; ++g) {
         const int n = g / H, y = g - n * H;
@@ -136,52 +161,78 @@ __global__ __launch_bounds__(256, W == 128 ? 1 : 2) void k_wgrad3x3(const uint16
         const uint16_t* ab = dYs + (size_t)buf * W3_BM * PA + a_row * PA + koff;
         const uint16_t* xb[3];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) xb[kh] = Xs + ((size_t)slot_of(y + (kh - 1) * D) * W3_BN + b_row) * PX + 8 + koff;
+        for (int kh = 0; kh < 3; ++kh) xb[kh] = Xs + ((size_t)slot_of(y + (kh - 1) * D) * BN + b_row) * PX + 8 + koff;
         // The 8 pixels of a lane's fragment are followed (lanes < 32) / preceded (lanes >= 32) by the fragment of lane ^ 32 of the same
         // sub-step, and preceded / followed by that lane's fragment of the previous / next sub-step: the two neighbour words of the
         // shifted taps come from v_permlane32_swap instead of two 4-byte LDS reads per fragment (64 lanes on 16 banks: 4-way
         // conflicts -- SQ_LDS_BANK_CONFLICT was 4x the forward kernel's).  The row ends are the zero padding columns.
         constexpr int KS = W / 16;
-        bf16x8 a[KS];
+        constexpr int KS_LO = 0, KS_N = KSPLIT ? KS / 2 : KS;      // this wave's sub-steps: [ks0, ks0 + KS_N)
+        const int ks0 = KSPLIT ? wc * (KS / 2) : KS_LO;
+        bf16x8 a[PL][KS_N];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ab + ks * 16));
+        for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+            for (int j = 0; j < KS_N; ++j)
+                a[pl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ab + pl * A_PLANE + (ks0 + j) * 16));
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-            uint4 cur[KS];
-            uint32_t w_up[KS], w_lo[KS], x_up[KS], x_lo[KS];     // partner's last / first word, as seen by the upper / lower half
+            // fragments of the three horizontal taps, per plane: f[pl][kw][j]
+            bf16x8 f0[PL][KS_N], f1[PL][KS_N], f2[PL][KS_N];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) cur[ks] = *reinterpret_cast<const uint4*>(xb[kh] + ks * 16);
+            for (int pl = 0; pl < PL; ++pl) {
+                // sub-steps ks0 - 1 .. ks0 + KS_N (clamped to the row): the neighbours' edge words come from them
+                uint4 cur[KS_N + 2];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const auto rw = __builtin_amdgcn_permlane32_swap(cur[ks].w, cur[ks].w, false, false);
-                const auto rx = __builtin_amdgcn_permlane32_swap(cur[ks].x, cur[ks].x, false, false);
-                w_up[ks] = rw[0]; w_lo[ks] = rw[1];              // [0]: lanes >= 32 hold the lower half's value; [1]: lanes < 32 the upper half's
-                x_up[ks] = rx[0]; x_lo[ks] = rx[1];
+                for (int j = 0; j < KS_N + 2; ++j) {
+                    const int ks = ks0 + j - 1;
+                    cur[j] = (ks >= 0 && ks < KS) ? *reinterpret_cast<const uint4*>(xb[kh] + pl * X_PLANE + ks * 16) : make_uint4(0, 0, 0, 0);
+                }
+                uint32_t w_up[KS_N + 2], w_lo[KS_N + 2], x_up[KS_N + 2], x_lo[KS_N + 2];     // partner's last / first word, as seen by the upper / lower half
+#pragma unroll
+                for (int j = 0; j < KS_N + 2; ++j) {
+                    const auto rw = __builtin_amdgcn_permlane32_swap(cur[j].w, cur[j].w, false, false);
+                    const auto rx = __builtin_amdgcn_permlane32_swap(cur[j].x, cur[j].x, false, false);
+                    w_up[j] = rw[0]; w_lo[j] = rw[1];            // [0]: lanes >= 32 hold the lower half's value; [1]: lanes < 32 the upper half's
+                    x_up[j] = rx[0]; x_lo[j] = rx[1];
+                }
+#pragma unroll
+                for (int j = 0; j < KS_N; ++j) {
+                    // (an out-of-row neighbour sub-step was loaded as zeros: the padding columns)
+                    const uint32_t prv = hi_half ? w_up[j + 1] : w_lo[j];
+                    const uint32_t nxt = hi_half ? x_up[j + 2] : x_lo[j + 1];
+                    const uint4 c = cur[j + 1];
+                    if (D == 1) {
+                        const uint32_t s1 = __builtin_amdgcn_alignbit(c.y, c.x, 16), s2 = __builtin_amdgcn_alignbit(c.z, c.y, 16),
+                                       s3 = __builtin_amdgcn_alignbit(c.w, c.z, 16);
+                        f0[pl][j] = frag(__builtin_amdgcn_alignbit(c.x, prv, 16), s1, s2, s3);            // X[p - 1]
+                        f2[pl][j] = frag(s1, s2, s3, __builtin_amdgcn_alignbit(nxt, c.w, 16));            // X[p + 1]
+                    } else {
+                        f0[pl][j] = frag(prv, c.x, c.y, c.z);                                             // X[p - 2]
+                        f2[pl][j] = frag(c.y, c.z, c.w, nxt);                                             // X[p + 2]
+                    }
+                    f1[pl][j] = __builtin_bit_cast(bf16x8, c);
+                }
             }
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const uint32_t prv = hi_half ? w_up[ks] : (ks > 0 ? w_lo[ks - 1] : 0u);
-                const uint32_t nxt = hi_half ? (ks + 1 < KS ? x_up[ks + 1] : 0u) : x_lo[ks];
-                const uint4 c = cur[ks];
-                bf16x8 f0, f2;
-                if (D == 1) {
-                    const uint32_t s1 = __builtin_amdgcn_alignbit(c.y, c.x, 16), s2 = __builtin_amdgcn_alignbit(c.z, c.y, 16),
-                                   s3 = __builtin_amdgcn_alignbit(c.w, c.z, 16);
-                    f0 = frag(__builtin_amdgcn_alignbit(c.x, prv, 16), s1, s2, s3);            // X[p - 1]
-                    f2 = frag(s1, s2, s3, __builtin_amdgcn_alignbit(nxt, c.w, 16));            // X[p + 1]
-                } else {
-                    f0 = frag(prv, c.x, c.y, c.z);                                             // X[p - 2]
-                    f2 = frag(c.y, c.z, c.w, nxt);                                             // X[p + 2]
+            for (int j = 0; j < KS_N; ++j) {
+                if (X3) {
+                    d[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PL - 1][j], f0[0][j], d[kh * 3 + 0], 0, 0, 0);
+                    d[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][j], f0[PL - 1][j], d[kh * 3 + 0], 0, 0, 0);
+                    d[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PL - 1][j], f1[0][j], d[kh * 3 + 1], 0, 0, 0);
+                    d[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][j], f1[PL - 1][j], d[kh * 3 + 1], 0, 0, 0);
+                    d[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PL - 1][j], f2[0][j], d[kh * 3 + 2], 0, 0, 0);
+                    d[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][j], f2[PL - 1][j], d[kh * 3 + 2], 0, 0, 0);
                 }
-                d[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], f0, d[kh * 3 + 0], 0, 0, 0);
-                d[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], __builtin_bit_cast(bf16x8, c), d[kh * 3 + 1], 0, 0, 0);
-                d[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], f2, d[kh * 3 + 2], 0, 0, 0);
+                d[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][j], f0[0][j], d[kh * 3 + 0], 0, 0, 0);
+                d[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][j], f1[0][j], d[kh * 3 + 1], 0, 0, 0);
+                d[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][j], f2[0][j], d[kh * 3 + 2], 0, 0, 0);
             }
         }
         buf ^= 1;
     }
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int nn = n0 + wc * 32 + (lane & 31);
+    const int nn = n0 + (KSPLIT ? 0 : wc * 32) + (lane & 31);
     if (nn < Ci) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -361,10 +412,10 @@ int launch_s2(const uint16_t* dY, const uint16_t* X, float* acc, int N, int Co, 
     return 0;
 }
 
-template <int W, int D>
-int launch(const uint16_t* dY, const uint16_t* X, float* acc, int N, int Co, int Ci, int H, hipStream_t st) {
-    using C = W3Cfg<W, D>;
-    const int tiles_m = (Co + W3_BM - 1) / W3_BM, tiles_n = (Ci + W3_BN - 1) / W3_BN, tiles = tiles_m * tiles_n;
+template <int W, int D, bool X3>
+int launch(const void* dY, const void* X, float* acc, int N, int Co, int Ci, int H, hipStream_t st) {
+    using C = W3Cfg<W, D, X3>;
+    const int tiles_m = (Co + W3_BM - 1) / W3_BM, tiles_n = (Ci + C::BN - 1) / C::BN, tiles = tiles_m * tiles_n;
     const long long rows_total = (long long)N * H;
     // Every workgroup ends with 9 x 64 x 64 float atomics (the cost of ~1000 MFMAs), so: ~512 workgroups (two per CU), and never fewer
     // than 1152 MFMAs per wave (18 images per rank: 1.93 -> 1.20 ms over the backbone's 14 convolutions; 144 images: 5.5 -> 5.1)
@@ -376,13 +427,13 @@ int launch(const uint16_t* dY, const uint16_t* X, float* acc, int N, int Co, int
     slices = (rows_total + rpb - 1) / rpb;
     static bool attr_set = false;                            // per instantiation; idempotent
     if (!attr_set) {
-        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3<W, D>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3<W, D, X3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::lds_bytes));
         attr_set = true;
     }
     AADG_HIP_TRY(hipMemsetAsync(acc, 0, (size_t)9 * Co * Ci * sizeof(float), st));
     const long long slice_groups = (slices + 7) / 8;          // slices are padded to a multiple of 8 (empty ones exit at once)
-    hipLaunchKernelGGL((k_wgrad3x3<W, D>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(256), C::lds_bytes, st, dY, X, acc, Co, Ci, H,
+    hipLaunchKernelGGL((k_wgrad3x3<W, D, X3>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(256), C::lds_bytes, st, dY, X, acc, Co, Ci, H,
                        tiles, tiles_n, (int)rows_total, (int)rpb);
     AADG_LAUNCH_CHECK();
     return 0;
@@ -394,23 +445,38 @@ extern "C" int aadg_conv3x3_wgrad_supported(int Co, int Ci, int H, int W, int di
     return Co > 0 && Ci > 0 && H > 0 && (W == 32 || W == 64 || W == 128) && (dilation == 1 || dilation == 2) ? 1 : 0;
 }
 
+namespace {
+template <bool X3>
+int wgrad3x3_dispatch(const void* a, const void* b, float* dweight9, int N, int Co, int Ci, int H, int W, int dilation, hipStream_t st) {
+    if (dilation == 1) {
+        if (W == 32) return launch<32, 1, X3>(a, b, dweight9, N, Co, Ci, H, st);
+        if (W == 64) return launch<64, 1, X3>(a, b, dweight9, N, Co, Ci, H, st);
+        return launch<128, 1, X3>(a, b, dweight9, N, Co, Ci, H, st);
+    }
+    if (W == 32) return launch<32, 2, X3>(a, b, dweight9, N, Co, Ci, H, st);
+    if (W == 64) return launch<64, 2, X3>(a, b, dweight9, N, Co, Ci, H, st);
+    if (X3) return AADG_E_UNSUPPORTED;                            // (both planes of a 128-pixel ring of six rows exceed the LDS)
+    return launch<128, 2, false>(a, b, dweight9, N, Co, Ci, H, st);
+}
+}  // namespace
+
 // dweight9: float32 [9][Co][Ci] (tap kh * 3 + kw major); the caller permutes it into [Co][Ci][3][3]
 extern "C" int aadg_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dweight9, int N, int Co, int Ci, int H, int W, int dilation,
                                        void* stream) {
     if (dy == nullptr || x == nullptr || dweight9 == nullptr || N <= 0) return AADG_E_BADARG;
     if ((((uintptr_t)dy | (uintptr_t)x) & 15u) != 0) return AADG_E_BADARG;
     if (!aadg_conv3x3_wgrad_supported(Co, Ci, H, W, dilation) || (long long)N * H > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    const uint16_t* a = (const uint16_t*)dy;
-    const uint16_t* b = (const uint16_t*)x;
-    if (dilation == 1) {
-        if (W == 32) return launch<32, 1>(a, b, dweight9, N, Co, Ci, H, st);
-        if (W == 64) return launch<64, 1>(a, b, dweight9, N, Co, Ci, H, st);
-        return launch<128, 1>(a, b, dweight9, N, Co, Ci, H, st);
-    }
-    if (W == 32) return launch<32, 2>(a, b, dweight9, N, Co, Ci, H, st);
-    if (W == 64) return launch<64, 2>(a, b, dweight9, N, Co, Ci, H, st);
-    return launch<128, 2>(a, b, dweight9, N, Co, Ci, H, st);
+    return wgrad3x3_dispatch<false>(dy, x, dweight9, N, Co, Ci, H, W, dilation, (hipStream_t)stream);
+}
+
+/* The same weight gradient from float32 NCHW dy / x at float32 precision ("f32x3") */
+extern "C" int aadg_conv3x3_wgrad_f32x3(const float* dy, const float* x, float* dweight9, int N, int Co, int Ci, int H, int W, int dilation,
+                                        void* stream) {
+    if (dy == nullptr || x == nullptr || dweight9 == nullptr || N <= 0) return AADG_E_BADARG;
+    if ((((uintptr_t)dy | (uintptr_t)x) & 15u) != 0) return AADG_E_BADARG;
+    if (!aadg_conv3x3_wgrad_supported(Co, Ci, H, W, dilation) || (W == 128 && dilation == 2) || (long long)N * H > 0x7FFFFFFFLL)
+        return AADG_E_UNSUPPORTED;
+    return wgrad3x3_dispatch<true>(dy, x, dweight9, N, Co, Ci, H, W, dilation, (hipStream_t)stream);
 }
 
 /* stride 2, padding 1, dilation 1: dy [N, Co, Ho, Wo], x [N, Ci, 2 Ho, 2 Wo]; Wo in {32, 64} */

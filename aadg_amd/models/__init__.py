@@ -71,7 +71,9 @@ def load_ddp_model(ngpus_per_node, args, cfg):
     model = build_model(cfg).to(dev)
     if dev.type == 'cuda':
         from . import deeplab
-        deeplab.batch_step_bookkeeping(model)            # weight casts and BatchNorm counters: two launches per forward
+        # weight casts and BatchNorm counters: two launches per forward; backbone_dtype 'f32x3' = float32 tensors, convolutions on the
+        # own float32-precision matrix-core kernels ('fp32': the library's float32 convolutions, 'bf16': bfloat16 autocast)
+        deeplab.batch_step_bookkeeping(model, f32x3=getattr(args, 'backbone_dtype', 'fp32') == 'f32x3')
     sync = bool(getattr(args, 'distributed', False) and getattr(args, 'sync_bn', False))
     if sync:
         # The reference's single-GPU batch mixes all domains in every BatchNorm batch; sharded replicas see only their rows.

@@ -41,11 +41,17 @@ def _bump(bn):
         bn.num_batches_tracked.add_(1)
 
 
-def batch_step_bookkeeping(model):
+def batch_step_bookkeeping(model, f32x3=False):
     """Per-forward bookkeeping of a CUDA model in two launches instead of ~130: the bfloat16 casts of the own convolutions' master
-    weights (a pre-hook: _lib.track_bf16_weights) and the BatchNorm counters of its layers (a post-hook)."""
+    weights (a pre-hook: _lib.track_bf16_weights) and the BatchNorm counters of its layers (a post-hook).
+    f32x3 = True: the model runs on float32 activations (no autocast) and its 1x1 / 3x3 convolutions take the own kernels' float32-
+    precision instantiations (three bfloat16 matrix-core products per pair of (hi, lo)-split operands, _lib.conv1x1_x3 / conv3x3_x3);
+    the tracked shadows are then the (hi, lo) halves of the weights.  False: float32 inputs go to the library's float32 convolutions."""
     from .. import _lib
-    _lib.track_bf16_weights(model, (Conv1x1, Conv3x3))
+    for m in model.modules():
+        if isinstance(m, (Conv1x1, Conv3x3, SeparableConv2d)):
+            m.f32x3 = bool(f32x3)
+    _lib.track_bf16_weights(model, (Conv1x1, Conv3x3), split=bool(f32x3))
     for m in model.modules():
         if type(m) is nn.BatchNorm2d:
             m._aadg_deferred_counter = True
@@ -138,10 +144,23 @@ class Conv1x1(nn.Conv2d):
     GEMMs on NCHW, the weight gradient runs on the matrix cores straight from the NCHW tensors
     (csrc/conv1x1_wgrad.hip) instead of transposing both activations to NHWC first."""
 
+    f32x3 = False           # float32 inputs: the own float32-precision kernels instead of the library's (batch_step_bookkeeping)
+
     def __init__(self, cin, cout, stride=1):
         super().__init__(cin, cout, 1, stride=stride, bias=False)
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and self.f32x3 and self.stride in ((1, 1), (2, 2)):
+            from .. import _lib
+            xc = x.contiguous()
+            if self.stride == (2, 2) and _lib.subsample2x2_supported(xc):
+                xs = _lib.subsample2x2(xc)                   # pick the even pixels (one streaming pass), then the stride-1 kernel
+                if _lib.conv1x1_x3_supported(xs, self.weight):
+                    return _lib.conv1x1_x3(xs, self.weight)
+                return F.conv2d(xs, self.weight)
+            if self.stride == (1, 1) and _lib.conv1x1_x3_supported(xc, self.weight):
+                return _lib.conv1x1_x3(xc, self.weight)
+            return super().forward(x)
         if x.is_cuda and x.dtype == torch.bfloat16 and self.stride in ((1, 1), (2, 2)):
             from .. import _lib
             xc = x.contiguous()
@@ -165,10 +184,19 @@ class Conv3x3(nn.Conv2d):
     zero-fill / cast of a float32 workspace.  Stride 2 (the first block of stages 2 and 3): the weight gradient only (even / odd column
     planes in LDS); forward and input gradient stay the library's."""
 
+    f32x3 = False           # float32 inputs: the own float32-precision kernels instead of the library's (batch_step_bookkeeping)
+
     def __init__(self, cin, cout, stride=1, dilation=1):
         super().__init__(cin, cout, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and self.f32x3:
+            if self.stride == (1, 1):
+                from .. import _lib
+                xc = x.contiguous()
+                if _lib.conv3x3_x3_supported(xc, self.weight, self.dilation[0]):
+                    return _lib.conv3x3_x3(xc, self.weight, self.dilation[0])
+            return super().forward(x)                        # (stride 2: the library's float32 convolution)
         if x.is_cuda and x.dtype == torch.bfloat16 and self.stride == (1, 1):
             from .. import _lib
             xc = x.contiguous()
@@ -219,6 +247,8 @@ class MaxPool3x3s2(nn.MaxPool2d):
 class SeparableConv2d(nn.Sequential):
     """Depthwise 3x3 (dilated) followed by a pointwise convolution, no normalisation in between."""
 
+    f32x3 = False
+
     def __init__(self, cin, cout, k=3, dilation=1):
         assert k == 3
         super().__init__(DepthwiseConv3x3(cin, dilation=dilation), Conv1x1(cin, cout))
@@ -232,6 +262,11 @@ class SeparableConv2d(nn.Sequential):
             # product) instead of streaming the whole activation through a convolution, forward and backward.  The gradient of
             # the eight unused taps is exactly zero either way.
             w = pw.weight * dw.weight[:, 0, 1, 1].view(1, -1, 1, 1)
+            if x.is_cuda and x.dtype == torch.float32 and self.f32x3:
+                from .. import _lib
+                xc = x.contiguous()
+                if _lib.conv1x1_x3_supported(xc, w):
+                    return _lib.conv1x1_x3(xc, w)            # (w is a product, not a tracked parameter: split per call)
             if x.is_cuda and x.dtype == torch.bfloat16:
                 from .. import _lib
                 xc = x.contiguous()

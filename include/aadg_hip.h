@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AADG_ABI_VERSION 7
+#define AADG_ABI_VERSION 8
 #define AADG_MAX_OPS 4
 
 #define AADG_E_BADARG (-1)
@@ -361,6 +361,12 @@ int aadg_dwconv3x3_wgrad(const void* x, const void* dy, float* dweight, int N, i
  * ------------------------------------------------------------------------------------------- */
 int aadg_conv1x1_nchw_supported(int M, int K, int HW);
 int aadg_conv1x1_nchw_bf16(const void* a, const void* in, void* out, int N, int M, int K, int HW, void* stream);
+/* ABI 8 -- "f32x3": the same contraction on float32 NCHW tensors at float32 precision (the reference runs its backbone in float32:
+ * search_dg.py:123-206).  gfx950 has no tf32 and its float32 MFMA runs at 1/16 of the bfloat16 rate, so every operand is split into
+ * bfloat16 halves x = hi + lo (hi = bf16(x), lo = bf16(x - hi); ~2^-17 relative) and every product is formed as hi*hi + hi*lo + lo*hi
+ * on the bfloat16 matrix cores with float32 accumulation: three MFMAs per product = 5.3x the float32-MFMA rate.  a_hi / a_lo [M, K]
+ * bfloat16: the halves of the float32 operand a (aadg_weight_layouts_split_bf16); in / out float32. */
+int aadg_conv1x1_nchw_f32x3(const void* a_hi, const void* a_lo, const float* in, float* out, int N, int M, int K, int HW, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The ResNet stem convolution, forward: y [N, 64, H/2, W/2] = conv2d(x [N, 3, H, W], weight [64, 3, 7, 7], stride 2, padding 3),
@@ -407,6 +413,8 @@ int aadg_maxpool3x3s2_backward(const void* index, const void* dy, void* dx, int 
  * ------------------------------------------------------------------------------------------- */
 int aadg_conv1x1_wgrad_supported(int Co, int Ci, int HW);
 int aadg_conv1x1_wgrad_bf16(const void* dy, const void* x, float* dweight, int N, int Co, int Ci, int HW, void* stream);
+/* ABI 8 -- f32x3 (see aadg_conv1x1_nchw_f32x3): float32 NCHW dy / x, float32 precision; HW a multiple of 32 */
+int aadg_conv1x1_wgrad_f32x3(const float* dy, const float* x, float* dweight, int N, int Co, int Ci, int HW, void* stream);
 
 /* Per-step re-layout of the float32 master weights of the convolutions above, every layer in one launch (csrc/weight_layouts.hip):
  * w [Co][Ci][taps] float32 -> plain [Co][Ci][taps], fwd [taps][Co][Ci], bwd [taps'][Ci][Co] bfloat16 (taps' = taps - 1 - t when flip,
@@ -422,6 +430,9 @@ typedef struct aadg_wl_item {
     int32_t Co, Ci, taps, flip;
 } aadg_wl_item;
 int aadg_weight_layouts_bf16(const aadg_wl_item* items, const int32_t* tiles, int n_tiles, void* stream);
+/* ABI 8: the same layouts as (hi, lo) bfloat16 halves for the f32x3 kernels -- every output buffer holds 2 * Co * Ci * taps elements:
+ * the hi plane first, the lo plane Co * Ci * taps elements behind it */
+int aadg_weight_layouts_split_bf16(const aadg_wl_item* items, const int32_t* tiles, int n_tiles, void* stream);
 
 /* Weight gradient of a 3x3 / stride-1 convolution with padding = dilation (the bottleneck conv2 of the ResNet stages), NCHW bfloat16:
  *     dweight9[kh * 3 + kw][o][c] = sum_{n, y, x} dy[n][o][y][x] * x[n][c][y + (kh - 1) d][x + (kw - 1) d]     (zero outside the image)
@@ -450,6 +461,12 @@ int aadg_conv3x3_nchw_supported(int M, int K, int H, int W, int dilation);
 int aadg_conv3x3_nchw_bf16(const void* a9, const void* in, void* out, int N, int M, int K, int H, int W, int dilation, void* stream);
 int aadg_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dweight9, int N, int Co, int Ci, int H, int W, int dilation,
                             void* stream);
+/* ABI 8 -- f32x3 (see aadg_conv1x1_nchw_f32x3): float32 NCHW tensors, float32 precision; a9_hi / a9_lo [9, M, K] bfloat16 halves of the
+ * tap-major float32 weights.  The weight gradient excludes W = 128 with d = 2 (LDS). */
+int aadg_conv3x3_nchw_f32x3(const void* a9_hi, const void* a9_lo, const float* in, float* out, int N, int M, int K, int H, int W,
+                            int dilation, void* stream);
+int aadg_conv3x3_wgrad_f32x3(const float* dy, const float* x, float* dweight9, int N, int Co, int Ci, int H, int W, int dilation,
+                             void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Policy controller (reference: models/controller.py:9-145) and its PPO update (losses.py:117-157) as fused kernels.

@@ -30,7 +30,9 @@ def parse_args(argv=None):
     parser.add_argument('--output_type', default='image', type=str)
     parser.add_argument('--seed', default=1023, type=int)
     parser.add_argument('--crop_size', default=256, type=int)
-    parser.add_argument('--backbone_dtype', default='fp32', choices=['fp32', 'bf16'])
+    parser.add_argument('--backbone_dtype', default='fp32', choices=['fp32', 'f32x3', 'bf16'],
+                        help="fp32: the library's float32 convolutions; f32x3: float32 tensors, own float32-precision matrix-core kernels; "
+                             "bf16: bfloat16 autocast (narrower than the reference)")
     parser.add_argument('--sync_bn', action='store_true', help='SyncBatchNorm over the row-sharded ranks')
     parser.add_argument('--placement', default='unit', choices=['unit', 'row'],
                         help='multi-GPU: whole (domain, policy) units per rank (SURVEY 8e) or the same sequence balanced to the row')

@@ -1,0 +1,138 @@
+"""GPU: the float32-precision ("f32x3") instantiations of the convolution kernels -- float32 NCHW tensors, every product formed as three
+bfloat16 matrix-core products of the (hi, lo) halves of both operands with float32 accumulation (csrc/conv1x1_fwd.hip, conv1x1_wgrad.hip,
+conv3x3_fwd.hip, conv3x3_wgrad.hip: X3; csrc/weight_layouts.hip: SPLIT) -- against float64 convolutions of the same float32 tensors, with
+the library's float32 result as the yardstick: the own kernels must be float32-grade (1e-5 of the output's scale; a bfloat16 product is
+4e-3), which is what lets the backbone run at the reference's precision (search_dg.py:123-206) on the bfloat16 matrix cores."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5            # of max |reference|: float32-grade (hi + lo carries ~17 mantissa bits; float32 accumulation as in the library)
+
+
+def _err(got, want64):
+    return (got.double() - want64).abs().max().item() / max(want64.abs().max().item(), 1e-30)
+
+
+def _split(hip, w):
+    return hip.split_weight(w)
+
+
+@pytest.mark.parametrize("N,K,M,H,W", [
+    (2, 64, 256, 32, 32), (1, 256, 64, 64, 64),            # bottleneck conv3 / conv1 shapes
+    (2, 304, 256, 32, 64), (1, 256, 48, 32, 32),           # decoder: K not a multiple of the K-step, M below the tile
+    (1, 24, 72, 8, 32), (3, 2048, 256, 16, 16),            # K < one K-step, M not a multiple of 32; the long reduction of ASPP
+    (1, 64, 64, 128, 128),
+])
+def test_conv1x1_x3_forward(hip, N, K, M, H, W):
+    torch.manual_seed(K + M)
+    x = torch.randn(N, K, H, W, device="cuda")
+    w = torch.randn(M, K, device="cuda") / K ** 0.5
+    got = hip.conv1x1_nchw_x3(_split(hip, w), x)
+    want = F.conv2d(x.double(), w.double()[:, :, None, None])
+    lib = F.conv2d(x, w[:, :, None, None])
+    assert got.dtype == torch.float32 and got.shape == lib.shape
+    assert _err(got, want) <= TOL, (_err(got, want), _err(lib, want))
+
+
+@pytest.mark.parametrize("N,Co,Ci,H,W", [
+    (2, 256, 64, 32, 32), (3, 64, 256, 64, 64), (2, 48, 256, 32, 32), (1, 512, 512, 32, 32), (5, 96, 40, 8, 32), (2, 64, 64, 128, 128),
+])
+def test_conv1x1_x3_wgrad(hip, N, Co, Ci, H, W):
+    torch.manual_seed(Co + Ci)
+    x = torch.randn(N, Ci, H, W, device="cuda")
+    dy = torch.randn(N, Co, H, W, device="cuda")
+    got = hip.conv1x1_wgrad_x3(dy, x)
+    want = torch.einsum("nohw,nchw->oc", dy.double(), x.double())
+    assert got.dtype == torch.float32 and tuple(got.shape) == (Co, Ci)
+    assert _err(got, want) <= TOL, _err(got, want)
+
+
+@pytest.mark.parametrize("N,K,M,H,W,d", [
+    (2, 64, 64, 32, 32, 1), (2, 64, 128, 32, 32, 2), (1, 128, 64, 64, 64, 1), (1, 64, 64, 48, 128, 1), (1, 64, 64, 20, 64, 2),
+    (2, 24, 72, 7, 32, 1),                                  # K below one K-step, M not a multiple of the tile, a partial row tile
+])
+def test_conv3x3_x3_forward_and_input_gradient(hip, N, K, M, H, W, d):
+    torch.manual_seed(K + M + d)
+    x = torch.randn(N, K, H, W, device="cuda")
+    w = torch.randn(M, K, 3, 3, device="cuda") / (9 * K) ** 0.5
+    a9 = _split(hip, w.permute(2, 3, 0, 1).reshape(9, M, K).contiguous())
+    got = hip.conv3x3_nchw_x3(a9, x, d)
+    want = F.conv2d(x.double(), w.double(), padding=d, dilation=d)
+    assert got.dtype == torch.float32
+    assert _err(got, want) <= TOL, _err(got, want)
+    # input gradient = the same kernel on dy with mirrored taps and swapped channel roles
+    dy = torch.randn(N, M, H, W, device="cuda")
+    a9t = _split(hip, w.flip(2, 3).permute(2, 3, 1, 0).reshape(9, K, M).contiguous())
+    if M % 8 == 0:
+        dx = hip.conv3x3_nchw_x3(a9t, dy, d)
+        want_dx = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, [1, 1], [d, d], [d, d], False, [0, 0], 1,
+                                                      [True, False, False])[0]
+        assert _err(dx, want_dx) <= TOL, _err(dx, want_dx)
+
+
+@pytest.mark.parametrize("N,Co,Ci,H,W,d", [
+    (2, 64, 64, 32, 32, 1), (3, 64, 64, 32, 32, 2), (2, 128, 64, 64, 64, 1), (1, 64, 128, 64, 64, 2), (2, 64, 64, 128, 128, 1),
+    (2, 96, 40, 20, 32, 1), (2, 40, 96, 7, 64, 2), (1, 64, 72, 16, 128, 1), (19, 64, 64, 32, 32, 1),
+])
+def test_conv3x3_x3_wgrad(hip, N, Co, Ci, H, W, d):
+    torch.manual_seed(N * 100 + Co + W)
+    x = torch.randn(N, Ci, H, W, device="cuda")
+    dy = torch.randn(N, Co, H, W, device="cuda")
+    got = hip.conv3x3_wgrad_x3(dy, x, d)
+    w0 = torch.zeros(Co, Ci, 3, 3, device="cuda", dtype=torch.float64)
+    want = torch.ops.aten.convolution_backward(dy.double(), x.double(), w0, None, [1, 1], [d, d], [d, d], False, [0, 0], 1,
+                                               [False, True, False])[1]
+    assert tuple(got.shape) == (Co, Ci, 3, 3) and got.dtype == torch.float32
+    assert _err(got, want) <= TOL, _err(got, want)
+
+
+def test_split_layouts_of_tracked_weights(hip):
+    """aadg_weight_layouts_split_bf16 through track_bf16_weights(split=True): hi + lo reproduces the float32 weight to ~2^-17, in the
+    plain, tap-major and transposed (mirrored) layouts the kernels read."""
+    from aadg_amd.models.deeplab import Conv1x1, Conv3x3
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(Conv1x1(40, 72), Conv3x3(72, 64, 1, 2)).cuda()
+    assert hip.track_bf16_weights(net, (Conv1x1, Conv3x3), split=True) == 2
+    hip.refresh_bf16_weights(net)
+    for m in net:
+        w = m.weight.detach()
+        Co, Ci, T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+        want = hip.split_weight(w)
+        plain = hip.split_layout(m.weight, "plain")
+        assert torch.equal(plain, want)
+        assert ((plain[0].float() + plain[1].float()) - w).abs().max().item() <= 2.0 ** -16 * w.abs().max().item()
+        fwd, bwd = hip.split_layout(m.weight, "fwd"), hip.split_layout(m.weight, "bwd")
+        assert torch.equal(fwd, want.permute(0, 3, 4, 1, 2).reshape(2, T, Co, Ci))
+        wb = want.flip(3, 4) if T == 9 else want                    # the stride-1 3x3 input gradient reads mirrored taps
+        assert torch.equal(bwd, wb.permute(0, 3, 4, 2, 1).reshape(2, T, Ci, Co))
+        assert hip.weight_layout(m.weight, "fwd") is None            # split shadows are not served as plain bfloat16 casts
+    hip.release_bf16_weights(net)
+    assert hip.split_layout(net[0].weight, "plain") is None
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_modules_in_f32x3_mode_equal_float32_convolutions(hip, stride):
+    """Conv1x1 / Conv3x3 / the folded SeparableConv2d with f32x3 set, forward and both gradients, against float64 autograd."""
+    from aadg_amd.models import deeplab as DL
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(DL.Conv1x1(64, 128, stride), DL.Conv3x3(128, 128, 1, 2), DL.Conv1x1(128, 64)).cuda()
+    DL.batch_step_bookkeeping(net, f32x3=True)
+    ref = torch.nn.Sequential(torch.nn.Conv2d(64, 128, 1, stride, bias=False), torch.nn.Conv2d(128, 128, 3, padding=2, dilation=2, bias=False),
+                              torch.nn.Conv2d(128, 64, 1, bias=False)).cuda().double()
+    ref.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    x1 = torch.randn(2, 64, 64 * stride, 32 * stride, device="cuda", requires_grad=True)
+    x2 = x1.detach().double().requires_grad_(True)
+    y1, y2 = net(x1), ref(x2)
+    assert y1.dtype == torch.float32 and _err(y1, y2.detach()) <= 3 * TOL
+    g = torch.randn_like(y1)
+    y1.backward(g)
+    y2.backward(g.double())
+    assert _err(x1.grad, x2.grad) <= 3 * TOL
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert a.grad.dtype == torch.float32 and _err(a.grad, b.grad) <= 3 * TOL
+    # a float32 input with f32x3 off goes to the library (no own kernel), a bfloat16 one still to the bfloat16 kernels
+    off = DL.Conv1x1(64, 64).cuda()
+    assert off(x1.detach()[:, :, :32, :32]).dtype == torch.float32
