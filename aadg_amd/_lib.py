@@ -57,7 +57,7 @@ EXPORTS = [
     "aadg_upsample_sum", "aadg_upsample_sum_backward",
     "aadg_weight_layouts_bf16",
     "aadg_weight_layouts_split_bf16", "aadg_conv1x1_nchw_f32x3", "aadg_conv1x1_wgrad_f32x3", "aadg_conv3x3_nchw_f32x3",
-    "aadg_conv3x3_wgrad_f32x3",
+    "aadg_conv3x3_wgrad_f32x3", "aadg_conv3x3s2_nchw_f32x3", "aadg_conv3x3s2_dgrad_f32x3", "aadg_conv3x3s2_wgrad_f32x3",
 ]
 
 _lib = None
@@ -248,6 +248,12 @@ def load():
     lib.aadg_conv3x3_nchw_f32x3.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
     lib.aadg_conv3x3_wgrad_f32x3.restype = _i
     lib.aadg_conv3x3_wgrad_f32x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
+    lib.aadg_conv3x3s2_nchw_f32x3.restype = _i
+    lib.aadg_conv3x3s2_nchw_f32x3.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
+    lib.aadg_conv3x3s2_dgrad_f32x3.restype = _i
+    lib.aadg_conv3x3s2_dgrad_f32x3.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
+    lib.aadg_conv3x3s2_wgrad_f32x3.restype = _i
+    lib.aadg_conv3x3s2_wgrad_f32x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     if lib.aadg_abi_version() != 8:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
@@ -2048,6 +2054,66 @@ def conv3x3_x3(x, weight, dilation=1):
     if not conv3x3_x3_supported(x, weight, dilation):
         raise AadgError("conv3x3_x3: unsupported shape / dtype / layout")
     return _Conv3x3X3.apply(x, weight, int(dilation))
+
+
+class _Conv3x3S2X3(torch.autograd.Function):
+    """3x3 / stride-2 / padding-1 convolution without bias on NCHW float32 activations at float32 precision: forward
+    (csrc/conv3x3_s2_fwd.hip), input gradient (csrc/conv3x3_s2_dgrad.hip: four parity classes) and weight gradient
+    (csrc/conv3x3_wgrad.hip: k_wgrad3x3_s2), all X3.  `weight` is the float32 parameter."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        lib = load()
+        Co, Ci = weight.shape[0], weight.shape[1]
+        N, _, H, W = x.shape
+        a9 = split_layout(weight, "fwd")
+        if a9 is None:
+            a9 = split_weight(weight.detach().permute(2, 3, 0, 1).reshape(9, Co, Ci).contiguous())
+        ctx.save_for_backward(x, weight)
+        ctx.a9t = _ShadowRef(weight, "bwd", split=True)
+        out = torch.empty((N, Co, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        _check(lib.aadg_conv3x3s2_nchw_f32x3(a9[0].data_ptr(), a9[1].data_ptr(), x.data_ptr(), out.data_ptr(), N, Co, Ci, H // 2, W // 2,
+                                             _stream()), "aadg_conv3x3s2_nchw_f32x3")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load()
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        Co, Ci = weight.shape[0], weight.shape[1]
+        N, _, Ho, Wo = dy.shape
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            a9t = ctx.a9t.get()                              # stride 2: taps NOT mirrored ([9, Ci, Co], a9t[t][c][m] = w[m][c][t])
+            if a9t is None:
+                a9t = split_weight(weight.detach().permute(2, 3, 1, 0).reshape(9, Ci, Co).contiguous())
+            dx = torch.empty_like(x)
+            _check(lib.aadg_conv3x3s2_dgrad_f32x3(a9t[0].data_ptr(), a9t[1].data_ptr(), dy.data_ptr(), dx.data_ptr(), N, Ci, Co, Ho, Wo,
+                                                  _stream()), "aadg_conv3x3s2_dgrad_f32x3")
+        if ctx.needs_input_grad[1]:
+            dw9 = torch.empty((9, Co, Ci), dtype=torch.float32, device=x.device)
+            _check(lib.aadg_conv3x3s2_wgrad_f32x3(dy.data_ptr(), x.data_ptr(), dw9.data_ptr(), N, Co, Ci, Ho, Wo, _stream()),
+                   "aadg_conv3x3s2_wgrad_f32x3")
+            dw = dw9.permute(1, 2, 0).reshape(Co, Ci, 3, 3)
+        return dx, dw
+
+
+def conv3x3s2_x3_supported(x, weight):
+    lib = load()
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous() and weight.dtype == torch.float32 and
+            tuple(weight.shape[2:]) == (3, 3) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0):
+        return False
+    Co, Ci, Ho, Wo = weight.shape[0], weight.shape[1], x.shape[2] // 2, x.shape[3] // 2
+    return bool(lib.aadg_conv3x3s2_nchw_supported(Co, Ci, Ho, Wo) and lib.aadg_conv3x3s2_dgrad_supported(Ci, Co, Ho, Wo) and
+                lib.aadg_conv3x3s2_wgrad_supported(Co, Ci, Ho, Wo))
+
+
+def conv3x3s2_x3(x, weight):
+    _require_cuda(x, weight)
+    if not conv3x3s2_x3_supported(x, weight):
+        raise AadgError("conv3x3s2_x3: unsupported shape / dtype / layout")
+    return _Conv3x3S2X3.apply(x, weight)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -23,7 +23,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int CF_BK = 64, CF_BP = 256;
-constexpr int CF_APITCH = CF_BK + 8;            // A rows: 144 bytes (conflict-free 16-byte fragment reads)
 constexpr int CF_BPITCH = CF_BP + 16;           // B rows: 544 bytes = 32 (mod 256): the 4 rows of a transpose read hit distinct banks
 
 __device__ __forceinline__ u32x2 lds_read_tr16(const uint16_t* p) {
@@ -49,7 +48,11 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
     constexpr int LA = BM * AC * PL / 256;                                 // A chunks per thread and K-step
     constexpr int LB = X3 ? BK * (CF_BP / 4) / 256 : BK * (CF_BP / 8) / 256;   // IN chunks (16 bytes: 4 float32 / 8 bfloat16 pixels)
     __shared__ __attribute__((aligned(16))) uint16_t As[PL * BM * APITCH];
-    __shared__ __attribute__((aligned(16))) uint16_t Bs[PL * BK * CF_BPITCH];
+    // B pitch.  bfloat16 kernel: 544 bytes.  X3: 576 bytes = 16 banks per row step -- a transpose read serves 32 lanes per LDS cycle (4 rows x
+    // two 16-column halves): with 8 banks per row step the second half of row r collides with the first half of row r + 1
+    // (SQ_LDS_BANK_CONFLICT was 36 % of SQ_LDS_IDX_ACTIVE); with 16 the 32 lanes cover the 64 banks exactly
+    constexpr int BPITCH = X3 ? CF_BP + 32 : CF_BPITCH;
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[PL * BK * BPITCH];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv / WC, wc = wv - wr * WC;
     // grid: pixel tile fastest, then output-channel tile, then image: the workgroups that share an IN tile are neighbours
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
     const int g = lane >> 5, i16 = lane & 15, gi = (lane >> 4) & 1;
     const uint16_t* a_base = As + (wr * 32 * MI + (lane & 31)) * APITCH + 8 * g;
     // transpose-read address of this lane: row (8 g + i16 / 4) of the K-sub-step, columns 16 gi + 4 (i16 % 4) of the N tile
-    const uint16_t* b_base = Bs + (8 * g + (i16 >> 2)) * CF_BPITCH + wc * 32 * NI + 16 * gi + 4 * (i16 & 3);
+    const uint16_t* b_base = Bs + (8 * g + (i16 >> 2)) * BPITCH + wc * 32 * NI + 16 * gi + 4 * (i16 & 3);
 
     fetch(0);
     for (int k0 = 0; k0 < K; k0 += BK) {
@@ -108,11 +111,11 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
                 uint2 hi, lo;
                 aadg_split4(make_float4(__uint_as_float(rb[i].x), __uint_as_float(rb[i].y), __uint_as_float(rb[i].z), __uint_as_float(rb[i].w)),
                             hi, lo);
-                uint16_t* dst = Bs + (id >> 6) * CF_BPITCH + (id & 63) * 4;
+                uint16_t* dst = Bs + (id >> 6) * BPITCH + (id & 63) * 4;
                 *reinterpret_cast<uint2*>(dst) = hi;
-                *reinterpret_cast<uint2*>(dst + BK * CF_BPITCH) = lo;
+                *reinterpret_cast<uint2*>(dst + BK * BPITCH) = lo;
             } else {
-                *reinterpret_cast<uint4*>(Bs + (id >> 5) * CF_BPITCH + (id & 31) * 8) = rb[i];
+                *reinterpret_cast<uint4*>(Bs + (id >> 5) * BPITCH + (id & 31) * 8) = rb[i];
             }
         }
         __syncthreads();
@@ -130,8 +133,8 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
             for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    lo[pl][ni] = lds_read_tr16(b_base + pl * BK * CF_BPITCH + (16 * ks) * CF_BPITCH + 32 * ni);
-                    hi[pl][ni] = lds_read_tr16(b_base + pl * BK * CF_BPITCH + (16 * ks + 4) * CF_BPITCH + 32 * ni);
+                    lo[pl][ni] = lds_read_tr16(b_base + pl * BK * BPITCH + (16 * ks) * BPITCH + 32 * ni);
+                    hi[pl][ni] = lds_read_tr16(b_base + pl * BK * BPITCH + (16 * ks + 4) * BPITCH + 32 * ni);
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // the transpose reads are opaque to the compiler's wait-count bookkeeping: pin their results behind the wait (volatile asm

@@ -47,7 +47,10 @@ struct C3Cfg {
     static constexpr int BM = 32 * MI;                              // MI 32-row tiles per wave; the four waves share the m range
     static constexpr int ROWS = C3_PIX / W;                         // image rows per tile
     static constexpr int SPX = (ROWS + 2 * D) * W;                  // staged pixels per channel
-    static constexpr int BP = ((SPX + 127) / 128) * 128 + 16;       // pitch: 32 bytes (mod 256): the 4 rows of a transpose read hit distinct banks
+    // pitch: 32 bytes (mod 256): the 4 rows of a transpose read hit distinct banks.  X3: 64 bytes (mod 256) -- a transpose read serves 32
+    // lanes per LDS cycle (4 rows x two 16-pixel halves); with 8 banks per row step the second half of row r collides with the first
+    // half of row r + 1, with 16 the 32 lanes cover the 64 banks exactly (conv1x1_fwd.hip)
+    static constexpr int BP = ((SPX + 127) / 128) * 128 + (X3 ? 32 : 16);
     static constexpr int PL = X3 ? 2 : 1;                           // operand planes in LDS
     static constexpr int A_EL = 9 * 32 * MI * C3_APITCH, B_EL = 3 * C3_BK * BP;       // per plane
     static constexpr size_t lds_bytes = (size_t)PL * (A_EL + B_EL) * sizeof(uint16_t);

@@ -251,35 +251,48 @@ __global__ __launch_bounds__(256, (W == 128 || X3) ? 1 : 2) void k_wgrad3x3(cons
 // staging step splits every input row into its even and odd columns (E[x] = X[2 x], O[x] = X[2 x + 1]; two v_perm per chunk), so
 // the three horizontal taps are again K-contiguous: kw = 1 -> E[x], kw = 2 -> O[x], kw = 0 -> O[x - 1] (funnel with the word before,
 // zero at the row start).
-template <int WO>
+// X3 = true ("f32x3"): dY / X float32, split into (hi, lo) bfloat16 halves on their way to LDS (two planes of the layout), fragments per
+// plane, hi*hi + hi*lo + lo*hi; at WO = 64 the in-channel tile is 32 (both planes of the five-row ring must fit the LDS) and the two waves
+// of a channel pair split the row's K-sub-steps.
+template <int WO, bool X3 = false>
 struct W3S2Cfg {
+    static constexpr int PL = X3 ? 2 : 1;
+    static constexpr int BN = (X3 && WO == 64) ? 32 : W3_BN;
     static constexpr int R = 5;
     static constexpr int PA = WO + 8;
     static constexpr int PX = 2 * WO + 24;          // 8 pad | E (WO) | 8 pad = O's left halo | O (WO) | 8 pad; pitch = 4 (mod 8) words
     static constexpr int EO = 8, OO = 16 + WO;
-    static constexpr int LPA = WO / 32;             // dY chunks per thread
-    static constexpr int LPX = WO / 16;             // chunks per thread of ONE input row (64 channels x 2 WO / 8 chunks / 256 threads)
-    static constexpr size_t lds_bytes = ((size_t)2 * W3_BM * PA + (size_t)R * W3_BN * PX) * sizeof(uint16_t);
+    static constexpr int CPA = X3 ? WO / 4 : WO / 8;                // 16-byte global chunks per dY row
+    static constexpr int LPA = W3_BM * CPA / 256;                   // dY chunks per thread
+    static constexpr int LPX = BN * (2 * WO / 8) / 256;             // 8-pixel chunks per thread of ONE input row
+    static constexpr size_t lds_bytes = (size_t)PL * ((size_t)2 * W3_BM * PA + (size_t)R * BN * PX) * sizeof(uint16_t);
 };
 
-template <int WO>
-__global__ __launch_bounds__(256, WO == 64 ? 1 : 2) void k_wgrad3x3_s2(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, float* __restrict__ acc,
+template <int WO, bool X3>
+__global__ __launch_bounds__(256, (WO == 64 || X3) ? 1 : 2) void k_wgrad3x3_s2(const void* __restrict__ dY_, const void* __restrict__ X_,
+                                                        float* __restrict__ acc,
                                                         int Co, int Ci, int Ho, int tiles, int tiles_n, int rows_total, int rows_per_block) {
-    using C = W3S2Cfg<WO>;
-    constexpr int R = C::R, PA = C::PA, PX = C::PX, LPA = C::LPA, LPX = C::LPX, WI = 2 * WO, CPA = WO / 8, CPX = WI / 8;
+    using C = W3S2Cfg<WO, X3>;
+    typedef typename std::conditional<X3, float, uint16_t>::type elem_t;
+    const elem_t* dY = reinterpret_cast<const elem_t*>(dY_);
+    const elem_t* X = reinterpret_cast<const elem_t*>(X_);
+    constexpr int R = C::R, PA = C::PA, PX = C::PX, LPA = C::LPA, LPX = C::LPX, WI = 2 * WO, CPA = C::CPA, CPX = WI / 8, PL = C::PL, BN = C::BN;
+    constexpr int EPA = X3 ? 4 : 8;                       // pixels per 16-byte dY chunk
+    constexpr bool KSPLIT = BN == 32;
+    constexpr int A_PLANE = 2 * W3_BM * PA, X_PLANE = R * BN * PX;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-    uint16_t* dYs = lds;                                  // [2][64][PA]
-    uint16_t* Xs = lds + 2 * W3_BM * PA;                  // [R][64][PX]
+    uint16_t* dYs = lds;                                  // [PL][2][64][PA]
+    uint16_t* Xs = lds + PL * A_PLANE;                    // [PL][R][BN][PX]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv >> 1, wc = wv & 1;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int tile = q % tiles, slice = (q / tiles) * 8 + xcd;
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * W3_BM, n0 = tn * W3_BN;
+    const int m0 = tm * W3_BM, n0 = tn * BN;
     const int g0 = slice * rows_per_block, g1 = min(rows_total, g0 + rows_per_block);
     if (g0 >= g1) return;
     const int Hi = 2 * Ho;
-    for (int i = tid; i < R * W3_BN; i += 256) {          // pads / halos: zero once
+    for (int i = tid; i < PL * R * BN; i += 256) {        // pads / halos: zero once
         uint16_t* row = Xs + (size_t)i * PX;
         *reinterpret_cast<uint4*>(row) = make_uint4(0, 0, 0, 0);
         *reinterpret_cast<uint4*>(row + 8 + WO) = make_uint4(0, 0, 0, 0);
@@ -289,37 +302,66 @@ __global__ __launch_bounds__(256, WO == 64 ? 1 : 2) void k_wgrad3x3_s2(const uin
     auto load_dy = [&](int n, int y, uint4* st) {
 #pragma unroll
         for (int i = 0; i < LPA; ++i) {
-            const int id = tid + 256 * i, row = id / CPA, c8 = (id - row * CPA) * 8, m = m0 + row;
-            st[i] = m < Co ? *reinterpret_cast<const uint4*>(dY + ((size_t)n * Co + m) * HWo + (size_t)y * WO + c8) : make_uint4(0, 0, 0, 0);
+            const int id = tid + 256 * i, row = id / CPA, c = (id - row * CPA) * EPA, m = m0 + row;
+            st[i] = m < Co ? *reinterpret_cast<const uint4*>(dY + ((size_t)n * Co + m) * HWo + (size_t)y * WO + c) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_dy = [&](int buf, const uint4* st) {
         uint16_t* base = dYs + (size_t)buf * W3_BM * PA;
 #pragma unroll
         for (int i = 0; i < LPA; ++i) {
-            const int id = tid + 256 * i, row = id / CPA, c8 = (id - row * CPA) * 8;
-            *reinterpret_cast<uint4*>(base + row * PA + c8) = st[i];
+            const int id = tid + 256 * i, row = id / CPA, c = (id - row * CPA) * EPA;
+            if (X3) {
+                uint2 hi, lo;
+                const uint4 v = st[i];
+                aadg_split4(make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)), hi, lo);
+                *reinterpret_cast<uint2*>(base + row * PA + c) = hi;
+                *reinterpret_cast<uint2*>(base + A_PLANE + row * PA + c) = lo;
+            } else {
+                *reinterpret_cast<uint4*>(base + row * PA + c) = st[i];
+            }
         }
     };
-    auto load_x = [&](int n, int r, uint4* st) {             // input row r; rows outside the image: zeros
+    // input row r; rows outside the image: zeros.  X3: st[2 i] / st[2 i + 1] = pixels 0..3 / 4..7 of chunk i as float32
+    auto load_x = [&](int n, int r, uint4* st) {
 #pragma unroll
         for (int i = 0; i < LPX; ++i) {
             const int id = tid + 256 * i, row = id / CPX, ch = id - row * CPX, c = n0 + row;
-            st[i] = (c < Ci && r >= 0 && r < Hi) ? *reinterpret_cast<const uint4*>(X + ((size_t)n * Ci + c) * HWi + (size_t)r * WI + ch * 8)
-                                                 : make_uint4(0, 0, 0, 0);
+            const bool ok = c < Ci && r >= 0 && r < Hi;
+            const elem_t* src = X + ((size_t)n * Ci + c) * HWi + (size_t)r * WI + ch * 8;
+            if (X3) {
+                st[2 * i] = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+                st[2 * i + 1] = ok ? *reinterpret_cast<const uint4*>(src + 4) : make_uint4(0, 0, 0, 0);
+            } else {
+                st[i] = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+            }
         }
     };
     auto slot_of = [&](int r) { return (r + 2 * R) % R; };
     auto store_x = [&](int r, const uint4* st) {             // split the 8 pixels of a chunk into 4 even + 4 odd columns
-        uint16_t* base = Xs + (size_t)slot_of(r) * W3_BN * PX;
+        uint16_t* base = Xs + (size_t)slot_of(r) * BN * PX;
 #pragma unroll
         for (int i = 0; i < LPX; ++i) {
             const int id = tid + 256 * i, row = id / CPX, ch = id - row * CPX;
-            const uint4 v = st[i];
-            const uint2 e = make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x05040100u), __builtin_amdgcn_perm(v.w, v.z, 0x05040100u));
-            const uint2 o = make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x07060302u), __builtin_amdgcn_perm(v.w, v.z, 0x07060302u));
-            *reinterpret_cast<uint2*>(base + row * PX + C::EO + 4 * ch) = e;
-            *reinterpret_cast<uint2*>(base + row * PX + C::OO + 4 * ch) = o;
+            uint4 vv[PL];
+            if (X3) {
+                uint2 h0, l0, h1, l1;
+                const uint4 q0 = st[2 * i], q1 = st[2 * i + 1];
+                aadg_split4(make_float4(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w)), h0, l0);
+                aadg_split4(make_float4(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q1.w)), h1, l1);
+                vv[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                vv[PL - 1] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            } else {
+                vv[0] = st[i];
+            }
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) {
+                const uint4 v = vv[pl];
+                const uint2 e = make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x05040100u), __builtin_amdgcn_perm(v.w, v.z, 0x05040100u));
+                const uint2 o = make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x07060302u), __builtin_amdgcn_perm(v.w, v.z, 0x07060302u));
+                *reinterpret_cast<uint2*>(base + pl * X_PLANE + row * PX + C::EO + 4 * ch) = e;
+                *reinterpret_cast<uint2*>(base + pl * X_PLANE + row * PX + C::OO + 4 * ch) = o;
+            }
         }
     };
 
@@ -328,8 +370,9 @@ __global__ __launch_bounds__(256, WO == 64 ? 1 : 2) void k_wgrad3x3_s2(const uin
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) d[t][r] = 0.0f;
-    const int a_row = wr * 32 + (lane & 31), b_row = wc * 32 + (lane & 31), koff = (lane >> 5) * 8;
-    uint4 sdy[LPA], sx0[LPX], sx1[LPX];
+    const int a_row = wr * 32 + (lane & 31), b_row = (KSPLIT ? 0 : wc * 32) + (lane & 31), koff = (lane >> 5) * 8;
+    constexpr int XR = X3 ? 2 * LPX : LPX;
+    uint4 sdy[LPA], sx0[XR], sx1[XR];
     int buf = 0;
     for (int g = g0; g < g1; ++g) {
         const int n = g / Ho, y = g - n * Ho;
@@ -354,26 +397,45 @@ __global__ __launch_bounds__(256, WO == 64 ? 1 : 2) void k_wgrad3x3_s2(const uin
         const uint16_t* ab = dYs + (size_t)buf * W3_BM * PA + a_row * PA + koff;
         const uint16_t* xb[3];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) xb[kh] = Xs + ((size_t)slot_of(2 * y + kh - 1) * W3_BN + b_row) * PX + koff;
+        for (int kh = 0; kh < 3; ++kh) xb[kh] = Xs + ((size_t)slot_of(2 * y + kh - 1) * BN + b_row) * PX + koff;
+        constexpr int KS = WO / 16, KS_N = KSPLIT ? KS / 2 : KS;
+        const int ks0 = KSPLIT ? wc * (KS / 2) : 0;
 #pragma unroll
-        for (int ks = 0; ks < WO / 16; ++ks) {
-            const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ab + ks * 16));
+        for (int j = 0; j < KS_N; ++j) {
+            const int ks = ks0 + j;
+            bf16x8 a[PL];
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) a[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ab + pl * A_PLANE + ks * 16));
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-                const uint16_t* xr = xb[kh] + ks * 16;
-                const uint4 e = *reinterpret_cast<const uint4*>(xr + C::EO);
-                const uint4 o = *reinterpret_cast<const uint4*>(xr + C::OO);
-                const uint32_t prv = *reinterpret_cast<const uint32_t*>(xr + C::OO - 2);
-                const bf16x8 f0 = frag(__builtin_amdgcn_alignbit(o.x, prv, 16), __builtin_amdgcn_alignbit(o.y, o.x, 16),
-                                       __builtin_amdgcn_alignbit(o.z, o.y, 16), __builtin_amdgcn_alignbit(o.w, o.z, 16));       // O[x - 1]
-                d[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, f0, d[kh * 3 + 0], 0, 0, 0);
-                d[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, e), d[kh * 3 + 1], 0, 0, 0);
-                d[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, o), d[kh * 3 + 2], 0, 0, 0);
+                bf16x8 f0[PL], f1[PL], f2[PL];
+#pragma unroll
+                for (int pl = 0; pl < PL; ++pl) {
+                    const uint16_t* xr = xb[kh] + pl * X_PLANE + ks * 16;
+                    const uint4 e = *reinterpret_cast<const uint4*>(xr + C::EO);
+                    const uint4 o = *reinterpret_cast<const uint4*>(xr + C::OO);
+                    const uint32_t prv = *reinterpret_cast<const uint32_t*>(xr + C::OO - 2);
+                    f0[pl] = frag(__builtin_amdgcn_alignbit(o.x, prv, 16), __builtin_amdgcn_alignbit(o.y, o.x, 16),
+                                  __builtin_amdgcn_alignbit(o.z, o.y, 16), __builtin_amdgcn_alignbit(o.w, o.z, 16));       // O[x - 1]
+                    f1[pl] = __builtin_bit_cast(bf16x8, e);
+                    f2[pl] = __builtin_bit_cast(bf16x8, o);
+                }
+                if (X3) {
+                    d[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PL - 1], f0[0], d[kh * 3 + 0], 0, 0, 0);
+                    d[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PL - 1], f1[0], d[kh * 3 + 1], 0, 0, 0);
+                    d[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PL - 1], f2[0], d[kh * 3 + 2], 0, 0, 0);
+                    d[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], f0[PL - 1], d[kh * 3 + 0], 0, 0, 0);
+                    d[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], f1[PL - 1], d[kh * 3 + 1], 0, 0, 0);
+                    d[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], f2[PL - 1], d[kh * 3 + 2], 0, 0, 0);
+                }
+                d[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], f0[0], d[kh * 3 + 0], 0, 0, 0);
+                d[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], f1[0], d[kh * 3 + 1], 0, 0, 0);
+                d[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], f2[0], d[kh * 3 + 2], 0, 0, 0);
             }
         }
         buf ^= 1;
     }
-    const int nn = n0 + wc * 32 + (lane & 31);
+    const int nn = n0 + (KSPLIT ? 0 : wc * 32) + (lane & 31);
     if (nn < Ci) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -387,10 +449,10 @@ __global__ __launch_bounds__(256, WO == 64 ? 1 : 2) void k_wgrad3x3_s2(const uin
     }
 }
 
-template <int WO>
-int launch_s2(const uint16_t* dY, const uint16_t* X, float* acc, int N, int Co, int Ci, int Ho, hipStream_t st) {
-    using C = W3S2Cfg<WO>;
-    const int tiles_m = (Co + W3_BM - 1) / W3_BM, tiles_n = (Ci + W3_BN - 1) / W3_BN, tiles = tiles_m * tiles_n;
+template <int WO, bool X3>
+int launch_s2(const void* dY, const void* X, float* acc, int N, int Co, int Ci, int Ho, hipStream_t st) {
+    using C = W3S2Cfg<WO, X3>;
+    const int tiles_m = (Co + W3_BM - 1) / W3_BM, tiles_n = (Ci + C::BN - 1) / C::BN, tiles = tiles_m * tiles_n;
     const long long rows_total = (long long)N * Ho;
     const long long target = 512, min_mfma = 1152;
     long long slices = (target + tiles - 1) / tiles;
@@ -400,13 +462,13 @@ int launch_s2(const uint16_t* dY, const uint16_t* X, float* acc, int N, int Co, 
     slices = (rows_total + rpb - 1) / rpb;
     static bool attr_set = false;
     if (!attr_set) {
-        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3_s2<WO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3_s2<WO, X3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::lds_bytes));
         attr_set = true;
     }
     AADG_HIP_TRY(hipMemsetAsync(acc, 0, (size_t)9 * Co * Ci * sizeof(float), st));
     const long long slice_groups = (slices + 7) / 8;
-    hipLaunchKernelGGL((k_wgrad3x3_s2<WO>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(256), C::lds_bytes, st, dY, X, acc, Co, Ci, Ho,
+    hipLaunchKernelGGL((k_wgrad3x3_s2<WO, X3>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(256), C::lds_bytes, st, dY, X, acc, Co, Ci, Ho,
                        tiles, tiles_n, (int)rows_total, (int)rpb);
     AADG_LAUNCH_CHECK();
     return 0;
@@ -488,6 +550,16 @@ extern "C" int aadg_conv3x3s2_wgrad_bf16(const void* dy, const void* x, float* d
     if ((((uintptr_t)dy | (uintptr_t)x) & 15u) != 0) return AADG_E_BADARG;
     if (!aadg_conv3x3s2_wgrad_supported(Co, Ci, Ho, Wo) || (long long)N * Ho > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (Wo == 32) return launch_s2<32>((const uint16_t*)dy, (const uint16_t*)x, dweight9, N, Co, Ci, Ho, st);
-    return launch_s2<64>((const uint16_t*)dy, (const uint16_t*)x, dweight9, N, Co, Ci, Ho, st);
+    if (Wo == 32) return launch_s2<32, false>(dy, x, dweight9, N, Co, Ci, Ho, st);
+    return launch_s2<64, false>(dy, x, dweight9, N, Co, Ci, Ho, st);
+}
+/* ... and from float32 tensors at float32 precision ("f32x3") */
+extern "C" int aadg_conv3x3s2_wgrad_f32x3(const float* dy, const float* x, float* dweight9, int N, int Co, int Ci, int Ho, int Wo,
+                                          void* stream) {
+    if (dy == nullptr || x == nullptr || dweight9 == nullptr || N <= 0) return AADG_E_BADARG;
+    if ((((uintptr_t)dy | (uintptr_t)x) & 15u) != 0) return AADG_E_BADARG;
+    if (!aadg_conv3x3s2_wgrad_supported(Co, Ci, Ho, Wo) || (long long)N * Ho > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (Wo == 32) return launch_s2<32, true>(dy, x, dweight9, N, Co, Ci, Ho, st);
+    return launch_s2<64, true>(dy, x, dweight9, N, Co, Ci, Ho, st);
 }

@@ -4,14 +4,19 @@
 //
 //   k_big_prep    rows normalised to unit length (so C = 1 - <x^, y^>), per-chunk column min / max
 //   k_big_schedule diameter of x u y, eps schedule (float64)
-//   k_big_cost    the four cost matrices C_xx, C_yy, C_xy, C_yx as dense 64x64-tiled contractions on the matrix
-//                 cores: v_mfma_f32_32x32x2_f32 -- exact f32 (an fmaf chain), operands staged in LDS with an
-//                 odd row stride; this is the one place on the path where a dense feature GEMM is the
-//                 bottleneck (N = 4096, E = 128: 4 x 4.3 GFLOP), so it is the one place MFMA is used
+//   k_big_cost    the cost matrices C_xx, C_yy, C_xy as dense 64x64-tiled contractions on the matrix cores:
+//                 v_mfma_f32_32x32x2_f32 -- exact f32 (an fmaf chain), operands staged in LDS with an odd row stride; this
+//                 is the one place on the path where a dense feature GEMM is the bottleneck (N = 4096, E = 128: 3 x 4.3
+//                 GFLOP), so it is the one place MFMA is used.  C_yx = C_xy^T is not a fourth contraction (round 5): the
+//                 C_xy workgroups write their tile a second time, transposed through LDS (coalesced rows of C_yx)
 //   k_big_sweep   one eps-scaling step: every row of the four matrices is an independent log-sum-exp,
-//                 one wavefront per row, float4 loads, online (max, sum) in registers, wave-shuffle merge;
-//                 potentials are double-buffered so the symmetrised update needs no second pass.
-//                 HBM-bound: 4 * N^2 * 4 bytes per step.
+//                 one wavefront per row, online (max, sum) in registers, wave-shuffle merge; potentials are
+//                 double-buffered so the symmetrised update needs no second pass.  HBM-bound: 4 * N^2 * 4 bytes per
+//                 step.  Round 5: the per-COLUMN term h_j = log w_j + pot_j / eps (a true division per matrix element
+//                 before) is written once per step by the wave that produces pot_j, pre-scaled by log2(e) so that an
+//                 element costs one FMA + one v_exp_f32; eight streaming float4 loads per lane are in flight before the
+//                 first is consumed, and four elements share one running-maximum update (5 exps per 4 elements,
+//                 branch-free).
 //   k_big_final   <alpha, b_x - a_x> + <beta, a_y - b_y>
 //
 // The number of eps steps depends on the data (diameter), which lives on the device: the host enqueues a fixed
@@ -25,7 +30,7 @@ constexpr int BIG_PREP_CHUNKS = 32;        // row chunks of the prep pass (one w
 constexpr int BIG_MAX_ITS = BIG_EPS_CAP;   // sweeps enqueued: init + up to BIG_EPS_CAP eps steps + final extrapolation
 
 struct BigLayout {                  // per-problem float offsets into the workspace
-    size_t xn, yn, cxx, cyy, cxy, cyx, pot, til, meta, scr, total;
+    size_t xn, yn, cxx, cyy, cxy, cyx, pot, hh, til, meta, scr, total;
 };
 __host__ __device__ inline BigLayout big_layout(int nmax, int E) {
     BigLayout l;
@@ -38,6 +43,7 @@ __host__ __device__ inline BigLayout big_layout(int nmax, int E) {
     l.cxy = o; o += mat;
     l.cyx = o; o += mat;
     l.pot = o; o += (size_t)2 * 4 * nmax;     // [buffer][a_x, b_y, a_y, b_x][nmax]
+    l.hh = o; o += (size_t)2 * 4 * nmax;      // [buffer][..][nmax]: (log w + pot / eps_next) * log2(e), what the NEXT step's softmins add per column
     l.til = o; o += (size_t)4 * nmax;
     l.meta = o; o += 2 * BIG_EPS_CAP + 8;      // eps_s as doubles (2 floats each) + nits
     l.scr = o; o += (size_t)BIG_PREP_CHUNKS * 2 * 512;   // per-chunk column min / max (E <= 512)
@@ -142,15 +148,15 @@ constexpr int CT = 64;          // block tile (4 waves, 32x32 each)
 constexpr int CK = 64;          // K chunk staged in LDS (2 x 64 x 65 floats = 33 KB)
 
 __global__ __launch_bounds__(256) void k_big_cost(const int* cloud_off, const int* prob_xy, int nmax, int E, float* ws) {
-    const int p = blockIdx.z >> 2, which = blockIdx.z & 3;            // 0 xx, 1 yy, 2 xy, 3 yx
+    const int p = blockIdx.z / 3, which = blockIdx.z - 3 * p;         // 0 xx, 1 yy, 2 xy (+ yx = its transpose)
     const BigLayout L = big_layout(nmax, E);
     float* base = ws + (size_t)p * L.total;
     const int cx = prob_xy[2 * p], cy = prob_xy[2 * p + 1];
     const int n = cloud_off[cx + 1] - cloud_off[cx], m = cloud_off[cy + 1] - cloud_off[cy];
     const float* Am = base + ((which == 0 || which == 2) ? L.xn : L.yn);
-    const float* Bm = base + ((which == 0 || which == 3) ? L.xn : L.yn);
-    const int rows = (which == 0 || which == 2) ? n : m, cols = (which == 0 || which == 3) ? n : m;
-    float* C = base + (which == 0 ? L.cxx : which == 1 ? L.cyy : which == 2 ? L.cxy : L.cyx);
+    const float* Bm = base + (which == 0 ? L.xn : L.yn);
+    const int rows = (which == 0 || which == 2) ? n : m, cols = which == 0 ? n : m;
+    float* C = base + (which == 0 ? L.cxx : which == 1 ? L.cyy : L.cxy);
     const int i0 = blockIdx.y * CT, j0 = blockIdx.x * CT;
     if (i0 >= rows || j0 >= cols) return;
     __shared__ float As[CT][CK + 1];
@@ -181,6 +187,21 @@ __global__ __launch_bounds__(256) void k_big_cost(const int* cloud_off, const in
         const int row = i0 + wi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = j0 + wj + (lane & 31);
         if (row < rows && col < cols) C[(size_t)row * nmax + col] = 1.0f - acc[r];
     }
+    if (which == 2) {
+        // C_yx[j][i] = C_xy[i][j] (the same fmaf chain: bit-identical to a contraction of its own).  Through LDS, so that 32 lanes
+        // write 128 contiguous bytes of a C_yx row: the wave's 32 x 32 tile goes to its slice of the (now free) operand buffers.
+        float* T = (wv < 2 ? &As[0][0] : &Bs[0][0]) + (wv & 1) * 32 * 33;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 33 + (lane & 31)] = 1.0f - acc[r];
+        __builtin_amdgcn_wave_barrier();
+        float* Ct = base + L.cyx;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int c = 2 * t + (lane >> 5), rr = lane & 31;            // element (row rr, column c) of the tile -> C_yx[j0 + wj + c][i0 + wi + rr]
+            const int row = i0 + wi + rr, col = j0 + wj + c;
+            if (row < rows && col < cols) Ct[(size_t)col * nmax + row] = T[rr * 33 + c];
+        }
+    }
 }
 
 // ---- one sweep: grid (4 * ceil(nmax/4), n_prob), 256 threads: wave <-> one row of one of the four softmins ---------
@@ -204,48 +225,72 @@ __global__ __launch_bounds__(256) void k_big_sweep(const int* cloud_off, const i
     const bool init = step == 0, fin = step == nits + 1;
     const int it = init ? 0 : (fin ? nits - 1 : step - 1);
     const double eps = eps_s[it];
-    const float inv = (float)(1.0 / eps), feps = (float)eps;
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    const float feps = (float)eps, inv2 = (float)(1.0 / eps) * LOG2E;
     // source potential of each softmin: a_x <- a_x, b_y <- b_y, a_y <- b_x, b_x <- a_y   (index into [a_x,b_y,a_y,b_x])
     const int src_kind = kind == 2 ? 3 : (kind == 3 ? 2 : kind);
     const int rd = init ? 0 : (fin ? (nits & 1) : ((step - 1) & 1));
-    const float* pot = base + L.pot + ((size_t)rd * 4 + src_kind) * nmax;
+    const float* hsrc = base + L.hh + ((size_t)rd * 4 + src_kind) * nmax;        // (log w_j + pot_j / eps) * log2(e), written by the previous step
     const float* own = base + L.pot + ((size_t)rd * 4 + kind) * nmax;
-    const float lw = logf(1.0f / (float)cols);
+    const float h0 = logf(1.0f / (float)cols) * LOG2E;                              // the initialisation has no potentials
     const float* Crow = base + (kind == 0 ? L.cxx : kind == 1 ? L.cyy : kind == 2 ? L.cyx : L.cxy) + (size_t)row * nmax;
+    // base-2 online log-sum-exp: running maximum mx, s = sum 2^(v - mx)
     float mx = -INFINITY, s = 0.f;
-    auto push = [&](float c, float pj) {
-        const float h = init ? lw : lw + pj / feps;
-        const float v = h - c * inv;
-        // online log-sum-exp; hardware exp (v_exp_f32, ~1 ulp): 4 * N^2 of these per step make the sweep VALU bound otherwise
-        if (v > mx) { s = s * __expf(mx - v) + 1.0f; mx = v; } else { s += __expf(v - mx); }
-    };
     const bool vec = (nmax & 3) == 0;
     if (vec) {
-        for (int j = lane * 4; j < cols; j += 256) {
-            const float4 c4 = *reinterpret_cast<const float4*>(Crow + j);
-            float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!init) p4 = *reinterpret_cast<const float4*>(pot + j);
-            push(c4.x, p4.x);
-            if (j + 1 < cols) push(c4.y, p4.y);
-            if (j + 2 < cols) push(c4.z, p4.z);
-            if (j + 3 < cols) push(c4.w, p4.w);
+        constexpr int U = 8;                                   // float4 loads per lane in flight (a 4096-column row = 2 rounds)
+        for (int j0 = lane * 4; j0 < cols; j0 += 256 * U) {
+            float4 c4[U], h4[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + 256 * u;
+                // (a row of the padded matrix is nmax floats: a float4 that starts below `cols` never leaves the row)
+                c4[u] = j < cols ? aadg_load_stream(Crow + j) : make_float4(0.f, 0.f, 0.f, 0.f);     // each element is read once per sweep
+                h4[u] = (j < cols && !init) ? *reinterpret_cast<const float4*>(hsrc + j) : make_float4(h0, h0, h0, h0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + 256 * u;
+                if (j >= cols) continue;
+                float v0 = fmaf(-c4[u].x, inv2, h4[u].x), v1 = fmaf(-c4[u].y, inv2, h4[u].y);
+                float v2 = fmaf(-c4[u].z, inv2, h4[u].z), v3 = fmaf(-c4[u].w, inv2, h4[u].w);
+                if (j + 1 >= cols) v1 = -INFINITY;
+                if (j + 2 >= cols) v2 = -INFINITY;
+                if (j + 3 >= cols) v3 = -INFINITY;
+                const float mn = fmaxf(fmaxf(mx, fmaxf(v0, v1)), fmaxf(v2, v3));
+                s = s * exp2f(mx - mn) + ((exp2f(v0 - mn) + exp2f(v1 - mn)) + (exp2f(v2 - mn) + exp2f(v3 - mn)));
+                mx = mn;
+            }
         }
     } else {
-        for (int j = lane; j < cols; j += 64) push(Crow[j], init ? 0.f : pot[j]);
+        for (int j = lane; j < cols; j += 64) {
+            const float v = fmaf(-Crow[j], inv2, init ? h0 : hsrc[j]);
+            const float mn = fmaxf(mx, v);
+            s = s * exp2f(mx - mn) + exp2f(v - mn);
+            mx = mn;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float m2 = __shfl_xor(mx, o, 64), s2 = __shfl_xor(s, o, 64);
         const float mn = fmaxf(mx, m2);
-        const float e1 = mx == -INFINITY ? 0.f : __expf(mx - mn), e2 = m2 == -INFINITY ? 0.f : __expf(m2 - mn);
+        const float e1 = mx == -INFINITY ? 0.f : exp2f(mx - mn), e2 = m2 == -INFINITY ? 0.f : exp2f(m2 - mn);
         s = s * e1 + s2 * e2;
         mx = mn;
     }
     if (lane == 0) {
-        const float val = -feps * (mx + logf(s));
-        if (init) base[L.pot + ((size_t)0 * 4 + kind) * nmax + row] = val;                 // buffer 0
-        else if (fin) base[L.til + (size_t)kind * nmax + row] = val;
-        else base[L.pot + ((size_t)(((step - 1) & 1) ^ 1) * 4 + kind) * nmax + row] = 0.5f * (own[row] + val);
+        const float val = -feps * ((mx + log2f(s)) * LN2);
+        if (fin) {
+            base[L.til + (size_t)kind * nmax + row] = val;
+        } else {
+            // this step's output and, once per element instead of once per matrix entry, the per-column term of the step that will read
+            // it: h = log w + pot / eps_next (the oracle's expression, a true division), scaled by log2(e)
+            const int wr = init ? 0 : (((step - 1) & 1) ^ 1);
+            const float pot = init ? val : 0.5f * (own[row] + val);
+            const float feps_next = (float)eps_s[min(step, nits - 1)];
+            base[L.pot + ((size_t)wr * 4 + kind) * nmax + row] = pot;
+            base[L.hh + ((size_t)wr * 4 + kind) * nmax + row] = (logf(1.0f / (float)rows) + pot / feps_next) * LOG2E;
+        }
     }
 }
 
@@ -287,7 +332,7 @@ int aadg_sinkhorn_big_launch(const float* feat, int ld, int E, const int* cloud_
     hipLaunchKernelGGL(k_big_schedule, dim3(n_prob), dim3(256), 0, st, nmax, E, blur, scaling, w);
     AADG_LAUNCH_CHECK();
     const int tiles = (nmax + CT - 1) / CT;
-    hipLaunchKernelGGL(k_big_cost, dim3(tiles, tiles, n_prob * 4), dim3(256), 0, st, cloud_off, prob_xy, nmax, E, w);
+    hipLaunchKernelGGL(k_big_cost, dim3(tiles, tiles, n_prob * 3), dim3(256), 0, st, cloud_off, prob_xy, nmax, E, w);
     AADG_LAUNCH_CHECK();
     const dim3 gs(4 * ((nmax + 3) / 4), n_prob);
     for (int step = 0; step <= BIG_MAX_ITS + 1; ++step) {

@@ -196,7 +196,12 @@ class Conv3x3(nn.Conv2d):
                 xc = x.contiguous()
                 if _lib.conv3x3_x3_supported(xc, self.weight, self.dilation[0]):
                     return _lib.conv3x3_x3(xc, self.weight, self.dilation[0])
-            return super().forward(x)                        # (stride 2: the library's float32 convolution)
+            elif self.stride == (2, 2) and self.dilation == (1, 1) and self.padding == (1, 1):
+                from .. import _lib
+                xc = x.contiguous()
+                if _lib.conv3x3s2_x3_supported(xc, self.weight):
+                    return _lib.conv3x3s2_x3(xc, self.weight)
+            return super().forward(x)
         if x.is_cuda and x.dtype == torch.bfloat16 and self.stride == (1, 1):
             from .. import _lib
             xc = x.contiguous()

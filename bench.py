@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="TRAIN.BATCH_SIZE (items; each item = one image per domain)")
     ap.add_argument("--backbone", default="resnet50", help="MODEL.BACKBONE for deeplabv3+ configs (the yaml's mobilenet_v2 is the "
                                                            "reference's only reachable encoder; BASELINE configs[1] names ResNet-50)")
-    ap.add_argument("--backbone_dtype", default="fp32", choices=["f32x3", "fp32", "bf16"],
+    ap.add_argument("--backbone_dtype", default="f32x3", choices=["f32x3", "fp32", "bf16"],
                     help="arithmetic of the backbone convolutions: f32x3 = float32 tensors, every product as three bfloat16 matrix-core "
                          "products with float32 accumulation (own kernels, the reference's precision: checked by the `precision` leg); "
                          "fp32 = the library's float32 convolutions; bf16 = bfloat16 autocast (narrower than the reference: secondary)")

@@ -452,6 +452,13 @@ int aadg_conv3x3s2_dgrad_supported(int C, int M, int Ho, int Wo);
  * the two layout transposes around it (csrc/conv3x3_s2_fwd.hip). */
 int aadg_conv3x3s2_nchw_supported(int M, int K, int Ho, int Wo);
 int aadg_conv3x3s2_nchw_bf16(const void* a9, const void* in, void* out, int N, int M, int K, int Ho, int Wo, void* stream);
+/* ABI 8 -- f32x3 (see aadg_conv1x1_nchw_f32x3): the stride-2 convolution, its input gradient and its weight gradient on float32 NCHW
+ * tensors at float32 precision; a9_hi / a9_lo ([9, M, K]) and a9t_hi / a9t_lo ([9, C, M]) = the bfloat16 halves of the tap-major weights */
+int aadg_conv3x3s2_nchw_f32x3(const void* a9_hi, const void* a9_lo, const float* in, float* out, int N, int M, int K, int Ho, int Wo,
+                              void* stream);
+int aadg_conv3x3s2_dgrad_f32x3(const void* a9t_hi, const void* a9t_lo, const float* dy, float* dx, int N, int C, int M, int Ho, int Wo,
+                               void* stream);
+int aadg_conv3x3s2_wgrad_f32x3(const float* dy, const float* x, float* dweight9, int N, int Co, int Ci, int Ho, int Wo, void* stream);
 int aadg_conv3x3s2_dgrad_bf16(const void* a9t, const void* dy, void* dx, int N, int C, int M, int Ho, int Wo, void* stream);
 /* The convolution itself and its input gradient, NCHW bfloat16 in and out, float32 accumulation (csrc/conv3x3_fwd.hip):
  *     out[n][m][y][x] = sum_{k, kh, kw} a9[kh * 3 + kw][m][k] * in[n][k][y + (kh - 1) d][x + (kw - 1) d]

@@ -62,7 +62,8 @@ def test_bench_eight_ranks_like_the_scaling_run(tmp_path):
     assert max(abs(x - y) for x, y in zip(a, b)) < 1e-4, (a, b)
 
 
-@pytest.mark.parametrize("name,dtype,world", [("mobilenet_v2", "fp32", 3), ("resnet50", "fp32", 2), ("resnet50", "bf16", 3)])
+@pytest.mark.parametrize("name,dtype,world", [("mobilenet_v2", "fp32", 3), ("resnet50", "fp32", 2), ("resnet50", "bf16", 3),
+                                              ("resnet50", "f32x3", 3)])
 def test_ddp_sync_bn_gradients_match_single_process(name, dtype, world):
     import socket
     s = socket.socket()

@@ -136,3 +136,22 @@ def test_modules_in_f32x3_mode_equal_float32_convolutions(hip, stride):
     # a float32 input with f32x3 off goes to the library (no own kernel), a bfloat16 one still to the bfloat16 kernels
     off = DL.Conv1x1(64, 64).cuda()
     assert off(x1.detach()[:, :, :32, :32]).dtype == torch.float32
+
+
+@pytest.mark.parametrize("N,Ci,Co,Ho,Wo", [(2, 128, 128, 64, 64), (2, 256, 256, 32, 32), (3, 40, 72, 10, 32), (1, 64, 96, 7, 64)])
+def test_conv3x3_stride2_x3(hip, N, Ci, Co, Ho, Wo):
+    """The stride-2 convolution of ResNet stages 2 / 3 (csrc/conv3x3_s2_fwd.hip, conv3x3_s2_dgrad.hip, k_wgrad3x3_s2: X3): forward, input
+    gradient (four parity classes) and weight gradient against float64 autograd."""
+    torch.manual_seed(Ci + Co + Wo)
+    x1 = torch.randn(N, Ci, 2 * Ho, 2 * Wo, device="cuda", requires_grad=True)
+    w1 = (torch.randn(Co, Ci, 3, 3, device="cuda") / (9 * Ci) ** 0.5).requires_grad_(True)
+    assert hip.conv3x3s2_x3_supported(x1, w1)
+    y1 = hip.conv3x3s2_x3(x1, w1)
+    x2, w2 = x1.detach().double().requires_grad_(True), w1.detach().double().requires_grad_(True)
+    y2 = F.conv2d(x2, w2, stride=2, padding=1)
+    assert y1.dtype == torch.float32 and _err(y1, y2.detach()) <= TOL, _err(y1, y2.detach())
+    g = torch.randn_like(y1)
+    y1.backward(g)
+    y2.backward(g.double())
+    assert _err(x1.grad, x2.grad) <= TOL, _err(x1.grad, x2.grad)
+    assert _err(w1.grad, w2.grad) <= TOL, _err(w1.grad, w2.grad)
