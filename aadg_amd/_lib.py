@@ -58,6 +58,7 @@ EXPORTS = [
     "aadg_weight_layouts_bf16",
     "aadg_weight_layouts_split_bf16", "aadg_conv1x1_nchw_f32x3", "aadg_conv1x1_wgrad_f32x3", "aadg_conv3x3_nchw_f32x3",
     "aadg_conv3x3_wgrad_f32x3", "aadg_conv3x3s2_nchw_f32x3", "aadg_conv3x3s2_dgrad_f32x3", "aadg_conv3x3s2_wgrad_f32x3",
+    "aadg_stem_conv7x7_f32x3", "aadg_stem_conv7x7_wgrad_f32x3",
 ]
 
 _lib = None
@@ -248,6 +249,10 @@ def load():
     lib.aadg_conv3x3_nchw_f32x3.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
     lib.aadg_conv3x3_wgrad_f32x3.restype = _i
     lib.aadg_conv3x3_wgrad_f32x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
+    lib.aadg_stem_conv7x7_f32x3.restype = _i
+    lib.aadg_stem_conv7x7_f32x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp, ctypes.c_size_t, _vp]
+    lib.aadg_stem_conv7x7_wgrad_f32x3.restype = _i
+    lib.aadg_stem_conv7x7_wgrad_f32x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp]
     lib.aadg_conv3x3s2_nchw_f32x3.restype = _i
     lib.aadg_conv3x3s2_nchw_f32x3.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.aadg_conv3x3s2_dgrad_f32x3.restype = _i
@@ -298,6 +303,19 @@ def _stream():
 
 
 _ws_cache = {}
+_zws_cache = {}
+
+
+def _zeroed_workspace(nbytes, device, tag):
+    """Scratch whose CONTENT is part of a kernel's contract: zero-filled when handed out for the first time, and every call leaves it
+    zero-filled (aadg_seg_bce_dice_*: integer accumulators and an arrival counter).  One buffer per (device, stream, tag, size): two
+    streams must not share accumulators."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream(), tag, int(nbytes))
+    buf = _zws_cache.get(key)
+    if buf is None:
+        buf = _zws_cache[key] = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+    return buf
+
 
 
 def workspace(nbytes, device, tag="default"):
@@ -619,7 +637,7 @@ def seg_bce_dice(logits, labels, M, want_grad=False, grad_scale=1.0):
     dice = torch.empty(K, dtype=torch.float32, device=logits.device)
     grad = torch.empty_like(logits) if want_grad else None
     nb = lib.aadg_seg_loss_workspace_bytes(N, K, HW)
-    ws = workspace(nb, logits.device, "segloss")
+    ws = _zeroed_workspace(nb, logits.device, "segloss")         # accumulators + arrival counter: zero on entry, left zeroed by the kernel
     rc = lib.aadg_seg_bce_dice_scaled_f32(logits.data_ptr(), labels.data_ptr(), N, K, HW, M, float(grad_scale), bce.data_ptr(),
                                           dice.data_ptr(), _ptr(grad), ws.data_ptr(), ws.numel(), _stream())
     _check(rc, "aadg_seg_bce_dice_scaled_f32")
@@ -1413,6 +1431,43 @@ class _StemConv7x7(torch.autograd.Function):
         dx, dw, _ = torch.ops.aten.convolution_backward(dy, xb, weight.to(torch.bfloat16), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
                                                         [True, True, False])
         return dx.to(x.dtype), dw.to(weight.dtype)
+
+
+class _StemConv7x7X3(torch.autograd.Function):
+    """conv2d(x [N,3,H,W] float32, weight [64,3,7,7] float32, stride 2, padding 3) -> float32 at float32 precision (the X3 instantiations
+    of csrc/stem_conv.hip: forward and weight gradient).  The image needs no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        lib = load()
+        N, C, H, W = x.shape
+        y = torch.empty((N, 64, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        ws = workspace(lib.aadg_stem_conv7x7_workspace_bytes(), x.device, "stem")
+        _check(lib.aadg_stem_conv7x7_f32x3(x.data_ptr(), weight.data_ptr(), y.data_ptr(), N, H, W, ws.data_ptr(), ws.numel(), _stream()),
+               "aadg_stem_conv7x7_f32x3")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[1]:
+            N, C, H, W = x.shape
+            dw = torch.empty_like(weight)
+            _check(load().aadg_stem_conv7x7_wgrad_f32x3(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, H, W, _stream()),
+                   "aadg_stem_conv7x7_wgrad_f32x3")
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        return dx, dw
+
+
+def stem_conv7x7_x3(x, weight):
+    _require_cuda(x, weight)
+    if not (stem_conv7x7_supported(x, weight) and x.dtype == torch.float32):
+        raise AadgError("stem_conv7x7_x3: unsupported shape / dtype / layout")
+    return _StemConv7x7X3.apply(x, weight)
 
 
 def stem_conv7x7_supported(x, weight):

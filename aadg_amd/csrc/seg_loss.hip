@@ -9,8 +9,16 @@
 // with one streaming read of logits + labels (float4 per lane) and an optional write of d(loss)/d(logits),
 // where loss = mean_j BCE_j, so that backward needs no further pass.
 //
-// Determinism: block partials go to the workspace and are combined in a fixed order by a second tiny
-// kernel (no float atomics).
+// ONE launch (round 5; a second tiny kernel combined the block partials before: 15 us + a launch boundary behind a 160 us pass).
+// Every workgroup adds its partial sums to accumulators in the workspace with INTEGER device-scope atomics -- the BCE sum as 40.24
+// fixed point (int64), the Dice counts as int32 per (sample, class) -- and then bumps an arrival counter; the workgroup that arrives
+// last reads the accumulators, writes the M + K results and leaves the workspace zeroed for the next call.  Integer addition is
+// associative, so the result does not depend on the arrival order: deterministic, as the two-kernel version was.  No __threadfence:
+// everything that crosses workgroups travels through returning device-scope atomics (performed at the memory side, past the
+// per-XCD L2s), and a workgroup bumps the counter only after its own atomics have returned -- a device-scope release fence per
+// workgroup (an L2 write-back each, 9216 of them) was measured to cost far more than the launch it would save (BatchNorm).
+// Fixed point: a workgroup's BCE partial (<= 100 x 8192 elements) is rounded to 2^-24: <= 3e-8 absolute per partial, ~5e-12 of a
+// policy's sum; the sum of a policy (<= 1.3e9 at N = 144 x 2 x 512^2) times 2^24 stays far inside int64.
 #include "common.h"
 
 namespace {
@@ -18,10 +26,21 @@ namespace {
 constexpr int SL_THREADS = 256;
 constexpr int SL_CHUNK = SL_THREADS * 4 * 8;  // elements per block: 8 float4 per thread
 
-struct Partial {
-    double bce;
-    int tp, fp, fn, pad;
+constexpr int SL_SLOTS = 16;                  // BCE accumulators per policy (spreads the atomics of ~1500 workgroups per policy)
+constexpr double SL_FIX = 16777216.0;         // 2^24
+
+// workspace: [M][SL_SLOTS] int64 BCE sums | [N*K][4] int32 (tp, fp, fn, -) | arrival counter
+struct SlWs {
+    size_t bce, cnt, counter, total;
 };
+__host__ __device__ inline SlWs sl_ws(int N, int K, int M) {
+    SlWs w;
+    w.bce = 0;
+    w.cnt = (size_t)M * SL_SLOTS * 8;
+    w.counter = w.cnt + (size_t)N * K * 16;
+    w.total = w.counter + 16;
+    return w;
+}
 
 __device__ __forceinline__ void elem(float z, float y, float gscale, float& bce, int& tp, int& fp, int& fn, float* g) {
     // torch.sigmoid then nn.BCELoss on the ROUNDED probability (so fp32 saturation behaves as in the reference:
@@ -43,9 +62,10 @@ __device__ __forceinline__ void elem(float z, float y, float gscale, float& bce,
 }
 
 // grid (chunks, N*K)
-__global__ __launch_bounds__(SL_THREADS) void k_seg_partial(const float* __restrict__ logits, const float* __restrict__ labels,
-                                                            int HW, float gscale, float* __restrict__ grad,
-                                                            Partial* __restrict__ part, int stream) {
+__global__ __launch_bounds__(SL_THREADS) void k_seg_loss(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                         int HW, float gscale, float* __restrict__ grad, unsigned char* __restrict__ ws,
+                                                         int stream, int N, int K, int M, float* __restrict__ out_bce,
+                                                         float* __restrict__ out_dice) {
     const int plane = blockIdx.y;
     const size_t base = (size_t)plane * HW;
     const int c0 = blockIdx.x * SL_CHUNK;
@@ -75,68 +95,78 @@ __global__ __launch_bounds__(SL_THREADS) void k_seg_partial(const float* __restr
     tp = wave_sum(tp); fp = wave_sum(fp); fn = wave_sum(fn);
     __shared__ double sb[4];
     __shared__ int st[4][3];
+    __shared__ int last;
     const int wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { sb[wv] = b; st[wv][0] = tp; st[wv][1] = fp; st[wv][2] = fn; }
     __syncthreads();
+    const SlWs W = sl_ws(N, K, M);
+    long long* acc_bce = reinterpret_cast<long long*>(ws + W.bce);
+    int* acc_cnt = reinterpret_cast<int*>(ws + W.cnt);
+    unsigned int* counter = reinterpret_cast<unsigned int*>(ws + W.counter);
     if (threadIdx.x == 0) {
-        Partial o;
-        o.bce = (sb[0] + sb[1]) + (sb[2] + sb[3]);
-        o.tp = st[0][0] + st[1][0] + st[2][0] + st[3][0];
-        o.fp = st[0][1] + st[1][1] + st[2][1] + st[3][1];
-        o.fn = st[0][2] + st[1][2] + st[2][2] + st[3][2];
-        o.pad = 0;
-        part[(size_t)plane * gridDim.x + blockIdx.x] = o;
+        const double bsum = (sb[0] + sb[1]) + (sb[2] + sb[3]);
+        const int n = plane / K, wg = plane * gridDim.x + blockIdx.x;
+        // returning device-scope atomics: performed at the memory side before their value comes back
+        long long r0 = __hip_atomic_fetch_add(acc_bce + (size_t)(n % M) * SL_SLOTS + (wg & (SL_SLOTS - 1)), __double2ll_rn(bsum * SL_FIX),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int r1 = __hip_atomic_fetch_add(acc_cnt + 4 * plane + 0, st[0][0] + st[1][0] + st[2][0] + st[3][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int r2 = __hip_atomic_fetch_add(acc_cnt + 4 * plane + 1, st[0][1] + st[1][1] + st[2][1] + st[3][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int r3 = __hip_atomic_fetch_add(acc_cnt + 4 * plane + 2, st[0][2] + st[1][2] + st[2][2] + st[3][2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the counter is bumped only once those four have returned (the asm consumes their values behind a full VMEM wait)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3)::"memory");
+        const unsigned int total = gridDim.x * gridDim.y;
+        const unsigned int before = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = before == total - 1u;
     }
-}
-
-// grid M + K workgroups of 256 threads: workgroup t < M -> BCE of policy t; workgroup M + k -> Dice of class k.  Every thread sums a
-// fixed subset of the partial records, the workgroup combines them in a fixed order (deterministic, no atomics).  (One wave per output
-// walking its records one after the other took 17 us -- 8 % of the pass it finishes.)
-__global__ __launch_bounds__(256) void k_seg_final(const Partial* __restrict__ part, int N, int K, int HW, int M,
-                                                  int chunks, float* __restrict__ out_bce, float* __restrict__ out_dice) {
-    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __syncthreads();
+    if (!last) return;
+    // ---- the last workgroup: every other workgroup's atomics were performed before its counter bump ---------------------------------
+    const int tid = threadIdx.x, lane = tid & 63;
     __shared__ double red[4];
-    double acc = 0.0;
-    if (t < M) {
-        // policy t owns the planes of rows t, t + M, ...: rows * K * chunks records
-        const int rows = (N - t + M - 1) / M, per_row = K * chunks, total = rows * per_row;
-#pragma unroll 4
-        for (int i = tid; i < total; i += 256) {
-            const int r = t + (i / per_row) * M;
-            acc += part[(size_t)r * per_row + (i % per_row)].bce;
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) red[wv] = acc;
+    auto block_sum = [&](double v) {
+        v = wave_sum(v);
         __syncthreads();
-        if (tid == 0) out_bce[t] = (float)(((red[0] + red[1]) + (red[2] + red[3])) / ((double)rows * K * HW));
-    } else {
-        // class k: samplewise F1; 32 lanes walk the chunks of one sample, a wave holds two samples at a time
-        const int k = t - M, half = lane >> 5, l = lane & 31;
-        for (int r0 = (wv * 2 + half); r0 < N + 8; r0 += 8) {                     // uniform trip count (shuffles below)
-            const bool live = r0 < N;
-            const Partial* p = part + ((size_t)min(r0, N - 1) * K + k) * chunks;
-            int tp = 0, fp = 0, fn = 0;
-            if (live)
-                for (int c = l; c < chunks; c += 32) { tp += p[c].tp; fp += p[c].fp; fn += p[c].fn; }
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { tp += __shfl_xor(tp, o, 64); fp += __shfl_xor(fp, o, 64); fn += __shfl_xor(fn, o, 64); }
-            const long den = 2l * tp + fp + fn;
-            if (live && l == 0) acc += den ? (2.0 * (double)tp) / (double)den : 0.0;
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) red[wv] = acc;
+        if (lane == 0) red[wv] = v;
         __syncthreads();
-        if (tid == 0) out_dice[k] = (float)(((red[0] + red[1]) + (red[2] + red[3])) / N);
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    for (int t = 0; t < M; ++t) {                                        // per-policy BCE: policy t owns the rows t, t + M, ...
+        long long v = 0;
+        if (tid < SL_SLOTS) {
+            v = __hip_atomic_load(acc_bce + (size_t)t * SL_SLOTS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(acc_bce + (size_t)t * SL_SLOTS + tid, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned long long u = wave_sum((unsigned long long)v);          // (two's complement: the wrap-around sum of signed values)
+        const int rows = (N - t + M - 1) / M;
+        if (tid == 0) out_bce[t] = (float)(((double)(long long)u / SL_FIX) / ((double)rows * K * HW));
     }
+    for (int k = 0; k < K; ++k) {                                        // class k: samplewise F1, mean over the samples
+        double acc = 0.0;
+        for (int n = tid; n < N; n += SL_THREADS) {
+            int* c = acc_cnt + 4 * (n * K + k);
+            const int a = __hip_atomic_load(c + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int f = __hip_atomic_load(c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int m = __hip_atomic_load(c + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(c + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(c + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(c + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long den = 2l * a + f + m;
+            acc += den ? (2.0 * (double)a) / (double)den : 0.0;
+        }
+        const double tot = block_sum(acc);
+        if (tid == 0) out_dice[k] = (float)(tot / N);
+    }
+    if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 int chunks_of(int HW) { return (HW + SL_CHUNK - 1) / SL_CHUNK; }
 
 }  // namespace
 
+// (sized for M <= N; independent of HW since round 5)
 extern "C" size_t aadg_seg_loss_workspace_bytes(int N, int K, int HW) {
     if (N <= 0 || K <= 0 || HW <= 0) return 0;
-    return aadg_align_up((size_t)N * K * chunks_of(HW) * sizeof(Partial), 256);
+    return aadg_align_up(sl_ws(N, K, N).total, 256);
 }
 
 extern "C" int aadg_seg_bce_dice_scaled_f32(const float* logits, const float* labels, int N, int K, int HW, int M, float grad_scale,
@@ -147,13 +177,12 @@ extern "C" int aadg_seg_bce_dice_scaled_f32(const float* logits, const float* la
     if (ws_bytes < aadg_seg_loss_workspace_bytes(N, K, HW)) return AADG_E_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int chunks = chunks_of(HW);
-    Partial* part = reinterpret_cast<Partial*>(ws);
+    if ((long long)chunks * N * K > 0x7FFFFFFFLL || (((uintptr_t)ws) & 7u) != 0) return AADG_E_BADARG;
     // d (grad_scale * mean_j(BCE_j)) / dz: every element of policy j weighs grad_scale / (M * (N/M) * K * HW)
     const float gscale = (float)((double)grad_scale / ((double)N * K * HW));
-    hipLaunchKernelGGL(k_seg_partial, dim3(chunks, N * K), dim3(SL_THREADS), 0, st, logits, labels, HW, gscale,
-                       grad_logits, part, (size_t)N * K * HW * sizeof(float) > ((size_t)128 << 20) ? 1 : 0);
-    AADG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_seg_final, dim3(M + K), dim3(256), 0, st, part, N, K, HW, M, chunks, out_bce, out_dice);
+    hipLaunchKernelGGL(k_seg_loss, dim3(chunks, N * K), dim3(SL_THREADS), 0, st, logits, labels, HW, gscale, grad_logits,
+                       reinterpret_cast<unsigned char*>(ws), (size_t)N * K * HW * sizeof(float) > ((size_t)128 << 20) ? 1 : 0, N, K, M, out_bce,
+                       out_dice);
     AADG_LAUNCH_CHECK();
     return 0;
 }

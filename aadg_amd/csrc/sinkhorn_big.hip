@@ -204,6 +204,112 @@ __global__ __launch_bounds__(256) void k_big_cost(const int* cloud_off, const in
     }
 }
 
+// ---- the same three matrices through the bfloat16 matrix cores at float32 precision ("f32x3", csrc/common.h: aadg_split4): every
+// operand value is split into bfloat16 halves x = hi + lo and every product formed as hi*hi + hi*lo + lo*hi with float32 accumulation:
+// a third of the bfloat16 MFMA rate = 5.3x the float32 MFMA rate (gfx950 has no tf32).  The unit-length rows keep |C| error <= 2^-17
+// (measured against the float32 kernel above: tests/test_gpu_sinkhorn.py).  Both operands are K-contiguous rows: a loaded float4 becomes
+// one 16-byte LDS chunk [hi0..3][lo0..3], a fragment (8 K-values) is two chunks.  128 x 128 tile (4 waves of 64 x 64), K chunks of 64.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+constexpr int CX = 128, CXK = 64, CX_PITCH = 2 * CXK + 8;     // tile, K chunk, LDS row pitch (bfloat16 elements: 272 bytes)
+
+__global__ __launch_bounds__(256) void k_big_cost_x3(const int* cloud_off, const int* prob_xy, int nmax, int E, float* ws) {
+    const int p = blockIdx.z / 3, which = blockIdx.z - 3 * p;         // 0 xx, 1 yy, 2 xy (+ yx = its transpose)
+    const BigLayout L = big_layout(nmax, E);
+    float* base = ws + (size_t)p * L.total;
+    const int cx = prob_xy[2 * p], cy = prob_xy[2 * p + 1];
+    const int n = cloud_off[cx + 1] - cloud_off[cx], m = cloud_off[cy + 1] - cloud_off[cy];
+    const float* Am = base + ((which == 0 || which == 2) ? L.xn : L.yn);
+    const float* Bm = base + (which == 0 ? L.xn : L.yn);
+    const int rows = (which == 0 || which == 2) ? n : m, cols = which == 0 ? n : m;
+    float* C = base + (which == 0 ? L.cxx : which == 1 ? L.cyy : L.cxy);
+    const int i0 = blockIdx.y * CX, j0 = blockIdx.x * CX;
+    if (i0 >= rows || j0 >= cols) return;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds_x3[];
+    uint16_t* As = lds_x3;                           // [128][CX_PITCH]
+    uint16_t* Bs = lds_x3 + CX * CX_PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wi = (wv >> 1) * 64, wj = (wv & 1) * 64, g = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    for (int k0 = 0; k0 < E; k0 += CXK) {
+        // 128 rows x 16 chunks of 4 K-values per operand: 8 chunks per thread and operand (E % 4 == 0: the caller checks)
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int id = tid + 256 * (i & 7), r = id >> 4, c = id & 15, k = k0 + 4 * c;
+            const bool isb = i >= 8;
+            const int gr = (isb ? j0 : i0) + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr < (isb ? cols : rows) && k < E) v = *reinterpret_cast<const float4*>((isb ? Bm : Am) + (size_t)gr * E + k);
+            uint2 hi, lo;
+            aadg_split4(v, hi, lo);
+            *reinterpret_cast<uint4*>((isb ? Bs : As) + r * CX_PITCH + 8 * c) = make_uint4(hi.x, hi.y, lo.x, lo.y);
+        }
+        __syncthreads();
+        const int kc = min(CXK, E - k0);
+#pragma unroll
+        for (int ks = 0; ks < CXK / 16; ++ks) {
+            if (16 * ks >= kc) break;
+            bf16x8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint16_t* pa = As + (wi + 32 * t + (lane & 31)) * CX_PITCH + 32 * ks + 16 * g;
+                const uint4 q0 = *reinterpret_cast<const uint4*>(pa), q1 = *reinterpret_cast<const uint4*>(pa + 8);
+                ah[t] = __builtin_bit_cast(bf16x8_t, make_uint4(q0.x, q0.y, q1.x, q1.y));
+                al[t] = __builtin_bit_cast(bf16x8_t, make_uint4(q0.z, q0.w, q1.z, q1.w));
+                const uint16_t* pb = Bs + (wj + 32 * t + (lane & 31)) * CX_PITCH + 32 * ks + 16 * g;
+                const uint4 r0 = *reinterpret_cast<const uint4*>(pb), r1 = *reinterpret_cast<const uint4*>(pb + 8);
+                bh[t] = __builtin_bit_cast(bf16x8_t, make_uint4(r0.x, r0.y, r1.x, r1.y));
+                bl[t] = __builtin_bit_cast(bf16x8_t, make_uint4(r0.z, r0.w, r1.z, r1.w));
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                }
+        }
+    }
+    // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wi + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * g, col = j0 + wj + 32 * b + (lane & 31);
+                if (row < rows && col < cols) C[(size_t)row * nmax + col] = 1.0f - acc[a][b][r];
+            }
+    if (which == 2) {
+        // C_yx = C_xy^T, transposed through LDS (the operand buffers are free): 32 lanes write 128 contiguous bytes of a C_yx row
+        __syncthreads();
+        float* T = reinterpret_cast<float*>(lds_x3) + wv * 32 * 33;
+        float* Ct = base + L.cyx;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * g) * 33 + (lane & 31)] = 1.0f - acc[a][b][r];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int c = 2 * t + g, rr = lane & 31;
+                    const int row = i0 + wi + 32 * a + rr, col = j0 + wj + 32 * b + c;
+                    if (row < rows && col < cols) Ct[(size_t)col * nmax + row] = T[rr * 33 + c];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+    }
+}
+
 // ---- one sweep: grid (4 * ceil(nmax/4), n_prob), 256 threads: wave <-> one row of one of the four softmins ---------
 // step 0: initialisation at eps_s[0] (no potentials);  1..nits: eps-scaling with symmetrised update;
 // nits+1: final extrapolation (no averaging, written to the tilde buffers);  beyond: nothing.
@@ -331,8 +437,20 @@ int aadg_sinkhorn_big_launch(const float* feat, int ld, int E, const int* cloud_
     AADG_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_big_schedule, dim3(n_prob), dim3(256), 0, st, nmax, E, blur, scaling, w);
     AADG_LAUNCH_CHECK();
-    const int tiles = (nmax + CT - 1) / CT;
-    hipLaunchKernelGGL(k_big_cost, dim3(tiles, tiles, n_prob * 3), dim3(256), 0, st, cloud_off, prob_xy, nmax, E, w);
+    if ((E & 3) == 0) {
+        // the float32-precision build on the bfloat16 matrix cores (three products per pair of split operands)
+        const int tiles = (nmax + CX - 1) / CX;
+        const size_t lds = (size_t)2 * CX * CX_PITCH * sizeof(uint16_t);
+        static bool attr_set = false;
+        if (!attr_set) {
+            AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_cost_x3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_big_cost_x3, dim3(tiles, tiles, n_prob * 3), dim3(256), lds, st, cloud_off, prob_xy, nmax, E, w);
+    } else {
+        const int tiles = (nmax + CT - 1) / CT;
+        hipLaunchKernelGGL(k_big_cost, dim3(tiles, tiles, n_prob * 3), dim3(256), 0, st, cloud_off, prob_xy, nmax, E, w);
+    }
     AADG_LAUNCH_CHECK();
     const dim3 gs(4 * ((nmax + 3) / 4), n_prob);
     for (int step = 0; step <= BIG_MAX_ITS + 1; ++step) {

@@ -45,13 +45,25 @@ __global__ __launch_bounds__(256) void k_stem_pack(const float* __restrict__ w, 
 #pragma unroll
         for (int k = 0; k < 7; ++k) v[k + 1] = p[k];
     }
-    wfrag[t] = make_uint4(aadg_f2bf_pk(v[0], v[1]), aadg_f2bf_pk(v[2], v[3]), aadg_f2bf_pk(v[4], v[5]), aadg_f2bf_pk(v[6], v[7]));
+    uint2 h0, l0, h1, l1;                                           // (hi, lo) halves: the float32-precision kernel reads both planes
+    aadg_split4(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
+    aadg_split4(make_float4(v[4], v[5], v[6], v[7]), h1, l1);
+    wfrag[t] = make_uint4(h0.x, h0.y, h1.x, h1.y);                  // = the bfloat16 rounding of the weights (what the bfloat16 kernel reads)
+    wfrag[ST_KS * 2 * 64 + t] = make_uint4(l0.x, l0.y, l1.x, l1.y);
 }
 
-template <typename TIN>
+// X3 = true ("f32x3", csrc/conv1x1_fwd.hip): float32 image in, float32 map out; the patch is staged as (hi, lo) bfloat16 planes, the
+// hi weight fragments stay in registers, the lo ones in LDS; hi*hi + hi*lo + lo*hi per fragment pair, float32 accumulation.
+template <typename TIN, bool X3>
 __global__ __launch_bounds__(256) void k_stem7x7(const TIN* __restrict__ x, const uint4* __restrict__ wfrag,
-                                                 uint16_t* __restrict__ y, int H, int W, int tiles_x, int tiles_y, int total_tiles) {
-    __shared__ __attribute__((aligned(16))) uint16_t P[3 * ST_PR * ST_PC];
+                                                 void* __restrict__ y_, int H, int W, int tiles_x, int tiles_y, int total_tiles) {
+    constexpr int PL = X3 ? 2 : 1, P_EL = 3 * ST_PR * ST_PC;
+    __shared__ __attribute__((aligned(16))) uint16_t P[PL * P_EL];
+    __shared__ __attribute__((aligned(16))) uint4 WLo[X3 ? ST_KS * 2 * 64 : 1];
+    uint16_t* y = reinterpret_cast<uint16_t*>(y_);
+    if (X3) {
+        for (int i = threadIdx.x; i < ST_KS * 2 * 64; i += 256) WLo[i] = wfrag[ST_KS * 2 * 64 + i];
+    }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int jj = lane & 31, g = lane >> 5;
     const int Ho = H / 2, Wo = W / 2;
@@ -75,9 +87,21 @@ __global__ __launch_bounds__(256) void k_stem7x7(const TIN* __restrict__ x, cons
             const int q = it % (ST_PC / 8), rc = it / (ST_PC / 8);
             const int pr = rc % ST_PR, c = rc / ST_PR;
             const int row = 2 * i0 - 3 + pr, col = 2 * j0 - 8 + 8 * q;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (row >= 0 && row < H && col >= 0 && col < W) v = load8_bf16<TIN>(xn + ((size_t)c * H + row) * W + col);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u), vl = make_uint4(0u, 0u, 0u, 0u);
+            if (row >= 0 && row < H && col >= 0 && col < W) {
+                if constexpr (X3) {
+                    const float* src = reinterpret_cast<const float*>(xn) + ((size_t)c * H + row) * W + col;
+                    uint2 h0, l0, h1, l1;
+                    aadg_split4(*reinterpret_cast<const float4*>(src), h0, l0);
+                    aadg_split4(*reinterpret_cast<const float4*>(src + 4), h1, l1);
+                    v = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                    vl = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                } else {
+                    v = load8_bf16<TIN>(xn + ((size_t)c * H + row) * W + col);
+                }
+            }
             *reinterpret_cast<uint4*>(P + (c * ST_PR + pr) * ST_PC + 8 * q) = v;
+            if (X3) *reinterpret_cast<uint4*>(P + P_EL + (c * ST_PR + pr) * ST_PC + 8 * q) = vl;
         }
         __syncthreads();
 #pragma unroll 1
@@ -95,16 +119,44 @@ __global__ __launch_bounds__(256) void k_stem7x7(const TIN* __restrict__ x, cons
             const uint32_t* Pw = reinterpret_cast<const uint32_t*>(P + 2 * ro * ST_PC + 2 * jj + 4);
 #pragma unroll
             for (int ks = 0; ks < ST_KS; ++ks) {
-                bf16x8 b[2];
+                bf16x8 b[2], bl[2], al[2];
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const uint32_t* p = Pw + (koff[ks] >> 1) + 32 * nt;
                     b[nt] = __builtin_bit_cast(bf16x8, make_uint4(p[0], p[1], p[2], p[3]));
+                    if (X3) {
+                        const uint32_t* q = p + P_EL / 2;
+                        bl[nt] = __builtin_bit_cast(bf16x8, make_uint4(q[0], q[1], q[2], q[3]));
+                    }
+                }
+                if (X3) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) al[mt] = __builtin_bit_cast(bf16x8, WLo[(ks * 2 + mt) * 64 + lane]);
                 }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) d[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][ks], b[nt], d[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < 2; ++nt) {
+                        if (X3) {
+                            d[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], b[nt], d[mt][nt], 0, 0, 0);
+                            d[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][ks], bl[nt], d[mt][nt], 0, 0, 0);
+                        }
+                        d[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][ks], b[nt], d[mt][nt], 0, 0, 0);
+                    }
+            }
+            if constexpr (X3) {
+                // float32 out: the 32 lanes of a channel row store 128 contiguous bytes (streaming: 2.4 GB at N = 144 x 512^2)
+                float* yf = reinterpret_cast<float*>(y_) + (((size_t)n * ST_CO) * Ho + i) * Wo + j0;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int o = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g, j = 32 * nt + jj;
+                            if (j0 + j < Wo) __builtin_nontemporal_store(d[mt][nt][r], yf + (size_t)o * Ho * Wo + j);
+                        }
+                continue;
             }
             // C/D layout: column (pixel) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
             // Lanes j (even) and j + 1 trade registers r / r + 1: the even lane stores pixels (j, j + 1) of channel row r,
@@ -147,13 +199,19 @@ constexpr int SW_DY_ELEMS = SW_ROWS * SW_CH * SW_DPITCH, SW_X_ELEMS = 2 * 3 * SW
 constexpr int SW_RED_FLOATS = SW_CH * 32 * SW_NT;
 constexpr int SW_DY_ITEMS = SW_ROWS * SW_CH * (SW_PX / 8) / 256, SW_X_CHUNKS = 3 * SW_XROWS * 18, SW_X_ITEMS = (SW_X_CHUNKS + 255) / 256;
 
-template <typename TIN>
-__global__ __launch_bounds__(256, 2) void k_stem7x7_wgrad(const TIN* __restrict__ x, const uint16_t* __restrict__ dy,
+// X3 = true ("f32x3"): x and dy float32; both are split into (hi, lo) bfloat16 planes on their way to LDS, the fragments are built per
+// plane, and every product is hi*hi + hi*lo + lo*hi with float32 accumulation.
+template <typename TIN, bool X3>
+__global__ __launch_bounds__(256, 2) void k_stem7x7_wgrad(const TIN* __restrict__ x, const void* __restrict__ dy_,
                                                        float* __restrict__ dw, int H, int W, int tiles_x, int tiles_y, int total_tiles) {
-    constexpr int LDS_BYTES = (SW_DY_ELEMS + SW_X_ELEMS) * 2 > SW_RED_FLOATS * 4 ? (SW_DY_ELEMS + SW_X_ELEMS) * 2 : SW_RED_FLOATS * 4;
+    constexpr int PL = X3 ? 2 : 1;
+    constexpr int OP_BYTES = PL * (SW_DY_ELEMS + SW_X_ELEMS) * 2;
+    constexpr int LDS_BYTES = OP_BYTES > SW_RED_FLOATS * 4 ? OP_BYTES : SW_RED_FLOATS * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
-    uint16_t* dyL = reinterpret_cast<uint16_t*>(lds_raw);                 // [row][channel][SW_DPITCH]
-    uint16_t* xL = dyL + SW_DY_ELEMS;                                     // [parity][c][patch row][SW_XPITCH], index = m + 2
+    uint16_t* dyL = reinterpret_cast<uint16_t*>(lds_raw);                 // [plane][row][channel][SW_DPITCH]
+    uint16_t* xL = dyL + PL * SW_DY_ELEMS;                                // [plane][parity][c][patch row][SW_XPITCH], index = m + 2
+    const uint16_t* dy = reinterpret_cast<const uint16_t*>(dy_);
+    const float* dyf = reinterpret_cast<const float*>(dy_);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int g = lane >> 5;
     const int Ho = H / 2, Wo = W / 2;
@@ -173,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7_wgrad(const TIN* __restrict_
         for (int r = 0; r < 16; ++r) d[nt][r] = 0.0f;
 
     // tile = (image, row block, column block, channel half); the staged chunks of a tile live in registers until the LDS is free
-    uint4 rdy[SW_DY_ITEMS], rx[SW_X_ITEMS];
+    uint4 rdy[PL * SW_DY_ITEMS], rx[PL * SW_X_ITEMS];            // X3: [2 k] / [2 k + 1] = pixels 0..3 / 4..7 of chunk k as float32
 #define AADG_SW_ISSUE(tile_)                                                                                               \
     do {                                                                                                                   \
         const int half_ = (tile_) & 1, t1_ = (tile_) >> 1;                                                                 \
@@ -181,20 +239,32 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7_wgrad(const TIN* __restrict_
         const int ty_ = t2_ % tiles_y, n_ = t2_ / tiles_y;                                                                 \
         const int i0_ = ty_ * SW_ROWS, j0_ = tx_ * SW_PX;                                                                  \
         const TIN* xn_ = x + (size_t)n_ * 3 * H * W;                                                                  \
-        const uint16_t* dyn_ = dy + ((size_t)n_ * ST_CO + half_ * SW_CH) * Ho * Wo;                                       \
+        const size_t dyo_ = ((size_t)n_ * ST_CO + half_ * SW_CH) * Ho * Wo;                                               \
         _Pragma("unroll") for (int k_ = 0; k_ < SW_DY_ITEMS; ++k_) {                                                       \
             const int it_ = tid + 256 * k_, q_ = it_ & 7, o_ = (it_ >> 3) & (SW_CH - 1), r_ = it_ >> 8;                    \
             const int i_ = i0_ + r_, j_ = j0_ + 8 * q_;                                                                    \
-            rdy[k_] = make_uint4(0u, 0u, 0u, 0u);                                                                          \
-            if (i_ < Ho && j_ < Wo) rdy[k_] = *reinterpret_cast<const uint4*>(dyn_ + ((size_t)o_ * Ho + i_) * Wo + j_);    \
+            const bool ok_ = i_ < Ho && j_ < Wo;                                                                           \
+            const size_t e_ = dyo_ + ((size_t)o_ * Ho + i_) * Wo + j_;                                                     \
+            if (X3) {                                                                                                      \
+                rdy[PL * k_] = ok_ ? *reinterpret_cast<const uint4*>(dyf + e_) : make_uint4(0u, 0u, 0u, 0u);               \
+                rdy[PL * k_ + PL - 1] = ok_ ? *reinterpret_cast<const uint4*>(dyf + e_ + 4) : make_uint4(0u, 0u, 0u, 0u);  \
+            } else {                                                                                                       \
+                rdy[k_] = ok_ ? *reinterpret_cast<const uint4*>(dy + e_) : make_uint4(0u, 0u, 0u, 0u);                     \
+            }                                                                                                              \
         }                                                                                                                  \
         _Pragma("unroll") for (int k_ = 0; k_ < SW_X_ITEMS; ++k_) {                                                        \
             const int it_ = tid + 256 * k_, q_ = it_ % 18, rc_ = it_ / 18;                                                 \
             const int pr_ = rc_ % SW_XROWS, c_ = rc_ / SW_XROWS;                                                           \
             const int row_ = 2 * i0_ - 3 + pr_, col_ = 2 * j0_ - 8 + 8 * q_;                                               \
-            rx[k_] = make_uint4(0u, 0u, 0u, 0u);                                                                           \
-            if (it_ < SW_X_CHUNKS && row_ >= 0 && row_ < H && col_ >= 0 && col_ < W)                                       \
-                rx[k_] = load8_bf16<TIN>(xn_ + ((size_t)c_ * H + row_) * W + col_);                        \
+            const bool okx_ = it_ < SW_X_CHUNKS && row_ >= 0 && row_ < H && col_ >= 0 && col_ < W;                         \
+            if (X3) {                                                                                                      \
+                const float* sx_ = reinterpret_cast<const float*>(xn_) + ((size_t)c_ * H + row_) * W + col_;               \
+                rx[PL * k_] = okx_ ? *reinterpret_cast<const uint4*>(sx_) : make_uint4(0u, 0u, 0u, 0u);                    \
+                rx[PL * k_ + PL - 1] = okx_ ? *reinterpret_cast<const uint4*>(sx_ + 4) : make_uint4(0u, 0u, 0u, 0u);       \
+            } else {                                                                                                       \
+                rx[k_] = make_uint4(0u, 0u, 0u, 0u);                                                                       \
+                if (okx_) rx[k_] = load8_bf16<TIN>(xn_ + ((size_t)c_ * H + row_) * W + col_);                              \
+            }                                                                                                              \
         }                                                                                                                  \
     } while (0)
 
@@ -203,10 +273,21 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7_wgrad(const TIN* __restrict_
     for (; tile < total_tiles; tile += gridDim.x) {
         const int i0 = (((tile >> 1) / tiles_x) % tiles_y) * SW_ROWS;
         __syncthreads();                                                  // the previous tile's readers are done with the LDS
+        // a chunk's two float4 -> its (hi, lo) bfloat16 halves, 8 pixels each
+        auto halves = [](uint4 q0, uint4 q1, uint4& hi, uint4& lo) {
+            uint2 h0, l0, h1, l1;
+            aadg_split4(make_float4(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w)), h0, l0);
+            aadg_split4(make_float4(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q1.w)), h1, l1);
+            hi = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        };
 #pragma unroll
         for (int k = 0; k < SW_DY_ITEMS; ++k) {
             const int it = tid + 256 * k, q = it & 7, o = (it >> 3) & (SW_CH - 1), r = it >> 8;
-            *reinterpret_cast<uint4*>(dyL + (r * SW_CH + o) * SW_DPITCH + 8 * q) = rdy[k];
+            uint4 vh = rdy[PL * k], vl = make_uint4(0u, 0u, 0u, 0u);
+            if (X3) halves(rdy[PL * k], rdy[PL * k + PL - 1], vh, vl);
+            *reinterpret_cast<uint4*>(dyL + (r * SW_CH + o) * SW_DPITCH + 8 * q) = vh;
+            if (X3) *reinterpret_cast<uint4*>(dyL + SW_DY_ELEMS + (r * SW_CH + o) * SW_DPITCH + 8 * q) = vl;
         }
         // input patch rows 2*i0 - 3 .. 2*i0 + 9, columns 2*j0 - 8 .. 2*j0 + 135, split into even / odd column planes:
         // chunk q (8 columns) -> plane indices 4q .. 4q + 3 of both planes
@@ -216,11 +297,17 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7_wgrad(const TIN* __restrict_
             if (it < SW_X_CHUNKS) {
                 const int q = it % 18, rc = it / 18;
                 const int pr = rc % SW_XROWS, c = rc / SW_XROWS;
-                const uint4 v = rx[k];
-                const uint2 ev = make_uint2((v.x & 0xFFFFu) | (v.y << 16), (v.z & 0xFFFFu) | (v.w << 16));
-                const uint2 od = make_uint2((v.x >> 16) | (v.y & 0xFFFF0000u), (v.z >> 16) | (v.w & 0xFFFF0000u));
-                *reinterpret_cast<uint2*>(xL + ((0 * 3 + c) * SW_XROWS + pr) * SW_XPITCH + 4 * q) = ev;
-                *reinterpret_cast<uint2*>(xL + ((1 * 3 + c) * SW_XROWS + pr) * SW_XPITCH + 4 * q) = od;
+                uint4 vv[PL];
+                vv[0] = rx[PL * k];
+                if (X3) halves(rx[PL * k], rx[PL * k + PL - 1], vv[0], vv[PL - 1]);
+#pragma unroll
+                for (int pl = 0; pl < PL; ++pl) {
+                    const uint4 v = vv[pl];
+                    const uint2 ev = make_uint2((v.x & 0xFFFFu) | (v.y << 16), (v.z & 0xFFFFu) | (v.w << 16));
+                    const uint2 od = make_uint2((v.x >> 16) | (v.y & 0xFFFF0000u), (v.z >> 16) | (v.w & 0xFFFF0000u));
+                    *reinterpret_cast<uint2*>(xL + pl * SW_X_ELEMS + ((0 * 3 + c) * SW_XROWS + pr) * SW_XPITCH + 4 * q) = ev;
+                    *reinterpret_cast<uint2*>(xL + pl * SW_X_ELEMS + ((1 * 3 + c) * SW_XROWS + pr) * SW_XPITCH + 4 * q) = od;
+                }
             }
         }
         __syncthreads();
@@ -229,16 +316,26 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7_wgrad(const TIN* __restrict_
             const uint16_t* A = dyL + (wv * SW_CH + (lane & 31)) * SW_DPITCH + 8 * g;
 #pragma unroll
             for (int ks = 0; ks < SW_PX / 16; ++ks) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(A + 16 * ks));
+                bf16x8 a[PL];
+#pragma unroll
+                for (int pl = 0; pl < PL; ++pl) a[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(A + pl * SW_DY_ELEMS + 16 * ks));
 #pragma unroll
                 for (int nt = 0; nt < SW_NT; ++nt) {
                     const int s = toff[nt] + 16 * ks;                                // first element of this lane's 8 K-values
-                    const uint32_t* p = reinterpret_cast<const uint32_t*>(xL) + (s >> 1);
                     const uint32_t sh = (uint32_t)(s & 1) * 2u;                      // byte shift inside the first dword
-                    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4];
-                    const bf16x8 b = __builtin_bit_cast(bf16x8, make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
-                                                                            __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh)));
-                    d[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, d[nt], 0, 0, 0);
+                    bf16x8 b[PL];
+#pragma unroll
+                    for (int pl = 0; pl < PL; ++pl) {
+                        const uint32_t* p = reinterpret_cast<const uint32_t*>(xL + pl * SW_X_ELEMS) + (s >> 1);
+                        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4];
+                        b[pl] = __builtin_bit_cast(bf16x8, make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
+                                                                      __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh)));
+                    }
+                    if (X3) {
+                        d[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PL - 1], b[0], d[nt], 0, 0, 0);
+                        d[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[PL - 1], d[nt], 0, 0, 0);
+                    }
+                    d[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], d[nt], 0, 0, 0);
                 }
             }
         }
@@ -271,7 +368,7 @@ extern "C" int aadg_stem_conv7x7_supported(int H, int W) {
     return H >= 2 && W >= 16 && (H % 2) == 0 && (W % 16) == 0 ? 1 : 0;      // output width a multiple of 8: aligned 16-byte patch chunks
 }
 
-extern "C" size_t aadg_stem_conv7x7_workspace_bytes(void) { return (size_t)ST_KS * 2 * 64 * sizeof(uint4); }
+extern "C" size_t aadg_stem_conv7x7_workspace_bytes(void) { return (size_t)2 * ST_KS * 2 * 64 * sizeof(uint4); }   // hi + lo weight fragments
 
 /* y [N, 64, H/2, W/2] (bfloat16) = conv2d(bfloat16(x [N, 3, H, W]), weight [64, 3, 7, 7] (float32), stride 2, padding 3);
  * x_dtype 0: x is float32 and is rounded to bfloat16 on load, 1: x is bfloat16 */
@@ -290,11 +387,32 @@ extern "C" int aadg_stem_conv7x7_bf16(const void* x, int x_dtype, const float* w
     AADG_LAUNCH_CHECK();
     const int grid = (int)(total < 512 ? total : 512);              // persistent: the 2 workgroups a CU holds (241 registers per lane), weight fragments loaded once each
     if (x_dtype == 0)
-        hipLaunchKernelGGL(k_stem7x7<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (const uint4*)ws, (uint16_t*)y, H, W, tiles_x,
+        hipLaunchKernelGGL((k_stem7x7<float, false>), dim3(grid), dim3(256), 0, st, (const float*)x, (const uint4*)ws, y, H, W, tiles_x,
                            tiles_y, (int)total);
     else
-        hipLaunchKernelGGL(k_stem7x7<uint16_t>, dim3(grid), dim3(256), 0, st, (const uint16_t*)x, (const uint4*)ws, (uint16_t*)y, H, W,
+        hipLaunchKernelGGL((k_stem7x7<uint16_t, false>), dim3(grid), dim3(256), 0, st, (const uint16_t*)x, (const uint4*)ws, y, H, W,
                            tiles_x, tiles_y, (int)total);
+    AADG_LAUNCH_CHECK();
+    return 0;
+}
+
+/* The same convolution at float32 precision ("f32x3", see aadg_conv1x1_nchw_f32x3): x [N, 3, H, W] and y [N, 64, H/2, W/2] float32 */
+extern "C" int aadg_stem_conv7x7_f32x3(const float* x, const float* weight, float* y, int N, int H, int W, void* ws, size_t ws_bytes,
+                                       void* stream) {
+    if (x == nullptr || weight == nullptr || y == nullptr || ws == nullptr || N <= 0) return AADG_E_BADARG;
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)ws) & 15u) != 0) return AADG_E_BADARG;
+    if (!aadg_stem_conv7x7_supported(H, W)) return AADG_E_UNSUPPORTED;
+    if (ws_bytes < aadg_stem_conv7x7_workspace_bytes()) return AADG_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int Ho = H / 2, Wo = W / 2;
+    const int tiles_x = (Wo + ST_TC - 1) / ST_TC, tiles_y = (Ho + ST_TR - 1) / ST_TR;
+    const long long total = (long long)N * tiles_x * tiles_y;
+    if (total > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_stem_pack, dim3((ST_KS * 2 * 64 + 255) / 256), dim3(256), 0, st, weight, reinterpret_cast<uint4*>(ws));
+    AADG_LAUNCH_CHECK();
+    const int grid = (int)(total < 512 ? total : 512);
+    hipLaunchKernelGGL((k_stem7x7<float, true>), dim3(grid), dim3(256), 0, st, x, (const uint4*)ws, (void*)y, H, W, tiles_x, tiles_y,
+                       (int)total);
     AADG_LAUNCH_CHECK();
     return 0;
 }
@@ -313,11 +431,29 @@ extern "C" int aadg_stem_conv7x7_wgrad_bf16(const void* x, int x_dtype, const vo
     AADG_HIP_TRY(hipMemsetAsync(dweight, 0, (size_t)ST_CO * 147 * sizeof(float), st));
     const int grid = (int)(total < 1024 ? total : 1024);                   // even: a workgroup keeps one channel half
     if (x_dtype == 0)
-        hipLaunchKernelGGL(k_stem7x7_wgrad<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (const uint16_t*)dy, dweight, H, W,
+        hipLaunchKernelGGL((k_stem7x7_wgrad<float, false>), dim3(grid), dim3(256), 0, st, (const float*)x, dy, dweight, H, W,
                            tiles_x, tiles_y, (int)total);
     else
-        hipLaunchKernelGGL(k_stem7x7_wgrad<uint16_t>, dim3(grid), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)dy, dweight, H, W,
+        hipLaunchKernelGGL((k_stem7x7_wgrad<uint16_t, false>), dim3(grid), dim3(256), 0, st, (const uint16_t*)x, dy, dweight, H, W,
                            tiles_x, tiles_y, (int)total);
+    AADG_LAUNCH_CHECK();
+    return 0;
+}
+
+/* ... and from float32 x [N, 3, H, W] / dy [N, 64, H/2, W/2] at float32 precision ("f32x3") */
+extern "C" int aadg_stem_conv7x7_wgrad_f32x3(const float* x, const float* dy, float* dweight, int N, int H, int W, void* stream) {
+    if (x == nullptr || dy == nullptr || dweight == nullptr || N <= 0) return AADG_E_BADARG;
+    if ((((uintptr_t)x | (uintptr_t)dy) & 15u) != 0) return AADG_E_BADARG;
+    if (!aadg_stem_conv7x7_supported(H, W)) return AADG_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int Ho = H / 2, Wo = W / 2;
+    const int tiles_x = (Wo + SW_PX - 1) / SW_PX, tiles_y = (Ho + SW_ROWS - 1) / SW_ROWS;
+    const long long total = (long long)N * tiles_x * tiles_y * 2;
+    if (total > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
+    AADG_HIP_TRY(hipMemsetAsync(dweight, 0, (size_t)ST_CO * 147 * sizeof(float), st));
+    const int grid = (int)(total < 1024 ? total : 1024);
+    hipLaunchKernelGGL((k_stem7x7_wgrad<float, true>), dim3(grid), dim3(256), 0, st, x, (const void*)dy, dweight, H, W, tiles_x, tiles_y,
+                       (int)total);
     AADG_LAUNCH_CHECK();
     return 0;
 }

@@ -49,7 +49,7 @@ def batch_step_bookkeeping(model, f32x3=False):
     the tracked shadows are then the (hi, lo) halves of the weights.  False: float32 inputs go to the library's float32 convolutions."""
     from .. import _lib
     for m in model.modules():
-        if isinstance(m, (Conv1x1, Conv3x3, SeparableConv2d)):
+        if isinstance(m, (Conv1x1, Conv3x3, SeparableConv2d, StemConv7x7)):
             m.f32x3 = bool(f32x3)
     _lib.track_bf16_weights(model, (Conv1x1, Conv3x3), split=bool(f32x3))
     for m in model.modules():
@@ -220,10 +220,18 @@ class StemConv7x7(nn.Conv2d):
     kernel of csrc/stem_conv.hip (straight from NCHW: the library surrounds its NHWC implicit GEMM with three layout
     transposes and a zero-fill), and so is the weight gradient."""
 
+    f32x3 = False           # float32 inputs outside autocast: the own float32-precision kernels (batch_step_bookkeeping)
+
     def __init__(self):
         super().__init__(3, 64, 7, stride=2, padding=3, bias=False)
 
     def forward(self, x):
+        if (x.is_cuda and x.dtype == torch.float32 and self.f32x3 and not torch.is_autocast_enabled('cuda')):
+            from .. import _lib
+            xc = x.contiguous()
+            if _lib.stem_conv7x7_supported(xc, self.weight):
+                return _lib.stem_conv7x7_x3(xc, self.weight)
+            return super().forward(x)
         lowp = x.dtype == torch.bfloat16 or (x.is_cuda and torch.is_autocast_enabled('cuda') and
                                              torch.get_autocast_dtype('cuda') == torch.bfloat16)
         if x.is_cuda and lowp:

@@ -195,6 +195,8 @@ int aadg_normalize_rewards_f32(const float* rewards, int M, float* out, void* st
  *   torchmetrics F1(num_classes=2, average=None, mdmc_average='samplewise')[1]  (:164-165)
  * logits/labels float [N, K, HW]; out_bce[M]; out_dice[K]; optional grad_logits (d mean_j BCE_j / dz).
  * ------------------------------------------------------------------------------------------- */
+/* ABI 8: ONE launch.  `ws` holds integer accumulators and an arrival counter: it must be zero-filled before the first call that uses it
+ * (and not be shared by calls that may overlap on different streams); every call leaves it zero-filled for the next one. */
 size_t aadg_seg_loss_workspace_bytes(int N, int K, int HW);
 int aadg_seg_bce_dice_f32(const float* logits, const float* labels, int N, int K, int HW, int M,
                           float* out_bce, float* out_dice, float* grad_logits, void* ws,
@@ -381,6 +383,10 @@ int aadg_stem_conv7x7_bf16(const void* x, int x_dtype, const float* weight, void
                            void* stream);
 /* dweight [64,3,7,7] (float32, overwritten) from x [N,3,H,W] and dy [N,64,H/2,W/2] (bfloat16): MFMA GEMM over the output pixels */
 int aadg_stem_conv7x7_wgrad_bf16(const void* x, int x_dtype, const void* dy, float* dweight, int N, int H, int W, void* stream);
+/* ABI 8 -- f32x3 (see aadg_conv1x1_nchw_f32x3): the stem convolution and its weight gradient on float32 tensors at float32 precision.
+ * aadg_stem_conv7x7_workspace_bytes() doubled with ABI 8 (hi + lo weight fragments). */
+int aadg_stem_conv7x7_f32x3(const float* x, const float* weight, float* y, int N, int H, int W, void* ws, size_t ws_bytes, void* stream);
+int aadg_stem_conv7x7_wgrad_f32x3(const float* x, const float* dy, float* dweight, int N, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stride-2 pixel sub-sampling of NCHW planes: y[p][i][j] = x[p][2i][2j], x [planes, H, W] -> y [planes, H/2, W/2], and its

@@ -108,9 +108,24 @@ def test_backbone_and_controller_entry_points_validate_arguments():
     # 1x1 convolution forward / input gradient
     assert lib.aadg_conv1x1_nchw_supported(64, 256, 1024) == 1 and lib.aadg_conv1x1_nchw_supported(64, 12, 1024) == 0
     assert lib.aadg_conv1x1_nchw_bf16(z, z, z, 1, 8, 8, 64, z) == -1
+    # ABI 8: the float32-precision (f32x3) entry points validate like their bfloat16 twins (null / misaligned pointers -1, shapes -3)
+    assert lib.aadg_conv1x1_nchw_f32x3(z, z, z, z, 1, 8, 8, 64, z) == -1
+    assert lib.aadg_conv1x1_nchw_f32x3(one, one, one, one, 1, 8, 12, 64, z) == -3          # K % 8
+    assert lib.aadg_conv1x1_wgrad_f32x3(z, z, z, 1, 8, 8, 64, z) == -1
+    assert lib.aadg_conv1x1_wgrad_f32x3(one, one, one, 1, 8, 8, 48, z) == -3               # HW % 32
+    assert lib.aadg_conv3x3_nchw_f32x3(z, z, z, z, 1, 8, 8, 8, 32, 1, z) == -1
+    assert lib.aadg_conv3x3_nchw_f32x3(one, one, one, one, 1, 8, 8, 8, 48, 1, z) == -3     # W not in {32, 64, 128}
+    assert lib.aadg_conv3x3_wgrad_f32x3(one, one, one, 1, 8, 8, 8, 128, 2, z) == -3        # W = 128 with dilation 2: LDS
+    assert lib.aadg_conv3x3s2_nchw_f32x3(z, z, z, z, 1, 8, 8, 8, 32, z) == -1
+    assert lib.aadg_conv3x3s2_dgrad_f32x3(one, one, one, one, 1, 8, 12, 8, 32, z) == -3    # M % 8
+    assert lib.aadg_conv3x3s2_wgrad_f32x3(one, one, one, 1, 8, 8, 8, 48, z) == -3
+    assert lib.aadg_stem_conv7x7_f32x3(z, z, z, 1, 64, 64, z, 0, z) == -1
+    assert lib.aadg_stem_conv7x7_f32x3(one, one, one, 1, 64, 64, one, 16, z) == -2         # workspace
+    assert lib.aadg_stem_conv7x7_wgrad_f32x3(one, one, one, 1, 64, 72, z) == -3
+    assert lib.aadg_weight_layouts_split_bf16(z, z, 1, z) == -1 and lib.aadg_weight_layouts_split_bf16(one, one, 0, z) == 0
     # stem convolution
     assert lib.aadg_stem_conv7x7_supported(512, 512) == 1 and lib.aadg_stem_conv7x7_supported(512, 520) == 0
-    assert lib.aadg_stem_conv7x7_workspace_bytes() == 11 * 2 * 64 * 16
+    assert lib.aadg_stem_conv7x7_workspace_bytes() == 2 * 11 * 2 * 64 * 16           # ABI 8: hi + lo weight fragments
     assert lib.aadg_stem_conv7x7_bf16(z, 1, z, z, 1, 32, 32, z, 0, z) == -1
     assert lib.aadg_stem_conv7x7_wgrad_bf16(z, 1, z, z, 1, 32, 32, z) == -1
     # stride-2 sub-sampling

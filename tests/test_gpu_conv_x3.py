@@ -155,3 +155,20 @@ def test_conv3x3_stride2_x3(hip, N, Ci, Co, Ho, Wo):
     y2.backward(g.double())
     assert _err(x1.grad, x2.grad) <= TOL, _err(x1.grad, x2.grad)
     assert _err(w1.grad, w2.grad) <= TOL, _err(w1.grad, w2.grad)
+
+
+@pytest.mark.parametrize("N,H,W", [(3, 64, 64), (2, 96, 160), (1, 34, 48)])
+def test_stem_conv7x7_x3(hip, N, H, W):
+    """The ResNet stem (7x7 / stride 2 / padding 3, 3 -> 64) on float32 images at float32 precision: forward and weight gradient
+    (csrc/stem_conv.hip, X3) against float64 autograd."""
+    torch.manual_seed(H + W)
+    x = torch.rand(N, 3, H, W, device="cuda") * 2 - 1
+    w1 = (torch.randn(64, 3, 7, 7, device="cuda") / 147 ** 0.5).requires_grad_(True)
+    y1 = hip.stem_conv7x7_x3(x, w1)
+    w2 = w1.detach().double().requires_grad_(True)
+    y2 = F.conv2d(x.double(), w2, stride=2, padding=3)
+    assert y1.dtype == torch.float32 and y1.shape == y2.shape and _err(y1, y2.detach()) <= TOL, _err(y1, y2.detach())
+    g = torch.randn_like(y1)
+    y1.backward(g)
+    y2.backward(g.double())
+    assert _err(w1.grad, w2.grad) <= TOL, _err(w1.grad, w2.grad)

@@ -73,3 +73,27 @@ def test_loss_and_backward_in_one_call(hip, scale, dtype):
     # no graph behind the logits: the losses still come back, nothing to propagate
     loss_c, _, _ = hip.policy_bce_backward(produce().detach(), y, M, scale)
     assert abs(loss_c.item() - loss_b.item()) < 1e-7
+
+
+def test_one_launch_accumulators_are_left_zeroed_and_results_deterministic(hip):
+    """Round 5: the loss is ONE launch -- integer device-scope atomics into accumulators in the workspace, the last-arriving workgroup
+    finalises and zeroes them.  Repeated calls (same and other shapes, sharing the cached workspace of their size) must return
+    bit-identical results, and the workspace must be all zero after every call."""
+    torch.manual_seed(3)
+    for N, K, S, M in ((24, 2, 256, 6), (6, 1, 64, 3), (24, 2, 256, 6), (144, 2, 128, 6)):
+        z = torch.randn(N, K, S, S, device="cuda") * 3
+        y = (torch.rand(N, K, S, S, device="cuda") > 0.6).float()
+        first = None
+        for _ in range(3):
+            bce, dice, grad = hip.seg_bce_dice(z, y, M, want_grad=True)
+            got = (bce.clone(), dice.clone())
+            if first is None:
+                first = got
+            assert torch.equal(got[0], first[0]) and torch.equal(got[1], first[1])
+        torch.cuda.synchronize()
+        for key, buf in hip._zws_cache.items():
+            if key[2] == "segloss":
+                assert int(buf.count_nonzero()) == 0, key
+        p = torch.sigmoid(z)
+        ref = torch.stack([torch.nn.functional.binary_cross_entropy(p[j::M], y[j::M]) for j in range(M)])
+        assert (first[0] - ref).abs().max().item() < 1e-4
