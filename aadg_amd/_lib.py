@@ -58,7 +58,7 @@ EXPORTS = [
     "aadg_weight_layouts_bf16",
     "aadg_weight_layouts_split_bf16", "aadg_conv1x1_nchw_f32x3", "aadg_conv1x1_wgrad_f32x3", "aadg_conv3x3_nchw_f32x3",
     "aadg_conv3x3_wgrad_f32x3", "aadg_conv3x3s2_nchw_f32x3", "aadg_conv3x3s2_dgrad_f32x3", "aadg_conv3x3s2_wgrad_f32x3",
-    "aadg_stem_conv7x7_f32x3", "aadg_stem_conv7x7_wgrad_f32x3",
+    "aadg_stem_conv7x7_f32x3", "aadg_stem_conv7x7_wgrad_f32x3", "aadg_sinkhorn_divergence_phases_f32",
 ]
 
 _lib = None
@@ -249,6 +249,8 @@ def load():
     lib.aadg_conv3x3_nchw_f32x3.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
     lib.aadg_conv3x3_wgrad_f32x3.restype = _i
     lib.aadg_conv3x3_wgrad_f32x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
+    lib.aadg_sinkhorn_divergence_phases_f32.restype = _i
+    lib.aadg_sinkhorn_divergence_phases_f32.argtypes = [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _sz, _i, _vp]
     lib.aadg_stem_conv7x7_f32x3.restype = _i
     lib.aadg_stem_conv7x7_f32x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp, ctypes.c_size_t, _vp]
     lib.aadg_stem_conv7x7_wgrad_f32x3.restype = _i
@@ -610,6 +612,22 @@ def sinkhorn_divergence(feat, cloud_rows, cloud_off, prob_xy, max_cloud, blur=0.
                                           cloud_off.data_ptr(), prob_xy.data_ptr(), n_prob, int(max_cloud), blur,
                                           scaling, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     _check(rc, "aadg_sinkhorn_divergence_f32")
+    return out
+
+
+def sinkhorn_divergence_phases(feat, cloud_rows, cloud_off, prob_xy, max_cloud, phases, blur=0.05, scaling=0.5, out=None):
+    """Measurement (bench.py): the large-cloud path in halves -- phases 1 = cost build into the workspace, 2 = sweeps over it + result,
+    3 = both."""
+    lib = load()
+    _require_cuda(feat, cloud_rows, cloud_off, prob_xy)
+    n_prob = prob_xy.numel() // 2
+    if out is None:
+        out = torch.empty(n_prob, dtype=torch.float32, device=feat.device)
+    nb = lib.aadg_sinkhorn_workspace_bytes(n_prob, int(max_cloud), feat.shape[1])
+    ws = workspace(nb, feat.device, "sinkhorn")
+    _check(lib.aadg_sinkhorn_divergence_phases_f32(feat.data_ptr(), feat.stride(0), feat.shape[1], cloud_rows.data_ptr(), cloud_off.data_ptr(),
+                                                   prob_xy.data_ptr(), n_prob, int(max_cloud), blur, scaling, out.data_ptr(), ws.data_ptr(),
+                                                   ws.numel(), int(phases), _stream()), "aadg_sinkhorn_divergence_phases_f32")
     return out
 
 
@@ -1574,10 +1592,12 @@ class _Conv1x1(torch.autograd.Function):
         x, wq = ctx.saved_tensors
         dy = dy.contiguous()
         dx = dw = None
+        # ONE check for both branches: the saved cast `wq` aliases the tracked shadow too, so the library branch must not run on a
+        # buffer a later forward has rewritten either (raises AadgError; None = untracked weight)
+        wt = ctx.wt.get()
         if ctx.needs_input_grad[0]:
             Co, Ci = wq.shape[0], wq.shape[1]
             if _own_gemm_1x1(Ci, Co, dy.shape[2] * dy.shape[3], dy.shape[0]):
-                wt = ctx.wt.get()                        # None: untracked, or the shadow has moved on since the forward
                 dx = conv1x1_nchw(wt[0] if wt is not None else wq.view(Co, Ci).t().contiguous(), dy)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
@@ -1741,7 +1761,11 @@ def track_bf16_weights(model, module_types, split=False):
     """Registers the float32 weights of `model`'s modules of the given types (1x1 / 3x3 convolutions: weight [Co, Ci, k, k], k*k <= 9)
     for the batched bfloat16 casts / re-layouts (CUDA models only).  A 3x3 module with stride 1 gets the mirrored-tap 'bwd' layout
     (its input gradient is the forward kernel on dY), any other the plain transposed one.  split = True: the layouts are the
-    (hi, lo) bfloat16 halves the f32x3 kernels read (float32 activations, float32-grade products)."""
+    (hi, lo) bfloat16 halves the f32x3 kernels read (float32 activations, float32-grade products).
+    Rule that comes with tracking: ONE forward per backward.  Every forward of the model rebuilds the shadows in place; what the autograd
+    functions of a forward keep are references into them, so each backward has to run before the model's NEXT forward (a second forward
+    in between -- gradient accumulation over two forwards, an eval / no_grad pass -- makes the earlier backward raise AadgError, on the own
+    and on the library branches alike, rather than compute with the newer weights).  Models that need another order stay untracked."""
     if getattr(model, "_aadg_weight_layouts", None) is not None:
         raise AadgError("track_bf16_weights: this model's weights are tracked already")
     entries = []
@@ -1855,10 +1879,10 @@ class _Conv3x3S2(torch.autograd.Function):
         x, wq = ctx.saved_tensors
         dy = dy.contiguous()
         dx = dw = None
+        a9t = ctx.a9t.get()                              # checked for both branches (see _Conv1x1.backward)
         if ctx.needs_input_grad[0]:
             M, C = wq.shape[0], wq.shape[1]
             if load().aadg_conv3x3s2_dgrad_supported(C, M, dy.shape[2], dy.shape[3]):
-                a9t = ctx.a9t.get()
                 dx = conv3x3s2_dgrad(a9t if a9t is not None else wq.permute(2, 3, 1, 0).reshape(9, C, M).contiguous(), dy)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
@@ -1930,11 +1954,11 @@ class _Conv3x3(torch.autograd.Function):
         d = ctx.dilation
         dy = dy.contiguous()
         dx = dw = None
+        a9t = ctx.a9t.get()                              # checked for both branches (see _Conv1x1.backward)
         if ctx.needs_input_grad[0]:
             Co, Ci = wq.shape[0], wq.shape[1]
             if _own_conv3x3_fwd(dy, Ci, Co, d):
                 # the same kernel on dy with the taps mirrored and the channel roles swapped
-                a9t = ctx.a9t.get()
                 a9t = a9t if a9t is not None else wq.flip(2, 3).permute(2, 3, 1, 0).reshape(9, Ci, Co).contiguous()
                 dx = conv3x3_nchw(a9t, dy, d)
             else:

@@ -1662,7 +1662,8 @@ template <bool SHARP>
 __device__ __forceinline__ void gen_hpass_pipe(const uint8_t* __restrict__ pool, const aadg_unit* __restrict__ units,
                                                const int* __restrict__ order, int slot, int bx, int by0, int Hs, int Ws, int crop,
                                                const int* __restrict__ tab, const uint8_t* __restrict__ lut,
-                                               size_t lut_stage_stride, uint32_t* __restrict__ hbuf, uint32_t* A, uint32_t* Bs, uint8_t* sl) {
+                                               size_t lut_stage_stride, uint32_t* __restrict__ hbuf, int hslot0, uint32_t* A, uint32_t* Bs,
+                                               uint8_t* sl) {
     const int u = order != nullptr ? order[slot] : slot;
     const aadg_unit& un = units[u];
     // the record's fields in one batch of scalar loads
@@ -1733,7 +1734,8 @@ __device__ __forceinline__ void gen_hpass_pipe(const uint8_t* __restrict__ pool,
         j0 = 0;
         while (j0 < n_ops && !is_stencil(un, j0)) ++j0;
     }
-    uint32_t* hrow = hbuf + ((size_t)slot * Hs + r_first) * crop + x0;      // uniform: row r_lo of the intermediate, column x0
+    // (the intermediate holds ONE chunk of list slots: slot s of a chunk that starts at hslot0 lives at index s - hslot0)
+    uint32_t* hrow = hbuf + ((size_t)(slot - hslot0) * Hs + r_first) * crop + x0;      // uniform: row r_lo of the intermediate, column x0
     __syncthreads();                                            // the byte maps are in LDS
 #pragma unroll 1
     for (int r_lo = r_first, i = 0; i < GH_NB && r_lo < ur_hi; ++i, r_lo += ROWS) {
@@ -1769,11 +1771,11 @@ template <bool SHARP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHARP ? 4 : 5))) void k_gen_hpass(const uint8_t* __restrict__ pool, const aadg_unit* __restrict__ units,
                                                    const int* __restrict__ order, int slot0, int Hs, int Ws, int crop,
                                                    const int* __restrict__ tab, const uint8_t* __restrict__ lut,
-                                                   size_t lut_stage_stride, uint32_t* __restrict__ hbuf) {
+                                                   size_t lut_stage_stride, uint32_t* __restrict__ hbuf, int hslot0) {
     __shared__ __attribute__((aligned(16))) uint32_t A[GH_CAP];
     __shared__ __attribute__((aligned(16))) uint32_t Bs[SHARP ? GH_CAP : 4];
     __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
-    gen_hpass_pipe<SHARP>(pool, units, order, slot0 + blockIdx.z, blockIdx.x, blockIdx.y, Hs, Ws, crop, tab, lut, lut_stage_stride, hbuf, A, Bs, sl);
+    gen_hpass_pipe<SHARP>(pool, units, order, slot0 + blockIdx.z, blockIdx.x, blockIdx.y, Hs, Ws, crop, tab, lut, lut_stage_stride, hbuf, hslot0, A, Bs, sl);
 }
 
 constexpr int GV_ROWS = 16;            // output rows per vertical-pass workgroup: 4 consecutive rows per wave
@@ -1876,6 +1878,7 @@ __global__ __launch_bounds__(256) void k_gen_vpass(const uint8_t* __restrict__ m
                                                    const int* __restrict__ order, int slot0, int Hs, int Ws, int crop, int dataset_in,
                                                    const int* __restrict__ tab, const uint32_t* __restrict__ hbuf,
                                                    float* __restrict__ out_img, float* __restrict__ out_lbl) {
+    // (slot0 = the first list slot of this launch's chunk = index 0 of the intermediate)
     const int dataset = dataset_in & 0xFF;
     const bool stream_out = (dataset_in & AUG_STREAM_OUT) != 0;
     const int slot = slot0 + blockIdx.z;
@@ -1914,7 +1917,7 @@ __global__ __launch_bounds__(256) void k_gen_vpass(const uint8_t* __restrict__ m
     const int xm[4] = {xm4.x, xm4.y, xm4.z, xm4.w}, xn[4] = {xn4.x, xn4.y, xn4.z, xn4.w};
     const int nty = axis_taps(Hs, un.scaled_h);
     const uint8_t* msk = masks + (size_t)un.src * Hs * Ws;
-    const uint32_t* hcol = hbuf + (size_t)slot * Hs * crop + xq;
+    const uint32_t* hcol = hbuf + (size_t)(slot - slot0) * Hs * crop + xq;
     const bool win_ok = xn[0] >= 0 && xn[3] >= 0 && xn[1] >= xn[0] && xn[2] >= xn[0] && xn[3] >= xn[0] && xn[1] - xn[0] < 8 && xn[2] - xn[0] < 8 &&
                         xn[3] - xn[0] < 8 && xn[0] + 8 <= Ws;
     // uniform: false for a wave that lies in the pad columns
@@ -2255,26 +2258,24 @@ int launch_tiles(const uint8_t* pool, const uint8_t* masks, const aadg_unit* uni
     // horizontal pass writes is read back by the vertical pass while it is still in the Infinity Cache (256 MB; 4 MB per unit at
     // 1024 x 1024), instead of after the whole batch's intermediate has gone to HBM and come back.
     const int chunk = (chunk_req > 0 && chunk_req < gen_chunk(Hs, crop)) ? chunk_req : gen_chunk(Hs, crop);
-    const size_t slot_words = (size_t)Hs * crop;
     const int hy1 = (Hs + GhRows<true>::value - 1) / GhRows<true>::value;
     for (int a = 0; a < ng; a += chunk) {
         const int b = min(ng, a + chunk);
-        uint32_t* hb = hbuf - (size_t)a * slot_words;                 // slot s of this chunk lives at hbuf + (s - a) * slot_words
         // listed: plain units are slots [0, n0), stencil units [s1, ng); unlisted: every slot is offered to both variants
         const int p0 = a, p1 = min(b, n0);
         const int q0 = max(a, s1), q1 = b;
         if (p1 > p0) {
             hipLaunchKernelGGL(k_gen_hpass<false>, dim3(hx, (hy0 + GH_NB - 1) / GH_NB, p1 - p0), dim3(256), 0, st, pool, units, order_gen, p0, Hs, Ws, crop, tab, lut,
-                               lut_stage_stride, hb);
+                               lut_stage_stride, hbuf, a);
             AADG_LAUNCH_CHECK();
         }
         if (q1 > q0) {
             hipLaunchKernelGGL(k_gen_hpass<true>, dim3(hx, (hy1 + GH_NB - 1) / GH_NB, q1 - q0), dim3(256), 0, st, pool, units, order_gen, q0, Hs, Ws, crop, tab, lut,
-                               lut_stage_stride, hb);
+                               lut_stage_stride, hbuf, a);
             AADG_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(k_gen_vpass, dim3((crop + 255) / 256, (crop + GV_ROWS - 1) / GV_ROWS, b - a), dim3(256), 0, st, masks, units, order_gen, a,
-                           Hs, Ws, crop, dsk, tab, hb, out_img, out_lbl);
+                           Hs, Ws, crop, dsk, tab, hbuf, out_img, out_lbl);
         AADG_LAUNCH_CHECK();
     }
     return 0;

@@ -243,7 +243,7 @@ int launch(const float* feat, int ld, int E, const int* cloud_rows, const int* c
 size_t aadg_sinkhorn_big_workspace_bytes(int n_prob, int nmax, int E);
 int aadg_sinkhorn_big_launch(const float* feat, int ld, int E, const int* cloud_rows, const int* cloud_off, const int* prob_xy,
                              int n_prob, int nmax, float blur, float scaling, float* out, void* ws, size_t ws_bytes,
-                             hipStream_t st);
+                             hipStream_t st, int phases);
 
 extern "C" size_t aadg_sinkhorn_workspace_bytes(int n_prob, int max_cloud, int E) {
     if (n_prob <= 0 || max_cloud <= 0 || E <= 0) return 0;
@@ -261,9 +261,23 @@ extern "C" int aadg_sinkhorn_divergence_f32(const float* feat, int ld, int E, co
     if (!(blur > 0.f) || !(scaling > 0.f && scaling < 1.f)) return AADG_E_BADARG;
     if (lds_bytes(max_cloud, E) > 160 * 1024)           // clouds too large for the LDS-resident kernel
         return aadg_sinkhorn_big_launch(feat, ld, E, cloud_rows, cloud_off, prob_xy, n_prob, max_cloud, blur, scaling, out, ws,
-                                        ws_bytes, reinterpret_cast<hipStream_t>(stream));
+                                        ws_bytes, reinterpret_cast<hipStream_t>(stream), 3);
     return launch<false>(feat, ld, E, cloud_rows, cloud_off, prob_xy, 0, 0, 0, n_prob, max_cloud, blur, scaling, out,
                          reinterpret_cast<hipStream_t>(stream));
+}
+
+/* Measurement entry (bench.py: roofline fractions of the two halves of the large-cloud path): as aadg_sinkhorn_divergence_f32 for clouds
+ * beyond the LDS-resident kernel, running only `phases` -- bit 0: row normalisation + eps schedule + cost matrices into `ws`, bit 1: the
+ * eps-scaling sweeps over the matrices already in `ws` + the result.  AADG_E_UNSUPPORTED for clouds the LDS-resident kernel takes. */
+extern "C" int aadg_sinkhorn_divergence_phases_f32(const float* feat, int ld, int E, const int32_t* cloud_rows, const int32_t* cloud_off,
+                                                   const int32_t* prob_xy, int n_prob, int max_cloud, float blur, float scaling,
+                                                   float* out, void* ws, size_t ws_bytes, int phases, void* stream) {
+    if (!feat || !cloud_rows || !cloud_off || !prob_xy || !out) return AADG_E_BADARG;
+    if (E <= 0 || ld < E || n_prob <= 0 || max_cloud <= 0 || phases < 1 || phases > 3) return AADG_E_BADARG;
+    if (!(blur > 0.f) || !(scaling > 0.f && scaling < 1.f)) return AADG_E_BADARG;
+    if (lds_bytes(max_cloud, E) <= 160 * 1024) return AADG_E_UNSUPPORTED;
+    return aadg_sinkhorn_big_launch(feat, ld, E, cloud_rows, cloud_off, prob_xy, n_prob, max_cloud, blur, scaling, out, ws, ws_bytes,
+                                    reinterpret_cast<hipStream_t>(stream), phases);
 }
 
 static int sinkhorn_rewards(const float* fe, const float* row_norm, int D, int B, int M, int E, float blur, float scaling,

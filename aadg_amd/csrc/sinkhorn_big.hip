@@ -428,10 +428,12 @@ size_t aadg_sinkhorn_big_workspace_bytes(int n_prob, int nmax, int E) {
 
 int aadg_sinkhorn_big_launch(const float* feat, int ld, int E, const int* cloud_rows, const int* cloud_off, const int* prob_xy,
                              int n_prob, int nmax, float blur, float scaling, float* out, void* ws, size_t ws_bytes,
-                             hipStream_t st) {
+                             hipStream_t st, int phases) {
+    // phases (measurement: bench.py times the two halves apart): bit 0 = prepare + schedule + cost matrices, bit 1 = sweeps + result
     if (!ws || ws_bytes < aadg_sinkhorn_big_workspace_bytes(n_prob, nmax, E)) return AADG_E_WORKSPACE;
     if (E > 64 * PREP_KPL) return AADG_E_UNSUPPORTED;
     float* w = reinterpret_cast<float*>(ws);
+    if (phases & 1) {
     hipLaunchKernelGGL(k_big_prep, dim3(BIG_PREP_CHUNKS, n_prob), dim3(256), 0, st, feat, ld, E, cloud_rows, cloud_off, prob_xy,
                        nmax, w);
     AADG_LAUNCH_CHECK();
@@ -452,6 +454,8 @@ int aadg_sinkhorn_big_launch(const float* feat, int ld, int E, const int* cloud_
         hipLaunchKernelGGL(k_big_cost, dim3(tiles, tiles, n_prob * 3), dim3(256), 0, st, cloud_off, prob_xy, nmax, E, w);
     }
     AADG_LAUNCH_CHECK();
+    }
+    if (!(phases & 2)) return 0;
     const dim3 gs(4 * ((nmax + 3) / 4), n_prob);
     for (int step = 0; step <= BIG_MAX_ITS + 1; ++step) {
         hipLaunchKernelGGL(k_big_sweep, gs, dim3(256), 0, st, cloud_off, prob_xy, nmax, E, step, w);

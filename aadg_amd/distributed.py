@@ -70,9 +70,33 @@ def small_group():
     return _SMALL["group"]
 
 
+_SIDE = {"group": None, "made": False}
+
+
+def side_group():
+    """Process group of the collectives issued from the controller's SIDE stream (the embedding all-gather, the policy broadcasts).
+    A process group has one communicator and one internal stream, which orders everything issued on it: on the BatchNorm group the
+    backward pass's statistics all-reduces (main stream) would queue behind an all-gather that is still waiting for the side stream's
+    embedding kernels -- the head-of-line blocking the small group was created to avoid.  So the side-stream collectives get a
+    communicator of their own.  Every rank issues the collectives of each group in the same order (the step is the same program on
+    every rank), which is what concurrent communicators need.  Same opt-out and fallback as small_group()."""
+    if not is_dist() or not USE_SMALL_GROUP:
+        return None
+    if not _SIDE["made"]:
+        _SIDE["made"] = True
+        try:
+            _SIDE["group"] = dist.new_group(ranks=list(range(dist.get_world_size())), backend=dist.get_backend())
+        except Exception as e:  # noqa: BLE001
+            import sys
+            print("aadg_amd.distributed: new_group failed (%r); side-stream collectives stay on the default group" % (e,), file=sys.stderr)
+            _SIDE["group"] = None
+    return _SIDE["group"]
+
+
 def reset_groups():
-    """forget the cached group (after destroy_process_group; tests that re-initialise the process group in one interpreter)"""
+    """forget the cached groups (after destroy_process_group; tests that re-initialise the process group in one interpreter)"""
     _SMALL["group"], _SMALL["made"] = None, False
+    _SIDE["group"], _SIDE["made"] = None, False
 
 
 class _CollectiveTimer(object):
@@ -113,7 +137,8 @@ def small_all_reduce(t, kind="all_reduce"):
 
 
 def small_broadcast(t, src=0, kind="broadcast"):
-    return COLLECTIVE_TIMER.run(kind, dist.broadcast, t, src, group=small_group())
+    # the policy broadcasts are issued from the controller's side stream: their own communicator (side_group)
+    return COLLECTIVE_TIMER.run(kind, dist.broadcast, t, src, group=side_group() if kind == "policy_broadcast" else small_group())
 
 
 def all_gather(tensors, group=None):
@@ -159,6 +184,8 @@ def describe():
         info.update(world_size=dist.get_world_size(), rank=dist.get_rank(), backend=str(dist.get_backend()))
         g = small_group()
         info["small_collectives_group"] = "own process group (own RCCL communicator + stream)" if g is not None else "default group"
+        info["side_stream_collectives_group"] = ("own process group (embedding all-gather, policy broadcasts: issued from the controller's "
+                                                 "stream)" if side_group() is not None else "default group")
     return info
 
 
@@ -269,5 +296,5 @@ class RowPlan(object):
                 r, o = take // self.max_count, take % self.max_count
                 take = r * self.max_count + o % self.n_local
         else:
-            flat = all_gather([local], group=small_group())[0]
+            flat = all_gather([local], group=side_group())[0]
         return flat.index_select(0, take)

@@ -49,7 +49,7 @@ def batch_step_bookkeeping(model, f32x3=False):
     the tracked shadows are then the (hi, lo) halves of the weights.  False: float32 inputs go to the library's float32 convolutions."""
     from .. import _lib
     for m in model.modules():
-        if isinstance(m, (Conv1x1, Conv3x3, SeparableConv2d, StemConv7x7)):
+        if isinstance(m, (Conv1x1, Conv3x3, SeparableConv2d, StemConv7x7, DeepLabV3Plus)):
             m.f32x3 = bool(f32x3)
     _lib.track_bf16_weights(model, (Conv1x1, Conv3x3), split=bool(f32x3))
     for m in model.modules():
@@ -606,10 +606,29 @@ class DeepLabV3Plus(nn.Module):
         else:
             y = torch.cat([_upsample_ac(a, skip.shape[-2:]), s], dim=1)
         y = self.fuse(y)
-        mask = _upsample_ac(self.classifier(y), x.shape[-2:])
+        mask = _upsample_ac(self._classify(y), x.shape[-2:])
         if not self.aux_pooling:
             return mask
         return mask, pooled
+
+
+def _classify(self, y):
+    """The 1x1 classifier (256 -> classes, with bias).  f32x3: the own float32-precision 1x1 kernels with the weight padded to 8 output
+    rows (their tiles want multiples of 8; the library ran this 2-channel convolution as a Winograd variant + an NHWC weight gradient
+    behind a transpose of the 2.4 GB input: ~3 ms per step for 2.4 GFLOP); the padded rows are zero and sliced away again."""
+    c = self.classifier
+    if (getattr(self, 'f32x3', False) and y.is_cuda and y.dtype == torch.float32 and not torch.is_autocast_enabled('cuda') and
+            c.kernel_size == (1, 1) and c.out_channels <= 8):
+        from .. import _lib
+        w8 = F.pad(c.weight, (0, 0, 0, 0, 0, 0, 0, 8 - c.out_channels))
+        yc = y.contiguous()
+        if _lib.conv1x1_x3_supported(yc, w8):
+            out = _lib.conv1x1_x3(yc, w8)[:, :c.out_channels]
+            return out + c.bias.view(1, -1, 1, 1) if c.bias is not None else out.contiguous()
+    return c(y)
+
+
+DeepLabV3Plus._classify = _classify
 
 
 class UNetSmall(nn.Module):

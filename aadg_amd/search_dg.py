@@ -242,7 +242,7 @@ class SearchState(object):
         self.controller, self.M, _ = load_ddp_controller(ngpus_per_node, args, config)
         self.discriminator, _, _ = load_ddp_discriminator(ngpus_per_node, args, config)
         rank, world = adist.world()
-        T.set_row_shard(rank, world, getattr(args, 'placement', 'unit'), force=bool(getattr(args, 'force_sharded', False)))
+        T.set_row_shard(rank, world, getattr(args, 'placement', 'row'), force=bool(getattr(args, 'force_sharded', False)))
         if adist.is_dist():
             # the controller is replicated, not wrapped (identical rewards -> identical updates); DDP broadcast the wrapped
             # modules' state at construction, do the same for it

@@ -75,7 +75,7 @@ def parse():
                     help="arithmetic of the backbone convolutions: f32x3 = float32 tensors, every product as three bfloat16 matrix-core "
                          "products with float32 accumulation (own kernels, the reference's precision: checked by the `precision` leg); "
                          "fp32 = the library's float32 convolutions; bf16 = bfloat16 autocast (narrower than the reference: secondary)")
-    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N = 1: fop,kernels,rvs1024,cpu,precision  (auto = all; none = skip)")
+    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N = 1: fop,kernels,rvs1024,cpu,precision,scale  (auto = all; none = skip)")
     ap.add_argument("--only_legs", default=None,
                     help="skip the headline step and print ONE JSON line holding only these legs (fop,kernels,rvs1024): the target of "
                          "the rocprofv3 runs behind profiles/r04_fop_*, profiles/r04_aug512_* and profiles/r04_rvs1024_*")
@@ -517,7 +517,7 @@ def float_ops_leg(B=144, size=512, repeats=10):
 
 def hot_kernels_leg(D=3, B=8, M=6, size=512, K=2, repeats=20):
     """Per-kernel figures of the two other own hot-path kernels north_star names: the one-pass BCE + Dice + gradient kernel
-    (k_seg_partial, HBM-bound: logits + labels read, gradient written = 12 B per element) and the Sinkhorn reward kernel
+    (k_seg_loss: one launch since round 5; HBM-bound: logits + labels read, gradient written = 12 B per element) and the Sinkhorn reward kernel
     (k_sinkhorn, latency-bound: 73.7 KB in, 24 B out -- microseconds and the launches it replaces)."""
     import torch
     from aadg_amd import _lib
@@ -574,13 +574,33 @@ def hot_kernels_leg(D=3, B=8, M=6, size=512, K=2, repeats=20):
         pxy = torch.tensor([v for a_ in range(D) for b_ in range(a_ + 1, D) for v in (a_, b_)], dtype=torch.int32, device="cuda")
         tb = _event_times(lambda: _lib.sinkhorn_divergence(xb, rows_i, off_i, pxy, n_pts), 5)
         big_ms = float(np.median(tb))
-        gemm_flop = P * 4 * 2.0 * n_pts * n_pts * 128
-        sweep_bytes = P * 4 * n_pts * n_pts * 4
-        big = {"workload": "%d problems of %d x %d points, E = 128, blur 0.05, scaling 0.5 (33 sweeps)" % (P, n_pts, n_pts), "ms": big_ms,
-               "cost_build_gflop": gemm_flop / 1e9, "bytes_per_full_symmetric_sweep": sweep_bytes,
-               "cost_build_ms_at_f32_mfma_peak_157TF": gemm_flop / 157e12 * 1e3,
-               "note": "per-kernel split in DESIGN.md section 4 (k_big_cost 1.09 ms = 47 TFLOP/s float32 MFMA, k_big_sweep 3.7 TB/s on the full "
-                       "symmetric sweeps); the debias sweeps are smaller than a full one"}
+        # the two halves apart (aadg_sinkhorn_divergence_phases_f32): cost build vs the matrix-core peak, sweeps vs HBM
+        cost_ms = float(np.median(_event_times(lambda: _lib.sinkhorn_divergence_phases(xb, rows_i, off_i, pxy, n_pts, 1), 5)))
+        sweep_ms = float(np.median(_event_times(lambda: _lib.sinkhorn_divergence_phases(xb, rows_i, off_i, pxy, n_pts, 2), 5)))
+        # eps steps per problem from the data (geomloss: 2 + ceil(log2(diameter / blur)) entries), + the initialisation and the final
+        # extrapolation: full symmetric sweeps over the four matrices of a problem
+        n_sweeps = 0
+        for q_ in range(P):
+            xa, xc = xb[int(pxy[2 * q_]) * n_pts:(int(pxy[2 * q_]) + 1) * n_pts], xb[int(pxy[2 * q_ + 1]) * n_pts:(int(pxy[2 * q_ + 1]) + 1) * n_pts]
+            lo_ = torch.minimum(xa.min(0).values, xc.min(0).values)
+            hi_ = torch.maximum(xa.max(0).values, xc.max(0).values)
+            diam = float((hi_ - lo_).norm())
+            n_sweeps += 2 + len([diam ** 2] + list(np.arange(2 * np.log(diam), 2 * np.log(0.05), 2 * np.log(0.5))) + [0.05 ** 2])
+        gemm_flop = P * 3 * 2.0 * n_pts * n_pts * 128                  # C_xx, C_yy, C_xy (C_yx = the transposed write of C_xy)
+        sweep_bytes = 4 * n_pts * n_pts * 4                             # one problem, one step: four matrices read once
+        MFMA_BF16_PEAK = 2500e12                                        # dense bfloat16, MI355X_MICROARCH.md; three products per multiply
+        big = {"workload": "%d problems of %d x %d points, E = 128, blur 0.05, scaling 0.5" % (P, n_pts, n_pts), "ms": big_ms,
+               "cost_build": {"bound": "mfma", "kernel": "k_big_cost_x3 (+ k_big_prep, k_big_schedule)", "ms": cost_ms,
+                              "gflop": gemm_flop / 1e9, "achieved": gemm_flop / (cost_ms * 1e-3) / 1e12,
+                              "peak": MFMA_BF16_PEAK / 3 / 1e12, "unit": "TFLOP/s (float32-equivalent: 3 bfloat16 products per multiply)",
+                              "frac": gemm_flop / (cost_ms * 1e-3) / (MFMA_BF16_PEAK / 3),
+                              "hbm_frac_of_the_4_matrix_writes": P * 4 * n_pts * n_pts * 4 / (cost_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+               "sweeps": {"bound": "hbm", "kernel": "k_big_sweep (+ k_big_final)", "ms": sweep_ms, "active_sweeps": n_sweeps,
+                          "bytes": n_sweeps * sweep_bytes, "achieved": n_sweeps * sweep_bytes / (sweep_ms * 1e-3) / 1e9,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": n_sweeps * sweep_bytes / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "launches": 34},
+               "note": "cost build: float32-precision products on the bfloat16 matrix cores (split operands), C_yx written transposed; sweeps: "
+                       "per-column terms hoisted, streaming loads; the 34 launches include ~20 that exit at once (the step count is on the device)"}
         del xb
     except Exception as e:  # noqa: BLE001
         big = {"error": repr(e)}
@@ -589,17 +609,61 @@ def hot_kernels_leg(D=3, B=8, M=6, size=512, K=2, repeats=20):
                         "bound": "latency / L2 (1 MB of weights, %d rows)" % N, "us": float(np.median(te)) * 1e3, "launches": 1,
                         "bytes": int(x.numel() * 4 + w1.numel() * 4 + N * 128 * 4)},
             "controller": ctrl,
-            "k_seg_partial+k_seg_final": {
+            "k_seg_loss": {
                 "replaces": "sigmoid + M BCELoss launches + 2*M*K torchmetrics F1 passes + autograd backward (search_dg.py:140-142,164-165)",
                 "bound": "hbm", "bytes": seg_bytes, "ms": seg_ms, "achieved": seg_bytes / (seg_ms * 1e-3) / 1e9,
                 "frac": seg_bytes / (seg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "shape": [N, K, size, size], "launches": 2, "launches_replaced_about": 3 * M + 4 * M * K + 2},
+                "shape": [N, K, size, size], "launches": 1, "launches_replaced_about": 3 * M + 4 * M * K + 2},
             "k_sinkhorn": {
                 "replaces": "%d geomloss SamplesLoss calls of ~44 KeOps launches + one host sync each (search_dg.py:150-162)" % (M * P),
                 "bound": "latency", "us": sk_ms * 1e3, "us_min": float(min(tk)) * 1e3, "problems": M * P, "workgroups": M * P,
                 "bytes_in": N * 128 * 4, "bytes_out": 4 * M, "launches": 1, "launches_replaced_about": 44 * M * P,
                 "host_syncs_replaced": M * P}}
 
+
+
+def scale_leg(a):
+    """What a reader needs to predict the multi-GPU runs the driver makes from THIS one-GPU run: (1) the step of rank
+    0's row slice of a G-rank job on one MI355X, no collectives (`--shard_of G`, G = 2 / 4 / 8; the row plan of `--placement`); (2) the ONE
+    rank run through the whole distributed path over RCCL (`--force_dist`): calls per step and GPU-side milliseconds of the small
+    collectives -- BatchNorm statistics all-reduces (float64 [2C + 1], one per layer and direction, each between two dependent kernels),
+    the embedding all-gather, the policy broadcasts; (3) `predicted_ms_per_step` = (1) + calls x per-call latency for three latencies:
+    the one measured here at world size 1 (a floor: no peer to wait for) and 15 / 30 us (typical small-message RCCL latencies on 8
+    ranks over xGMI).  The DDP gradient all-reduce (4 bytes x parameters per step, bucketed, overlapped with the backward pass) is not in
+    the model.  Child processes: the parent has released its GPU memory."""
+    import subprocess
+    base = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--cfg", a.cfg, "--size", str(a.size), "--batch", str(a.batch),
+            "--backbone", a.backbone, "--backbone_dtype", a.backbone_dtype, "--placement", a.placement, "--legs", "none"]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    def run(extra, timeout=420):
+        p = subprocess.run(base + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=timeout)
+        lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not lines:
+            raise RuntimeError("child bench failed (%d): %s" % (p.returncode, p.stderr.decode()[-400:]))
+        return json.loads(lines[-1])
+    out = {"placement": a.placement, "per_rank_step_ms_one_gpu_no_collectives": {}, "rows_of_rank0": {}}
+    for G in (2, 4, 8):
+        r = run(["--shard_of", str(G), "--steps", "6", "--warmup", "2"])
+        out["per_rank_step_ms_one_gpu_no_collectives"][str(G)] = r["ms_per_step"]
+        out["rows_of_rank0"][str(G)] = r["config"].get("images_per_step_this_rank")
+    fd = run(["--force_dist", "--dist_backend", "nccl", "--steps", "4", "--warmup", "2"])
+    d = fd["config"]["distributed"]
+    coll = d.get("small_collectives_gpu_ms_per_step") or {}
+    out["one_rank_over_rccl"] = {"ms_per_step": fd["ms_per_step"], "rccl_version": d.get("rccl_version"),
+                                 "collectives_per_step": d.get("collectives_per_step"), "small_collectives_gpu_ms_per_step": coll,
+                                 "small_collectives_gpu_ms_per_step_total": d.get("small_collectives_gpu_ms_per_step_total")}
+    calls = sum(v["calls_per_step"] for v in coll.values()) if coll else None
+    lat_here = (sum(v["ms_per_step"] for v in coll.values()) / calls * 1e3) if calls else None
+    out["small_collective_calls_per_step"] = calls
+    out["latency_us_per_call_world1"] = lat_here
+    if calls:
+        out["predicted_ms_per_step"] = {
+            str(G): {("lat_%dus" % round(l)): out["per_rank_step_ms_one_gpu_no_collectives"][str(G)] + calls * l * 1e-3
+                     for l in (lat_here, 15.0, 30.0)} for G in (2, 4, 8)}
+        out["predicted_steps_per_s_at_15us"] = {str(G): 1e3 / out["predicted_ms_per_step"][str(G)]["lat_15us"] for G in (2, 4, 8)}
+    return out
 
 
 def rvs_1024_leg(n_units=144, size=1024, cfg_rel=os.path.join("experiments", "rvs_sinkhorn", "diversity_ex.yaml"), K=1,
@@ -773,7 +837,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.only_legs:
         return only_legs_main(a)
-    legs = set() if a.legs == "none" else set(("fop,kernels,precision,rvs1024,cpu" if a.legs == "auto" else a.legs).split(","))
+    legs = set() if a.legs == "none" else set(("fop,kernels,precision,rvs1024,cpu,scale" if a.legs == "auto" else a.legs).split(","))
     if a.no_cpu_baseline:
         legs.discard("cpu")
     if world > 1 or a.shard_of or a.dump_rewards or a.force_dist:
@@ -1080,7 +1144,7 @@ def main():
                                    % ("BASELINE configs[1]" if "optic_sinkhorn/diversity.yaml" in a.cfg.replace(os.sep, "/") and a.size == 512
                                       else os.path.basename(a.cfg), cfg.MODEL.NAME, cfg.MODEL.BACKBONE, D, cfg.DATASET.NAME, a.size, a.size,
                                       a.batch, M, n_rows, cfg.CONTROLLER.LOSS.upper()),
-                       "images_per_step": n_rows,
+                       "images_per_step": n_rows, "images_per_step_this_rank": int(plan.n_local),
                        "parallelism": "1 GPU" if world == 1 and not a.force_dist else
                                       "%d GPU(s): domain-major (domain, policy) units cut by %s (rows per rank %s), one embedding all-gather + DDP "
                                       "gradient all-reduce%s" % (world, a.placement, "/".join(str(c) for c in plan.counts),
@@ -1104,8 +1168,13 @@ def main():
         try:
             leg = hot_kernels_leg()
             out["kernels"] = leg
-            out["roofline"]["k_seg_frac"] = leg["k_seg_partial+k_seg_final"]["frac"]
+            out["roofline"]["k_seg_frac"] = leg["k_seg_loss"]["frac"]
             out["roofline"]["k_sinkhorn_us"] = leg["k_sinkhorn"]["us"]
+            big = leg.get("sinkhorn_large_clouds") or {}
+            if "cost_build" in big:
+                out["roofline"]["sinkhorn_big_ms"] = big["ms"]
+                out["roofline"]["sinkhorn_big_cost_build_mfma_frac"] = big["cost_build"]["frac"]
+                out["roofline"]["sinkhorn_big_sweep_hbm_frac"] = big["sweeps"]["frac"]
         except Exception as e:  # noqa: BLE001
             out["kernels"] = {"error": repr(e)}
     if rank == 0 and "rvs1024" in legs:
@@ -1174,6 +1243,19 @@ def main():
                 out["roofline"]["bf16_backbone_steps_per_s"] = n16 / el16
         except Exception as e:  # noqa: BLE001
             out["bf16_backbone"] = {"error": repr(e)}
+    if rank == 0 and "scale" in legs:
+        try:
+            st = st16 = st32 = z = fe = None              # (whatever is still alive) -- the children need the memory
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            leg = scale_leg(a)
+            out["config"]["distributed"]["scale_model"] = leg
+            out["scale_model"] = {"predicted_steps_per_s_at_15us": leg.get("predicted_steps_per_s_at_15us"),
+                                  "small_collective_calls_per_step": leg.get("small_collective_calls_per_step"),
+                                  "latency_us_per_call_world1": leg.get("latency_us_per_call_world1"), "detail": "config.distributed.scale_model"}
+        except Exception as e:  # noqa: BLE001
+            out["scale_model"] = {"error": repr(e)}
     if rank == 0:
         # the prose of the extra legs (what a figure replaces, how it was taken) goes to the detail file: the line stays below 8 KB
         def strip(obj, prefix):

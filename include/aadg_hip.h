@@ -177,6 +177,12 @@ int aadg_sinkhorn_divergence_f32(const float* feat, int ld, int E, const int32_t
                                  const int32_t* cloud_off, const int32_t* prob_xy, int n_prob,
                                  int max_cloud, float blur, float scaling, float* out, void* ws,
                                  size_t ws_bytes, void* stream);
+/* ABI 8, measurement: the large-cloud path (clouds beyond the LDS-resident kernel) in two halves -- phases bit 0 = row normalisation +
+ * eps schedule + cost matrices into ws, bit 1 = the sweeps over the matrices in ws + the result -- so that bench.py can price the cost
+ * build against the matrix-core peak and the sweeps against HBM.  -3 for clouds the LDS-resident kernel takes. */
+int aadg_sinkhorn_divergence_phases_f32(const float* feat, int ld, int E, const int32_t* cloud_rows, const int32_t* cloud_off,
+                                        const int32_t* prob_xy, int n_prob, int max_cloud, float blur, float scaling, float* out,
+                                        void* ws, size_t ws_bytes, int phases, void* stream);
 /* fe [D*B*M, E], row (b*D + d)*M + j  (train_dg_collate_fn order);  rewards[j] += sum over the
  * D(D-1)/2 domain pairs, added in the reference's order (d1<d2 lexicographic). */
 int aadg_sinkhorn_rewards_f32(const float* fe, int D, int B, int M, int E, float blur,

@@ -34,8 +34,8 @@ def parse_args(argv=None):
                         help="fp32: the library's float32 convolutions; f32x3: float32 tensors, own float32-precision matrix-core kernels; "
                              "bf16: bfloat16 autocast (narrower than the reference)")
     parser.add_argument('--sync_bn', action='store_true', help='SyncBatchNorm over the row-sharded ranks')
-    parser.add_argument('--placement', default='unit', choices=['unit', 'row'],
-                        help='multi-GPU: whole (domain, policy) units per rank (SURVEY 8e) or the same sequence balanced to the row')
+    parser.add_argument('--placement', default='row', choices=['unit', 'row'],
+                        help='multi-GPU cut of the domain-major (domain, policy) unit sequence: balanced to the row (default, as bench.py: 18 rows per rank at 8 GPUs) or whole units per rank (SURVEY 8e as written: 3/3/2/... units = 24 rows on the slowest rank); one domain per GPU at 3 GPUs either way')
     parser.add_argument('--fixed_policy', action='store_true',
                         help='no controller search: every policy is [Contrast .5, Sharpness .5] (BASELINE configs[0])')
     parser.add_argument('--max_epochs', default=None, type=int)

@@ -37,7 +37,7 @@ def main():
             m.p = 0.0
     if dtype == 'f32x3':                   # float32 tensors on the own float32-precision convolution kernels (the bench headline's mode)
         for m in model.modules():
-            if isinstance(m, (deeplab.Conv1x1, deeplab.Conv3x3, deeplab.SeparableConv2d, deeplab.StemConv7x7)):
+            if isinstance(m, (deeplab.Conv1x1, deeplab.Conv3x3, deeplab.SeparableConv2d, deeplab.StemConv7x7, deeplab.DeepLabV3Plus)):
                 m.f32x3 = True
     ref = copy.deepcopy(model)
     N = int(os.environ.get("DDP_TEST_ROWS", "10"))     # 10 rows over 3 ranks: 4 / 3 / 3
