@@ -59,6 +59,7 @@ EXPORTS = [
     "aadg_weight_layouts_split_bf16", "aadg_conv1x1_nchw_f32x3", "aadg_conv1x1_wgrad_f32x3", "aadg_conv3x3_nchw_f32x3",
     "aadg_conv3x3_wgrad_f32x3", "aadg_conv3x3s2_nchw_f32x3", "aadg_conv3x3s2_dgrad_f32x3", "aadg_conv3x3s2_wgrad_f32x3",
     "aadg_stem_conv7x7_f32x3", "aadg_stem_conv7x7_wgrad_f32x3", "aadg_sinkhorn_divergence_phases_f32",
+    "aadg_conv1x1_nchw_f32x3_stats",
 ]
 
 _lib = None
@@ -243,6 +244,8 @@ def load():
     lib.aadg_weight_layouts_split_bf16.argtypes = [_vp, _vp, _i, _vp]
     lib.aadg_conv1x1_nchw_f32x3.restype = _i
     lib.aadg_conv1x1_nchw_f32x3.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
+    lib.aadg_conv1x1_nchw_f32x3_stats.restype = _i
+    lib.aadg_conv1x1_nchw_f32x3_stats.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]
     lib.aadg_conv1x1_wgrad_f32x3.restype = _i
     lib.aadg_conv1x1_wgrad_f32x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp]
     lib.aadg_conv3x3_nchw_f32x3.restype = _i
@@ -851,9 +854,11 @@ class _BatchNormAct(torch.autograd.Function):
     which the backward kernel sums while reading them instead of autograd running elementwise adds over the full activation."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, act, handles, out=None):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, act, handles, out=None, presums=None):
         lib = load()
         N, C, H, W = x.shape
+        # presums: float64 [2C + 1] totals of x (sum, sum of squares per channel, element count) the PRODUCING convolution left behind
+        # (aadg_conv1x1_nchw_f32x3_stats): the statistics pass over x is not run
         # out: a channel slice of a concatenation buffer (concat_slices): the result is written there, image stride = the buffer's
         y = torch.empty_like(x) if out is None else out
         y_stride = 0 if out is None else out.stride(0)
@@ -865,9 +870,15 @@ class _BatchNormAct(torch.autograd.Function):
             nb = lib.aadg_bn_mask_bytes(N, C, H * W, _BN_DTYPES[x.dtype])
             if nb and (x.data_ptr() | residual.data_ptr() | y.data_ptr()) % 16 == 0:
                 mask = torch.empty(nb, dtype=torch.uint8, device=x.device)
-        rc = lib.aadg_bn_forward(x.data_ptr(), _ptr(residual), y.data_ptr(), _ptr(mask), _ptr(weight), _ptr(bias),
-                                 _ptr(running_mean), _ptr(running_var), momentum, eps, act, 1, N, C, H * W, _BN_DTYPES[x.dtype],
-                                 mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), y_stride, _stream())
+        if presums is not None:
+            rc = lib.aadg_bn_sync_forward(2, x.data_ptr(), _ptr(residual), y.data_ptr(), _ptr(mask), _ptr(weight), _ptr(bias),
+                                          _ptr(running_mean), _ptr(running_var), momentum, eps, act, N, C, H * W, _BN_DTYPES[x.dtype],
+                                          mean.data_ptr(), invstd.data_ptr(), presums.data_ptr(), ws.data_ptr(), ws.numel(), y_stride,
+                                          _stream())
+        else:
+            rc = lib.aadg_bn_forward(x.data_ptr(), _ptr(residual), y.data_ptr(), _ptr(mask), _ptr(weight), _ptr(bias),
+                                     _ptr(running_mean), _ptr(running_var), momentum, eps, act, 1, N, C, H * W, _BN_DTYPES[x.dtype],
+                                     mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), y_stride, _stream())
         _check(rc, "aadg_bn_forward")
         if out is not None:
             ctx.mark_dirty(out)
@@ -896,7 +907,7 @@ class _BatchNormAct(torch.autograd.Function):
                                   _ptr(dres), dw.data_ptr(), db.data_ptr(), N, C, H * W, _BN_DTYPES[x.dtype], ws.data_ptr(),
                                   ws.numel(), dy_stride, _stream())
         _check(rc, "aadg_bn_backward")
-        return (dx, dres, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None, None)
+        return (dx, dres, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None, None, None)
 
 
 def _bn_prepare_grads(grads, x, has_res):
@@ -955,14 +966,15 @@ class _SyncBatchNormAct(torch.autograd.Function):
     all-reduces per layer and step ([2C + 1] and [2C] float64)."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, act, handles, out=None):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, act, handles, out=None, presums=None):
         lib = load()
         N, C, H, W = x.shape
         y = torch.empty_like(x) if out is None else out
         y_stride = 0 if out is None else out.stride(0)
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
-        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
+        # presums: this rank's float64 sums from the producing convolution's epilogue: phase 1 (the local statistics pass) is not run
+        sums = presums if presums is not None else torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
         ws = _bn_ws(C, x.device)
         mask = None
         if residual is not None and act != ACT_NONE:
@@ -972,7 +984,8 @@ class _SyncBatchNormAct(torch.autograd.Function):
         args = (x.data_ptr(), _ptr(residual), y.data_ptr(), _ptr(mask), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
                 momentum, eps, act, N, C, H * W, _BN_DTYPES[x.dtype], mean.data_ptr(), invstd.data_ptr(), sums.data_ptr(), ws.data_ptr(),
                 ws.numel(), y_stride, _stream())
-        _check(lib.aadg_bn_sync_forward(1, *args), "aadg_bn_sync_forward(1)")
+        if presums is None:
+            _check(lib.aadg_bn_sync_forward(1, *args), "aadg_bn_sync_forward(1)")
         _bn_sync_reduce(sums)
         _check(lib.aadg_bn_sync_forward(2, *args), "aadg_bn_sync_forward(2)")
         if out is not None:
@@ -1003,7 +1016,7 @@ class _SyncBatchNormAct(torch.autograd.Function):
         _check(lib.aadg_bn_sync_backward(1, *args), "aadg_bn_sync_backward(1)")
         _bn_sync_reduce(sums)
         _check(lib.aadg_bn_sync_backward(2, *args), "aadg_bn_sync_backward(2)")
-        return (dx, dres, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None, None)
+        return (dx, dres, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None, None, None)
 
 
 class _SyncBatchNormActGroup(torch.autograd.Function):
@@ -1215,7 +1228,7 @@ def bn_act_supported(x, residual=None):
 
 
 def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentum, eps, act=ACT_NONE, residual=None, dual=False,
-                   handles=None, out=None, sync=False):
+                   handles=None, out=None, sync=False, presums=None):
     """act(F.batch_norm(x, ...) [+ residual]) on NCHW float32 / bfloat16 GPU tensors.  handles = k > 1 (training only; dual =
     True means k = 2) returns the output as a tuple of k tensors on one storage, one per consumer, see _BatchNormAct."""
     handles = int(handles) if handles else (2 if dual else 1)
@@ -1227,7 +1240,9 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
                                 out.data_ptr() % 16 or out.stride(0) % 8):
             raise AadgError("batch_norm_act: `out` must be a channel slice of a contiguous NCHW buffer of the same dtype")
         fn = _SyncBatchNormAct if sync else _BatchNormAct
-        return fn.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), int(act), handles, out)
+        if presums is not None and (presums.dtype != torch.float64 or presums.numel() != 2 * x.shape[1] + 1 or not presums.is_cuda):
+            raise AadgError("batch_norm_act: presums must be the float64 [2C + 1] totals of x")
+        return fn.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), int(act), handles, out, presums)
     lib = load()
     N, C, H, W = x.shape
     if x.requires_grad or (residual is not None and residual.requires_grad):
@@ -1988,8 +2003,9 @@ def conv3x3(x, weight, dilation=1):
 # x = hi + lo and every product formed as hi*hi + hi*lo + lo*hi on the bfloat16 matrix cores with float32 accumulation (csrc/common.h:
 # aadg_split4; the X3 instantiations of the convolution kernels).  Activations are split inside the kernels while they are staged in
 # LDS; the weights come pre-split from the tracked shadows (track_bf16_weights(..., split=True)) or, untracked, from split_weight().
-def conv1x1_nchw_x3(a2, x):
-    """out [N, M, H, W] float32 = a [M, K] applied to the channels of x [N, K, H, W] float32; a2 [2, M, K] bfloat16 = (hi, lo) of a"""
+def conv1x1_nchw_x3(a2, x, bn_sums=None):
+    """out [N, M, H, W] float32 = a [M, K] applied to the channels of x [N, K, H, W] float32; a2 [2, M, K] bfloat16 = (hi, lo) of a.
+    bn_sums (float64 [2M + 1], optional) receives the BatchNorm statistics of out from the kernel's epilogue."""
     _require_cuda(a2, x)
     N, K, H, W = x.shape
     M = a2.shape[1]
@@ -1997,8 +2013,8 @@ def conv1x1_nchw_x3(a2, x):
             not (a2.is_contiguous() and x.is_contiguous()) or not load().aadg_conv1x1_nchw_supported(M, K, H * W)):
         raise AadgError("conv1x1_nchw_x3: unsupported shape / dtype / layout")
     out = torch.empty((N, M, H, W), dtype=torch.float32, device=x.device)
-    _check(load().aadg_conv1x1_nchw_f32x3(a2[0].data_ptr(), a2[1].data_ptr(), x.data_ptr(), out.data_ptr(), N, M, K, H * W, _stream()),
-           "aadg_conv1x1_nchw_f32x3")
+    _check(load().aadg_conv1x1_nchw_f32x3_stats(a2[0].data_ptr(), a2[1].data_ptr(), x.data_ptr(), out.data_ptr(), N, M, K, H * W,
+                                                _ptr(bn_sums), _stream()), "aadg_conv1x1_nchw_f32x3")
     return out
 
 
@@ -2021,16 +2037,23 @@ class _Conv1x1X3(torch.autograd.Function):
     (csrc/conv1x1_fwd.hip, X3) and weight gradient (csrc/conv1x1_wgrad.hip, X3).  `weight` is the float32 parameter."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, want_stats=False):
+        """want_stats: also return the float64 [2 Co + 1] BatchNorm totals of the output (sum, sum of squares per channel, count), taken
+        in the kernel's epilogue -- for the BatchNorm layer behind this convolution (batch_norm_act(..., presums=...))."""
         Co, Ci = weight.shape[0], weight.shape[1]
         a2 = split_layout(weight, "plain")
         a2 = a2.view(2, Co, Ci) if a2 is not None else split_weight(weight.detach().reshape(Co, Ci))
         ctx.save_for_backward(x, weight)
         ctx.wt = _ShadowRef(weight, "bwd", split=True)          # [2, 1, Ci, Co] of the tracked shadow (this step's weights)
-        return conv1x1_nchw_x3(a2, x)
+        if not want_stats:
+            return conv1x1_nchw_x3(a2, x)
+        sums = torch.empty(2 * Co + 1, dtype=torch.float64, device=x.device)
+        y = conv1x1_nchw_x3(a2, x, sums)
+        ctx.mark_non_differentiable(sums)
+        return y, sums
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         Co, Ci = weight.shape[0], weight.shape[1]
@@ -2041,7 +2064,7 @@ class _Conv1x1X3(torch.autograd.Function):
             dx = conv1x1_nchw_x3(at, dy)
         if ctx.needs_input_grad[1]:
             dw = conv1x1_wgrad_x3(dy, x).view(weight.shape)
-        return dx, dw
+        return dx, dw, None
 
 
 def conv1x1_x3_supported(x, weight):
@@ -2051,11 +2074,17 @@ def conv1x1_x3_supported(x, weight):
             bool(load().aadg_conv1x1_nchw_supported(weight.shape[0], weight.shape[1], HW)))
 
 
-def conv1x1_x3(x, weight):
+def conv1x1_x3(x, weight, want_stats=False):
+    """want_stats: returns the output with its BatchNorm totals attached as `y._aadg_bn_sums` (float64 [2 Co + 1]); models/deeplab.py's
+    bn_act hands them to the BatchNorm kernels, which then skip their statistics pass over y."""
     _require_cuda(x, weight)
     if not conv1x1_x3_supported(x, weight):
         raise AadgError("conv1x1_x3: unsupported shape / dtype / layout")
-    return _Conv1x1X3.apply(x, weight)
+    if not want_stats:
+        return _Conv1x1X3.apply(x, weight, False)
+    y, sums = _Conv1x1X3.apply(x, weight, True)
+    y._aadg_bn_sums = sums
+    return y
 
 
 def conv3x3_nchw_x3(a9, x, dilation=1):

@@ -40,7 +40,7 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const uint16_t* p) {
 template <int WR, int WC, int MI, int NI, bool X3>
 __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restrict__ A, const uint16_t* __restrict__ A_lo,
                                                          const void* __restrict__ IN_, void* __restrict__ OUT_, int M, int K, int HW,
-                                                         int tiles_p, int tiles_m) {
+                                                         int tiles_p, int tiles_m, double* __restrict__ stats) {
     static_assert(WR * WC == 4 && 32 * NI * WC == CF_BP, "4 waves, 256 pixels");
     constexpr int BM = 32 * MI * WR;
     constexpr int BK = X3 ? 32 : CF_BK, APITCH = BK + 8, PL = X3 ? 2 : 1;
@@ -175,6 +175,59 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
                     const int p = p0 + wc * 32 * NI + 32 * ni + jj;
                     if (m < M && p < HW) outf[(size_t)m * HW + p] = d[mi][ni][r];
                 }
+        if (stats != nullptr) {
+            // BatchNorm statistics of the output in the epilogue (training: the layer behind this convolution is a BatchNorm): per
+            // channel sum and sum of squares over the tile's pixels -> double atomics into stats[2 m], stats[2 m + 1] (the float64
+            // totals aadg_bn_sync_forward(phase 2, ...) normalises with), instead of a pass of k_bn_reduce_fwd over the whole float32
+            // tensor.  Pixels beyond HW were computed from zero-filled input: they contribute 0.  A lane holds, for each of its
+            // 16 MI rows, NI pixels: summed per lane, then over the 32 lanes of the row with a halving butterfly -- at step `msk` a
+            // lane keeps one half of its items and hands the other half to lane ^ msk (ds_swizzle: the LDS crossbar, no memory), so
+            // 32 + 16 + 8 + 4 + 2 exchanges leave every lane with the two totals of ONE row (row index = the lane's bits reversed).
+            constexpr int NR = 16 * MI;                     // rows per lane half
+            static_assert(NR == 32, "the butterfly below pairs 32 rows with the 32 lanes of a half");
+            float v[2 * NR];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float s = 0.f, q = 0.f;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) { s += d[mi][ni][r]; q = fmaf(d[mi][ni][r], d[mi][ni][r], q); }
+                    v[2 * (16 * mi + r)] = s;
+                    v[2 * (16 * mi + r) + 1] = q;
+                }
+#define AADG_BFLY(MSK, HALF, PAT)                                                                       \
+            {                                                                                           \
+                const bool up = (lane & (MSK)) != 0;                                                    \
+                _Pragma("unroll") for (int i = 0; i < (HALF); ++i) {                                    \
+                    const float keep = up ? v[i + (HALF)] : v[i], send = up ? v[i] : v[i + (HALF)];     \
+                    v[i] = keep + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send), (PAT))); \
+                }                                                                                       \
+            }
+            // ds_swizzle bit mode: and_mask 0x1F | xor_mask << 10 (groups of 32 lanes)
+            AADG_BFLY(16, 32, 0x1F | (16 << 10))
+            AADG_BFLY(8, 16, 0x1F | (8 << 10))
+            AADG_BFLY(4, 8, 0x1F | (4 << 10))
+            AADG_BFLY(2, 4, 0x1F | (2 << 10))
+            AADG_BFLY(1, 2, 0x1F | (1 << 10))
+#undef AADG_BFLY
+            // item kept through the steps: bit 4 of the lane picked the upper 32 items, bit 3 the upper 16 of those, ...
+            const int item = ((lane >> 4) & 1) * 32 + ((lane >> 3) & 1) * 16 + ((lane >> 2) & 1) * 8 + ((lane >> 1) & 1) * 4 + (lane & 1) * 2;
+            const int rr = item >> 1, mi = rr >> 4, r = rr & 15;
+            const int row = wr * 32 * MI + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * g;       // row of the workgroup's tile
+            // the WC waves that share a row are combined in LDS first (the operand buffers are free once every wave has left the
+            // K loop): one float64 atomic per channel, statistic and WORKGROUP -- with one per wave the 36 864 atomics per address of
+            // a 64-channel layer at 128 x 128 doubled that kernel's duration
+            float* red = reinterpret_cast<float*>(As);
+            __syncthreads();
+            for (int i = tid; i < 2 * BM; i += 256) red[i] = 0.0f;
+            __syncthreads();
+            __hip_atomic_fetch_add(red + 2 * row, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(red + 2 * row + 1, v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __syncthreads();
+            for (int i = tid; i < 2 * BM; i += 256)
+                if (m0 + (i >> 1) < M) unsafeAtomicAdd(stats + 2 * (size_t)m0 + i, (double)red[i]);
+        }
         return;
     }
     // bfloat16 out: lanes p / p + 1 trade registers r / r + 1 so that each stores two adjacent pixels of one channel row (4-byte stores)
@@ -198,13 +251,14 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
 }
 
 template <int WR, int WC, int MI, int NI, bool X3>
-int launch(const uint16_t* A, const uint16_t* A_lo, const void* IN, void* OUT, int N, int M, int K, int HW, hipStream_t st) {
+int launch(const uint16_t* A, const uint16_t* A_lo, const void* IN, void* OUT, int N, int M, int K, int HW, hipStream_t st,
+           double* stats = nullptr) {
     constexpr int BM = 32 * MI * WR;
     const int tiles_p = (HW + CF_BP - 1) / CF_BP, tiles_m = (M + BM - 1) / BM;
     const long long wgs = (long long)N * tiles_p * tiles_m;
     if (wgs > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
     hipLaunchKernelGGL((k_conv1x1_nchw<WR, WC, MI, NI, X3>), dim3((unsigned)wgs), dim3(256), 0, st, A, A_lo, IN, OUT, M, K, HW, tiles_p,
-                       tiles_m);
+                       tiles_m, stats);
     AADG_LAUNCH_CHECK();
     return 0;
 }
@@ -229,14 +283,34 @@ extern "C" int aadg_conv1x1_nchw_bf16(const void* a, const void* in, void* out, 
 
 /* The same contraction at float32 precision ("f32x3"): in / out float32 NCHW; a_hi / a_lo = the bfloat16 (hi, lo) halves of the
  * float32 operand a [M, K] (aadg_weight_layouts_split_bf16); products hi*hi + hi*lo + lo*hi on the matrix cores, float32 accumulation */
+namespace {
+__global__ __launch_bounds__(256) void k_bn_sums_init(double* __restrict__ sums, int C, double count) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 2 * C) sums[i] = 0.0;
+    if (i == 2 * C) sums[i] = count;
+}
+}  // namespace
+
 extern "C" int aadg_conv1x1_nchw_f32x3(const void* a_hi, const void* a_lo, const float* in, float* out, int N, int M, int K, int HW,
                                        void* stream) {
+    return aadg_conv1x1_nchw_f32x3_stats(a_hi, a_lo, in, out, N, M, K, HW, nullptr, stream);
+}
+
+/* ... and, with bn_sums != NULL, the BatchNorm statistics of `out` from the convolution's epilogue: bn_sums [2 M + 1] doubles receives
+ * (sum, sum of squares) per output channel and the element count N * HW in the last entry -- the buffer aadg_bn_sync_forward(phase 2)
+ * / aadg_bn_sync_backward take (one pass over the float32 output less per BatchNorm layer; the buffer is zeroed in here). */
+extern "C" int aadg_conv1x1_nchw_f32x3_stats(const void* a_hi, const void* a_lo, const float* in, float* out, int N, int M, int K, int HW,
+                                             double* bn_sums, void* stream) {
     if (a_hi == nullptr || a_lo == nullptr || in == nullptr || out == nullptr || N <= 0) return AADG_E_BADARG;
-    if ((((uintptr_t)a_hi | (uintptr_t)a_lo | (uintptr_t)in | (uintptr_t)out) & 15u) != 0) return AADG_E_BADARG;
+    if ((((uintptr_t)a_hi | (uintptr_t)a_lo | (uintptr_t)in | (uintptr_t)out) & 15u) != 0 || (((uintptr_t)bn_sums) & 7u) != 0) return AADG_E_BADARG;
     if (!aadg_conv1x1_nchw_supported(M, K, HW)) return AADG_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const uint16_t* ph = (const uint16_t*)a_hi;
     const uint16_t* pl = (const uint16_t*)a_lo;
-    if (M <= 64) return launch<1, 4, 2, 2, true>(ph, pl, in, out, N, M, K, HW, st);
-    return launch<2, 2, 2, 4, true>(ph, pl, in, out, N, M, K, HW, st);
+    if (bn_sums != nullptr) {
+        hipLaunchKernelGGL(k_bn_sums_init, dim3((2 * M + 1 + 255) / 256), dim3(256), 0, st, bn_sums, M, (double)N * (double)HW);
+        AADG_LAUNCH_CHECK();
+    }
+    if (M <= 64) return launch<1, 4, 2, 2, true>(ph, pl, in, out, N, M, K, HW, st, bn_sums);
+    return launch<2, 2, 2, 4, true>(ph, pl, in, out, N, M, K, HW, st, bn_sums);
 }

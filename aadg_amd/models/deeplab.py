@@ -51,6 +51,8 @@ def batch_step_bookkeeping(model, f32x3=False):
     for m in model.modules():
         if isinstance(m, (Conv1x1, Conv3x3, SeparableConv2d, StemConv7x7, DeepLabV3Plus)):
             m.f32x3 = bool(f32x3)
+    if f32x3:
+        mark_bn_producers(model)
     _lib.track_bf16_weights(model, (Conv1x1, Conv3x3), split=bool(f32x3))
     for m in model.modules():
         if type(m) is nn.BatchNorm2d:
@@ -66,6 +68,27 @@ def batch_step_bookkeeping(model, f32x3=False):
 
     model.register_forward_pre_hook(before)
     model.register_forward_hook(after)
+
+
+def mark_bn_producers(model):
+    """Sets `bn_stats` on every pointwise convolution whose output goes straight into a BatchNorm of this module tree -- the bottleneck's
+    conv1 / conv3, a (convolution, BNAct) pair inside an nn.Sequential (projection shortcuts, ASPP branches, the decoder) and the pointwise
+    half of a SeparableConv2d in such a pair: in f32x3 training mode those convolutions take the BatchNorm statistics of their output in
+    the kernel epilogue (csrc/conv1x1_fwd.hip) and bn_act skips the statistics pass."""
+    n = 0
+    for m in model.modules():
+        if isinstance(m, Bottleneck):
+            m.conv1.bn_stats = m.conv3.bn_stats = True
+            n += 2
+        if isinstance(m, nn.Sequential):
+            mods = list(m)
+            for a_, b_ in zip(mods[:-1], mods[1:]):
+                if type(b_) is BNAct:
+                    c = a_[1] if isinstance(a_, SeparableConv2d) else a_
+                    if isinstance(c, Conv1x1):
+                        c.bn_stats = True
+                        n += 1
+    return n
 
 
 def set_bn_sync(flag):
@@ -86,11 +109,13 @@ def bn_act(bn, x, act=None, residual=None, handles=1, out=None):
         if _lib.bn_act_supported(xc, rc):
             if bn.training:
                 _bump(bn)
+            # statistics the producing convolution took in its epilogue (Conv1x1 in f32x3 mode, `bn_stats`): no statistics pass over x
+            presums = getattr(x, '_aadg_bn_sums', None) if bn.training else None
             # out (training only): a slice of a concatenation buffer (_lib.concat_slices) that receives the result
             return _lib.batch_norm_act(xc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum,
                                        bn.eps, _ACT_CODE[act], rc,
                                        handles=handles if (bn.training and torch.is_grad_enabled() and rc is not None) else 1,
-                                       out=out if bn.training else None, sync=_BN_SYNC and bn.training)
+                                       out=out if bn.training else None, sync=_BN_SYNC and bn.training, presums=presums)
     if _BN_SYNC and bn.training and type(bn) is nn.BatchNorm2d:
         # the DDP wrapper runs with broadcast_buffers=False on the assumption that EVERY BatchNorm layer synchronises its statistics
         # through the HIP path above; a layer that falls through to plain bn(x) would silently use per-rank statistics
@@ -145,6 +170,7 @@ class Conv1x1(nn.Conv2d):
     (csrc/conv1x1_wgrad.hip) instead of transposing both activations to NHWC first."""
 
     f32x3 = False           # float32 inputs: the own float32-precision kernels instead of the library's (batch_step_bookkeeping)
+    bn_stats = False        # f32x3, training: a BatchNorm follows -- its statistics come out of this convolution's epilogue (mark_bn_producers)
 
     def __init__(self, cin, cout, stride=1):
         super().__init__(cin, cout, 1, stride=stride, bias=False)
@@ -153,13 +179,14 @@ class Conv1x1(nn.Conv2d):
         if x.is_cuda and x.dtype == torch.float32 and self.f32x3 and self.stride in ((1, 1), (2, 2)):
             from .. import _lib
             xc = x.contiguous()
+            stats = self.bn_stats and self.training and torch.is_grad_enabled()
             if self.stride == (2, 2) and _lib.subsample2x2_supported(xc):
                 xs = _lib.subsample2x2(xc)                   # pick the even pixels (one streaming pass), then the stride-1 kernel
                 if _lib.conv1x1_x3_supported(xs, self.weight):
-                    return _lib.conv1x1_x3(xs, self.weight)
+                    return _lib.conv1x1_x3(xs, self.weight, stats)
                 return F.conv2d(xs, self.weight)
             if self.stride == (1, 1) and _lib.conv1x1_x3_supported(xc, self.weight):
-                return _lib.conv1x1_x3(xc, self.weight)
+                return _lib.conv1x1_x3(xc, self.weight, stats)
             return super().forward(x)
         if x.is_cuda and x.dtype == torch.bfloat16 and self.stride in ((1, 1), (2, 2)):
             from .. import _lib

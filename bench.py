@@ -718,7 +718,7 @@ def rvs_1024_leg(n_units=144, size=1024, cfg_rel=os.path.join("experiments", "rv
     kb = unit_bytes(units, Hs, Hs, size, K, False)
     sb = unit_bytes(units, Hs, Hs, size, K, True)
     k_ms, c_ms = float(np.mean([p[0].elapsed_time(p[1]) for p in kp])), float(np.mean([p[0].elapsed_time(p[1]) for p in cp]))
-    tr = (committed("r04_rvs1024_traffic.json") or committed("r03_rvs1024_traffic.json")) if size == 1024 else None
+    tr = (committed("r05_rvs1024_traffic.json") or committed("r04_rvs1024_traffic.json")) if size == 1024 else None
     return {"workload": "%s: %s pipeline, %dx%d crops from %dx%d sources, "
                         "%d units per batch (hot path only: augmentation call)" % (label, cfg_rel, size, size, Hs, Hs, len(units)),
             "units": len(units), "units_by_tile_kernel": {"up_plain": n_flow[0], "up_sharpness": n_flow[1], "generic_downscale": n_flow[2],
@@ -1068,8 +1068,8 @@ def main():
         with open(a.dump_rewards, "w") as f:
             json.dump({"normalized": [n.tolist() for n, _ in dump], "raw": [r.tolist() for _, r in dump]}, f)
     if rank == 0:
-        traffic = committed("r04_traffic_k_fused3.json") or committed("r03_traffic_k_fused3.json")
-        prof = committed("r04_bench_kernel_stats.json") or committed("r03_bench_kernel_stats.json")
+        traffic = committed("r05_traffic_k_fused3.json") or committed("r04_traffic_k_fused3.json")
+        prof = committed("r05_bench_kernel_stats.json") or committed("r04_bench_kernel_stats.json")
         # `roofline`: flat scalars first (the driver's record keeps scalars of this block), nested blocks after them
         roof = {"bound": "hbm", "kernel": "k_fused3 (LDS-tiled op chain + Pillow-exact resample + crop + normalise + CHW float32 store)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -375,6 +375,11 @@ int aadg_conv1x1_nchw_bf16(const void* a, const void* in, void* out, int N, int 
  * on the bfloat16 matrix cores with float32 accumulation: three MFMAs per product = 5.3x the float32-MFMA rate.  a_hi / a_lo [M, K]
  * bfloat16: the halves of the float32 operand a (aadg_weight_layouts_split_bf16); in / out float32. */
 int aadg_conv1x1_nchw_f32x3(const void* a_hi, const void* a_lo, const float* in, float* out, int N, int M, int K, int HW, void* stream);
+/* ... with the BatchNorm statistics of `out` from the convolution's epilogue: bn_sums [2 M + 1] doubles = (sum, sum of squares) per output
+ * channel + the element count N * HW -- the buffer aadg_bn_sync_forward(phase 2, ...) normalises with (the statistics pass over the
+ * float32 output is not run); bn_sums == NULL: plain convolution */
+int aadg_conv1x1_nchw_f32x3_stats(const void* a_hi, const void* a_lo, const float* in, float* out, int N, int M, int K, int HW,
+                                  double* bn_sums, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The ResNet stem convolution, forward: y [N, 64, H/2, W/2] = conv2d(x [N, 3, H, W], weight [64, 3, 7, 7], stride 2, padding 3),

@@ -135,8 +135,8 @@ def test_f32x3_network_equals_the_float32_library_network(hip):
     """Round 5: DeepLabV3+/ResNet-50 in f32x3 mode (float32 tensors; stem, 1x1, 3x3 stride 1 / 2 and the classifier on the own float32-
     precision matrix-core kernels, tracked (hi, lo) weight shadows) against the same weights on the library's float32 convolutions:
     logits, pooled feature and all parameter gradients -- float32-grade on both sides, so they must agree as tightly as two float32
-    implementations of this BatchNorm network do (the HIP-layers-vs-library bound above); then two optimizer steps (the shadows must
-    follow the updated weights: torch's fused Adam does not bump version counters)."""
+    implementations of this BatchNorm network do (the HIP-layers-vs-library bound above); then two more steps from updated weights (the
+    shadows must follow them: torch's fused Adam does not bump version counters)."""
     from aadg_amd.models import deeplab
     torch.manual_seed(11)
     a = deeplab.DeepLabV3Plus("resnet50", 2).cuda().train()
@@ -160,8 +160,8 @@ def test_f32x3_network_equals_the_float32_library_network(hip):
     for key, name in names.items():
         setattr(hip, name, counted(key))
     try:
-        x = torch.randn(6, 3, 256, 256, device="cuda")
-        y = (torch.rand(6, 2, 256, 256, device="cuda") > 0.5).float()
+        x = torch.randn(4, 3, 512, 512, device="cuda")          # the headline's map sizes: every convolution has an own kernel
+        y = (torch.rand(4, 2, 512, 512, device="cuda") > 0.5).float()
         oa = torch.optim.Adam(a.parameters(), lr=1e-3, fused=True)
         ob = torch.optim.Adam(b.parameters(), lr=1e-3, fused=True)
         for step in range(3):
@@ -192,9 +192,13 @@ def test_f32x3_network_equals_the_float32_library_network(hip):
                 print("logits vs float32 library: f32x3 %.2e, bfloat16 autocast %.2e" % (e3, e16))
                 assert e3 < 1e-2 and e3 < 0.25 * e16, (e3, e16)
                 del c, lc, fc
-            tol = (1e-2, 1e-2, 0.25) if step == 0 else (5e-2, 5e-2, 0.5)       # later steps: the two trajectories have separated a little
+            tol = (1e-2, 1e-2, 0.25)
             assert _rel(outs[0][0], outs[1][0]) < tol[0] and _rel(outs[0][1], outs[1][1]) < tol[1], (step, _rel(outs[0][0], outs[1][0]))
             assert _rel(outs[0][2], outs[1][2]) < tol[2], (step, _rel(outs[0][2], outs[1][2]))
+            # both networks start the next step from the SAME weights (Adam's first steps are sign-like: two float32-grade gradients
+            # that differ in the last digits send near-zero entries opposite ways, and the trajectories of this chaotic network part):
+            # what the later steps test is that the f32x3 network's shadows follow ITS updated weights
+            b.load_state_dict(a.state_dict())
     finally:
         for key, name in names.items():
             setattr(hip, name, real[key])

@@ -18,10 +18,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(tmp_path, gpus, tag, extra=(), batch=2):
+def _bench(tmp_path, gpus, tag, extra=(), batch=2, backbone="mobilenet_v2", dtype="fp32", size=64):
     dump = os.path.join(str(tmp_path), "rewards_%s.json" % tag)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "0", "--size", "64",
-           "--batch", str(batch), "--backbone", "mobilenet_v2", "--backbone_dtype", "fp32", "--no_cpu_baseline", "--no_dropout",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "0", "--size", str(size),
+           "--batch", str(batch), "--backbone", backbone, "--backbone_dtype", dtype, "--no_cpu_baseline", "--no_dropout",
            "--dump_rewards", dump] + list(extra)
     if gpus > 1:
         cmd.append("--all_ranks_on_gpu0")
@@ -99,3 +99,24 @@ def test_force_dist_one_rank_over_rccl(tmp_path):
     assert max(abs(x - y) for x, y in zip(a, b)) < 1e-4, (a, b)
     for a, b in zip(r1["raw"][1:], rg["raw"][1:]):
         assert max(abs(x - y) for x, y in zip(a, b)) < 0.25 * max(abs(x) for x in a), (a, b)
+
+
+@pytest.mark.parametrize("dtype", ["f32x3", "bf16"])
+def test_force_dist_resnet50_sync_bn_over_rccl(tmp_path, dtype):
+    """Round 5: the ResNet-50 paths of the synchronised BatchNorm -- `sync_batch_norm_act_group` (the five ASPP
+    layers share one all-reduce per direction) and `sync_batch_norm_shortcut_pair` (bn3 + the projection shortcut's BatchNorm) -- had run
+    over gloo only.  One rank through the whole distributed path over RCCL with the headline's backbone, in the headline's arithmetic
+    (f32x3) and under bfloat16 autocast: the first step's rewards equal the plain single-process run's (float32-grade: 1e-3; bfloat16:
+    loosely), and the collectives are the expected ones (ResNet-50: 53 BatchNorm layers, 5 + 4 of them grouped / paired)."""
+    one, r1 = _bench(tmp_path, 1, "r50plain_" + dtype, backbone="resnet50", dtype=dtype, size=128)
+    out, rg = _bench(tmp_path, 1, "r50rccl_" + dtype, ["--force_dist", "--dist_backend", "nccl"], backbone="resnet50", dtype=dtype, size=128)
+    d = out["config"]["distributed"]
+    assert d["initialized"] and d["backend"] == "nccl" and d["world_size"] == 1 and d["forced_one_rank_run_of_the_distributed_path"], d
+    assert "own process group" in d["small_collectives_group"] and "own process group" in d["side_stream_collectives_group"], d
+    n_bn = d["collectives_per_step"]["batchnorm_statistics_all_reduce"]
+    assert 80 <= n_bn <= 106, n_bn               # 53 layers x 2 directions, minus the grouped (5 -> 1) and paired (2 -> 1) ones
+    t = d["small_collectives_gpu_ms_per_step"]
+    assert t["all_gather"]["calls_per_step"] == 1 and t["policy_broadcast"]["calls_per_step"] == 2, t
+    a, b = r1["raw"][0], rg["raw"][0]
+    tol = 1e-3 if dtype == "f32x3" else 0.1 * max(abs(x) for x in a)     # (other BatchNorm kernels on the sharded path: float64 totals)
+    assert max(abs(x - y) for x, y in zip(a, b)) < tol, (a, b)

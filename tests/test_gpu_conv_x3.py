@@ -172,3 +172,56 @@ def test_stem_conv7x7_x3(hip, N, H, W):
     y1.backward(g)
     y2.backward(g.double())
     assert _err(w1.grad, w2.grad) <= TOL, _err(w1.grad, w2.grad)
+
+
+@pytest.mark.parametrize("N,K,M,H,W", [(3, 64, 256, 32, 32), (2, 256, 64, 64, 64), (2, 128, 72, 16, 32), (1, 304, 256, 32, 40)])
+def test_conv1x1_x3_batchnorm_statistics_from_the_epilogue(hip, N, K, M, H, W):
+    """aadg_conv1x1_nchw_f32x3_stats: (sum, sum of squares) per output channel + the element count, accumulated in the convolution's
+    epilogue (halving butterfly over the lanes of a row, float64 atomics) == the sums of the stored output."""
+    torch.manual_seed(M + W)
+    x = torch.randn(N, K, H, W, device="cuda") + 0.3
+    w = torch.randn(M, K, device="cuda") / K ** 0.5
+    sums = torch.full((2 * M + 1,), 7.0, dtype=torch.float64, device="cuda")           # (the call zeroes it)
+    y = hip.conv1x1_nchw_x3(hip.split_weight(w), x, sums)
+    yd = y.double()
+    want_s, want_q = yd.sum(dim=(0, 2, 3)), (yd * yd).sum(dim=(0, 2, 3))
+    got = sums[:2 * M].view(M, 2)
+    assert sums[2 * M].item() == N * H * W
+    assert (got[:, 0] - want_s).abs().max().item() <= 1e-5 * want_q.sqrt().max().item() * (N * H * W) ** 0.5
+    assert ((got[:, 1] - want_q).abs() / want_q).max().item() <= 1e-5
+    assert torch.equal(y, hip.conv1x1_nchw_x3(hip.split_weight(w), x))                   # the output itself is unchanged
+
+
+@pytest.mark.parametrize("act,res", [("relu", False), (None, False), ("relu", True)])
+def test_batchnorm_behind_an_f32x3_convolution_uses_its_statistics(hip, act, res):
+    """models/deeplab.py: a Conv1x1 marked `bn_stats` (mark_bn_producers) hands the BatchNorm totals of its output to bn_act, which then
+    runs only the normalisation kernel: output, running statistics and all gradients == plain torch (float64)."""
+    from aadg_amd.models import deeplab as DL
+    torch.manual_seed(9)
+    net = torch.nn.Sequential(DL.Conv1x1(64, 128), DL.BNAct(128, act)).cuda().train()
+    DL.batch_step_bookkeeping(net, f32x3=True)
+    assert net[0].bn_stats
+    conv = torch.nn.Conv2d(64, 128, 1, bias=False).cuda().double()
+    bn = torch.nn.BatchNorm2d(128).cuda().double().train()
+    conv.weight.data.copy_(net[0].weight.data.double())
+    x1 = torch.randn(4, 64, 32, 32, device="cuda", requires_grad=True)
+    x2 = x1.detach().double().requires_grad_(True)
+    r1 = torch.randn(4, 128, 32, 32, device="cuda", requires_grad=True) if res else None
+    c1 = net[0](x1)
+    assert getattr(c1, "_aadg_bn_sums", None) is not None and c1._aadg_bn_sums.dtype == torch.float64
+    y1 = DL.bn_act(net[1].bn, c1, act, residual=r1)
+    y2 = bn(conv(x2))
+    if res:
+        y2 = y2 + r1.detach().double()
+    if act == "relu":
+        y2 = torch.relu(y2)
+    assert _err(y1, y2.detach()) <= 3e-5                 # (the convolution's 1e-5, divided by the batch's standard deviation)
+    assert _err(net[1].bn.running_var, bn.running_var) <= 1e-6 and (net[1].bn.running_mean.double() - bn.running_mean).abs().max().item() <= 1e-6
+    g = torch.randn_like(y1)
+    y1.backward(g)
+    y2.backward(g.double())
+    # with a residual the ReLU gate sits on bn(x) + r: a handful of the 4096 elements per channel land on the other side of zero in
+    # float32 than in float64, which moves the channel's gradient sums by ~1 / 4096 -- a property of the kink, not of the kernels
+    gt = 1e-3 if res else 3e-5
+    assert _err(x1.grad, x2.grad) <= gt and _err(net[0].weight.grad, conv.weight.grad) <= gt
+    assert _err(net[1].bn.weight.grad, bn.weight.grad) <= gt and _err(net[1].bn.bias.grad, bn.bias.grad) <= gt
