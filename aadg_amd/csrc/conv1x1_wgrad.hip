@@ -32,7 +32,8 @@ constexpr int WG_PITCH = WG_BK + 8;       // LDS row pitch in elements (144 byte
 // X3 = true ("f32x3"): dY / X are float32.  A K-step is still 128 bytes per row = 32 pixels; every loaded float4 becomes one 16-byte LDS
 // chunk [hi0..3][lo0..3] (aadg_split4), so the 8 K-values of a fragment are the hi halves of two neighbouring chunks and their lo
 // halves come with the same two reads; products hi*hi + hi*lo + lo*hi, float32 accumulation.
-template <int WR, int WC, int MI, int NI, bool X3>
+// EXACT (X3 only): Co / Ci whole tiles -- no null-row branches around the loads (one basic block per K-step).
+template <int WR, int WC, int MI, int NI, bool X3, bool EXACT = false>
 __global__ __launch_bounds__(64 * WR * WC) void k_wgrad1x1(const void* __restrict__ dY_, const void* __restrict__ X_,
                                                            float* __restrict__ acc, int Co, int Ci, int HW, int tiles, int tiles_n,
                                                            int steps_total, int steps_per_block) {
@@ -77,8 +78,8 @@ __global__ __launch_bounds__(64 * WR * WC) void k_wgrad1x1(const void* __restric
         const int n = step / spi, kk = (step - n * spi) * BKE;
 #pragma unroll
         for (int i = 0; i < LPT; ++i)
-            stage[i] = src[i] != nullptr ? *reinterpret_cast<const uint4*>(src[i] + (size_t)n * (i < LPT_A ? stride_a : stride_b) + kk)
-                                         : make_uint4(0, 0, 0, 0);
+            stage[i] = (EXACT || src[i] != nullptr) ? *reinterpret_cast<const uint4*>(src[i] + (size_t)n * (i < LPT_A ? stride_a : stride_b) + kk)
+                                                    : make_uint4(0, 0, 0, 0);
     };
 
     f32x16 d[MI][NI];
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_wgrad1x1(const void* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wr * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < Co && n < Ci) unsafeAtomicAdd(acc + (size_t)m * Ci + n, d[mi][ni][r]);
+                if (EXACT || (m < Co && n < Ci)) unsafeAtomicAdd(acc + (size_t)m * Ci + n, d[mi][ni][r]);
             }
         }
 }
@@ -188,10 +189,16 @@ int launch(const void* dY, const void* X, float* acc, int N, int Co, int Ci, int
     if (!attr_set) {
         AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad1x1<WR, WC, MI, NI, X3>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad1x1<WR, WC, MI, NI, X3, X3>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     AADG_HIP_TRY(hipMemsetAsync(acc, 0, (size_t)Co * Ci * sizeof(float), st));
     const int slice_groups = (split + 7) / 8;                 // slices are padded to a multiple of 8 (empty ones exit at once)
+    if (X3 && (Co % BM) == 0 && (Ci % BN) == 0)
+        hipLaunchKernelGGL((k_wgrad1x1<WR, WC, MI, NI, X3, X3>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(NT), lds, st, dY, X, acc, Co,
+                           Ci, HW, tiles, tiles_n, steps_total, steps_per_block);
+    else
     hipLaunchKernelGGL((k_wgrad1x1<WR, WC, MI, NI, X3>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(NT), lds, st, dY, X, acc, Co, Ci,
                        HW, tiles, tiles_n, steps_total, steps_per_block);
     AADG_LAUNCH_CHECK();
