@@ -79,37 +79,54 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void k_conv3x3_nchw(const uint16_t
     const uint16_t* inn = reinterpret_cast<const uint16_t*>(IN_) + (X3 ? 0 : (size_t)n * K * HW);
     const float* innf = reinterpret_cast<const float*>(IN_) + (X3 ? (size_t)n * K * HW : 0);
 
+    // Per-thread staging descriptors, computed ONCE: which chunk of the weight slab / of the IN tile this thread moves in every K-step,
+    // where it comes from (element offset at k0 = 0; -1: always zero -- beyond the tile, or a row above / below the image) and where it
+    // goes in LDS.  Inside the K loop only `k0` is added: the divisions by SR * CPR (48, 96, ...) and the image-border tests were a
+    // third of the kernel's VALU instructions when they were redone per K-step (SQ_INSTS_VALU 378 per wave and K-step for 108 MFMAs).
+    int a_src[LA], a_dst[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int id = tid + 256 * i;
+        const int t = id / (BM * 2), r = id - t * (BM * 2), m = m0 + (r >> 1);
+        a_src[i] = (id < NA && m < M) ? (t * M + m) * K + (r & 1) * 8 : -1;               // (9 M K < 2^31: checked by the launcher)
+        a_dst[i] = (id >> 1) * C3_APITCH + (id & 1) * 8;
+    }
+    int b_src[LB], b_dst[LB], b_cc[LB];
+    bool b_first[LB], b_last[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int id = tid + 256 * i;
+        const int cc = id / (SR * CPR), r2 = id - cc * (SR * CPR), rr = r2 / CPR, ch = r2 - rr * CPR, yy = y0 - D + rr;
+        b_cc[i] = id < NB ? cc : C3_BK;                                                   // C3_BK: never below K - k0
+        b_src[i] = (id < NB && yy >= 0 && yy < H) ? (cc * H + yy) * W + ch * 8 : -1;      // (16 H W < 2^31)
+        b_dst[i] = cc * BP + r2 * 8;
+        b_first[i] = ch == 0;
+        b_last[i] = ch == CPR - 1;
+    }
     uint4 ra[PL][LA], rb[PL][LB];          // X3: rb[0] / rb[1] = pixels 0..3 / 4..7 of the chunk as float32
     auto fetch = [&](int k0) {
+        const int krem = K - k0;                                  // channels left: a chunk of channel cc is live iff cc < krem
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            const int id = tid + 256 * i;
 #pragma unroll
             for (int pl = 0; pl < PL; ++pl) ra[pl][i] = make_uint4(0, 0, 0, 0);
-            if (id < NA) {
-                const int t = id / (BM * 2), r = id - t * (BM * 2), m = m0 + (r >> 1), k = k0 + (r & 1) * 8;
-                if (m < M && k < K) {
-                    ra[0][i] = *reinterpret_cast<const uint4*>(A9 + ((size_t)t * M + m) * K + k);
-                    if (X3) ra[PL - 1][i] = *reinterpret_cast<const uint4*>(A9_lo + ((size_t)t * M + m) * K + k);
-                }
+            if (a_src[i] >= 0 && ((tid + 256 * i) & 1) * 8 < krem) {
+                ra[0][i] = *reinterpret_cast<const uint4*>(A9 + a_src[i] + k0);
+                if (X3) ra[PL - 1][i] = *reinterpret_cast<const uint4*>(A9_lo + a_src[i] + k0);
             }
         }
+        const size_t koff = (size_t)k0 * HW;
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
-            const int id = tid + 256 * i;
 #pragma unroll
             for (int pl = 0; pl < PL; ++pl) rb[pl][i] = make_uint4(0, 0, 0, 0);
-            if (id < NB) {
-                const int cc = id / (SR * CPR), r2 = id - cc * (SR * CPR), rr = r2 / CPR, ch = r2 - rr * CPR;
-                const int k = k0 + cc, yy = y0 - D + rr;
-                if (k < K && yy >= 0 && yy < H) {
-                    if (X3) {
-                        const float* src = innf + ((size_t)k * H + yy) * W + ch * 8;
-                        rb[0][i] = *reinterpret_cast<const uint4*>(src);
-                        rb[PL - 1][i] = *reinterpret_cast<const uint4*>(src + 4);
-                    } else {
-                        rb[0][i] = *reinterpret_cast<const uint4*>(inn + ((size_t)k * H + yy) * W + ch * 8);
-                    }
+            if (b_src[i] >= 0 && b_cc[i] < krem) {
+                if (X3) {
+                    const float* src = innf + koff + b_src[i];
+                    rb[0][i] = *reinterpret_cast<const uint4*>(src);
+                    rb[PL - 1][i] = *reinterpret_cast<const uint4*>(src + 4);
+                } else {
+                    rb[0][i] = *reinterpret_cast<const uint4*>(inn + koff + b_src[i]);
                 }
             }
         }
@@ -133,10 +150,9 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void k_conv3x3_nchw(const uint16_t
         __syncthreads();                                  // the previous step's fragment reads are done
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            const int id = tid + 256 * i;
-            if (id < NA) {
+            if (tid + 256 * i < NA) {
 #pragma unroll
-                for (int pl = 0; pl < PL; ++pl) *reinterpret_cast<uint4*>(As + pl * C::A_EL + (id >> 1) * C3_APITCH + (id & 1) * 8) = ra[pl][i];
+                for (int pl = 0; pl < PL; ++pl) *reinterpret_cast<uint4*>(As + pl * C::A_EL + a_dst[i]) = ra[pl][i];
             }
         }
 #pragma unroll
@@ -159,10 +175,9 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void k_conv3x3_nchw(const uint16_t
                 const uint4 v = vv[pl];
                 uint32_t left = __shfl_up(v.w, 1, 64), right = __shfl_down(v.x, 1, 64);
                 if (id < NB) {
-                    const int cc = id / (SR * CPR), r2 = id - cc * (SR * CPR), ch = r2 % CPR;
-                    if (ch == 0) left = 0u;                    // the padding columns
-                    if (ch == CPR - 1) right = 0u;
-                    uint16_t* dst = Bs + pl * C::B_EL + cc * BP + r2 * 8;
+                    if (b_first[i]) left = 0u;                 // the padding columns
+                    if (b_last[i]) right = 0u;
+                    uint16_t* dst = Bs + pl * C::B_EL + b_dst[i];
                     uint4 vm, vp;                              // vm[p] = IN[p - D], vp[p] = IN[p + D]
                     if (D == 1) {
                         const uint32_t s1 = __builtin_amdgcn_alignbit(v.y, v.x, 16), s2 = __builtin_amdgcn_alignbit(v.z, v.y, 16),
@@ -181,51 +196,80 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void k_conv3x3_nchw(const uint16_t
         }
         __syncthreads();
         if (k0 + C3_BK < K) fetch(k0 + C3_BK);            // in flight during the MFMAs below
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            bf16x8 a[PL][3][MI];
+        // fragments of one tap row: 3 x (MI weight fragments + NI transpose-read pairs) per plane
+        struct Frags {
+            uint4 a[PL][3][MI];
             u32x2 lo[PL][3][NI], hi[PL][3][NI];
+        };
+        auto read_row = [&](int kh, Frags& f) {
 #pragma unroll
             for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
-                        a[pl][kw][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a_base + pl * C::A_EL +
-                                                                                                  ((kh * 3 + kw) * BM + 32 * mi) * C3_APITCH));
+                        f.a[pl][kw][mi] = *reinterpret_cast<const uint4*>(a_base + pl * C::A_EL + ((kh * 3 + kw) * BM + 32 * mi) * C3_APITCH);
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
                         const uint16_t* p = b_base + pl * C::B_EL + kw * C3_BK * BP + kh * D * W + 32 * ni;
-                        lo[pl][kw][ni] = lds_tr16(p);
-                        hi[pl][kw][ni] = lds_tr16(p + 4 * BP);
+                        f.lo[pl][kw][ni] = lds_tr16(p);
+                        f.hi[pl][kw][ni] = lds_tr16(p + 4 * BP);
                     }
                 }
-            // the transpose reads are opaque to the compiler's wait-count bookkeeping; tying their results to the wait keeps the
-            // scheduler from moving an MFMA that uses them above it (it did: the second pixel tile of every wave came out wrong)
+        };
+        // the transpose reads are opaque to the compiler's wait-count bookkeeping; tying their results to the wait keeps the
+        // scheduler from moving an MFMA that uses them above it (it did: the second pixel tile of every wave came out wrong)
+        auto settle = [&](Frags& f) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(lo[pl][kw][ni]), "+v"(hi[pl][kw][ni]));
+                    for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(f.lo[pl][kw][ni]), "+v"(f.hi[pl][kw][ni]));
+        };
+        auto mfma_row = [&](const Frags& f) {
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    const bf16x8 b = __builtin_bit_cast(bf16x8, make_uint4(lo[0][kw][ni].x, lo[0][kw][ni].y, hi[0][kw][ni].x, hi[0][kw][ni].y));
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, make_uint4(f.lo[0][kw][ni].x, f.lo[0][kw][ni].y, f.hi[0][kw][ni].x, f.hi[0][kw][ni].y));
                     if (X3) {
-                        const bf16x8 bl = __builtin_bit_cast(bf16x8, make_uint4(lo[PL - 1][kw][ni].x, lo[PL - 1][kw][ni].y, hi[PL - 1][kw][ni].x,
-                                                                                hi[PL - 1][kw][ni].y));
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, make_uint4(f.lo[PL - 1][kw][ni].x, f.lo[PL - 1][kw][ni].y, f.hi[PL - 1][kw][ni].x,
+                                                                                f.hi[PL - 1][kw][ni].y));
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi) {
-                            d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PL - 1][kw][mi], b, d[mi][ni], 0, 0, 0);
-                            d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][kw][mi], bl, d[mi][ni], 0, 0, 0);
+                            d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[PL - 1][kw][mi]), b, d[mi][ni], 0, 0, 0);
+                            d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[0][kw][mi]), bl, d[mi][ni], 0, 0, 0);
                         }
                     }
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][kw][mi], b, d[mi][ni], 0, 0, 0);
+                    for (int mi = 0; mi < MI; ++mi)
+                        d[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[0][kw][mi]), b, d[mi][ni], 0, 0, 0);
                 }
+        };
+        if (X3) {
+            // one wave per SIMD (both planes fill the LDS): nothing else covers the fragment reads' latency (36 b128 + 72 transpose reads
+            // per tap row through one LDS pipe shared by the four waves), so the reads of tap row kh + 1 are issued before the 36 MFMAs
+            // of row kh -- a second register set, free at this occupancy
+            Frags f0, f1;
+            read_row(0, f0);
+            settle(f0);
+            read_row(1, f1);
+            mfma_row(f0);
+            settle(f1);
+            read_row(2, f0);
+            mfma_row(f1);
+            settle(f0);
+            mfma_row(f0);
+        } else {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                Frags f;
+                read_row(kh, f);
+                settle(f);
+                mfma_row(f);
+            }
         }
     }
     // C/D layout: column (pixel) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); lanes p / p + 1 trade
@@ -273,6 +317,7 @@ int launch(const uint16_t* A9, const uint16_t* A9_lo, const void* IN, void* OUT,
     const long long pts = (long long)N * tiles_r, groups = (pts + 7) / 8;
     const long long wgs = groups * 8 * tiles_m;
     if (wgs > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
+    if ((long long)9 * M * K > 0x7FFFFFFFLL || (long long)C3_BK * H * W > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;    // 32-bit staging offsets
     static bool attr_set = false;                            // per instantiation; idempotent
     if (!attr_set) {
         AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_nchw<W, D, MI, X3>), hipFuncAttributeMaxDynamicSharedMemorySize,

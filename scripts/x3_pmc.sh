@@ -13,4 +13,4 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
   rocprofv3 --pmc $set -d /tmp/pmc_x3_$i -- python $R/scripts/x3_one_layer.py "$@" > /dev/null 2> $O/err_$i.txt
   python $R/scripts/pmc_by_kernel.py /tmp/pmc_x3_$i "k_" > $O/set$i.txt
 done
-cat $O/set*.txt
+grep -h "k_conv\|k_wgrad" $O/set*.txt
