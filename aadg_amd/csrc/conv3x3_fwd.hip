@@ -375,10 +375,18 @@ extern "C" int aadg_conv3x3_nchw_bf16(const void* a9, const void* in, void* out,
 
 /* The same convolution at float32 precision ("f32x3"): in / out float32 NCHW; a9_hi / a9_lo = the bfloat16 (hi, lo) halves of the float32
  * tap-major weights [9, M, K] (aadg_weight_layouts_split_bf16); hi*hi + hi*lo + lo*hi on the matrix cores, float32 accumulation */
+bool aadg_conv3x3_x3q_takes(int M, int K, int H, int W, int dilation);
+int aadg_conv3x3_x3q(const uint16_t* a9_hi, const uint16_t* a9_lo, const float* in, float* out, int N, int M, int K, int H, int W, int dilation,
+                     hipStream_t st);
 extern "C" int aadg_conv3x3_nchw_f32x3(const void* a9_hi, const void* a9_lo, const float* in, float* out, int N, int M, int K, int H, int W,
                                        int dilation, void* stream) {
     if (a9_hi == nullptr || a9_lo == nullptr || in == nullptr || out == nullptr || N <= 0) return AADG_E_BADARG;
     if ((((uintptr_t)a9_hi | (uintptr_t)a9_lo | (uintptr_t)in | (uintptr_t)out) & 15u) != 0) return AADG_E_BADARG;
     if (!aadg_conv3x3_nchw_supported(M, K, H, W, dilation)) return AADG_E_UNSUPPORTED;
+#ifndef AADG_NO_X3Q
+    // whole-tile shapes (every such layer of the backbone): the [pixel][k] kernel of conv3x3_x3.hip, two workgroups per CU
+    if (aadg_conv3x3_x3q_takes(M, K, H, W, dilation))
+        return aadg_conv3x3_x3q((const uint16_t*)a9_hi, (const uint16_t*)a9_lo, in, out, N, M, K, H, W, dilation, (hipStream_t)stream);
+#endif
     return conv3x3_dispatch<true>((const uint16_t*)a9_hi, (const uint16_t*)a9_lo, in, out, N, M, K, H, W, dilation, (hipStream_t)stream);
 }

@@ -53,6 +53,9 @@ def test_conv1x1_x3_wgrad(hip, N, Co, Ci, H, W):
 @pytest.mark.parametrize("N,K,M,H,W,d", [
     (2, 64, 64, 32, 32, 1), (2, 64, 128, 32, 32, 2), (1, 128, 64, 64, 64, 1), (1, 64, 64, 48, 128, 1), (1, 64, 64, 20, 64, 2),
     (2, 24, 72, 7, 32, 1),                                  # K below one K-step, M not a multiple of the tile, a partial row tile
+    # whole 64 x 16 channel tiles take k_conv3x3_x3q (csrc/conv3x3_x3.hip): partial row tiles, pixel tiles not a multiple of the 8 XCDs,
+    # the backbone's largest layer; K % 16 != 0 stays on k_conv3x3_nchw<.., true>
+    (9, 64, 64, 13, 32, 1), (1, 80, 128, 7, 64, 2), (3, 32, 192, 5, 128, 1), (2, 72, 64, 16, 32, 1), (1, 512, 512, 32, 32, 2),
 ])
 def test_conv3x3_x3_forward_and_input_gradient(hip, N, K, M, H, W, d):
     torch.manual_seed(K + M + d)
