@@ -49,6 +49,7 @@ struct CtrlParams {                // torch parameter order of the module
     float* bmag;  // [NMAGS]
 };
 struct CtrlPtrs9 { float* p[9]; };
+constexpr int PPO_MAX_STAMPS = 400;
 
 // workspace layout (floats)
 struct CtrlWs {
@@ -59,6 +60,7 @@ struct CtrlWs {
     // k_ctrl_ppo (one launch for all PPO epochs):
     size_t lpq;                    // [M * Q] 64-bit words {epoch tag, sum log-prob of the sequence} (zero between launches)
     size_t sync;                   // 2 ints: the grid barrier's arrival counter, the exit counter (zero between launches)
+    size_t stamps;                 // phase time stamps of workgroup 0 (PPO_STAMP): 64-bit count, then (wall_clock64, id) pairs
     size_t total;
 };
 __host__ __device__ inline int ctrl_n_params(const CtrlDims& d) {
@@ -82,6 +84,7 @@ __host__ __device__ inline CtrlWs ctrl_ws(const CtrlDims& d) {
     o = (o + 3) / 4 * 4;
     w.lpq = o; o += (size_t)(2 * d.M * d.Q + 3) / 4 * 4;
     w.sync = o; o += 4;
+    w.stamps = o; o += 2 * (1 + 2 * PPO_MAX_STAMPS);
     w.total = o;
     return w;
 }
@@ -796,30 +799,6 @@ __global__ __launch_bounds__(256) void k_ctrl_adam(CtrlParams P, CtrlPtrs9 exp_a
 constexpr int PPO_MAX_S = 8;
 constexpr int PPO_MAX_UPD = 16;
 struct PpoSched { float bc1[PPO_MAX_UPD], bc2_sqrt[PPO_MAX_UPD]; };
-// gradient + Adam phase: gate rows per pass, thread ranges of the four roles, 16-byte vectors / words staged per thread
-constexpr int PPO_JP = 14;
-constexpr int PPO_T_WIH = 352, PPO_T_HEAD = 464, PPO_T_EMB = 496;
-constexpr int PPO_GA_HS = 8, PPO_GA_XI = 2, PPO_GA_DG = 4;
-struct PpoGaLds { size_t HS, XI, DXg, DGs, DLs, TOK, total; };
-__host__ __device__ inline PpoGaLds ppo_ga_lds(const CtrlDims& d) {
-    PpoGaLds l;
-    const size_t R = (size_t)d.M * d.Q * d.S, RS = (size_t)d.M * d.Q * (d.S + 1);
-    size_t o = 0;
-    l.HS = o; o += RS * d.H;              // hidden states of every sequence [M Q][S + 1][H]
-    l.XI = o; o += R * d.E;               // step inputs
-    l.DXg = o; o += R * d.E;              // d step inputs
-    l.DGs = o; o += R * 16;               // the pass's columns of d gates (pitch 16)
-    l.DLs = o; o += (R + 3) / 4 * 4;      // the pass's column of d logits
-    l.TOK = o; o += (R + 3) / 4 * 4;      // input tokens
-    l.total = o;
-    return l;
-}
-// the staging registers of the gradient phase cover these many rows
-inline bool ppo_ga_fits(const CtrlDims& d) {
-    const int R = d.M * d.Q * d.S, RS = d.M * d.Q * (d.S + 1);
-    return RS * (d.H / 4) <= PPO_GA_HS * CT_THREADS && R * (d.E / 4) <= PPO_GA_XI * CT_THREADS && R * 16 <= PPO_GA_DG * CT_THREADS && R <= CT_THREADS;
-}
-
 constexpr int PPO_WIP = 4;             // padding of the LDS copy of W_ih (row pitch E + 4 floats)
 struct PpoLds { size_t G, Cs, TC, Hs, X, P, TL, DL, DG, DX, partx, part, Wi, act, tok, misc, Wh, Bh, Emb, total; };
 __host__ __device__ inline PpoLds ppo_lds(const CtrlDims& d) {
@@ -850,19 +829,82 @@ __host__ __device__ inline PpoLds ppo_lds(const CtrlDims& d) {
     return l;
 }
 
-// arrive at a counter and wait until `target` arrivals (device scope): every thread's earlier writes are visible to every
-// thread of the workgroups that leave the barrier
-// (one thread fences for the workgroup: the workgroup barriers on either side order the other threads' accesses with its
-// device-scope release / acquire; a fence per wave -- 880 L2 write-backs per barrier -- cost ~40 us per barrier)
+// gradient + Adam phase: gate rows per pass, thread ranges of the four roles, 16-byte vectors / words staged per thread
+constexpr int PPO_JP = 14;
+constexpr int PPO_T_WIH = 352, PPO_T_HEAD = 464, PPO_T_EMB = 496;
+constexpr int PPO_GA_HS = 8, PPO_GA_XI = 2, PPO_GA_DG = 4;
+struct PpoGaLds { size_t HS, XI, DXg, DGs, DLs, TOK, PT, total; };
+__host__ __device__ inline PpoGaLds ppo_ga_lds(const CtrlDims& d) {
+    PpoGaLds l;
+    const size_t R = (size_t)d.M * d.Q * d.S, RS = (size_t)d.M * d.Q * (d.S + 1);
+    size_t o = 0;
+    l.HS = o; o += RS * d.H;              // hidden states of every sequence [M Q][S + 1][H]
+    l.XI = o; o += R * d.E;               // step inputs
+    l.DXg = o; o += R * d.E;              // d step inputs
+    l.DGs = o; o += R * 16;               // the pass's columns of d gates (pitch 16)
+    l.DLs = o; o += (R + 3) / 4 * 4;      // the pass's column of d logits
+    l.TOK = o; o += (R + 3) / 4 * 4;      // input tokens
+    {                                     // 27 pointers (parameters, exp_avg, exp_avg_sq) behind BOTH layouts: written once per launch
+        CtrlDims dd = d;
+        const size_t ra = ppo_lds(dd).total;
+        o = (o > ra ? o : ra);
+        o = (o + 3) / 4 * 4;
+    }
+    l.PT = o; o += 2 * 28;
+    l.total = o;
+    return l;
+}
+// the staging registers of the gradient phase cover these many rows
+inline bool ppo_ga_fits(const CtrlDims& d) {
+    const int R = d.M * d.Q * d.S, RS = d.M * d.Q * (d.S + 1);
+    return RS * (d.H / 4) <= PPO_GA_HS * CT_THREADS && R * (d.E / 4) <= PPO_GA_XI * CT_THREADS && R * 16 <= PPO_GA_DG * CT_THREADS && R <= CT_THREADS;
+}
+
+
+// ---- data that crosses workgroups inside the launch (the parameters, the sequences' factors) ------------------------------
+// Device-scope acquire / release FENCES are cache maintenance on this part (the L2 of every XCD is written back / invalidated:
+// measured ~8 us until the first load behind a fence returns, 2 x 8 us per epoch).  Instead every access to shared data is a relaxed
+// device-scope atomic (global_load / global_store ... sc1: served at the coherence point of the device, the rest of the L2 stays
+// valid), and a barrier is: __syncthreads() (which waits for vmcnt(0): every store of the workgroup has been acknowledged) ->
+// one relaxed atomic add -> poll -> __syncthreads().  What is read behind the barrier is read with sc1 loads only.
+__device__ __forceinline__ float4 ld_coh4(const float* p) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<float*>(p));
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
+}
+__device__ __forceinline__ void st_coh4(float* p, float4 v) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+    __hip_atomic_store(q, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_coh1(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned*>(const_cast<float*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_coh1(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// arrive at a counter and wait until `target` arrivals
 __device__ __forceinline__ void ppo_arrive_wait(int* cnt, int target) {
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     __syncthreads();
 }
+
+// Phase time stamps of workgroup 0 (thread 0): always recorded -- a scalar clock read and one 16-byte store per stamp -- so that what is
+// timed IS the shipped kernel (an instrumented copy allocates registers differently: its forward loop spilled, the shipped one does
+// not).  Read back by scripts/ubench/ctrl_phase_times.py through aadg_controller_debug_stamps.  The running count lives in LDS.
+#define PPO_STAMP(id)                                                                                                     \
+    do {                                                                                                                  \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                                                        \
+            int* n_ = reinterpret_cast<int*>(L + ppo_ga_lds(d).PT + 55);                                                  \
+            unsigned long long* sb_ = reinterpret_cast<unsigned long long*>(ws + ctrl_ws(d).stamps);                      \
+            if (*n_ < PPO_MAX_STAMPS) { sb_[1 + 2 * *n_] = wall_clock64(); sb_[2 + 2 * *n_] = (id); *n_ += 1; sb_[0] = *n_; }  \
+        }                                                                                                                 \
+    } while (0)
 
 template <int CTRL>
 __device__ __forceinline__ float quad_lane(float v) {          // lane CTRL of the caller's quad
@@ -882,376 +924,29 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// The gradient + Adam phase of k_ctrl_ppo as a function of its own (inlined, it made the register allocator spill the
+// recurrence's weight slices inside the forward loop; the 27 parameter / moment pointers reach it through an LDS table so that
+// the call passes scalars only).
+// Workgroup w owns the gate rows [w JW, (w + 1) JW) of W_ih / W_hh / both biases and the head / embedding rows
+// [w AW, (w + 1) AW): it stages every sequence's hidden states, inputs and d inputs in LDS once (one batch of loads), per
+// pass its <= 14 columns of d gates and one column of d logits, sums over the rows r in ascending order (the order of
+// k_ctrl_adam) and applies torch.optim.Adam's update to its parameters.
 template <int EC, int HC>
-__global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9 exp_avg, CtrlPtrs9 exp_avg_sq, CtrlDims d, float* ws,
-                                                         const long long* __restrict__ policies, const float* __restrict__ old_log_probs,
-                                                         const float* __restrict__ reward, float clip, int n_updates, PpoSched sched,
-                                                         float lr, float beta1, float beta2, float eps, float* __restrict__ loss_terms) {
-    static_assert(EC % 16 == 0 && HC % 4 == 0 && 4 * HC <= CT_THREADS && CT_HP * HC <= CT_THREADS && 3 * CT_HP * EC <= CT_THREADS &&
-                  (4 * HC) % CT_HP == 0 && (4 * HC / CT_HP) % 4 == 0, "widths must fit the lane <-> weight-slice mappings");
-    extern __shared__ __attribute__((aligned(16))) float L[];
-    const CtrlWs W = ctrl_ws(d);
-    const PpoLds O = ppo_lds(d);
-    const PpoGaLds Og = ppo_ga_lds(d);
-    const int w = blockIdx.x, NW = gridDim.x;
-    const int Q = d.Q, S = d.S, nseq = d.M * d.Q;
+__device__ __noinline__ void ppo_gradients_adam(int M, int Q, int S, int NOPS, int NMAGS, float* ws, float* L, int w, int tid,
+                                                float bc1, float bc2s, float lr, float beta1, float beta2, float eps) {
     constexpr int H4 = 4 * HC, A = CT_MAX_A;
-    const int NT = d.NOPS + d.NMAGS;
-    const int m = w / Q;
-    float* G = L + O.G; float* Cs = L + O.Cs; float* TC = L + O.TC; float* Hs = L + O.Hs; float* X = L + O.X;
-    float* Pp = L + O.P; float* TL = L + O.TL; float* DL = L + O.DL; float* DG = L + O.DG; float* DX = L + O.DX;
-    float* partx = L + O.partx; float* part = L + O.part; float* Wi = L + O.Wi; int* act = reinterpret_cast<int*>(L + O.act);
-    int* tok = reinterpret_cast<int*>(L + O.tok); float* misc = L + O.misc;
-    float* Wh = L + O.Wh; float* Bh = L + O.Bh; float* Emb = L + O.Emb;
-    int* sync = reinterpret_cast<int*>(ws + W.sync);
-    int* cnt_grid = sync;
-    int* cnt_exit = sync + 1;
-    unsigned long long* lpq = reinterpret_cast<unsigned long long*>(ws + W.lpq);
-    // parameter offsets inside a gseq row = inside the concatenation of the module's 9 parameters
-    const int o_wih = NT * EC, o_whh = o_wih + H4 * EC, o_bih = o_whh + H4 * HC, o_bhh = o_bih + H4, o_wop = o_bhh + H4,
-              o_bop = o_wop + d.NOPS * HC, o_wmag = o_bop + d.NOPS, o_bmag = o_wmag + d.NMAGS * HC;
-
-    constexpr int XSL = EC / 4, HSL = (HC / 16) * 4, HL = HC - 3 * HSL;
-    static_assert(HL % 4 == 0 && HL >= HSL && HL - HSL <= HSL, "k-slices must be multiples of 4");
-    constexpr int JS = 4 * HC / (4 * CT_HP);
-    constexpr int XT = CT_HP * EC;                                               // dx lanes per step group
-
-    for (int it = 0; it < n_updates; ++it) {
-        // the thread index is made opaque per epoch: everything below derives from it, and the compiler otherwise hoists every
-        // lane address and predicate of the epoch's ~15 phases out of the loop and spills ~300 registers around the weight slices
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        {
-            const float* pw_ih = P.w_ih;
-            const float* pw_hh = P.w_hh;
-            const uint32_t otid = (uint32_t)tid;                    // 32-bit element offsets from the uniform bases
-            const uint32_t ogu = otid >> 2, osl = otid & 3u;
-            // lane <-> weight-slice mappings (those of k_ctrl_rollout's compile-time-width instantiation)
-            const int gu = tid >> 2, gsl = tid & 3;
-            const int hkg = (tid >> 2) % (HC / 4), hjg = (tid >> 2) / (HC / 4);          // dh lanes: tid < CT_HP * HC
-            const int xgrp = tid / XT, xl = tid - xgrp * XT;
-            const int xkg = (xl >> 2) % (EC / 4), xjg = (xl >> 2) / (EC / 4);
-            // ------------------------------------------------------------------------------------------ tables, weights
-            // every global load of the forward in ONE batch (after the epoch's acquire they all miss the caches: ~3 us per
-            // dependent round trip): head weights and embedding rows as one 16-byte vector per thread, then the weight slices
-            float4 r_op = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r_mag = r_op, r_emb = r_op;
-            float r_bop = 0.0f, r_bmag = 0.0f;
-            if (tid < d.NOPS * (HC / 4)) r_op = reinterpret_cast<const float4*>(P.wop)[tid];
-            if (tid < d.NMAGS * (HC / 4)) r_mag = reinterpret_cast<const float4*>(P.wmag)[tid];
-            if (tid < NT * (EC / 4)) r_emb = reinterpret_cast<const float4*>(P.emb)[tid];
-            if (tid < d.NOPS) r_bop = P.bop[tid];
-            if (tid < d.NMAGS) r_bmag = P.bmag[tid];
-            constexpr int WIV = H4 * EC / 4, WIN = (WIV + CT_THREADS - 1) / CT_THREADS;     // W_ih as 16-byte vectors
-            float4 r_wi[WIN];
-#pragma unroll
-            for (int i = 0; i < WIN; ++i) r_wi[i] = reinterpret_cast<const float4*>(pw_ih)[min(otid + (uint32_t)(i * CT_THREADS), (uint32_t)(WIV - 1))];
-            float wxr[4][XSL], whr[4][HL];
-            float bias = 0.0f;
-            if (tid < H4) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float* rx = pw_ih + ((uint32_t)(g * HC) + ogu) * (uint32_t)EC + (uint32_t)XSL * osl;
-                    const float* rh = pw_hh + ((uint32_t)(g * HC) + ogu) * (uint32_t)HC + (uint32_t)HSL * osl;
-#pragma unroll
-                    for (int i = 0; i < XSL; i += 4) {
-                        const float4 v = *reinterpret_cast<const float4*>(rx + i);
-                        wxr[g][i] = v.x; wxr[g][i + 1] = v.y; wxr[g][i + 2] = v.z; wxr[g][i + 3] = v.w;
-                    }
-#pragma unroll
-                    for (int i = 0; i < HL; i += 4) {
-                        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                        if (i < HSL || gsl == 3) v = *reinterpret_cast<const float4*>(rh + i);
-                        whr[g][i] = v.x; whr[g][i + 1] = v.y; whr[g][i + 2] = v.z; whr[g][i + 3] = v.w;
-                    }
-                }
-                bias = P.b_ih[gsl * HC + gu] + P.b_hh[gsl * HC + gu];
-            }
-            if (tid < S) {                                      // the sequence's actions and input tokens
-                const int a = (int)policies[(size_t)w * S + tid];
-                act[tid] = a;
-                if (tid + 1 < S) tok[tid + 1] = a + ((tid & 1) == 0 ? 0 : d.NOPS);
-                if (tid == 0) tok[0] = -1;
-            }
-            if (tid < d.NOPS * (HC / 4)) reinterpret_cast<float4*>(Wh)[tid] = r_op;
-            if (tid < d.NMAGS * (HC / 4)) reinterpret_cast<float4*>(Wh + d.NOPS * HC)[tid] = r_mag;
-            if (tid < NT * (EC / 4)) reinterpret_cast<float4*>(Emb)[tid] = r_emb;
-            if (tid < A) { Bh[tid] = r_bop; Bh[A + tid] = r_bmag; }
-#pragma unroll
-            for (int i = 0; i < WIN; ++i) {
-                const int v = tid + i * CT_THREADS;
-                if (v < WIV) *reinterpret_cast<float4*>(Wi + (v / (EC / 4)) * (EC + PPO_WIP) + 4 * (v % (EC / 4))) = r_wi[i];
-            }
-            for (int i = tid; i < HC; i += CT_THREADS) Hs[i] = 0.0f;
-            lds_barrier();                                      // Emb, act, tok
-            for (int i = tid; i < S * EC; i += CT_THREADS) {    // teacher forcing: every step's input is known
-                const int t = i / EC, k = i - t * EC;
-                X[i] = t > 0 ? Emb[(size_t)tok[t] * EC + k] : 0.0f;
-            }
-            lds_barrier();
-
-            // ------------------------------------------------------------------------------------------ forward recurrence
-            float c_prev = 0.0f;
-            for (int t = 0; t < S; ++t) {
-                if (tid < H4) {
-                    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                    if (t > 0) {
-#pragma unroll
-                        for (int i = 0; i < XSL; i += 4) {
-                            const float4 a = *reinterpret_cast<const float4*>(X + t * EC + XSL * gsl + i);
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                acc[g] = fmaf(wxr[g][i], a.x, acc[g]); acc[g] = fmaf(wxr[g][i + 1], a.y, acc[g]);
-                                acc[g] = fmaf(wxr[g][i + 2], a.z, acc[g]); acc[g] = fmaf(wxr[g][i + 3], a.w, acc[g]);
-                            }
-                        }
-#pragma unroll
-                        for (int i = 0; i < HL; i += 4) {
-                            // slices 0..2 read 4 inputs of the next slice in their last round: weights zero there
-                            const float4 a = *reinterpret_cast<const float4*>(Hs + t * HC + HSL * gsl + i);
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                acc[g] = fmaf(whr[g][i], a.x, acc[g]); acc[g] = fmaf(whr[g][i + 1], a.y, acc[g]);
-                                acc[g] = fmaf(whr[g][i + 2], a.z, acc[g]); acc[g] = fmaf(whr[g][i + 3], a.w, acc[g]);
-                            }
-                        }
-                    }
-                    // sum of the four k-slices; lane sl activates gate sl, then the quad exchanges the four gates and every
-                    // lane carries the cell state of hidden unit gu
-                    float mine = 0.0f;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float v = quad_sum(acc[g]);
-                        mine = gsl == g ? v : mine;
-                    }
-                    mine += bias;
-                    const float av = gsl == 2 ? tanhf(mine) : sigmoidf_(mine);
-                    G[t * H4 + gsl * HC + gu] = av;
-                    const float ig = quad_lane<0>(av), fg = quad_lane<1>(av), gg = quad_lane<2>(av), og = quad_lane<3>(av);
-                    const float c = fg * c_prev + ig * gg;
-                    const float tc = tanhf(c);
-                    c_prev = c;
-                    if (gsl == 0) {
-                        Cs[t * HC + gu] = c;
-                        TC[t * HC + gu] = tc;
-                        Hs[(t + 1) * HC + gu] = og * tc;
-                    }
-                }
-                lds_barrier();
-            }
-            // the backward's weight slices: in flight while the heads run
-            float wbh[JS][4];
-            const uint32_t ohrow = (4u * ((otid >> 2) / (uint32_t)(HC / 4)) + osl) * (uint32_t)JS, ohcol = 4u * ((otid >> 2) % (uint32_t)(HC / 4));
-            if (tid < CT_HP * HC) {
-#pragma unroll
-                for (int i = 0; i < JS; ++i) {
-                    const float4 v = *reinterpret_cast<const float4*>(pw_hh + (ohrow + (uint32_t)i) * (uint32_t)HC + ohcol);
-                    wbh[i][0] = v.x; wbh[i][1] = v.y; wbh[i][2] = v.z; wbh[i][3] = v.w;
-                }
-            }
-            // ------------------------------------------------------------------------------------------ heads, all steps
-            {                                                   // 4 lanes per (step, action) logit
-                const int o = tid >> 2, prt = tid & 3;
-                const int t = o / A, a = o - t * A;
-                const bool op_step = (t & 1) == 0;
-                const bool live = t < S && a < (op_step ? d.NOPS : d.NMAGS);
-                float z = 0.0f;
-                if (live) {
-                    const float* wrow = Wh + (size_t)((op_step ? 0 : d.NOPS) + a) * HC;
-                    const float* h = Hs + (t + 1) * HC;
-#pragma unroll 5
-                    for (int k = prt; k < HC; k += 4) z = fmaf(wrow[k], h[k], z);
-                }
-                z += __shfl_xor(z, 1, 64); z += __shfl_xor(z, 2, 64);
-                if (live && prt == 0) {
-                    z += Bh[(op_step ? 0 : A) + a];
-                    const float tl = tanhf(z);
-                    TL[t * A + a] = tl;
-                    Pp[t * A + a] = d.cdiv * tl;
-                }
-            }
-            lds_barrier();
-            if (tid < S * A) {                                  // soft-max of every step: 16 lanes per step
-                const int t = tid / A, a = tid - t * A;
-                const int NA = (t & 1) == 0 ? d.NOPS : d.NMAGS;
-                const bool live = a < NA;
-                const float v = live ? Pp[t * A + a] : -INFINITY;
-                float mx = v;
-#pragma unroll
-                for (int o = A / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, A));
-                const float z = v - mx;
-                float sum = live ? expf(z) : 0.0f;
-#pragma unroll
-                for (int o = A / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, A);
-                const float lp = z - logf(sum);
-                if (live) Pp[t * A + a] = expf(lp);
-                const float lp_sel = __shfl(lp, act[t], A);
-                if (a == 0) misc[8 + t] = lp_sel;
-            }
-            lds_barrier();
-            // the policy's log-probability = sum over its Q sequences: every workgroup publishes {epoch tag, value} as ONE 64-bit word
-            // and the first Q lanes poll the policy's slots -- the payload travels inside the atomic, no fence, no counter
-            if (tid == 0) {
-                float s = 0.0f;
-                for (int t = 0; t < S; ++t) s += misc[8 + t];
-                const unsigned long long word = ((unsigned long long)(unsigned)(it + 1) << 32) | (unsigned long long)__float_as_uint(s);
-                __hip_atomic_store(lpq + w, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (tid < Q) {
-                unsigned long long word;
-                do {
-                    word = __hip_atomic_load(lpq + m * Q + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } while ((unsigned)(word >> 32) != (unsigned)(it + 1));
-                misc[8 + tid] = __uint_as_float((unsigned)word);
-            }
-            lds_barrier();
-            if (tid == 0) {
-                float lp = 0.0f;
-                for (int q = 0; q < Q; ++q) lp += misc[8 + q];
-                const float ratio = expf(lp - old_log_probs[m]);
-                const float clipped = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
-                const float r = reward[m];
-                const float a = ratio * r, b = clipped * r;
-                if (w == m * Q) loss_terms[(size_t)it * d.M + m] = -fminf(a, b);      // the caller averages over M
-                // d(-min(a, b))/d lp: through a when a <= b (ties: both halves reach `ratio` because clamp is then the identity)
-                const bool inside = ratio >= 1.0f - clip && ratio <= 1.0f + clip;
-                float g = 0.0f;
-                if (a < b || (a == b && inside)) g = -r * ratio;
-                else if (a == b && !inside) g = -0.5f * r * ratio;
-                misc[3] = g / (float)d.M;
-            }
-            lds_barrier();
-            const float gl = misc[3];
-
-            // ------------------------------------------------------------------------------------------ backward
-            if (tid < S * A) {                                  // d logits of every step
-                const int t = tid / A, a = tid - t * A;
-                const int NA = (t & 1) == 0 ? d.NOPS : d.NMAGS;
-                float dl = 0.0f;
-                if (a < NA) {
-                    const float p = Pp[t * A + a], tl = TL[t * A + a];
-                    const float dz = gl * ((a == act[t] ? 1.0f : 0.0f) - p);
-                    dl = dz * d.cdiv * (1.0f - tl * tl);
-                }
-                DL[t * A + a] = dl;
-            }
-            lds_barrier();
-            float dc_carry = 0.0f;                              // thread u < HC: d loss / d c_t carried to step t - 1
-            for (int t = S - 1; t >= 0; --t) {
-                const bool op_step = (t & 1) == 0;
-                const int NA = op_step ? d.NOPS : d.NMAGS;
-                if (tid < HC) {                                 // through the head and the cell
-                    const int u = tid;
-                    float dh = 0.0f;
-                    if (t < S - 1)
-                        for (int pr = 0; pr < CT_HP; ++pr) dh += part[pr * HC + u];
-                    const float* wh = Wh + (size_t)(op_step ? 0 : d.NOPS) * HC;
-                    for (int a = 0; a < NA; ++a) dh = fmaf(wh[(size_t)a * HC + u], DL[t * A + a], dh);
-                    const float* g4 = G + t * H4;
-                    const float ig = g4[u], fg = g4[HC + u], gg = g4[2 * HC + u], og = g4[3 * HC + u];
-                    const float tc = TC[t * HC + u];
-                    const float cp = t > 0 ? Cs[(t - 1) * HC + u] : 0.0f;
-                    const float d_o = dh * tc;
-                    const float dc = dh * og * (1.0f - tc * tc) + dc_carry;
-                    dc_carry = dc * fg;
-                    float* dg = DG + t * H4;
-                    dg[u] = dc * gg * ig * (1.0f - ig);
-                    dg[HC + u] = dc * cp * fg * (1.0f - fg);
-                    dg[2 * HC + u] = dc * ig * (1.0f - gg * gg);
-                    dg[3 * HC + u] = d_o * og * (1.0f - og);
-                }
-                lds_barrier();
-                if (t > 0) {
-                    // dh_{t-1} = W_hh^T dgates: lane (jg, kg, jl) owns columns 4 kg .. 4 kg + 3 x gate rows [(4 jg + jl) JS, + JS)
-                    if (tid < CT_HP * HC) {
-                        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                        for (int i = 0; i < JS; i += 4) {
-                            const float4 a = *reinterpret_cast<const float4*>(DG + t * H4 + (4 * hjg + gsl) * JS + i);
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                acc[c] = fmaf(wbh[i][c], a.x, acc[c]); acc[c] = fmaf(wbh[i + 1][c], a.y, acc[c]);
-                                acc[c] = fmaf(wbh[i + 2][c], a.z, acc[c]); acc[c] = fmaf(wbh[i + 3][c], a.w, acc[c]);
-                            }
-                        }
-                        float mine = 0.0f;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const float v = quad_sum(acc[c]);
-                            mine = gsl == c ? v : mine;
-                        }
-                        part[hjg * HC + 4 * hkg + gsl] = mine;
-                    }
-                    lds_barrier();
-                }
-            }
-            // dx_t = W_ih^T dgates of every step t >= 1 (gradient of the embedding row that fed the step): three steps at a time
-            if (tid < 3 * XT) {
-                for (int t = 1 + xgrp; t < S; t += 3) {
-                    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int i = 0; i < JS; i += 4) {
-                        const float4 a = *reinterpret_cast<const float4*>(DG + t * H4 + (4 * xjg + gsl) * JS + i);
-                        float wv[4][4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float4 v = *reinterpret_cast<const float4*>(Wi + ((4 * xjg + gsl) * JS + i + r) * (EC + PPO_WIP) + 4 * xkg);
-                            wv[r][0] = v.x; wv[r][1] = v.y; wv[r][2] = v.z; wv[r][3] = v.w;
-                        }
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            acc[c] = fmaf(wv[0][c], a.x, acc[c]); acc[c] = fmaf(wv[1][c], a.y, acc[c]);
-                            acc[c] = fmaf(wv[2][c], a.z, acc[c]); acc[c] = fmaf(wv[3][c], a.w, acc[c]);
-                        }
-                    }
-                    float mine = 0.0f;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float v = quad_sum(acc[c]);
-                        mine = gsl == c ? v : mine;
-                    }
-                    partx[(t * CT_HP + xjg) * EC + 4 * xkg + gsl] = mine;
-                }
-            }
-            lds_barrier();
-            for (int i = tid; i < S * EC; i += CT_THREADS) {
-                const int t = i / EC, k = i - t * EC;
-                float s = 0.0f;
-                if (t > 0)
-                    for (int pr = 0; pr < CT_HP; ++pr) s += partx[(t * CT_HP + pr) * EC + k];
-                DX[i] = s;
-            }
-            lds_barrier();
-
-            // ------------------------------------------------------------------------------------------ the sequence's factors
-            // rows r = w S + t of the scratch arrays: d gates, d logits, d inputs, inputs, tokens; hidden states as [w][S + 1][H]
-            // (slot t = h_{t-1}, slot t + 1 = h_t): 11 KB per sequence instead of its 225 KB of parameter gradients
-            {
-                const size_t r0 = (size_t)w * S;
-                float4* gdg = reinterpret_cast<float4*>(ws + W.dg + r0 * H4);
-                for (int i = tid; i < S * (H4 / 4); i += CT_THREADS) gdg[i] = reinterpret_cast<const float4*>(DG)[i];
-                float4* ghs = reinterpret_cast<float4*>(ws + W.hprev + (size_t)w * (S + 1) * HC);
-                for (int i = tid; i < (S + 1) * (HC / 4); i += CT_THREADS) ghs[i] = reinterpret_cast<const float4*>(Hs)[i];
-                if (tid < S * (EC / 4)) {
-                    reinterpret_cast<float4*>(ws + W.xin + r0 * EC)[tid] = reinterpret_cast<const float4*>(X)[tid];
-                    reinterpret_cast<float4*>(ws + W.dx + r0 * EC)[tid] = reinterpret_cast<const float4*>(DX)[tid];
-                }
-                if (tid < S * (A / 4)) reinterpret_cast<float4*>(ws + W.dl + r0 * A)[tid] = reinterpret_cast<const float4*>(DL)[tid];
-                if (tid < S) reinterpret_cast<int*>(ws + W.tok)[r0 + tid] = tok[tid];
-            }
-        }
-        // ---------------------------------------------------------------------------------------------- gradients + Adam, sliced
-        ppo_arrive_wait(cnt_grid, (2 * it + 1) * NW);
-        // Workgroup w owns the gate rows [w JW, (w + 1) JW) of W_ih / W_hh / both biases and the head / embedding rows
-        // [w AW, (w + 1) AW): it stages every sequence's hidden states, inputs and d inputs in LDS once (one batch of loads), per
-        // pass its <= 14 columns of d gates and one column of d logits, sums over the rows r in ascending order (the order of
-        // k_ctrl_adam) and applies torch.optim.Adam's update to its parameters.
-        {
+    const CtrlDims d = {M, Q, S, EC, HC, NOPS, NMAGS, 0.0f};
+    const CtrlWs W = ctrl_ws(d);
+    const PpoGaLds Og = ppo_ga_lds(d);
+    const int nseq = M * Q, NT = NOPS + NMAGS;
+    float* const* PT = reinterpret_cast<float* const*>(L + Og.PT);
+    {
             const int R = nseq * S, RS = nseq * (S + 1);
             float* HSg = L + Og.HS; float* XI = L + Og.XI; float* DXg = L + Og.DXg; float* DGs = L + Og.DGs; float* DLs = L + Og.DLs;
             int* TOK = reinterpret_cast<int*>(L + Og.TOK);
             const int JW = (H4 + nseq - 1) / nseq, AW = (NT + nseq - 1) / nseq;
             const int npass = max((JW + PPO_JP - 1) / PPO_JP, AW);
-            const float bc1 = sched.bc1[it], bc2s = sched.bc2_sqrt[it];
+            PPO_STAMP(15);
             // role of this thread (the same in every pass): 0 W_hh rows, 1 W_ih rows + biases, 2 head row + its bias, 3 embedding row
             const int role = tid < PPO_JP * (HC / 4) ? 0 : (tid >= PPO_T_WIH && tid < PPO_T_WIH + PPO_JP * (EC / 4)) ? 1 :
                              (tid >= PPO_T_HEAD && tid < PPO_T_HEAD + HC / 4 + 1) ? 2 : (tid >= PPO_T_EMB && tid < PPO_T_EMB + EC / 4) ? 3 : 4;
@@ -1269,29 +964,30 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
                 bool vec = true, live = false;
                 if (role == 0 && jj < jn) {
                     const size_t o = (size_t)(j0 + jj) * HC + 4 * k4;
-                    pp = P.w_hh + o; mp = exp_avg.p[2] + o; vp = exp_avg_sq.p[2] + o; live = true;
+                    pp = PT[2] + o; mp = PT[11] + o; vp = PT[20] + o; live = true;
                 } else if (role == 1 && jj < jn) {
                     const size_t o = (size_t)(j0 + jj) * EC + 4 * k4;
-                    pp = P.w_ih + o; mp = exp_avg.p[1] + o; vp = exp_avg_sq.p[1] + o; live = true;
+                    pp = PT[1] + o; mp = PT[10] + o; vp = PT[19] + o; live = true;
                 } else if (role == 2 && has_a) {
                     live = true;
                     if (k4 < HC / 4) {
                         const size_t o = (size_t)acol * HC + 4 * k4;
-                        pp = (apar ? P.wmag : P.wop) + o; mp = (apar ? exp_avg.p[7] : exp_avg.p[5]) + o; vp = (apar ? exp_avg_sq.p[7] : exp_avg_sq.p[5]) + o;
+                        const int wi = apar ? 7 : 5;
+                        pp = PT[wi] + o; mp = PT[9 + wi] + o; vp = PT[18 + wi] + o;
                     } else {
                         vec = false;
-                        pp = (apar ? P.bmag : P.bop) + acol; mp = (apar ? exp_avg.p[8] : exp_avg.p[6]) + acol; vp = (apar ? exp_avg_sq.p[8] : exp_avg_sq.p[6]) + acol;
+                        const int wi = apar ? 8 : 6;
+                        pp = PT[wi] + acol; mp = PT[9 + wi] + acol; vp = PT[18 + wi] + acol;
                     }
                 } else if (role == 3 && has_a) {
                     const size_t o = (size_t)arow * EC + 4 * k4;
-                    pp = P.emb + o; mp = exp_avg.p[0] + o; vp = exp_avg_sq.p[0] + o; live = true;
+                    pp = PT[0] + o; mp = PT[9] + o; vp = PT[18] + o; live = true;
                 }
                 // bias lanes of role 1: k4 == 0 -> b_ih[j], k4 == 1 -> b_hh[j]
                 const bool blane = role == 1 && jj < jn && k4 < 2;
                 float* bp = nullptr; float* bm = nullptr; float* bv = nullptr;
                 if (blane) {
-                    bp = (k4 == 0 ? P.b_ih : P.b_hh) + j0 + jj; bm = (k4 == 0 ? exp_avg.p[3] : exp_avg.p[4]) + j0 + jj;
-                    bv = (k4 == 0 ? exp_avg_sq.p[3] : exp_avg_sq.p[4]) + j0 + jj;
+                    bp = PT[3 + k4] + j0 + jj; bm = PT[12 + k4] + j0 + jj; bv = PT[21 + k4] + j0 + jj;
                 }
                 // ---- ONE batch of loads: (first pass) every sequence's hidden states / inputs / d inputs / tokens; the pass's columns of
                 // d gates and d logits; the parameters and moments this thread will update
@@ -1303,28 +999,31 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
                     const float4* gxi = reinterpret_cast<const float4*>(ws + W.xin);
                     const float4* gdx = reinterpret_cast<const float4*>(ws + W.dx);
 #pragma unroll
-                    for (int i = 0; i < PPO_GA_HS; ++i) rh[i] = ghs[min(tid + i * CT_THREADS, nhs - 1)];
+                    for (int i = 0; i < PPO_GA_HS; ++i) rh[i] = ld_coh4(reinterpret_cast<const float*>(ghs + min(tid + i * CT_THREADS, nhs - 1)));
 #pragma unroll
-                    for (int i = 0; i < PPO_GA_XI; ++i) { rx[i] = gxi[min(tid + i * CT_THREADS, nxi - 1)]; rd[i] = gdx[min(tid + i * CT_THREADS, nxi - 1)]; }
-                    tk = reinterpret_cast<const int*>(ws + W.tok)[min(tid, R - 1)];
+                    for (int i = 0; i < PPO_GA_XI; ++i) {
+                        rx[i] = ld_coh4(reinterpret_cast<const float*>(gxi + min(tid + i * CT_THREADS, nxi - 1)));
+                        rd[i] = ld_coh4(reinterpret_cast<const float*>(gdx + min(tid + i * CT_THREADS, nxi - 1)));
+                    }
+                    tk = __float_as_int(ld_coh1(ws + W.tok + min(tid, R - 1)));
                 }
                 float rg[PPO_GA_DG];
 #pragma unroll
                 for (int i = 0; i < PPO_GA_DG; ++i) {
                     const int e = tid + i * CT_THREADS, r = min(e >> 4, R - 1), cj = e & 15;
-                    rg[i] = ws[W.dg + (size_t)r * H4 + min(j0 + cj, H4 - 1)];
+                    rg[i] = ld_coh1(ws + W.dg + (size_t)r * H4 + min(j0 + cj, H4 - 1));
                 }
-                const float rl = ws[W.dl + (size_t)min(tid, R - 1) * A + (has_a ? acol : 0)];
+                const float rl = ld_coh1(ws + W.dl + (size_t)min(tid, R - 1) * A + (has_a ? acol : 0));
                 float pv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, mv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, vv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 float bpv = 0.0f, bmv = 0.0f, bvv = 0.0f;
                 if (live && vec) {
-                    const float4 p0 = *reinterpret_cast<const float4*>(pp), m0 = *reinterpret_cast<const float4*>(mp), v0 = *reinterpret_cast<const float4*>(vp);
+                    const float4 p0 = ld_coh4(pp), m0 = *reinterpret_cast<const float4*>(mp), v0 = *reinterpret_cast<const float4*>(vp);
                     pv[0] = p0.x; pv[1] = p0.y; pv[2] = p0.z; pv[3] = p0.w; mv[0] = m0.x; mv[1] = m0.y; mv[2] = m0.z; mv[3] = m0.w;
                     vv[0] = v0.x; vv[1] = v0.y; vv[2] = v0.z; vv[3] = v0.w;
                 } else if (live) {
-                    pv[0] = *pp; mv[0] = *mp; vv[0] = *vp;
+                    pv[0] = ld_coh1(pp); mv[0] = *mp; vv[0] = *vp;
                 }
-                if (blane) { bpv = *bp; bmv = *bm; bvv = *bv; }
+                if (blane) { bpv = ld_coh1(bp); bmv = *bm; bvv = *bv; }
                 if (ps == 0) {
 #pragma unroll
                     for (int i = 0; i < PPO_GA_HS; ++i)
@@ -1345,7 +1044,9 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
                     if (e < R * 16) DGs[e] = rg[i];
                 }
                 if (tid < R) DLs[tid] = rl;
+                PPO_STAMP(16);                                                  // thread 0's loads have arrived
                 lds_barrier();
+                PPO_STAMP(17);
                 // ---- the sums over the rows r = (sequence, step), ascending; UR rows' operands in flight at a time
                 constexpr int UR = 8;
                 float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1406,6 +1107,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
                         }
                     }
                 }
+                PPO_STAMP(18);
                 // ---- torch.optim.Adam (no weight decay, no amsgrad): m, v EMAs (lerp, as torch does), step = lr / bc1,
                 // denom = sqrt(v) / sqrt(bc2) + eps
                 if (live) {
@@ -1421,25 +1123,408 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
                     if (vec) {
                         *reinterpret_cast<float4*>(mp) = make_float4(mn[0], mn[1], mn[2], mn[3]);
                         *reinterpret_cast<float4*>(vp) = make_float4(vn[0], vn[1], vn[2], vn[3]);
-                        *reinterpret_cast<float4*>(pp) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+                        st_coh4(pp, make_float4(pn[0], pn[1], pn[2], pn[3]));
                     } else {
-                        *mp = mn[0]; *vp = vn[0]; *pp = pn[0];
+                        *mp = mn[0]; *vp = vn[0]; st_coh1(pp, pn[0]);
                     }
                 }
                 if (blane) {
                     const float mnew = bmv + (bsum - bmv) * (1.0f - beta1);
                     const float vnew = beta2 * bvv + (1.0f - beta2) * bsum * bsum;
                     *bm = mnew; *bv = vnew;
-                    *bp = bpv - (lr / bc1) * (mnew / (sqrtf(vnew) / bc2s + eps));
+                    st_coh1(bp, bpv - (lr / bc1) * (mnew / (sqrtf(vnew) / bc2s + eps)));
+                }
+                PPO_STAMP(19);
+            }
+    }
+}
+
+template <int EC, int HC>
+__global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9 exp_avg, CtrlPtrs9 exp_avg_sq, CtrlDims d, float* ws,
+                                                         const long long* __restrict__ policies, const float* __restrict__ old_log_probs,
+                                                         const float* __restrict__ reward, float clip, int n_updates, PpoSched sched,
+                                                         float lr, float beta1, float beta2, float eps, float* __restrict__ loss_terms) {
+    static_assert(EC % 16 == 0 && HC % 4 == 0 && 4 * HC <= CT_THREADS && CT_HP * HC <= CT_THREADS && 3 * CT_HP * EC <= CT_THREADS &&
+                  (4 * HC) % CT_HP == 0 && (4 * HC / CT_HP) % 4 == 0, "widths must fit the lane <-> weight-slice mappings");
+    extern __shared__ __attribute__((aligned(16))) float L[];
+    const CtrlWs W = ctrl_ws(d);
+    const PpoLds O = ppo_lds(d);
+    const PpoGaLds Og = ppo_ga_lds(d);
+    const int w = blockIdx.x, NW = gridDim.x;
+    const int Q = d.Q, S = d.S, nseq = d.M * d.Q;
+    constexpr int H4 = 4 * HC, A = CT_MAX_A;
+    const int NT = d.NOPS + d.NMAGS;
+    const int m = w / Q;
+    float* G = L + O.G; float* Cs = L + O.Cs; float* TC = L + O.TC; float* Hs = L + O.Hs; float* X = L + O.X;
+    float* Pp = L + O.P; float* TL = L + O.TL; float* DL = L + O.DL; float* DG = L + O.DG; float* DX = L + O.DX;
+    float* partx = L + O.partx; float* part = L + O.part; float* Wi = L + O.Wi; int* act = reinterpret_cast<int*>(L + O.act);
+    int* tok = reinterpret_cast<int*>(L + O.tok); float* misc = L + O.misc;
+    float* Wh = L + O.Wh; float* Bh = L + O.Bh; float* Emb = L + O.Emb;
+    int* sync = reinterpret_cast<int*>(ws + W.sync);
+    int* cnt_grid = sync;
+    int* cnt_exit = sync + 1;
+    unsigned long long* lpq = reinterpret_cast<unsigned long long*>(ws + W.lpq);
+    // parameter offsets inside a gseq row = inside the concatenation of the module's 9 parameters
+    const int o_wih = NT * EC, o_whh = o_wih + H4 * EC, o_bih = o_whh + H4 * HC, o_bhh = o_bih + H4, o_wop = o_bhh + H4,
+              o_bop = o_wop + d.NOPS * HC, o_wmag = o_bop + d.NOPS, o_bmag = o_wmag + d.NMAGS * HC;
+
+    constexpr int XSL = EC / 4, HSL = (HC / 16) * 4, HL = HC - 3 * HSL;
+    static_assert(HL % 4 == 0 && HL >= HSL && HL - HSL <= HSL, "k-slices must be multiples of 4");
+    constexpr int JS = 4 * HC / (4 * CT_HP);
+    constexpr int XT = CT_HP * EC;                                               // dx lanes per step group
+
+    {                                                           // the pointer table of the gradient phase (behind both LDS layouts)
+        const PpoGaLds Og = ppo_ga_lds(d);
+        float** PT = reinterpret_cast<float**>(L + Og.PT);
+        if (threadIdx.x == 0) {
+            *reinterpret_cast<int*>(L + Og.PT + 55) = 0;
+            PT[0] = P.emb; PT[1] = P.w_ih; PT[2] = P.w_hh; PT[3] = P.b_ih; PT[4] = P.b_hh; PT[5] = P.wop; PT[6] = P.bop; PT[7] = P.wmag; PT[8] = P.bmag;
+            for (int i = 0; i < 9; ++i) { PT[9 + i] = exp_avg.p[i]; PT[18 + i] = exp_avg_sq.p[i]; }
+        }
+    }
+    for (int it = 0; it < n_updates; ++it) {
+        // the thread index is made opaque per epoch: everything below derives from it, and the compiler otherwise hoists every
+        // lane address and predicate of the epoch's ~15 phases out of the loop and spills ~300 registers around the weight slices
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        PPO_STAMP(1);
+        {
+            const float* pw_ih = P.w_ih;
+            const float* pw_hh = P.w_hh;
+            const uint32_t otid = (uint32_t)tid;                    // 32-bit element offsets from the uniform bases
+            const uint32_t ogu = otid >> 2, osl = otid & 3u;
+            // lane <-> weight-slice mappings (those of k_ctrl_rollout's compile-time-width instantiation)
+            const int gu = tid >> 2, gsl = tid & 3;
+            const int hkg = (tid >> 2) % (HC / 4), hjg = (tid >> 2) / (HC / 4);          // dh lanes: tid < CT_HP * HC
+            const int xgrp = tid / XT, xl = tid - xgrp * XT;
+            const int xkg = (xl >> 2) % (EC / 4), xjg = (xl >> 2) / (EC / 4);
+            // ------------------------------------------------------------------------------------------ tables, weights
+            // every global load of the forward in ONE batch (after the epoch's acquire they all miss the caches: ~3 us per
+            // dependent round trip): head weights and embedding rows as one 16-byte vector per thread, then the weight slices
+            float4 r_op = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r_mag = r_op, r_emb = r_op;
+            float r_bop = 0.0f, r_bmag = 0.0f;
+            if (tid < d.NOPS * (HC / 4)) r_op = ld_coh4(P.wop + 4 * tid);
+            if (tid < d.NMAGS * (HC / 4)) r_mag = ld_coh4(P.wmag + 4 * tid);
+            if (tid < NT * (EC / 4)) r_emb = ld_coh4(P.emb + 4 * tid);
+            if (tid < d.NOPS) r_bop = ld_coh1(P.bop + tid);
+            if (tid < d.NMAGS) r_bmag = ld_coh1(P.bmag + tid);
+            constexpr int WIV = H4 * EC / 4, WIN = (WIV + CT_THREADS - 1) / CT_THREADS;     // W_ih as 16-byte vectors
+            float4 r_wi[WIN];
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) r_wi[i] = ld_coh4(pw_ih + 4u * min(otid + (uint32_t)(i * CT_THREADS), (uint32_t)(WIV - 1)));
+            float whr[4][HL];                                   // (the input-to-hidden weights are read from the LDS copy of W_ih)
+            float bias = 0.0f;
+            if (tid < H4) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float* rh = pw_hh + ((uint32_t)(g * HC) + ogu) * (uint32_t)HC + (uint32_t)HSL * osl;
+#pragma unroll
+                    for (int i = 0; i < HL; i += 4) {
+                        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (i < HSL || gsl == 3) v = ld_coh4(rh + i);
+                        whr[g][i] = v.x; whr[g][i + 1] = v.y; whr[g][i + 2] = v.z; whr[g][i + 3] = v.w;
+                    }
+                }
+                bias = ld_coh1(P.b_ih + gsl * HC + gu) + ld_coh1(P.b_hh + gsl * HC + gu);
+            }
+            if (tid < S) {                                      // the sequence's actions and input tokens
+                const int a = (int)policies[(size_t)w * S + tid];
+                act[tid] = a;
+                if (tid + 1 < S) tok[tid + 1] = a + ((tid & 1) == 0 ? 0 : d.NOPS);
+                if (tid == 0) tok[0] = -1;
+            }
+            if (tid < d.NOPS * (HC / 4)) reinterpret_cast<float4*>(Wh)[tid] = r_op;
+            if (tid < d.NMAGS * (HC / 4)) reinterpret_cast<float4*>(Wh + d.NOPS * HC)[tid] = r_mag;
+            if (tid < NT * (EC / 4)) reinterpret_cast<float4*>(Emb)[tid] = r_emb;
+            if (tid < A) { Bh[tid] = r_bop; Bh[A + tid] = r_bmag; }
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) {
+                const int v = tid + i * CT_THREADS;
+                if (v < WIV) *reinterpret_cast<float4*>(Wi + (v / (EC / 4)) * (EC + PPO_WIP) + 4 * (v % (EC / 4))) = r_wi[i];
+            }
+            for (int i = tid; i < HC; i += CT_THREADS) Hs[i] = 0.0f;
+            PPO_STAMP(2);                                       // thread 0's first loads have arrived
+            lds_barrier();                                      // Emb, act, tok
+            for (int i = tid; i < S * EC; i += CT_THREADS) {    // teacher forcing: every step's input is known
+                const int t = i / EC, k = i - t * EC;
+                X[i] = t > 0 ? Emb[(size_t)tok[t] * EC + k] : 0.0f;
+            }
+            lds_barrier();
+            PPO_STAMP(3);
+
+            // ------------------------------------------------------------------------------------------ forward recurrence
+            float c_prev = 0.0f;
+            for (int t = 0; t < S; ++t) {
+                if (tid < H4) {
+                    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (t > 0) {
+#pragma unroll
+                        for (int i = 0; i < XSL; i += 4) {
+                            const float4 a = *reinterpret_cast<const float4*>(X + t * EC + XSL * gsl + i);
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const float4 wv = *reinterpret_cast<const float4*>(Wi + (g * HC + gu) * (EC + PPO_WIP) + XSL * gsl + i);
+                                acc[g] = fmaf(wv.x, a.x, acc[g]); acc[g] = fmaf(wv.y, a.y, acc[g]);
+                                acc[g] = fmaf(wv.z, a.z, acc[g]); acc[g] = fmaf(wv.w, a.w, acc[g]);
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < HL; i += 4) {
+                            // slices 0..2 read 4 inputs of the next slice in their last round: weights zero there
+                            const float4 a = *reinterpret_cast<const float4*>(Hs + t * HC + HSL * gsl + i);
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                acc[g] = fmaf(whr[g][i], a.x, acc[g]); acc[g] = fmaf(whr[g][i + 1], a.y, acc[g]);
+                                acc[g] = fmaf(whr[g][i + 2], a.z, acc[g]); acc[g] = fmaf(whr[g][i + 3], a.w, acc[g]);
+                            }
+                        }
+                    }
+                    // sum of the four k-slices; lane sl activates gate sl, then the quad exchanges the four gates and every
+                    // lane carries the cell state of hidden unit gu
+                    float mine = 0.0f;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float v = quad_sum(acc[g]);
+                        mine = gsl == g ? v : mine;
+                    }
+                    mine += bias;
+                    const float av = gsl == 2 ? tanhf(mine) : sigmoidf_(mine);
+                    G[t * H4 + gsl * HC + gu] = av;
+                    const float ig = quad_lane<0>(av), fg = quad_lane<1>(av), gg = quad_lane<2>(av), og = quad_lane<3>(av);
+                    const float c = fg * c_prev + ig * gg;
+                    const float tc = tanhf(c);
+                    c_prev = c;
+                    if (gsl == 0) {
+                        Cs[t * HC + gu] = c;
+                        TC[t * HC + gu] = tc;
+                        Hs[(t + 1) * HC + gu] = og * tc;
+                    }
+                }
+                lds_barrier();
+            }
+            PPO_STAMP(4);
+            // the backward's weight slices: in flight while the heads run
+            float wbh[JS][4];
+            const uint32_t ohrow = (4u * ((otid >> 2) / (uint32_t)(HC / 4)) + osl) * (uint32_t)JS, ohcol = 4u * ((otid >> 2) % (uint32_t)(HC / 4));
+            if (tid < CT_HP * HC) {
+#pragma unroll
+                for (int i = 0; i < JS; ++i) {
+                    const float4 v = ld_coh4(pw_hh + (ohrow + (uint32_t)i) * (uint32_t)HC + ohcol);
+                    wbh[i][0] = v.x; wbh[i][1] = v.y; wbh[i][2] = v.z; wbh[i][3] = v.w;
                 }
             }
+            // ------------------------------------------------------------------------------------------ heads, all steps
+            {                                                   // 4 lanes per (step, action) logit
+                const int o = tid >> 2, prt = tid & 3;
+                const int t = o / A, a = o - t * A;
+                const bool op_step = (t & 1) == 0;
+                const bool live = t < S && a < (op_step ? d.NOPS : d.NMAGS);
+                float z = 0.0f;
+                if (live) {
+                    const float* wrow = Wh + (size_t)((op_step ? 0 : d.NOPS) + a) * HC;
+                    const float* h = Hs + (t + 1) * HC;
+#pragma unroll 5
+                    for (int k = prt; k < HC; k += 4) z = fmaf(wrow[k], h[k], z);
+                }
+                z += __shfl_xor(z, 1, 64); z += __shfl_xor(z, 2, 64);
+                if (live && prt == 0) {
+                    z += Bh[(op_step ? 0 : A) + a];
+                    const float tl = tanhf(z);
+                    TL[t * A + a] = tl;
+                    Pp[t * A + a] = d.cdiv * tl;
+                }
+            }
+            lds_barrier();
+            PPO_STAMP(5);
+            if (tid < S * A) {                                  // soft-max of every step: 16 lanes per step
+                const int t = tid / A, a = tid - t * A;
+                const int NA = (t & 1) == 0 ? d.NOPS : d.NMAGS;
+                const bool live = a < NA;
+                const float v = live ? Pp[t * A + a] : -INFINITY;
+                float mx = v;
+#pragma unroll
+                for (int o = A / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, A));
+                const float z = v - mx;
+                float sum = live ? expf(z) : 0.0f;
+#pragma unroll
+                for (int o = A / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, A);
+                const float lp = z - logf(sum);
+                if (live) Pp[t * A + a] = expf(lp);
+                const float lp_sel = __shfl(lp, act[t], A);
+                if (a == 0) misc[8 + t] = lp_sel;
+            }
+            lds_barrier();
+            PPO_STAMP(6);
+            // the policy's log-probability = sum over its Q sequences: every workgroup publishes {epoch tag, value} as ONE 64-bit word
+            // and the first Q lanes poll the policy's slots -- the payload travels inside the atomic, no fence, no counter
+            if (tid == 0) {
+                float s = 0.0f;
+                for (int t = 0; t < S; ++t) s += misc[8 + t];
+                const unsigned long long word = ((unsigned long long)(unsigned)(it + 1) << 32) | (unsigned long long)__float_as_uint(s);
+                __hip_atomic_store(lpq + w, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid < Q) {
+                unsigned long long word;
+                do {
+                    word = __hip_atomic_load(lpq + m * Q + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((unsigned)(word >> 32) != (unsigned)(it + 1));
+                misc[8 + tid] = __uint_as_float((unsigned)word);
+            }
+            lds_barrier();
+            PPO_STAMP(7);
+            if (tid == 0) {
+                float lp = 0.0f;
+                for (int q = 0; q < Q; ++q) lp += misc[8 + q];
+                const float ratio = expf(lp - old_log_probs[m]);
+                const float clipped = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+                const float r = reward[m];
+                const float a = ratio * r, b = clipped * r;
+                if (w == m * Q) loss_terms[(size_t)it * d.M + m] = -fminf(a, b);      // the caller averages over M
+                // d(-min(a, b))/d lp: through a when a <= b (ties: both halves reach `ratio` because clamp is then the identity)
+                const bool inside = ratio >= 1.0f - clip && ratio <= 1.0f + clip;
+                float g = 0.0f;
+                if (a < b || (a == b && inside)) g = -r * ratio;
+                else if (a == b && !inside) g = -0.5f * r * ratio;
+                misc[3] = g / (float)d.M;
+            }
+            lds_barrier();
+            PPO_STAMP(8);
+            const float gl = misc[3];
+
+            // ------------------------------------------------------------------------------------------ backward
+            if (tid < S * A) {                                  // d logits of every step
+                const int t = tid / A, a = tid - t * A;
+                const int NA = (t & 1) == 0 ? d.NOPS : d.NMAGS;
+                float dl = 0.0f;
+                if (a < NA) {
+                    const float p = Pp[t * A + a], tl = TL[t * A + a];
+                    const float dz = gl * ((a == act[t] ? 1.0f : 0.0f) - p);
+                    dl = dz * d.cdiv * (1.0f - tl * tl);
+                }
+                DL[t * A + a] = dl;
+            }
+            lds_barrier();
+            PPO_STAMP(9);
+            float dc_carry = 0.0f;                              // thread u < HC: d loss / d c_t carried to step t - 1
+            for (int t = S - 1; t >= 0; --t) {
+                const bool op_step = (t & 1) == 0;
+                const int NA = op_step ? d.NOPS : d.NMAGS;
+                if (tid < HC) {                                 // through the head and the cell
+                    const int u = tid;
+                    float dh = 0.0f;
+                    if (t < S - 1)
+                        for (int pr = 0; pr < CT_HP; ++pr) dh += part[pr * HC + u];
+                    const float* wh = Wh + (size_t)(op_step ? 0 : d.NOPS) * HC;
+                    for (int a = 0; a < NA; ++a) dh = fmaf(wh[(size_t)a * HC + u], DL[t * A + a], dh);
+                    const float* g4 = G + t * H4;
+                    const float ig = g4[u], fg = g4[HC + u], gg = g4[2 * HC + u], og = g4[3 * HC + u];
+                    const float tc = TC[t * HC + u];
+                    const float cp = t > 0 ? Cs[(t - 1) * HC + u] : 0.0f;
+                    const float d_o = dh * tc;
+                    const float dc = dh * og * (1.0f - tc * tc) + dc_carry;
+                    dc_carry = dc * fg;
+                    float* dg = DG + t * H4;
+                    dg[u] = dc * gg * ig * (1.0f - ig);
+                    dg[HC + u] = dc * cp * fg * (1.0f - fg);
+                    dg[2 * HC + u] = dc * ig * (1.0f - gg * gg);
+                    dg[3 * HC + u] = d_o * og * (1.0f - og);
+                }
+                lds_barrier();
+                if (t > 0) {
+                    // dh_{t-1} = W_hh^T dgates: lane (jg, kg, jl) owns columns 4 kg .. 4 kg + 3 x gate rows [(4 jg + jl) JS, + JS)
+                    if (tid < CT_HP * HC) {
+                        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int i = 0; i < JS; i += 4) {
+                            const float4 a = *reinterpret_cast<const float4*>(DG + t * H4 + (4 * hjg + gsl) * JS + i);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                acc[c] = fmaf(wbh[i][c], a.x, acc[c]); acc[c] = fmaf(wbh[i + 1][c], a.y, acc[c]);
+                                acc[c] = fmaf(wbh[i + 2][c], a.z, acc[c]); acc[c] = fmaf(wbh[i + 3][c], a.w, acc[c]);
+                            }
+                        }
+                        float mine = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float v = quad_sum(acc[c]);
+                            mine = gsl == c ? v : mine;
+                        }
+                        part[hjg * HC + 4 * hkg + gsl] = mine;
+                    }
+                    lds_barrier();
+                }
+            }
+            PPO_STAMP(10);
+            // dx_t = W_ih^T dgates of every step t >= 1 (gradient of the embedding row that fed the step): three steps at a time
+            if (tid < 3 * XT) {
+                for (int t = 1 + xgrp; t < S; t += 3) {
+                    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int i = 0; i < JS; i += 4) {
+                        const float4 a = *reinterpret_cast<const float4*>(DG + t * H4 + (4 * xjg + gsl) * JS + i);
+                        float wv[4][4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float4 v = *reinterpret_cast<const float4*>(Wi + ((4 * xjg + gsl) * JS + i + r) * (EC + PPO_WIP) + 4 * xkg);
+                            wv[r][0] = v.x; wv[r][1] = v.y; wv[r][2] = v.z; wv[r][3] = v.w;
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            acc[c] = fmaf(wv[0][c], a.x, acc[c]); acc[c] = fmaf(wv[1][c], a.y, acc[c]);
+                            acc[c] = fmaf(wv[2][c], a.z, acc[c]); acc[c] = fmaf(wv[3][c], a.w, acc[c]);
+                        }
+                    }
+                    float mine = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float v = quad_sum(acc[c]);
+                        mine = gsl == c ? v : mine;
+                    }
+                    partx[(t * CT_HP + xjg) * EC + 4 * xkg + gsl] = mine;
+                }
+            }
+            lds_barrier();
+            PPO_STAMP(11);
+            for (int i = tid; i < S * EC; i += CT_THREADS) {
+                const int t = i / EC, k = i - t * EC;
+                float s = 0.0f;
+                if (t > 0)
+                    for (int pr = 0; pr < CT_HP; ++pr) s += partx[(t * CT_HP + pr) * EC + k];
+                DX[i] = s;
+            }
+            lds_barrier();
+
+            PPO_STAMP(12);
+            // ------------------------------------------------------------------------------------------ the sequence's factors
+            // rows r = w S + t of the scratch arrays: d gates, d logits, d inputs, inputs, tokens; hidden states as [w][S + 1][H]
+            // (slot t = h_{t-1}, slot t + 1 = h_t): 11 KB per sequence instead of its 225 KB of parameter gradients
+            {
+                const size_t r0 = (size_t)w * S;
+                float4* gdg = reinterpret_cast<float4*>(ws + W.dg + r0 * H4);
+                for (int i = tid; i < S * (H4 / 4); i += CT_THREADS) st_coh4(reinterpret_cast<float*>(gdg + i), reinterpret_cast<const float4*>(DG)[i]);
+                float4* ghs = reinterpret_cast<float4*>(ws + W.hprev + (size_t)w * (S + 1) * HC);
+                for (int i = tid; i < (S + 1) * (HC / 4); i += CT_THREADS) st_coh4(reinterpret_cast<float*>(ghs + i), reinterpret_cast<const float4*>(Hs)[i]);
+                if (tid < S * (EC / 4)) {
+                    st_coh4(ws + W.xin + r0 * EC + 4 * tid, reinterpret_cast<const float4*>(X)[tid]);
+                    st_coh4(ws + W.dx + r0 * EC + 4 * tid, reinterpret_cast<const float4*>(DX)[tid]);
+                }
+                if (tid < S * (A / 4)) st_coh4(ws + W.dl + r0 * A + 4 * tid, reinterpret_cast<const float4*>(DL)[tid]);
+                if (tid < S) st_coh1(ws + W.tok + r0 + tid, __int_as_float(tok[tid]));
+            }
+            PPO_STAMP(13);
         }
+        // ---------------------------------------------------------------------------------------------- gradients + Adam, sliced
+        ppo_arrive_wait(cnt_grid, (2 * it + 1) * NW);
+        PPO_STAMP(14);
+        ppo_gradients_adam<EC, HC>(d.M, d.Q, d.S, d.NOPS, d.NMAGS, ws, L, w, tid, sched.bc1[it], sched.bc2_sqrt[it], lr, beta1, beta2, eps);
+        PPO_STAMP(20);
         if (it + 1 < n_updates) ppo_arrive_wait(cnt_grid, (2 * it + 2) * NW);
+        PPO_STAMP(21);
     }
     // the last workgroup to leave zeroes the counters for the next launch
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (__hip_atomic_fetch_add(cnt_exit, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == NW - 1) {
+        if (__hip_atomic_fetch_add(cnt_exit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NW - 1) {
             for (int i = 0; i < nseq; ++i) __hip_atomic_store(lpq + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(sync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1573,4 +1658,19 @@ extern "C" int aadg_controller_ppo_update_f32(void* const* params, void* const* 
         AADG_LAUNCH_CHECK();
     }
     return 0;
+}
+
+/* Phase time stamps of the last one-launch PPO update (workgroup 0): copies up to `cap` (wall_clock64 [100 MHz], id) pairs from the
+ * workspace; returns their number.  Diagnostic (scripts/ubench/ctrl_phase_times.py): not part of the product path. */
+extern "C" int aadg_controller_debug_stamps(const void* ws, int M, int Q, int S, int E, int H, int n_ops, int n_mags,
+                                            unsigned long long* out, int cap) {
+    CtrlDims d = {M, Q, S, E, H, n_ops, n_mags, 1.0f};
+    if (ws == nullptr || out == nullptr || !ctrl_ok(d)) return AADG_E_BADARG;
+    unsigned long long n = 0;
+    const unsigned long long* sb = reinterpret_cast<const unsigned long long*>(static_cast<const float*>(ws) + ctrl_ws(d).stamps);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(&n, sb, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if ((int)n > cap) n = (unsigned long long)cap;
+    if (n > 0 && hipMemcpy(out, sb + 1, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)n;
 }
