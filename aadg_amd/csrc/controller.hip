@@ -49,7 +49,6 @@ struct CtrlParams {                // torch parameter order of the module
     float* bmag;  // [NMAGS]
 };
 struct CtrlPtrs9 { float* p[9]; };
-constexpr int PPO_MAX_STAMPS = 400;
 
 // workspace layout (floats)
 struct CtrlWs {
@@ -57,10 +56,8 @@ struct CtrlWs {
     size_t dg, dl, dx, xin, hprev, hcur, tok;   // R rows each: 4H, CT_MAX_A, E, E, H, H, 1(int)
     size_t probs;                  // [M][2][CT_MAX_A] partial head-probability sums
     size_t counter;                // 1 int
-    // k_ctrl_ppo (one launch for all PPO epochs):
-    size_t lpq;                    // [M * Q] 64-bit words {epoch tag, sum log-prob of the sequence} (zero between launches)
-    size_t sync;                   // 2 ints: the grid barrier's arrival counter, the exit counter (zero between launches)
-    size_t stamps;                 // phase time stamps of workgroup 0 (PPO_STAMP): 64-bit count, then (wall_clock64, id) pairs
+    // k_ppo_rollout:
+    size_t lpq;                    // [M * Q] 64-bit words {Adam step number of the epoch, sum log-prob of the sequence}
     size_t total;
 };
 __host__ __device__ inline int ctrl_n_params(const CtrlDims& d) {
@@ -83,8 +80,6 @@ __host__ __device__ inline CtrlWs ctrl_ws(const CtrlDims& d) {
     w.counter = o; o += 4;
     o = (o + 3) / 4 * 4;
     w.lpq = o; o += (size_t)(2 * d.M * d.Q + 3) / 4 * 4;
-    w.sync = o; o += 4;
-    w.stamps = o; o += 2 * (1 + 2 * PPO_MAX_STAMPS);
     w.total = o;
     return w;
 }
@@ -775,30 +770,31 @@ __global__ __launch_bounds__(256) void k_ctrl_adam(CtrlParams P, CtrlPtrs9 exp_a
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_ctrl_ppo (round 5): ALL PPO epochs in one launch, one workgroup per SEQUENCE.
+// PPO epoch as two short kernels, one workgroup per SEQUENCE (round 5): k_ppo_rollout, k_ppo_grad_adam.
 //   With the actions given, the M * Q sub-policies are independent sequences of S = 2L steps (the reference resets the LSTM
 //   state per sub-policy, models/controller.py:82-84), the step inputs are known up front, and the heads / softmax of a step
 //   do not feed the recurrence.  So instead of M workgroups that walk Q sequences in lock-step through S x (gates, cell,
-//   head, softmax) with 4 barriers per step:
-//     * workgroup w < M * Q owns sequence (m, q) = (w / Q, w % Q): the recurrence is S x (gate products + cell update fused
-//       in the quad that holds the four gate sums: ONE barrier per step), then the heads and soft-maxes of all S steps at once;
-//     * the policy's log-probability (sum over its Q sequences -> PPO ratio -> d loss / d log-prob) crosses workgroups
-//       through a per-policy arrival counter;
+//   head, softmax) with 4 barriers per step, and one thread per parameter summing R = M Q S scratch rows:
+//   k_ppo_rollout (grid M Q):
+//     * workgroup w owns sequence (m, q) = (w / Q, w % Q): the recurrence is S x (gate products + cell update fused in the
+//       quad that holds the four gate sums: ONE LDS-only barrier per step), then the heads and soft-maxes of all S steps at once;
+//       W_ih lives in LDS, the W_hh slices in registers;
+//     * the policy's log-probability (sum over its Q sequences -> PPO ratio -> d loss / d log-prob) crosses workgroups as
+//       tagged 64-bit words {Adam step number, value}: published with one atomic store, polled by the first Q lanes -- no
+//       fence, no counter (the Q workgroups of a policy are co-resident: the grid is <= 128 workgroups, one per CU suffices);
 //     * BPTT: d logits of all steps at once, S x (cell backward, W_hh^T dgates: two barriers), W_ih^T dgates of all steps at
-//       once; then the sequence's parameter gradients as register-tiled outer products (4 x 4 outputs per thread and step)
-//       into gseq[w] -- the old k_ctrl_adam summed R = M Q S scratch rows per parameter (2 R uncoalesced loads);
-//     * grid barrier; every workgroup of the grid (enough for one thread per parameter) sums the M Q per-sequence
-//       gradients in fixed order and applies torch.optim.Adam's update in place; grid barrier; next epoch.
-//   The barriers are arrival counters in the workspace (monotone within a launch, reset by the last workgroup to leave).
-//   All workgroups must be co-resident: the grid is <= 128 workgroups of 512 threads with < 64 KB of LDS (one per CU
-//   suffices); workgroups of other streams' kernels that hold CUs finish without waiting for this one, so a late
-//   workgroup of this grid is always scheduled eventually.
-// Widths: the module's 32 / 100 only (register-resident weights); S <= 8, n_updates <= 16; anything else takes the
-// per-epoch launches above.
+//       once; the sequence's FACTORS (d gates, d logits, d inputs, inputs, hidden states: 11 KB) go to the scratch rows;
+//   k_ppo_grad_adam (grid M Q): workgroup w owns a slice of the parameters (14 gate rows of W_ih / W_hh / the biases, one
+//     head row, one embedding row), stages all sequences' factors in LDS with one batch of loads, sums over the rows in
+//     ascending order and applies torch.optim.Adam's update to its slice.
+//   Measured and dropped in the same round: ALL epochs in ONE persistent launch (grid barriers on arrival counters, the
+//   gradient phase as a noinline function, then fence-free with sc1 atomics for everything shared): 333-395 us against the
+//   324 us of the 10 launches above -- a device-scope acquire / release is L2 maintenance on every XCD (~8 us until the
+//   first load behind it returns), without the fences every shared access goes to the coherence point, and the
+//   ~6000-instruction kernel made the register allocator spill the weight slices inside the recurrence.
+// Widths: the module's 32 / 100 only; S <= 8, M Q S <= 128; anything else takes the launches above.
 // ------------------------------------------------------------------------------------------------
 constexpr int PPO_MAX_S = 8;
-constexpr int PPO_MAX_UPD = 16;
-struct PpoSched { float bc1[PPO_MAX_UPD], bc2_sqrt[PPO_MAX_UPD]; };
 constexpr int PPO_WIP = 4;             // padding of the LDS copy of W_ih (row pitch E + 4 floats)
 struct PpoLds { size_t G, Cs, TC, Hs, X, P, TL, DL, DG, DX, partx, part, Wi, act, tok, misc, Wh, Bh, Emb, total; };
 __host__ __device__ inline PpoLds ppo_lds(const CtrlDims& d) {
@@ -833,7 +829,7 @@ __host__ __device__ inline PpoLds ppo_lds(const CtrlDims& d) {
 constexpr int PPO_JP = 14;
 constexpr int PPO_T_WIH = 352, PPO_T_HEAD = 464, PPO_T_EMB = 496;
 constexpr int PPO_GA_HS = 8, PPO_GA_XI = 2, PPO_GA_DG = 4;
-struct PpoGaLds { size_t HS, XI, DXg, DGs, DLs, TOK, PT, total; };
+struct PpoGaLds { size_t HS, XI, DXg, DGs, DLs, HIT, ROW, PT, total; };
 __host__ __device__ inline PpoGaLds ppo_ga_lds(const CtrlDims& d) {
     PpoGaLds l;
     const size_t R = (size_t)d.M * d.Q * d.S, RS = (size_t)d.M * d.Q * (d.S + 1);
@@ -842,15 +838,11 @@ __host__ __device__ inline PpoGaLds ppo_ga_lds(const CtrlDims& d) {
     l.XI = o; o += R * d.E;               // step inputs
     l.DXg = o; o += R * d.E;              // d step inputs
     l.DGs = o; o += R * 16;               // the pass's columns of d gates (pitch 16)
-    l.DLs = o; o += (R + 3) / 4 * 4;      // the pass's column of d logits
-    l.TOK = o; o += (R + 3) / 4 * 4;      // input tokens
-    {                                     // 27 pointers (parameters, exp_avg, exp_avg_sq) behind BOTH layouts: written once per launch
-        CtrlDims dd = d;
-        const size_t ra = ppo_lds(dd).total;
-        o = (o > ra ? o : ra);
-        o = (o + 3) / 4 * 4;
-    }
-    l.PT = o; o += 2 * 28;
+    l.DLs = o; o += (R + 3) / 4 * 4;      // the pass's column of d logits (zero at the other head's steps)
+    l.HIT = o; o += (R + 3) / 4 * 4;      // 1 where the row's input token is the pass's embedding row
+    l.ROW = o; o += (R + 3) / 4 * 4;      // row of h_{t-1} in HS: r + r / S
+    o = (o + 3) / 4 * 4;
+    l.PT = o; o += 2 * 28;               // 27 pointers: parameters, exp_avg, exp_avg_sq
     l.total = o;
     return l;
 }
@@ -860,51 +852,6 @@ inline bool ppo_ga_fits(const CtrlDims& d) {
     return RS * (d.H / 4) <= PPO_GA_HS * CT_THREADS && R * (d.E / 4) <= PPO_GA_XI * CT_THREADS && R * 16 <= PPO_GA_DG * CT_THREADS && R <= CT_THREADS;
 }
 
-
-// ---- data that crosses workgroups inside the launch (the parameters, the sequences' factors) ------------------------------
-// Device-scope acquire / release FENCES are cache maintenance on this part (the L2 of every XCD is written back / invalidated:
-// measured ~8 us until the first load behind a fence returns, 2 x 8 us per epoch).  Instead every access to shared data is a relaxed
-// device-scope atomic (global_load / global_store ... sc1: served at the coherence point of the device, the rest of the L2 stays
-// valid), and a barrier is: __syncthreads() (which waits for vmcnt(0): every store of the workgroup has been acknowledged) ->
-// one relaxed atomic add -> poll -> __syncthreads().  What is read behind the barrier is read with sc1 loads only.
-__device__ __forceinline__ float4 ld_coh4(const float* p) {
-    unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<float*>(p));
-    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
-}
-__device__ __forceinline__ void st_coh4(float* p, float4 v) {
-    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
-    __hip_atomic_store(q, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 1, ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_coh1(const float* p) {
-    return __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned*>(const_cast<float*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void st_coh1(float* p, float v) {
-    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// arrive at a counter and wait until `target` arrivals
-__device__ __forceinline__ void ppo_arrive_wait(int* cnt, int target) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-    }
-    __syncthreads();
-}
-
-// Phase time stamps of workgroup 0 (thread 0): always recorded -- a scalar clock read and one 16-byte store per stamp -- so that what is
-// timed IS the shipped kernel (an instrumented copy allocates registers differently: its forward loop spilled, the shipped one does
-// not).  Read back by scripts/ubench/ctrl_phase_times.py through aadg_controller_debug_stamps.  The running count lives in LDS.
-#define PPO_STAMP(id)                                                                                                     \
-    do {                                                                                                                  \
-        if (blockIdx.x == 0 && threadIdx.x == 0) {                                                                        \
-            int* n_ = reinterpret_cast<int*>(L + ppo_ga_lds(d).PT + 55);                                                  \
-            unsigned long long* sb_ = reinterpret_cast<unsigned long long*>(ws + ctrl_ws(d).stamps);                      \
-            if (*n_ < PPO_MAX_STAMPS) { sb_[1 + 2 * *n_] = wall_clock64(); sb_[2 + 2 * *n_] = (id); *n_ += 1; sb_[0] = *n_; }  \
-        }                                                                                                                 \
-    } while (0)
 
 template <int CTRL>
 __device__ __forceinline__ float quad_lane(float v) {          // lane CTRL of the caller's quad
@@ -924,35 +871,40 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// The gradient + Adam phase of k_ctrl_ppo as a function of its own (inlined, it made the register allocator spill the
-// recurrence's weight slices inside the forward loop; the 27 parameter / moment pointers reach it through an LDS table so that
-// the call passes scalars only).
+// k_ppo_grad_adam: the gradient + Adam half of a PPO epoch, grid M * Q.
 // Workgroup w owns the gate rows [w JW, (w + 1) JW) of W_ih / W_hh / both biases and the head / embedding rows
 // [w AW, (w + 1) AW): it stages every sequence's hidden states, inputs and d inputs in LDS once (one batch of loads), per
 // pass its <= 14 columns of d gates and one column of d logits, sums over the rows r in ascending order (the order of
 // k_ctrl_adam) and applies torch.optim.Adam's update to its parameters.
 template <int EC, int HC>
-__device__ __noinline__ void ppo_gradients_adam(int M, int Q, int S, int NOPS, int NMAGS, float* ws, float* L, int w, int tid,
-                                                float bc1, float bc2s, float lr, float beta1, float beta2, float eps) {
+__global__ __launch_bounds__(CT_THREADS) void k_ppo_grad_adam(CtrlParams P, CtrlPtrs9 exp_avg, CtrlPtrs9 exp_avg_sq, CtrlDims d, float* ws,
+                                                              float bc1, float bc2s, float lr, float beta1, float beta2, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float L[];
     constexpr int H4 = 4 * HC, A = CT_MAX_A;
-    const CtrlDims d = {M, Q, S, EC, HC, NOPS, NMAGS, 0.0f};
     const CtrlWs W = ctrl_ws(d);
     const PpoGaLds Og = ppo_ga_lds(d);
-    const int nseq = M * Q, NT = NOPS + NMAGS;
-    float* const* PT = reinterpret_cast<float* const*>(L + Og.PT);
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int S = d.S, nseq = d.M * d.Q, NT = d.NOPS + d.NMAGS;
+    // parameter / moment pointers as a table (role-dependent index below): 0..8 parameters, 9..17 exp_avg, 18..26 exp_avg_sq
+    float** PT = reinterpret_cast<float**>(L + Og.PT);
+    if (tid == 0) {
+        PT[0] = P.emb; PT[1] = P.w_ih; PT[2] = P.w_hh; PT[3] = P.b_ih; PT[4] = P.b_hh; PT[5] = P.wop; PT[6] = P.bop; PT[7] = P.wmag; PT[8] = P.bmag;
+        for (int i = 0; i < 9; ++i) { PT[9 + i] = exp_avg.p[i]; PT[18 + i] = exp_avg_sq.p[i]; }
+    }
+    __syncthreads();
     {
             const int R = nseq * S, RS = nseq * (S + 1);
             float* HSg = L + Og.HS; float* XI = L + Og.XI; float* DXg = L + Og.DXg; float* DGs = L + Og.DGs; float* DLs = L + Og.DLs;
-            int* TOK = reinterpret_cast<int*>(L + Og.TOK);
+            float* HIT = L + Og.HIT; int* ROW = reinterpret_cast<int*>(L + Og.ROW);
             const int JW = (H4 + nseq - 1) / nseq, AW = (NT + nseq - 1) / nseq;
             const int npass = max((JW + PPO_JP - 1) / PPO_JP, AW);
-            PPO_STAMP(15);
             // role of this thread (the same in every pass): 0 W_hh rows, 1 W_ih rows + biases, 2 head row + its bias, 3 embedding row
             const int role = tid < PPO_JP * (HC / 4) ? 0 : (tid >= PPO_T_WIH && tid < PPO_T_WIH + PPO_JP * (EC / 4)) ? 1 :
                              (tid >= PPO_T_HEAD && tid < PPO_T_HEAD + HC / 4 + 1) ? 2 : (tid >= PPO_T_EMB && tid < PPO_T_EMB + EC / 4) ? 3 : 4;
             const int l = role == 0 ? tid : role == 1 ? tid - PPO_T_WIH : role == 2 ? tid - PPO_T_HEAD : tid - PPO_T_EMB;
             const int jj = role == 0 ? l / (HC / 4) : l / (EC / 4);
             const int k4 = role == 0 ? l - jj * (HC / 4) : role == 1 ? l - jj * (EC / 4) : l;
+            int tk = -2;                                                    // input token of row `tid` (loaded in the first pass)
             for (int ps = 0; ps < npass; ++ps) {
                 const int j0 = w * JW + ps * PPO_JP;                            // first gate row of the pass
                 const int jn = max(0, min(min(H4, (w + 1) * JW) - j0, PPO_JP)); // its rows
@@ -992,38 +944,37 @@ __device__ __noinline__ void ppo_gradients_adam(int M, int Q, int S, int NOPS, i
                 // ---- ONE batch of loads: (first pass) every sequence's hidden states / inputs / d inputs / tokens; the pass's columns of
                 // d gates and d logits; the parameters and moments this thread will update
                 float4 rh[PPO_GA_HS], rx[PPO_GA_XI], rd[PPO_GA_XI];
-                int tk = 0;
                 const int nhs = RS * (HC / 4), nxi = R * (EC / 4);
                 if (ps == 0) {
                     const float4* ghs = reinterpret_cast<const float4*>(ws + W.hprev);
                     const float4* gxi = reinterpret_cast<const float4*>(ws + W.xin);
                     const float4* gdx = reinterpret_cast<const float4*>(ws + W.dx);
 #pragma unroll
-                    for (int i = 0; i < PPO_GA_HS; ++i) rh[i] = ld_coh4(reinterpret_cast<const float*>(ghs + min(tid + i * CT_THREADS, nhs - 1)));
+                    for (int i = 0; i < PPO_GA_HS; ++i) rh[i] = ghs[min(tid + i * CT_THREADS, nhs - 1)];
 #pragma unroll
                     for (int i = 0; i < PPO_GA_XI; ++i) {
-                        rx[i] = ld_coh4(reinterpret_cast<const float*>(gxi + min(tid + i * CT_THREADS, nxi - 1)));
-                        rd[i] = ld_coh4(reinterpret_cast<const float*>(gdx + min(tid + i * CT_THREADS, nxi - 1)));
+                        rx[i] = gxi[min(tid + i * CT_THREADS, nxi - 1)];
+                        rd[i] = gdx[min(tid + i * CT_THREADS, nxi - 1)];
                     }
-                    tk = __float_as_int(ld_coh1(ws + W.tok + min(tid, R - 1)));
+                    tk = reinterpret_cast<const int*>(ws + W.tok)[min(tid, R - 1)];
                 }
                 float rg[PPO_GA_DG];
 #pragma unroll
                 for (int i = 0; i < PPO_GA_DG; ++i) {
                     const int e = tid + i * CT_THREADS, r = min(e >> 4, R - 1), cj = e & 15;
-                    rg[i] = ld_coh1(ws + W.dg + (size_t)r * H4 + min(j0 + cj, H4 - 1));
+                    rg[i] = ws[W.dg + (size_t)r * H4 + min(j0 + cj, H4 - 1)];
                 }
-                const float rl = ld_coh1(ws + W.dl + (size_t)min(tid, R - 1) * A + (has_a ? acol : 0));
+                const float rl = ws[W.dl + (size_t)min(tid, R - 1) * A + (has_a ? acol : 0)];
                 float pv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, mv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, vv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 float bpv = 0.0f, bmv = 0.0f, bvv = 0.0f;
                 if (live && vec) {
-                    const float4 p0 = ld_coh4(pp), m0 = *reinterpret_cast<const float4*>(mp), v0 = *reinterpret_cast<const float4*>(vp);
+                    const float4 p0 = *reinterpret_cast<const float4*>(pp), m0 = *reinterpret_cast<const float4*>(mp), v0 = *reinterpret_cast<const float4*>(vp);
                     pv[0] = p0.x; pv[1] = p0.y; pv[2] = p0.z; pv[3] = p0.w; mv[0] = m0.x; mv[1] = m0.y; mv[2] = m0.z; mv[3] = m0.w;
                     vv[0] = v0.x; vv[1] = v0.y; vv[2] = v0.z; vv[3] = v0.w;
                 } else if (live) {
-                    pv[0] = ld_coh1(pp); mv[0] = *mp; vv[0] = *vp;
+                    pv[0] = *pp; mv[0] = *mp; vv[0] = *vp;
                 }
-                if (blane) { bpv = ld_coh1(bp); bmv = *bm; bvv = *bv; }
+                if (blane) { bpv = *bp; bmv = *bm; bvv = *bv; }
                 if (ps == 0) {
 #pragma unroll
                     for (int i = 0; i < PPO_GA_HS; ++i)
@@ -1034,7 +985,7 @@ __device__ __noinline__ void ppo_gradients_adam(int M, int Q, int S, int NOPS, i
                             reinterpret_cast<float4*>(XI)[tid + i * CT_THREADS] = rx[i];
                             reinterpret_cast<float4*>(DXg)[tid + i * CT_THREADS] = rd[i];
                         }
-                    if (tid < R) TOK[tid] = tk;
+                    if (tid < R) ROW[tid] = tid + tid / S;
                 } else {
                     lds_barrier();                                              // the previous pass has read its columns
                 }
@@ -1043,26 +994,33 @@ __device__ __noinline__ void ppo_gradients_adam(int M, int Q, int S, int NOPS, i
                     const int e = tid + i * CT_THREADS;
                     if (e < R * 16) DGs[e] = rg[i];
                 }
-                if (tid < R) DLs[tid] = rl;
-                PPO_STAMP(16);                                                  // thread 0's loads have arrived
+                if (tid < R) {
+                    DLs[tid] = (tid & 1) == apar ? rl : 0.0f;               // S is even: row parity = step parity = head
+                    HIT[tid] = has_a && tk == arow ? 1.0f : 0.0f;
+                }
                 lds_barrier();
-                PPO_STAMP(17);
-                // ---- the sums over the rows r = (sequence, step), ascending; UR rows' operands in flight at a time
-                constexpr int UR = 8;
+                // ---- the sums over the rows r = (sequence, step), ascending; UR rows' operands in flight at a time.  ONE loop for the four
+                // roles (a wave that holds several roles would otherwise walk several latency-bound loops one after the other):
+                //   sum_r g[r] * y[r][4 k4 ..]   with   g = the row's d gate (roles 0, 1) / its d logit, zero at the other head's steps
+                //   (role 2) / 1 where the row's input token is this embedding row, else 0 (role 3) -- adding 0 * y changes nothing --
+                //   and y = h_{t-1} / x_t / h_t / d x_t
+                constexpr int UR = 16;
                 float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 float bsum = 0.0f;
-                if (live && role <= 1) {
-                    const float* gcol = DGs + jj;
-                    const float* ycol = role == 0 ? HSg + 4 * k4 : XI + 4 * k4;
-                    const int pitch = role == 0 ? HC : EC;
+                if (live) {
+                    const float* gcol = role <= 1 ? DGs + jj : role == 2 ? DLs : HIT;
+                    const int gstride = role <= 1 ? 16 : 1;
+                    const bool hrows = role == 0 || role == 2;                  // y rows are hidden states: [sequence][S + 1] slots
+                    const float* ycol = role == 0 ? HSg + 4 * k4 : role == 1 ? XI + 4 * k4 : role == 2 ? HSg + HC + 4 * min(k4, HC / 4 - 1) : DXg + 4 * k4;
+                    const int pitch = hrows ? HC : EC;
                     for (int r0 = 0; r0 < R; r0 += UR) {
                         float g[UR];
                         float4 y[UR];
 #pragma unroll
                         for (int i = 0; i < UR; ++i) {
                             const int r = min(r0 + i, R - 1);
-                            const int yr = role == 0 ? r + r / S : r;           // hidden states: [sequence][S + 1] rows, slot t = h_{t-1}
-                            g[i] = r0 + i < R ? gcol[r * 16] : 0.0f;
+                            const int yr = hrows ? ROW[r] : r;
+                            g[i] = r0 + i < R ? gcol[r * gstride] : 0.0f;
                             y[i] = *reinterpret_cast<const float4*>(ycol + yr * pitch);
                         }
 #pragma unroll
@@ -1072,42 +1030,7 @@ __device__ __noinline__ void ppo_gradients_adam(int M, int Q, int S, int NOPS, i
                             bsum += g[i];
                         }
                     }
-                } else if (live && role == 2) {                                 // steps of the row's head only; h_t = slot t + 1
-                    const int R2 = R / 2;                                       // S is even: row parity = step parity
-                    for (int q0 = 0; q0 < R2; q0 += UR) {
-                        float g[UR];
-                        float4 y[UR];
-#pragma unroll
-                        for (int i = 0; i < UR; ++i) {
-                            const int r = 2 * min(q0 + i, R2 - 1) + apar;
-                            g[i] = q0 + i < R2 ? DLs[r] : 0.0f;
-                            y[i] = *reinterpret_cast<const float4*>(HSg + (r + r / S + 1) * HC + 4 * min(k4, HC / 4 - 1));
-                        }
-#pragma unroll
-                        for (int i = 0; i < UR; ++i) {
-                            acc[0] = fmaf(g[i], y[i].x, acc[0]); acc[1] = fmaf(g[i], y[i].y, acc[1]);
-                            acc[2] = fmaf(g[i], y[i].z, acc[2]); acc[3] = fmaf(g[i], y[i].w, acc[3]);
-                            bsum += g[i];
-                        }
-                    }
-                } else if (live && role == 3) {                                 // the steps this embedding row fed
-                    for (int r0 = 0; r0 < R; r0 += UR) {
-                        bool hit[UR];
-                        float4 y[UR];
-#pragma unroll
-                        for (int i = 0; i < UR; ++i) {
-                            const int r = min(r0 + i, R - 1);
-                            hit[i] = r0 + i < R && TOK[r] == arow;
-                            y[i] = *reinterpret_cast<const float4*>(DXg + r * EC + 4 * k4);
-                        }
-#pragma unroll
-                        for (int i = 0; i < UR; ++i) {
-                            acc[0] = hit[i] ? acc[0] + y[i].x : acc[0]; acc[1] = hit[i] ? acc[1] + y[i].y : acc[1];
-                            acc[2] = hit[i] ? acc[2] + y[i].z : acc[2]; acc[3] = hit[i] ? acc[3] + y[i].w : acc[3];
-                        }
-                    }
                 }
-                PPO_STAMP(18);
                 // ---- torch.optim.Adam (no weight decay, no amsgrad): m, v EMAs (lerp, as torch does), step = lr / bc1,
                 // denom = sqrt(v) / sqrt(bc2) + eps
                 if (live) {
@@ -1123,34 +1046,32 @@ __device__ __noinline__ void ppo_gradients_adam(int M, int Q, int S, int NOPS, i
                     if (vec) {
                         *reinterpret_cast<float4*>(mp) = make_float4(mn[0], mn[1], mn[2], mn[3]);
                         *reinterpret_cast<float4*>(vp) = make_float4(vn[0], vn[1], vn[2], vn[3]);
-                        st_coh4(pp, make_float4(pn[0], pn[1], pn[2], pn[3]));
+                        *reinterpret_cast<float4*>(pp) = make_float4(pn[0], pn[1], pn[2], pn[3]);
                     } else {
-                        *mp = mn[0]; *vp = vn[0]; st_coh1(pp, pn[0]);
+                        *mp = mn[0]; *vp = vn[0]; *pp = pn[0];
                     }
                 }
                 if (blane) {
                     const float mnew = bmv + (bsum - bmv) * (1.0f - beta1);
                     const float vnew = beta2 * bvv + (1.0f - beta2) * bsum * bsum;
                     *bm = mnew; *bv = vnew;
-                    st_coh1(bp, bpv - (lr / bc1) * (mnew / (sqrtf(vnew) / bc2s + eps)));
+                    *bp = bpv - (lr / bc1) * (mnew / (sqrtf(vnew) / bc2s + eps));
                 }
-                PPO_STAMP(19);
             }
     }
 }
 
 template <int EC, int HC>
-__global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9 exp_avg, CtrlPtrs9 exp_avg_sq, CtrlDims d, float* ws,
-                                                         const long long* __restrict__ policies, const float* __restrict__ old_log_probs,
-                                                         const float* __restrict__ reward, float clip, int n_updates, PpoSched sched,
-                                                         float lr, float beta1, float beta2, float eps, float* __restrict__ loss_terms) {
+__global__ __launch_bounds__(CT_THREADS) void k_ppo_rollout(CtrlParams P, CtrlDims d, float* ws, const long long* __restrict__ policies,
+                                                            const float* __restrict__ old_log_probs, const float* __restrict__ reward,
+                                                            float clip, unsigned tag, float* __restrict__ loss_terms /* this epoch's [M] */) {
     static_assert(EC % 16 == 0 && HC % 4 == 0 && 4 * HC <= CT_THREADS && CT_HP * HC <= CT_THREADS && 3 * CT_HP * EC <= CT_THREADS &&
                   (4 * HC) % CT_HP == 0 && (4 * HC / CT_HP) % 4 == 0, "widths must fit the lane <-> weight-slice mappings");
     extern __shared__ __attribute__((aligned(16))) float L[];
     const CtrlWs W = ctrl_ws(d);
     const PpoLds O = ppo_lds(d);
     const PpoGaLds Og = ppo_ga_lds(d);
-    const int w = blockIdx.x, NW = gridDim.x;
+    const int w = blockIdx.x;
     const int Q = d.Q, S = d.S, nseq = d.M * d.Q;
     constexpr int H4 = 4 * HC, A = CT_MAX_A;
     const int NT = d.NOPS + d.NMAGS;
@@ -1160,9 +1081,6 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
     float* partx = L + O.partx; float* part = L + O.part; float* Wi = L + O.Wi; int* act = reinterpret_cast<int*>(L + O.act);
     int* tok = reinterpret_cast<int*>(L + O.tok); float* misc = L + O.misc;
     float* Wh = L + O.Wh; float* Bh = L + O.Bh; float* Emb = L + O.Emb;
-    int* sync = reinterpret_cast<int*>(ws + W.sync);
-    int* cnt_grid = sync;
-    int* cnt_exit = sync + 1;
     unsigned long long* lpq = reinterpret_cast<unsigned long long*>(ws + W.lpq);
     // parameter offsets inside a gseq row = inside the concatenation of the module's 9 parameters
     const int o_wih = NT * EC, o_whh = o_wih + H4 * EC, o_bih = o_whh + H4 * HC, o_bhh = o_bih + H4, o_wop = o_bhh + H4,
@@ -1173,21 +1091,8 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
     constexpr int JS = 4 * HC / (4 * CT_HP);
     constexpr int XT = CT_HP * EC;                                               // dx lanes per step group
 
-    {                                                           // the pointer table of the gradient phase (behind both LDS layouts)
-        const PpoGaLds Og = ppo_ga_lds(d);
-        float** PT = reinterpret_cast<float**>(L + Og.PT);
-        if (threadIdx.x == 0) {
-            *reinterpret_cast<int*>(L + Og.PT + 55) = 0;
-            PT[0] = P.emb; PT[1] = P.w_ih; PT[2] = P.w_hh; PT[3] = P.b_ih; PT[4] = P.b_hh; PT[5] = P.wop; PT[6] = P.bop; PT[7] = P.wmag; PT[8] = P.bmag;
-            for (int i = 0; i < 9; ++i) { PT[9 + i] = exp_avg.p[i]; PT[18 + i] = exp_avg_sq.p[i]; }
-        }
-    }
-    for (int it = 0; it < n_updates; ++it) {
-        // the thread index is made opaque per epoch: everything below derives from it, and the compiler otherwise hoists every
-        // lane address and predicate of the epoch's ~15 phases out of the loop and spills ~300 registers around the weight slices
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        PPO_STAMP(1);
+    {
+        const int tid = threadIdx.x;
         {
             const float* pw_ih = P.w_ih;
             const float* pw_hh = P.w_hh;
@@ -1203,15 +1108,15 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
             // dependent round trip): head weights and embedding rows as one 16-byte vector per thread, then the weight slices
             float4 r_op = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r_mag = r_op, r_emb = r_op;
             float r_bop = 0.0f, r_bmag = 0.0f;
-            if (tid < d.NOPS * (HC / 4)) r_op = ld_coh4(P.wop + 4 * tid);
-            if (tid < d.NMAGS * (HC / 4)) r_mag = ld_coh4(P.wmag + 4 * tid);
-            if (tid < NT * (EC / 4)) r_emb = ld_coh4(P.emb + 4 * tid);
-            if (tid < d.NOPS) r_bop = ld_coh1(P.bop + tid);
-            if (tid < d.NMAGS) r_bmag = ld_coh1(P.bmag + tid);
+            if (tid < d.NOPS * (HC / 4)) r_op = reinterpret_cast<const float4*>(P.wop)[tid];
+            if (tid < d.NMAGS * (HC / 4)) r_mag = reinterpret_cast<const float4*>(P.wmag)[tid];
+            if (tid < NT * (EC / 4)) r_emb = reinterpret_cast<const float4*>(P.emb)[tid];
+            if (tid < d.NOPS) r_bop = P.bop[tid];
+            if (tid < d.NMAGS) r_bmag = P.bmag[tid];
             constexpr int WIV = H4 * EC / 4, WIN = (WIV + CT_THREADS - 1) / CT_THREADS;     // W_ih as 16-byte vectors
             float4 r_wi[WIN];
 #pragma unroll
-            for (int i = 0; i < WIN; ++i) r_wi[i] = ld_coh4(pw_ih + 4u * min(otid + (uint32_t)(i * CT_THREADS), (uint32_t)(WIV - 1)));
+            for (int i = 0; i < WIN; ++i) r_wi[i] = reinterpret_cast<const float4*>(pw_ih)[min(otid + (uint32_t)(i * CT_THREADS), (uint32_t)(WIV - 1))];
             float whr[4][HL];                                   // (the input-to-hidden weights are read from the LDS copy of W_ih)
             float bias = 0.0f;
             if (tid < H4) {
@@ -1221,11 +1126,11 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
 #pragma unroll
                     for (int i = 0; i < HL; i += 4) {
                         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                        if (i < HSL || gsl == 3) v = ld_coh4(rh + i);
+                        if (i < HSL || gsl == 3) v = *reinterpret_cast<const float4*>(rh + i);
                         whr[g][i] = v.x; whr[g][i + 1] = v.y; whr[g][i + 2] = v.z; whr[g][i + 3] = v.w;
                     }
                 }
-                bias = ld_coh1(P.b_ih + gsl * HC + gu) + ld_coh1(P.b_hh + gsl * HC + gu);
+                bias = P.b_ih[gsl * HC + gu] + P.b_hh[gsl * HC + gu];
             }
             if (tid < S) {                                      // the sequence's actions and input tokens
                 const int a = (int)policies[(size_t)w * S + tid];
@@ -1243,14 +1148,12 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
                 if (v < WIV) *reinterpret_cast<float4*>(Wi + (v / (EC / 4)) * (EC + PPO_WIP) + 4 * (v % (EC / 4))) = r_wi[i];
             }
             for (int i = tid; i < HC; i += CT_THREADS) Hs[i] = 0.0f;
-            PPO_STAMP(2);                                       // thread 0's first loads have arrived
             lds_barrier();                                      // Emb, act, tok
             for (int i = tid; i < S * EC; i += CT_THREADS) {    // teacher forcing: every step's input is known
                 const int t = i / EC, k = i - t * EC;
                 X[i] = t > 0 ? Emb[(size_t)tok[t] * EC + k] : 0.0f;
             }
             lds_barrier();
-            PPO_STAMP(3);
 
             // ------------------------------------------------------------------------------------------ forward recurrence
             float c_prev = 0.0f;
@@ -1302,14 +1205,13 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
                 }
                 lds_barrier();
             }
-            PPO_STAMP(4);
             // the backward's weight slices: in flight while the heads run
             float wbh[JS][4];
             const uint32_t ohrow = (4u * ((otid >> 2) / (uint32_t)(HC / 4)) + osl) * (uint32_t)JS, ohcol = 4u * ((otid >> 2) % (uint32_t)(HC / 4));
             if (tid < CT_HP * HC) {
 #pragma unroll
                 for (int i = 0; i < JS; ++i) {
-                    const float4 v = ld_coh4(pw_hh + (ohrow + (uint32_t)i) * (uint32_t)HC + ohcol);
+                    const float4 v = *reinterpret_cast<const float4*>(pw_hh + (ohrow + (uint32_t)i) * (uint32_t)HC + ohcol);
                     wbh[i][0] = v.x; wbh[i][1] = v.y; wbh[i][2] = v.z; wbh[i][3] = v.w;
                 }
             }
@@ -1335,7 +1237,6 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
                 }
             }
             lds_barrier();
-            PPO_STAMP(5);
             if (tid < S * A) {                                  // soft-max of every step: 16 lanes per step
                 const int t = tid / A, a = tid - t * A;
                 const int NA = (t & 1) == 0 ? d.NOPS : d.NMAGS;
@@ -1354,24 +1255,22 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
                 if (a == 0) misc[8 + t] = lp_sel;
             }
             lds_barrier();
-            PPO_STAMP(6);
             // the policy's log-probability = sum over its Q sequences: every workgroup publishes {epoch tag, value} as ONE 64-bit word
             // and the first Q lanes poll the policy's slots -- the payload travels inside the atomic, no fence, no counter
             if (tid == 0) {
                 float s = 0.0f;
                 for (int t = 0; t < S; ++t) s += misc[8 + t];
-                const unsigned long long word = ((unsigned long long)(unsigned)(it + 1) << 32) | (unsigned long long)__float_as_uint(s);
+                const unsigned long long word = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(s);
                 __hip_atomic_store(lpq + w, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (tid < Q) {
                 unsigned long long word;
                 do {
                     word = __hip_atomic_load(lpq + m * Q + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } while ((unsigned)(word >> 32) != (unsigned)(it + 1));
+                } while ((unsigned)(word >> 32) != tag);
                 misc[8 + tid] = __uint_as_float((unsigned)word);
             }
             lds_barrier();
-            PPO_STAMP(7);
             if (tid == 0) {
                 float lp = 0.0f;
                 for (int q = 0; q < Q; ++q) lp += misc[8 + q];
@@ -1379,7 +1278,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
                 const float clipped = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
                 const float r = reward[m];
                 const float a = ratio * r, b = clipped * r;
-                if (w == m * Q) loss_terms[(size_t)it * d.M + m] = -fminf(a, b);      // the caller averages over M
+                if (w == m * Q) loss_terms[m] = -fminf(a, b);      // the caller averages over M
                 // d(-min(a, b))/d lp: through a when a <= b (ties: both halves reach `ratio` because clamp is then the identity)
                 const bool inside = ratio >= 1.0f - clip && ratio <= 1.0f + clip;
                 float g = 0.0f;
@@ -1388,7 +1287,6 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
                 misc[3] = g / (float)d.M;
             }
             lds_barrier();
-            PPO_STAMP(8);
             const float gl = misc[3];
 
             // ------------------------------------------------------------------------------------------ backward
@@ -1404,7 +1302,6 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
                 DL[t * A + a] = dl;
             }
             lds_barrier();
-            PPO_STAMP(9);
             float dc_carry = 0.0f;                              // thread u < HC: d loss / d c_t carried to step t - 1
             for (int t = S - 1; t >= 0; --t) {
                 const bool op_step = (t & 1) == 0;
@@ -1454,7 +1351,6 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
                     lds_barrier();
                 }
             }
-            PPO_STAMP(10);
             // dx_t = W_ih^T dgates of every step t >= 1 (gradient of the embedding row that fed the step): three steps at a time
             if (tid < 3 * XT) {
                 for (int t = 1 + xgrp; t < S; t += 3) {
@@ -1484,7 +1380,6 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
                 }
             }
             lds_barrier();
-            PPO_STAMP(11);
             for (int i = tid; i < S * EC; i += CT_THREADS) {
                 const int t = i / EC, k = i - t * EC;
                 float s = 0.0f;
@@ -1494,40 +1389,22 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo(CtrlParams P, CtrlPtrs9
             }
             lds_barrier();
 
-            PPO_STAMP(12);
             // ------------------------------------------------------------------------------------------ the sequence's factors
             // rows r = w S + t of the scratch arrays: d gates, d logits, d inputs, inputs, tokens; hidden states as [w][S + 1][H]
             // (slot t = h_{t-1}, slot t + 1 = h_t): 11 KB per sequence instead of its 225 KB of parameter gradients
             {
                 const size_t r0 = (size_t)w * S;
                 float4* gdg = reinterpret_cast<float4*>(ws + W.dg + r0 * H4);
-                for (int i = tid; i < S * (H4 / 4); i += CT_THREADS) st_coh4(reinterpret_cast<float*>(gdg + i), reinterpret_cast<const float4*>(DG)[i]);
+                for (int i = tid; i < S * (H4 / 4); i += CT_THREADS) gdg[i] = reinterpret_cast<const float4*>(DG)[i];
                 float4* ghs = reinterpret_cast<float4*>(ws + W.hprev + (size_t)w * (S + 1) * HC);
-                for (int i = tid; i < (S + 1) * (HC / 4); i += CT_THREADS) st_coh4(reinterpret_cast<float*>(ghs + i), reinterpret_cast<const float4*>(Hs)[i]);
+                for (int i = tid; i < (S + 1) * (HC / 4); i += CT_THREADS) ghs[i] = reinterpret_cast<const float4*>(Hs)[i];
                 if (tid < S * (EC / 4)) {
-                    st_coh4(ws + W.xin + r0 * EC + 4 * tid, reinterpret_cast<const float4*>(X)[tid]);
-                    st_coh4(ws + W.dx + r0 * EC + 4 * tid, reinterpret_cast<const float4*>(DX)[tid]);
+                    reinterpret_cast<float4*>(ws + W.xin + r0 * EC)[tid] = reinterpret_cast<const float4*>(X)[tid];
+                    reinterpret_cast<float4*>(ws + W.dx + r0 * EC)[tid] = reinterpret_cast<const float4*>(DX)[tid];
                 }
-                if (tid < S * (A / 4)) st_coh4(ws + W.dl + r0 * A + 4 * tid, reinterpret_cast<const float4*>(DL)[tid]);
-                if (tid < S) st_coh1(ws + W.tok + r0 + tid, __int_as_float(tok[tid]));
+                if (tid < S * (A / 4)) reinterpret_cast<float4*>(ws + W.dl + r0 * A)[tid] = reinterpret_cast<const float4*>(DL)[tid];
+                if (tid < S) reinterpret_cast<int*>(ws + W.tok)[r0 + tid] = tok[tid];
             }
-            PPO_STAMP(13);
-        }
-        // ---------------------------------------------------------------------------------------------- gradients + Adam, sliced
-        ppo_arrive_wait(cnt_grid, (2 * it + 1) * NW);
-        PPO_STAMP(14);
-        ppo_gradients_adam<EC, HC>(d.M, d.Q, d.S, d.NOPS, d.NMAGS, ws, L, w, tid, sched.bc1[it], sched.bc2_sqrt[it], lr, beta1, beta2, eps);
-        PPO_STAMP(20);
-        if (it + 1 < n_updates) ppo_arrive_wait(cnt_grid, (2 * it + 2) * NW);
-        PPO_STAMP(21);
-    }
-    // the last workgroup to leave zeroes the counters for the next launch
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (__hip_atomic_fetch_add(cnt_exit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NW - 1) {
-            for (int i = 0; i < nseq; ++i) __hip_atomic_store(lpq + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -1618,26 +1495,30 @@ extern "C" int aadg_controller_ppo_update_f32(void* const* params, void* const* 
     auto* kern = fast ? &k_ctrl_rollout<false, CT_E, CT_H> : &k_ctrl_rollout<false, 0, 0>;
     const int n_params = ctrl_n_params(d);
     {
-        // all epochs in ONE launch (k_ctrl_ppo): the module's widths, short sequences, a grid that is co-resident by a wide margin
+        // the module's widths, short sequences: two short kernels per epoch, one workgroup per sequence
         const int grid = M * Q;
-        const size_t lds_a = ppo_lds(d).total * sizeof(float), lds_b = ppo_ga_lds(d).total * sizeof(float);
-        const size_t lds1 = lds_a > lds_b ? lds_a : lds_b;
-        if (fast && S <= PPO_MAX_S && n_updates <= PPO_MAX_UPD && grid <= 128 && lds1 <= 150 * 1024 && ppo_ga_fits(d)) {
-            static size_t lds_set = 0;
-            if (lds1 > lds_set) {
-                AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ctrl_ppo<CT_E, CT_H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-                lds_set = lds1;
+        const size_t lds_r = ppo_lds(d).total * sizeof(float), lds_g = ppo_ga_lds(d).total * sizeof(float);
+        if (fast && S <= PPO_MAX_S && grid <= 128 && lds_r <= 150 * 1024 && lds_g <= 150 * 1024 && ppo_ga_fits(d)) {
+            static size_t set_r = 0, set_g = 0;
+            if (lds_r > set_r) {
+                AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ppo_rollout<CT_E, CT_H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+                set_r = lds_r;
             }
-            PpoSched sched;
+            if (lds_g > set_g) {
+                AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ppo_grad_adam<CT_E, CT_H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
+                set_g = lds_g;
+            }
             for (int it = 0; it < n_updates; ++it) {
                 const double step = (double)(step0 + it + 1);
-                sched.bc1[it] = (float)(1.0 - pow((double)beta1, step));
-                sched.bc2_sqrt[it] = (float)sqrt(1.0 - pow((double)beta2, step));
+                const float bc1 = (float)(1.0 - pow((double)beta1, step));
+                const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
+                hipLaunchKernelGGL((k_ppo_rollout<CT_E, CT_H>), dim3(grid), dim3(CT_THREADS), lds_r, st, P, d, (float*)ws, policies, old_log_probs,
+                                   reward, clip, (unsigned)(step0 + it + 1), loss_terms + (size_t)it * M);
+                AADG_LAUNCH_CHECK();
+                hipLaunchKernelGGL((k_ppo_grad_adam<CT_E, CT_H>), dim3(grid), dim3(CT_THREADS), lds_g, st, P, m1, m2, d, (float*)ws, bc1, bc2_sqrt,
+                                   lr, beta1, beta2, eps);
+                AADG_LAUNCH_CHECK();
             }
-            for (int it = n_updates; it < PPO_MAX_UPD; ++it) sched.bc1[it] = sched.bc2_sqrt[it] = 1.0f;
-            hipLaunchKernelGGL((k_ctrl_ppo<CT_E, CT_H>), dim3(grid), dim3(CT_THREADS), lds1, st, P, m1, m2, d, (float*)ws, policies,
-                               old_log_probs, reward, clip, n_updates, sched, lr, beta1, beta2, eps, loss_terms);
-            AADG_LAUNCH_CHECK();
             return 0;
         }
     }
@@ -1658,19 +1539,4 @@ extern "C" int aadg_controller_ppo_update_f32(void* const* params, void* const* 
         AADG_LAUNCH_CHECK();
     }
     return 0;
-}
-
-/* Phase time stamps of the last one-launch PPO update (workgroup 0): copies up to `cap` (wall_clock64 [100 MHz], id) pairs from the
- * workspace; returns their number.  Diagnostic (scripts/ubench/ctrl_phase_times.py): not part of the product path. */
-extern "C" int aadg_controller_debug_stamps(const void* ws, int M, int Q, int S, int E, int H, int n_ops, int n_mags,
-                                            unsigned long long* out, int cap) {
-    CtrlDims d = {M, Q, S, E, H, n_ops, n_mags, 1.0f};
-    if (ws == nullptr || out == nullptr || !ctrl_ok(d)) return AADG_E_BADARG;
-    unsigned long long n = 0;
-    const unsigned long long* sb = reinterpret_cast<const unsigned long long*>(static_cast<const float*>(ws) + ctrl_ws(d).stamps);
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpy(&n, sb, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if ((int)n > cap) n = (unsigned long long)cap;
-    if (n > 0 && hipMemcpy(out, sb + 1, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return (int)n;
 }

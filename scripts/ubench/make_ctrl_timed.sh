@@ -1,22 +1,16 @@
-# Builds scripts/ubench/libaadg_timed.so: libaadg_hip.so with a wall_clock64 stamp after every barrier of k_ctrl_rollout (default)
-# or k_ctrl_ppo (`make_ctrl_timed.sh ppo`: workgroup-local and counter barriers) (workgroup 0) and an extra export aadg_debug_ctrl_times; used by scripts/ubench/ctrl_phase_times.py.
+# Builds scripts/ubench/libaadg_timed.so: libaadg_hip.so with a wall_clock64 stamp after every barrier of k_ctrl_rollout
+# (workgroup 0) and an extra export aadg_debug_ctrl_times; used by scripts/ubench/ctrl_phase_times.py.
 set -e
 cd "$(dirname "$0")/../.."
-python - "${1:-rollout}" <<'PY'
-import sys
-which = sys.argv[1]
+python - <<'PY'
 s = open('aadg_amd/csrc/controller.hip').read()
-if which == 'ppo':
-    a = s.index('__global__ __launch_bounds__(CT_THREADS) void k_ctrl_ppo')
-    b = s.index('inline bool ctrl_ok')
-else:
-    a = s.index('__global__ __launch_bounds__(CT_THREADS) void k_ctrl_rollout')
-    b = s.index('// sum_r a[r * sa] * b[r * sb]')
+a = s.index('__global__ __launch_bounds__(CT_THREADS) void k_ctrl_rollout')
+b = s.index('// sum_r a[r * sa] * b[r * sb]')
 head, body, tail = s[:a], s[a:b], s[b:]
 out, n = [], 0
 for l in body.split('\n'):
     out.append(l)
-    if l.strip() == '__syncthreads();' or l.strip().startswith('lds_barrier();') or l.strip().startswith('ppo_arrive_wait(') or l.strip().startswith('if (it + 1 < n_updates) ppo_arrive_wait('):
+    if l.strip() == '__syncthreads();':
         n += 1
         out.append('    CTT(%d);' % n)
 body = '\n'.join(out)
