@@ -827,9 +827,11 @@ __host__ __device__ inline PpoLds ppo_lds(const CtrlDims& d) {
 
 // gradient + Adam phase: gate rows per pass, thread ranges of the four roles, 16-byte vectors / words staged per thread
 constexpr int PPO_JP = 14;
+constexpr int PPO_GA_GRID = 100;       // workgroups of k_ppo_grad_adam: 4 gate rows each
 constexpr int PPO_T_WIH = 352, PPO_T_HEAD = 464, PPO_T_EMB = 496;
 constexpr int PPO_GA_HS = 8, PPO_GA_XI = 2, PPO_GA_DG = 4;
-struct PpoGaLds { size_t HS, XI, DXg, DGs, DLs, HIT, ROW, PT, total; };
+constexpr int PPO_GA_UR = 16;           // rows per round of the sums: the per-row tables are padded to a multiple of it
+struct PpoGaLds { size_t HS, XI, DXg, DGs, DLs, HIT, ROW, IDN, PT, total; };
 __host__ __device__ inline PpoGaLds ppo_ga_lds(const CtrlDims& d) {
     PpoGaLds l;
     const size_t R = (size_t)d.M * d.Q * d.S, RS = (size_t)d.M * d.Q * (d.S + 1);
@@ -837,10 +839,12 @@ __host__ __device__ inline PpoGaLds ppo_ga_lds(const CtrlDims& d) {
     l.HS = o; o += RS * d.H;              // hidden states of every sequence [M Q][S + 1][H]
     l.XI = o; o += R * d.E;               // step inputs
     l.DXg = o; o += R * d.E;              // d step inputs
-    l.DGs = o; o += R * 16;               // the pass's columns of d gates (pitch 16)
-    l.DLs = o; o += (R + 3) / 4 * 4;      // the pass's column of d logits (zero at the other head's steps)
-    l.HIT = o; o += (R + 3) / 4 * 4;      // 1 where the row's input token is the pass's embedding row
-    l.ROW = o; o += (R + 3) / 4 * 4;      // row of h_{t-1} in HS: r + r / S
+    const size_t Rp = (R + PPO_GA_UR - 1) / PPO_GA_UR * PPO_GA_UR;
+    l.DGs = o; o += Rp * 16;              // the pass's columns of d gates (pitch 16), zero rows behind R
+    l.DLs = o; o += Rp;                   // the pass's column of d logits (zero at the other head's steps)
+    l.HIT = o; o += Rp;                   // 1 where the row's input token is the pass's embedding row
+    l.ROW = o; o += Rp;                   // float offset of h_{t-1} in HS: (r + r / S) * H
+    l.IDN = o; o += Rp;                   // float offset of row r in XI / DXg: r * E
     o = (o + 3) / 4 * 4;
     l.PT = o; o += 2 * 28;               // 27 pointers: parameters, exp_avg, exp_avg_sq
     l.total = o;
@@ -849,7 +853,8 @@ __host__ __device__ inline PpoGaLds ppo_ga_lds(const CtrlDims& d) {
 // the staging registers of the gradient phase cover these many rows
 inline bool ppo_ga_fits(const CtrlDims& d) {
     const int R = d.M * d.Q * d.S, RS = d.M * d.Q * (d.S + 1);
-    return RS * (d.H / 4) <= PPO_GA_HS * CT_THREADS && R * (d.E / 4) <= PPO_GA_XI * CT_THREADS && R * 16 <= PPO_GA_DG * CT_THREADS && R <= CT_THREADS;
+    const int Rp = (R + PPO_GA_UR - 1) / PPO_GA_UR * PPO_GA_UR;
+    return RS * (d.H / 4) <= PPO_GA_HS * CT_THREADS && R * (d.E / 4) <= PPO_GA_XI * CT_THREADS && Rp * 16 <= PPO_GA_DG * CT_THREADS && Rp <= CT_THREADS;
 }
 
 
@@ -895,8 +900,10 @@ __global__ __launch_bounds__(CT_THREADS) void k_ppo_grad_adam(CtrlParams P, Ctrl
     {
             const int R = nseq * S, RS = nseq * (S + 1);
             float* HSg = L + Og.HS; float* XI = L + Og.XI; float* DXg = L + Og.DXg; float* DGs = L + Og.DGs; float* DLs = L + Og.DLs;
-            float* HIT = L + Og.HIT; int* ROW = reinterpret_cast<int*>(L + Og.ROW);
-            const int JW = (H4 + nseq - 1) / nseq, AW = (NT + nseq - 1) / nseq;
+            float* HIT = L + Og.HIT; int* ROW = reinterpret_cast<int*>(L + Og.ROW); int* IDN = reinterpret_cast<int*>(L + Og.IDN);
+            const int Rp = (R + PPO_GA_UR - 1) / PPO_GA_UR * PPO_GA_UR;
+            const int NG = gridDim.x;                                       // the parameter slices are per workgroup of THIS grid
+            const int JW = (H4 + NG - 1) / NG, AW = (NT + NG - 1) / NG;
             const int npass = max((JW + PPO_JP - 1) / PPO_JP, AW);
             // role of this thread (the same in every pass): 0 W_hh rows, 1 W_ih rows + biases, 2 head row + its bias, 3 embedding row
             const int role = tid < PPO_JP * (HC / 4) ? 0 : (tid >= PPO_T_WIH && tid < PPO_T_WIH + PPO_JP * (EC / 4)) ? 1 :
@@ -985,18 +992,22 @@ __global__ __launch_bounds__(CT_THREADS) void k_ppo_grad_adam(CtrlParams P, Ctrl
                             reinterpret_cast<float4*>(XI)[tid + i * CT_THREADS] = rx[i];
                             reinterpret_cast<float4*>(DXg)[tid + i * CT_THREADS] = rd[i];
                         }
-                    if (tid < R) ROW[tid] = tid + tid / S;
+                    if (tid < Rp) {
+                        const int r = min(tid, R - 1);
+                        ROW[tid] = (r + r / S) * HC;
+                        IDN[tid] = r * EC;
+                    }
                 } else {
                     lds_barrier();                                              // the previous pass has read its columns
                 }
 #pragma unroll
                 for (int i = 0; i < PPO_GA_DG; ++i) {
                     const int e = tid + i * CT_THREADS;
-                    if (e < R * 16) DGs[e] = rg[i];
+                    if (e < Rp * 16) DGs[e] = e < R * 16 ? rg[i] : 0.0f;
                 }
-                if (tid < R) {
-                    DLs[tid] = (tid & 1) == apar ? rl : 0.0f;               // S is even: row parity = step parity = head
-                    HIT[tid] = has_a && tk == arow ? 1.0f : 0.0f;
+                if (tid < Rp) {
+                    DLs[tid] = tid < R && (tid & 1) == apar ? rl : 0.0f;    // S is even: row parity = step parity = head
+                    HIT[tid] = tid < R && has_a && tk == arow ? 1.0f : 0.0f;
                 }
                 lds_barrier();
                 // ---- the sums over the rows r = (sequence, step), ascending; UR rows' operands in flight at a time.  ONE loop for the four
@@ -1004,24 +1015,26 @@ __global__ __launch_bounds__(CT_THREADS) void k_ppo_grad_adam(CtrlParams P, Ctrl
                 //   sum_r g[r] * y[r][4 k4 ..]   with   g = the row's d gate (roles 0, 1) / its d logit, zero at the other head's steps
                 //   (role 2) / 1 where the row's input token is this embedding row, else 0 (role 3) -- adding 0 * y changes nothing --
                 //   and y = h_{t-1} / x_t / h_t / d x_t
-                constexpr int UR = 16;
+                // No load of the loop is conditional (a padded row has g = 0) and no address needs a multiply (the tables hold float offsets):
+                // a round is 16 table reads, then 32 operand reads, in flight together.
+                constexpr int UR = PPO_GA_UR;
                 float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 float bsum = 0.0f;
                 if (live) {
                     const float* gcol = role <= 1 ? DGs + jj : role == 2 ? DLs : HIT;
-                    const int gstride = role <= 1 ? 16 : 1;
-                    const bool hrows = role == 0 || role == 2;                  // y rows are hidden states: [sequence][S + 1] slots
+                    const int gsh = role <= 1 ? 4 : 0;
+                    const int* rowtab = (role == 0 || role == 2) ? ROW : IDN;      // hidden-state rows: [sequence][S + 1] slots
                     const float* ycol = role == 0 ? HSg + 4 * k4 : role == 1 ? XI + 4 * k4 : role == 2 ? HSg + HC + 4 * min(k4, HC / 4 - 1) : DXg + 4 * k4;
-                    const int pitch = hrows ? HC : EC;
-                    for (int r0 = 0; r0 < R; r0 += UR) {
+                    for (int r0 = 0; r0 < Rp; r0 += UR) {
+                        int yo[UR];
                         float g[UR];
                         float4 y[UR];
 #pragma unroll
+                        for (int i = 0; i < UR; ++i) yo[i] = rowtab[r0 + i];
+#pragma unroll
                         for (int i = 0; i < UR; ++i) {
-                            const int r = min(r0 + i, R - 1);
-                            const int yr = hrows ? ROW[r] : r;
-                            g[i] = r0 + i < R ? gcol[r * gstride] : 0.0f;
-                            y[i] = *reinterpret_cast<const float4*>(ycol + yr * pitch);
+                            g[i] = gcol[(r0 + i) << gsh];
+                            y[i] = *reinterpret_cast<const float4*>(ycol + yo[i]);
                         }
 #pragma unroll
                         for (int i = 0; i < UR; ++i) {
@@ -1515,7 +1528,7 @@ extern "C" int aadg_controller_ppo_update_f32(void* const* params, void* const* 
                 hipLaunchKernelGGL((k_ppo_rollout<CT_E, CT_H>), dim3(grid), dim3(CT_THREADS), lds_r, st, P, d, (float*)ws, policies, old_log_probs,
                                    reward, clip, (unsigned)(step0 + it + 1), loss_terms + (size_t)it * M);
                 AADG_LAUNCH_CHECK();
-                hipLaunchKernelGGL((k_ppo_grad_adam<CT_E, CT_H>), dim3(grid), dim3(CT_THREADS), lds_g, st, P, m1, m2, d, (float*)ws, bc1, bc2_sqrt,
+                hipLaunchKernelGGL((k_ppo_grad_adam<CT_E, CT_H>), dim3(PPO_GA_GRID), dim3(CT_THREADS), lds_g, st, P, m1, m2, d, (float*)ws, bc1, bc2_sqrt,
                                    lr, beta1, beta2, eps);
                 AADG_LAUNCH_CHECK();
             }
