@@ -57,7 +57,7 @@ struct CtrlWs {
     size_t probs;                  // [M][2][CT_MAX_A] partial head-probability sums
     size_t counter;                // 1 int
     // k_ppo_rollout:
-    size_t lpq;                    // [M * Q] 64-bit words {Adam step number of the epoch, sum log-prob of the sequence}
+    size_t lpq;                    // [M * Q] 64-bit words {Adam step number of the epoch, sum log-prob of the sequence}; zero between epochs
     size_t total;
 };
 __host__ __device__ inline int ctrl_n_params(const CtrlDims& d) {
@@ -896,6 +896,8 @@ __global__ __launch_bounds__(CT_THREADS) void k_ppo_grad_adam(CtrlParams P, Ctrl
         PT[0] = P.emb; PT[1] = P.w_ih; PT[2] = P.w_hh; PT[3] = P.b_ih; PT[4] = P.b_hh; PT[5] = P.wop; PT[6] = P.bop; PT[7] = P.wmag; PT[8] = P.bmag;
         for (int i = 0; i < 9; ++i) { PT[9 + i] = exp_avg.p[i]; PT[18 + i] = exp_avg_sq.p[i]; }
     }
+    // the rollout's {step, log-prob} slots: zero again before the next rollout (every tag >= 1 is then fresh, whatever step0 a caller passes)
+    if (w == 0 && tid < nseq) reinterpret_cast<unsigned long long*>(ws + W.lpq)[tid] = 0ull;
     __syncthreads();
     {
             const int R = nseq * S, RS = nseq * (S + 1);
@@ -904,7 +906,6 @@ __global__ __launch_bounds__(CT_THREADS) void k_ppo_grad_adam(CtrlParams P, Ctrl
             const int Rp = (R + PPO_GA_UR - 1) / PPO_GA_UR * PPO_GA_UR;
             const int NG = gridDim.x;                                       // the parameter slices are per workgroup of THIS grid
             const int JW = (H4 + NG - 1) / NG, AW = (NT + NG - 1) / NG;
-            const int npass = max((JW + PPO_JP - 1) / PPO_JP, AW);
             // role of this thread (the same in every pass): 0 W_hh rows, 1 W_ih rows + biases, 2 head row + its bias, 3 embedding row
             const int role = tid < PPO_JP * (HC / 4) ? 0 : (tid >= PPO_T_WIH && tid < PPO_T_WIH + PPO_JP * (EC / 4)) ? 1 :
                              (tid >= PPO_T_HEAD && tid < PPO_T_HEAD + HC / 4 + 1) ? 2 : (tid >= PPO_T_EMB && tid < PPO_T_EMB + EC / 4) ? 3 : 4;
@@ -912,7 +913,10 @@ __global__ __launch_bounds__(CT_THREADS) void k_ppo_grad_adam(CtrlParams P, Ctrl
             const int jj = role == 0 ? l / (HC / 4) : l / (EC / 4);
             const int k4 = role == 0 ? l - jj * (HC / 4) : role == 1 ? l - jj * (EC / 4) : l;
             int tk = -2;                                                    // input token of row `tid` (loaded in the first pass)
-            for (int ps = 0; ps < npass; ++ps) {
+            // ONE pass: the grid (PPO_GA_GRID workgroups) is sized so that a workgroup owns <= PPO_JP gate rows and <= 1 head / embedding row
+            {
+                constexpr int ps = 0;
+                constexpr bool FIRST = true;
                 const int j0 = w * JW + ps * PPO_JP;                            // first gate row of the pass
                 const int jn = max(0, min(min(H4, (w + 1) * JW) - j0, PPO_JP)); // its rows
                 const int arow = w * AW + ps;                                   // head / embedding row of the pass
@@ -952,7 +956,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_ppo_grad_adam(CtrlParams P, Ctrl
                 // d gates and d logits; the parameters and moments this thread will update
                 float4 rh[PPO_GA_HS], rx[PPO_GA_XI], rd[PPO_GA_XI];
                 const int nhs = RS * (HC / 4), nxi = R * (EC / 4);
-                if (ps == 0) {
+                if constexpr (FIRST) {
                     const float4* ghs = reinterpret_cast<const float4*>(ws + W.hprev);
                     const float4* gxi = reinterpret_cast<const float4*>(ws + W.xin);
                     const float4* gdx = reinterpret_cast<const float4*>(ws + W.dx);
@@ -982,7 +986,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_ppo_grad_adam(CtrlParams P, Ctrl
                     pv[0] = *pp; mv[0] = *mp; vv[0] = *vp;
                 }
                 if (blane) { bpv = *bp; bmv = *bm; bvv = *bv; }
-                if (ps == 0) {
+                if constexpr (FIRST) {
 #pragma unroll
                     for (int i = 0; i < PPO_GA_HS; ++i)
                         if (tid + i * CT_THREADS < nhs) reinterpret_cast<float4*>(HSg)[tid + i * CT_THREADS] = rh[i];
@@ -1511,7 +1515,8 @@ extern "C" int aadg_controller_ppo_update_f32(void* const* params, void* const* 
         // the module's widths, short sequences: two short kernels per epoch, one workgroup per sequence
         const int grid = M * Q;
         const size_t lds_r = ppo_lds(d).total * sizeof(float), lds_g = ppo_ga_lds(d).total * sizeof(float);
-        if (fast && S <= PPO_MAX_S && grid <= 128 && lds_r <= 150 * 1024 && lds_g <= 150 * 1024 && ppo_ga_fits(d)) {
+        if (fast && S <= PPO_MAX_S && grid <= 128 && lds_r <= 150 * 1024 && lds_g <= 150 * 1024 && ppo_ga_fits(d) &&
+            (4 * H + PPO_GA_GRID - 1) / PPO_GA_GRID <= PPO_JP && n_ops + n_mags <= PPO_GA_GRID) {
             static size_t set_r = 0, set_g = 0;
             if (lds_r > set_r) {
                 AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ppo_rollout<CT_E, CT_H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));

@@ -558,8 +558,8 @@ def hot_kernels_leg(D=3, B=8, M=6, size=512, K=2, repeats=20):
         ctrl = {"sample_us": float(np.median(ts)) * 1e3, "ppo_update_us": float(np.median(tu)) * 1e3,
                 "replaces": "Controller.sample: ~200 launches; PPO: 5 x (evaluate + surrogate + backward + Adam) ~ 5000 launches eager "
                             "(models/controller.py:73-145, losses.py:117-157)",
-                "bound": "latency (56 260 parameters, M = %d policy rows = %d workgroups)" % (M, M),
-                "note": "event times include the host-side launch sequence of the call (3 + 11 launches)"}
+                "bound": "latency (56 260 parameters; sample: M = %d workgroups; update: one workgroup per sequence = %d, two kernels per epoch)" % (M, 5 * M),
+                "note": "event times include the host-side launch sequence of the call (1 + 10 launches); round 4: 325-335 us for the update"}
     except Exception as e:  # noqa: BLE001
         ctrl = {"error": repr(e)}
     # the scaled synthetic of SURVEY 8(d): 3 problems of 4096 x 4096 points, E = 128 -- the cost matrices no longer fit LDS, the large-cloud

@@ -503,6 +503,9 @@ int aadg_conv3x3_wgrad_f32x3(const float* dy, const float* x, float* dweight9, i
  * ppo_update: n_updates x { evaluate(policies) -> ratio = exp(lp - old) -> -min(ratio R, clip(ratio, 1 -+ clip) R).mean()
  *   -> backward -> Adam(lr, beta1, beta2, eps; step = step0 + 1 ...) } in place on params / exp_avg / exp_avg_sq;
  *   loss_terms [n_updates, M] receives the per-row surrogate terms (their mean over M is the update's loss).
+ *   (round 5: for the module's widths 32 / 100, S <= 8 and M Q S <= 128 an epoch is two launches of M Q workgroups, one per
+ *   (policy, sub-policy) sequence -- k_ppo_rollout, k_ppo_grad_adam -- instead of the M-workgroup rollout + per-parameter Adam.)
+ * `ws`: aadg_controller_workspace_bytes() bytes, ZERO-filled once by the caller before the first call, then owned by the kernels.
  * ------------------------------------------------------------------------------------------- */
 int aadg_controller_supported(int M, int Q, int S, int E, int H, int n_ops, int n_mags);
 size_t aadg_controller_workspace_bytes(int M, int Q, int S, int E, int H, int n_ops, int n_mags);
