@@ -1671,6 +1671,7 @@ __device__ __forceinline__ void gen_hpass_pipe(const uint8_t* __restrict__ pool,
     const int sc = sharp_count4(un, n_ops);
     if ((Ws & 3) || (crop & 3) || sc > MAX_SHARP || (w >= Ws && h >= Hs) || 2 * w < Ws || 2 * h < Hs) return;      // not a FLOW_GENERIC unit
     if ((sc > 0) != SHARP) return;                              // the other variant owns this unit
+    if (!SHARP && h >= Hs && Ws >= 8) return;                   // shrinks the width only: k_fused3w's unit (one pass)
     const int s = SHARP ? sc : 0;
     const int ROWS = GH_PATCH_ROWS - 2 * s;                     // the patch holds the block's rows + the stencils' halo
     const int tid = threadIdx.x;
@@ -1885,6 +1886,7 @@ __global__ __launch_bounds__(256) void k_gen_vpass(const uint8_t* __restrict__ m
     const int u = order != nullptr ? order[slot] : slot;
     const aadg_unit& un = units[u];
     if (unit_flow(true, un, Hs, Ws, crop) != FLOW_GENERIC) return;
+    if (un.scaled_h >= Hs && Ws >= 8 && sharp_count4(un, un.n_ops) == 0) return;      // k_fused3w's unit
     __shared__ float lutf[256];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // uniform: the row tables become scalar loads
@@ -2197,6 +2199,220 @@ __global__ __launch_bounds__(256) void k_fused3(const uint8_t* __restrict__ pool
                  blockIdx.x, blockIdx.y, blockIdx.z, A, B, sl, lutf);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_fused3w (round 5): ONE pass for the down-scaling units that shrink the WIDTH only (scaled height >= source height, no Sharpness
+// stencil: 40 % of the RVS pipeline's down-scaling units).  Their vertical pass is the up-scaling one (<= 2 taps, 17 source rows per
+// 16-row tile), so the tile is k_fused3's with 128 output columns: the <= 2 * 128 + 5 source columns (+ alignment) x 17 rows of the
+// patch fit k_fused3's patch buffer, the horizontally resampled rows its second buffer -- the same 39 KiB of LDS, 4 workgroups per
+// CU -- and the unit no longer writes and re-reads the RGBX intermediate of the two passes (4 bytes x source rows x output columns).
+//   horizontal pass: thread <-> (output column, row parity), <= 5 taps (hpass_px, the two-pass kernel's arithmetic);
+//   vertical pass:   half-wave <-> output row, lane <-> 4 columns, <= 2 taps (k_fused3's arithmetic); the 4 NEAREST mask bytes of a
+//                    lane lie within 8 consecutive source bytes (the axis shrinks by at most 2).
+// Results are those of k_gen_hpass + k_gen_vpass (Pillow's order: the horizontal pass rounded to uint8 first), bit for bit.
+// ------------------------------------------------------------------------------------------------
+constexpr int FW_W = 128;
+
+__device__ __forceinline__ bool unit_wonly(const aadg_unit& un, int Hs, int Ws, int crop) {     // generic, plain, shrinks the width only
+    return Ws >= 8 && unit_flow(true, un, Hs, Ws, crop) == FLOW_GENERIC && un.scaled_h >= Hs && sharp_count4(un, un.n_ops) == 0;
+}
+
+__global__ __launch_bounds__(256) void k_fused3w(const uint8_t* __restrict__ pool, const uint8_t* __restrict__ masks,
+                                                 const aadg_unit* __restrict__ units, const int* __restrict__ order, int Hs, int Ws, int crop,
+                                                 int dataset_in, const int* __restrict__ tab, const uint8_t* __restrict__ lut,
+                                                 size_t lut_stage_stride, float* __restrict__ out_img, float* __restrict__ out_lbl) {
+    __shared__ __attribute__((aligned(16))) uint32_t A[PATCH_CAP_PLAIN];
+    __shared__ __attribute__((aligned(16))) uint32_t B[HBUF_ROWS * FT_W];
+    __shared__ __attribute__((aligned(16))) uint8_t sl[AADG_MAX_OPS * 768];
+    __shared__ float lutf[256];
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int u = order != nullptr ? order[blockIdx.z] : (int)blockIdx.z;
+    const int dataset = dataset_in & 0xFF;
+    const bool stream_out = (dataset_in & AUG_STREAM_OUT) != 0;
+    const aadg_unit& un = units[u];
+    const int n_ops = un.n_ops;
+    const int w = un.scaled_w, h = un.scaled_h;
+    const int u_pad = un.pad, u_cx = un.crop_x, u_cy = un.crop_y, u_src = un.src;
+    const int sc_all = sharp_count4(un, n_ops);
+    if ((Ws & 3) || (crop & 3) || Ws < 8 || sc_all != 0 || w >= Ws || 2 * w < Ws || h < Hs) return;      // not a width-only unit (unit_wonly)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    lutf[tid] = normalise_u8(tid);
+
+    const int K = dataset == AADG_DATASET_OPTIC ? 2 : 1;
+    const uint32_t plane = (uint32_t)crop * (uint32_t)crop;
+    float* oi = out_img + (size_t)u * 3 * plane;
+    float* ol = out_lbl + (size_t)u * K * plane;
+    const int x0 = bx * FW_W, x1 = min(x0 + FW_W, crop);
+    const int y0 = by * FT_H, y1 = min(y0 + FT_H, crop);
+    if (y0 >= crop || x0 >= crop) return;
+    const int ox = u_cx - u_pad, oy = u_cy - u_pad;
+    const int fx = max(x0, -ox), lx = min(x1 - 1, w - 1 - ox);
+    const int lh = lane & 31, rsub = lane >> 5;             // vertical pass: half-wave <-> row, lane of the half <-> 4 consecutive columns
+    const int xq = x0 + 4 * lh;
+    const bool col_ok = xq < x1;
+    constexpr int RPW = FT_H / 8;                           // row pairs per wave
+    auto pad_rows = [&](int ya, int yb) {
+        if (!col_ok) return;
+        const float lab0 = dataset == AADG_DATASET_OPTIC ? 1.0f : 0.0f;
+        const float4 m1 = make_float4(-1.0f, -1.0f, -1.0f, -1.0f), lb = make_float4(lab0, lab0, lab0, lab0);
+        for (int y = ya + 2 * wv + rsub; y < yb; y += 8) {
+            const uint32_t off = (uint32_t)y * (uint32_t)crop + (uint32_t)xq;
+            store_out4(oi + off, m1, stream_out);
+            store_out4(oi + plane + off, m1, stream_out);
+            store_out4(oi + 2 * (size_t)plane + off, m1, stream_out);
+            store_out4(ol + off, lb, stream_out);
+            if (K == 2) store_out4(ol + plane + off, make_float4(1.0f, 1.0f, 1.0f, 1.0f), stream_out);
+        }
+    };
+    const int* base = tab + (size_t)u * crop * TAB_STRIDE;
+    const int* xmin_t = base;
+    const int* xk_t = xmin_t + crop;
+    const int* ymin_t = xk_t + (size_t)crop * KMAX;
+    const int* yk_t = ymin_t + crop;
+    const int* xnn_t = yk_t + (size_t)crop * KMAX;
+    const int* ynn_t = xnn_t + crop;
+    const bool resy = h != Hs;
+
+    // ---- every table entry of the tile in one batch of loads (clamped indices: no load is conditional) ----
+    const int ya = y0, yb = y1;
+    const int fy = max(ya, -oy), ly = min(yb - 1, h - 1 - oy);
+    const int cl = crop - 1;
+    const int t_clo = xmin_t[min(max(fx, 0), cl)], t_chi = xmin_t[min(max(lx, 0), cl)];
+    const int t_rlo = ymin_t[min(max(fy, 0), cl)], t_rhi = ymin_t[min(max(ly, 0), cl)];
+    int vym[RPW], vyn[RPW];
+    uint32_t vk0[RPW], vk1[RPW];
+    const int wvv = tid >> 6;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int yc = min(ya + 2 * (wvv + 4 * r) + rsub, yb - 1);
+        vym[r] = ymin_t[yc];
+        vyn[r] = ynn_t[yc];
+        const int2 ky = *reinterpret_cast<const int2*>(yk_t + (size_t)yc * KMAX);
+        vk0[r] = prescale4(ky.x); vk1[r] = prescale4(ky.y);
+    }
+    const int hc = tid & (FW_W - 1);                        // horizontal pass: thread <-> (output column, row parity: uniform per wave)
+    const int hg = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int xh = x0 + hc;
+    const int xhc = min(max(min(max(xh, fx), lx), 0), cl);
+    int hxm = xmin_t[xhc];
+    int kraw[GT_TAPS];
+#pragma unroll
+    for (int t = 0; t < GT_TAPS; ++t) kraw[t] = xk_t[(size_t)xhc * KMAX + t];
+    const int4 xn4 = *reinterpret_cast<const int4*>(xnn_t + min(xq, crop - 4));
+    if (fx > lx || fy > ly) { pad_rows(y0, y1); return; }   // no valid column / row in this tile
+    const int ntx = axis_taps(Ws, w);
+    uint32_t hk[GT_TAPS];
+#pragma unroll
+    for (int t = 0; t < GT_TAPS; ++t) hk[t] = t < ntx ? prescale4(kraw[t]) : 0u;
+    if (xh < fx || xh > lx) hxm = -1;                       // pad column
+    const int xn[4] = {xn4.x, xn4.y, xn4.z, xn4.w};
+    const uint8_t* msk = masks + (size_t)u_src * Hs * Ws;
+    const uint8_t* src = pool + (size_t)u_src * Hs * Ws * 3;
+    const uint32_t lbl_t0 = dataset == AADG_DATASET_OPTIC ? 50u : 0u;
+    const bool lbl_flip = dataset != AADG_DATASET_OPTIC;
+    const char* lutb = reinterpret_cast<const char*>(lutf);
+
+    // ---- patch -> LDS with the op chain applied ----
+    const int r_lo = t_rlo;
+    const int nty = resy ? 2 : 1;
+    const int r_hi = min(Hs, t_rhi + nty);
+    const int c_hi = min(Ws, t_chi + ntx);
+    const int c_lo_h = t_clo & ~3, c_hi_h = min(Ws, (c_hi + 3) & ~3);
+    const int pw = c_hi_h - c_lo_h;
+    const uint32_t* cur = build_patch<5, 2>(un, n_ops, src, Hs, Ws, r_lo, r_hi, c_lo_h, c_hi_h, A, B, lut, lut_stage_stride, u, sl);
+    uint32_t* Hbuf = cur == A ? B : A;
+    // mask: the bytes of this lane's 4 columns lie within 8 consecutive source bytes: two (unaligned) dwords per row
+    uint32_t mlo[RPW], mhi[RPW], msh[4], mkeep[4];
+    {
+        int mbase = -1;
+#pragma unroll
+        for (int i = 3; i >= 0; --i) mbase = xn[i] >= 0 ? xn[i] : mbase;      // first valid column of the lane
+        const bool lane_has = mbase >= 0;
+        mbase = min(max(mbase, 0), Ws - 8);                                    // keep the 8-byte window inside the row
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sh = xn[i] - mbase;
+            const bool ok = xn[i] >= 0 && lane_has && sh >= 0 && sh < 8;
+            msh[i] = ok ? 8u * (uint32_t)sh : 0u;
+            mkeep[i] = ok ? 255u : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {                                        // unconditional: pad rows read row 0, result unused
+            const uint8_t* mrow = msk + (size_t)max(vyn[r], 0) * Ws + mbase;
+            mlo[r] = reinterpret_cast<const UnalignedU32*>(mrow)->v;
+            mhi[r] = reinterpret_cast<const UnalignedU32*>(mrow + 4)->v;
+        }
+    }
+    // ---- horizontal pass into the other buffer: rows hg, hg + 2, ... of the patch ----
+    const int nrows = r_hi - r_lo;
+    uint32_t* hout = Hbuf + hc;
+    if (hxm >= 0) {
+        const uint32_t* colp = cur + (hxm - c_lo_h);
+#define AADG_FW_ROWS(NT) _Pragma("unroll 2") for (int rr = hg; rr < nrows; rr += 2) hout[rr * FW_W] = hpass_px<NT>(colp + rr * pw, hk)
+        switch (ntx) {                                        // uniform per unit
+            case 3: AADG_FW_ROWS(3); break;
+            case 4: AADG_FW_ROWS(4); break;
+            default: AADG_FW_ROWS(GT_TAPS); break;
+        }
+#undef AADG_FW_ROWS
+    } else {
+        for (int rr = hg; rr < nrows; rr += 2) hout[rr * FW_W] = 0u;
+    }
+    __syncthreads();
+
+    // ---- vertical pass + normalise + store ----
+    if (col_ok) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int y = ya + 2 * (wv + 4 * r) + rsub;
+            if (y >= yb) continue;
+            const int ym = vym[r];
+            float o[3][4];
+            if (ym >= 0) {
+                const uint32_t ky0 = vk0[r], ky1 = vk1[r];
+                const uint4 h0 = *reinterpret_cast<const uint4*>(Hbuf + (ym - r_lo) * FW_W + 4 * lh);
+                const uint32_t a0[4] = {h0.x, h0.y, h0.z, h0.w};
+                if (resy) {
+                    const uint4 h1 = *reinterpret_cast<const uint4*>(Hbuf + (ym + (ky1 ? 1 : 0) - r_lo) * FW_W + 4 * lh);
+                    const uint32_t a1[4] = {h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const uint32_t v = (1u << 23) + __umul24((a0[i] >> (8 * c)) & 255u, ky0) + __umul24((a1[i] >> (8 * c)) & 255u, ky1);
+                            o[c][i] = *reinterpret_cast<const float*>(lutb + ((v >> 24) << 2));
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) o[c][i] = *reinterpret_cast<const float*>(lutb + (((a0[i] >> (8 * c)) & 255u) << 2));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (xq + i < fx || xq + i > lx) o[0][i] = o[1][i] = o[2][i] = -1.0f;      // pad columns: normalise(0)
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[0][i] = o[1][i] = o[2][i] = -1.0f;              // pad rows
+            }
+            float l0[4], l1[4];
+            const unsigned long long mrow = vyn[r] >= 0 ? (((unsigned long long)mhi[r] << 32) | mlo[r]) : 0ull;      // pad rows: mask 0
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t m = (uint32_t)(mrow >> msh[i]) & mkeep[i];
+                l0[i] = ((m <= lbl_t0) != lbl_flip) ? 1.0f : 0.0f;
+                l1[i] = m <= 200u ? 1.0f : 0.0f;
+            }
+            const uint32_t off = (uint32_t)y * (uint32_t)crop + (uint32_t)xq;
+            store_out4(oi + off, make_float4(o[0][0], o[0][1], o[0][2], o[0][3]), stream_out);
+            store_out4(oi + plane + off, make_float4(o[1][0], o[1][1], o[1][2], o[1][3]), stream_out);
+            store_out4(oi + 2 * (size_t)plane + off, make_float4(o[2][0], o[2][1], o[2][2], o[2][3]), stream_out);
+            store_out4(ol + off, make_float4(l0[0], l0[1], l0[2], l0[3]), stream_out);
+            if (K == 2) store_out4(ol + plane + off, make_float4(l1[0], l1[1], l1[2], l1[3]), stream_out);
+        }
+    }
+}
+
 // list slots per chunk of the two-pass generic flow: as many as keep the chunk's intermediate (Hs x crop words per slot) within 128 MB, half of
 // the Infinity Cache -- 32 slots at 1024 x 1024 (measured there, 86 generic units of 168: all at once 0.914 ms for the batch's tile kernels,
 // chunks of 8 / 16 / 24 / 32 / 48 / 64 slots 0.971 / 0.909 / 0.870 / 0.862 / 0.910 / 0.931 ms).  aadg_aug_lists.gen_chunk (ABI 7) asks for
@@ -2239,7 +2455,7 @@ constexpr int HINT_FUSED = 1, HINT_STAGED = 2, HINT_GENERIC = 4;
 // two passes (0 = gen_chunk(); never more than that: the workspace holds one default chunk).
 int launch_tiles(const uint8_t* pool, const uint8_t* masks, const aadg_unit* units, const int* order_up, int np, int ns, const int* order_gen,
                  int ng, int ng_sharp, int Hs, int Ws, int crop, int dsk, const int* tab, const uint8_t* lut, size_t lut_stage_stride,
-                 uint32_t* hbuf, float* out_img, float* out_lbl, hipStream_t st, int chunk_req = 0) {
+                 uint32_t* hbuf, float* out_img, float* out_lbl, hipStream_t st, int chunk_req = 0, int ng_wonly = 0) {
     const int gx = (crop + FT_W - 1) / FT_W, gy = (crop + FT_H - 1) / FT_H, gz = np + 2 * ns;
     const int* order_sharp = order_up != nullptr ? order_up + np : nullptr;
     // with the caller's list the stencil units are the last ng_sharp entries; without one every unit is offered to both variants
@@ -2254,12 +2470,19 @@ int launch_tiles(const uint8_t* pool, const uint8_t* masks, const aadg_unit* uni
         AADG_LAUNCH_CHECK();
     }
     if (ng <= 0) return 0;
+    // the width-only units (ABI 9: the FIRST ng_wonly slots of the caller's list; without a list every slot is offered): one pass
+    const int nw = listed ? ng_wonly : 0;
+    if ((listed ? nw : ng) > 0 && Ws >= 8) {
+        hipLaunchKernelGGL(k_fused3w, dim3((crop + FW_W - 1) / FW_W, gy, listed ? nw : ng), dim3(256), 0, st, pool, masks, units, order_gen, Hs, Ws, crop,
+                           dsk, tab, lut, lut_stage_stride, out_img, out_lbl);
+        AADG_LAUNCH_CHECK();
+    }
     // The generic units go through the two passes in chunks of gen_chunk() list slots that share ONE slice of the intermediate: what the
     // horizontal pass writes is read back by the vertical pass while it is still in the Infinity Cache (256 MB; 4 MB per unit at
     // 1024 x 1024), instead of after the whole batch's intermediate has gone to HBM and come back.
     const int chunk = (chunk_req > 0 && chunk_req < gen_chunk(Hs, crop)) ? chunk_req : gen_chunk(Hs, crop);
     const int hy1 = (Hs + GhRows<true>::value - 1) / GhRows<true>::value;
-    for (int a = 0; a < ng; a += chunk) {
+    for (int a = nw; a < ng; a += chunk) {
         const int b = min(ng, a + chunk);
         // listed: plain units are slots [0, n0), stencil units [s1, ng); unlisted: every slot is offered to both variants
         const int p0 = a, p1 = min(b, n0);
@@ -2393,7 +2616,7 @@ int forward_cached(const uint8_t* pool, const uint8_t* masks, const UnitRef& ur,
     if (ev_before) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_before), st));
     {
         const int rc = launch_tiles(pool, masks, ur.units, ls.order, n_plain, n_sharp, ls.order + n_plain + n_sharp, n_generic, ls.n_generic_sharp, Hs, Ws,
-                                    crop, dsk, tab, lut, lut_stage_stride, reinterpret_cast<uint32_t*>(ws8 + L.hbuf), out_img, out_lbl, st, ls.gen_chunk);
+                                    crop, dsk, tab, lut, lut_stage_stride, reinterpret_cast<uint32_t*>(ws8 + L.hbuf), out_img, out_lbl, st, ls.gen_chunk, ls.n_generic_wonly);
         if (rc) return rc;
     }
     if (ev_after) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_after), st));
@@ -2408,7 +2631,7 @@ extern "C" int aadg_aug_u8_plan(const aadg_unit* units, int N, int P, int Hs, in
     if (units == nullptr || order == nullptr || stat_units == nullptr || late_units == nullptr || summary == nullptr) return AADG_E_BADARG;
     if (N <= 0 || P <= 0 || Hs <= 0 || Ws <= 0 || crop <= 0) return AADG_E_BADARG;
     const bool tiles_ok = !((Ws & 3) || (crop & 3));
-    int n_cls[5] = {0, 0, 0, 0, 0}, n_stat[AADG_MAX_OPS], n_sten[AADG_MAX_OPS], n_late = 0, max_ops = 0, classes = 0, stats_mask = 0;
+    int n_cls[6] = {0, 0, 0, 0, 0, 0}, n_stat[AADG_MAX_OPS], n_sten[AADG_MAX_OPS], n_late = 0, max_ops = 0, classes = 0, stats_mask = 0;
     for (int k = 0; k < AADG_MAX_OPS; ++k) n_stat[k] = n_sten[k] = 0;
     // pass 1: validation, class and statistics lists (late_units doubles as the per-unit class until the counting sort below)
     for (int i = 0; i < N; ++i) {
@@ -2430,7 +2653,9 @@ extern "C" int aadg_aug_u8_plan(const aadg_unit* units, int N, int P, int Hs, in
         const bool ok = tiles_ok && sharp <= MAX_SHARP;
         const bool up = ok && u.scaled_w >= Ws && u.scaled_h >= Hs;
         const bool generic = ok && !up && 2 * (long long)u.scaled_w >= Ws && 2 * (long long)u.scaled_h >= Hs;
-        const int cls = up ? (sharp == 0 ? 0 : 1) : generic ? (sharp == 0 ? 2 : 3) : 4;
+        // generic without a stencil: the units that shrink the width only first (ABI 9: k_fused3w's list), then the others
+        const bool wonly = generic && sharp == 0 && u.scaled_h >= Hs && Ws >= 8;
+        const int cls = up ? (sharp == 0 ? 0 : 1) : generic ? (sharp == 0 ? (wonly ? 2 : 3) : 4) : 5;
         classes |= up ? HINT_FUSED : generic ? HINT_GENERIC : HINT_STAGED;
         ++n_cls[cls];
         // statistics: a pixel pass per op that needs the image's statistics, unless the histogram can be pushed forward from the raw
@@ -2476,18 +2701,19 @@ extern "C" int aadg_aug_u8_plan(const aadg_unit* units, int N, int P, int Hs, in
         for (size_t t = 0; t < rest.size(); ++t) row[w++] = rest[t];
     }
     // pass 2: stable counting sort by class; the late list in place (its write position never passes the read position)
-    int off[5];
+    int off[6];
     off[0] = 0;
-    for (int c = 1; c < 5; ++c) off[c] = off[c - 1] + n_cls[c - 1];
+    for (int c = 1; c < 6; ++c) off[c] = off[c - 1] + n_cls[c - 1];
     for (int i = 0; i < N; ++i) {
         const int v = late_units[i];
         order[off[v & 7]++] = i;
         if (v & 8) late_units[n_late++] = i;
     }
-    summary[0] = n_cls[0]; summary[1] = n_cls[1]; summary[2] = n_cls[2] + n_cls[3]; summary[3] = n_cls[3];
+    summary[0] = n_cls[0]; summary[1] = n_cls[1]; summary[2] = n_cls[2] + n_cls[3] + n_cls[4]; summary[3] = n_cls[4];
     summary[4] = n_late; summary[5] = classes; summary[6] = stats_mask; summary[7] = max_ops;
     for (int k = 0; k < AADG_MAX_OPS; ++k) summary[8 + k] = n_stat[k];
     for (int k = 0; k < AADG_MAX_OPS; ++k) summary[8 + AADG_MAX_OPS + k] = n_sten[k];
+    summary[8 + 2 * AADG_MAX_OPS] = n_cls[2];
     return 0;
 }
 
@@ -2524,6 +2750,7 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
     if ((size_t)N * (size_t)crop > (size_t)1 << 28) return AADG_E_BADARG;
     if (order != nullptr && (n_plain < 0 || n_sharp < 0 || n_generic < 0 || (long long)n_plain + n_sharp + n_generic > N)) return AADG_E_BADARG;
     if (order != nullptr && (lists->n_generic_sharp < 0 || lists->n_generic_sharp > n_generic)) return AADG_E_BADARG;
+    if (order != nullptr && (lists->n_generic_wonly < 0 || lists->n_generic_wonly > n_generic - lists->n_generic_sharp)) return AADG_E_BADARG;
     const WsLayout L = ws_layout(N, Hs, Ws, crop);
     const int dsk = aug_dataset_arg(dataset, N, crop);
     if (ws_bytes < L.total) return AADG_E_WORKSPACE;
@@ -2563,13 +2790,13 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
         const int ng = (classes & HINT_GENERIC) ? (order ? n_generic : N) : 0;
         const int rc2 = launch_tiles(pool, masks, units, order, np, ns, order ? order + n_plain + n_sharp : nullptr, ng,
                                      lists ? lists->n_generic_sharp : 0, Hs, Ws, crop, dsk, tab, ws8 + L.lut, (size_t)N * 768,
-                                     reinterpret_cast<uint32_t*>(ws8 + L.hbuf), out_img, out_lbl, st, chunk_req);
+                                     reinterpret_cast<uint32_t*>(ws8 + L.hbuf), out_img, out_lbl, st, chunk_req, lists ? lists->n_generic_wonly : 0);
         if (rc2) return rc2;
     } else if (classes & HINT_GENERIC) {
         const int ng = order ? n_generic : N;
         const int rc2 = launch_tiles(pool, masks, units, nullptr, 0, 0, order ? order + n_plain + n_sharp : nullptr, ng, lists ? lists->n_generic_sharp : 0,
                                      Hs, Ws, crop, dsk, tab, ws8 + L.lut, (size_t)N * 768, reinterpret_cast<uint32_t*>(ws8 + L.hbuf), out_img, out_lbl,
-                                     st, chunk_req);
+                                     st, chunk_req, lists ? lists->n_generic_wonly : 0);
         if (rc2) return rc2;
     }
     if (classes & HINT_STAGED) {

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AADG_ABI_VERSION 8
+#define AADG_ABI_VERSION 9
 #define AADG_MAX_OPS 4
 
 #define AADG_E_BADARG (-1)
@@ -103,7 +103,8 @@ int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks, int P, int
  * class returns at once but still occupies a slot with its LDS for about a microsecond).
  *   order       int32 [N]: unit indices grouped by tile class -- first the n_plain up-scaling units (both scaled sizes >= the
  *               source's) that chain no Sharpness stencil, then the n_sharp up-scaling units that do, then the n_generic units that
- *               shrink an axis by at most 2x -- among them LAST the n_generic_sharp ones that chain a Sharpness stencil (ABI 5: their
+ *               shrink an axis by at most 2x -- among them FIRST the n_generic_wonly ones that shrink the width only and chain no
+ *               stencil (ABI 9: one-pass tile), LAST the n_generic_sharp ones that chain a Sharpness stencil (ABI 5: their
  *               horizontal pass is a launch of its own, with the stencil's ping-pong buffer) --; the remaining (staged) units follow
  *               in any order.
  *   stat_units  per op slot k: the n_stat[k] units whose k-th op needs image statistics (AutoContrast / Equalize / Contrast) --
@@ -137,6 +138,9 @@ typedef struct aadg_aug_lists {
      * slice of the workspace).  0 = the library's choice (as many as keep a chunk's intermediate within 128 MB); a smaller positive
      * value is honoured (tests of the chunk boundaries), a larger one is clamped to the library's. */
     int32_t gen_chunk;
+    /* ABI 9: how many of the n_generic units -- the FIRST ones in `order`, none of them a Sharpness unit -- shrink the WIDTH only (scaled
+     * height >= source height, source width >= 8): they run through the one-pass tile k_fused3w instead of the two passes. */
+    int32_t n_generic_wonly;
 } aadg_aug_lists;
 /* per-image histograms of a source pool [P, Hs, Ws, 3] (what PIL's Image.histogram() / ImageStat.Stat(convert('L')).mean read:
  * data/basic.py AutoContrast / Equalize / Contrast via ImageOps / ImageEnhance) */
@@ -151,8 +155,9 @@ int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks, int P, in
  * scale factor below 1/3, Cutout box not clipped to the image, Posterize bits) and fills the work lists `aadg_aug_lists` carries -- no GPU
  * work, host pointers (the caller copies the lists to the device next to the records).
  *   order [N]: unit indices by tile class;  stat_units [AADG_MAX_OPS][N]: per op slot the units that need a statistics pass;
- *   late_units [N];  summary [8 + 2 * AADG_MAX_OPS] = n_plain, n_sharp, n_generic, n_generic_sharp, n_late, classes_hint, stats_mask_hint,
- *   max_ops, n_stat[0 .. AADG_MAX_OPS), n_stat_stencil[0 .. AADG_MAX_OPS) (ABI 7; stat_units[k] lists the stencil units first).  (The reference does this work implicitly, op by op, in PIL: data/policy.py:45-61.) */
+ *   late_units [N];  summary [9 + 2 * AADG_MAX_OPS] = n_plain, n_sharp, n_generic, n_generic_sharp, n_late, classes_hint, stats_mask_hint,
+ *   max_ops, n_stat[0 .. AADG_MAX_OPS), n_stat_stencil[0 .. AADG_MAX_OPS) (ABI 7; stat_units[k] lists the stencil units first),
+ *   n_generic_wonly (ABI 9).  (The reference does this work implicitly, op by op, in PIL: data/policy.py:45-61.) */
 int aadg_aug_u8_plan(const aadg_unit* units, int N, int P, int Hs, int Ws, int crop, int32_t* order, int32_t* stat_units,
                      int32_t* late_units, int32_t* summary);
 

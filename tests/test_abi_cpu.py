@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libaadg_hip.so does not export %s" % name
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.aadg_abi_version() == 8
+    assert lib.aadg_abi_version() == 9
 
 
 def test_unit_struct_layout_matches_header():
@@ -187,7 +187,10 @@ def test_round2_entry_points_validate_arguments():
     lists = _lib.AugLists()
     lists.gen_chunk = -1
     assert lib.aadg_aug_u8_forward_ex2(one, one, 1, 8, 8, one, 4, 2, 8, 0, one, one, one, 1 << 30, z, 0, -1, z, z, ctypes.byref(lists)) == -1
-    assert ctypes.sizeof(_lib.AugLists) == 8 + 16 + 8 * _lib.MAX_OPS + 4 * _lib.MAX_OPS + 8 + 8 + 8 + 4 * _lib.MAX_OPS + 8   # mirror of aadg_aug_lists (n_generic_sharp fills the padding behind n_late; ABI 7: n_stat_stencil, gen_chunk + tail padding)
+    assert ctypes.sizeof(_lib.AugLists) == 8 + 16 + 8 * _lib.MAX_OPS + 4 * _lib.MAX_OPS + 8 + 8 + 8 + 4 * _lib.MAX_OPS + 8   # mirror of aadg_aug_lists (n_generic_sharp fills the padding behind n_late; ABI 7: n_stat_stencil, gen_chunk; ABI 9: n_generic_wonly in the former tail padding)
+    lists = _lib.AugLists()
+    lists.order, lists.n_generic, lists.n_generic_sharp, lists.n_generic_wonly = 16, 3, 2, 2      # ABI 9: more width-only units than plain generic ones
+    assert lib.aadg_aug_u8_forward_ex2(one, one, 1, 8, 8, one, 4, 2, 8, 0, one, one, one, 1 << 30, z, 0, -1, z, z, ctypes.byref(lists)) == -1
 
 
 def test_round3_entry_points_validate_arguments():
@@ -225,7 +228,7 @@ def test_host_planner_matches_python_statement():
     lib = _lib.load()
     K = _lib.MAX_OPS
     rs = np.random.RandomState(11)
-    seen_mixed = False
+    seen_mixed = seen_wonly = False
     for (H, crop, sr, L, N) in ((64, 64, (1.0, 1.5), 2, 97), (96, 64, (0.5, 2.0), 4, 160), (128, 96, (0.34, 0.6), 3, 50), (33, 31, (1.0, 1.5), 2, 40),
                                 (64, 64, (0.5, 2.0), 4, 1)):
         P = 7
@@ -241,11 +244,13 @@ def test_host_planner_matches_python_statement():
         order = np.full(N, -1, np.int32)
         stat = np.full((K, N), -1, np.int32)
         late = np.full(N, -1, np.int32)
-        summary = (ctypes.c_int32 * (8 + 2 * K))()
+        summary = (ctypes.c_int32 * (9 + 2 * K))()
         rc = lib.aadg_aug_u8_plan(cont.ctypes.data, N, P, H, H, crop, order.ctypes.data, stat.ctypes.data, late.ctypes.data, summary)
         assert rc == 0
-        classes, stats_mask, want_order, counts, stat_lists, want_late, n_sten = _lib.launch_plan(units, H, H, crop)
+        classes, stats_mask, want_order, counts, stat_lists, want_late, n_sten, n_wonly = _lib.launch_plan(units, H, H, crop)
         assert tuple(summary[:4]) == tuple(counts) and summary[5] == classes and summary[6] == stats_mask
+        assert summary[8 + 2 * K] == n_wonly                             # ABI 9: the width-only units lead the generic run
+        seen_wonly = seen_wonly or 0 < n_wonly < counts[2] - counts[3]
         assert summary[7] == _lib.validate_units(units, P, H, H)
         assert np.array_equal(order, want_order)
         for k in range(K):
@@ -254,6 +259,7 @@ def test_host_planner_matches_python_statement():
         seen_mixed = seen_mixed or any(0 < n_sten[k] < stat_lists[k].size for k in range(1, K))
         assert summary[4] == want_late.size and np.array_equal(late[:want_late.size], want_late)
     assert seen_mixed                 # a list with both kinds of unit was among the cases
+    assert seen_wonly                 # ... and a generic run with both width-only and other plain units
 
     def refused(mutate):
         units = random_units(np.random.RandomState(3), 8, 4, 64, 64, 64, (1.0, 1.5))
@@ -262,7 +268,7 @@ def test_host_planner_matches_python_statement():
         cont = np.ascontiguousarray(units)
         bufs = [np.zeros(8 * (K if i == 1 else 1), np.int32) for i in range(3)]
         rc = lib.aadg_aug_u8_plan(cont.ctypes.data, 8, 4, 64, 64, 64, bufs[0].ctypes.data, bufs[1].ctypes.data, bufs[2].ctypes.data,
-                                  (ctypes.c_int32 * (8 + 2 * K))())
+                                  (ctypes.c_int32 * (9 + 2 * K))())
         with pytest.raises(_lib.AadgError):
             _lib.validate_units(units, 4, 64, 64)
         return rc

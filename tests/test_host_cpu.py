@@ -338,11 +338,13 @@ def test_launch_plan_classes_statistics_and_late_units():
         unit([(AC, 0), (SHA, 1.2), (EQ, 0)], 20, 64),   # 8 shrinks by > 2: staged; staged units never push forward
         unit([(SHA, 1.2), (SHA, 1.3), (SHA, 1.4)]),     # 9 three stencils: staged
         unit([(SHA, 1.2)], sw=64, sh=40),               # 10 shrinks y by < 2 with a stencil: generic, listed behind the plain generic units
+        unit([(BRI, 1.1)], sw=70, sh=40),               # 11 shrinks y only: generic, two passes
+        unit([(SHA, 1.2)], sw=40, sh=70),               # 12 shrinks x only but chains a stencil: generic with a stencil (two passes)
     ])
-    classes, stats_mask, order, counts, stat_lists, late, _ = _lib.launch_plan(units, H, W, crop)
+    classes, stats_mask, order, counts, stat_lists, late, _, n_wonly = _lib.launch_plan(units, H, W, crop)
     assert classes == 1 | 2 | 4
-    assert counts == (6, 1, 2, 1)
-    assert sorted(order[:6].tolist()) == [0, 1, 2, 3, 4, 6] and order[6] == 5 and order[7] == 7 and order[8] == 10 and sorted(order[9:].tolist()) == [8, 9]
+    assert counts == (6, 1, 4, 2) and n_wonly == 1                   # ABI 9: unit 7 (shrinks the width only, no stencil) leads the generic run
+    assert sorted(order[:6].tolist()) == [0, 1, 2, 3, 4, 6] and order[6] == 5 and order[7:11].tolist() == [7, 11, 10, 12] and sorted(order[11:].tolist()) == [8, 9]
     assert stat_lists[0].tolist() == [1, 2, 8]                 # raw histograms: slot-0 statistics and push-forward sources
     assert stat_lists[1].tolist() == [3, 4] and stat_lists[2].tolist() == [8] and stat_lists[3].size == 0
     assert stats_mask == 0b111
