@@ -484,3 +484,54 @@ def _aug_with_forced_split(hip, d_img, d_msk, units, crop, ph, mode):
         return hip.aug_u8_forward(d_img, d_msk, units, crop, 1, pool_hist=ph)
     finally:
         _lib.load = orig_load
+
+
+@pytest.mark.parametrize("H,W,crop,kind", [(176, 320, 200, 0), (256, 256, 256, 1), (96, 520, 132, 1)])
+def test_width_only_units_one_pass_tile_vs_oracle(hip, oracle, H, W, crop, kind):
+    """Round 5 (ABI 9): a down-scaling unit that shrinks the WIDTH only and chains no Sharpness stencil runs through the one-pass tile
+    k_fused3w (128 x 16 outputs; horizontal pass of 3 / 4 / 5 taps into LDS, up-scaling vertical pass) instead of the two passes.  Units of
+    every tap class with byte-map / Color / Cutout ops in front, scaled heights from 1x to 2x, crops wider than one tile with a partial last
+    tile and pad columns / rows, both datasets -- against the oracle bit for bit, with the planner's lists and through the list-free entry
+    (every unit offered to every tile kernel: the two-pass kernels must leave these units alone)."""
+    from aadg_amd._lib import UNIT_DTYPE
+    rs = np.random.RandomState(H + W + crop)
+    P = 4
+    imgs, msks = synth_pool(rs, P, H, W, vessel=(kind == 1))
+    widths = sorted(set([W // 2, W // 2 + 1, (2 * W) // 3, (2 * W) // 3 + 1, (3 * W) // 4, W - 1, int(W * 0.55), int(W * 0.9)]))
+    heights = [H, H + 1, int(H * 1.3), 2 * H]
+    recs = []
+    for i, (w, h) in enumerate([(a, b) for a in widths for b in heights]):
+        u = np.zeros((), UNIT_DTYPE)
+        u["rect"][:, 2:] = -1
+        u["src"] = i % P
+        if i % 4 == 1:
+            u["n_ops"] = 2; u["op"][0] = 1; u["op"][1] = 6; u["farg"][1] = np.float32(1.5)          # Invert, Color
+        elif i % 4 == 2:
+            u["n_ops"] = 2; u["op"][0] = 0; u["op"][1] = 9; u["rect"][1] = (W // 5, H // 4, W // 2, H // 2)     # AutoContrast, Cutout
+        elif i % 4 == 3:
+            u["n_ops"] = 1; u["op"][0] = 5; u["farg"][0] = np.float32(1.4)                            # Contrast
+        u["scaled_w"], u["scaled_h"] = w, h
+        pad = max((crop - w) // 2 + 5, (crop - h) // 2 + 5) if (w < crop or h < crop) else 0
+        u["pad"] = pad
+        u["crop_x"] = rs.randint(0, w + 2 * pad - crop + 1)
+        u["crop_y"] = rs.randint(0, h + 2 * pad - crop + 1)
+        recs.append(u)
+    units = np.array(recs, dtype=UNIT_DTYPE)
+    plan = hip.launch_plan(units, H, W, crop)
+    assert plan[7] == len(units) and plan[3][2] == len(units)                   # every unit is a width-only generic unit
+    d_img, d_msk = torch.from_numpy(imgs).cuda(), torch.from_numpy(msks).cuda()
+    got_img, got_lbl = hip.aug_u8_forward(d_img, d_msk, units, crop, kind)
+    want_img, want_lbl = oracle.aug_units(imgs, msks, units, crop, kind)
+    bad = [i for i in range(len(units)) if not np.array_equal(got_img[i].cpu().numpy(), want_img[i])]
+    assert not bad, [(int(units[i]["scaled_w"]), int(units[i]["scaled_h"])) for i in bad[:8]]
+    assert np.array_equal(got_lbl.cpu().numpy(), want_lbl)
+    # the list-free entry
+    lib = hip.load()
+    d_units = hip.units_to_device(units, d_img.device)
+    o_img = torch.empty_like(got_img); o_lbl = torch.empty_like(got_lbl)
+    ws = torch.empty(lib.aadg_aug_u8_workspace_bytes(len(units), H, W, crop), dtype=torch.uint8, device="cuda")
+    rc = lib.aadg_aug_u8_forward(d_img.data_ptr(), d_msk.data_ptr(), P, H, W, d_units.data_ptr(), len(units), 4, crop, kind, o_img.data_ptr(),
+                                 o_lbl.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o_img, got_img) and torch.equal(o_lbl, got_lbl)
