@@ -58,6 +58,9 @@ struct CtrlWs {
     size_t counter;                // 1 int
     // k_ppo_rollout:
     size_t lpq;                    // [M * Q] 64-bit words {Adam step number of the epoch, sum log-prob of the sequence}; zero between epochs
+    // k_ctrl_sample_seq:
+    size_t sprobs;                 // [M * Q][2][CT_MAX_A] per-sequence head-probability sums
+    size_t slp;                    // [M * Q][2] per-sequence sum log-prob, sum entropy
     size_t total;
 };
 __host__ __device__ inline int ctrl_n_params(const CtrlDims& d) {
@@ -80,6 +83,8 @@ __host__ __device__ inline CtrlWs ctrl_ws(const CtrlDims& d) {
     w.counter = o; o += 4;
     o = (o + 3) / 4 * 4;
     w.lpq = o; o += (size_t)(2 * d.M * d.Q + 3) / 4 * 4;
+    w.sprobs = o; o += (size_t)d.M * d.Q * 2 * CT_MAX_A;
+    w.slp = o; o += (size_t)(2 * d.M * d.Q + 3) / 4 * 4;
     w.total = o;
     return w;
 }
@@ -1087,9 +1092,8 @@ __global__ __launch_bounds__(CT_THREADS) void k_ppo_rollout(CtrlParams P, CtrlDi
     extern __shared__ __attribute__((aligned(16))) float L[];
     const CtrlWs W = ctrl_ws(d);
     const PpoLds O = ppo_lds(d);
-    const PpoGaLds Og = ppo_ga_lds(d);
     const int w = blockIdx.x;
-    const int Q = d.Q, S = d.S, nseq = d.M * d.Q;
+    const int Q = d.Q, S = d.S;
     constexpr int H4 = 4 * HC, A = CT_MAX_A;
     const int NT = d.NOPS + d.NMAGS;
     const int m = w / Q;
@@ -1099,10 +1103,6 @@ __global__ __launch_bounds__(CT_THREADS) void k_ppo_rollout(CtrlParams P, CtrlDi
     int* tok = reinterpret_cast<int*>(L + O.tok); float* misc = L + O.misc;
     float* Wh = L + O.Wh; float* Bh = L + O.Bh; float* Emb = L + O.Emb;
     unsigned long long* lpq = reinterpret_cast<unsigned long long*>(ws + W.lpq);
-    // parameter offsets inside a gseq row = inside the concatenation of the module's 9 parameters
-    const int o_wih = NT * EC, o_whh = o_wih + H4 * EC, o_bih = o_whh + H4 * HC, o_bhh = o_bih + H4, o_wop = o_bhh + H4,
-              o_bop = o_wop + d.NOPS * HC, o_wmag = o_bop + d.NOPS, o_bmag = o_wmag + d.NMAGS * HC;
-
     constexpr int XSL = EC / 4, HSL = (HC / 16) * 4, HL = HC - 3 * HSL;
     static_assert(HL % 4 == 0 && HL >= HSL && HL - HSL <= HSL, "k-slices must be multiples of 4");
     constexpr int JS = 4 * HC / (4 * CT_HP);
@@ -1121,7 +1121,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_ppo_rollout(CtrlParams P, CtrlDi
             const int xgrp = tid / XT, xl = tid - xgrp * XT;
             const int xkg = (xl >> 2) % (EC / 4), xjg = (xl >> 2) / (EC / 4);
             // ------------------------------------------------------------------------------------------ tables, weights
-            // every global load of the forward in ONE batch (after the epoch's acquire they all miss the caches: ~3 us per
+            // every global load of the forward in ONE batch (behind the kernel boundary they all miss the caches: ~3 us per
             // dependent round trip): head weights and embedding rows as one 16-byte vector per thread, then the weight slices
             float4 r_op = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r_mag = r_op, r_emb = r_op;
             float r_bop = 0.0f, r_bmag = 0.0f;
@@ -1426,6 +1426,201 @@ __global__ __launch_bounds__(CT_THREADS) void k_ppo_rollout(CtrlParams P, CtrlDi
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_ctrl_sample_seq (round 5): Controller.sample with one workgroup per SEQUENCE, as k_ppo_rollout's forward half -- the Q
+// sub-policies of a policy row are independent sequences (state reset per sub-policy, models/controller.py:82-84), each draws
+// from its own uniforms.  Per step: gate products + cell update (one barrier), the step's head logits (4 lanes per action),
+// soft-max + inverse-CDF draw + next input on 16 lanes.  The per-policy sums (log-prob, entropy) and the mean head
+// probabilities cross workgroups as per-sequence partials that the last workgroup to arrive combines in ascending order.
+// 43 -> 17 us for M = 6, Q = 5, S = 4.  Widths 32 / 100 only; anything else takes k_ctrl_rollout<true>.
+// ------------------------------------------------------------------------------------------------
+template <int EC, int HC>
+__global__ __launch_bounds__(CT_THREADS) void k_ctrl_sample_seq(CtrlParams P, CtrlDims d, float* ws, const float* __restrict__ uniforms,
+                                                                long long* __restrict__ policies, float* __restrict__ op_probs,
+                                                                float* __restrict__ mag_probs, float* __restrict__ log_probs,
+                                                                float* __restrict__ entropies) {
+    extern __shared__ __attribute__((aligned(16))) float L[];
+    const CtrlWs W = ctrl_ws(d);
+    const PpoLds O = ppo_lds(d);
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int Q = d.Q, S = d.S, nseq = d.M * d.Q;
+    constexpr int H4 = 4 * HC, A = CT_MAX_A;
+    const int NT = d.NOPS + d.NMAGS;
+    float* Hs = L + O.Hs; float* X = L + O.X; float* Pp = L + O.P; float* Wi = L + O.Wi; float* misc = L + O.misc;
+    float* Wh = L + O.Wh; float* Bh = L + O.Bh; float* Emb = L + O.Emb;
+    constexpr int XSL = EC / 4, HSL = (HC / 16) * 4, HL = HC - 3 * HSL;
+    const int gu = tid >> 2, gsl = tid & 3;
+    // ---- every global load in one batch: head weights, embedding rows, W_ih (-> LDS), this lane's W_hh slices and bias
+    float4 r_op = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r_mag = r_op, r_emb = r_op;
+    float r_bop = 0.0f, r_bmag = 0.0f;
+    if (tid < d.NOPS * (HC / 4)) r_op = reinterpret_cast<const float4*>(P.wop)[tid];
+    if (tid < d.NMAGS * (HC / 4)) r_mag = reinterpret_cast<const float4*>(P.wmag)[tid];
+    if (tid < NT * (EC / 4)) r_emb = reinterpret_cast<const float4*>(P.emb)[tid];
+    if (tid < d.NOPS) r_bop = P.bop[tid];
+    if (tid < d.NMAGS) r_bmag = P.bmag[tid];
+    constexpr int WIV = H4 * EC / 4, WIN = (WIV + CT_THREADS - 1) / CT_THREADS;
+    float4 r_wi[WIN];
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) r_wi[i] = reinterpret_cast<const float4*>(P.w_ih)[min(tid + i * CT_THREADS, WIV - 1)];
+    float whr[4][HL];
+    float bias = 0.0f;
+    if (tid < H4) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float* rh = P.w_hh + (size_t)(g * HC + gu) * HC + HSL * gsl;
+#pragma unroll
+            for (int i = 0; i < HL; i += 4) {
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (i < HSL || gsl == 3) v = *reinterpret_cast<const float4*>(rh + i);
+                whr[g][i] = v.x; whr[g][i + 1] = v.y; whr[g][i + 2] = v.z; whr[g][i + 3] = v.w;
+            }
+        }
+        bias = P.b_ih[gsl * HC + gu] + P.b_hh[gsl * HC + gu];
+    }
+    if (tid < d.NOPS * (HC / 4)) reinterpret_cast<float4*>(Wh)[tid] = r_op;
+    if (tid < d.NMAGS * (HC / 4)) reinterpret_cast<float4*>(Wh + d.NOPS * HC)[tid] = r_mag;
+    if (tid < NT * (EC / 4)) reinterpret_cast<float4*>(Emb)[tid] = r_emb;
+    if (tid < A) { Bh[tid] = r_bop; Bh[A + tid] = r_bmag; }
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) {
+        const int v = tid + i * CT_THREADS;
+        if (v < WIV) *reinterpret_cast<float4*>(Wi + (v / (EC / 4)) * (EC + PPO_WIP) + 4 * (v % (EC / 4))) = r_wi[i];
+    }
+    for (int i = tid; i < HC; i += CT_THREADS) Hs[i] = 0.0f;
+    for (int i = tid; i < EC; i += CT_THREADS) X[i] = 0.0f;
+    lds_barrier();
+
+    float c_prev = 0.0f, my_lp = 0.0f, my_ent = 0.0f;
+    for (int t = 0; t < S; ++t) {
+        const bool op_step = (t & 1) == 0;
+        const int NA = op_step ? d.NOPS : d.NMAGS;
+        if (tid < H4) {                                     // gate products + cell update, as k_ppo_rollout
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (t > 0) {
+#pragma unroll
+                for (int i = 0; i < XSL; i += 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(X + t * EC + XSL * gsl + i);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 wv = *reinterpret_cast<const float4*>(Wi + (g * HC + gu) * (EC + PPO_WIP) + XSL * gsl + i);
+                        acc[g] = fmaf(wv.x, a.x, acc[g]); acc[g] = fmaf(wv.y, a.y, acc[g]);
+                        acc[g] = fmaf(wv.z, a.z, acc[g]); acc[g] = fmaf(wv.w, a.w, acc[g]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < HL; i += 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(Hs + t * HC + HSL * gsl + i);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        acc[g] = fmaf(whr[g][i], a.x, acc[g]); acc[g] = fmaf(whr[g][i + 1], a.y, acc[g]);
+                        acc[g] = fmaf(whr[g][i + 2], a.z, acc[g]); acc[g] = fmaf(whr[g][i + 3], a.w, acc[g]);
+                    }
+                }
+            }
+            float mine = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float v = quad_sum(acc[g]);
+                mine = gsl == g ? v : mine;
+            }
+            mine += bias;
+            const float av = gsl == 2 ? tanhf(mine) : sigmoidf_(mine);
+            const float ig = quad_lane<0>(av), fg = quad_lane<1>(av), gg = quad_lane<2>(av), og = quad_lane<3>(av);
+            const float c = fg * c_prev + ig * gg;
+            c_prev = c;
+            if (gsl == 0) Hs[(t + 1) * HC + gu] = og * tanhf(c);
+        }
+        lds_barrier();
+        {                                                   // head logits of the step: 4 lanes per action
+            const int a = tid >> 2, prt = tid & 3;
+            const bool live = a < NA;
+            float z = 0.0f;
+            if (live) {
+                const float* wrow = Wh + (size_t)((op_step ? 0 : d.NOPS) + a) * HC;
+                const float* h = Hs + (t + 1) * HC;
+#pragma unroll 5
+                for (int k = prt; k < HC; k += 4) z = fmaf(wrow[k], h[k], z);
+            }
+            z += __shfl_xor(z, 1, 64); z += __shfl_xor(z, 2, 64);
+            if (live && prt == 0) Pp[t * A + a] = d.cdiv * tanhf(z + Bh[(op_step ? 0 : A) + a]);
+        }
+        lds_barrier();
+        if (tid < A) {                                      // soft-max, draw, next input token: 16 lanes
+            const int a = tid;
+            float* p = Pp + t * A;
+            const bool live = a < NA;
+            const float v = live ? p[a] : -INFINITY;
+            float mx = v;
+#pragma unroll
+            for (int o = A / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, A));
+            const float z = v - mx;
+            float sum = live ? expf(z) : 0.0f;
+#pragma unroll
+            for (int o = A / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, A);
+            const float lp = z - logf(sum), pr = live ? expf(lp) : 0.0f;
+            float ent = live ? -lp * pr : 0.0f;
+#pragma unroll
+            for (int o = A / 2; o > 0; o >>= 1) ent += __shfl_xor(ent, o, A);
+            if (live) p[a] = pr;
+            // inverse CDF in action order (a sequential sum, as a host-side scan of the same probabilities would do it)
+            const float u = uniforms[(size_t)w * S + t];
+            float cum = 0.0f;
+            int a_sel = NA - 1;
+            bool found = false;
+#pragma unroll
+            for (int b = 0; b < A; ++b) {                   // (lanes 0..15 of wave 0: lane b's value through a scalar register)
+                cum += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pr), b));
+                if (!found && b < NA && u < cum) { a_sel = b; found = true; }
+            }
+            if (a == 0) policies[(size_t)w * S + t] = a_sel;
+            my_lp += __shfl(lp, a_sel, A);
+            my_ent += ent;
+            if (t + 1 < S) {
+                const int tok = a_sel + (op_step ? 0 : d.NOPS);
+                for (int k = a; k < EC; k += A) X[(t + 1) * EC + k] = Emb[(size_t)tok * EC + k];
+            }
+        }
+        lds_barrier();
+    }
+    // ---- per-sequence partials; the last workgroup to arrive combines them in ascending order.  No device-scope fence (cache
+    // maintenance on every XCD, several us): the partials are written and read with relaxed device-scope atomics (sc1: served at the
+    // device's coherence point), __syncthreads() waits for the stores' acknowledgements (vmcnt(0)) before the arrival is counted.
+    auto st_dev = [](float* p, float v) { __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto ld_dev = [](const float* p) {
+        return __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned*>(const_cast<float*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    };
+    float* sp = ws + W.sprobs + (size_t)w * 2 * A;
+    if (tid < 2 * A) {
+        const int head = tid / A, a = tid - head * A;
+        float s = 0.0f;
+        for (int t = head; t < S; t += 2) s += Pp[t * A + a];
+        st_dev(sp + tid, (a < (head == 0 ? d.NOPS : d.NMAGS)) ? s : 0.0f);
+    }
+    if (tid == 0) { st_dev(ws + W.slp + 2 * w, my_lp); st_dev(ws + W.slp + 2 * w + 1, my_ent); }
+    __syncthreads();
+    int* counter = reinterpret_cast<int*>(ws + W.counter);
+    __shared__ int last;
+    if (tid == 0) last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nseq - 1;
+    __syncthreads();
+    if (last) {
+        if (tid < 2 * A) {
+            const int head = tid / A, a = tid - head * A;
+            float s = 0.0f;
+            for (int i = 0; i < nseq; ++i) s += ld_dev(ws + W.sprobs + (size_t)i * 2 * A + tid);
+            const float inv = 1.0f / (float)(nseq * (S / 2));
+            if (head == 0 && a < d.NOPS) op_probs[a] = s * inv;
+            if (head == 1 && a < d.NMAGS) mag_probs[a] = s * inv;
+        }
+        if (tid >= 64 && tid < 64 + d.M) {
+            const int mm = tid - 64;
+            float a = 0.0f, b = 0.0f;
+            for (int q = 0; q < Q; ++q) { a += ld_dev(ws + W.slp + 2 * (mm * Q + q)); b += ld_dev(ws + W.slp + 2 * (mm * Q + q) + 1); }
+            log_probs[mm] = a; entropies[mm] = b;
+        }
+        if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 inline bool ctrl_ok(const CtrlDims& d) {
     return d.M > 0 && d.Q > 0 && d.Q <= CT_MAX_Q && d.S > 0 && (d.S % 2) == 0 && d.E > 0 && d.H > 0 && 4 * d.H <= CT_THREADS &&
            d.NOPS > 0 && d.NOPS <= CT_MAX_A && d.NMAGS > 0 && d.NMAGS <= CT_MAX_A && d.Q * CT_MAX_A * 4 <= CT_THREADS &&
@@ -1477,6 +1672,18 @@ extern "C" int aadg_controller_sample_f32(void* const* params, int M, int Q, int
     const CtrlParams P = as_params(params);
     const size_t lds = ctrl_lds(d).total * sizeof(float);
     const bool fast = ctrl_fast(d);
+    if (fast && M * Q <= 128 && M <= CT_THREADS - 64 && ppo_lds(d).total * sizeof(float) <= 150 * 1024) {      // one workgroup per sequence
+        const size_t lds_s = ppo_lds(d).total * sizeof(float);
+        static size_t set_s = 0;
+        if (lds_s > set_s) {
+            AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ctrl_sample_seq<CT_E, CT_H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+            set_s = lds_s;
+        }
+        hipLaunchKernelGGL((k_ctrl_sample_seq<CT_E, CT_H>), dim3(M * Q), dim3(CT_THREADS), lds_s, st, P, d, (float*)ws, uniforms, policies, op_probs,
+                           mag_probs, log_probs, entropies);
+        AADG_LAUNCH_CHECK();
+        return 0;
+    }
     const int rc = fast ? set_lds<true, CT_E, CT_H>(lds) : set_lds<true, 0, 0>(lds);
     if (rc) return rc;
     if (!fast) {                                           // the compile-time-width kernel reads the parameters as they lie
