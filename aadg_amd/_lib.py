@@ -1591,6 +1591,67 @@ def _own_gemm_1x1(M, K, HW, N=None):
     return M <= 128 or (M <= 320 and (K <= 128 or K in (304, 1024)))
 
 
+# ------------------------------------------------------------------------------------------------
+# Weight gradients BESIDE the backward chain.  The input gradient of a convolution feeds the next BatchNorm backward of the chain; its
+# weight gradient feeds nothing until the optimizer step.  With set_wgrad_stream(True) the convolution Functions below launch their
+# weight-gradient kernels (matrix-core bound, 147 KB of LDS: one workgroup per CU) on a second HIP stream, where they overlap the
+# chain's BatchNorm passes (HBM bound, no LDS) instead of standing in line with them, and hand the result over at the END of the
+# backward pass: a callback queued on the autograd engine makes the launch stream wait for the side stream and puts the gradients
+# into `.grad` (what AccumulateGrad would have done).  The gradients therefore bypass autograd's accumulation hooks: NOT for modules
+# wrapped in DistributedDataParallel (its reducer listens to those hooks) and not for torch.autograd.grad(); off by default.
+_WG = {"on": False, "stream": None, "pending": [], "queued": False}
+
+
+def set_wgrad_stream(flag):
+    """Weight-gradient kernels of the own convolutions on a side stream, gradients written to `.grad` at the end of the backward pass
+    (single-process training without DDP only).  Returns the previous setting."""
+    old = _WG["on"]
+    _WG["on"] = bool(flag)
+    return old
+
+
+def wgrad_stream_enabled():
+    return _WG["on"]
+
+
+def _flush_wgrads():
+    side = _WG["stream"]
+    pending, _WG["pending"], _WG["queued"] = _WG["pending"], [], False
+    if not pending:
+        return
+    main = torch.cuda.current_stream()
+    main.wait_stream(side)
+    for weight, dw in pending:
+        dw.record_stream(main)
+        if dw.shape != weight.shape or dw.stride() != weight.stride():
+            dw = dw.reshape(weight.shape).contiguous()           # the layout AccumulateGrad would have given it
+        if weight.grad is None:
+            weight.grad = dw
+        else:
+            weight.grad.add_(dw)
+
+
+def _wgrad_beside(weight, fn, *reads):
+    """dw = fn() for the parameter `weight`, reading the tensors `reads` (produced on the current stream).  Side stream off (or `weight`
+    is no leaf that accumulates into .grad): runs fn() here and returns dw.  On: launches fn() on the side stream and returns None --
+    the gradient reaches weight.grad in _flush_wgrads() when the backward pass ends."""
+    if not (_WG["on"] and weight.is_leaf and weight.requires_grad and weight.is_cuda):
+        return fn()
+    if _WG["stream"] is None:
+        _WG["stream"] = torch.cuda.Stream(device=weight.device)
+    side = _WG["stream"]
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        dw = fn()
+    for t in reads:
+        t.record_stream(side)                 # the caching allocator must not hand these out again before the side stream has read them
+    _WG["pending"].append((weight, dw))
+    if not _WG["queued"]:
+        _WG["queued"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
+    return None
+
+
 class _Conv1x1(torch.autograd.Function):
     """1x1 / stride-1 convolution without bias on NCHW bfloat16 activations.  Forward and input gradient: the matrix-core
     kernel of csrc/conv1x1_fwd.hip where it is the faster one (_own_gemm_1x1), else the library GEMMs; weight gradient: the
@@ -1600,6 +1661,7 @@ class _Conv1x1(torch.autograd.Function):
     def forward(ctx, x, weight):
         wq = cast_weight(weight, x.dtype)
         ctx.save_for_backward(x, wq)
+        ctx.wparam = weight
         ctx.wt = _ShadowRef(weight, "bwd")               # [1, Ci, Co] of the tracked shadow (this step's weights)
         Co, Ci = wq.shape[0], wq.shape[1]
         if _own_gemm_1x1(Co, Ci, x.shape[2] * x.shape[3], x.shape[0]):
@@ -1622,7 +1684,7 @@ class _Conv1x1(torch.autograd.Function):
                 dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            dw = conv1x1_wgrad(dy, x).view(wq.shape)
+            dw = _wgrad_beside(ctx.wparam, lambda: conv1x1_wgrad(dy, x).view(wq.shape), dy, x)
         return dx, dw
 
 
@@ -1886,6 +1948,7 @@ class _Conv3x3S2(torch.autograd.Function):
     def forward(ctx, x, weight):
         wq = cast_weight(weight, x.dtype)
         ctx.save_for_backward(x, wq)
+        ctx.wparam = weight
         ctx.a9t = _ShadowRef(weight, "bwd")              # tap-major transposed shadow (this step's weights)
         Co, Ci = wq.shape[0], wq.shape[1]
         if load().aadg_conv3x3s2_nchw_supported(Co, Ci, x.shape[2] // 2, x.shape[3] // 2):
@@ -1907,7 +1970,7 @@ class _Conv3x3S2(torch.autograd.Function):
                 dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            dw = conv3x3s2_wgrad(dy, x)
+            dw = _wgrad_beside(ctx.wparam, lambda: conv3x3s2_wgrad(dy, x), dy, x)
         return dx, dw
 
 
@@ -1959,6 +2022,7 @@ class _Conv3x3(torch.autograd.Function):
     def forward(ctx, x, weight, dilation):
         wq = cast_weight(weight, x.dtype)
         ctx.save_for_backward(x, wq)
+        ctx.wparam = weight
         ctx.a9t = _ShadowRef(weight, "bwd")              # tap-major transposed shadow (this step's weights)
         ctx.dilation = dilation
         Co, Ci = wq.shape[0], wq.shape[1]
@@ -1984,7 +2048,7 @@ class _Conv3x3(torch.autograd.Function):
                 dx = torch.ops.aten.convolution_backward(dy, x, wq, None, [1, 1], [d, d], [d, d], False, [0, 0], 1,
                                                          [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            dw = conv3x3_wgrad(dy, x, d)
+            dw = _wgrad_beside(ctx.wparam, lambda: conv3x3_wgrad(dy, x, d), dy, x)
         return dx, dw, None
 
 
@@ -2048,6 +2112,7 @@ class _Conv1x1X3(torch.autograd.Function):
         a2 = split_layout(weight, "plain")
         a2 = a2.view(2, Co, Ci) if a2 is not None else split_weight(weight.detach().reshape(Co, Ci))
         ctx.save_for_backward(x, weight)
+        ctx.wparam = weight
         ctx.wt = _ShadowRef(weight, "bwd", split=True)          # [2, 1, Ci, Co] of the tracked shadow (this step's weights)
         if not want_stats:
             return conv1x1_nchw_x3(a2, x)
@@ -2067,7 +2132,7 @@ class _Conv1x1X3(torch.autograd.Function):
             at = wt.view(2, Ci, Co) if wt is not None else split_weight(weight.detach().reshape(Co, Ci).t().contiguous())
             dx = conv1x1_nchw_x3(at, dy)
         if ctx.needs_input_grad[1]:
-            dw = conv1x1_wgrad_x3(dy, x).view(weight.shape)
+            dw = _wgrad_beside(ctx.wparam, lambda: conv1x1_wgrad_x3(dy, x).view(weight.shape), dy, x)
         return dx, dw, None
 
 
@@ -2133,6 +2198,7 @@ class _Conv3x3X3(torch.autograd.Function):
         if a9 is None:
             a9 = split_weight(weight.detach().permute(2, 3, 0, 1).reshape(9, Co, Ci).contiguous())
         ctx.save_for_backward(x, weight)
+        ctx.wparam = weight
         ctx.a9t = _ShadowRef(weight, "bwd", split=True)
         ctx.dilation = dilation
         return conv3x3_nchw_x3(a9, x, dilation)
@@ -2150,7 +2216,7 @@ class _Conv3x3X3(torch.autograd.Function):
                 a9t = split_weight(weight.detach().flip(2, 3).permute(2, 3, 1, 0).reshape(9, Ci, Co).contiguous())
             dx = conv3x3_nchw_x3(a9t, dy, d)
         if ctx.needs_input_grad[1]:
-            dw = conv3x3_wgrad_x3(dy, x, d)
+            dw = _wgrad_beside(ctx.wparam, lambda: conv3x3_wgrad_x3(dy, x, d), dy, x)
         return dx, dw, None
 
 
@@ -2182,6 +2248,7 @@ class _Conv3x3S2X3(torch.autograd.Function):
         if a9 is None:
             a9 = split_weight(weight.detach().permute(2, 3, 0, 1).reshape(9, Co, Ci).contiguous())
         ctx.save_for_backward(x, weight)
+        ctx.wparam = weight
         ctx.a9t = _ShadowRef(weight, "bwd", split=True)
         out = torch.empty((N, Co, H // 2, W // 2), dtype=torch.float32, device=x.device)
         _check(lib.aadg_conv3x3s2_nchw_f32x3(a9[0].data_ptr(), a9[1].data_ptr(), x.data_ptr(), out.data_ptr(), N, Co, Ci, H // 2, W // 2,
@@ -2204,10 +2271,12 @@ class _Conv3x3S2X3(torch.autograd.Function):
             _check(lib.aadg_conv3x3s2_dgrad_f32x3(a9t[0].data_ptr(), a9t[1].data_ptr(), dy.data_ptr(), dx.data_ptr(), N, Ci, Co, Ho, Wo,
                                                   _stream()), "aadg_conv3x3s2_dgrad_f32x3")
         if ctx.needs_input_grad[1]:
-            dw9 = torch.empty((9, Co, Ci), dtype=torch.float32, device=x.device)
-            _check(lib.aadg_conv3x3s2_wgrad_f32x3(dy.data_ptr(), x.data_ptr(), dw9.data_ptr(), N, Co, Ci, Ho, Wo, _stream()),
-                   "aadg_conv3x3s2_wgrad_f32x3")
-            dw = dw9.permute(1, 2, 0).reshape(Co, Ci, 3, 3)
+            def wgrad():
+                dw9 = torch.empty((9, Co, Ci), dtype=torch.float32, device=x.device)
+                _check(lib.aadg_conv3x3s2_wgrad_f32x3(dy.data_ptr(), x.data_ptr(), dw9.data_ptr(), N, Co, Ci, Ho, Wo, _stream()),
+                       "aadg_conv3x3s2_wgrad_f32x3")
+                return dw9.permute(1, 2, 0).reshape(Co, Ci, 3, 3)
+            dw = _wgrad_beside(ctx.wparam, wgrad, dy, x)
         return dx, dw
 
 

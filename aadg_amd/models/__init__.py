@@ -87,6 +87,11 @@ def load_ddp_model(ngpus_per_node, args, cfg):
             model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     # with synchronised statistics the running buffers are identical on every rank: no per-forward buffer broadcast
     model = _wrap(model, args, dev, broadcast_buffers=not sync)
+    if dev.type == 'cuda':
+        # weight-gradient kernels of the own convolutions on a second stream, beside the backward chain (_lib.set_wgrad_stream): only
+        # without DistributedDataParallel, whose reducer listens to autograd's accumulation hooks
+        from .. import _lib
+        _lib.set_wgrad_stream(bool(getattr(args, 'wgrad_stream', True)) and not isinstance(model, torch.nn.parallel.DistributedDataParallel))
     return model, cfg.TRAIN.BATCH_SIZE, args.workers
 
 

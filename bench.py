@@ -75,6 +75,8 @@ def parse():
                     help="arithmetic of the backbone convolutions: f32x3 = float32 tensors, every product as three bfloat16 matrix-core "
                          "products with float32 accumulation (own kernels, the reference's precision: checked by the `precision` leg); "
                          "fp32 = the library's float32 convolutions; bf16 = bfloat16 autocast (narrower than the reference: secondary)")
+    ap.add_argument("--no_wgrad_stream", action="store_true",
+                    help="weight-gradient kernels in line with the backward chain (default: on a second stream beside it, one process / no DDP only)")
     ap.add_argument("--legs", default="auto", help="comma list of extra legs at N = 1: fop,kernels,rvs1024,cpu,precision,scale  (auto = all; none = skip)")
     ap.add_argument("--only_legs", default=None,
                     help="skip the headline step and print ONE JSON line holding only these legs (fop,kernels,rvs1024): the target of "
@@ -329,6 +331,7 @@ def build_state(a, local_rank, world, backbone_dtype=None):
     args.gpu, args.workers, args.distributed = local_rank, 0, world > 1 or force
     args.crop_size, args.backbone_dtype, args.epoch_items = a.size, backbone_dtype or a.backbone_dtype, a.batch
     args.sync_bn = (world > 1 or force) and not a.no_sync_bn
+    args.wgrad_stream = not getattr(a, 'no_wgrad_stream', False)
     args.force_sharded = force
     args.placement = a.placement
     st = SearchState(local_rank, world, cfg, args)

@@ -30,6 +30,8 @@ def parse_args(argv=None):
     parser.add_argument('--output_type', default='image', type=str)
     parser.add_argument('--seed', default=1023, type=int)
     parser.add_argument('--crop_size', default=256, type=int)
+    parser.add_argument('--no_wgrad_stream', dest='wgrad_stream', action='store_false',
+                        help='weight-gradient kernels in line with the backward chain (default: on a second HIP stream beside it; always in line under DDP)')
     parser.add_argument('--backbone_dtype', default='fp32', choices=['fp32', 'f32x3', 'bf16'],
                         help="fp32: the library's float32 convolutions; f32x3: float32 tensors, own float32-precision matrix-core kernels; "
                              "bf16: bfloat16 autocast (narrower than the reference)")
