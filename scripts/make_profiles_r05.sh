@@ -1,5 +1,5 @@
 # Round-5 profile artefacts (run through gpurun; results land in gpurun_out/r5p/<tag>/, copy the ones to keep into profiles/).
-#   bash scripts/make_profiles_r05.sh <tag> [parts]      parts: any of  fop aug512 rvs bench shard8 segformer x3layers fp32lib bf16 skbig  (default: fop aug512 rvs)
+#   bash scripts/make_profiles_r05.sh <tag> [parts]      parts: any of  fop aug512 rvs bench shard8 segformer x3layers fp32lib bf16 skbig ctrl  (default: fop aug512 rvs)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-final}
@@ -132,6 +132,11 @@ bf16)
   rocprofv3 --kernel-trace --stats -d /tmp/prof_b16 -- python $R/bench.py --legs none --backbone_dtype bf16 --steps 10 --warmup 3 > $O/bf16_under_rocprof.json 2>/dev/null
   DBB=$(find /tmp/prof_b16 -name "*.db" | head -1)
   python $R/scripts/prof_summary.py $DBB $O/bf16_kernel_stats.txt > /dev/null
+  ;;
+ctrl)
+  # the fused controller calls: event times of sample / 5-epoch PPO update, kernel table (k_ctrl_sample_seq, k_ppo_rollout, k_ppo_grad_adam)
+  python $R/scripts/ubench/ctrl_time.py 300 > $O/controller_times.txt 2>/dev/null
+  bash $R/scripts/ubench/ctrl_prof.sh > $O/controller_kernel_stats.txt 2>/dev/null
   ;;
 skbig)
   # SURVEY 8(d)'s scaled synthetic Sinkhorn (3 x 4096^2 points): wall time and kernel table
