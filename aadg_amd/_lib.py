@@ -1599,7 +1599,7 @@ def _own_gemm_1x1(M, K, HW, N=None):
 # backward pass: a callback queued on the autograd engine makes the launch stream wait for the side stream and puts the gradients
 # into `.grad` (what AccumulateGrad would have done).  The gradients therefore bypass autograd's accumulation hooks: NOT for modules
 # wrapped in DistributedDataParallel (its reducer listens to those hooks) and not for torch.autograd.grad(); off by default.
-_WG = {"on": False, "stream": None, "pending": [], "queued": False}
+_WG = {"on": False, "stream": None, "pending": []}
 
 
 def set_wgrad_stream(flag):
@@ -1616,7 +1616,7 @@ def wgrad_stream_enabled():
 
 def _flush_wgrads():
     side = _WG["stream"]
-    pending, _WG["pending"], _WG["queued"] = _WG["pending"], [], False
+    pending, _WG["pending"] = _WG["pending"], []
     if not pending:
         return
     main = torch.cuda.current_stream()
@@ -1646,9 +1646,9 @@ def _wgrad_beside(weight, fn, *reads):
     for t in reads:
         t.record_stream(side)                 # the caching allocator must not hand these out again before the side stream has read them
     _WG["pending"].append((weight, dw))
-    if not _WG["queued"]:
-        _WG["queued"] = True
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
+    # one callback per deferred gradient (the first to run delivers everything pending, the others find nothing): no state that a
+    # backward pass cut short by an exception could leave behind
+    torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
     return None
 
 
