@@ -15,6 +15,8 @@
 //                      refreshed transposed copies for the next epoch
 //
 // float32 throughout; same arithmetic as the eager module up to summation order.
+// Round 5: for the module's widths the calls run one workgroup per SEQUENCE instead (k_ctrl_sample_seq, k_ppo_rollout, k_ppo_grad_adam,
+// further down); the three kernels above serve every other width.
 //
 // Round 2 (wall_clock64 stamps after every barrier, scripts/ubench/ctrl_phase_times.py): with one gate row per lane the gate
 // phase took 10.5 us per step -- not load latency (weights in registers changed nothing) but 165 broadcast ds_read_b128 per wave

@@ -732,7 +732,7 @@ def rvs_1024_leg(n_units=144, size=1024, cfg_rel=os.path.join("experiments", "rv
                                                    "down-scaling units as a horizontal and a vertical streaming pass)",
                          "achieved": kb / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": int(tr["hbm_bytes_per_unit"] * len(units)) if tr else None,
-                         "traffic_source": "profiles/r04_rvs1024_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes, summed "
+                         "traffic_source": "profiles/r05_rvs1024_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes, summed "
                                            "over the tile kernels), per unit x units" if tr else None,
                          "bytes_per_launch": kb, "kernel_ms": k_ms,
                          # the raw images' statistics come from the per-pool cache: the call reads the source once
