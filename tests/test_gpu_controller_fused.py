@@ -19,8 +19,14 @@ def _cfg(L=2, num_mags=10, exclude=0):
 
 # widths (32, 100) are the module's defaults = the register-resident-weights instantiation of k_ctrl_rollout; any other
 # width runs the run-time-width instantiation
+# the limits of the one-workgroup-per-sequence kernels (k_ctrl_sample_seq / k_ppo_rollout + k_ppo_grad_adam: S = 2 L <= 8 steps, M Q <= 128
+# sequences) and the shapes just beyond them, which run k_ctrl_rollout; the widest heads the library takes (16 actions); one policy
+EDGE_SHAPES = [(4, 10, 0, 6, (32, 100)), (2, 10, 0, 25, (32, 100)), (2, 10, 0, 26, (32, 100)), (4, 10, 0, 26, (32, 100)),
+               (2, 16, 0, 4, (32, 100)), (1, 3, 5, 1, (32, 100))]
+
+
 @pytest.mark.parametrize("L,num_mags,exclude,M,widths", [(2, 10, 0, 6, (32, 100)), (1, 5, 2, 3, (32, 100)), (3, 12, 0, 8, (32, 100)),
-                                                       (2, 10, 0, 6, (16, 60))])
+                                                       (2, 10, 0, 6, (16, 60))] + EDGE_SHAPES)
 def test_fused_sample_is_consistent_with_the_module(hip, L, num_mags, exclude, M, widths):
     from aadg_amd.models.controller import Controller
     cfg = _cfg(L, num_mags, exclude)
@@ -72,7 +78,7 @@ def test_fused_sampling_follows_the_head_distribution(hip):
 
 
 @pytest.mark.parametrize("L,num_mags,exclude,M,widths", [(2, 10, 0, 6, (32, 100)), (1, 5, 2, 3, (32, 100)), (3, 12, 0, 8, (32, 100)),
-                                                       (2, 10, 0, 6, (16, 60))])
+                                                       (2, 10, 0, 6, (16, 60))] + EDGE_SHAPES)
 def test_fused_ppo_update_equals_eager(hip, L, num_mags, exclude, M, widths):
     from aadg_amd.models.controller import Controller
     from aadg_amd.models.graphed import FusedControllerStep, make_controller_step
