@@ -59,7 +59,7 @@ EXPORTS = [
     "aadg_weight_layouts_split_bf16", "aadg_conv1x1_nchw_f32x3", "aadg_conv1x1_wgrad_f32x3", "aadg_conv3x3_nchw_f32x3",
     "aadg_conv3x3_wgrad_f32x3", "aadg_conv3x3s2_nchw_f32x3", "aadg_conv3x3s2_dgrad_f32x3", "aadg_conv3x3s2_wgrad_f32x3",
     "aadg_stem_conv7x7_f32x3", "aadg_stem_conv7x7_wgrad_f32x3", "aadg_sinkhorn_divergence_phases_f32",
-    "aadg_conv1x1_nchw_f32x3_stats",
+    "aadg_conv1x1_nchw_f32x3_stats", "aadg_conv3x3_nchw_f32x3_stats", "aadg_conv3x3_f32x3_stats_supported",
 ]
 
 _lib = None
@@ -250,6 +250,10 @@ def load():
     lib.aadg_conv1x1_wgrad_f32x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp]
     lib.aadg_conv3x3_nchw_f32x3.restype = _i
     lib.aadg_conv3x3_nchw_f32x3.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
+    lib.aadg_conv3x3_nchw_f32x3_stats.restype = _i
+    lib.aadg_conv3x3_nchw_f32x3_stats.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]
+    lib.aadg_conv3x3_f32x3_stats_supported.restype = _i
+    lib.aadg_conv3x3_f32x3_stats_supported.argtypes = [_i, _i, _i, _i, _i]
     lib.aadg_conv3x3_wgrad_f32x3.restype = _i
     lib.aadg_conv3x3_wgrad_f32x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
     lib.aadg_sinkhorn_divergence_phases_f32.restype = _i
@@ -264,7 +268,7 @@ def load():
     lib.aadg_conv3x3s2_dgrad_f32x3.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.aadg_conv3x3s2_wgrad_f32x3.restype = _i
     lib.aadg_conv3x3s2_wgrad_f32x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
-    if lib.aadg_abi_version() != 9:
+    if lib.aadg_abi_version() != 10:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -2156,9 +2160,10 @@ def conv1x1_x3(x, weight, want_stats=False):
     return y
 
 
-def conv3x3_nchw_x3(a9, x, dilation=1):
+def conv3x3_nchw_x3(a9, x, dilation=1, bn_sums=None):
     """out [N, M, H, W] float32 = 3x3 convolution (stride 1, padding = dilation) of x [N, K, H, W] float32; a9 [2, 9, M, K] bfloat16 =
-    (hi, lo) of the tap-major weights"""
+    (hi, lo) of the tap-major weights.  bn_sums (float64 [2M + 1], optional; shapes of conv3x3_x3_stats_supported) receives the BatchNorm
+    statistics of out from the kernel's epilogue."""
     _require_cuda(a9, x)
     if a9.dtype != torch.bfloat16 or x.dtype != torch.float32 or not (a9.is_contiguous() and x.is_contiguous()) or a9.dim() != 4:
         raise AadgError("conv3x3_nchw_x3: expected contiguous bfloat16 a9 [2,9,M,K] and NCHW float32 x")
@@ -2167,8 +2172,8 @@ def conv3x3_nchw_x3(a9, x, dilation=1):
     if a9.shape[0] != 2 or a9.shape[1] != 9 or a9.shape[3] != K:
         raise AadgError("conv3x3_nchw_x3: shape mismatch")
     out = torch.empty((N, M, H, W), dtype=torch.float32, device=x.device)
-    _check(load().aadg_conv3x3_nchw_f32x3(a9[0].data_ptr(), a9[1].data_ptr(), x.data_ptr(), out.data_ptr(), N, M, K, H, W, int(dilation),
-                                          _stream()), "aadg_conv3x3_nchw_f32x3")
+    _check(load().aadg_conv3x3_nchw_f32x3_stats(a9[0].data_ptr(), a9[1].data_ptr(), x.data_ptr(), out.data_ptr(), N, M, K, H, W,
+                                                int(dilation), _ptr(bn_sums), _stream()), "aadg_conv3x3_nchw_f32x3")
     return out
 
 
@@ -2192,7 +2197,8 @@ class _Conv3x3X3(torch.autograd.Function):
     (csrc/conv3x3_fwd.hip and csrc/conv3x3_wgrad.hip, X3).  `weight` is the float32 parameter."""
 
     @staticmethod
-    def forward(ctx, x, weight, dilation):
+    def forward(ctx, x, weight, dilation, want_stats=False):
+        """want_stats: also return the float64 [2 Co + 1] BatchNorm totals of the output from the kernel's epilogue (as _Conv1x1X3)"""
         Co, Ci = weight.shape[0], weight.shape[1]
         a9 = split_layout(weight, "fwd")
         if a9 is None:
@@ -2201,10 +2207,15 @@ class _Conv3x3X3(torch.autograd.Function):
         ctx.wparam = weight
         ctx.a9t = _ShadowRef(weight, "bwd", split=True)
         ctx.dilation = dilation
-        return conv3x3_nchw_x3(a9, x, dilation)
+        if not want_stats:
+            return conv3x3_nchw_x3(a9, x, dilation)
+        sums = torch.empty(2 * Co + 1, dtype=torch.float64, device=x.device)
+        y = conv3x3_nchw_x3(a9, x, dilation, sums)
+        ctx.mark_non_differentiable(sums)
+        return y, sums
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         x, weight = ctx.saved_tensors
         d = ctx.dilation
         dy = dy.contiguous()
@@ -2217,7 +2228,7 @@ class _Conv3x3X3(torch.autograd.Function):
             dx = conv3x3_nchw_x3(a9t, dy, d)
         if ctx.needs_input_grad[1]:
             dw = _wgrad_beside(ctx.wparam, lambda: conv3x3_wgrad_x3(dy, x, d), dy, x)
-        return dx, dw, None
+        return dx, dw, None, None
 
 
 def conv3x3_x3_supported(x, weight, dilation):
@@ -2227,11 +2238,21 @@ def conv3x3_x3_supported(x, weight, dilation):
             bool(load().aadg_conv3x3_wgrad_supported(weight.shape[0], weight.shape[1], x.shape[2], x.shape[3], int(dilation))))
 
 
-def conv3x3_x3(x, weight, dilation=1):
+def conv3x3_x3_stats_supported(x, weight, dilation):
+    """the shapes whose BatchNorm statistics the 3x3 kernel takes in its epilogue (the whole-tile kernel: Co % 64 == 0, Ci % 16 == 0)"""
+    return bool(load().aadg_conv3x3_f32x3_stats_supported(weight.shape[0], weight.shape[1], x.shape[2], x.shape[3], int(dilation)))
+
+
+def conv3x3_x3(x, weight, dilation=1, want_stats=False):
+    """want_stats: returns the output with its BatchNorm totals attached as `y._aadg_bn_sums` (see conv1x1_x3)"""
     _require_cuda(x, weight)
     if not conv3x3_x3_supported(x, weight, dilation):
         raise AadgError("conv3x3_x3: unsupported shape / dtype / layout")
-    return _Conv3x3X3.apply(x, weight, int(dilation))
+    if not want_stats:
+        return _Conv3x3X3.apply(x, weight, int(dilation), False)
+    y, sums = _Conv3x3X3.apply(x, weight, int(dilation), True)
+    y._aadg_bn_sums = sums
+    return y
 
 
 class _Conv3x3S2X3(torch.autograd.Function):

@@ -377,16 +377,30 @@ extern "C" int aadg_conv3x3_nchw_bf16(const void* a9, const void* in, void* out,
  * tap-major weights [9, M, K] (aadg_weight_layouts_split_bf16); hi*hi + hi*lo + lo*hi on the matrix cores, float32 accumulation */
 bool aadg_conv3x3_x3q_takes(int M, int K, int H, int W, int dilation);
 int aadg_conv3x3_x3q(const uint16_t* a9_hi, const uint16_t* a9_lo, const float* in, float* out, int N, int M, int K, int H, int W, int dilation,
-                     hipStream_t st);
+                     double* bn_sums, hipStream_t st);
 extern "C" int aadg_conv3x3_nchw_f32x3(const void* a9_hi, const void* a9_lo, const float* in, float* out, int N, int M, int K, int H, int W,
                                        int dilation, void* stream) {
+    return aadg_conv3x3_nchw_f32x3_stats(a9_hi, a9_lo, in, out, N, M, K, H, W, dilation, nullptr, stream);
+}
+
+/* the shapes whose BatchNorm statistics the convolution can take in its epilogue (the whole-tile kernel of conv3x3_x3.hip) */
+extern "C" int aadg_conv3x3_f32x3_stats_supported(int M, int K, int H, int W, int dilation) {
+    return aadg_conv3x3_nchw_supported(M, K, H, W, dilation) && aadg_conv3x3_x3q_takes(M, K, H, W, dilation) ? 1 : 0;
+}
+
+/* ... and, with bn_sums != NULL, the BatchNorm statistics of `out` from the epilogue (as aadg_conv1x1_nchw_f32x3_stats: float64 [2 M + 1] =
+ * (sum, sum of squares) per output channel + the element count N H W, zeroed in here).  AADG_E_UNSUPPORTED for a shape outside
+ * aadg_conv3x3_f32x3_stats_supported when bn_sums is given. */
+extern "C" int aadg_conv3x3_nchw_f32x3_stats(const void* a9_hi, const void* a9_lo, const float* in, float* out, int N, int M, int K, int H,
+                                             int W, int dilation, double* bn_sums, void* stream) {
     if (a9_hi == nullptr || a9_lo == nullptr || in == nullptr || out == nullptr || N <= 0) return AADG_E_BADARG;
-    if ((((uintptr_t)a9_hi | (uintptr_t)a9_lo | (uintptr_t)in | (uintptr_t)out) & 15u) != 0) return AADG_E_BADARG;
+    if ((((uintptr_t)a9_hi | (uintptr_t)a9_lo | (uintptr_t)in | (uintptr_t)out) & 15u) != 0 || (((uintptr_t)bn_sums) & 7u) != 0) return AADG_E_BADARG;
     if (!aadg_conv3x3_nchw_supported(M, K, H, W, dilation)) return AADG_E_UNSUPPORTED;
 #ifndef AADG_NO_X3Q
     // whole-tile shapes (every such layer of the backbone): the [pixel][k] kernel of conv3x3_x3.hip, two workgroups per CU
     if (aadg_conv3x3_x3q_takes(M, K, H, W, dilation))
-        return aadg_conv3x3_x3q((const uint16_t*)a9_hi, (const uint16_t*)a9_lo, in, out, N, M, K, H, W, dilation, (hipStream_t)stream);
+        return aadg_conv3x3_x3q((const uint16_t*)a9_hi, (const uint16_t*)a9_lo, in, out, N, M, K, H, W, dilation, bn_sums, (hipStream_t)stream);
 #endif
+    if (bn_sums != nullptr) return AADG_E_UNSUPPORTED;
     return conv3x3_dispatch<true>((const uint16_t*)a9_hi, (const uint16_t*)a9_lo, in, out, N, M, K, H, W, dilation, (hipStream_t)stream);
 }

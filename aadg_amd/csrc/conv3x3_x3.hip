@@ -45,10 +45,10 @@ struct QCfg {
 // byte offset of chunk c of record r
 __device__ __forceinline__ int q_chunk(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3)) << 4); }
 
-template <int W, int D>
+template <int W, int D, bool STATS>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_x3q(const uint16_t* __restrict__ A9, const uint16_t* __restrict__ A9_lo,
                                                         const float* __restrict__ IN, float* __restrict__ OUT, int M, int K, int H,
-                                                        int tiles_m, int tiles_r, int pts) {
+                                                        int tiles_m, int tiles_r, int pts, double* __restrict__ stats) {
     using C = QCfg<W, D>;
     constexpr int ROWS = C::ROWS, SR = C::SR, PW = C::PW, MI = 2, NI = 2, QPR = W / 4;     // QPR: pixel quads per image row
     constexpr int NAU = 9 * Q_BM * 2, LA = (NAU + 255) / 256;       // weight units of 8 k (16 bytes of each plane) per K-step
@@ -197,10 +197,62 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_x3q(const uint16_t* __restri
                 const size_t p = p_tile + 32 * ni + l31;
                 if (p < HW) outf[(size_t)m * HW + p] = d[mi][ni][r];
             }
+    if (!STATS) return;
+    // BatchNorm statistics of the output in the epilogue (the layer behind a bottleneck's 3x3 convolution is a BatchNorm): per channel sum
+    // and sum of squares over the tile's pixels -> float64 atomics into stats[2 m], stats[2 m + 1], as k_conv1x1_nchw does
+    // (conv1x1_fwd.hip: the halving butterfly over the 32 lanes of a row, the workgroup's four waves -- same 64 channels, 64 pixels each --
+    // combined in LDS, one atomic per channel, statistic and workgroup).  Pixels beyond the image (a last tile of fewer rows) are not
+    // stored and do not count.
+    float v[64];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = 0.f, qq = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const float e = (p_tile + 32 * ni + l31 < HW) ? d[mi][ni][r] : 0.0f;
+                s += e; qq = fmaf(e, e, qq);
+            }
+            v[2 * (16 * mi + r)] = s;
+            v[2 * (16 * mi + r) + 1] = qq;
+        }
+#define AADG_BFLY(MSK, HALF, PAT)                                                                       \
+    {                                                                                                   \
+        const bool up = (lane & (MSK)) != 0;                                                            \
+        _Pragma("unroll") for (int i = 0; i < (HALF); ++i) {                                            \
+            const float keep = up ? v[i + (HALF)] : v[i], send = up ? v[i] : v[i + (HALF)];             \
+            v[i] = keep + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send), (PAT)));     \
+        }                                                                                               \
+    }
+    AADG_BFLY(16, 32, 0x1F | (16 << 10))
+    AADG_BFLY(8, 16, 0x1F | (8 << 10))
+    AADG_BFLY(4, 8, 0x1F | (4 << 10))
+    AADG_BFLY(2, 4, 0x1F | (2 << 10))
+    AADG_BFLY(1, 2, 0x1F | (1 << 10))
+#undef AADG_BFLY
+    // the item a lane is left with: bit 4 of the lane picked the upper 32 items, bit 3 the upper 16 of those, ...
+    const int item = ((lane >> 4) & 1) * 32 + ((lane >> 3) & 1) * 16 + ((lane >> 2) & 1) * 8 + ((lane >> 1) & 1) * 4 + (lane & 1) * 2;
+    const int rr = item >> 1, smi = rr >> 4, sr = rr & 15;
+    const int row = 32 * smi + (sr & 3) + 8 * (sr >> 2) + 4 * g;
+    float* red = reinterpret_cast<float*>(Bs);                // the pixel records are free once every wave has left the K loop
+    __syncthreads();
+    if (tid < 2 * Q_BM) red[tid] = 0.0f;
+    __syncthreads();
+    __hip_atomic_fetch_add(red + 2 * row, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(red + 2 * row + 1, v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    if (tid < 2 * Q_BM) unsafeAtomicAdd(stats + 2 * (size_t)m0 + tid, (double)red[tid]);
+}
+
+__global__ __launch_bounds__(256) void k_q_sums_init(double* __restrict__ sums, int C, double count) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 2 * C) sums[i] = 0.0;
+    if (i == 2 * C) sums[i] = count;
 }
 
 template <int W, int D>
-int launch_q(const uint16_t* A9, const uint16_t* A9_lo, const float* IN, float* OUT, int N, int M, int K, int H, hipStream_t st) {
+int launch_q(const uint16_t* A9, const uint16_t* A9_lo, const float* IN, float* OUT, int N, int M, int K, int H, double* stats, hipStream_t st) {
     using C = QCfg<W, D>;
     const int tiles_m = M / Q_BM, tiles_r = (H + C::ROWS - 1) / C::ROWS;
     const long long pts = (long long)N * tiles_r, groups = (pts + 7) / 8;
@@ -208,12 +260,21 @@ int launch_q(const uint16_t* A9, const uint16_t* A9_lo, const float* IN, float* 
     if (wgs > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
     static bool attr_set = false;                            // per instantiation; idempotent
     if (!attr_set) {
-        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_x3q<W, D>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_x3q<W, D, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)C::lds_bytes));
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_x3q<W, D, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::lds_bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv3x3_x3q<W, D>), dim3((unsigned)wgs), dim3(256), C::lds_bytes, st, A9, A9_lo, IN, OUT, M, K, H, tiles_m, tiles_r,
-                       (int)pts);
+    if (stats != nullptr) {
+        hipLaunchKernelGGL(k_q_sums_init, dim3((2 * M + 1 + 255) / 256), dim3(256), 0, st, stats, M, (double)N * (double)H * (double)W);
+        AADG_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_conv3x3_x3q<W, D, true>), dim3((unsigned)wgs), dim3(256), C::lds_bytes, st, A9, A9_lo, IN, OUT, M, K, H, tiles_m,
+                           tiles_r, (int)pts, stats);
+    } else {
+        hipLaunchKernelGGL((k_conv3x3_x3q<W, D, false>), dim3((unsigned)wgs), dim3(256), C::lds_bytes, st, A9, A9_lo, IN, OUT, M, K, H, tiles_m,
+                           tiles_r, (int)pts, stats);
+    }
     AADG_LAUNCH_CHECK();
     return 0;
 }
@@ -226,13 +287,14 @@ bool aadg_conv3x3_x3q_takes(int M, int K, int H, int W, int dilation) {
            (long long)9 * M * K <= 0x7FFFFFFFLL && (long long)K * H * W <= 0x7FFFFFFFLL;
 }
 
+// bn_sums (optional): float64 [2 M + 1] = (sum, sum of squares) per output channel and the element count, zeroed in here
 int aadg_conv3x3_x3q(const uint16_t* a9_hi, const uint16_t* a9_lo, const float* in, float* out, int N, int M, int K, int H, int W,
-                     int dilation, hipStream_t st) {
+                     int dilation, double* bn_sums, hipStream_t st) {
     if (dilation == 1) {
-        if (W == 32) return launch_q<32, 1>(a9_hi, a9_lo, in, out, N, M, K, H, st);
-        if (W == 64) return launch_q<64, 1>(a9_hi, a9_lo, in, out, N, M, K, H, st);
-        return launch_q<128, 1>(a9_hi, a9_lo, in, out, N, M, K, H, st);
+        if (W == 32) return launch_q<32, 1>(a9_hi, a9_lo, in, out, N, M, K, H, bn_sums, st);
+        if (W == 64) return launch_q<64, 1>(a9_hi, a9_lo, in, out, N, M, K, H, bn_sums, st);
+        return launch_q<128, 1>(a9_hi, a9_lo, in, out, N, M, K, H, bn_sums, st);
     }
-    if (W == 32) return launch_q<32, 2>(a9_hi, a9_lo, in, out, N, M, K, H, st);
-    return launch_q<64, 2>(a9_hi, a9_lo, in, out, N, M, K, H, st);
+    if (W == 32) return launch_q<32, 2>(a9_hi, a9_lo, in, out, N, M, K, H, bn_sums, st);
+    return launch_q<64, 2>(a9_hi, a9_lo, in, out, N, M, K, H, bn_sums, st);
 }

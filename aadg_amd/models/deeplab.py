@@ -71,15 +71,15 @@ def batch_step_bookkeeping(model, f32x3=False):
 
 
 def mark_bn_producers(model):
-    """Sets `bn_stats` on every pointwise convolution whose output goes straight into a BatchNorm of this module tree -- the bottleneck's
-    conv1 / conv3, a (convolution, BNAct) pair inside an nn.Sequential (projection shortcuts, ASPP branches, the decoder) and the pointwise
+    """Sets `bn_stats` on every convolution whose output goes straight into a BatchNorm of this module tree -- the bottleneck's
+    conv1 / conv2 / conv3, a (convolution, BNAct) pair inside an nn.Sequential (projection shortcuts, ASPP branches, the decoder) and the pointwise
     half of a SeparableConv2d in such a pair: in f32x3 training mode those convolutions take the BatchNorm statistics of their output in
     the kernel epilogue (csrc/conv1x1_fwd.hip) and bn_act skips the statistics pass."""
     n = 0
     for m in model.modules():
         if isinstance(m, Bottleneck):
-            m.conv1.bn_stats = m.conv3.bn_stats = True
-            n += 2
+            m.conv1.bn_stats = m.conv2.bn_stats = m.conv3.bn_stats = True      # (conv2: at stride 1, shapes of the whole-tile kernel)
+            n += 3
         if isinstance(m, nn.Sequential):
             mods = list(m)
             for a_, b_ in zip(mods[:-1], mods[1:]):
@@ -212,6 +212,7 @@ class Conv3x3(nn.Conv2d):
     planes in LDS); forward and input gradient stay the library's."""
 
     f32x3 = False           # float32 inputs: the own float32-precision kernels instead of the library's (batch_step_bookkeeping)
+    bn_stats = False        # f32x3, training, stride 1: the BatchNorm behind it takes its statistics from this convolution's epilogue
 
     def __init__(self, cin, cout, stride=1, dilation=1):
         super().__init__(cin, cout, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
@@ -222,7 +223,9 @@ class Conv3x3(nn.Conv2d):
                 from .. import _lib
                 xc = x.contiguous()
                 if _lib.conv3x3_x3_supported(xc, self.weight, self.dilation[0]):
-                    return _lib.conv3x3_x3(xc, self.weight, self.dilation[0])
+                    stats = (self.bn_stats and self.training and torch.is_grad_enabled() and
+                             _lib.conv3x3_x3_stats_supported(xc, self.weight, self.dilation[0]))
+                    return _lib.conv3x3_x3(xc, self.weight, self.dilation[0], stats)
             elif self.stride == (2, 2) and self.dilation == (1, 1) and self.padding == (1, 1):
                 from .. import _lib
                 xc = x.contiguous()

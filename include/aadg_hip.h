@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AADG_ABI_VERSION 9
+#define AADG_ABI_VERSION 10
 #define AADG_MAX_OPS 4
 
 #define AADG_E_BADARG (-1)
@@ -494,6 +494,12 @@ int aadg_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dweight9, int 
  * tap-major float32 weights.  The weight gradient excludes W = 128 with d = 2 (LDS). */
 int aadg_conv3x3_nchw_f32x3(const void* a9_hi, const void* a9_lo, const float* in, float* out, int N, int M, int K, int H, int W,
                             int dilation, void* stream);
+/* ABI 10 -- the same with the BatchNorm statistics of `out` from the epilogue (see aadg_conv1x1_nchw_f32x3_stats: bn_sums float64
+ * [2 M + 1] = (sum, sum of squares) per output channel + the element count, zeroed by the call; NULL = none).  Only the shapes of
+ * aadg_conv3x3_f32x3_stats_supported (M % 64 == 0, K % 16 == 0: every bottleneck of the backbone) -- AADG_E_UNSUPPORTED otherwise. */
+int aadg_conv3x3_f32x3_stats_supported(int M, int K, int H, int W, int dilation);
+int aadg_conv3x3_nchw_f32x3_stats(const void* a9_hi, const void* a9_lo, const float* in, float* out, int N, int M, int K, int H, int W,
+                                  int dilation, double* bn_sums, void* stream);
 int aadg_conv3x3_wgrad_f32x3(const float* dy, const float* x, float* dweight9, int N, int Co, int Ci, int H, int W, int dilation,
                              void* stream);
 

@@ -195,6 +195,70 @@ def test_conv1x1_x3_batchnorm_statistics_from_the_epilogue(hip, N, K, M, H, W):
     assert torch.equal(y, hip.conv1x1_nchw_x3(hip.split_weight(w), x))                   # the output itself is unchanged
 
 
+@pytest.mark.parametrize("N,K,M,H,W,d", [(3, 64, 64, 32, 32, 1), (2, 128, 128, 64, 64, 1), (2, 32, 64, 128, 128, 1), (2, 64, 192, 32, 32, 2),
+                                         (1, 48, 64, 30, 64, 2), (2, 16, 64, 7, 32, 1)])
+def test_conv3x3_x3_batchnorm_statistics_from_the_epilogue(hip, N, K, M, H, W, d):
+    """aadg_conv3x3_nchw_f32x3_stats (ABI 10): (sum, sum of squares) per output channel + the element count from the epilogue of the
+    whole-tile 3x3 kernel == the sums of the stored output; heights that are not a multiple of the tile's rows (the pixels of the last
+    tile beyond the image are computed but must not count)."""
+    torch.manual_seed(M + W + d)
+    x = torch.randn(N, K, H, W, device="cuda") + 0.3
+    w = torch.randn(M, K, 3, 3, device="cuda") / (9 * K) ** 0.5
+    a9 = hip.split_weight(w.permute(2, 3, 0, 1).reshape(9, M, K).contiguous())
+    assert hip.conv3x3_x3_stats_supported(x, w, d)
+    sums = torch.full((2 * M + 1,), 7.0, dtype=torch.float64, device="cuda")           # (the call zeroes it)
+    y = hip.conv3x3_nchw_x3(a9, x, d, sums)
+    yd = y.double()
+    want_s, want_q = yd.sum(dim=(0, 2, 3)), (yd * yd).sum(dim=(0, 2, 3))
+    got = sums[:2 * M].view(M, 2)
+    assert sums[2 * M].item() == N * H * W
+    assert (got[:, 0] - want_s).abs().max().item() <= 1e-5 * want_q.sqrt().max().item() * (N * H * W) ** 0.5
+    assert ((got[:, 1] - want_q).abs() / want_q).max().item() <= 1e-5
+    assert torch.equal(y, hip.conv3x3_nchw_x3(a9, x, d))                                # the output itself is unchanged
+
+
+def test_conv3x3_x3_statistics_only_for_whole_tile_shapes(hip):
+    x = torch.randn(1, 24, 32, 32, device="cuda")                                       # 24 input channels: the [k][pixel] kernel's shape
+    w = torch.randn(64, 24, 3, 3, device="cuda")
+    assert hip.conv3x3_x3_supported(x, w, 1) and not hip.conv3x3_x3_stats_supported(x, w, 1)
+    a9 = hip.split_weight(w.permute(2, 3, 0, 1).reshape(9, 64, 24).contiguous())
+    with pytest.raises(hip.AadgError):
+        hip.conv3x3_nchw_x3(a9, x, 1, torch.zeros(129, dtype=torch.float64, device="cuda"))
+    hip.conv3x3_nchw_x3(a9, x, 1)                                                       # without statistics: the other kernel takes it
+
+
+@pytest.mark.parametrize("dilation", [1, 2])
+def test_batchnorm_behind_an_f32x3_3x3_convolution_uses_its_statistics(hip, dilation):
+    """models/deeplab.py: a bottleneck's Conv3x3 marked `bn_stats` hands the BatchNorm totals of its output to bn_act: output, running
+    statistics and all gradients == plain torch (float64)."""
+    from aadg_amd.models import deeplab as DL
+    torch.manual_seed(19)
+    conv1 = DL.Conv3x3(64, 64, 1, dilation).cuda().train()
+    bnact = DL.BNAct(64, "relu").cuda().train()
+    net = torch.nn.Sequential(conv1, bnact)
+    DL.batch_step_bookkeeping(net, f32x3=True)
+    conv1.bn_stats = True
+    conv = torch.nn.Conv2d(64, 64, 3, padding=dilation, dilation=dilation, bias=False).cuda().double()
+    bn = torch.nn.BatchNorm2d(64).cuda().double().train()
+    conv.weight.data.copy_(conv1.weight.data.double())
+    x1 = torch.randn(4, 64, 32, 32, device="cuda", requires_grad=True)
+    x2 = x1.detach().double().requires_grad_(True)
+    c1 = conv1(x1)
+    assert getattr(c1, "_aadg_bn_sums", None) is not None and c1._aadg_bn_sums.dtype == torch.float64
+    y1 = DL.bn_act(bnact.bn, c1, "relu")
+    y2 = torch.relu(bn(conv(x2)))
+    assert _err(y1, y2.detach()) <= 3e-5
+    assert _err(bnact.bn.running_var, bn.running_var) <= 1e-6 and (bnact.bn.running_mean.double() - bn.running_mean).abs().max().item() <= 1e-6
+    g = torch.randn_like(y1)
+    y1.backward(g)
+    y2.backward(g.double())
+    assert _err(x1.grad, x2.grad) <= 3e-5 and _err(conv1.weight.grad, conv.weight.grad) <= 3e-5
+    assert _err(bnact.bn.weight.grad, bn.weight.grad) <= 3e-5 and _err(bnact.bn.bias.grad, bn.bias.grad) <= 3e-5
+    # no statistics in evaluation mode / without gradients
+    with torch.no_grad():
+        assert getattr(conv1(x1), "_aadg_bn_sums", None) is None
+
+
 @pytest.mark.parametrize("act,res", [("relu", False), (None, False), ("relu", True)])
 def test_batchnorm_behind_an_f32x3_convolution_uses_its_statistics(hip, act, res):
     """models/deeplab.py: a Conv1x1 marked `bn_stats` (mark_bn_producers) hands the BatchNorm totals of its output to bn_act, which then
