@@ -80,7 +80,7 @@ def parse():
     ap.add_argument("--legs", default="auto", help="comma list of extra legs at N = 1: fop,kernels,rvs1024,cpu,precision,scale  (auto = all; none = skip)")
     ap.add_argument("--only_legs", default=None,
                     help="skip the headline step and print ONE JSON line holding only these legs (fop,kernels,rvs1024): the target of "
-                         "the rocprofv3 runs behind profiles/r04_fop_*, profiles/r04_aug512_* and profiles/r04_rvs1024_*")
+                         "the rocprofv3 runs behind profiles/r05_fop_*, profiles/r05_aug512_* and profiles/r05_rvs1024_*")
     ap.add_argument("--no_cpu_baseline", action="store_true", help="same as removing `cpu` from --legs")
     ap.add_argument("--cpu_repeats", type=int, default=20)
     ap.add_argument("--no_sync_bn", action="store_true",
@@ -514,8 +514,8 @@ def float_ops_leg(B=144, size=512, repeats=10):
                     % repeats,
             "frac_min": float(min(fr)), "frac_median": float(np.median(fr)), "slowest": {"op": worst[0], "achieved": worst[1]},
             "ops": res,
-            "rocprof": "profiles/r04_fop_kernel_stats.txt (rocprofv3 --kernel-trace --stats -- python bench.py --only_legs fop), "
-                       "profiles/r04_fop_traffic.json (FETCH_SIZE / WRITE_SIZE passes)"}
+            "rocprof": "profiles/r05_fop_kernel_stats.txt (rocprofv3 --kernel-trace --stats -- python bench.py --only_legs fop), "
+                       "profiles/r05_fop_traffic.json (FETCH_SIZE / WRITE_SIZE passes)"}
 
 
 def hot_kernels_leg(D=3, B=8, M=6, size=512, K=2, repeats=20):
