@@ -7,7 +7,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("shape,d", [((2, 8, 32, 32), 12), ((2, 8, 32, 32), 36), ((3, 5, 32, 32), 24), ((2, 16, 128, 128), 1),
-                                     ((2, 4, 16, 8), 2), ((1, 3, 40, 24), 1), ((2, 6, 9, 256), 3), ((5, 7, 8, 8), 1)])
+                                     ((2, 4, 16, 8), 2), ((1, 3, 40, 24), 1), ((2, 6, 9, 256), 3), ((5, 7, 8, 8), 1),
+                                     # widths that are no power of two: more rows per thread than the weight gradient preloads (9 > 8),
+                                     # strided and walking row order
+                                     ((2, 3, 96, 96), 1), ((2, 3, 90, 88), 1), ((2, 2, 96, 96), 2)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_dwconv_matches_conv2d(hip, shape, d, dtype):
     torch.manual_seed(shape[1] + d)
