@@ -60,6 +60,7 @@ EXPORTS = [
     "aadg_conv3x3_wgrad_f32x3", "aadg_conv3x3s2_nchw_f32x3", "aadg_conv3x3s2_dgrad_f32x3", "aadg_conv3x3s2_wgrad_f32x3",
     "aadg_stem_conv7x7_f32x3", "aadg_stem_conv7x7_wgrad_f32x3", "aadg_sinkhorn_divergence_phases_f32",
     "aadg_conv1x1_nchw_f32x3_stats", "aadg_conv3x3_nchw_f32x3_stats", "aadg_conv3x3_f32x3_stats_supported",
+    "aadg_bn_finalize_f32", "aadg_conv1x1_f32x3_pre_supported", "aadg_conv1x1_nchw_f32x3_pre", "aadg_conv1x1_wgrad_f32x3_pre",
 ]
 
 _lib = None
@@ -248,6 +249,14 @@ def load():
     lib.aadg_conv1x1_nchw_f32x3_stats.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]
     lib.aadg_conv1x1_wgrad_f32x3.restype = _i
     lib.aadg_conv1x1_wgrad_f32x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp]
+    lib.aadg_bn_finalize_f32.restype = _i
+    lib.aadg_bn_finalize_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]
+    lib.aadg_conv1x1_f32x3_pre_supported.restype = _i
+    lib.aadg_conv1x1_f32x3_pre_supported.argtypes = [_i, _i, _i]
+    lib.aadg_conv1x1_nchw_f32x3_pre.restype = _i
+    lib.aadg_conv1x1_nchw_f32x3_pre.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]
+    lib.aadg_conv1x1_wgrad_f32x3_pre.restype = _i
+    lib.aadg_conv1x1_wgrad_f32x3_pre.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]
     lib.aadg_conv3x3_nchw_f32x3.restype = _i
     lib.aadg_conv3x3_nchw_f32x3.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
     lib.aadg_conv3x3_nchw_f32x3_stats.restype = _i
@@ -2075,23 +2084,29 @@ def conv3x3(x, weight, dilation=1):
 # x = hi + lo and every product formed as hi*hi + hi*lo + lo*hi on the bfloat16 matrix cores with float32 accumulation (csrc/common.h:
 # aadg_split4; the X3 instantiations of the convolution kernels).  Activations are split inside the kernels while they are staged in
 # LDS; the weights come pre-split from the tracked shadows (track_bf16_weights(..., split=True)) or, untracked, from split_weight().
-def conv1x1_nchw_x3(a2, x, bn_sums=None):
+def conv1x1_nchw_x3(a2, x, bn_sums=None, pre=None):
     """out [N, M, H, W] float32 = a [M, K] applied to the channels of x [N, K, H, W] float32; a2 [2, M, K] bfloat16 = (hi, lo) of a.
-    bn_sums (float64 [2M + 1], optional) receives the BatchNorm statistics of out from the kernel's epilogue."""
+    bn_sums (float64 [2M + 1], optional) receives the BatchNorm statistics of out from the kernel's epilogue.
+    pre = (scale, shift) float32 [K] (optional; shapes of conv1x1_x3_pre_supported): x is the INPUT of a BatchNorm + ReLU and the
+    kernel applies max(x * scale[k] + shift[k], 0) while it loads it."""
     _require_cuda(a2, x)
     N, K, H, W = x.shape
     M = a2.shape[1]
     if (a2.dtype != torch.bfloat16 or x.dtype != torch.float32 or a2.dim() != 3 or a2.shape[0] != 2 or a2.shape[2] != K or
             not (a2.is_contiguous() and x.is_contiguous()) or not load().aadg_conv1x1_nchw_supported(M, K, H * W)):
         raise AadgError("conv1x1_nchw_x3: unsupported shape / dtype / layout")
+    if pre is not None and not all(p.dtype == torch.float32 and p.numel() == K and p.is_cuda and p.is_contiguous() for p in pre):
+        raise AadgError("conv1x1_nchw_x3: pre = (scale, shift), float32 [K]")
     out = torch.empty((N, M, H, W), dtype=torch.float32, device=x.device)
-    _check(load().aadg_conv1x1_nchw_f32x3_stats(a2[0].data_ptr(), a2[1].data_ptr(), x.data_ptr(), out.data_ptr(), N, M, K, H * W,
-                                                _ptr(bn_sums), _stream()), "aadg_conv1x1_nchw_f32x3")
+    _check(load().aadg_conv1x1_nchw_f32x3_pre(a2[0].data_ptr(), a2[1].data_ptr(), x.data_ptr(), out.data_ptr(), N, M, K, H * W,
+                                              _ptr(pre[0]) if pre else None, _ptr(pre[1]) if pre else None, _ptr(bn_sums), _stream()),
+           "aadg_conv1x1_nchw_f32x3")
     return out
 
 
-def conv1x1_wgrad_x3(dy, x):
-    """dW [Co, Ci] float32 of a 1x1 / stride-1 convolution from NCHW float32 dy [N,Co,H,W] and x [N,Ci,H,W]"""
+def conv1x1_wgrad_x3(dy, x, pre=None):
+    """dW [Co, Ci] float32 of a 1x1 / stride-1 convolution from NCHW float32 dy [N,Co,H,W] and x [N,Ci,H,W]; pre = (scale, shift): the
+    convolution consumed max(x * scale[c] + shift[c], 0) (conv1x1_nchw_x3(..., pre=...))"""
     _require_cuda(dy, x)
     if dy.dtype != torch.float32 or x.dtype != torch.float32 or not (dy.is_contiguous() and x.is_contiguous()):
         raise AadgError("conv1x1_wgrad_x3: expected contiguous NCHW float32 tensors")
@@ -2100,7 +2115,8 @@ def conv1x1_wgrad_x3(dy, x):
     if x.shape[0] != N or x.shape[2:] != dy.shape[2:]:
         raise AadgError("conv1x1_wgrad_x3: shape mismatch")
     dw = torch.empty((Co, Ci), dtype=torch.float32, device=x.device)
-    _check(load().aadg_conv1x1_wgrad_f32x3(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, Co, Ci, H * W, _stream()), "aadg_conv1x1_wgrad_f32x3")
+    _check(load().aadg_conv1x1_wgrad_f32x3_pre(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, Co, Ci, H * W,
+                                               _ptr(pre[0]) if pre else None, _ptr(pre[1]) if pre else None, _stream()), "aadg_conv1x1_wgrad_f32x3")
     return dw
 
 
@@ -2109,25 +2125,29 @@ class _Conv1x1X3(torch.autograd.Function):
     (csrc/conv1x1_fwd.hip, X3) and weight gradient (csrc/conv1x1_wgrad.hip, X3).  `weight` is the float32 parameter."""
 
     @staticmethod
-    def forward(ctx, x, weight, want_stats=False):
+    def forward(ctx, x, weight, want_stats=False, pre_scale=None, pre_shift=None):
         """want_stats: also return the float64 [2 Co + 1] BatchNorm totals of the output (sum, sum of squares per channel, count), taken
-        in the kernel's epilogue -- for the BatchNorm layer behind this convolution (batch_norm_act(..., presums=...))."""
+        in the kernel's epilogue -- for the BatchNorm layer behind this convolution (batch_norm_act(..., presums=...)).
+        pre_scale / pre_shift: x is the output of batch_norm_lazy -- the raw input of a BatchNorm + ReLU that this convolution (and its
+        weight gradient) applies on load."""
         Co, Ci = weight.shape[0], weight.shape[1]
         a2 = split_layout(weight, "plain")
         a2 = a2.view(2, Co, Ci) if a2 is not None else split_weight(weight.detach().reshape(Co, Ci))
-        ctx.save_for_backward(x, weight)
+        pre = (pre_scale, pre_shift) if pre_scale is not None else None
+        ctx.save_for_backward(x, weight, pre_scale, pre_shift)
         ctx.wparam = weight
         ctx.wt = _ShadowRef(weight, "bwd", split=True)          # [2, 1, Ci, Co] of the tracked shadow (this step's weights)
         if not want_stats:
-            return conv1x1_nchw_x3(a2, x)
+            return conv1x1_nchw_x3(a2, x, None, pre)
         sums = torch.empty(2 * Co + 1, dtype=torch.float64, device=x.device)
-        y = conv1x1_nchw_x3(a2, x, sums)
+        y = conv1x1_nchw_x3(a2, x, sums, pre)
         ctx.mark_non_differentiable(sums)
         return y, sums
 
     @staticmethod
     def backward(ctx, dy, *unused):
-        x, weight = ctx.saved_tensors
+        x, weight, pre_scale, pre_shift = ctx.saved_tensors
+        pre = (pre_scale, pre_shift) if pre_scale is not None else None
         dy = dy.contiguous()
         Co, Ci = weight.shape[0], weight.shape[1]
         dx = dw = None
@@ -2136,8 +2156,8 @@ class _Conv1x1X3(torch.autograd.Function):
             at = wt.view(2, Ci, Co) if wt is not None else split_weight(weight.detach().reshape(Co, Ci).t().contiguous())
             dx = conv1x1_nchw_x3(at, dy)
         if ctx.needs_input_grad[1]:
-            dw = _wgrad_beside(ctx.wparam, lambda: conv1x1_wgrad_x3(dy, x).view(weight.shape), dy, x)
-        return dx, dw, None
+            dw = _wgrad_beside(ctx.wparam, lambda: conv1x1_wgrad_x3(dy, x, pre).view(weight.shape), dy, x)
+        return dx, dw, None, None, None
 
 
 def conv1x1_x3_supported(x, weight):
@@ -2147,17 +2167,75 @@ def conv1x1_x3_supported(x, weight):
             bool(load().aadg_conv1x1_nchw_supported(weight.shape[0], weight.shape[1], HW)))
 
 
-def conv1x1_x3(x, weight, want_stats=False):
+def conv1x1_x3_pre_supported(x, weight):
+    """the shapes on which the 1x1 kernels apply a BatchNorm + ReLU to x while they load it (forward and weight gradient: whole tiles)"""
+    Co, Ci = weight.shape[0], weight.shape[1]
+    HW = x.shape[2] * x.shape[3] if x.dim() == 4 else 0
+    # (the weight gradient's tiles: 256 x 64 for Ci <= 64, else 128 x 128 or 256 x 256)
+    return (conv1x1_x3_supported(x, weight) and bool(load().aadg_conv1x1_f32x3_pre_supported(Co, Ci, HW)) and Co % 256 == 0 and
+            (Ci == 64 or Ci % 128 == 0))
+
+
+def conv1x1_x3(x, weight, want_stats=False, pre=None):
     """want_stats: returns the output with its BatchNorm totals attached as `y._aadg_bn_sums` (float64 [2 Co + 1]); models/deeplab.py's
-    bn_act hands them to the BatchNorm kernels, which then skip their statistics pass over y."""
+    bn_act hands them to the BatchNorm kernels, which then skip their statistics pass over y.
+    pre = (scale, shift) from batch_norm_lazy, x its first output: the BatchNorm + ReLU in front of this convolution runs on operand load."""
     _require_cuda(x, weight)
-    if not conv1x1_x3_supported(x, weight):
+    if not conv1x1_x3_supported(x, weight) or (pre is not None and not conv1x1_x3_pre_supported(x, weight)):
         raise AadgError("conv1x1_x3: unsupported shape / dtype / layout")
+    ps, ph = pre if pre is not None else (None, None)
     if not want_stats:
-        return _Conv1x1X3.apply(x, weight, False)
-    y, sums = _Conv1x1X3.apply(x, weight, True)
+        return _Conv1x1X3.apply(x, weight, False, ps, ph)
+    y, sums = _Conv1x1X3.apply(x, weight, True, ps, ph)
     y._aadg_bn_sums = sums
     return y
+
+
+class _BatchNormLazy(torch.autograd.Function):
+    """Training-mode relu(batch_norm(x)) whose elementwise pass the CONSUMING convolution applies on load (conv1x1_x3(..., pre=...)):
+    the forward only finalises the statistics (aadg_bn_finalize_f32, from the totals the producing convolution left) and hands x on
+    UNCHANGED together with scale / shift; the backward is the ordinary two-pass BatchNorm backward with the ReLU mask re-derived from
+    x.  The first output stands for relu(bn(x)) in the graph but HOLDS x: only a consumer that applies (scale, shift) may read it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, presums):
+        lib = load()
+        C = x.shape[1]
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        scale = torch.empty(C, dtype=torch.float32, device=x.device)
+        shift = torch.empty(C, dtype=torch.float32, device=x.device)
+        _check(lib.aadg_bn_finalize_f32(presums.data_ptr(), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var), momentum, eps,
+                                        C, mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _stream()),
+               "aadg_bn_finalize_f32")
+        ctx.save_for_backward(x, weight, bias, mean, invstd)
+        ctx.mark_non_differentiable(scale, shift)
+        return x.view_as(x), scale, shift
+
+    @staticmethod
+    def backward(ctx, dz, *unused):
+        lib = load()
+        x, weight, bias, mean, invstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dz = dz.contiguous()
+        dx = torch.empty_like(x)
+        dw = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _bn_ws(C, x.device)
+        rc = lib.aadg_bn_backward(x.data_ptr(), None, None, dz.data_ptr(), None, 0, None, _ptr(weight), _ptr(bias), mean.data_ptr(),
+                                  invstd.data_ptr(), ACT_RELU, dx.data_ptr(), None, dw.data_ptr(), db.data_ptr(), N, C, H * W,
+                                  _BN_DTYPES[x.dtype], ws.data_ptr(), ws.numel(), 0, _stream())
+        _check(rc, "aadg_bn_backward")
+        return dx, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None
+
+
+def batch_norm_lazy(x, weight, bias, running_mean, running_var, momentum, eps, presums):
+    """(x', scale, shift): see _BatchNormLazy.  x float32 NCHW contiguous on the GPU, presums its float64 [2C + 1] totals."""
+    _require_cuda(x)
+    if (x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous() or presums is None or presums.dtype != torch.float64 or
+            presums.numel() != 2 * x.shape[1] + 1 or not bn_act_supported(x, None)):
+        raise AadgError("batch_norm_lazy: expected a contiguous NCHW float32 tensor and its float64 [2C + 1] totals")
+    return _BatchNormLazy.apply(x, weight, bias, running_mean, running_var, float(momentum), float(eps), presums)
 
 
 def conv3x3_nchw_x3(a9, x, dilation=1, bn_sums=None):

@@ -880,6 +880,50 @@ extern "C" int aadg_bn_sync_backward(int phase, const void* x, const void* y, co
     return AADG_E_BADARG;
 }
 
+// ---- statistics only (ABI 10): the BatchNorm whose normalise + ReLU pass the CONSUMING convolution applies on load ------------
+namespace {
+__global__ __launch_bounds__(256) void k_bn_finalize(const double* __restrict__ sums, int C, const float* __restrict__ weight,
+                                                     const float* __restrict__ bias, float* __restrict__ running_mean,
+                                                     float* __restrict__ running_var, float momentum, float eps, float* __restrict__ save_mean,
+                                                     float* __restrict__ save_invstd, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    // (k_bn_apply's finalisation, expression by expression: the backward re-derives the ReLU mask from these coefficients)
+    const double count = sums[2 * (size_t)C];
+    const double m = sums[2 * c] / count;
+    double var = sums[2 * c + 1] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    float sc, sh;
+    bn_scale_shift_of(weight, bias, (float)m, is, c, &sc, &sh);
+    scale[c] = sc; shift[c] = sh;
+    save_mean[c] = (float)m;
+    save_invstd[c] = is;
+    if (running_mean != nullptr) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+}  // namespace
+
+/* Training-mode BatchNorm WITHOUT its elementwise pass: from the float64 totals of x (`sums` [2C + 1]: sum, sum of squares per channel,
+ * element count -- aadg_conv3x3_nchw_f32x3_stats / aadg_conv1x1_nchw_f32x3_stats / aadg_bn_sync_forward(phase 1)) the saved mean /
+ * invstd, the running statistics' update and scale / shift [C] of y = x * scale + shift -- the coefficients the consuming convolution
+ * applies on load (aadg_conv1x1_nchw_f32x3_pre).  The backward is aadg_bn_backward with act = ReLU and no stored output (the mask is
+ * re-derived from x). */
+extern "C" int aadg_bn_finalize_f32(const double* sums, const float* weight, const float* bias, float* running_mean, float* running_var,
+                                    float momentum, float eps, int C, float* save_mean, float* save_invstd, float* scale, float* shift,
+                                    void* stream) {
+    if (sums == nullptr || save_mean == nullptr || save_invstd == nullptr || scale == nullptr || shift == nullptr || C <= 0 ||
+        (running_mean == nullptr) != (running_var == nullptr))
+        return AADG_E_BADARG;
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, weight, bias, running_mean, running_var,
+                       momentum, eps, save_mean, save_invstd, scale, shift);
+    AADG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int aadg_bn_relu_maxpool_supported(int H, int W, int dtype) {
     const int Ho = (H - 1) / 2 + 1, Wo = W / 2;
     return (dtype == 0 || dtype == 1) && H >= 2 && W >= 8 && (W % 8) == 0 && ((long long)Ho * Wo) % 1024 == 0 ? 1 : 0;

@@ -39,10 +39,17 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const uint16_t* p) {
 // accumulation): float32-grade products at a third of the bfloat16 rate.  K-step 32 (both planes of both operands: 55 KB of LDS).
 // EXACT (X3 only): M, K and HW are whole tiles / K-steps -- no bounds checks, i.e. no exec-mask branches around the twelve loads of a
 // K-step (each guarded load is a basic block of its own: the loads of a step cannot be issued together across them).
-template <int WR, int WC, int MI, int NI, bool X3, bool EXACT = false>
+// PRE (X3 + EXACT only, K <= CF_PRE_K): IN is the INPUT of a BatchNorm + ReLU whose output this convolution consumes -- the loaded
+// values become max(fma(x, pre_scale[k], pre_shift[k]), 0) on their way to LDS (the BatchNorm kernels' own expression, so the mask its
+// backward re-derives from x is the one applied here); the normalised tensor is never written.
+constexpr int CF_PRE_K = 512;
+template <int WR, int WC, int MI, int NI, bool X3, bool EXACT = false, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restrict__ A, const uint16_t* __restrict__ A_lo,
                                                          const void* __restrict__ IN_, void* __restrict__ OUT_, int M, int K, int HW,
-                                                         int tiles_p, int tiles_m, double* __restrict__ stats) {
+                                                         int tiles_p, int tiles_m, double* __restrict__ stats,
+                                                         const float* __restrict__ pre_scale = nullptr,
+                                                         const float* __restrict__ pre_shift = nullptr) {
+    static_assert(!PRE || (X3 && EXACT), "the load transform exists for whole-tile float32 shapes");
     static_assert(WR * WC == 4 && 32 * NI * WC == CF_BP, "4 waves, 256 pixels");
     constexpr int BM = 32 * MI * WR;
     constexpr int BK = X3 ? 32 : CF_BK, APITCH = BK + 8, PL = X3 ? 2 : 1;
@@ -55,8 +62,11 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
     // (SQ_LDS_BANK_CONFLICT was 36 % of SQ_LDS_IDX_ACTIVE); with 16 the 32 lanes cover the 64 banks exactly
     constexpr int BPITCH = X3 ? CF_BP + 32 : CF_BPITCH;
     __shared__ __attribute__((aligned(16))) uint16_t Bs[PL * BK * BPITCH];
+    __shared__ float Ps[PRE ? 2 * CF_PRE_K : 2];                          // PRE: scale [K] | shift [K] (visible behind the loop's first barrier)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv / WC, wc = wv - wr * WC;
+    if (PRE)
+        for (int i = tid; i < K; i += 256) { Ps[i] = pre_scale[i]; Ps[CF_PRE_K + i] = pre_shift[i]; }
     // grid: pixel tile fastest, then output-channel tile, then image: the workgroups that share an IN tile are neighbours
     const int tp = blockIdx.x % tiles_p, t2 = blockIdx.x / tiles_p;
     const int tm = t2 % tiles_m, n = t2 / tiles_m;
@@ -111,8 +121,13 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
             const int id = tid + 256 * i;
             if (X3) {
                 uint2 hi, lo;
-                aadg_split4(make_float4(__uint_as_float(rb[i].x), __uint_as_float(rb[i].y), __uint_as_float(rb[i].z), __uint_as_float(rb[i].w)),
-                            hi, lo);
+                float4 f = make_float4(__uint_as_float(rb[i].x), __uint_as_float(rb[i].y), __uint_as_float(rb[i].z), __uint_as_float(rb[i].w));
+                if (PRE) {
+                    const float sc = Ps[k0 + (id >> 6)], sh = Ps[CF_PRE_K + k0 + (id >> 6)];
+                    f.x = fmaxf(fmaf(f.x, sc, sh), 0.0f); f.y = fmaxf(fmaf(f.y, sc, sh), 0.0f);
+                    f.z = fmaxf(fmaf(f.z, sc, sh), 0.0f); f.w = fmaxf(fmaf(f.w, sc, sh), 0.0f);
+                }
+                aadg_split4(f, hi, lo);
                 uint16_t* dst = Bs + (id >> 6) * BPITCH + (id & 63) * 4;
                 *reinterpret_cast<uint2*>(dst) = hi;
                 *reinterpret_cast<uint2*>(dst + BK * BPITCH) = lo;
@@ -254,16 +269,23 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
 
 template <int WR, int WC, int MI, int NI, bool X3>
 int launch(const uint16_t* A, const uint16_t* A_lo, const void* IN, void* OUT, int N, int M, int K, int HW, hipStream_t st,
-           double* stats = nullptr) {
+           double* stats = nullptr, const float* pre_scale = nullptr, const float* pre_shift = nullptr) {
     constexpr int BM = 32 * MI * WR;
     if (X3 && (M % BM) == 0 && (K % 32) == 0 && (HW % CF_BP) == 0) {          // whole tiles: the branch-free instantiation
         const long long wgs_e = (long long)N * (HW / CF_BP) * (M / BM);
         if (wgs_e > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
-        hipLaunchKernelGGL((k_conv1x1_nchw<WR, WC, MI, NI, X3, X3>), dim3((unsigned)wgs_e), dim3(256), 0, st, A, A_lo, IN, OUT, M, K, HW,
-                           HW / CF_BP, M / BM, stats);
+        if (pre_scale != nullptr) {
+            if (K > CF_PRE_K) return AADG_E_UNSUPPORTED;
+            hipLaunchKernelGGL((k_conv1x1_nchw<WR, WC, MI, NI, X3, X3, X3>), dim3((unsigned)wgs_e), dim3(256), 0, st, A, A_lo, IN, OUT, M, K, HW,
+                               HW / CF_BP, M / BM, stats, pre_scale, pre_shift);
+        } else {
+            hipLaunchKernelGGL((k_conv1x1_nchw<WR, WC, MI, NI, X3, X3>), dim3((unsigned)wgs_e), dim3(256), 0, st, A, A_lo, IN, OUT, M, K, HW,
+                               HW / CF_BP, M / BM, stats);
+        }
         AADG_LAUNCH_CHECK();
         return 0;
     }
+    if (pre_scale != nullptr) return AADG_E_UNSUPPORTED;
     const int tiles_p = (HW + CF_BP - 1) / CF_BP, tiles_m = (M + BM - 1) / BM;
     const long long wgs = (long long)N * tiles_p * tiles_m;
     if (wgs > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
@@ -311,6 +333,21 @@ extern "C" int aadg_conv1x1_nchw_f32x3(const void* a_hi, const void* a_lo, const
  * / aadg_bn_sync_backward take (one pass over the float32 output less per BatchNorm layer; the buffer is zeroed in here). */
 extern "C" int aadg_conv1x1_nchw_f32x3_stats(const void* a_hi, const void* a_lo, const float* in, float* out, int N, int M, int K, int HW,
                                              double* bn_sums, void* stream) {
+    return aadg_conv1x1_nchw_f32x3_pre(a_hi, a_lo, in, out, N, M, K, HW, nullptr, nullptr, bn_sums, stream);
+}
+
+/* the shapes of aadg_conv1x1_nchw_f32x3_pre: whole tiles (M % 128, K % 32, HW % 256 == 0), K <= 512 */
+extern "C" int aadg_conv1x1_f32x3_pre_supported(int M, int K, int HW) {
+    return aadg_conv1x1_nchw_supported(M, K, HW) && M > 64 && (M % 128) == 0 && (K % 32) == 0 && K <= CF_PRE_K && (HW % CF_BP) == 0 ? 1 : 0;
+}
+
+/* ... and, with pre_scale / pre_shift [K] != NULL (ABI 10), `in` is the INPUT of the BatchNorm + ReLU in front of this convolution: every
+ * loaded value becomes max(in * pre_scale[k] + pre_shift[k], 0) on its way to the matrix cores, so the normalised tensor is never
+ * written or read (scale / shift: aadg_bn_finalize_f32).  Shapes of aadg_conv1x1_f32x3_pre_supported only. */
+extern "C" int aadg_conv1x1_nchw_f32x3_pre(const void* a_hi, const void* a_lo, const float* in, float* out, int N, int M, int K, int HW,
+                                           const float* pre_scale, const float* pre_shift, double* bn_sums, void* stream) {
+    if ((pre_scale == nullptr) != (pre_shift == nullptr)) return AADG_E_BADARG;
+    if (pre_scale != nullptr && !aadg_conv1x1_f32x3_pre_supported(M, K, HW)) return AADG_E_UNSUPPORTED;
     if (a_hi == nullptr || a_lo == nullptr || in == nullptr || out == nullptr || N <= 0) return AADG_E_BADARG;
     if ((((uintptr_t)a_hi | (uintptr_t)a_lo | (uintptr_t)in | (uintptr_t)out) & 15u) != 0 || (((uintptr_t)bn_sums) & 7u) != 0) return AADG_E_BADARG;
     if (!aadg_conv1x1_nchw_supported(M, K, HW)) return AADG_E_UNSUPPORTED;
@@ -322,5 +359,5 @@ extern "C" int aadg_conv1x1_nchw_f32x3_stats(const void* a_hi, const void* a_lo,
         AADG_LAUNCH_CHECK();
     }
     if (M <= 64) return launch<1, 4, 2, 2, true>(ph, pl, in, out, N, M, K, HW, st, bn_sums);
-    return launch<2, 2, 2, 4, true>(ph, pl, in, out, N, M, K, HW, st, bn_sums);
+    return launch<2, 2, 2, 4, true>(ph, pl, in, out, N, M, K, HW, st, bn_sums, pre_scale, pre_shift);
 }

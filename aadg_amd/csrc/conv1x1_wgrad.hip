@@ -33,10 +33,14 @@ constexpr int WG_PITCH = WG_BK + 8;       // LDS row pitch in elements (144 byte
 // chunk [hi0..3][lo0..3] (aadg_split4), so the 8 K-values of a fragment are the hi halves of two neighbouring chunks and their lo
 // halves come with the same two reads; products hi*hi + hi*lo + lo*hi, float32 accumulation.
 // EXACT (X3 only): Co / Ci whole tiles -- no null-row branches around the loads (one basic block per K-step).
-template <int WR, int WC, int MI, int NI, bool X3, bool EXACT = false>
+// PRE (X3 + EXACT only): X is the INPUT of the BatchNorm + ReLU whose output the convolution consumed (aadg_conv1x1_nchw_f32x3_pre): the
+// rows of X become max(fma(x, pre_scale[c], pre_shift[c]), 0) while they are staged -- the same expression, the same values.
+template <int WR, int WC, int MI, int NI, bool X3, bool EXACT = false, bool PRE = false>
 __global__ __launch_bounds__(64 * WR * WC) void k_wgrad1x1(const void* __restrict__ dY_, const void* __restrict__ X_,
                                                            float* __restrict__ acc, int Co, int Ci, int HW, int tiles, int tiles_n,
-                                                           int steps_total, int steps_per_block) {
+                                                           int steps_total, int steps_per_block, const float* __restrict__ pre_scale = nullptr,
+                                                           const float* __restrict__ pre_shift = nullptr) {
+    static_assert(!PRE || (X3 && EXACT), "the load transform exists for whole-tile float32 shapes");
     typedef typename std::conditional<X3, float, uint16_t>::type elem_t;
     const elem_t* dY = reinterpret_cast<const elem_t*>(dY_);
     const elem_t* X = reinterpret_cast<const elem_t*>(X_);
@@ -73,6 +77,14 @@ __global__ __launch_bounds__(64 * WR * WC) void k_wgrad1x1(const void* __restric
         }
     }
     const size_t stride_a = (size_t)Co * HW, stride_b = (size_t)Ci * HW;
+    float xs[PRE ? LPT - LPT_A : 1], xh[PRE ? LPT - LPT_A : 1];          // PRE: scale / shift of the thread's X rows (constant over the steps)
+    if (PRE) {
+#pragma unroll
+        for (int i = LPT_A; i < LPT; ++i) {
+            const int n = n0 + row0 + (NT / 8) * i - BM;
+            xs[i - LPT_A] = pre_scale[n]; xh[i - LPT_A] = pre_shift[n];
+        }
+    }
     uint4 stage[LPT];
     auto fetch = [&](int step) {
         const int n = step / spi, kk = (step - n * spi) * BKE;
@@ -101,7 +113,13 @@ __global__ __launch_bounds__(64 * WR * WC) void k_wgrad1x1(const void* __restric
             uint4 v = stage[i];
             if (X3) {
                 uint2 hi, lo;
-                aadg_split4(make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)), hi, lo);
+                float4 f = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                if (PRE && i >= LPT_A) {
+                    const float sc = xs[i - LPT_A], sh = xh[i - LPT_A];
+                    f.x = fmaxf(fmaf(f.x, sc, sh), 0.0f); f.y = fmaxf(fmaf(f.y, sc, sh), 0.0f);
+                    f.z = fmaxf(fmaf(f.z, sc, sh), 0.0f); f.w = fmaxf(fmaf(f.w, sc, sh), 0.0f);
+                }
+                aadg_split4(f, hi, lo);
                 v = make_uint4(hi.x, hi.y, lo.x, lo.y);
             }
             *reinterpret_cast<uint4*>(L + st_off + (NT / 8) * i * WG_PITCH) = v;
@@ -168,7 +186,8 @@ __global__ __launch_bounds__(64 * WR * WC) void k_wgrad1x1(const void* __restric
 
 // target_wgs: workgroups aimed at (every one of them ends with BM * BN float atomics: the big tile runs one per CU)
 template <int WR, int WC, int MI, int NI, bool X3>
-int launch(const void* dY, const void* X, float* acc, int N, int Co, int Ci, int HW, int target_wgs, hipStream_t st) {
+int launch(const void* dY, const void* X, float* acc, int N, int Co, int Ci, int HW, int target_wgs, hipStream_t st,
+           const float* pre_scale = nullptr, const float* pre_shift = nullptr) {
     constexpr int BKE = X3 ? 32 : WG_BK;
     constexpr int BM = 32 * MI * WR, BN = 32 * NI * WC, R = BM + BN, NT = 64 * WR * WC;
     const int tiles_m = (Co + BM - 1) / BM, tiles_n = (Ci + BN - 1) / BN, tiles = tiles_m * tiles_n;
@@ -191,11 +210,17 @@ int launch(const void* dY, const void* X, float* acc, int N, int Co, int Ci, int
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad1x1<WR, WC, MI, NI, X3, X3>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad1x1<WR, WC, MI, NI, X3, X3, X3>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    if (pre_scale != nullptr && !(X3 && (Co % BM) == 0 && (Ci % BN) == 0)) return AADG_E_UNSUPPORTED;
     AADG_HIP_TRY(hipMemsetAsync(acc, 0, (size_t)Co * Ci * sizeof(float), st));
     const int slice_groups = (split + 7) / 8;                 // slices are padded to a multiple of 8 (empty ones exit at once)
-    if (X3 && (Co % BM) == 0 && (Ci % BN) == 0)
+    if (pre_scale != nullptr)
+        hipLaunchKernelGGL((k_wgrad1x1<WR, WC, MI, NI, X3, X3, X3>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(NT), lds, st, dY, X, acc,
+                           Co, Ci, HW, tiles, tiles_n, steps_total, steps_per_block, pre_scale, pre_shift);
+    else if (X3 && (Co % BM) == 0 && (Ci % BN) == 0)
         hipLaunchKernelGGL((k_wgrad1x1<WR, WC, MI, NI, X3, X3>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(NT), lds, st, dY, X, acc, Co,
                            Ci, HW, tiles, tiles_n, steps_total, steps_per_block);
     else
@@ -213,15 +238,16 @@ extern "C" int aadg_conv1x1_wgrad_supported(int Co, int Ci, int HW) {
 
 namespace {
 template <bool X3>
-int wgrad1x1_dispatch(const void* a, const void* b, float* dweight, int N, int Co, int Ci, int HW, hipStream_t st) {
+int wgrad1x1_dispatch(const void* a, const void* b, float* dweight, int N, int Co, int Ci, int HW, hipStream_t st,
+                      const float* pre_scale = nullptr, const float* pre_shift = nullptr) {
     constexpr int BKE = X3 ? 32 : WG_BK;
-    if (Co <= 64) return launch<1, 4, 2, 2, X3>(a, b, dweight, N, Co, Ci, HW, 1024, st);
-    if (Ci <= 64) return launch<4, 1, 2, 2, X3>(a, b, dweight, N, Co, Ci, HW, 1024, st);
+    if (Co <= 64) return launch<1, 4, 2, 2, X3>(a, b, dweight, N, Co, Ci, HW, 1024, st, pre_scale, pre_shift);
+    if (Ci <= 64) return launch<4, 1, 2, 2, X3>(a, b, dweight, N, Co, Ci, HW, 1024, st, pre_scale, pre_shift);
     // the 256 x 256 tile needs a reduction long enough for ~one workgroup per CU at >= 32 steps each
     const long long big_wgs = (long long)(Co / 256) * (Ci / 256) * ((long long)N * (HW / BKE) / 32);
     if (Co >= 256 && Ci >= 256 && (Co % 256) == 0 && (Ci % 256) == 0 && (long long)Co * Ci >= 512 * 512 && big_wgs >= 192)
-        return launch<2, 4, 4, 2, X3>(a, b, dweight, N, Co, Ci, HW, 256, st);
-    return launch<2, 2, 2, 2, X3>(a, b, dweight, N, Co, Ci, HW, 1024, st);
+        return launch<2, 4, 4, 2, X3>(a, b, dweight, N, Co, Ci, HW, 256, st, pre_scale, pre_shift);
+    return launch<2, 2, 2, 2, X3>(a, b, dweight, N, Co, Ci, HW, 1024, st, pre_scale, pre_shift);
 }
 }  // namespace
 
@@ -235,8 +261,16 @@ extern "C" int aadg_conv1x1_wgrad_bf16(const void* dy, const void* x, float* dwe
 /* dW [Co, Ci] float32 from float32 NCHW dy / x at float32 precision ("f32x3": three bfloat16 matrix-core products per pair of
  * (hi, lo)-split operands, float32 accumulation).  HW % 32 == 0. */
 extern "C" int aadg_conv1x1_wgrad_f32x3(const float* dy, const float* x, float* dweight, int N, int Co, int Ci, int HW, void* stream) {
-    if (dy == nullptr || x == nullptr || dweight == nullptr || N <= 0) return AADG_E_BADARG;
+    return aadg_conv1x1_wgrad_f32x3_pre(dy, x, dweight, N, Co, Ci, HW, nullptr, nullptr, stream);
+}
+
+/* ... and, with pre_scale / pre_shift [Ci] != NULL (ABI 10), x is the INPUT of the BatchNorm + ReLU in front of the convolution (see
+ * aadg_conv1x1_nchw_f32x3_pre): its rows become max(x * pre_scale[c] + pre_shift[c], 0) while they are staged.  Whole-tile shapes only
+ * (Co, Ci multiples of the tile the dispatch picks: every bottleneck of the backbone) -- AADG_E_UNSUPPORTED otherwise. */
+extern "C" int aadg_conv1x1_wgrad_f32x3_pre(const float* dy, const float* x, float* dweight, int N, int Co, int Ci, int HW,
+                                            const float* pre_scale, const float* pre_shift, void* stream) {
+    if (dy == nullptr || x == nullptr || dweight == nullptr || N <= 0 || (pre_scale == nullptr) != (pre_shift == nullptr)) return AADG_E_BADARG;
     if ((((uintptr_t)dy | (uintptr_t)x) & 15u) != 0) return AADG_E_BADARG;
     if (Co <= 0 || Ci <= 0 || HW < 32 || (HW % 32) != 0 || (long long)N * (HW / 32) > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
-    return wgrad1x1_dispatch<true>(dy, x, dweight, N, Co, Ci, HW, (hipStream_t)stream);
+    return wgrad1x1_dispatch<true>(dy, x, dweight, N, Co, Ci, HW, (hipStream_t)stream, pre_scale, pre_shift);
 }

@@ -355,8 +355,30 @@ class Bottleneck(nn.Module):
             return bn_act(self.bn3, main, 'relu', residual=bn_act(bns, short, None), handles=handles)
         idt = x_res if self.downsample is None else self.downsample(x_res)
         out = bn_act(self.bn1, self.conv1(x_main), 'relu')
-        out = bn_act(self.bn2, self.conv2(out), 'relu')
-        return bn_act(self.bn3, self.conv3(out), 'relu', residual=idt, handles=handles)
+        c2 = self.conv2(out)
+        c3 = self._bn2_on_load(c2)
+        if c3 is None:
+            c3 = self.conv3(bn_act(self.bn2, c2, 'relu'))
+        return bn_act(self.bn3, c3, 'relu', residual=idt, handles=handles)
+
+    lazy_bn2 = True         # f32x3 training: bn2 + ReLU applied by conv3 while it loads its operand (no elementwise pass, no normalised tensor)
+
+    def _bn2_on_load(self, c2):
+        """conv3(relu(bn2(c2))) with the normalisation applied on conv3's operand load (_lib.batch_norm_lazy + conv1x1_x3(pre=...)), or None
+        where that path does not apply: needs the statistics conv2 left in its epilogue, plain per-device BatchNorm, whole-tile shapes."""
+        bn, conv3 = self.bn2, self.conv3
+        sums = getattr(c2, '_aadg_bn_sums', None)
+        if not (self.lazy_bn2 and sums is not None and self.training and torch.is_grad_enabled() and not _BN_SYNC and conv3.f32x3 and
+                c2.is_cuda and c2.dtype == torch.float32 and conv3.stride == (1, 1) and type(bn) is nn.BatchNorm2d and
+                bn.momentum is not None and bn.track_running_stats and bn.affine):
+            return None
+        from .. import _lib
+        c2c = c2.contiguous()
+        if not (_lib.conv1x1_x3_pre_supported(c2c, conv3.weight) and _lib.bn_act_supported(c2c, None)):
+            return None
+        _bump(bn)
+        z, scale, shift = _lib.batch_norm_lazy(c2c, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, sums)
+        return _lib.conv1x1_x3(z, conv3.weight, conv3.bn_stats, pre=(scale, shift))
 
     def _pairs_shortcut(self, x):
         d = self.downsample

@@ -297,3 +297,111 @@ def test_batchnorm_behind_an_f32x3_convolution_uses_its_statistics(hip, act, res
         return
     assert _err(x1.grad, x2.grad) <= 3e-5 and _err(net[0].weight.grad, conv.weight.grad) <= 3e-5
     assert _err(net[1].bn.weight.grad, bn.weight.grad) <= 3e-5 and _err(net[1].bn.bias.grad, bn.bias.grad) <= 3e-5
+
+
+# ---- BatchNorm + ReLU on operand load (ABI 10): bn2 of a bottleneck without its elementwise pass -------------------------------------
+@pytest.mark.parametrize("N,K,M,H,W", [(3, 64, 256, 32, 32), (2, 128, 512, 16, 32), (2, 256, 1024, 16, 16), (1, 512, 2048, 32, 32)])
+def test_conv1x1_x3_applies_batchnorm_relu_on_load(hip, N, K, M, H, W):
+    """aadg_conv1x1_nchw_f32x3_pre / aadg_conv1x1_wgrad_f32x3_pre: the kernels read x and use max(x * scale[k] + shift[k], 0) -- forward
+    output and weight gradient == the same kernels on the materialised tensor (the transform is the BatchNorm kernels' fmaf: bit-equal
+    inputs, so the results agree to the last bits of the split-K atomics)."""
+    torch.manual_seed(K + M)
+    x = torch.randn(N, K, H, W, device="cuda") * 1.7 + 0.2
+    sc = torch.rand(K, device="cuda") + 0.5
+    sh = torch.randn(K, device="cuda") * 0.5
+    w = torch.randn(M, K, 1, 1, device="cuda") / K ** 0.5
+    assert hip.conv1x1_x3_pre_supported(x, w)
+    # the explicit tensor, with the kernels' fused multiply-add (float64 product + sum rounded once == fmaf for these magnitudes)
+    z = torch.clamp_min((x.double() * sc.view(1, -1, 1, 1).double() + sh.view(1, -1, 1, 1).double()).float(), 0.0)
+    a2 = hip.split_weight(w.reshape(M, K))
+    y_pre = hip.conv1x1_nchw_x3(a2, x, None, (sc, sh))
+    y_ref = hip.conv1x1_nchw_x3(a2, z)
+    assert _err(y_pre, y_ref) <= 2e-6, _err(y_pre, y_ref)
+    sums = torch.empty(2 * M + 1, dtype=torch.float64, device="cuda")
+    y2 = hip.conv1x1_nchw_x3(a2, x, sums, (sc, sh))                                        # with the statistics epilogue as well
+    assert torch.equal(y2, y_pre) and abs(sums[:2 * M:2].sum().item() - y_pre.double().sum().item()) <= 1e-6 * y_pre.double().abs().sum().item()
+    dy = torch.randn(N, M, H, W, device="cuda")
+    dw_pre = hip.conv1x1_wgrad_x3(dy, x, (sc, sh))
+    dw_ref = hip.conv1x1_wgrad_x3(dy, z)
+    assert _err(dw_pre, dw_ref) <= 2e-6, _err(dw_pre, dw_ref)
+
+
+def test_conv1x1_x3_load_transform_only_for_whole_tile_shapes(hip):
+    x = torch.randn(1, 48, 16, 16, device="cuda")                                       # 48 input channels, 192 outputs: no whole tiles
+    w = torch.randn(192, 48, 1, 1, device="cuda")
+    assert hip.conv1x1_x3_supported(x, w) and not hip.conv1x1_x3_pre_supported(x, w)
+    sc, sh = torch.ones(48, device="cuda"), torch.zeros(48, device="cuda")
+    with pytest.raises(hip.AadgError):
+        hip.conv1x1_nchw_x3(hip.split_weight(w.reshape(192, 48)), x, None, (sc, sh))
+    with pytest.raises(hip.AadgError):
+        hip.conv1x1_x3(x, w, pre=(sc, sh))
+
+
+def test_batch_norm_lazy_finalises_like_torch(hip):
+    """aadg_bn_finalize_f32: mean / invstd / running statistics / scale / shift from the float64 totals == torch's training-mode
+    BatchNorm on the same tensor; the first output IS x (the consumer applies scale / shift)."""
+    torch.manual_seed(4)
+    N, C, H, W = 4, 64, 16, 32
+    x = (torch.randn(N, C, H, W, device="cuda") * 2.0 + 0.7).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    ref = torch.nn.BatchNorm2d(C).cuda().double().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
+        ref.weight.copy_(bn.weight.double()); ref.bias.copy_(bn.bias.double())
+    xd = x.detach().double()
+    sums = torch.cat([torch.stack([xd.sum(dim=(0, 2, 3)), (xd * xd).sum(dim=(0, 2, 3))], 1).reshape(-1),
+                      torch.tensor([float(N * H * W)], dtype=torch.float64, device="cuda")])
+    z, scale, shift = hip.batch_norm_lazy(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, sums)
+    assert z.data_ptr() == x.data_ptr() and not scale.requires_grad
+    yr = ref(xd.requires_grad_(True))
+    got = torch.clamp_min(z.detach().double() * scale.view(1, -1, 1, 1).double() + shift.view(1, -1, 1, 1).double(), 0)
+    assert _err(got, torch.relu(yr).detach()) <= 1e-6
+    assert (bn.running_mean.double() - ref.running_mean).abs().max().item() <= 1e-6 and _err(bn.running_var, ref.running_var) <= 1e-6
+    g = torch.randn(N, C, H, W, device="cuda")
+    z.backward(g)                                                                       # gradient w.r.t. relu(bn(x)) -> BatchNorm backward
+    torch.relu(yr).backward(g.double())
+    assert _err(x.grad, xd.grad) <= 1e-5
+    assert _err(bn.weight.grad, ref.weight.grad) <= 1e-5 and _err(bn.bias.grad, ref.bias.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("planes,dilation", [(64, 1), (128, 2)])
+def test_bottleneck_with_bn2_on_operand_load_equals_the_materialised_path(hip, planes, dilation):
+    """models/deeplab.py Bottleneck: conv3 applies bn2 + ReLU while it loads conv2's output (lazy_bn2) -- output, running statistics and
+    every gradient equal the path that materialises the normalised tensor (same kernels otherwise; bit-reproducible forward: the
+    statistics epilogues off would change both alike, so they stay on) and plain torch in float64."""
+    from aadg_amd.models import deeplab as DL
+    torch.manual_seed(23)
+    blk = DL.Bottleneck(4 * planes, planes, 1, dilation).cuda().train()
+    DL.batch_step_bookkeeping(blk, f32x3=True)
+    DL.mark_bn_producers(blk)
+    x1 = torch.randn(4, 4 * planes, 32, 32, device="cuda")
+    g = torch.randn(4, 4 * planes, 32, 32, device="cuda")
+
+    def run(lazy):
+        torch.manual_seed(0)
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        blk.zero_grad(set_to_none=True)
+        blk.lazy_bn2 = lazy
+        xi = x1.clone().requires_grad_(True)
+        y = blk(xi)
+        y.backward(g)
+        torch.cuda.synchronize()
+        return y.detach(), xi.grad, {n: p.grad.clone() for n, p in blk.named_parameters()}, blk.bn2.running_var.clone()
+
+    calls = []
+    orig = hip.batch_norm_lazy
+    hip.batch_norm_lazy = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        y_l, dx_l, gp_l, rv_l = run(True)
+    finally:
+        hip.batch_norm_lazy = orig
+    assert calls, "the bottleneck did not take the on-load path"
+    y_m, dx_m, gp_m, rv_m = run(False)
+    assert _err(y_l, y_m) <= 1e-5 and _err(rv_l, rv_m) <= 1e-6
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()      # noqa: E731  (float64 atomics of the epilogues: last-bit statistics)
+    assert rel(dx_l, dx_m) <= 1e-3
+    for n in gp_m:
+        assert rel(gp_l[n], gp_m[n]) <= 1e-3, n
+    blk.lazy_bn2 = True
