@@ -61,6 +61,7 @@ EXPORTS = [
     "aadg_stem_conv7x7_f32x3", "aadg_stem_conv7x7_wgrad_f32x3", "aadg_sinkhorn_divergence_phases_f32",
     "aadg_conv1x1_nchw_f32x3_stats", "aadg_conv3x3_nchw_f32x3_stats", "aadg_conv3x3_f32x3_stats_supported",
     "aadg_bn_finalize_f32", "aadg_conv1x1_f32x3_pre_supported", "aadg_conv1x1_nchw_f32x3_pre", "aadg_conv1x1_wgrad_f32x3_pre",
+    "aadg_conv3x3_nchw_f32x3_pre", "aadg_conv3x3_wgrad_f32x3_pre",
 ]
 
 _lib = None
@@ -257,6 +258,10 @@ def load():
     lib.aadg_conv1x1_nchw_f32x3_pre.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]
     lib.aadg_conv1x1_wgrad_f32x3_pre.restype = _i
     lib.aadg_conv1x1_wgrad_f32x3_pre.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]
+    lib.aadg_conv3x3_nchw_f32x3_pre.restype = _i
+    lib.aadg_conv3x3_nchw_f32x3_pre.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]
+    lib.aadg_conv3x3_wgrad_f32x3_pre.restype = _i
+    lib.aadg_conv3x3_wgrad_f32x3_pre.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]
     lib.aadg_conv3x3_nchw_f32x3.restype = _i
     lib.aadg_conv3x3_nchw_f32x3.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
     lib.aadg_conv3x3_nchw_f32x3_stats.restype = _i
@@ -2238,10 +2243,11 @@ def batch_norm_lazy(x, weight, bias, running_mean, running_var, momentum, eps, p
     return _BatchNormLazy.apply(x, weight, bias, running_mean, running_var, float(momentum), float(eps), presums)
 
 
-def conv3x3_nchw_x3(a9, x, dilation=1, bn_sums=None):
+def conv3x3_nchw_x3(a9, x, dilation=1, bn_sums=None, pre=None):
     """out [N, M, H, W] float32 = 3x3 convolution (stride 1, padding = dilation) of x [N, K, H, W] float32; a9 [2, 9, M, K] bfloat16 =
     (hi, lo) of the tap-major weights.  bn_sums (float64 [2M + 1], optional; shapes of conv3x3_x3_stats_supported) receives the BatchNorm
-    statistics of out from the kernel's epilogue."""
+    statistics of out from the kernel's epilogue.  pre = (scale, shift) float32 [K] (with bn_sums, K <= 512): x is the INPUT of a
+    BatchNorm + ReLU that the kernel applies while it stages x (zero padding as for the normalised tensor)."""
     _require_cuda(a9, x)
     if a9.dtype != torch.bfloat16 or x.dtype != torch.float32 or not (a9.is_contiguous() and x.is_contiguous()) or a9.dim() != 4:
         raise AadgError("conv3x3_nchw_x3: expected contiguous bfloat16 a9 [2,9,M,K] and NCHW float32 x")
@@ -2249,14 +2255,18 @@ def conv3x3_nchw_x3(a9, x, dilation=1, bn_sums=None):
     M = a9.shape[2]
     if a9.shape[0] != 2 or a9.shape[1] != 9 or a9.shape[3] != K:
         raise AadgError("conv3x3_nchw_x3: shape mismatch")
+    if pre is not None and not all(p.dtype == torch.float32 and p.numel() == K and p.is_cuda and p.is_contiguous() for p in pre):
+        raise AadgError("conv3x3_nchw_x3: pre = (scale, shift), float32 [K]")
     out = torch.empty((N, M, H, W), dtype=torch.float32, device=x.device)
-    _check(load().aadg_conv3x3_nchw_f32x3_stats(a9[0].data_ptr(), a9[1].data_ptr(), x.data_ptr(), out.data_ptr(), N, M, K, H, W,
-                                                int(dilation), _ptr(bn_sums), _stream()), "aadg_conv3x3_nchw_f32x3")
+    _check(load().aadg_conv3x3_nchw_f32x3_pre(a9[0].data_ptr(), a9[1].data_ptr(), x.data_ptr(), out.data_ptr(), N, M, K, H, W, int(dilation),
+                                              _ptr(pre[0]) if pre else None, _ptr(pre[1]) if pre else None, _ptr(bn_sums), _stream()),
+           "aadg_conv3x3_nchw_f32x3")
     return out
 
 
-def conv3x3_wgrad_x3(dy, x, dilation=1):
-    """dW [Co, Ci, 3, 3] float32 of a 3x3 / stride-1 / padding = dilation convolution from NCHW float32 dy, x"""
+def conv3x3_wgrad_x3(dy, x, dilation=1, pre=None):
+    """dW [Co, Ci, 3, 3] float32 of a 3x3 / stride-1 / padding = dilation convolution from NCHW float32 dy, x; pre = (scale, shift): the
+    convolution consumed max(x * scale[c] + shift[c], 0) (conv3x3_nchw_x3(..., pre=...))"""
     _require_cuda(dy, x)
     if dy.dtype != torch.float32 or x.dtype != torch.float32 or not (dy.is_contiguous() and x.is_contiguous()):
         raise AadgError("conv3x3_wgrad_x3: expected contiguous NCHW float32 tensors")
@@ -2265,7 +2275,8 @@ def conv3x3_wgrad_x3(dy, x, dilation=1):
     if x.shape[0] != N or x.shape[2:] != dy.shape[2:]:
         raise AadgError("conv3x3_wgrad_x3: shape mismatch")
     dw9 = torch.empty((9, Co, Ci), dtype=torch.float32, device=x.device)
-    _check(load().aadg_conv3x3_wgrad_f32x3(dy.data_ptr(), x.data_ptr(), dw9.data_ptr(), N, Co, Ci, H, W, int(dilation), _stream()),
+    _check(load().aadg_conv3x3_wgrad_f32x3_pre(dy.data_ptr(), x.data_ptr(), dw9.data_ptr(), N, Co, Ci, H, W, int(dilation),
+                                               _ptr(pre[0]) if pre else None, _ptr(pre[1]) if pre else None, _stream()),
            "aadg_conv3x3_wgrad_f32x3")
     return dw9.permute(1, 2, 0).reshape(Co, Ci, 3, 3)
 
@@ -2275,26 +2286,29 @@ class _Conv3x3X3(torch.autograd.Function):
     (csrc/conv3x3_fwd.hip and csrc/conv3x3_wgrad.hip, X3).  `weight` is the float32 parameter."""
 
     @staticmethod
-    def forward(ctx, x, weight, dilation, want_stats=False):
-        """want_stats: also return the float64 [2 Co + 1] BatchNorm totals of the output from the kernel's epilogue (as _Conv1x1X3)"""
+    def forward(ctx, x, weight, dilation, want_stats=False, pre_scale=None, pre_shift=None):
+        """want_stats: also return the float64 [2 Co + 1] BatchNorm totals of the output from the kernel's epilogue (as _Conv1x1X3);
+        pre_scale / pre_shift (with want_stats): x is the first output of batch_norm_lazy, normalised + rectified on operand load"""
         Co, Ci = weight.shape[0], weight.shape[1]
         a9 = split_layout(weight, "fwd")
         if a9 is None:
             a9 = split_weight(weight.detach().permute(2, 3, 0, 1).reshape(9, Co, Ci).contiguous())
-        ctx.save_for_backward(x, weight)
+        pre = (pre_scale, pre_shift) if pre_scale is not None else None
+        ctx.save_for_backward(x, weight, pre_scale, pre_shift)
         ctx.wparam = weight
         ctx.a9t = _ShadowRef(weight, "bwd", split=True)
         ctx.dilation = dilation
         if not want_stats:
             return conv3x3_nchw_x3(a9, x, dilation)
         sums = torch.empty(2 * Co + 1, dtype=torch.float64, device=x.device)
-        y = conv3x3_nchw_x3(a9, x, dilation, sums)
+        y = conv3x3_nchw_x3(a9, x, dilation, sums, pre)
         ctx.mark_non_differentiable(sums)
         return y, sums
 
     @staticmethod
     def backward(ctx, dy, *unused):
-        x, weight = ctx.saved_tensors
+        x, weight, pre_scale, pre_shift = ctx.saved_tensors
+        pre = (pre_scale, pre_shift) if pre_scale is not None else None
         d = ctx.dilation
         dy = dy.contiguous()
         Co, Ci = weight.shape[0], weight.shape[1]
@@ -2305,8 +2319,8 @@ class _Conv3x3X3(torch.autograd.Function):
                 a9t = split_weight(weight.detach().flip(2, 3).permute(2, 3, 1, 0).reshape(9, Ci, Co).contiguous())
             dx = conv3x3_nchw_x3(a9t, dy, d)
         if ctx.needs_input_grad[1]:
-            dw = _wgrad_beside(ctx.wparam, lambda: conv3x3_wgrad_x3(dy, x, d), dy, x)
-        return dx, dw, None, None
+            dw = _wgrad_beside(ctx.wparam, lambda: conv3x3_wgrad_x3(dy, x, d, pre), dy, x)
+        return dx, dw, None, None, None, None
 
 
 def conv3x3_x3_supported(x, weight, dilation):
@@ -2321,14 +2335,22 @@ def conv3x3_x3_stats_supported(x, weight, dilation):
     return bool(load().aadg_conv3x3_f32x3_stats_supported(weight.shape[0], weight.shape[1], x.shape[2], x.shape[3], int(dilation)))
 
 
-def conv3x3_x3(x, weight, dilation=1, want_stats=False):
-    """want_stats: returns the output with its BatchNorm totals attached as `y._aadg_bn_sums` (see conv1x1_x3)"""
+def conv3x3_x3_pre_supported(x, weight, dilation):
+    """the shapes on which the 3x3 kernels apply a BatchNorm + ReLU to x while they stage it (the whole-tile forward kernel, <= 512 input
+    channels; the weight gradient takes any shape it supports)"""
+    return conv3x3_x3_supported(x, weight, dilation) and conv3x3_x3_stats_supported(x, weight, dilation) and weight.shape[1] <= 512
+
+
+def conv3x3_x3(x, weight, dilation=1, want_stats=False, pre=None):
+    """want_stats: returns the output with its BatchNorm totals attached as `y._aadg_bn_sums` (see conv1x1_x3); pre = (scale, shift) from
+    batch_norm_lazy, x its first output (needs want_stats and a shape of conv3x3_x3_pre_supported)"""
     _require_cuda(x, weight)
-    if not conv3x3_x3_supported(x, weight, dilation):
+    if not conv3x3_x3_supported(x, weight, dilation) or (pre is not None and not (want_stats and conv3x3_x3_pre_supported(x, weight, dilation))):
         raise AadgError("conv3x3_x3: unsupported shape / dtype / layout")
     if not want_stats:
-        return _Conv3x3X3.apply(x, weight, int(dilation), False)
-    y, sums = _Conv3x3X3.apply(x, weight, int(dilation), True)
+        return _Conv3x3X3.apply(x, weight, int(dilation), False, None, None)
+    ps, ph = pre if pre is not None else (None, None)
+    y, sums = _Conv3x3X3.apply(x, weight, int(dilation), True, ps, ph)
     y._aadg_bn_sums = sums
     return y
 

@@ -377,7 +377,7 @@ extern "C" int aadg_conv3x3_nchw_bf16(const void* a9, const void* in, void* out,
  * tap-major weights [9, M, K] (aadg_weight_layouts_split_bf16); hi*hi + hi*lo + lo*hi on the matrix cores, float32 accumulation */
 bool aadg_conv3x3_x3q_takes(int M, int K, int H, int W, int dilation);
 int aadg_conv3x3_x3q(const uint16_t* a9_hi, const uint16_t* a9_lo, const float* in, float* out, int N, int M, int K, int H, int W, int dilation,
-                     double* bn_sums, hipStream_t st);
+                     double* bn_sums, hipStream_t st, const float* pre_scale, const float* pre_shift);
 extern "C" int aadg_conv3x3_nchw_f32x3(const void* a9_hi, const void* a9_lo, const float* in, float* out, int N, int M, int K, int H, int W,
                                        int dilation, void* stream) {
     return aadg_conv3x3_nchw_f32x3_stats(a9_hi, a9_lo, in, out, N, M, K, H, W, dilation, nullptr, stream);
@@ -393,14 +393,25 @@ extern "C" int aadg_conv3x3_f32x3_stats_supported(int M, int K, int H, int W, in
  * aadg_conv3x3_f32x3_stats_supported when bn_sums is given. */
 extern "C" int aadg_conv3x3_nchw_f32x3_stats(const void* a9_hi, const void* a9_lo, const float* in, float* out, int N, int M, int K, int H,
                                              int W, int dilation, double* bn_sums, void* stream) {
-    if (a9_hi == nullptr || a9_lo == nullptr || in == nullptr || out == nullptr || N <= 0) return AADG_E_BADARG;
+    return aadg_conv3x3_nchw_f32x3_pre(a9_hi, a9_lo, in, out, N, M, K, H, W, dilation, nullptr, nullptr, bn_sums, stream);
+}
+
+/* ... and, with pre_scale / pre_shift [K] != NULL, `in` is the INPUT of the BatchNorm + ReLU in front of this convolution (see
+ * aadg_conv1x1_nchw_f32x3_pre): max(in * pre_scale[k] + pre_shift[k], 0) on the way to LDS, zero padding as for the normalised tensor.
+ * Needs bn_sums (the forward of a bottleneck's conv2), K <= 512 and a shape of aadg_conv3x3_f32x3_stats_supported. */
+extern "C" int aadg_conv3x3_nchw_f32x3_pre(const void* a9_hi, const void* a9_lo, const float* in, float* out, int N, int M, int K, int H, int W,
+                                           int dilation, const float* pre_scale, const float* pre_shift, double* bn_sums, void* stream) {
+    if (a9_hi == nullptr || a9_lo == nullptr || in == nullptr || out == nullptr || N <= 0 || (pre_scale == nullptr) != (pre_shift == nullptr))
+        return AADG_E_BADARG;
     if ((((uintptr_t)a9_hi | (uintptr_t)a9_lo | (uintptr_t)in | (uintptr_t)out) & 15u) != 0 || (((uintptr_t)bn_sums) & 7u) != 0) return AADG_E_BADARG;
     if (!aadg_conv3x3_nchw_supported(M, K, H, W, dilation)) return AADG_E_UNSUPPORTED;
 #ifndef AADG_NO_X3Q
     // whole-tile shapes (every such layer of the backbone): the [pixel][k] kernel of conv3x3_x3.hip, two workgroups per CU
     if (aadg_conv3x3_x3q_takes(M, K, H, W, dilation))
-        return aadg_conv3x3_x3q((const uint16_t*)a9_hi, (const uint16_t*)a9_lo, in, out, N, M, K, H, W, dilation, bn_sums, (hipStream_t)stream);
+        return aadg_conv3x3_x3q((const uint16_t*)a9_hi, (const uint16_t*)a9_lo, in, out, N, M, K, H, W, dilation, bn_sums, (hipStream_t)stream,
+                                pre_scale, pre_shift);
 #endif
+    if (pre_scale != nullptr) return AADG_E_UNSUPPORTED;
     if (bn_sums != nullptr) return AADG_E_UNSUPPORTED;
     return conv3x3_dispatch<true>((const uint16_t*)a9_hi, (const uint16_t*)a9_lo, in, out, N, M, K, H, W, dilation, (hipStream_t)stream);
 }

@@ -51,10 +51,14 @@ __device__ __forceinline__ bf16x8 frag(uint32_t a, uint32_t b, uint32_t c, uint3
     return __builtin_bit_cast(bf16x8, make_uint4(a, b, c, d));
 }
 
-template <int W, int D, bool X3>
+// PRE (X3 only): X is the INPUT of the BatchNorm + ReLU the convolution applied on load (aadg_conv3x3_nchw_f32x3_pre): its rows become
+// max(fma(x, pre_scale[c], pre_shift[c]), 0) on their way to LDS; rows outside the image stay zero (the padding of the normalised tensor).
+template <int W, int D, bool X3, bool PRE = false>
 __global__ __launch_bounds__(256, (W == 128 || X3) ? 1 : 2) void k_wgrad3x3(const void* __restrict__ dY_, const void* __restrict__ X_,
                                                   float* __restrict__ acc,
-                                                  int Co, int Ci, int H, int tiles, int tiles_n, int rows_total, int rows_per_block) {
+                                                  int Co, int Ci, int H, int tiles, int tiles_n, int rows_total, int rows_per_block,
+                                                  const float* __restrict__ pre_scale = nullptr, const float* __restrict__ pre_shift = nullptr) {
+    static_assert(!PRE || X3, "the load transform exists for float32 tensors");
     using C = W3Cfg<W, D, X3>;
     typedef typename std::conditional<X3, float, uint16_t>::type elem_t;
     const elem_t* dY = reinterpret_cast<const elem_t*>(dY_);
@@ -112,12 +116,29 @@ __global__ __launch_bounds__(256, (W == 128 || X3) ? 1 : 2) void k_wgrad3x3(cons
             *reinterpret_cast<uint4*>(dst) = v;
         }
     };
+    float xs[PRE ? LPX : 1], xh[PRE ? LPX : 1];              // PRE: scale / shift of the thread's X rows (channels n0 + row: constant)
+    if (PRE) {
+#pragma unroll
+        for (int i = 0; i < LPX; ++i) {
+            const int ch = min(n0 + (tid + 256 * i) / CPR, Ci - 1);
+            xs[i] = pre_scale[ch]; xh[i] = pre_shift[ch];
+        }
+    }
     auto store_x = [&](int y, const uint4* st) {
         uint16_t* base = Xs + (size_t)slot_of(y) * BN * PX;
+        const bool live = y >= 0 && y < H;                    // (uniform) a row of the image: else zeros, the padding
 #pragma unroll
         for (int i = 0; i < LPX; ++i) {
             const int id = tid + 256 * i, row = id / CPR, c = (id - row * CPR) * EPC;
-            put(base + row * PX + 8 + c, X_PLANE, st[i]);
+            uint4 v = st[i];
+            if (PRE && live && n0 + row < Ci) {
+                const float sc = xs[i], sh = xh[i];
+                v.x = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.x), sc, sh), 0.0f));
+                v.y = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.y), sc, sh), 0.0f));
+                v.z = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.z), sc, sh), 0.0f));
+                v.w = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.w), sc, sh), 0.0f));
+            }
+            put(base + row * PX + 8 + c, X_PLANE, v);
         }
     };
     auto store_dy = [&](int buf, const uint4* st) {
@@ -475,7 +496,8 @@ int launch_s2(const void* dY, const void* X, float* acc, int N, int Co, int Ci, 
 }
 
 template <int W, int D, bool X3>
-int launch(const void* dY, const void* X, float* acc, int N, int Co, int Ci, int H, hipStream_t st) {
+int launch(const void* dY, const void* X, float* acc, int N, int Co, int Ci, int H, hipStream_t st, const float* pre_scale = nullptr,
+           const float* pre_shift = nullptr) {
     using C = W3Cfg<W, D, X3>;
     const int tiles_m = (Co + W3_BM - 1) / W3_BM, tiles_n = (Ci + C::BN - 1) / C::BN, tiles = tiles_m * tiles_n;
     const long long rows_total = (long long)N * H;
@@ -491,10 +513,17 @@ int launch(const void* dY, const void* X, float* acc, int N, int Co, int Ci, int
     if (!attr_set) {
         AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3<W, D, X3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::lds_bytes));
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3<W, D, X3, X3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)C::lds_bytes));
         attr_set = true;
     }
+    if (pre_scale != nullptr && !X3) return AADG_E_UNSUPPORTED;
     AADG_HIP_TRY(hipMemsetAsync(acc, 0, (size_t)9 * Co * Ci * sizeof(float), st));
     const long long slice_groups = (slices + 7) / 8;          // slices are padded to a multiple of 8 (empty ones exit at once)
+    if (pre_scale != nullptr)
+        hipLaunchKernelGGL((k_wgrad3x3<W, D, X3, X3>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(256), C::lds_bytes, st, dY, X, acc, Co, Ci,
+                           H, tiles, tiles_n, (int)rows_total, (int)rpb, pre_scale, pre_shift);
+    else
     hipLaunchKernelGGL((k_wgrad3x3<W, D, X3>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(256), C::lds_bytes, st, dY, X, acc, Co, Ci, H,
                        tiles, tiles_n, (int)rows_total, (int)rpb);
     AADG_LAUNCH_CHECK();
@@ -509,14 +538,15 @@ extern "C" int aadg_conv3x3_wgrad_supported(int Co, int Ci, int H, int W, int di
 
 namespace {
 template <bool X3>
-int wgrad3x3_dispatch(const void* a, const void* b, float* dweight9, int N, int Co, int Ci, int H, int W, int dilation, hipStream_t st) {
+int wgrad3x3_dispatch(const void* a, const void* b, float* dweight9, int N, int Co, int Ci, int H, int W, int dilation, hipStream_t st,
+                      const float* ps = nullptr, const float* ph = nullptr) {
     if (dilation == 1) {
-        if (W == 32) return launch<32, 1, X3>(a, b, dweight9, N, Co, Ci, H, st);
-        if (W == 64) return launch<64, 1, X3>(a, b, dweight9, N, Co, Ci, H, st);
-        return launch<128, 1, X3>(a, b, dweight9, N, Co, Ci, H, st);
+        if (W == 32) return launch<32, 1, X3>(a, b, dweight9, N, Co, Ci, H, st, ps, ph);
+        if (W == 64) return launch<64, 1, X3>(a, b, dweight9, N, Co, Ci, H, st, ps, ph);
+        return launch<128, 1, X3>(a, b, dweight9, N, Co, Ci, H, st, ps, ph);
     }
-    if (W == 32) return launch<32, 2, X3>(a, b, dweight9, N, Co, Ci, H, st);
-    if (W == 64) return launch<64, 2, X3>(a, b, dweight9, N, Co, Ci, H, st);
+    if (W == 32) return launch<32, 2, X3>(a, b, dweight9, N, Co, Ci, H, st, ps, ph);
+    if (W == 64) return launch<64, 2, X3>(a, b, dweight9, N, Co, Ci, H, st, ps, ph);
     if (X3) return AADG_E_UNSUPPORTED;                            // (both planes of a 128-pixel ring of six rows exceed the LDS)
     return launch<128, 2, false>(a, b, dweight9, N, Co, Ci, H, st);
 }
@@ -534,11 +564,18 @@ extern "C" int aadg_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dwe
 /* The same weight gradient from float32 NCHW dy / x at float32 precision ("f32x3") */
 extern "C" int aadg_conv3x3_wgrad_f32x3(const float* dy, const float* x, float* dweight9, int N, int Co, int Ci, int H, int W, int dilation,
                                         void* stream) {
-    if (dy == nullptr || x == nullptr || dweight9 == nullptr || N <= 0) return AADG_E_BADARG;
+    return aadg_conv3x3_wgrad_f32x3_pre(dy, x, dweight9, N, Co, Ci, H, W, dilation, nullptr, nullptr, stream);
+}
+
+/* ... and, with pre_scale / pre_shift [Ci] != NULL (ABI 10), x is the INPUT of the BatchNorm + ReLU the convolution applied on load
+ * (aadg_conv3x3_nchw_f32x3_pre) */
+extern "C" int aadg_conv3x3_wgrad_f32x3_pre(const float* dy, const float* x, float* dweight9, int N, int Co, int Ci, int H, int W, int dilation,
+                                            const float* pre_scale, const float* pre_shift, void* stream) {
+    if (dy == nullptr || x == nullptr || dweight9 == nullptr || N <= 0 || (pre_scale == nullptr) != (pre_shift == nullptr)) return AADG_E_BADARG;
     if ((((uintptr_t)dy | (uintptr_t)x) & 15u) != 0) return AADG_E_BADARG;
     if (!aadg_conv3x3_wgrad_supported(Co, Ci, H, W, dilation) || (W == 128 && dilation == 2) || (long long)N * H > 0x7FFFFFFFLL)
         return AADG_E_UNSUPPORTED;
-    return wgrad3x3_dispatch<true>(dy, x, dweight9, N, Co, Ci, H, W, dilation, (hipStream_t)stream);
+    return wgrad3x3_dispatch<true>(dy, x, dweight9, N, Co, Ci, H, W, dilation, (hipStream_t)stream, pre_scale, pre_shift);
 }
 
 /* stride 2, padding 1, dilation 1: dy [N, Co, Ho, Wo], x [N, Ci, 2 Ho, 2 Wo]; Wo in {32, 64} */

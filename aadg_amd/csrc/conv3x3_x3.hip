@@ -45,10 +45,15 @@ struct QCfg {
 // byte offset of chunk c of record r
 __device__ __forceinline__ int q_chunk(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3)) << 4); }
 
-template <int W, int D, bool STATS>
+// PRE (K <= Q_PRE_K): IN is the INPUT of the BatchNorm + ReLU in front of this convolution -- the staged values become
+// max(fma(x, pre_scale[k], pre_shift[k]), 0) (conv1x1_fwd.hip, PRE); the padding stays zero: it pads the NORMALISED tensor.
+constexpr int Q_PRE_K = 512;
+template <int W, int D, bool STATS, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_x3q(const uint16_t* __restrict__ A9, const uint16_t* __restrict__ A9_lo,
                                                         const float* __restrict__ IN, float* __restrict__ OUT, int M, int K, int H,
-                                                        int tiles_m, int tiles_r, int pts, double* __restrict__ stats) {
+                                                        int tiles_m, int tiles_r, int pts, double* __restrict__ stats,
+                                                        const float* __restrict__ pre_scale = nullptr,
+                                                        const float* __restrict__ pre_shift = nullptr) {
     using C = QCfg<W, D>;
     constexpr int ROWS = C::ROWS, SR = C::SR, PW = C::PW, MI = 2, NI = 2, QPR = W / 4;     // QPR: pixel quads per image row
     constexpr int NAU = 9 * Q_BM * 2, LA = (NAU + 255) / 256;       // weight units of 8 k (16 bytes of each plane) per K-step
@@ -56,6 +61,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_x3q(const uint16_t* __restri
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsq[];
     unsigned char* As = ldsq;                      // [9 * 64 records][64 B]
     unsigned char* Bs = ldsq + C::A_BYTES;         // [NPX records][80 B]
+    float* Ps = reinterpret_cast<float*>(ldsq + C::lds_bytes);      // PRE: scale [Q_PRE_K] | shift [Q_PRE_K] behind the tiles
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // XCD-aware decode: the out-channel tiles of one pixel tile run on one XCD and share the IN tile through its L2
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -68,6 +74,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_x3q(const uint16_t* __restri
 
     // zero the pixel records once: the padding columns and the rows outside the image are never written again
     for (int i = tid; i < C::B_BYTES / 16; i += 256) reinterpret_cast<uint4*>(Bs)[i] = make_uint4(0, 0, 0, 0);
+    if (PRE)
+        for (int i = tid; i < K; i += 256) { Ps[i] = pre_scale[i]; Ps[Q_PRE_K + i] = pre_shift[i]; }
 
     // per-thread staging descriptors (constant over the K loop)
     int a_src[LA], a_dst[LA];
@@ -103,7 +111,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_x3q(const uint16_t* __restri
             for (int c = 0; c < 4; ++c) rb[i][c] = *reinterpret_cast<const uint4*>(src + (size_t)c * HW);
         }
     };
-    auto stage = [&]() {
+    auto stage = [&](int k0) {
+        float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), h4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PRE) {                                  // the item's four channels: k0 + 4 (tid & 3) + 0..3 for every i (256 = 0 mod 4)
+            s4 = *reinterpret_cast<const float4*>(Ps + k0 + 4 * (tid & 3));
+            h4 = *reinterpret_cast<const float4*>(Ps + Q_PRE_K + k0 + 4 * (tid & 3));
+        }
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             if (tid + 256 * i < NAU) {
@@ -121,7 +134,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_x3q(const uint16_t* __restri
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {                      // pixel j of the quad: its four channels -> one chunk
                     uint2 hi, lo;
-                    aadg_split4(make_float4(f0[j], f1[j], f2[j], f3[j]), hi, lo);
+                    float4 f = make_float4(f0[j], f1[j], f2[j], f3[j]);
+                    if (PRE) {
+                        f.x = fmaxf(fmaf(f.x, s4.x, h4.x), 0.0f); f.y = fmaxf(fmaf(f.y, s4.y, h4.y), 0.0f);
+                        f.z = fmaxf(fmaf(f.z, s4.z, h4.z), 0.0f); f.w = fmaxf(fmaf(f.w, s4.w, h4.w), 0.0f);
+                    }
+                    aadg_split4(f, hi, lo);
                     *reinterpret_cast<uint4*>(Bs + b_dst[i] + j * C::B_REC) = make_uint4(hi.x, hi.y, lo.x, lo.y);
                 }
             }
@@ -152,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_x3q(const uint16_t* __restri
     fetch(0);
     for (int k0 = 0; k0 < K; k0 += Q_BK) {
         __syncthreads();                                  // the previous step's fragment reads (and, first, the zero fill) are done
-        stage();
+        stage(k0);
         __syncthreads();
         if (k0 + Q_BK < K) fetch(k0 + Q_BK);              // in flight during the MFMAs below
 #pragma unroll
@@ -252,25 +270,34 @@ __global__ __launch_bounds__(256) void k_q_sums_init(double* __restrict__ sums, 
 }
 
 template <int W, int D>
-int launch_q(const uint16_t* A9, const uint16_t* A9_lo, const float* IN, float* OUT, int N, int M, int K, int H, double* stats, hipStream_t st) {
+int launch_q(const uint16_t* A9, const uint16_t* A9_lo, const float* IN, float* OUT, int N, int M, int K, int H, double* stats, hipStream_t st,
+             const float* pre_scale = nullptr, const float* pre_shift = nullptr) {
     using C = QCfg<W, D>;
     const int tiles_m = M / Q_BM, tiles_r = (H + C::ROWS - 1) / C::ROWS;
     const long long pts = (long long)N * tiles_r, groups = (pts + 7) / 8;
     const long long wgs = groups * 8 * tiles_m;
     if (wgs > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
     static bool attr_set = false;                            // per instantiation; idempotent
+    constexpr int PRE_BYTES = 2 * Q_PRE_K * (int)sizeof(float);
     if (!attr_set) {
         AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_x3q<W, D, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::lds_bytes));
         AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_x3q<W, D, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::lds_bytes));
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_x3q<W, D, true, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes + PRE_BYTES));
         attr_set = true;
     }
+    if (pre_scale != nullptr && (stats == nullptr || K > Q_PRE_K)) return AADG_E_UNSUPPORTED;       // (the load transform comes with the statistics)
     if (stats != nullptr) {
         hipLaunchKernelGGL(k_q_sums_init, dim3((2 * M + 1 + 255) / 256), dim3(256), 0, st, stats, M, (double)N * (double)H * (double)W);
         AADG_LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_conv3x3_x3q<W, D, true>), dim3((unsigned)wgs), dim3(256), C::lds_bytes, st, A9, A9_lo, IN, OUT, M, K, H, tiles_m,
-                           tiles_r, (int)pts, stats);
+        if (pre_scale != nullptr)
+            hipLaunchKernelGGL((k_conv3x3_x3q<W, D, true, true>), dim3((unsigned)wgs), dim3(256), C::lds_bytes + PRE_BYTES, st, A9, A9_lo, IN, OUT,
+                               M, K, H, tiles_m, tiles_r, (int)pts, stats, pre_scale, pre_shift);
+        else
+            hipLaunchKernelGGL((k_conv3x3_x3q<W, D, true>), dim3((unsigned)wgs), dim3(256), C::lds_bytes, st, A9, A9_lo, IN, OUT, M, K, H, tiles_m,
+                               tiles_r, (int)pts, stats);
     } else {
         hipLaunchKernelGGL((k_conv3x3_x3q<W, D, false>), dim3((unsigned)wgs), dim3(256), C::lds_bytes, st, A9, A9_lo, IN, OUT, M, K, H, tiles_m,
                            tiles_r, (int)pts, stats);
@@ -289,12 +316,12 @@ bool aadg_conv3x3_x3q_takes(int M, int K, int H, int W, int dilation) {
 
 // bn_sums (optional): float64 [2 M + 1] = (sum, sum of squares) per output channel and the element count, zeroed in here
 int aadg_conv3x3_x3q(const uint16_t* a9_hi, const uint16_t* a9_lo, const float* in, float* out, int N, int M, int K, int H, int W,
-                     int dilation, double* bn_sums, hipStream_t st) {
+                     int dilation, double* bn_sums, hipStream_t st, const float* pre_scale, const float* pre_shift) {
     if (dilation == 1) {
-        if (W == 32) return launch_q<32, 1>(a9_hi, a9_lo, in, out, N, M, K, H, bn_sums, st);
-        if (W == 64) return launch_q<64, 1>(a9_hi, a9_lo, in, out, N, M, K, H, bn_sums, st);
-        return launch_q<128, 1>(a9_hi, a9_lo, in, out, N, M, K, H, bn_sums, st);
+        if (W == 32) return launch_q<32, 1>(a9_hi, a9_lo, in, out, N, M, K, H, bn_sums, st, pre_scale, pre_shift);
+        if (W == 64) return launch_q<64, 1>(a9_hi, a9_lo, in, out, N, M, K, H, bn_sums, st, pre_scale, pre_shift);
+        return launch_q<128, 1>(a9_hi, a9_lo, in, out, N, M, K, H, bn_sums, st, pre_scale, pre_shift);
     }
-    if (W == 32) return launch_q<32, 2>(a9_hi, a9_lo, in, out, N, M, K, H, bn_sums, st);
-    return launch_q<64, 2>(a9_hi, a9_lo, in, out, N, M, K, H, bn_sums, st);
+    if (W == 32) return launch_q<32, 2>(a9_hi, a9_lo, in, out, N, M, K, H, bn_sums, st, pre_scale, pre_shift);
+    return launch_q<64, 2>(a9_hi, a9_lo, in, out, N, M, K, H, bn_sums, st, pre_scale, pre_shift);
 }

@@ -354,23 +354,40 @@ class Bottleneck(nn.Module):
                     short, (bns.weight, bns.bias, bns.running_mean, bns.running_var, bns.momentum, bns.eps), _ACT_CODE['relu'], handles)
             return bn_act(self.bn3, main, 'relu', residual=bn_act(bns, short, None), handles=handles)
         idt = x_res if self.downsample is None else self.downsample(x_res)
-        out = bn_act(self.bn1, self.conv1(x_main), 'relu')
-        c2 = self.conv2(out)
+        c2 = self._bn1_on_load(self.conv1(x_main))
         c3 = self._bn2_on_load(c2)
         if c3 is None:
             c3 = self.conv3(bn_act(self.bn2, c2, 'relu'))
         return bn_act(self.bn3, c3, 'relu', residual=idt, handles=handles)
 
+    lazy_bn1 = True         # f32x3 training: bn1 + ReLU applied by conv2 (stride 1) while it stages its operand, as lazy_bn2 below
     lazy_bn2 = True         # f32x3 training: bn2 + ReLU applied by conv3 while it loads its operand (no elementwise pass, no normalised tensor)
+
+    def _lazy_ok(self, bn, x, conv):
+        return (self.training and torch.is_grad_enabled() and not _BN_SYNC and conv.f32x3 and x.is_cuda and x.dtype == torch.float32 and
+                conv.stride == (1, 1) and getattr(x, '_aadg_bn_sums', None) is not None and type(bn) is nn.BatchNorm2d and
+                bn.momentum is not None and bn.track_running_stats and bn.affine)
+
+    def _bn1_on_load(self, c1):
+        """conv2(relu(bn1(c1))): bn1 + ReLU on conv2's operand load where that applies (see _bn2_on_load), else the materialised path"""
+        bn, conv2 = self.bn1, self.conv2
+        if self.lazy_bn1 and conv2.bn_stats and self._lazy_ok(bn, c1, conv2):
+            from .. import _lib
+            c1c = c1.contiguous()
+            d = conv2.dilation[0]
+            if _lib.conv3x3_x3_pre_supported(c1c, conv2.weight, d) and _lib.bn_act_supported(c1c, None):
+                _bump(bn)
+                z, scale, shift = _lib.batch_norm_lazy(c1c, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                                       c1._aadg_bn_sums)
+                return _lib.conv3x3_x3(z, conv2.weight, d, True, pre=(scale, shift))
+        return self.conv2(bn_act(bn, c1, 'relu'))
 
     def _bn2_on_load(self, c2):
         """conv3(relu(bn2(c2))) with the normalisation applied on conv3's operand load (_lib.batch_norm_lazy + conv1x1_x3(pre=...)), or None
         where that path does not apply: needs the statistics conv2 left in its epilogue, plain per-device BatchNorm, whole-tile shapes."""
         bn, conv3 = self.bn2, self.conv3
         sums = getattr(c2, '_aadg_bn_sums', None)
-        if not (self.lazy_bn2 and sums is not None and self.training and torch.is_grad_enabled() and not _BN_SYNC and conv3.f32x3 and
-                c2.is_cuda and c2.dtype == torch.float32 and conv3.stride == (1, 1) and type(bn) is nn.BatchNorm2d and
-                bn.momentum is not None and bn.track_running_stats and bn.affine):
+        if not (self.lazy_bn2 and self._lazy_ok(bn, c2, conv3)):
             return None
         from .. import _lib
         c2c = c2.contiguous()

@@ -450,6 +450,12 @@ int aadg_conv1x1_nchw_f32x3_pre(const void* a_hi, const void* a_lo, const float*
                                 const float* pre_scale, const float* pre_shift, double* bn_sums, void* stream);
 int aadg_conv1x1_wgrad_f32x3_pre(const float* dy, const float* x, float* dweight, int N, int Co, int Ci, int HW, const float* pre_scale,
                                  const float* pre_shift, void* stream);
+/* ... and the 3x3 pair (a bottleneck's bn1 in front of conv2): the forward needs bn_sums (its own output's statistics), K <= 512 and a
+ * shape of aadg_conv3x3_f32x3_stats_supported; zero padding as for the normalised tensor. */
+int aadg_conv3x3_nchw_f32x3_pre(const void* a9_hi, const void* a9_lo, const float* in, float* out, int N, int M, int K, int H, int W,
+                                int dilation, const float* pre_scale, const float* pre_shift, double* bn_sums, void* stream);
+int aadg_conv3x3_wgrad_f32x3_pre(const float* dy, const float* x, float* dweight9, int N, int Co, int Ci, int H, int W, int dilation,
+                                 const float* pre_scale, const float* pre_shift, void* stream);
 
 /* Per-step re-layout of the float32 master weights of the convolutions above, every layer in one launch (csrc/weight_layouts.hip):
  * w [Co][Ci][taps] float32 -> plain [Co][Ci][taps], fwd [taps][Co][Ci], bwd [taps'][Ci][Co] bfloat16 (taps' = taps - 1 - t when flip,

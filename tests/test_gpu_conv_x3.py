@@ -326,6 +326,33 @@ def test_conv1x1_x3_applies_batchnorm_relu_on_load(hip, N, K, M, H, W):
     assert _err(dw_pre, dw_ref) <= 2e-6, _err(dw_pre, dw_ref)
 
 
+@pytest.mark.parametrize("N,K,M,H,W,d", [(3, 64, 64, 32, 32, 1), (2, 128, 128, 64, 64, 1), (2, 64, 64, 128, 128, 1), (2, 512, 512, 32, 32, 2),
+                                         (1, 48, 64, 30, 64, 2)])
+def test_conv3x3_x3_applies_batchnorm_relu_on_load(hip, N, K, M, H, W, d):
+    """aadg_conv3x3_nchw_f32x3_pre / aadg_conv3x3_wgrad_f32x3_pre: max(x * scale[k] + shift[k], 0) while staging, ZERO padding (the
+    padding of the normalised tensor, not relu(shift)) -- forward and weight gradient == the kernels on the materialised tensor."""
+    torch.manual_seed(K + W + d)
+    x = torch.randn(N, K, H, W, device="cuda") * 1.7 + 0.2
+    sc = torch.rand(K, device="cuda") + 0.5
+    sh = torch.randn(K, device="cuda") * 0.5 + 0.3                       # relu(shift) > 0 for most channels: a padding bug would show
+    w = torch.randn(M, K, 3, 3, device="cuda") / (9 * K) ** 0.5
+    assert hip.conv3x3_x3_pre_supported(x, w, d)
+    z = torch.clamp_min((x.double() * sc.view(1, -1, 1, 1).double() + sh.view(1, -1, 1, 1).double()).float(), 0.0)
+    a9 = hip.split_weight(w.permute(2, 3, 0, 1).reshape(9, M, K).contiguous())
+    s1 = torch.empty(2 * M + 1, dtype=torch.float64, device="cuda")
+    s2 = torch.empty(2 * M + 1, dtype=torch.float64, device="cuda")
+    y_pre = hip.conv3x3_nchw_x3(a9, x, d, s1, (sc, sh))
+    y_ref = hip.conv3x3_nchw_x3(a9, z, d, s2)
+    assert _err(y_pre, y_ref) <= 2e-6, _err(y_pre, y_ref)
+    assert (s1 - s2).abs().max().item() <= 1e-5 * s2.abs().max().item()
+    dy = torch.randn(N, M, H, W, device="cuda")
+    dw_pre = hip.conv3x3_wgrad_x3(dy, x, d, (sc, sh))
+    dw_ref = hip.conv3x3_wgrad_x3(dy, z, d)
+    assert _err(dw_pre, dw_ref) <= 2e-6, _err(dw_pre, dw_ref)
+    with pytest.raises(hip.AadgError):
+        hip.conv3x3_nchw_x3(a9, x, d, None, (sc, sh))                    # the load transform comes with the statistics epilogue only
+
+
 def test_conv1x1_x3_load_transform_only_for_whole_tile_shapes(hip):
     x = torch.randn(1, 48, 16, 16, device="cuda")                                       # 48 input channels, 192 outputs: no whole tiles
     w = torch.randn(192, 48, 1, 1, device="cuda")
@@ -365,8 +392,8 @@ def test_batch_norm_lazy_finalises_like_torch(hip):
 
 
 @pytest.mark.parametrize("planes,dilation", [(64, 1), (128, 2)])
-def test_bottleneck_with_bn2_on_operand_load_equals_the_materialised_path(hip, planes, dilation):
-    """models/deeplab.py Bottleneck: conv3 applies bn2 + ReLU while it loads conv2's output (lazy_bn2) -- output, running statistics and
+def test_bottleneck_with_batchnorm_on_operand_load_equals_the_materialised_path(hip, planes, dilation):
+    """models/deeplab.py Bottleneck: conv2 / conv3 apply bn1 / bn2 + ReLU while they load conv1's / conv2's output (lazy_bn1, lazy_bn2) -- output, running statistics and
     every gradient equal the path that materialises the normalised tensor (same kernels otherwise; bit-reproducible forward: the
     statistics epilogues off would change both alike, so they stay on) and plain torch in float64."""
     from aadg_amd.models import deeplab as DL
@@ -383,7 +410,7 @@ def test_bottleneck_with_bn2_on_operand_load_equals_the_materialised_path(hip, p
             if isinstance(m, torch.nn.BatchNorm2d):
                 m.reset_running_stats()
         blk.zero_grad(set_to_none=True)
-        blk.lazy_bn2 = lazy
+        blk.lazy_bn1 = blk.lazy_bn2 = lazy
         xi = x1.clone().requires_grad_(True)
         y = blk(xi)
         y.backward(g)
@@ -397,11 +424,11 @@ def test_bottleneck_with_bn2_on_operand_load_equals_the_materialised_path(hip, p
         y_l, dx_l, gp_l, rv_l = run(True)
     finally:
         hip.batch_norm_lazy = orig
-    assert calls, "the bottleneck did not take the on-load path"
+    assert len(calls) == 2, "the bottleneck did not take the on-load path for bn1 and bn2"
     y_m, dx_m, gp_m, rv_m = run(False)
     assert _err(y_l, y_m) <= 1e-5 and _err(rv_l, rv_m) <= 1e-6
     rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()      # noqa: E731  (float64 atomics of the epilogues: last-bit statistics)
     assert rel(dx_l, dx_m) <= 1e-3
     for n in gp_m:
         assert rel(gp_l[n], gp_m[n]) <= 1e-3, n
-    blk.lazy_bn2 = True
+    blk.lazy_bn1 = blk.lazy_bn2 = True
