@@ -3,7 +3,7 @@ backbone in float32 tensors on the f32x3 kernels and ASSERTS north_star's 1e-4 (
 labelled secondary figure whose looser bounds the remaining tests keep.  History: until round 4 the headline ran the convolutions
 under bfloat16 autocast; BASELINE configs[1] is float32.  On IDENTICAL weights and inputs (forward only, dropout off) the quantities
 the policy search consumes must agree between the two: raw Sinkhorn rewards per policy, per-policy BCE, Dice.  The bounds asserted
-here (at a reduced 256 x 256 config, weights a few search steps old: median reward within 10 %, per-policy BCE within 1 %, Dice within 0.01)
+here (at a reduced 256 x 256 config, weights a few search steps old: median reward within 10 %, per-policy BCE within 1.5 %, Dice within 0.02)
 are the ones bench.py states in its `dtype` field; the values measured at the headline config travel in its `precision` block
 (0.1 % / 0.04 % / 0.0007 in round 3).  Round 4: three seeded batches, and `within_north_star_1e-4` flags -- the bf16 backbone moves the raw
 rewards by 0.75e-4 .. 3.2e-4 and Dice by 0.9e-4 .. 6e-4 (absolute, headline config, runs of round 4): around, not reliably inside, the 1e-4
@@ -61,8 +61,9 @@ def test_bf16_backbone_keeps_the_search_quantities(hip, backbone, size, batch):
     # The five warm-up steps are not bit-reproducible (split-K float atomics in the weight gradients), so the compared weights differ from
     # run to run: 30 runs of round 5 gave medians of 0.3 - 5.2 % (one run in ten above 5 %) -- the bounds are twice that.
     assert float(np.median([b["reward_rel"] for b in p["per_batch"]])) <= 1e-1 and p["reward_rel_max_diff"] <= 2e-1, p
-    assert p["bce_rel_max_diff"] <= 1e-2, p
-    assert p["dice_abs_max_diff"] <= 1e-2, p
+    # (scripts/ab/precision_spread.py, 30 runs of the mobilenet case: per-policy BCE 0.28 - 0.76 %, Dice 0.001 - 0.0103 -- same reason)
+    assert p["bce_rel_max_diff"] <= 1.5e-2, p
+    assert p["dice_abs_max_diff"] <= 2e-2, p
     assert p["batches"] == 3 and len(p["per_batch"]) == 3
     for b in p["per_batch"]:
         assert np.isfinite(b["rewards_bf16"]).all() and len(b["rewards_bf16"]) == st.M
