@@ -61,7 +61,7 @@ EXPORTS = [
     "aadg_stem_conv7x7_f32x3", "aadg_stem_conv7x7_wgrad_f32x3", "aadg_sinkhorn_divergence_phases_f32",
     "aadg_conv1x1_nchw_f32x3_stats", "aadg_conv3x3_nchw_f32x3_stats", "aadg_conv3x3_f32x3_stats_supported",
     "aadg_bn_finalize_f32", "aadg_conv1x1_f32x3_pre_supported", "aadg_conv1x1_nchw_f32x3_pre", "aadg_conv1x1_wgrad_f32x3_pre",
-    "aadg_conv3x3_nchw_f32x3_pre", "aadg_conv3x3_wgrad_f32x3_pre",
+    "aadg_conv3x3_nchw_f32x3_pre", "aadg_conv3x3_wgrad_f32x3_pre", "aadg_conv1x1_wgrad_f32x3_pre_supported",
 ]
 
 _lib = None
@@ -258,6 +258,8 @@ def load():
     lib.aadg_conv1x1_nchw_f32x3_pre.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]
     lib.aadg_conv1x1_wgrad_f32x3_pre.restype = _i
     lib.aadg_conv1x1_wgrad_f32x3_pre.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]
+    lib.aadg_conv1x1_wgrad_f32x3_pre_supported.restype = _i
+    lib.aadg_conv1x1_wgrad_f32x3_pre_supported.argtypes = [_i, _i, _i, _i]
     lib.aadg_conv3x3_nchw_f32x3_pre.restype = _i
     lib.aadg_conv3x3_nchw_f32x3_pre.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]
     lib.aadg_conv3x3_wgrad_f32x3_pre.restype = _i
@@ -2173,12 +2175,13 @@ def conv1x1_x3_supported(x, weight):
 
 
 def conv1x1_x3_pre_supported(x, weight):
-    """the shapes on which the 1x1 kernels apply a BatchNorm + ReLU to x while they load it (forward and weight gradient: whole tiles)"""
+    """the shapes on which the 1x1 kernels apply a BatchNorm + ReLU to x while they load it: forward and weight gradient both need whole
+    tiles of x (the transformed operand); the number of output channels is free"""
     Co, Ci = weight.shape[0], weight.shape[1]
     HW = x.shape[2] * x.shape[3] if x.dim() == 4 else 0
-    # (the weight gradient's tiles: 256 x 64 for Ci <= 64, else 128 x 128 or 256 x 256)
-    return (conv1x1_x3_supported(x, weight) and bool(load().aadg_conv1x1_f32x3_pre_supported(Co, Ci, HW)) and Co % 256 == 0 and
-            (Ci == 64 or Ci % 128 == 0))
+    lib = load()
+    return (conv1x1_x3_supported(x, weight) and bool(lib.aadg_conv1x1_f32x3_pre_supported(Co, Ci, HW)) and
+            bool(lib.aadg_conv1x1_wgrad_f32x3_pre_supported(x.shape[0], Co, Ci, HW)))
 
 
 def conv1x1_x3(x, weight, want_stats=False, pre=None):

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
                                                          int tiles_p, int tiles_m, double* __restrict__ stats,
                                                          const float* __restrict__ pre_scale = nullptr,
                                                          const float* __restrict__ pre_shift = nullptr) {
-    static_assert(!PRE || (X3 && EXACT), "the load transform exists for whole-tile float32 shapes");
+    static_assert(!PRE || X3, "the load transform exists for float32 tensors (whole IN tiles: K % 32 == 0, HW % 256 == 0)");
     static_assert(WR * WC == 4 && 32 * NI * WC == CF_BP, "4 waves, 256 pixels");
     constexpr int BM = 32 * MI * WR;
     constexpr int BK = X3 ? 32 : CF_BK, APITCH = BK + 8, PL = X3 ? 2 : 1;
@@ -285,7 +285,17 @@ int launch(const uint16_t* A, const uint16_t* A_lo, const void* IN, void* OUT, i
         AADG_LAUNCH_CHECK();
         return 0;
     }
-    if (pre_scale != nullptr) return AADG_E_UNSUPPORTED;
+    if (pre_scale != nullptr) {
+        // M is not a whole number of tiles (the 8-row classifier): the IN tiles still are -- no zero-filled IN value that the transform would
+        // turn into relu(shift)
+        if (!X3 || (K % 32) != 0 || (HW % CF_BP) != 0 || K > CF_PRE_K) return AADG_E_UNSUPPORTED;
+        const long long wgs_p = (long long)N * (HW / CF_BP) * ((M + BM - 1) / BM);
+        if (wgs_p > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
+        hipLaunchKernelGGL((k_conv1x1_nchw<WR, WC, MI, NI, X3, false, X3>), dim3((unsigned)wgs_p), dim3(256), 0, st, A, A_lo, IN, OUT, M, K, HW,
+                           HW / CF_BP, (M + BM - 1) / BM, stats, pre_scale, pre_shift);
+        AADG_LAUNCH_CHECK();
+        return 0;
+    }
     const int tiles_p = (HW + CF_BP - 1) / CF_BP, tiles_m = (M + BM - 1) / BM;
     const long long wgs = (long long)N * tiles_p * tiles_m;
     if (wgs > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
@@ -336,9 +346,9 @@ extern "C" int aadg_conv1x1_nchw_f32x3_stats(const void* a_hi, const void* a_lo,
     return aadg_conv1x1_nchw_f32x3_pre(a_hi, a_lo, in, out, N, M, K, HW, nullptr, nullptr, bn_sums, stream);
 }
 
-/* the shapes of aadg_conv1x1_nchw_f32x3_pre: whole tiles (M % 128, K % 32, HW % 256 == 0), K <= 512 */
+/* the shapes of aadg_conv1x1_nchw_f32x3_pre: whole tiles of `in` (K % 32 == 0, HW % 256 == 0), K <= 512; any M */
 extern "C" int aadg_conv1x1_f32x3_pre_supported(int M, int K, int HW) {
-    return aadg_conv1x1_nchw_supported(M, K, HW) && M > 64 && (M % 128) == 0 && (K % 32) == 0 && K <= CF_PRE_K && (HW % CF_BP) == 0 ? 1 : 0;
+    return aadg_conv1x1_nchw_supported(M, K, HW) && (K % 32) == 0 && K <= CF_PRE_K && (HW % CF_BP) == 0 ? 1 : 0;
 }
 
 /* ... and, with pre_scale / pre_shift [K] != NULL (ABI 10), `in` is the INPUT of the BatchNorm + ReLU in front of this convolution: every
@@ -358,6 +368,6 @@ extern "C" int aadg_conv1x1_nchw_f32x3_pre(const void* a_hi, const void* a_lo, c
         hipLaunchKernelGGL(k_bn_sums_init, dim3((2 * M + 1 + 255) / 256), dim3(256), 0, st, bn_sums, M, (double)N * (double)HW);
         AADG_LAUNCH_CHECK();
     }
-    if (M <= 64) return launch<1, 4, 2, 2, true>(ph, pl, in, out, N, M, K, HW, st, bn_sums);
+    if (M <= 64) return launch<1, 4, 2, 2, true>(ph, pl, in, out, N, M, K, HW, st, bn_sums, pre_scale, pre_shift);
     return launch<2, 2, 2, 4, true>(ph, pl, in, out, N, M, K, HW, st, bn_sums, pre_scale, pre_shift);
 }

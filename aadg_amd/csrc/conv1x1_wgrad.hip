@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_wgrad1x1(const void* __restric
                                                            float* __restrict__ acc, int Co, int Ci, int HW, int tiles, int tiles_n,
                                                            int steps_total, int steps_per_block, const float* __restrict__ pre_scale = nullptr,
                                                            const float* __restrict__ pre_shift = nullptr) {
-    static_assert(!PRE || (X3 && EXACT), "the load transform exists for whole-tile float32 shapes");
+    static_assert(!PRE || X3, "the load transform exists for float32 tensors (whole X tiles: Ci a multiple of the tile's columns)");
     typedef typename std::conditional<X3, float, uint16_t>::type elem_t;
     const elem_t* dY = reinterpret_cast<const elem_t*>(dY_);
     const elem_t* X = reinterpret_cast<const elem_t*>(X_);
@@ -212,13 +212,18 @@ int launch(const void* dY, const void* X, float* acc, int N, int Co, int Ci, int
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad1x1<WR, WC, MI, NI, X3, X3, X3>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AADG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad1x1<WR, WC, MI, NI, X3, false, X3>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    if (pre_scale != nullptr && !(X3 && (Co % BM) == 0 && (Ci % BN) == 0)) return AADG_E_UNSUPPORTED;
+    if (pre_scale != nullptr && !(X3 && (Ci % BN) == 0)) return AADG_E_UNSUPPORTED;       // every staged X row must exist
     AADG_HIP_TRY(hipMemsetAsync(acc, 0, (size_t)Co * Ci * sizeof(float), st));
     const int slice_groups = (split + 7) / 8;                 // slices are padded to a multiple of 8 (empty ones exit at once)
-    if (pre_scale != nullptr)
+    if (pre_scale != nullptr && (Co % BM) == 0)
         hipLaunchKernelGGL((k_wgrad1x1<WR, WC, MI, NI, X3, X3, X3>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(NT), lds, st, dY, X, acc,
+                           Co, Ci, HW, tiles, tiles_n, steps_total, steps_per_block, pre_scale, pre_shift);
+    else if (pre_scale != nullptr)                          // Co is no whole number of tiles (the 8-row classifier): null dY rows, whole X tiles
+        hipLaunchKernelGGL((k_wgrad1x1<WR, WC, MI, NI, X3, false, X3>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(NT), lds, st, dY, X, acc,
                            Co, Ci, HW, tiles, tiles_n, steps_total, steps_per_block, pre_scale, pre_shift);
     else if (X3 && (Co % BM) == 0 && (Ci % BN) == 0)
         hipLaunchKernelGGL((k_wgrad1x1<WR, WC, MI, NI, X3, X3>), dim3((unsigned)(slice_groups * tiles * 8)), dim3(NT), lds, st, dY, X, acc, Co,
@@ -256,6 +261,17 @@ extern "C" int aadg_conv1x1_wgrad_bf16(const void* dy, const void* x, float* dwe
     if ((((uintptr_t)dy | (uintptr_t)x) & 15u) != 0) return AADG_E_BADARG;
     if (!aadg_conv1x1_wgrad_supported(Co, Ci, HW) || (long long)N * (HW / WG_BK) > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
     return wgrad1x1_dispatch<false>(dy, x, dweight, N, Co, Ci, HW, (hipStream_t)stream);
+}
+
+/* the shapes whose weight gradient takes pre_scale / pre_shift (aadg_conv1x1_wgrad_f32x3_pre): Ci a whole number of the X tiles of the
+ * configuration the dispatch picks for (N, Co, Ci, HW) */
+extern "C" int aadg_conv1x1_wgrad_f32x3_pre_supported(int N, int Co, int Ci, int HW) {
+    if (N <= 0 || Co <= 0 || Ci <= 0 || HW < 32 || (HW % 32) != 0) return 0;
+    if (Co <= 64) return (Ci % 256) == 0;
+    if (Ci <= 64) return (Ci % 64) == 0;
+    const long long big_wgs = (long long)(Co / 256) * (Ci / 256) * ((long long)N * (HW / 32) / 32);
+    if (Co >= 256 && Ci >= 256 && (Co % 256) == 0 && (Ci % 256) == 0 && (long long)Co * Ci >= 512 * 512 && big_wgs >= 192) return 1;
+    return (Ci % 128) == 0;
 }
 
 /* dW [Co, Ci] float32 from float32 NCHW dy / x at float32 precision ("f32x3": three bfloat16 matrix-core products per pair of

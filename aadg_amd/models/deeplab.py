@@ -674,11 +674,39 @@ class DeepLabV3Plus(nn.Module):
             y = _lib.upsample_cat(a, s)                     # up-sampling written straight into the concatenation
         else:
             y = torch.cat([_upsample_ac(a, skip.shape[-2:]), s], dim=1)
-        y = self.fuse(y)
-        mask = _upsample_ac(self._classify(y), x.shape[-2:])
+        logits = self._fuse_classify_on_load(y)
+        if logits is None:
+            logits = self._classify(self.fuse(y))
+        mask = _upsample_ac(logits, x.shape[-2:])
         if not self.aux_pooling:
             return mask
         return mask, pooled
+
+
+def _fuse_classify_on_load(self, y):
+    """classifier(relu(bn(fuse_conv(y)))) with the decoder's last BatchNorm + ReLU applied while the 1x1 classifier (weight padded to 8
+    rows, see _classify) loads the fuse convolution's output -- the normalised [N, 256, H/4, W/4] tensor, the largest of the decoder, is
+    never written (Bottleneck._bn2_on_load has the conditions); None where that path does not apply."""
+    c, fuse = self.classifier, self.fuse
+    if not (self.lazy_fuse_bn and getattr(self, 'f32x3', False) and self.training and torch.is_grad_enabled() and not _BN_SYNC and
+            y.is_cuda and y.dtype == torch.float32 and not torch.is_autocast_enabled('cuda') and c.kernel_size == (1, 1) and
+            c.out_channels <= 8 and len(fuse) == 2 and isinstance(fuse[0], SeparableConv2d) and type(fuse[1]) is BNAct and
+            fuse[1].act == 'relu'):
+        return None
+    bn = fuse[1].bn
+    if not (type(bn) is nn.BatchNorm2d and bn.momentum is not None and bn.track_running_stats and bn.affine):
+        return None
+    from .. import _lib
+    f = fuse[0](y)
+    sums = getattr(f, '_aadg_bn_sums', None)
+    w8 = F.pad(c.weight, (0, 0, 0, 0, 0, 0, 0, 8 - c.out_channels))
+    fc = f.contiguous()
+    if sums is None or not (_lib.conv1x1_x3_pre_supported(fc, w8) and _lib.bn_act_supported(fc, None)):
+        return self._classify(fuse[1](f))
+    _bump(bn)
+    z, scale, shift = _lib.batch_norm_lazy(fc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, sums)
+    out = _lib.conv1x1_x3(z, w8, pre=(scale, shift))[:, :c.out_channels]
+    return out + c.bias.view(1, -1, 1, 1) if c.bias is not None else out.contiguous()
 
 
 def _classify(self, y):
@@ -698,6 +726,8 @@ def _classify(self, y):
 
 
 DeepLabV3Plus._classify = _classify
+DeepLabV3Plus._fuse_classify_on_load = _fuse_classify_on_load
+DeepLabV3Plus.lazy_fuse_bn = True     # f32x3 training: the decoder's last BatchNorm + ReLU on the classifier's operand load
 
 
 class UNetSmall(nn.Module):

@@ -441,11 +441,12 @@ int aadg_conv1x1_wgrad_f32x3(const float* dy, const float* x, float* dweight, in
  * leaves the float64 totals of its output x (..._stats), aadg_bn_finalize_f32 turns them into mean / invstd / running statistics and
  * scale / shift [C], and the consuming 1x1 convolution (forward and weight gradient) reads x and applies max(x * scale[c] + shift[c], 0)
  * while it stages its operand -- the normalised tensor is never written.  The BatchNorm's backward is aadg_bn_backward with act = ReLU and
- * no stored output / mask (re-derived from x with the same coefficients).  Whole-tile shapes (aadg_conv1x1_f32x3_pre_supported: M % 128,
- * K % 32, HW % 256 == 0, K <= 512; the weight gradient: Co, Ci multiples of its tile) -- AADG_E_UNSUPPORTED otherwise. */
+ * no stored output / mask (re-derived from x with the same coefficients).  Whole tiles of the transformed operand only
+ * (aadg_conv1x1_f32x3_pre_supported: K % 32, HW % 256 == 0, K <= 512; aadg_conv1x1_wgrad_f32x3_pre_supported) -- AADG_E_UNSUPPORTED otherwise. */
 int aadg_bn_finalize_f32(const double* sums, const float* weight, const float* bias, float* running_mean, float* running_var, float momentum,
                          float eps, int C, float* save_mean, float* save_invstd, float* scale, float* shift, void* stream);
 int aadg_conv1x1_f32x3_pre_supported(int M, int K, int HW);
+int aadg_conv1x1_wgrad_f32x3_pre_supported(int N, int Co, int Ci, int HW);
 int aadg_conv1x1_nchw_f32x3_pre(const void* a_hi, const void* a_lo, const float* in, float* out, int N, int M, int K, int HW,
                                 const float* pre_scale, const float* pre_shift, double* bn_sums, void* stream);
 int aadg_conv1x1_wgrad_f32x3_pre(const float* dy, const float* x, float* dweight, int N, int Co, int Ci, int HW, const float* pre_scale,

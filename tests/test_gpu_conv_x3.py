@@ -432,3 +432,48 @@ def test_bottleneck_with_batchnorm_on_operand_load_equals_the_materialised_path(
     for n in gp_m:
         assert rel(gp_l[n], gp_m[n]) <= 1e-3, n
     blk.lazy_bn1 = blk.lazy_bn2 = True
+
+
+def test_decoder_classifier_applies_the_last_batchnorm_on_load(hip):
+    """models/deeplab.py DeepLabV3Plus._fuse_classify_on_load: the decoder's last BatchNorm + ReLU runs on the operand load of the 8-row
+    classifier (an output-channel count that is no whole tile: the PRE instantiations without EXACT) -- logits, running statistics and the
+    gradients of the fuse convolution, the BatchNorm and the classifier equal the materialised path."""
+    from aadg_amd.models import deeplab as DL
+    torch.manual_seed(31)
+    m = DL.DeepLabV3Plus("mobilenet_v2", 2).cuda().train()
+    DL.batch_step_bookkeeping(m, f32x3=True)
+    for hook in list(m._forward_pre_hooks.values()):
+        hook(m, ())                                                  # the per-forward weight bookkeeping (split shadows) of the model
+    y0 = torch.randn(3, 304, 32, 32, device="cuda")
+    g = torch.randn(3, 2, 32, 32, device="cuda")
+    bn = m.fuse[1].bn
+
+    def run(lazy):
+        bn.reset_running_stats()
+        m.zero_grad(set_to_none=True)
+        m.lazy_fuse_bn = lazy
+        yi = y0.clone().requires_grad_(True)
+        out = m._fuse_classify_on_load(yi)
+        if not lazy:
+            assert out is None
+            out = m._classify(m.fuse(yi))
+        out.backward(g)
+        torch.cuda.synchronize()
+        grads = {n: p.grad.clone() for n, p in list(m.fuse.named_parameters()) + list(m.classifier.named_parameters())}
+        return out.detach(), yi.grad, grads, bn.running_var.clone()
+
+    calls = []
+    orig = hip.batch_norm_lazy
+    hip.batch_norm_lazy = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        o_l, dy_l, gp_l, rv_l = run(True)
+    finally:
+        hip.batch_norm_lazy = orig
+    assert len(calls) == 1, "the head did not take the on-load path"
+    o_m, dy_m, gp_m, rv_m = run(False)
+    m.lazy_fuse_bn = True
+    assert _err(o_l, o_m) <= 1e-5 and _err(rv_l, rv_m) <= 1e-6
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()      # noqa: E731
+    assert rel(dy_l, dy_m) <= 1e-3
+    for n in gp_m:
+        assert rel(gp_l[n], gp_m[n]) <= 1e-3, n
