@@ -61,7 +61,7 @@ EXPORTS = [
     "aadg_stem_conv7x7_f32x3", "aadg_stem_conv7x7_wgrad_f32x3", "aadg_sinkhorn_divergence_phases_f32",
     "aadg_conv1x1_nchw_f32x3_stats", "aadg_conv3x3_nchw_f32x3_stats", "aadg_conv3x3_f32x3_stats_supported",
     "aadg_bn_finalize_f32", "aadg_conv1x1_f32x3_pre_supported", "aadg_conv1x1_nchw_f32x3_pre", "aadg_conv1x1_wgrad_f32x3_pre",
-    "aadg_conv3x3_nchw_f32x3_pre", "aadg_conv3x3_wgrad_f32x3_pre", "aadg_conv1x1_wgrad_f32x3_pre_supported",
+    "aadg_conv3x3_nchw_f32x3_pre", "aadg_conv3x3_wgrad_f32x3_pre", "aadg_conv1x1_wgrad_f32x3_pre_supported", "aadg_bn_forward_res_affine_f32",
 ]
 
 _lib = None
@@ -258,6 +258,8 @@ def load():
     lib.aadg_conv1x1_nchw_f32x3_pre.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]
     lib.aadg_conv1x1_wgrad_f32x3_pre.restype = _i
     lib.aadg_conv1x1_wgrad_f32x3_pre.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]
+    lib.aadg_bn_forward_res_affine_f32.restype = _i
+    lib.aadg_bn_forward_res_affine_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]
     lib.aadg_conv1x1_wgrad_f32x3_pre_supported.restype = _i
     lib.aadg_conv1x1_wgrad_f32x3_pre_supported.argtypes = [_i, _i, _i, _i]
     lib.aadg_conv3x3_nchw_f32x3_pre.restype = _i
@@ -878,9 +880,12 @@ class _BatchNormAct(torch.autograd.Function):
     which the backward kernel sums while reading them instead of autograd running elementwise adds over the full activation."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, act, handles, out=None, presums=None):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, act, handles, out=None, presums=None,
+                res_scale=None, res_shift=None):
         lib = load()
         N, C, H, W = x.shape
+        # res_scale / res_shift: `residual` is the first output of batch_norm_lazy(..., act=ACT_NONE) -- the RAW output of the projection
+        # shortcut's convolution, normalised while this kernel reads it (float32, with presums)
         # presums: float64 [2C + 1] totals of x (sum, sum of squares per channel, element count) the PRODUCING convolution left behind
         # (aadg_conv1x1_nchw_f32x3_stats): the statistics pass over x is not run
         # out: a channel slice of a concatenation buffer (concat_slices): the result is written there, image stride = the buffer's
@@ -894,7 +899,14 @@ class _BatchNormAct(torch.autograd.Function):
             nb = lib.aadg_bn_mask_bytes(N, C, H * W, _BN_DTYPES[x.dtype])
             if nb and (x.data_ptr() | residual.data_ptr() | y.data_ptr()) % 16 == 0:
                 mask = torch.empty(nb, dtype=torch.uint8, device=x.device)
-        if presums is not None:
+        if res_scale is not None:
+            if presums is None or residual is None or out is not None or x.dtype != torch.float32:
+                raise AadgError("batch_norm_act: res_affine needs float32 tensors, a residual, presums and no `out`")
+            rc = lib.aadg_bn_forward_res_affine_f32(x.data_ptr(), residual.data_ptr(), res_scale.data_ptr(), res_shift.data_ptr(), y.data_ptr(),
+                                                    _ptr(mask), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var), momentum, eps,
+                                                    act, N, C, H * W, mean.data_ptr(), invstd.data_ptr(), presums.data_ptr(), ws.data_ptr(),
+                                                    ws.numel(), _stream())
+        elif presums is not None:
             rc = lib.aadg_bn_sync_forward(2, x.data_ptr(), _ptr(residual), y.data_ptr(), _ptr(mask), _ptr(weight), _ptr(bias),
                                           _ptr(running_mean), _ptr(running_var), momentum, eps, act, N, C, H * W, _BN_DTYPES[x.dtype],
                                           mean.data_ptr(), invstd.data_ptr(), presums.data_ptr(), ws.data_ptr(), ws.numel(), y_stride,
@@ -931,7 +943,8 @@ class _BatchNormAct(torch.autograd.Function):
                                   _ptr(dres), dw.data_ptr(), db.data_ptr(), N, C, H * W, _BN_DTYPES[x.dtype], ws.data_ptr(),
                                   ws.numel(), dy_stride, _stream())
         _check(rc, "aadg_bn_backward")
-        return (dx, dres, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None, None, None)
+        return (dx, dres, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None, None, None,
+                None, None)
 
 
 def _bn_prepare_grads(grads, x, has_res):
@@ -1252,7 +1265,7 @@ def bn_act_supported(x, residual=None):
 
 
 def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentum, eps, act=ACT_NONE, residual=None, dual=False,
-                   handles=None, out=None, sync=False, presums=None):
+                   handles=None, out=None, sync=False, presums=None, res_affine=None):
     """act(F.batch_norm(x, ...) [+ residual]) on NCHW float32 / bfloat16 GPU tensors.  handles = k > 1 (training only; dual =
     True means k = 2) returns the output as a tuple of k tensors on one storage, one per consumer, see _BatchNormAct."""
     handles = int(handles) if handles else (2 if dual else 1)
@@ -1266,6 +1279,12 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
         fn = _SyncBatchNormAct if sync else _BatchNormAct
         if presums is not None and (presums.dtype != torch.float64 or presums.numel() != 2 * x.shape[1] + 1 or not presums.is_cuda):
             raise AadgError("batch_norm_act: presums must be the float64 [2C + 1] totals of x")
+        if res_affine is not None:
+            # `residual` = the first output of batch_norm_lazy(..., act=ACT_NONE) of a projection shortcut, normalised on load
+            if sync:
+                raise AadgError("batch_norm_act: res_affine is a per-device path")
+            return fn.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), int(act), handles, out, presums,
+                            res_affine[0], res_affine[1])
         return fn.apply(x, residual, weight, bias, running_mean, running_var, float(momentum), float(eps), int(act), handles, out, presums)
     lib = load()
     N, C, H, W = x.shape
@@ -2206,8 +2225,9 @@ class _BatchNormLazy(torch.autograd.Function):
     x.  The first output stands for relu(bn(x)) in the graph but HOLDS x: only a consumer that applies (scale, shift) may read it."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, presums):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, presums, act=ACT_RELU):
         lib = load()
+        ctx.act = act
         C = x.shape[1]
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
@@ -2231,19 +2251,23 @@ class _BatchNormLazy(torch.autograd.Function):
         db = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _bn_ws(C, x.device)
         rc = lib.aadg_bn_backward(x.data_ptr(), None, None, dz.data_ptr(), None, 0, None, _ptr(weight), _ptr(bias), mean.data_ptr(),
-                                  invstd.data_ptr(), ACT_RELU, dx.data_ptr(), None, dw.data_ptr(), db.data_ptr(), N, C, H * W,
+                                  invstd.data_ptr(), ctx.act, dx.data_ptr(), None, dw.data_ptr(), db.data_ptr(), N, C, H * W,
                                   _BN_DTYPES[x.dtype], ws.data_ptr(), ws.numel(), 0, _stream())
         _check(rc, "aadg_bn_backward")
-        return dx, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None
+        return dx, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None
 
 
-def batch_norm_lazy(x, weight, bias, running_mean, running_var, momentum, eps, presums):
-    """(x', scale, shift): see _BatchNormLazy.  x float32 NCHW contiguous on the GPU, presums its float64 [2C + 1] totals."""
+def batch_norm_lazy(x, weight, bias, running_mean, running_var, momentum, eps, presums, act=ACT_RELU):
+    """(x', scale, shift): see _BatchNormLazy.  x float32 NCHW contiguous on the GPU, presums its float64 [2C + 1] totals.  act: the
+    activation the consumer applies after scale / shift (ACT_RELU: the convolutions' operand load; ACT_NONE: a projection shortcut read as
+    the residual of batch_norm_act(..., res_affine=(scale, shift)))."""
     _require_cuda(x)
     if (x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous() or presums is None or presums.dtype != torch.float64 or
             presums.numel() != 2 * x.shape[1] + 1 or not bn_act_supported(x, None)):
         raise AadgError("batch_norm_lazy: expected a contiguous NCHW float32 tensor and its float64 [2C + 1] totals")
-    return _BatchNormLazy.apply(x, weight, bias, running_mean, running_var, float(momentum), float(eps), presums)
+    if act not in (ACT_RELU, ACT_NONE):
+        raise AadgError("batch_norm_lazy: act is ReLU or none")
+    return _BatchNormLazy.apply(x, weight, bias, running_mean, running_var, float(momentum), float(eps), presums, int(act))
 
 
 def conv3x3_nchw_x3(a9, x, dilation=1, bn_sums=None, pre=None):

@@ -336,7 +336,10 @@ template <typename T, int VEC, int ACT, bool RES, bool MASK, bool FIN>
 __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                   uint8_t* __restrict__ mask, const float* __restrict__ scale,
                                                   const float* __restrict__ shift, BnFin fin, int act_rt, int C, int len, int plen,
-                                                  long long y_img_stride) {
+                                                  long long y_img_stride, const float* __restrict__ res_scale = nullptr,
+                                                  const float* __restrict__ res_shift = nullptr) {
+    // res_scale / res_shift (RES only, ABI 10): `res` is the INPUT of the projection shortcut's BatchNorm (no activation) and is
+    // normalised here, r = fma(res, res_scale[c], res_shift[c]) -- what that BatchNorm's own pass would have stored, never written
     static_assert(!MASK || VEC > 1, "one mask byte per 16-byte vector");
     const int act = ACT >= 0 ? ACT : (act_rt & 0xFF);
     const bool stream = (act_rt & BN_STREAM) != 0;
@@ -363,6 +366,9 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const
     } else {
         sc = scale[c]; sh = shift[c];
     }
+    const bool raff = RES && res_scale != nullptr;
+    float rsc = 1.0f, rsh = 0.0f;
+    if (raff) { rsc = res_scale[c]; rsh = res_shift[c]; }
     const size_t base = (size_t)strip * len * VEC;
     // y may be a channel slice of a wider tensor (written straight into a concatenation buffer): image stride given by the caller
     T* yp = y + (y_img_stride > 0 ? (size_t)(strip / C) * (size_t)y_img_stride + (size_t)c * len * VEC : base);
@@ -374,6 +380,10 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const
         if (VEC == 1) v[0] = Pack<T>::load1(x + off); else Pack<T>::load(x + off, v);
         if (RES) {
             if (VEC == 1) r[0] = Pack<T>::load1(res + off); else Pack<T>::load(res + off, r);
+            if (raff) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) r[i] = Pack<T>::round(fmaf(r[i], rsc, rsh));
+            }
         }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
@@ -461,7 +471,8 @@ inline bool make_shape(int N, int C, int HW, const void* a, const void* b, const
 template <typename T>
 int bn_forward(const T* x, const T* res, T* y, uint8_t* mask, const float* weight, const float* bias, float* rmean, float* rvar, float momentum,
                float eps, int act, int training, int N, int C, int HW, float* save_mean, float* save_invstd, float* ws,
-               long long y_img_stride, hipStream_t st, int phase = 0, double* sums = nullptr) {
+               long long y_img_stride, hipStream_t st, int phase = 0, double* sums = nullptr, const float* res_scale = nullptr,
+               const float* res_shift = nullptr) {
     // phase 0: everything on this device.  Synchronised statistics (training): phase 1 = local sums -> `sums` [2C + 1] doubles
     // (the last one is this rank's element count); the caller all-reduces `sums`; phase 2 = normalise with the totals.
     const int stream_flag = bn_stream((size_t)N * C * HW * sizeof(T)) ? BN_STREAM : 0;
@@ -500,7 +511,7 @@ int bn_forward(const T* x, const T* res, T* y, uint8_t* mask, const float* weigh
     const BnFin fin = {split < 0 ? reinterpret_cast<const float*>(sums) : ws + L.partial, split, (double)N * (double)HW, weight, bias, rmean,
                        rvar, momentum, eps, save_mean, save_invstd, count_dev};
 #define AADG_BN_APPLY(VEC_, ACT_, RES_, MASK_, FIN_) \
-    hipLaunchKernelGGL((k_bn_apply<T, VEC_, ACT_, RES_, MASK_, FIN_>), grid, blk, 0, st, x, res, y, mask, (const float*)scale, (const float*)shift, fin, act | stream_flag, C, s.len, s.pc.plen, y_img_stride)
+    hipLaunchKernelGGL((k_bn_apply<T, VEC_, ACT_, RES_, MASK_, FIN_>), grid, blk, 0, st, x, res, y, mask, (const float*)scale, (const float*)shift, fin, act | stream_flag, C, s.len, s.pc.plen, y_img_stride, res_scale, res_shift)
 #define AADG_BN_APPLY_ACT(ACT_)                                                          \
     do {                                                                                 \
         if (!training) { if (res != nullptr) AADG_BN_APPLY(Pack<T>::N, ACT_, true, false, false); else AADG_BN_APPLY(Pack<T>::N, ACT_, false, false, false); } \
@@ -852,6 +863,21 @@ extern "C" int aadg_bn_sync_forward(int phase, const void* x, const void* residu
                                           (uint8_t*)act_mask, weight, bias, running_mean, running_var, momentum, eps, act, 1, N, C, HW,
                                           save_mean, save_invstd, (float*)ws, y_image_stride, st, phase, sums);
     return AADG_E_BADARG;
+}
+
+/* aadg_bn_sync_forward(phase 2) of float32 tensors whose `residual` is the INPUT of another BatchNorm without activation (a bottleneck's
+ * projection shortcut): res_scale / res_shift [C] (aadg_bn_finalize_f32 of that BatchNorm) are applied while the residual is read -- the
+ * shortcut's normalised tensor is never written.  (ABI 10) */
+extern "C" int aadg_bn_forward_res_affine_f32(const float* x, const float* residual, const float* res_scale, const float* res_shift, float* y,
+                                              void* act_mask, const float* weight, const float* bias, float* running_mean, float* running_var,
+                                              float momentum, float eps, int act, int N, int C, int HW, float* save_mean, float* save_invstd,
+                                              double* sums, void* ws, size_t ws_bytes, void* stream) {
+    if (x == nullptr || residual == nullptr || res_scale == nullptr || res_shift == nullptr || y == nullptr || sums == nullptr ||
+        ws == nullptr || save_mean == nullptr || save_invstd == nullptr || act < 0 || act > AADG_ACT_RELU6 || (((uintptr_t)sums) & 7u) != 0)
+        return AADG_E_BADARG;
+    if (C <= 0 || ws_bytes < aadg_bn_workspace_bytes(C)) return AADG_E_WORKSPACE;
+    return bn_forward<float>(x, residual, y, (uint8_t*)act_mask, weight, bias, running_mean, running_var, momentum, eps, act, 1, N, C, HW,
+                             save_mean, save_invstd, (float*)ws, 0, (hipStream_t)stream, 2, sums, res_scale, res_shift);
 }
 
 extern "C" int aadg_bn_sync_backward(int phase, const void* x, const void* y, const void* act_mask, const void* dy,

@@ -98,7 +98,7 @@ def set_bn_sync(flag):
     _BN_SYNC = bool(flag)
 
 
-def bn_act(bn, x, act=None, residual=None, handles=1, out=None):
+def bn_act(bn, x, act=None, residual=None, handles=1, out=None, res_affine=None):
     """act(bn(x) [+ residual]).  On the GPU a plain `nn.BatchNorm2d` runs as the fused HIP streaming kernels
     (csrc/batchnorm.hip: statistics, normalise + activation + residual add in one pass, two-pass backward); anything
     else (SyncBatchNorm after `--sync_bn`, CPU shape tests) takes the module's own path."""
@@ -115,7 +115,9 @@ def bn_act(bn, x, act=None, residual=None, handles=1, out=None):
             return _lib.batch_norm_act(xc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum,
                                        bn.eps, _ACT_CODE[act], rc,
                                        handles=handles if (bn.training and torch.is_grad_enabled() and rc is not None) else 1,
-                                       out=out if bn.training else None, sync=_BN_SYNC and bn.training, presums=presums)
+                                       out=out if bn.training else None, sync=_BN_SYNC and bn.training, presums=presums,
+                                       res_affine=res_affine)
+    assert res_affine is None, "res_affine: the fused training path only (Bottleneck._shortcut_on_load checks its conditions)"
     if _BN_SYNC and bn.training and type(bn) is nn.BatchNorm2d:
         # the DDP wrapper runs with broadcast_buffers=False on the assumption that EVERY BatchNorm layer synchronises its statistics
         # through the HIP path above; a layer that falls through to plain bn(x) would silently use per-rank statistics
@@ -353,12 +355,35 @@ class Bottleneck(nn.Module):
                     main, (self.bn3.weight, self.bn3.bias, self.bn3.running_mean, self.bn3.running_var, self.bn3.momentum, self.bn3.eps),
                     short, (bns.weight, bns.bias, bns.running_mean, bns.running_var, bns.momentum, bns.eps), _ACT_CODE['relu'], handles)
             return bn_act(self.bn3, main, 'relu', residual=bn_act(bns, short, None), handles=handles)
-        idt = x_res if self.downsample is None else self.downsample(x_res)
         c2 = self._bn1_on_load(self.conv1(x_main))
         c3 = self._bn2_on_load(c2)
         if c3 is None:
             c3 = self.conv3(bn_act(self.bn2, c2, 'relu'))
-        return bn_act(self.bn3, c3, 'relu', residual=idt, handles=handles)
+        idt, raff = (x_res, None) if self.downsample is None else self._shortcut_on_load(x_res, c3)
+        return bn_act(self.bn3, c3, 'relu', residual=idt, handles=handles, res_affine=raff)
+
+    lazy_shortcut = True    # f32x3 training: the projection shortcut's BatchNorm applied while bn3's kernel reads the residual
+
+    def _shortcut_on_load(self, x_res, c3):
+        """(residual, res_affine) of the projection shortcut: the RAW output of its convolution + (scale, shift) of its BatchNorm, which
+        bn3's kernel applies while it reads the residual (no elementwise pass, no normalised shortcut tensor) -- or (downsample(x), None)."""
+        d = self.downsample
+        if (self.lazy_shortcut and isinstance(d, nn.Sequential) and len(d) == 2 and type(d[1]) is BNAct and d[1].act is None and
+                isinstance(d[0], Conv1x1) and getattr(c3, '_aadg_bn_sums', None) is not None and self.training and torch.is_grad_enabled() and
+                not _BN_SYNC and d[0].f32x3 and c3.dtype == torch.float32 and type(self.bn3) is nn.BatchNorm2d):
+            bns = d[1].bn
+            short = d[0](x_res)
+            if (getattr(short, '_aadg_bn_sums', None) is not None and short.shape == c3.shape and type(bns) is nn.BatchNorm2d and
+                    bns.momentum is not None and bns.track_running_stats and bns.affine):
+                from .. import _lib
+                sc = short.contiguous()
+                if _lib.bn_act_supported(c3.contiguous(), sc):
+                    _bump(bns)
+                    z, scale, shift = _lib.batch_norm_lazy(sc, bns.weight, bns.bias, bns.running_mean, bns.running_var, bns.momentum, bns.eps,
+                                                           short._aadg_bn_sums, act=_ACT_CODE[None])
+                    return z, (scale, shift)
+            return d[1](short), None
+        return d(x_res), None
 
     lazy_bn1 = True         # f32x3 training: bn1 + ReLU applied by conv2 (stride 1) while it stages its operand, as lazy_bn2 below
     lazy_bn2 = True         # f32x3 training: bn2 + ReLU applied by conv3 while it loads its operand (no elementwise pass, no normalised tensor)

@@ -445,6 +445,13 @@ int aadg_conv1x1_wgrad_f32x3(const float* dy, const float* x, float* dweight, in
  * (aadg_conv1x1_f32x3_pre_supported: K % 32, HW % 256 == 0, K <= 512; aadg_conv1x1_wgrad_f32x3_pre_supported) -- AADG_E_UNSUPPORTED otherwise. */
 int aadg_bn_finalize_f32(const double* sums, const float* weight, const float* bias, float* running_mean, float* running_var, float momentum,
                          float eps, int C, float* save_mean, float* save_invstd, float* scale, float* shift, void* stream);
+/* ... and a bottleneck's projection shortcut: its BatchNorm (no activation) is applied while the main branch's BatchNorm kernel reads the
+ * residual -- aadg_bn_sync_forward(phase 2) of float32 tensors with the shortcut's raw convolution output as `residual` and its scale /
+ * shift (aadg_bn_finalize_f32); the shortcut BatchNorm's backward is aadg_bn_backward with act = none on the residual gradient. */
+int aadg_bn_forward_res_affine_f32(const float* x, const float* residual, const float* res_scale, const float* res_shift, float* y,
+                                   void* act_mask, const float* weight, const float* bias, float* running_mean, float* running_var,
+                                   float momentum, float eps, int act, int N, int C, int HW, float* save_mean, float* save_invstd, double* sums,
+                                   void* ws, size_t ws_bytes, void* stream);
 int aadg_conv1x1_f32x3_pre_supported(int M, int K, int HW);
 int aadg_conv1x1_wgrad_f32x3_pre_supported(int N, int Co, int Ci, int HW);
 int aadg_conv1x1_nchw_f32x3_pre(const void* a_hi, const void* a_lo, const float* in, float* out, int N, int M, int K, int HW,

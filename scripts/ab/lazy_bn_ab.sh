@@ -1,14 +1,14 @@
-# BatchNorm + ReLU on the consuming convolution's operand load: all (default: bn1 / bn2 of the bottlenecks + the decoder's last one) /
-# bottlenecks only / none, interleaved on ONE box
+# BatchNorm on the consumer's operand load: all (default: bn1 / bn2 of the bottlenecks, the decoder's last one, the projection shortcuts') /
+# all but the shortcuts / none, interleaved on ONE box
 cd $GRAFT_REPO_ROOT
 for i in 1 2 3 4; do
-for v in all blocks none; do
+for v in all noshort none; do
 python -c "
 import sys; sys.argv=['bench.py','--legs','none','--steps','8','--warmup','3']
 from aadg_amd.models import deeplab
 v = '$v'
-deeplab.Bottleneck.lazy_bn1 = deeplab.Bottleneck.lazy_bn2 = v != 'none'
-deeplab.DeepLabV3Plus.lazy_fuse_bn = v == 'all'
+deeplab.Bottleneck.lazy_bn1 = deeplab.Bottleneck.lazy_bn2 = deeplab.DeepLabV3Plus.lazy_fuse_bn = v != 'none'
+deeplab.Bottleneck.lazy_shortcut = v == 'all'
 import runpy; runpy.run_path('bench.py', run_name='__main__')" 2>/dev/null | python -c "
 import json,sys
 r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', r['ms_per_step'])"

@@ -477,3 +477,47 @@ def test_decoder_classifier_applies_the_last_batchnorm_on_load(hip):
     assert rel(dy_l, dy_m) <= 1e-3
     for n in gp_m:
         assert rel(gp_l[n], gp_m[n]) <= 1e-3, n
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_bottleneck_projection_shortcut_normalised_on_residual_load(hip, stride):
+    """models/deeplab.py Bottleneck._shortcut_on_load: the projection shortcut's BatchNorm (no activation) is applied by bn3's kernel while
+    it reads the residual (aadg_bn_forward_res_affine_f32) -- output, running statistics of both BatchNorm layers and every gradient
+    equal the path that materialises the normalised shortcut."""
+    from aadg_amd.models import deeplab as DL
+    torch.manual_seed(41)
+    down = torch.nn.Sequential(DL.Conv1x1(128, 256, stride), DL.BNAct(256, None))
+    blk = DL.Bottleneck(128, 64, stride, 1, down).cuda().train()
+    DL.batch_step_bookkeeping(blk, f32x3=True)
+    DL.mark_bn_producers(blk)
+    x1 = torch.randn(4, 128, 64, 64, device="cuda")
+    g = torch.randn(4, 256, 64 // stride, 64 // stride, device="cuda")
+
+    def run(lazy):
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        blk.zero_grad(set_to_none=True)
+        blk.lazy_shortcut = lazy
+        xi = x1.clone().requires_grad_(True)
+        y = blk(xi)
+        y.backward(g)
+        torch.cuda.synchronize()
+        return (y.detach(), xi.grad, {n: p.grad.clone() for n, p in blk.named_parameters()}, blk.downsample[1].bn.running_var.clone(),
+                blk.bn3.running_mean.clone())
+
+    seen = []
+    orig = hip.batch_norm_act
+    hip.batch_norm_act = lambda *a, **k: (seen.append(k.get("res_affine") is not None), orig(*a, **k))[1]
+    try:
+        y_l, dx_l, gp_l, rv_l, rm_l = run(True)
+    finally:
+        hip.batch_norm_act = orig
+    assert any(seen), "bn3 did not normalise the shortcut on load"
+    y_m, dx_m, gp_m, rv_m, rm_m = run(False)
+    blk.lazy_shortcut = True
+    assert _err(y_l, y_m) <= 1e-5 and _err(rv_l, rv_m) <= 1e-6 and (rm_l - rm_m).abs().max().item() <= 1e-6
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()      # noqa: E731
+    assert rel(dx_l, dx_m) <= 1e-3
+    for n in gp_m:
+        assert rel(gp_l[n], gp_m[n]) <= 1e-3, n
