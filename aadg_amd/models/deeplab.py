@@ -360,6 +360,8 @@ class Bottleneck(nn.Module):
         if c3 is None:
             c3 = self.conv3(bn_act(self.bn2, c2, 'relu'))
         idt, raff = (x_res, None) if self.downsample is None else self._shortcut_on_load(x_res, c3)
+        if raff is None:
+            return bn_act(self.bn3, c3, 'relu', residual=idt, handles=handles)
         return bn_act(self.bn3, c3, 'relu', residual=idt, handles=handles, res_affine=raff)
 
     lazy_shortcut = True    # f32x3 training: the projection shortcut's BatchNorm applied while bn3's kernel reads the residual
