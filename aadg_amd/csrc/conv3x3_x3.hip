@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_x3q(const uint16_t* __restri
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsq[];
     unsigned char* As = ldsq;                      // [9 * 64 records][64 B]
     unsigned char* Bs = ldsq + C::A_BYTES;         // [NPX records][80 B]
-    float* Ps = reinterpret_cast<float*>(ldsq + C::lds_bytes);      // PRE: scale [Q_PRE_K] | shift [Q_PRE_K] behind the tiles
+    float* Ps = reinterpret_cast<float*>(ldsq + C::lds_bytes);      // PRE: scale [K] | shift [K] behind the tiles (2 K floats of dynamic LDS:
+                                                                    // 64 channels at W = 128 keep the second workgroup of the CU)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // XCD-aware decode: the out-channel tiles of one pixel tile run on one XCD and share the IN tile through its L2
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_x3q(const uint16_t* __restri
     // zero the pixel records once: the padding columns and the rows outside the image are never written again
     for (int i = tid; i < C::B_BYTES / 16; i += 256) reinterpret_cast<uint4*>(Bs)[i] = make_uint4(0, 0, 0, 0);
     if (PRE)
-        for (int i = tid; i < K; i += 256) { Ps[i] = pre_scale[i]; Ps[Q_PRE_K + i] = pre_shift[i]; }
+        for (int i = tid; i < K; i += 256) { Ps[i] = pre_scale[i]; Ps[K + i] = pre_shift[i]; }
 
     // per-thread staging descriptors (constant over the K loop)
     int a_src[LA], a_dst[LA];
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_x3q(const uint16_t* __restri
         float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), h4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (PRE) {                                  // the item's four channels: k0 + 4 (tid & 3) + 0..3 for every i (256 = 0 mod 4)
             s4 = *reinterpret_cast<const float4*>(Ps + k0 + 4 * (tid & 3));
-            h4 = *reinterpret_cast<const float4*>(Ps + Q_PRE_K + k0 + 4 * (tid & 3));
+            h4 = *reinterpret_cast<const float4*>(Ps + K + k0 + 4 * (tid & 3));
         }
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
@@ -293,7 +294,7 @@ int launch_q(const uint16_t* A9, const uint16_t* A9_lo, const float* IN, float* 
         hipLaunchKernelGGL(k_q_sums_init, dim3((2 * M + 1 + 255) / 256), dim3(256), 0, st, stats, M, (double)N * (double)H * (double)W);
         AADG_LAUNCH_CHECK();
         if (pre_scale != nullptr)
-            hipLaunchKernelGGL((k_conv3x3_x3q<W, D, true, true>), dim3((unsigned)wgs), dim3(256), C::lds_bytes + PRE_BYTES, st, A9, A9_lo, IN, OUT,
+            hipLaunchKernelGGL((k_conv3x3_x3q<W, D, true, true>), dim3((unsigned)wgs), dim3(256), C::lds_bytes + 2 * (size_t)K * sizeof(float), st, A9, A9_lo, IN, OUT,
                                M, K, H, tiles_m, tiles_r, (int)pts, stats, pre_scale, pre_shift);
         else
             hipLaunchKernelGGL((k_conv3x3_x3q<W, D, true>), dim3((unsigned)wgs), dim3(256), C::lds_bytes, st, A9, A9_lo, IN, OUT, M, K, H, tiles_m,
