@@ -61,7 +61,7 @@ EXPORTS = [
     "aadg_stem_conv7x7_f32x3", "aadg_stem_conv7x7_wgrad_f32x3", "aadg_sinkhorn_divergence_phases_f32",
     "aadg_conv1x1_nchw_f32x3_stats", "aadg_conv3x3_nchw_f32x3_stats", "aadg_conv3x3_f32x3_stats_supported",
     "aadg_bn_finalize_f32", "aadg_conv1x1_f32x3_pre_supported", "aadg_conv1x1_nchw_f32x3_pre", "aadg_conv1x1_wgrad_f32x3_pre",
-    "aadg_conv3x3_nchw_f32x3_pre", "aadg_conv3x3_wgrad_f32x3_pre", "aadg_conv1x1_wgrad_f32x3_pre_supported", "aadg_bn_forward_res_affine_f32",
+    "aadg_conv3x3_nchw_f32x3_pre", "aadg_conv3x3_wgrad_f32x3_pre", "aadg_conv1x1_wgrad_f32x3_pre_supported", "aadg_bn_forward_res_affine_f32", "aadg_bn_backward_res_bn_f32",
 ]
 
 _lib = None
@@ -260,6 +260,9 @@ def load():
     lib.aadg_conv1x1_wgrad_f32x3_pre.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]
     lib.aadg_bn_forward_res_affine_f32.restype = _i
     lib.aadg_bn_forward_res_affine_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]
+    lib.aadg_bn_backward_res_bn_f32.restype = _i
+    lib.aadg_bn_backward_res_bn_f32.argtypes = [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                _vp, _i, _i, _i, _vp, _sz, _vp, _sz, _c.c_longlong, _vp]
     lib.aadg_conv1x1_wgrad_f32x3_pre_supported.restype = _i
     lib.aadg_conv1x1_wgrad_f32x3_pre_supported.argtypes = [_i, _i, _i, _i]
     lib.aadg_conv3x3_nchw_f32x3_pre.restype = _i
@@ -2255,6 +2258,76 @@ class _BatchNormLazy(torch.autograd.Function):
                                   _BN_DTYPES[x.dtype], ws.data_ptr(), ws.numel(), 0, _stream())
         _check(rc, "aadg_bn_backward")
         return dx, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None
+
+
+class _BatchNormActResBN(torch.autograd.Function):
+    """act(batch_norm(x) + batch_norm2(x2)), training mode, float32, both layers' statistics from their producers' epilogues: a
+    bottleneck's bn3 with its projection shortcut's BatchNorm (no activation) folded in.  Forward: the shortcut's statistics are
+    finalised (aadg_bn_finalize_f32) and its normalisation happens while the main kernel reads the residual
+    (aadg_bn_forward_res_affine_f32); backward: both layers in the two passes of one (aadg_bn_backward_res_bn_f32).  The shortcut's
+    normalised tensor and its own forward / backward passes do not exist."""
+
+    @staticmethod
+    def forward(ctx, x, x2, weight, bias, running_mean, running_var, momentum, eps, act, handles, presums,
+                weight2, bias2, running_mean2, running_var2, momentum2, eps2, presums2):
+        lib = load()
+        N, C, H, W = x.shape
+        dev = x.device
+        f32 = lambda: torch.empty(C, dtype=torch.float32, device=dev)      # noqa: E731
+        mean, invstd, mean2, invstd2, scale2, shift2 = f32(), f32(), f32(), f32(), f32(), f32()
+        _check(lib.aadg_bn_finalize_f32(presums2.data_ptr(), _ptr(weight2), _ptr(bias2), _ptr(running_mean2), _ptr(running_var2), momentum2,
+                                        eps2, C, mean2.data_ptr(), invstd2.data_ptr(), scale2.data_ptr(), shift2.data_ptr(), _stream()),
+               "aadg_bn_finalize_f32")
+        y = torch.empty_like(x)
+        mask = torch.empty(lib.aadg_bn_mask_bytes(N, C, H * W, 0), dtype=torch.uint8, device=dev)
+        ws = _bn_ws(C, dev)
+        _check(lib.aadg_bn_forward_res_affine_f32(x.data_ptr(), x2.data_ptr(), scale2.data_ptr(), shift2.data_ptr(), y.data_ptr(),
+                                                  mask.data_ptr(), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var), momentum,
+                                                  eps, act, N, C, H * W, mean.data_ptr(), invstd.data_ptr(), presums.data_ptr(),
+                                                  ws.data_ptr(), ws.numel(), _stream()), "aadg_bn_forward_res_affine_f32")
+        ctx.act = act
+        ctx.save_for_backward(x, x2, mask, weight, bias, mean, invstd, weight2, mean2, invstd2)
+        if handles > 1:
+            return (y,) + tuple(y.view_as(y) for _ in range(handles - 1))
+        return y
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = load()
+        x, x2, mask, weight, bias, mean, invstd, weight2, mean2, invstd2 = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dy, extra, pconst, dy_stride = _bn_prepare_grads(grads, x, True)
+        dx, dres, dx2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x2)
+        f32 = lambda: torch.empty(C, dtype=torch.float32, device=x.device)      # noqa: E731
+        dw, db, dw2, db2 = f32(), f32(), f32(), f32()
+        ws = _bn_ws(C, x.device)
+        ws2 = torch.empty(ws.numel(), dtype=ws.dtype, device=x.device)
+        rc = lib.aadg_bn_backward_res_bn_f32(x.data_ptr(), mask.data_ptr(), dy.data_ptr(), _ptr_array(extra) if extra else None, len(extra),
+                                             _ptr(pconst), _ptr(weight), _ptr(bias), mean.data_ptr(), invstd.data_ptr(), ctx.act,
+                                             dx.data_ptr(), dres.data_ptr(), dw.data_ptr(), db.data_ptr(), x2.data_ptr(), _ptr(weight2),
+                                             mean2.data_ptr(), invstd2.data_ptr(), dx2.data_ptr(), dw2.data_ptr(), db2.data_ptr(), N, C,
+                                             H * W, ws.data_ptr(), ws.numel() * ws.element_size(), ws2.data_ptr(),
+                                             ws2.numel() * ws2.element_size(), dy_stride, _stream())
+        _check(rc, "aadg_bn_backward_res_bn_f32")
+        return (dx, dx2, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None, None,
+                dw2 if weight2 is not None else None, db2 if weight2 is not None else None, None, None, None, None, None)
+
+
+def batch_norm_act_res_bn(x, bn, x2, bn2, act, handles=1):
+    """act(bn(x) + bn2(x2)) for a bottleneck's bn3 and its projection shortcut's BatchNorm (training, per-device statistics, float32;
+    x / x2 carry their producers' statistics as `_aadg_bn_sums`): see _BatchNormActResBN.  bn / bn2: (weight, bias, running_mean,
+    running_var, momentum, eps)."""
+    _require_cuda(x, x2)
+    s1, s2 = getattr(x, '_aadg_bn_sums', None), getattr(x2, '_aadg_bn_sums', None)
+    xc, x2c = x.contiguous(), x2.contiguous()
+    if (s1 is None or s2 is None or xc.dtype != torch.float32 or xc.shape != x2c.shape or act == ACT_NONE or not bn_act_supported(xc, x2c) or
+            not load().aadg_bn_mask_bytes(xc.shape[0], xc.shape[1], xc.shape[2] * xc.shape[3], 0) or
+            (xc.data_ptr() | x2c.data_ptr()) % 16 != 0):
+        raise AadgError("batch_norm_act_res_bn: expected two float32 NCHW tensors of one shape with their producers' statistics")
+    w, b, rm, rv, mom, eps = bn
+    w2, b2, rm2, rv2, mom2, eps2 = bn2
+    return _BatchNormActResBN.apply(xc, x2c, w, b, rm, rv, float(mom), float(eps), int(act), int(handles), s1,
+                                    w2, b2, rm2, rv2, float(mom2), float(eps2), s2)
 
 
 def batch_norm_lazy(x, weight, bias, running_mean, running_var, momentum, eps, presums, act=ACT_RELU):

@@ -217,20 +217,26 @@ __global__ __launch_bounds__(256) void k_bn_reduce_fwd(const T* __restrict__ x, 
 //   MK 2: generic -- v read from y when given, else recomputed from x; `act` is a run-time value (scalar / odd shapes)
 //   MK 3 / 4: ReLU / ReLU6 with v recomputed from x exactly as the forward computed it (BatchNorm without a fused residual)
 //   NE  : number of extra gradients (-1 = more.n at run time);  DRES: 0 / 1 (-1 = dres may or may not be null)
-template <typename T, int VEC, int MK, int NE, int DRES>
+// DUAL (ABI 10): the residual of this BatchNorm is the output of a SECOND BatchNorm without activation (a projection shortcut normalised
+// on load, aadg_bn_forward_res_affine_f32): its gradient is this layer's masked gradient g, so its backward sums -- sum g (the same) and
+// sum g * xhat2 -- are taken in the same pass over g: one more read (x2) instead of a reduction pass of its own (two reads).
+template <typename T> struct BnRed2 { const T* x2; const float* mean2; const float* invstd2; float* partial2; };
+template <typename T, int VEC, int MK, int NE, int DRES, bool DUAL = false>
 __global__ __launch_bounds__(256) void k_bn_reduce_bwd(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
                                                        BnExtra<T> more, const float* __restrict__ pconst, const uint8_t* __restrict__ mask,
                                                        T* __restrict__ dres, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ weight, const float* __restrict__ bias, int act_rt,
                                                        int C, int len, int per_strip, int plen, int total, float* __restrict__ partial,
-                                                       long long dy_img_stride) {
+                                                       long long dy_img_stride, BnRed2<T> d2 = BnRed2<T>()) {
     static_assert(MK == 2 || VEC > 1, "the specialised variants are vector-only");
     const int act = act_rt & 0xFF;
     const bool stream = (act_rt & BN_STREAM) != 0;
     const int c = blockIdx.y, S = gridDim.x;
     const size_t strip_elems = (size_t)len * VEC;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     const float mu = mean[c], is = invstd[c];
+    float mu2 = 0.f, is2 = 0.f;
+    if (DUAL) { mu2 = d2.mean2[c]; is2 = d2.invstd2[c]; }
     float sc = 0.f, sh = 0.f;
     if (MK >= 2) bn_scale_shift_of(weight, bias, mu, is, c, &sc, &sh);
     const bool write_g = DRES < 0 ? dres != nullptr : DRES != 0;
@@ -251,6 +257,10 @@ __global__ __launch_bounds__(256) void k_bn_reduce_bwd(const T* __restrict__ x, 
             else { Pack<T>::load_keep(x + off, xv); Pack<T>::load_keep(dyp + (size_t)j * VEC, gv); }
             uint32_t mbits = 0;
             if (MK == 1) mbits = mask[strip * len + j];
+            float x2v[VEC];
+            if (DUAL) {
+                if (VEC == 1) x2v[0] = Pack<T>::load1(d2.x2 + off); else Pack<T>::load_keep(d2.x2 + off, x2v);
+            }
             if (MK == 2 && y != nullptr) {
                 if (VEC == 1) yv[0] = Pack<T>::load1(y + off); else Pack<T>::load(y + off, yv);
             }
@@ -283,6 +293,7 @@ __global__ __launch_bounds__(256) void k_bn_reduce_bwd(const T* __restrict__ x, 
                 gv[i] = g;
                 s0 += g;
                 s1 = fmaf(g, (xv[i] - mu) * is, s1);
+                if (DUAL) s2 = fmaf(g, (x2v[i] - mu2) * is2, s2);
             }
             if (write_g) {
                 if (VEC == 1) Pack<T>::store1(dres + off, gv[0]); else Pack<T>::store(dres + off, gv, stream);
@@ -291,6 +302,11 @@ __global__ __launch_bounds__(256) void k_bn_reduce_bwd(const T* __restrict__ x, 
     }
     const float2 r = block_sum2(s0, s1);
     if (threadIdx.x == 0) reinterpret_cast<float2*>(partial)[(size_t)c * BN_MAX_SPLIT + blockIdx.x] = r;
+    if (DUAL) {
+        __syncthreads();                                          // block_sum2's scratch is read by every thread
+        const float2 r2 = block_sum2(s0, s2);
+        if (threadIdx.x == 0) reinterpret_cast<float2*>(d2.partial2)[(size_t)c * BN_MAX_SPLIT + blockIdx.x] = r2;
+    }
 }
 
 // inference: scale / shift from the running statistics
@@ -404,14 +420,18 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const
 // ACT = activation whose mask is re-derived from x exactly as the forward did (0: none, or `dy` already holds the masked
 // gradient g = dres); ACT < 0: run-time `act_rt`.  The channel's coefficients of dx = a*g + b*x + c0 are finalised here from
 // the backward reduction's partial sums; the workgroup of image 0 stores dweight / dbias.
-template <typename T, int VEC, int ACT>
+// DUAL: the second BatchNorm of k_bn_reduce_bwd<.., DUAL> -- its input gradient dx2 = a2 g + b2 x2 + c2 from the same g, in the same pass
+template <typename T> struct BnDx2 {
+    const T* x2; T* dx2; const float* partial2; const float* weight2; const float* mean2; const float* invstd2; float* dweight2; float* dbias2;
+};
+template <typename T, int VEC, int ACT, bool DUAL = false>
 __global__ __launch_bounds__(256) void k_bn_dx(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                const float* __restrict__ partial, int split, double count_host,
                                                const double* __restrict__ count_dev,
                                                const float* __restrict__ weight, const float* __restrict__ bias,
                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                float* __restrict__ dweight, float* __restrict__ dbias, int act_rt, int C, int len,
-                                               int plen, long long dy_img_stride) {
+                                               int plen, long long dy_img_stride, BnDx2<T> d2 = BnDx2<T>()) {
     const int act = ACT >= 0 ? ACT : (act_rt & 0xFF);
     const bool stream = (act_rt & BN_STREAM) != 0;
     const int strip = blockIdx.x, c = strip % C;
@@ -430,22 +450,42 @@ __global__ __launch_bounds__(256) void k_bn_dx(const T* __restrict__ x, const T*
     }
     float sc = 0.f, sh = 0.f;
     if (ACT != 0) bn_scale_shift_of(weight, bias, mu_f, is_f, c, &sc, &sh);
+    float a2 = 0.f, b2 = 0.f, c2 = 0.f;
+    if (DUAL) {
+        double sg2, sgx2;
+        bn_combine(d2.partial2, c, split, &sg2, &sgx2);
+        const double w2 = d2.weight2 != nullptr ? (double)d2.weight2[c] : 1.0;
+        const double is2 = (double)d2.invstd2[c], mu2 = (double)d2.mean2[c];
+        const double ad2 = w2 * is2, bd2 = -ad2 * is2 * sgx2 / count;
+        a2 = (float)ad2; b2 = (float)bd2; c2 = (float)(-ad2 * sg2 / count - bd2 * mu2);
+        if (strip == c && blockIdx.y == 0 && threadIdx.x == 0) {
+            if (d2.dweight2 != nullptr) d2.dweight2[c] = (float)sgx2;
+            if (d2.dbias2 != nullptr) d2.dbias2[c] = (float)sg2;
+        }
+    }
     const size_t base = (size_t)strip * len * VEC;
     const T* dyp = dy + (dy_img_stride > 0 ? (size_t)(strip / C) * (size_t)dy_img_stride + (size_t)c * len * VEC : base);
     const int j1 = min(len, ((int)blockIdx.y + 1) * plen);
 #pragma unroll 4
     for (int j = blockIdx.y * plen + threadIdx.x; j < j1; j += blockDim.x) {
         const size_t off = base + (size_t)j * VEC;
-        float xv[VEC], gv[VEC];
+        float xv[VEC], gv[VEC], x2v[VEC];
         if (VEC == 1) { xv[0] = Pack<T>::load1(x + off); gv[0] = Pack<T>::load1(dyp + j); }
         else { Pack<T>::load(x + off, xv); Pack<T>::load(dyp + (size_t)j * VEC, gv); }
+        if (DUAL) {
+            if (VEC == 1) x2v[0] = Pack<T>::load1(d2.x2 + off); else Pack<T>::load(d2.x2 + off, x2v);
+        }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float g = gv[i];
             if (act != AADG_ACT_NONE && !act_open(Pack<T>::round(fmaf(xv[i], sc, sh)), act)) g = 0.0f;
             xv[i] = fmaf(a, g, fmaf(b, xv[i], c0));
+            if (DUAL) x2v[i] = fmaf(a2, g, fmaf(b2, x2v[i], c2));
         }
         if (VEC == 1) Pack<T>::store1(dx + off, xv[0]); else Pack<T>::store(dx + off, xv, stream);
+        if (DUAL) {
+            if (VEC == 1) Pack<T>::store1(d2.dx2 + off, x2v[0]); else Pack<T>::store(d2.dx2 + off, x2v, stream);
+        }
     }
 }
 
@@ -533,7 +573,8 @@ int bn_forward(const T* x, const T* res, T* y, uint8_t* mask, const float* weigh
 template <typename T>
 int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const void* const* dy_extra, int n_extra, const float* pconst, const float* weight, const float* bias, const float* mean, const float* invstd,
                 int act, T* dx, T* dres, float* dweight, float* dbias, int N, int C, int HW, float* ws, long long dy_img_stride,
-                hipStream_t st, int phase = 0, double* sums = nullptr, const double* count_dev = nullptr) {
+                hipStream_t st, int phase = 0, double* sums = nullptr, const double* count_dev = nullptr, const BnDx2<T>* dual = nullptr,
+                float* ws2 = nullptr) {
     // phase 0: everything on this device.  Synchronised statistics: phase 1 = masked gradient (dres) + local sums -> `sums`
     // [2C] doubles and the LOCAL dweight / dbias; the caller all-reduces `sums`; phase 2 = dx from the totals and the forward's
     // all-reduced element count (`count_dev`).
@@ -551,6 +592,29 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
     }
     more.n = n_extra;
     int split = s.split;
+    if (dual != nullptr) {
+        // this layer's residual is a second BatchNorm normalised on load: both backward passes serve both layers
+        if (s.vec == 1 || mask == nullptr || dres == nullptr || act == AADG_ACT_NONE || phase != 0 || ws2 == nullptr) return AADG_E_UNSUPPORTED;
+        const BnRed2<T> r2 = {dual->x2, dual->mean2, dual->invstd2, ws2 + L.partial};
+        const dim3 rgrid(s.split, C);
+#define AADG_BN_REDUCE_DUAL(NE_)                                                                                                      \
+    hipLaunchKernelGGL((k_bn_reduce_bwd<T, Pack<T>::N, 1, NE_, 1, true>), rgrid, blk, 0, st, x, y, dy, more, pconst, mask, dres, mean,    \
+                       invstd, weight, bias, act | stream_flag, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial,          \
+                       dy_img_stride, r2)
+        if (n_extra == 0) AADG_BN_REDUCE_DUAL(0);
+        else if (n_extra == 1) AADG_BN_REDUCE_DUAL(1);
+        else AADG_BN_REDUCE_DUAL(-1);
+#undef AADG_BN_REDUCE_DUAL
+        AADG_LAUNCH_CHECK();
+        BnDx2<T> d2 = *dual;
+        d2.partial2 = ws2 + L.partial;
+        const dim3 dgrid(N * C, s.pc.per_strip);
+        hipLaunchKernelGGL((k_bn_dx<T, Pack<T>::N, AADG_ACT_NONE, true>), dgrid, blk, 0, st, x, (const T*)dres, dx,
+                           (const float*)(ws + L.partial), split, (double)N * (double)HW, count_dev, weight, bias, mean, invstd, dweight,
+                           dbias, AADG_ACT_NONE | stream_flag, C, s.len, s.pc.plen, 0LL, d2);
+        AADG_LAUNCH_CHECK();
+        return 0;
+    }
     if (phase == 2) {
         split = -1;                                             // k_bn_dx reads the float64 totals directly
         dweight = nullptr; dbias = nullptr;                     // written by phase 1 (local sums)
@@ -835,6 +899,29 @@ extern "C" int aadg_bn_backward(const void* x, const void* y, const void* act_ma
                                            (const __hip_bfloat16*)dy, dy_extra, n_extra, dy_plane_const, weight, bias, save_mean, save_invstd, act,
                                            (__hip_bfloat16*)dx, (__hip_bfloat16*)dres, dweight, dbias, N, C, HW, (float*)ws, dy_image_stride, st);
     return AADG_E_BADARG;
+}
+
+/* The backward of aadg_bn_forward_res_affine_f32 (float32): BOTH BatchNorm layers in the two passes of one -- x2 / weight2 / mean2 /
+ * invstd2 describe the projection shortcut's BatchNorm (no activation), whose output gradient is this layer's masked gradient g: its
+ * sums are taken beside this layer's (one more read of x2), its input gradient dx2 = a2 g + b2 x2 + c2 is written beside dx.  `dres`
+ * (required) receives g -- nobody else needs it.  ws2: a second workspace of aadg_bn_workspace_bytes(C).  (ABI 10) */
+extern "C" int aadg_bn_backward_res_bn_f32(const float* x, const void* act_mask, const float* dy, const void* const* dy_extra, int n_extra,
+                                           const float* dy_plane_const, const float* weight, const float* bias, const float* save_mean,
+                                           const float* save_invstd, int act, float* dx, float* dres, float* dweight, float* dbias,
+                                           const float* x2, const float* weight2, const float* save_mean2, const float* save_invstd2,
+                                           float* dx2, float* dweight2, float* dbias2, int N, int C, int HW, void* ws, size_t ws_bytes,
+                                           void* ws2, size_t ws2_bytes, long long dy_image_stride, void* stream) {
+    if (x == nullptr || act_mask == nullptr || dy == nullptr || dx == nullptr || dres == nullptr || save_mean == nullptr ||
+        save_invstd == nullptr || x2 == nullptr || save_mean2 == nullptr || save_invstd2 == nullptr || dx2 == nullptr || ws == nullptr ||
+        ws2 == nullptr || act <= 0 || act > AADG_ACT_RELU6 || dy_image_stride < 0)
+        return AADG_E_BADARG;
+    if (n_extra < 0 || n_extra > BN_MAX_EXTRA || (n_extra > 0 && dy_extra == nullptr)) return AADG_E_BADARG;
+    if ((((uintptr_t)x2 | (uintptr_t)dx2) & 15u) != 0) return AADG_E_BADARG;
+    if (C <= 0 || ws_bytes < aadg_bn_workspace_bytes(C) || ws2_bytes < aadg_bn_workspace_bytes(C)) return AADG_E_WORKSPACE;
+    const BnDx2<float> d2 = {x2, dx2, nullptr, weight2, save_mean2, save_invstd2, dweight2, dbias2};
+    return bn_backward<float>(x, nullptr, (const uint8_t*)act_mask, dy, dy_extra, n_extra, dy_plane_const, weight, bias, save_mean, save_invstd,
+                              act, dx, dres, dweight, dbias, N, C, HW, (float*)ws, dy_image_stride, (hipStream_t)stream, 0, nullptr, nullptr,
+                              &d2, (float*)ws2);
 }
 
 // ---- synchronised statistics over data-parallel ranks (the reference's single-GPU batch mixes all domains in every

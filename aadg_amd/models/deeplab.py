@@ -359,10 +359,46 @@ class Bottleneck(nn.Module):
         c3 = self._bn2_on_load(c2)
         if c3 is None:
             c3 = self.conv3(bn_act(self.bn2, c2, 'relu'))
+        if self.downsample is not None:
+            pair = self._bn3_with_shortcut(x_res, c3, handles)
+            if pair is not None:
+                return pair
         idt, raff = (x_res, None) if self.downsample is None else self._shortcut_on_load(x_res, c3)
         if raff is None:
             return bn_act(self.bn3, c3, 'relu', residual=idt, handles=handles)
         return bn_act(self.bn3, c3, 'relu', residual=idt, handles=handles, res_affine=raff)
+
+    pair_shortcut_bn = True  # f32x3 training: bn3 and the projection shortcut's BatchNorm as ONE forward pass and ONE two-pass backward
+
+    def _bn3_with_shortcut(self, x_res, c3, handles):
+        """relu(bn3(c3) + bn_s(conv_s(x))) through _lib.batch_norm_act_res_bn (the shortcut's BatchNorm has no pass of its own in either
+        direction), or None where that does not apply (then _shortcut_on_load / the materialised path)."""
+        d = self.downsample
+        if not (self.pair_shortcut_bn and self.lazy_shortcut and isinstance(d, nn.Sequential) and len(d) == 2 and type(d[1]) is BNAct and
+                d[1].act is None and isinstance(d[0], Conv1x1) and getattr(c3, '_aadg_bn_sums', None) is not None and self.training and
+                torch.is_grad_enabled() and not _BN_SYNC and d[0].f32x3 and d[0].bn_stats and c3.dtype == torch.float32 and
+                type(self.bn3) is nn.BatchNorm2d and self.bn3.affine and self.bn3.momentum is not None and self.bn3.track_running_stats):
+            return None
+        bns = d[1].bn
+        if not (type(bns) is nn.BatchNorm2d and bns.momentum is not None and bns.track_running_stats and bns.affine):
+            return None
+        from .. import _lib
+        xs = x_res.contiguous()
+        cs = d[0]
+        # (the shortcut convolution's own conditions, so that a shape it cannot take falls back BEFORE anything is computed twice)
+        probe = _lib.subsample2x2_supported(xs) if cs.stride == (2, 2) else cs.stride == (1, 1)
+        if not probe:
+            return None
+        short = cs(x_res)
+        if getattr(short, '_aadg_bn_sums', None) is None or short.shape != c3.shape or not _lib.bn_act_supported(c3.contiguous(), short.contiguous()):
+            self._short_cached = short
+            return None
+        _bump(self.bn3)
+        _bump(bns)
+        b3 = self.bn3
+        return _lib.batch_norm_act_res_bn(c3, (b3.weight, b3.bias, b3.running_mean, b3.running_var, b3.momentum, b3.eps),
+                                          short, (bns.weight, bns.bias, bns.running_mean, bns.running_var, bns.momentum, bns.eps),
+                                          _ACT_CODE['relu'], handles)
 
     lazy_shortcut = True    # f32x3 training: the projection shortcut's BatchNorm applied while bn3's kernel reads the residual
 
@@ -374,7 +410,9 @@ class Bottleneck(nn.Module):
                 isinstance(d[0], Conv1x1) and getattr(c3, '_aadg_bn_sums', None) is not None and self.training and torch.is_grad_enabled() and
                 not _BN_SYNC and d[0].f32x3 and c3.dtype == torch.float32 and type(self.bn3) is nn.BatchNorm2d):
             bns = d[1].bn
-            short = d[0](x_res)
+            short = self.__dict__.pop('_short_cached', None)
+            if short is None:
+                short = d[0](x_res)
             if (getattr(short, '_aadg_bn_sums', None) is not None and short.shape == c3.shape and type(bns) is nn.BatchNorm2d and
                     bns.momentum is not None and bns.track_running_stats and bns.affine):
                 from .. import _lib

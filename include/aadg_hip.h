@@ -452,6 +452,14 @@ int aadg_bn_forward_res_affine_f32(const float* x, const float* residual, const 
                                    void* act_mask, const float* weight, const float* bias, float* running_mean, float* running_var,
                                    float momentum, float eps, int act, int N, int C, int HW, float* save_mean, float* save_invstd, double* sums,
                                    void* ws, size_t ws_bytes, void* stream);
+/* ... and the backward of that pair in the two passes of one BatchNorm backward: the shortcut's sums are taken beside the main branch's
+ * (its output gradient IS the main branch's masked gradient), its input gradient dx2 is written beside dx.  ws2: a second workspace. */
+int aadg_bn_backward_res_bn_f32(const float* x, const void* act_mask, const float* dy, const void* const* dy_extra, int n_extra,
+                                const float* dy_plane_const, const float* weight, const float* bias, const float* save_mean,
+                                const float* save_invstd, int act, float* dx, float* dres, float* dweight, float* dbias, const float* x2,
+                                const float* weight2, const float* save_mean2, const float* save_invstd2, float* dx2, float* dweight2,
+                                float* dbias2, int N, int C, int HW, void* ws, size_t ws_bytes, void* ws2, size_t ws2_bytes,
+                                long long dy_image_stride, void* stream);
 int aadg_conv1x1_f32x3_pre_supported(int M, int K, int HW);
 int aadg_conv1x1_wgrad_f32x3_pre_supported(int N, int Co, int Ci, int HW);
 int aadg_conv1x1_nchw_f32x3_pre(const void* a_hi, const void* a_lo, const float* in, float* out, int N, int M, int K, int HW,

@@ -509,6 +509,7 @@ def test_bottleneck_projection_shortcut_normalised_on_residual_load(hip, stride)
     seen = []
     orig = hip.batch_norm_act
     hip.batch_norm_act = lambda *a, **k: (seen.append(k.get("res_affine") is not None), orig(*a, **k))[1]
+    blk.pair_shortcut_bn = False
     try:
         y_l, dx_l, gp_l, rv_l, rm_l = run(True)
     finally:
@@ -516,6 +517,21 @@ def test_bottleneck_projection_shortcut_normalised_on_residual_load(hip, stride)
     assert any(seen), "bn3 did not normalise the shortcut on load"
     y_m, dx_m, gp_m, rv_m, rm_m = run(False)
     blk.lazy_shortcut = True
+    # ... and the pair as ONE forward pass / ONE two-pass backward (aadg_bn_backward_res_bn_f32)
+    pairs = []
+    orig2 = hip.batch_norm_act_res_bn
+    hip.batch_norm_act_res_bn = lambda *a, **k: (pairs.append(1), orig2(*a, **k))[1]
+    blk.pair_shortcut_bn = True
+    try:
+        y_p, dx_p, gp_p, rv_p, rm_p = run(True)
+    finally:
+        hip.batch_norm_act_res_bn = orig2
+    assert pairs, "bn3 and the shortcut's BatchNorm did not run as a pair"
+    assert _err(y_p, y_m) <= 1e-5 and _err(rv_p, rv_m) <= 1e-6 and (rm_p - rm_m).abs().max().item() <= 1e-6
+    rel0 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()     # noqa: E731
+    assert rel0(dx_p, dx_m) <= 1e-3
+    for n in gp_m:
+        assert rel0(gp_p[n], gp_m[n]) <= 1e-3, n
     assert _err(y_l, y_m) <= 1e-5 and _err(rv_l, rv_m) <= 1e-6 and (rm_l - rm_m).abs().max().item() <= 1e-6
     rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()      # noqa: E731
     assert rel(dx_l, dx_m) <= 1e-3
