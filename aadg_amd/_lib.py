@@ -1303,6 +1303,9 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
 
 
 # ------------------------------------------------------------------------------------------------
+_POOL_BWD_FUSED_F32 = True      # (scripts/ab/pool_bwd_ab.sh switches it off for the comparison)
+
+
 class _BNReluMaxPool(torch.autograd.Function):
     """max_pool2d(relu(batch_norm(x)), 3, 2, 1), training mode, in one pass over x (csrc/batchnorm.hip k_bn_relu_maxpool): the
     normalised map is never materialised.  Backward (bfloat16): two passes over x that rebuild the pooling gradient from
@@ -1330,15 +1333,16 @@ class _BNReluMaxPool(torch.autograd.Function):
         x, idx, weight, bias, mean, invstd = ctx.saved_tensors
         N, C, H, W = x.shape
         dyp = dyp.contiguous()
-        if x.dtype == torch.bfloat16:
+        if x.dtype == torch.bfloat16 or (_POOL_BWD_FUSED_F32 and W % 8 == 0 and dyp.data_ptr() % 8 == 0):
             # both BatchNorm backward passes rebuild the pooling gradient from (index, dyp): nothing activation-sized in between
+            # (float32 since round 5: 4-column vectors)
             dx = torch.empty_like(x)
             dw = torch.empty(C, dtype=torch.float32, device=x.device)
             db = torch.empty(C, dtype=torch.float32, device=x.device)
             ws = _bn_ws(C, x.device)
             _check(lib.aadg_bn_relu_maxpool_backward(x.data_ptr(), idx.data_ptr(), dyp.data_ptr(), _ptr(weight), _ptr(bias), mean.data_ptr(),
-                                                     invstd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), N, C, H, W, 1,
-                                                     ws.data_ptr(), ws.numel(), _stream()), "aadg_bn_relu_maxpool_backward")
+                                                     invstd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), N, C, H, W,
+                                                     _BN_DTYPES[x.dtype], ws.data_ptr(), ws.numel(), _stream()), "aadg_bn_relu_maxpool_backward")
             return dx, dw if weight is not None else None, db if bias is not None else None, None, None, None, None
         dy = torch.empty_like(x)
         _check(lib.aadg_maxpool3x3s2_backward(idx.data_ptr(), dyp.data_ptr(), dy.data_ptr(), N * C, H, W, _BN_DTYPES[x.dtype], _stream()),

@@ -764,13 +764,48 @@ __device__ __forceinline__ void pool_gather8(const uint8_t* __restrict__ idx, co
     for (int k = 0; k < 8; ++k) acc[k] = Pack<__hip_bfloat16>::round(acc[k]);
 }
 
+// float32 (round 5): one vector = 4 columns 4 cg .. 4 cg + 3 of row r = the centre / right columns of the windows of outputs 2 cg and
+// 2 cg + 1 and the left column of output 2 cg + 2's
+__device__ __forceinline__ void pool_gather_vec(const uint8_t* __restrict__ idx, const float* __restrict__ dyp, int r, int cg, int Ho, int Wo,
+                                                float* acc) {
+    const int j0 = 2 * cg;
+    const bool has3 = j0 + 2 < Wo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int sft = 0; sft < 2; ++sft) {
+        const int i = (r + sft) >> 1;
+        const int a = r - 2 * i + 1;                         // window row of input row r in output row i
+        if ((sft == 1 && !(r & 1)) || i >= Ho) continue;
+        const size_t o = (size_t)i * Wo + j0;
+        const uint32_t w = *reinterpret_cast<const uint16_t*>(idx + o);
+        const float2 t = *reinterpret_cast<const float2*>(dyp + o);
+        float gq[3] = {t.x, t.y, 0.0f};
+        uint32_t p[3] = {w & 255u, w >> 8, 255u};
+        if (has3) { p[2] = idx[o + 2]; gq[2] = dyp[o + 2]; }
+        const uint32_t base = 3u * (uint32_t)a;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = k >> 1;
+            if (p[j] == base + 1u + (uint32_t)(k & 1)) acc[k] += gq[j];
+            if ((k & 1) && p[j + 1] == base) acc[k] += gq[j + 1];
+        }
+    }
+}
+__device__ __forceinline__ void pool_gather_vec(const uint8_t* __restrict__ idx, const __hip_bfloat16* __restrict__ dyp, int r, int cg, int Ho,
+                                                int Wo, float* acc) {
+    pool_gather8(idx, dyp, r, cg, Ho, Wo, acc);
+}
+
 // grid (split, C), as k_bn_reduce_bwd with MK = 3 (ReLU mask recomputed from x)
-__global__ __launch_bounds__(256) void k_bn_pool_reduce_bwd(const __hip_bfloat16* __restrict__ x, const uint8_t* __restrict__ idx,
-                                                            const __hip_bfloat16* __restrict__ dyp, const float* __restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_pool_reduce_bwd(const T* __restrict__ x, const uint8_t* __restrict__ idx,
+                                                            const T* __restrict__ dyp, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ weight,
                                                             const float* __restrict__ bias, int C, int H, int W, int Ho, int Wo, int len,
                                                             int per_strip, int plen, int total, float* __restrict__ partial) {
-    const int c = blockIdx.y, S = gridDim.x, w8 = W / 8;
+    constexpr int V = Pack<T>::N;
+    const int c = blockIdx.y, S = gridDim.x, w8 = W / V;
     float s0 = 0.f, s1 = 0.f;
     const float mu = mean[c], is = invstd[c];
     float sc, sh;
@@ -778,19 +813,19 @@ __global__ __launch_bounds__(256) void k_bn_pool_reduce_bwd(const __hip_bfloat16
     for (int p = blockIdx.x; p < total; p += S) {
         const int n = p / per_strip, part = p - n * per_strip;
         const size_t strip = (size_t)n * C + c;
-        const __hip_bfloat16* px = x + strip * (size_t)len * 8;
+        const T* px = x + strip * (size_t)len * V;
         const uint8_t* pi = idx + strip * (size_t)Ho * Wo;
-        const __hip_bfloat16* pg = dyp + strip * (size_t)Ho * Wo;
+        const T* pg = dyp + strip * (size_t)Ho * Wo;
         const int j1 = min(len, (part + 1) * plen);
 #pragma unroll 2
         for (int j = part * plen + threadIdx.x; j < j1; j += blockDim.x) {
-            float xv[8], gv[8];
-            Pack<__hip_bfloat16>::load(px + (size_t)j * 8, xv);
+            float xv[V], gv[V];
+            Pack<T>::load(px + (size_t)j * V, xv);
             const int r = j / w8, cg = j - r * w8;
-            pool_gather8(pi, pg, r, cg, Ho, Wo, gv);
+            pool_gather_vec(pi, pg, r, cg, Ho, Wo, gv);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool open = Pack<__hip_bfloat16>::round(fmaf(xv[i], sc, sh)) > 0.0f;
+            for (int i = 0; i < V; ++i) {
+                const bool open = Pack<T>::round(fmaf(xv[i], sc, sh)) > 0.0f;
                 const float g = open ? gv[i] : 0.0f;
                 s0 += g;
                 s1 = fmaf(g, (xv[i] - mu) * is, s1);
@@ -802,15 +837,17 @@ __global__ __launch_bounds__(256) void k_bn_pool_reduce_bwd(const __hip_bfloat16
 }
 
 // grid (N * C strips, pieces), as k_bn_dx with ACT = ReLU
-__global__ __launch_bounds__(256) void k_bn_pool_dx(const __hip_bfloat16* __restrict__ x, const uint8_t* __restrict__ idx,
-                                                    const __hip_bfloat16* __restrict__ dyp, __hip_bfloat16* __restrict__ dx,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_pool_dx(const T* __restrict__ x, const uint8_t* __restrict__ idx,
+                                                    const T* __restrict__ dyp, T* __restrict__ dx,
                                                     const float* __restrict__ partial, int split, double count,
                                                     const float* __restrict__ weight, const float* __restrict__ bias,
                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                                     float* __restrict__ dweight, float* __restrict__ dbias, int C, int H, int W, int Ho,
                                                     int Wo, int len, int plen, int stream_out) {
+    constexpr int V = Pack<T>::N;
     const bool stream = stream_out != 0;
-    const int strip = blockIdx.x, c = strip % C, w8 = W / 8;
+    const int strip = blockIdx.x, c = strip % C, w8 = W / V;
     double sg, sgx;
     bn_combine(partial, c, split, &sg, &sgx);
     const float mu_f = mean[c], is_f = invstd[c];
@@ -825,23 +862,23 @@ __global__ __launch_bounds__(256) void k_bn_pool_dx(const __hip_bfloat16* __rest
     }
     float sc, sh;
     bn_scale_shift_of(weight, bias, mu_f, is_f, c, &sc, &sh);
-    const __hip_bfloat16* px = x + (size_t)strip * len * 8;
-    __hip_bfloat16* pdx = dx + (size_t)strip * len * 8;
+    const T* px = x + (size_t)strip * len * V;
+    T* pdx = dx + (size_t)strip * len * V;
     const uint8_t* pi = idx + (size_t)strip * Ho * Wo;
-    const __hip_bfloat16* pg = dyp + (size_t)strip * Ho * Wo;
+    const T* pg = dyp + (size_t)strip * Ho * Wo;
     const int j1 = min(len, ((int)blockIdx.y + 1) * plen);
 #pragma unroll 2
     for (int j = blockIdx.y * plen + threadIdx.x; j < j1; j += blockDim.x) {
-        float xv[8], gv[8];
-        Pack<__hip_bfloat16>::load(px + (size_t)j * 8, xv);
+        float xv[V], gv[V];
+        Pack<T>::load(px + (size_t)j * V, xv);
         const int r = j / w8, cg = j - r * w8;
-        pool_gather8(pi, pg, r, cg, Ho, Wo, gv);
+        pool_gather_vec(pi, pg, r, cg, Ho, Wo, gv);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float g = Pack<__hip_bfloat16>::round(fmaf(xv[i], sc, sh)) > 0.0f ? gv[i] : 0.0f;
+        for (int i = 0; i < V; ++i) {
+            const float g = Pack<T>::round(fmaf(xv[i], sc, sh)) > 0.0f ? gv[i] : 0.0f;
             xv[i] = fmaf(a, g, fmaf(b, xv[i], c0));
         }
-        Pack<__hip_bfloat16>::store(pdx + (size_t)j * 8, xv, stream);
+        Pack<T>::store(pdx + (size_t)j * V, xv, stream);
     }
 }
 
@@ -1083,6 +1120,26 @@ extern "C" int aadg_bn_relu_maxpool_forward(const void* x, void* y, void* index,
 
 /* Backward of aadg_bn_relu_maxpool_forward (bfloat16 only): dx [N, C, H, W], dweight, dbias from x, the pooling index and the
  * pooled gradient dy [N, C, Ho, Wo] -- the gradient of the normalised map is rebuilt on the fly in both passes, never stored. */
+namespace {
+template <typename T>
+int bn_pool_backward(const T* px, const uint8_t* index, const T* pg, const float* weight, const float* bias, const float* save_mean,
+                     const float* save_invstd, T* dx, float* dweight, float* dbias, int N, int C, int H, int W, float* wsf, hipStream_t st) {
+    const BnWs L = bn_ws(C);
+    const int Ho = (H - 1) / 2 + 1, Wo = W / 2, HW = H * W;
+    Shape s;
+    if (!make_shape<T>(N, C, HW, px, dx, nullptr, nullptr, &s) || s.vec == 1) return AADG_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_bn_pool_reduce_bwd<T>, dim3(s.split, C), dim3(s.threads), 0, st, px, index, pg, save_mean, save_invstd,
+                       weight, bias, C, H, W, Ho, Wo, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, wsf + L.partial);
+    AADG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_pool_dx<T>, dim3(N * C, s.pc.per_strip), dim3(s.threads), 0, st, px, index, pg, dx,
+                       (const float*)(wsf + L.partial), s.split, (double)N * (double)HW, weight, bias, save_mean, save_invstd, dweight,
+                       dbias, C, H, W, Ho, Wo, s.len, s.pc.plen, bn_stream((size_t)N * C * H * W * sizeof(T)) ? 1 : 0);
+    AADG_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace
+
+/* dtype 1 (bfloat16) and, since ABI 10, 0 (float32: W a multiple of 4, dy 8-byte aligned, index 2-byte aligned) */
 extern "C" int aadg_bn_relu_maxpool_backward(const void* x, const void* index, const void* dy, const float* weight, const float* bias,
                                              const float* save_mean, const float* save_invstd, void* dx, float* dweight, float* dbias,
                                              int N, int C, int H, int W, int dtype, void* ws, size_t ws_bytes, void* stream) {
@@ -1090,21 +1147,13 @@ extern "C" int aadg_bn_relu_maxpool_backward(const void* x, const void* index, c
         return AADG_E_BADARG;
     if ((((uintptr_t)x | (uintptr_t)dx) & 15u) != 0 || (((uintptr_t)index) & 3u) != 0 || (((uintptr_t)dy) & 7u) != 0) return AADG_E_BADARG;
     if (N <= 0 || C <= 0 || ws_bytes < aadg_bn_workspace_bytes(C)) return AADG_E_WORKSPACE;
-    if (dtype != 1 || !aadg_bn_relu_maxpool_supported(H, W, dtype)) return AADG_E_UNSUPPORTED;
+    if ((dtype != 0 && dtype != 1) || !aadg_bn_relu_maxpool_supported(H, W, dtype)) return AADG_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    float* wsf = (float*)ws;
-    const BnWs L = bn_ws(C);
-    const int Ho = (H - 1) / 2 + 1, Wo = W / 2, HW = H * W;
-    Shape s;
-    if (!make_shape<__hip_bfloat16>(N, C, HW, x, dx, nullptr, nullptr, &s) || s.vec == 1) return AADG_E_UNSUPPORTED;
-    const __hip_bfloat16* px = (const __hip_bfloat16*)x;
-    const __hip_bfloat16* pg = (const __hip_bfloat16*)dy;
-    hipLaunchKernelGGL(k_bn_pool_reduce_bwd, dim3(s.split, C), dim3(s.threads), 0, st, px, (const uint8_t*)index, pg, save_mean, save_invstd,
-                       weight, bias, C, H, W, Ho, Wo, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, wsf + L.partial);
-    AADG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bn_pool_dx, dim3(N * C, s.pc.per_strip), dim3(s.threads), 0, st, px, (const uint8_t*)index, pg, (__hip_bfloat16*)dx,
-                       (const float*)(wsf + L.partial), s.split, (double)N * (double)HW, weight, bias, save_mean, save_invstd, dweight,
-                       dbias, C, H, W, Ho, Wo, s.len, s.pc.plen, bn_stream((size_t)N * C * H * W * 2) ? 1 : 0);
-    AADG_LAUNCH_CHECK();
-    return 0;
+    if (dtype == 0) {
+        if ((W % 4) != 0 || ((W / 2) % 2) != 0) return AADG_E_UNSUPPORTED;        // 4-column vectors, 2-byte / 8-byte aligned output pairs
+        return bn_pool_backward<float>((const float*)x, (const uint8_t*)index, (const float*)dy, weight, bias, save_mean, save_invstd, (float*)dx,
+                                       dweight, dbias, N, C, H, W, (float*)ws, st);
+    }
+    return bn_pool_backward<__hip_bfloat16>((const __hip_bfloat16*)x, (const uint8_t*)index, (const __hip_bfloat16*)dy, weight, bias, save_mean,
+                                            save_invstd, (__hip_bfloat16*)dx, dweight, dbias, N, C, H, W, (float*)ws, st);
 }
