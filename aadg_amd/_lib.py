@@ -1644,13 +1644,14 @@ def _own_gemm_1x1(M, K, HW, N=None):
 # chain's BatchNorm passes (HBM bound, no LDS) instead of standing in line with them, and hand the result over at the END of the
 # backward pass: a callback queued on the autograd engine makes the launch stream wait for the side stream and puts the gradients
 # into `.grad` (what AccumulateGrad would have done).  The gradients therefore bypass autograd's accumulation hooks: NOT for modules
-# wrapped in DistributedDataParallel (its reducer listens to those hooks) and not for torch.autograd.grad(); off by default.
+# wrapped in torch's DistributedDataParallel (its reducer listens to those hooks) and not for torch.autograd.grad(); the package's own
+# data-parallel wrapper (aadg_amd/reducer.py) takes them over on the side stream instead.  Off by default.
 _WG = {"on": False, "stream": None, "pending": []}
 
 
 def set_wgrad_stream(flag):
     """Weight-gradient kernels of the own convolutions on a side stream, gradients written to `.grad` at the end of the backward pass
-    (single-process training without DDP only).  Returns the previous setting."""
+    (not under torch's DistributedDataParallel; aadg_amd.reducer.GradReducer is built for it).  Returns the previous setting."""
     old = _WG["on"]
     _WG["on"] = bool(flag)
     return old
@@ -1665,9 +1666,12 @@ def _flush_wgrads():
     pending, _WG["pending"] = _WG["pending"], []
     if not pending:
         return
+    task = torch._C._current_graph_task_id()
     main = torch.cuda.current_stream()
     main.wait_stream(side)
-    for weight, dw in pending:
+    for stamp, weight, dw in pending:
+        if stamp != task:
+            continue            # left behind by a backward pass that raised before its callbacks ran: not this pass's gradient
         dw.record_stream(main)
         if dw.shape != weight.shape or dw.stride() != weight.stride():
             dw = dw.reshape(weight.shape).contiguous()           # the layout AccumulateGrad would have given it
@@ -1680,20 +1684,26 @@ def _flush_wgrads():
 def _wgrad_beside(weight, fn, *reads):
     """dw = fn() for the parameter `weight`, reading the tensors `reads` (produced on the current stream).  Side stream off (or `weight`
     is no leaf that accumulates into .grad): runs fn() here and returns dw.  On: launches fn() on the side stream and returns None --
-    the gradient reaches weight.grad in _flush_wgrads() when the backward pass ends."""
+    the gradient reaches weight.grad in _flush_wgrads() when the backward pass ends, or, for a parameter of a data-parallel replica
+    (aadg_amd/reducer.py: `weight._aadg_grad_sink`), goes into its gradient bucket ON the side stream, from where the bucket's
+    all-reduce is issued as soon as its last member is in."""
     if not (_WG["on"] and weight.is_leaf and weight.requires_grad and weight.is_cuda):
         return fn()
     if _WG["stream"] is None:
         _WG["stream"] = torch.cuda.Stream(device=weight.device)
     side = _WG["stream"]
+    sink = getattr(weight, "_aadg_grad_sink", None)
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         dw = fn()
+        if sink is not None:
+            sink.deliver(weight, dw)
     for t in reads:
         t.record_stream(side)                 # the caching allocator must not hand these out again before the side stream has read them
-    _WG["pending"].append((weight, dw))
-    # one callback per deferred gradient (the first to run delivers everything pending, the others find nothing): no state that a
-    # backward pass cut short by an exception could leave behind
+    if sink is not None:
+        return None
+    _WG["pending"].append((torch._C._current_graph_task_id(), weight, dw))
+    # one callback per deferred gradient (the first to run delivers everything pending, the others find nothing)
     torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
     return None
 
@@ -2189,7 +2199,9 @@ class _Conv1x1X3(torch.autograd.Function):
             at = wt.view(2, Ci, Co) if wt is not None else split_weight(weight.detach().reshape(Co, Ci).t().contiguous())
             dx = conv1x1_nchw_x3(at, dy)
         if ctx.needs_input_grad[1]:
-            dw = _wgrad_beside(ctx.wparam, lambda: conv1x1_wgrad_x3(dy, x, pre).view(weight.shape), dy, x)
+            # pre_scale / pre_shift are read by the side-stream kernel too: without record_stream the allocator hands their
+            # [K] blocks to the next BatchNorm backward's dw / db while the weight-gradient kernel may still be reading them
+            dw = _wgrad_beside(ctx.wparam, lambda: conv1x1_wgrad_x3(dy, x, pre).view(weight.shape), dy, x, *(pre or ()))
         return dx, dw, None, None, None
 
 
@@ -2423,7 +2435,7 @@ class _Conv3x3X3(torch.autograd.Function):
                 a9t = split_weight(weight.detach().flip(2, 3).permute(2, 3, 1, 0).reshape(9, Ci, Co).contiguous())
             dx = conv3x3_nchw_x3(a9t, dy, d)
         if ctx.needs_input_grad[1]:
-            dw = _wgrad_beside(ctx.wparam, lambda: conv3x3_wgrad_x3(dy, x, d, pre), dy, x)
+            dw = _wgrad_beside(ctx.wparam, lambda: conv3x3_wgrad_x3(dy, x, d, pre), dy, x, *(pre or ()))
         return dx, dw, None, None, None, None
 
 

@@ -24,8 +24,9 @@ Exchange pattern of one inner iteration on G GPUs:
      gathered rows back into collate order, then every rank runs the Sinkhorn kernel redundantly on the full
      [N, 128] matrix, so rewards (and hence the replicated controller) stay bit-identical on all ranks
      without a second collective,
-  3. gradient all-reduce of the segmentation model / discriminator (DDP buckets, overlapped with backward).
-     DDP averages over ranks; with n_r rows on rank r the local loss is the local mean times n_r*G/N
+  3. gradient all-reduce of the segmentation model / discriminator: flat 32 MiB buckets of aadg_amd/reducer.py, each issued
+     asynchronously from the stream its last member arrived on (the weight-gradient side stream for the convolution weights), on a
+     communicator of its own, overlapped with backward.  The reducer averages over ranks; with n_r rows on rank r the local loss is the local mean times n_r*G/N
      (`RowPlan.loss_weight`), so the averaged gradient is the gradient of the mean over all N rows whatever
      the split (count-weighted mean),
   4. with --sync_bn the per-channel BatchNorm sums are all-reduced between the statistics and the
@@ -93,10 +94,31 @@ def side_group():
     return _SIDE["group"]
 
 
+_GRAD = {"group": None, "made": False}
+
+
+def grad_group():
+    """Process group of the gradient buckets (aadg_amd/reducer.py): a third communicator, so a 32 MiB bucket in flight never stands in
+    front of a BatchNorm statistics all-reduce (small_group, main stream) or the embedding all-gather (side_group, controller stream).
+    The buckets are issued from the weight-gradient stream / the backward chain's stream and wait for nothing but their members."""
+    if not is_dist() or not USE_SMALL_GROUP:
+        return None
+    if not _GRAD["made"]:
+        _GRAD["made"] = True
+        try:
+            _GRAD["group"] = dist.new_group(ranks=list(range(dist.get_world_size())), backend=dist.get_backend())
+        except Exception as e:  # noqa: BLE001
+            import sys
+            print("aadg_amd.distributed: new_group failed (%r); gradient buckets stay on the default group" % (e,), file=sys.stderr)
+            _GRAD["group"] = None
+    return _GRAD["group"]
+
+
 def reset_groups():
     """forget the cached groups (after destroy_process_group; tests that re-initialise the process group in one interpreter)"""
     _SMALL["group"], _SMALL["made"] = None, False
     _SIDE["group"], _SIDE["made"] = None, False
+    _GRAD["group"], _GRAD["made"] = None, False
 
 
 class _CollectiveTimer(object):
@@ -186,6 +208,7 @@ def describe():
         info["small_collectives_group"] = "own process group (own RCCL communicator + stream)" if g is not None else "default group"
         info["side_stream_collectives_group"] = ("own process group (embedding all-gather, policy broadcasts: issued from the controller's "
                                                  "stream)" if side_group() is not None else "default group")
+        info["gradient_buckets_group"] = "own process group (aadg_amd.reducer.GradReducer)" if grad_group() is not None else "default group"
     return info
 
 
@@ -291,6 +314,8 @@ class RowPlan(object):
             pad = local.new_zeros((self.max_count - self.n_local,) + tuple(local.shape[1:]))
             local = torch.cat([local, pad], dim=0)
         if emulate:
+            if is_dist():
+                all_gather([local], group=side_group())          # the call a rank of the real job makes (bench.py --shard_of G --force_dist)
             flat = local.repeat((self.world,) + (1,) * (local.dim() - 1))
             if self.n_local < self.max_count:        # never read a padding row: fold the index into the valid range
                 r, o = take // self.max_count, take % self.max_count

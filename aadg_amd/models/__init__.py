@@ -6,8 +6,9 @@ Differences that are design, not omission:
     `MODEL.BACKBONE: resnet50` is accepted in addition to `mobilenet_v2`, `MODEL.NAME: unet` for config 0,
     `MODEL.NAME: segformer` / `MODEL.BACKBONE: mit_b2` (models/segformer.py) for config 4;
   * data parallelism is NOT "split TRAIN.BATCH_SIZE across DDP replicas" but row sharding of the N =
-    D*B*M augmented images (aadg_amd/distributed.py); the model is still wrapped in DDP (RCCL bucketed
-    all-reduce overlapped with backward), the controller is replicated deterministically (identical
+    D*B*M augmented images (aadg_amd/distributed.py); the model is wrapped in the package's own gradient reducer
+    (aadg_amd/reducer.py: bucketed asynchronous RCCL all-reduce overlapped with backward, issued from the weight-gradient
+    stream), the controller is replicated deterministically (identical
     rewards on every rank), so it needs no collective at all.
 """
 import torch
@@ -44,9 +45,10 @@ def _device(args):
 
 def _wrap(module, args, dev, broadcast_buffers=True):
     if getattr(args, 'distributed', False) and any(p.requires_grad for p in module.parameters()):
-        ids = [dev.index] if dev.type == 'cuda' else None
-        return torch.nn.parallel.DistributedDataParallel(module, device_ids=ids, gradient_as_bucket_view=True,
-                                                         broadcast_buffers=broadcast_buffers)
+        # the package's own data-parallel wrapper (reducer.py) instead of torch's DistributedDataParallel: flat gradient buckets,
+        # all-reduced asynchronously from the stream their members arrive on -- the weight-gradient side stream stays on
+        from ..reducer import GradReducer
+        return GradReducer(module, broadcast_buffers=broadcast_buffers)
     return module
 
 
@@ -73,7 +75,7 @@ def load_ddp_model(ngpus_per_node, args, cfg):
         from . import deeplab
         # weight casts and BatchNorm counters: two launches per forward; backbone_dtype 'f32x3' = float32 tensors, convolutions on the
         # own float32-precision matrix-core kernels ('fp32': the library's float32 convolutions, 'bf16': bfloat16 autocast)
-        deeplab.batch_step_bookkeeping(model, f32x3=getattr(args, 'backbone_dtype', 'fp32') == 'f32x3')
+        deeplab.batch_step_bookkeeping(model, f32x3=getattr(args, 'backbone_dtype', 'f32x3') == 'f32x3')
     sync = bool(getattr(args, 'distributed', False) and getattr(args, 'sync_bn', False))
     if sync:
         # The reference's single-GPU batch mixes all domains in every BatchNorm batch; sharded replicas see only their rows.
@@ -88,10 +90,10 @@ def load_ddp_model(ngpus_per_node, args, cfg):
     # with synchronised statistics the running buffers are identical on every rank: no per-forward buffer broadcast
     model = _wrap(model, args, dev, broadcast_buffers=not sync)
     if dev.type == 'cuda':
-        # weight-gradient kernels of the own convolutions on a second stream, beside the backward chain (_lib.set_wgrad_stream): only
-        # without DistributedDataParallel, whose reducer listens to autograd's accumulation hooks
+        # weight-gradient kernels of the own convolutions on a second stream, beside the backward chain (_lib.set_wgrad_stream); in a
+        # data-parallel job the GradReducer takes them over there and issues the bucket all-reduces from that stream
         from .. import _lib
-        _lib.set_wgrad_stream(bool(getattr(args, 'wgrad_stream', True)) and not isinstance(model, torch.nn.parallel.DistributedDataParallel))
+        _lib.set_wgrad_stream(bool(getattr(args, 'wgrad_stream', True)))
     return model, cfg.TRAIN.BATCH_SIZE, args.workers
 
 
@@ -115,12 +117,12 @@ def load_ddp_discriminator(ngpus_per_node, args, cfg):
     elif name == 'momentum_feature':
         model = MomentumFeatureDiscriminator(num_classes, in_channels)
         # the EMA twin is only ever written by momentum_update()/synchronize_parameters(); marking it
-        # non-trainable keeps DDP from waiting for gradients that never come
+        # non-trainable keeps the reducer from carrying (and all-reducing) gradients that never come
         for p in list(model.mom_dis.parameters()) + list(model.mom_fc.parameters()):
             p.requires_grad_(False)
     else:
         raise NotImplementedError(name + ' has not been implemented!')
-    # DDP as in the reference (models/__init__.py:165): the online branch's gradients are averaged over the ranks, so the
+    # data-parallel as in the reference (models/__init__.py:165 wraps it in DDP): the online branch's gradients are averaged over the ranks, so the
     # online and (through momentum_update) the EMA weights stay identical everywhere -- the all-gathered embeddings come
     # from ONE network.  The search loop reaches the EMA branch / momentum_update through `.module` (search_dg._bare).
     return _wrap(model.to(dev), args, dev), cfg.TRAIN.BATCH_SIZE, args.workers

@@ -41,6 +41,21 @@ def _bump(bn):
         bn.num_batches_tracked.add_(1)
 
 
+F32X3_PATHS = {}         # layer name -> "own" | "library: <reason>" (f32x3 mode; filled by the first forward passes, `f32x3_coverage`)
+
+
+def _took(mod, path, x=None):
+    name = getattr(mod, '_aadg_name', None)
+    if name is not None and name not in F32X3_PATHS:
+        F32X3_PATHS[name] = path if x is None else "%s (input %s, weight %s)" % (path, tuple(x.shape), tuple(mod.weight.shape))
+
+
+def f32x3_coverage():
+    """(layers on the own float32-precision kernels, {layer: reason} of those that fell back to the library's float32 convolution)"""
+    own = sorted(k for k, v in F32X3_PATHS.items() if v == "own")
+    return own, {k: v for k, v in F32X3_PATHS.items() if v != "own"}
+
+
 def batch_step_bookkeeping(model, f32x3=False):
     """Per-forward bookkeeping of a CUDA model in two launches instead of ~130: the bfloat16 casts of the own convolutions' master
     weights (a pre-hook: _lib.track_bf16_weights) and the BatchNorm counters of its layers (a post-hook).
@@ -53,6 +68,14 @@ def batch_step_bookkeeping(model, f32x3=False):
             m.f32x3 = bool(f32x3)
     if f32x3:
         mark_bn_producers(model)
+        F32X3_PATHS.clear()
+        for name, m in model.named_modules():
+            if isinstance(m, (Conv1x1, Conv3x3, StemConv7x7)):
+                m._aadg_name = name
+        if not any(isinstance(m, (Conv1x1, Conv3x3, StemConv7x7)) for m in model.modules()):
+            import sys
+            print("aadg_amd: --backbone_dtype f32x3: %s has no layer the own float32-precision convolution kernels cover; it runs on the "
+                  "library's float32 kernels (= --backbone_dtype fp32)" % type(model).__name__, file=sys.stderr)
     _lib.track_bf16_weights(model, (Conv1x1, Conv3x3), split=bool(f32x3))
     for m in model.modules():
         if type(m) is nn.BatchNorm2d:
@@ -61,10 +84,19 @@ def batch_step_bookkeeping(model, f32x3=False):
     def before(mod, args):
         del _PENDING_BN_COUNTERS[:]
 
+    reported = []
+
     def after(mod, args, out):
         if _PENDING_BN_COUNTERS:
             torch._foreach_add_(_PENDING_BN_COUNTERS, 1)
             del _PENDING_BN_COUNTERS[:]
+        if f32x3 and not reported and mod.training and F32X3_PATHS:
+            # once, after the first training forward: say which convolutions did NOT take the own kernels, and why (run.py's default)
+            reported.append(True)
+            own, lib = f32x3_coverage()
+            import sys
+            print("aadg_amd: f32x3: %d convolution layers on the own float32-precision matrix-core kernels, %d on the library's float32 "
+                  "convolution%s" % (len(own), len(lib), "".join("\n  %s: %s" % kv for kv in sorted(lib.items()))), file=sys.stderr)
 
     model.register_forward_pre_hook(before)
     model.register_forward_hook(after)
@@ -185,10 +217,14 @@ class Conv1x1(nn.Conv2d):
             if self.stride == (2, 2) and _lib.subsample2x2_supported(xc):
                 xs = _lib.subsample2x2(xc)                   # pick the even pixels (one streaming pass), then the stride-1 kernel
                 if _lib.conv1x1_x3_supported(xs, self.weight):
+                    _took(self, "own")
                     return _lib.conv1x1_x3(xs, self.weight, stats)
+                _took(self, "library: shape outside the 1x1 kernel's tiles", xs)
                 return F.conv2d(xs, self.weight)
             if self.stride == (1, 1) and _lib.conv1x1_x3_supported(xc, self.weight):
+                _took(self, "own")
                 return _lib.conv1x1_x3(xc, self.weight, stats)
+            _took(self, "library: shape outside the 1x1 kernel's tiles (pixels % 32, channels % 8)", x)
             return super().forward(x)
         if x.is_cuda and x.dtype == torch.bfloat16 and self.stride in ((1, 1), (2, 2)):
             from .. import _lib
@@ -227,12 +263,15 @@ class Conv3x3(nn.Conv2d):
                 if _lib.conv3x3_x3_supported(xc, self.weight, self.dilation[0]):
                     stats = (self.bn_stats and self.training and torch.is_grad_enabled() and
                              _lib.conv3x3_x3_stats_supported(xc, self.weight, self.dilation[0]))
+                    _took(self, "own")
                     return _lib.conv3x3_x3(xc, self.weight, self.dilation[0], stats)
             elif self.stride == (2, 2) and self.dilation == (1, 1) and self.padding == (1, 1):
                 from .. import _lib
                 xc = x.contiguous()
                 if _lib.conv3x3s2_x3_supported(xc, self.weight):
+                    _took(self, "own")
                     return _lib.conv3x3s2_x3(xc, self.weight)
+            _took(self, "library: shape outside the 3x3 kernels' tiles", x)
             return super().forward(x)
         if x.is_cuda and x.dtype == torch.bfloat16 and self.stride == (1, 1):
             from .. import _lib
@@ -262,7 +301,9 @@ class StemConv7x7(nn.Conv2d):
             from .. import _lib
             xc = x.contiguous()
             if _lib.stem_conv7x7_supported(xc, self.weight):
+                _took(self, "own")
                 return _lib.stem_conv7x7_x3(xc, self.weight)
+            _took(self, "library: shape outside the stem kernel's tiles", x)
             return super().forward(x)
         lowp = x.dtype == torch.bfloat16 or (x.is_cuda and torch.is_autocast_enabled('cuda') and
                                              torch.get_autocast_dtype('cuda') == torch.bfloat16)

@@ -30,7 +30,7 @@ from .scheduler import get_dis_optimizer_scheduler, get_optimizer_scheduler
 
 
 def _autocast(args):
-    dt = getattr(args, 'backbone_dtype', 'fp32')
+    dt = getattr(args, 'backbone_dtype', 'f32x3')
     if dt == 'bf16' and torch.cuda.is_available():
         return torch.autocast('cuda', dtype=torch.bfloat16)
     return torch.autocast('cuda', enabled=False) if torch.cuda.is_available() else torch.autocast('cpu', enabled=False)

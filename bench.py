@@ -632,8 +632,10 @@ def scale_leg(a):
     collectives -- BatchNorm statistics all-reduces (float64 [2C + 1], one per layer and direction, each between two dependent kernels),
     the embedding all-gather, the policy broadcasts; (3) `predicted_ms_per_step` = (1) + calls x per-call latency for three latencies:
     the one measured here at world size 1 (a floor: no peer to wait for) and 15 / 30 us (typical small-message RCCL latencies on 8
-    ranks over xGMI).  The DDP gradient all-reduce (4 bytes x parameters per step, bucketed, overlapped with the backward pass) is not in
-    the model.  Child processes: the parent has released its GPU memory."""
+    ranks over xGMI).  Round 6: (1) is taken WITH the distributed path on (`--shard_of G --force_dist`: what a rank of the job really
+    runs -- process group, synchronised BatchNorm, the gradient buckets of aadg_amd/reducer.py issued from the weight-gradient stream),
+    and the gradient buckets' bytes / an assumed xGMI all-reduce rate are printed next to the prediction.
+    Child processes: the parent has released its GPU memory."""
     import subprocess
     base = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--cfg", a.cfg, "--size", str(a.size), "--batch", str(a.batch),
             "--backbone", a.backbone, "--backbone_dtype", a.backbone_dtype, "--placement", a.placement, "--legs", "none"]
@@ -646,24 +648,40 @@ def scale_leg(a):
         if p.returncode != 0 or not lines:
             raise RuntimeError("child bench failed (%d): %s" % (p.returncode, p.stderr.decode()[-400:]))
         return json.loads(lines[-1])
-    out = {"placement": a.placement, "per_rank_step_ms_one_gpu_no_collectives": {}, "rows_of_rank0": {}}
+    out = {"placement": a.placement, "per_rank_step_ms": {}, "rows_of_rank0": {},
+           "per_rank_step_is": "rank 0's row slice of a G-rank job on one MI355X WITH the distributed path on (--shard_of G --force_dist): process "
+                               "group over RCCL at world 1, synchronised BatchNorm all-reduces, gradient buckets of aadg_amd.reducer.GradReducer "
+                               "issued from the weight-gradient side stream, policy broadcasts; the peers' embedding rows are stood in by repetition"}
+    grad = None
     for G in (2, 4, 8):
-        r = run(["--shard_of", str(G), "--steps", "6", "--warmup", "2"])
-        out["per_rank_step_ms_one_gpu_no_collectives"][str(G)] = r["ms_per_step"]
+        r = run(["--shard_of", str(G), "--force_dist", "--dist_backend", "nccl", "--steps", "6", "--warmup", "2"])
+        out["per_rank_step_ms"][str(G)] = r["ms_per_step"]
         out["rows_of_rank0"][str(G)] = r["config"].get("images_per_step_this_rank")
-    fd = run(["--force_dist", "--dist_backend", "nccl", "--steps", "4", "--warmup", "2"])
+        grad = r["config"]["distributed"].get("gradient_buckets") or grad
+    fd = run(["--force_dist", "--dist_backend", "nccl", "--steps", "6", "--warmup", "2"])
     d = fd["config"]["distributed"]
     coll = d.get("small_collectives_gpu_ms_per_step") or {}
     out["one_rank_over_rccl"] = {"ms_per_step": fd["ms_per_step"], "rccl_version": d.get("rccl_version"),
                                  "collectives_per_step": d.get("collectives_per_step"), "small_collectives_gpu_ms_per_step": coll,
-                                 "small_collectives_gpu_ms_per_step_total": d.get("small_collectives_gpu_ms_per_step_total")}
+                                 "small_collectives_gpu_ms_per_step_total": d.get("small_collectives_gpu_ms_per_step_total"),
+                                 "weight_gradient_side_stream": d.get("weight_gradient_side_stream"), "gradient_buckets": d.get("gradient_buckets")}
     calls = sum(v["calls_per_step"] for v in coll.values()) if coll else None
     lat_here = (sum(v["ms_per_step"] for v in coll.values()) / calls * 1e3) if calls else None
     out["small_collective_calls_per_step"] = calls
     out["latency_us_per_call_world1"] = lat_here
+    # gradient buckets: bytes per step and what a ring all-reduce of them costs at an ASSUMED xGMI rate (overlapped with the backward pass:
+    # listed next to the prediction, not added to it)
+    XGMI_BUS_GBS = 300.0       # assumed all-reduce bus bandwidth of 8 MI355X over xGMI (7 links x ~153 GB/s per GPU peak; RCCL rings reach about a third)
+    if grad:
+        nbytes = sum(sum(v["bucket_bytes"]) for v in grad.values())
+        out["gradient_all_reduce"] = {
+            "bytes_per_step": nbytes, "buckets": {k: v["bucket_bytes"] for k, v in grad.items()}, "assumed_bus_GBps": XGMI_BUS_GBS,
+            "ring_ms_per_step": {str(G): 2.0 * (G - 1) / G * nbytes / (XGMI_BUS_GBS * 1e9) * 1e3 for G in (2, 4, 8)},
+            "note": "issued asynchronously per bucket while the backward pass runs; hidden unless the ring time exceeds the backward time behind the first bucket"}
     if calls:
+        # the world-1 latency of every small collective is already inside per_rank_step_ms: add only what a real peer costs beyond it
         out["predicted_ms_per_step"] = {
-            str(G): {("lat_%dus" % round(l)): out["per_rank_step_ms_one_gpu_no_collectives"][str(G)] + calls * l * 1e-3
+            str(G): {("lat_%dus" % round(l)): out["per_rank_step_ms"][str(G)] + calls * max(0.0, l - lat_here) * 1e-3
                      for l in (lat_here, 15.0, 30.0)} for G in (2, 4, 8)}
         out["predicted_steps_per_s_at_15us"] = {str(G): 1e3 / out["predicted_ms_per_step"][str(G)]["lat_15us"] for G in (2, 4, 8)}
     return out
@@ -1120,12 +1138,20 @@ def main():
         dinfo["forced_one_rank_run_of_the_distributed_path"] = bool(a.force_dist)
         if dist_on:
             dinfo["collectives_per_step"] = {"batchnorm_statistics_all_reduce": bn_collectives, "embedding_all_gather": 1, "policy_broadcast": 2,
-                                             "gradient_all_reduce": "DDP buckets (segmentation model + discriminator), overlapped with backward"}
+                                             "gradient_all_reduce": "aadg_amd.reducer.GradReducer buckets (segmentation model + discriminator), each "
+                                                                    "issued async from the stream its last member arrived on, overlapped with backward"}
+            red = {}
+            for nm, mod in (("model", st.model), ("discriminator", st.discriminator)):
+                if hasattr(mod, "describe") and hasattr(mod, "stats"):
+                    red[nm] = dict(mod.describe(), launches_total=mod.stats["launches"], side_stream_arrivals_total=mod.stats["side_stream_arrivals"],
+                                   hook_arrivals_total=mod.stats["hook_arrivals"])
+            dinfo["gradient_buckets"] = red
+            dinfo["weight_gradient_side_stream"] = bool(_lib.wgrad_stream_enabled())
             dinfo["small_collectives_gpu_ms_per_step"] = coll
             dinfo["small_collectives_gpu_ms_per_step_total"] = float(sum(v["ms_per_step"] for v in coll.values())) if coll else None
             dinfo["note"] = ("BatchNorm: one float64 all-reduce of [2C + 1] / [2C] sums per layer and direction (ASPP's five layers share one, a "
                              "projection shortcut travels with its main path); issued on a process group of their own so that they never "
-                             "queue behind a DDP gradient bucket; ms = HIP events around each call on the issuing stream in 3 extra steps "
+                             "queue behind a gradient bucket; ms = HIP events around each call on the issuing stream in 3 extra steps "
                              "after the timed region (includes waiting for the slowest peer)")
         out = {
             "metric": "policy-search steps/sec", "value": 1e3 / ms_per_step, "unit": "steps/s",
@@ -1149,8 +1175,8 @@ def main():
                                       a.batch, M, n_rows, cfg.CONTROLLER.LOSS.upper()),
                        "images_per_step": n_rows, "images_per_step_this_rank": int(plan.n_local),
                        "parallelism": "1 GPU" if world == 1 and not a.force_dist else
-                                      "%d GPU(s): domain-major (domain, policy) units cut by %s (rows per rank %s), one embedding all-gather + DDP "
-                                      "gradient all-reduce%s" % (world, a.placement, "/".join(str(c) for c in plan.counts),
+                                      "%d GPU(s): domain-major (domain, policy) units cut by %s (rows per rank %s), one embedding all-gather + bucketed "
+                                      "gradient all-reduce (own reducer, from the weight-gradient stream)%s" % (world, a.placement, "/".join(str(c) for c in plan.counts),
                                                                    "" if a.no_sync_bn else " + BatchNorm statistics all-reduce"),
                        "backbone_dtype": a.backbone_dtype,
                        "world_size": dinfo["world_size"], "dist_backend": dinfo["backend"], "rccl_version": dinfo["rccl_version"],

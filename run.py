@@ -2,7 +2,7 @@
 [--mode search] [--gpu N] [--multiprocessing_distributed] [--dist_backend nccl] [--dist_url ...] ...
 
 Extra, optional flags (not in the reference): --crop_size (the reference hard-codes 256),
---backbone_dtype {fp32,bf16}, --max_epochs / --epoch_items (short synthetic runs), --sync_bn / --placement (multi-GPU),
+--backbone_dtype {f32x3,fp32,bf16} (default f32x3: the own float32-precision convolution kernels), --max_epochs / --epoch_items (short synthetic runs), --sync_bn / --placement (multi-GPU),
 --fixed_policy (BASELINE configs[0])."""
 import argparse
 import sys
@@ -31,10 +31,13 @@ def parse_args(argv=None):
     parser.add_argument('--seed', default=1023, type=int)
     parser.add_argument('--crop_size', default=256, type=int)
     parser.add_argument('--no_wgrad_stream', dest='wgrad_stream', action='store_false',
-                        help='weight-gradient kernels in line with the backward chain (default: on a second HIP stream beside it; always in line under DDP)')
-    parser.add_argument('--backbone_dtype', default='fp32', choices=['fp32', 'f32x3', 'bf16'],
-                        help="fp32: the library's float32 convolutions; f32x3: float32 tensors, own float32-precision matrix-core kernels; "
-                             "bf16: bfloat16 autocast (narrower than the reference)")
+                        help='weight-gradient kernels in line with the backward chain (default: on a second HIP stream beside it, multi-GPU included)')
+    parser.add_argument('--backbone_dtype', default='f32x3', choices=['fp32', 'f32x3', 'bf16'],
+                        help="f32x3 (default, the measured path of bench.py): float32 tensors, the own float32-precision matrix-core convolution "
+                             "kernels (products as three bfloat16 MFMA products of split operands, float32 accumulation; inside north_star's 1e-4 "
+                             "contract, tests/test_gpu_precision.py) -- layers / backbones they do not cover take the library's float32 convolution "
+                             "and are listed on stderr after the first step; fp32: the library's float32 convolutions everywhere (2.2x slower on "
+                             "ResNet-50); bf16: bfloat16 autocast (narrower than the reference)")
     parser.add_argument('--sync_bn', action='store_true', help='SyncBatchNorm over the row-sharded ranks')
     parser.add_argument('--placement', default='row', choices=['unit', 'row'],
                         help='multi-GPU cut of the domain-major (domain, policy) unit sequence: balanced to the row (default, as bench.py: 18 rows per rank at 8 GPUs) or whole units per rank (SURVEY 8e as written: 3/3/2/... units = 24 rows on the slowest rank); one domain per GPU at 3 GPUs either way')

@@ -95,10 +95,11 @@ def check_plan(rank, world, law, D, B, M, size, crop, full, O, adist, T):
     assert np.array_equal(rewards, truth)
     gathered = adist.all_gather([torch.from_numpy(rewards)])[0].view(world, M)
     assert all(torch.equal(gathered[0], gathered[r]) for r in range(world))     # identical on every rank
-    # gradient all-reduce: DDP over gloo averages; local mean x n_local * G / N  ==  the global mean, uneven splits included
+    # gradient all-reduce: the package's reducer over gloo averages; local mean x n_local * G / N  ==  the global mean, uneven splits included
+    from aadg_amd.reducer import GradReducer
     torch.manual_seed(5)
     lin = torch.nn.Linear(8, 1)
-    ddp = torch.nn.parallel.DistributedDataParallel(lin)
+    ddp = GradReducer(lin)
     x = torch.arange(N * 8, dtype=torch.float32).view(N, 8) / 100.0
     (ddp(x[rows]).mean() * plan.loss_weight).backward()
     ref = torch.nn.Linear(8, 1)
@@ -109,7 +110,7 @@ def check_plan(rank, world, law, D, B, M, size, crop, full, O, adist, T):
 
 
 def check_discriminator(rank, world, D, plan):
-    """load_ddp_discriminator wraps the online branch in DDP: after an optimiser step on DIFFERENT local rows the parameters
+    """load_ddp_discriminator wraps the online branch in the gradient reducer: after an optimiser step on DIFFERENT local rows the parameters
     (online and, through momentum_update, EMA) are still identical on every rank."""
     from helpers import Cfg
     from aadg_amd.losses import CrossEntropy
@@ -123,9 +124,10 @@ def check_discriminator(rank, world, D, plan):
     cfg.DATASET = Cfg._C(); cfg.DATASET.NAME = 'optic'; cfg.DATASET.DG = Cfg._C(); cfg.DATASET.DG.TRAIN = list(range(D))
     cfg.MODEL = Cfg._C(); cfg.MODEL.NAME = 'unet'; cfg.MODEL.BACKBONE = 'unet'
     cfg.TRAIN = Cfg._C(); cfg.TRAIN.BATCH_SIZE = 2
-    torch.manual_seed(77 + rank)                       # deliberately different initial weights: DDP broadcasts rank 0's
+    torch.manual_seed(77 + rank)                       # deliberately different initial weights: the reducer broadcasts rank 0's
     disc, _, _ = load_ddp_discriminator(1, A(), cfg)
-    assert isinstance(disc, torch.nn.parallel.DistributedDataParallel)
+    from aadg_amd.reducer import GradReducer
+    assert isinstance(disc, GradReducer)
     bare = disc.module
     bare.synchronize_parameters()
     opt = torch.optim.Adam([p for p in disc.parameters() if p.requires_grad], lr=1e-2)
@@ -160,6 +162,87 @@ def check_discriminator(rank, world, D, plan):
     assert torch.allclose(flat, rflat, atol=2e-5), (flat - rflat).abs().max()
 
 
+def check_reducer(rank, world, plan):
+    """aadg_amd/reducer.py on a small network with BatchNorm buffers: several buckets (tiny capacity), both zero_grad modes, a
+    parameter that takes no part, a backward pass that raises, buffers broadcast from rank 0 -- after every step the replicas are
+    identical and equal to single-process training on ALL rows with the count-weighted loss."""
+    from aadg_amd.reducer import GradReducer
+    from aadg_amd import distributed as adist
+
+    def make():
+        torch.manual_seed(31)
+        class Net(torch.nn.Sequential):
+            def __init__(self):
+                super().__init__(torch.nn.Linear(6, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(),
+                                 torch.nn.Linear(16, 3))
+                self.unused = torch.nn.Parameter(torch.ones(4, 4))      # requires a gradient, never gets one
+        return Net()
+    g = torch.Generator().manual_seed(4)
+    N = plan.n_rows
+    x, y = torch.randn(N, 6, generator=g), torch.randn(N, 3, generator=g)
+    rows = torch.from_numpy(plan.rows)
+    torch.manual_seed(1000 + rank)
+    net = make()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(rank * 0.1)                          # replicas start different: construction broadcasts rank 0's
+    assert adist.grad_group() is not None and adist.grad_group() is not adist.small_group()
+    red = GradReducer(net, bucket_bytes=600)           # 16x16 floats = 1 KiB: several buckets
+    assert red.stats["buckets"] >= 3
+    ref = make()
+    # BatchNorm over the LOCAL rows differs from the full batch: eval-mode statistics keep the comparison exact
+    net[1].eval(); ref[1].eval()
+    opt, ropt = torch.optim.SGD(red.parameters(), lr=0.1), torch.optim.SGD(ref.parameters(), lr=0.1)
+    for step in range(4):
+        none = step % 2 == 0
+        opt.zero_grad(set_to_none=none); ropt.zero_grad(set_to_none=none)
+        if step == 2:                                   # a pass cut short: its arrivals must not leak into the next one
+            class Boom(torch.autograd.Function):
+                @staticmethod
+                def forward(ctx, t):
+                    return t.clone()
+
+                @staticmethod
+                def backward(ctx, g):
+                    raise ValueError("boom")
+            try:
+                (Boom.apply(red(x[rows])[:, :1]).sum() + red.module[5].weight.sum()).backward()
+                raise AssertionError("expected the backward pass to raise")
+            except ValueError:
+                pass
+            opt.zero_grad(set_to_none=none)
+        (((red(x[rows]) - y[rows]) ** 2).mean() * plan.loss_weight).backward()
+        ((ref(x) - y) ** 2).mean().backward()
+        for (n, p), q in zip(net.named_parameters(), ref.parameters()):
+            if n.startswith("unused"):
+                assert p.grad is None or not p.grad.any()
+                continue
+            assert p.grad is not None and torch.allclose(p.grad, q.grad, atol=2e-6), (step, n, (p.grad - q.grad).abs().max())
+        opt.step(); ropt.step()
+    assert red.stats["buckets"] >= 3 and red._rebuilt
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    every = adist.all_gather([flat[None]])[0]
+    assert all(torch.equal(every[0], every[r]) for r in range(world)), "replicas diverged"
+    # buffers: a training forward starts from rank 0's running statistics
+    net[1].train()
+    with torch.no_grad():
+        net[1].running_mean.fill_(float(rank))
+    seen = []
+    h = net[1].register_forward_pre_hook(lambda m, inp: seen.append(m.running_mean.clone()))
+    red(x[rows])
+    h.remove()
+    assert torch.equal(seen[0], torch.zeros(16))        # every rank starts the forward from rank 0's buffer
+    with torch.no_grad():
+        net[1].running_mean.fill_(float(rank + 5))
+    red.eval()
+    red(x[rows])                                        # dirty after the training forward: one more broadcast, then none
+    assert torch.equal(net[1].running_mean, torch.full((16,), 5.0))
+    with torch.no_grad():
+        net[1].running_mean.fill_(float(rank))
+    red(x[rows])
+    assert torch.equal(net[1].running_mean, torch.full((16,), float(rank)))
+
+
 def worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -179,6 +262,7 @@ def worker(rank, world, port, out_dir):
     for law in ('unit', 'row'):
         part = check_plan(rank, world, law, D, B, M, size, crop, full, O, adist, T)
     check_discriminator(rank, world, D, part['plan'])
+    check_reducer(rank, world, part['plan'])
     # test batches are NOT sharded: every rank scores the whole test set (validate() then agrees everywhere)
     T.set_row_shard(rank, world, 'unit')
     tb = build_batch(11, D, B, M, size, crop)

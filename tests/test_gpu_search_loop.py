@@ -142,3 +142,27 @@ def test_early_controller_update_is_the_same_search(hip, tmp_path, monkeypatch):
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     for k in a[0]:
         assert torch.equal(a[0][k], b[0][k]), k
+
+
+def test_run_py_reference_yaml_without_flags_takes_the_own_kernels(hip, tmp_path, capfd):
+    """`python run.py --cfg experiments/optic_sinkhorn/diversity.yaml` -- the reference's yaml, NO arithmetic flag --
+    runs the measured path: --backbone_dtype defaults to f32x3, the convolutions of the model the yaml names (DeepLabV3+/MobileNetV2)
+    take the own float32-precision kernels, the weight-gradient stream is on, and layers outside the kernels' tiles are listed with the
+    reason (library float32).  (--max_epochs / --epoch_items / --crop_size only shorten the run.)"""
+    import run
+    from aadg_amd import _lib
+    from aadg_amd.config.defaults import _C
+    from aadg_amd.models import deeplab
+    assert run.parse_args(["--cfg", "x"]).backbone_dtype == "f32x3"
+    args = ["--cfg", os.path.join(ROOT, "experiments", "optic_sinkhorn", "diversity.yaml"), "--output_dir", str(tmp_path / "out"),
+            "--max_epochs", "1", "--epoch_items", "4", "--crop_size", "128"]
+    _C.defrost()
+    _C.LOG_DIR = str(tmp_path / "log")
+    best = run.main(args)
+    assert np.isfinite(best["avg_dsc"])
+    own, lib = deeplab.f32x3_coverage()
+    assert len(own) >= 40, (len(own), lib)                    # MobileNetV2's pointwise convolutions, ASPP, decoder
+    assert all(v.startswith("library: ") for v in lib.values())
+    assert _lib.wgrad_stream_enabled()
+    err = capfd.readouterr().err
+    assert "f32x3: %d convolution layers on the own float32-precision matrix-core kernels" % len(own) in err
