@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("AADG_LIB_PATH") or os.path.join(_HERE, "lib", "libaadg_hip.so")     # (override: kernel experiments)
+LIB_PATH = os.path.join(_HERE, "lib", "libaadg_hip.so")      # tests / kernel A/B scripts may assign another path before load() (scripts/ab/hook)
 MAX_OPS = 4
 
 # mirror of `aadg_unit` (include/aadg_hip.h); 140 bytes, no padding

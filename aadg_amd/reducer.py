@@ -29,7 +29,7 @@ from . import distributed as adist
 
 
 class _Bucket(object):
-    __slots__ = ("flat", "params", "views", "pending", "arrived", "streams", "work", "launched")
+    __slots__ = ("flat", "params", "views", "pending", "arrived", "bypassed", "streams", "work", "launched")
 
     def __init__(self, params, device):
         self.params = params
@@ -44,6 +44,7 @@ class _Bucket(object):
     def reset(self):
         self.pending = len(self.params)
         self.arrived = [False] * len(self.params)
+        self.bypassed = [False] * len(self.params)
         self.streams = []
         self.work = None
         self.launched = False
@@ -64,6 +65,7 @@ class GradReducer(torch.nn.Module):
         self.bucket_bytes = int(bucket_bytes)
         self.broadcast_buffers = bool(broadcast_buffers)
         self._params = [p for p in module.parameters() if p.requires_grad]
+        self._names = {id(p): n for n, p in module.named_parameters()}
         if not self._params:
             raise ValueError("GradReducer: the module has no parameter that requires a gradient")
         if any(p.dtype != torch.float32 for p in self._params):
@@ -138,8 +140,13 @@ class GradReducer(torch.nn.Module):
     def _hook(self, param):
         """post-accumulate hook: param.grad holds this pass's gradient (a fresh tensor after zero_grad(set_to_none=True), or the
         bucket view itself after zero_grad(set_to_none=False))"""
-        self.stats["hook_arrivals"] += 1
         g = param.grad
+        if g is None:
+            return                               # AccumulateGrad ran on an undefined gradient (torch still calls the hook): no arrival
+        bi, k = self._slot[id(param)]
+        if self._task == torch._C._current_graph_task_id() and self._buckets[bi].bypassed[k]:
+            return                               # its gradient came in from the weight-gradient stream; the node only saw `None`
+        self.stats["hook_arrivals"] += 1
         self._arrive(param, g)
 
     def deliver(self, param, grad):
@@ -156,8 +163,8 @@ class GradReducer(torch.nn.Module):
         view = b.views[k]
         if b.arrived[k]:
             if b.launched:
-                raise RuntimeError("GradReducer: a parameter's gradient arrived twice in one backward pass after its bucket left "
-                                   "(a weight shared between two layers?)")
+                raise RuntimeError("GradReducer: the gradient of %s arrived twice in one backward pass (now %s) after its bucket left "
+                                   "(a weight shared between two layers?)" % (self._names.get(id(param)), "from the weight-gradient stream" if bypass else "through AccumulateGrad"))
             view.add_(grad)
             return
         if bypass and param.grad is not None and param.grad.data_ptr() == view.data_ptr():
@@ -166,6 +173,7 @@ class GradReducer(torch.nn.Module):
             view.copy_(grad)
         param.grad = view
         b.arrived[k] = True
+        b.bypassed[k] = bypass
         b.pending -= 1
         if not self._rebuilt:
             self._order.append(param)

@@ -1,7 +1,7 @@
 # the aug512 and rvs1024 legs for library variants on ONE box: bash scripts/ab/exp_aug.sh [tag ...]  (tree = the built library)
 cd $GRAFT_REPO_ROOT
 for v in ${@:-tree}; do
-  if [ "$v" = tree ]; then unset AADG_LIB_PATH; else export AADG_LIB_PATH=$PWD/exp_libs/$v.so; fi
+  if [ "$v" = tree ]; then unset AADG_LIB_PATH; else export AADG_LIB_PATH=$PWD/exp_libs/$v.so PYTHONPATH=$PWD/scripts/ab/hook:$PYTHONPATH; fi
   for leg in aug512:aug_512 rvs1024:rvs_1024; do
     python bench.py --only_legs ${leg%%:*} 2>/dev/null | python -c "
 import json,sys

@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 K=$1; shift
 for v in ${@:-tree}; do
-  if [ "$v" = tree ]; then unset AADG_LIB_PATH; else export AADG_LIB_PATH=$R/exp_libs/$v.so; fi
+  if [ "$v" = tree ]; then unset AADG_LIB_PATH; else export AADG_LIB_PATH=$R/exp_libs/$v.so PYTHONPATH=$R/scripts/ab/hook:$PYTHONPATH; fi
   for leg in aug512 rvs1024; do
     rm -rf /tmp/prof_kt
     rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- python $R/bench.py --only_legs $leg > /dev/null 2>&1

@@ -19,5 +19,5 @@ torch.cuda.synchronize()
 print("%.3f ms" % sorted(a.elapsed_time(b) for a, b in ev)[3])
 PY
 echo -n "tree: "; python /tmp/x3_abl.py $ARGS
-for t in "$@"; do echo -n "$t: "; AADG_LIB_PATH=exp_libs/$t.so python /tmp/x3_abl.py $ARGS; done
+for t in "$@"; do echo -n "$t: "; AADG_LIB_PATH=exp_libs/$t.so PYTHONPATH=scripts/ab/hook:$PYTHONPATH python /tmp/x3_abl.py $ARGS; done
 echo -n "tree again: "; python /tmp/x3_abl.py $ARGS
