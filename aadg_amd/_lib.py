@@ -1076,9 +1076,17 @@ class _SyncBatchNormActGroup(torch.autograd.Function):
         offs = [0]
         for C in Cs:
             offs.append(offs[-1] + 2 * C + 1)
-        sums = torch.empty(offs[-1], dtype=torch.float64, device=dev)
+        # a member's totals from its producer's epilogue (meta[i][3], optional): its statistics pass is not run
+        pres = [m[3] if len(m) > 3 else None for m in meta]
+        if all(p is not None for p in pres):
+            sums = torch.cat(pres)
+        else:
+            sums = torch.empty(offs[-1], dtype=torch.float64, device=dev)
+            for i, p in enumerate(pres):
+                if p is not None:
+                    sums[offs[i]:offs[i + 1]].copy_(p)
         calls, ys, saved = [], [], []
-        for i, ((x, weight, bias, rm, rv, out), (momentum, eps, act)) in enumerate(zip(mem, meta)):
+        for i, ((x, weight, bias, rm, rv, out), (momentum, eps, act)) in enumerate(zip(mem, [m[:3] for m in meta])):
             N, C, H, W = x.shape
             y = torch.empty_like(x) if out is None else out
             mean = torch.empty(C, dtype=torch.float32, device=dev)
@@ -1089,15 +1097,16 @@ class _SyncBatchNormActGroup(torch.autograd.Function):
                           ws.data_ptr(), ws.numel(), 0 if out is None else out.stride(0), _stream()))
             ys.append(y)
             saved += [x, weight, bias, mean, invstd]
-        for a in calls:
-            _check(lib.aadg_bn_sync_forward(1, *a), "aadg_bn_sync_forward(1)")
+        for a, p in zip(calls, pres):
+            if p is None:
+                _check(lib.aadg_bn_sync_forward(1, *a), "aadg_bn_sync_forward(1)")
         _bn_sync_reduce(sums)
         for a in calls:
             _check(lib.aadg_bn_sync_forward(2, *a), "aadg_bn_sync_forward(2)")
         dirty = [m[5] for m in mem if m[5] is not None]
         if dirty:
             ctx.mark_dirty(*dirty)
-        ctx.meta, ctx.offs = meta, offs
+        ctx.meta, ctx.offs = [m[:3] for m in meta], offs
         ctx.save_for_backward(sums, *saved)
         return tuple(ys)
 
@@ -1142,13 +1151,16 @@ class _SyncBatchNormShortcutPair(torch.autograd.Function):
     nodes; the shortcut's normalised output is the main layer's fused residual and is not kept for the backward."""
 
     @staticmethod
-    def forward(ctx, a, b, wa, ba, rma, rva, wb, bb, rmb, rvb, mom_a, eps_a, mom_b, eps_b, act, handles):
+    def forward(ctx, a, b, wa, ba, rma, rva, wb, bb, rmb, rvb, mom_a, eps_a, mom_b, eps_b, act, handles, pre_a=None, pre_b=None):
+        """pre_a / pre_b (both or neither): this rank's float64 [2C + 1] totals of a / b from their producers' epilogues -- phase 1 (a
+        statistics pass over each tensor) is then not run"""
         lib = load()
         N, C, H, W = a.shape
         dev, dt = a.device, _BN_DTYPES[a.dtype]
         y, idt = torch.empty_like(a), torch.empty_like(a)
         stat = [torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4)]        # mean_a, invstd_a, mean_b, invstd_b
-        sums = torch.empty(2 * (2 * C + 1), dtype=torch.float64, device=dev)
+        have = pre_a is not None and pre_b is not None
+        sums = torch.cat([pre_a, pre_b]) if have else torch.empty(2 * (2 * C + 1), dtype=torch.float64, device=dev)
         ws_a = workspace(lib.aadg_bn_workspace_bytes(C), dev, "bn_group_0")
         ws_b = workspace(lib.aadg_bn_workspace_bytes(C), dev, "bn_group_1")
         mask = None
@@ -1159,8 +1171,9 @@ class _SyncBatchNormShortcutPair(torch.autograd.Function):
                   stat[2].data_ptr(), stat[3].data_ptr(), sums.data_ptr() + 8 * (2 * C + 1), ws_b.data_ptr(), ws_b.numel(), 0, _stream())
         call_a = (a.data_ptr(), idt.data_ptr(), y.data_ptr(), _ptr(mask), _ptr(wa), _ptr(ba), _ptr(rma), _ptr(rva), mom_a, eps_a, act, N, C, H * W, dt,
                   stat[0].data_ptr(), stat[1].data_ptr(), sums.data_ptr(), ws_a.data_ptr(), ws_a.numel(), 0, _stream())
-        _check(lib.aadg_bn_sync_forward(1, *call_a), "aadg_bn_sync_forward(1)")
-        _check(lib.aadg_bn_sync_forward(1, *call_b), "aadg_bn_sync_forward(1)")
+        if not have:
+            _check(lib.aadg_bn_sync_forward(1, *call_a), "aadg_bn_sync_forward(1)")
+            _check(lib.aadg_bn_sync_forward(1, *call_b), "aadg_bn_sync_forward(1)")
         _bn_sync_reduce(sums)
         _check(lib.aadg_bn_sync_forward(2, *call_b), "aadg_bn_sync_forward(2)")          # the shortcut first: it is the main layer's residual
         _check(lib.aadg_bn_sync_forward(2, *call_a), "aadg_bn_sync_forward(2)")
@@ -1195,7 +1208,7 @@ class _SyncBatchNormShortcutPair(torch.autograd.Function):
         _check(lib.aadg_bn_sync_backward(2, *call_a), "aadg_bn_sync_backward(2)")
         _check(lib.aadg_bn_sync_backward(2, *call_b), "aadg_bn_sync_backward(2)")
         return (da, db_, par[0] if wa is not None else None, par[1] if ba is not None else None, None, None,
-                par[2] if wb is not None else None, par[3] if bb is not None else None, None, None, None, None, None, None, None, None)
+                par[2] if wb is not None else None, par[3] if bb is not None else None, None, None, None, None, None, None, None, None, None, None)
 
 
 def sync_batch_norm_shortcut_pair(a, main, b, short, act=ACT_RELU, handles=1):
@@ -1204,8 +1217,12 @@ def sync_batch_norm_shortcut_pair(a, main, b, short, act=ACT_RELU, handles=1):
     _require_cuda(a, b)
     if a.shape != b.shape or a.dtype != b.dtype or not bn_act_supported(a, b):
         raise AadgError("sync_batch_norm_shortcut_pair: expected two contiguous NCHW float32/bfloat16 tensors of one shape")
+    pa, pb = getattr(a, '_aadg_bn_sums', None), getattr(b, '_aadg_bn_sums', None)      # the producing convolutions' epilogue totals
+    C = a.shape[1]
+    if not all(p is not None and p.dtype == torch.float64 and p.numel() == 2 * C + 1 for p in (pa, pb)):
+        pa = pb = None
     return _SyncBatchNormShortcutPair.apply(a, b, main[0], main[1], main[2], main[3], short[0], short[1], short[2], short[3],
-                                            float(main[4]), float(main[5]), float(short[4]), float(short[5]), int(act), int(handles))
+                                            float(main[4]), float(main[5]), float(short[4]), float(short[5]), int(act), int(handles), pa, pb)
 
 
 def sync_batch_norm_act_group(members):
@@ -1219,7 +1236,10 @@ def sync_batch_norm_act_group(members):
         if out is not None and (out.shape != x.shape or out.dtype != x.dtype or tuple(out.stride()[1:]) != tuple(x.stride()[1:]) or
                                 out.data_ptr() % 16 or out.stride(0) % 8):
             raise AadgError("sync_batch_norm_act_group: `out` must be a channel slice of a contiguous NCHW buffer of the same dtype")
-        meta.append((float(momentum), float(eps), int(act)))
+        pre = getattr(x, '_aadg_bn_sums', None)
+        if pre is not None and not (pre.dtype == torch.float64 and pre.numel() == 2 * x.shape[1] + 1):
+            pre = None
+        meta.append((float(momentum), float(eps), int(act), pre))
         flat += [x, weight, bias, rm, rv, out]
     return _SyncBatchNormActGroup.apply(meta, *flat)
 
@@ -2241,39 +2261,53 @@ class _BatchNormLazy(torch.autograd.Function):
     """Training-mode relu(batch_norm(x)) whose elementwise pass the CONSUMING convolution applies on load (conv1x1_x3(..., pre=...)):
     the forward only finalises the statistics (aadg_bn_finalize_f32, from the totals the producing convolution left) and hands x on
     UNCHANGED together with scale / shift; the backward is the ordinary two-pass BatchNorm backward with the ReLU mask re-derived from
-    x.  The first output stands for relu(bn(x)) in the graph but HOLDS x: only a consumer that applies (scale, shift) may read it."""
+    x.  The first output stands for relu(bn(x)) in the graph but HOLDS x: only a consumer that applies (scale, shift) may read it.
+    sync (data-parallel ranks, round 6): the totals are all-reduced IN PLACE before they are finalised and the backward's (sum g,
+    sum g x^) between its two passes (aadg_bn_sync_backward), as _SyncBatchNormAct does -- the on-load layers keep their fusion in a
+    multi-GPU job."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, presums, act=ACT_RELU):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, presums, act=ACT_RELU, sync=False):
         lib = load()
-        ctx.act = act
+        ctx.act, ctx.sync = act, bool(sync)
         C = x.shape[1]
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         scale = torch.empty(C, dtype=torch.float32, device=x.device)
         shift = torch.empty(C, dtype=torch.float32, device=x.device)
+        if sync:
+            _bn_sync_reduce(presums)               # [2C + 1]: sums, sums of squares, element count -- the global batch's from here on
         _check(lib.aadg_bn_finalize_f32(presums.data_ptr(), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var), momentum, eps,
                                         C, mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _stream()),
                "aadg_bn_finalize_f32")
-        ctx.save_for_backward(x, weight, bias, mean, invstd)
+        ctx.save_for_backward(x, weight, bias, mean, invstd, presums if sync else None)
         ctx.mark_non_differentiable(scale, shift)
         return x.view_as(x), scale, shift
 
     @staticmethod
     def backward(ctx, dz, *unused):
         lib = load()
-        x, weight, bias, mean, invstd = ctx.saved_tensors
+        x, weight, bias, mean, invstd, fsums = ctx.saved_tensors
         N, C, H, W = x.shape
         dz = dz.contiguous()
         dx = torch.empty_like(x)
         dw = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _bn_ws(C, x.device)
-        rc = lib.aadg_bn_backward(x.data_ptr(), None, None, dz.data_ptr(), None, 0, None, _ptr(weight), _ptr(bias), mean.data_ptr(),
-                                  invstd.data_ptr(), ctx.act, dx.data_ptr(), None, dw.data_ptr(), db.data_ptr(), N, C, H * W,
-                                  _BN_DTYPES[x.dtype], ws.data_ptr(), ws.numel(), 0, _stream())
-        _check(rc, "aadg_bn_backward")
-        return dx, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None
+        if ctx.sync:
+            sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+            args = (x.data_ptr(), None, None, dz.data_ptr(), None, 0, None, _ptr(weight), _ptr(bias), mean.data_ptr(), invstd.data_ptr(),
+                    ctx.act, dx.data_ptr(), None, dw.data_ptr(), db.data_ptr(), N, C, H * W, _BN_DTYPES[x.dtype], sums.data_ptr(),
+                    fsums.data_ptr() + 16 * C, ws.data_ptr(), ws.numel(), 0, _stream())
+            _check(lib.aadg_bn_sync_backward(1, *args), "aadg_bn_sync_backward(1)")
+            _bn_sync_reduce(sums)
+            _check(lib.aadg_bn_sync_backward(2, *args), "aadg_bn_sync_backward(2)")
+        else:
+            rc = lib.aadg_bn_backward(x.data_ptr(), None, None, dz.data_ptr(), None, 0, None, _ptr(weight), _ptr(bias), mean.data_ptr(),
+                                      invstd.data_ptr(), ctx.act, dx.data_ptr(), None, dw.data_ptr(), db.data_ptr(), N, C, H * W,
+                                      _BN_DTYPES[x.dtype], ws.data_ptr(), ws.numel(), 0, _stream())
+            _check(rc, "aadg_bn_backward")
+        return dx, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None, None
 
 
 class _BatchNormActResBN(torch.autograd.Function):
@@ -2346,8 +2380,9 @@ def batch_norm_act_res_bn(x, bn, x2, bn2, act, handles=1):
                                     w2, b2, rm2, rv2, float(mom2), float(eps2), s2)
 
 
-def batch_norm_lazy(x, weight, bias, running_mean, running_var, momentum, eps, presums, act=ACT_RELU):
-    """(x', scale, shift): see _BatchNormLazy.  x float32 NCHW contiguous on the GPU, presums its float64 [2C + 1] totals.  act: the
+def batch_norm_lazy(x, weight, bias, running_mean, running_var, momentum, eps, presums, act=ACT_RELU, sync=False):
+    """(x', scale, shift): see _BatchNormLazy.  x float32 NCHW contiguous on the GPU, presums its float64 [2C + 1] totals (sync: this
+    rank's; all-reduced in place).  act: the
     activation the consumer applies after scale / shift (ACT_RELU: the convolutions' operand load; ACT_NONE: a projection shortcut read as
     the residual of batch_norm_act(..., res_affine=(scale, shift)))."""
     _require_cuda(x)
@@ -2356,7 +2391,7 @@ def batch_norm_lazy(x, weight, bias, running_mean, running_var, momentum, eps, p
         raise AadgError("batch_norm_lazy: expected a contiguous NCHW float32 tensor and its float64 [2C + 1] totals")
     if act not in (ACT_RELU, ACT_NONE):
         raise AadgError("batch_norm_lazy: act is ReLU or none")
-    return _BatchNormLazy.apply(x, weight, bias, running_mean, running_var, float(momentum), float(eps), presums, int(act))
+    return _BatchNormLazy.apply(x, weight, bias, running_mean, running_var, float(momentum), float(eps), presums, int(act), bool(sync))
 
 
 def conv3x3_nchw_x3(a9, x, dilation=1, bn_sums=None, pre=None):

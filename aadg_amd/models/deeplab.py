@@ -381,13 +381,18 @@ class Bottleneck(nn.Module):
         one per consumer (conv1 / residual branch or downsample), so that their gradients reach the producing BatchNorm
         kernel separately and are summed there instead of by autograd adds over the whole activation."""
         x_main, x_res = (x[0], x[1]) if isinstance(x, tuple) else (x, x)
-        if self._pairs_shortcut(x_res):
-            # synchronised statistics: bn3 and the projection shortcut's BatchNorm share one all-reduce per direction
+        pairs = self._pairs_shortcut(x_res)
+        if pairs:
             from .. import _lib
             short = self.downsample[0](x_res).contiguous()
-            out = bn_act(self.bn1, self.conv1(x_main), 'relu')
-            out = bn_act(self.bn2, self.conv2(out), 'relu')
-            main = self.conv3(out).contiguous()
+        c2 = self._bn1_on_load(self.conv1(x_main))
+        c3 = self._bn2_on_load(c2)
+        if c3 is None:
+            c3 = self.conv3(bn_act(self.bn2, c2, 'relu'))
+        if pairs:
+            # synchronised statistics: bn3 and the projection shortcut's BatchNorm share one all-reduce per direction (bn1 / bn2 keep their
+            # on-load paths: batch_norm_lazy(sync=True))
+            main = c3.contiguous()
             bns = self.downsample[1].bn
             if main.shape == short.shape and _lib.bn_act_supported(main, short):
                 _bump(self.bn3)
@@ -396,10 +401,6 @@ class Bottleneck(nn.Module):
                     main, (self.bn3.weight, self.bn3.bias, self.bn3.running_mean, self.bn3.running_var, self.bn3.momentum, self.bn3.eps),
                     short, (bns.weight, bns.bias, bns.running_mean, bns.running_var, bns.momentum, bns.eps), _ACT_CODE['relu'], handles)
             return bn_act(self.bn3, main, 'relu', residual=bn_act(bns, short, None), handles=handles)
-        c2 = self._bn1_on_load(self.conv1(x_main))
-        c3 = self._bn2_on_load(c2)
-        if c3 is None:
-            c3 = self.conv3(bn_act(self.bn2, c2, 'relu'))
         if self.downsample is not None:
             pair = self._bn3_with_shortcut(x_res, c3, handles)
             if pair is not None:
@@ -470,7 +471,8 @@ class Bottleneck(nn.Module):
     lazy_bn2 = True         # f32x3 training: bn2 + ReLU applied by conv3 while it loads its operand (no elementwise pass, no normalised tensor)
 
     def _lazy_ok(self, bn, x, conv):
-        return (self.training and torch.is_grad_enabled() and not _BN_SYNC and conv.f32x3 and x.is_cuda and x.dtype == torch.float32 and
+        # (_BN_SYNC: the lazy Function all-reduces the totals itself, batch_norm_lazy(sync=True))
+        return (self.training and torch.is_grad_enabled() and conv.f32x3 and x.is_cuda and x.dtype == torch.float32 and
                 conv.stride == (1, 1) and getattr(x, '_aadg_bn_sums', None) is not None and type(bn) is nn.BatchNorm2d and
                 bn.momentum is not None and bn.track_running_stats and bn.affine)
 
@@ -484,7 +486,7 @@ class Bottleneck(nn.Module):
             if _lib.conv3x3_x3_pre_supported(c1c, conv2.weight, d) and _lib.bn_act_supported(c1c, None):
                 _bump(bn)
                 z, scale, shift = _lib.batch_norm_lazy(c1c, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                                                       c1._aadg_bn_sums)
+                                                       c1._aadg_bn_sums, sync=_BN_SYNC)
                 return _lib.conv3x3_x3(z, conv2.weight, d, True, pre=(scale, shift))
         return self.conv2(bn_act(bn, c1, 'relu'))
 
@@ -500,7 +502,7 @@ class Bottleneck(nn.Module):
         if not (_lib.conv1x1_x3_pre_supported(c2c, conv3.weight) and _lib.bn_act_supported(c2c, None)):
             return None
         _bump(bn)
-        z, scale, shift = _lib.batch_norm_lazy(c2c, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, sums)
+        z, scale, shift = _lib.batch_norm_lazy(c2c, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, sums, sync=_BN_SYNC)
         return _lib.conv1x1_x3(z, conv3.weight, conv3.bn_stats, pre=(scale, shift))
 
     def _pairs_shortcut(self, x):
@@ -794,7 +796,7 @@ def _fuse_classify_on_load(self, y):
     rows, see _classify) loads the fuse convolution's output -- the normalised [N, 256, H/4, W/4] tensor, the largest of the decoder, is
     never written (Bottleneck._bn2_on_load has the conditions); None where that path does not apply."""
     c, fuse = self.classifier, self.fuse
-    if not (self.lazy_fuse_bn and getattr(self, 'f32x3', False) and self.training and torch.is_grad_enabled() and not _BN_SYNC and
+    if not (self.lazy_fuse_bn and getattr(self, 'f32x3', False) and self.training and torch.is_grad_enabled() and
             y.is_cuda and y.dtype == torch.float32 and not torch.is_autocast_enabled('cuda') and c.kernel_size == (1, 1) and
             c.out_channels <= 8 and len(fuse) == 2 and isinstance(fuse[0], SeparableConv2d) and type(fuse[1]) is BNAct and
             fuse[1].act == 'relu'):
@@ -810,7 +812,7 @@ def _fuse_classify_on_load(self, y):
     if sums is None or not (_lib.conv1x1_x3_pre_supported(fc, w8) and _lib.bn_act_supported(fc, None)):
         return self._classify(fuse[1](f))
     _bump(bn)
-    z, scale, shift = _lib.batch_norm_lazy(fc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, sums)
+    z, scale, shift = _lib.batch_norm_lazy(fc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, sums, sync=_BN_SYNC)
     out = _lib.conv1x1_x3(z, w8, pre=(scale, shift))[:, :c.out_channels]
     return out + c.bias.view(1, -1, 1, 1) if c.bias is not None else out.contiguous()
 
