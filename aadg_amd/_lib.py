@@ -62,6 +62,7 @@ EXPORTS = [
     "aadg_conv1x1_nchw_f32x3_stats", "aadg_conv3x3_nchw_f32x3_stats", "aadg_conv3x3_f32x3_stats_supported",
     "aadg_bn_finalize_f32", "aadg_conv1x1_f32x3_pre_supported", "aadg_conv1x1_nchw_f32x3_pre", "aadg_conv1x1_wgrad_f32x3_pre",
     "aadg_conv3x3_nchw_f32x3_pre", "aadg_conv3x3_wgrad_f32x3_pre", "aadg_conv1x1_wgrad_f32x3_pre_supported", "aadg_bn_forward_res_affine_f32", "aadg_bn_backward_res_bn_f32",
+    "aadg_bn_sync_backward_res_bn_f32",
 ]
 
 _lib = None
@@ -263,6 +264,9 @@ def load():
     lib.aadg_bn_backward_res_bn_f32.restype = _i
     lib.aadg_bn_backward_res_bn_f32.argtypes = [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                 _vp, _i, _i, _i, _vp, _sz, _vp, _sz, _c.c_longlong, _vp]
+    lib.aadg_bn_sync_backward_res_bn_f32.restype = _i
+    lib.aadg_bn_sync_backward_res_bn_f32.argtypes = [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                     _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _sz, _c.c_longlong, _vp]
     lib.aadg_conv1x1_wgrad_f32x3_pre_supported.restype = _i
     lib.aadg_conv1x1_wgrad_f32x3_pre_supported.argtypes = [_i, _i, _i, _i]
     lib.aadg_conv3x3_nchw_f32x3_pre.restype = _i
@@ -289,7 +293,7 @@ def load():
     lib.aadg_conv3x3s2_dgrad_f32x3.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.aadg_conv3x3s2_wgrad_f32x3.restype = _i
     lib.aadg_conv3x3s2_wgrad_f32x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
-    if lib.aadg_abi_version() != 10:
+    if lib.aadg_abi_version() != 11:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -2315,14 +2319,21 @@ class _BatchNormActResBN(torch.autograd.Function):
     bottleneck's bn3 with its projection shortcut's BatchNorm (no activation) folded in.  Forward: the shortcut's statistics are
     finalised (aadg_bn_finalize_f32) and its normalisation happens while the main kernel reads the residual
     (aadg_bn_forward_res_affine_f32); backward: both layers in the two passes of one (aadg_bn_backward_res_bn_f32).  The shortcut's
-    normalised tensor and its own forward / backward passes do not exist."""
+    normalised tensor and its own forward / backward passes do not exist.
+    sync (data-parallel ranks, round 6): both layers' totals travel in ONE all-reduce per direction -- the concatenated epilogue totals
+    before they are finalised, and [4C] float64 between the two phases of aadg_bn_sync_backward_res_bn_f32."""
 
     @staticmethod
     def forward(ctx, x, x2, weight, bias, running_mean, running_var, momentum, eps, act, handles, presums,
-                weight2, bias2, running_mean2, running_var2, momentum2, eps2, presums2):
+                weight2, bias2, running_mean2, running_var2, momentum2, eps2, presums2, sync=False):
         lib = load()
         N, C, H, W = x.shape
         dev = x.device
+        ctx.sync = bool(sync)
+        if sync:
+            both = torch.cat([presums, presums2])
+            _bn_sync_reduce(both)
+            presums, presums2 = both[:2 * C + 1], both[2 * C + 1:]
         f32 = lambda: torch.empty(C, dtype=torch.float32, device=dev)      # noqa: E731
         mean, invstd, mean2, invstd2, scale2, shift2 = f32(), f32(), f32(), f32(), f32(), f32()
         _check(lib.aadg_bn_finalize_f32(presums2.data_ptr(), _ptr(weight2), _ptr(bias2), _ptr(running_mean2), _ptr(running_var2), momentum2,
@@ -2336,7 +2347,7 @@ class _BatchNormActResBN(torch.autograd.Function):
                                                   eps, act, N, C, H * W, mean.data_ptr(), invstd.data_ptr(), presums.data_ptr(),
                                                   ws.data_ptr(), ws.numel(), _stream()), "aadg_bn_forward_res_affine_f32")
         ctx.act = act
-        ctx.save_for_backward(x, x2, mask, weight, bias, mean, invstd, weight2, mean2, invstd2)
+        ctx.save_for_backward(x, x2, mask, weight, bias, mean, invstd, weight2, mean2, invstd2, presums if sync else None)
         if handles > 1:
             return (y,) + tuple(y.view_as(y) for _ in range(handles - 1))
         return y
@@ -2344,7 +2355,7 @@ class _BatchNormActResBN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         lib = load()
-        x, x2, mask, weight, bias, mean, invstd, weight2, mean2, invstd2 = ctx.saved_tensors
+        x, x2, mask, weight, bias, mean, invstd, weight2, mean2, invstd2, fsums = ctx.saved_tensors
         N, C, H, W = x.shape
         dy, extra, pconst, dy_stride = _bn_prepare_grads(grads, x, True)
         dx, dres, dx2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x2)
@@ -2352,6 +2363,19 @@ class _BatchNormActResBN(torch.autograd.Function):
         dw, db, dw2, db2 = f32(), f32(), f32(), f32()
         ws = _bn_ws(C, x.device)
         ws2 = torch.empty(ws.numel(), dtype=ws.dtype, device=x.device)
+        if ctx.sync:
+            sums = torch.empty(4 * C, dtype=torch.float64, device=x.device)
+            extra_arr = _ptr_array(extra) if extra else None
+            args = (x.data_ptr(), mask.data_ptr(), dy.data_ptr(), extra_arr, len(extra), _ptr(pconst), _ptr(weight), _ptr(bias), mean.data_ptr(),
+                    invstd.data_ptr(), ctx.act, dx.data_ptr(), dres.data_ptr(), dw.data_ptr(), db.data_ptr(), x2.data_ptr(), _ptr(weight2),
+                    mean2.data_ptr(), invstd2.data_ptr(), dx2.data_ptr(), dw2.data_ptr(), db2.data_ptr(), N, C, H * W, sums.data_ptr(),
+                    fsums.data_ptr() + 16 * C, ws.data_ptr(), ws.numel() * ws.element_size(), ws2.data_ptr(), ws2.numel() * ws2.element_size(),
+                    dy_stride, _stream())
+            _check(lib.aadg_bn_sync_backward_res_bn_f32(1, *args), "aadg_bn_sync_backward_res_bn_f32(1)")
+            _bn_sync_reduce(sums)
+            _check(lib.aadg_bn_sync_backward_res_bn_f32(2, *args), "aadg_bn_sync_backward_res_bn_f32(2)")
+            return (dx, dx2, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None, None,
+                    dw2 if weight2 is not None else None, db2 if weight2 is not None else None, None, None, None, None, None, None)
         rc = lib.aadg_bn_backward_res_bn_f32(x.data_ptr(), mask.data_ptr(), dy.data_ptr(), _ptr_array(extra) if extra else None, len(extra),
                                              _ptr(pconst), _ptr(weight), _ptr(bias), mean.data_ptr(), invstd.data_ptr(), ctx.act,
                                              dx.data_ptr(), dres.data_ptr(), dw.data_ptr(), db.data_ptr(), x2.data_ptr(), _ptr(weight2),
@@ -2360,10 +2384,10 @@ class _BatchNormActResBN(torch.autograd.Function):
                                              ws2.numel() * ws2.element_size(), dy_stride, _stream())
         _check(rc, "aadg_bn_backward_res_bn_f32")
         return (dx, dx2, dw if weight is not None else None, db if bias is not None else None, None, None, None, None, None, None, None,
-                dw2 if weight2 is not None else None, db2 if weight2 is not None else None, None, None, None, None, None)
+                dw2 if weight2 is not None else None, db2 if weight2 is not None else None, None, None, None, None, None, None)
 
 
-def batch_norm_act_res_bn(x, bn, x2, bn2, act, handles=1):
+def batch_norm_act_res_bn(x, bn, x2, bn2, act, handles=1, sync=False):
     """act(bn(x) + bn2(x2)) for a bottleneck's bn3 and its projection shortcut's BatchNorm (training, per-device statistics, float32;
     x / x2 carry their producers' statistics as `_aadg_bn_sums`): see _BatchNormActResBN.  bn / bn2: (weight, bias, running_mean,
     running_var, momentum, eps)."""
@@ -2377,7 +2401,7 @@ def batch_norm_act_res_bn(x, bn, x2, bn2, act, handles=1):
     w, b, rm, rv, mom, eps = bn
     w2, b2, rm2, rv2, mom2, eps2 = bn2
     return _BatchNormActResBN.apply(xc, x2c, w, b, rm, rv, float(mom), float(eps), int(act), int(handles), s1,
-                                    w2, b2, rm2, rv2, float(mom2), float(eps2), s2)
+                                    w2, b2, rm2, rv2, float(mom2), float(eps2), s2, bool(sync))
 
 
 def batch_norm_lazy(x, weight, bias, running_mean, running_var, momentum, eps, presums, act=ACT_RELU, sync=False):

@@ -594,23 +594,37 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
     int split = s.split;
     if (dual != nullptr) {
         // this layer's residual is a second BatchNorm normalised on load: both backward passes serve both layers
-        if (s.vec == 1 || mask == nullptr || dres == nullptr || act == AADG_ACT_NONE || phase != 0 || ws2 == nullptr) return AADG_E_UNSUPPORTED;
-        const BnRed2<T> r2 = {dual->x2, dual->mean2, dual->invstd2, ws2 + L.partial};
-        const dim3 rgrid(s.split, C);
+        // (phase 1 / 2, round 6: synchronised statistics -- `sums` [4C] doubles = this layer's (sum g, sum g x^) per channel, then the
+        // shortcut layer's (sum g, sum g x2^); the caller all-reduces them between the two phases)
+        if (s.vec == 1 || mask == nullptr || dres == nullptr || act == AADG_ACT_NONE || ws2 == nullptr) return AADG_E_UNSUPPORTED;
+        if (phase != 2) {
+            const BnRed2<T> r2 = {dual->x2, dual->mean2, dual->invstd2, ws2 + L.partial};
+            const dim3 rgrid(s.split, C);
 #define AADG_BN_REDUCE_DUAL(NE_)                                                                                                      \
     hipLaunchKernelGGL((k_bn_reduce_bwd<T, Pack<T>::N, 1, NE_, 1, true>), rgrid, blk, 0, st, x, y, dy, more, pconst, mask, dres, mean,    \
                        invstd, weight, bias, act | stream_flag, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial,          \
                        dy_img_stride, r2)
-        if (n_extra == 0) AADG_BN_REDUCE_DUAL(0);
-        else if (n_extra == 1) AADG_BN_REDUCE_DUAL(1);
-        else AADG_BN_REDUCE_DUAL(-1);
+            if (n_extra == 0) AADG_BN_REDUCE_DUAL(0);
+            else if (n_extra == 1) AADG_BN_REDUCE_DUAL(1);
+            else AADG_BN_REDUCE_DUAL(-1);
 #undef AADG_BN_REDUCE_DUAL
-        AADG_LAUNCH_CHECK();
+            AADG_LAUNCH_CHECK();
+            if (phase == 1) {
+                hipLaunchKernelGGL(k_bn_pack, dim3(C), dim3(64), 0, st, (const float*)(ws + L.partial), s.split, C, 0.0, sums,
+                                   (double*)nullptr, dweight, dbias);
+                hipLaunchKernelGGL(k_bn_pack, dim3(C), dim3(64), 0, st, (const float*)(ws2 + L.partial), s.split, C, 0.0,
+                                   sums + 2 * (size_t)C, (double*)nullptr, dual->dweight2, dual->dbias2);
+                AADG_LAUNCH_CHECK();
+                return 0;
+            }
+        }
         BnDx2<T> d2 = *dual;
-        d2.partial2 = ws2 + L.partial;
+        d2.partial2 = phase == 2 ? reinterpret_cast<float*>(sums + 2 * (size_t)C) : ws2 + L.partial;
+        if (phase == 2) { split = -1; dweight = nullptr; dbias = nullptr; d2.dweight2 = nullptr; d2.dbias2 = nullptr; }
         const dim3 dgrid(N * C, s.pc.per_strip);
         hipLaunchKernelGGL((k_bn_dx<T, Pack<T>::N, AADG_ACT_NONE, true>), dgrid, blk, 0, st, x, (const T*)dres, dx,
-                           (const float*)(ws + L.partial), split, (double)N * (double)HW, count_dev, weight, bias, mean, invstd, dweight,
+                           phase == 2 ? reinterpret_cast<const float*>(sums) : (const float*)(ws + L.partial), split,
+                           (double)N * (double)HW, count_dev, weight, bias, mean, invstd, dweight,
                            dbias, AADG_ACT_NONE | stream_flag, C, s.len, s.pc.plen, 0LL, d2);
         AADG_LAUNCH_CHECK();
         return 0;
@@ -958,6 +972,30 @@ extern "C" int aadg_bn_backward_res_bn_f32(const float* x, const void* act_mask,
     const BnDx2<float> d2 = {x2, dx2, nullptr, weight2, save_mean2, save_invstd2, dweight2, dbias2};
     return bn_backward<float>(x, nullptr, (const uint8_t*)act_mask, dy, dy_extra, n_extra, dy_plane_const, weight, bias, save_mean, save_invstd,
                               act, dx, dres, dweight, dbias, N, C, HW, (float*)ws, dy_image_stride, (hipStream_t)stream, 0, nullptr, nullptr,
+                              &d2, (float*)ws2);
+}
+
+/* aadg_bn_backward_res_bn_f32 with synchronised statistics (ABI 11): phase 1 = both layers' local sums -> `sums` [4C] doubles (this
+ * layer's (sum g, sum g x^) per channel, then the shortcut's), the masked gradient dres and the LOCAL dweight / dbias / dweight2 / dbias2;
+ * the caller all-reduces `sums`; phase 2 = dx and dx2 from the totals and the forward's all-reduced element count `count`. */
+extern "C" int aadg_bn_sync_backward_res_bn_f32(int phase, const float* x, const void* act_mask, const float* dy, const void* const* dy_extra,
+                                                int n_extra, const float* dy_plane_const, const float* weight, const float* bias,
+                                                const float* save_mean, const float* save_invstd, int act, float* dx, float* dres,
+                                                float* dweight, float* dbias, const float* x2, const float* weight2, const float* save_mean2,
+                                                const float* save_invstd2, float* dx2, float* dweight2, float* dbias2, int N, int C, int HW,
+                                                double* sums, const double* count, void* ws, size_t ws_bytes, void* ws2, size_t ws2_bytes,
+                                                long long dy_image_stride, void* stream) {
+    if ((phase != 1 && phase != 2) || x == nullptr || act_mask == nullptr || dy == nullptr || dx == nullptr || dres == nullptr ||
+        save_mean == nullptr || save_invstd == nullptr || x2 == nullptr || save_mean2 == nullptr || save_invstd2 == nullptr || dx2 == nullptr ||
+        ws == nullptr || ws2 == nullptr || sums == nullptr || act <= 0 || act > AADG_ACT_RELU6 || dy_image_stride < 0 ||
+        (((uintptr_t)sums) & 7u) != 0 || (phase == 2 && count == nullptr))
+        return AADG_E_BADARG;
+    if (n_extra < 0 || n_extra > BN_MAX_EXTRA || (n_extra > 0 && dy_extra == nullptr)) return AADG_E_BADARG;
+    if ((((uintptr_t)x2 | (uintptr_t)dx2) & 15u) != 0) return AADG_E_BADARG;
+    if (C <= 0 || ws_bytes < aadg_bn_workspace_bytes(C) || ws2_bytes < aadg_bn_workspace_bytes(C)) return AADG_E_WORKSPACE;
+    const BnDx2<float> d2 = {x2, dx2, nullptr, weight2, save_mean2, save_invstd2, dweight2, dbias2};
+    return bn_backward<float>(x, nullptr, (const uint8_t*)act_mask, dy, dy_extra, n_extra, dy_plane_const, weight, bias, save_mean, save_invstd,
+                              act, dx, dres, dweight, dbias, N, C, HW, (float*)ws, dy_image_stride, (hipStream_t)stream, phase, sums, count,
                               &d2, (float*)ws2);
 }
 

@@ -381,30 +381,31 @@ class Bottleneck(nn.Module):
         one per consumer (conv1 / residual branch or downsample), so that their gradients reach the producing BatchNorm
         kernel separately and are summed there instead of by autograd adds over the whole activation."""
         x_main, x_res = (x[0], x[1]) if isinstance(x, tuple) else (x, x)
-        pairs = self._pairs_shortcut(x_res)
-        if pairs:
-            from .. import _lib
-            short = self.downsample[0](x_res).contiguous()
         c2 = self._bn1_on_load(self.conv1(x_main))
         c3 = self._bn2_on_load(c2)
         if c3 is None:
             c3 = self.conv3(bn_act(self.bn2, c2, 'relu'))
-        if pairs:
-            # synchronised statistics: bn3 and the projection shortcut's BatchNorm share one all-reduce per direction (bn1 / bn2 keep their
-            # on-load paths: batch_norm_lazy(sync=True))
-            main = c3.contiguous()
-            bns = self.downsample[1].bn
-            if main.shape == short.shape and _lib.bn_act_supported(main, short):
-                _bump(self.bn3)
-                _bump(bns)
-                return _lib.sync_batch_norm_shortcut_pair(
-                    main, (self.bn3.weight, self.bn3.bias, self.bn3.running_mean, self.bn3.running_var, self.bn3.momentum, self.bn3.eps),
-                    short, (bns.weight, bns.bias, bns.running_mean, bns.running_var, bns.momentum, bns.eps), _ACT_CODE['relu'], handles)
-            return bn_act(self.bn3, main, 'relu', residual=bn_act(bns, short, None), handles=handles)
         if self.downsample is not None:
-            pair = self._bn3_with_shortcut(x_res, c3, handles)
+            pair = self._bn3_with_shortcut(x_res, c3, handles)          # (synchronised statistics included: one all-reduce per direction)
             if pair is not None:
                 return pair
+            if self._pairs_shortcut(x_res):
+                # synchronised statistics where the fused pair does not apply (bfloat16, shapes outside its tiles): bn3 and the projection
+                # shortcut's BatchNorm as two materialised layers that share one all-reduce per direction
+                from .. import _lib
+                short = self.__dict__.pop('_short_cached', None)
+                if short is None:
+                    short = self.downsample[0](x_res)
+                short = short.contiguous()
+                main = c3.contiguous()
+                bns = self.downsample[1].bn
+                if main.shape == short.shape and _lib.bn_act_supported(main, short):
+                    _bump(self.bn3)
+                    _bump(bns)
+                    return _lib.sync_batch_norm_shortcut_pair(
+                        main, (self.bn3.weight, self.bn3.bias, self.bn3.running_mean, self.bn3.running_var, self.bn3.momentum, self.bn3.eps),
+                        short, (bns.weight, bns.bias, bns.running_mean, bns.running_var, bns.momentum, bns.eps), _ACT_CODE['relu'], handles)
+                return bn_act(self.bn3, main, 'relu', residual=bn_act(bns, short, None), handles=handles)
         idt, raff = (x_res, None) if self.downsample is None else self._shortcut_on_load(x_res, c3)
         if raff is None:
             return bn_act(self.bn3, c3, 'relu', residual=idt, handles=handles)
@@ -418,7 +419,7 @@ class Bottleneck(nn.Module):
         d = self.downsample
         if not (self.pair_shortcut_bn and self.lazy_shortcut and isinstance(d, nn.Sequential) and len(d) == 2 and type(d[1]) is BNAct and
                 d[1].act is None and isinstance(d[0], Conv1x1) and getattr(c3, '_aadg_bn_sums', None) is not None and self.training and
-                torch.is_grad_enabled() and not _BN_SYNC and d[0].f32x3 and d[0].bn_stats and c3.dtype == torch.float32 and
+                torch.is_grad_enabled() and d[0].f32x3 and d[0].bn_stats and c3.dtype == torch.float32 and
                 type(self.bn3) is nn.BatchNorm2d and self.bn3.affine and self.bn3.momentum is not None and self.bn3.track_running_stats):
             return None
         bns = d[1].bn
@@ -440,7 +441,7 @@ class Bottleneck(nn.Module):
         b3 = self.bn3
         return _lib.batch_norm_act_res_bn(c3, (b3.weight, b3.bias, b3.running_mean, b3.running_var, b3.momentum, b3.eps),
                                           short, (bns.weight, bns.bias, bns.running_mean, bns.running_var, bns.momentum, bns.eps),
-                                          _ACT_CODE['relu'], handles)
+                                          _ACT_CODE['relu'], handles, sync=_BN_SYNC)
 
     lazy_shortcut = True    # f32x3 training: the projection shortcut's BatchNorm applied while bn3's kernel reads the residual
 
@@ -465,7 +466,8 @@ class Bottleneck(nn.Module):
                                                            short._aadg_bn_sums, act=_ACT_CODE[None])
                     return z, (scale, shift)
             return d[1](short), None
-        return d(x_res), None
+        short = self.__dict__.pop('_short_cached', None)           # (_bn3_with_shortcut ran the convolution and then declined)
+        return (d(x_res) if short is None else d[1](short)), None
 
     lazy_bn1 = True         # f32x3 training: bn1 + ReLU applied by conv2 (stride 1) while it stages its operand, as lazy_bn2 below
     lazy_bn2 = True         # f32x3 training: bn2 + ReLU applied by conv3 while it loads its operand (no elementwise pass, no normalised tensor)

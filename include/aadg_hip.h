@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AADG_ABI_VERSION 10
+#define AADG_ABI_VERSION 11
 #define AADG_MAX_OPS 4
 
 #define AADG_E_BADARG (-1)
@@ -460,6 +460,16 @@ int aadg_bn_backward_res_bn_f32(const float* x, const void* act_mask, const floa
                                 const float* weight2, const float* save_mean2, const float* save_invstd2, float* dx2, float* dweight2,
                                 float* dbias2, int N, int C, int HW, void* ws, size_t ws_bytes, void* ws2, size_t ws2_bytes,
                                 long long dy_image_stride, void* stream);
+/* ... and with synchronised statistics (ABI 11; data-parallel ranks, reference: models/sync_batchnorm/batchnorm.py:102-105 sums the
+ * statistics over the replicas): phase 1 leaves both layers' float64 sums in `sums` [4C] (this layer's (sum g, sum g x^) per channel, then
+ * the shortcut's) + the masked gradient dres + the LOCAL parameter gradients; the caller all-reduces `sums`; phase 2 writes dx / dx2 from
+ * the totals and the forward's all-reduced element count `count` (device pointer). */
+int aadg_bn_sync_backward_res_bn_f32(int phase, const float* x, const void* act_mask, const float* dy, const void* const* dy_extra, int n_extra,
+                                     const float* dy_plane_const, const float* weight, const float* bias, const float* save_mean,
+                                     const float* save_invstd, int act, float* dx, float* dres, float* dweight, float* dbias, const float* x2,
+                                     const float* weight2, const float* save_mean2, const float* save_invstd2, float* dx2, float* dweight2,
+                                     float* dbias2, int N, int C, int HW, double* sums, const double* count, void* ws, size_t ws_bytes, void* ws2,
+                                     size_t ws2_bytes, long long dy_image_stride, void* stream);
 int aadg_conv1x1_f32x3_pre_supported(int M, int K, int HW);
 int aadg_conv1x1_wgrad_f32x3_pre_supported(int N, int Co, int Ci, int HW);
 int aadg_conv1x1_nchw_f32x3_pre(const void* a_hi, const void* a_lo, const float* in, float* out, int N, int M, int K, int HW,

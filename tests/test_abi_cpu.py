@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libaadg_hip.so does not export %s" % name
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.aadg_abi_version() == 10
+    assert lib.aadg_abi_version() == 11
 
 
 def test_unit_struct_layout_matches_header():
