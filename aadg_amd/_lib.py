@@ -1671,6 +1671,7 @@ def _own_gemm_1x1(M, K, HW, N=None):
 # wrapped in torch's DistributedDataParallel (its reducer listens to those hooks) and not for torch.autograd.grad(); the package's own
 # data-parallel wrapper (aadg_amd/reducer.py) takes them over on the side stream instead.  Off by default.
 _WG = {"on": False, "stream": None, "pending": []}
+_EXP = {}          # timing experiments (scripts/r6/*): never set by the product
 
 
 def set_wgrad_stream(flag):
@@ -2298,6 +2299,12 @@ class _BatchNormLazy(torch.autograd.Function):
         dw = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _bn_ws(C, x.device)
+        if _EXP.get("skip_lazy_dx"):             # timing experiment only (scripts/r6/exp_skip_dx.py): the reduction alone, dx := dz
+            sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+            _check(lib.aadg_bn_sync_backward(1, x.data_ptr(), None, None, dz.data_ptr(), None, 0, None, _ptr(weight), _ptr(bias), mean.data_ptr(),
+                                             invstd.data_ptr(), ctx.act, dx.data_ptr(), None, dw.data_ptr(), db.data_ptr(), N, C, H * W,
+                                             _BN_DTYPES[x.dtype], sums.data_ptr(), None, ws.data_ptr(), ws.numel(), 0, _stream()), "exp")
+            return dz, dw, db, None, None, None, None, None, None, None
         if ctx.sync:
             sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
             args = (x.data_ptr(), None, None, dz.data_ptr(), None, 0, None, _ptr(weight), _ptr(bias), mean.data_ptr(), invstd.data_ptr(),
