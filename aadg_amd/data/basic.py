@@ -6,7 +6,7 @@ ops do not touch pixels on the host.  An op function accepts either
 
   * an `ImageRef` (deferred mode, used by the batched pipeline): the op and every random draw it
     makes are *recorded*; pixels are produced later by ONE fused GPU call for the whole batch
-    (aadg_amd/_lib.py: aug_u8_forward), or
+    (aadg_amd/_lib/aug.py: aug_u8_forward), or
   * a uint8 HWC torch tensor on the GPU (eager mode): the op runs immediately through the C ABI
     (aadg_op_u8).
 

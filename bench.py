@@ -449,7 +449,7 @@ def time_steps(st, a, world, steps, warmup, first_epoch=0, want_kernel_events=Tr
     return float(t.item()), step_ms, kern_ms, call_ms
 
 
-# float tensor ops of data/functional.py (a9-a12), in registry order of aadg_amd/_lib.py: FOP
+# float tensor ops of data/functional.py (a9-a12), in registry order of aadg_amd/_lib/hotpath.py: FOP
 FLOAT_OPS = [("invert", None), ("solarize", 0.5), ("posterize", 0.5), ("gray", None), ("contrast", 0.3), ("auto_contrast", None),
              ("saturate", 0.3), ("brightness", 0.3), ("hue", 0.2), ("sample_pairing", 0.3), ("equalize", None), ("sharpness", 0.3),
              ("gaussian_blur3x3", 0.7), ("shear_x", 0.2), ("shear_y", 0.2), ("translate_x", 0.1), ("translate_y", 0.1), ("rotate", 20.0),

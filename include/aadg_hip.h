@@ -115,7 +115,7 @@ int aadg_aug_u8_forward_ex(const uint8_t* pool, const uint8_t* masks, int P, int
  *               that draws it.  With the pool resident for the whole run they are computed once instead of per unit and call.
  *               The caller owns the cache: recompute after writing to the pool.
  * A unit listed under the wrong class is skipped (its outputs are not written): the lists must follow unit_flow() of
- * csrc/aug_u8.hip (aadg_amd/_lib.py: launch_hints builds them from the host copy of the unit records). */
+ * csrc/aug_u8.hip (aadg_amd/_lib/aug.py: launch_hints builds them from the host copy of the unit records). */
 #define AADG_HIST_STRIDE 772    /* uint32 words per image: 3 x 256 bins, uint64 sum of L (ImageStat mean of convert('L')), pad */
 typedef struct aadg_aug_lists {
     const int32_t* order;
