@@ -217,7 +217,10 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
         live = np.arange(MAX_OPS)[None, :] < units["n_ops"][:, None]
         PROFILE_MIX.append({"units": int(N), "ops": int(live.sum()), "sharpness_ops": int(((units["op"] == 8) & live).sum()),
                             "sharpness_units": int(n_sharp), "stat_ops": int(sum(summary[8:8 + MAX_OPS])), "late_units": int(n_late),
-                            "upscaled": int(((units["scaled_w"] != Ws) | (units["scaled_h"] != Hs)).sum())})
+                            "upscaled": int(((units["scaled_w"] != Ws) | (units["scaled_h"] != Hs)).sum()),
+                            # units per tile kernel: k_fused3 (plain + Sharpness), k_fused3w (width-only down-scaling), the two passes
+                            "tile_units": {"k_fused3": int(n_plain + n_sharp), "k_fused3w": int(lists.n_generic_wonly),
+                                           "two_pass": int(n_generic - lists.n_generic_wonly), "two_pass_with_sharpness": int(n_generic_sharp)}})
     if PROFILE_EVENTS is not None:
         ev0, ev1 = PROFILE_EVENTS[0].cuda_event, PROFILE_EVENTS[1].cuda_event
     if PROFILE_CALL_EVENTS is not None:

@@ -1586,7 +1586,8 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_sample_seq(CtrlParams P, Ct
     }
     // ---- per-sequence partials; the last workgroup to arrive combines them in ascending order.  No device-scope fence (cache
     // maintenance on every XCD, several us): the partials are written and read with relaxed device-scope atomics (sc1: served at the
-    // device's coherence point), __syncthreads() waits for the stores' acknowledgements (vmcnt(0)) before the arrival is counted.
+    // device's coherence point); every storing wave waits for its stores' acknowledgements (an explicit s_waitcnt vmcnt(0), as k_seg_loss
+    // does: a workgroup barrier alone does not promise it -- ADVICE r5) before the barrier behind which the arrival is counted.
     auto st_dev = [](float* p, float v) { __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     auto ld_dev = [](const float* p) {
         return __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned*>(const_cast<float*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -1599,6 +1600,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_ctrl_sample_seq(CtrlParams P, Ct
         st_dev(sp + tid, (a < (head == 0 ? d.NOPS : d.NMAGS)) ? s : 0.0f);
     }
     if (tid == 0) { st_dev(ws + W.slp + 2 * w, my_lp); st_dev(ws + W.slp + 2 * w + 1, my_ent); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int* counter = reinterpret_cast<int*>(ws + W.counter);
     __shared__ int last;

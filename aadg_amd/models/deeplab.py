@@ -130,6 +130,16 @@ def set_bn_sync(flag):
     _BN_SYNC = bool(flag)
 
 
+def _take_bn_sums(x):
+    """The float64 totals the producing convolution attached to its output (`_aadg_bn_sums`), for the ONE BatchNorm that consumes them.
+    With synchronised statistics the consumer all-reduces them in place, so the attribute is cleared on the way out: a second reader
+    gets None (and takes its own statistics pass) instead of totals that were already summed over the ranks."""
+    sums = getattr(x, '_aadg_bn_sums', None)
+    if sums is not None and _BN_SYNC:
+        x._aadg_bn_sums = None
+    return sums
+
+
 def bn_act(bn, x, act=None, residual=None, handles=1, out=None, res_affine=None):
     """act(bn(x) [+ residual]).  On the GPU a plain `nn.BatchNorm2d` runs as the fused HIP streaming kernels
     (csrc/batchnorm.hip: statistics, normalise + activation + residual add in one pass, two-pass backward); anything
@@ -142,7 +152,7 @@ def bn_act(bn, x, act=None, residual=None, handles=1, out=None, res_affine=None)
             if bn.training:
                 _bump(bn)
             # statistics the producing convolution took in its epilogue (Conv1x1 in f32x3 mode, `bn_stats`): no statistics pass over x
-            presums = getattr(x, '_aadg_bn_sums', None) if bn.training else None
+            presums = _take_bn_sums(x) if bn.training else None
             # out (training only): a slice of a concatenation buffer (_lib.concat_slices) that receives the result
             return _lib.batch_norm_act(xc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum,
                                        bn.eps, _ACT_CODE[act], rc,
@@ -488,7 +498,7 @@ class Bottleneck(nn.Module):
             if _lib.conv3x3_x3_pre_supported(c1c, conv2.weight, d) and _lib.bn_act_supported(c1c, None):
                 _bump(bn)
                 z, scale, shift = _lib.batch_norm_lazy(c1c, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                                                       c1._aadg_bn_sums, sync=_BN_SYNC)
+                                                       _take_bn_sums(c1), sync=_BN_SYNC)
                 return _lib.conv3x3_x3(z, conv2.weight, d, True, pre=(scale, shift))
         return self.conv2(bn_act(bn, c1, 'relu'))
 
@@ -496,13 +506,13 @@ class Bottleneck(nn.Module):
         """conv3(relu(bn2(c2))) with the normalisation applied on conv3's operand load (_lib.batch_norm_lazy + conv1x1_x3(pre=...)), or None
         where that path does not apply: needs the statistics conv2 left in its epilogue, plain per-device BatchNorm, whole-tile shapes."""
         bn, conv3 = self.bn2, self.conv3
-        sums = getattr(c2, '_aadg_bn_sums', None)
         if not (self.lazy_bn2 and self._lazy_ok(bn, c2, conv3)):
             return None
         from .. import _lib
         c2c = c2.contiguous()
         if not (_lib.conv1x1_x3_pre_supported(c2c, conv3.weight) and _lib.bn_act_supported(c2c, None)):
             return None
+        sums = _take_bn_sums(c2)
         _bump(bn)
         z, scale, shift = _lib.batch_norm_lazy(c2c, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, sums, sync=_BN_SYNC)
         return _lib.conv1x1_x3(z, conv3.weight, conv3.bn_stats, pre=(scale, shift))
@@ -814,6 +824,7 @@ def _fuse_classify_on_load(self, y):
     if sums is None or not (_lib.conv1x1_x3_pre_supported(fc, w8) and _lib.bn_act_supported(fc, None)):
         return self._classify(fuse[1](f))
     _bump(bn)
+    sums = _take_bn_sums(f)
     z, scale, shift = _lib.batch_norm_lazy(fc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, sums, sync=_BN_SYNC)
     out = _lib.conv1x1_x3(z, w8, pre=(scale, shift))[:, :c.out_channels]
     return out + c.bias.view(1, -1, 1, 1) if c.bias is not None else out.contiguous()

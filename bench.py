@@ -80,7 +80,7 @@ def parse():
     ap.add_argument("--legs", default="auto", help="comma list of extra legs at N = 1: fop,kernels,rvs1024,cpu,precision,scale  (auto = all; none = skip)")
     ap.add_argument("--only_legs", default=None,
                     help="skip the headline step and print ONE JSON line holding only these legs (fop,kernels,rvs1024): the target of "
-                         "the rocprofv3 runs behind profiles/r05_fop_*, profiles/r05_aug512_* and profiles/r05_rvs1024_*")
+                         "the rocprofv3 runs behind profiles/r06_fop_*, profiles/r06_aug512_* and profiles/r06_rvs1024_*")
     ap.add_argument("--no_cpu_baseline", action="store_true", help="same as removing `cpu` from --legs")
     ap.add_argument("--cpu_repeats", type=int, default=20)
     ap.add_argument("--no_sync_bn", action="store_true",
@@ -514,8 +514,8 @@ def float_ops_leg(B=144, size=512, repeats=10):
                     % repeats,
             "frac_min": float(min(fr)), "frac_median": float(np.median(fr)), "slowest": {"op": worst[0], "achieved": worst[1]},
             "ops": res,
-            "rocprof": "profiles/r05_fop_kernel_stats.txt (rocprofv3 --kernel-trace --stats -- python bench.py --only_legs fop), "
-                       "profiles/r05_fop_traffic.json (FETCH_SIZE / WRITE_SIZE passes)"}
+            "rocprof": "profiles/r06_fop_kernel_stats.txt (rocprofv3 --kernel-trace --stats -- python bench.py --only_legs fop), "
+                       "profiles/r06_fop_traffic.json (FETCH_SIZE / WRITE_SIZE passes)"}
 
 
 def hot_kernels_leg(D=3, B=8, M=6, size=512, K=2, repeats=20):
@@ -721,6 +721,7 @@ def rvs_1024_leg(n_units=144, size=1024, cfg_rel=os.path.join("experiments", "rv
     next(it)                                                # warm-up batch
     torch.cuda.synchronize()
     n_flow = None
+    _lib.PROFILE_MIX = []
     for i in range(R):
         _lib.PROFILE_EVENTS, _lib.PROFILE_CALL_EVENTS = kp[i], cp[i]
         try:
@@ -728,7 +729,10 @@ def rvs_1024_leg(n_units=144, size=1024, cfg_rel=os.path.join("experiments", "rv
         except StopIteration:
             it = iter(loader)
             next(it)
+    mixes, _lib.PROFILE_MIX = _lib.PROFILE_MIX, None
     _lib.PROFILE_EVENTS = _lib.PROFILE_CALL_EVENTS = None
+    # units per tile kernel, averaged over the timed batches (the per-kernel fractions of profiles/r06_rvs1024_traffic.json divide by these)
+    tile_units = {k: float(np.mean([m["tile_units"][k] for m in mixes])) for k in mixes[0]["tile_units"]} if mixes else None
     torch.cuda.synchronize()
     # bytes of one batch plan (same law as the optic leg; the source here is 1024 x 1024)
     batch = [loader.dataset[0] for _ in range(8)]
@@ -739,18 +743,19 @@ def rvs_1024_leg(n_units=144, size=1024, cfg_rel=os.path.join("experiments", "rv
     kb = unit_bytes(units, Hs, Hs, size, K, False)
     sb = unit_bytes(units, Hs, Hs, size, K, True)
     k_ms, c_ms = float(np.mean([p[0].elapsed_time(p[1]) for p in kp])), float(np.mean([p[0].elapsed_time(p[1]) for p in cp]))
-    tr = (committed("r05_rvs1024_traffic.json") or committed("r04_rvs1024_traffic.json")) if size == 1024 else None
+    tr = (committed("r06_rvs1024_traffic.json") or committed("r05_rvs1024_traffic.json")) if size == 1024 else None
     return {"workload": "%s: %s pipeline, %dx%d crops from %dx%d sources, "
                         "%d units per batch (hot path only: augmentation call)" % (label, cfg_rel, size, size, Hs, Hs, len(units)),
             "units": len(units), "units_by_tile_kernel": {"up_plain": n_flow[0], "up_sharpness": n_flow[1], "generic_downscale": n_flow[2],
                                                           "generic_with_sharpness": n_flow[3],
                                                           "staged": len(units) - sum(n_flow[:3])},
+            "units_per_batch_by_tile_kernel": tile_units,
             "img_per_s": len(units) / (c_ms * 1e-3),
             "roofline": {"bound": "hbm", "kernel": "k_fused3 + k_gen_hpass + k_gen_vpass (tile kernels of the batch: up-scaling units in one pass, "
                                                    "down-scaling units as a horizontal and a vertical streaming pass)",
                          "achieved": kb / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": int(tr["hbm_bytes_per_unit"] * len(units)) if tr else None,
-                         "traffic_source": "profiles/r05_rvs1024_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes, summed "
+                         "traffic_source": "profiles/" + tr.get("file", "r05_rvs1024_traffic.json") + " (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes, summed "
                                            "over the tile kernels), per unit x units" if tr else None,
                          "bytes_per_launch": kb, "kernel_ms": k_ms,
                          # the raw images' statistics come from the per-pool cache: the call reads the source once
@@ -1089,8 +1094,8 @@ def main():
         with open(a.dump_rewards, "w") as f:
             json.dump({"normalized": [n.tolist() for n, _ in dump], "raw": [r.tolist() for _, r in dump]}, f)
     if rank == 0:
-        traffic = committed("r05_traffic_k_fused3.json") or committed("r04_traffic_k_fused3.json")
-        prof = committed("r05_bench_kernel_stats.json") or committed("r04_bench_kernel_stats.json")
+        traffic = committed("r06_traffic_k_fused3.json") or committed("r05_traffic_k_fused3.json")
+        prof = committed("r06_bench_kernel_stats.json") or committed("r05_bench_kernel_stats.json")
         # `roofline`: flat scalars first (the driver's record keeps scalars of this block), nested blocks after them
         roof = {"bound": "hbm", "kernel": "k_fused3 (LDS-tiled op chain + Pillow-exact resample + crop + normalise + CHW float32 store)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -56,6 +56,63 @@ def test_weight_gradients_beside_the_chain_equal_gradients_in_line(hip, dtype):
         assert float((b - 2 * a).abs().max()) <= 2 * tol * float(a.abs().max())
 
 
+def test_on_load_batchnorm_operands_survive_on_the_side_stream(hip):
+    """the weight-gradient kernels of a convolution that applies a BatchNorm + ReLU on operand load read pre_scale /
+    pre_shift ON THE SIDE STREAM; those [K] tensors are freed to the launch stream's allocator as soon as the node's backward returns,
+    and the very next node (the lazy BatchNorm's backward) allocates dw / db of the same size.  With the tensors recorded on the side
+    stream the gradients beside the chain equal the in-line ones -- checked under allocator pressure: many same-sized allocations and
+    writes on the launch stream right behind each backward node, side stream lagging behind a long kernel."""
+    torch.manual_seed(9)
+    N, C, H = 8, 64, 32
+    x = torch.randn(N, C, H, H, device="cuda")
+    w1 = torch.nn.Parameter(torch.randn(C, C, 1, 1, device="cuda") * 0.1)
+    w2 = torch.nn.Parameter(torch.randn(C, C, 3, 3, device="cuda") * 0.05)
+    w3 = torch.nn.Parameter(torch.randn(4 * C, C, 1, 1, device="cuda") * 0.1)
+    bn = [(torch.nn.Parameter(torch.rand(C, device="cuda") + 0.5), torch.nn.Parameter(torch.randn(C, device="cuda") * 0.1)) for _ in range(2)]
+    r = torch.randn(N, 4 * C, H, H, device="cuda")
+    if not (hip.conv3x3_x3_pre_supported(x, w2, 1) and hip.conv1x1_x3_pre_supported(x, w3)):
+        pytest.skip("shape outside the on-load tiles")
+
+    class Churn(torch.autograd.Function):
+        """identity whose backward hammers the launch stream's allocator with [C]-sized blocks (what the next node's dw / db would get)"""
+        @staticmethod
+        def forward(ctx, t):
+            return t.view_as(t)
+
+        @staticmethod
+        def backward(ctx, g):
+            for i in range(64):
+                torch.full((C,), float(i + 1e6), device="cuda")           # allocated, written, freed: recycles the freed [K] blocks
+            return g
+
+    def run(mode):
+        old = hip.set_wgrad_stream(mode)
+        try:
+            for p in [w1, w2, w3] + [t for pair in bn for t in pair]:
+                p.grad = None
+            c1 = hip.conv1x1_x3(x, w1, True)
+            z1, s1, h1 = hip.batch_norm_lazy(c1, bn[0][0], bn[0][1], torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), 0.1, 1e-5, c1._aadg_bn_sums)
+            c2 = hip.conv3x3_x3(Churn.apply(z1), w2, 1, True, pre=(s1, h1))
+            z2, s2, h2 = hip.batch_norm_lazy(c2, bn[1][0], bn[1][1], torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), 0.1, 1e-5, c2._aadg_bn_sums)
+            c3 = hip.conv1x1_x3(Churn.apply(z2), w3, False, pre=(s2, h2))
+            if mode:
+                # the side stream lags: a long kernel queued on it in front of the weight gradients
+                side = hip._WG["stream"] or torch.cuda.Stream()
+                hip._WG["stream"] = side
+                with torch.cuda.stream(side):
+                    torch.cuda._sleep(20_000_000)
+            ((c3 * r).sum() * 1e-3).backward()
+            torch.cuda.synchronize()
+            return [p.grad.detach().clone() for p in (w1, w2, w3)]
+        finally:
+            hip.set_wgrad_stream(old)
+    line = run(False)
+    for rep in range(3):
+        side = run(True)
+        for a, b in zip(line, side):
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), (rep, float((a - b).abs().max()), float(a.abs().max()))
+
+
 def test_search_step_with_the_side_stream(hip):
     """The whole policy-search step with the weight gradients beside the chain: the loader switches it on (one process, no DDP), every
     parameter of the segmentation model receives a finite gradient of its own shape, nothing is left pending, and the first step's loss
