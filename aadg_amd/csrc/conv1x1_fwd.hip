@@ -25,10 +25,12 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 constexpr int CF_BK = 64, CF_BP = 256;
 constexpr int CF_BPITCH = CF_BP + 16;           // B rows: 544 bytes = 32 (mod 256): the 4 rows of a transpose read hit distinct banks
 
+// the gfx950 LDS transpose read as a compiler builtin (round 6; it was inline assembly with a hand-placed s_waitcnt): the scheduler moves
+// the reads of the next K sub-step between the MFMAs of the current one and counts its own waits (2-3 % on the compute-bound layers)
+typedef short cf_v4i16 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x2 lds_read_tr16(const uint16_t* p) {
-    u32x2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
-    return v;
+    const cf_v4i16 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cf_v4i16 __attribute__((address_space(3)))*)(p));
+    return __builtin_bit_cast(u32x2, v);
 }
 
 // WR x WC waves; wave tile (32 MI) x (32 NI); BM = 32 MI WR, BP = 32 NI WC = 256.
@@ -153,13 +155,6 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
                     lo[pl][ni] = lds_read_tr16(b_base + pl * BK * BPITCH + (16 * ks) * BPITCH + 32 * ni);
                     hi[pl][ni] = lds_read_tr16(b_base + pl * BK * BPITCH + (16 * ks + 4) * BPITCH + 32 * ni);
                 }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // the transpose reads are opaque to the compiler's wait-count bookkeeping: pin their results behind the wait (volatile asm
-            // statements keep their order), or the scheduler may move an MFMA that uses them above it
-#pragma unroll
-            for (int pl = 0; pl < PL; ++pl)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(lo[pl][ni]), "+v"(hi[pl][ni]));
 #pragma unroll
             for (int pl = 0; pl < PL; ++pl)
 #pragma unroll

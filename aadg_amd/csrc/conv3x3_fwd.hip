@@ -32,10 +32,12 @@ constexpr int C3_BK = 16;                 // input channels per K-step
 constexpr int C3_APITCH = C3_BK + 8;      // A rows: 48 bytes (conflict-free 16-byte fragment reads)
 constexpr int C3_PIX = 256;               // pixels per workgroup tile
 
+// (a compiler builtin since round 6, it was inline assembly behind a hand-placed s_waitcnt: the scheduler interleaves the reads with the
+// MFMAs and counts its own waits)
+typedef short lds_tr16_v4i16 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x2 lds_tr16(const uint16_t* p) {
-    u32x2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
-    return v;
+    const lds_tr16_v4i16 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr16_v4i16 __attribute__((address_space(3)))*)(p));
+    return __builtin_bit_cast(u32x2, v);
 }
 
 // X3 = true ("f32x3"): IN / OUT are float32, A9 comes pre-split as two bfloat16 planes (hi, lo).  A staged 8-pixel chunk (two float4
@@ -217,17 +219,7 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void k_conv3x3_nchw(const uint16_t
                     }
                 }
         };
-        // the transpose reads are opaque to the compiler's wait-count bookkeeping; tying their results to the wait keeps the
-        // scheduler from moving an MFMA that uses them above it (it did: the second pixel tile of every wave came out wrong)
-        auto settle = [&](Frags& f) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int pl = 0; pl < PL; ++pl)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(f.lo[pl][kw][ni]), "+v"(f.hi[pl][kw][ni]));
-        };
+        auto settle = [&](Frags&) {};                          // (the reads are builtins now: the compiler waits for them itself)
         auto mfma_row = [&](const Frags& f) {
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw)

@@ -25,10 +25,12 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int DG_BK = 16, DG_APITCH = DG_BK + 8, DG_BM = 64, DG_PIX = 128;
 
+// (a compiler builtin since round 6, it was inline assembly behind a hand-placed s_waitcnt: the scheduler interleaves the reads with the
+// MFMAs and counts its own waits)
+typedef short dg_tr16_v4i16 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x2 dg_tr16(const uint16_t* p) {
-    u32x2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
-    return v;
+    const dg_tr16_v4i16 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dg_tr16_v4i16 __attribute__((address_space(3)))*)(p));
+    return __builtin_bit_cast(u32x2, v);
 }
 
 // X3 = true ("f32x3", see conv1x1_fwd.hip): dY / dX float32, A9 pre-split into bfloat16 (hi, lo) planes; a staged 8-pixel chunk (two
@@ -177,13 +179,6 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void k_dgrad3x3_s2(const uint16_t*
                         lo[pl][dj][di] = dg_tr16(p);
                         hi[pl][dj][di] = dg_tr16(p + 4 * BP);
                     }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int pl = 0; pl < PL; ++pl)
-#pragma unroll
-                for (int dj = 0; dj < 2; ++dj)
-#pragma unroll
-                    for (int di = 0; di < 2; ++di) asm volatile("" : "+v"(lo[pl][dj][di]), "+v"(hi[pl][dj][di]));
             bf16x8 b[PL][2][2];
 #pragma unroll
             for (int pl = 0; pl < PL; ++pl)

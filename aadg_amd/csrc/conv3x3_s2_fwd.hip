@@ -25,10 +25,12 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int S2_BK = 16, S2_APITCH = S2_BK + 8, S2_BM = 64, S2_PIX = 128;
 
+// (a compiler builtin since round 6, it was inline assembly behind a hand-placed s_waitcnt: the scheduler interleaves the reads with the
+// MFMAs and counts its own waits)
+typedef short s2_tr16_v4i16 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x2 s2_tr16(const uint16_t* p) {
-    u32x2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
-    return v;
+    const s2_tr16_v4i16 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s2_tr16_v4i16 __attribute__((address_space(3)))*)(p));
+    return __builtin_bit_cast(u32x2, v);
 }
 
 // X3 = true ("f32x3", see conv1x1_fwd.hip): IN / OUT float32, A9 pre-split into bfloat16 (hi, lo) planes; a staged 8-pixel chunk (two
@@ -177,13 +179,6 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void k_conv3x3_s2(const uint16_t* 
                         hi[pl][kw][ni] = s2_tr16(p + 4 * BP);
                     }
                 }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int pl = 0; pl < PL; ++pl)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) asm volatile("" : "+v"(lo[pl][kw][ni]), "+v"(hi[pl][kw][ni]));
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
