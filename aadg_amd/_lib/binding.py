@@ -59,7 +59,7 @@ EXPORTS = [
     "aadg_conv1x1_nchw_f32x3_stats", "aadg_conv3x3_nchw_f32x3_stats", "aadg_conv3x3_f32x3_stats_supported",
     "aadg_bn_finalize_f32", "aadg_conv1x1_f32x3_pre_supported", "aadg_conv1x1_nchw_f32x3_pre", "aadg_conv1x1_wgrad_f32x3_pre",
     "aadg_conv3x3_nchw_f32x3_pre", "aadg_conv3x3_wgrad_f32x3_pre", "aadg_conv1x1_wgrad_f32x3_pre_supported", "aadg_bn_forward_res_affine_f32", "aadg_bn_backward_res_bn_f32",
-    "aadg_bn_sync_backward_res_bn_f32",
+    "aadg_bn_sync_backward_res_bn_f32", "aadg_draw_python_stream",
 ]
 
 _lib = None
@@ -261,6 +261,8 @@ def load():
     lib.aadg_bn_backward_res_bn_f32.restype = _i
     lib.aadg_bn_backward_res_bn_f32.argtypes = [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                 _vp, _i, _i, _i, _vp, _sz, _vp, _sz, _c.c_longlong, _vp]
+    lib.aadg_draw_python_stream.restype = _i
+    lib.aadg_draw_python_stream.argtypes = [_vp, _i, _i, _i, _vp, _vp, _c.c_double, _c.c_double, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]
     lib.aadg_bn_sync_backward_res_bn_f32.restype = _i
     lib.aadg_bn_sync_backward_res_bn_f32.argtypes = [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                      _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _sz, _c.c_longlong, _vp]

@@ -187,17 +187,25 @@ def controller_workspace(controller, M):
     return torch.zeros(need, dtype=torch.uint8, device=next(controller.parameters()).device)
 
 
-def controller_sample(controller, M, uniforms, ws):
+def controller_pointers(controller, exp_avg=None, exp_avg_sq=None):
+    """The pointer arrays of the fused controller calls, built once (models/graphed.py keeps them while the tensors keep their storage):
+    (parameters, exp_avg, exp_avg_sq, the data_ptr they were built from)."""
+    params = list(controller.parameters())
+    return (_ptr_array(params), _ptr_array(exp_avg) if exp_avg is not None else None, _ptr_array(exp_avg_sq) if exp_avg_sq is not None else None,
+            tuple(p.data_ptr() for p in params))
+
+
+def controller_sample(controller, M, uniforms, ws, ptrs=None, dims=None):
     """Fused controller.sample(M): returns (policies int64 [M, Q*2L], mean op probs, mean mag probs, log_probs, entropies)."""
     lib = load()
-    dims = controller_dims(controller, M)
+    dims = dims or controller_dims(controller, M)
     dev = uniforms.device
     policies = torch.empty((M, dims[1] * dims[2]), dtype=torch.int64, device=dev)
     op_probs = torch.empty(dims[5], dtype=torch.float32, device=dev)
     mag_probs = torch.empty(dims[6], dtype=torch.float32, device=dev)
     log_probs = torch.empty(M, dtype=torch.float32, device=dev)
     entropies = torch.empty(M, dtype=torch.float32, device=dev)
-    params = _ptr_array(list(controller.parameters()))
+    params = ptrs[0] if ptrs is not None else _ptr_array(list(controller.parameters()))
     rc = lib.aadg_controller_sample_f32(params, *dims, float(controller.C) / float(controller.T), uniforms.data_ptr(),
                                         policies.data_ptr(), op_probs.data_ptr(), mag_probs.data_ptr(), log_probs.data_ptr(),
                                         entropies.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
@@ -206,12 +214,14 @@ def controller_sample(controller, M, uniforms, ws):
 
 
 def controller_ppo_update(controller, M, exp_avg, exp_avg_sq, policies, old_log_probs, reward, clip, n_updates, step0, lr,
-                          betas, eps, ws):
+                          betas, eps, ws, ptrs=None, dims=None):
     """n_updates PPO epochs (evaluate -> clipped surrogate -> backward -> Adam) in place; returns loss terms [n_updates, M]."""
     lib = load()
-    dims = controller_dims(controller, M)
+    dims = dims or controller_dims(controller, M)
     losses = torch.empty((n_updates, M), dtype=torch.float32, device=policies.device)
-    rc = lib.aadg_controller_ppo_update_f32(_ptr_array(list(controller.parameters())), _ptr_array(exp_avg), _ptr_array(exp_avg_sq),
+    if ptrs is None:
+        ptrs = (_ptr_array(list(controller.parameters())), _ptr_array(exp_avg), _ptr_array(exp_avg_sq))
+    rc = lib.aadg_controller_ppo_update_f32(ptrs[0], ptrs[1], ptrs[2],
                                             *dims, float(controller.C) / float(controller.T), policies.data_ptr(),
                                             old_log_probs.data_ptr(), reward.data_ptr(), float(clip), int(n_updates), int(step0),
                                             float(lr), float(betas[0]), float(betas[1]), float(eps), losses.data_ptr(),

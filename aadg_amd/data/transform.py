@@ -446,8 +446,9 @@ def _policy_tables(mp, pool):
     return tabs
 
 
-def _draw_python_stream(n_items, D, M, nsub, queue_lens, sc, n_code, W0, H0):
-    """Phase A of a training batch: every draw the pipeline makes from python's `random` generator, in the pipeline's order --
+def _draw_python_stream_py(n_items, D, M, nsub, queue_lens, sc, n_code, W0, H0):
+    """(The Python statement of aadg_draw_python_stream -- csrc/host_draw.hip runs the same loop on a copy of the generator's state; tests compare
+    the two draw for draw.)  Phase A of a training batch: every draw the pipeline makes from python's `random` generator, in the pipeline's order --
     per (item, domain): per policy the CutMix-queue draw and the sub-policy draw (data/policy.py:17-23), then DGRandomScaleCrop for
     the original and each augmented image (data/transform.py:104-131), then ToTensor's soft domain code (:260-274).  None of them
     depends on what the policies CONTAIN (only on how many sub-policies each has and on the length of its CutMix queue), so this
@@ -539,6 +540,40 @@ def _draw_python_stream(n_items, D, M, nsub, queue_lens, sc, n_code, W0, H0):
     return {'n_items': n_items, 'D': D, 'M': M, 'nsub': tuple(nsub), 'queue_before': tuple(queue_lens), 'queue_after': tuple(qlen),
             'R': R, 'R_np': np.frombuffer(array('q', R), dtype=np.int64), 'geo': np.frombuffer(array('i', geo), dtype=np.int32).reshape(n, 5),
             'dcs': dcs}
+
+
+USE_C_DRAW = True          # phase A through the library's host-side planner (csrc/host_draw.hip); False: the Python statement above
+
+
+def _draw_python_stream(n_items, D, M, nsub, queue_lens, sc, n_code, W0, H0):
+    """Phase A of a training batch (see _draw_python_stream_py) by the library's host planner: python's Mersenne-Twister state is copied
+    out (random.getstate), advanced by aadg_draw_python_stream draw for draw as the interpreter would, and put back (random.setstate) --
+    ~60 us instead of ~230 us of interpreter time per 24-sample batch.  Same record, same generator end state."""
+    if not USE_C_DRAW:
+        return _draw_python_stream_py(n_items, D, M, nsub, queue_lens, sc, n_code, W0, H0)
+    lib = _lib.load()
+    version, words, gauss = random.getstate()
+    if version != 3 or len(words) != 625:
+        return _draw_python_stream_py(n_items, D, M, nsub, queue_lens, sc, n_code, W0, H0)     # another interpreter's generator
+    mt = np.array(words, dtype=np.uint32)
+    S = n_items * D
+    n = S + S * M
+    nsub_a = np.asarray(nsub, dtype=np.int32)
+    qlen = np.array(queue_lens, dtype=np.int32)
+    sub = np.empty(S * M, dtype=np.int64)
+    geo = np.empty((n, 5), dtype=np.int32)
+    codes = np.empty((S, n_code), dtype=np.float64)
+    crop_h, crop_w = sc.crop.size
+    rc = lib.aadg_draw_python_stream(mt.ctypes.data, n_items, D, M, nsub_a.ctypes.data, qlen.ctypes.data, float(sc.scale_range[0]),
+                                     float(sc.scale_range[1]), int(crop_h), int(crop_w), int(sc.crop.padding), int(n_code), int(W0), int(H0),
+                                     sub.ctypes.data, geo.ctypes.data, codes.ctypes.data)
+    if rc != 0:
+        # an empty crop range (python's randint raises ValueError) or sizes the planner refuses: the Python statement raises / handles it,
+        # from the UNTOUCHED generator state
+        return _draw_python_stream_py(n_items, D, M, nsub, queue_lens, sc, n_code, W0, H0)
+    random.setstate((version, tuple(mt.tolist()), gauss))
+    return {'n_items': n_items, 'D': D, 'M': M, 'nsub': tuple(nsub), 'queue_before': tuple(queue_lens), 'queue_after': tuple(qlen.tolist()),
+            'R': sub, 'R_np': sub, 'geo': geo, 'dcs': codes}
 
 
 def _standard_pipeline(dataset):

@@ -141,6 +141,14 @@ class FusedControllerStep(object):
                 state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
         self.exp_avg = [optimizer.state[p]['exp_avg'] for p in self.params]
         self.exp_avg_sq = [optimizer.state[p]['exp_avg_sq'] for p in self.params]
+        self._dims = _lib.controller_dims(controller, M)
+        self._ptrs = None                                       # pointer arrays of the calls: rebuilt when a parameter changed its storage
+
+    def _pointers(self):
+        p = self._ptrs
+        if p is None or any(t.data_ptr() != q for t, q in zip(self.params, p[3])):
+            p = self._ptrs = self._lib.controller_pointers(self.controller, self.exp_avg, self.exp_avg_sq)
+        return p
 
     @staticmethod
     def supported(controller, criterion, optimizer, M):
@@ -159,7 +167,8 @@ class FusedControllerStep(object):
     def sample(self):
         dev = self.params[0].device
         uniforms = torch.rand(self.M, self.n_dec, device=dev)
-        policies, op_probs, mag_probs, log_probs, entropies = self._lib.controller_sample(self.controller, self.M, uniforms, self.ws)
+        policies, op_probs, mag_probs, log_probs, entropies = self._lib.controller_sample(self.controller, self.M, uniforms, self.ws,
+                                                                                          self._pointers(), self._dims)
         self.policies, self.old_log_probs = policies, log_probs
         return policies, op_probs, mag_probs, log_probs, entropies
 
@@ -172,7 +181,7 @@ class FusedControllerStep(object):
         n = crit.n_updates_per_iteration
         terms = self._lib.controller_ppo_update(self.controller, self.M, self.exp_avg, self.exp_avg_sq, self.policies,
                                                 self.old_log_probs, reward.contiguous().float(), crit.clip, n, step0,
-                                                group['lr'], group['betas'], group['eps'], self.ws)
+                                                group['lr'], group['betas'], group['eps'], self.ws, self._pointers(), self._dims)
         for p in self.params:
             self.optimizer.state[p]['step'] += n
         mean_loss = terms.mean()

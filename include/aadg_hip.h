@@ -161,6 +161,17 @@ int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks, int P, in
 int aadg_aug_u8_plan(const aadg_unit* units, int N, int P, int Hs, int Ws, int crop, int32_t* order, int32_t* stat_units,
                      int32_t* late_units, int32_t* summary);
 
+/* (ABI 11) Host-side planner, part 2 (no GPU work): every draw one training batch of the standard pipeline makes from PYTHON's `random`
+ * generator, in the reference's order -- per (item, domain): per policy the CutMix-queue draw and the sub-policy draw (data/policy.py:17-23),
+ * DGRandomScaleCrop for the original and each of the M augmented images (data/transform.py:104-131, RandomCrop :38-53), the soft domain code
+ * (:260-274) -- on a copy of the interpreter's MT19937 state: mt_state [625] = random.getstate()[1], advanced in place (the caller puts it
+ * back with random.setstate).  queue_lens [M] in / out: the CutMix queue lengths (capped at 10).  sub [S M] int64: sub-policy per (sample,
+ * policy); geo [(S + S M) 5] int32: (scaled_w, scaled_h, pad, crop_x, crop_y) per row (rows [0, S): the un-augmented images; S + s M + j: the
+ * augmented ones); codes [S n_code] float64.  S = n_items * D.  AADG_E_BADARG: bad sizes, or an empty crop range (python raises ValueError). */
+int aadg_draw_python_stream(uint32_t* mt_state, int n_items, int D, int M, const int32_t* nsub, int32_t* queue_lens, double scale_lo,
+                            double scale_hi, int crop_h, int crop_w, int crop_pad, int n_code, int W0, int H0, int64_t* sub, int32_t* geo,
+                            double* codes);
+
 /* One registry op on one image, replaces fn(img, mask, v) of augment_list()
  * (data/basic.py:70-120,137-167) for uint8 HWC tensors.  ws >= aadg_aug_u8_workspace_bytes(1,H,W,0);
  * in != out. */

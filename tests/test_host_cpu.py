@@ -388,3 +388,61 @@ def test_pillow_tap_count_bound_behind_axis_taps():
             taps = int((xmax - xmin).max())
             bound = 3 if 3 * n_out > 2 * n_in else (4 if 2 * n_out > n_in else 5)
             assert taps <= bound, (n_in, n_out, taps, bound)
+
+
+def test_c_planner_draws_pythons_stream_draw_for_draw():
+    """Round 6: aadg_draw_python_stream (csrc/host_draw.hip) advances a copy of the interpreter's Mersenne-Twister state
+    exactly as the Python statement (_draw_python_stream_py: the reference pipeline's draws from `random`, data/policy.py:17-23,
+    data/transform.py:38-53,104-131,260-274) -- same sub-policy choices, geometry, soft codes, queue lengths and the same generator state
+    afterwards, over scale ranges that up- and down-scale, padded crops, ragged sub-policy counts, queues at and below their cap; an empty
+    crop range raises what python's randint raises."""
+    import random
+    import time
+    from aadg_amd.data import transform as T
+
+    class Crop(object):
+        def __init__(self, size, padding):
+            self.size, self.padding = size, padding
+
+    class SC(object):
+        def __init__(self, lo, hi, size, padding):
+            self.scale_range, self.crop = (lo, hi), Crop((size, size), padding)
+    rs = np.random.RandomState(3)
+    t_c = t_py = 0.0
+    for case in range(40):
+        n_items, D, M = int(rs.randint(1, 9)), int(rs.randint(1, 9)), int(rs.randint(1, 7))
+        nsub = tuple(int(v) for v in rs.randint(1, 7, M))
+        qlens = tuple(int(v) for v in rs.randint(0, 12, M))
+        lo, hi = [(1.0, 1.5), (0.5, 2.0), (0.75, 1.25), (1.0, 1.0)][case % 4]
+        W0 = int(rs.choice([64, 100, 256, 512]))
+        size = int(rs.choice([W0, W0 // 2, W0 + 24]))
+        sc = SC(lo, hi, size, int(rs.choice([0, 0, 4])))
+        n_code = D + int(rs.randint(0, 3))
+        random.seed(1000 + case)
+        for _ in range(case):                                   # any position inside the 624-word block, and across a refill
+            random.random()
+        st = random.getstate()
+        t0 = time.perf_counter()
+        a = T._draw_python_stream_py(n_items, D, M, nsub, qlens, sc, n_code, W0, W0)
+        t_py += time.perf_counter() - t0
+        end_py = random.getstate()
+        random.setstate(st)
+        t0 = time.perf_counter()
+        b = T._draw_python_stream(n_items, D, M, nsub, qlens, sc, n_code, W0, W0)
+        t_c += time.perf_counter() - t0
+        assert random.getstate() == end_py, case
+        assert isinstance(b['R'], np.ndarray), "the library's planner did not run"
+        assert list(a['R']) == b['R'].tolist() and np.array_equal(a['geo'], b['geo']) and a['queue_after'] == b['queue_after'], case
+        assert np.array_equal(np.array(a['dcs'], dtype=np.float64), b['dcs']), case          # bit-equal float64 codes
+    assert t_c < t_py, (t_c, t_py)
+    # an empty crop range: the crop is larger than the scaled image can ever be padded to -> python's randint raises; so does the fast path
+    sc = SC(1.0, 1.0, 64, 0)
+    sc.crop.size = (64, 200)                                    # (h, w): no padding branch (w >= crop_h, h >= crop_w fails -> pad), then m2 <= 0
+    for fn in (T._draw_python_stream_py, T._draw_python_stream):
+        random.seed(5)
+        try:
+            fn(1, 1, 1, (1,), (0,), sc, 1, 64, 300)
+            raised = False
+        except ValueError:
+            raised = True
+        assert raised, fn
