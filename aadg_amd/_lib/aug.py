@@ -46,7 +46,7 @@ def validate_units(units, P, Hs, Ws):
 
 
 def launch_plan(units, Hs, Ws, crop):
-    """(classes, stats_mask, order, counts, stat_lists, late, n_stat_stencil, n_generic_wonly) for aadg_aug_u8_forward_ex2 -- mirrors unit_flow() in
+    """(classes, stats_mask, order, counts, stat_lists, late, n_stat_stencil, n_generic_wonly, (n_plain_late, n_sharp_late)) for aadg_aug_u8_forward_ex2 -- mirrors unit_flow() in
     csrc/aug_u8.hip.  n_generic_wonly (ABI 9): the first ones of the generic run shrink the width only and chain no stencil (one-pass tile).
     order: unit indices grouped by tile class (plain up-scaling, up-scaling with a Sharpness stencil, generic, staged);
     counts = (n_plain, n_sharp, n_generic, n_generic_sharp: the last ones of the generic run chain a Sharpness stencil); stat_lists[k]: the units whose k-th op needs a pixel pass for its image statistics;
@@ -80,7 +80,9 @@ def launch_plan(units, Hs, Ws, crop):
     # (among the generic units without a stencil those that shrink the width only come first: k_fused3w's list, ABI 9)
     wonly = generic & (sharp == 0) & (units["scaled_h"] >= Hs) & (Ws >= 8)
     cls = np.where(up & (sharp == 0), 0, np.where(up, 1, np.where(wonly, 2, np.where(generic & (sharp == 0), 3, np.where(generic, 4, 5)))))
-    order = np.argsort(cls, kind="stable").astype(np.int32)
+    # (ABI 12: inside the plain and the Sharpness up-scaling class the late units -- a slot k >= 1 needs a pixel pass -- come last)
+    late_flag = pixel_pass[:, 1:].any(axis=1)
+    order = np.argsort(cls * 2 + (late_flag & (cls < 2)), kind="stable").astype(np.int32)
     counts = (int((cls == 0).sum()), int((cls == 1).sum()), int(((cls == 2) | (cls == 3) | (cls == 4)).sum()), int((cls == 4).sum()))
     # work lists of the histogram kernels; slot k's list starts with the units that have a Sharpness stencil among ops [0, k) (ABI 7:
     # aadg_aug_lists.n_stat_stencil -- their tiles get a workgroup each), both parts in ascending unit order
@@ -93,7 +95,8 @@ def launch_plan(units, Hs, Ws, crop):
         n_stencil.append(int(before.sum()))
     # "late" units: a slot k >= 1 needs a pixel pass (include/aadg_hip.h: aadg_aug_lists.late_units)
     late = np.nonzero(pixel_pass[:, 1:].any(axis=1))[0].astype(np.int32)
-    return classes, stats_mask, order, counts, stat_lists, late, n_stencil, int((cls == 2).sum())
+    return (classes, stats_mask, order, counts, stat_lists, late, n_stencil, int((cls == 2).sum()),
+            (int((late_flag & (cls == 0)).sum()), int((late_flag & (cls == 1)).sum())))
 
 
 def launch_hints(units, Hs, Ws, crop):
@@ -106,7 +109,8 @@ class AugLists(ctypes.Structure):
     _fields_ = [("order", ctypes.c_void_p), ("n_plain", ctypes.c_int32), ("n_sharp", ctypes.c_int32), ("n_generic", ctypes.c_int32),
                 ("stat_units", ctypes.c_void_p * MAX_OPS), ("n_stat", ctypes.c_int32 * MAX_OPS), ("pool_hist", ctypes.c_void_p),
                 ("late_units", ctypes.c_void_p), ("n_late", ctypes.c_int32), ("n_generic_sharp", ctypes.c_int32),
-                ("n_stat_stencil", ctypes.c_int32 * MAX_OPS), ("gen_chunk", ctypes.c_int32), ("n_generic_wonly", ctypes.c_int32)]
+                ("n_stat_stencil", ctypes.c_int32 * MAX_OPS), ("gen_chunk", ctypes.c_int32), ("n_generic_wonly", ctypes.c_int32),
+                ("n_plain_late", ctypes.c_int32), ("n_sharp_late", ctypes.c_int32)]
 
 
 HIST_STRIDE = 772      # AADG_HIST_STRIDE
@@ -184,7 +188,7 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
     # validation + work lists (tile-class order, per-slot statistics lists, late list) by the library's host-side planner, written
     # straight into the staging buffer behind the records: [order N][stat_units MAX_OPS x N][late N] int32
     base = stage.data_ptr()
-    summary = (ctypes.c_int32 * (9 + 2 * MAX_OPS))()
+    summary = (ctypes.c_int32 * (11 + 2 * MAX_OPS))()
     rc = lib.aadg_aug_u8_plan(base, N, P, Hs, Ws, crop, base + nb_units, base + nb_units + 4 * N, base + nb_units + 4 * N * (1 + MAX_OPS), summary)
     if rc != 0:
         validate_units(units, P, Hs, Ws)                     # raises with the reason
@@ -195,6 +199,7 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
     lists.order = d_units.data_ptr() + nb_units
     lists.n_plain, lists.n_sharp, lists.n_generic, lists.n_generic_sharp = n_plain, n_sharp, n_generic, n_generic_sharp
     lists.n_generic_wonly = summary[8 + 2 * MAX_OPS]
+    lists.n_plain_late, lists.n_sharp_late = summary[9 + 2 * MAX_OPS], summary[10 + 2 * MAX_OPS]
     lists.gen_chunk = int(gen_chunk)
     for k in range(MAX_OPS):
         lists.stat_units[k] = d_units.data_ptr() + nb_units + 4 * N * (1 + k)

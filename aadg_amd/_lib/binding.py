@@ -292,7 +292,7 @@ def load():
     lib.aadg_conv3x3s2_dgrad_f32x3.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.aadg_conv3x3s2_wgrad_f32x3.restype = _i
     lib.aadg_conv3x3s2_wgrad_f32x3.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
-    if lib.aadg_abi_version() != 11:
+    if lib.aadg_abi_version() != 12:
         raise RuntimeError("libaadg_hip.so ABI version mismatch")
     _lib = lib
     return lib

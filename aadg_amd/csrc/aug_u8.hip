@@ -2455,9 +2455,12 @@ constexpr int HINT_FUSED = 1, HINT_STAGED = 2, HINT_GENERIC = 4;
 // two passes (0 = gen_chunk(); never more than that: the workspace holds one default chunk).
 int launch_tiles(const uint8_t* pool, const uint8_t* masks, const aadg_unit* units, const int* order_up, int np, int ns, const int* order_gen,
                  int ng, int ng_sharp, int Hs, int Ws, int crop, int dsk, const int* tab, const uint8_t* lut, size_t lut_stage_stride,
-                 uint32_t* hbuf, float* out_img, float* out_lbl, hipStream_t st, int chunk_req = 0, int ng_wonly = 0) {
+                 uint32_t* hbuf, float* out_img, float* out_lbl, hipStream_t st, int chunk_req = 0, int ng_wonly = 0,
+                 const int* order_sharp_override = nullptr) {
     const int gx = (crop + FT_W - 1) / FT_W, gy = (crop + FT_H - 1) / FT_H, gz = np + 2 * ns;
-    const int* order_sharp = order_up != nullptr ? order_up + np : nullptr;
+    // (order_sharp_override: a sub-range of the caller's lists -- forward_cached launches the units that wait for no statistics pass apart
+    // from the late ones)
+    const int* order_sharp = order_sharp_override != nullptr ? order_sharp_override : order_up != nullptr ? order_up + np : nullptr;
     // with the caller's list the stencil units are the last ng_sharp entries; without one every unit is offered to both variants
     const bool listed = order_gen != nullptr;
     const int n0 = listed ? ng - ng_sharp : ng, s1 = listed ? ng - ng_sharp : 0;
@@ -2583,6 +2586,28 @@ static inline int aug_dataset_arg(int dataset, int N, int crop) {
     return dataset | ((size_t)N * (3 + K) * crop * crop * sizeof(float) > AUG_STREAM_BYTES ? AUG_STREAM_OUT : 0);
 }
 
+// helper stream + events of forward_cached's fork (one per process and device: one process drives one GPU); nullptr if they cannot be made
+struct AugFork {
+    int device;
+    hipStream_t helper;
+    hipEvent_t tables, chain, done;
+};
+AugFork* aug_fork() {
+    static AugFork f = {-1, nullptr, nullptr, nullptr, nullptr};
+    static bool failed = false;
+    int dev = 0;
+    if (failed || hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (f.device == dev) return &f;
+    if (f.device >= 0) return nullptr;                                  // made for another device: keep to one stream there
+    if (hipStreamCreateWithFlags(&f.helper, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&f.tables, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&f.chain, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&f.done, hipEventDisableTiming) != hipSuccess) {
+        failed = true;
+        return nullptr;
+    }
+    f.device = dev;
+    return &f;
+}
+
 int forward_cached(const uint8_t* pool, const uint8_t* masks, const UnitRef& ur, int N, int Hs, int Ws, int max_ops, int crop, int dataset,
                    float* out_img, float* out_lbl, uint8_t* ws8, const WsLayout& L, hipStream_t st, int classes, int stats_mask,
                    void* ev_before, void* ev_after, const aadg_aug_lists& ls) {
@@ -2601,23 +2626,60 @@ int forward_cached(const uint8_t* pool, const uint8_t* masks, const UnitRef& ur,
     hipLaunchKernelGGL(k_luts_tables, dim3(3 * N), dim3(256), 0, st, ur, N, max_ops, npix, Hs, Ws, crop, ls.pool_hist, lut, tab,
                        (pixel_pass && chain) ? hist0 : (uint32_t*)nullptr);
     AADG_LAUNCH_CHECK();
+    // Round 6 (ABI 12): the late units' chain -- histogram pass(es), their byte maps -- and their tiles run on a helper stream BESIDE the tile
+    // kernel of the units that wait for nothing (the planner lists the late units last inside the plain and the Sharpness class:
+    // n_plain_late / n_sharp_late).  The early tiles read the tables and the early units' byte maps only, all complete behind
+    // k_luts_tables; the chain writes the late units' histograms and byte maps only.  The down-scaling units (any of them may be late)
+    // follow on the caller's stream behind the chain.  Not while the caller times the tile kernel (ev_before / ev_after): one stream then.
+    const int npl = ls.n_plain_late, nsl = ls.n_sharp_late;
+    const int n_early = (n_plain - npl) + (n_sharp - nsl);
+    AugFork* fk = (chain && ev_before == nullptr && ev_after == nullptr && n_early > 0)
+                      ? aug_fork() : nullptr;
+    hipStream_t cs = fk != nullptr ? fk->helper : st;                  // the chain's stream
+    if (fk != nullptr) {
+        AADG_HIP_TRY(hipEventRecord(fk->tables, st));
+        AADG_HIP_TRY(hipStreamWaitEvent(fk->helper, fk->tables, 0));
+    }
     if (chain)
         for (int k = 1; k < max_ops; ++k) {
             uint32_t* hist = hist0 + (size_t)k * hist_stage;
             if (((stats_mask >> k) & 1) && ls.n_stat[k] > 0) {
                 const int rc = launch_hist_fused(pool, ur.units, ls.stat_units[k], ls.n_stat[k], ls.n_stat_stencil[k], k, Hs, Ws, crop, lut,
-                                                 lut_stage_stride, hist, st);
+                                                 lut_stage_stride, hist, cs);
                 if (rc) return rc;
             }
-            hipLaunchKernelGGL(k_lut, dim3(n_late), dim3(256), 0, st, ur, k, N, ls.late_units, npix, Hs, Ws, crop, (const uint32_t*)hist0,
+            hipLaunchKernelGGL(k_lut, dim3(n_late), dim3(256), 0, cs, ur, k, N, ls.late_units, npix, Hs, Ws, crop, (const uint32_t*)hist0,
                                (const uint32_t*)hist, ls.pool_hist, lut);
             AADG_LAUNCH_CHECK();
         }
     if (ev_before) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_before), st));
-    {
+    if (fk == nullptr) {
         const int rc = launch_tiles(pool, masks, ur.units, ls.order, n_plain, n_sharp, ls.order + n_plain + n_sharp, n_generic, ls.n_generic_sharp, Hs, Ws,
                                     crop, dsk, tab, lut, lut_stage_stride, reinterpret_cast<uint32_t*>(ws8 + L.hbuf), out_img, out_lbl, st, ls.gen_chunk, ls.n_generic_wonly);
         if (rc) return rc;
+    } else {
+        uint32_t* hbuf = reinterpret_cast<uint32_t*>(ws8 + L.hbuf);
+        // helper: the chain is complete here
+        if (n_generic > 0) AADG_HIP_TRY(hipEventRecord(fk->chain, fk->helper));
+        // caller's stream: the early units' tiles (plain [0, n_plain - npl), Sharpness [0, n_sharp - nsl) of their class lists)
+        int rc = launch_tiles(pool, masks, ur.units, ls.order, n_plain - npl, n_sharp - nsl, nullptr, 0, 0, Hs, Ws, crop, dsk, tab, lut, lut_stage_stride,
+                              hbuf, out_img, out_lbl, st, 0, 0, ls.order + n_plain);
+        if (rc) return rc;
+        // helper: the late units' tiles
+        if (npl + nsl > 0) {
+            rc = launch_tiles(pool, masks, ur.units, ls.order + (n_plain - npl), npl, nsl, nullptr, 0, 0, Hs, Ws, crop, dsk, tab, lut, lut_stage_stride,
+                              hbuf, out_img, out_lbl, fk->helper, 0, 0, ls.order + n_plain + (n_sharp - nsl));
+            if (rc) return rc;
+        }
+        AADG_HIP_TRY(hipEventRecord(fk->done, fk->helper));
+        // caller's stream: the down-scaling units behind the chain
+        if (n_generic > 0) {
+            AADG_HIP_TRY(hipStreamWaitEvent(st, fk->chain, 0));
+            rc = launch_tiles(pool, masks, ur.units, nullptr, 0, 0, ls.order + n_plain + n_sharp, n_generic, ls.n_generic_sharp, Hs, Ws, crop, dsk, tab, lut,
+                              lut_stage_stride, hbuf, out_img, out_lbl, st, ls.gen_chunk, ls.n_generic_wonly);
+            if (rc) return rc;
+        }
+        AADG_HIP_TRY(hipStreamWaitEvent(st, fk->done, 0));               // join: the call is complete on the caller's stream
     }
     if (ev_after) AADG_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_after), st));
     return 0;
@@ -2632,6 +2694,7 @@ extern "C" int aadg_aug_u8_plan(const aadg_unit* units, int N, int P, int Hs, in
     if (N <= 0 || P <= 0 || Hs <= 0 || Ws <= 0 || crop <= 0) return AADG_E_BADARG;
     const bool tiles_ok = !((Ws & 3) || (crop & 3));
     int n_cls[6] = {0, 0, 0, 0, 0, 0}, n_stat[AADG_MAX_OPS], n_sten[AADG_MAX_OPS], n_late = 0, max_ops = 0, classes = 0, stats_mask = 0;
+    int n_cls_late[2] = {0, 0};                 // ABI 12: late units of the plain / Sharpness up-scaling classes (listed last in their class)
     for (int k = 0; k < AADG_MAX_OPS; ++k) n_stat[k] = n_sten[k] = 0;
     // pass 1: validation, class and statistics lists (late_units doubles as the per-unit class until the counting sort below)
     for (int i = 0; i < N; ++i) {
@@ -2682,6 +2745,7 @@ extern "C" int aadg_aug_u8_plan(const aadg_unit* units, int N, int P, int Hs, in
                 late = late || k >= 1;
             }
         late_units[i] = cls | (late ? 8 : 0);
+        if (late && cls < 2) ++n_cls_late[cls];
     }
     // slot k's list: the units with a Sharpness stencil in front of the op FIRST (k_hist_fused gives each of their tiles a workgroup of
     // its own), the others behind them; both parts keep the ascending unit order (stable partition; mixed lists are rare)
@@ -2704,9 +2768,11 @@ extern "C" int aadg_aug_u8_plan(const aadg_unit* units, int N, int P, int Hs, in
     int off[6];
     off[0] = 0;
     for (int c = 1; c < 6; ++c) off[c] = off[c - 1] + n_cls[c - 1];
+    int off_late[2] = {off[0] + n_cls[0] - n_cls_late[0], off[1] + n_cls[1] - n_cls_late[1]};
     for (int i = 0; i < N; ++i) {
-        const int v = late_units[i];
-        order[off[v & 7]++] = i;
+        const int v = late_units[i], c = v & 7;
+        if (c < 2 && (v & 8)) order[off_late[c]++] = i;                  // the late units of a class behind its early ones, both in unit order
+        else order[off[c]++] = i;
         if (v & 8) late_units[n_late++] = i;
     }
     summary[0] = n_cls[0]; summary[1] = n_cls[1]; summary[2] = n_cls[2] + n_cls[3] + n_cls[4]; summary[3] = n_cls[4];
@@ -2714,6 +2780,8 @@ extern "C" int aadg_aug_u8_plan(const aadg_unit* units, int N, int P, int Hs, in
     for (int k = 0; k < AADG_MAX_OPS; ++k) summary[8 + k] = n_stat[k];
     for (int k = 0; k < AADG_MAX_OPS; ++k) summary[8 + AADG_MAX_OPS + k] = n_sten[k];
     summary[8 + 2 * AADG_MAX_OPS] = n_cls[2];
+    summary[9 + 2 * AADG_MAX_OPS] = n_cls_late[0];
+    summary[10 + 2 * AADG_MAX_OPS] = n_cls_late[1];
     return 0;
 }
 
@@ -2751,6 +2819,8 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
     if (order != nullptr && (n_plain < 0 || n_sharp < 0 || n_generic < 0 || (long long)n_plain + n_sharp + n_generic > N)) return AADG_E_BADARG;
     if (order != nullptr && (lists->n_generic_sharp < 0 || lists->n_generic_sharp > n_generic)) return AADG_E_BADARG;
     if (order != nullptr && (lists->n_generic_wonly < 0 || lists->n_generic_wonly > n_generic - lists->n_generic_sharp)) return AADG_E_BADARG;
+    if (order != nullptr && (lists->n_plain_late < 0 || lists->n_plain_late > n_plain || lists->n_sharp_late < 0 || lists->n_sharp_late > n_sharp))
+        return AADG_E_BADARG;                                     // ABI 12
     const WsLayout L = ws_layout(N, Hs, Ws, crop);
     const int dsk = aug_dataset_arg(dataset, N, crop);
     if (ws_bytes < L.total) return AADG_E_WORKSPACE;

@@ -423,7 +423,9 @@ def time_steps(st, a, world, steps, warmup, first_epoch=0, want_kernel_events=Tr
     for i in range(steps):
         marks[i].record()
         if want_kernel_events:
-            _lib.PROFILE_EVENTS, _lib.PROFILE_CALL_EVENTS = kpairs[i], cpairs[i]
+            # even steps time the tile kernel (the library then keeps the whole call on one stream), odd steps the whole call (with the
+            # late units' chain on the library's helper stream beside the tile kernel: ABI 12)
+            _lib.PROFILE_EVENTS, _lib.PROFILE_CALL_EVENTS = (kpairs[i], None) if i % 2 == 0 else (None, cpairs[i])
         if want_kernel_events:
             _lib.PROFILE_MIX = []
         nr = st.search_step(first_epoch + warmup + i, max_iters=1)[3]
@@ -441,8 +443,10 @@ def time_steps(st, a, world, steps, warmup, first_epoch=0, want_kernel_events=Tr
     if torch.distributed.is_initialized():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
-    kern_ms = [p[0].elapsed_time(p[1]) for p in kpairs] if want_kernel_events else []
-    call_ms = [p[0].elapsed_time(p[1]) for p in cpairs] if want_kernel_events else []
+    kern_ms = [p[0].elapsed_time(p[1]) for i, p in enumerate(kpairs) if i % 2 == 0] if want_kernel_events else []
+    call_ms = [p[0].elapsed_time(p[1]) for i, p in enumerate(cpairs) if i % 2 == 1] if want_kernel_events else []
+    if want_kernel_events and not call_ms:                  # a one-step run: the kernel's bracket stands for the call
+        call_ms = list(kern_ms)
     global LAST_MIXES, LAST_BN_COLLECTIVES
     LAST_MIXES = mixes
     LAST_BN_COLLECTIVES = _lib.BN_SYNC_COLLECTIVES[0] / max(steps, 1)
@@ -723,7 +727,7 @@ def rvs_1024_leg(n_units=144, size=1024, cfg_rel=os.path.join("experiments", "rv
     n_flow = None
     _lib.PROFILE_MIX = []
     for i in range(R):
-        _lib.PROFILE_EVENTS, _lib.PROFILE_CALL_EVENTS = kp[i], cp[i]
+        _lib.PROFILE_EVENTS, _lib.PROFILE_CALL_EVENTS = (kp[i], None) if i % 2 == 0 else (None, cp[i])      # (as time_steps: kernel / call in turn)
         try:
             next(it)
         except StopIteration:
@@ -742,7 +746,8 @@ def rvs_1024_leg(n_units=144, size=1024, cfg_rel=os.path.join("experiments", "rv
     n_flow = _lib.launch_hints(units, Hs, Hs, size)[3]
     kb = unit_bytes(units, Hs, Hs, size, K, False)
     sb = unit_bytes(units, Hs, Hs, size, K, True)
-    k_ms, c_ms = float(np.mean([p[0].elapsed_time(p[1]) for p in kp])), float(np.mean([p[0].elapsed_time(p[1]) for p in cp]))
+    k_ms = float(np.mean([p[0].elapsed_time(p[1]) for i, p in enumerate(kp) if i % 2 == 0]))
+    c_ms = float(np.mean([p[0].elapsed_time(p[1]) for i, p in enumerate(cp) if i % 2 == 1]))
     tr = (committed("r06_rvs1024_traffic.json") or committed("r05_rvs1024_traffic.json")) if size == 1024 else None
     return {"workload": "%s: %s pipeline, %dx%d crops from %dx%d sources, "
                         "%d units per batch (hot path only: augmentation call)" % (label, cfg_rel, size, size, Hs, Hs, len(units)),
@@ -1036,13 +1041,14 @@ def main():
     sync()
     t0 = time.perf_counter()
     for i in range(HK):
-        _lib.PROFILE_EVENTS, _lib.PROFILE_CALL_EVENTS = hk_pairs[i][:2], hk_pairs[i][2:]
+        # one step in four brackets the tile kernel (one stream inside the call), the others the whole call (helper stream on: ABI 12)
+        _lib.PROFILE_EVENTS, _lib.PROFILE_CALL_EVENTS = (hk_pairs[i][:2], None) if i % 4 == 0 else (None, hk_pairs[i][2:])
         hot_step()
     _lib.PROFILE_EVENTS = _lib.PROFILE_CALL_EVENTS = None
     sync()
     hot_ms = (time.perf_counter() - t0) / HK * 1e3
-    hot_kern_ms = sum(p[0].elapsed_time(p[1]) for p in hk_pairs) / HK
-    hot_call_ms = sum(p[2].elapsed_time(p[3]) for p in hk_pairs) / HK
+    hot_kern_ms = float(np.mean([p[0].elapsed_time(p[1]) for i, p in enumerate(hk_pairs) if i % 4 == 0]))
+    hot_call_ms = float(np.mean([p[2].elapsed_time(p[3]) for i, p in enumerate(hk_pairs) if i % 4 != 0]))
     # a second pass with events around every stage: the GPU time of each stage's kernels.  The host is the slower side of this loop, so
     # every stage is queued behind a blocker (a spin kernel of ~3 ms, torch.cuda._sleep): the stage's launches are all enqueued while
     # the blocker runs and then execute back to back -- the event pair (recorded behind the blocker / behind the last launch) brackets
@@ -1128,8 +1134,10 @@ def main():
                          "frac": call_bytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "frac_survey_8d_bytes": sbytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "pool_statistics": "cached" if not a.no_pool_stats else "per call"}
-        detail["roofline.per_step"] = [dict(m, kernel_us=round(k * 1e3, 1), call_us=round(c * 1e3, 1))
-                                       for m, k, c in zip(main_mixes, kern_ms_l, call_ms_l)]
+        # (even steps bracket the tile kernel, odd steps the whole call: time_steps)
+        detail["roofline.per_step"] = [dict(m, **({"kernel_us": round(kern_ms_l[i // 2] * 1e3, 1)} if i % 2 == 0 else
+                                                  {"call_us": round(call_ms_l[i // 2] * 1e3, 1)} if i // 2 < len(call_ms_l) else {}))
+                                       for i, m in enumerate(main_mixes)]
         if traffic:
             roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes), per unit x units" % traffic.get("file", "r04_traffic_k_fused3.json")
         if prof:

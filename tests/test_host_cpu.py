@@ -341,7 +341,7 @@ def test_launch_plan_classes_statistics_and_late_units():
         unit([(BRI, 1.1)], sw=70, sh=40),               # 11 shrinks y only: generic, two passes
         unit([(SHA, 1.2)], sw=40, sh=70),               # 12 shrinks x only but chains a stencil: generic with a stencil (two passes)
     ])
-    classes, stats_mask, order, counts, stat_lists, late, _, n_wonly = _lib.launch_plan(units, H, W, crop)
+    classes, stats_mask, order, counts, stat_lists, late, _, n_wonly, _late_counts = _lib.launch_plan(units, H, W, crop)
     assert classes == 1 | 2 | 4
     assert counts == (6, 1, 4, 2) and n_wonly == 1                   # ABI 9: unit 7 (shrinks the width only, no stencil) leads the generic run
     assert sorted(order[:6].tolist()) == [0, 1, 2, 3, 4, 6] and order[6] == 5 and order[7:11].tolist() == [7, 11, 10, 12] and sorted(order[11:].tolist()) == [8, 9]
