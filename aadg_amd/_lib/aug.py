@@ -132,6 +132,8 @@ def pool_histograms(pool):
 
 # optional (start, stop) torch.cuda.Event pair recorded around the dominant kernel of the next
 # aug_u8_forward call(s); used by bench.py to time that kernel live on the launch stream
+# False: the library keeps the whole call on the caller's stream (A/B of the helper-stream fork, ABI 12)
+AUG_FORK = True
 PROFILE_EVENTS = None
 # optional list: every aug_u8_forward call appends the op mix of its units (bench.py: the tile kernel's duration follows it)
 PROFILE_MIX = None
@@ -200,6 +202,8 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
     lists.n_plain, lists.n_sharp, lists.n_generic, lists.n_generic_sharp = n_plain, n_sharp, n_generic, n_generic_sharp
     lists.n_generic_wonly = summary[8 + 2 * MAX_OPS]
     lists.n_plain_late, lists.n_sharp_late = summary[9 + 2 * MAX_OPS], summary[10 + 2 * MAX_OPS]
+    if not AUG_FORK:
+        lists.n_plain_late, lists.n_sharp_late = n_plain, n_sharp       # every unit "late": nothing to run beside the chain, one stream
     lists.gen_chunk = int(gen_chunk)
     for k in range(MAX_OPS):
         lists.stat_units[k] = d_units.data_ptr() + nb_units + 4 * N * (1 + k)

@@ -242,6 +242,10 @@ class SearchState(object):
         self.controller, self.M, _ = load_ddp_controller(ngpus_per_node, args, config)
         self.discriminator, _, _ = load_ddp_discriminator(ngpus_per_node, args, config)
         rank, world = adist.world()
+        # The augmentation call's helper stream (ABI 12: the late units' statistics chain beside the tile kernel) stays off in a
+        # data-parallel job: beside RCCL's communicator streams it cost 7-26 ms per step on the boxes measured (one rank over RCCL: 189-209
+        # against 182 ms, scripts/r6/exp_dist_knobs.py; more hardware queues change nothing) for 0.02 ms of a 180 ms step.
+        _lib.AUG_FORK = not adist.is_dist()
         T.set_row_shard(rank, world, getattr(args, 'placement', 'row'), force=bool(getattr(args, 'force_sharded', False)))
         if adist.is_dist():
             # the controller is replicated, not wrapped (identical rewards -> identical updates); DDP broadcast the wrapped
