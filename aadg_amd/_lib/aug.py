@@ -46,7 +46,7 @@ def validate_units(units, P, Hs, Ws):
 
 
 def launch_plan(units, Hs, Ws, crop):
-    """(classes, stats_mask, order, counts, stat_lists, late, n_stat_stencil, n_generic_wonly, (n_plain_late, n_sharp_late)) for aadg_aug_u8_forward_ex2 -- mirrors unit_flow() in
+    """(classes, stats_mask, order, counts, stat_lists, late, n_stat_stencil, n_generic_wonly, (n_plain_early, n_sharp_early)) for aadg_aug_u8_forward_ex2 -- mirrors unit_flow() in
     csrc/aug_u8.hip.  n_generic_wonly (ABI 9): the first ones of the generic run shrink the width only and chain no stencil (one-pass tile).
     order: unit indices grouped by tile class (plain up-scaling, up-scaling with a Sharpness stencil, generic, staged);
     counts = (n_plain, n_sharp, n_generic, n_generic_sharp: the last ones of the generic run chain a Sharpness stencil); stat_lists[k]: the units whose k-th op needs a pixel pass for its image statistics;
@@ -96,7 +96,7 @@ def launch_plan(units, Hs, Ws, crop):
     # "late" units: a slot k >= 1 needs a pixel pass (include/aadg_hip.h: aadg_aug_lists.late_units)
     late = np.nonzero(pixel_pass[:, 1:].any(axis=1))[0].astype(np.int32)
     return (classes, stats_mask, order, counts, stat_lists, late, n_stencil, int((cls == 2).sum()),
-            (int((late_flag & (cls == 0)).sum()), int((late_flag & (cls == 1)).sum())))
+            (int((~late_flag & (cls == 0)).sum()), int((~late_flag & (cls == 1)).sum())))
 
 
 def launch_hints(units, Hs, Ws, crop):
@@ -110,7 +110,7 @@ class AugLists(ctypes.Structure):
                 ("stat_units", ctypes.c_void_p * MAX_OPS), ("n_stat", ctypes.c_int32 * MAX_OPS), ("pool_hist", ctypes.c_void_p),
                 ("late_units", ctypes.c_void_p), ("n_late", ctypes.c_int32), ("n_generic_sharp", ctypes.c_int32),
                 ("n_stat_stencil", ctypes.c_int32 * MAX_OPS), ("gen_chunk", ctypes.c_int32), ("n_generic_wonly", ctypes.c_int32),
-                ("n_plain_late", ctypes.c_int32), ("n_sharp_late", ctypes.c_int32)]
+                ("n_plain_early", ctypes.c_int32), ("n_sharp_early", ctypes.c_int32)]
 
 
 HIST_STRIDE = 772      # AADG_HIST_STRIDE
@@ -201,9 +201,7 @@ def aug_u8_forward(pool, masks, units, crop, dataset, out_img=None, out_lbl=None
     lists.order = d_units.data_ptr() + nb_units
     lists.n_plain, lists.n_sharp, lists.n_generic, lists.n_generic_sharp = n_plain, n_sharp, n_generic, n_generic_sharp
     lists.n_generic_wonly = summary[8 + 2 * MAX_OPS]
-    lists.n_plain_late, lists.n_sharp_late = summary[9 + 2 * MAX_OPS], summary[10 + 2 * MAX_OPS]
-    if not AUG_FORK:
-        lists.n_plain_late, lists.n_sharp_late = n_plain, n_sharp       # every unit "late": nothing to run beside the chain, one stream
+    lists.n_plain_early, lists.n_sharp_early = (summary[9 + 2 * MAX_OPS], summary[10 + 2 * MAX_OPS]) if AUG_FORK else (0, 0)     # (0, 0): one stream
     lists.gen_chunk = int(gen_chunk)
     for k in range(MAX_OPS):
         lists.stat_units[k] = d_units.data_ptr() + nb_units + 4 * N * (1 + k)

@@ -2627,12 +2627,12 @@ int forward_cached(const uint8_t* pool, const uint8_t* masks, const UnitRef& ur,
                        (pixel_pass && chain) ? hist0 : (uint32_t*)nullptr);
     AADG_LAUNCH_CHECK();
     // Round 6 (ABI 12): the late units' chain -- histogram pass(es), their byte maps -- and their tiles run on a helper stream BESIDE the tile
-    // kernel of the units that wait for nothing (the planner lists the late units last inside the plain and the Sharpness class:
-    // n_plain_late / n_sharp_late).  The early tiles read the tables and the early units' byte maps only, all complete behind
+    // kernel of the units that wait for nothing (the planner lists them first inside the plain and the Sharpness class:
+    // n_plain_early / n_sharp_early; a zero-initialised struct says "none": one stream).  The early tiles read the tables and the early units' byte maps only, all complete behind
     // k_luts_tables; the chain writes the late units' histograms and byte maps only.  The down-scaling units (any of them may be late)
     // follow on the caller's stream behind the chain.  Not while the caller times the tile kernel (ev_before / ev_after): one stream then.
-    const int npl = ls.n_plain_late, nsl = ls.n_sharp_late;
-    const int n_early = (n_plain - npl) + (n_sharp - nsl);
+    const int npl = n_plain - ls.n_plain_early, nsl = n_sharp - ls.n_sharp_early;      // the late units close their class
+    const int n_early = ls.n_plain_early + ls.n_sharp_early;
     AugFork* fk = (chain && ev_before == nullptr && ev_after == nullptr && n_early > 0)
                       ? aug_fork() : nullptr;
     hipStream_t cs = fk != nullptr ? fk->helper : st;                  // the chain's stream
@@ -2780,8 +2780,8 @@ extern "C" int aadg_aug_u8_plan(const aadg_unit* units, int N, int P, int Hs, in
     for (int k = 0; k < AADG_MAX_OPS; ++k) summary[8 + k] = n_stat[k];
     for (int k = 0; k < AADG_MAX_OPS; ++k) summary[8 + AADG_MAX_OPS + k] = n_sten[k];
     summary[8 + 2 * AADG_MAX_OPS] = n_cls[2];
-    summary[9 + 2 * AADG_MAX_OPS] = n_cls_late[0];
-    summary[10 + 2 * AADG_MAX_OPS] = n_cls_late[1];
+    summary[9 + 2 * AADG_MAX_OPS] = n_cls[0] - n_cls_late[0];           // ABI 12: the units of the class that wait for no statistics pass
+    summary[10 + 2 * AADG_MAX_OPS] = n_cls[1] - n_cls_late[1];
     return 0;
 }
 
@@ -2819,7 +2819,7 @@ extern "C" int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks
     if (order != nullptr && (n_plain < 0 || n_sharp < 0 || n_generic < 0 || (long long)n_plain + n_sharp + n_generic > N)) return AADG_E_BADARG;
     if (order != nullptr && (lists->n_generic_sharp < 0 || lists->n_generic_sharp > n_generic)) return AADG_E_BADARG;
     if (order != nullptr && (lists->n_generic_wonly < 0 || lists->n_generic_wonly > n_generic - lists->n_generic_sharp)) return AADG_E_BADARG;
-    if (order != nullptr && (lists->n_plain_late < 0 || lists->n_plain_late > n_plain || lists->n_sharp_late < 0 || lists->n_sharp_late > n_sharp))
+    if (order != nullptr && (lists->n_plain_early < 0 || lists->n_plain_early > n_plain || lists->n_sharp_early < 0 || lists->n_sharp_early > n_sharp))
         return AADG_E_BADARG;                                     // ABI 12
     const WsLayout L = ws_layout(N, Hs, Ws, crop);
     const int dsk = aug_dataset_arg(dataset, N, crop);

@@ -141,10 +141,13 @@ typedef struct aadg_aug_lists {
     /* ABI 9: how many of the n_generic units -- the FIRST ones in `order`, none of them a Sharpness unit -- shrink the WIDTH only (scaled
      * height >= source height, source width >= 8): they run through the one-pass tile k_fused3w instead of the two passes. */
     int32_t n_generic_wonly;
-    /* ABI 12: how many of the n_plain / n_sharp units -- the LAST ones of their class in `order` -- are late units.  With the cached-statistics
-     * call the library runs the late units' chain (histogram passes, byte maps) and their tiles on a helper stream beside the tile kernel of
-     * the other units and joins before it returns to the caller's stream (not while ev_before / ev_after time the tile kernel). */
-    int32_t n_plain_late, n_sharp_late;
+    /* ABI 12: how many of the n_plain / n_sharp units -- the FIRST ones of their class in `order` -- wait for no statistics pass (the late
+     * units close their class).  With the cached-statistics call the library runs the late units' chain (histogram passes, byte maps) and
+     * their tiles on a helper stream beside the tile kernel of these early units and joins before it returns to the caller's stream (not
+     * while ev_before / ev_after time the tile kernel).  0 / 0 (a zero-initialised struct, or lists whose classes are not ordered that way):
+     * the call stays on the caller's stream.  The helper stream and its events are one per process: forking calls must be stream-ordered
+     * with one another (they already are: they share the caller's workspace). */
+    int32_t n_plain_early, n_sharp_early;
 } aadg_aug_lists;
 /* per-image histograms of a source pool [P, Hs, Ws, 3] (what PIL's Image.histogram() / ImageStat.Stat(convert('L')).mean read:
  * data/basic.py AutoContrast / Equalize / Contrast via ImageOps / ImageEnhance) */
@@ -161,7 +164,7 @@ int aadg_aug_u8_forward_ex2(const uint8_t* pool, const uint8_t* masks, int P, in
  *   order [N]: unit indices by tile class;  stat_units [AADG_MAX_OPS][N]: per op slot the units that need a statistics pass;
  *   late_units [N];  summary [11 + 2 * AADG_MAX_OPS] = n_plain, n_sharp, n_generic, n_generic_sharp, n_late, classes_hint, stats_mask_hint,
  *   max_ops, n_stat[0 .. AADG_MAX_OPS), n_stat_stencil[0 .. AADG_MAX_OPS) (ABI 7; stat_units[k] lists the stencil units first),
- *   n_generic_wonly (ABI 9), n_plain_late, n_sharp_late (ABI 12: summary [11 + 2 * AADG_MAX_OPS]; inside the plain and the Sharpness class of
+ *   n_generic_wonly (ABI 9), n_plain_early, n_sharp_early (ABI 12: summary [11 + 2 * AADG_MAX_OPS]; inside the plain and the Sharpness class of
  *   `order` the late units come last).  (The reference does this work implicitly, op by op, in PIL: data/policy.py:45-61.) */
 int aadg_aug_u8_plan(const aadg_unit* units, int N, int P, int Hs, int Ws, int crop, int32_t* order, int32_t* stat_units,
                      int32_t* late_units, int32_t* summary);

@@ -187,12 +187,12 @@ def test_round2_entry_points_validate_arguments():
     lists = _lib.AugLists()
     lists.gen_chunk = -1
     assert lib.aadg_aug_u8_forward_ex2(one, one, 1, 8, 8, one, 4, 2, 8, 0, one, one, one, 1 << 30, z, 0, -1, z, z, ctypes.byref(lists)) == -1
-    assert ctypes.sizeof(_lib.AugLists) == 8 + 16 + 8 * _lib.MAX_OPS + 4 * _lib.MAX_OPS + 8 + 8 + 8 + 4 * _lib.MAX_OPS + 8 + 8   # mirror of aadg_aug_lists (n_generic_sharp fills the padding behind n_late; ABI 7: n_stat_stencil, gen_chunk; ABI 9: n_generic_wonly in the former tail padding; ABI 12: n_plain_late, n_sharp_late)
+    assert ctypes.sizeof(_lib.AugLists) == 8 + 16 + 8 * _lib.MAX_OPS + 4 * _lib.MAX_OPS + 8 + 8 + 8 + 4 * _lib.MAX_OPS + 8 + 8   # mirror of aadg_aug_lists (n_generic_sharp fills the padding behind n_late; ABI 7: n_stat_stencil, gen_chunk; ABI 9: n_generic_wonly in the former tail padding; ABI 12: n_plain_early, n_sharp_early)
     lists = _lib.AugLists()
     lists.order, lists.n_generic, lists.n_generic_sharp, lists.n_generic_wonly = 16, 3, 2, 2      # ABI 9: more width-only units than plain generic ones
     assert lib.aadg_aug_u8_forward_ex2(one, one, 1, 8, 8, one, 4, 2, 8, 0, one, one, one, 1 << 30, z, 0, -1, z, z, ctypes.byref(lists)) == -1
     lists = _lib.AugLists()
-    lists.order, lists.n_plain, lists.n_plain_late = 16, 2, 3                                      # ABI 12: more late units than the class holds
+    lists.order, lists.n_plain, lists.n_plain_early = 16, 2, 3                                     # ABI 12: more early units than the class holds
     assert lib.aadg_aug_u8_forward_ex2(one, one, 1, 8, 8, one, 4, 2, 8, 0, one, one, one, 1 << 30, z, 0, -1, z, z, ctypes.byref(lists)) == -1
 
 
@@ -250,10 +250,10 @@ def test_host_planner_matches_python_statement():
         summary = (ctypes.c_int32 * (11 + 2 * K))()
         rc = lib.aadg_aug_u8_plan(cont.ctypes.data, N, P, H, H, crop, order.ctypes.data, stat.ctypes.data, late.ctypes.data, summary)
         assert rc == 0
-        classes, stats_mask, want_order, counts, stat_lists, want_late, n_sten, n_wonly, n_cls_late = _lib.launch_plan(units, H, H, crop)
-        assert (summary[9 + 2 * K], summary[10 + 2 * K]) == n_cls_late     # ABI 12: the late units close the plain / Sharpness class
-        for c0, nc, nl in ((0, counts[0], n_cls_late[0]), (counts[0], counts[1], n_cls_late[1])):
-            assert set(order[c0 + nc - nl:c0 + nc].tolist()) <= set(want_late.tolist()) and not set(order[c0:c0 + nc - nl].tolist()) & set(want_late.tolist())
+        classes, stats_mask, want_order, counts, stat_lists, want_late, n_sten, n_wonly, n_cls_early = _lib.launch_plan(units, H, H, crop)
+        assert (summary[9 + 2 * K], summary[10 + 2 * K]) == n_cls_early    # ABI 12: the units that wait for no statistics pass lead the plain / Sharpness class
+        for c0, nc, ne in ((0, counts[0], n_cls_early[0]), (counts[0], counts[1], n_cls_early[1])):
+            assert set(order[c0 + ne:c0 + nc].tolist()) <= set(want_late.tolist()) and not set(order[c0:c0 + ne].tolist()) & set(want_late.tolist())
         assert tuple(summary[:4]) == tuple(counts) and summary[5] == classes and summary[6] == stats_mask
         assert summary[8 + 2 * K] == n_wonly                             # ABI 9: the width-only units lead the generic run
         seen_wonly = seen_wonly or 0 < n_wonly < counts[2] - counts[3]

@@ -535,3 +535,46 @@ def test_width_only_units_one_pass_tile_vs_oracle(hip, oracle, H, W, crop, kind)
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.equal(o_img, got_img) and torch.equal(o_lbl, got_lbl)
+
+
+@pytest.mark.parametrize("H,crop,sr", [(64, 64, (1.0, 1.5)), (96, 64, (0.5, 2.0))])
+def test_helper_stream_fork_is_the_same_call(hip, oracle, H, crop, sr):
+    """ABI 12: with cached pool statistics the library runs the late units' chain (histogram pass, byte maps) and their tiles on a helper
+    stream beside the tile kernel of the other units.  The planner lists the late units last inside the plain / Sharpness class; the call
+    with the fork (default) equals the one-stream call (`_lib.AUG_FORK = False`) and the oracle bit for bit, back to back on one workspace
+    and with other work queued on the caller's stream in front of and behind it."""
+    from helpers import random_units, synth_pool
+    rs = np.random.RandomState(7 + H)
+    P, N = 5, 120
+    imgs, msks = synth_pool(rs, P, H, H)
+    units = random_units(rs, N, P, H, H, crop, sr, L=3)
+    # late units of both up-scaling classes: a statistics op behind Color (2: equalize behind 6: color) / behind Sharpness
+    units['op'][:30, 0] = 6; units['farg'][:30, 0] = np.float32(1.4); units['op'][:30, 1] = np.tile([0, 2, 5], 10); units['farg'][:30, 1] = np.float32(1.2)
+    units['n_ops'][:30] = np.maximum(units['n_ops'][:30], 2)
+    units['op'][30:44, 0] = 8; units['farg'][30:44, 0] = np.float32(1.6); units['op'][30:44, 1] = 5; units['farg'][30:44, 1] = np.float32(0.7)
+    units['n_ops'][30:44] = np.maximum(units['n_ops'][30:44], 2)
+    plan = hip.launch_plan(units, H, H, crop)
+    n_plain, n_sharp = plan[3][0], plan[3][1]
+    npe, nse = plan[8]
+    npl, nsl = n_plain - npe, n_sharp - nse
+    assert plan[5].size > 0 and (npl > 0 or nsl > 0) and npe + nse > 0                               # something to fork, something beside it
+    order, late = plan[2], set(plan[5].tolist())
+    assert all(int(u) in late for u in order[n_plain - npl:n_plain]) and not any(int(u) in late for u in order[:n_plain - npl])
+    want_img, want_lbl = oracle.aug_units(imgs, msks, units, crop, 0)
+    d_img, d_msk = torch.from_numpy(imgs).cuda(), torch.from_numpy(msks).cuda()
+    ph = hip.pool_histograms(d_img)
+    busy = torch.randn(1 << 22, device="cuda")
+    outs = {}
+    for fork in (True, False, True):
+        hip.AUG_FORK = fork
+        try:
+            for _ in range(3):
+                busy.mul_(1.0001)                              # work in front of the call on the caller's stream
+                got = hip.aug_u8_forward(d_img, d_msk, units, crop, 0, pool_hist=ph)
+                busy.add_(1e-6)                                # ... and behind it
+        finally:
+            hip.AUG_FORK = True
+        torch.cuda.synchronize()
+        assert np.array_equal(got[0].cpu().numpy(), want_img) and np.array_equal(got[1].cpu().numpy(), want_lbl), fork
+        outs[fork] = got
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
