@@ -21,6 +21,9 @@ that design:
     optimizer.step()` reads averaged gradients exactly as under DDP (count-weighted mean: `RowPlan.loss_weight` on the loss).
 
 Works on CPU tensors over gloo too (no streams there): tests/test_dist_cpu.py.
+
+Not provided (as under DDP without `no_sync()`): accumulating several backward passes into `.grad` before one optimizer step -- every pass
+ends with its own all-reduce.  Every rank must run the same program (the same set of parameters takes part in a pass on every rank).
 """
 import torch
 import torch.distributed as dist
