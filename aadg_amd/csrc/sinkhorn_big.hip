@@ -237,12 +237,13 @@ __global__ __launch_bounds__(256) void k_big_cost_x3(const int* cloud_off, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
     for (int k0 = 0; k0 < E; k0 += CXK) {
-        // 128 rows x 16 chunks of 4 K-values per operand: 8 chunks per thread and operand (E % 4 == 0: the caller checks)
+        // 128 rows x CXK / 4 chunks of 4 K-values per operand (E % 4 == 0: the caller checks)
         __syncthreads();
+        constexpr int NCH = CXK / 4, PER = CX * NCH / 256;           // chunks of 4 K-values per row; chunks per thread and operand
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int id = tid + 256 * (i & 7), r = id >> 4, c = id & 15, k = k0 + 4 * c;
-            const bool isb = i >= 8;
+        for (int i = 0; i < 2 * PER; ++i) {
+            const int id = tid + 256 * (i % PER), r = id / NCH, c = id % NCH, k = k0 + 4 * c;
+            const bool isb = i >= PER;
             const int gr = (isb ? j0 : i0) + r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gr < (isb ? cols : rows) && k < E) v = *reinterpret_cast<const float4*>((isb ? Bm : Am) + (size_t)gr * E + k);
