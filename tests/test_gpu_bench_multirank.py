@@ -1,6 +1,7 @@
 """GPU: the N > 1 path of bench.py on the one GPU of the test box -- `python bench.py --gpus 2 --all_ranks_on_gpu0` starts its
 two ranks itself (torch.distributed.run, gloo because RCCL refuses two ranks on one device), shards the (domain, policy) units,
-all-gathers the embeddings, all-reduces the BatchNorm sums between the HIP kernels and the gradients through DDP.
+all-gathers the embeddings, all-reduces the BatchNorm sums between the HIP kernels and the gradients through the package's own
+bucketed reducer (aadg_amd/reducer.py; DistributedDataParallel until round 5).
 
 With synchronised statistics, a float32 backbone and dropout off, the sharded job computes the SAME function as the single
 rank, for both placement laws and for an uneven 3-rank split: the first step's rewards (forward pass) agree to rounding, and
