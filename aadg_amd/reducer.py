@@ -22,8 +22,10 @@ that design:
 
 Works on CPU tensors over gloo too (no streams there): tests/test_dist_cpu.py.
 
-Not provided (as under DDP without `no_sync()`): accumulating several backward passes into `.grad` before one optimizer step -- every pass
-ends with its own all-reduce.  Every rank must run the same program (the same set of parameters takes part in a pass on every rank).
+Several backward passes before one optimizer step accumulate as under DDP without `no_sync()`: every pass ends with its own all-reduce; a
+gradient that is already in its bucket (the average of the earlier passes, equal on every rank) goes through the sum / world unchanged
+and the new local contribution is added to it before the bucket leaves (tests/dist_worker.py: check_reducer, the two-pass step).  Every
+rank must run the same program (the same set of parameters takes part in a pass on every rank).
 """
 import torch
 import torch.distributed as dist
@@ -207,8 +209,10 @@ class GradReducer(torch.nn.Module):
             return
         for b in self._buckets[self._next:]:
             for k, done in enumerate(b.arrived):
-                if not done:
-                    b.views[k].zero_()           # took no part in this pass on this rank: contributes zero, .grad stays as it is
+                # took no part in this pass.  If .grad IS the view it holds what an earlier pass (or an in-place zero_grad) left there,
+                # the same on every rank: sum / world gives it back, as under DDP.  Otherwise the slot is scratch: contribute zero
+                if not done and not (b.params[k].grad is not None and b.params[k].grad.data_ptr() == b.views[k].data_ptr()):
+                    b.views[k].zero_()
             self._launch(b)
         self._next = len(self._buckets)
         inv = 1.0 / self.world

@@ -220,6 +220,19 @@ def check_reducer(rank, world, plan):
             assert p.grad is not None and torch.allclose(p.grad, q.grad, atol=2e-6), (step, n, (p.grad - q.grad).abs().max())
         opt.step(); ropt.step()
     assert red.stats["buckets"] >= 3 and red._rebuilt
+    # two backward passes into one optimizer step (as DDP without no_sync(): each pass all-reduces, .grad accumulates); the second pass
+    # leaves the first layers out -- their gradient is the first pass's average and must come through the second all-reduce unchanged
+    for none in (True, False):
+        opt.zero_grad(set_to_none=none); ropt.zero_grad(set_to_none=none)
+        (((red(x[rows]) - y[rows]) ** 2).mean() * plan.loss_weight).backward()
+        ((ref(x) - y) ** 2).mean().backward()
+        z = torch.randn(N, 16, generator=torch.Generator().manual_seed(9))
+        ((red.module[5](z[rows]) ** 2).mean() * plan.loss_weight).backward()              # the last layer only
+        (ref[5](z) ** 2).mean().backward()
+        for (n, p), q in zip(net.named_parameters(), ref.parameters()):
+            if not n.startswith("unused"):
+                assert torch.allclose(p.grad, q.grad, atol=3e-6), ("two passes", none, n, (p.grad - q.grad).abs().max())
+        opt.step(); ropt.step()
     flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     every = adist.all_gather([flat[None]])[0]
     assert all(torch.equal(every[0], every[r]) for r in range(world)), "replicas diverged"
