@@ -2576,10 +2576,10 @@ int run_stages(const Bufs& bufs, const UnitRef& ur, int N, int Hs, int Ws, int c
 // byte map that waits for no pixel pass (all of them for most units).  What is left is the late units' chain -- per slot k >= 1: histogram
 // pass over the image after k ops, then the maps of the late units -- and the tiles:
 //     k_luts_tables | k_hist_fused(1) k_lut(1, late) ... | k_fused3 (up-scaling units) | k_gen_hpass + k_gen_vpass (down-scaling units, in chunks)
-// (Measured and dropped: the chain and the late units' tiles on a second, highest-priority stream beside the tile kernel of the other
-// units -- 268 instead of 278 us per 168-unit call once k_hist_fused fitted the LDS slot a retiring tile workgroup leaves (35 KiB; with
-// 51 KiB it starved until the tile kernel had drained).  3.5 % of the call for a fork / join, a second kernel name and a tile-kernel
-// duration that no longer says how fast the tile kernel is.)
+// (Round 5 measured the chain and the late units' tiles on a second, highest-priority stream and dropped it: 268 instead of 278 us per
+// 168-unit call, against a second kernel name and a tile-kernel duration that no longer says how fast the tile kernel is.  Round 6 took it
+// up again in the form below -- the planner lists the units that wait for nothing first, the fork is off whenever the caller times the
+// tile kernel -- because the chain had become the largest part of the call outside the tile kernel: whole 512^2 call 0.566 -> 0.60-0.63.)
 // the `dataset` argument of the kernels that write the outputs: + AUG_STREAM_OUT when the batch's outputs exceed AUG_STREAM_BYTES
 static inline int aug_dataset_arg(int dataset, int N, int crop) {
     const size_t K = dataset == AADG_DATASET_OPTIC ? 2 : 1;
