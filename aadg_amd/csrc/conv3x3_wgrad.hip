@@ -29,6 +29,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int W3_BM = 64, W3_BN = 64;
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));     // a 16-byte LDS read at 4-byte alignment
 
 // X3 = true ("f32x3"): dY / X are float32; a loaded float4 (4 pixels) is split into (hi, lo) bfloat16 halves on its way to LDS (two planes
 // of the layout below) and the tap fragments are built per plane; products hi*hi + hi*lo + lo*hi, float32 accumulation.  Both planes are
@@ -202,6 +203,22 @@ __global__ __launch_bounds__(256, (W == 128 || X3) ? 1 : 2) void k_wgrad3x3(cons
             bf16x8 f0[PL][KS_N], f1[PL][KS_N], f2[PL][KS_N];
 #pragma unroll
             for (int pl = 0; pl < PL; ++pl) {
+                if (D == 2 && KSPLIT) {
+                    // dilation 2 = a shift by one 32-bit word: the shifted fragments as 4-byte-aligned 16-byte LDS reads (two ds_read2_b32
+                    // each, straight into the MFMA operand registers -- no VALU); the words beyond the row ends are the zero pads.
+                    // Round 6, measured against the lane-exchange path below: 0.727 vs 0.80 ms at 64 x 64 (256 -> 256, 36 images: the
+                    // K-split tile, two waves share the fragments' rows), but 2.43 vs 2.31 ms at 32 x 32 (512 -> 512, 144 images) --
+                    // there the register moves of the exchange cost less than 2.25x the LDS read passes (scripts/r6/w3_time.py)
+#pragma unroll
+                    for (int j = 0; j < KS_N; ++j) {
+                        const uint16_t* p = xb[kh] + pl * X_PLANE + (ks0 + j) * 16;
+                        const u32x4_a4 l = *reinterpret_cast<const u32x4_a4*>(p - 2), r = *reinterpret_cast<const u32x4_a4*>(p + 2);
+                        f0[pl][j] = frag(l.x, l.y, l.z, l.w);
+                        f1[pl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
+                        f2[pl][j] = frag(r.x, r.y, r.z, r.w);
+                    }
+                    continue;
+                }
                 // sub-steps ks0 - 1 .. ks0 + KS_N (clamped to the row): the neighbours' edge words come from them
                 uint4 cur[KS_N + 2];
 #pragma unroll

@@ -1,0 +1,21 @@
+"""The dilation-2 weight gradient of the 3x3 convolution (k_wgrad3x3<W, 2>): time and result checksum on the layer-4 shape and a 64-pixel one.
+    python scripts/r6/w3_time.py            (A/B against a variant library: AADG_LIB_PATH=exp_libs/<x>.so PYTHONPATH=scripts/ab/hook python ...)"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from aadg_amd import _lib
+torch.manual_seed(0)
+for (Co, Ci, H, d, N) in ((512, 512, 32, 2, 144), (256, 256, 64, 2, 36), (512, 512, 32, 1, 144)):
+    x = torch.randn(N, Ci, H, H, device="cuda")
+    dy = torch.randn(N, Co, H, H, device="cuda")
+    f = lambda: _lib.conv3x3_wgrad_x3(dy, x, d)
+    out = f(); torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(9)]
+    for p, q in ev:
+        p.record(); f(); q.record()
+    torch.cuda.synchronize()
+    ref = torch.nn.grad.conv2d_weight(x[:4].double(), (Co, Ci, 3, 3), dy[:4].double(), padding=d, dilation=d)
+    got = _lib.conv3x3_wgrad_x3(dy[:4].contiguous(), x[:4].contiguous(), d).double()
+    got = got.reshape(ref.shape) if got.numel() == ref.numel() and got.shape != ref.shape else got
+    print("%d->%d @%d d%d N%d: %.3f ms   max err vs float64 (4 images) %.2e  (|ref| max %.1f)" % (
+        Ci, Co, H, d, N, sorted(p.elapsed_time(q) for p, q in ev)[4], (got - ref).abs().max().item(), ref.abs().max().item()))
