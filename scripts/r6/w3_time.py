@@ -19,3 +19,23 @@ for (Co, Ci, H, d, N) in ((512, 512, 32, 2, 144), (256, 256, 64, 2, 36), (512, 5
     got = got.reshape(ref.shape) if got.numel() == ref.numel() and got.shape != ref.shape else got
     print("%d->%d @%d d%d N%d: %.3f ms   max err vs float64 (4 images) %.2e  (|ref| max %.1f)" % (
         Ci, Co, H, d, N, sorted(p.elapsed_time(q) for p, q in ev)[4], (got - ref).abs().max().item(), ref.abs().max().item()))
+# stride 2 (k_wgrad3x3_s2): layer2 / layer3's first blocks
+lib = _lib.load()
+for (Co, Ci, Ho, N) in ((128, 128, 64, 144), (256, 256, 32, 144)):
+    x = torch.randn(N, Ci, 2 * Ho, 2 * Ho, device="cuda")
+    dy = torch.randn(N, Co, Ho, Ho, device="cuda")
+    dw9 = torch.empty((9, Co, Ci), dtype=torch.float32, device="cuda")
+    def f():
+        rc = lib.aadg_conv3x3s2_wgrad_f32x3(dy.data_ptr(), x.data_ptr(), dw9.data_ptr(), N, Co, Ci, Ho, Ho, _lib._stream())
+        assert rc == 0, rc
+    f(); torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(9)]
+    for p, q in ev:
+        p.record(); f(); q.record()
+    torch.cuda.synchronize()
+    ref = torch.nn.grad.conv2d_weight(x[:2].double(), (Co, Ci, 3, 3), dy[:2].double(), stride=2, padding=1)
+    g9 = torch.empty_like(dw9)
+    lib.aadg_conv3x3s2_wgrad_f32x3(dy[:2].contiguous().data_ptr(), x[:2].contiguous().data_ptr(), g9.data_ptr(), 2, Co, Ci, Ho, Ho, _lib._stream())
+    got = g9.permute(1, 2, 0).reshape(Co, Ci, 3, 3).double()
+    print("stride 2 %d->%d @%d N%d: %.3f ms   max err vs float64 (2 images) %.2e  (|ref| max %.1f)" % (
+        Ci, Co, Ho, N, sorted(p.elapsed_time(q) for p, q in ev)[4], (got - ref).abs().max().item(), ref.abs().max().item()))
