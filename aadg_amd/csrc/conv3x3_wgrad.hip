@@ -54,8 +54,10 @@ __device__ __forceinline__ bf16x8 frag(uint32_t a, uint32_t b, uint32_t c, uint3
 
 // PRE (X3 only): X is the INPUT of the BatchNorm + ReLU the convolution applied on load (aadg_conv3x3_nchw_f32x3_pre): its rows become
 // max(fma(x, pre_scale[c], pre_shift[c]), 0) on their way to LDS; rows outside the image stay zero (the padding of the normalised tensor).
+// (W = 32, D = 1 in f32x3: 78 KB of LDS -- two workgroups fit a CU, and the compiler fits the on-load instantiation into 252 registers when
+// told to (it took 268-296 and one wave per SIMD: 0.62 -> 0.52 ms on 256 -> 256, 144 images; the plain instantiation was at 243 already))
 template <int W, int D, bool X3, bool PRE = false>
-__global__ __launch_bounds__(256, (W == 128 || X3) ? 1 : 2) void k_wgrad3x3(const void* __restrict__ dY_, const void* __restrict__ X_,
+__global__ __launch_bounds__(256, (W == 128 || (X3 && !(W == 32 && D == 1))) ? 1 : 2) void k_wgrad3x3(const void* __restrict__ dY_, const void* __restrict__ X_,
                                                   float* __restrict__ acc,
                                                   int Co, int Ci, int H, int tiles, int tiles_n, int rows_total, int rows_per_block,
                                                   const float* __restrict__ pre_scale = nullptr, const float* __restrict__ pre_shift = nullptr) {
