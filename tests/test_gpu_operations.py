@@ -65,9 +65,9 @@ def test_operation_draws_follow_the_reference_distributions(hip):
     m = op.get_mask(4096)
     assert set(np.unique(m.cpu().numpy())) <= {0.0, 1.0} and abs(float(m.mean()) - 0.7) < 0.05
     # magnitude = clamp(_magnitude, range) * scale (data/operations.py:110-119)
-    assert abs(float(Ops.Rotate(initial_magnitude=1.7).magnitude) - 30.0) < 1e-6
-    assert abs(float(Ops.ShearX(initial_magnitude=0.5).magnitude) - 0.15) < 1e-6
-    assert abs(float(Ops.TranslateY(initial_magnitude=0.2).magnitude) - 0.09) < 1e-6
+    assert abs(float(Ops.Rotate(initial_magnitude=1.7).magnitude.detach()) - 30.0) < 1e-6
+    assert abs(float(Ops.ShearX(initial_magnitude=0.5).magnitude.detach()) - 0.15) < 1e-6
+    assert abs(float(Ops.TranslateY(initial_magnitude=0.2).magnitude.detach()) - 0.09) < 1e-6
     assert abs(float(Ops.Hue(initial_magnitude=0.25).magnitude) - 0.5) < 1e-6
 
 
