@@ -192,7 +192,10 @@ int launch(const void* dY, const void* X, float* acc, int N, int Co, int Ci, int
     constexpr int BM = 32 * MI * WR, BN = 32 * NI * WC, R = BM + BN, NT = 64 * WR * WC;
     const int tiles_m = (Co + BM - 1) / BM, tiles_n = (Ci + BN - 1) / BN, tiles = tiles_m * tiles_n;
     const int steps_total = N * (HW / BKE);
-    int split = (target_wgs + tiles - 1) / tiles;
+    // the big tile runs ONE workgroup per CU (target 256): rounded DOWN, so that tiles x split never exceeds the chip (1280 -> 256, 5
+    // tiles: 51 slices = 255 workgroups instead of 52 = 260 with four of them in a second round; no measurable change -- that layer's
+    // time is its 255 x 65536 float atomics onto 327 k addresses)
+    int split = target_wgs <= 256 ? (target_wgs / tiles > 0 ? target_wgs / tiles : 1) : (target_wgs + tiles - 1) / tiles;
     // K-steps per workgroup: each workgroup ends with BM x BN float atomics (the cost of several K-steps), so 32 steps when the
     // reduction is long enough to still fill the chip (N = 144: 4.66 -> 4.46 ms over the 16 backbone shapes against 8), fewer --
     // down to 8 -- when that would leave CUs idle (the 32 x 32 layers at 18 images per rank have 288 steps in all)
