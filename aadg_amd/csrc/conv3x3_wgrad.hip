@@ -39,7 +39,12 @@ template <int W, int D, bool X3 = false>
 struct W3Cfg {
     static constexpr int PL = X3 ? 2 : 1;
     static constexpr int BN = (X3 && (W == 128 || (W == 64 && D == 2))) ? 32 : W3_BN;       // in-channel tile (both planes must fit the LDS)
-    static constexpr int R = 2 * D + 2;             // ring slots: rows y - D .. y + D in use, one being replaced
+    // Dilation 2 (round 6): output row y reads the input rows y - 2, y, y + 2 -- rows of its own parity only -- so the even and the odd
+    // rows of an image are two independent sequences whose vertical taps are ONE row apart: the K-steps walk the even rows, then the
+    // odd ones, and the ring holds 4 rows instead of 6 (32 x 32: 78 KB of LDS instead of 106 -- two workgroups per CU).  DV = the
+    // ring distance of the vertical taps; the horizontal taps still shift by D pixels.
+    static constexpr int DV = D == 2 ? 1 : D;
+    static constexpr int R = 2 * DV + 2;            // ring slots: rows j - DV .. j + DV of the sequence in use, one being replaced
     static constexpr int PA = W + 8;                // dY row pitch (elements): 2 W + 16 bytes = 4 (mod 8) words -> conflict-free b128
     static constexpr int PX = W + 24;               // X row pitch: 8 pad | W data | 2 halo | pad; data 16-byte aligned, pitch = 4 (mod 8) words
     static constexpr int CPR = X3 ? W / 4 : W / 8;  // 16-byte global chunks per row (4 float32 / 8 bfloat16 pixels)
@@ -54,10 +59,10 @@ __device__ __forceinline__ bf16x8 frag(uint32_t a, uint32_t b, uint32_t c, uint3
 
 // PRE (X3 only): X is the INPUT of the BatchNorm + ReLU the convolution applied on load (aadg_conv3x3_nchw_f32x3_pre): its rows become
 // max(fma(x, pre_scale[c], pre_shift[c]), 0) on their way to LDS; rows outside the image stay zero (the padding of the normalised tensor).
-// (W = 32, D = 1 in f32x3: 78 KB of LDS -- two workgroups fit a CU, and the compiler fits the on-load instantiation into 252 registers when
+// (W = 32 in f32x3: 78 KB of LDS -- two workgroups fit a CU, and the compiler fits the on-load instantiation into 252 registers when
 // told to (it took 268-296 and one wave per SIMD: 0.62 -> 0.52 ms on 256 -> 256, 144 images; the plain instantiation was at 243 already))
 template <int W, int D, bool X3, bool PRE = false>
-__global__ __launch_bounds__(256, (W == 128 || (X3 && !(W == 32 && D == 1))) ? 1 : 2) void k_wgrad3x3(const void* __restrict__ dY_, const void* __restrict__ X_,
+__global__ __launch_bounds__(256, (W == 128 || (X3 && W != 32)) ? 1 : 2) void k_wgrad3x3(const void* __restrict__ dY_, const void* __restrict__ X_,
                                                   float* __restrict__ acc,
                                                   int Co, int Ci, int H, int tiles, int tiles_n, int rows_total, int rows_per_block,
                                                   const float* __restrict__ pre_scale = nullptr, const float* __restrict__ pre_shift = nullptr) {
@@ -127,8 +132,8 @@ __global__ __launch_bounds__(256, (W == 128 || (X3 && !(W == 32 && D == 1))) ? 1
             xs[i] = pre_scale[ch]; xh[i] = pre_shift[ch];
         }
     }
-    auto store_x = [&](int y, const uint4* st) {
-        uint16_t* base = Xs + (size_t)slot_of(y) * BN * PX;
+    auto store_xj = [&](int j, int y, const uint4* st) {      // j: position in the row sequence (ring slot), y: the image row it is (or -1)
+        uint16_t* base = Xs + (size_t)slot_of(j) * BN * PX;
         const bool live = y >= 0 && y < H;                    // (uniform) a row of the image: else zeros, the padding
 #pragma unroll
         for (int i = 0; i < LPX; ++i) {
@@ -144,6 +149,7 @@ __global__ __launch_bounds__(256, (W == 128 || (X3 && !(W == 32 && D == 1))) ? 1
             put(base + row * PX + 8 + c, X_PLANE, v);
         }
     };
+    auto store_x = [&](int y, const uint4* st) { store_xj(y, y, st); };      // rows in image order: the sequence position is the row
     auto store_dy = [&](int buf, const uint4* st) {
         uint16_t* base = dYs + (size_t)buf * W3_BM * PA;
 #pragma unroll
@@ -165,32 +171,60 @@ __global__ __launch_bounds__(256, (W == 128 || (X3 && !(W == 32 && D == 1))) ? 1
     // trips with nothing else in flight.  Round 6: all rows of a refill are requested at once (3x3 256 -> 256 at 32 x 32, 144 images:
     // 0.562 -> 0.446 ms; dilation 2 unchanged).  Measured and dropped: requesting the NEXT image's first rows before the MFMAs of this
     // image's last row, like any other step's rows -- 0.69 ms (the extra staged rows of registers live across the loop).
+    constexpr int DV = C::DV;
+    constexpr bool PAR = D == 2;                             // rows in parity order (W3Cfg): the sequences of an image are its even / odd rows
+    const int Hh = (H + 1) >> 1;                             // rows of the even sequence
     uint4 sdy[LPA], sx[LPX];
     int buf = 0;
     for (int g = g0; g < g1; ++g) {
-        const int n = g / H, y = g - n * H;
-        if (g == g0 || y == 0) {
-            // (re)fill the ring for this image: rows y - D .. y + D, and dY row y
-            __syncthreads();                                 // every wave is done with the previous image's rows
-            uint4 fill[2 * D + 1][LPX];
+        const int n = g / H, y = g - n * H;                  // PAR: y is the position in the image's even-then-odd order
+        int j = y;                                           // position in the sequence (= the row itself in image order)
+        if constexpr (PAR) {
+            const int par = y >= Hh ? 1 : 0;
+            j = y - par * Hh;
+            const int Hs = par ? H - Hh : Hh;                // rows of this sequence
+            auto row_of = [&](int jj) { return (jj < 0 || jj >= Hs) ? -1 : 2 * jj + par; };      // image row of position jj (-1: padding)
+            if (g == g0 || j == 0) {
+                __syncthreads();                             // every wave is done with the previous sequence's rows
+                uint4 fill[3][LPX];
 #pragma unroll
-            for (int r = 0; r <= 2 * D; ++r) load_x(n, y - D + r, fill[r]);
-            load_dy(n, y, sdy);
+                for (int r = 0; r < 3; ++r) load_x(n, row_of(j - 1 + r), fill[r]);
+                load_dy(n, row_of(j), sdy);
 #pragma unroll
-            for (int r = 0; r <= 2 * D; ++r) store_x(y - D + r, fill[r]);
+                for (int r = 0; r < 3; ++r) store_xj(j - 1 + r, row_of(j - 1 + r), fill[r]);
+            } else {
+                store_xj(j + 1, row_of(j + 1), sx);          // fetched during the previous step
+            }
+            store_dy(buf, sdy);
+            __syncthreads();
+            if (g + 1 < g1 && j + 1 < Hs) {                  // next step's rows: in flight during the MFMAs below
+                load_dy(n, row_of(j + 1), sdy);
+                load_x(n, row_of(j + 2), sx);
+            }
         } else {
-            store_x(y + D, sx);                              // fetched during the previous step
-        }
-        store_dy(buf, sdy);
-        __syncthreads();
-        if (g + 1 < g1 && y + 1 < H) {                       // next step's rows: in flight during the MFMAs below
-            load_dy(n, y + 1, sdy);
-            load_x(n, y + 1 + D, sx);
+            if (g == g0 || y == 0) {
+                // (re)fill the ring for this image: rows y - D .. y + D, and dY row y
+                __syncthreads();                             // every wave is done with the previous image's rows
+                uint4 fill[2 * D + 1][LPX];
+#pragma unroll
+                for (int r = 0; r <= 2 * D; ++r) load_x(n, y - D + r, fill[r]);
+                load_dy(n, y, sdy);
+#pragma unroll
+                for (int r = 0; r <= 2 * D; ++r) store_x(y - D + r, fill[r]);
+            } else {
+                store_x(y + D, sx);                          // fetched during the previous step
+            }
+            store_dy(buf, sdy);
+            __syncthreads();
+            if (g + 1 < g1 && y + 1 < H) {                   // next step's rows: in flight during the MFMAs below
+                load_dy(n, y + 1, sdy);
+                load_x(n, y + 1 + D, sx);
+            }
         }
         const uint16_t* ab = dYs + (size_t)buf * W3_BM * PA + a_row * PA + koff;
         const uint16_t* xb[3];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) xb[kh] = Xs + ((size_t)slot_of(y + (kh - 1) * D) * BN + b_row) * PX + 8 + koff;
+        for (int kh = 0; kh < 3; ++kh) xb[kh] = Xs + ((size_t)slot_of(j + (kh - 1) * DV) * BN + b_row) * PX + 8 + koff;
         // The 8 pixels of a lane's fragment are followed (lanes < 32) / preceded (lanes >= 32) by the fragment of lane ^ 32 of the same
         // sub-step, and preceded / followed by that lane's fragment of the previous / next sub-step: the two neighbour words of the
         // shifted taps come from v_permlane32_swap instead of two 4-byte LDS reads per fragment (64 lanes on 16 banks: 4-way

@@ -79,6 +79,9 @@ def test_conv3x3_x3_forward_and_input_gradient(hip, N, K, M, H, W, d):
 @pytest.mark.parametrize("N,Co,Ci,H,W,d", [
     (2, 64, 64, 32, 32, 1), (3, 64, 64, 32, 32, 2), (2, 128, 64, 64, 64, 1), (1, 64, 128, 64, 64, 2), (2, 64, 64, 128, 128, 1),
     (2, 96, 40, 20, 32, 1), (2, 40, 96, 7, 64, 2), (1, 64, 72, 16, 128, 1), (19, 64, 64, 32, 32, 1),
+    # dilation 2 walks the even rows of an image, then the odd ones (round 6): odd heights, one / two / three rows, many images (slices
+    # that start in the middle of a sequence), the K-split tile at 64 pixels
+    (1, 64, 64, 1, 32, 2), (2, 64, 64, 2, 32, 2), (3, 64, 64, 3, 32, 2), (21, 64, 64, 33, 32, 2), (40, 128, 64, 32, 32, 2), (2, 64, 64, 37, 64, 2),
 ])
 def test_conv3x3_x3_wgrad(hip, N, Co, Ci, H, W, d):
     torch.manual_seed(N * 100 + Co + W)
