@@ -33,7 +33,7 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const uint16_t* p) {
     return __builtin_bit_cast(u32x2, v);
 }
 
-// WR x WC waves; wave tile (32 MI) x (32 NI); BM = 32 MI WR, BP = 32 NI WC = 256.
+// WR x WC waves; wave tile (32 MI) x (32 NI); BM = 32 MI WR, BP = 32 NI WC = 256.  (f32x3: 1 x 4 waves of 128 x 64 -- few transpose reads per MFMA.)
 //
 // X3 = true ("f32x3"): IN / OUT are float32 and A comes pre-split as two bfloat16 planes (A = hi, A_lo = lo; csrc/weight_layouts.hip).
 // A loaded float4 of IN (4 pixels of one channel) is split into (hi, lo) bfloat16 halves while it goes to LDS -- two planes of the same
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
             // 16 MI rows, NI pixels: summed per lane, then over the 32 lanes of the row with a halving butterfly -- at step `msk` a
             // lane keeps one half of its items and hands the other half to lane ^ msk (ds_swizzle: the LDS crossbar, no memory), so
             // 32 + 16 + 8 + 4 + 2 exchanges leave every lane with the two totals of ONE row (row index = the lane's bits reversed).
-            constexpr int NR = 16 * MI;                     // rows per lane half
-            static_assert(NR == 32, "the butterfly below pairs 32 rows with the 32 lanes of a half");
+            constexpr int NR = 16 * MI, NG = NR / 32;       // rows per lane half; groups of 32 rows (one butterfly each)
+            static_assert(NR % 32 == 0, "the butterfly below pairs 32 rows with the 32 lanes of a half");
             float v[2 * NR];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
@@ -208,25 +208,27 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
                     v[2 * (16 * mi + r)] = s;
                     v[2 * (16 * mi + r) + 1] = q;
                 }
-#define AADG_BFLY(MSK, HALF, PAT)                                                                       \
+#define AADG_BFLY(B, MSK, HALF, PAT)                                                                    \
             {                                                                                           \
                 const bool up = (lane & (MSK)) != 0;                                                    \
                 _Pragma("unroll") for (int i = 0; i < (HALF); ++i) {                                    \
-                    const float keep = up ? v[i + (HALF)] : v[i], send = up ? v[i] : v[i + (HALF)];     \
-                    v[i] = keep + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send), (PAT))); \
+                    const float keep = up ? v[(B) + i + (HALF)] : v[(B) + i], send = up ? v[(B) + i] : v[(B) + i + (HALF)]; \
+                    v[(B) + i] = keep + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send), (PAT))); \
                 }                                                                                       \
             }
-            // ds_swizzle bit mode: and_mask 0x1F | xor_mask << 10 (groups of 32 lanes)
-            AADG_BFLY(16, 32, 0x1F | (16 << 10))
-            AADG_BFLY(8, 16, 0x1F | (8 << 10))
-            AADG_BFLY(4, 8, 0x1F | (4 << 10))
-            AADG_BFLY(2, 4, 0x1F | (2 << 10))
-            AADG_BFLY(1, 2, 0x1F | (1 << 10))
+            // ds_swizzle bit mode: and_mask 0x1F | xor_mask << 10 (groups of 32 lanes); one butterfly per group of 32 rows (mi pairs)
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+                AADG_BFLY(64 * q, 16, 32, 0x1F | (16 << 10))
+                AADG_BFLY(64 * q, 8, 16, 0x1F | (8 << 10))
+                AADG_BFLY(64 * q, 4, 8, 0x1F | (4 << 10))
+                AADG_BFLY(64 * q, 2, 4, 0x1F | (2 << 10))
+                AADG_BFLY(64 * q, 1, 2, 0x1F | (1 << 10))
+            }
 #undef AADG_BFLY
             // item kept through the steps: bit 4 of the lane picked the upper 32 items, bit 3 the upper 16 of those, ...
             const int item = ((lane >> 4) & 1) * 32 + ((lane >> 3) & 1) * 16 + ((lane >> 2) & 1) * 8 + ((lane >> 1) & 1) * 4 + (lane & 1) * 2;
             const int rr = item >> 1, mi = rr >> 4, r = rr & 15;
-            const int row = wr * 32 * MI + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * g;       // row of the workgroup's tile
             // the WC waves that share a row are combined in LDS first (the operand buffers are free once every wave has left the
             // K loop): one float64 atomic per channel, statistic and WORKGROUP -- with one per wave the 36 864 atomics per address of
             // a 64-channel layer at 128 x 128 doubled that kernel's duration
@@ -234,8 +236,12 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
             __syncthreads();
             for (int i = tid; i < 2 * BM; i += 256) red[i] = 0.0f;
             __syncthreads();
-            __hip_atomic_fetch_add(red + 2 * row, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(red + 2 * row + 1, v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+                const int row = wr * 32 * MI + 32 * (mi + 2 * q) + (r & 3) + 8 * (r >> 2) + 4 * g;       // row of the workgroup's tile
+                __hip_atomic_fetch_add(red + 2 * row, v[64 * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(red + 2 * row + 1, v[64 * q + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             __syncthreads();
             for (int i = tid; i < 2 * BM; i += 256)
                 if (m0 + (i >> 1) < M) unsafeAtomicAdd(stats + 2 * (size_t)m0 + i, (double)red[i]);
@@ -364,5 +370,8 @@ extern "C" int aadg_conv1x1_nchw_f32x3_pre(const void* a_hi, const void* a_lo, c
         AADG_LAUNCH_CHECK();
     }
     if (M <= 64) return launch<1, 4, 2, 2, true>(ph, pl, in, out, N, M, K, HW, st, bn_sums, pre_scale, pre_shift);
-    return launch<2, 2, 2, 4, true>(ph, pl, in, out, N, M, K, HW, st, bn_sums, pre_scale, pre_shift);
+    // 128 x 256 tile, every wave = all 128 rows x 64 pixels (round 6; it was 2 x 2 waves of 64 x 128): per 16 k a wave reads 8 A fragments
+    // (plain ds_read_b128) and 4 B fragments (transpose reads) instead of 4 and 8 -- the transpose reads are the slow ones: 6-8 % on the
+    // compute-bound layers (512 -> 2048 at 32 x 32, 144 images: 1.26 -> 1.16 ms; scripts/r6/c1_time.py)
+    return launch<1, 4, 4, 2, true>(ph, pl, in, out, N, M, K, HW, st, bn_sums, pre_scale, pre_shift);
 }
