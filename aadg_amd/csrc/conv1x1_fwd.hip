@@ -52,17 +52,19 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
                                                          const float* __restrict__ pre_scale = nullptr,
                                                          const float* __restrict__ pre_shift = nullptr) {
     static_assert(!PRE || X3, "the load transform exists for float32 tensors (whole IN tiles: K % 32 == 0, HW % 256 == 0)");
-    static_assert(WR * WC == 4 && 32 * NI * WC == CF_BP, "4 waves, 256 pixels");
+    constexpr int BP = 32 * NI * WC;                                       // pixels per tile: 256 (128 for the 256-row f32x3 tile)
+    static_assert(WR * WC == 4 && (BP == CF_BP || (X3 && BP == 128)), "4 waves, 256 (f32x3: or 128) pixels");
+    constexpr int QPR = BP / 4;                                            // float4 chunks per staged IN row (f32x3)
     constexpr int BM = 32 * MI * WR;
     constexpr int BK = X3 ? 32 : CF_BK, APITCH = BK + 8, PL = X3 ? 2 : 1;
     constexpr int AC = BK / 8;                                             // 16-byte chunks per A row and plane
     constexpr int LA = BM * AC * PL / 256;                                 // A chunks per thread and K-step
-    constexpr int LB = X3 ? BK * (CF_BP / 4) / 256 : BK * (CF_BP / 8) / 256;   // IN chunks (16 bytes: 4 float32 / 8 bfloat16 pixels)
+    constexpr int LB = X3 ? BK * (BP / 4) / 256 : BK * (BP / 8) / 256;         // IN chunks (16 bytes: 4 float32 / 8 bfloat16 pixels)
     __shared__ __attribute__((aligned(16))) uint16_t As[PL * BM * APITCH];
     // B pitch.  bfloat16 kernel: 544 bytes.  X3: 576 bytes = 16 banks per row step -- a transpose read serves 32 lanes per LDS cycle (4 rows x
     // two 16-column halves): with 8 banks per row step the second half of row r collides with the first half of row r + 1
     // (SQ_LDS_BANK_CONFLICT was 36 % of SQ_LDS_IDX_ACTIVE); with 16 the 32 lanes cover the 64 banks exactly
-    constexpr int BPITCH = X3 ? CF_BP + 32 : CF_BPITCH;
+    constexpr int BPITCH = X3 ? BP + 32 : CF_BPITCH;
     __shared__ __attribute__((aligned(16))) uint16_t Bs[PL * BK * BPITCH];
     __shared__ float Ps[PRE ? 2 * CF_PRE_K : 2];                          // PRE: scale [K] | shift [K] (visible behind the loop's first barrier)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
     // grid: pixel tile fastest, then output-channel tile, then image: the workgroups that share an IN tile are neighbours
     const int tp = blockIdx.x % tiles_p, t2 = blockIdx.x / tiles_p;
     const int tm = t2 % tiles_m, n = t2 / tiles_m;
-    const int m0 = tm * BM, p0 = tp * CF_BP;
+    const int m0 = tm * BM, p0 = tp * BP;
     const uint16_t* inn = reinterpret_cast<const uint16_t*>(IN_) + (size_t)n * K * HW * (X3 ? 2 : 1);
     const float* innf = reinterpret_cast<const float*>(IN_) + (size_t)n * K * HW;
 
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
         for (int i = 0; i < LB; ++i) {
             const int id = tid + 256 * i;
             if (X3) {
-                const int row = id >> 6, c = (id & 63) * 4, k = k0 + row, p = p0 + c;
+                const int row = id / QPR, c = (id % QPR) * 4, k = k0 + row, p = p0 + c;
                 rb[i] = (EXACT || (k < K && p < HW)) ? *reinterpret_cast<const uint4*>(innf + (size_t)k * HW + p) : make_uint4(0, 0, 0, 0);
             } else {
                 const int row = id >> 5, c = (id & 31) * 8, k = k0 + row, p = p0 + c;
@@ -125,12 +127,12 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
                 uint2 hi, lo;
                 float4 f = make_float4(__uint_as_float(rb[i].x), __uint_as_float(rb[i].y), __uint_as_float(rb[i].z), __uint_as_float(rb[i].w));
                 if (PRE) {
-                    const float sc = Ps[k0 + (id >> 6)], sh = Ps[CF_PRE_K + k0 + (id >> 6)];
+                    const float sc = Ps[k0 + id / QPR], sh = Ps[CF_PRE_K + k0 + id / QPR];
                     f.x = fmaxf(fmaf(f.x, sc, sh), 0.0f); f.y = fmaxf(fmaf(f.y, sc, sh), 0.0f);
                     f.z = fmaxf(fmaf(f.z, sc, sh), 0.0f); f.w = fmaxf(fmaf(f.w, sc, sh), 0.0f);
                 }
                 aadg_split4(f, hi, lo);
-                uint16_t* dst = Bs + (id >> 6) * BPITCH + (id & 63) * 4;
+                uint16_t* dst = Bs + (id / QPR) * BPITCH + (id % QPR) * 4;
                 *reinterpret_cast<uint2*>(dst) = hi;
                 *reinterpret_cast<uint2*>(dst + BK * BPITCH) = lo;
             } else {
@@ -271,17 +273,17 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
 template <int WR, int WC, int MI, int NI, bool X3>
 int launch(const uint16_t* A, const uint16_t* A_lo, const void* IN, void* OUT, int N, int M, int K, int HW, hipStream_t st,
            double* stats = nullptr, const float* pre_scale = nullptr, const float* pre_shift = nullptr) {
-    constexpr int BM = 32 * MI * WR;
-    if (X3 && (M % BM) == 0 && (K % 32) == 0 && (HW % CF_BP) == 0) {          // whole tiles: the branch-free instantiation
-        const long long wgs_e = (long long)N * (HW / CF_BP) * (M / BM);
+    constexpr int BM = 32 * MI * WR, BP = 32 * NI * WC;
+    if (X3 && (M % BM) == 0 && (K % 32) == 0 && (HW % BP) == 0) {          // whole tiles: the branch-free instantiation
+        const long long wgs_e = (long long)N * (HW / BP) * (M / BM);
         if (wgs_e > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
         if (pre_scale != nullptr) {
             if (K > CF_PRE_K) return AADG_E_UNSUPPORTED;
             hipLaunchKernelGGL((k_conv1x1_nchw<WR, WC, MI, NI, X3, X3, X3>), dim3((unsigned)wgs_e), dim3(256), 0, st, A, A_lo, IN, OUT, M, K, HW,
-                               HW / CF_BP, M / BM, stats, pre_scale, pre_shift);
+                               HW / BP, M / BM, stats, pre_scale, pre_shift);
         } else {
             hipLaunchKernelGGL((k_conv1x1_nchw<WR, WC, MI, NI, X3, X3>), dim3((unsigned)wgs_e), dim3(256), 0, st, A, A_lo, IN, OUT, M, K, HW,
-                               HW / CF_BP, M / BM, stats);
+                               HW / BP, M / BM, stats);
         }
         AADG_LAUNCH_CHECK();
         return 0;
@@ -289,15 +291,15 @@ int launch(const uint16_t* A, const uint16_t* A_lo, const void* IN, void* OUT, i
     if (pre_scale != nullptr) {
         // M is not a whole number of tiles (the 8-row classifier): the IN tiles still are -- no zero-filled IN value that the transform would
         // turn into relu(shift)
-        if (!X3 || (K % 32) != 0 || (HW % CF_BP) != 0 || K > CF_PRE_K) return AADG_E_UNSUPPORTED;
-        const long long wgs_p = (long long)N * (HW / CF_BP) * ((M + BM - 1) / BM);
+        if (!X3 || (K % 32) != 0 || (HW % BP) != 0 || K > CF_PRE_K) return AADG_E_UNSUPPORTED;
+        const long long wgs_p = (long long)N * (HW / BP) * ((M + BM - 1) / BM);
         if (wgs_p > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
         hipLaunchKernelGGL((k_conv1x1_nchw<WR, WC, MI, NI, X3, false, X3>), dim3((unsigned)wgs_p), dim3(256), 0, st, A, A_lo, IN, OUT, M, K, HW,
-                           HW / CF_BP, (M + BM - 1) / BM, stats, pre_scale, pre_shift);
+                           HW / BP, (M + BM - 1) / BM, stats, pre_scale, pre_shift);
         AADG_LAUNCH_CHECK();
         return 0;
     }
-    const int tiles_p = (HW + CF_BP - 1) / CF_BP, tiles_m = (M + BM - 1) / BM;
+    const int tiles_p = (HW + BP - 1) / BP, tiles_m = (M + BM - 1) / BM;
     const long long wgs = (long long)N * tiles_p * tiles_m;
     if (wgs > 0x7FFFFFFFLL) return AADG_E_UNSUPPORTED;
     hipLaunchKernelGGL((k_conv1x1_nchw<WR, WC, MI, NI, X3>), dim3((unsigned)wgs), dim3(256), 0, st, A, A_lo, IN, OUT, M, K, HW, tiles_p,
@@ -373,5 +375,7 @@ extern "C" int aadg_conv1x1_nchw_f32x3_pre(const void* a_hi, const void* a_lo, c
     // 128 x 256 tile, every wave = all 128 rows x 64 pixels (round 6; it was 2 x 2 waves of 64 x 128): per 16 k a wave reads 8 A fragments
     // (plain ds_read_b128) and 4 B fragments (transpose reads) instead of 4 and 8 -- the transpose reads are the slow ones: 6-8 % on the
     // compute-bound layers (512 -> 2048 at 32 x 32, 144 images: 1.26 -> 1.16 ms; scripts/r6/c1_time.py)
+    // (measured and not taken: a 256 x 128 tile of 2 x 2 such waves -- launch<2, 2, 4, 2, true>, the kernel takes 128-pixel tiles for it --
+    // halves the activation bytes a workgroup stages per output: within +-3 % of this one, layer by layer)
     return launch<1, 4, 4, 2, true>(ph, pl, in, out, N, M, K, HW, st, bn_sums, pre_scale, pre_shift);
 }
