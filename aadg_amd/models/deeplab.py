@@ -662,6 +662,12 @@ def global_avg_pool_f32(x):
     return _GlobalAvgPoolF32.apply(x)
 
 
+# activations whose concatenations are produced in place (the BatchNorm kernels write their channel slice of the buffer, their backward
+# reads its slice of the gradient): bfloat16 since round 2; float32 -- the f32x3 default -- since the end of round 6 (it still took torch.cat:
+# 0.47 ms for the ASPP head's copy plus the slice copies of its backward)
+_INPLACE_CONCAT_DTYPES = (torch.bfloat16, torch.float32)
+
+
 class ASPP(nn.Module):
     def __init__(self, cin, cout=256, rates=(12, 24, 36)):
         super().__init__()
@@ -678,7 +684,7 @@ class ASPP(nn.Module):
         h = _handles(x, nb if pooled is not None else nb + 1)      # one handle of the encoder output per consumer
         ref = h[0]
         fused, convs = self._forward_into_concat(h, pooled) if (pooled is not None and self.training and torch.is_grad_enabled() and
-                                                                ref.is_cuda and ref.dtype == torch.bfloat16) else (None, None)
+                                                                ref.is_cuda and ref.dtype in _INPLACE_CONCAT_DTYPES) else (None, None)
         if fused is not None:
             return self.project(fused)
         if convs is not None:
@@ -771,7 +777,7 @@ class DeepLabV3Plus(nn.Module):
         for mod in list(self.aspp)[1:]:
             a = mod(a)
         y = None
-        if (a.is_cuda and self.training and torch.is_grad_enabled() and a.dtype == torch.bfloat16 and len(self.skip) == 2 and
+        if (a.is_cuda and self.training and torch.is_grad_enabled() and a.dtype in _INPLACE_CONCAT_DTYPES and len(self.skip) == 2 and
                 type(self.skip[1]) is BNAct and type(self.skip[1].bn) is nn.BatchNorm2d):
             # both halves of the decoder concatenation are produced in place: the skip branch's BatchNorm writes its slice of
             # the buffer, the up-sampling kernel the other

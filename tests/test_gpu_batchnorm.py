@@ -106,7 +106,7 @@ def test_backbone_fused_bn_matches_module_path(hip, encoder):
     rm1 = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
     saved = deeplab.bn_act
 
-    def module_path(bn, t, act=None, residual=None, handles=1):
+    def module_path(bn, t, act=None, residual=None, handles=1, out=None, res_affine=None):      # (out: the caller copies the result into its slice)
         y = bn(t)
         if residual is not None:
             y = y + residual
