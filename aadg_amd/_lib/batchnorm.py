@@ -529,10 +529,13 @@ class _BatchNormLazy(torch.autograd.Function):
                "aadg_bn_finalize_f32")
         ctx.save_for_backward(x, weight, bias, mean, invstd, presums if sync else None)
         ctx.mark_non_differentiable(scale, shift)
+        ctx.set_materialize_grads(False)       # no zero-filled gradient tensors for scale / shift in every backward pass (two fill launches)
         return x.view_as(x), scale, shift
 
     @staticmethod
     def backward(ctx, dz, *unused):
+        if dz is None:
+            return (None,) * 10
         lib = load()
         x, weight, bias, mean, invstd, fsums = ctx.saved_tensors
         N, C, H, W = x.shape

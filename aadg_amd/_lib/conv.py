@@ -436,10 +436,13 @@ class _Conv1x1X3(torch.autograd.Function):
         sums = torch.empty(2 * Co + 1, dtype=torch.float64, device=x.device)
         y = conv1x1_nchw_x3(a2, x, sums, pre)
         ctx.mark_non_differentiable(sums)
+        ctx.set_materialize_grads(False)       # no zero-filled gradient tensor for `sums` in every backward pass (a fill launch each)
         return y, sums
 
     @staticmethod
     def backward(ctx, dy, *unused):
+        if dy is None:                           # (set_materialize_grads(False): the output took no part in the loss)
+            return (None,) * 5
         x, weight, pre_scale, pre_shift = ctx.saved_tensors
         pre = (pre_scale, pre_shift) if pre_scale is not None else None
         dy = dy.contiguous()
@@ -548,10 +551,13 @@ class _Conv3x3X3(torch.autograd.Function):
         sums = torch.empty(2 * Co + 1, dtype=torch.float64, device=x.device)
         y = conv3x3_nchw_x3(a9, x, dilation, sums, pre)
         ctx.mark_non_differentiable(sums)
+        ctx.set_materialize_grads(False)       # no zero-filled gradient tensor for `sums` in every backward pass (a fill launch each)
         return y, sums
 
     @staticmethod
     def backward(ctx, dy, *unused):
+        if dy is None:                           # (set_materialize_grads(False): the output took no part in the loss)
+            return (None,) * 6
         x, weight, pre_scale, pre_shift = ctx.saved_tensors
         pre = (pre_scale, pre_shift) if pre_scale is not None else None
         d = ctx.dilation
