@@ -84,17 +84,22 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_nchw(const uint16_t* __restr
         for (int i = 0; i < LA; ++i) {
             const int id = tid + 256 * i, pl = id / (BM * AC), r = id - pl * (BM * AC), row = r / AC, c = (r - row * AC) * 8;
             const int m = m0 + row, k = k0 + c;
-            ra[i] = (EXACT || (m < M && k < K)) ? *reinterpret_cast<const uint4*>((pl ? A_lo : A) + (size_t)m * K + k) : make_uint4(0, 0, 0, 0);
+            // (not whole tiles: the element that does not exist is LOADED from the nearest one that does and zeroed with a select --
+            // round 6; a guarded load is a basic block of its own and the loads of a step cannot be issued together across them)
+            const uint4 va = *reinterpret_cast<const uint4*>((pl ? A_lo : A) + (size_t)(EXACT ? m : min(m, M - 1)) * K + (EXACT ? k : min(k, K - 8)));
+            ra[i] = (EXACT || (m < M && k < K)) ? va : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             const int id = tid + 256 * i;
             if (X3) {
                 const int row = id / QPR, c = (id % QPR) * 4, k = k0 + row, p = p0 + c;
-                rb[i] = (EXACT || (k < K && p < HW)) ? *reinterpret_cast<const uint4*>(innf + (size_t)k * HW + p) : make_uint4(0, 0, 0, 0);
+                const uint4 vb = *reinterpret_cast<const uint4*>(innf + (size_t)(EXACT ? k : min(k, K - 1)) * HW + (EXACT ? p : min(p, HW - 4)));
+                rb[i] = (EXACT || (k < K && p < HW)) ? vb : make_uint4(0, 0, 0, 0);
             } else {
                 const int row = id >> 5, c = (id & 31) * 8, k = k0 + row, p = p0 + c;
-                rb[i] = (k < K && p < HW) ? *reinterpret_cast<const uint4*>(inn + (size_t)k * HW + p) : make_uint4(0, 0, 0, 0);
+                const uint4 vb = *reinterpret_cast<const uint4*>(inn + (size_t)min(k, K - 1) * HW + min(p, HW - 8));
+                rb[i] = (k < K && p < HW) ? vb : make_uint4(0, 0, 0, 0);
             }
         }
     };

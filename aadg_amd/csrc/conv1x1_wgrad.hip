@@ -62,18 +62,24 @@ __global__ __launch_bounds__(64 * WR * WC) void k_wgrad1x1(const void* __restric
     if (s0 >= s1) return;
     const int spi = HW / BKE;             // steps per image
 
-    // this thread's LPT (row, 16-byte chunk) slots of the staged tile; rows beyond Co / Ci read as zero
+    // this thread's LPT (row, 16-byte chunk) slots of the staged tile; rows beyond Co / Ci read as zero.  Round 6: a row that does not
+    // exist is LOADED from the last one that does and zeroed with a select -- a guarded load is a basic block of its own (the loads of a
+    // step could not be issued together), an unconditional one is not
     const elem_t* src[LPT];
+    uint32_t live = 0;                                     // bit i: slot i is a row of the tensors
+    static_assert(LPT <= 32, "one bit per slot");
     const int row0 = tid >> 3, c8 = (tid & 7) * 8, cg = (tid & 7) * (BKE / 8);     // chunk offset in LDS / in the global row (elements)
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
         const int row = row0 + (NT / 8) * i;
         if (i < LPT_A) {
             const int m = m0 + row;
-            src[i] = m < Co ? dY + (size_t)m * HW + cg : nullptr;
+            src[i] = dY + (size_t)min(m, Co - 1) * HW + cg;
+            if (m < Co) live |= 1u << i;
         } else {
             const int n = n0 + row - BM;
-            src[i] = n < Ci ? X + (size_t)n * HW + cg : nullptr;
+            src[i] = X + (size_t)min(n, Ci - 1) * HW + cg;
+            if (n < Ci) live |= 1u << i;
         }
     }
     const size_t stride_a = (size_t)Co * HW, stride_b = (size_t)Ci * HW;
@@ -90,8 +96,10 @@ __global__ __launch_bounds__(64 * WR * WC) void k_wgrad1x1(const void* __restric
         const int n = step / spi, kk = (step - n * spi) * BKE;
 #pragma unroll
         for (int i = 0; i < LPT; ++i)
-            stage[i] = (EXACT || src[i] != nullptr) ? *reinterpret_cast<const uint4*>(src[i] + (size_t)n * (i < LPT_A ? stride_a : stride_b) + kk)
-                                                    : make_uint4(0, 0, 0, 0);
+        {
+            const uint4 v = *reinterpret_cast<const uint4*>(src[i] + (size_t)n * (i < LPT_A ? stride_a : stride_b) + kk);
+            stage[i] = (EXACT || ((live >> i) & 1u)) ? v : make_uint4(0, 0, 0, 0);
+        }
     };
 
     f32x16 d[MI][NI];
