@@ -20,6 +20,22 @@
 namespace {
 
 constexpr int BN_MAX_SPLIT = 64;
+// grid of the reduction kernels.  (split, C) -- the channel in blockIdx.y -- made neighbouring workgroups read the SAME channel of
+// images 16 MB apart; (C, split) makes them read neighbouring channels of one image: one contiguous sweep of the tensor (round 6)
+#ifndef BN_GRID_C_FAST
+#define BN_GRID_C_FAST 1
+#endif
+#if BN_GRID_C_FAST
+#define BN_RED_C blockIdx.x
+#define BN_RED_S blockIdx.y
+#define BN_RED_NS gridDim.y
+#define BN_RED_GRID(split, C) dim3((C), (split))
+#else
+#define BN_RED_C blockIdx.y
+#define BN_RED_S blockIdx.x
+#define BN_RED_NS gridDim.x
+#define BN_RED_GRID(split, C) dim3((split), (C))
+#endif
 
 // ---- 16-byte vectors of T ---------------------------------------------------------------------------------
 // Outputs larger than this are written with streaming stores: they would not survive in the 256 MB Infinity Cache until their
@@ -192,10 +208,10 @@ template <typename T> struct BnExtra {      // further gradients of the same out
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void k_bn_reduce_fwd(const T* __restrict__ x, int C, int len, int per_strip, int plen, int total,
                                                        float* __restrict__ partial) {
-    const int c = blockIdx.y, S = gridDim.x;
+    const int c = BN_RED_C, S = BN_RED_NS;
     const size_t strip_elems = (size_t)len * VEC;
     float s0 = 0.f, s1 = 0.f;
-    for (int p = blockIdx.x; p < total; p += S) {
+    for (int p = BN_RED_S; p < total; p += S) {
         const int n = p / per_strip, part = p - n * per_strip;
         const size_t base = ((size_t)n * C + c) * strip_elems;
         const int j1 = min(len, (part + 1) * plen);
@@ -208,7 +224,7 @@ __global__ __launch_bounds__(256) void k_bn_reduce_fwd(const T* __restrict__ x, 
         }
     }
     const float2 r = block_sum2(s0, s1);
-    if (threadIdx.x == 0) reinterpret_cast<float2*>(partial)[(size_t)c * BN_MAX_SPLIT + blockIdx.x] = r;
+    if (threadIdx.x == 0) reinterpret_cast<float2*>(partial)[(size_t)c * BN_MAX_SPLIT + BN_RED_S] = r;
 }
 
 // backward: g = (dy + extra gradients) * act'(v), v = the value the forward stored; sums g and g * (x - mean) * invstd;
@@ -231,7 +247,7 @@ __global__ __launch_bounds__(256) void k_bn_reduce_bwd(const T* __restrict__ x, 
     static_assert(MK == 2 || VEC > 1, "the specialised variants are vector-only");
     const int act = act_rt & 0xFF;
     const bool stream = (act_rt & BN_STREAM) != 0;
-    const int c = blockIdx.y, S = gridDim.x;
+    const int c = BN_RED_C, S = BN_RED_NS;
     const size_t strip_elems = (size_t)len * VEC;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     const float mu = mean[c], is = invstd[c];
@@ -240,7 +256,7 @@ __global__ __launch_bounds__(256) void k_bn_reduce_bwd(const T* __restrict__ x, 
     float sc = 0.f, sh = 0.f;
     if (MK >= 2) bn_scale_shift_of(weight, bias, mu, is, c, &sc, &sh);
     const bool write_g = DRES < 0 ? dres != nullptr : DRES != 0;
-    for (int p = blockIdx.x; p < total; p += S) {
+    for (int p = BN_RED_S; p < total; p += S) {
         const int n = p / per_strip, part = p - n * per_strip;
         const size_t strip = (size_t)n * C + c;
         const size_t base = strip * strip_elems;
@@ -301,11 +317,11 @@ __global__ __launch_bounds__(256) void k_bn_reduce_bwd(const T* __restrict__ x, 
         }
     }
     const float2 r = block_sum2(s0, s1);
-    if (threadIdx.x == 0) reinterpret_cast<float2*>(partial)[(size_t)c * BN_MAX_SPLIT + blockIdx.x] = r;
+    if (threadIdx.x == 0) reinterpret_cast<float2*>(partial)[(size_t)c * BN_MAX_SPLIT + BN_RED_S] = r;
     if (DUAL) {
         __syncthreads();                                          // block_sum2's scratch is read by every thread
         const float2 r2 = block_sum2(s0, s2);
-        if (threadIdx.x == 0) reinterpret_cast<float2*>(d2.partial2)[(size_t)c * BN_MAX_SPLIT + blockIdx.x] = r2;
+        if (threadIdx.x == 0) reinterpret_cast<float2*>(d2.partial2)[(size_t)c * BN_MAX_SPLIT + BN_RED_S] = r2;
     }
 }
 
@@ -527,7 +543,7 @@ int bn_forward(const T* x, const T* res, T* y, uint8_t* mask, const float* weigh
     int split = s.split;
     const double* count_dev = nullptr;
     if (training && phase != 2) {
-        const dim3 grid(s.split, C);
+        const dim3 grid = BN_RED_GRID(s.split, C);
         if (s.vec > 1)
             hipLaunchKernelGGL((k_bn_reduce_fwd<T, Pack<T>::N>), grid, blk, 0, st, x, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial);
         else
@@ -599,7 +615,7 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
         if (s.vec == 1 || mask == nullptr || dres == nullptr || act == AADG_ACT_NONE || ws2 == nullptr) return AADG_E_UNSUPPORTED;
         if (phase != 2) {
             const BnRed2<T> r2 = {dual->x2, dual->mean2, dual->invstd2, ws2 + L.partial};
-            const dim3 rgrid(s.split, C);
+            const dim3 rgrid = BN_RED_GRID(s.split, C);
 #define AADG_BN_REDUCE_DUAL(NE_)                                                                                                      \
     hipLaunchKernelGGL((k_bn_reduce_bwd<T, Pack<T>::N, 1, NE_, 1, true>), rgrid, blk, 0, st, x, y, dy, more, pconst, mask, dres, mean,    \
                        invstd, weight, bias, act | stream_flag, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial,          \
@@ -633,7 +649,7 @@ int bn_backward(const T* x, const T* y, const uint8_t* mask, const T* dy, const 
         split = -1;                                             // k_bn_dx reads the float64 totals directly
         dweight = nullptr; dbias = nullptr;                     // written by phase 1 (local sums)
     } else {
-        const dim3 grid(s.split, C);
+        const dim3 grid = BN_RED_GRID(s.split, C);
 #define AADG_BN_REDUCE_BWD(VEC_, MK_, NE_, DRES_)                                                                                        \
     hipLaunchKernelGGL((k_bn_reduce_bwd<T, VEC_, MK_, NE_, DRES_>), grid, blk, 0, st, x, y, dy, more, pconst, mask, dres, mean, invstd,  \
                        weight, bias, act | stream_flag, C, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, ws + L.partial, dy_img_stride)
@@ -819,12 +835,12 @@ __global__ __launch_bounds__(256) void k_bn_pool_reduce_bwd(const T* __restrict_
                                                             const float* __restrict__ bias, int C, int H, int W, int Ho, int Wo, int len,
                                                             int per_strip, int plen, int total, float* __restrict__ partial) {
     constexpr int V = Pack<T>::N;
-    const int c = blockIdx.y, S = gridDim.x, w8 = W / V;
+    const int c = BN_RED_C, S = BN_RED_NS, w8 = W / V;
     float s0 = 0.f, s1 = 0.f;
     const float mu = mean[c], is = invstd[c];
     float sc, sh;
     bn_scale_shift_of(weight, bias, mu, is, c, &sc, &sh);
-    for (int p = blockIdx.x; p < total; p += S) {
+    for (int p = BN_RED_S; p < total; p += S) {
         const int n = p / per_strip, part = p - n * per_strip;
         const size_t strip = (size_t)n * C + c;
         const T* px = x + strip * (size_t)len * V;
@@ -847,7 +863,7 @@ __global__ __launch_bounds__(256) void k_bn_pool_reduce_bwd(const T* __restrict_
         }
     }
     const float2 rr = block_sum2(s0, s1);
-    if (threadIdx.x == 0) reinterpret_cast<float2*>(partial)[(size_t)c * BN_MAX_SPLIT + blockIdx.x] = rr;
+    if (threadIdx.x == 0) reinterpret_cast<float2*>(partial)[(size_t)c * BN_MAX_SPLIT + BN_RED_S] = rr;
 }
 
 // grid (N * C strips, pieces), as k_bn_dx with ACT = ReLU
@@ -1136,11 +1152,11 @@ extern "C" int aadg_bn_relu_maxpool_forward(const void* x, void* y, void* index,
     Shape s;
     if (dtype == 0) {
         if (!make_shape<float>(N, C, HW, x, nullptr, nullptr, nullptr, &s) || s.vec == 1) return AADG_E_UNSUPPORTED;
-        hipLaunchKernelGGL((k_bn_reduce_fwd<float, 4>), dim3(s.split, C), dim3(s.threads), 0, st, (const float*)x, C, s.len, s.pc.per_strip,
+        hipLaunchKernelGGL((k_bn_reduce_fwd<float, 4>), BN_RED_GRID(s.split, C), dim3(s.threads), 0, st, (const float*)x, C, s.len, s.pc.per_strip,
                            s.pc.plen, s.pc.total, wsf + L.partial);
     } else {
         if (!make_shape<__hip_bfloat16>(N, C, HW, x, nullptr, nullptr, nullptr, &s) || s.vec == 1) return AADG_E_UNSUPPORTED;
-        hipLaunchKernelGGL((k_bn_reduce_fwd<__hip_bfloat16, 8>), dim3(s.split, C), dim3(s.threads), 0, st, (const __hip_bfloat16*)x, C, s.len,
+        hipLaunchKernelGGL((k_bn_reduce_fwd<__hip_bfloat16, 8>), BN_RED_GRID(s.split, C), dim3(s.threads), 0, st, (const __hip_bfloat16*)x, C, s.len,
                            s.pc.per_strip, s.pc.plen, s.pc.total, wsf + L.partial);
     }
     AADG_LAUNCH_CHECK();
@@ -1166,7 +1182,7 @@ int bn_pool_backward(const T* px, const uint8_t* index, const T* pg, const float
     const int Ho = (H - 1) / 2 + 1, Wo = W / 2, HW = H * W;
     Shape s;
     if (!make_shape<T>(N, C, HW, px, dx, nullptr, nullptr, &s) || s.vec == 1) return AADG_E_UNSUPPORTED;
-    hipLaunchKernelGGL(k_bn_pool_reduce_bwd<T>, dim3(s.split, C), dim3(s.threads), 0, st, px, index, pg, save_mean, save_invstd,
+    hipLaunchKernelGGL(k_bn_pool_reduce_bwd<T>, BN_RED_GRID(s.split, C), dim3(s.threads), 0, st, px, index, pg, save_mean, save_invstd,
                        weight, bias, C, H, W, Ho, Wo, s.len, s.pc.per_strip, s.pc.plen, s.pc.total, wsf + L.partial);
     AADG_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bn_pool_dx<T>, dim3(N * C, s.pc.per_strip), dim3(s.threads), 0, st, px, index, pg, dx,
