@@ -233,14 +233,14 @@ __global__ __launch_bounds__(256) void k_dw3x3(const T* __restrict__ x, const fl
     }
 }
 
-// grid (split, C): partial[c][split][9] = sum over this workgroup's (plane group, tile) items of
+// grid (C, split): partial[c][split][9] = sum over this workgroup's (plane group, tile) items of
 // dy[i][j] * x[i+(a-1)d][j+(b-1)d];  with tiles == 1 an item is PP images' planes of channel c
 template <typename T>
 __global__ __launch_bounds__(256) void k_dw3x3_wgrad(const T* __restrict__ x, const T* __restrict__ dy, int N, int C, DwGeom g,
                                                      float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float L[];
     __shared__ float red[4][9];
-    const int c = blockIdx.y, S = gridDim.x;
+    const int c = blockIdx.x, S = gridDim.y;           // grid (C, split): neighbouring workgroups read neighbouring channels of one image (round 6; it was (split, C))
     const int cg = threadIdx.x % g.w4, ro = threadIdx.x / g.w4;
     const int j0 = cg * 4;
     const size_t psz = (size_t)g.H * g.W;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_wgrad(const T* __restrict__ x, co
     for (int i = 0; i < 9; ++i) acc[i] = 0.f;
     const int groups = (N + g.PP - 1) / g.PP;
     const int items = groups * g.tiles;
-    for (int q = blockIdx.x; q < items; q += S) {
+    for (int q = blockIdx.y; q < items; q += S) {
         const int grp = q / g.tiles, tile = q - grp * g.tiles;
         const int n0 = grp * g.PP, np = min(g.PP, N - n0);
         const int r0 = tile * g.TH, r1 = min(g.H, r0 + g.TH);
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_wgrad(const T* __restrict__ x, co
         for (int i = 0; i < 9; ++i) red[threadIdx.x >> 6][i] = acc[i];
     __syncthreads();
     if (threadIdx.x < 9)
-        partial[((size_t)c * DW_MAX_SPLIT + blockIdx.x) * 9 + threadIdx.x] =
+        partial[((size_t)c * DW_MAX_SPLIT + blockIdx.y) * 9 + threadIdx.x] =
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
@@ -358,14 +358,14 @@ __global__ __launch_bounds__(256) void k_dw3x3_wgrad_rows(const uint16_t* __rest
                                                           float* __restrict__ partial) {
     constexpr int W = LPR * 8, GROUPS = 256 / LPR;
     __shared__ float red[4][9];
-    const int c = blockIdx.y, S = gridDim.x;
+    const int c = blockIdx.x, S = gridDim.y;           // grid (C, split): neighbouring workgroups read neighbouring channels of one image (round 6; it was (split, C))
     const int grp = threadIdx.x / LPR, lir = threadIdx.x % LPR;
     const int strips = (H + DWR_ROWS - 1) / DWR_ROWS, tasks = N * strips;
     const size_t psz = (size_t)H * W;
     float acc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = 0.f;
-    for (int t = blockIdx.x * GROUPS + grp; t < tasks; t += S * GROUPS) {
+    for (int t = blockIdx.y * GROUPS + grp; t < tasks; t += S * GROUPS) {
         const int n = t / strips, st = t - n * strips;
         const int r0 = st * DWR_ROWS, r1 = min(H, r0 + DWR_ROWS);
         const uint16_t* px = x + ((size_t)n * C + c) * psz;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_wgrad_rows(const uint16_t* __rest
         for (int i = 0; i < 9; ++i) red[threadIdx.x >> 6][i] = acc[i];
     __syncthreads();
     if (threadIdx.x < 9)
-        partial[((size_t)c * DW_MAX_SPLIT + blockIdx.x) * 9 + threadIdx.x] =
+        partial[((size_t)c * DW_MAX_SPLIT + blockIdx.y) * 9 + threadIdx.x] =
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
@@ -443,9 +443,9 @@ int dw_wgrad(const T* x, const T* dy, float* dw, int N, int C, int H, int W, int
         if (d == 1 && (W == 32 || W == 64 || W == 128)) {
             // the register-window kernel: tasks = (image, 32-row strip), 256 / (W / 8) lane groups per workgroup
             split = dw_even_split(N * ((H + DWR_ROWS - 1) / DWR_ROWS), 256 / (W / 8));
-            if (W == 128) hipLaunchKernelGGL(k_dw3x3_wgrad_rows<16>, dim3(split, C), dim3(256), 0, st, px, pg, N, C, H, ws);
-            else if (W == 64) hipLaunchKernelGGL(k_dw3x3_wgrad_rows<8>, dim3(split, C), dim3(256), 0, st, px, pg, N, C, H, ws);
-            else hipLaunchKernelGGL(k_dw3x3_wgrad_rows<4>, dim3(split, C), dim3(256), 0, st, px, pg, N, C, H, ws);
+            if (W == 128) hipLaunchKernelGGL(k_dw3x3_wgrad_rows<16>, dim3(C, split), dim3(256), 0, st, px, pg, N, C, H, ws);
+            else if (W == 64) hipLaunchKernelGGL(k_dw3x3_wgrad_rows<8>, dim3(C, split), dim3(256), 0, st, px, pg, N, C, H, ws);
+            else hipLaunchKernelGGL(k_dw3x3_wgrad_rows<4>, dim3(C, split), dim3(256), 0, st, px, pg, N, C, H, ws);
             done = true;
         }
         if (done) {
@@ -456,7 +456,7 @@ int dw_wgrad(const T* x, const T* dy, float* dw, int N, int C, int H, int W, int
         }
     }
     const size_t lds = (size_t)g.PP * g.lds_rows * W * sizeof(float);
-    hipLaunchKernelGGL((k_dw3x3_wgrad<T>), dim3(split, C), dim3(256), lds, st, x, dy, N, C, g, ws);
+    hipLaunchKernelGGL((k_dw3x3_wgrad<T>), dim3(C, split), dim3(256), lds, st, x, dy, N, C, g, ws);
     AADG_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_dw3x3_wgrad_final, dim3((C * 9 + 255) / 256), dim3(256), 0, st, (const float*)ws, split, C, dw);
     AADG_LAUNCH_CHECK();
