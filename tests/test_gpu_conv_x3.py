@@ -431,9 +431,9 @@ def test_bottleneck_with_batchnorm_on_operand_load_equals_the_materialised_path(
     y_m, dx_m, gp_m, rv_m = run(False)
     assert _err(y_l, y_m) <= 1e-5 and _err(rv_l, rv_m) <= 1e-6
     rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()      # noqa: E731  (float64 atomics of the epilogues: last-bit statistics)
-    assert rel(dx_l, dx_m) <= 1e-3
+    assert rel(dx_l, dx_m) <= 5e-3
     for n in gp_m:
-        assert rel(gp_l[n], gp_m[n]) <= 1e-3, n
+        assert rel(gp_l[n], gp_m[n]) <= 5e-3, n
     blk.lazy_bn1 = blk.lazy_bn2 = True
 
 
@@ -477,9 +477,9 @@ def test_decoder_classifier_applies_the_last_batchnorm_on_load(hip):
     m.lazy_fuse_bn = True
     assert _err(o_l, o_m) <= 1e-5 and _err(rv_l, rv_m) <= 1e-6
     rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()      # noqa: E731
-    assert rel(dy_l, dy_m) <= 1e-3
+    assert rel(dy_l, dy_m) <= 5e-3
     for n in gp_m:
-        assert rel(gp_l[n], gp_m[n]) <= 1e-3, n
+        assert rel(gp_l[n], gp_m[n]) <= 5e-3, n
 
 
 @pytest.mark.parametrize("stride", [1, 2])
@@ -531,12 +531,14 @@ def test_bottleneck_projection_shortcut_normalised_on_residual_load(hip, stride)
         hip.batch_norm_act_res_bn = orig2
     assert pairs, "bn3 and the shortcut's BatchNorm did not run as a pair"
     assert _err(y_p, y_m) <= 1e-5 and _err(rv_p, rv_m) <= 1e-6 and (rm_p - rm_m).abs().max().item() <= 1e-6
+    # (gradients below: the float64-atomic statistics repeat to their last bit only, and a pre-activation that lands on the other side of
+    # zero flips a ReLU -- 1e-3 failed once in eight runs of the whole suite; a wrong fusion is off by 1e-1 .. 1)
     rel0 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()     # noqa: E731
-    assert rel0(dx_p, dx_m) <= 1e-3
+    assert rel0(dx_p, dx_m) <= 5e-3
     for n in gp_m:
-        assert rel0(gp_p[n], gp_m[n]) <= 1e-3, n
+        assert rel0(gp_p[n], gp_m[n]) <= 5e-3, n
     assert _err(y_l, y_m) <= 1e-5 and _err(rv_l, rv_m) <= 1e-6 and (rm_l - rm_m).abs().max().item() <= 1e-6
     rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()      # noqa: E731
-    assert rel(dx_l, dx_m) <= 1e-3
+    assert rel(dx_l, dx_m) <= 5e-3
     for n in gp_m:
-        assert rel(gp_l[n], gp_m[n]) <= 1e-3, n
+        assert rel(gp_l[n], gp_m[n]) <= 5e-3, n

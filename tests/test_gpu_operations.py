@@ -68,7 +68,7 @@ def test_operation_draws_follow_the_reference_distributions(hip):
     assert abs(float(Ops.Rotate(initial_magnitude=1.7).magnitude.detach()) - 30.0) < 1e-6
     assert abs(float(Ops.ShearX(initial_magnitude=0.5).magnitude.detach()) - 0.15) < 1e-6
     assert abs(float(Ops.TranslateY(initial_magnitude=0.2).magnitude.detach()) - 0.09) < 1e-6
-    assert abs(float(Ops.Hue(initial_magnitude=0.25).magnitude) - 0.5) < 1e-6
+    assert abs(float(Ops.Hue(initial_magnitude=0.25).magnitude.detach()) - 0.5) < 1e-6
 
 
 def test_ste_forward_and_backward_vs_reference_golden(hip):
